@@ -1,0 +1,231 @@
+"""ctypes binding of include/dpmm_hip.h.  No fallback: if libdpmmhip.so is missing or no
+gfx950 device is usable, construction raises -- nothing here computes on the CPU."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PRIOR_NIW, PRIOR_MULT = 0, 1
+MAX_CLUSTERS = 1024
+
+_c_i64p = ctypes.POINTER(ctypes.c_int64)
+_c_f32p = ctypes.POINTER(ctypes.c_float)
+_c_f64p = ctypes.POINTER(ctypes.c_double)
+
+# every symbol include/dpmm_hip.h declares: (name, restype, argtypes)
+ABI = [
+    ("dpmm_abi_version", ctypes.c_int, []),
+    ("dpmm_create", ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_uint64]),
+    ("dpmm_destroy", ctypes.c_int, [ctypes.c_void_p]),
+    ("dpmm_last_error", ctypes.c_char_p, [ctypes.c_void_p]),
+    ("dpmm_upload_points", ctypes.c_int, [ctypes.c_void_p, _c_f32p, ctypes.c_int64]),
+    ("dpmm_upload_points_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
+    ("dpmm_init_labels", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32]),
+    ("dpmm_set_labels", ctypes.c_int, [ctypes.c_void_p, _c_i64p, _c_i64p]),
+    ("dpmm_get_labels", ctypes.c_int, [ctypes.c_void_p, _c_i64p, _c_i64p]),
+    ("dpmm_set_params_niw", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p]),
+    ("dpmm_set_params_niw_chol", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p]),
+    ("dpmm_set_params_mult", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_f32p, _c_f32p, _c_f32p]),
+    ("dpmm_sweep", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int]),
+    ("dpmm_packed_stride", ctypes.c_int64, [ctypes.c_void_p]),
+    ("dpmm_suffstats_packed_device", ctypes.c_int, [ctypes.c_void_p, _c_i64p, ctypes.c_int, ctypes.c_void_p]),
+    ("dpmm_suffstats_packed", ctypes.c_int, [ctypes.c_void_p, _c_i64p, ctypes.c_int, _c_f64p]),
+    ("dpmm_unpack_suffstats", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_f64p, _c_f64p, _c_f64p, _c_f64p]),
+    ("dpmm_split", ctypes.c_int, [ctypes.c_void_p, _c_i64p, _c_i64p, ctypes.c_int, ctypes.c_uint32]),
+    ("dpmm_merge", ctypes.c_int, [ctypes.c_void_p, _c_i64p, _c_i64p, ctypes.c_int]),
+    ("dpmm_remove_empty", ctypes.c_int, [ctypes.c_void_p, _c_i64p, ctypes.c_int]),
+    ("dpmm_reset_sublabels", ctypes.c_int, [ctypes.c_void_p, _c_i64p, ctypes.c_int, ctypes.c_uint32]),
+    ("dpmm_debug_loglik", ctypes.c_int, [ctypes.c_void_p, _c_f32p]),
+    ("dpmm_sync", ctypes.c_int, [ctypes.c_void_p]),
+    ("dpmm_stream", ctypes.c_void_p, [ctypes.c_void_p]),
+    ("dpmm_last_kernel_ms", ctypes.c_int, [ctypes.c_void_p, _c_f32p, _c_f32p]),
+]
+
+
+class DpmmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libdpmmhip error {code}: {msg}")
+        self.code = code
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libdpmmhip.so")
+
+
+def build_library(force=False):
+    """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
+    args = ["make", "-s", "-C", os.path.join(_HERE, "csrc"), "-j4"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    return lib_path()
+
+
+_LIB = None
+
+
+def load_library():
+    global _LIB
+    if _LIB is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise FileNotFoundError(f"{p} not built: run __graft_entry__.build() (there is no CPU fallback)")
+        lib = ctypes.CDLL(p)
+        for name, res, args in ABI:
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+    return _LIB
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+class Worker:
+    """One shard of the points on one GPU: the stand-in for one reference worker process
+    (the functions a worker runs on its `localpart`s, src/local_clusters_actions.jl)."""
+
+    def __init__(self, prior, D, n_local, first_index=0, device=0, seed=0):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        self.prior, self.D, self.n, self.first_index, self.device = prior, int(D), int(n_local), int(first_index), device
+        rc = self._lib.dpmm_create(ctypes.byref(self._h), prior, D, n_local, first_index, device, ctypes.c_uint64(seed))
+        if rc != 0:
+            raise DpmmError(rc, self._lib.dpmm_last_error(None).decode())
+        self.K = 0
+        self.packed_stride = int(self._lib.dpmm_packed_stride(self._h))
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise DpmmError(rc, self._lib.dpmm_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.dpmm_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- data
+    def upload_points(self, X):
+        """X: (n_local, ld) float32 C-contiguous, row i = point i (== Julia's D x n column-major)."""
+        X = _f32(X)
+        assert X.ndim == 2 and X.shape[0] == self.n and X.shape[1] >= self.D
+        self._chk(self._lib.dpmm_upload_points(self._h, _p(X, _c_f32p), X.shape[1]))
+
+    def upload_points_device(self, ptr, ldx):
+        self._chk(self._lib.dpmm_upload_points_device(self._h, ctypes.c_void_p(ptr), ldx))
+
+    def init_labels(self, init_clusters, epoch):
+        self._chk(self._lib.dpmm_init_labels(self._h, init_clusters, epoch))
+
+    def set_labels(self, labels=None, sub=None):
+        labels = _i64(labels) if labels is not None else None
+        sub = _i64(sub) if sub is not None else None
+        self._chk(self._lib.dpmm_set_labels(self._h, _p(labels, _c_i64p), _p(sub, _c_i64p)))
+
+    def get_labels(self):
+        lab = np.empty(self.n, np.int64); sub = np.empty(self.n, np.int64)
+        self._chk(self._lib.dpmm_get_labels(self._h, _p(lab, _c_i64p), _p(sub, _c_i64p)))
+        return lab, sub
+
+    # ---- parameters
+    def set_params_niw(self, mu, inv_sigma, logdet, lr_weights, weights):
+        K = len(weights)
+        mu, inv_sigma, logdet, lr_weights, weights = map(_f32, (mu, inv_sigma, logdet, lr_weights, weights))
+        assert mu.shape == (3 * K, self.D) and inv_sigma.size == 3 * K * self.D * self.D and logdet.shape == (3 * K,) and lr_weights.shape == (K, 2)
+        self._chk(self._lib.dpmm_set_params_niw(self._h, K, _p(mu, _c_f32p), _p(inv_sigma, _c_f32p), _p(logdet, _c_f32p), _p(lr_weights, _c_f32p), _p(weights, _c_f32p)))
+        self.K = K
+
+    def set_params_niw_chol(self, mu, R, logdet, lr_weights, weights):
+        K = len(weights)
+        mu, R, logdet, lr_weights, weights = map(_f32, (mu, R, logdet, lr_weights, weights))
+        assert mu.shape == (3 * K, self.D) and R.size == 3 * K * self.D * self.D and logdet.shape == (3 * K,) and lr_weights.shape == (K, 2)
+        self._chk(self._lib.dpmm_set_params_niw_chol(self._h, K, _p(mu, _c_f32p), _p(R, _c_f32p), _p(logdet, _c_f32p), _p(lr_weights, _c_f32p), _p(weights, _c_f32p)))
+        self.K = K
+
+    def set_params_mult(self, logp, lr_weights, weights):
+        K = len(weights)
+        logp, lr_weights, weights = map(_f32, (logp, lr_weights, weights))
+        assert logp.shape == (3 * K, self.D) and lr_weights.shape == (K, 2)
+        self._chk(self._lib.dpmm_set_params_mult(self._h, K, _p(logp, _c_f32p), _p(lr_weights, _c_f32p), _p(weights, _c_f32p)))
+        self.K = K
+
+    # ---- the hot path
+    def sweep(self, epoch, final=False):
+        self._chk(self._lib.dpmm_sweep(self._h, epoch, int(bool(final))))
+
+    def suffstats_packed(self, cluster_idx=None):
+        out = np.empty((2 * self.K, self.packed_stride), np.float64)
+        idx = _i64(cluster_idx) if cluster_idx is not None else None
+        self._chk(self._lib.dpmm_suffstats_packed(self._h, _p(idx, _c_i64p), 0 if idx is None else len(idx), _p(out, _c_f64p)))
+        return out
+
+    def suffstats_packed_device(self, dev_ptr, cluster_idx=None):
+        idx = _i64(cluster_idx) if cluster_idx is not None else None
+        self._chk(self._lib.dpmm_suffstats_packed_device(self._h, _p(idx, _c_i64p), 0 if idx is None else len(idx), ctypes.c_void_p(dev_ptr)))
+
+    def unpack(self, packed, K=None):
+        K = self.K if K is None else K
+        packed = np.ascontiguousarray(packed, np.float64)
+        N = np.empty((K, 3)); s = np.empty((K, 3, self.D))
+        S = np.empty((K, 3, self.D, self.D)) if self.prior == PRIOR_NIW else None
+        self._chk(self._lib.dpmm_unpack_suffstats(self._h, K, _p(packed, _c_f64p), _p(N, _c_f64p), _p(s, _c_f64p), _p(S, _c_f64p)))
+        return (N, s, S) if S is not None else (N, s)
+
+    def suffstats(self, cluster_idx=None):
+        return self.unpack(self.suffstats_packed(cluster_idx))
+
+    # ---- relabel
+    def split(self, idx, new_idx, epoch):
+        idx, new_idx = _i64(idx), _i64(new_idx)
+        self._chk(self._lib.dpmm_split(self._h, _p(idx, _c_i64p), _p(new_idx, _c_i64p), len(idx), epoch))
+
+    def merge(self, idx, new_idx):
+        idx, new_idx = _i64(idx), _i64(new_idx)
+        self._chk(self._lib.dpmm_merge(self._h, _p(idx, _c_i64p), _p(new_idx, _c_i64p), len(idx)))
+
+    def remove_empty(self, pts_count):
+        pc = _i64(pts_count)
+        self._chk(self._lib.dpmm_remove_empty(self._h, _p(pc, _c_i64p), len(pc)))
+
+    def reset_sublabels(self, idx, epoch):
+        if idx is None:
+            self._chk(self._lib.dpmm_reset_sublabels(self._h, None, 0, epoch))
+        else:
+            idx = _i64(idx)
+            self._chk(self._lib.dpmm_reset_sublabels(self._h, _p(idx, _c_i64p), len(idx), epoch))
+
+    # ---- diagnostics
+    def debug_loglik(self):
+        out = np.empty((self.K, self.n), np.float32)
+        self._chk(self._lib.dpmm_debug_loglik(self._h, _p(out, _c_f32p)))
+        return out
+
+    def sync(self):
+        self._chk(self._lib.dpmm_sync(self._h))
+
+    @property
+    def stream(self):
+        return self._lib.dpmm_stream(self._h)
+
+    def last_kernel_ms(self):
+        a = ctypes.c_float(); b = ctypes.c_float()
+        self._chk(self._lib.dpmm_last_kernel_ms(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value

@@ -1,0 +1,575 @@
+// dpmm_api.cpp -- C ABI of libdpmmhip.so (see include/dpmm_hip.h for the contract and the
+// reference functions each entry point replaces).  Host-side glue only: device memory
+// ownership, parameter staging, kernel sequencing on ONE stream, error mapping.
+// There is no CPU fallback anywhere in this file: without a usable gfx950 device
+// dpmm_create fails with DPMM_ENODEVICE.
+#include "../../include/dpmm_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "dpmm_kernels.h"
+
+using namespace dpmm;
+
+static_assert(DPMM_MAX_CLUSTERS == DPMM_MAX_CLUSTERS_K, "header / kernel limits out of sync");
+
+namespace {
+thread_local std::string g_create_error;
+
+int nb_for_dim(int D) { return D <= 16 ? 1 : D <= 32 ? 2 : D <= 64 ? 4 : D <= 128 ? 8 : 16; }
+}  // namespace
+
+struct dpmm_ctx {
+    int prior = 0, D = 0, device = 0;
+    int64_t n = 0, first = 0, ldx = 0;
+    uint64_t seed = 0;
+    int NB = 0;          // NIW: 16-blocks per dimension
+    int tile = 0;        // points per sweep workgroup tile
+    int64_t ntiles = 0;
+    int cus = 256;
+    int sweep_grid = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool have_sweep_ev = false, have_stats_ev = false;
+
+    float *dX = nullptr;
+    int32_t *dbins = nullptr;
+    bool have_points = false, have_labels = false;
+
+    // parameters
+    int K = 0, Kcap = 0;
+    float *d_raw = nullptr;   // NIW: R [3K][D][D] ; MULT: unused
+    float *d_mu = nullptr;    // NIW raw mu [3K][D]
+    float *d_Rp = nullptr;    // NIW packed fragments / MULT packed logp
+    float *d_mup = nullptr;   // NIW padded mu
+    float *d_cst = nullptr;   // [3K]
+    float *d_scratch = nullptr;
+    int64_t scratch_stride = 0;
+    bool have_params = false;
+
+    // sort + stats
+    SortBufs sb{};
+    int nt_sort = 0;
+    int chunk = 512;
+    int max_items = 0;
+    double *d_slabs = nullptr;
+    int64_t slab_stride = 0;
+    double *d_out = nullptr;
+    int64_t packed_stride = 0;
+    int32_t *d_small = nullptr;  // index lists for relabel kernels (Int32, <= 4*DPMM_MAX_CLUSTERS)
+    std::vector<uint8_t> h_sel;
+
+    std::string err;
+};
+
+#define HIPCHK(ctx, expr)                                                                               \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess) {                                                                        \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                            \
+            return DPMM_EHIP;                                                                           \
+        }                                                                                               \
+    } while (0)
+
+static int fail(dpmm_ctx *c, int code, const std::string &msg) {
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+int dpmm_abi_version(void) { return DPMM_ABI_VERSION; }
+
+const char *dpmm_last_error(const dpmm_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+static void free_params(dpmm_ctx *c) {
+    hipFree(c->d_raw); hipFree(c->d_mu); hipFree(c->d_Rp); hipFree(c->d_mup); hipFree(c->d_cst);
+    hipFree(c->d_scratch); hipFree(c->d_slabs); hipFree(c->d_out);
+    c->d_raw = c->d_mu = c->d_Rp = c->d_mup = c->d_cst = c->d_scratch = nullptr;
+    c->d_slabs = c->d_out = nullptr;
+}
+
+// (re)allocate everything whose size depends on the number of clusters
+static int ensure_capacity(dpmm_ctx *c, int K) {
+    if (K <= c->Kcap) return DPMM_OK;
+    int cap = std::max(8, c->Kcap);
+    while (cap < K) cap *= 2;
+    cap = std::min(cap, DPMM_MAX_CLUSTERS);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_params(c);
+    const size_t D = (size_t)c->D;
+    if (c->prior == DPMM_PRIOR_NIW) {
+        const size_t NP = (size_t)c->NB * (c->NB + 1) / 2;
+        HIPCHK(c, hipMalloc(&c->d_raw, sizeof(float) * 3 * cap * D * D));
+        HIPCHK(c, hipMalloc(&c->d_mu, sizeof(float) * 3 * cap * D));
+        HIPCHK(c, hipMalloc(&c->d_Rp, sizeof(float) * 3 * cap * NP * 256));
+        HIPCHK(c, hipMalloc(&c->d_mup, sizeof(float) * 3 * cap * 16 * c->NB));
+    } else {
+        const size_t NT = (size_t)(c->ldx + 15) / 16, NRB = (size_t)(3 * cap + 15) / 16;
+        HIPCHK(c, hipMalloc(&c->d_raw, sizeof(float) * 3 * cap * (size_t)c->ldx));
+        HIPCHK(c, hipMalloc(&c->d_Rp, sizeof(float) * NRB * NT * 256));
+    }
+    HIPCHK(c, hipMalloc(&c->d_cst, sizeof(float) * 3 * cap));
+    // sweep scratch: one a_k row set per resident workgroup; the Multinomial kernel keeps all 3K rows
+    const int rows = (c->prior == DPMM_PRIOR_NIW) ? cap : 3 * cap;
+    c->scratch_stride = (int64_t)c->sweep_grid * c->tile;
+    HIPCHK(c, hipMalloc(&c->d_scratch, sizeof(float) * (size_t)rows * (size_t)c->scratch_stride));
+    // statistics
+    c->max_items = (int)((c->n + c->chunk - 1) / c->chunk) + 2 * cap;
+    HIPCHK(c, hipMalloc(&c->d_slabs, sizeof(double) * (size_t)c->max_items * (size_t)c->slab_stride));
+    HIPCHK(c, hipMalloc(&c->d_out, sizeof(double) * 2 * cap * (size_t)c->packed_stride));
+    c->Kcap = cap;
+    return DPMM_OK;
+}
+
+int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t first_index, int device, uint64_t seed) {
+    if (!out) return fail(nullptr, DPMM_EINVAL, "ctx out pointer is null");
+    *out = nullptr;
+    if (prior_kind != DPMM_PRIOR_NIW && prior_kind != DPMM_PRIOR_MULT) return fail(nullptr, DPMM_EINVAL, "unknown prior kind");
+    if (D < 1 || n_local < 0 || first_index < 0) return fail(nullptr, DPMM_EINVAL, "bad D / n_local / first_index");
+    if (n_local > 2000000000LL) return fail(nullptr, DPMM_ELIMIT, "n_local exceeds the Int32 point index of this build");
+    if (prior_kind == DPMM_PRIOR_NIW && D > DPMM_MAX_DIM_NIW) return fail(nullptr, DPMM_ELIMIT, "NIW: D > DPMM_MAX_DIM_NIW");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, DPMM_ENODEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(nullptr, DPMM_ENODEVICE, "device ordinal out of range");
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, DPMM_ENODEVICE, "hipSetDevice failed");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(nullptr, DPMM_ENODEVICE, "hipGetDeviceProperties failed");
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(nullptr, DPMM_ENODEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+
+    dpmm_ctx *c = new dpmm_ctx();
+    c->prior = prior_kind; c->D = D; c->n = n_local; c->first = first_index; c->device = device; c->seed = seed;
+    c->ldx = (D + 3) / 4 * 4;
+    c->cus = prop.multiProcessorCount;
+    auto bail = [&](int code) { std::string m = c->err; dpmm_destroy(c); g_create_error = m; return code; };
+#define CHK_CREATE(expr)                                                                  \
+    do {                                                                                  \
+        hipError_t e__ = (expr);                                                          \
+        if (e__ != hipSuccess) { c->err = std::string(#expr) + ": " + hipGetErrorString(e__); return bail(DPMM_EHIP); } \
+    } while (0)
+    CHK_CREATE(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto &e : c->ev) CHK_CREATE(hipEventCreate(&e));
+    if (prior_kind == DPMM_PRIOR_NIW) {
+        c->NB = nb_for_dim(D);
+        c->tile = niw_tile_points(c->NB);
+        c->slab_stride = niw_slab_stride(D);
+        c->packed_stride = 1 + (int64_t)D + (int64_t)D * (D + 1) / 2;
+        c->sweep_grid = c->cus * (c->NB <= 8 ? 2 : 1);
+    } else {
+        c->tile = mult_tile_points();
+        c->slab_stride = mult_slab_stride(D);
+        c->packed_stride = 1 + (int64_t)D;
+        c->sweep_grid = c->cus * 2;
+    }
+    c->ntiles = (n_local + c->tile - 1) / c->tile;
+    if (c->ntiles < c->sweep_grid) c->sweep_grid = (int)std::max<int64_t>(1, c->ntiles);
+    c->chunk = (int)std::max<int64_t>(512, ((n_local + 4095) / 4096 + 3) / 4 * 4);
+    const size_t nalloc = (size_t)std::max<int64_t>(n_local, 1);
+    CHK_CREATE(hipMalloc(&c->dX, sizeof(float) * nalloc * (size_t)c->ldx));
+    CHK_CREATE(hipMalloc(&c->dbins, sizeof(int32_t) * nalloc));
+    c->nt_sort = (int)((n_local + SORT_TILE - 1) / SORT_TILE);
+    const size_t nbmax = 2 * DPMM_MAX_CLUSTERS;
+    CHK_CREATE(hipMalloc(&c->sb.tile_hist, sizeof(int32_t) * nbmax * (size_t)std::max(1, c->nt_sort)));
+    CHK_CREATE(hipMalloc(&c->sb.bin_total, sizeof(int32_t) * nbmax));
+    CHK_CREATE(hipMalloc(&c->sb.bin_start, sizeof(int32_t) * (nbmax + 1)));
+    CHK_CREATE(hipMalloc(&c->sb.item_start, sizeof(int32_t) * (nbmax + 1)));
+    CHK_CREATE(hipMalloc(&c->sb.perm, sizeof(int32_t) * nalloc));
+    CHK_CREATE(hipMalloc(&c->sb.bin_sel, nbmax));
+    CHK_CREATE(hipMalloc(&c->d_small, sizeof(int32_t) * 4 * DPMM_MAX_CLUSTERS));
+#undef CHK_CREATE
+    *out = c;
+    return DPMM_OK;
+}
+
+int dpmm_destroy(dpmm_ctx *c) {
+    if (!c) return DPMM_OK;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    free_params(c);
+    hipFree(c->dX); hipFree(c->dbins);
+    hipFree(c->sb.tile_hist); hipFree(c->sb.bin_total); hipFree(c->sb.bin_start); hipFree(c->sb.item_start);
+    hipFree(c->sb.perm); hipFree(c->sb.bin_sel); hipFree(c->d_small);
+    for (auto &e : c->ev) if (e) hipEventDestroy(e);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return DPMM_OK;
+}
+
+static int upload_common(dpmm_ctx *c, const float *X, int64_t ldx, hipMemcpyKind kind) {
+    if (!c) return DPMM_EINVAL;
+    if (!X && c->n > 0) return fail(c, DPMM_EINVAL, "X is null");
+    if (ldx < c->D) return fail(c, DPMM_EINVAL, "ldx < D");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n > 0) {
+        if (c->ldx != c->D) HIPCHK(c, hipMemsetAsync(c->dX, 0, sizeof(float) * (size_t)c->n * c->ldx, c->stream));
+        HIPCHK(c, hipMemcpy2DAsync(c->dX, sizeof(float) * c->ldx, X, sizeof(float) * ldx, sizeof(float) * c->D, (size_t)c->n, kind, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    c->have_points = true;
+    return DPMM_OK;
+}
+
+int dpmm_upload_points(dpmm_ctx *c, const float *X, int64_t ldx) { return upload_common(c, X, ldx, hipMemcpyHostToDevice); }
+int dpmm_upload_points_device(dpmm_ctx *c, const float *dX, int64_t ldx) { return upload_common(c, dX, ldx, hipMemcpyDeviceToDevice); }
+
+int dpmm_init_labels(dpmm_ctx *c, int init_clusters, uint32_t epoch) {
+    if (!c) return DPMM_EINVAL;
+    if (init_clusters < 1 || init_clusters > DPMM_MAX_CLUSTERS) return fail(c, DPMM_ELIMIT, "init_clusters out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n > 0) HIPCHK(c, launch_init_labels(c->dbins, c->n, c->first, init_clusters, c->seed, epoch, c->stream));
+    c->have_labels = true;
+    return DPMM_OK;
+}
+
+int dpmm_set_labels(dpmm_ctx *c, const int64_t *labels, const int64_t *sub) {
+    if (!c) return DPMM_EINVAL;
+    if (!c->have_labels && (!labels || !sub)) return fail(c, DPMM_ESTATE, "first dpmm_set_labels must provide both vectors");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n == 0) { c->have_labels = true; return DPMM_OK; }
+    int64_t *tmp = nullptr;
+    HIPCHK(c, hipMalloc(&tmp, sizeof(int64_t) * 2 * (size_t)c->n));
+    int rc = DPMM_OK;
+    hipError_t e = hipSuccess;
+    if (labels) e = hipMemcpyAsync(tmp, labels, sizeof(int64_t) * c->n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && sub) e = hipMemcpyAsync(tmp + c->n, sub, sizeof(int64_t) * c->n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_bins_from_i64(c->dbins, labels ? tmp : nullptr, sub ? tmp + c->n : nullptr, c->n, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(tmp);
+    if (e != hipSuccess) { c->err = std::string("dpmm_set_labels: ") + hipGetErrorString(e); rc = DPMM_EHIP; }
+    else c->have_labels = true;
+    return rc;
+}
+
+int dpmm_get_labels(dpmm_ctx *c, int64_t *labels, int64_t *sub) {
+    if (!c) return DPMM_EINVAL;
+    if (!c->have_labels) return fail(c, DPMM_ESTATE, "labels not initialised");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n == 0) return DPMM_OK;
+    int64_t *tmp = nullptr;
+    HIPCHK(c, hipMalloc(&tmp, sizeof(int64_t) * 2 * (size_t)c->n));
+    hipError_t e = launch_bins_to_i64(c->dbins, tmp, tmp + c->n, c->n, c->stream);
+    if (e == hipSuccess && labels) e = hipMemcpyAsync(labels, tmp, sizeof(int64_t) * c->n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && sub) e = hipMemcpyAsync(sub, tmp + c->n, sizeof(int64_t) * c->n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(tmp);
+    if (e != hipSuccess) { c->err = std::string("dpmm_get_labels: ") + hipGetErrorString(e); return DPMM_EHIP; }
+    return DPMM_OK;
+}
+
+static int check_K(dpmm_ctx *c, int K) {
+    if (K < 1) return fail(c, DPMM_EINVAL, "K < 1");
+    if (K > DPMM_MAX_CLUSTERS) return fail(c, DPMM_ELIMIT, "K > DPMM_MAX_CLUSTERS");
+    return DPMM_OK;
+}
+
+static void build_cst(std::vector<float> &cst, int K, const float *logdet, const float *lr, const float *w) {
+    cst.resize(3 * (size_t)K);
+    for (int k = 0; k < K; ++k) {
+        cst[3 * k] = (logdet ? -0.5f * logdet[3 * k] : 0.f) + logf(w[k]);
+        cst[3 * k + 1] = (logdet ? -0.5f * logdet[3 * k + 1] : 0.f) + logf(lr[2 * k]);
+        cst[3 * k + 2] = (logdet ? -0.5f * logdet[3 * k + 2] : 0.f) + logf(lr[2 * k + 1]);
+    }
+}
+
+int dpmm_set_params_niw_chol(dpmm_ctx *c, int K, const float *mu, const float *R, const float *logdet, const float *lr, const float *w) {
+    if (!c) return DPMM_EINVAL;
+    if (c->prior != DPMM_PRIOR_NIW) return fail(c, DPMM_EINVAL, "context was created for another prior");
+    if (!mu || !R || !logdet || !lr || !w) return fail(c, DPMM_EINVAL, "null parameter array");
+    if (int rc = check_K(c, K)) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = ensure_capacity(c, K)) return rc;
+    const size_t D = (size_t)c->D;
+    std::vector<float> cst;
+    build_cst(cst, K, logdet, lr, w);
+    HIPCHK(c, hipMemcpyAsync(c->d_raw, R, sizeof(float) * 3 * K * D * D, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_mu, mu, sizeof(float) * 3 * K * D, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_cst, cst.data(), sizeof(float) * 3 * K, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_niw_pack(c->d_raw, c->d_mu, c->d_Rp, c->d_mup, c->D, c->NB, 3 * K, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // host staging (cst) goes out of scope
+    c->K = K;
+    c->have_params = true;
+    return DPMM_OK;
+}
+
+int dpmm_set_params_niw(dpmm_ctx *c, int K, const float *mu, const float *inv_sigma, const float *logdet, const float *lr, const float *w) {
+    if (!c) return DPMM_EINVAL;
+    if (c->prior != DPMM_PRIOR_NIW) return fail(c, DPMM_EINVAL, "context was created for another prior");
+    if (!inv_sigma) return fail(c, DPMM_EINVAL, "null parameter array");
+    if (int rc = check_K(c, K)) return rc;
+    // compat path: Sigma^-1 = R'R (upper Cholesky factor) in Float64 on the host
+    const int D = c->D;
+    std::vector<float> R((size_t)3 * K * D * D, 0.f);
+    std::vector<double> L((size_t)D * D);
+    for (int j = 0; j < 3 * K; ++j) {
+        const float *A = inv_sigma + (size_t)j * D * D;
+        std::fill(L.begin(), L.end(), 0.0);
+        for (int a = 0; a < D; ++a) {  // lower factor, row by row
+            for (int b = 0; b <= a; ++b) {
+                double s = 0.5 * ((double)A[(size_t)a * D + b] + (double)A[(size_t)b * D + a]);
+                for (int t = 0; t < b; ++t) s -= L[(size_t)a * D + t] * L[(size_t)b * D + t];
+                L[(size_t)a * D + b] = (a == b) ? std::sqrt(s) : s / L[(size_t)b * D + b];
+            }
+        }
+        float *Rj = R.data() + (size_t)j * D * D;
+        for (int a = 0; a < D; ++a)
+            for (int b = a; b < D; ++b) Rj[(size_t)a * D + b] = (float)L[(size_t)b * D + a];  // R = L'
+    }
+    return dpmm_set_params_niw_chol(c, K, mu, R.data(), logdet, lr, w);
+}
+
+int dpmm_set_params_mult(dpmm_ctx *c, int K, const float *logp, const float *lr, const float *w) {
+    if (!c) return DPMM_EINVAL;
+    if (c->prior != DPMM_PRIOR_MULT) return fail(c, DPMM_EINVAL, "context was created for another prior");
+    if (!logp || !lr || !w) return fail(c, DPMM_EINVAL, "null parameter array");
+    if (int rc = check_K(c, K)) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = ensure_capacity(c, K)) return rc;
+    std::vector<float> cst;
+    build_cst(cst, K, nullptr, lr, w);
+    if (c->ldx != c->D) HIPCHK(c, hipMemsetAsync(c->d_raw, 0, sizeof(float) * 3 * K * (size_t)c->ldx, c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(c->d_raw, sizeof(float) * c->ldx, logp, sizeof(float) * c->D, sizeof(float) * c->D, (size_t)3 * K, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_cst, cst.data(), sizeof(float) * 3 * K, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_mult_pack(c->d_raw, c->d_Rp, 3 * K, c->ldx, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->K = K;
+    c->have_params = true;
+    return DPMM_OK;
+}
+
+static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table, int64_t table_stride) {
+    if (!c->have_points || !c->have_params) return fail(c, DPMM_ESTATE, "sweep needs points and parameters");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n == 0) return DPMM_OK;
+    if (!table) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    if (c->prior == DPMM_PRIOR_NIW) {
+        NiwSweepArgs a{};
+        a.X = c->dX; a.ldx = c->ldx; a.n = c->n; a.first_index = c->first; a.ntiles = c->ntiles; a.K = c->K;
+        a.Rp = c->d_Rp; a.mup = c->d_mup; a.cst = c->d_cst;
+        a.scratch = table ? table : c->d_scratch;
+        a.scratch_stride = table ? table_stride : c->scratch_stride;
+        a.scratch_by_tile = table ? 1 : 0;
+        a.labels_only = table ? 1 : 0;
+        a.bins = c->dbins; a.seed = c->seed; a.epoch = epoch; a.final_argmax = final_argmax;
+        HIPCHK(c, launch_niw_sweep(c->NB, a, c->sweep_grid, c->stream));
+    } else {
+        MultSweepArgs a{};
+        a.X = c->dX; a.ldx = c->ldx; a.n = c->n; a.first_index = c->first; a.D = c->D; a.K = c->K;
+        a.logp = c->d_Rp; a.cst = c->d_cst;
+        a.scratch = table ? table : c->d_scratch;
+        a.scratch_stride = table ? table_stride : c->scratch_stride;
+        a.scratch_by_tile = table ? 1 : 0;
+        a.labels_only = table ? 1 : 0;
+        a.bins = c->dbins; a.seed = c->seed; a.epoch = epoch; a.final_argmax = final_argmax;
+        HIPCHK(c, launch_mult_sweep(a, c->sweep_grid, c->stream));
+    }
+    if (!table) {
+        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+        c->have_sweep_ev = true;
+        c->have_labels = true;
+    }
+    return DPMM_OK;
+}
+
+int dpmm_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax) {
+    if (!c) return DPMM_EINVAL;
+    return run_sweep(c, epoch, final_argmax, nullptr, 0);
+}
+
+int dpmm_debug_loglik(dpmm_ctx *c, float *out) {
+    if (!c || !out) return DPMM_EINVAL;
+    if (!c->have_points || !c->have_params) return fail(c, DPMM_ESTATE, "debug_loglik needs points and parameters");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n == 0) return DPMM_OK;
+    const int64_t stride = c->ntiles * c->tile;
+    const int rows = (c->prior == DPMM_PRIOR_NIW) ? c->K : 3 * c->K;
+    float *table = nullptr;
+    HIPCHK(c, hipMalloc(&table, sizeof(float) * (size_t)rows * (size_t)stride));
+    int rc = run_sweep(c, 0, 0, table, stride);
+    if (rc == DPMM_OK) {
+        // Multinomial: rows 3k of the 3K-row table are the cluster-level rows
+        const size_t src_pitch = sizeof(float) * stride * (c->prior == DPMM_PRIOR_MULT ? 3 : 1);
+        hipError_t e = hipMemcpy2DAsync(out, sizeof(float) * c->n, table, src_pitch, sizeof(float) * c->n,
+                                        (size_t)c->K, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { c->err = std::string("dpmm_debug_loglik: ") + hipGetErrorString(e); rc = DPMM_EHIP; }
+    }
+    hipFree(table);
+    return rc;
+}
+
+int64_t dpmm_packed_stride(const dpmm_ctx *c) { return c ? c->packed_stride : 0; }
+
+static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx) {
+    if (!c->have_points || !c->have_labels || c->K < 1) return fail(c, DPMM_ESTATE, "suffstats need points, labels and parameters (K)");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int nbins = 2 * c->K;
+    c->h_sel.assign(nbins, idx ? 0 : 1);
+    if (idx) {
+        for (int j = 0; j < n_idx; ++j) {
+            if (idx[j] < 1 || idx[j] > c->K) return fail(c, DPMM_EINVAL, "cluster index out of range");
+            c->h_sel[2 * (idx[j] - 1)] = 1;
+            c->h_sel[2 * (idx[j] - 1) + 1] = 1;
+        }
+    }
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->sb.bin_sel, c->h_sel.data(), nbins, hipMemcpyHostToDevice, c->stream));
+    StatsArgs a{};
+    a.X = c->dX; a.ldx = c->ldx; a.n = c->n; a.D = c->D; a.nbins = nbins; a.chunk = c->chunk;
+    a.max_items = (int)((c->n + c->chunk - 1) / c->chunk) + nbins;
+    a.sb = c->sb; a.slabs = c->d_slabs; a.slab_stride = c->slab_stride; a.out = c->d_out; a.packed_stride = c->packed_stride;
+    if (c->n > 0) {
+        HIPCHK(c, launch_sort_by_bin(c->dbins, c->n, nbins, c->sb, c->stream));
+    } else {
+        HIPCHK(c, hipMemsetAsync(c->sb.bin_total, 0, sizeof(int32_t) * nbins, c->stream));
+    }
+    HIPCHK(c, launch_sort_finish(c->dbins, a, c->stream));
+    if (c->prior == DPMM_PRIOR_NIW) HIPCHK(c, launch_niw_stats(a, c->stream));
+    else HIPCHK(c, launch_mult_stats(a, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    c->have_stats_ev = true;
+    return DPMM_OK;
+}
+
+int dpmm_suffstats_packed_device(dpmm_ctx *c, const int64_t *idx, int n_idx, double *d_out) {
+    if (!c || !d_out) return DPMM_EINVAL;
+    if (int rc = run_stats(c, idx, n_idx)) return rc;
+    HIPCHK(c, hipMemcpyAsync(d_out, c->d_out, sizeof(double) * 2 * c->K * (size_t)c->packed_stride, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // h_sel staging must outlive the copy
+    return DPMM_OK;
+}
+
+int dpmm_suffstats_packed(dpmm_ctx *c, const int64_t *idx, int n_idx, double *out) {
+    if (!c || !out) return DPMM_EINVAL;
+    if (int rc = run_stats(c, idx, n_idx)) return rc;
+    HIPCHK(c, hipMemcpyAsync(out, c->d_out, sizeof(double) * 2 * c->K * (size_t)c->packed_stride, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DPMM_OK;
+}
+
+int dpmm_unpack_suffstats(const dpmm_ctx *c, int K, const double *packed, double *N, double *sum, double *S) {
+    if (!c || !packed || !N || !sum) return DPMM_EINVAL;
+    const int D = c->D;
+    const int64_t ps = c->packed_stride;
+    for (int k = 0; k < K; ++k) {
+        const double *l = packed + (size_t)(2 * k) * ps, *r = packed + (size_t)(2 * k + 1) * ps;
+        N[3 * k + 1] = l[0]; N[3 * k + 2] = r[0]; N[3 * k] = l[0] + r[0];
+        for (int d = 0; d < D; ++d) {
+            sum[(size_t)(3 * k + 1) * D + d] = l[1 + d];
+            sum[(size_t)(3 * k + 2) * D + d] = r[1 + d];
+            sum[(size_t)(3 * k) * D + d] = l[1 + d] + r[1 + d];
+        }
+        if (S && c->prior == DPMM_PRIOR_NIW) {
+            double *Sc = S + (size_t)(3 * k) * D * D, *Sl = Sc + (size_t)D * D, *Sr = Sl + (size_t)D * D;
+            for (int a = 0; a < D; ++a)
+                for (int b = 0; b <= a; ++b) {
+                    const double vl = l[1 + D + (size_t)a * (a + 1) / 2 + b], vr = r[1 + D + (size_t)a * (a + 1) / 2 + b];
+                    Sl[(size_t)a * D + b] = Sl[(size_t)b * D + a] = vl;
+                    Sr[(size_t)a * D + b] = Sr[(size_t)b * D + a] = vr;
+                    Sc[(size_t)a * D + b] = Sc[(size_t)b * D + a] = vl + vr;
+                }
+        }
+    }
+    return DPMM_OK;
+}
+
+static int upload_idx(dpmm_ctx *c, const int64_t *a, const int64_t *b, int n, int limit) {
+    if (n < 0 || n > 2 * DPMM_MAX_CLUSTERS) return fail(c, DPMM_ELIMIT, "index list too long");
+    std::vector<int32_t> h((size_t)(b ? 2 : 1) * n);
+    for (int j = 0; j < n; ++j) {
+        if (a[j] < 1 || a[j] > limit) return fail(c, DPMM_EINVAL, "cluster index out of range");
+        h[j] = (int32_t)(a[j] - 1);
+        if (b) {
+            if (b[j] < 1 || b[j] > limit) return fail(c, DPMM_EINVAL, "cluster index out of range");
+            h[n + j] = (int32_t)(b[j] - 1);
+        }
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_small, h.data(), sizeof(int32_t) * h.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DPMM_OK;
+}
+
+int dpmm_split(dpmm_ctx *c, const int64_t *idx, const int64_t *new_idx, int n, uint32_t epoch) {
+    if (!c) return DPMM_EINVAL;
+    if (!c->have_labels) return fail(c, DPMM_ESTATE, "labels not initialised");
+    if (n == 0) return DPMM_OK;
+    if (!idx || !new_idx) return fail(c, DPMM_EINVAL, "null index list");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = upload_idx(c, idx, new_idx, n, DPMM_MAX_CLUSTERS)) return rc;
+    if (c->n > 0) HIPCHK(c, launch_split(c->dbins, c->n, c->first, c->d_small, n, c->seed, epoch, c->stream));
+    return DPMM_OK;
+}
+
+int dpmm_merge(dpmm_ctx *c, const int64_t *idx, const int64_t *new_idx, int n) {
+    if (!c) return DPMM_EINVAL;
+    if (!c->have_labels) return fail(c, DPMM_ESTATE, "labels not initialised");
+    if (n == 0) return DPMM_OK;
+    if (!idx || !new_idx) return fail(c, DPMM_EINVAL, "null index list");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = upload_idx(c, idx, new_idx, n, DPMM_MAX_CLUSTERS)) return rc;
+    if (c->n > 0) HIPCHK(c, launch_merge(c->dbins, c->n, c->d_small, n, c->stream));
+    return DPMM_OK;
+}
+
+int dpmm_remove_empty(dpmm_ctx *c, const int64_t *pts_count, int K) {
+    if (!c) return DPMM_EINVAL;
+    if (!c->have_labels) return fail(c, DPMM_ESTATE, "labels not initialised");
+    if (!pts_count || K < 1 || K > DPMM_MAX_CLUSTERS) return fail(c, DPMM_EINVAL, "bad pts_count / K");
+    HIPCHK(c, hipSetDevice(c->device));
+    // literal simulation of remove_empty_clusters_worker! on the identity label vector -> lookup table
+    std::vector<int32_t> map(DPMM_MAX_CLUSTERS);
+    for (int l = 1; l <= DPMM_MAX_CLUSTERS; ++l) {
+        int v = l, removed = 0;
+        for (int k = 1; k <= K; ++k)
+            if (pts_count[k - 1] == 0) {
+                if (v > k - removed) v -= 1;
+                removed += 1;
+            }
+        map[l - 1] = v - 1;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_small, map.data(), sizeof(int32_t) * map.size(), hipMemcpyHostToDevice, c->stream));
+    if (c->n > 0) HIPCHK(c, launch_remap(c->dbins, c->n, c->d_small, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DPMM_OK;
+}
+
+int dpmm_reset_sublabels(dpmm_ctx *c, const int64_t *idx, int n, uint32_t epoch) {
+    if (!c) return DPMM_EINVAL;
+    if (!c->have_labels) return fail(c, DPMM_ESTATE, "labels not initialised");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (idx) {
+        if (n == 0) return DPMM_OK;
+        if (int rc = upload_idx(c, idx, nullptr, n, DPMM_MAX_CLUSTERS)) return rc;
+    }
+    if (c->n > 0) HIPCHK(c, launch_reset_sub(c->dbins, c->n, c->first, idx ? c->d_small : nullptr, idx ? n : 0, c->seed, epoch, c->stream));
+    return DPMM_OK;
+}
+
+int dpmm_sync(dpmm_ctx *c) {
+    if (!c) return DPMM_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DPMM_OK;
+}
+
+void *dpmm_stream(dpmm_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int dpmm_last_kernel_ms(dpmm_ctx *c, float *sweep_ms, float *stats_ms) {
+    if (!c) return DPMM_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (sweep_ms) { *sweep_ms = 0.f; if (c->have_sweep_ev) HIPCHK(c, hipEventElapsedTime(sweep_ms, c->ev[0], c->ev[1])); }
+    if (stats_ms) { *stats_ms = 0.f; if (c->have_stats_ev) HIPCHK(c, hipEventElapsedTime(stats_ms, c->ev[2], c->ev[3])); }
+    return DPMM_OK;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

@@ -1,0 +1,81 @@
+// dpmm_device.h -- device-side helpers shared by all kernels (gfx950 only).
+//
+// philox4x32_10 / u01 / exp_det are defined operation-for-operation like their
+// counterparts in oracle/dpmm_oracle.c so that, given the same Float32 log-likelihood
+// table, the categorical draw (reference: src/utils.jl:19-31) is bit-identical on the
+// CPU oracle and on the GPU.  The translation unit is compiled with -ffp-contract=off;
+// every fused multiply-add below is an explicit fmaf.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dpmm {
+
+constexpr int WAVE = 64;
+
+enum : uint32_t { STREAM_SWEEP = 0, STREAM_INIT = 1, STREAM_SPLIT = 2, STREAM_RESET = 3 };
+
+struct Philox4 {
+    uint32_t v[4];
+};
+
+__device__ __forceinline__ Philox4 philox4x32_10(uint64_t seed, uint64_t idx, uint32_t epoch, uint32_t stream) {
+    uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = epoch, c3 = stream;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0;
+        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    Philox4 o;
+    o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+    return o;
+}
+
+__device__ __forceinline__ float u01(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
+
+// Deterministic expf for max-shifted arguments (x <= 0); see oracle/dpmm_oracle.c exp_det.
+__device__ __forceinline__ float exp_det(float x) {
+    if (!(x >= -86.0f)) return 0.0f;
+    const float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693145751953125f, x);
+    r = __builtin_fmaf(n, -1.42860682030941723212e-6f, r);
+    float p = 1.0f / 5040.0f;
+    p = __builtin_fmaf(p, r, 1.0f / 720.0f);
+    p = __builtin_fmaf(p, r, 1.0f / 120.0f);
+    p = __builtin_fmaf(p, r, 1.0f / 24.0f);
+    p = __builtin_fmaf(p, r, 1.0f / 6.0f);
+    p = __builtin_fmaf(p, r, 0.5f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    const uint32_t sb = (uint32_t)((int)n + 127) << 23;
+    return p * __uint_as_float(sb);
+}
+
+__device__ __forceinline__ float nan_to_ninf(float a) { return (a != a) ? -INFINITY : a; }
+
+// 2-way draw of create_subclusters_labels! (src/local_clusters_actions.jl:83-95 -> utils.jl:19-31
+// with two columns).  Returns 0 (left, sub-label 1) or 1 (right, sub-label 2).
+__device__ __forceinline__ int draw2(float b0, float b1, float u) {
+    b0 = nan_to_ninf(b0);
+    b1 = nan_to_ninf(b1);
+    float m = -INFINITY;
+    if (b0 > m) m = b0;
+    if (b1 > m) m = b1;
+    if (m == -INFINITY) return 0;
+    const float p0 = exp_det(b0 - m), p1 = exp_det(b1 - m);
+    float s = 0.0f;
+    s += p0;
+    s += p1;
+    const float t = u * s;
+    float cw = 0.0f;
+    cw += p0;
+    return (cw < t) ? 1 : 0;
+}
+
+}  // namespace dpmm

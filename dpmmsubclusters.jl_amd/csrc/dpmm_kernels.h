@@ -1,0 +1,108 @@
+// dpmm_kernels.h -- kernel argument blocks and host-side launchers (internal to libdpmmhip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DPMM_MAX_CLUSTERS_K 1024
+
+namespace dpmm {
+
+// Device-resident label state: bins[i] = 2*(label-1) + (sub_label-1)  (Int32).
+// The (label, sub-label) pair of the reference (src/ds.jl:54-55) is exactly the
+// sufficient-statistics bin the point contributes to.
+
+struct NiwSweepArgs {
+    const float *X;      // [n][ldx] points (zero padded to ldx = roundup(D,4))
+    int64_t ldx;
+    int64_t n;
+    int64_t first_index; // global index of point 0 (RNG counter)
+    int64_t ntiles;
+    int K;
+    const float *Rp;     // packed factor fragments [3K][NP][64][4]
+    const float *mup;    // [3K][DP]
+    const float *cst;    // [3K]: 3k: -logdet/2 + log w_k ; 3k+1+s: -logdet/2 + log lr_w[k][s]
+    float *scratch;      // a_k rows: scratch[k*scratch_stride + base + point_in_tile]
+    int64_t scratch_stride;
+    int scratch_by_tile; // 1: base = tile*TILE (full table, debug) ; 0: base = blockIdx*TILE
+    int labels_only;     // 1: stop after the label phase (debug_loglik)
+    int32_t *bins;       // out
+    uint64_t seed;
+    uint32_t epoch;
+    int final_argmax;
+};
+
+int niw_tile_points(int NB);
+hipError_t launch_niw_sweep(int NB, const NiwSweepArgs &a, int grid, hipStream_t s);
+hipError_t launch_niw_pack(const float *R, const float *mu, float *Rp, float *mup, int D, int NB, int nmat, hipStream_t s);
+
+struct MultSweepArgs {
+    const float *X;
+    int64_t ldx;
+    int64_t n;
+    int64_t first_index;
+    int D;
+    int K;
+    const float *logp;   // packed fragment image Lp[ceil(3K/16)][ceil(ldx/16)][64][4]
+    const float *cst;    // [3K]: 3k: log w_k ; 3k+1+s: log lr_w[k][s]
+    float *scratch;
+    int64_t scratch_stride;
+    int scratch_by_tile;
+    int labels_only;
+    int32_t *bins;
+    uint64_t seed;
+    uint32_t epoch;
+    int final_argmax;
+};
+hipError_t launch_mult_sweep(const MultSweepArgs &a, int grid, hipStream_t s);
+hipError_t launch_mult_pack(const float *logp, float *Lp, int rows, int64_t ldx, hipStream_t s);
+int mult_tile_points();
+
+// ---- label bookkeeping (labels.hip)
+hipError_t launch_init_labels(int32_t *bins, int64_t n, int64_t first_index, int init_clusters, uint64_t seed,
+                              uint32_t epoch, hipStream_t s);
+hipError_t launch_bins_from_i64(int32_t *bins, const int64_t *labels, const int64_t *sub, int64_t n, hipStream_t s);
+hipError_t launch_bins_to_i64(const int32_t *bins, int64_t *labels, int64_t *sub, int64_t n, hipStream_t s);
+// pairs: [2*m] = idx[0..m-1], new_idx[0..m-1] as 0-based Int32 cluster ids (device memory)
+hipError_t launch_split(int32_t *bins, int64_t n, int64_t first_index, const int32_t *pairs, int m, uint64_t seed,
+                        uint32_t epoch, hipStream_t s);
+hipError_t launch_merge(int32_t *bins, int64_t n, const int32_t *pairs, int m, hipStream_t s);
+hipError_t launch_remap(int32_t *bins, int64_t n, const int32_t *map, hipStream_t s);  // label k -> map[k]
+hipError_t launch_reset_sub(int32_t *bins, int64_t n, int64_t first_index, const int32_t *idx, int m, uint64_t seed,
+                            uint32_t epoch, hipStream_t s);
+
+// ---- stable counting sort of the points by bin + segmented statistics (suffstats.hip)
+constexpr int SORT_TILE = 2048;  // points per sorting wave
+
+struct SortBufs {
+    int32_t *tile_hist;   // [nbins][ntiles_sort]
+    int32_t *bin_total;   // [nbins]
+    int32_t *bin_start;   // [nbins + 1]
+    int32_t *perm;        // [n]
+    int32_t *item_start;  // [nbins + 1]
+    uint8_t *bin_sel;     // [nbins] 1 = compute statistics for this bin
+};
+
+hipError_t launch_sort_by_bin(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s);
+struct StatsArgs;
+hipError_t launch_sort_finish(const int32_t *bins, const StatsArgs &a, hipStream_t s);
+
+struct StatsArgs {
+    const float *X;
+    int64_t ldx;
+    int64_t n;
+    int D;
+    int nbins;
+    int chunk;             // points per work item
+    int max_items;
+    SortBufs sb;
+    double *slabs;         // [max_items][slab_stride]
+    int64_t slab_stride;
+    double *out;           // packed [nbins][packed_stride]
+    int64_t packed_stride;
+};
+int64_t niw_slab_stride(int D);
+int64_t mult_slab_stride(int D);
+hipError_t launch_niw_stats(const StatsArgs &a, hipStream_t s);
+hipError_t launch_mult_stats(const StatsArgs &a, hipStream_t s);
+
+}  // namespace dpmm

@@ -1,0 +1,133 @@
+// labels.hip -- integer label bookkeeping on the device-resident bin vector.
+// bins[i] = 2*(label-1) + (sub_label-1).  All kernels are elementwise, HBM-bound
+// (4 B read + 4 B write per point) and exact.
+//
+// Reference functions replaced (paths relative to the reference checkout):
+//   rand(1:init_clusters), rand(1:2)      src/dp-parallel-sampling.jl:49-50
+//   split_cluster_local_worker!           src/local_clusters_actions.jl:265-278
+//   merge_clusters_worker!                src/local_clusters_actions.jl:293-304
+//   remove_empty_clusters_worker!         src/local_clusters_actions.jl:446-455
+//   reset_bad_clusters_worker!            src/local_clusters_actions.jl:481-488 (+ :474-479, :257-261)
+#include "dpmm_device.h"
+#include "dpmm_kernels.h"
+
+namespace dpmm {
+
+static inline int grid_for(int64_t n, int block = 256) {
+    int64_t g = (n + block - 1) / block;
+    if (g > 256 * 8) g = 256 * 8;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+__global__ void init_labels_kernel(int32_t *bins, int64_t n, int64_t first, int init_clusters, uint64_t seed, uint32_t epoch) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const Philox4 r = philox4x32_10(seed, (uint64_t)(first + i), epoch, STREAM_INIT);
+        const int z = (int)(((uint64_t)r.v[0] * (uint64_t)init_clusters) >> 32);
+        bins[i] = 2 * z + (int)(r.v[1] & 1u);
+    }
+}
+
+__global__ void bins_from_i64_kernel(int32_t *bins, const int64_t *labels, const int64_t *sub, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int b = bins[i];
+        int z = b >> 1, s = b & 1;
+        if (labels) z = (int)(labels[i] - 1);
+        if (sub) s = (int)(sub[i] - 1);
+        bins[i] = 2 * z + s;
+    }
+}
+
+__global__ void bins_to_i64_kernel(const int32_t *bins, int64_t *labels, int64_t *sub, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = bins[i];
+        if (labels) labels[i] = (int64_t)(b >> 1) + 1;
+        if (sub) sub[i] = (int64_t)(b & 1) + 1;
+    }
+}
+
+// pair by pair, in order: label==idx & sub==2 -> new_idx ; every point that had label idx gets rand(1:2)
+__global__ void split_kernel(int32_t *bins, int64_t n, int64_t first, const int32_t *pairs, int m, uint64_t seed, uint32_t epoch) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = bins[i];
+        int z = b >> 1, s = b & 1;
+        bool touched = false;
+        for (int j = 0; j < m; ++j) {
+            if (z == pairs[j]) {
+                if (s == 1) z = pairs[m + j];
+                if (!touched) {
+                    touched = true;
+                }
+                const Philox4 r = philox4x32_10(seed, (uint64_t)(first + i), epoch, STREAM_SPLIT);
+                s = (int)(r.v[0] & 1u);
+            }
+        }
+        if (touched) bins[i] = 2 * z + s;
+    }
+}
+
+__global__ void merge_kernel(int32_t *bins, int64_t n, const int32_t *pairs, int m) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = bins[i];
+        int z = b >> 1, s = b & 1;
+        for (int j = 0; j < m; ++j) {
+            if (z == pairs[j]) s = 0;
+            if (z == pairs[m + j]) { s = 1; z = pairs[j]; }
+        }
+        const int nb = 2 * z + s;
+        if (nb != b) bins[i] = nb;
+    }
+}
+
+__global__ void remap_kernel(int32_t *bins, int64_t n, const int32_t *map) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = bins[i];
+        const int z = map[b >> 1];
+        const int nb = 2 * z + (b & 1);
+        if (nb != b) bins[i] = nb;
+    }
+}
+
+__global__ void reset_sub_kernel(int32_t *bins, int64_t n, int64_t first, const int32_t *idx, int m, uint64_t seed, uint32_t epoch) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = bins[i];
+        const int z = b >> 1;
+        bool hit = (idx == nullptr);
+        for (int j = 0; j < m && !hit; ++j) hit = (z == idx[j]);
+        if (hit) {
+            const Philox4 r = philox4x32_10(seed, (uint64_t)(first + i), epoch, STREAM_RESET);
+            bins[i] = 2 * z + (int)(r.v[0] & 1u);
+        }
+    }
+}
+
+hipError_t launch_init_labels(int32_t *bins, int64_t n, int64_t first, int init_clusters, uint64_t seed, uint32_t epoch, hipStream_t s) {
+    hipLaunchKernelGGL(init_labels_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, n, first, init_clusters, seed, epoch);
+    return hipGetLastError();
+}
+hipError_t launch_bins_from_i64(int32_t *bins, const int64_t *labels, const int64_t *sub, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(bins_from_i64_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, labels, sub, n);
+    return hipGetLastError();
+}
+hipError_t launch_bins_to_i64(const int32_t *bins, int64_t *labels, int64_t *sub, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(bins_to_i64_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, labels, sub, n);
+    return hipGetLastError();
+}
+hipError_t launch_split(int32_t *bins, int64_t n, int64_t first, const int32_t *pairs, int m, uint64_t seed, uint32_t epoch, hipStream_t s) {
+    hipLaunchKernelGGL(split_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, n, first, pairs, m, seed, epoch);
+    return hipGetLastError();
+}
+hipError_t launch_merge(int32_t *bins, int64_t n, const int32_t *pairs, int m, hipStream_t s) {
+    hipLaunchKernelGGL(merge_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, n, pairs, m);
+    return hipGetLastError();
+}
+hipError_t launch_remap(int32_t *bins, int64_t n, const int32_t *map, hipStream_t s) {
+    hipLaunchKernelGGL(remap_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, n, map);
+    return hipGetLastError();
+}
+hipError_t launch_reset_sub(int32_t *bins, int64_t n, int64_t first, const int32_t *idx, int m, uint64_t seed, uint32_t epoch, hipStream_t s) {
+    hipLaunchKernelGGL(reset_sub_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, n, first, idx, m, seed, epoch);
+    return hipGetLastError();
+}
+
+}  // namespace dpmm

@@ -1,0 +1,154 @@
+// mult_sweep.hip -- fused label + sub-label sampling for the Multinomial prior on gfx950.
+//
+// Stands in for (reference paths relative to the reference checkout):
+//   sample_labels_worker!               src/local_clusters_actions.jl:112-134
+//   log_likelihood!(::multinomial_dist) src/distributions/multinomial_dist.jl:13-15  (r_i = alpha' x_i)
+//   sample_log_cat_array!               src/utils.jl:19-31
+//   sample_sub_clusters_worker! / create_subclusters_labels!   src/local_clusters_actions.jl:70-95
+//
+// Regime: D ~ 1000 dense Float32 counts, 4*D bytes per point against 2*D*(K+2) flops: HBM
+// streaming with a skinny GEMM on top.  The x stream is read once; all 3K log-probability
+// rows (cluster, left, right for every cluster) are contracted against it on the FP32 matrix
+// cores (v_mfma_f32_16x16x4_f32, M = 16 parameter rows, N = 16 points, K = 4 features), so the
+// sub-label phase needs no second pass over x and no dependence on the label mix of a tile.
+//   A operand: logp rows, pre-packed fragment image Lp[rowblock][t][lane][4] (L2 resident)
+//   B operand: x, float4 per lane straight from HBM: lane (c, g) reads elements 16t+4g.. of point c
+// The 3K x TILE table (+ log weights) goes to a per-workgroup scratch (L2), then every lane
+// draws label and sub-label for one point with the oracle-identical inverse-CDF scan.
+#include "dpmm_device.h"
+#include "dpmm_kernels.h"
+
+namespace dpmm {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int M_NG = 4;        // 16-point groups per wave
+constexpr int M_TILE = 256;    // points per workgroup
+constexpr int M_RBP = 8;       // row blocks (of 16 parameter rows) per pass over the features
+
+__global__ __launch_bounds__(256) void mult_sweep_kernel(MultSweepArgs A, const float *__restrict__ Lp, int NT, int NRB) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ci = lane & 15, g = lane >> 4;
+    const int K = A.K, rows = 3 * K;
+    const int64_t ntiles = (A.n + M_TILE - 1) / M_TILE;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t wbase = tile * M_TILE + (int64_t)wave * 64;
+        float *scr = A.scratch + (A.scratch_by_tile ? tile * M_TILE : (int64_t)blockIdx.x * M_TILE) + wave * 64;
+        const int64_t sstride = A.scratch_stride;
+        const float *xp[M_NG];
+        bool pv[M_NG];
+#pragma unroll
+        for (int n = 0; n < M_NG; ++n) {
+            const int64_t p = wbase + 16 * n + ci;
+            pv[n] = p < A.n;
+            xp[n] = A.X + (pv[n] ? p : 0) * A.ldx + 4 * g;
+        }
+        for (int rb0 = 0; rb0 < NRB; rb0 += M_RBP) {
+            f32x4 acc[M_RBP][M_NG];
+#pragma unroll
+            for (int rb = 0; rb < M_RBP; ++rb)
+#pragma unroll
+                for (int n = 0; n < M_NG; ++n) acc[rb][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int nrb = min(M_RBP, NRB - rb0);
+#pragma unroll 2
+            for (int t = 0; t < NT; ++t) {
+                f32x4 x[M_NG];
+                const bool ev = 16 * t + 4 * g < A.ldx;
+#pragma unroll
+                for (int n = 0; n < M_NG; ++n)
+                    x[n] = (pv[n] && ev) ? *reinterpret_cast<const f32x4 *>(xp[n] + 16 * t) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int rb = 0; rb < M_RBP; ++rb) {
+                    if (rb < nrb) {
+                        const f32x4 a = *reinterpret_cast<const f32x4 *>(Lp + ((size_t)(rb0 + rb) * NT + t) * 256 + lane * 4);
+#pragma unroll
+                        for (int n = 0; n < M_NG; ++n) {
+                            acc[rb][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x[n].x, acc[rb][n], 0, 0, 0);
+                            acc[rb][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x[n].y, acc[rb][n], 0, 0, 0);
+                            acc[rb][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x[n].z, acc[rb][n], 0, 0, 0);
+                            acc[rb][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x[n].w, acc[rb][n], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            // C layout: reg r -> parameter row 16(rb0+rb) + 4g + r, point 16n + ci
+#pragma unroll
+            for (int rb = 0; rb < M_RBP; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * (rb0 + rb) + 4 * g + r;
+                    if (rb < nrb && row < rows) {
+                        const float cst = A.cst[row];
+#pragma unroll
+                        for (int n = 0; n < M_NG; ++n) scr[(int64_t)row * sstride + 16 * n + ci] = acc[rb][n][r] + cst;
+                    }
+                }
+        }
+        __syncthreads();  // table rows were written by other lanes of the wave (workgroup-scope fence)
+        const int64_t myp = wbase + lane;
+        const bool valid = myp < A.n;
+        if (valid && !A.labels_only) {
+            const float *col = scr + lane;
+            const Philox4 rr = philox4x32_10(A.seed, (uint64_t)(A.first_index + myp), A.epoch, STREAM_SWEEP);
+            int z = 0;
+            float m = -INFINITY;
+            int best = 0;
+            bool nan_seen = false;
+            for (int k = 0; k < K; ++k) {
+                const float a = col[(int64_t)(3 * k) * sstride];
+                if (a != a) {
+                    if (!nan_seen) { nan_seen = true; best = k; }
+                } else if (a > m) {
+                    m = a;
+                    if (!nan_seen) best = k;
+                }
+            }
+            if (A.final_argmax) {
+                z = best;
+            } else if (m == -INFINITY) {
+                z = 0;
+            } else {
+                float s = 0.f;
+                for (int k = 0; k < K; ++k) s += exp_det(nan_to_ninf(col[(int64_t)(3 * k) * sstride]) - m);
+                const float t = u01(rr.v[0]) * s;
+                float cw = 0.f;
+                z = K - 1;
+                for (int k = 0; k < K; ++k) {
+                    cw += exp_det(nan_to_ninf(col[(int64_t)(3 * k) * sstride]) - m);
+                    if (!(cw < t)) { z = k; break; }
+                }
+            }
+            const float b0 = col[(int64_t)(3 * z + 1) * sstride], b1 = col[(int64_t)(3 * z + 2) * sstride];
+            A.bins[myp] = 2 * z + draw2(b0, b1, u01(rr.v[1]));
+        }
+        __syncthreads();  // scratch rows are reused by the next tile
+    }
+}
+
+// Lp[rb][t][lane][jj] = logp[16 rb + (lane & 15)][16 t + 4 (lane >> 4) + jj]  (zero outside [3K) x [ldx))
+__global__ void mult_pack_kernel(const float *__restrict__ logp, float *__restrict__ Lp, int rows, int64_t ldx, int NT, int NRB) {
+    const int64_t total = (int64_t)NRB * NT * 256;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int jj = (int)(e & 3), lane = (int)((e >> 2) & 63);
+        const int64_t bt = e >> 8;
+        const int t = (int)(bt % NT), rb = (int)(bt / NT);
+        const int row = 16 * rb + (lane & 15), col = 16 * t + 4 * (lane >> 4) + jj;
+        Lp[e] = (row < rows && col < ldx) ? logp[(size_t)row * ldx + col] : 0.f;
+    }
+}
+
+int mult_tile_points() { return M_TILE; }
+
+hipError_t launch_mult_pack(const float *logp, float *Lp, int rows, int64_t ldx, hipStream_t s) {
+    const int NT = (int)((ldx + 15) / 16), NRB = (rows + 15) / 16;
+    hipLaunchKernelGGL(mult_pack_kernel, dim3(512), dim3(256), 0, s, logp, Lp, rows, ldx, NT, NRB);
+    return hipGetLastError();
+}
+
+hipError_t launch_mult_sweep(const MultSweepArgs &a, int grid, hipStream_t s) {
+    const int NT = (int)((a.ldx + 15) / 16), NRB = (3 * a.K + 15) / 16;
+    hipLaunchKernelGGL(mult_sweep_kernel, dim3(grid), dim3(256), 0, s, a, a.logp, NT, NRB);
+    return hipGetLastError();
+}
+
+}  // namespace dpmm

@@ -1,0 +1,372 @@
+// niw_sweep.hip -- fused label + sub-label sampling for the NIW / Gaussian prior on gfx950.
+//
+// Stands in for (reference paths relative to the reference checkout):
+//   sample_labels_worker!            src/local_clusters_actions.jl:112-134
+//   log_likelihood!(::mv_gaussian)   src/distributions/mv_gaussian.jl:21-25  (+ utils.jl:75-84)
+//   sample_log_cat_array!            src/utils.jl:19-31
+//   sample_sub_clusters_worker!      src/local_clusters_actions.jl:70-81
+//   create_subclusters_labels!       src/local_clusters_actions.jl:83-95
+//
+// Design (CDNA4, wave64):
+//   * the quadratic form is evaluated through the upper-triangular factor R of Sigma^-1
+//     (Sigma^-1 = R'R):  q = || R (x - mu) ||^2 .  y = R z is a (D x D)(D x P) product on the
+//     FP32 matrix cores (v_mfma_f32_16x16x4_f32, exact f32 fma chains); only the
+//     16x16 blocks on or above the diagonal are visited (D=64: 10 of 16 blocks).
+//   * one wave owns 16*NG points.  Their x stays in registers for the whole sweep (the
+//     B operand); z = x - mu_k is formed on the fly; the A operand (a pre-packed
+//     fragment image of R_k, 1 KiB per 16x16 block) is staged global -> registers -> LDS
+//     one chunk ahead of the MFMAs and shared by the 4 waves of the workgroup.
+//   * a_k = -1/2 q + (-1/2 logdet_k + log w_k) goes to a per-workgroup scratch row
+//     (L2-resident); each lane then draws the label of "its" point with the deterministic
+//     inverse-CDF scan shared with the CPU oracle, using Philox(seed; global index, epoch).
+//   * sub-labels: the workgroup walks the distinct labels it just drew; for each it
+//     evaluates the left/right sub-cluster forms for its points and draws 1 of 2.
+//
+// Fragment conventions for v_mfma_f32_16x16x4_f32 (lane l: i = l & 15, g = l >> 4):
+//   A[i][k=g], B[k=g][col=i], C/D reg r: row 4g + r, col i.
+// Contraction step (t, jj) covers vector elements {16t + 4g + jj : g = 0..3}; x is loaded as
+// float4 at element 16t + 4g, so element (16t + 4g + jj) is component jj of that float4.
+#include "dpmm_device.h"
+#include "dpmm_kernels.h"
+
+namespace dpmm {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NB>
+__host__ __device__ constexpr int pair_base(int bi) {
+    return bi * NB - (bi * (bi - 1)) / 2;
+}
+
+template <int NB, int NG, int CH>
+struct NiwCfg {
+    static constexpr int DP = 16 * NB;
+    static constexpr int NP = NB * (NB + 1) / 2;     // 16x16 blocks on/above the diagonal
+    static constexpr int MATSZ = NP * 256;            // floats per packed matrix
+    static constexpr int NCH = (NB + CH - 1) / CH;    // chunks per matrix
+    static constexpr int TILE = 64 * NG;              // points per workgroup tile (4 waves x 16 NG)
+    static constexpr int WPTS = 16 * NG;              // points per wave
+    __host__ __device__ static constexpr int row0(int c) { return c * CH; }
+    __host__ __device__ static constexpr int row1(int c) { return (c + 1) * CH < NB ? (c + 1) * CH : NB; }
+    __host__ __device__ static constexpr int pairs(int c) { return pair_base<NB>(row1(c)) - pair_base<NB>(row0(c)); }
+    __host__ __device__ static constexpr int passes(int c) { return (pairs(c) + 3) / 4; }
+    __host__ __device__ static constexpr int max_pairs() {
+        int m = 0;
+        for (int c = 0; c < NCH; ++c) m = pairs(c) > m ? pairs(c) : m;
+        return m;
+    }
+    static constexpr int MAXPAIRS = max_pairs();
+    static constexpr int MAXPASS = (MAXPAIRS + 3) / 4;
+};
+
+template <int NB, int NG, int CH>
+struct QuadEval {
+    using C = NiwCfg<NB, NG, CH>;
+    // staging registers: named members + compile-time selector (an indexed array here ends up in
+    // scratch memory: the conditional writes defeat SROA)
+    f32x4 st0, st1, st2, st3;
+    static_assert(C::MAXPASS <= 4, "chunk too large for the staging registers");
+    template <int p>
+    __device__ __forceinline__ f32x4 &S() {
+        if constexpr (p == 0) return st0;
+        else if constexpr (p == 1) return st1;
+        else if constexpr (p == 2) return st2;
+        else return st3;
+    }
+    template <int c, int p>
+    __device__ __forceinline__ void prefetch_pass(const f32x4 *src) {
+        if constexpr (p < C::passes(c)) {
+            const int i4 = p * 256 + (int)threadIdx.x;
+            if constexpr ((p + 1) * 256 <= C::pairs(c) * 64) S<p>() = src[i4];
+            else if (i4 < C::pairs(c) * 64) S<p>() = src[i4];
+            prefetch_pass<c, p + 1>(src);
+        }
+    }
+    template <int c, int p>
+    __device__ __forceinline__ void commit_pass(f32x4 *dst) {
+        if constexpr (p < C::passes(c)) {
+            const int i4 = p * 256 + (int)threadIdx.x;
+            if constexpr ((p + 1) * 256 <= C::pairs(c) * 64) dst[i4] = S<p>();
+            else if (i4 < C::pairs(c) * 64) dst[i4] = S<p>();
+            commit_pass<c, p + 1>(dst);
+        }
+    }
+    // issue the global loads of chunk c of packed matrix Rm into registers
+    template <int c>
+    __device__ __forceinline__ void prefetch(const float *__restrict__ Rm) {
+        prefetch_pass<c, 0>(reinterpret_cast<const f32x4 *>(Rm + pair_base<NB>(C::row0(c)) * 256));
+    }
+    template <int c>
+    __device__ __forceinline__ void commit(float *lds) {
+        commit_pass<c, 0>(reinterpret_cast<f32x4 *>(lds));
+    }
+    // accumulate q[n] += sum over the chunk's rows of y_row^2, y = R (x - mu)
+    template <int c>
+    __device__ __forceinline__ void compute(const float *lds, const f32x4 (&x)[NG][NB], const f32x4 (&mu)[NB],
+                                            float (&q)[NG], int lane) {
+#pragma unroll
+        for (int bi = C::row0(c); bi < C::row1(c); ++bi) {
+            f32x4 acc[NG];
+#pragma unroll
+            for (int n = 0; n < NG; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = bi; t < NB; ++t) {
+                const int pic = pair_base<NB>(bi) + (t - bi) - pair_base<NB>(C::row0(c));
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(lds + pic * 256 + lane * 4);
+#pragma unroll
+                for (int n = 0; n < NG; ++n) {
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x[n][t].x - mu[t].x, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x[n][t].y - mu[t].y, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x[n][t].z - mu[t].z, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x[n][t].w - mu[t].w, acc[n], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < NG; ++n) {
+                q[n] = __builtin_fmaf(acc[n][0], acc[n][0], q[n]);
+                q[n] = __builtin_fmaf(acc[n][1], acc[n][1], q[n]);
+                q[n] = __builtin_fmaf(acc[n][2], acc[n][2], q[n]);
+                q[n] = __builtin_fmaf(acc[n][3], acc[n][3], q[n]);
+            }
+        }
+    }
+};
+
+// Evaluate q for one packed matrix (all chunks), prefetching the first chunk of `Rnext`
+// (may be null) behind the last chunk's MFMAs.  On entry the first chunk of Rcur must already
+// be in ev.st.  `active` is wave-uniform: inactive waves take part in the staging but skip the MFMAs.
+template <int NB, int NG, int CH, int c = 0>
+__device__ __forceinline__ void eval_matrix(QuadEval<NB, NG, CH> &ev, float *lds, const float *Rcur, const float *Rnext,
+                                            const f32x4 (&x)[NG][NB], const f32x4 (&mu)[NB], float (&q)[NG],
+                                            int lane, bool active) {
+    using C = NiwCfg<NB, NG, CH>;
+    __syncthreads();  // previous chunk's LDS reads are done
+    ev.template commit<c>(lds);
+    __syncthreads();
+    if constexpr (c + 1 < C::NCH) {
+        ev.template prefetch<c + 1>(Rcur);
+    } else {
+        if (Rnext) ev.template prefetch<0>(Rnext);
+    }
+    if (active) ev.template compute<c>(lds, x, mu, q, lane);
+    if constexpr (c + 1 < C::NCH) eval_matrix<NB, NG, CH, c + 1>(ev, lds, Rcur, Rnext, x, mu, q, lane, active);
+}
+
+template <int NG>
+__device__ __forceinline__ float reduce_select(float (&q)[NG], int g) {
+    float sel = 0.f;
+#pragma unroll
+    for (int n = 0; n < NG; ++n) {
+        float v = q[n];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (g == n) sel = v;
+    }
+    return sel;
+}
+
+template <int NB, int NG, int CH>
+__global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSweepArgs A) {
+    using C = NiwCfg<NB, NG, CH>;
+    __shared__ __attribute__((aligned(16))) float lds[C::MAXPAIRS * 256];
+    __shared__ uint32_t present[DPMM_MAX_CLUSTERS_K / 32];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int ci = lane & 15;  // column (point within a 16-group) for the B operand
+    const int g = lane >> 4;   // k-slot / row group
+    const int K = A.K;
+    const bool owner = lane < C::WPTS;  // lane `lane` draws for point `lane` of the wave
+
+    QuadEval<NB, NG, CH> ev;
+
+    for (int64_t tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
+        const int64_t wbase = tile * C::TILE + (int64_t)wave * C::WPTS;  // first point of this wave
+        // ---- x tile -> registers (B-operand layout)
+        f32x4 x[NG][NB];
+#pragma unroll
+        for (int n = 0; n < NG; ++n) {
+            const int64_t p = wbase + 16 * n + ci;
+#pragma unroll
+            for (int t = 0; t < NB; ++t) {
+                const int e = 16 * t + 4 * g;
+                x[n][t] = (p < A.n && e < A.ldx) ? *reinterpret_cast<const f32x4 *>(A.X + p * A.ldx + e)
+                                                  : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        const int64_t myp = wbase + lane;  // owner's point
+        const bool valid = owner && myp < A.n;
+        float *scr = A.scratch + (A.scratch_by_tile ? tile * C::TILE : (int64_t)blockIdx.x * C::TILE) + wave * C::WPTS + lane;
+        const int64_t sstride = A.scratch_stride;
+
+        // ---- phase 1: a_k for every cluster
+        float m_run = -INFINITY;
+        int best = 0;
+        bool nan_seen = false;
+        ev.template prefetch<0>(A.Rp);
+        for (int k = 0; k < K; ++k) {
+            const float *Rcur = A.Rp + (size_t)(3 * k) * C::MATSZ;
+            const float *Rnext = (k + 1 < K) ? A.Rp + (size_t)(3 * (k + 1)) * C::MATSZ : nullptr;
+            f32x4 mu[NB];
+#pragma unroll
+            for (int t = 0; t < NB; ++t)
+                mu[t] = *reinterpret_cast<const f32x4 *>(A.mup + (size_t)(3 * k) * C::DP + 16 * t + 4 * g);
+            float q[NG];
+#pragma unroll
+            for (int n = 0; n < NG; ++n) q[n] = 0.f;
+            eval_matrix<NB, NG, CH>(ev, lds, Rcur, Rnext, x, mu, q, lane, true);
+            const float qs = reduce_select<NG>(q, g);
+            const float a = __builtin_fmaf(-0.5f, qs, A.cst[3 * k]);
+            if (valid) {
+                scr[(int64_t)k * sstride] = a;
+                if (a != a) {
+                    if (!nan_seen) { nan_seen = true; best = k; }  // Julia argmax: first NaN wins
+                } else {
+                    if (a > m_run) { m_run = a; if (!nan_seen) best = k; }
+                }
+            }
+        }
+
+        // ---- label draw (owner lanes), src/utils.jl:19-31
+        int z = 0;
+        float u_sub = 0.f;
+        if (valid) {
+            const Philox4 r = philox4x32_10(A.seed, (uint64_t)(A.first_index + myp), A.epoch, STREAM_SWEEP);
+            u_sub = u01(r.v[1]);
+            if (A.final_argmax) {
+                z = best;
+            } else if (m_run == -INFINITY) {
+                z = 0;
+            } else {
+                float s = 0.f;
+                for (int k = 0; k < K; ++k) s += exp_det(nan_to_ninf(scr[(int64_t)k * sstride]) - m_run);
+                const float t = u01(r.v[0]) * s;
+                float cw = 0.f;
+                z = K - 1;
+                for (int k = 0; k < K; ++k) {
+                    cw += exp_det(nan_to_ninf(scr[(int64_t)k * sstride]) - m_run);
+                    if (!(cw < t)) { z = k; break; }
+                }
+            }
+        }
+        if (A.labels_only) continue;  // debug_loglik: table only (uniform branch)
+
+        // ---- phase 2: sub-labels.  Distinct labels of the workgroup -> LDS bitmap
+        __syncthreads();
+        if (tid < DPMM_MAX_CLUSTERS_K / 32) present[tid] = 0u;
+        __syncthreads();
+        if (valid) atomicOr(&present[z >> 5], 1u << (z & 31));
+        __syncthreads();
+        float b0 = -INFINITY, b1 = -INFINITY;
+        const int nwords = (K + 31) >> 5;
+        // find the first label, then walk the set with one-label lookahead for the prefetch
+        int w = 0;
+        uint32_t bits = __builtin_amdgcn_readfirstlane(present[0]);
+        auto next_label = [&](int &ww, uint32_t &bb) -> int {
+            while (bb == 0u) {
+                ++ww;
+                if (ww >= nwords) return -1;
+                bb = __builtin_amdgcn_readfirstlane(present[ww]);
+            }
+            const int b = __builtin_ctz(bb);
+            bb &= bb - 1u;
+            return (ww << 5) + b;
+        };
+        int kcur = next_label(w, bits);
+        if (kcur >= 0) ev.template prefetch<0>(A.Rp + (size_t)(3 * kcur + 1) * C::MATSZ);
+        while (kcur >= 0) {
+            const int knext = next_label(w, bits);
+            const bool wave_has = __any(valid && z == kcur);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int j = 3 * kcur + 1 + s;
+                const float *Rcur = A.Rp + (size_t)j * C::MATSZ;
+                const float *Rnext = (s == 0) ? A.Rp + (size_t)(j + 1) * C::MATSZ
+                                              : (knext >= 0 ? A.Rp + (size_t)(3 * knext + 1) * C::MATSZ : nullptr);
+                f32x4 mu[NB];
+#pragma unroll
+                for (int t = 0; t < NB; ++t)
+                    mu[t] = *reinterpret_cast<const f32x4 *>(A.mup + (size_t)j * C::DP + 16 * t + 4 * g);
+                float q[NG];
+#pragma unroll
+                for (int n = 0; n < NG; ++n) q[n] = 0.f;
+                eval_matrix<NB, NG, CH>(ev, lds, Rcur, Rnext, x, mu, q, lane, wave_has);
+                const float qs = reduce_select<NG>(q, g);
+                const float b = __builtin_fmaf(-0.5f, qs, A.cst[j]);
+                if (valid && z == kcur) {
+                    if (s == 0) b0 = b; else b1 = b;
+                }
+            }
+            kcur = knext;
+        }
+        if (valid) {
+            const int sl = draw2(b0, b1, u_sub);
+            A.bins[myp] = 2 * z + sl;
+        }
+    }
+}
+
+template <int NB, int NG, int CH>
+static hipError_t launch_cfg(const NiwSweepArgs &a, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((niw_sweep_kernel<NB, NG, CH>), dim3(grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+int niw_tile_points(int NB) {
+    switch (NB) {
+        case 1: case 2: case 4: return 256;
+        case 8: return 128;
+        default: return 128;
+    }
+}
+
+hipError_t launch_niw_sweep(int NB, const NiwSweepArgs &a, int grid, hipStream_t s) {
+    switch (NB) {
+        case 1: return launch_cfg<1, 4, 1>(a, grid, s);
+        case 2: return launch_cfg<2, 4, 2>(a, grid, s);
+        case 4: return launch_cfg<4, 4, 4>(a, grid, s);
+        case 8: return launch_cfg<8, 2, 2>(a, grid, s);
+        case 16: return launch_cfg<16, 2, 1>(a, grid, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Parameter packing: raw R (row-major [3K][D][D], upper triangular) -> MFMA A-fragment image.
+// Rp[j][pair(bi,t)][lane][jj] = R[16 bi + (lane & 15)][16 t + 4 (lane >> 4) + jj], zero beyond D
+// and below the diagonal.  mup[j][DP] = mu zero-padded.
+__global__ void niw_pack_kernel(const float *__restrict__ R, const float *__restrict__ mu, float *__restrict__ Rp,
+                                float *__restrict__ mup, int D, int NB, int nmat) {
+    const int NP = NB * (NB + 1) / 2;
+    const int DP = 16 * NB;
+    const int64_t total = (int64_t)nmat * NP * 256;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int jj = (int)(e & 3);
+        const int lane = (int)((e >> 2) & 63);
+        const int64_t pj = e >> 8;
+        const int pair = (int)(pj % NP);
+        const int j = (int)(pj / NP);
+        int bi = 0, rem = pair;
+        while (rem >= NB - bi) { rem -= NB - bi; ++bi; }
+        const int t = bi + rem;
+        const int row = 16 * bi + (lane & 15);
+        const int col = 16 * t + 4 * (lane >> 4) + jj;
+        float v = 0.f;
+        if (row < D && col < D && col >= row) v = R[((size_t)j * D + row) * D + col];
+        Rp[e] = v;
+    }
+    const int64_t totmu = (int64_t)nmat * DP;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < totmu; e += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(e % DP);
+        const int j = (int)(e / DP);
+        mup[e] = d < D ? mu[(size_t)j * D + d] : 0.f;
+    }
+}
+
+hipError_t launch_niw_pack(const float *R, const float *mu, float *Rp, float *mup, int D, int NB, int nmat, hipStream_t s) {
+    hipLaunchKernelGGL(niw_pack_kernel, dim3(512), dim3(256), 0, s, R, mu, Rp, mup, D, NB, nmat);
+    return hipGetLastError();
+}
+
+}  // namespace dpmm

@@ -1,0 +1,402 @@
+// suffstats.hip -- per-(cluster, sub-cluster) sufficient statistics on gfx950.
+//
+// Stands in for create_suff_stats_dict_worker (src/local_clusters_actions.jl:149-169) with
+// create_sufficient_statistics for the NIW prior (src/priors/niw.jl:42-51: N, sum x, X X' in
+// Float64) and for the Multinomial prior (src/priors/multinomial_prior.jl:27-32: N, sum x).
+//
+// The reference builds a boolean mask per cluster and gathers; here the points are grouped
+// once per pass by a stable counting sort on the bin = (label, sub-label) and every bin is
+// then a contiguous segment of `perm`:
+//   1. hist      one wave per SORT_TILE points, LDS counters -> tile_hist[bin][tile]
+//   2. scan      one workgroup per bin: exclusive scan over tiles, bin totals
+//   3. starts    bin_start (exclusive scan of totals) and the work-item table
+//   4. scatter   stable rank inside the wave (ballot match loop) -> perm
+//   5. stats     work item = (bin, <= chunk points): gather the columns, Float64 MFMA
+//                (v_mfma_f64_16x16x4_f64) outer-product accumulation of the lower block
+//                triangle + Float64 column sums, one slab per item
+//   6. reduce    per bin: sum the item slabs in item order (deterministic), emit the packed
+//                row {N, sum, lower triangle of S}
+// Statistics are bitwise reproducible run to run (no floating-point atomics).
+//
+// f64 MFMA fragment conventions (lane l: i = l & 15, g = l >> 4): A[i][k=g], B[k=g][col=i],
+// C/D element r (0..3): row g + 4r, col i.
+#include "dpmm_device.h"
+#include "dpmm_kernels.h"
+
+namespace dpmm {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------ sort
+__global__ __launch_bounds__(64) void hist_kernel(const int32_t *__restrict__ bins, int64_t n, int nbins, int nt,
+                                                  int32_t *__restrict__ tile_hist) {
+    extern __shared__ int cnt[];
+    const int lane = threadIdx.x;
+    for (int b = lane; b < nbins; b += 64) cnt[b] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
+    for (int it = 0; it < SORT_TILE / 64; ++it) {
+        const int64_t i = base + it * 64 + lane;
+        if (i < n) {
+            const int b = bins[i];
+            if ((unsigned)b < (unsigned)nbins) atomicAdd(&cnt[b], 1);
+        }
+    }
+    __syncthreads();
+    for (int b = lane; b < nbins; b += 64) tile_hist[(int64_t)b * nt + blockIdx.x] = cnt[b];
+}
+
+// exclusive scan over the tiles of one bin (in place) + bin total
+__global__ __launch_bounds__(256) void scan_tiles_kernel(int32_t *__restrict__ tile_hist, int nt, int32_t *__restrict__ bin_total) {
+    __shared__ int part[256];
+    int32_t *row = tile_hist + (int64_t)blockIdx.x * nt;
+    const int per = (nt + 255) / 256;
+    const int lo = threadIdx.x * per, hi = min(lo + per, nt);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += row[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over the 256 partials
+    for (int off = 1; off < 256; off <<= 1) {
+        int v = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - s;  // exclusive prefix of this thread's range
+    for (int i = lo; i < hi; ++i) {
+        const int v = row[i];
+        row[i] = run;
+        run += v;
+    }
+    if (threadIdx.x == 255) bin_total[blockIdx.x] = part[255];
+}
+
+// bin_start[b] = sum_{b'<b} total ; item_start[b] = sum_{b'<b} ceil(sel*total / chunk)
+__global__ __launch_bounds__(256) void starts_kernel(const int32_t *__restrict__ bin_total, const uint8_t *__restrict__ bin_sel,
+                                                     int nbins, int chunk, int32_t *__restrict__ bin_start,
+                                                     int32_t *__restrict__ item_start) {
+    __shared__ int pa[256], pb[256];
+    const int per = (nbins + 255) / 256;
+    const int lo = threadIdx.x * per, hi = min(lo + per, nbins);
+    int sa = 0, sb = 0;
+    for (int b = lo; b < hi; ++b) {
+        const int t = bin_total[b];
+        sa += t;
+        sb += bin_sel[b] ? (t + chunk - 1) / chunk : 0;
+    }
+    pa[threadIdx.x] = sa;
+    pb[threadIdx.x] = sb;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        int va = (threadIdx.x >= off) ? pa[threadIdx.x - off] : 0;
+        int vb = (threadIdx.x >= off) ? pb[threadIdx.x - off] : 0;
+        __syncthreads();
+        pa[threadIdx.x] += va;
+        pb[threadIdx.x] += vb;
+        __syncthreads();
+    }
+    int ra = pa[threadIdx.x] - sa, rb = pb[threadIdx.x] - sb;
+    for (int b = lo; b < hi; ++b) {
+        bin_start[b] = ra;
+        item_start[b] = rb;
+        const int t = bin_total[b];
+        ra += t;
+        rb += bin_sel[b] ? (t + chunk - 1) / chunk : 0;
+    }
+    if (threadIdx.x == 255) {
+        bin_start[nbins] = pa[255];
+        item_start[nbins] = pb[255];
+    }
+}
+
+__global__ __launch_bounds__(64) void scatter_kernel(const int32_t *__restrict__ bins, int64_t n, int nbins, int nt,
+                                                     const int32_t *__restrict__ tile_hist,
+                                                     const int32_t *__restrict__ bin_start, int32_t *__restrict__ perm) {
+    extern __shared__ int base[];
+    const int lane = threadIdx.x;
+    for (int b = lane; b < nbins; b += 64) base[b] = bin_start[b] + tile_hist[(int64_t)b * nt + blockIdx.x];
+    __syncthreads();
+    const int64_t tbase = (int64_t)blockIdx.x * SORT_TILE;
+    for (int it = 0; it < SORT_TILE / 64; ++it) {
+        const int64_t i = tbase + it * 64 + lane;
+        int b = -1;
+        if (i < n) {
+            b = bins[i];
+            if ((unsigned)b >= (unsigned)nbins) b = -1;
+        }
+        const bool valid = b >= 0;
+        unsigned long long todo = __ballot(valid);
+        int rank = 0, cntb = 0;
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int lb = __shfl(b, leader);
+            const unsigned long long m = __ballot(valid && b == lb);
+            if (valid && b == lb) {
+                rank = __popcll(m & ((1ull << lane) - 1ull));
+                cntb = __popcll(m);
+            }
+            todo &= ~m;
+        }
+        int pos = 0;
+        if (valid) pos = base[b] + rank;
+        __syncthreads();
+        if (valid) {
+            perm[pos] = (int32_t)i;
+            if (rank == 0) base[b] += cntb;
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_sort_by_bin(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s) {
+    const int nt = (int)((n + SORT_TILE - 1) / SORT_TILE);
+    if (nt == 0) return hipSuccess;
+    hipLaunchKernelGGL(hist_kernel, dim3(nt), dim3(64), nbins * sizeof(int), s, bins, n, nbins, nt, b.tile_hist);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(nbins), dim3(256), 0, s, b.tile_hist, nt, b.bin_total);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------ items
+__device__ __forceinline__ int find_bin(const int32_t *__restrict__ item_start, int nbins, int item) {
+    int lo = 0, hi = nbins;  // largest b with item_start[b] <= item and item < item_start[b+1]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (item_start[mid] <= item) lo = mid; else hi = mid;
+    }
+    // skip empty bins that share the same start
+    while (lo + 1 < nbins && item_start[lo + 1] <= item) ++lo;
+    return lo;
+}
+
+// ------------------------------------------------------------------------------------ NIW statistics
+template <int NBK>
+struct StatCfg {
+    static constexpr int NPAIR = NBK * (NBK + 1) / 2;
+    static constexpr int DP = 16 * NBK;
+    static constexpr int NPANEL = (NBK <= 4) ? 1 : (NBK == 8 ? 2 : 4);
+    static constexpr int PP = (NPAIR + NPANEL - 1) / NPANEL;  // pairs per panel
+};
+
+__host__ __device__ inline int64_t niw_slab_stride_nbk(int NBK) { return (int64_t)(NBK * (NBK + 1) / 2) * 256 + 16 * NBK; }
+
+template <int NBK, int PANEL>
+__device__ __forceinline__ void niw_stats_body(const StatsArgs &A, int seg, int cnt, double *__restrict__ slab) {
+    using C = StatCfg<NBK>;
+    constexpr int P0 = PANEL * C::PP;
+    constexpr int P1 = (P0 + C::PP < C::NPAIR) ? P0 + C::PP : C::NPAIR;
+    constexpr int NP = P1 - P0;
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, g = lane >> 4;
+    f64x4 acc[NP > 0 ? NP : 1];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) acc[p] = (f64x4){0., 0., 0., 0.};
+    double xs[NBK];
+#pragma unroll
+    for (int b = 0; b < NBK; ++b) xs[b] = 0.;
+
+    constexpr int U = (NBK <= 4) ? 4 : 2;  // k-steps (of 4 points) in flight
+    const int nsteps = (cnt + 3) >> 2;
+    for (int s0 = 0; s0 < nsteps; s0 += U) {
+        float xf[U][NBK];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int pl = 4 * (s0 + u) + g;
+            const bool valid = pl < cnt;
+            const int64_t pt = valid ? (int64_t)A.sb.perm[seg + pl] : 0;
+            const float *xp = A.X + pt * A.ldx + NBK * i;
+            if constexpr (NBK >= 4) {
+#pragma unroll
+                for (int c4 = 0; c4 < NBK / 4; ++c4) {
+                    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (valid && NBK * i + 4 * c4 < A.ldx) v = *reinterpret_cast<const f32x4 *>(xp + 4 * c4);
+                    xf[u][4 * c4 + 0] = v.x; xf[u][4 * c4 + 1] = v.y; xf[u][4 * c4 + 2] = v.z; xf[u][4 * c4 + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < NBK; ++b) xf[u][b] = (valid && NBK * i + b < A.ldx) ? xp[b] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            double xd[NBK];
+#pragma unroll
+            for (int b = 0; b < NBK; ++b) {
+                xd[b] = (double)xf[u][b];
+                if constexpr (PANEL == 0) xs[b] += xd[b];
+            }
+            // lower block triangle, pair index p(ba,bb) = ba(ba+1)/2 + bb, ba >= bb
+#pragma unroll
+            for (int ba = 0; ba < NBK; ++ba)
+#pragma unroll
+                for (int bb = 0; bb <= ba; ++bb) {
+                    const int p = ba * (ba + 1) / 2 + bb;
+                    if (p >= P0 && p < P1)
+                        acc[p - P0] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd[ba], xd[bb], acc[p - P0], 0, 0, 0);
+                }
+        }
+    }
+    // slab[pair][r][lane]
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[(int64_t)(P0 + p) * 256 + r * 64 + lane] = acc[p][r];
+    if constexpr (PANEL == 0) {
+#pragma unroll
+        for (int b = 0; b < NBK; ++b) {
+            double v = xs[b];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (g == 0) slab[(int64_t)C::NPAIR * 256 + NBK * i + b] = v;
+        }
+    }
+}
+
+template <int NBK>
+__global__ __launch_bounds__(64 * StatCfg<NBK>::NPANEL) void niw_stats_kernel(StatsArgs A) {
+    using C = StatCfg<NBK>;
+    const int total_items = A.sb.item_start[A.nbins];
+    for (int item = blockIdx.x; item < total_items; item += gridDim.x) {
+        const int b = find_bin(A.sb.item_start, A.nbins, item);
+        const int j = item - A.sb.item_start[b];
+        const int bcnt = A.sb.bin_total[b];
+        const int seg = A.sb.bin_start[b] + j * A.chunk;
+        const int cnt = min(A.chunk, bcnt - j * A.chunk);
+        double *slab = A.slabs + (int64_t)item * A.slab_stride;
+        const int panel = threadIdx.x >> 6;
+        if constexpr (C::NPANEL == 1) {
+            niw_stats_body<NBK, 0>(A, seg, cnt, slab);
+        } else if constexpr (C::NPANEL == 2) {
+            if (panel == 0) niw_stats_body<NBK, 0>(A, seg, cnt, slab);
+            else niw_stats_body<NBK, 1>(A, seg, cnt, slab);
+        } else {
+            switch (panel) {
+                case 0: niw_stats_body<NBK, 0>(A, seg, cnt, slab); break;
+                case 1: niw_stats_body<NBK, 1>(A, seg, cnt, slab); break;
+                case 2: niw_stats_body<NBK, 2>(A, seg, cnt, slab); break;
+                default: niw_stats_body<NBK, 3>(A, seg, cnt, slab); break;
+            }
+        }
+    }
+}
+
+// packed row: [0] N, [1..D] sum, [1+D + a(a+1)/2 + b] S[a][b] (a >= b)
+__global__ __launch_bounds__(256) void niw_reduce_kernel(StatsArgs A, int NBK) {
+    const int b = blockIdx.y;
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= A.packed_stride) return;
+    double *out = A.out + (int64_t)b * A.packed_stride;
+    if (!A.sb.bin_sel[b]) { out[e] = 0.; return; }
+    if (e == 0) { out[0] = (double)A.sb.bin_total[b]; return; }
+    const int NPAIR = NBK * (NBK + 1) / 2;
+    int64_t off;
+    if (e <= A.D) {
+        off = (int64_t)NPAIR * 256 + (e - 1);
+    } else {
+        const int64_t te = e - 1 - A.D;
+        int a = (int)((sqrt(8.0 * (double)te + 1.0) - 1.0) * 0.5);
+        while ((int64_t)(a + 1) * (a + 2) / 2 <= te) ++a;
+        while ((int64_t)a * (a + 1) / 2 > te) --a;
+        const int c = (int)(te - (int64_t)a * (a + 1) / 2);
+        int ia = a / NBK, ba = a % NBK, ib = c / NBK, bb = c % NBK;
+        int R, Cc, pa, pb;
+        if (ba >= bb) { pa = ba; pb = bb; R = ia; Cc = ib; }
+        else { pa = bb; pb = ba; R = ib; Cc = ia; }
+        const int pair = pa * (pa + 1) / 2 + pb;
+        const int lane = Cc + 16 * (R & 3);
+        const int r = R >> 2;
+        off = (int64_t)pair * 256 + r * 64 + lane;
+    }
+    double s = 0.;
+    const int i0 = A.sb.item_start[b], i1 = A.sb.item_start[b + 1];
+    for (int it = i0; it < i1; ++it) s += A.slabs[(int64_t)it * A.slab_stride + off];
+    out[e] = s;
+}
+
+int64_t niw_slab_stride(int D) {
+    const int NBK = D <= 16 ? 1 : D <= 32 ? 2 : D <= 64 ? 4 : D <= 128 ? 8 : 16;
+    return niw_slab_stride_nbk(NBK);
+}
+
+static int niw_nbk(int D) { return D <= 16 ? 1 : D <= 32 ? 2 : D <= 64 ? 4 : D <= 128 ? 8 : 16; }
+
+hipError_t launch_niw_stats(const StatsArgs &a, hipStream_t s) {
+    const int NBK = niw_nbk(a.D);
+    const int grid = a.max_items < 1 ? 1 : a.max_items;
+    switch (NBK) {
+        case 1: hipLaunchKernelGGL((niw_stats_kernel<1>), dim3(grid), dim3(64), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((niw_stats_kernel<2>), dim3(grid), dim3(64), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((niw_stats_kernel<4>), dim3(grid), dim3(64), 0, s, a); break;
+        case 8: hipLaunchKernelGGL((niw_stats_kernel<8>), dim3(grid), dim3(128), 0, s, a); break;
+        default: hipLaunchKernelGGL((niw_stats_kernel<16>), dim3(grid), dim3(256), 0, s, a); break;
+    }
+    hipLaunchKernelGGL(niw_reduce_kernel, dim3((unsigned)((a.packed_stride + 255) / 256), a.nbins), dim3(256), 0, s, a, NBK);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------ Multinomial statistics
+// item = (bin, <= chunk points); 256 threads, thread t owns dims t, t+256, ...; Float64 sums
+// (exact for count data; rounded to Float32 by the host as the reference stores them).
+__global__ __launch_bounds__(256) void mult_stats_kernel(StatsArgs A) {
+    const int total_items = A.sb.item_start[A.nbins];
+    for (int item = blockIdx.x; item < total_items; item += gridDim.x) {
+        const int b = find_bin(A.sb.item_start, A.nbins, item);
+        const int j = item - A.sb.item_start[b];
+        const int bcnt = A.sb.bin_total[b];
+        const int seg = A.sb.bin_start[b] + j * A.chunk;
+        const int cnt = min(A.chunk, bcnt - j * A.chunk);
+        double *slab = A.slabs + (int64_t)item * A.slab_stride;
+        for (int d0 = 0; d0 < A.D; d0 += 256 * 4) {
+            double s[4] = {0., 0., 0., 0.};
+            for (int p = 0; p < cnt; ++p) {
+                const float *xp = A.X + (int64_t)A.sb.perm[seg + p] * A.ldx;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int d = d0 + q * 256 + threadIdx.x;
+                    if (d < A.D) s[q] += (double)xp[d];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int d = d0 + q * 256 + threadIdx.x;
+                if (d < A.D) slab[d] = s[q];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void mult_reduce_kernel(StatsArgs A) {
+    const int b = blockIdx.y;
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= A.packed_stride) return;
+    double *out = A.out + (int64_t)b * A.packed_stride;
+    if (!A.sb.bin_sel[b]) { out[e] = 0.; return; }
+    if (e == 0) { out[0] = (double)A.sb.bin_total[b]; return; }
+    double s = 0.;
+    const int i0 = A.sb.item_start[b], i1 = A.sb.item_start[b + 1];
+    for (int it = i0; it < i1; ++it) s += A.slabs[(int64_t)it * A.slab_stride + (e - 1)];
+    out[e] = s;
+}
+
+int64_t mult_slab_stride(int D) { return D; }
+
+hipError_t launch_mult_stats(const StatsArgs &a, hipStream_t s) {
+    const int grid = a.max_items < 1 ? 1 : a.max_items;
+    hipLaunchKernelGGL(mult_stats_kernel, dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(mult_reduce_kernel, dim3((unsigned)((a.packed_stride + 255) / 256), a.nbins), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// second half of the sort (needs the selection mask and the chunk size of the statistics pass)
+hipError_t launch_sort_finish(const int32_t *bins, const StatsArgs &a, hipStream_t s) {
+    const int nt = (int)((a.n + SORT_TILE - 1) / SORT_TILE);
+    hipLaunchKernelGGL(starts_kernel, dim3(1), dim3(256), 0, s, a.sb.bin_total, a.sb.bin_sel, a.nbins, a.chunk,
+                       a.sb.bin_start, a.sb.item_start);
+    if (nt > 0)
+        hipLaunchKernelGGL(scatter_kernel, dim3(nt), dim3(64), a.nbins * sizeof(int), s, bins, a.n, a.nbins, nt,
+                           a.sb.tile_hist, a.sb.bin_start, a.sb.perm);
+    return hipGetLastError();
+}
+
+}  // namespace dpmm

@@ -1,0 +1,161 @@
+/*
+ * dpmm_hip.h -- C ABI of libdpmmhip.so: the MI355X (gfx950) worker path of the
+ * DPMMSubClusters.jl restricted-Gibbs sweep.
+ *
+ * The reference has no FFI; its seam is the set of WORKER functions the master process
+ * invokes through Distributed RPC on each worker's `localpart` of the DArrays.  One
+ * dpmm_ctx == one reference worker == one GPU holding one contiguous column range of the
+ * D x N Float32 data.  Every entry point below names the reference function(s) it stands
+ * in for (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - all functions return 0 on success, a negative DPMM_E* code otherwise;
+ *     dpmm_last_error(ctx) returns a human-readable message for the last failure.
+ *   - the caller owns every host buffer; the library copies in/out and never keeps host
+ *     pointers after the call returns.  The library owns all device memory of the ctx.
+ *   - labels / sub-labels cross the boundary as Int64, 1-based (src/ds.jl:54-55).
+ *   - cluster parameter arrays are ordered (cluster, left, right) per cluster: row 3k+w,
+ *     w = 0 cluster_dist, 1 l_dist, 2 r_dist (src/ds.jl:29-34 thin_cluster_params).
+ *   - one ctx is used from one host thread at a time; calls are stream-ordered in call
+ *     order (the reference relies on per-worker FIFO task order,
+ *     src/local_clusters_actions.jl:65-67,106-108).
+ *   - randomness is counter-based (Philox4x32-10): key = seed, counter = (global point
+ *     index, epoch, stream).  `epoch` is supplied by the caller and must be unique per
+ *     randomised call; results do not depend on how N is sharded over contexts.
+ *   - there is NO CPU fallback: every entry point that computes fails with
+ *     DPMM_ENODEVICE when no gfx950 device is usable.
+ */
+#ifndef DPMM_HIP_H
+#define DPMM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPMM_ABI_VERSION 1
+
+typedef struct dpmm_ctx dpmm_ctx;
+
+enum { DPMM_PRIOR_NIW = 0, DPMM_PRIOR_MULT = 1 };
+
+enum {
+    DPMM_OK = 0,
+    DPMM_EINVAL = -1,    /* bad argument */
+    DPMM_ENODEVICE = -2, /* no usable HIP device */
+    DPMM_EHIP = -3,      /* HIP runtime error (message has the hipError string) */
+    DPMM_ESTATE = -4,    /* call order violated (e.g. sweep before params) */
+    DPMM_ELIMIT = -5     /* K or D beyond what this build supports */
+};
+
+#define DPMM_MAX_CLUSTERS 1024
+#define DPMM_MAX_DIM_NIW 256
+
+int dpmm_abi_version(void);
+
+/* Worker construction: the shard [first_index, first_index + n_local) of the N points.
+ * Replaces: the worker-side state created by `distribute` in init_model_from_data
+ * (src/dp-parallel-sampling.jl:36-53) -- localpart(points), localpart(labels),
+ * localpart(labels_subcluster) -- and Random.seed!(seed) on the worker (:37-39). */
+int dpmm_create(dpmm_ctx **ctx, int prior_kind, int D, int64_t n_local, int64_t first_index,
+                int device, uint64_t seed);
+int dpmm_destroy(dpmm_ctx *ctx);
+const char *dpmm_last_error(const dpmm_ctx *ctx); /* ctx may be NULL: last create error */
+
+/* Points of this shard: X is D x n_local Float32, column-major with leading dimension ldx
+ * (point i = X + i*ldx), host memory.  Replaces distribute(all_data) (dp-parallel-sampling.jl:42-44).
+ * _device: same, but X already lives in device memory of ctx's device (zero-copy hand-over
+ * from a producer on the GPU; copied into the ctx-owned layout on the ctx stream). */
+int dpmm_upload_points(dpmm_ctx *ctx, const float *X, int64_t ldx);
+int dpmm_upload_points_device(dpmm_ctx *ctx, const float *dX, int64_t ldx);
+
+/* labels = rand(1:init_clusters), sub-labels = rand(1:2) (dp-parallel-sampling.jl:49-50). */
+int dpmm_init_labels(dpmm_ctx *ctx, int init_clusters, uint32_t epoch);
+/* Resume / tests: overwrite or read back this shard's labels (Array(group.labels),
+ * dp-parallel-sampling.jl:218,276,371).  Either pointer may be NULL. */
+int dpmm_set_labels(dpmm_ctx *ctx, const int64_t *labels, const int64_t *sub_labels);
+int dpmm_get_labels(dpmm_ctx *ctx, int64_t *labels, int64_t *sub_labels);
+
+/* Cluster parameters for the next sweep.  Replaces broadcast_cluster_params /
+ * set_global_data (local_clusters_actions.jl:518-549): the fields of thin_cluster_params the
+ * workers actually read -- mv_gaussian mu, invSigma, logdetSigma (distributions/mv_gaussian.jl:12-18),
+ * lr_weights, and the mixture weights.
+ *   mu        [3K][D]        inv_sigma [3K][D*D] (symmetric; row/column-major agree)
+ *   logdet    [3K]           lr_weights [K][2]      weights [K]
+ * dpmm_set_params_niw factorises inv_sigma = R'R on the host (compat path, O(K D^3));
+ * dpmm_set_params_niw_chol takes the upper-triangular factor R directly
+ * (row-major [3K][D][D], entries below the diagonal ignored): the quadratic form is
+ * evaluated as ||R (x - mu)||^2. */
+int dpmm_set_params_niw(dpmm_ctx *ctx, int K, const float *mu, const float *inv_sigma, const float *logdet,
+                        const float *lr_weights, const float *weights);
+int dpmm_set_params_niw_chol(dpmm_ctx *ctx, int K, const float *mu, const float *R, const float *logdet,
+                             const float *lr_weights, const float *weights);
+/* multinomial_dist alpha = log-probabilities (distributions/multinomial_dist.jl:8-10): logp [3K][D] */
+int dpmm_set_params_mult(dpmm_ctx *ctx, int K, const float *logp, const float *lr_weights, const float *weights);
+
+/* One label + sub-label sampling pass over the shard.
+ * Replaces sample_labels_worker! (local_clusters_actions.jl:112-134; log_likelihood!
+ * mv_gaussian.jl:21-25 / multinomial_dist.jl:13-15; sample_log_cat_array! utils.jl:19-31)
+ * followed by sample_sub_clusters_worker! / create_subclusters_labels! (:70-95).
+ * final_argmax != 0 selects argmax for the labels (`final`/hard_clustering, :129-130);
+ * sub-labels are always sampled. Asynchronous (stream-ordered). */
+int dpmm_sweep(dpmm_ctx *ctx, uint32_t epoch, int final_argmax);
+
+/* Sufficient statistics of this shard.
+ * Replaces create_suff_stats_dict_worker (local_clusters_actions.jl:149-169) with
+ * create_sufficient_statistics (priors/niw.jl:42-51, priors/multinomial_prior.jl:27-32).
+ * cluster_idx: 1-based cluster ids to compute (NULL => all K, as `indices == nothing`).
+ *
+ * The packed form is what crosses GPUs (one all-reduce(sum) replaces the two-level
+ * reduce of create_suff_stats_dict_node_leader / update_suff_stats_posterior!,
+ * :171-254, aggregate_suff_stats niw.jl:64-66 / multinomial_prior.jl:41-43):
+ *   Float64 [2K][dpmm_packed_stride(ctx)] ; row 2k+s (s=0 left/sub==1, s=1 right/sub==2) =
+ *   { N, sum[0..D-1], S lower triangle row-major (a>=b: S[a][b]) }   (NIW)
+ *   { N, sum[0..D-1] }                                               (Multinomial)
+ * Rows of clusters not listed in cluster_idx are zero.  Cluster-level statistics are
+ * left + right (the reference recomputes them; equal up to Float64 rounding).
+ * dpmm_suffstats_packed_device writes the packed rows into caller-provided DEVICE memory
+ * (stream-ordered; use dpmm_sync before reading from another stream);
+ * dpmm_suffstats_packed copies them to host memory (synchronous). */
+int64_t dpmm_packed_stride(const dpmm_ctx *ctx);
+int dpmm_suffstats_packed_device(dpmm_ctx *ctx, const int64_t *cluster_idx, int n_idx, double *d_out);
+int dpmm_suffstats_packed(dpmm_ctx *ctx, const int64_t *cluster_idx, int n_idx, double *out);
+/* Expand packed rows (after any cross-GPU sum) into the reference's thin_suff_stats shape
+ * (src/ds.jl:37-41), order (cluster, left, right): N [K][3], sum [K][3][D], S [K][3][D][D]
+ * (S symmetric; NULL for Multinomial).  Pure host code. */
+int dpmm_unpack_suffstats(const dpmm_ctx *ctx, int K, const double *packed, double *N, double *sum, double *S);
+
+/* Relabel operations (integer bookkeeping, exact).
+ * dpmm_split:  split_cluster_local_worker! (local_clusters_actions.jl:265-278)
+ * dpmm_merge:  merge_clusters_worker! (:293-304)
+ * dpmm_remove_empty: remove_empty_clusters_worker! (:446-455), pts_count [K]
+ * dpmm_reset_sublabels: reset_bad_clusters_worker! (:481-488); idx == NULL => every point
+ *                       (split_first_cluster_worker!, :257-261)
+ * idx / new_idx are 1-based cluster ids, processed pair by pair in order. */
+int dpmm_split(dpmm_ctx *ctx, const int64_t *idx, const int64_t *new_idx, int n, uint32_t epoch);
+int dpmm_merge(dpmm_ctx *ctx, const int64_t *idx, const int64_t *new_idx, int n);
+int dpmm_remove_empty(dpmm_ctx *ctx, const int64_t *pts_count, int K);
+int dpmm_reset_sublabels(dpmm_ctx *ctx, const int64_t *idx, int n, uint32_t epoch);
+
+/* Diagnostics / parity: run the label phase of the last-set parameters and return the
+ * Float32 table parr[k][i] = loglik_k(x_i) + log w_k WITHOUT the reference's constant
+ * -D*D/2*log(2 pi) normaliser term (mv_gaussian.jl:24; identical for every cluster, so it
+ * never affects a draw; add it back to compare with reference values).  out: [K][n_local]. */
+int dpmm_debug_loglik(dpmm_ctx *ctx, float *out);
+
+/* Block until all queued work of the ctx has completed. */
+int dpmm_sync(dpmm_ctx *ctx);
+/* The HIP stream (hipStream_t) all work of this ctx is queued on, for callers that
+ * want to time with HIP events or order other work against it. */
+void *dpmm_stream(dpmm_ctx *ctx);
+/* Milliseconds spent in the dominant kernels during the last dpmm_sweep /
+ * dpmm_suffstats_* call, measured with HIP events on the ctx stream (0 if none yet).
+ * Calling this synchronises the stream. */
+int dpmm_last_kernel_ms(dpmm_ctx *ctx, float *sweep_ms, float *suffstats_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPMM_HIP_H */

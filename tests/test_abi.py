@@ -1,0 +1,54 @@
+"""CPU-side checks of the drop-in boundary: libdpmmhip.so loads, exports every symbol that
+include/dpmm_hip.h declares, and refuses to work without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from __graft_entry__ import ROOT, load_package
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = load_package()
+    p.build_library()
+    return p
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "dpmm_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dpmm_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree(pkg):
+    from dpmmsubclusters_jl_amd import binding
+    assert declared_functions() == sorted(n for n, _, _ in binding.ABI)
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = ctypes.CDLL(pkg.lib_path())
+    for name in declared_functions():
+        assert hasattr(lib, name), name
+    lib.dpmm_abi_version.restype = ctypes.c_int
+    assert lib.dpmm_abi_version() == 1
+
+
+def test_no_cpu_fallback(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.DpmmError) as e:
+        pkg.Worker(pkg.PRIOR_NIW, 4, 10, device=0)
+    assert e.value.code == -2  # DPMM_ENODEVICE
+
+
+def test_product_never_imports_the_oracle():
+    pkg_dir = os.path.join(ROOT, "dpmmsubclusters.jl_amd")
+    for dp, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+                assert "liboracle" not in txt and "orc_" not in txt, f

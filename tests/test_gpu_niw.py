@@ -1,0 +1,254 @@
+"""GPU parity tests for the NIW worker path: HIP kernels (through the C ABI) vs the CPU oracle on
+the same seeded inputs.  Tolerances (fp32 contraction on the matrix cores vs the oracle's f32/f64):
+  per-point log-lik: atol 2e-3 + rtol 2e-5 against the Float64 evaluation of the same f32 parameters
+  labels under shared uniforms: exact except counted near-boundary flips (< 2e-4 of points, each
+      explained by a CDF margin below 1e-3 of the row mass)
+  draw given the GPU's own table: bit-exact (same exp_det / scan arithmetic)
+  N counts and all relabel bookkeeping: bit-exact; sum x, sum xx' vs Float64 oracle: rtol 1e-12
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    from __graft_entry__ import load_package
+    return load_package()
+
+
+def make_problem(D, n, K, seed, sep=3.0, sorted_points=False):
+    rng = np.random.default_rng(seed)
+    mus = rng.normal(size=(3 * K, D)) * sep
+    for k in range(K):
+        d = rng.normal(size=D) * 0.4
+        mus[3 * k + 1] = mus[3 * k] + d
+        mus[3 * k + 2] = mus[3 * k] - d
+    A = rng.normal(size=(3 * K, D, D)) * (0.3 / np.sqrt(D))
+    Sig = A @ A.transpose(0, 2, 1) + np.eye(D) * (0.5 + rng.random((3 * K, 1, 1)))
+    invS = np.linalg.inv(Sig)
+    invS = 0.5 * (invS + invS.transpose(0, 2, 1))
+    logdet = np.linalg.slogdet(Sig)[1]
+    z = rng.integers(0, K, n)
+    if sorted_points:
+        z.sort()
+    L = np.linalg.cholesky(Sig[3 * z])
+    X = (mus[3 * z] + np.einsum("nij,nj->ni", L, rng.normal(size=(n, D)))).astype(np.float32)
+    w = rng.dirichlet(np.ones(K) * 5).astype(np.float32)
+    lr = rng.dirichlet(np.ones(2) * 5, size=K).astype(np.float32)
+    return dict(D=D, n=n, K=K, X=X, mu=mus.astype(np.float32), invS=invS.reshape(3 * K, -1).astype(np.float32),
+                logdet=logdet.astype(np.float32), w=w, lr=lr, z=z)
+
+
+def gpu_worker(pkg, P, seed, first_index=0):
+    wk = pkg.Worker(pkg.PRIOR_NIW, P["D"], P["n"], first_index=first_index, device=0, seed=seed)
+    wk.upload_points(P["X"])
+    wk.set_params_niw(P["mu"], P["invS"], P["logdet"], P["lr"], P["w"])
+    return wk
+
+
+def table_f64(P):
+    K, n, D = P["K"], P["n"], P["D"]
+    t = np.empty((K, n))
+    for k in range(K):
+        t[k] = orc.niw_loglik_f64(P["X"], D, P["mu"][3 * k], P["invS"][3 * k], P["logdet"][3 * k]) + np.log(np.float64(P["w"][k]))
+    return t
+
+
+@pytest.mark.parametrize("D,n,K", [(2, 1000, 5), (3, 4097, 3), (16, 3000, 4), (20, 2500, 6), (32, 3000, 4),
+                                   (64, 6000, 8), (100, 1500, 3), (128, 2000, 4), (256, 1200, 3)])
+def test_loglik_table(pkg, D, n, K):
+    P = make_problem(D, n, K, seed=D * 7 + K)
+    wk = gpu_worker(pkg, P, seed=1)
+    got = wk.debug_loglik().astype(np.float64)
+    # the GPU table omits the reference's constant -D^2/2 log(2 pi) term (mv_gaussian.jl:24)
+    want = table_f64(P) + 0.5 * D * D * np.log(2 * np.pi)
+    scale = np.abs(want).max(axis=0, keepdims=True)
+    err = np.abs(got - want)
+    assert np.all(err <= 2e-3 + 2e-5 * np.abs(want)), (err.max(), scale.max())
+    # the differences that matter for a draw: relative to the row maximum
+    rel = (got - got.max(0)) - (want - want.max(0))
+    near = (want - want.max(0)) > -30
+    assert np.abs(rel[near]).max() < 5e-3
+    wk.close()
+
+
+@pytest.mark.parametrize("D,n,K,sorted_points", [(2, 5000, 6, False), (64, 20000, 8, False), (64, 20000, 8, True),
+                                                  (32, 9000, 5, False), (128, 4000, 4, False), (256, 2500, 3, True)])
+def test_sweep_labels_vs_oracle(pkg, D, n, K, sorted_points):
+    P = make_problem(D, n, K, seed=11 + D, sep=1.2, sorted_points=sorted_points)
+    seed, epoch, first = 123456789, 5, 1000003
+    wk = gpu_worker(pkg, P, seed=seed, first_index=first)
+    wk.sweep(epoch)
+    lab, sub = wk.get_labels()
+    assert lab.min() >= 1 and lab.max() <= K and set(np.unique(sub)) <= {1, 2}
+    # (1) draw given the GPU's own Float32 table must be bit-exact
+    tab = wk.debug_loglik()
+    u0, u1 = orc.uniforms(seed, epoch, 0, first, n)
+    assert np.array_equal(orc.sample_log_cat(tab, u0), lab)
+    # (2) against the oracle's independent Float32 evaluation: counted near-boundary flips only
+    olab, osub, otab = orc.sweep_niw(P["X"], D, P["mu"], P["invS"], P["logdet"], np.log(P["w"]), np.log(P["lr"]),
+                                     seed=seed, epoch=epoch, first_idx=first, want_parr=True)
+    flips = np.flatnonzero(lab != olab)
+    assert len(flips) <= max(2, int(2e-4 * n)), len(flips)
+    t64 = table_f64(P)
+    p = np.exp(t64 - t64.max(0))
+    cdf = np.cumsum(p, 0) / p.sum(0)
+    for i in flips:  # every flip must sit on a CDF edge
+        assert np.min(np.abs(cdf[:, i] - u0[i])) < 1e-3, (i, u0[i], cdf[:, i])
+    same = lab == olab
+    sflips = int((sub[same] != osub[same]).sum())
+    assert sflips <= max(2, int(5e-4 * n)), sflips
+    # the labels must be informative (not a degenerate draw)
+    assert (lab == P["z"] + 1).mean() > 0.5
+    wk.close()
+
+
+def test_final_argmax(pkg):
+    P = make_problem(64, 7000, 7, seed=3, sep=0.8)
+    wk = gpu_worker(pkg, P, seed=5)
+    wk.sweep(9, final=True)
+    lab, sub = wk.get_labels()
+    tab = wk.debug_loglik()
+    assert np.array_equal(lab, orc.argmax_rows(tab))
+    assert np.array_equal(lab, tab.argmax(0) + 1)
+    assert set(np.unique(sub)) == {1, 2}  # sub-labels are still sampled (local_clusters_actions.jl:83-95)
+    wk.close()
+
+
+def test_shard_invariance(pkg):
+    """RNG counters use the global index: sharding the points over contexts changes nothing."""
+    P = make_problem(64, 9000, 5, seed=21, sep=1.0)
+    wk = gpu_worker(pkg, P, seed=77)
+    wk.sweep(3)
+    lab, sub = wk.get_labels()
+    cut = 4321
+    parts = []
+    for lo, hi in ((0, cut), (cut, P["n"])):
+        Q = dict(P); Q["X"] = np.ascontiguousarray(P["X"][lo:hi]); Q["n"] = hi - lo
+        w2 = gpu_worker(pkg, Q, seed=77, first_index=lo)
+        w2.sweep(3)
+        parts.append(w2.get_labels())
+        w2.close()
+    assert np.array_equal(np.concatenate([p[0] for p in parts]), lab)
+    assert np.array_equal(np.concatenate([p[1] for p in parts]), sub)
+    wk.close()
+
+
+@pytest.mark.parametrize("D,n,K", [(2, 1000, 5), (3, 5000, 4), (16, 4000, 3), (40, 3000, 5), (64, 30000, 8),
+                                   (128, 5000, 4), (200, 3000, 3), (256, 4000, 2)])
+def test_suffstats_vs_oracle(pkg, D, n, K):
+    rng = np.random.default_rng(D + n)
+    X = (rng.normal(size=(n, D)) * 2 + rng.normal(size=D) * 5).astype(np.float32)
+    lab = rng.integers(1, K + 1, n).astype(np.int64)
+    sub = rng.integers(1, 3, n).astype(np.int64)
+    lab[lab == 2] = 1 if K > 2 else 2  # leave one cluster empty when K > 2
+    wk = pkg.Worker(pkg.PRIOR_NIW, D, n, device=0, seed=1)
+    wk.upload_points(X)
+    wk.set_labels(lab, sub)
+    g0, g1 = wk.get_labels()
+    assert np.array_equal(g0, lab) and np.array_equal(g1, sub)
+    wk.K = K
+    # K is taken from the last parameter upload: give it dummy parameters
+    wk.set_params_niw_chol(np.zeros((3 * K, D)), np.tile(np.eye(D).ravel(), (3 * K, 1)), np.zeros(3 * K),
+                           np.full((K, 2), 0.5), np.full(K, 1.0 / K))
+    N, s, S = wk.suffstats()
+    oN, os_, oS = orc.suffstats_niw(X, D, lab, sub, K)
+    assert np.array_equal(N, oN)  # integer counts: exact
+    np.testing.assert_allclose(s, os_, rtol=1e-12, atol=1e-10)
+    np.testing.assert_allclose(S, oS, rtol=1e-12, atol=1e-9)
+    # subset pass (update_suff_stats_posterior!(group, indices), local_clusters_actions.jl:668)
+    idx = [K, 1]
+    pk = wk.suffstats_packed(idx)
+    N2, s2, S2 = wk.unpack(pk)
+    for k in range(K):
+        if k + 1 in idx:
+            assert np.array_equal(N2[k], oN[k]); np.testing.assert_allclose(S2[k], oS[k], rtol=1e-12, atol=1e-9)
+        else:
+            assert not N2[k].any() and not S2[k].any()
+    # run-to-run bitwise reproducibility
+    assert np.array_equal(wk.suffstats_packed(), wk.suffstats_packed())
+    wk.close()
+
+
+def test_suffstats_golden_niw(pkg, golden_dir):
+    """The reference's own checkpoint (examples/save_load_model/checkpoint__50.jld2) as known answer."""
+    g = np.load(f"{golden_dir}/niw_golden.npz")
+    X = np.ascontiguousarray(g["X"], np.float32)
+    wk = pkg.Worker(pkg.PRIOR_NIW, 2, 1000, device=0, seed=1)
+    wk.upload_points(X)
+    wk.set_labels(g["labels"], g["sub"])
+    K = 5
+    wk.set_params_niw_chol(np.zeros((3 * K, 2)), np.tile(np.eye(2).ravel(), (3 * K, 1)), np.zeros(3 * K),
+                           np.full((K, 2), 0.5), np.full(K, 0.2))
+    N, s, S = wk.suffstats()
+    i = 0
+    for k in range(5):
+        for w in range(3):
+            assert N[k, w] == g["counts"][i]
+            np.testing.assert_allclose(s[k, w], g["points_sum"][i], rtol=0, atol=5e-7 * 10 * max(N[k, w], 1))
+            np.testing.assert_allclose(S[k, w], g["S"][i], rtol=2e-6, atol=1e-4)
+            i += 1
+    wk.close()
+
+
+def test_relabel_ops_bit_exact(pkg):
+    rng = np.random.default_rng(9)
+    n, D = 50000, 2
+    X = rng.normal(size=(n, D)).astype(np.float32)
+    seed, first = 42, 777
+    wk = pkg.Worker(pkg.PRIOR_NIW, D, n, first_index=first, device=0, seed=seed)
+    wk.upload_points(X)
+    wk.init_labels(5, epoch=1)
+    lab, sub = wk.get_labels()
+    olab, osub = orc.init_labels(n, 5, seed, 1, first)
+    assert np.array_equal(lab, olab) and np.array_equal(sub, osub)
+    # split (local_clusters_actions.jl:265-278)
+    wk.split([2, 4], [6, 7], epoch=2)
+    orc.split_relabel(olab, osub, [2, 4], [6, 7], seed, 2, first)
+    lab, sub = wk.get_labels()
+    assert np.array_equal(lab, olab) and np.array_equal(sub, osub)
+    # merge (:293-304)
+    wk.merge([1, 3], [5, 6])
+    orc.merge_relabel(olab, osub, [1, 3], [5, 6])
+    lab, sub = wk.get_labels()
+    assert np.array_equal(lab, olab) and np.array_equal(sub, osub)
+    # remove empty (:446-455)
+    cnt = np.bincount(olab, minlength=8)[1:8]
+    assert (cnt == 0).sum() == 2
+    wk.remove_empty(cnt)
+    orc.remove_empty(olab, cnt)
+    lab, sub = wk.get_labels()
+    assert np.array_equal(lab, olab) and np.array_equal(sub, osub) and lab.max() == 5
+    # reset bad clusters (:481-488) and reset all (:257-261)
+    wk.reset_sublabels([2, 5], epoch=3)
+    orc.reset_sub(olab, osub, [2, 5], seed, 3, first)
+    lab, sub = wk.get_labels()
+    assert np.array_equal(sub, osub)
+    wk.reset_sublabels(None, epoch=4)
+    orc.reset_sub(olab, osub, None, seed, 4, first)
+    assert np.array_equal(wk.get_labels()[1], osub)
+    wk.close()
+
+
+def test_error_paths(pkg):
+    with pytest.raises(pkg.DpmmError):
+        pkg.Worker(pkg.PRIOR_NIW, 300, 10, device=0)  # D beyond DPMM_MAX_DIM_NIW
+    with pytest.raises(pkg.DpmmError):
+        pkg.Worker(pkg.PRIOR_NIW, 4, 10, device=99)
+    wk = pkg.Worker(pkg.PRIOR_NIW, 4, 10, device=0)
+    with pytest.raises(pkg.DpmmError):
+        wk.sweep(1)  # no points / params yet
+    wk.close()
+    # empty shard is legal (a worker can own zero columns)
+    wk = pkg.Worker(pkg.PRIOR_NIW, 4, 0, device=0)
+    wk.upload_points(np.zeros((0, 4), np.float32))
+    wk.init_labels(1, 0)
+    wk.set_params_niw_chol(np.zeros((3, 4)), np.tile(np.eye(4).ravel(), (3, 1)), np.zeros(3), np.full((1, 2), 0.5), np.ones(1))
+    wk.sweep(1)
+    N, s, S = wk.suffstats()
+    assert not N.any()
+    wk.close()
