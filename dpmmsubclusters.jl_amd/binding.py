@@ -28,6 +28,7 @@ ABI = [
     ("dpmm_set_params_niw", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p]),
     ("dpmm_set_params_niw_chol", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p]),
     ("dpmm_set_params_mult", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_f32p, _c_f32p, _c_f32p]),
+    ("dpmm_set_num_clusters", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("dpmm_sweep", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int]),
     ("dpmm_packed_stride", ctypes.c_int64, [ctypes.c_void_p]),
     ("dpmm_suffstats_packed_device", ctypes.c_int, [ctypes.c_void_p, _c_i64p, ctypes.c_int, ctypes.c_void_p]),
@@ -166,6 +167,10 @@ class Worker:
         assert logp.shape == (3 * K, self.D) and lr_weights.shape == (K, 2)
         self._chk(self._lib.dpmm_set_params_mult(self._h, K, _p(logp, _c_f32p), _p(lr_weights, _c_f32p), _p(weights, _c_f32p)))
         self.K = K
+
+    def set_num_clusters(self, K):
+        self._chk(self._lib.dpmm_set_num_clusters(self._h, int(K)))
+        self.K = int(K)
 
     # ---- the hot path
     def sweep(self, epoch, final=False):

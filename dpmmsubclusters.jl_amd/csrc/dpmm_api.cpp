@@ -345,6 +345,16 @@ int dpmm_set_params_mult(dpmm_ctx *c, int K, const float *logp, const float *lr,
     return DPMM_OK;
 }
 
+int dpmm_set_num_clusters(dpmm_ctx *c, int K) {
+    if (!c) return DPMM_EINVAL;
+    if (int rc = check_K(c, K)) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = ensure_capacity(c, K)) return rc;
+    if (K != c->K) c->have_params = false;
+    c->K = K;
+    return DPMM_OK;
+}
+
 static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table, int64_t table_stride) {
     if (!c->have_points || !c->have_params) return fail(c, DPMM_ESTATE, "sweep needs points and parameters");
     HIPCHK(c, hipSetDevice(c->device));

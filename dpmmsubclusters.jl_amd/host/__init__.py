@@ -1,0 +1,10 @@
+"""Host side of the sampler (above the C ABI): prior plug-ins, master-side sweep, user API."""
+try:  # numpy's BLAS worker threads spin-wait and starve the OpenMP host maths: keep BLAS single-threaded
+    from threadpoolctl import threadpool_limits as _tpl
+    _blas_limit = _tpl(limits=1, user_api="blas")
+except Exception:  # pragma: no cover
+    _blas_limit = None
+
+from .priors import niw_hyperparams, multinomial_hyper, mv_gaussian, multinomial_dist  # noqa: E402,F401
+from .api import fit, dp_parallel, generate_gaussian_data, generate_mnmm_data, get_labels_histogram, dp_parallel_sampling  # noqa: E402,F401
+from .sampler import DPMMSampler, LocalComm  # noqa: E402,F401

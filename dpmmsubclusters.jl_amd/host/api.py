@@ -1,0 +1,157 @@
+"""Entry points mirroring the reference's user API (src/DPMMSubClusters.jl:36 exports):
+
+    fit(all_data, [hyper_params], alpha; iters, init_clusters, seed, verbose, save_model, burnout,
+        gt, max_clusters, outlier_weight, outlier_params, smart_splits)     dp-parallel-sampling.jl:215-293
+    dp_parallel(all_data, hyper_params, alpha, iters, init_clusters, seed, verbose, save_model,
+        burnout, gt, max_clusters, outlier_weight, outlier_params, smart_splits)          :121-157
+    generate_gaussian_data / generate_mnmm_data   (data_generators.jl:19-72; build-owned recipes)
+
+Argument meaning, defaults, coercions (Float32 data / Int64 iters, :279-293), the default NIW prior
+(kappa=1, m=0, nu=D+3, psi=I, :272-274) and the 9-tuple / 5-tuple results follow the reference.
+`all_data` is Dimensions x Samples (D x N) as in the reference.  Out of scope here (SURVEY.md
+section 8: next rows): save_model / checkpoints, outlier component, smart splits -- passing a
+non-default value for those raises NotImplementedError rather than being silently ignored.
+
+Distributed: when torch.distributed is initialised (one process per GPU) every rank calls `fit`
+with the SAME full arguments; each rank keeps the contiguous column range
+[rank*N/W, (rank+1)*N/W) of the data on its GPU (the DArray layout of `distribute`,
+dp-parallel-sampling.jl:42-50) and the per-sweep exchange is one all-reduce of the packed
+sufficient statistics (host/comm.py).
+"""
+import numpy as np
+
+from .. import binding
+from . import priors as _priors
+from .priors import multinomial_hyper, niw_hyperparams
+from .sampler import DPMMSampler, LocalComm
+
+
+class dp_parallel_sampling:
+    """Result handle (the reference's `dp_parallel_sampling` struct, src/ds.jl:75-78, reduced to what
+    callers use): hyper-parameters, alpha, the sampler with cluster state, and labels."""
+
+    def __init__(self, sampler, labels, sub_labels):
+        self.sampler = sampler
+        self.model_hyperparams = dict(distribution_hyper_params=sampler.prior, alpha=sampler.alpha, total_dim=sampler.n_total)
+        self.labels = labels
+        self.labels_subcluster = sub_labels
+
+    @property
+    def num_clusters(self):
+        return self.sampler.K
+
+
+def _shard(N, comm):
+    lo = (N * comm.rank) // comm.world
+    hi = (N * (comm.rank + 1)) // comm.world
+    return lo, hi
+
+
+def _make_sampler(all_data, hyper, alpha, seed, burnout, max_clusters, comm, device, nthreads=None):
+    X = np.asarray(all_data)
+    if X.ndim != 2:
+        raise ValueError("all_data must be Dimensions x Samples")
+    D, N = X.shape
+    if hyper.dim != D:
+        raise ValueError(f"prior dimension {hyper.dim} != data dimension {D}")
+    lo, hi = _shard(N, comm)
+    Xs = np.ascontiguousarray(X[:, lo:hi].T, dtype=np.float32)  # (n_local, D): row = point
+    if seed is None:
+        seed = int(np.random.SeedSequence().generate_state(1)[0])
+        seed = comm.broadcast_int(seed) if hasattr(comm, "broadcast_int") else seed
+    wk = binding.Worker(hyper.kind, D, hi - lo, first_index=lo, device=device, seed=int(seed))
+    wk.upload_points(Xs)
+    return DPMMSampler(wk, hyper, alpha, N, int(seed), burnout=burnout, max_clusters=max_clusters, comm=comm, nthreads=nthreads)
+
+
+def dp_parallel(all_data, local_hyper_params, alpha_param, iters=100, init_clusters=1, seed=None, verbose=True,
+                save_model=False, burnout=15, gt=None, max_clusters=np.inf, outlier_weight=0, outlier_params=None,
+                smart_splits=False, comm=None, device=None, nthreads=None):
+    """Returns (dp_model, iter_count, nmi_score_history, likelihood_history, cluster_count_history)."""
+    if save_model:
+        raise NotImplementedError("checkpointing is outside this build's scope (SURVEY.md 8f)")
+    if outlier_weight != 0 or outlier_params is not None:
+        raise NotImplementedError("outlier component is outside this build's scope (SURVEY.md 8f)")
+    if smart_splits:
+        raise NotImplementedError("smart splits are outside this build's scope (SURVEY.md 8f)")
+    if not isinstance(local_hyper_params, _priors.distribution_hyper_params):
+        raise TypeError("local_hyper_params must be a distribution_hyper_params (niw_hyperparams / multinomial_hyper)")
+    if comm is None:
+        from .comm import default_comm
+        comm = default_comm()
+    if device is None:
+        device = getattr(comm, "device", 0)
+    s = _make_sampler(all_data, local_hyper_params, np.float32(alpha_param), seed, int(burnout), max_clusters, comm, device, nthreads)
+    s.init_first_clusters(int(init_clusters))
+    iter_count, nmi, lik, kh = s.run_model(int(iters), 1, verbose=verbose, gt=gt)
+    labels, sub = comm.gather_labels(s.wk)
+    return dp_parallel_sampling(s, labels, sub), iter_count, nmi, lik, kh
+
+
+def fit(all_data, *args, iters=100, init_clusters=1, seed=None, verbose=True, save_model=False, burnout=20, gt=None,
+        max_clusters=np.inf, outlier_weight=0, outlier_params=None, smart_splits=False, **kw):
+    """fit(all_data, alpha; ...) or fit(all_data, hyper_params, alpha; ...).
+
+    Returns the reference's 9-tuple: (labels, clusters, weights, iter_count, nmi_score_history,
+    likelihood_history, cluster_count_history, sub_labels, dp_model)."""
+    if len(args) == 1:
+        D = np.asarray(all_data).shape[0]
+        hyper = niw_hyperparams(1.0, np.zeros(D), D + 3, np.eye(D))   # dp-parallel-sampling.jl:272-274
+        alpha = args[0]
+    elif len(args) == 2:
+        hyper, alpha = args
+    else:
+        raise TypeError("fit(all_data, alpha; ...) or fit(all_data, hyper_params, alpha; ...)")
+    dp_model, iter_count, nmi, lik, kh = dp_parallel(all_data, hyper, alpha, int(iters), int(init_clusters), seed, verbose,
+                                                     save_model, burnout, gt, max_clusters, outlier_weight, outlier_params,
+                                                     smart_splits, **kw)
+    s = dp_model.sampler
+    clusters = s.prior.distributions(s.params, [3 * k for k in range(s.K)])
+    return (dp_model.labels, clusters, s.weights.copy(), iter_count, nmi, lik, kh, dp_model.labels_subcluster, dp_model)
+
+
+def get_labels_histogram(labels):
+    """utils.jl:39-48: sorted [(label, count)]"""
+    v, c = np.unique(np.asarray(labels), return_counts=True)
+    return list(zip(v.tolist(), c.tolist()))
+
+
+# ----------------------------------------------------------------------------- synthetic inputs
+def generate_gaussian_data(N, D, K, MixtureVar, seed=None):
+    """Recipe of data_generators.jl:19-42: pi ~ Dir(1_K); counts ~ Multinomial(N, pi); mu_k ~ N(0, MixtureVar I);
+    Sigma_k ~ InvWishart(D+2, I); points of a component contiguous.  Returns (x D x N f32, labels, means D x K, covs D x D x K)."""
+    rng = np.random.default_rng(seed)
+    tpi = rng.dirichlet(np.ones(K))
+    tzn = rng.multinomial(N, tpi)
+    x = np.empty((D, N), np.float32)
+    tz = np.empty(N, np.float32)
+    tmean = np.zeros((D, K), np.float32); tcov = np.zeros((D, D, K), np.float32)
+    ind = 0
+    for i in range(K):
+        tmean[:, i] = rng.normal(size=D) * np.sqrt(MixtureVar)
+        # InvWishart(D+2, I): inverse of a Wishart(D+2, I) draw
+        G = rng.normal(size=(D + 2, D))
+        cov = np.linalg.inv(G.T @ G)
+        tcov[:, :, i] = cov
+        L = np.linalg.cholesky(cov)
+        n = tzn[i]
+        x[:, ind:ind + n] = (tmean[:, i][:, None] + L @ rng.normal(size=(D, n))).astype(np.float32)
+        tz[ind:ind + n] = i + 1
+        ind += n
+    return x, tz, tmean, tcov
+
+
+def generate_mnmm_data(N, D, K, trials, seed=None):
+    """Recipe of data_generators.jl:59-72. Returns (x D x N f32 counts, labels, clusters D x K)."""
+    rng = np.random.default_rng(seed)
+    clusters = np.zeros((D, K))
+    labels = rng.integers(1, K + 1, N)
+    for i in range(K):
+        alphas = rng.integers(1, 21, D).astype(float)
+        alphas[i % D] = rng.integers(30, 101)
+        clusters[:, i] = rng.dirichlet(alphas)
+    x = np.empty((D, N), np.float32)
+    for i in range(K):
+        m = labels == i + 1
+        x[:, m] = rng.multinomial(trials, clusters[:, i], size=int(m.sum())).T
+    return x, labels, clusters

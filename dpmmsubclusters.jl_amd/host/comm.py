@@ -1,0 +1,65 @@
+"""Cross-GPU exchange of the sweep: ONE all-reduce(sum) of the packed sufficient statistics.
+
+Replaces the reference's two-level tree reduce of `thin_suff_stats` dicts
+(create_suff_stats_dict_node_leader / update_suff_stats_posterior!,
+src/local_clusters_actions.jl:171-254; aggregate_suff_stats, priors/niw.jl:64-66,
+priors/multinomial_prior.jl:41-43).  One process per GPU; torch.distributed is used as plumbing
+only (backend "nccl" == RCCL over xGMI on the GPU box; "gloo" in the CPU tests).
+N counts travel as Float64 integers (exact below 2^53), so one dtype, one collective.
+"""
+import os
+
+import numpy as np
+
+from .sampler import LocalComm
+
+
+class TorchDistComm:
+    def __init__(self, device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.backend = dist.get_backend()
+        self.device = int(os.environ.get("LOCAL_RANK", 0)) if device is None else device
+        self._buf = None
+
+    def _buffer(self, n):
+        t = self.torch
+        if self._buf is None or self._buf.numel() < n:
+            dev = f"cuda:{self.device}" if self.backend == "nccl" else "cpu"
+            self._buf = t.empty(n, dtype=t.float64, device=dev)
+        return self._buf[:n]
+
+    def reduce_stats(self, worker, idx):
+        n = 2 * worker.K * worker.packed_stride
+        buf = self._buffer(n)
+        if self.backend == "nccl":
+            worker.suffstats_packed_device(buf.data_ptr(), idx)   # stream-synchronised inside
+            self.dist.all_reduce(buf)
+            return buf.cpu().numpy().reshape(2 * worker.K, worker.packed_stride)
+        local = worker.suffstats_packed(idx)
+        buf.copy_(self.torch.from_numpy(local.ravel()))
+        self.dist.all_reduce(buf)
+        return buf.numpy().reshape(2 * worker.K, worker.packed_stride).copy()
+
+    def gather_labels(self, worker):
+        lab, sub = worker.get_labels()
+        objs = [None] * self.world
+        self.dist.all_gather_object(objs, (lab, sub))
+        return np.concatenate([o[0] for o in objs]), np.concatenate([o[1] for o in objs])
+
+    def broadcast_int(self, v):
+        obj = [int(v)]
+        self.dist.broadcast_object_list(obj, src=0)
+        return obj[0]
+
+
+def default_comm():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return TorchDistComm()
+    except ImportError:
+        pass
+    return LocalComm()

@@ -1,0 +1,305 @@
+// dpmm_host.cpp -- native host-side maths of the sampler (libdpmmhost.so, plain C++/OpenMP).
+//
+// north_star keeps "posterior cluster-parameter draws and split/merge Metropolis steps" on the
+// host; at K ~ 32, D = 64..256 these are 3K dense D x D factorisations per sweep and would
+// dominate a ~1.5 ms GPU sweep if left to an interpreter, so they are native and threaded over
+// clusters.  Reference functions restated (paths relative to the reference checkout):
+//   calc_posterior          src/priors/niw.jl:20-31
+//   sample_distribution     src/priors/niw.jl:34-40   (Sigma ~ InvWishart(nu, nu psi), mu ~ N(m, Sigma/kappa))
+//   log_marginal_likelihood src/priors/niw.jl:53-62   (only the logdet(psi) terms are computed here)
+//   sample_distribution     src/priors/multinomial_prior.jl:23-25 (log of a Dirichlet draw)
+//
+// Sampling without ever forming Sigma: with Psi = nu psi = U U' (U upper triangular, "reverse"
+// Cholesky) and A lower-triangular Bartlett (A_ii^2 ~ chi2(nu - i), A_ij ~ N(0,1), i > j),
+//   Sigma^-1 = W = (U^-T A)(U^-T A)' ~ Wishart(nu, Psi^-1),   R := A' U^-1  (upper),  W = R'R
+// so the GPU's factor R comes out of one triangular solve, logdet Sigma = -2 sum log R_ii, and
+// mu = m + R^-1 xi / sqrt(kappa).  Randomness: Philox4x32-10 keyed by (seed; draw id, epoch),
+// so results do not depend on thread count or batch composition (all ranks of a multi-GPU run
+// draw identical parameters from identical all-reduced statistics).
+#include <math.h>
+#include <omp.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#define HAPI extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+struct Philox {
+    uint32_t key[2];
+    uint32_t ctr[4];
+    uint32_t out[4];
+    int have = 0;
+    double spare = 0.0;
+    bool has_spare = false;
+    Philox(uint64_t seed, uint32_t id, uint32_t epoch, uint32_t stream) {
+        key[0] = (uint32_t)seed; key[1] = (uint32_t)(seed >> 32);
+        ctr[0] = 0; ctr[1] = id; ctr[2] = epoch; ctr[3] = stream;
+    }
+    void refill() {
+        uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+        for (int r = 0; r < 10; ++r) {
+            const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+            const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+            c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        }
+        out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+        ctr[0] += 1;  // 2^32 blocks per (id, epoch, stream): ample
+        have = 4;
+    }
+    uint32_t u32() { if (!have) refill(); return out[--have]; }
+    double uniform() {  // (0,1), 53 bits
+        const uint64_t a = u32(), b = u32();
+        return ((double)(((a << 32) | b) >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+    }
+    double normal() {
+        if (has_spare) { has_spare = false; return spare; }
+        const double u1 = uniform(), u2 = uniform();
+        const double r = sqrt(-2.0 * log(u1));
+        double s, c;
+        sincos(6.283185307179586476925 * u2, &s, &c);
+        spare = r * s; has_spare = true;
+        return r * c;
+    }
+    double gamma(double a) {  // Marsaglia-Tsang, shape a > 0, scale 1
+        if (a < 1.0) {
+            const double u = uniform();
+            return gamma(a + 1.0) * pow(u, 1.0 / a);
+        }
+        const double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+        for (;;) {
+            double x, v;
+            do { x = normal(); v = 1.0 + c * x; } while (v <= 0.0);
+            v = v * v * v;
+            const double u = uniform();
+            if (u < 1.0 - 0.0331 * x * x * x * x) return d * v;
+            if (log(u) < 0.5 * x * x + d * (1.0 - v + log(v))) return d * v;
+        }
+    }
+};
+
+// Psi (row-major, symmetric, D x D) = U U', U upper triangular (row-major, zeros below the diagonal).
+// Returns false when Psi is not positive definite.
+bool reverse_cholesky(const double *P, int D, double *U) {
+    memset(U, 0, sizeof(double) * (size_t)D * D);
+    for (int j = D - 1; j >= 0; --j) {
+        double s = P[(size_t)j * D + j];
+        const double *uj = U + (size_t)j * D;
+        for (int k = j + 1; k < D; ++k) s -= uj[k] * uj[k];
+        if (!(s > 0.0)) return false;
+        const double ujj = sqrt(s);
+        U[(size_t)j * D + j] = ujj;
+        const double inv = 1.0 / ujj;
+        for (int i = 0; i < j; ++i) {
+            double t = P[(size_t)i * D + j];
+            const double *ui = U + (size_t)i * D;
+            for (int k = j + 1; k < D; ++k) t -= ui[k] * uj[k];
+            U[(size_t)i * D + j] = t * inv;
+        }
+    }
+    return true;
+}
+
+// priors/niw.jl:20-31 for one statistic set; psi_out symmetric.  N == 0 -> prior.
+void niw_posterior_one(int D, double k0, double v0, const double *m0, const double *psi0, double N, const double *sum,
+                       const double *S, double *kap, double *nu, double *m, double *psi) {
+    if (N == 0.0) {
+        *kap = k0; *nu = v0;
+        memcpy(m, m0, sizeof(double) * D);
+        memcpy(psi, psi0, sizeof(double) * (size_t)D * D);
+        return;
+    }
+    const double k1 = k0 + N, v1 = v0 + N;
+    *kap = k1; *nu = v1;
+    for (int a = 0; a < D; ++a) m[a] = (m0[a] * k0 + sum[a]) / k1;
+    for (int a = 0; a < D; ++a)
+        for (int b = 0; b <= a; ++b) {
+            const double sab = 0.5 * (S[(size_t)a * D + b] + S[(size_t)b * D + a]);
+            const double pab = 0.5 * (psi0[(size_t)a * D + b] + psi0[(size_t)b * D + a]);
+            const double v = (v0 * pab + k0 * m0[a] * m0[b] - k1 * m[a] * m[b] + sab) / v1;
+            psi[(size_t)a * D + b] = v;
+            psi[(size_t)b * D + a] = v;
+        }
+}
+
+}  // namespace
+
+// Batch posterior + factorisation.  Outputs: kappa[n], nu[n], m[n][D], psi[n][D*D] (may be NULL),
+// U[n][D*D] with nu*psi = U U' (may be NULL), logdet_psi[n] (NaN when psi is not positive definite).
+HAPI int dpmmh_niw_posterior(int n, int D, double kappa0, double nu0, const double *m0, const double *psi0,
+                             const double *N, const double *sum, const double *S, double *kappa, double *nu, double *m,
+                             double *psi, double *U, double *logdet_psi, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+    {
+        std::vector<double> P((size_t)D * D), Ul((size_t)D * D), pl((size_t)D * D);
+#pragma omp for schedule(dynamic, 1)
+        for (int i = 0; i < n; ++i) {
+            double *pp = psi ? psi + (size_t)i * D * D : pl.data();
+            niw_posterior_one(D, kappa0, nu0, m0, psi0, N[i], sum + (size_t)i * D, S + (size_t)i * D * D, &kappa[i], &nu[i],
+                              m + (size_t)i * D, pp);
+            for (size_t e = 0; e < (size_t)D * D; ++e) P[e] = pp[e] * nu[i];
+            double *Uo = U ? U + (size_t)i * D * D : Ul.data();
+            if (reverse_cholesky(P.data(), D, Uo)) {
+                double ld = 0.0;
+                for (int d = 0; d < D; ++d) ld += log(Uo[(size_t)d * D + d]);
+                logdet_psi[i] = 2.0 * ld - D * log(nu[i]);
+            } else {
+                logdet_psi[i] = NAN;
+            }
+        }
+    }
+    return 0;
+}
+
+// logdet(psi') of the posterior for the MERGED statistics of cluster pairs (shared_actions.jl:21-38 needs
+// log_marginal_likelihood of the pooled cluster).  pairs[2p], pairs[2p+1] index rows of N/sum/S.
+HAPI int dpmmh_niw_logdet_pairs(int npairs, const int32_t *pairs, int D, double kappa0, double nu0, const double *m0,
+                                const double *psi0, const double *N, const double *sum, const double *S,
+                                double *logdet_psi, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+    {
+        std::vector<double> Sm((size_t)D * D), sm(D), mm(D), P((size_t)D * D), Ul((size_t)D * D);
+#pragma omp for schedule(dynamic, 4)
+        for (int p = 0; p < npairs; ++p) {
+            const int a = pairs[2 * p], b = pairs[2 * p + 1];
+            const double *Sa = S + (size_t)a * D * D, *Sb = S + (size_t)b * D * D;
+            for (size_t e = 0; e < (size_t)D * D; ++e) Sm[e] = Sa[e] + Sb[e];
+            for (int d = 0; d < D; ++d) sm[d] = sum[(size_t)a * D + d] + sum[(size_t)b * D + d];
+            double kap, nu;
+            niw_posterior_one(D, kappa0, nu0, m0, psi0, N[a] + N[b], sm.data(), Sm.data(), &kap, &nu, mm.data(), P.data());
+            for (size_t e = 0; e < (size_t)D * D; ++e) P[e] *= nu;
+            if (reverse_cholesky(P.data(), D, Ul.data())) {
+                double ld = 0.0;
+                for (int d = 0; d < D; ++d) ld += log(Ul[(size_t)d * D + d]);
+                logdet_psi[p] = 2.0 * ld - D * log(nu);
+            } else {
+                logdet_psi[p] = NAN;
+            }
+        }
+    }
+    return 0;
+}
+
+// Draw (mu, R, logdet Sigma) for n prepared posteriors.  ids[i] keys the random stream of draw i.
+// want_sigma: also return Sigma (Float32 [n][D*D]) -- only needed for the user-facing result of fit().
+HAPI int dpmmh_niw_sample(int n, int D, const double *kappa, const double *nu, const double *m, const double *U,
+                          uint64_t seed, uint32_t epoch, const int32_t *ids, float *mu, float *R, float *logdet_sigma,
+                          int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+    {
+        std::vector<double> A((size_t)D * D), Rl((size_t)D * D), a(D), xi(D), v(D);
+#pragma omp for schedule(dynamic, 1)
+        for (int i = 0; i < n; ++i) {
+            Philox rng(seed, (uint32_t)ids[i], epoch, 16u);
+            const double *Ui = U + (size_t)i * D * D;
+            // Bartlett factor, lower triangular (column-major access below: A[r][c], r >= c)
+            for (int r = 0; r < D; ++r) {
+                for (int c = 0; c < r; ++c) A[(size_t)r * D + c] = rng.normal();
+                A[(size_t)r * D + r] = sqrt(2.0 * rng.gamma(0.5 * (nu[i] - r)));
+            }
+            // R = A' U^-1 : row j of R solves r_j U[j:, j:] = A[j:, j]'
+            memset(Rl.data(), 0, sizeof(double) * (size_t)D * D);
+            double ld = 0.0;
+            for (int j = 0; j < D; ++j) {
+                for (int r = j; r < D; ++r) a[r] = A[(size_t)r * D + j];
+                double *rj = Rl.data() + (size_t)j * D;
+                for (int c = j; c < D; ++c) {
+                    const double *uc = Ui + (size_t)c * D;
+                    const double val = a[c] / uc[c];
+                    rj[c] = val;
+                    for (int cc = c + 1; cc < D; ++cc) a[cc] -= val * uc[cc];
+                }
+                ld += log(rj[j]);
+            }
+            logdet_sigma[i] = (float)(-2.0 * ld);
+            // mu = m + R^-1 xi / sqrt(kappa)
+            for (int d = 0; d < D; ++d) xi[d] = rng.normal();
+            for (int r = D - 1; r >= 0; --r) {
+                double s = xi[r];
+                const double *rr = Rl.data() + (size_t)r * D;
+                for (int c = r + 1; c < D; ++c) s -= rr[c] * v[c];
+                v[r] = s / rr[r];
+            }
+            const double isk = 1.0 / sqrt(kappa[i]);
+            for (int d = 0; d < D; ++d) mu[(size_t)i * D + d] = (float)(m[(size_t)i * D + d] + v[d] * isk);
+            float *Ro = R + (size_t)i * D * D;
+            for (size_t e = 0; e < (size_t)D * D; ++e) Ro[e] = (float)Rl[e];
+        }
+    }
+    return 0;
+}
+
+// Sigma^-1 = R'R and Sigma = (R'R)^-1 in Float64 from the Float32 factor (user-facing mv_gaussian
+// fields of the fit() result, distributions/mv_gaussian.jl:12-18; never used on the hot path).
+HAPI int dpmmh_niw_expand(int n, int D, const float *R, double *inv_sigma, double *sigma, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+    for (int i = 0; i < n; ++i) {
+        const float *Ri = R + (size_t)i * D * D;
+        double *W = inv_sigma + (size_t)i * D * D;
+        for (int a = 0; a < D; ++a)
+            for (int b = 0; b <= a; ++b) {
+                double s = 0.0;
+                for (int k = 0; k <= b; ++k) s += (double)Ri[(size_t)k * D + a] * (double)Ri[(size_t)k * D + b];
+                W[(size_t)a * D + b] = W[(size_t)b * D + a] = s;
+            }
+        if (sigma) {
+            // Sigma = R^-1 R^-T : invert the upper-triangular factor, then multiply
+            std::vector<double> Ri64((size_t)D * D, 0.0), Inv((size_t)D * D, 0.0);
+            for (size_t e = 0; e < (size_t)D * D; ++e) Ri64[e] = Ri[e];
+            for (int c = 0; c < D; ++c) {  // column c of R^-1
+                for (int r = c; r >= 0; --r) {
+                    double s = (r == c) ? 1.0 : 0.0;
+                    for (int k = r + 1; k <= c; ++k) s -= Ri64[(size_t)r * D + k] * Inv[(size_t)k * D + c];
+                    Inv[(size_t)r * D + c] = s / Ri64[(size_t)r * D + r];
+                }
+            }
+            double *Sg = sigma + (size_t)i * D * D;
+            for (int a = 0; a < D; ++a)
+                for (int b = 0; b <= a; ++b) {
+                    double s = 0.0;
+                    for (int k = a; k < D; ++k) s += Inv[(size_t)a * D + k] * Inv[(size_t)b * D + k];
+                    Sg[(size_t)a * D + b] = Sg[(size_t)b * D + a] = s;
+                }
+        }
+    }
+    return 0;
+}
+
+// log of Dirichlet(alpha) draws (priors/multinomial_prior.jl:23-25): logp[i][d] = log(g_d / sum g), g_d ~ Gamma(alpha_d)
+HAPI int dpmmh_dirichlet_log(int n, int D, const float *alpha, uint64_t seed, uint32_t epoch, const int32_t *ids,
+                             float *logp, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+    {
+        std::vector<double> lg(D);
+#pragma omp for schedule(dynamic, 1)
+        for (int i = 0; i < n; ++i) {
+            Philox rng(seed, (uint32_t)ids[i], epoch, 17u);
+            const float *al = alpha + (size_t)i * D;
+            // work with log-gammas so that tiny shapes do not underflow: log g = log Gamma(a+1) draw + log(u)/a
+            double mx = -INFINITY;
+            for (int d = 0; d < D; ++d) {
+                const double a = (double)al[d];
+                double l;
+                if (a < 1.0) l = log(rng.gamma(a + 1.0)) + log(rng.uniform()) / a;
+                else l = log(rng.gamma(a));
+                lg[d] = l;
+                if (l > mx) mx = l;
+            }
+            double s = 0.0;
+            for (int d = 0; d < D; ++d) s += exp(lg[d] - mx);
+            const double lse = mx + log(s);
+            for (int d = 0; d < D; ++d) logp[(size_t)i * D + d] = (float)(lg[d] - lse);
+        }
+    }
+    return 0;
+}
+
+HAPI int dpmmh_max_threads(void) { return omp_get_max_threads(); }

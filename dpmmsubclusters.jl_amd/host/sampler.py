@@ -1,0 +1,367 @@
+"""Master-side sampler: the host half of one restricted-Gibbs sweep.
+
+Restates, over struct-of-arrays cluster state and the GPU `Worker` (one per rank), the
+master-process functions of the reference (paths relative to the reference checkout):
+
+    group_step                          src/local_clusters_actions.jl:658-673
+    sample_clusters!                    src/local_clusters_actions.jl:417-437
+    sample_cluster_params               src/shared_actions.jl:41-66   (burn-in gate :51-63)
+    update_suff_stats_posterior!        src/local_clusters_actions.jl:206-254
+    reset_bad_clusters!                 src/local_clusters_actions.jl:501-516
+    check_and_split! / should_split_local! / split_cluster_local!   :345-382, :318-343, :280-291
+    check_and_merge! / should_merge! / merge_clusters!              :385-413, shared_actions.jl:21-38, :308-315
+    remove_empty_clusters!              src/local_clusters_actions.jl:457-471
+    init_first_clusters!                src/dp-parallel-sampling.jl:62-78
+    run_model / calculate_posterior     src/dp-parallel-sampling.jl:336-404, :458-470
+
+Cluster k occupies rows 3k (cluster), 3k+1 (left), 3k+2 (right) of every per-distribution array.
+In a multi-GPU run every rank executes this file redundantly on identical all-reduced statistics
+with identical counter-based randomness, so no parameter broadcast is needed (the reference's
+broadcast_cluster_params, :518-549, becomes a local H2D copy on every rank).
+"""
+import time
+
+import numpy as np
+from scipy.special import gammaln
+
+# schedule constants that `fit` cannot change (src/global_params.jl:10-11)
+ARGMAX_SAMPLE_STOP = 5
+SPLIT_STOP = 5
+
+
+class LocalComm:
+    """Single process, single GPU: the statistics come straight off the device."""
+    rank, world = 0, 1
+
+    def reduce_stats(self, worker, idx):
+        return worker.suffstats_packed(idx)
+
+    def gather_labels(self, worker):
+        return worker.get_labels()
+
+
+class DPMMSampler:
+    def __init__(self, worker, prior, alpha, n_total, seed, burnout=20, max_clusters=np.inf, comm=None,
+                 argmax_sample_stop=ARGMAX_SAMPLE_STOP, split_stop=SPLIT_STOP, nthreads=None):
+        self.wk = worker
+        self.prior = prior
+        self.alpha = float(np.float32(alpha))
+        self.n_total = int(n_total)
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.burnout = int(burnout)
+        self.max_clusters = max_clusters
+        self.comm = comm or LocalComm()
+        self.argmax_sample_stop = argmax_sample_stop
+        self.split_stop = split_stop
+        self.nthreads = nthreads
+        self.rng = np.random.Generator(np.random.Philox(key=self.seed))
+        self.epoch = 0
+        self.K = 0
+        self.timers = {}
+
+    # ------------------------------------------------------------------ small helpers
+    def _next_epoch(self):
+        self.epoch += 1
+        return self.epoch
+
+    def _tic(self, name, t0):
+        self.timers[name] = self.timers.get(name, 0.0) + (time.perf_counter() - t0)
+
+    def _dirichlet(self, a):
+        g = self.rng.standard_gamma(np.asarray(a, np.float64))
+        return g / g.sum(-1, keepdims=True)
+
+    def _rows(self, ks):
+        ks = np.asarray(ks, np.int64)
+        return (3 * ks[:, None] + np.arange(3)[None, :]).ravel()
+
+    def _alloc(self, K):
+        D = self.prior.dim
+        self.K = K
+        st = self.prior.empty_stats(3 * K)
+        self.N = st["N"].reshape(K, 3); self.sums = st["sums"].reshape(K, 3, D)
+        self.S = st["S"].reshape(K, 3, D, D) if st["S"] is not None else None
+        self.post = None
+        self.params = None
+        self.lr_weights = np.full((K, 2), 0.5, np.float32)
+        self.weights = np.full(K, 1.0 / K, np.float32)
+        self.splittable = np.zeros(K, bool)
+        self.hist = np.full((K, self.burnout + 5), -np.inf, np.float32)
+        self.points_count = np.zeros(K, np.int64)
+
+    def _set_post_rows(self, rows, post):
+        if self.post is None:
+            self.post = {k: np.array(v) for k, v in post.items()}
+            return
+        for k, v in post.items():
+            self.post[k][rows] = v
+
+    def _stats_flat(self):
+        K, D = self.K, self.prior.dim
+        return self.N.reshape(3 * K), self.sums.reshape(3 * K, D), (self.S.reshape(3 * K, D, D) if self.S is not None else None)
+
+    # ------------------------------------------------------------------ statistics (step 5)
+    def update_suff_stats_posterior(self, ks=None):
+        """ks: 0-based cluster ids (None = all).  One GPU statistics pass + (multi-GPU) one all-reduce."""
+        if ks is not None and len(ks) == 0:
+            return
+        t0 = time.perf_counter()
+        idx = None if ks is None else (np.asarray(ks, np.int64) + 1)
+        packed = self.comm.reduce_stats(self.wk, idx)
+        self._tic("stats_gpu", t0)
+        t0 = time.perf_counter()
+        un = self.wk.unpack(packed, self.K)
+        N, sums = un[0], un[1]
+        S = un[2] if len(un) > 2 else None
+        sel = np.arange(self.K) if ks is None else np.asarray(ks, np.int64)
+        self.N[sel] = N[sel]; self.sums[sel] = sums[sel]
+        if S is not None:
+            self.S[sel] = S[sel]
+        self.points_count[sel] = np.rint(N[sel, 0]).astype(np.int64)
+        rows = self._rows(sel)
+        Nf, sf, Sf = self._stats_flat()
+        post = self.prior.posterior(Nf[rows], sf[rows], Sf[rows] if Sf is not None else None, nthreads=self.nthreads)
+        if ks is None:
+            self.post = post
+        else:
+            self._set_post_rows(rows, post)
+        self._tic("posterior_host", t0)
+
+    # ------------------------------------------------------------------ step 1
+    def sample_clusters(self):
+        t0 = time.perf_counter()
+        K = self.K
+        self.params = self.prior.sample(self.post, self.seed, self._next_epoch(), np.arange(3 * K), nthreads=self.nthreads)
+        self._tic("sample_params_host", t0)
+        t0 = time.perf_counter()
+        half = self.alpha / 2
+        self.lr_weights = self._dirichlet(self.N[:, 1:3] + half).astype(np.float32)
+        L = self.prior.log_marginal(self.post, self.N.reshape(3 * K)).reshape(K, 3)
+        b = self.burnout
+        self.hist[:, : b - 1] = self.hist[:, 1:b]
+        with np.errstate(invalid="ignore", over="ignore"):
+            self.hist[:, b - 1] = (L[:, 1] + L[:, 2]).astype(np.float32)
+            now = (self.hist[:, :b].astype(np.float64) * (1.0 / (b - 0.1))).sum(1)
+            gate = (now != -np.inf) & ((now - self.hist[:, b - 1]) < 1e-2)
+        self.splittable |= gate
+        w = self._dirichlet(np.concatenate([self.N[:, 0], [self.alpha]]))
+        self.weights = w[:K].astype(np.float32)
+        self._tic("host_misc", t0)
+
+    # ------------------------------------------------------------------ step 6
+    def reset_bad_clusters(self):
+        bad = np.flatnonzero((self.N[:, 1] == 0) | (self.N[:, 2] == 0))
+        if len(bad) == 0:
+            return
+        self.hist[bad] = -np.inf
+        self.splittable[bad] = False
+        self.wk.reset_sublabels(bad + 1, self._next_epoch())
+        self.update_suff_stats_posterior(bad)
+
+    # ------------------------------------------------------------------ step 7a
+    def check_and_split(self, final):
+        K = self.K
+        if final:
+            return np.zeros(0, np.int64)
+        cand = np.flatnonzero(self.splittable & (self.N[:, 0] > 1) & (self.N[:, 1] > 0) & (self.N[:, 2] > 0))
+        if len(cand) == 0:
+            return np.zeros(0, np.int64)
+        L = self.prior.log_marginal(self.post, self.N.reshape(3 * K)).reshape(K, 3)
+        Nc, Nl, Nr = self.N[cand, 0], self.N[cand, 1], self.N[cand, 2]
+        log_hr = np.log(self.alpha) + gammaln(Nl) + L[cand, 1] + gammaln(Nr) + L[cand, 2] - (gammaln(Nc) + L[cand, 0])
+        u = self.rng.random(len(cand))
+        with np.errstate(divide="ignore"):
+            acc = cand[log_hr > np.log(u)]
+        if len(acc) == 0:
+            return np.zeros(0, np.int64)
+        new = K + np.arange(len(acc))
+        self._grow(K + len(acc))
+        for i, j in zip(acc, new):      # split_cluster_local!: old <- left, new <- right
+            ri, rj = 3 * i, 3 * j
+            self._copy_row(rj, ri + 2); self._copy_row(rj + 1, rj); self._copy_row(rj + 2, rj)
+            self._copy_row(ri, ri + 1); self._copy_row(ri + 1, ri); self._copy_row(ri + 2, ri)
+            for k in (i, j):
+                self.lr_weights[k] = self._dirichlet([self.alpha / 2, self.alpha / 2]).astype(np.float32)
+                self.splittable[k] = False
+                self.hist[k] = -np.inf
+                self.points_count[k] = int(round(self.N[k, 0]))
+        self.wk.set_num_clusters(self.K)
+        self.wk.split(acc + 1, new + 1, self._next_epoch())
+        return np.concatenate([acc, new])
+
+    def _grow(self, K2):
+        K, D = self.K, self.prior.dim
+        add = K2 - K
+        self.N = np.concatenate([self.N, np.zeros((add, 3))])
+        self.sums = np.concatenate([self.sums, np.zeros((add, 3, D))])
+        if self.S is not None:
+            self.S = np.concatenate([self.S, np.zeros((add, 3, D, D))])
+        for d in (self.post, self.params):
+            for k in list(d.keys()):
+                d[k] = np.concatenate([d[k], np.zeros((3 * add,) + d[k].shape[1:], d[k].dtype)])
+        self.lr_weights = np.concatenate([self.lr_weights, np.full((add, 2), 0.5, np.float32)])
+        self.weights = np.concatenate([self.weights, np.zeros(add, np.float32)])
+        self.splittable = np.concatenate([self.splittable, np.zeros(add, bool)])
+        self.hist = np.concatenate([self.hist, np.full((add, self.hist.shape[1]), -np.inf, np.float32)])
+        self.points_count = np.concatenate([self.points_count, np.zeros(add, np.int64)])
+        self.K = K2
+
+    def _copy_row(self, dst, src):
+        """Copy one distribution row (statistics, posterior, drawn parameters)."""
+        kd, wd = divmod(dst, 3); ks, ws = divmod(src, 3)
+        self.N[kd, wd] = self.N[ks, ws]; self.sums[kd, wd] = self.sums[ks, ws]
+        if self.S is not None:
+            self.S[kd, wd] = self.S[ks, ws]
+        for d in (self.post, self.params):
+            for k in d:
+                d[k][dst] = d[k][src]
+
+    # ------------------------------------------------------------------ step 7c
+    def check_and_merge(self, final):
+        K = self.K
+        ok = self.splittable & (self.N[:, 0] > 0)
+        ids = np.flatnonzero(ok)
+        if len(ids) < 2:
+            return
+        ii, jj = np.triu_indices(len(ids), 1)
+        pi, pj = ids[ii], ids[jj]                     # lexicographic (i<j) order
+        Nf, sf, Sf = self._stats_flat()
+        Lc = self.prior.log_marginal(self.post, Nf).reshape(K, 3)[:, 0]
+        t0 = time.perf_counter()
+        Lp = self.prior.log_marginal_pairs(np.stack([3 * pi, 3 * pj], 1), dict(N=Nf, sums=sf, S=Sf), nthreads=self.nthreads)
+        self._tic("merge_pairs_host", t0)
+        a = self.alpha
+        Ni, Nj = self.N[pi, 0], self.N[pj, 0]
+        Np = Ni + Nj
+        log_hr = (-np.log(a) + gammaln(a) - 2 * gammaln(0.5 * a) + gammaln(Np) - gammaln(Np + a)
+                  + gammaln(Ni + 0.5 * a) - gammaln(Ni) - gammaln(Nj) + gammaln(Nj + 0.5 * a) + Lp - Lc[pi] - Lc[pj])
+        u = self.rng.random(len(pi))
+        with np.errstate(divide="ignore"):
+            acc = (log_hr > np.log(u)) | (final & (log_hr > np.log(0.1)))
+        used = np.zeros(K, bool)
+        m_i, m_j = [], []
+        for p in np.flatnonzero(acc):
+            i, j = pi[p], pj[p]
+            if used[i] or used[j]:
+                continue
+            used[i] = used[j] = True
+            m_i.append(i); m_j.append(j)
+        if not m_i:
+            return
+        for i, j in zip(m_i, m_j):                 # merge_clusters! / merge_clusters_to_splittable
+            ri, rj = 3 * i, 3 * j
+            Ni_, Nj_ = self.N[i, 0], self.N[j, 0]
+            self._copy_row(ri + 1, ri)             # left  := old cluster i
+            self._copy_row(ri + 2, rj)             # right := old cluster j
+            self.N[i, 0] = Ni_ + Nj_
+            self.sums[i, 0] = self.sums[i, 1] + self.sums[i, 2]
+            if self.S is not None:
+                self.S[i, 0] = self.S[i, 1] + self.S[i, 2]
+            Nf, sf, Sf = self._stats_flat()
+            self._set_post_rows([ri], self.prior.posterior(Nf[[ri]], sf[[ri]], Sf[[ri]] if Sf is not None else None, nthreads=1))
+            self.lr_weights[i] = self._dirichlet([Ni_ + a / 2, Nj_ + a / 2]).astype(np.float32)
+            self.splittable[i] = False
+            self.hist[i] = -np.inf
+            self.points_count[i] += self.points_count[j]
+            self.points_count[j] = 0
+            self.N[j, 0] = 0
+            self.splittable[j] = False
+        self.wk.merge(np.asarray(m_i) + 1, np.asarray(m_j) + 1)
+
+    # ------------------------------------------------------------------ step 8
+    def remove_empty_clusters(self):
+        keep = self.points_count > 0
+        if keep.all():
+            return
+        self.wk.remove_empty(self.points_count)
+        rows = self._rows(np.flatnonzero(keep))
+        self.N = self.N[keep]; self.sums = self.sums[keep]
+        if self.S is not None:
+            self.S = self.S[keep]
+        for d in (self.post, self.params):
+            for k in list(d.keys()):
+                d[k] = d[k][rows]
+        self.lr_weights = self.lr_weights[keep]; self.weights = self.weights[keep]
+        self.splittable = self.splittable[keep]; self.hist = self.hist[keep]
+        self.points_count = self.points_count[keep]
+        self.K = int(keep.sum())
+        self.wk.set_num_clusters(self.K)
+
+    # ------------------------------------------------------------------ the sweep
+    def group_step(self, no_more_splits, final):
+        self.sample_clusters()                                   # 1
+        t0 = time.perf_counter()
+        self.prior.upload(self.wk, self.params, self.lr_weights, self.weights)   # 2
+        self._tic("upload_params", t0)
+        t0 = time.perf_counter()
+        self.wk.sweep(self._next_epoch(), final)                 # 3 + 4 (asynchronous)
+        self._tic("sweep_launch", t0)
+        self.update_suff_stats_posterior()                       # 5
+        self.reset_bad_clusters()                                # 6
+        if not no_more_splits:                                   # 7
+            t0 = time.perf_counter()
+            touched = self.check_and_split(final)
+            self._tic("split_host", t0)
+            self.update_suff_stats_posterior(touched)
+            t0 = time.perf_counter()
+            self.check_and_merge(final)
+            self._tic("merge_host", t0)
+        self.remove_empty_clusters()                             # 8
+
+    def init_first_clusters(self, init_clusters):
+        """init_model_from_data labels (dp-parallel-sampling.jl:49-50) + init_first_clusters! (:62-78)."""
+        self._alloc(int(init_clusters))
+        self.wk.init_labels(int(init_clusters), self._next_epoch())
+        self.wk.reset_sublabels(None, self._next_epoch())   # split_first_cluster_worker!
+        self.wk.set_num_clusters(self.K)
+        self.update_suff_stats_posterior()
+        self.sample_clusters()
+
+    def start_from_labels(self, labels, sub_labels, K):
+        """Resume / benchmark entry: adopt given (local shard) labels instead of random ones."""
+        self._alloc(int(K))
+        self.wk.set_labels(labels, sub_labels)
+        self.wk.set_num_clusters(self.K)
+        self.update_suff_stats_posterior()
+        self.sample_clusters()
+
+    def log_posterior(self):
+        """calculate_posterior (dp-parallel-sampling.jl:458-470)."""
+        K = self.K
+        L = self.prior.log_marginal(self.post, self.N.reshape(3 * K)).reshape(K, 3)[:, 0]
+        Nc = self.N[:, 0]
+        lp = gammaln(self.alpha) - gammaln(self.n_total + self.alpha)
+        nz = Nc > 0
+        return float(lp + np.sum(L[nz] + np.log(self.alpha) + gammaln(Nc[nz])))
+
+    def run_model(self, iterations, first_iter=1, verbose=False, gt=None, on_iteration=None):
+        """run_model (dp-parallel-sampling.jl:336-404): returns iter_count, nmi_history, likelihood_history, cluster_count_history."""
+        iter_count, nmi_hist, lik_hist, k_hist = [], [], [], []
+        for i in range(first_iter, iterations + 1):
+            final = i >= iterations - self.argmax_sample_stop
+            no_more_splits = (i >= iterations - self.split_stop) or (self.K >= self.max_clusters)
+            t0 = time.perf_counter()
+            self.group_step(no_more_splits, final)
+            dt = time.perf_counter() - t0
+            iter_count.append(dt)
+            k_hist.append(self.K)
+            if gt is not None:
+                lab = self.comm.gather_labels(self.wk)[0]
+                nmi_hist.append(_nmi(np.asarray(gt).astype(np.int64), lab))
+            else:
+                nmi_hist.append("no gt")
+            if verbose:
+                lik_hist.append(self.log_posterior())
+                if self.comm.rank == 0:
+                    print(f"Iteration: {i} || Clusters count: {self.K} || Log posterior: {lik_hist[-1]} || NMI score: {nmi_hist[-1]}"
+                          f" || Iter Time:{dt} || Total time:{sum(iter_count)}")
+            else:
+                lik_hist.append(1)
+            if on_iteration is not None:
+                on_iteration(i, self)
+        return iter_count, nmi_hist, lik_hist, k_hist
+
+
+def _nmi(a, b):
+    from sklearn.metrics import normalized_mutual_info_score
+    return float(normalized_mutual_info_score(a, b))

@@ -95,6 +95,14 @@ int dpmm_set_params_niw_chol(dpmm_ctx *ctx, int K, const float *mu, const float 
 /* multinomial_dist alpha = log-probabilities (distributions/multinomial_dist.jl:8-10): logp [3K][D] */
 int dpmm_set_params_mult(dpmm_ctx *ctx, int K, const float *logp, const float *lr_weights, const float *weights);
 
+/* Declares the number of clusters K that labels may reference from now on WITHOUT uploading
+ * parameters: the master resizes group.local_clusters in check_and_split!
+ * (local_clusters_actions.jl:361) and shrinks it in remove_empty_clusters! (:470); reference
+ * workers learn K implicitly from length(clusters_vector) (:152,:174).  Needed before a
+ * statistics pass that follows a split or a removal.  Parameters must be set again before
+ * the next dpmm_sweep. */
+int dpmm_set_num_clusters(dpmm_ctx *ctx, int K);
+
 /* One label + sub-label sampling pass over the shard.
  * Replaces sample_labels_worker! (local_clusters_actions.jl:112-134; log_likelihood!
  * mv_gaussian.jl:21-25 / multinomial_dist.jl:13-15; sample_log_cat_array! utils.jl:19-31)

@@ -1,0 +1,58 @@
+"""End-to-end `fit` on the GPU, mirroring the reference's own outcome tests
+(test/module_tests.jl) and its docs example (docs/src/getting_started.md:27-37 == BASELINE config 1)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def host():
+    from __graft_entry__ import load_package
+    load_package()
+    import importlib
+    return importlib.import_module("dpmmsubclusters_jl_amd.host")
+
+
+def test_module_deterministic_point_masses(host):
+    """test/module_tests.jl:1-32: four point masses, 250 copies each."""
+    data = np.zeros((2, 1000), np.float32)
+    data[:, 0:250] = [[-1], [-1]]; data[:, 250:500] = [[-1], [1]]
+    data[:, 500:750] = [[1], [-1]]; data[:, 750:1000] = [[1], [1]]
+    res = host.fit(data, 100.0, iters=200, seed=123456789, burnout=15, verbose=False)
+    labels, clusters, weights = res[0], res[1], res[2]
+    assert len(clusters) == 4                                   # :21
+    assert np.all(weights >= 0.15)                              # :23
+    for _, v in host.get_labels_histogram(labels):              # :29-31
+        assert v == 250
+    assert len(res) == 9 and len(res[3]) == 200 and res[6][-1] == 4
+    for c in clusters:                                          # cluster means sit on the masses
+        assert np.min(np.abs(np.abs(c.mu) - 1)) < 0.2
+
+
+def test_docs_example_config1(host):
+    """docs/src/getting_started.md:27-37: N=10^4, D=2, 6 components, alpha=10, burnout=10, 100 iterations."""
+    x, y, _, _ = host.generate_gaussian_data(10 ** 4, 2, 6, 100.0, seed=4)
+    res = host.fit(x, 10.0, iters=100, burnout=10, gt=y, seed=12345, verbose=False)
+    labels, clusters, nmi, kh = res[0], res[1], res[4], res[6]
+    big = (np.bincount(y.astype(int))[1:] > 50).sum()
+    assert big - 1 <= len(clusters) <= 7
+    assert nmi[-1] > 0.95
+    assert len(labels) == 10 ** 4 and labels.min() == 1 and labels.max() == len(clusters)
+    assert kh[0] >= 1 and kh[-1] == len(clusters)
+
+
+def test_module_random_mess(host):
+    """test/module_tests.jl:36-47: N=10^5, D=3, 10 components, alpha=1e21 via dp_parallel; asserts K > 1."""
+    x, labels, _, _ = host.generate_gaussian_data(10 ** 5, 3, 10, 100.0, seed=12345)
+    hyper = host.niw_hyperparams(1.0, np.zeros(3), 5, np.eye(3))
+    dp = host.dp_parallel(x, hyper, np.float32(1e21), 100, 1, None, False, False, 15, labels)
+    assert dp[0].num_clusters > 1
+    assert len(dp) == 5 and len(dp[1]) == 100
+
+
+def test_fit_d64_recovers_components(host):
+    x, y, _, _ = host.generate_gaussian_data(60000, 64, 8, 100.0, seed=3)
+    res = host.fit(x, 10.0, iters=60, burnout=8, gt=y, seed=7, verbose=False)
+    assert res[4][-1] > 0.98
+    assert 8 <= len(res[1]) <= 10
