@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -20,6 +21,9 @@ using namespace dpmm;
 
 static_assert(DPMM_MAX_CLUSTERS == DPMM_MAX_CLUSTERS_K, "header / kernel limits out of sync");
 
+#ifdef DPMM_STAMPS
+static unsigned long long *g_dbg = nullptr;
+#endif
 namespace {
 thread_local std::string g_create_error;
 
@@ -163,7 +167,7 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
         c->tile = niw_tile_points(c->NB);
         c->slab_stride = niw_slab_stride(D);
         c->packed_stride = 1 + (int64_t)D + (int64_t)D * (D + 1) / 2;
-        c->sweep_grid = c->cus * (c->NB <= 8 ? 2 : 1);
+        c->sweep_grid = c->cus * niw_occupancy(c->NB);
     } else {
         c->tile = mult_tile_points();
         c->slab_stride = mult_slab_stride(D);
@@ -369,6 +373,19 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
         a.scratch_by_tile = table ? 1 : 0;
         a.labels_only = table ? 1 : 0;
         a.bins = c->dbins; a.seed = c->seed; a.epoch = epoch; a.final_argmax = final_argmax;
+        {
+            static const int stag = [] { const char *e = getenv("DPMM_NIW_STAGGER"); return e ? atoi(e) : 0; }();
+            if (stag > 0 && !table && c->NB <= 4) {
+                unsigned *ctr = reinterpret_cast<unsigned *>(c->d_small + 4 * DPMM_MAX_CLUSTERS - 4);
+                HIPCHK(c, hipMemsetAsync(ctr, 0, sizeof(unsigned), c->stream));
+                a.tile_counter = ctr;
+                a.stagger_cycles_per_cluster = stag;
+            }
+        }
+#ifdef DPMM_STAMPS
+        if (!g_dbg) { hipMalloc(&g_dbg, sizeof(unsigned long long) * 8 * 4 * 4096); hipMemset(g_dbg, 0, sizeof(unsigned long long) * 8 * 4 * 4096); }
+        a.dbg = g_dbg;
+#endif
         HIPCHK(c, launch_niw_sweep(c->NB, a, c->sweep_grid, c->stream));
     } else {
         MultSweepArgs a{};
@@ -569,6 +586,15 @@ int dpmm_sync(dpmm_ctx *c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return DPMM_OK;
 }
+
+#ifdef DPMM_STAMPS
+// diagnostic builds only: copy the per-wave phase cycle sums of the last NIW sweep
+int dpmm_dev_stamps(dpmm_ctx *c, unsigned long long *out, int nwaves) {
+    hipStreamSynchronize(c->stream);
+    hipMemcpy(out, g_dbg, sizeof(unsigned long long) * 8 * nwaves, hipMemcpyDeviceToHost);
+    return c->sweep_grid * 4;
+}
+#endif
 
 void *dpmm_stream(dpmm_ctx *c) { return c ? (void *)c->stream : nullptr; }
 

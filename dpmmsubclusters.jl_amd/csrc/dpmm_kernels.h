@@ -29,9 +29,14 @@ struct NiwSweepArgs {
     uint64_t seed;
     uint32_t epoch;
     int final_argmax;
+    unsigned *tile_counter;   // zeroed before the launch: dynamic tile queue (null: static striding)
+    int stagger_cycles_per_cluster;
+    int lds_rows;             // set by the launcher: rows of the a_k table that live in LDS (0: global scratch)
+    unsigned long long *dbg;  // diagnostic builds only (DPMM_STAMPS): per-wave phase cycle sums
 };
 
 int niw_tile_points(int NB);
+int niw_occupancy(int NB);  // resident 256-thread workgroups per CU the sweep kernel is built for
 hipError_t launch_niw_sweep(int NB, const NiwSweepArgs &a, int grid, hipStream_t s);
 hipError_t launch_niw_pack(const float *R, const float *mu, float *Rp, float *mup, int D, int NB, int nmat, hipStream_t s);
 

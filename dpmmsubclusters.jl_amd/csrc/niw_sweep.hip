@@ -28,6 +28,8 @@
 // float4 at element 16t + 4g, so element (16t + 4g + jj) is component jj of that float4.
 #include "dpmm_device.h"
 #include "dpmm_kernels.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace dpmm {
 
@@ -113,12 +115,16 @@ struct QuadEval {
             for (int t = bi; t < NB; ++t) {
                 const int pic = pair_base<NB>(bi) + (t - bi) - pair_base<NB>(C::row0(c));
                 const f32x4 a = *reinterpret_cast<const f32x4 *>(lds + pic * 256 + lane * 4);
+                // rotate over the NG independent accumulators: a dependent MFMA pair needs 40 cycles,
+                // the issue interval is 32
+                f32x4 zz[NG];
 #pragma unroll
-                for (int n = 0; n < NG; ++n) {
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x[n][t].x - mu[t].x, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x[n][t].y - mu[t].y, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x[n][t].z - mu[t].z, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x[n][t].w - mu[t].w, acc[n], 0, 0, 0);
+                for (int n = 0; n < NG; ++n) zz[n] = x[n][t] - mu[t];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+                    for (int n = 0; n < NG; ++n)
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj], zz[n][jj], acc[n], 0, 0, 0);
                 }
             }
 #pragma unroll
@@ -307,15 +313,314 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// "Direct" variant for D <= 64 (NB <= 4): no LDS, no barriers.  A packed factor is only
+// NP KiB (10 KiB at D=64) and is re-read by every wave from L2 (~4 B/clk/CU, far below the
+// L2 rate), so each wave streams its own A fragments global -> registers one matrix ahead of
+// the MFMAs and never synchronises with its neighbours: waves drift apart and fill each
+// other's epilogue / draw phases on the shared matrix pipe, and the sub-label phase walks the
+// distinct labels of the wave's own 64 points (not of the whole workgroup).
+// Streaming evaluation of one packed matrix: row-block bi is computed from `cur` while the
+// fragments of the next row-block (or of row-block 0 of the next matrix, plus its mu) are in
+// flight.  On entry rb0/mu hold row-block 0 and mu of THIS matrix; on exit those of Rnext.
+template <int NB, int NG>
+__device__ __forceinline__ float quad_stream(const float *__restrict__ Rm, const float *__restrict__ Rnext,
+                                             const float *__restrict__ mup_next, f32x4 (&rb0)[NB], f32x4 (&mu)[NB],
+                                             const f32x4 (&x)[NG][NB], int lane, int g, bool active) {
+    float q[NG];
+#pragma unroll
+    for (int n = 0; n < NG; ++n) q[n] = 0.f;
+    f32x4 cur[NB], mun[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) { cur[t] = rb0[t]; mun[t] = mu[t]; }
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi) {
+        f32x4 nxt[NB];
+        if (bi + 1 < NB) {
+#pragma unroll
+            for (int t = 0; t < NB - bi - 1; ++t)
+                nxt[t] = *reinterpret_cast<const f32x4 *>(Rm + (pair_base<NB>(bi + 1) + t) * 256 + lane * 4);
+        } else if (Rnext) {
+#pragma unroll
+            for (int t = 0; t < NB; ++t) {
+                nxt[t] = *reinterpret_cast<const f32x4 *>(Rnext + t * 256 + lane * 4);
+                mun[t] = *reinterpret_cast<const f32x4 *>(mup_next + 16 * t + 4 * g);
+            }
+        }
+        if (active) {
+            f32x4 acc[NG];
+#pragma unroll
+            for (int n = 0; n < NG; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = bi; t < NB; ++t) {
+                const f32x4 a = cur[t - bi];
+                f32x4 zz[NG];
+#pragma unroll
+#ifdef DPMM_EXP_NOSUB
+                for (int n = 0; n < NG; ++n) zz[n] = x[n][t];
+#else
+                for (int n = 0; n < NG; ++n) zz[n] = x[n][t] - mu[t];
+#endif
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+                    for (int n = 0; n < NG; ++n)
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj], zz[n][jj], acc[n], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < NG; ++n) {
+                q[n] = __builtin_fmaf(acc[n][0], acc[n][0], q[n]);
+                q[n] = __builtin_fmaf(acc[n][1], acc[n][1], q[n]);
+                q[n] = __builtin_fmaf(acc[n][2], acc[n][2], q[n]);
+                q[n] = __builtin_fmaf(acc[n][3], acc[n][3], q[n]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NB; ++t) cur[t] = nxt[t];
+    }
+#pragma unroll
+    for (int t = 0; t < NB; ++t) { rb0[t] = cur[t]; mu[t] = mun[t]; }
+    // Cross-lane sum over the 4 row groups g without leaving the matrix pipe: with A = ones,
+    // D[i][c] = sum_g B[g][c], i.e. every lane of column c receives the column total.
+    float sel = 0.f;
+#pragma unroll
+    for (int n = 0; n < NG; ++n) {
+        const f32x4 tot = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, q[n], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        if (g == n) sel = tot[0];
+    }
+    return sel;
+}
+
+template <int NB>
+__device__ __forceinline__ void load_rb0(const float *__restrict__ Rm, const float *__restrict__ mup, f32x4 (&rb0)[NB],
+                                         f32x4 (&mu)[NB], int lane, int g) {
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+        rb0[t] = *reinterpret_cast<const f32x4 *>(Rm + t * 256 + lane * 4);
+        mu[t] = *reinterpret_cast<const f32x4 *>(mup + 16 * t + 4 * g);
+    }
+}
+
+#ifdef DPMM_STAMPS
+#define STAMP(var) unsigned long long var; do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(var)
+#endif
+template <int NB, int NG, int OCC>
+__global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs A) {
+#ifdef DPMM_STAMPS
+    unsigned long long T_x = 0, T_quad = 0, T_epi = 0, T_draw = 0, T_p2 = 0, T_tot = 0; int ntile = 0;
+#endif
+    constexpr int DP = 16 * NB, NP = NB * (NB + 1) / 2, MATSZ = NP * 256, WPTS = 16 * NG;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int ci = lane & 15, g = lane >> 4;
+    const int K = A.K;
+    const bool owner = lane < WPTS;
+    const int64_t nwtiles = (A.n + WPTS - 1) / WPTS;              // one tile per wave
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + (tid >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    extern __shared__ __attribute__((aligned(16))) float lds_tab[];
+    // wave-private [K][WPTS] table of a_k in LDS when it fits (A.lds_rows >= K), else the global scratch
+    const bool tab_lds = A.lds_rows >= K && !A.scratch_by_tile;
+    float *ltab = lds_tab + (size_t)(tid >> 6) * A.lds_rows * WPTS + lane;
+
+    // Waves that share a SIMD would otherwise run in lockstep (same program, same work) and idle the
+    // matrix pipe together during their draw / epilogue phases: odd hardware wave slots start half a
+    // tile late, and tiles are handed out dynamically so the late starters simply take fewer.
+    if (A.tile_counter) {
+        const unsigned slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));  // HW_REG_HW_ID.WAVE_ID
+        if (slot & 1u) {
+            const int naps = (K * A.stagger_cycles_per_cluster) >> 13;
+            for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+    }
+    auto next_tile = [&](int64_t prev) -> int64_t {
+        if (!A.tile_counter) return prev < 0 ? wave_id : prev + nwaves;
+        unsigned v = 0;
+        if (lane == 0) v = atomicAdd(A.tile_counter, 1u);
+        return (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)v);
+    };
+    for (int64_t tile = next_tile(-1); tile < nwtiles; tile = next_tile(tile)) {
+        const int64_t wbase = tile * WPTS;
+        STAMP(s0);
+        f32x4 x[NG][NB];
+#pragma unroll
+        for (int n = 0; n < NG; ++n) {
+            const int64_t p = wbase + 16 * n + ci;
+#pragma unroll
+            for (int t = 0; t < NB; ++t) {
+                const int e = 16 * t + 4 * g;
+                x[n][t] = (p < A.n && e < A.ldx) ? *reinterpret_cast<const f32x4 *>(A.X + p * A.ldx + e)
+                                                  : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#ifdef DPMM_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        STAMP(s1);
+        const int64_t myp = wbase + lane;
+        const bool valid = owner && myp < A.n;
+        float *scr = A.scratch + (A.scratch_by_tile ? tile * WPTS : wave_id * WPTS) + lane;
+        const int64_t sstride = A.scratch_stride;
+
+        float m_run = -INFINITY;
+        int best = 0;
+        bool nan_seen = false;
+        f32x4 rb0[NB], mu[NB];
+        load_rb0<NB>(A.Rp, A.mup, rb0, mu, lane, g);
+        for (int k = 0; k < K; ++k) {
+            const float *Rcur = A.Rp + (size_t)(3 * k) * MATSZ;
+            const float *Rnext = (k + 1 < K) ? A.Rp + (size_t)(3 * (k + 1)) * MATSZ : nullptr;
+            STAMP(q0);
+            const float qs = quad_stream<NB, NG>(Rcur, Rnext, A.mup + (size_t)(3 * (k + 1)) * DP, rb0, mu, x, lane, g, true);
+            STAMP(q1);
+            const float a = __builtin_fmaf(-0.5f, qs, A.cst[3 * k]);
+            if (tab_lds) ltab[k * WPTS] = a;
+            else if (valid) scr[(int64_t)k * sstride] = a;
+            if (a != a) {
+                if (!nan_seen) { nan_seen = true; best = k; }
+            } else if (a > m_run) {
+                m_run = a;
+                if (!nan_seen) best = k;
+            }
+            STAMP(q2);
+#ifdef DPMM_STAMPS
+            T_quad += q1 - q0; T_epi += q2 - q1;
+#endif
+        }
+        STAMP(s2);
+
+        int z = 0;
+        float u_sub = 0.f;
+        if (valid) {
+            const Philox4 r = philox4x32_10(A.seed, (uint64_t)(A.first_index + myp), A.epoch, STREAM_SWEEP);
+            u_sub = u01(r.v[1]);
+            if (A.final_argmax) {
+                z = best;
+            } else if (m_run == -INFINITY) {
+                z = 0;
+            } else if (tab_lds) {
+                // same arithmetic, same order as the global-table path (and the CPU oracle); 4 table reads in flight
+                float s = 0.f;
+                int k = 0;
+                for (; k + 4 <= K; k += 4) {
+                    const float a0 = ltab[(k + 0) * WPTS], a1 = ltab[(k + 1) * WPTS], a2 = ltab[(k + 2) * WPTS], a3 = ltab[(k + 3) * WPTS];
+                    s += exp_det(nan_to_ninf(a0) - m_run);
+                    s += exp_det(nan_to_ninf(a1) - m_run);
+                    s += exp_det(nan_to_ninf(a2) - m_run);
+                    s += exp_det(nan_to_ninf(a3) - m_run);
+                }
+                for (; k < K; ++k) s += exp_det(nan_to_ninf(ltab[k * WPTS]) - m_run);
+                const float t = u01(r.v[0]) * s;
+                float cw = 0.f;
+                z = K - 1;
+                for (k = 0; k < K; ++k) {
+                    cw += exp_det(nan_to_ninf(ltab[k * WPTS]) - m_run);
+                    if (!(cw < t)) { z = k; break; }
+                }
+            } else {
+                float s = 0.f;
+                for (int k = 0; k < K; ++k) s += exp_det(nan_to_ninf(scr[(int64_t)k * sstride]) - m_run);
+                const float t = u01(r.v[0]) * s;
+                float cw = 0.f;
+                z = K - 1;
+                for (int k = 0; k < K; ++k) {
+                    cw += exp_det(nan_to_ninf(scr[(int64_t)k * sstride]) - m_run);
+                    if (!(cw < t)) { z = k; break; }
+                }
+            }
+        }
+        if (A.labels_only) continue;
+        STAMP(s3);
+
+        // sub-labels: walk the distinct labels of this wave (wave-uniform loop)
+        float b0 = -INFINITY, b1 = -INFINITY;
+        unsigned long long todo = __ballot(valid);
+        auto next_label = [&]() -> int {
+            if (!todo) return -1;
+            const int leader = __ffsll((long long)todo) - 1;
+            const int kk = __shfl(z, leader);
+            todo &= ~__ballot(valid && z == kk);
+            return kk;
+        };
+        int kcur = next_label();
+        if (kcur >= 0) load_rb0<NB>(A.Rp + (size_t)(3 * kcur + 1) * MATSZ, A.mup + (size_t)(3 * kcur + 1) * DP, rb0, mu, lane, g);
+        while (kcur >= 0) {
+            const int knext = next_label();
+            const int jl = 3 * kcur + 1, jr = jl + 1, jn = 3 * (knext >= 0 ? knext : 0) + 1;
+            const float bl = __builtin_fmaf(-0.5f, quad_stream<NB, NG>(A.Rp + (size_t)jl * MATSZ, A.Rp + (size_t)jr * MATSZ,
+                                                                          A.mup + (size_t)jr * DP, rb0, mu, x, lane, g, true), A.cst[jl]);
+            const float br = __builtin_fmaf(-0.5f, quad_stream<NB, NG>(A.Rp + (size_t)jr * MATSZ,
+                                                                          knext >= 0 ? A.Rp + (size_t)jn * MATSZ : nullptr,
+                                                                          A.mup + (size_t)jn * DP, rb0, mu, x, lane, g, true), A.cst[jr]);
+            if (valid && z == kcur) { b0 = bl; b1 = br; }
+            kcur = knext;
+        }
+        if (valid) A.bins[myp] = 2 * z + draw2(b0, b1, u_sub);
+        STAMP(s4);
+#ifdef DPMM_STAMPS
+        T_x += s1 - s0; T_draw += s3 - s2; T_p2 += s4 - s3; T_tot += s4 - s0; ++ntile;
+#endif
+    }
+#ifdef DPMM_STAMPS
+    if (lane == 0 && A.dbg) {
+        unsigned long long *d = A.dbg + wave_id * 8;
+        d[0] = T_x; d[1] = T_quad; d[2] = T_epi; d[3] = T_draw; d[4] = T_p2; d[5] = T_tot; d[6] = ntile; d[7] = 0;
+    }
+#endif
+}
+
+template <int NB, int NG, int OCC>
+static hipError_t launch_direct(const NiwSweepArgs &a, int grid, hipStream_t s) {
+    // a_k table in LDS: the CU's 160 KiB split over OCC resident workgroups of 4 waves
+    NiwSweepArgs b = a;
+    const int budget_rows = (int)((160 * 1024 / OCC - 512) / (4 * 16 * NG * sizeof(float)));
+    b.lds_rows = a.K <= budget_rows ? a.K : 0;
+    const size_t lds_bytes = (size_t)b.lds_rows * 4 * 16 * NG * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void *)niw_sweep_direct_kernel<NB, NG, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / OCC);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((niw_sweep_direct_kernel<NB, NG, OCC>), dim3(grid), dim3(256), lds_bytes, s, b);
+    return hipGetLastError();
+}
+
 template <int NB, int NG, int CH>
 static hipError_t launch_cfg(const NiwSweepArgs &a, int grid, hipStream_t s) {
     hipLaunchKernelGGL((niw_sweep_kernel<NB, NG, CH>), dim3(grid), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
+// D=64 configuration (dev-tunable through DPMM_NIW_D64_CFG: "NG,OCC")
+static int d64_ng() {
+    static int ng = [] { const char *e = getenv("DPMM_NIW_D64_CFG"); return e ? atoi(e) : 4; }();
+    return ng;
+}
+static int d64_occ() {
+    static int occ = [] { const char *e = getenv("DPMM_NIW_D64_CFG"); const char *c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : 2; }();
+    return occ;
+}
+static hipError_t niw_direct_d64(const NiwSweepArgs &a, int grid, hipStream_t s) {
+    const int ng = d64_ng(), occ = d64_occ();
+    if (ng == 4) return launch_direct<4, 4, 2>(a, grid, s);
+    if (ng == 2 && occ == 2) return launch_direct<4, 2, 2>(a, grid, s);
+    if (ng == 2 && occ == 3) return launch_direct<4, 2, 3>(a, grid, s);
+    if (ng == 2) return launch_direct<4, 2, 4>(a, grid, s);
+    if (ng == 1) return launch_direct<4, 1, 4>(a, grid, s);
+    return hipErrorInvalidValue;
+}
+int niw_occupancy(int NB) {
+    if (NB == 4) return d64_ng() == 4 ? 2 : d64_occ();
+    return NB <= 8 ? 2 : 1;
+}
+
 int niw_tile_points(int NB) {
     switch (NB) {
-        case 1: case 2: case 4: return 256;
+        case 4: return 64 * d64_ng();
+        case 1: case 2: return 256;
         case 8: return 128;
         default: return 128;
     }
@@ -323,9 +628,9 @@ int niw_tile_points(int NB) {
 
 hipError_t launch_niw_sweep(int NB, const NiwSweepArgs &a, int grid, hipStream_t s) {
     switch (NB) {
-        case 1: return launch_cfg<1, 4, 1>(a, grid, s);
-        case 2: return launch_cfg<2, 4, 2>(a, grid, s);
-        case 4: return launch_cfg<4, 4, 4>(a, grid, s);
+        case 1: return launch_direct<1, 4, 4>(a, grid, s);
+        case 2: return launch_direct<2, 4, 3>(a, grid, s);
+        case 4: return niw_direct_d64(a, grid, s);
         case 8: return launch_cfg<8, 2, 2>(a, grid, s);
         case 16: return launch_cfg<16, 2, 1>(a, grid, s);
         default: return hipErrorInvalidValue;

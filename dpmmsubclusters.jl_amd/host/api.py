@@ -141,6 +141,37 @@ def generate_gaussian_data(N, D, K, MixtureVar, seed=None):
     return x, tz, tmean, tcov
 
 
+def gaussian_mixture_shard(N, D, K, MixtureVar, seed, lo, hi, chunk=100000):
+    """Columns [lo, hi) of the SAME N-point mixture as `generate_gaussian_data`'s recipe, generated
+    chunk-wise with per-chunk seeds so that every rank of a multi-GPU run can build only its own
+    column range (benchmark input; the dataset does not depend on the number of ranks).
+    Returns (X (hi-lo, D) float32 row = point, labels (hi-lo,) int64 1-based)."""
+    rng = np.random.default_rng([int(seed), 0])
+    tpi = rng.dirichlet(np.ones(K))
+    tzn = rng.multinomial(N, tpi)
+    means = rng.normal(size=(K, D)) * np.sqrt(MixtureVar)
+    chol = np.empty((K, D, D))
+    for i in range(K):
+        G = rng.normal(size=(D + 2, D))
+        chol[i] = np.linalg.cholesky(np.linalg.inv(G.T @ G))
+    edges = np.concatenate([[0], np.cumsum(tzn)])
+    X = np.empty((hi - lo, D), np.float32)
+    lab = np.empty(hi - lo, np.int64)
+    c0, c1 = lo // chunk, (hi - 1) // chunk if hi > lo else -1
+    for c in range(c0, c1 + 1):
+        a, b = c * chunk, min((c + 1) * chunk, N)
+        z = np.random.default_rng([int(seed), 1 + c]).standard_normal((b - a, D), dtype=np.float32)
+        comp = np.searchsorted(edges, np.arange(a, b), side="right") - 1
+        out = np.empty((b - a, D), np.float32)
+        for k in np.unique(comp):
+            m = comp == k
+            out[m] = (means[k] + z[m] @ chol[k].T.astype(np.float32)).astype(np.float32)
+        s, e = max(a, lo), min(b, hi)
+        X[s - lo:e - lo] = out[s - a:e - a]
+        lab[s - lo:e - lo] = comp[s - a:e - a] + 1
+    return X, lab
+
+
 def generate_mnmm_data(N, D, K, trials, seed=None):
     """Recipe of data_generators.jl:59-72. Returns (x D x N f32 counts, labels, clusters D x K)."""
     rng = np.random.default_rng(seed)
