@@ -47,7 +47,7 @@ def _shard(N, comm):
     return lo, hi
 
 
-def _make_sampler(all_data, hyper, alpha, seed, burnout, max_clusters, comm, device, nthreads=None):
+def _make_sampler(all_data, hyper, alpha, seed, burnout, max_clusters, comm, device, nthreads=None, worker_factory=None):
     X = np.asarray(all_data)
     if X.ndim != 2:
         raise ValueError("all_data must be Dimensions x Samples")
@@ -59,14 +59,14 @@ def _make_sampler(all_data, hyper, alpha, seed, burnout, max_clusters, comm, dev
     if seed is None:
         seed = int(np.random.SeedSequence().generate_state(1)[0])
         seed = comm.broadcast_int(seed) if hasattr(comm, "broadcast_int") else seed
-    wk = binding.Worker(hyper.kind, D, hi - lo, first_index=lo, device=device, seed=int(seed))
+    wk = (worker_factory or binding.Worker)(hyper.kind, D, hi - lo, first_index=lo, device=device, seed=int(seed))
     wk.upload_points(Xs)
     return DPMMSampler(wk, hyper, alpha, N, int(seed), burnout=burnout, max_clusters=max_clusters, comm=comm, nthreads=nthreads)
 
 
 def dp_parallel(all_data, local_hyper_params, alpha_param, iters=100, init_clusters=1, seed=None, verbose=True,
                 save_model=False, burnout=15, gt=None, max_clusters=np.inf, outlier_weight=0, outlier_params=None,
-                smart_splits=False, comm=None, device=None, nthreads=None):
+                smart_splits=False, comm=None, device=None, nthreads=None, worker_factory=None):
     """Returns (dp_model, iter_count, nmi_score_history, likelihood_history, cluster_count_history)."""
     if save_model:
         raise NotImplementedError("checkpointing is outside this build's scope (SURVEY.md 8f)")
@@ -81,7 +81,8 @@ def dp_parallel(all_data, local_hyper_params, alpha_param, iters=100, init_clust
         comm = default_comm()
     if device is None:
         device = getattr(comm, "device", 0)
-    s = _make_sampler(all_data, local_hyper_params, np.float32(alpha_param), seed, int(burnout), max_clusters, comm, device, nthreads)
+    s = _make_sampler(all_data, local_hyper_params, np.float32(alpha_param), seed, int(burnout), max_clusters, comm, device,
+                      nthreads, worker_factory)
     s.init_first_clusters(int(init_clusters))
     iter_count, nmi, lik, kh = s.run_model(int(iters), 1, verbose=verbose, gt=gt)
     labels, sub = comm.gather_labels(s.wk)

@@ -1,0 +1,112 @@
+"""TEST-ONLY stand-in for the GPU `Worker` (dpmmsubclusters.jl_amd/binding.py) built on the CPU oracle.
+It exists so that the host sampler and the multi-rank exchange can be exercised on machines
+without a GPU (world_size-2 gloo tests).  It is never importable from the product package."""
+import numpy as np
+
+from oracle import oracle as orc
+
+PRIOR_NIW, PRIOR_MULT = 0, 1
+
+
+class FakeWorker:
+    def __init__(self, prior, D, n_local, first_index=0, device=0, seed=0):
+        self.prior, self.D, self.n, self.first_index, self.seed = prior, int(D), int(n_local), int(first_index), int(seed)
+        self.K = 0
+        self.packed_stride = 1 + D + (D * (D + 1) // 2 if prior == PRIOR_NIW else 0)
+        self.labels = np.ones(self.n, np.int64); self.sub = np.ones(self.n, np.int64)
+
+    def close(self):
+        pass
+
+    def upload_points(self, X):
+        self.X = np.ascontiguousarray(X, np.float32)
+
+    def init_labels(self, init_clusters, epoch):
+        self.labels, self.sub = orc.init_labels(self.n, init_clusters, self.seed, epoch, self.first_index)
+
+    def set_labels(self, labels=None, sub=None):
+        if labels is not None:
+            self.labels = np.array(labels, np.int64)
+        if sub is not None:
+            self.sub = np.array(sub, np.int64)
+
+    def get_labels(self):
+        return self.labels.copy(), self.sub.copy()
+
+    def set_num_clusters(self, K):
+        self.K = int(K)
+
+    def set_params_niw_chol(self, mu, R, logdet, lr_weights, weights):
+        K = len(weights)
+        R = np.asarray(R, np.float32).reshape(3 * K, self.D, self.D).astype(np.float64)
+        R = np.triu(R)
+        self.invS = np.einsum("kji,kjl->kil", R, R).reshape(3 * K, -1).astype(np.float32)  # R'R
+        self.mu = np.asarray(mu, np.float32); self.logdet = np.asarray(logdet, np.float32)
+        self.logw = np.log(np.asarray(weights, np.float32)); self.loglr = np.log(np.asarray(lr_weights, np.float32))
+        self.K = K
+
+    def set_params_mult(self, logp, lr_weights, weights):
+        self.logp = np.asarray(logp, np.float32)
+        self.logw = np.log(np.asarray(weights, np.float32)); self.loglr = np.log(np.asarray(lr_weights, np.float32))
+        self.K = len(weights)
+
+    def sweep(self, epoch, final=False):
+        if self.n == 0:
+            return
+        if self.prior == PRIOR_NIW:
+            self.labels, self.sub = orc.sweep_niw(self.X, self.D, self.mu, self.invS, self.logdet, self.logw, self.loglr,
+                                                  self.seed, epoch, self.first_index, final)
+        else:
+            self.labels, self.sub = orc.sweep_mult(self.X, self.D, self.logp, self.logw, self.loglr, self.seed, epoch,
+                                                   self.first_index, final)
+
+    def suffstats_packed(self, cluster_idx=None):
+        K, D = self.K, self.D
+        out = np.zeros((2 * K, self.packed_stride))
+        if self.prior == PRIOR_NIW:
+            N, s, S = orc.suffstats_niw(self.X, D, self.labels, self.sub, K)
+        else:
+            N, s = orc.suffstats_mult(self.X, D, self.labels, self.sub, K)
+            N = N.astype(np.float64); s = s.astype(np.float64); S = None
+        sel = range(K) if cluster_idx is None else [int(i) - 1 for i in cluster_idx]
+        il = np.tril_indices(D)
+        for k in sel:
+            for w in (1, 2):
+                row = out[2 * k + w - 1]
+                row[0] = N[k, w]; row[1:1 + D] = s[k, w]
+                if S is not None:
+                    row[1 + D:] = S[k, w][il]
+        return out
+
+    def unpack(self, packed, K=None):
+        K = self.K if K is None else K
+        D = self.D
+        N = np.zeros((K, 3)); s = np.zeros((K, 3, D))
+        S = np.zeros((K, 3, D, D)) if self.prior == PRIOR_NIW else None
+        il = np.tril_indices(D)
+        for k in range(K):
+            for w in (1, 2):
+                row = packed[2 * k + w - 1]
+                N[k, w] = row[0]; s[k, w] = row[1:1 + D]
+                if S is not None:
+                    M = np.zeros((D, D)); M[il] = row[1 + D:]
+                    S[k, w] = M + np.tril(M, -1).T
+            N[k, 0] = N[k, 1] + N[k, 2]; s[k, 0] = s[k, 1] + s[k, 2]
+            if S is not None:
+                S[k, 0] = S[k, 1] + S[k, 2]
+        return (N, s, S) if S is not None else (N, s)
+
+    def split(self, idx, new_idx, epoch):
+        orc.split_relabel(self.labels, self.sub, idx, new_idx, self.seed, epoch, self.first_index)
+
+    def merge(self, idx, new_idx):
+        orc.merge_relabel(self.labels, self.sub, idx, new_idx)
+
+    def remove_empty(self, pts_count):
+        orc.remove_empty(self.labels, pts_count)
+
+    def reset_sublabels(self, idx, epoch):
+        orc.reset_sub(self.labels, self.sub, idx, self.seed, epoch, self.first_index)
+
+    def sync(self):
+        pass

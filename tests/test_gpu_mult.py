@@ -1,0 +1,108 @@
+"""GPU parity tests for the Multinomial worker path (histogram sufficient statistics + alpha'x log-likelihood).
+Tolerances: log-lik table rtol 1e-5 / atol 1e-3 (f32 contraction over D terms, different summation order);
+draw given the GPU's own table: bit-exact; labels vs the oracle's own f32 table: counted near-boundary flips;
+N and sum x: exact for count data (integer-valued Float64 sums)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    from __graft_entry__ import load_package
+    return load_package()
+
+
+def make_problem(D, n, K, trials, seed):
+    rng = np.random.default_rng(seed)
+    P = rng.dirichlet(np.ones(D) * 0.5, size=3 * K)
+    for k in range(K):  # sub-clusters are perturbations of the cluster
+        P[3 * k + 1] = 0.8 * P[3 * k] + 0.2 * rng.dirichlet(np.ones(D))
+        P[3 * k + 2] = 0.8 * P[3 * k] + 0.2 * rng.dirichlet(np.ones(D))
+    z = rng.integers(0, K, n)
+    X = np.stack([rng.multinomial(trials, P[3 * k]) for k in z]).astype(np.float32)
+    logp = np.log(np.maximum(P, 1e-30)).astype(np.float32)
+    w = rng.dirichlet(np.ones(K) * 5).astype(np.float32)
+    lr = rng.dirichlet(np.ones(2) * 5, size=K).astype(np.float32)
+    return dict(D=D, n=n, K=K, X=X, logp=logp, w=w, lr=lr, z=z)
+
+
+def worker(pkg, P, seed, first=0):
+    wk = pkg.Worker(pkg.PRIOR_MULT, P["D"], P["n"], first_index=first, device=0, seed=seed)
+    wk.upload_points(P["X"])
+    wk.set_params_mult(P["logp"], P["lr"], P["w"])
+    return wk
+
+
+@pytest.mark.parametrize("D,n,K,trials", [(100, 1000, 2, 50), (10, 3000, 5, 30), (1000, 3000, 32, 100), (37, 2049, 7, 20), (257, 1500, 50, 60)])
+def test_table_and_labels(pkg, D, n, K, trials):
+    P = make_problem(D, n, K, trials, seed=D + K)
+    seed, epoch, first = 99, 3, 12345
+    wk = worker(pkg, P, seed, first)
+    tab = wk.debug_loglik()
+    want = np.stack([P["X"].astype(np.float64) @ P["logp"][3 * k].astype(np.float64) + np.log(np.float64(P["w"][k])) for k in range(K)])
+    np.testing.assert_allclose(tab, want, rtol=1e-5, atol=1e-3)
+    wk.sweep(epoch)
+    lab, sub = wk.get_labels()
+    u0, u1 = orc.uniforms(seed, epoch, 0, first, n)
+    assert np.array_equal(orc.sample_log_cat(tab, u0), lab)           # draw arithmetic: bit-exact
+    olab, osub = orc.sweep_mult(P["X"], D, P["logp"], np.log(P["w"]), np.log(P["lr"]), seed, epoch, first)
+    assert (lab != olab).sum() <= max(2, int(3e-4 * n))
+    same = lab == olab
+    assert (sub[same] != osub[same]).sum() <= max(2, int(1e-3 * n))
+    assert (lab == P["z"] + 1).mean() > 0.5
+    wk.sweep(epoch + 1, final=True)
+    assert np.array_equal(wk.get_labels()[0], orc.argmax_rows(tab))
+    wk.close()
+
+
+def test_suffstats_golden_bit_exact(pkg, golden_dir):
+    """The reference's own checkpoint (test/save_load_test/checkpoint_20.jld2): Float32 points_sum, bit-exact."""
+    g = np.load(f"{golden_dir}/mnm_golden.npz")
+    X = np.ascontiguousarray(g["X"], np.float32)
+    wk = pkg.Worker(pkg.PRIOR_MULT, 100, 1000, device=0, seed=1)
+    wk.upload_points(X)
+    wk.set_labels(g["labels"], g["sub"])
+    wk.set_num_clusters(2)
+    N, s = wk.suffstats()
+    i = 0
+    for k in range(2):
+        for w in range(3):
+            assert np.array_equal(s[k, w].astype(np.float32), g["points_sum"][i])
+            assert np.array_equal((g["prior_alpha"] + s[k, w].astype(np.float32)).astype(np.float32), g["post_alpha"][i])
+            i += 1
+    assert N[:, 0].tolist() == [463, 537]
+    wk.close()
+
+
+@pytest.mark.parametrize("D,n,K", [(1000, 20000, 32), (100, 5000, 3), (7, 3000, 4)])
+def test_suffstats_vs_oracle(pkg, D, n, K):
+    rng = np.random.default_rng(D)
+    X = rng.poisson(0.3, size=(n, D)).astype(np.float32)
+    lab = rng.integers(1, K + 1, n); sub = rng.integers(1, 3, n)
+    wk = pkg.Worker(pkg.PRIOR_MULT, D, n, device=0, seed=1)
+    wk.upload_points(X)
+    wk.set_labels(lab, sub)
+    wk.set_num_clusters(K)
+    N, s = wk.suffstats()
+    oN, os_ = orc.suffstats_mult(X, D, lab, sub, K)
+    assert np.array_equal(N, oN.astype(np.float64)) and np.array_equal(s, os_.astype(np.float64))
+    wk.close()
+
+
+def test_fit_multinomial_module_test(pkg):
+    """test/module_tests.jl:49-60 (without the save/load half): mnmm data N=10^3, D=100, 20 components, 50 trials;
+    params of test/save_load_test/multinomial_params.jl (alpha=1e5, prior ones(100), 39 iterations): asserts K > 1."""
+    import importlib
+    host = importlib.import_module("dpmmsubclusters_jl_amd.host")
+    x, labels, _ = host.generate_mnmm_data(10 ** 3, 100, 20, 50, seed=12345)
+    hyper = host.multinomial_hyper(np.ones(100, np.float32))
+    dp = host.dp_parallel(x, hyper, np.float32(100000.0), 39, 1, None, False, False, 20)
+    assert dp[0].num_clusters > 1
+    # and a well-separated problem is actually recovered
+    x, labels, _ = host.generate_mnmm_data(20000, 50, 5, 200, seed=3)
+    res = host.fit(x, hyper.__class__(np.ones(50, np.float32)), 10.0, iters=60, burnout=5, gt=labels, seed=5, verbose=False)
+    assert res[4][-1] > 0.9
