@@ -155,6 +155,55 @@ HAPI int dpmmh_niw_posterior(int n, int D, double kappa0, double nu0, const doub
     return 0;
 }
 
+// Fused unpack + posterior for the clusters in `sel` (NULL: all K), in place on the sampler's persistent
+// arrays.  packed rows follow include/dpmm_hip.h: row 2k+s = {N, sum[D], lower triangle of S}.
+// Outputs, per distribution row 3k+w (w = 0 cluster = left + right, 1 left, 2 right):
+//   N[3K], sums[3K][D], S[3K][D*D], kappa/nu[3K], m[3K][D], U[3K][D*D], logdet_psi[3K].
+// Replaces update_suff_stats_posterior!'s per-cluster aggregate + update_splittable_cluster_params!
+// (src/local_clusters_actions.jl:237-251,137-147).
+HAPI int dpmmh_niw_update_from_packed(int K, int D, const double *packed, int64_t stride, const int32_t *sel, int nsel,
+                                      double kappa0, double nu0, const double *m0, const double *psi0, double *N,
+                                      double *sums, double *S, double *kappa, double *nu, double *m, double *U,
+                                      double *logdet_psi, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    const int nk = sel ? nsel : K;
+    const size_t DD = (size_t)D * D;
+#pragma omp parallel num_threads(nthreads)
+    {
+        std::vector<double> P(DD), psi(DD);
+#pragma omp for schedule(dynamic, 1) collapse(2)
+        for (int j = 0; j < nk; ++j)
+            for (int w = 0; w < 3; ++w) {
+                const int k = sel ? sel[j] : j;
+                const double *l = packed + (size_t)(2 * k) * stride, *r = l + stride;
+                const int row = 3 * k + w;
+                double *Sr = S + (size_t)row * DD, *sr = sums + (size_t)row * D;
+                const double cl = (w != 2) ? 1.0 : 0.0, cr = (w != 1) ? 1.0 : 0.0;   // c = l + r
+                N[row] = cl * l[0] + cr * r[0];
+                for (int d = 0; d < D; ++d) sr[d] = cl * l[1 + d] + cr * r[1 + d];
+                const double *tl = l + 1 + D, *tr = r + 1 + D;
+                for (int a = 0; a < D; ++a)
+                    for (int b = 0; b <= a; ++b) {
+                        const size_t t = (size_t)a * (a + 1) / 2 + b;
+                        const double v = cl * tl[t] + cr * tr[t];
+                        Sr[(size_t)a * D + b] = v;
+                        Sr[(size_t)b * D + a] = v;
+                    }
+                niw_posterior_one(D, kappa0, nu0, m0, psi0, N[row], sr, Sr, &kappa[row], &nu[row], m + (size_t)row * D, psi.data());
+                for (size_t e = 0; e < DD; ++e) P[e] = psi[e] * nu[row];
+                double *Uo = U + (size_t)row * DD;
+                if (reverse_cholesky(P.data(), D, Uo)) {
+                    double ld = 0.0;
+                    for (int d = 0; d < D; ++d) ld += log(Uo[(size_t)d * D + d]);
+                    logdet_psi[row] = 2.0 * ld - D * log(nu[row]);
+                } else {
+                    logdet_psi[row] = NAN;
+                }
+            }
+    }
+    return 0;
+}
+
 // logdet(psi') of the posterior for the MERGED statistics of cluster pairs (shared_actions.jl:21-38 needs
 // log_marginal_likelihood of the pooled cluster).  pairs[2p], pairs[2p+1] index rows of N/sum/S.
 HAPI int dpmmh_niw_logdet_pairs(int npairs, const int32_t *pairs, int D, double kappa0, double nu0, const double *m0,

@@ -76,6 +76,14 @@ class niw_hyperparams(distribution_hyper_params):
         kap, nu, m, _, U, ld = native.niw_posterior(self.kappa, self.nu, self.m, self.psi, N, sums, S, nthreads=nthreads)
         return dict(kappa=kap, nu=nu, m=m, U=U, logdet_psi=ld)
 
+    def empty_post(self, n):
+        D = self.dim
+        return dict(kappa=np.zeros(n), nu=np.zeros(n), m=np.zeros((n, D)), U=np.zeros((n, D, D)), logdet_psi=np.zeros(n))
+
+    def update_from_packed(self, packed, sel, N, sums, S, post, nthreads=None):
+        """Fused unpack + calc_posterior + factorisation, in place (native, threaded over clusters x {c,l,r})."""
+        native.niw_update_from_packed(packed, sel, self.kappa, self.nu, self.m, self.psi, N, sums, S, post, nthreads=nthreads)
+
     def log_marginal(self, post, N):
         """niw.jl:53-62 with lnΓ_D accumulated in Float64 (the reference's utils.jl:66-72 uses a Float32
         accumulator; that quirk is NOT reproduced -- see DESIGN.md)."""

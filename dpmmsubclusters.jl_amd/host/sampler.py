@@ -110,10 +110,18 @@ class DPMMSampler:
         packed = self.comm.reduce_stats(self.wk, idx)
         self._tic("stats_gpu", t0)
         t0 = time.perf_counter()
+        sel = np.arange(self.K) if ks is None else np.asarray(ks, np.int64)
+        if hasattr(self.prior, "update_from_packed"):
+            if self.post is None or len(self.post["kappa"]) != 3 * self.K:
+                self.post = self.prior.empty_post(3 * self.K)
+            self.prior.update_from_packed(packed, None if ks is None else sel, self.N, self.sums, self.S, self.post,
+                                          nthreads=self.nthreads)
+            self.points_count[sel] = np.rint(self.N[sel, 0]).astype(np.int64)
+            self._tic("posterior_host", t0)
+            return
         un = self.wk.unpack(packed, self.K)
         N, sums = un[0], un[1]
         S = un[2] if len(un) > 2 else None
-        sel = np.arange(self.K) if ks is None else np.asarray(ks, np.int64)
         self.N[sel] = N[sel]; self.sums[sel] = sums[sel]
         if S is not None:
             self.S[sel] = S[sel]

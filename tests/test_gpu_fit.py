@@ -56,3 +56,24 @@ def test_fit_d64_recovers_components(host):
     res = host.fit(x, 10.0, iters=60, burnout=8, gt=y, seed=7, verbose=False)
     assert res[4][-1] > 0.98
     assert 8 <= len(res[1]) <= 10
+
+
+def test_nccl_comm_path_single_rank(host):
+    """The multi-GPU exchange path (device-side packed buffer -> RCCL all-reduce -> host) with a 1-rank group:
+    must give exactly the LocalComm result (same seed, same data)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from dpmmsubclusters_jl_amd.host.comm import TorchDistComm
+    x, y, _, _ = host.generate_gaussian_data(20000, 8, 4, 100.0, seed=9)
+    ref = host.fit(x, 10.0, iters=30, burnout=5, seed=77, verbose=False)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29655", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        comm = TorchDistComm()
+        assert comm.backend == "nccl"
+        got = host.fit(x, 10.0, iters=30, burnout=5, seed=77, verbose=False, comm=comm)
+    finally:
+        dist.destroy_process_group()
+    assert np.array_equal(ref[0], got[0]) and np.array_equal(ref[7], got[7]) and ref[6] == got[6]
