@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -69,18 +70,42 @@ struct dpmm_ctx {
     int64_t packed_stride = 0;
     int32_t *d_small = nullptr;  // index lists for relabel kernels (Int32, <= 4*DPMM_MAX_CLUSTERS)
     std::vector<uint8_t> h_sel;
+    // pinned host staging for every per-step transfer (pageable copies stall for tens of ms now and then)
+    char *h_pin = nullptr;
+    size_t h_pin_bytes = 0;
 
     std::string err;
 };
 
+static const bool g_trace_slow = getenv("DPMM_TRACE_SLOW") != nullptr;
+static inline double now_ms() {
+    timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
+}
 #define HIPCHK(ctx, expr)                                                                               \
     do {                                                                                                \
+        const double t0__ = g_trace_slow ? now_ms() : 0.0;                                              \
         hipError_t e__ = (expr);                                                                        \
+        if (g_trace_slow) {                                                                             \
+            const double dt__ = now_ms() - t0__;                                                        \
+            if (dt__ > 5.0) fprintf(stderr, "[dpmm slow] %.2f ms in %s (line %d)\n", dt__, #expr, __LINE__); \
+        }                                                                                               \
         if (e__ != hipSuccess) {                                                                        \
             (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                            \
             return DPMM_EHIP;                                                                           \
         }                                                                                               \
     } while (0)
+
+static int ensure_pinned(dpmm_ctx *c, size_t bytes) {
+    if (bytes <= c->h_pin_bytes) return DPMM_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->h_pin) hipHostFree(c->h_pin);
+    c->h_pin = nullptr; c->h_pin_bytes = 0;
+    size_t cap = 1 << 20;
+    while (cap < bytes) cap *= 2;
+    HIPCHK(c, hipHostMalloc((void **)&c->h_pin, cap, hipHostMallocDefault));
+    c->h_pin_bytes = cap;
+    return DPMM_OK;
+}
 
 static int fail(dpmm_ctx *c, int code, const std::string &msg) {
     if (c) c->err = msg; else g_create_error = msg;
@@ -202,6 +227,7 @@ int dpmm_destroy(dpmm_ctx *c) {
     hipFree(c->dX); hipFree(c->dbins);
     hipFree(c->sb.tile_hist); hipFree(c->sb.bin_total); hipFree(c->sb.bin_start); hipFree(c->sb.item_start);
     hipFree(c->sb.perm); hipFree(c->sb.bin_sel); hipFree(c->d_small);
+    if (c->h_pin) hipHostFree(c->h_pin);
     for (auto &e : c->ev) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -294,11 +320,16 @@ int dpmm_set_params_niw_chol(dpmm_ctx *c, int K, const float *mu, const float *R
     const size_t D = (size_t)c->D;
     std::vector<float> cst;
     build_cst(cst, K, logdet, lr, w);
-    HIPCHK(c, hipMemcpyAsync(c->d_raw, R, sizeof(float) * 3 * K * D * D, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_mu, mu, sizeof(float) * 3 * K * D, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_cst, cst.data(), sizeof(float) * 3 * K, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, launch_niw_pack(c->d_raw, c->d_mu, c->d_Rp, c->d_mup, c->D, c->NB, 3 * K, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // host staging (cst) goes out of scope
+    const size_t nR = 3 * (size_t)K * D * D, nmu = 3 * (size_t)K * D, ncst = 3 * (size_t)K;
+    if (int rc = ensure_pinned(c, sizeof(float) * (nR + nmu + ncst))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // the staging buffer may still feed an earlier copy
+    float *hp = reinterpret_cast<float *>(c->h_pin);
+    memcpy(hp, R, sizeof(float) * nR);
+    memcpy(hp + nR, mu, sizeof(float) * nmu);
+    memcpy(hp + nR + nmu, cst.data(), sizeof(float) * ncst);
+    // the pack kernel reads R and mu straight from the pinned staging buffer (no copy-engine transfer)
+    HIPCHK(c, launch_copy_bytes(c->d_cst, hp + nR + nmu, sizeof(float) * ncst, c->stream));
+    HIPCHK(c, launch_niw_pack(hp, hp + nR, c->d_Rp, c->d_mup, c->D, c->NB, 3 * K, c->stream));
     c->K = K;
     c->have_params = true;
     return DPMM_OK;
@@ -339,11 +370,16 @@ int dpmm_set_params_mult(dpmm_ctx *c, int K, const float *logp, const float *lr,
     if (int rc = ensure_capacity(c, K)) return rc;
     std::vector<float> cst;
     build_cst(cst, K, nullptr, lr, w);
-    if (c->ldx != c->D) HIPCHK(c, hipMemsetAsync(c->d_raw, 0, sizeof(float) * 3 * K * (size_t)c->ldx, c->stream));
-    HIPCHK(c, hipMemcpy2DAsync(c->d_raw, sizeof(float) * c->ldx, logp, sizeof(float) * c->D, sizeof(float) * c->D, (size_t)3 * K, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_cst, cst.data(), sizeof(float) * 3 * K, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, launch_mult_pack(c->d_raw, c->d_Rp, 3 * K, c->ldx, c->stream));
+    const size_t nlp = 3 * (size_t)K * c->D, ncst = 3 * (size_t)K;
+    if (int rc = ensure_pinned(c, sizeof(float) * (nlp + ncst))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    float *hp = reinterpret_cast<float *>(c->h_pin);
+    memcpy(hp, logp, sizeof(float) * nlp);
+    memcpy(hp + nlp, cst.data(), sizeof(float) * ncst);
+    if (c->ldx != c->D) HIPCHK(c, hipMemsetAsync(c->d_raw, 0, sizeof(float) * 3 * K * (size_t)c->ldx, c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(c->d_raw, sizeof(float) * c->ldx, hp, sizeof(float) * c->D, sizeof(float) * c->D, (size_t)3 * K, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_cst, hp + nlp, sizeof(float) * ncst, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_mult_pack(c->d_raw, c->d_Rp, 3 * K, c->ldx, c->stream));
     c->K = K;
     c->have_params = true;
     return DPMM_OK;
@@ -447,8 +483,12 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx) {
             c->h_sel[2 * (idx[j] - 1) + 1] = 1;
         }
     }
+    const size_t out_bytes = sizeof(double) * 2 * c->K * (size_t)c->packed_stride;
+    if (int rc = ensure_pinned(c, out_bytes + nbins + 8)) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(c->h_pin + ((out_bytes + 3) & ~(size_t)3), c->h_sel.data(), nbins);
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->sb.bin_sel, c->h_sel.data(), nbins, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_copy_bytes(c->sb.bin_sel, c->h_pin + ((out_bytes + 3) & ~(size_t)3), nbins, c->stream));
     StatsArgs a{};
     a.X = c->dX; a.ldx = c->ldx; a.n = c->n; a.D = c->D; a.nbins = nbins; a.chunk = c->chunk;
     a.max_items = (int)((c->n + c->chunk - 1) / c->chunk) + nbins;
@@ -477,8 +517,23 @@ int dpmm_suffstats_packed_device(dpmm_ctx *c, const int64_t *idx, int n_idx, dou
 int dpmm_suffstats_packed(dpmm_ctx *c, const int64_t *idx, int n_idx, double *out) {
     if (!c || !out) return DPMM_EINVAL;
     if (int rc = run_stats(c, idx, n_idx)) return rc;
-    HIPCHK(c, hipMemcpyAsync(out, c->d_out, sizeof(double) * 2 * c->K * (size_t)c->packed_stride, hipMemcpyDeviceToHost, c->stream));
+    const size_t out_bytes = sizeof(double) * 2 * c->K * (size_t)c->packed_stride;
+    HIPCHK(c, launch_copy_bytes(c->h_pin, c->d_out, out_bytes, c->stream));
+    static const bool trace = getenv("DPMM_TRACE_SLOW") != nullptr;
+    timespec t0, t1, t2;
+    if (trace) clock_gettime(CLOCK_MONOTONIC, &t0);
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (trace) clock_gettime(CLOCK_MONOTONIC, &t1);
+    memcpy(out, c->h_pin, out_bytes);
+    if (trace) {
+        clock_gettime(CLOCK_MONOTONIC, &t2);
+        const double a = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6, b = (t2.tv_sec - t1.tv_sec) * 1e3 + (t2.tv_nsec - t1.tv_nsec) * 1e-6;
+        if (a + b > 10.0) {
+            float sm = 0, st = 0;
+            hipEventElapsedTime(&sm, c->ev[0], c->ev[1]); hipEventElapsedTime(&st, c->ev[2], c->ev[3]);
+            fprintf(stderr, "[dpmm slow] sync %.2f ms, memcpy %.2f ms; GPU events: sweep %.3f ms stats %.3f ms\n", a, b, sm, st);
+        }
+    }
     return DPMM_OK;
 }
 
@@ -519,8 +574,10 @@ static int upload_idx(dpmm_ctx *c, const int64_t *a, const int64_t *b, int n, in
             h[n + j] = (int32_t)(b[j] - 1);
         }
     }
-    HIPCHK(c, hipMemcpyAsync(c->d_small, h.data(), sizeof(int32_t) * h.size(), hipMemcpyHostToDevice, c->stream));
+    if (int rc = ensure_pinned(c, sizeof(int32_t) * h.size())) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(c->h_pin, h.data(), sizeof(int32_t) * h.size());
+    HIPCHK(c, launch_copy_bytes(c->d_small, c->h_pin, sizeof(int32_t) * h.size(), c->stream));
     return DPMM_OK;
 }
 
@@ -562,9 +619,11 @@ int dpmm_remove_empty(dpmm_ctx *c, const int64_t *pts_count, int K) {
             }
         map[l - 1] = v - 1;
     }
-    HIPCHK(c, hipMemcpyAsync(c->d_small, map.data(), sizeof(int32_t) * map.size(), hipMemcpyHostToDevice, c->stream));
-    if (c->n > 0) HIPCHK(c, launch_remap(c->dbins, c->n, c->d_small, c->stream));
+    if (int rc = ensure_pinned(c, sizeof(int32_t) * map.size())) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(c->h_pin, map.data(), sizeof(int32_t) * map.size());
+    HIPCHK(c, launch_copy_bytes(c->d_small, c->h_pin, sizeof(int32_t) * map.size(), c->stream));
+    if (c->n > 0) HIPCHK(c, launch_remap(c->dbins, c->n, c->d_small, c->stream));
     return DPMM_OK;
 }
 

@@ -63,6 +63,8 @@ hipError_t launch_mult_pack(const float *logp, float *Lp, int rows, int64_t ldx,
 int mult_tile_points();
 
 // ---- label bookkeeping (labels.hip)
+// dst/src: device or pinned-host pointers, 4-byte aligned; bytes rounded up to a multiple of 4
+hipError_t launch_copy_bytes(void *dst, const void *src, size_t bytes, hipStream_t s);
 hipError_t launch_init_labels(int32_t *bins, int64_t n, int64_t first_index, int init_clusters, uint64_t seed,
                               uint32_t epoch, hipStream_t s);
 hipError_t launch_bins_from_i64(int32_t *bins, const int64_t *labels, const int64_t *sub, int64_t n, hipStream_t s);

@@ -101,6 +101,18 @@ __global__ void reset_sub_kernel(int32_t *bins, int64_t n, int64_t first, const 
     }
 }
 
+// Per-step host<->device transfers go through pinned (GPU-addressable) staging and this kernel instead of
+// hipMemcpyAsync: the copy-engine path stalled the stream for tens of ms every dozen steps on the test box.
+__global__ void copy_words_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, int64_t nwords) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nwords; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+hipError_t launch_copy_bytes(void *dst, const void *src, size_t bytes, hipStream_t s) {
+    const int64_t nw = (int64_t)((bytes + 3) / 4);
+    if (nw == 0) return hipSuccess;
+    hipLaunchKernelGGL(copy_words_kernel, dim3(grid_for(nw)), dim3(256), 0, s, (uint32_t *)dst, (const uint32_t *)src, nw);
+    return hipGetLastError();
+}
+
 hipError_t launch_init_labels(int32_t *bins, int64_t n, int64_t first, int init_clusters, uint64_t seed, uint32_t epoch, hipStream_t s) {
     hipLaunchKernelGGL(init_labels_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, n, first, init_clusters, seed, epoch);
     return hipGetLastError();

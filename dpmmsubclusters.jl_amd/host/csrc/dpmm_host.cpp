@@ -17,15 +17,89 @@
 // so results do not depend on thread count or batch composition (all ranks of a multi-GPU run
 // draw identical parameters from identical all-reduced statistics).
 #include <math.h>
-#include <omp.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <string.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #define HAPI extern "C" __attribute__((visibility("default")))
 
 namespace {
+
+// Passive thread pool.  OpenMP's idle workers spin-wait after every parallel region; in a container
+// with a CFS CPU quota (the GPU box: 256 visible CPUs, 16 CPUs of quota) that burns the quota and
+// the whole process gets throttled for ~50 ms every 100 ms.  Workers here sleep on a condition
+// variable between jobs; items are handed out dynamically through an atomic counter.
+class Pool {
+  public:
+    static Pool &get() { static Pool p; return p; }
+    // run fn(item, slot) for item in [0, n) on up to `nthreads` threads (slot < nthreads identifies the thread)
+    void run(int n, int nthreads, const std::function<void(int, int)> &fn) {
+        if (n <= 0) return;
+        if (nthreads > n) nthreads = n;
+        if (nthreads <= 1) { for (int i = 0; i < n; ++i) fn(i, 0); return; }
+        std::unique_lock<std::mutex> call_lock(call_mu_);   // one job at a time
+        ensure(nthreads - 1);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &fn; n_ = n; next_.store(0); active_ = nthreads - 1; pending_ = nthreads - 1; ++gen_;
+        }
+        cv_.notify_all();
+        work(0);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [&] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+  private:
+    Pool() {}
+    ~Pool() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++gen_; }
+        cv_.notify_all();
+        for (auto &t : threads_) t.join();
+    }
+    void ensure(int nworkers) {
+        while ((int)threads_.size() < nworkers) {
+            const int id = (int)threads_.size();
+            threads_.emplace_back([this, id] { loop(id); });
+        }
+    }
+    void work(int slot) {
+        for (;;) {
+            const int i = next_.fetch_add(1);
+            if (i >= n_) break;
+            (*fn_)(i, slot);
+        }
+    }
+    void loop(int id) {
+        uint64_t seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return gen_ != seen; });
+            seen = gen_;
+            if (stop_) return;
+            if (id >= active_) continue;     // not needed for this job
+            lk.unlock();
+            work(id + 1);
+            lk.lock();
+            if (--pending_ == 0) done_cv_.notify_one();
+        }
+    }
+    std::mutex mu_, call_mu_;
+    std::condition_variable cv_, done_cv_;
+    std::vector<std::thread> threads_;
+    const std::function<void(int, int)> *fn_ = nullptr;
+    std::atomic<int> next_{0};
+    int n_ = 0, active_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
 
 struct Philox {
     uint32_t key[2];
@@ -133,11 +207,11 @@ HAPI int dpmmh_niw_posterior(int n, int D, double kappa0, double nu0, const doub
                              const double *N, const double *sum, const double *S, double *kappa, double *nu, double *m,
                              double *psi, double *U, double *logdet_psi, int nthreads) {
     if (nthreads < 1) nthreads = 1;
-#pragma omp parallel num_threads(nthreads)
     {
-        std::vector<double> P((size_t)D * D), Ul((size_t)D * D), pl((size_t)D * D);
-#pragma omp for schedule(dynamic, 1)
-        for (int i = 0; i < n; ++i) {
+        std::vector<std::vector<double>> scratch(nthreads, std::vector<double>(3 * (size_t)D * D));
+        Pool::get().run(n, nthreads, [&](int i, int slot) {
+            double *P_ = scratch[slot].data(), *Ul_ = P_ + (size_t)D * D, *pl_ = Ul_ + (size_t)D * D;
+            struct { double *p; double *data() { return p; } double &operator[](size_t e) { return p[e]; } } P{P_}, Ul{Ul_}, pl{pl_};
             double *pp = psi ? psi + (size_t)i * D * D : pl.data();
             niw_posterior_one(D, kappa0, nu0, m0, psi0, N[i], sum + (size_t)i * D, S + (size_t)i * D * D, &kappa[i], &nu[i],
                               m + (size_t)i * D, pp);
@@ -150,7 +224,7 @@ HAPI int dpmmh_niw_posterior(int n, int D, double kappa0, double nu0, const doub
             } else {
                 logdet_psi[i] = NAN;
             }
-        }
+        });
     }
     return 0;
 }
@@ -168,12 +242,13 @@ HAPI int dpmmh_niw_update_from_packed(int K, int D, const double *packed, int64_
     if (nthreads < 1) nthreads = 1;
     const int nk = sel ? nsel : K;
     const size_t DD = (size_t)D * D;
-#pragma omp parallel num_threads(nthreads)
     {
-        std::vector<double> P(DD), psi(DD);
-#pragma omp for schedule(dynamic, 1) collapse(2)
-        for (int j = 0; j < nk; ++j)
-            for (int w = 0; w < 3; ++w) {
+        std::vector<std::vector<double>> scratch(nthreads, std::vector<double>(2 * DD));
+        Pool::get().run(3 * nk, nthreads, [&](int item, int slot) {
+            {
+                const int j = item / 3, w = item % 3;
+                double *P = scratch[slot].data(), *psi_ = P + DD;
+                struct { double *p; double *data() { return p; } double &operator[](size_t e) { return p[e]; } } psi{psi_};
                 const int k = sel ? sel[j] : j;
                 const double *l = packed + (size_t)(2 * k) * stride, *r = l + stride;
                 const int row = 3 * k + w;
@@ -192,7 +267,7 @@ HAPI int dpmmh_niw_update_from_packed(int K, int D, const double *packed, int64_
                 niw_posterior_one(D, kappa0, nu0, m0, psi0, N[row], sr, Sr, &kappa[row], &nu[row], m + (size_t)row * D, psi.data());
                 for (size_t e = 0; e < DD; ++e) P[e] = psi[e] * nu[row];
                 double *Uo = U + (size_t)row * DD;
-                if (reverse_cholesky(P.data(), D, Uo)) {
+                if (reverse_cholesky(P, D, Uo)) {
                     double ld = 0.0;
                     for (int d = 0; d < D; ++d) ld += log(Uo[(size_t)d * D + d]);
                     logdet_psi[row] = 2.0 * ld - D * log(nu[row]);
@@ -200,6 +275,7 @@ HAPI int dpmmh_niw_update_from_packed(int K, int D, const double *packed, int64_
                     logdet_psi[row] = NAN;
                 }
             }
+        });
     }
     return 0;
 }
@@ -210,11 +286,13 @@ HAPI int dpmmh_niw_logdet_pairs(int npairs, const int32_t *pairs, int D, double 
                                 const double *psi0, const double *N, const double *sum, const double *S,
                                 double *logdet_psi, int nthreads) {
     if (nthreads < 1) nthreads = 1;
-#pragma omp parallel num_threads(nthreads)
     {
-        std::vector<double> Sm((size_t)D * D), sm(D), mm(D), P((size_t)D * D), Ul((size_t)D * D);
-#pragma omp for schedule(dynamic, 4)
-        for (int p = 0; p < npairs; ++p) {
+        const size_t DD = (size_t)D * D;
+        std::vector<std::vector<double>> scratch(nthreads, std::vector<double>(3 * DD + 2 * (size_t)D));
+        Pool::get().run(npairs, nthreads, [&](int p, int slot) {
+            struct V { double *p; double *data() { return p; } double &operator[](size_t e) { return p[e]; } };
+            double *base = scratch[slot].data();
+            V Sm{base}, P{base + DD}, Ul{base + 2 * DD}, sm{base + 3 * DD}, mm{base + 3 * DD + D};
             const int a = pairs[2 * p], b = pairs[2 * p + 1];
             const double *Sa = S + (size_t)a * D * D, *Sb = S + (size_t)b * D * D;
             for (size_t e = 0; e < (size_t)D * D; ++e) Sm[e] = Sa[e] + Sb[e];
@@ -229,7 +307,7 @@ HAPI int dpmmh_niw_logdet_pairs(int npairs, const int32_t *pairs, int D, double 
             } else {
                 logdet_psi[p] = NAN;
             }
-        }
+        });
     }
     return 0;
 }
@@ -240,11 +318,13 @@ HAPI int dpmmh_niw_sample(int n, int D, const double *kappa, const double *nu, c
                           uint64_t seed, uint32_t epoch, const int32_t *ids, float *mu, float *R, float *logdet_sigma,
                           int nthreads) {
     if (nthreads < 1) nthreads = 1;
-#pragma omp parallel num_threads(nthreads)
     {
-        std::vector<double> A((size_t)D * D), Rl((size_t)D * D), a(D), xi(D), v(D);
-#pragma omp for schedule(dynamic, 1)
-        for (int i = 0; i < n; ++i) {
+        const size_t DD = (size_t)D * D;
+        std::vector<std::vector<double>> scratch(nthreads, std::vector<double>(2 * DD + 3 * (size_t)D));
+        Pool::get().run(n, nthreads, [&](int i, int slot) {
+            struct V { double *p; double *data() { return p; } double &operator[](size_t e) { return p[e]; } };
+            double *base = scratch[slot].data();
+            V A{base}, Rl{base + DD}, a{base + 2 * DD}, xi{base + 2 * DD + D}, v{base + 2 * DD + 2 * D};
             Philox rng(seed, (uint32_t)ids[i], epoch, 16u);
             const double *Ui = U + (size_t)i * D * D;
             // Bartlett factor, lower triangular (column-major access below: A[r][c], r >= c)
@@ -253,7 +333,7 @@ HAPI int dpmmh_niw_sample(int n, int D, const double *kappa, const double *nu, c
                 A[(size_t)r * D + r] = sqrt(2.0 * rng.gamma(0.5 * (nu[i] - r)));
             }
             // R = A' U^-1 : row j of R solves r_j U[j:, j:] = A[j:, j]'
-            memset(Rl.data(), 0, sizeof(double) * (size_t)D * D);
+            memset(Rl.data(), 0, sizeof(double) * DD);
             double ld = 0.0;
             for (int j = 0; j < D; ++j) {
                 for (int r = j; r < D; ++r) a[r] = A[(size_t)r * D + j];
@@ -279,7 +359,7 @@ HAPI int dpmmh_niw_sample(int n, int D, const double *kappa, const double *nu, c
             for (int d = 0; d < D; ++d) mu[(size_t)i * D + d] = (float)(m[(size_t)i * D + d] + v[d] * isk);
             float *Ro = R + (size_t)i * D * D;
             for (size_t e = 0; e < (size_t)D * D; ++e) Ro[e] = (float)Rl[e];
-        }
+        });
     }
     return 0;
 }
@@ -288,8 +368,7 @@ HAPI int dpmmh_niw_sample(int n, int D, const double *kappa, const double *nu, c
 // fields of the fit() result, distributions/mv_gaussian.jl:12-18; never used on the hot path).
 HAPI int dpmmh_niw_expand(int n, int D, const float *R, double *inv_sigma, double *sigma, int nthreads) {
     if (nthreads < 1) nthreads = 1;
-#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
-    for (int i = 0; i < n; ++i) {
+    Pool::get().run(n, nthreads, [&](int i, int) {
         const float *Ri = R + (size_t)i * D * D;
         double *W = inv_sigma + (size_t)i * D * D;
         for (int a = 0; a < D; ++a)
@@ -317,7 +396,7 @@ HAPI int dpmmh_niw_expand(int n, int D, const float *R, double *inv_sigma, doubl
                     Sg[(size_t)a * D + b] = Sg[(size_t)b * D + a] = s;
                 }
         }
-    }
+    });
     return 0;
 }
 
@@ -325,11 +404,10 @@ HAPI int dpmmh_niw_expand(int n, int D, const float *R, double *inv_sigma, doubl
 HAPI int dpmmh_dirichlet_log(int n, int D, const float *alpha, uint64_t seed, uint32_t epoch, const int32_t *ids,
                              float *logp, int nthreads) {
     if (nthreads < 1) nthreads = 1;
-#pragma omp parallel num_threads(nthreads)
     {
-        std::vector<double> lg(D);
-#pragma omp for schedule(dynamic, 1)
-        for (int i = 0; i < n; ++i) {
+        std::vector<std::vector<double>> scratch(nthreads, std::vector<double>(D));
+        Pool::get().run(n, nthreads, [&](int i, int slot) {
+            double *lg = scratch[slot].data();
             Philox rng(seed, (uint32_t)ids[i], epoch, 17u);
             const float *al = alpha + (size_t)i * D;
             // work with log-gammas so that tiny shapes do not underflow: log g = log Gamma(a+1) draw + log(u)/a
@@ -346,9 +424,26 @@ HAPI int dpmmh_dirichlet_log(int n, int D, const float *alpha, uint64_t seed, ui
             for (int d = 0; d < D; ++d) s += exp(lg[d] - mx);
             const double lse = mx + log(s);
             for (int d = 0; d < D; ++d) logp[(size_t)i * D + d] = (float)(lg[d] - lse);
-        }
+        });
     }
     return 0;
 }
 
-HAPI int dpmmh_max_threads(void) { return omp_get_max_threads(); }
+HAPI int dpmmh_max_threads(void) { return (int)std::thread::hardware_concurrency(); }
+
+// self-test of the thread pool (used by tests): returns the number of distinct slots that executed items
+HAPI int dpmmh_pool_selftest(int n, int nthreads, int spin) {
+    std::vector<int> used(nthreads > 0 ? nthreads : 1, 0);
+    std::vector<double> sink(n > 0 ? n : 1);
+    Pool::get().run(n, nthreads, [&](int i, int slot) {
+        double s = 0;
+        for (int k = 0; k < spin; ++k) s += sin(k * 1e-3 + i);
+        sink[i] = s;
+        used[slot] += 1;
+    });
+    int c = 0;
+    for (int u : used) c += (u > 0);
+    if (spin < 0) return 0;
+    if (getenv("DPMM_POOL_DEBUG")) { for (int u : used) fprintf(stderr, "%d ", u); fprintf(stderr, "\n"); }
+    return c;
+}

@@ -36,13 +36,33 @@ def lib():
     return _LIB
 
 
+def _cpu_budget():
+    """CPUs this process may actually use: the cgroup CFS quota when there is one (a container can show 256 CPUs
+    and grant 16), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def default_threads():
     env = os.environ.get("DPMM_HOST_THREADS")
     if env:
         return max(1, int(env))
-    ncpu = os.cpu_count() or 1
     world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
-    return max(1, min(32, ncpu // max(1, 2 * world)))
+    # leave room for the HIP runtime's own threads and the Python thread
+    return max(1, min(32, (_cpu_budget() - 2 * world) // max(1, world)))
 
 
 def _d(a):
