@@ -29,6 +29,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense FP32 matrix peak (no TF32/xf32 on gfx950)
+# HBM bytes per point per launch of the D=64 sweep kernel, from the PMC counters (separate rocprofv3 --pmc passes,
+# FETCH_SIZE doubled per the gfx950 correction): profiles/r01_bench_niw_d64_n1e7_pmc.json -> (2*1270231.6 + 39062.5) KiB / 1e7
+PMC_BYTES_PER_POINT_D64 = (2 * 1270231.625 + 39062.5) * 1024 / 1e7
 
 
 def cpu_baseline(host, X_local, D, K, sampler, budget_points):
@@ -144,7 +147,8 @@ def main():
                    "points_per_gpu": n_local, "parallelism": f"points sharded over {world} GPU(s), 1 all-reduce of packed suff-stats per statistics pass"},
         "roofline": {"kernel": "niw_sweep_direct_kernel<4,4,2>" if D == 64 else "niw_sweep_kernel", "bound": "mfma",
                      "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                     "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                     "traffic": (PMC_BYTES_PER_POINT_D64 * n_local if D == 64 else None),
                      "avg_launch_ms": avg_sweep_ms, "algorithmic_flops_per_launch": flops_per_launch,
                      "stats_kernels_ms": float(np.mean(stats_ms))},
         "host_ms_per_step": {k: 1e3 * v / (args.steps + args.warmup + burnout + 1) for k, v in s.timers.items()},
