@@ -55,6 +55,8 @@ struct dpmm_ctx {
     float *d_Rp = nullptr;    // NIW packed fragments / MULT packed logp
     float *d_mup = nullptr;   // NIW padded mu
     float *d_cst = nullptr;   // [3K]
+    uint32_t *d_Lp16 = nullptr;  // MULT: 3-plane bf16 split of the log-probabilities (count data fast path)
+    int x_bf16_exact = 0;     // MULT: every x is exactly representable in bf16 (checked at upload)
     float *d_scratch = nullptr;
     int64_t scratch_stride = 0;
     bool have_params = false;
@@ -121,7 +123,8 @@ const char *dpmm_last_error(const dpmm_ctx *ctx) { return ctx ? ctx->err.c_str()
 
 static void free_params(dpmm_ctx *c) {
     hipFree(c->d_raw); hipFree(c->d_mu); hipFree(c->d_Rp); hipFree(c->d_mup); hipFree(c->d_cst);
-    hipFree(c->d_scratch); hipFree(c->d_slabs); hipFree(c->d_out);
+    hipFree(c->d_scratch); hipFree(c->d_slabs); hipFree(c->d_out); hipFree(c->d_Lp16);
+    c->d_Lp16 = nullptr;
     c->d_raw = c->d_mu = c->d_Rp = c->d_mup = c->d_cst = c->d_scratch = nullptr;
     c->d_slabs = c->d_out = nullptr;
 }
@@ -145,6 +148,7 @@ static int ensure_capacity(dpmm_ctx *c, int K) {
         const size_t NT = (size_t)(c->ldx + 15) / 16, NRB = (size_t)(3 * cap + 15) / 16;
         HIPCHK(c, hipMalloc(&c->d_raw, sizeof(float) * 3 * cap * (size_t)c->ldx));
         HIPCHK(c, hipMalloc(&c->d_Rp, sizeof(float) * NRB * NT * 256));
+        HIPCHK(c, hipMalloc(&c->d_Lp16, sizeof(uint32_t) * mult_pack_bf16_words(3 * cap, c->ldx)));
     }
     HIPCHK(c, hipMalloc(&c->d_cst, sizeof(float) * 3 * cap));
     // sweep scratch: one a_k row set per resident workgroup; the Multinomial kernel keeps all 3K rows
@@ -243,6 +247,16 @@ static int upload_common(dpmm_ctx *c, const float *X, int64_t ldx, hipMemcpyKind
     if (c->n > 0) {
         if (c->ldx != c->D) HIPCHK(c, hipMemsetAsync(c->dX, 0, sizeof(float) * (size_t)c->n * c->ldx, c->stream));
         HIPCHK(c, hipMemcpy2DAsync(c->dX, sizeof(float) * c->ldx, X, sizeof(float) * ldx, sizeof(float) * c->D, (size_t)c->n, kind, c->stream));
+        if (c->prior == DPMM_PRIOR_MULT) {
+            static const bool force_f32 = getenv("DPMM_MULT_FORCE_F32") != nullptr;
+            int *flag = reinterpret_cast<int *>(c->d_small);
+            HIPCHK(c, hipMemsetAsync(flag, 0, sizeof(int), c->stream));
+            HIPCHK(c, launch_bf16_exact_check(c->dX, c->n * c->ldx, flag, c->stream));
+            int h = 1;
+            HIPCHK(c, hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            c->x_bf16_exact = (h == 0 && !force_f32) ? 1 : 0;
+        }
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     c->have_points = true;
@@ -381,6 +395,7 @@ int dpmm_set_params_mult(dpmm_ctx *c, int K, const float *logp, const float *lr,
     HIPCHK(c, hipMemcpy2DAsync(c->d_raw, sizeof(float) * c->ldx, hp, sizeof(float) * c->D, sizeof(float) * c->D, (size_t)3 * K, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_cst, hp + nlp, sizeof(float) * ncst, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, launch_mult_pack(c->d_raw, c->d_Rp, 3 * K, c->ldx, c->stream));
+    if (c->x_bf16_exact) HIPCHK(c, launch_mult_pack_bf16(c->d_raw, c->d_Lp16, 3 * K, c->ldx, c->stream));
     c->K = K;
     c->have_params = true;
     return DPMM_OK;
@@ -433,7 +448,8 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
         a.scratch_by_tile = table ? 1 : 0;
         a.labels_only = table ? 1 : 0;
         a.bins = c->dbins; a.seed = c->seed; a.epoch = epoch; a.final_argmax = final_argmax;
-        HIPCHK(c, launch_mult_sweep(a, c->sweep_grid, c->stream));
+        if (c->x_bf16_exact) HIPCHK(c, launch_mult_sweep_bf16(a, c->d_Lp16, c->sweep_grid, c->stream));
+        else HIPCHK(c, launch_mult_sweep(a, c->sweep_grid, c->stream));
     }
     if (!table) {
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));

@@ -61,6 +61,11 @@ struct MultSweepArgs {
 hipError_t launch_mult_sweep(const MultSweepArgs &a, int grid, hipStream_t s);
 hipError_t launch_mult_pack(const float *logp, float *Lp, int rows, int64_t ldx, hipStream_t s);
 int mult_tile_points();
+// bf16 path (count data): exactness check of X, 3-plane bf16 split of the log-probabilities, sweep
+hipError_t launch_bf16_exact_check(const float *X, int64_t nwords, int *d_flag, hipStream_t s);
+size_t mult_pack_bf16_words(int rows, int64_t ldx);
+hipError_t launch_mult_pack_bf16(const float *logp, uint32_t *Lp16, int rows, int64_t ldx, hipStream_t s);
+hipError_t launch_mult_sweep_bf16(const MultSweepArgs &a, const uint32_t *Lp16, int grid, hipStream_t s);
 
 // ---- label bookkeeping (labels.hip)
 // dst/src: device or pinned-host pointers, 4-byte aligned; bytes rounded up to a multiple of 4

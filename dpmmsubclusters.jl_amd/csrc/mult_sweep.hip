@@ -137,6 +137,223 @@ __global__ void mult_pack_kernel(const float *__restrict__ logp, float *__restri
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// bf16 path.  Multinomial observations are counts: whenever every x is exactly representable in
+// bf16 (checked once at upload; integers up to 256 are) the products are formed on the bf16 matrix
+// cores, 16x the FP32-MFMA rate.  Each Float32 log-probability is split exactly into three bf16
+// terms (hi + mid + lo, 8 significant bits each), every bf16 x bf16 product is exact in the f32
+// accumulator, so the table differs from the f32-MFMA one only by summation order.
+//   v_mfma_f32_16x16x32_bf16: lane (i = l & 15, g = l >> 4): A[row i][k = 8g + j], B[k = 8g + j][col i], j = 0..7;
+//   C/D reg r: row 4g + r, col i.
+// A chunk for one k-step (32 features) = NRB x 3 planes x 1 KiB, staged global -> registers -> LDS one
+// k-step ahead and shared by the 4 waves; x (f32 in HBM) is loaded one k-step ahead and truncated to bf16.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+
+__device__ __forceinline__ u32x4 pack_bf16x8(const f32x4 lo, const f32x4 hi) {
+    u32x4 r;
+    r.x = (__float_as_uint(lo.x) >> 16) | (__float_as_uint(lo.y) & 0xffff0000u);
+    r.y = (__float_as_uint(lo.z) >> 16) | (__float_as_uint(lo.w) & 0xffff0000u);
+    r.z = (__float_as_uint(hi.x) >> 16) | (__float_as_uint(hi.y) & 0xffff0000u);
+    r.w = (__float_as_uint(hi.z) >> 16) | (__float_as_uint(hi.w) & 0xffff0000u);
+    return r;
+}
+
+template <int B_RBP>   // row blocks (16 parameter rows each) per pass over the features
+__global__ __launch_bounds__(256, (B_RBP <= 6 ? 2 : 1)) void mult_sweep_bf16_kernel(MultSweepArgs A, const uint32_t *__restrict__ Lp16, int NKS, int NRB) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2][B_RBP * 3 * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ci = lane & 15, g = lane >> 4;
+    const int K = A.K, rows = 3 * K;
+    const int64_t ntiles = (A.n + M_TILE - 1) / M_TILE;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t wbase = tile * M_TILE + (int64_t)wave * 64;
+        float *scr = A.scratch + (A.scratch_by_tile ? tile * M_TILE : (int64_t)blockIdx.x * M_TILE) + wave * 64;
+        const int64_t sstride = A.scratch_stride;
+        const float *xp[M_NG];
+        bool pv[M_NG];
+#pragma unroll
+        for (int n = 0; n < M_NG; ++n) {
+            const int64_t p = wbase + 16 * n + ci;
+            pv[n] = p < A.n;
+            xp[n] = A.X + (pv[n] ? p : 0) * A.ldx + 8 * g;
+        }
+        for (int rb0 = 0; rb0 < NRB; rb0 += B_RBP) {
+            const int nrb = min(B_RBP, NRB - rb0);
+            const int chunk_words = nrb * 3 * 256;                // uint32 words per k-step chunk
+            f32x4 acc[B_RBP][M_NG];
+#pragma unroll
+            for (int rb = 0; rb < B_RBP; ++rb)
+#pragma unroll
+                for (int n = 0; n < M_NG; ++n) acc[rb][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // chunk(ks) lives at Lp16 + (ks * NRB + rb0) * 768 words; the nrb row blocks of a pass are contiguous
+            u32x4 st[(B_RBP * 3 * 256 / 4 + 255) / 256];
+            auto prefetch = [&](int ks) {
+                const u32x4 *src = reinterpret_cast<const u32x4 *>(Lp16 + ((size_t)ks * NRB + rb0) * 768);
+#pragma unroll
+                for (int p = 0; p < (B_RBP * 3 * 256 / 4 + 255) / 256; ++p) {
+                    const int i4 = p * 256 + tid;
+                    if (i4 * 4 < chunk_words) st[p] = src[i4];
+                }
+            };
+            auto loadx = [&](int ks, f32x4 (&xl)[M_NG], f32x4 (&xh)[M_NG]) {
+                const int e = 32 * ks + 8 * g;
+#pragma unroll
+                for (int n = 0; n < M_NG; ++n) {
+                    xl[n] = (pv[n] && e < A.ldx) ? *reinterpret_cast<const f32x4 *>(xp[n] + 32 * ks) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    xh[n] = (pv[n] && e + 4 < A.ldx) ? *reinterpret_cast<const f32x4 *>(xp[n] + 32 * ks + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            };
+            f32x4 xl[M_NG], xh[M_NG];
+            prefetch(0);
+            loadx(0, xl, xh);
+            for (int ks = 0; ks < NKS; ++ks) {
+                uint32_t *buf = lds[ks & 1];
+                // the buffer being overwritten was last read two k-steps ago; one barrier per k-step suffices
+#pragma unroll
+                for (int p = 0; p < (B_RBP * 3 * 256 / 4 + 255) / 256; ++p) {
+                    const int i4 = p * 256 + tid;
+                    if (i4 * 4 < chunk_words) reinterpret_cast<u32x4 *>(buf)[i4] = st[p];
+                }
+                __syncthreads();
+                u32x4 xb[M_NG];
+#pragma unroll
+                for (int n = 0; n < M_NG; ++n) xb[n] = pack_bf16x8(xl[n], xh[n]);
+                if (ks + 1 < NKS) {
+                    prefetch(ks + 1);
+                    loadx(ks + 1, xl, xh);
+                }
+#pragma unroll
+                for (int rb = 0; rb < B_RBP; ++rb) {
+                    if (rb < nrb) {
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) {
+                            const u32x4 a = *reinterpret_cast<const u32x4 *>(buf + (rb * 3 + pl) * 256 + lane * 4);
+#pragma unroll
+                            for (int n = 0; n < M_NG; ++n)
+                                acc[rb][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, xb[n]), acc[rb][n], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int rb = 0; rb < B_RBP; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * (rb0 + rb) + 4 * g + r;
+                    if (rb < nrb && row < rows) {
+                        const float cst = A.cst[row];
+#pragma unroll
+                        for (int n = 0; n < M_NG; ++n) scr[(int64_t)row * sstride + 16 * n + ci] = acc[rb][n][r] + cst;
+                    }
+                }
+            __syncthreads();  // LDS buffers are reused by the next pass / tile
+        }
+        __syncthreads();
+        const int64_t myp = wbase + lane;
+        const bool valid = myp < A.n;
+        if (valid && !A.labels_only) {
+            const float *col = scr + lane;
+            const Philox4 rr = philox4x32_10(A.seed, (uint64_t)(A.first_index + myp), A.epoch, STREAM_SWEEP);
+            int z = 0;
+            float m = -INFINITY;
+            int best = 0;
+            bool nan_seen = false;
+            for (int k = 0; k < K; ++k) {
+                const float a = col[(int64_t)(3 * k) * sstride];
+                if (a != a) {
+                    if (!nan_seen) { nan_seen = true; best = k; }
+                } else if (a > m) {
+                    m = a;
+                    if (!nan_seen) best = k;
+                }
+            }
+            if (A.final_argmax) {
+                z = best;
+            } else if (m == -INFINITY) {
+                z = 0;
+            } else {
+                float s = 0.f;
+                for (int k = 0; k < K; ++k) s += exp_det(nan_to_ninf(col[(int64_t)(3 * k) * sstride]) - m);
+                const float t = u01(rr.v[0]) * s;
+                float cw = 0.f;
+                z = K - 1;
+                for (int k = 0; k < K; ++k) {
+                    cw += exp_det(nan_to_ninf(col[(int64_t)(3 * k) * sstride]) - m);
+                    if (!(cw < t)) { z = k; break; }
+                }
+            }
+            const float b0 = col[(int64_t)(3 * z + 1) * sstride], b1 = col[(int64_t)(3 * z + 2) * sstride];
+            A.bins[myp] = 2 * z + draw2(b0, b1, u01(rr.v[1]));
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ uint32_t bf16_rne_bits(float v) {  // round to nearest even, finite inputs
+    const uint32_t u = __float_as_uint(v);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+// Lp16[ks][rb][plane][lane][8 bf16] : element j of lane (i, g) = plane_p(logp[16 rb + i][32 ks + 8 g + j])
+__global__ void mult_pack_bf16_kernel(const float *__restrict__ logp, uint32_t *__restrict__ Lp16, int rows, int64_t ldx, int NKS, int NRB) {
+    const int64_t total = (int64_t)NKS * NRB * 3 * 256;   // uint32 words, two bf16 each
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(e & 3), lane = (int)((e >> 2) & 63);
+        int64_t t = e >> 8;
+        const int pl = (int)(t % 3); t /= 3;
+        const int rb = (int)(t % NRB), ks = (int)(t / NRB);
+        const int row = 16 * rb + (lane & 15);
+        uint32_t out = 0;
+        for (int h = 0; h < 2; ++h) {
+            const int col = 32 * ks + 8 * (lane >> 4) + 2 * w + h;
+            float v = (row < rows && col < ldx) ? logp[(size_t)row * ldx + col] : 0.f;
+            uint32_t bits = 0;
+            for (int p = 0; p <= pl; ++p) {
+                bits = bf16_rne_bits(v);
+                v -= __uint_as_float(bits << 16);
+            }
+            out |= (bits & 0xffffu) << (16 * h);
+        }
+        Lp16[e] = out;
+    }
+}
+
+// data check at upload: 1 if every element is exactly representable in bf16 (low 16 mantissa bits zero)
+__global__ void bf16_exact_kernel(const float *__restrict__ X, int64_t nwords, int *__restrict__ flag) {
+    int bad = 0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nwords; i += (int64_t)gridDim.x * blockDim.x)
+        bad |= (__float_as_uint(X[i]) & 0xffffu) != 0u;
+    if (bad) atomicOr(flag, 1);
+}
+
+hipError_t launch_bf16_exact_check(const float *X, int64_t nwords, int *d_flag, hipStream_t s) {
+    hipLaunchKernelGGL(bf16_exact_kernel, dim3(2048), dim3(256), 0, s, X, nwords, d_flag);
+    return hipGetLastError();
+}
+
+size_t mult_pack_bf16_words(int rows, int64_t ldx) {
+    const int NKS = (int)((ldx + 31) / 32), NRB = (rows + 15) / 16;
+    return (size_t)NKS * NRB * 3 * 256;
+}
+
+hipError_t launch_mult_pack_bf16(const float *logp, uint32_t *Lp16, int rows, int64_t ldx, hipStream_t s) {
+    const int NKS = (int)((ldx + 31) / 32), NRB = (rows + 15) / 16;
+    hipLaunchKernelGGL(mult_pack_bf16_kernel, dim3(512), dim3(256), 0, s, logp, Lp16, rows, ldx, NKS, NRB);
+    return hipGetLastError();
+}
+
+hipError_t launch_mult_sweep_bf16(const MultSweepArgs &a, const uint32_t *Lp16, int grid, hipStream_t s) {
+    const int NKS = (int)((a.ldx + 31) / 32), NRB = (3 * a.K + 15) / 16;
+    if (NRB <= 2) hipLaunchKernelGGL(mult_sweep_bf16_kernel<2>, dim3(grid), dim3(256), 0, s, a, Lp16, NKS, NRB);
+    else if (NRB <= 4) hipLaunchKernelGGL(mult_sweep_bf16_kernel<4>, dim3(grid), dim3(256), 0, s, a, Lp16, NKS, NRB);
+    else if (NRB <= 6) hipLaunchKernelGGL(mult_sweep_bf16_kernel<6>, dim3(grid), dim3(256), 0, s, a, Lp16, NKS, NRB);
+    else hipLaunchKernelGGL(mult_sweep_bf16_kernel<8>, dim3(grid), dim3(256), 0, s, a, Lp16, NKS, NRB);
+    return hipGetLastError();
+}
+
 int mult_tile_points() { return M_TILE; }
 
 hipError_t launch_mult_pack(const float *logp, float *Lp, int rows, int64_t ldx, hipStream_t s) {

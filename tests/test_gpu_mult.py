@@ -106,3 +106,18 @@ def test_fit_multinomial_module_test(pkg):
     x, labels, _ = host.generate_mnmm_data(20000, 50, 5, 200, seed=3)
     res = host.fit(x, hyper.__class__(np.ones(50, np.float32)), 10.0, iters=60, burnout=5, gt=labels, seed=5, verbose=False)
     assert res[4][-1] > 0.9
+
+
+def test_f32_fallback_for_non_count_data(pkg):
+    """Data that is not exactly representable in bf16 must take the FP32-MFMA kernel and give the same quality."""
+    P = make_problem(100, 3000, 4, 40, seed=77)
+    P["X"] = (P["X"] + np.float32(0.3)).astype(np.float32)      # 0.3 is not bf16-exact
+    wk = worker(pkg, P, seed=5)
+    tab = wk.debug_loglik()
+    want = np.stack([P["X"].astype(np.float64) @ P["logp"][3 * k].astype(np.float64) + np.log(np.float64(P["w"][k])) for k in range(4)])
+    np.testing.assert_allclose(tab, want, rtol=1e-5, atol=1e-3)
+    wk.sweep(1)
+    lab, _ = wk.get_labels()
+    u0, _ = orc.uniforms(5, 1, 0, 0, 3000)
+    assert np.array_equal(orc.sample_log_cat(tab, u0), lab)
+    wk.close()
