@@ -314,9 +314,41 @@ HAPI int dpmmh_niw_logdet_pairs(int npairs, const int32_t *pairs, int D, double 
 
 // Draw (mu, R, logdet Sigma) for n prepared posteriors.  ids[i] keys the random stream of draw i.
 // want_sigma: also return Sigma (Float32 [n][D*D]) -- only needed for the user-facing result of fit().
+// Standard-normal noise of the draws (strictly-lower Bartlett entries, row-major [n][D*D], and xi [n][D]).
+// It depends on (seed, epoch, id) only -- not on the statistics -- so the sampler generates it while the GPU
+// sweeps and hands it to dpmmh_niw_sample_noise afterwards.
+HAPI int dpmmh_niw_noise(int n, int D, uint64_t seed, uint32_t epoch, const int32_t *ids, double *A_noise, double *xi,
+                         int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    Pool::get().run(n, nthreads, [&](int i, int) {
+        Philox rng(seed, (uint32_t)ids[i], epoch, 16u);
+        double *A = A_noise + (size_t)i * D * D;
+        for (int r = 0; r < D; ++r)
+            for (int c = 0; c < r; ++c) A[(size_t)r * D + c] = rng.normal();
+        for (int d = 0; d < D; ++d) xi[(size_t)i * D + d] = rng.normal();
+    });
+    return 0;
+}
+
+static int niw_sample_impl(int n, int D, const double *kappa, const double *nu, const double *m, const double *U,
+                           uint64_t seed, uint32_t epoch, const int32_t *ids, const double *A_noise, const double *xi_in,
+                           float *mu, float *R, float *logdet_sigma, int nthreads);
+
+HAPI int dpmmh_niw_sample_noise(int n, int D, const double *kappa, const double *nu, const double *m, const double *U,
+                                uint64_t seed, uint32_t epoch, const int32_t *ids, const double *A_noise, const double *xi,
+                                float *mu, float *R, float *logdet_sigma, int nthreads) {
+    return niw_sample_impl(n, D, kappa, nu, m, U, seed, epoch, ids, A_noise, xi, mu, R, logdet_sigma, nthreads);
+}
+
 HAPI int dpmmh_niw_sample(int n, int D, const double *kappa, const double *nu, const double *m, const double *U,
                           uint64_t seed, uint32_t epoch, const int32_t *ids, float *mu, float *R, float *logdet_sigma,
                           int nthreads) {
+    return niw_sample_impl(n, D, kappa, nu, m, U, seed, epoch, ids, nullptr, nullptr, mu, R, logdet_sigma, nthreads);
+}
+
+static int niw_sample_impl(int n, int D, const double *kappa, const double *nu, const double *m, const double *U,
+                           uint64_t seed, uint32_t epoch, const int32_t *ids, const double *A_noise, const double *xi_in,
+                           float *mu, float *R, float *logdet_sigma, int nthreads) {
     if (nthreads < 1) nthreads = 1;
     {
         const size_t DD = (size_t)D * D;
@@ -325,12 +357,14 @@ HAPI int dpmmh_niw_sample(int n, int D, const double *kappa, const double *nu, c
             struct V { double *p; double *data() { return p; } double &operator[](size_t e) { return p[e]; } };
             double *base = scratch[slot].data();
             V A{base}, Rl{base + DD}, a{base + 2 * DD}, xi{base + 2 * DD + D}, v{base + 2 * DD + 2 * D};
-            Philox rng(seed, (uint32_t)ids[i], epoch, 16u);
+            // normals: stream 16 (identical whether pre-generated or not); chi-squares: stream 18
+            Philox rng(seed, (uint32_t)ids[i], epoch, 16u), rng_chi(seed, (uint32_t)ids[i], epoch, 18u);
             const double *Ui = U + (size_t)i * D * D;
-            // Bartlett factor, lower triangular (column-major access below: A[r][c], r >= c)
+            // Bartlett factor, lower triangular (A[r][c], r >= c)
+            const double *An = A_noise ? A_noise + (size_t)i * D * D : nullptr;
             for (int r = 0; r < D; ++r) {
-                for (int c = 0; c < r; ++c) A[(size_t)r * D + c] = rng.normal();
-                A[(size_t)r * D + r] = sqrt(2.0 * rng.gamma(0.5 * (nu[i] - r)));
+                for (int c = 0; c < r; ++c) A[(size_t)r * D + c] = An ? An[(size_t)r * D + c] : rng.normal();
+                A[(size_t)r * D + r] = sqrt(2.0 * rng_chi.gamma(0.5 * (nu[i] - r)));
             }
             // R = A' U^-1 : row j of R solves r_j U[j:, j:] = A[j:, j]'
             memset(Rl.data(), 0, sizeof(double) * DD);
@@ -348,7 +382,7 @@ HAPI int dpmmh_niw_sample(int n, int D, const double *kappa, const double *nu, c
             }
             logdet_sigma[i] = (float)(-2.0 * ld);
             // mu = m + R^-1 xi / sqrt(kappa)
-            for (int d = 0; d < D; ++d) xi[d] = rng.normal();
+            for (int d = 0; d < D; ++d) xi[d] = xi_in ? xi_in[(size_t)i * D + d] : rng.normal();
             for (int r = D - 1; r >= 0; --r) {
                 double s = xi[r];
                 const double *rr = Rl.data() + (size_t)r * D;

@@ -113,6 +113,28 @@ def niw_sample(kappa, nu, m, U, seed, epoch, ids, nthreads=None):
     return mu, R, ld
 
 
+def niw_noise(n, D, seed, epoch, ids, nthreads=None):
+    """Pre-generate the standard-normal noise of `n` draws (see dpmmh_niw_noise)."""
+    ids = np.ascontiguousarray(ids, np.int32)
+    A = np.empty((n, D, D)); xi = np.empty((n, D))
+    lib().dpmmh_niw_noise(n, D, ctypes.c_uint64(seed), ctypes.c_uint32(epoch), _p(ids, _i32p), _p(A, _f64p), _p(xi, _f64p),
+                          nthreads or default_threads())
+    return A, xi
+
+
+def niw_sample_noise(kappa, nu, m, U, seed, epoch, ids, A, xi, nthreads=None):
+    kappa = _d(kappa).ravel(); n = kappa.size
+    nu = _d(nu).ravel(); m = _d(m); D = m.shape[-1]
+    m = m.reshape(n, D); U = _d(U).reshape(n, D, D)
+    ids = np.ascontiguousarray(ids, np.int32)
+    assert A.shape[0] >= n and A.flags.c_contiguous and xi.flags.c_contiguous
+    mu = np.empty((n, D), np.float32); R = np.empty((n, D, D), np.float32); ld = np.empty(n, np.float32)
+    lib().dpmmh_niw_sample_noise(n, D, _p(kappa, _f64p), _p(nu, _f64p), _p(m, _f64p), _p(U, _f64p), ctypes.c_uint64(seed),
+                                 ctypes.c_uint32(epoch), _p(ids, _i32p), _p(A, _f64p), _p(xi, _f64p), _p(mu, _f32p),
+                                 _p(R, _f32p), _p(ld, _f32p), nthreads or default_threads())
+    return mu, R, ld
+
+
 def niw_expand(R, want_sigma=True, nthreads=None):
     R = np.ascontiguousarray(R, np.float32)
     n, D = R.shape[0], R.shape[-1]

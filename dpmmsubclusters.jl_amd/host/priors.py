@@ -104,10 +104,19 @@ class niw_hyperparams(distribution_hyper_params):
         post = dict(nu=self.nu + Np, kappa=self.kappa + Np, logdet_psi=ld)
         return self.log_marginal(post, Np)
 
-    def sample(self, post, seed, epoch, ids, nthreads=None):
-        """Batch sample_distribution (niw.jl:34-40): μ, R (invΣ = R'R), logdetΣ as Float32."""
-        mu, R, ld = native.niw_sample(post["kappa"], post["nu"], post["m"], post["U"], seed, epoch, ids, nthreads=nthreads)
+    def sample(self, post, seed, epoch, ids, nthreads=None, noise=None):
+        """Batch sample_distribution (niw.jl:34-40): μ, R (invΣ = R'R), logdetΣ as Float32.
+        `noise` = (A, xi) from `draw_noise` for the same (seed, epoch, ids[0..n)) -- identical result, less work."""
+        if noise is not None and noise[0].shape[0] >= len(ids):
+            mu, R, ld = native.niw_sample_noise(post["kappa"], post["nu"], post["m"], post["U"], seed, epoch, ids,
+                                                noise[0], noise[1], nthreads=nthreads)
+        else:
+            mu, R, ld = native.niw_sample(post["kappa"], post["nu"], post["m"], post["U"], seed, epoch, ids, nthreads=nthreads)
         return dict(mu=mu, R=R, logdet=ld)
+
+    def draw_noise(self, n, seed, epoch, nthreads=None):
+        """Statistics-independent part of `sample` (standard normals); the sampler runs it while the GPU sweeps."""
+        return native.niw_noise(n, self.dim, seed, epoch, np.arange(n), nthreads=nthreads)
 
     def upload(self, worker, params, lr_weights, weights):
         K = len(weights)

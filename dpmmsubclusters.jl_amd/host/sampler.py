@@ -55,9 +55,11 @@ class DPMMSampler:
         self.split_stop = split_stop
         self.nthreads = nthreads
         self.rng = np.random.Generator(np.random.Philox(key=self.seed))
-        self.epoch = 0
+        self.epoch = 0          # device-side randomised calls (stream-unique)
+        self.draw_epoch = 1 << 20   # host parameter draws: separate, predictable counter (noise is pre-generated)
         self.K = 0
         self.timers = {}
+        self._noise_job = None
 
     # ------------------------------------------------------------------ small helpers
     def _next_epoch(self):
@@ -100,6 +102,31 @@ class DPMMSampler:
         K, D = self.K, self.prior.dim
         return self.N.reshape(3 * K), self.sums.reshape(3 * K, D), (self.S.reshape(3 * K, D, D) if self.S is not None else None)
 
+    # ------------------------------------------------------------------ noise prefetch (overlaps the GPU sweep)
+    def _start_noise(self):
+        """Generate the standard-normal part of the NEXT parameter draws on a helper thread while the GPU sweeps."""
+        if not hasattr(self.prior, "draw_noise"):
+            return
+        import threading
+        rows = 3 * (self.K + 4)          # head-room for clusters born from splits
+        job = dict(epoch=self.draw_epoch + 1, rows=rows, out=None)
+
+        def work():
+            job["out"] = self.prior.draw_noise(rows, self.seed, job["epoch"], nthreads=self.nthreads)
+
+        job["thread"] = threading.Thread(target=work, daemon=True)
+        job["thread"].start()
+        self._noise_job = job
+
+    def _take_noise(self, epoch, rows):
+        job, self._noise_job = self._noise_job, None
+        if job is None:
+            return None
+        job["thread"].join()
+        if job["epoch"] != epoch or job["rows"] < rows:
+            return None
+        return job["out"]
+
     # ------------------------------------------------------------------ statistics (step 5)
     def update_suff_stats_posterior(self, ks=None):
         """ks: 0-based cluster ids (None = all).  One GPU statistics pass + (multi-GPU) one all-reduce."""
@@ -139,7 +166,12 @@ class DPMMSampler:
     def sample_clusters(self):
         t0 = time.perf_counter()
         K = self.K
-        self.params = self.prior.sample(self.post, self.seed, self._next_epoch(), np.arange(3 * K), nthreads=self.nthreads)
+        self.draw_epoch += 1
+        noise = self._take_noise(self.draw_epoch, 3 * K)
+        if noise is not None:
+            self.params = self.prior.sample(self.post, self.seed, self.draw_epoch, np.arange(3 * K), nthreads=self.nthreads, noise=noise)
+        else:
+            self.params = self.prior.sample(self.post, self.seed, self.draw_epoch, np.arange(3 * K), nthreads=self.nthreads)
         self._tic("sample_params_host", t0)
         t0 = time.perf_counter()
         half = self.alpha / 2
@@ -303,6 +335,7 @@ class DPMMSampler:
         self._tic("upload_params", t0)
         t0 = time.perf_counter()
         self.wk.sweep(self._next_epoch(), final)                 # 3 + 4 (asynchronous)
+        self._start_noise()                                      # host works while the GPU sweeps
         self._tic("sweep_launch", t0)
         self.update_suff_stats_posterior()                       # 5
         self.reset_bad_clusters()                                # 6
