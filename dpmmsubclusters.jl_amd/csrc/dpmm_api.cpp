@@ -47,6 +47,7 @@ struct dpmm_ctx {
     float *dX = nullptr;
     int32_t *dbins = nullptr;
     bool have_points = false, have_labels = false;
+    bool have_perm = false;   // sb.perm holds a permutation of [0,n) sorted by a recent labelling
 
     // parameters
     int K = 0, Kcap = 0;
@@ -218,6 +219,7 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
     CHK_CREATE(hipMalloc(&c->sb.item_start, sizeof(int32_t) * (nbmax + 1)));
     CHK_CREATE(hipMalloc(&c->sb.perm, sizeof(int32_t) * nalloc));
     CHK_CREATE(hipMalloc(&c->sb.bin_sel, nbmax));
+    CHK_CREATE(hipMalloc(&c->sb.perm_total, sizeof(int32_t)));
     CHK_CREATE(hipMalloc(&c->d_small, sizeof(int32_t) * 4 * DPMM_MAX_CLUSTERS));
 #undef CHK_CREATE
     *out = c;
@@ -231,7 +233,7 @@ int dpmm_destroy(dpmm_ctx *c) {
     free_params(c);
     hipFree(c->dX); hipFree(c->dbins);
     hipFree(c->sb.tile_hist); hipFree(c->sb.bin_total); hipFree(c->sb.bin_start); hipFree(c->sb.item_start);
-    hipFree(c->sb.perm); hipFree(c->sb.bin_sel); hipFree(c->d_small);
+    hipFree(c->sb.perm); hipFree(c->sb.bin_sel); hipFree(c->sb.perm_total); hipFree(c->d_small);
     if (c->h_pin) hipHostFree(c->h_pin);
     for (auto &e : c->ev) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -426,6 +428,11 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
         a.labels_only = table ? 1 : 0;
         a.bins = c->dbins; a.seed = c->seed; a.epoch = epoch; a.final_argmax = final_argmax;
         {
+            static const bool no_order = getenv("DPMM_NIW_NO_ORDER") != nullptr;
+            a.order = (!table && c->have_perm && !no_order) ? c->sb.perm : nullptr;
+            a.order_total = c->sb.perm_total;
+        }
+        {
             static const int stag = [] { const char *e = getenv("DPMM_NIW_STAGGER"); return e ? atoi(e) : 0; }();
             if (stag > 0 && !table && c->NB <= 4) {
                 unsigned *ctr = reinterpret_cast<unsigned *>(c->d_small + 4 * DPMM_MAX_CLUSTERS - 4);
@@ -516,6 +523,7 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx) {
         HIPCHK(c, hipMemsetAsync(c->sb.bin_total, 0, sizeof(int32_t) * nbins, c->stream));
     }
     HIPCHK(c, launch_sort_finish(c->dbins, a, c->stream));
+    c->have_perm = c->n > 0;
     if (c->prior == DPMM_PRIOR_NIW) HIPCHK(c, launch_niw_stats(a, c->stream));
     else HIPCHK(c, launch_mult_stats(a, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));

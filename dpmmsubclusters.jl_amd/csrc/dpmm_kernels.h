@@ -26,6 +26,8 @@ struct NiwSweepArgs {
     int scratch_by_tile; // 1: base = tile*TILE (full table, debug) ; 0: base = blockIdx*TILE
     int labels_only;     // 1: stop after the label phase (debug_loglik)
     int32_t *bins;       // out
+    const int32_t *order_total; // device scalar: number of points `order` covers (must equal n, else identity is used)
+    const int32_t *order; // processing order (permutation of [0,n), e.g. sorted by the previous bins) or null = identity
     uint64_t seed;
     uint32_t epoch;
     int final_argmax;
@@ -92,6 +94,7 @@ struct SortBufs {
     int32_t *perm;        // [n]
     int32_t *item_start;  // [nbins + 1]
     uint8_t *bin_sel;     // [nbins] 1 = compute statistics for this bin
+    int32_t *perm_total;  // [1] number of points placed in perm by the last sort (== n when every label was in range)
 };
 
 hipError_t launch_sort_by_bin(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s);

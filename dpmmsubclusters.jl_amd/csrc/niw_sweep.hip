@@ -183,6 +183,7 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
     const int ci = lane & 15;  // column (point within a 16-group) for the B operand
     const int g = lane >> 4;   // k-slot / row group
     const int K = A.K;
+    const bool use_order = A.order != nullptr && *A.order_total == (int32_t)A.n;
     const bool owner = lane < C::WPTS;  // lane `lane` draws for point `lane` of the wave
 
     QuadEval<NB, NG, CH> ev;
@@ -193,16 +194,18 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
         f32x4 x[NG][NB];
 #pragma unroll
         for (int n = 0; n < NG; ++n) {
-            const int64_t p = wbase + 16 * n + ci;
+            const int64_t pos = wbase + 16 * n + ci;
+            const int64_t p = (pos < A.n && use_order) ? (int64_t)A.order[pos] : pos;
 #pragma unroll
             for (int t = 0; t < NB; ++t) {
                 const int e = 16 * t + 4 * g;
-                x[n][t] = (p < A.n && e < A.ldx) ? *reinterpret_cast<const f32x4 *>(A.X + p * A.ldx + e)
-                                                  : (f32x4){0.f, 0.f, 0.f, 0.f};
+                x[n][t] = (pos < A.n && e < A.ldx) ? *reinterpret_cast<const f32x4 *>(A.X + p * A.ldx + e)
+                                                    : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
-        const int64_t myp = wbase + lane;  // owner's point
-        const bool valid = owner && myp < A.n;
+        const int64_t mypos = wbase + lane;  // owner's position in processing order
+        const bool valid = owner && mypos < A.n;
+        const int64_t myp = (valid && use_order) ? (int64_t)A.order[mypos] : mypos;   // owner's point
         float *scr = A.scratch + (A.scratch_by_tile ? tile * C::TILE : (int64_t)blockIdx.x * C::TILE) + wave * C::WPTS + lane;
         const int64_t sstride = A.scratch_stride;
 
@@ -417,6 +420,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
     const int tid = threadIdx.x, lane = tid & 63;
     const int ci = lane & 15, g = lane >> 4;
     const int K = A.K;
+    const bool use_order = A.order != nullptr && *A.order_total == (int32_t)A.n;
     const bool owner = lane < WPTS;
     const int64_t nwtiles = (A.n + WPTS - 1) / WPTS;              // one tile per wave
     const int64_t wave_id = (int64_t)blockIdx.x * 4 + (tid >> 6);
@@ -448,20 +452,22 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
         f32x4 x[NG][NB];
 #pragma unroll
         for (int n = 0; n < NG; ++n) {
-            const int64_t p = wbase + 16 * n + ci;
+            const int64_t pos = wbase + 16 * n + ci;
+            const int64_t p = (pos < A.n && use_order) ? (int64_t)A.order[pos] : pos;
 #pragma unroll
             for (int t = 0; t < NB; ++t) {
                 const int e = 16 * t + 4 * g;
-                x[n][t] = (p < A.n && e < A.ldx) ? *reinterpret_cast<const f32x4 *>(A.X + p * A.ldx + e)
-                                                  : (f32x4){0.f, 0.f, 0.f, 0.f};
+                x[n][t] = (pos < A.n && e < A.ldx) ? *reinterpret_cast<const f32x4 *>(A.X + p * A.ldx + e)
+                                                    : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
 #ifdef DPMM_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         STAMP(s1);
-        const int64_t myp = wbase + lane;
-        const bool valid = owner && myp < A.n;
+        const int64_t mypos = wbase + lane;    // position in processing order
+        const bool valid = owner && mypos < A.n;
+        const int64_t myp = (valid && use_order) ? (int64_t)A.order[mypos] : mypos;   // the point this lane draws for
         float *scr = A.scratch + (A.scratch_by_tile ? tile * WPTS : wave_id * WPTS) + lane;
         const int64_t sstride = A.scratch_stride;
 

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void scan_tiles_kernel(int32_t *__restrict__ t
 // bin_start[b] = sum_{b'<b} total ; item_start[b] = sum_{b'<b} ceil(sel*total / chunk)
 __global__ __launch_bounds__(256) void starts_kernel(const int32_t *__restrict__ bin_total, const uint8_t *__restrict__ bin_sel,
                                                      int nbins, int chunk, int32_t *__restrict__ bin_start,
-                                                     int32_t *__restrict__ item_start) {
+                                                     int32_t *__restrict__ item_start, int32_t *__restrict__ perm_total) {
     __shared__ int pa[256], pb[256];
     const int per = (nbins + 255) / 256;
     const int lo = threadIdx.x * per, hi = min(lo + per, nbins);
@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256) void starts_kernel(const int32_t *__restrict__
     if (threadIdx.x == 255) {
         bin_start[nbins] = pa[255];
         item_start[nbins] = pb[255];
+        if (perm_total) *perm_total = pa[255];
     }
 }
 
@@ -392,7 +393,7 @@ hipError_t launch_mult_stats(const StatsArgs &a, hipStream_t s) {
 hipError_t launch_sort_finish(const int32_t *bins, const StatsArgs &a, hipStream_t s) {
     const int nt = (int)((a.n + SORT_TILE - 1) / SORT_TILE);
     hipLaunchKernelGGL(starts_kernel, dim3(1), dim3(256), 0, s, a.sb.bin_total, a.sb.bin_sel, a.nbins, a.chunk,
-                       a.sb.bin_start, a.sb.item_start);
+                       a.sb.bin_start, a.sb.item_start, a.sb.perm_total);
     if (nt > 0)
         hipLaunchKernelGGL(scatter_kernel, dim3(nt), dim3(64), a.nbins * sizeof(int), s, bins, a.n, a.nbins, nt,
                            a.sb.tile_hist, a.sb.bin_start, a.sb.perm);
