@@ -38,6 +38,9 @@ ABI = [
     ("dpmm_merge", ctypes.c_int, [ctypes.c_void_p, _c_i64p, _c_i64p, ctypes.c_int]),
     ("dpmm_remove_empty", ctypes.c_int, [ctypes.c_void_p, _c_i64p, ctypes.c_int]),
     ("dpmm_reset_sublabels", ctypes.c_int, [ctypes.c_void_p, _c_i64p, ctypes.c_int, ctypes.c_uint32]),
+    ("dpmm_set_predictive_niw", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p]),
+    ("dpmm_set_predictive_mult", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_f32p, _c_f32p]),
+    ("dpmm_predict", ctypes.c_int, [ctypes.c_void_p, _c_f32p]),
     ("dpmm_debug_loglik", ctypes.c_int, [ctypes.c_void_p, _c_f32p]),
     ("dpmm_sync", ctypes.c_int, [ctypes.c_void_p]),
     ("dpmm_stream", ctypes.c_void_p, [ctypes.c_void_p]),
@@ -216,6 +219,27 @@ class Worker:
         else:
             idx = _i64(idx)
             self._chk(self._lib.dpmm_reset_sublabels(self._h, _p(idx, _c_i64p), len(idx), epoch))
+
+    # ---- prediction (posterior predictive table)
+    def predict_table_niw(self, m, R, logdet, df, weights):
+        K = len(weights)
+        m, R, logdet, df, weights = map(_f32, (m, R, logdet, df, weights))
+        assert m.shape == (K, self.D) and R.size == K * self.D * self.D
+        self._chk(self._lib.dpmm_set_predictive_niw(self._h, K, _p(m, _c_f32p), _p(R, _c_f32p), _p(logdet, _c_f32p), _p(df, _c_f32p), _p(weights, _c_f32p)))
+        self.K = K
+        out = np.empty((K, self.n), np.float32)
+        self._chk(self._lib.dpmm_predict(self._h, _p(out, _c_f32p)))
+        return out
+
+    def predict_table_mult(self, logp, weights):
+        K = len(weights)
+        logp, weights = _f32(logp), _f32(weights)
+        assert logp.shape == (K, self.D)
+        self._chk(self._lib.dpmm_set_predictive_mult(self._h, K, _p(logp, _c_f32p), _p(weights, _c_f32p)))
+        self.K = K
+        out = np.empty((K, self.n), np.float32)
+        self._chk(self._lib.dpmm_predict(self._h, _p(out, _c_f32p)))
+        return out
 
     # ---- diagnostics
     def debug_loglik(self):

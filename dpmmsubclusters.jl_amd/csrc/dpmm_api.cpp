@@ -61,6 +61,8 @@ struct dpmm_ctx {
     float *d_scratch = nullptr;
     int64_t scratch_stride = 0;
     bool have_params = false;
+    float *d_tdf = nullptr;   // Student-t constants of the predictive mode ([3K][2]) or null
+    bool predictive = false;
 
     // sort + stats
     SortBufs sb{};
@@ -124,8 +126,8 @@ const char *dpmm_last_error(const dpmm_ctx *ctx) { return ctx ? ctx->err.c_str()
 
 static void free_params(dpmm_ctx *c) {
     hipFree(c->d_raw); hipFree(c->d_mu); hipFree(c->d_Rp); hipFree(c->d_mup); hipFree(c->d_cst);
-    hipFree(c->d_scratch); hipFree(c->d_slabs); hipFree(c->d_out); hipFree(c->d_Lp16);
-    c->d_Lp16 = nullptr;
+    hipFree(c->d_scratch); hipFree(c->d_slabs); hipFree(c->d_out); hipFree(c->d_Lp16); hipFree(c->d_tdf);
+    c->d_Lp16 = nullptr; c->d_tdf = nullptr;
     c->d_raw = c->d_mu = c->d_Rp = c->d_mup = c->d_cst = c->d_scratch = nullptr;
     c->d_slabs = c->d_out = nullptr;
 }
@@ -152,6 +154,7 @@ static int ensure_capacity(dpmm_ctx *c, int K) {
         HIPCHK(c, hipMalloc(&c->d_Lp16, sizeof(uint32_t) * mult_pack_bf16_words(3 * cap, c->ldx)));
     }
     HIPCHK(c, hipMalloc(&c->d_cst, sizeof(float) * 3 * cap));
+    HIPCHK(c, hipMalloc(&c->d_tdf, sizeof(float) * 6 * cap));
     // sweep scratch: one a_k row set per resident workgroup; the Multinomial kernel keeps all 3K rows
     const int rows = (c->prior == DPMM_PRIOR_NIW) ? cap : 3 * cap;
     c->scratch_stride = (int64_t)c->sweep_grid * c->tile;
@@ -349,6 +352,7 @@ int dpmm_set_params_niw_chol(dpmm_ctx *c, int K, const float *mu, const float *R
     HIPCHK(c, launch_niw_pack(hp, hp + nR, c->d_Rp, c->d_mup, c->D, c->NB, 3 * K, c->stream));
     c->K = K;
     c->have_params = true;
+    c->predictive = false;
     return DPMM_OK;
 }
 
@@ -396,6 +400,7 @@ int dpmm_set_params_mult(dpmm_ctx *c, int K, const float *logp, const float *lr,
     if (c->ldx != c->D) HIPCHK(c, hipMemsetAsync(c->d_raw, 0, sizeof(float) * 3 * K * (size_t)c->ldx, c->stream));
     HIPCHK(c, hipMemcpy2DAsync(c->d_raw, sizeof(float) * c->ldx, hp, sizeof(float) * c->D, sizeof(float) * c->D, (size_t)3 * K, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_cst, hp + nlp, sizeof(float) * ncst, hipMemcpyHostToDevice, c->stream));
+    c->predictive = false;
     HIPCHK(c, launch_mult_pack(c->d_raw, c->d_Rp, 3 * K, c->ldx, c->stream));
     if (c->x_bf16_exact) HIPCHK(c, launch_mult_pack_bf16(c->d_raw, c->d_Lp16, 3 * K, c->ldx, c->stream));
     c->K = K;
@@ -422,6 +427,7 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
         NiwSweepArgs a{};
         a.X = c->dX; a.ldx = c->ldx; a.n = c->n; a.first_index = c->first; a.ntiles = c->ntiles; a.K = c->K;
         a.Rp = c->d_Rp; a.mup = c->d_mup; a.cst = c->d_cst;
+        a.tdf = c->predictive ? c->d_tdf : nullptr;
         a.scratch = table ? table : c->d_scratch;
         a.scratch_stride = table ? table_stride : c->scratch_stride;
         a.scratch_by_tile = table ? 1 : 0;
@@ -468,7 +474,59 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
 
 int dpmm_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax) {
     if (!c) return DPMM_EINVAL;
+    if (c->predictive) return fail(c, DPMM_ESTATE, "predictive parameters are loaded: set the sweep parameters again");
     return run_sweep(c, epoch, final_argmax, nullptr, 0);
+}
+
+int dpmm_set_predictive_niw(dpmm_ctx *c, int K, const float *m, const float *R, const float *logdet, const float *df, const float *w) {
+    if (!c) return DPMM_EINVAL;
+    if (c->prior != DPMM_PRIOR_NIW) return fail(c, DPMM_EINVAL, "context was created for another prior");
+    if (!m || !R || !logdet || !df || !w) return fail(c, DPMM_EINVAL, "null parameter array");
+    if (int rc = check_K(c, K)) return rc;
+    const size_t D = (size_t)c->D;
+    // expand to the (cluster, left, right) row layout of the sweep kernels; only rows 3k are read in table mode
+    std::vector<float> mu3(3 * K * D, 0.f), R3(3 * K * D * D, 0.f), ld3(3 * (size_t)K, 0.f), lr(2 * (size_t)K, 0.5f);
+    for (int k = 0; k < K; ++k) {
+        memcpy(&mu3[(size_t)3 * k * D], m + (size_t)k * D, sizeof(float) * D);
+        memcpy(&R3[(size_t)3 * k * D * D], R + (size_t)k * D * D, sizeof(float) * D * D);
+    }
+    if (int rc = dpmm_set_params_niw_chol(c, K, mu3.data(), R3.data(), ld3.data(), lr.data(), w)) return rc;
+    // MvTDist log-density constant: lgamma((df+D)/2) - lgamma(df/2) - D/2 log(df pi) - logdet(Sigma)/2 + log w
+    std::vector<float> cst(3 * (size_t)K, 0.f), tdf(6 * (size_t)K, 1.f);
+    for (int k = 0; k < K; ++k) {
+        const double v = df[k];
+        cst[3 * k] = (float)(lgamma(0.5 * (v + D)) - lgamma(0.5 * v) - 0.5 * D * log(v * M_PI) - 0.5 * logdet[k] + log((double)w[k]));
+        tdf[6 * k] = (float)v;
+        tdf[6 * k + 1] = (float)(0.5 * (v + D));
+    }
+    if (int rc = ensure_pinned(c, sizeof(float) * 9 * K)) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(c->h_pin, cst.data(), sizeof(float) * 3 * K);
+    memcpy(c->h_pin + sizeof(float) * 3 * K, tdf.data(), sizeof(float) * 6 * K);
+    HIPCHK(c, launch_copy_bytes(c->d_cst, c->h_pin, sizeof(float) * 3 * K, c->stream));
+    HIPCHK(c, launch_copy_bytes(c->d_tdf, c->h_pin + sizeof(float) * 3 * K, sizeof(float) * 6 * K, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->predictive = true;
+    return DPMM_OK;
+}
+
+int dpmm_set_predictive_mult(dpmm_ctx *c, int K, const float *logp, const float *w) {
+    if (!c) return DPMM_EINVAL;
+    if (c->prior != DPMM_PRIOR_MULT) return fail(c, DPMM_EINVAL, "context was created for another prior");
+    if (!logp || !w) return fail(c, DPMM_EINVAL, "null parameter array");
+    if (int rc = check_K(c, K)) return rc;
+    const size_t D = (size_t)c->D;
+    std::vector<float> lp3(3 * K * D, 0.f), lr(2 * (size_t)K, 0.5f);
+    for (int k = 0; k < K; ++k) memcpy(&lp3[(size_t)3 * k * D], logp + (size_t)k * D, sizeof(float) * D);
+    if (int rc = dpmm_set_params_mult(c, K, lp3.data(), lr.data(), w)) return rc;
+    c->predictive = true;
+    return DPMM_OK;
+}
+
+int dpmm_predict(dpmm_ctx *c, float *parr) {
+    if (!c || !parr) return DPMM_EINVAL;
+    if (!c->predictive) return fail(c, DPMM_ESTATE, "dpmm_predict needs dpmm_set_predictive_* first");
+    return dpmm_debug_loglik(c, parr);
 }
 
 int dpmm_debug_loglik(dpmm_ctx *c, float *out) {

@@ -21,6 +21,7 @@ struct NiwSweepArgs {
     const float *Rp;     // packed factor fragments [3K][NP][64][4]
     const float *mup;    // [3K][DP]
     const float *cst;    // [3K]: 3k: -logdet/2 + log w_k ; 3k+1+s: -logdet/2 + log lr_w[k][s]
+    const float *tdf;    // null: Gaussian a = cst - q/2 ; else Student-t (posterior predictive): [3K][2] = {df, (df+D)/2}, a = cst - hdf*log1p(q/df)
     float *scratch;      // a_k rows: scratch[k*scratch_stride + base + point_in_tile]
     int64_t scratch_stride;
     int scratch_by_tile; // 1: base = tile*TILE (full table, debug) ; 0: base = blockIdx*TILE

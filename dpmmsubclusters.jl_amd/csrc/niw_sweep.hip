@@ -226,7 +226,8 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
             for (int n = 0; n < NG; ++n) q[n] = 0.f;
             eval_matrix<NB, NG, CH>(ev, lds, Rcur, Rnext, x, mu, q, lane, true);
             const float qs = reduce_select<NG>(q, g);
-            const float a = __builtin_fmaf(-0.5f, qs, A.cst[3 * k]);
+            const float a = A.tdf ? A.cst[3 * k] - A.tdf[6 * k + 1] * log1pf(qs / A.tdf[6 * k])
+                                  : __builtin_fmaf(-0.5f, qs, A.cst[3 * k]);
             if (valid) {
                 scr[(int64_t)k * sstride] = a;
                 if (a != a) {
@@ -482,7 +483,8 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
             STAMP(q0);
             const float qs = quad_stream<NB, NG>(Rcur, Rnext, A.mup + (size_t)(3 * (k + 1)) * DP, rb0, mu, x, lane, g, true);
             STAMP(q1);
-            const float a = __builtin_fmaf(-0.5f, qs, A.cst[3 * k]);
+            const float a = A.tdf ? A.cst[3 * k] - A.tdf[6 * k + 1] * log1pf(qs / A.tdf[6 * k])
+                                  : __builtin_fmaf(-0.5f, qs, A.cst[3 * k]);
             if (tab_lds) ltab[k * WPTS] = a;
             else if (valid) scr[(int64_t)k * sstride] = a;
             if (a != a) {

@@ -111,6 +111,35 @@ def fit(all_data, *args, iters=100, init_clusters=1, seed=None, verbose=True, sa
     return (dp_model.labels, clusters, s.weights.copy(), iter_count, nmi, lik, kh, dp_model.labels_subcluster, dp_model)
 
 
+def predict(dp_model, data, device=None, worker_factory=None):
+    """predict(dp_model, data) -- src/dp-parallel-sampling.jl:532-537 with predict_points
+    (src/local_clusters_actions.jl:23-40): weights = (points_count + alpha) / sum; per cluster the posterior predictive
+    log-density (GPU), labels = row-wise argmax, probabilities = normalised exponentials (NaN -> -Inf).
+    `data` is Dimensions x Samples.  Returns (labels (n,) Int64 1-based, probs (n, K) Float32)."""
+    s = dp_model.sampler
+    X = np.ascontiguousarray(np.asarray(data, dtype=np.float32).T)
+    n, D = X.shape
+    if D != s.prior.dim:
+        raise ValueError("data dimension does not match the model")
+    w = s.points_count.astype(np.float64) + s.alpha
+    w = (w / w.sum()).astype(np.float32)
+    dev = getattr(s.wk, "device", 0) if device is None else device
+    wk = (worker_factory or binding.Worker)(s.prior.kind, D, n, first_index=0, device=dev, seed=0)
+    try:
+        wk.upload_points(X)
+        parr = s.prior.predictive_table(wk, s.post, [3 * k for k in range(s.K)], w).T.astype(np.float32)   # (n, K)
+    finally:
+        wk.close()
+    with np.errstate(invalid="ignore"):
+        has_nan = np.isnan(parr).any(1)
+        lbls = np.where(has_nan, np.isnan(parr).argmax(1), parr.argmax(1)) + 1   # Julia's argmax returns the first NaN
+        parr = np.where(np.isnan(parr), -np.inf, parr)
+        parr = parr - parr.max(1, keepdims=True)
+        np.exp(parr, out=parr)
+        parr /= parr.sum(1, keepdims=True)
+    return lbls.astype(np.int64), parr
+
+
 def get_labels_histogram(labels):
     """utils.jl:39-48: sorted [(label, count)]"""
     v, c = np.unique(np.asarray(labels), return_counts=True)

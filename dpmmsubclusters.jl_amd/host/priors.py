@@ -129,6 +129,18 @@ class niw_hyperparams(distribution_hyper_params):
         return [mv_gaussian(params["mu"][r].copy(), sig[i].astype(np.float32), inv[i].astype(np.float32),
                             float(params["logdet"][r]), params["R"][r].copy()) for i, r in enumerate(rows)]
 
+    def predictive_table(self, worker, post, rows, weights):
+        """posterior_predictive! (niw.jl:68-76): MvTDist(nu-D+1, m, ((kappa+1)/(kappa (nu-D+1))) nu psi) per cluster;
+        returns parr[k][i] = logpdf + log w_k from the GPU (Student-t mode of the sweep kernel)."""
+        D = self.dim
+        kap, nu, m, U = post["kappa"][rows], post["nu"][rows], post["m"][rows], post["U"][rows]
+        df = nu - D + 1
+        c = (kap + 1) / (kap * df)
+        Uinv = np.linalg.inv(U)                                # upper triangular: (nu psi)^-1 = Uinv' Uinv
+        R = Uinv / np.sqrt(c)[:, None, None]                   # Sigma_t^-1 = R'R
+        logdet = D * np.log(c) + 2 * np.log(np.einsum("kii->ki", U)).sum(1)
+        return worker.predict_table_niw(m, R.reshape(len(rows), -1), logdet, df, weights)
+
     def posterior_hyperparams(self, post, row):
         """The reference's per-cluster posterior_hyperparams object (niw_hyperparams)."""
         U = post["U"][row]
@@ -183,6 +195,11 @@ class multinomial_hyper(distribution_hyper_params):
 
     def distributions(self, params, rows):
         return [multinomial_dist(params["logp"][r].copy()) for r in rows]
+
+    def predictive_table(self, worker, post, rows, weights):
+        """posterior_predictive! (multinomial_prior.jl:45-48): log(alpha'/sum(alpha'))' x"""
+        a = post["alpha"][rows].astype(np.float64)
+        return worker.predict_table_mult(np.log(a / a.sum(1, keepdims=True)), weights)
 
     def posterior_hyperparams(self, post, row):
         return multinomial_hyper(post["alpha"][row])

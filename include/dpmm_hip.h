@@ -153,6 +153,20 @@ int dpmm_reset_sublabels(dpmm_ctx *ctx, const int64_t *idx, int n, uint32_t epoc
  * never affects a draw; add it back to compare with reference values).  out: [K][n_local]. */
 int dpmm_debug_loglik(dpmm_ctx *ctx, float *out);
 
+/* Prediction for the points held by the ctx (next row of the scope table: predict / predict_points,
+ * src/dp-parallel-sampling.jl:532-537, src/local_clusters_actions.jl:23-40, with posterior_predictive!
+ * priors/niw.jl:68-76 and priors/multinomial_prior.jl:45-48).
+ *   NIW: cluster k's posterior predictive is MvTDist(df_k, m_k, Sigma_k); pass m [K][D], the upper-triangular
+ *        factor R [K][D][D] of Sigma_k^-1 (= R'R), logdet Sigma_k [K], df [K] and the mixture weights [K].
+ *   Multinomial: logp [K][D] = log(alpha'/sum(alpha')), weights [K].
+ * dpmm_predict then writes parr[k][i] = log predictive density of point i under cluster k + log w_k (Float32,
+ * [K][n_local]); the caller takes the row-wise argmax / normalised exponentials as predict_points does.
+ * These calls replace the sweep parameters of the ctx: set them again before the next dpmm_sweep. */
+int dpmm_set_predictive_niw(dpmm_ctx *ctx, int K, const float *m, const float *R, const float *logdet,
+                            const float *df, const float *weights);
+int dpmm_set_predictive_mult(dpmm_ctx *ctx, int K, const float *logp, const float *weights);
+int dpmm_predict(dpmm_ctx *ctx, float *parr);
+
 /* Block until all queued work of the ctx has completed. */
 int dpmm_sync(dpmm_ctx *ctx);
 /* The HIP stream (hipStream_t) all work of this ctx is queued on, for callers that

@@ -240,6 +240,15 @@ def niw_log_marginal(prior, post, N, D, f32_quirk=True):
             - (v1 / 2) * (D * np.log(v1) + ld1) + (D / 2) * np.log(k0 / k1))
 
 
+def niw_posterior_predictive(X, kappa, m, nu, psi):
+    """priors/niw.jl:68-76: logpdf(MvTDist(nu-D+1, m, ((kappa+1)/(kappa (nu-D+1))) nu psi), x) via scipy (closed form
+    independent of the build)."""
+    from scipy.stats import multivariate_t
+    D = len(m)
+    df = nu - D + 1
+    return multivariate_t(loc=m, shape=((kappa + 1) / (kappa * df)) * nu * np.asarray(psi), df=df).logpdf(np.asarray(X, float))
+
+
 def mult_calc_posterior(alpha, N, points_sum):
     """priors/multinomial_prior.jl:16-21 (Float32 arithmetic)."""
     if N == 0:

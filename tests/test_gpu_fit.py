@@ -77,3 +77,44 @@ def test_nccl_comm_path_single_rank(host):
     finally:
         dist.destroy_process_group()
     assert np.array_equal(ref[0], got[0]) and np.array_equal(ref[7], got[7]) and ref[6] == got[6]
+
+
+def test_predict_matches_reference_semantics(host):
+    """test/module_tests.jl:25-28: predict(model, data)[1] == labels on the deterministic point-mass problem, and the
+    posterior-predictive table equals scipy's multivariate-t closed form (priors/niw.jl:68-76)."""
+    from oracle import oracle as orc
+    data = np.zeros((2, 1000), np.float32)
+    data[:, 0:250] = [[-1], [-1]]; data[:, 250:500] = [[-1], [1]]
+    data[:, 500:750] = [[1], [-1]]; data[:, 750:1000] = [[1], [1]]
+    res = host.fit(data, 100.0, iters=200, seed=123456789, burnout=15, verbose=False)
+    labels, model = res[0], res[-1]
+    preds, probs = host.predict(model, data)
+    assert np.array_equal(preds, labels)                               # :25-28
+    assert probs.shape == (1000, 4) and np.allclose(probs.sum(1), 1, atol=1e-5)
+    # closed-form check on a generic problem
+    x, y, _, _ = host.generate_gaussian_data(5000, 5, 3, 50.0, seed=2)
+    res = host.fit(x, 10.0, iters=40, burnout=5, seed=3, verbose=False)
+    s = res[-1].sampler
+    preds, probs = host.predict(res[-1], x)
+    w = s.points_count + s.alpha; w = w / w.sum()
+    tab = np.empty((5000, s.K))
+    for k in range(s.K):
+        U = s.post["U"][3 * k]
+        tab[:, k] = orc.niw_posterior_predictive(x.T, s.post["kappa"][3 * k], s.post["m"][3 * k], s.post["nu"][3 * k],
+                                                 (U @ U.T) / s.post["nu"][3 * k]) + np.log(w[k])
+    want = np.exp(tab - tab.max(1, keepdims=True)); want /= want.sum(1, keepdims=True)
+    np.testing.assert_allclose(probs, want, atol=2e-4)
+    assert (preds == tab.argmax(1) + 1).mean() > 0.999
+
+
+def test_predict_multinomial(host):
+    x, labels, _ = host.generate_mnmm_data(4000, 30, 4, 100, seed=8)
+    hyper = host.multinomial_hyper(np.ones(30, np.float32))
+    res = host.fit(x, hyper, 10.0, iters=40, burnout=5, seed=2, verbose=False)
+    s = res[-1].sampler
+    preds, probs = host.predict(res[-1], x)
+    a = s.post["alpha"][[3 * k for k in range(s.K)]].astype(np.float64)
+    w = s.points_count + s.alpha; w = w / w.sum()
+    tab = x.T.astype(np.float64) @ np.log(a / a.sum(1, keepdims=True)).T + np.log(w)
+    assert (preds == tab.argmax(1) + 1).mean() > 0.999
+    assert (preds == res[0]).mean() > 0.95
