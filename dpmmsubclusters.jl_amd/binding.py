@@ -41,6 +41,8 @@ ABI = [
     ("dpmm_set_predictive_niw", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p]),
     ("dpmm_set_predictive_mult", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_f32p, _c_f32p]),
     ("dpmm_predict", ctypes.c_int, [ctypes.c_void_p, _c_f32p]),
+    ("dpmm_set_ground_truth", ctypes.c_int, [ctypes.c_void_p, _c_i64p, ctypes.c_int]),
+    ("dpmm_contingency", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_i64p]),
     ("dpmm_debug_loglik", ctypes.c_int, [ctypes.c_void_p, _c_f32p]),
     ("dpmm_sync", ctypes.c_int, [ctypes.c_void_p]),
     ("dpmm_stream", ctypes.c_void_p, [ctypes.c_void_p]),
@@ -239,6 +241,24 @@ class Worker:
         self.K = K
         out = np.empty((K, self.n), np.float32)
         self._chk(self._lib.dpmm_predict(self._h, _p(out, _c_f32p)))
+        return out
+
+    # ---- on-device evaluation
+    def set_ground_truth(self, gt):
+        """gt: integer ids of this shard's points (any integers; remapped to 0..n_gt-1 by the caller)."""
+        gt = _i64(gt)
+        self.n_gt = int(gt.max()) + 1 if len(gt) else 1
+        self._chk(self._lib.dpmm_set_ground_truth(self._h, _p(gt, _c_i64p), self.n_gt))
+
+    def set_ground_truth_range(self, gt, n_gt):
+        gt = _i64(gt)
+        self.n_gt = int(n_gt)
+        self._chk(self._lib.dpmm_set_ground_truth(self._h, _p(gt, _c_i64p), self.n_gt))
+
+    def contingency(self, K=None):
+        K = self.K if K is None else K
+        out = np.zeros((K, self.n_gt), np.int64)
+        self._chk(self._lib.dpmm_contingency(self._h, K, _p(out, _c_i64p)))
         return out
 
     # ---- diagnostics

@@ -47,6 +47,9 @@ struct dpmm_ctx {
     float *dX = nullptr;
     int32_t *dbins = nullptr;
     bool have_points = false, have_labels = false;
+    int32_t *d_gt = nullptr;  // ground truth of the shard (on-device evaluation)
+    int n_gt = 0;
+    unsigned long long *d_cont = nullptr;
     bool have_perm = false;   // sb.perm holds a permutation of [0,n) sorted by a recent labelling
 
     // parameters
@@ -234,7 +237,7 @@ int dpmm_destroy(dpmm_ctx *c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     free_params(c);
-    hipFree(c->dX); hipFree(c->dbins);
+    hipFree(c->dX); hipFree(c->dbins); hipFree(c->d_gt); hipFree(c->d_cont);
     hipFree(c->sb.tile_hist); hipFree(c->sb.bin_total); hipFree(c->sb.bin_start); hipFree(c->sb.item_start);
     hipFree(c->sb.perm); hipFree(c->sb.bin_sel); hipFree(c->sb.perm_total); hipFree(c->d_small);
     if (c->h_pin) hipHostFree(c->h_pin);
@@ -719,6 +722,41 @@ int dpmm_reset_sublabels(dpmm_ctx *c, const int64_t *idx, int n, uint32_t epoch)
         if (int rc = upload_idx(c, idx, nullptr, n, DPMM_MAX_CLUSTERS)) return rc;
     }
     if (c->n > 0) HIPCHK(c, launch_reset_sub(c->dbins, c->n, c->first, idx ? c->d_small : nullptr, idx ? n : 0, c->seed, epoch, c->stream));
+    return DPMM_OK;
+}
+
+int dpmm_set_ground_truth(dpmm_ctx *c, const int64_t *gt, int n_gt) {
+    if (!c) return DPMM_EINVAL;
+    if ((!gt && c->n > 0) || n_gt < 1 || n_gt > 65536) return fail(c, DPMM_EINVAL, "bad ground truth");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->d_gt) HIPCHK(c, hipMalloc(&c->d_gt, sizeof(int32_t) * (size_t)std::max<int64_t>(c->n, 1)));
+    if (c->d_cont) { hipFree(c->d_cont); c->d_cont = nullptr; }
+    HIPCHK(c, hipMalloc(&c->d_cont, sizeof(unsigned long long) * (size_t)DPMM_MAX_CLUSTERS * n_gt));
+    if (c->n > 0) {
+        int64_t *tmp = nullptr;
+        HIPCHK(c, hipMalloc(&tmp, sizeof(int64_t) * (size_t)c->n));
+        hipError_t e = hipMemcpyAsync(tmp, gt, sizeof(int64_t) * c->n, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = launch_i64_to_i32(c->d_gt, tmp, c->n, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        hipFree(tmp);
+        if (e != hipSuccess) { c->err = std::string("dpmm_set_ground_truth: ") + hipGetErrorString(e); return DPMM_EHIP; }
+    }
+    c->n_gt = n_gt;
+    return DPMM_OK;
+}
+
+int dpmm_contingency(dpmm_ctx *c, int K, int64_t *counts) {
+    if (!c || !counts) return DPMM_EINVAL;
+    if (!c->d_gt || !c->have_labels) return fail(c, DPMM_ESTATE, "contingency needs labels and dpmm_set_ground_truth");
+    if (int rc = check_K(c, K)) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t bytes = sizeof(unsigned long long) * (size_t)K * c->n_gt;
+    if (int rc = ensure_pinned(c, bytes)) return rc;
+    HIPCHK(c, hipMemsetAsync(c->d_cont, 0, bytes, c->stream));
+    if (c->n > 0) HIPCHK(c, launch_contingency(c->dbins, c->d_gt, c->n, K, c->n_gt, c->d_cont, c->stream));
+    HIPCHK(c, launch_copy_bytes(c->h_pin, c->d_cont, bytes, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(counts, c->h_pin, bytes);
     return DPMM_OK;
 }
 

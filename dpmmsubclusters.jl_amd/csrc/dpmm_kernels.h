@@ -77,6 +77,8 @@ hipError_t launch_init_labels(int32_t *bins, int64_t n, int64_t first_index, int
                               uint32_t epoch, hipStream_t s);
 hipError_t launch_bins_from_i64(int32_t *bins, const int64_t *labels, const int64_t *sub, int64_t n, hipStream_t s);
 hipError_t launch_bins_to_i64(const int32_t *bins, int64_t *labels, int64_t *sub, int64_t n, hipStream_t s);
+hipError_t launch_contingency(const int32_t *bins, const int32_t *gt, int64_t n, int K, int n_gt, unsigned long long *counts, hipStream_t s);
+hipError_t launch_i64_to_i32(int32_t *dst, const int64_t *src, int64_t n, hipStream_t s);
 // pairs: [2*m] = idx[0..m-1], new_idx[0..m-1] as 0-based Int32 cluster ids (device memory)
 hipError_t launch_split(int32_t *bins, int64_t n, int64_t first_index, const int32_t *pairs, int m, uint64_t seed,
                         uint32_t epoch, hipStream_t s);

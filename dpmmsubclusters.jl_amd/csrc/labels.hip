@@ -113,6 +113,43 @@ hipError_t launch_copy_bytes(void *dst, const void *src, size_t bytes, hipStream
     return hipGetLastError();
 }
 
+// counts[k * n_gt + g] += 1 over the shard; per-workgroup LDS privatisation when the table is small
+__global__ void contingency_kernel(const int32_t *__restrict__ bins, const int32_t *__restrict__ gt, int64_t n, int K, int n_gt,
+                                   unsigned long long *__restrict__ counts) {
+    extern __shared__ unsigned int tab[];
+    const int cells = K * n_gt;
+    const bool use_lds = cells <= 8192;
+    if (use_lds) {
+        for (int c = threadIdx.x; c < cells; c += blockDim.x) tab[c] = 0u;
+        __syncthreads();
+    }
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = bins[i] >> 1, g = gt[i];
+        if ((unsigned)k < (unsigned)K && (unsigned)g < (unsigned)n_gt) {
+            if (use_lds) atomicAdd(&tab[k * n_gt + g], 1u);
+            else atomicAdd(&counts[(size_t)k * n_gt + g], 1ull);
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int c = threadIdx.x; c < cells; c += blockDim.x)
+            if (tab[c]) atomicAdd(&counts[c], (unsigned long long)tab[c]);
+    }
+}
+hipError_t launch_contingency(const int32_t *bins, const int32_t *gt, int64_t n, int K, int n_gt, unsigned long long *counts, hipStream_t s) {
+    const int cells = K * n_gt;
+    const size_t lds = cells <= 8192 ? sizeof(unsigned) * cells : 0;
+    hipLaunchKernelGGL(contingency_kernel, dim3(grid_for(n)), dim3(256), lds, s, bins, gt, n, K, n_gt, counts);
+    return hipGetLastError();
+}
+__global__ void i64_to_i32_kernel(int32_t *dst, const int64_t *src, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = (int32_t)src[i];
+}
+hipError_t launch_i64_to_i32(int32_t *dst, const int64_t *src, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(i64_to_i32_kernel, dim3(grid_for(n)), dim3(256), 0, s, dst, src, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_init_labels(int32_t *bins, int64_t n, int64_t first, int init_clusters, uint64_t seed, uint32_t epoch, hipStream_t s) {
     hipLaunchKernelGGL(init_labels_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, n, first, init_clusters, seed, epoch);
     return hipGetLastError();

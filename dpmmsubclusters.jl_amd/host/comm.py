@@ -49,6 +49,13 @@ class TorchDistComm:
         self.dist.all_gather_object(objs, (lab, sub))
         return np.concatenate([o[0] for o in objs]), np.concatenate([o[1] for o in objs])
 
+    def reduce_counts(self, table):
+        t = self.torch.from_numpy(np.ascontiguousarray(table, np.int64))
+        if self.backend == "nccl":
+            t = t.to(f"cuda:{self.device}")
+        self.dist.all_reduce(t)
+        return t.cpu().numpy()
+
     def broadcast_int(self, v):
         obj = [int(v)]
         self.dist.broadcast_object_list(obj, src=0)

@@ -39,6 +39,25 @@ class LocalComm:
     def gather_labels(self, worker):
         return worker.get_labels()
 
+    def reduce_counts(self, table):
+        return table
+
+
+def nmi_vi_from_contingency(C):
+    """NMI (Clustering.jl `mutualinfo(a, b, normed=true)` = 2 I / (H_a + H_b)) and VI (`varinfo` = H_a + H_b - 2 I)
+    from a contingency table -- what run_model logs per iteration (src/dp-parallel-sampling.jl:370-377)."""
+    C = np.asarray(C, np.float64)
+    N = C.sum()
+    if N == 0:
+        return 0.0, 0.0
+    pij = C / N
+    pi = pij.sum(1); pj = pij.sum(0)
+    nz = pij > 0
+    mi = float((pij[nz] * np.log(pij[nz] / (pi[:, None] * pj[None, :])[nz])).sum())
+    hi = float(-(pi[pi > 0] * np.log(pi[pi > 0])).sum()); hj = float(-(pj[pj > 0] * np.log(pj[pj > 0])).sum())
+    nmi = 2 * mi / (hi + hj) if (hi + hj) > 0 else 1.0
+    return nmi, hi + hj - 2 * mi
+
 
 class DPMMSampler:
     def __init__(self, worker, prior, alpha, n_total, seed, burnout=20, max_clusters=np.inf, comm=None,
@@ -378,6 +397,12 @@ class DPMMSampler:
     def run_model(self, iterations, first_iter=1, verbose=False, gt=None, on_iteration=None):
         """run_model (dp-parallel-sampling.jl:336-404): returns iter_count, nmi_history, likelihood_history, cluster_count_history."""
         iter_count, nmi_hist, lik_hist, k_hist = [], [], [], []
+        self.vi_history = []
+        if gt is not None:
+            # ground truth of this shard goes to the GPU once; per iteration only a K x n_gt table comes back
+            ids, inv = np.unique(np.asarray(gt), return_inverse=True)
+            lo = getattr(self.wk, "first_index", 0)
+            self.wk.set_ground_truth_range(inv[lo:lo + self.wk.n], len(ids))
         for i in range(first_iter, iterations + 1):
             final = i >= iterations - self.argmax_sample_stop
             no_more_splits = (i >= iterations - self.split_stop) or (self.K >= self.max_clusters)
@@ -387,10 +412,10 @@ class DPMMSampler:
             iter_count.append(dt)
             k_hist.append(self.K)
             if gt is not None:
-                lab = self.comm.gather_labels(self.wk)[0]
-                nmi_hist.append(_nmi(np.asarray(gt).astype(np.int64), lab))
+                nmi, vi = nmi_vi_from_contingency(self.comm.reduce_counts(self.wk.contingency(self.K)))
+                nmi_hist.append(nmi); self.vi_history.append(vi)
             else:
-                nmi_hist.append("no gt")
+                nmi_hist.append("no gt"); self.vi_history.append("no gt")
             if verbose:
                 lik_hist.append(self.log_posterior())
                 if self.comm.rank == 0:
@@ -402,7 +427,3 @@ class DPMMSampler:
                 on_iteration(i, self)
         return iter_count, nmi_hist, lik_hist, k_hist
 
-
-def _nmi(a, b):
-    from sklearn.metrics import normalized_mutual_info_score
-    return float(normalized_mutual_info_score(a, b))

@@ -167,6 +167,13 @@ int dpmm_set_predictive_niw(dpmm_ctx *ctx, int K, const float *m, const float *R
 int dpmm_set_predictive_mult(dpmm_ctx *ctx, int K, const float *logp, const float *weights);
 int dpmm_predict(dpmm_ctx *ctx, float *parr);
 
+/* On-device evaluation (next row of the scope table): with a ground truth the reference gathers all N labels to
+ * the master EVERY iteration to compute NMI / VI (src/dp-parallel-sampling.jl:370-377).  Here the ground truth of
+ * the shard is uploaded once (Int64, any integer ids in [0, n_gt)), and each call returns only the
+ * K x n_gt contingency table counts[k][g] = #{i : label_i == k+1, gt_i == g} (Int64, summable across shards). */
+int dpmm_set_ground_truth(dpmm_ctx *ctx, const int64_t *gt, int n_gt);
+int dpmm_contingency(dpmm_ctx *ctx, int K, int64_t *counts);
+
 /* Block until all queued work of the ctx has completed. */
 int dpmm_sync(dpmm_ctx *ctx);
 /* The HIP stream (hipStream_t) all work of this ctx is queued on, for callers that

@@ -108,5 +108,14 @@ class FakeWorker:
     def reset_sublabels(self, idx, epoch):
         orc.reset_sub(self.labels, self.sub, idx, self.seed, epoch, self.first_index)
 
+    def set_ground_truth_range(self, gt, n_gt):
+        self.gt = np.asarray(gt, np.int64); self.n_gt = int(n_gt)
+
+    def contingency(self, K=None):
+        K = self.K if K is None else K
+        out = np.zeros((K, self.n_gt), np.int64)
+        np.add.at(out, (self.labels - 1, self.gt), 1)
+        return out
+
     def sync(self):
         pass

@@ -252,3 +252,24 @@ def test_error_paths(pkg):
     N, s, S = wk.suffstats()
     assert not N.any()
     wk.close()
+
+
+def test_contingency_table(pkg):
+    """On-device evaluation: K x n_gt contingency table == numpy's, and NMI from it == sklearn's."""
+    import importlib
+    host = importlib.import_module("dpmmsubclusters_jl_amd.host")
+    from sklearn.metrics import normalized_mutual_info_score
+    rng = np.random.default_rng(4)
+    n, K, G = 123457, 9, 7
+    lab = rng.integers(1, K + 1, n); sub = rng.integers(1, 3, n); gt = rng.integers(0, G, n)
+    gt[lab < 4] = lab[lab < 4]  # some structure
+    wk = pkg.Worker(pkg.PRIOR_NIW, 2, n, device=0)
+    wk.upload_points(np.zeros((n, 2), np.float32))
+    wk.set_labels(lab, sub)
+    wk.set_ground_truth_range(gt, G)
+    C = wk.contingency(K)
+    want = np.zeros((K, G), np.int64); np.add.at(want, (lab - 1, gt), 1)
+    assert np.array_equal(C, want)
+    nmi, vi = host.sampler.nmi_vi_from_contingency(C)
+    assert abs(nmi - normalized_mutual_info_score(gt, lab)) < 1e-10 and vi >= 0
+    wk.close()
