@@ -438,6 +438,9 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
         a.bins = c->dbins; a.seed = c->seed; a.epoch = epoch; a.final_argmax = final_argmax;
         {
             static const bool no_order = getenv("DPMM_NIW_NO_ORDER") != nullptr;
+            static const float margin = [] { const char *e = getenv("DPMM_NIW_SCREEN"); return e ? (float)atof(e) : 50.f; }();
+            a.screen_margin = table ? 0.f : margin;
+            a.use_prev = c->have_labels ? 1 : 0;
             a.order = (!table && c->have_perm && !no_order) ? c->sb.perm : nullptr;
             a.order_total = c->sb.perm_total;
         }

@@ -34,6 +34,8 @@ struct NiwSweepArgs {
     int final_argmax;
     unsigned *tile_counter;   // zeroed before the launch: dynamic tile queue (null: static striding)
     int stagger_cycles_per_cluster;
+    float screen_margin;      // > 0: skip clusters whose a_k is provably below (reference - margin) for a whole wave (NIW, D in 17..64)
+    int use_prev;             // bins hold labels from a previous sweep (reference clusters of the screen)
     int lds_rows;             // set by the launcher: rows of the a_k table that live in LDS (0: global scratch)
     unsigned long long *dbg;  // diagnostic builds only (DPMM_STAMPS): per-wave phase cycle sums
 };

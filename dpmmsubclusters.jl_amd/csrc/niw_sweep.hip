@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
 template <int NB, int NG>
 __device__ __forceinline__ float quad_stream(const float *__restrict__ Rm, const float *__restrict__ Rnext,
                                              const float *__restrict__ mup_next, f32x4 (&rb0)[NB], f32x4 (&mu)[NB],
-                                             const f32x4 (&x)[NG][NB], int lane, int g, bool active) {
+                                             const f32x4 (&x)[NG][NB], int lane, int g, bool active, float (&tot_all)[NG]) {
     float q[NG];
 #pragma unroll
     for (int n = 0; n < NG; ++n) q[n] = 0.f;
@@ -392,6 +392,7 @@ __device__ __forceinline__ float quad_stream(const float *__restrict__ Rm, const
 #pragma unroll
     for (int n = 0; n < NG; ++n) {
         const f32x4 tot = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, q[n], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        tot_all[n] = tot[0];       // quadratic form of point (n, column of this lane): same value in all 4 row-group lanes
         if (g == n) sel = tot[0];
     }
     return sel;
@@ -426,6 +427,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
     const int64_t nwtiles = (A.n + WPTS - 1) / WPTS;              // one tile per wave
     const int64_t wave_id = (int64_t)blockIdx.x * 4 + (tid >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
+    __shared__ uint32_t surv_bits[4][32];   // per wave: clusters that survived the screen (K <= 1024)
     extern __shared__ __attribute__((aligned(16))) float lds_tab[];
     // wave-private [K][WPTS] table of a_k in LDS when it fits (A.lds_rows >= K), else the global scratch
     const bool tab_lds = A.lds_rows >= K && !A.scratch_by_tile;
@@ -476,26 +478,137 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
         int best = 0;
         bool nan_seen = false;
         f32x4 rb0[NB], mu[NB];
-        load_rb0<NB>(A.Rp, A.mup, rb0, mu, lane, g);
-        for (int k = 0; k < K; ++k) {
-            const float *Rcur = A.Rp + (size_t)(3 * k) * MATSZ;
-            const float *Rnext = (k + 1 < K) ? A.Rp + (size_t)(3 * (k + 1)) * MATSZ : nullptr;
-            STAMP(q0);
-            const float qs = quad_stream<NB, NG>(Rcur, Rnext, A.mup + (size_t)(3 * (k + 1)) * DP, rb0, mu, x, lane, g, true);
-            STAMP(q1);
-            const float a = A.tdf ? A.cst[3 * k] - A.tdf[6 * k + 1] * log1pf(qs / A.tdf[6 * k])
-                                  : __builtin_fmaf(-0.5f, qs, A.cst[3 * k]);
+        float tot_all[NG];
+        auto record = [&](int k, float a) {     // table + running max / argmax bookkeeping for the owner lane
             if (tab_lds) ltab[k * WPTS] = a;
             else if (valid) scr[(int64_t)k * sstride] = a;
             if (a != a) {
-                if (!nan_seen) { nan_seen = true; best = k; }
-            } else if (a > m_run) {
+                if (!nan_seen || k < best) { nan_seen = true; best = k; }   // Julia's argmax: the first NaN wins
+            } else if (a > m_run || (a == m_run && k < best && !nan_seen && m_run != -INFINITY)) {
                 m_run = a;
                 if (!nan_seen) best = k;
             }
-            STAMP(q2);
+        };
+        const bool screening = NB >= 2 && A.screen_margin > 0.f && !A.tdf && !A.scratch_by_tile && K > 2;
+        if (!screening) {
+            load_rb0<NB>(A.Rp, A.mup, rb0, mu, lane, g);
+            for (int k = 0; k < K; ++k) {
+                const float *Rcur = A.Rp + (size_t)(3 * k) * MATSZ;
+                const float *Rnext = (k + 1 < K) ? A.Rp + (size_t)(3 * (k + 1)) * MATSZ : nullptr;
+                STAMP(q0);
+                const float qs = quad_stream<NB, NG>(Rcur, Rnext, A.mup + (size_t)(3 * (k + 1)) * DP, rb0, mu, x, lane, g, true, tot_all);
+                STAMP(q1);
+                const float a = A.tdf ? A.cst[3 * k] - A.tdf[6 * k + 1] * log1pf(qs / A.tdf[6 * k])
+                                      : __builtin_fmaf(-0.5f, qs, A.cst[3 * k]);
+                record(k, a);
+                STAMP(q2);
 #ifdef DPMM_STAMPS
-            T_quad += q1 - q0; T_epi += q2 - q1;
+                T_quad += q1 - q0; T_epi += q2 - q1;
+#endif
+            }
+        } else {
+            // ---- screened label phase -----------------------------------------------------------------
+            // (1) reference clusters: the previous labels of the wave's first and last point, evaluated in full;
+            // (2) every other cluster: only the LAST 16-row block of y = R z (R upper triangular: it needs the last
+            //     16 features only, 16 MFMAs); the sum over a lane's rows is a lower bound of q, so
+            //     cst_k - q_lane/2 is an upper bound of a_k.  If it is below (reference - margin) for every point
+            //     of the wave the cluster's probability is < e^-margin relative and it is skipped (a_k = -inf);
+            // (3) survivors are evaluated in full.
+            STAMP(q0);
+            for (int k = 0; k < K; ++k) {
+                if (tab_lds) ltab[k * WPTS] = -INFINITY;
+                else if (valid) scr[(int64_t)k * sstride] = -INFINITY;
+            }
+            bool pvalid[NG];
+#pragma unroll
+            for (int n = 0; n < NG; ++n) pvalid[n] = wbase + 16 * n + ci < A.n;
+            int prev = (valid && A.use_prev) ? (A.bins[myp] >> 1) : -1;
+            if ((unsigned)prev >= (unsigned)K) prev = -1;
+            const unsigned long long pm = __ballot(prev >= 0);
+            int k0 = 0, k1 = 0;
+            if (pm) {
+                k0 = __shfl(prev, __ffsll((long long)pm) - 1);
+                k1 = __shfl(prev, 63 - __clzll((long long)pm));
+            }
+            k0 = __builtin_amdgcn_readfirstlane(k0);
+            k1 = __builtin_amdgcn_readfirstlane(k1);
+            float bestn[NG];
+#pragma unroll
+            for (int n = 0; n < NG; ++n) bestn[n] = -INFINITY;
+            auto full_eval = [&](int k, const float *Rnext, const float *mup_next) {
+                const float qs = quad_stream<NB, NG>(A.Rp + (size_t)(3 * k) * MATSZ, Rnext, mup_next, rb0, mu, x, lane, g, true, tot_all);
+                const float c = A.cst[3 * k];
+#pragma unroll
+                for (int n = 0; n < NG; ++n) {
+                    const float an = __builtin_fmaf(-0.5f, tot_all[n], c);
+                    if (an > bestn[n]) bestn[n] = an;
+                }
+                record(k, __builtin_fmaf(-0.5f, qs, c));
+            };
+            load_rb0<NB>(A.Rp + (size_t)(3 * k0) * MATSZ, A.mup + (size_t)(3 * k0) * DP, rb0, mu, lane, g);
+            full_eval(k0, k1 != k0 ? A.Rp + (size_t)(3 * k1) * MATSZ : nullptr, A.mup + (size_t)(3 * k1) * DP);
+            if (k1 != k0) full_eval(k1, nullptr, A.mup);
+            // (2) screen
+            uint32_t *sv = surv_bits[tid >> 6];
+            if (lane < 32) sv[lane] = 0u;
+            const float margin = A.screen_margin;
+            constexpr int LASTP = NP - 1, LB = NB - 1;
+            f32x4 fr = *reinterpret_cast<const f32x4 *>(A.Rp + (size_t)LASTP * 256 + lane * 4);
+            f32x4 ml = *reinterpret_cast<const f32x4 *>(A.mup + 16 * LB + 4 * g);
+            for (int k = 0; k < K; ++k) {
+                const f32x4 a = fr, m4 = ml;
+                if (k + 1 < K) {
+                    fr = *reinterpret_cast<const f32x4 *>(A.Rp + ((size_t)(3 * (k + 1)) * NP + LASTP) * 256 + lane * 4);
+                    ml = *reinterpret_cast<const f32x4 *>(A.mup + (size_t)(3 * (k + 1)) * DP + 16 * LB + 4 * g);
+                }
+                if (k == k0 || k == k1) continue;
+                f32x4 acc[NG], zz[NG];
+#pragma unroll
+                for (int n = 0; n < NG; ++n) { acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; zz[n] = x[n][LB] - m4; }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int n = 0; n < NG; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj], zz[n][jj], acc[n], 0, 0, 0);
+                const float c = A.cst[3 * k];
+                bool skip = true;
+#pragma unroll
+                for (int n = 0; n < NG; ++n) {
+                    float ql = acc[n][0] * acc[n][0];
+                    ql = __builtin_fmaf(acc[n][1], acc[n][1], ql);
+                    ql = __builtin_fmaf(acc[n][2], acc[n][2], ql);
+                    ql = __builtin_fmaf(acc[n][3], acc[n][3], ql);
+                    const bool cond = !pvalid[n] || (__builtin_fmaf(-0.5f, ql, c) < bestn[n] - margin);
+                    unsigned long long mk = __ballot(cond);     // a point is covered if ANY of its 4 row-group lanes proves the bound
+                    mk |= mk >> 32;
+                    mk |= mk >> 16;
+                    skip = skip && ((mk & 0xFFFFull) == 0xFFFFull);
+                }
+                if (!skip && lane == 0) sv[k >> 5] |= 1u << (k & 31);
+            }
+            // (3) survivors, with one-matrix lookahead for the fragment prefetch
+            const int nwords = (K + 31) >> 5;
+            int w = 0;
+            uint32_t bits = __builtin_amdgcn_readfirstlane(sv[0]);
+            auto next_surv = [&]() -> int {
+                while (bits == 0u) {
+                    ++w;
+                    if (w >= nwords) return -1;
+                    bits = __builtin_amdgcn_readfirstlane(sv[w]);
+                }
+                const int bpos = __builtin_ctz(bits);
+                bits &= bits - 1u;
+                return (w << 5) + bpos;
+            };
+            int kc = next_surv();
+            if (kc >= 0) load_rb0<NB>(A.Rp + (size_t)(3 * kc) * MATSZ, A.mup + (size_t)(3 * kc) * DP, rb0, mu, lane, g);
+            while (kc >= 0) {
+                const int kn = next_surv();
+                full_eval(kc, kn >= 0 ? A.Rp + (size_t)(3 * kn) * MATSZ : nullptr, A.mup + (size_t)(3 * (kn >= 0 ? kn : 0)) * DP);
+                kc = kn;
+            }
+            STAMP(q1);
+#ifdef DPMM_STAMPS
+            T_quad += q1 - q0;
 #endif
         }
         STAMP(s2);
@@ -559,10 +672,10 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
             const int knext = next_label();
             const int jl = 3 * kcur + 1, jr = jl + 1, jn = 3 * (knext >= 0 ? knext : 0) + 1;
             const float bl = __builtin_fmaf(-0.5f, quad_stream<NB, NG>(A.Rp + (size_t)jl * MATSZ, A.Rp + (size_t)jr * MATSZ,
-                                                                          A.mup + (size_t)jr * DP, rb0, mu, x, lane, g, true), A.cst[jl]);
+                                                                          A.mup + (size_t)jr * DP, rb0, mu, x, lane, g, true, tot_all), A.cst[jl]);
             const float br = __builtin_fmaf(-0.5f, quad_stream<NB, NG>(A.Rp + (size_t)jr * MATSZ,
                                                                           knext >= 0 ? A.Rp + (size_t)jn * MATSZ : nullptr,
-                                                                          A.mup + (size_t)jn * DP, rb0, mu, x, lane, g, true), A.cst[jr]);
+                                                                          A.mup + (size_t)jn * DP, rb0, mu, x, lane, g, true, tot_all), A.cst[jr]);
             if (valid && z == kcur) { b0 = bl; b1 = br; }
             kcur = knext;
         }

@@ -162,6 +162,7 @@ bool reverse_cholesky(const double *P, int D, double *U) {
     for (int j = D - 1; j >= 0; --j) {
         double s = P[(size_t)j * D + j];
         const double *uj = U + (size_t)j * D;
+#pragma omp simd reduction(- : s)
         for (int k = j + 1; k < D; ++k) s -= uj[k] * uj[k];
         if (!(s > 0.0)) return false;
         const double ujj = sqrt(s);
@@ -170,6 +171,7 @@ bool reverse_cholesky(const double *P, int D, double *U) {
         for (int i = 0; i < j; ++i) {
             double t = P[(size_t)i * D + j];
             const double *ui = U + (size_t)i * D;
+#pragma omp simd reduction(- : t)
             for (int k = j + 1; k < D; ++k) t -= ui[k] * uj[k];
             U[(size_t)i * D + j] = t * inv;
         }
@@ -376,7 +378,9 @@ static int niw_sample_impl(int n, int D, const double *kappa, const double *nu, 
                     const double *uc = Ui + (size_t)c * D;
                     const double val = a[c] / uc[c];
                     rj[c] = val;
-                    for (int cc = c + 1; cc < D; ++cc) a[cc] -= val * uc[cc];
+                    double *ap = a.data();
+#pragma omp simd
+                    for (int cc = c + 1; cc < D; ++cc) ap[cc] -= val * uc[cc];
                 }
                 ld += log(rj[j]);
             }
@@ -386,7 +390,9 @@ static int niw_sample_impl(int n, int D, const double *kappa, const double *nu, 
             for (int r = D - 1; r >= 0; --r) {
                 double s = xi[r];
                 const double *rr = Rl.data() + (size_t)r * D;
-                for (int c = r + 1; c < D; ++c) s -= rr[c] * v[c];
+                const double *vp = v.data();
+#pragma omp simd reduction(- : s)
+                for (int c = r + 1; c < D; ++c) s -= rr[c] * vp[c];
                 v[r] = s / rr[r];
             }
             const double isk = 1.0 / sqrt(kappa[i]);
