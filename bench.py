@@ -30,8 +30,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense FP32 matrix peak (no TF32/xf32 on gfx950)
 # HBM bytes per point per launch of the D=64 sweep kernel, from the PMC counters (separate rocprofv3 --pmc passes,
-# FETCH_SIZE doubled per the gfx950 correction): profiles/r01_bench_niw_d64_n1e7_pmc.json -> (2*1270231.6 + 39062.5) KiB / 1e7
-PMC_BYTES_PER_POINT_D64 = (2 * 1270231.625 + 39062.5) * 1024 / 1e7
+# FETCH_SIZE doubled per the gfx950 correction): profiles/r01b_bench_niw_d64_n1e7_pmc.json -> (2*1316816.5 + 77807.5) KiB / 1e7
+PMC_BYTES_PER_POINT_D64 = (2 * 1316816.5 + 77807.5) * 1024 / 1e7
 
 
 def cpu_baseline(host, X_local, D, K, sampler, budget_points):
