@@ -197,35 +197,51 @@ __device__ __forceinline__ void niw_stats_body(const StatsArgs &A, int seg, int 
 #pragma unroll
     for (int b = 0; b < NBK; ++b) xs[b] = 0.;
 
-    constexpr int U = (NBK <= 4) ? 4 : 2;  // k-steps (of 4 points) in flight
+    constexpr int U = (NBK <= 4) ? 4 : 2;  // k-steps (of 4 points) per batch
     const int nsteps = (cnt + 3) >> 2;
-    for (int s0 = 0; s0 < nsteps; s0 += U) {
-        float xf[U][NBK];
+    const int nbatch = (nsteps + U - 1) / U;
+    // software pipeline: perm indices two batches ahead, x one batch ahead of the MFMAs
+    auto load_idx = [&](int b, int64_t (&pt)[U], bool (&ok)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int pl = 4 * (s0 + u) + g;
-            const bool valid = pl < cnt;
-            const int64_t pt = valid ? (int64_t)A.sb.perm[seg + pl] : 0;
-            const float *xp = A.X + pt * A.ldx + NBK * i;
+            const int pl = 4 * (b * U + u) + g;
+            ok[u] = pl < cnt;
+            pt[u] = ok[u] ? (int64_t)A.sb.perm[seg + pl] : 0;
+        }
+    };
+    auto load_x = [&](const int64_t (&pt)[U], const bool (&ok)[U], float (&xf)[U][NBK]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float *xp = A.X + pt[u] * A.ldx + NBK * i;
             if constexpr (NBK >= 4) {
 #pragma unroll
                 for (int c4 = 0; c4 < NBK / 4; ++c4) {
                     f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (valid && NBK * i + 4 * c4 < A.ldx) v = *reinterpret_cast<const f32x4 *>(xp + 4 * c4);
+                    if (ok[u] && NBK * i + 4 * c4 < A.ldx) v = *reinterpret_cast<const f32x4 *>(xp + 4 * c4);
                     xf[u][4 * c4 + 0] = v.x; xf[u][4 * c4 + 1] = v.y; xf[u][4 * c4 + 2] = v.z; xf[u][4 * c4 + 3] = v.w;
                 }
             } else {
 #pragma unroll
-                for (int b = 0; b < NBK; ++b) xf[u][b] = (valid && NBK * i + b < A.ldx) ? xp[b] : 0.f;
+                for (int b2 = 0; b2 < NBK; ++b2) xf[u][b2] = (ok[u] && NBK * i + b2 < A.ldx) ? xp[b2] : 0.f;
             }
         }
+    };
+    int64_t pt_a[U], pt_b[U];
+    bool ok_a[U], ok_b[U];
+    float xcur[U][NBK], xnext[U][NBK];
+    load_idx(0, pt_a, ok_a);
+    load_x(pt_a, ok_a, xcur);
+    load_idx(1, pt_b, ok_b);
+    for (int bt = 0; bt < nbatch; ++bt) {
+        load_x(pt_b, ok_b, xnext);          // batch bt+1 (all-false beyond the end)
+        load_idx(bt + 2, pt_b, ok_b);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             double xd[NBK];
 #pragma unroll
-            for (int b = 0; b < NBK; ++b) {
-                xd[b] = (double)xf[u][b];
-                if constexpr (PANEL == 0) xs[b] += xd[b];
+            for (int b2 = 0; b2 < NBK; ++b2) {
+                xd[b2] = (double)xcur[u][b2];
+                if constexpr (PANEL == 0) xs[b2] += xd[b2];
             }
             // lower block triangle, pair index p(ba,bb) = ba(ba+1)/2 + bb, ba >= bb
 #pragma unroll
@@ -237,6 +253,10 @@ __device__ __forceinline__ void niw_stats_body(const StatsArgs &A, int seg, int 
                         acc[p - P0] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd[ba], xd[bb], acc[p - P0], 0, 0, 0);
                 }
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int b2 = 0; b2 < NBK; ++b2) xcur[u][b2] = xnext[u][b2];
     }
     // slab[pair][r][lane]
 #pragma unroll
