@@ -64,6 +64,8 @@ struct dpmm_ctx {
     float *d_scratch = nullptr;
     int64_t scratch_stride = 0;
     bool have_params = false;
+    float *d_lam = nullptr, *d_mdist = nullptr;   // NIW screening constants (per sweep)
+    bool have_screen_prep = false;
     float *d_tdf = nullptr;   // Student-t constants of the predictive mode ([3K][2]) or null
     bool predictive = false;
 
@@ -129,8 +131,8 @@ const char *dpmm_last_error(const dpmm_ctx *ctx) { return ctx ? ctx->err.c_str()
 
 static void free_params(dpmm_ctx *c) {
     hipFree(c->d_raw); hipFree(c->d_mu); hipFree(c->d_Rp); hipFree(c->d_mup); hipFree(c->d_cst);
-    hipFree(c->d_scratch); hipFree(c->d_slabs); hipFree(c->d_out); hipFree(c->d_Lp16); hipFree(c->d_tdf);
-    c->d_Lp16 = nullptr; c->d_tdf = nullptr;
+    hipFree(c->d_scratch); hipFree(c->d_slabs); hipFree(c->d_out); hipFree(c->d_Lp16); hipFree(c->d_tdf); hipFree(c->d_lam); hipFree(c->d_mdist);
+    c->d_Lp16 = nullptr; c->d_tdf = nullptr; c->d_lam = nullptr; c->d_mdist = nullptr;
     c->d_raw = c->d_mu = c->d_Rp = c->d_mup = c->d_cst = c->d_scratch = nullptr;
     c->d_slabs = c->d_out = nullptr;
 }
@@ -150,6 +152,8 @@ static int ensure_capacity(dpmm_ctx *c, int K) {
         HIPCHK(c, hipMalloc(&c->d_mu, sizeof(float) * 3 * cap * D));
         HIPCHK(c, hipMalloc(&c->d_Rp, sizeof(float) * 3 * cap * NP * 256));
         HIPCHK(c, hipMalloc(&c->d_mup, sizeof(float) * 3 * cap * 16 * c->NB));
+        HIPCHK(c, hipMalloc(&c->d_lam, sizeof(float) * cap));
+        HIPCHK(c, hipMalloc(&c->d_mdist, sizeof(float) * (size_t)cap * cap));
     } else {
         const size_t NT = (size_t)(c->ldx + 15) / 16, NRB = (size_t)(3 * cap + 15) / 16;
         HIPCHK(c, hipMalloc(&c->d_raw, sizeof(float) * 3 * cap * (size_t)c->ldx));
@@ -353,6 +357,21 @@ int dpmm_set_params_niw_chol(dpmm_ctx *c, int K, const float *mu, const float *R
     // the pack kernel reads R and mu straight from the pinned staging buffer (no copy-engine transfer)
     HIPCHK(c, launch_copy_bytes(c->d_cst, hp + nR + nmu, sizeof(float) * ncst, c->stream));
     HIPCHK(c, launch_niw_pack(hp, hp + nR, c->d_Rp, c->d_mup, c->D, c->NB, 3 * K, c->stream));
+    c->have_screen_prep = false;
+    if (c->D > 16 && c->D <= 64 && K > 2) {
+        static const bool no_pre = getenv("DPMM_NIW_NO_PRESCREEN") != nullptr;
+        if (!no_pre) {
+            HIPCHK(c, launch_niw_screen_prep(hp, hp + nR, c->D, K, c->d_lam, c->d_mdist, c->stream));
+            c->have_screen_prep = true;
+            if (g_trace_slow) {
+                std::vector<float> l(K), dd((size_t)K * K);
+                hipStreamSynchronize(c->stream);
+                hipMemcpy(l.data(), c->d_lam, sizeof(float) * K, hipMemcpyDeviceToHost);
+                hipMemcpy(dd.data(), c->d_mdist, sizeof(float) * K * K, hipMemcpyDeviceToHost);
+                fprintf(stderr, "[dpmm prep] lam: %g %g %g %g ... dist[0][1..3]: %g %g %g\n", l[0], l[1], l[2], l[K - 1], dd[1], dd[2], dd[3]);
+            }
+        }
+    }
     c->K = K;
     c->have_params = true;
     c->predictive = false;
@@ -441,6 +460,8 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
             static const float margin = [] { const char *e = getenv("DPMM_NIW_SCREEN"); return e ? (float)atof(e) : 50.f; }();
             a.screen_margin = table ? 0.f : margin;
             a.use_prev = c->have_labels ? 1 : 0;
+            a.lam = (c->have_screen_prep && !c->predictive) ? c->d_lam : nullptr;
+            a.mdist = c->d_mdist;
             a.order = (!table && c->have_perm && !no_order) ? c->sb.perm : nullptr;
             a.order_total = c->sb.perm_total;
         }

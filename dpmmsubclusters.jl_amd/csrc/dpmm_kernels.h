@@ -35,6 +35,9 @@ struct NiwSweepArgs {
     unsigned *tile_counter;   // zeroed before the launch: dynamic tile queue (null: static striding)
     int stagger_cycles_per_cluster;
     float screen_margin;      // > 0: skip clusters whose a_k is provably below (reference - margin) for a whole wave (NIW, D in 17..64)
+    const float *lam;         // [K] lower bounds of lambda_min(Sigma_k^-1) (null: no scalar pre-screen)
+    const float *mdist;       // [K][K] distances between the cluster means
+    int screen_lds;           // set by the launcher: screen operands of all K clusters are staged in LDS
     int use_prev;             // bins hold labels from a previous sweep (reference clusters of the screen)
     int lds_rows;             // set by the launcher: rows of the a_k table that live in LDS (0: global scratch)
     unsigned long long *dbg;  // diagnostic builds only (DPMM_STAMPS): per-wave phase cycle sums
@@ -43,6 +46,7 @@ struct NiwSweepArgs {
 int niw_tile_points(int NB);
 int niw_occupancy(int NB);  // resident 256-thread workgroups per CU the sweep kernel is built for
 hipError_t launch_niw_sweep(int NB, const NiwSweepArgs &a, int grid, hipStream_t s);
+hipError_t launch_niw_screen_prep(const float *R, const float *mu, int D, int K, float *lam, float *dist, hipStream_t s);
 hipError_t launch_niw_pack(const float *R, const float *mu, float *Rp, float *mup, int D, int NB, int nmat, hipStream_t s);
 
 struct MultSweepArgs {

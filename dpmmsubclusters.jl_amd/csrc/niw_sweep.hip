@@ -416,7 +416,7 @@ __device__ __forceinline__ void load_rb0(const float *__restrict__ Rm, const flo
 template <int NB, int NG, int OCC>
 __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs A) {
 #ifdef DPMM_STAMPS
-    unsigned long long T_x = 0, T_quad = 0, T_epi = 0, T_draw = 0, T_p2 = 0, T_tot = 0; int ntile = 0;
+    unsigned long long T_x = 0, T_quad = 0, T_epi = 0, T_draw = 0, T_p2 = 0, T_tot = 0, N_scr = 0; int ntile = 0;
 #endif
     constexpr int DP = 16 * NB, NP = NB * (NB + 1) / 2, MATSZ = NP * 256, WPTS = 16 * NG;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -428,10 +428,21 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
     const int64_t wave_id = (int64_t)blockIdx.x * 4 + (tid >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     __shared__ uint32_t surv_bits[4][32];   // per wave: clusters that survived the screen (K <= 1024)
+    __shared__ uint32_t eval_bits[4][32];   // per wave: reference clusters + survivors
     extern __shared__ __attribute__((aligned(16))) float lds_tab[];
     // wave-private [K][WPTS] table of a_k in LDS when it fits (A.lds_rows >= K), else the global scratch
     const bool tab_lds = A.lds_rows >= K && !A.scratch_by_tile;
     float *ltab = lds_tab + (size_t)(tid >> 6) * A.lds_rows * WPTS + lane;
+    // screen operands of all K clusters (last fragment pair 1 KiB + last 16 means), staged once per workgroup
+    float *scrA = lds_tab + (size_t)4 * A.lds_rows * WPTS;
+    float *scrM = scrA + (size_t)K * 256;
+    if (A.screen_lds) {
+        for (int e = tid; e < K * 64; e += 256)
+            reinterpret_cast<f32x4 *>(scrA)[e] = *reinterpret_cast<const f32x4 *>(A.Rp + ((size_t)(3 * (e >> 6)) * NP + (NP - 1)) * 256 + (e & 63) * 4);
+        for (int e = tid; e < K * 4; e += 256)
+            reinterpret_cast<f32x4 *>(scrM)[e] = *reinterpret_cast<const f32x4 *>(A.mup + (size_t)(3 * (e >> 2)) * DP + 16 * (NB - 1) + 4 * (e & 3));
+        __syncthreads();
+    }
 
     // Waves that share a SIMD would otherwise run in lockstep (same program, same work) and idle the
     // matrix pipe together during their draw / epilogue phases: odd hardware wave slots start half a
@@ -546,22 +557,83 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                 record(k, __builtin_fmaf(-0.5f, qs, c));
             };
             load_rb0<NB>(A.Rp + (size_t)(3 * k0) * MATSZ, A.mup + (size_t)(3 * k0) * DP, rb0, mu, lane, g);
+            // (2a) scalar pre-screen: ||x - mu_k|| >= ||mu_k - mu_k0|| - ||x - mu_k0|| and q_k >= lam_k ||x - mu_k||^2.
+            // Its operands are fetched / formed BEFORE the reference evaluation so that their latency hides behind it.
+            float rn[NG];
+            const bool prescreen = A.lam != nullptr;
+            float pc_c = 0.f, pc_l = 0.f, pc_d = 0.f;      // lane j: constants of cluster j (first chunk of 64)
+            if (prescreen) {
+                if (lane < K) { pc_c = A.cst[3 * lane]; pc_l = A.lam[lane]; pc_d = A.mdist[(size_t)k0 * K + lane] * 0.99999f; }
+#pragma unroll
+                for (int n = 0; n < NG; ++n) {
+                    float part = 0.f;
+#pragma unroll
+                    for (int t = 0; t < NB; ++t) {
+                        const f32x4 dz = x[n][t] - mu[t];              // mu = means of k0 (just loaded by load_rb0)
+                        part = __builtin_fmaf(dz.x, dz.x, part); part = __builtin_fmaf(dz.y, dz.y, part);
+                        part = __builtin_fmaf(dz.z, dz.z, part); part = __builtin_fmaf(dz.w, dz.w, part);
+                    }
+                    const f32x4 tot = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, part, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    rn[n] = sqrtf(tot[0]) * 1.00001f;
+                }
+            }
             full_eval(k0, k1 != k0 ? A.Rp + (size_t)(3 * k1) * MATSZ : nullptr, A.mup + (size_t)(3 * k1) * DP);
             if (k1 != k0) full_eval(k1, nullptr, A.mup);
-            // (2) screen
+            STAMP(r1);
+            // far mask: lane j owns cluster (64 chunk + j); the wave walks its points with readlane broadcasts
+            auto far_chunk = [&](int base) -> unsigned long long {
+                const int j = base + lane;
+                float cj = pc_c, lj = pc_l, dj = pc_d;
+                if (base > 0) {
+                    cj = lj = dj = 0.f;
+                    if (j < K) { cj = A.cst[3 * j]; lj = A.lam[j]; dj = A.mdist[(size_t)k0 * K + j] * 0.99999f; }
+                }
+                bool far = (j < K) && lj > 0.f;
+#pragma unroll
+                for (int n = 0; n < NG; ++n) {
+                    for (int c = 0; c < 16; ++c) {
+                        const float rp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rn[n]), c));
+                        const float bp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bestn[n]), c));
+                        const bool pv = wbase + 16 * n + c < A.n;          // wave-uniform
+                        const float dd = fmaxf(dj - rp, 0.f);
+                        far = far && (!pv || (cj - 0.5f * lj * dd * dd < bp - A.screen_margin));
+                    }
+                }
+                return __ballot(far);
+            };
+            unsigned long long farmask = 0ull;
+            int farbase = -64;
+            // (2b) MFMA screen of the clusters that remain
             uint32_t *sv = surv_bits[tid >> 6];
-            if (lane < 32) sv[lane] = 0u;
+            uint32_t *ev = eval_bits[tid >> 6];      // every cluster whose a_k is finite in the table (refs + survivors)
+            if (lane < 32) { sv[lane] = 0u; ev[lane] = 0u; }
+            if (lane == 0) { ev[k0 >> 5] |= 1u << (k0 & 31); ev[k1 >> 5] |= 1u << (k1 & 31); }
             const float margin = A.screen_margin;
             constexpr int LASTP = NP - 1, LB = NB - 1;
-            f32x4 fr = *reinterpret_cast<const f32x4 *>(A.Rp + (size_t)LASTP * 256 + lane * 4);
-            f32x4 ml = *reinterpret_cast<const f32x4 *>(A.mup + 16 * LB + 4 * g);
+            f32x4 fr = (f32x4){0.f, 0.f, 0.f, 0.f}, ml = fr;
+            if (!A.screen_lds) {
+                fr = *reinterpret_cast<const f32x4 *>(A.Rp + (size_t)LASTP * 256 + lane * 4);
+                ml = *reinterpret_cast<const f32x4 *>(A.mup + 16 * LB + 4 * g);
+            }
             for (int k = 0; k < K; ++k) {
-                const f32x4 a = fr, m4 = ml;
-                if (k + 1 < K) {
+                f32x4 a = fr, m4 = ml;
+                if (!A.screen_lds && k + 1 < K) {
                     fr = *reinterpret_cast<const f32x4 *>(A.Rp + ((size_t)(3 * (k + 1)) * NP + LASTP) * 256 + lane * 4);
                     ml = *reinterpret_cast<const f32x4 *>(A.mup + (size_t)(3 * (k + 1)) * DP + 16 * LB + 4 * g);
                 }
                 if (k == k0 || k == k1) continue;
+                if (prescreen) {
+                    if (k >= farbase + 64) { farbase = k & ~63; farmask = far_chunk(farbase); }
+                    if ((farmask >> (k - farbase)) & 1ull) continue;
+                }
+                if (A.screen_lds) {
+                    a = *reinterpret_cast<const f32x4 *>(scrA + (size_t)k * 256 + lane * 4);
+                    m4 = *reinterpret_cast<const f32x4 *>(scrM + (size_t)k * 16 + 4 * g);
+                }
+#ifdef DPMM_STAMPS
+                ++N_scr;
+#endif
+                const float c = A.cst[3 * k];
                 f32x4 acc[NG], zz[NG];
 #pragma unroll
                 for (int n = 0; n < NG; ++n) { acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; zz[n] = x[n][LB] - m4; }
@@ -569,7 +641,6 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                 for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
                     for (int n = 0; n < NG; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj], zz[n][jj], acc[n], 0, 0, 0);
-                const float c = A.cst[3 * k];
                 bool skip = true;
 #pragma unroll
                 for (int n = 0; n < NG; ++n) {
@@ -583,8 +654,9 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                     mk |= mk >> 16;
                     skip = skip && ((mk & 0xFFFFull) == 0xFFFFull);
                 }
-                if (!skip && lane == 0) sv[k >> 5] |= 1u << (k & 31);
+                if (!skip && lane == 0) { sv[k >> 5] |= 1u << (k & 31); ev[k >> 5] |= 1u << (k & 31); }
             }
+            STAMP(r2);
             // (3) survivors, with one-matrix lookahead for the fragment prefetch
             const int nwords = (K + 31) >> 5;
             int w = 0;
@@ -608,7 +680,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
             }
             STAMP(q1);
 #ifdef DPMM_STAMPS
-            T_quad += q1 - q0;
+            T_quad += r1 - q0; T_epi += r2 - r1; T_x += q1 - r2;   // refs / screen loop / survivors (x-load slot reused)
 #endif
         }
         STAMP(s2);
@@ -622,6 +694,34 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                 z = best;
             } else if (m_run == -INFINITY) {
                 z = 0;
+            } else if (tab_lds && screening) {
+                // skipped clusters hold -inf and contribute exact zeros: visit only the evaluated ones, in index order
+                // (bit-identical to the full scan)
+                const uint32_t *ev = eval_bits[tid >> 6];
+                const int nw = (K + 31) >> 5;
+                float s = 0.f;
+                for (int w = 0; w < nw; ++w)
+                    for (uint32_t bb = ev[w]; bb; bb &= bb - 1u) {
+                        const int k = (w << 5) + __builtin_ctz(bb);
+                        s += exp_det(nan_to_ninf(ltab[k * WPTS]) - m_run);
+                    }
+                const float t = u01(r.v[0]) * s;
+                float cw = 0.f;
+                z = K - 1;
+                bool found = false;
+                int last = 0;
+                for (int w = 0; w < nw && !found; ++w)
+                    for (uint32_t bb = ev[w]; bb; bb &= bb - 1u) {
+                        const int k = (w << 5) + __builtin_ctz(bb);
+                        last = k;
+                        cw += exp_det(nan_to_ninf(ltab[k * WPTS]) - m_run);
+                        if (!(cw < t)) { z = k; found = true; break; }
+                    }
+                // the full scan stops at the first k with cw >= t.  cw only changes at evaluated clusters, so if the
+                // threshold was never reached the reference scan ends at K-1; if it was reached at an evaluated k it
+                // is that k -- unless cw >= t already held BEFORE the first evaluated cluster (t == 0): then k = 0.
+                if (t <= 0.f) z = 0;
+                (void)last;
             } else if (tab_lds) {
                 // same arithmetic, same order as the global-table path (and the CPU oracle); 4 table reads in flight
                 float s = 0.f;
@@ -682,13 +782,13 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
         if (valid) A.bins[myp] = 2 * z + draw2(b0, b1, u_sub);
         STAMP(s4);
 #ifdef DPMM_STAMPS
-        T_x += s1 - s0; T_draw += s3 - s2; T_p2 += s4 - s3; T_tot += s4 - s0; ++ntile;
+        T_draw += s3 - s2; T_p2 += s4 - s3; T_tot += s4 - s0; ++ntile;
 #endif
     }
 #ifdef DPMM_STAMPS
     if (lane == 0 && A.dbg) {
         unsigned long long *d = A.dbg + wave_id * 8;
-        d[0] = T_x; d[1] = T_quad; d[2] = T_epi; d[3] = T_draw; d[4] = T_p2; d[5] = T_tot; d[6] = ntile; d[7] = 0;
+        d[0] = T_x; d[1] = T_quad; d[2] = T_epi; d[3] = T_draw; d[4] = T_p2; d[5] = T_tot; d[6] = ntile; d[7] = N_scr;
     }
 #endif
 }
@@ -699,7 +799,10 @@ static hipError_t launch_direct(const NiwSweepArgs &a, int grid, hipStream_t s) 
     NiwSweepArgs b = a;
     const int budget_rows = (int)((160 * 1024 / OCC - 512) / (4 * 16 * NG * sizeof(float)));
     b.lds_rows = a.K <= budget_rows ? a.K : 0;
-    const size_t lds_bytes = (size_t)b.lds_rows * 4 * 16 * NG * sizeof(float);
+    size_t lds_bytes = (size_t)b.lds_rows * 4 * 16 * NG * sizeof(float);
+    const size_t screen_bytes = (size_t)a.K * (256 + 16) * sizeof(float);
+    b.screen_lds = (NB >= 2 && a.screen_margin > 0.f && lds_bytes + screen_bytes + 1024 <= (size_t)(160 * 1024 / OCC)) ? 1 : 0;
+    if (b.screen_lds) lds_bytes += screen_bytes;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void *)niw_sweep_direct_kernel<NB, NG, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / OCC);
@@ -788,6 +891,54 @@ __global__ void niw_pack_kernel(const float *__restrict__ R, const float *__rest
         const int j = (int)(e / DP);
         mup[e] = d < D ? mu[(size_t)j * D + d] : 0.f;
     }
+}
+
+// Screening constants of the cluster-level distributions (rows 3k), one workgroup per cluster:
+//   lam[k]   = 0.9 / ||R_k^-1||_F^2  <=  sigma_min(R_k)^2 = lambda_min(Sigma_k^-1)   (R upper triangular, row-major [D][D])
+//   dist[k][j] = || mu_k - mu_j ||_2
+// Thread c solves R v = e_c by back substitution (column c of R^-1); v lives in LDS.
+__global__ __launch_bounds__(256) void niw_screen_prep_kernel(const float *__restrict__ R, const float *__restrict__ mu,
+                                                              int D, int K, float *__restrict__ lam, float *__restrict__ dist) {
+    extern __shared__ float sh[];            // Rk [D*D] | v [D][D+1] | red[256]
+    float *Rk = sh, *v = sh + (size_t)D * D, *red = v + (size_t)D * (D + 1);
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const float *Rg = R + (size_t)(3 * k) * D * D;
+    for (int e = tid; e < D * D; e += blockDim.x) Rk[e] = Rg[e];
+    __syncthreads();
+    float ss = 0.f;
+    for (int c = tid; c < D; c += blockDim.x) {
+        float *vc = v + (size_t)c * (D + 1);
+        for (int i = c; i >= 0; --i) {
+            float acc = (i == c) ? 1.f : 0.f;
+            for (int t = i + 1; t <= c; ++t) acc -= Rk[(size_t)i * D + t] * vc[t];
+            const float val = acc / Rk[(size_t)i * D + i];
+            vc[i] = val;
+            ss += val * val;
+        }
+    }
+    red[tid] = ss;
+    __syncthreads();
+    for (int off = blockDim.x / 2; off > 0; off >>= 1) {
+        if (tid < off) red[tid] += red[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float f = red[0];
+        lam[k] = (f > 0.f && f == f && f < INFINITY) ? 0.9f / f : 0.f;   // 0 disables the bound for this cluster
+    }
+    const float *mk = mu + (size_t)(3 * k) * D;
+    for (int j = tid; j < K; j += blockDim.x) {
+        const float *mj = mu + (size_t)(3 * j) * D;
+        float d2 = 0.f;
+        for (int d = 0; d < D; ++d) { const float t = mk[d] - mj[d]; d2 += t * t; }
+        dist[(size_t)k * K + j] = sqrtf(d2);
+    }
+}
+
+hipError_t launch_niw_screen_prep(const float *R, const float *mu, int D, int K, float *lam, float *dist, hipStream_t s) {
+    const size_t lds = sizeof(float) * ((size_t)D * D + (size_t)D * (D + 1) + 256);
+    hipLaunchKernelGGL(niw_screen_prep_kernel, dim3(K), dim3(256), lds, s, R, mu, D, K, lam, dist);
+    return hipGetLastError();
 }
 
 hipError_t launch_niw_pack(const float *R, const float *mu, float *Rp, float *mup, int D, int NB, int nmat, hipStream_t s) {

@@ -27,7 +27,7 @@ lib.dpmm_dev_stamps.restype = ctypes.c_int
 used = lib.dpmm_dev_stamps(wk._h, buf.ctypes.data_as(ctypes.c_void_p), nw)
 d = buf[:used].astype(np.float64)
 d = d[d[:, 6] > 0]
-names = ["load_x", "quad(34x)", "epilogue", "draw", "phase2", "total"]
+names = ["survivors", "refs(full)", "screen", "draw", "phase2", "total"]
 print("waves", len(d), "tiles/wave", d[:, 6].mean())
 for i, nm in enumerate(names):
     print(f"{nm:10s} cycles/tile {d[:, i].sum() / d[:, 6].sum():10.0f}   share {100 * d[:, i].sum() / d[:, 5].sum():5.1f}%")
