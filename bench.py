@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=float, default=1e7, help="total number of points (default: the BASELINE metric's N)")
+    ap.add_argument("--points", type=float, default=1e7, help="total number of points (default: the BASELINE metric's N)")
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--clusters", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -73,10 +73,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
+    # test hook (not used by the driver): DPMM_BENCH_BACKEND=gloo + DPMM_BENCH_SHARE_DEVICE=1 lets several ranks share
+    # one GPU so that the world_size > 1 code path can be exercised on a single-GPU box
+    backend = os.environ.get("DPMM_BENCH_BACKEND", "nccl")
+    if os.environ.get("DPMM_BENCH_SHARE_DEVICE"):
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the product has no CPU fallback)")
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
@@ -86,7 +94,7 @@ def main():
     host = importlib.import_module("dpmmsubclusters_jl_amd.host")
     from dpmmsubclusters_jl_amd.host.comm import default_comm
 
-    N, D, K = int(args.n), args.dim, args.clusters
+    N, D, K = int(args.points), args.dim, args.clusters
     comm = default_comm()
     lo, hi = (N * rank) // world, (N * (rank + 1)) // world
     data_seed, sampler_seed, burnout = 12345, 123456789, 20
@@ -120,7 +128,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=(f"cuda:{local_rank}" if backend == "nccl" else "cpu"))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

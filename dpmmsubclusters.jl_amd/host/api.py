@@ -123,6 +123,9 @@ def predict(dp_model, data, device=None, worker_factory=None):
         raise ValueError("data dimension does not match the model")
     w = s.points_count.astype(np.float64) + s.alpha
     w = (w / w.sum()).astype(np.float32)
+    if getattr(s, "leader_mode", False):          # collective: the posteriors live on the leader only
+        for key in sorted(s.post):
+            s.comm.broadcast(s.post[key])
     dev = getattr(s.wk, "device", 0) if device is None else device
     wk = (worker_factory or binding.Worker)(s.prior.kind, D, n, first_index=0, device=dev, seed=0)
     try:

@@ -22,6 +22,8 @@ class TorchDistComm:
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.backend = dist.get_backend()
         self.device = int(os.environ.get("LOCAL_RANK", 0)) if device is None else device
+        if os.environ.get("DPMM_BENCH_SHARE_DEVICE"):
+            self.device = 0
         self._buf = None
 
     def _buffer(self, n):
@@ -55,6 +57,18 @@ class TorchDistComm:
             t = t.to(f"cuda:{self.device}")
         self.dist.all_reduce(t)
         return t.cpu().numpy()
+
+    def broadcast(self, arr, src=0):
+        """In-place broadcast of a C-contiguous numpy array from rank `src` (leader mode of the sampler)."""
+        t = self.torch.from_numpy(arr)
+        if self.backend == "nccl":
+            d = t.to(f"cuda:{self.device}")
+            self.dist.broadcast(d, src)
+            if self.rank != src:
+                t.copy_(d.cpu())
+        else:
+            self.dist.broadcast(t, src)
+        return arr
 
     def broadcast_int(self, v):
         obj = [int(v)]

@@ -114,6 +114,10 @@ class niw_hyperparams(distribution_hyper_params):
             mu, R, ld = native.niw_sample(post["kappa"], post["nu"], post["m"], post["U"], seed, epoch, ids, nthreads=nthreads)
         return dict(mu=mu, R=R, logdet=ld)
 
+    def empty_params(self, n):
+        D = self.dim
+        return dict(mu=np.zeros((n, D), np.float32), R=np.zeros((n, D, D), np.float32), logdet=np.zeros(n, np.float32))
+
     def draw_noise(self, n, seed, epoch, nthreads=None):
         """Statistics-independent part of `sample` (standard normals); the sampler runs it while the GPU sweeps."""
         return native.niw_noise(n, self.dim, seed, epoch, np.arange(n), nthreads=nthreads)
@@ -188,6 +192,9 @@ class multinomial_hyper(distribution_hyper_params):
     def sample(self, post, seed, epoch, ids, nthreads=None):
         """multinomial_prior.jl:23-25: log.(rand(Dirichlet(α')))"""
         return dict(logp=native.dirichlet_log(post["alpha"], seed, epoch, ids, nthreads=nthreads))
+
+    def empty_params(self, n):
+        return dict(logp=np.zeros((n, self.dim), np.float32))
 
     def upload(self, worker, params, lr_weights, weights):
         K = len(weights)

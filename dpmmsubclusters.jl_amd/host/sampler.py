@@ -42,6 +42,9 @@ class LocalComm:
     def reduce_counts(self, table):
         return table
 
+    def broadcast(self, arr, src=0):
+        return arr
+
 
 def nmi_vi_from_contingency(C):
     """NMI (Clustering.jl `mutualinfo(a, b, normed=true)` = 2 I / (H_a + H_b)) and VI (`varinfo` = H_a + H_b - 2 I)
@@ -79,6 +82,17 @@ class DPMMSampler:
         self.K = 0
         self.timers = {}
         self._noise_job = None
+        # Leader mode (multi-rank only): rank 0 alone runs the heavy host maths (posterior factorisations, parameter
+        # draws, merge log-marginals) with all host threads and broadcasts the small results; every rank still takes
+        # the same Metropolis decisions from the same numbers.  Chosen when redundant execution would leave each rank
+        # with only a few host threads (e.g. a container CPU quota); DPMM_LEADER_MODE=0/1 overrides.
+        import os
+        from . import native as _native
+        env = os.environ.get("DPMM_LEADER_MODE")
+        self.leader_mode = self.comm.world > 1 and (env == "1" or (env is None and (nthreads or _native.default_threads()) < 8))
+        self.is_leader = self.comm.rank == 0
+        if self.leader_mode and self.is_leader and nthreads is None:
+            self.nthreads = max(1, min(32, _native._cpu_budget() - 2))
 
     # ------------------------------------------------------------------ small helpers
     def _next_epoch(self):
@@ -124,7 +138,7 @@ class DPMMSampler:
     # ------------------------------------------------------------------ noise prefetch (overlaps the GPU sweep)
     def _start_noise(self):
         """Generate the standard-normal part of the NEXT parameter draws on a helper thread while the GPU sweeps."""
-        if not hasattr(self.prior, "draw_noise"):
+        if not hasattr(self.prior, "draw_noise") or (self.leader_mode and not self.is_leader):
             return
         import threading
         rows = 3 * (self.K + 4)          # head-room for clusters born from splits
@@ -160,8 +174,10 @@ class DPMMSampler:
         if hasattr(self.prior, "update_from_packed"):
             if self.post is None or len(self.post["kappa"]) != 3 * self.K:
                 self.post = self.prior.empty_post(3 * self.K)
-            self.prior.update_from_packed(packed, None if ks is None else sel, self.N, self.sums, self.S, self.post,
-                                          nthreads=self.nthreads)
+            if not self.leader_mode or self.is_leader:
+                self.prior.update_from_packed(packed, None if ks is None else sel, self.N, self.sums, self.S, self.post,
+                                              nthreads=self.nthreads)
+            self._sync_small()
             self.points_count[sel] = np.rint(self.N[sel, 0]).astype(np.int64)
             self._tic("posterior_host", t0)
             return
@@ -181,16 +197,38 @@ class DPMMSampler:
             self._set_post_rows(rows, post)
         self._tic("posterior_host", t0)
 
+    def _sync_small(self):
+        """Leader mode: the per-distribution scalars every rank needs for its (identical) decisions."""
+        if not self.leader_mode or self.post is None or "kappa" not in self.post:
+            return
+        K = self.K
+        buf = np.empty((4, 3 * K))
+        if self.is_leader:
+            buf[0] = self.N.reshape(3 * K); buf[1] = self.post["kappa"]; buf[2] = self.post["nu"]; buf[3] = self.post["logdet_psi"]
+        self.comm.broadcast(buf)
+        if not self.is_leader:
+            self.N[:] = buf[0].reshape(K, 3)
+            self.post["kappa"][:] = buf[1]; self.post["nu"][:] = buf[2]; self.post["logdet_psi"][:] = buf[3]
+
+    def _sync_params(self):
+        if not self.leader_mode:
+            return
+        for k in sorted(self.params):
+            self.comm.broadcast(self.params[k])
+
     # ------------------------------------------------------------------ step 1
     def sample_clusters(self):
         t0 = time.perf_counter()
         K = self.K
         self.draw_epoch += 1
         noise = self._take_noise(self.draw_epoch, 3 * K)
-        if noise is not None:
+        if self.leader_mode and not self.is_leader:
+            self.params = self.prior.empty_params(3 * K)
+        elif noise is not None:
             self.params = self.prior.sample(self.post, self.seed, self.draw_epoch, np.arange(3 * K), nthreads=self.nthreads, noise=noise)
         else:
             self.params = self.prior.sample(self.post, self.seed, self.draw_epoch, np.arange(3 * K), nthreads=self.nthreads)
+        self._sync_params()
         self._tic("sample_params_host", t0)
         t0 = time.perf_counter()
         half = self.alpha / 2
@@ -287,7 +325,11 @@ class DPMMSampler:
         Nf, sf, Sf = self._stats_flat()
         Lc = self.prior.log_marginal(self.post, Nf).reshape(K, 3)[:, 0]
         t0 = time.perf_counter()
-        Lp = self.prior.log_marginal_pairs(np.stack([3 * pi, 3 * pj], 1), dict(N=Nf, sums=sf, S=Sf), nthreads=self.nthreads)
+        if not self.leader_mode or self.is_leader:
+            Lp = self.prior.log_marginal_pairs(np.stack([3 * pi, 3 * pj], 1), dict(N=Nf, sums=sf, S=Sf), nthreads=self.nthreads)
+        else:
+            Lp = np.empty(len(pi))
+        Lp = self.comm.broadcast(np.ascontiguousarray(Lp, np.float64)) if self.leader_mode else Lp
         self._tic("merge_pairs_host", t0)
         a = self.alpha
         Ni, Nj = self.N[pi, 0], self.N[pj, 0]
@@ -317,7 +359,8 @@ class DPMMSampler:
             if self.S is not None:
                 self.S[i, 0] = self.S[i, 1] + self.S[i, 2]
             Nf, sf, Sf = self._stats_flat()
-            self._set_post_rows([ri], self.prior.posterior(Nf[[ri]], sf[[ri]], Sf[[ri]] if Sf is not None else None, nthreads=1))
+            if not self.leader_mode or self.is_leader or "kappa" not in self.post:
+                self._set_post_rows([ri], self.prior.posterior(Nf[[ri]], sf[[ri]], Sf[[ri]] if Sf is not None else None, nthreads=1))
             self.lr_weights[i] = self._dirichlet([Ni_ + a / 2, Nj_ + a / 2]).astype(np.float32)
             self.splittable[i] = False
             self.hist[i] = -np.inf
@@ -325,6 +368,7 @@ class DPMMSampler:
             self.points_count[j] = 0
             self.N[j, 0] = 0
             self.splittable[j] = False
+        self._sync_small()
         self.wk.merge(np.asarray(m_i) + 1, np.asarray(m_j) + 1)
 
     # ------------------------------------------------------------------ step 8

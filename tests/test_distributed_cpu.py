@@ -19,7 +19,8 @@ def _problem():
     return x, z + 1
 
 
-def _run(rank, world, port, out):
+def _run(rank, world, port, out, leader="0"):
+    os.environ["DPMM_LEADER_MODE"] = leader
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from __graft_entry__ import load_package
@@ -43,11 +44,11 @@ def _run(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def _spawn(world, port, out):
+def _spawn(world, port, out, leader="0"):
     if world == 1:
         _run(0, 1, port, out)
     else:
-        mp.spawn(_run, args=(world, port, out), nprocs=world, join=True)
+        mp.spawn(_run, args=(world, port, out, leader), nprocs=world, join=True)
 
 
 @pytest.mark.timeout(600)
@@ -61,6 +62,18 @@ def test_two_ranks_match_one_rank(tmp_path):
     assert (a["labels"] != b["labels"]).mean() < 1e-3           # index-keyed RNG: sharding does not change the draws
     assert a["nmi"][-1] > 0.95 and b["nmi"][-1] > 0.95
     np.testing.assert_allclose(a["weights"], b["weights"], rtol=1e-5)
+
+
+@pytest.mark.timeout(600)
+def test_leader_mode_matches_redundant_mode(tmp_path):
+    """Leader mode (rank 0 does the heavy host maths and broadcasts the results) must take exactly the decisions of the
+    redundant mode: same K history, same labels."""
+    o1, o2 = str(tmp_path / "red.npz"), str(tmp_path / "lead.npz")
+    _spawn(2, 29613, o1, "0")
+    _spawn(2, 29614, o2, "1")
+    a, b = np.load(o1), np.load(o2)
+    assert np.array_equal(a["K"], b["K"]) and np.array_equal(a["labels"], b["labels"]) and np.array_equal(a["sub"], b["sub"])
+    np.testing.assert_array_equal(a["weights"], b["weights"])
 
 
 def test_fake_worker_matches_packed_contract():
