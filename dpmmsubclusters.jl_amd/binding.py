@@ -77,7 +77,11 @@ def load_library():
     if _LIB is None:
         p = lib_path()
         if not os.path.exists(p):
-            raise FileNotFoundError(f"{p} not built: run __graft_entry__.build() (there is no CPU fallback)")
+            try:   # fresh checkout: compile for gfx950 (hipcc cross-compiles without a GPU); never falls back to CPU code
+                build_library()
+            except Exception as e:
+                raise FileNotFoundError(f"{p} not built and building it failed ({e}): run __graft_entry__.build() "
+                                        "(there is no CPU fallback)") from e
         lib = ctypes.CDLL(p)
         for name, res, args in ABI:
             fn = getattr(lib, name)

@@ -273,3 +273,42 @@ def test_contingency_table(pkg):
     nmi, vi = host.sampler.nmi_vi_from_contingency(C)
     assert abs(nmi - normalized_mutual_info_score(gt, lab)) < 1e-10 and vi >= 0
     wk.close()
+
+
+@pytest.mark.parametrize("D,n,K", [(64, 9000, 70), (64, 6000, 130), (48, 5000, 40), (24, 6000, 12)])
+def test_many_clusters_and_padded_dims_with_screening(pkg, D, n, K):
+    """K > 64 exercises the chunked far-mask, K > ~150 the global-scratch table; D = 48 / 24 the zero-padded blocks.
+    Runs two consecutive sweeps so that the second one uses previous labels (reference clusters), the bin-sorted
+    processing order and the screen; labels must equal the oracle draw from the GPU's own full table."""
+    P = make_problem(D, n, K, seed=5 + K, sep=2.5, sorted_points=False)
+    seed, first = 31337, 17
+    wk = gpu_worker(pkg, P, seed=seed, first_index=first)
+    wk.sweep(1)
+    wk.suffstats_packed()                       # builds the permutation the next sweep walks
+    wk.set_params_niw(P["mu"], P["invS"], P["logdet"], P["lr"], P["w"])
+    wk.sweep(2)
+    lab, sub = wk.get_labels()
+    tab = wk.debug_loglik()
+    u0, u1 = orc.uniforms(seed, 2, 0, first, n)
+    assert np.array_equal(orc.sample_log_cat(tab, u0), lab)
+    olab, osub = orc.sweep_niw(P["X"], D, P["mu"], P["invS"], P["logdet"], np.log(P["w"]), np.log(P["lr"]), seed=seed, epoch=2, first_idx=first)
+    assert (lab != olab).sum() <= max(2, int(3e-4 * n))
+    same = lab == olab
+    assert (sub[same] != osub[same]).sum() <= max(2, int(1e-3 * n))
+    wk.sweep(3, final=True)
+    assert np.array_equal(wk.get_labels()[0], orc.argmax_rows(tab))
+    wk.close()
+
+
+def test_large_k_global_table_path(pkg):
+    """K = 300 > LDS table budget: a_k table in the global scratch, screening bits over 10 words."""
+    P = make_problem(32, 4000, 300, seed=77, sep=3.0)
+    wk = gpu_worker(pkg, P, seed=3)
+    wk.sweep(1); wk.suffstats_packed()
+    wk.set_params_niw(P["mu"], P["invS"], P["logdet"], P["lr"], P["w"])
+    wk.sweep(2)
+    lab, _ = wk.get_labels()
+    tab = wk.debug_loglik()
+    u0, _ = orc.uniforms(3, 2, 0, 0, 4000)
+    assert np.array_equal(orc.sample_log_cat(tab, u0), lab)
+    wk.close()
