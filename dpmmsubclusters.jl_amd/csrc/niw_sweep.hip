@@ -416,7 +416,7 @@ __device__ __forceinline__ void load_rb0(const float *__restrict__ Rm, const flo
 template <int NB, int NG, int OCC>
 __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs A) {
 #ifdef DPMM_STAMPS
-    unsigned long long T_x = 0, T_quad = 0, T_epi = 0, T_draw = 0, T_p2 = 0, T_tot = 0, N_scr = 0; int ntile = 0;
+    unsigned long long T_x = 0, T_quad = 0, T_epi = 0, T_draw = 0, T_p2 = 0, T_tot = 0, N_scr = 0, T_p2x = 0, T_p2y = 0; int ntile = 0;
 #endif
     constexpr int DP = 16 * NB, NP = NB * (NB + 1) / 2, MATSZ = NP * 256, WPTS = 16 * NG;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -580,7 +580,22 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
             full_eval(k0, k1 != k0 ? A.Rp + (size_t)(3 * k1) * MATSZ : nullptr, A.mup + (size_t)(3 * k1) * DP);
             if (k1 != k0) full_eval(k1, nullptr, A.mup);
             STAMP(r1);
-            // far mask: lane j owns cluster (64 chunk + j); the wave walks its points with readlane broadcasts
+            // far mask: lane j owns cluster (chunk base + j).  The wave is reduced to its worst case first
+            // (r_max = farthest point from mu_k0, best_min = lowest reference value), so one vector step tests 64 clusters:
+            //   a_k(x) <= cst_k - lam_k/2 (||mu_k - mu_k0|| - r_max)_+^2  <  best_min - margin   for every point x of the wave.
+            float r_max = 0.f, b_min = INFINITY;
+            if (prescreen) {
+#pragma unroll
+                for (int n = 0; n < NG; ++n) {
+                    if (pvalid[n]) { r_max = fmaxf(r_max, rn[n]); b_min = fminf(b_min, bestn[n]); }
+                }
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) {      // the 16 columns; the 4 row groups hold copies
+                    r_max = fmaxf(r_max, __shfl_xor(r_max, off));
+                    b_min = fminf(b_min, __shfl_xor(b_min, off));
+                }
+            }
+            float ch_c = pc_c;                                // cst of cluster (farbase + lane) for the current chunk
             auto far_chunk = [&](int base) -> unsigned long long {
                 const int j = base + lane;
                 float cj = pc_c, lj = pc_l, dj = pc_d;
@@ -588,21 +603,11 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                     cj = lj = dj = 0.f;
                     if (j < K) { cj = A.cst[3 * j]; lj = A.lam[j]; dj = A.mdist[(size_t)k0 * K + j] * 0.99999f; }
                 }
-                bool far = (j < K) && lj > 0.f;
-#pragma unroll
-                for (int n = 0; n < NG; ++n) {
-                    for (int c = 0; c < 16; ++c) {
-                        const float rp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rn[n]), c));
-                        const float bp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bestn[n]), c));
-                        const bool pv = wbase + 16 * n + c < A.n;          // wave-uniform
-                        const float dd = fmaxf(dj - rp, 0.f);
-                        far = far && (!pv || (cj - 0.5f * lj * dd * dd < bp - A.screen_margin));
-                    }
-                }
+                ch_c = cj;
+                const float dd = fmaxf(dj - r_max, 0.f);
+                const bool far = (j < K) && lj > 0.f && (cj - 0.5f * lj * dd * dd < b_min - A.screen_margin);
                 return __ballot(far);
             };
-            unsigned long long farmask = 0ull;
-            int farbase = -64;
             // (2b) MFMA screen of the clusters that remain
             uint32_t *sv = surv_bits[tid >> 6];
             uint32_t *ev = eval_bits[tid >> 6];      // every cluster whose a_k is finite in the table (refs + survivors)
@@ -610,37 +615,31 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
             if (lane == 0) { ev[k0 >> 5] |= 1u << (k0 & 31); ev[k1 >> 5] |= 1u << (k1 & 31); }
             const float margin = A.screen_margin;
             constexpr int LASTP = NP - 1, LB = NB - 1;
-            f32x4 fr = (f32x4){0.f, 0.f, 0.f, 0.f}, ml = fr;
-            if (!A.screen_lds) {
-                fr = *reinterpret_cast<const f32x4 *>(A.Rp + (size_t)LASTP * 256 + lane * 4);
-                ml = *reinterpret_cast<const f32x4 *>(A.mup + 16 * LB + 4 * g);
-            }
-            for (int k = 0; k < K; ++k) {
-                f32x4 a = fr, m4 = ml;
-                if (!A.screen_lds && k + 1 < K) {
-                    fr = *reinterpret_cast<const f32x4 *>(A.Rp + ((size_t)(3 * (k + 1)) * NP + LASTP) * 256 + lane * 4);
-                    ml = *reinterpret_cast<const f32x4 *>(A.mup + (size_t)(3 * (k + 1)) * DP + 16 * LB + 4 * g);
-                }
-                if (k == k0 || k == k1) continue;
-                if (prescreen) {
-                    if (k >= farbase + 64) { farbase = k & ~63; farmask = far_chunk(farbase); }
-                    if ((farmask >> (k - farbase)) & 1ull) continue;
-                }
+            STAMP(r1a);
+            STAMP(r1b);
+            // candidates = clusters that are neither references nor provably far; each gets the MFMA screen
+            // (a two-stage pipeline of issue/finish was measured: no gain, and it spills)
+            auto issue = [&](int k, f32x4 (&acc)[NG]) {
+                f32x4 a, m4;
                 if (A.screen_lds) {
                     a = *reinterpret_cast<const f32x4 *>(scrA + (size_t)k * 256 + lane * 4);
                     m4 = *reinterpret_cast<const f32x4 *>(scrM + (size_t)k * 16 + 4 * g);
+                } else {
+                    a = *reinterpret_cast<const f32x4 *>(A.Rp + ((size_t)(3 * k) * NP + LASTP) * 256 + lane * 4);
+                    m4 = *reinterpret_cast<const f32x4 *>(A.mup + (size_t)(3 * k) * DP + 16 * LB + 4 * g);
                 }
-#ifdef DPMM_STAMPS
-                ++N_scr;
-#endif
-                const float c = A.cst[3 * k];
-                f32x4 acc[NG], zz[NG];
+                f32x4 zz[NG];
 #pragma unroll
                 for (int n = 0; n < NG; ++n) { acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; zz[n] = x[n][LB] - m4; }
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
                     for (int n = 0; n < NG; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj], zz[n][jj], acc[n], 0, 0, 0);
+            };
+            auto finish = [&](int k, float c, const f32x4 (&acc)[NG]) {
+#ifdef DPMM_STAMPS
+                ++N_scr;
+#endif
                 bool skip = true;
 #pragma unroll
                 for (int n = 0; n < NG; ++n) {
@@ -655,6 +654,26 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                     skip = skip && ((mk & 0xFFFFull) == 0xFFFFull);
                 }
                 if (!skip && lane == 0) { sv[k >> 5] |= 1u << (k & 31); ev[k >> 5] |= 1u << (k & 31); }
+            };
+            for (int base = 0; base < K; base += 64) {
+                unsigned long long cand = (K - base >= 64) ? ~0ull : ((1ull << (K - base)) - 1ull);
+                if (prescreen) cand &= ~far_chunk(base);            // also loads ch_c for this chunk
+                if (k0 >= base && k0 < base + 64) cand &= ~(1ull << (k0 - base));
+                if (k1 >= base && k1 < base + 64) cand &= ~(1ull << (k1 - base));
+                auto pop = [&]() -> int {
+                    if (!cand) return -1;
+                    const int b = __builtin_ctzll(cand);
+                    cand &= cand - 1ull;
+                    return base + b;
+                };
+                auto cst_of = [&](int k) -> float {
+                    return prescreen ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ch_c), k - base)) : A.cst[3 * k];
+                };
+                f32x4 acc[NG];
+                for (int k = pop(); k >= 0; k = pop()) {
+                    issue(k, acc);
+                    finish(k, cst_of(k), acc);
+                }
             }
             STAMP(r2);
             // (3) survivors, with one-matrix lookahead for the fragment prefetch
@@ -680,7 +699,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
             }
             STAMP(q1);
 #ifdef DPMM_STAMPS
-            T_quad += r1 - q0; T_epi += r2 - r1; T_x += q1 - r2;   // refs / screen loop / survivors (x-load slot reused)
+            T_quad += r1 - q0; T_epi += r2 - r1b; T_x += q1 - r2; T_p2x += r1a - r1; T_p2y += r1b - r1a;  // refs / K-loop / survivors / pre-far / far-mask
 #endif
         }
         STAMP(s2);
@@ -788,7 +807,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
 #ifdef DPMM_STAMPS
     if (lane == 0 && A.dbg) {
         unsigned long long *d = A.dbg + wave_id * 8;
-        d[0] = T_x; d[1] = T_quad; d[2] = T_epi; d[3] = T_draw; d[4] = T_p2; d[5] = T_tot; d[6] = ntile; d[7] = N_scr;
+        d[0] = T_x; d[1] = T_quad; d[2] = T_epi; d[3] = T_draw; d[4] = T_p2; d[5] = T_tot; d[6] = ntile; d[7] = N_scr; d[0] = T_p2x; d[3] = T_p2y;
     }
 #endif
 }

@@ -24,7 +24,7 @@ buf = np.zeros((nw, 8), np.uint64)
 lib.dpmm_dev_stamps.restype = ctypes.c_int
 used = lib.dpmm_dev_stamps(wk._h, buf.ctypes.data_as(ctypes.c_void_p), nw)
 d = buf[:used].astype(np.float64); d = d[d[:, 6] > 0]
-names = ["survivors", "refs(full)", "screen", "draw", "phase2", "total"]
+names = ["pre-far(init,sv)", "refs(full)", "K-loop", "far-mask", "phase2", "total"]
 for i, nm in enumerate(names):
     print(f"{nm:10s} cycles/tile {d[:, i].sum() / d[:, 6].sum():10.0f}   share {100 * d[:, i].sum() / d[:, 5].sum():5.1f}%")
 print("MFMA-screened clusters per tile:", d[:, 7].sum() / d[:, 6].sum())
