@@ -64,8 +64,8 @@ struct dpmm_ctx {
     float *d_scratch = nullptr;
     int64_t scratch_stride = 0;
     bool have_params = false;
-    float *d_lam = nullptr, *d_mdist = nullptr;   // NIW screening constants (per sweep)
-    bool have_screen_prep = false;
+    float *d_lam = nullptr, *d_mdist = nullptr, *d_tail = nullptr;   // NIW screening constants (per sweep)
+    bool have_screen_prep = false, have_tail = false;
     float *d_tdf = nullptr;   // Student-t constants of the predictive mode ([3K][2]) or null
     bool predictive = false;
 
@@ -131,8 +131,8 @@ const char *dpmm_last_error(const dpmm_ctx *ctx) { return ctx ? ctx->err.c_str()
 
 static void free_params(dpmm_ctx *c) {
     hipFree(c->d_raw); hipFree(c->d_mu); hipFree(c->d_Rp); hipFree(c->d_mup); hipFree(c->d_cst);
-    hipFree(c->d_scratch); hipFree(c->d_slabs); hipFree(c->d_out); hipFree(c->d_Lp16); hipFree(c->d_tdf); hipFree(c->d_lam); hipFree(c->d_mdist);
-    c->d_Lp16 = nullptr; c->d_tdf = nullptr; c->d_lam = nullptr; c->d_mdist = nullptr;
+    hipFree(c->d_scratch); hipFree(c->d_slabs); hipFree(c->d_out); hipFree(c->d_Lp16); hipFree(c->d_tdf); hipFree(c->d_lam); hipFree(c->d_mdist); hipFree(c->d_tail);
+    c->d_Lp16 = nullptr; c->d_tdf = nullptr; c->d_lam = nullptr; c->d_mdist = nullptr; c->d_tail = nullptr;
     c->d_raw = c->d_mu = c->d_Rp = c->d_mup = c->d_cst = c->d_scratch = nullptr;
     c->d_slabs = c->d_out = nullptr;
 }
@@ -153,6 +153,7 @@ static int ensure_capacity(dpmm_ctx *c, int K) {
         HIPCHK(c, hipMalloc(&c->d_Rp, sizeof(float) * 3 * cap * NP * 256));
         HIPCHK(c, hipMalloc(&c->d_mup, sizeof(float) * 3 * cap * 16 * c->NB));
         HIPCHK(c, hipMalloc(&c->d_lam, sizeof(float) * cap));
+        HIPCHK(c, hipMalloc(&c->d_tail, sizeof(float) * 16 * cap));
         HIPCHK(c, hipMalloc(&c->d_mdist, sizeof(float) * (size_t)cap * cap));
     } else {
         const size_t NT = (size_t)(c->ldx + 15) / 16, NRB = (size_t)(3 * cap + 15) / 16;
@@ -356,11 +357,17 @@ int dpmm_set_params_niw_chol(dpmm_ctx *c, int K, const float *mu, const float *R
     memcpy(hp + nR + nmu, cst.data(), sizeof(float) * ncst);
     // the pack kernel reads R and mu straight from the pinned staging buffer (no copy-engine transfer)
     HIPCHK(c, launch_copy_bytes(c->d_cst, hp + nR + nmu, sizeof(float) * ncst, c->stream));
-    HIPCHK(c, launch_niw_pack(hp, hp + nR, c->d_Rp, c->d_mup, c->D, c->NB, 3 * K, c->stream));
+    static const bool no_tail = getenv("DPMM_NIW_NO_TAIL") != nullptr;
+    c->have_tail = !no_tail && c->D >= 4 && c->D % 4 == 0 && c->D <= 64 && K > 2;
+    HIPCHK(c, launch_niw_pack(hp, hp + nR, c->d_Rp, c->d_mup, c->D, c->NB, 3 * K, c->have_tail ? c->d_tail : nullptr, c->d_cst, c->stream));
     c->have_screen_prep = false;
     if (c->D > 16 && c->D <= 64 && K > 2) {
+        // the vectorised far mask (64 clusters per step) pays once there are many clusters, or when the VALU tail
+        // screen is unavailable (D not a multiple of 4); DPMM_NIW_PRESCREEN=0/1 forces it off/on
+        static const int pre_env = [] { const char *e = getenv("DPMM_NIW_PRESCREEN"); return e ? atoi(e) : -1; }();
         static const bool no_pre = getenv("DPMM_NIW_NO_PRESCREEN") != nullptr;
-        if (!no_pre) {
+        const bool want = pre_env >= 0 ? pre_env != 0 : (!c->have_tail || K > 64);
+        if (!no_pre && want) {
             HIPCHK(c, launch_niw_screen_prep(hp, hp + nR, c->D, K, c->d_lam, c->d_mdist, c->stream));
             c->have_screen_prep = true;
             if (g_trace_slow) {
@@ -462,20 +469,17 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
             a.use_prev = c->have_labels ? 1 : 0;
             a.lam = (c->have_screen_prep && !c->predictive) ? c->d_lam : nullptr;
             a.mdist = c->d_mdist;
+            a.tail = (c->have_tail && !c->predictive) ? c->d_tail : nullptr;
+            a.tail_g = ((c->D - 4) % 16) / 4;
             a.order = (!table && c->have_perm && !no_order) ? c->sb.perm : nullptr;
             a.order_total = c->sb.perm_total;
         }
         {
             static const int stag = [] { const char *e = getenv("DPMM_NIW_STAGGER"); return e ? atoi(e) : 0; }();
-            if (stag > 0 && !table && c->NB <= 4) {
-                unsigned *ctr = reinterpret_cast<unsigned *>(c->d_small + 4 * DPMM_MAX_CLUSTERS - 4);
-                HIPCHK(c, hipMemsetAsync(ctr, 0, sizeof(unsigned), c->stream));
-                a.tile_counter = ctr;
-                a.stagger_cycles_per_cluster = stag;
-            }
+            if (stag > 0 && !table && c->NB <= 4) a.stagger_cycles_per_cluster = stag;   // cycles odd wave slots sleep at start
         }
 #ifdef DPMM_STAMPS
-        if (!g_dbg) { hipMalloc(&g_dbg, sizeof(unsigned long long) * 8 * 4 * 4096); hipMemset(g_dbg, 0, sizeof(unsigned long long) * 8 * 4 * 4096); }
+        if (!g_dbg) { hipMalloc(&g_dbg, sizeof(unsigned long long) * 16 * 4 * 4096); hipMemset(g_dbg, 0, sizeof(unsigned long long) * 16 * 4 * 4096); }
         a.dbg = g_dbg;
 #endif
         HIPCHK(c, launch_niw_sweep(c->NB, a, c->sweep_grid, c->stream));
@@ -795,7 +799,7 @@ int dpmm_sync(dpmm_ctx *c) {
 // diagnostic builds only: copy the per-wave phase cycle sums of the last NIW sweep
 int dpmm_dev_stamps(dpmm_ctx *c, unsigned long long *out, int nwaves) {
     hipStreamSynchronize(c->stream);
-    hipMemcpy(out, g_dbg, sizeof(unsigned long long) * 8 * nwaves, hipMemcpyDeviceToHost);
+    hipMemcpy(out, g_dbg, sizeof(unsigned long long) * 16 * nwaves, hipMemcpyDeviceToHost);
     return c->sweep_grid * 4;
 }
 #endif

@@ -35,6 +35,8 @@ struct NiwSweepArgs {
     unsigned *tile_counter;   // zeroed before the launch: dynamic tile queue (null: static striding)
     int stagger_cycles_per_cluster;
     float screen_margin;      // > 0: skip clusters whose a_k is provably below (reference - margin) for a whole wave (NIW, D in 17..64)
+    const float *tail;        // [K][16] 4x4 tail factors + tail means of the cluster-level matrices (null: no VALU tail screen)
+    int tail_g;               // row group (lane >> 4) whose x registers of the last block hold features D-4..D-1
     const float *lam;         // [K] lower bounds of lambda_min(Sigma_k^-1) (null: no scalar pre-screen)
     const float *mdist;       // [K][K] distances between the cluster means
     int screen_lds;           // set by the launcher: screen operands of all K clusters are staged in LDS
@@ -47,7 +49,7 @@ int niw_tile_points(int NB);
 int niw_occupancy(int NB);  // resident 256-thread workgroups per CU the sweep kernel is built for
 hipError_t launch_niw_sweep(int NB, const NiwSweepArgs &a, int grid, hipStream_t s);
 hipError_t launch_niw_screen_prep(const float *R, const float *mu, int D, int K, float *lam, float *dist, hipStream_t s);
-hipError_t launch_niw_pack(const float *R, const float *mu, float *Rp, float *mup, int D, int NB, int nmat, hipStream_t s);
+hipError_t launch_niw_pack(const float *R, const float *mu, float *Rp, float *mup, int D, int NB, int nmat, float *tail, const float *cst, hipStream_t s);
 
 struct MultSweepArgs {
     const float *X;

@@ -20,11 +20,15 @@ for _ in range(6):
 print("kernel ms (stamped build)", wk.last_kernel_ms()[0])
 lib = b.load_library()
 nw = 4 * 4096
-buf = np.zeros((nw, 8), np.uint64)
+buf = np.zeros((nw, 16), np.uint64)
 lib.dpmm_dev_stamps.restype = ctypes.c_int
 used = lib.dpmm_dev_stamps(wk._h, buf.ctypes.data_as(ctypes.c_void_p), nw)
-d = buf[:used].astype(np.float64); d = d[d[:, 6] > 0]
-names = ["pre-far(init,sv)", "refs(full)", "K-loop", "far-mask", "phase2", "total"]
+d = buf[:used].astype(np.float64); d = d[d[:, 8] > 0]
+names = ["x load", "refs(full)", "screen setup", "K-loop", "survivors", "draw", "phase2", "total"]
+nt = d[:, 8].sum()
 for i, nm in enumerate(names):
-    print(f"{nm:10s} cycles/tile {d[:, i].sum() / d[:, 6].sum():10.0f}   share {100 * d[:, i].sum() / d[:, 5].sum():5.1f}%")
-print("MFMA-screened clusters per tile:", d[:, 7].sum() / d[:, 6].sum())
+    print(f"{nm:14s} cycles/tile {d[:, i].sum() / nt:10.0f}   share {100 * d[:, i].sum() / d[:, 7].sum():5.1f}%")
+print("refs setup (table init, prev labels, first fragments, pre-screen norms) cycles/tile:", d[:, 12].sum() / nt)
+print("  of which: table init + k0:", d[:, 13].sum() / nt, " first fragments + pre-screen constants arrive:", d[:, 14].sum() / nt)
+print("tail-screened clusters per tile:", d[:, 9].sum() / nt)
+print("MFMA-screened clusters per tile:", d[:, 10].sum() / nt)
