@@ -218,7 +218,8 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
     c->ntiles = (n_local + c->tile - 1) / c->tile;
     if (c->ntiles < c->sweep_grid) c->sweep_grid = (int)std::max<int64_t>(1, c->ntiles);
     // statistics work items: ~4 per resident wave slot (2 waves/SIMD) so the last round is not mostly empty
-    c->chunk = (int)std::max<int64_t>(256, ((n_local + 8191) / 8192 + 3) / 4 * 4);
+    static const int64_t target_items = [] { const char *e = getenv("DPMM_STATS_ITEMS"); return e ? (int64_t)atoll(e) : (int64_t)8192; }();
+    c->chunk = (int)std::max<int64_t>(256, ((n_local + target_items - 1) / target_items + 3) / 4 * 4);
     const size_t nalloc = (size_t)std::max<int64_t>(n_local, 1);
     CHK_CREATE(hipMalloc(&c->dX, sizeof(float) * nalloc * (size_t)c->ldx));
     CHK_CREATE(hipMalloc(&c->dbins, sizeof(int32_t) * nalloc));

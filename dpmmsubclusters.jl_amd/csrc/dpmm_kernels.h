@@ -120,6 +120,7 @@ struct StatsArgs {
     int nbins;
     int chunk;             // points per work item
     int max_items;
+    int range_groups;      // NIW: workgroups of the statistics kernel; each owns a contiguous range of items (0: one item per workgroup)
     SortBufs sb;
     double *slabs;         // [max_items][slab_stride]
     int64_t slab_stride;

@@ -20,6 +20,7 @@
 //
 // f64 MFMA fragment conventions (lane l: i = l & 15, g = l >> 4): A[i][k=g], B[k=g][col=i],
 // C/D element r (0..3): row g + 4r, col i.
+#include <cstdlib>
 #include "dpmm_device.h"
 #include "dpmm_kernels.h"
 
@@ -197,50 +198,61 @@ __device__ __forceinline__ void niw_stats_body(const StatsArgs &A, int seg, int 
 #pragma unroll
     for (int b = 0; b < NBK; ++b) xs[b] = 0.;
 
-    constexpr int U = (NBK <= 4) ? 4 : 2;  // k-steps (of 4 points) per batch
+    constexpr int U = (NBK <= 4) ? 4 : (NBK <= 8 ? 2 : 1);  // k-steps (of 4 points) per batch
     const int nsteps = (cnt + 3) >> 2;
     const int nbatch = (nsteps + U - 1) / U;
-    // software pipeline: perm indices two batches ahead, x one batch ahead of the MFMAs
-    auto load_idx = [&](int b, int64_t (&pt)[U], bool (&ok)[U]) {
+    // Loads are UNCONDITIONAL (clamped addresses) and nothing touches a loaded value before its batch is consumed:
+    // a conditional load becomes a branch with `s_waitcnt vmcnt(0)` behind it, and a select right after a load
+    // waits for it -- either drains every prefetch in flight.  Rows beyond the item and columns beyond the row
+    // are zeroed when the batch is converted to Float64.
+    auto load_idx = [&](int b, int (&pt)[U]) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int pl = 4 * (b * U + u) + g;
-            ok[u] = pl < cnt;
-            pt[u] = ok[u] ? (int64_t)A.sb.perm[seg + pl] : 0;
-        }
+        for (int u = 0; u < U; ++u) pt[u] = A.sb.perm[seg + min(4 * (b * U + u) + g, cnt - 1)];
     };
-    auto load_x = [&](const int64_t (&pt)[U], const bool (&ok)[U], float (&xf)[U][NBK]) {
+    bool colok[NBK >= 4 ? NBK / 4 : NBK];
+    int coloff[NBK >= 4 ? NBK / 4 : NBK];
+#pragma unroll
+    for (int c = 0; c < (NBK >= 4 ? NBK / 4 : NBK); ++c) {
+        const int col = NBK * i + (NBK >= 4 ? 4 * c : c);
+        colok[c] = col < A.ldx;
+        coloff[c] = colok[c] ? col : 0;
+    }
+    auto load_x = [&](const int (&pt)[U], float (&xf)[U][NBK]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const float *xp = A.X + pt[u] * A.ldx + NBK * i;
+            const float *xrow = A.X + (int64_t)pt[u] * A.ldx;
             if constexpr (NBK >= 4) {
 #pragma unroll
                 for (int c4 = 0; c4 < NBK / 4; ++c4) {
-                    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (ok[u] && NBK * i + 4 * c4 < A.ldx) v = *reinterpret_cast<const f32x4 *>(xp + 4 * c4);
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(xrow + coloff[c4]);
                     xf[u][4 * c4 + 0] = v.x; xf[u][4 * c4 + 1] = v.y; xf[u][4 * c4 + 2] = v.z; xf[u][4 * c4 + 3] = v.w;
                 }
             } else {
 #pragma unroll
-                for (int b2 = 0; b2 < NBK; ++b2) xf[u][b2] = (ok[u] && NBK * i + b2 < A.ldx) ? xp[b2] : 0.f;
+                for (int b2 = 0; b2 < NBK; ++b2) xf[u][b2] = xrow[coloff[b2]];
             }
         }
     };
-    int64_t pt_a[U], pt_b[U];
-    bool ok_a[U], ok_b[U];
-    float xcur[U][NBK], xnext[U][NBK];
-    load_idx(0, pt_a, ok_a);
-    load_x(pt_a, ok_a, xcur);
-    load_idx(1, pt_b, ok_b);
-    for (int bt = 0; bt < nbatch; ++bt) {
-        load_x(pt_b, ok_b, xnext);          // batch bt+1 (all-false beyond the end)
-        load_idx(bt + 2, pt_b, ok_b);
+    // Software pipeline: x two batches (D <= 128) or one batch (D = 256: no registers left) ahead of the MFMAs, perm
+    // indices one batch further.  In every iteration the index loads are issued BEFORE the x loads that consume the
+    // previous iteration's indices: vmcnt retires in order, so waiting for an index never drains the x loads behind it.
+    constexpr bool DEEP = NBK <= 8;
+    constexpr int AHEAD = DEEP ? 2 : 1;
+    // The x buffers rotate by ROLE (loop unrolled over the buffers), never by copying: a register move of a
+    // freshly loaded value would wait for the load it was meant to overlap.
+    int pt_b[U], pt_c[U];
+    float xa[U][NBK], xb[U][NBK], xc[DEEP ? U : 1][DEEP ? NBK : 1];
+    auto step = [&](int bt, const float (&xu)[U][NBK], float (&xl)[U][NBK]) {
+        load_idx(bt + AHEAD + 1, pt_c);
+        load_x(pt_b, xl);                          // batch bt + AHEAD
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            const bool rowok = 4 * (bt * U + u) + g < cnt;
             double xd[NBK];
 #pragma unroll
             for (int b2 = 0; b2 < NBK; ++b2) {
-                xd[b2] = (double)xcur[u][b2];
+                const bool keep = rowok && colok[NBK >= 4 ? b2 / 4 : b2];
+                xd[b2] = (double)(keep ? xu[u][b2] : 0.f);
                 if constexpr (PANEL == 0) xs[b2] += xd[b2];
             }
             // lower block triangle, pair index p(ba,bb) = ba(ba+1)/2 + bb, ba >= bb
@@ -254,9 +266,24 @@ __device__ __forceinline__ void niw_stats_body(const StatsArgs &A, int seg, int 
                 }
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int b2 = 0; b2 < NBK; ++b2) xcur[u][b2] = xnext[u][b2];
+        for (int u = 0; u < U; ++u) pt_b[u] = pt_c[u];   // indices were issued before this step's x loads: no drain
+    };
+    load_idx(0, pt_b);
+    load_x(pt_b, xa);
+    load_idx(1, pt_b);
+    if constexpr (DEEP) {
+        load_x(pt_b, xb);
+        load_idx(2, pt_b);
+        for (int bt = 0; bt < nbatch; bt += 3) {
+            step(bt, xa, xc);
+            if (bt + 1 < nbatch) step(bt + 1, xb, xa);
+            if (bt + 2 < nbatch) step(bt + 2, xc, xb);
+        }
+    } else {
+        for (int bt = 0; bt < nbatch; bt += 2) {
+            step(bt, xa, xb);
+            if (bt + 1 < nbatch) step(bt + 1, xb, xa);
+        }
     }
     // slab[pair][r][lane]
 #pragma unroll
@@ -274,16 +301,24 @@ __device__ __forceinline__ void niw_stats_body(const StatsArgs &A, int seg, int 
     }
 }
 
+// Workgroup w owns the contiguous item range [w q, (w+1) q), q = ceil(total / groups).  Consecutive items of one
+// bin are contiguous in perm, so the range splits into one segment per bin it touches; each segment is accumulated
+// in registers and written as ONE slab, stored at the slot of its first item (its "head").  Heads of bin b are
+// item_start[b] and every multiple of q inside the bin -- the reduce kernel walks exactly those.
 template <int NBK>
 __global__ __launch_bounds__(64 * StatCfg<NBK>::NPANEL) void niw_stats_kernel(StatsArgs A) {
     using C = StatCfg<NBK>;
     const int total_items = A.sb.item_start[A.nbins];
-    for (int item = blockIdx.x; item < total_items; item += gridDim.x) {
+    const int q = (total_items + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int it0 = (int)blockIdx.x * q;
+    const int it1 = min(total_items, it0 + q);
+    for (int item = it0; item < it1;) {
         const int b = find_bin(A.sb.item_start, A.nbins, item);
+        const int e = min(it1, A.sb.item_start[b + 1]);
         const int j = item - A.sb.item_start[b];
         const int bcnt = A.sb.bin_total[b];
         const int seg = A.sb.bin_start[b] + j * A.chunk;
-        const int cnt = min(A.chunk, bcnt - j * A.chunk);
+        const int cnt = min((e - item) * A.chunk, bcnt - j * A.chunk);
         double *slab = A.slabs + (int64_t)item * A.slab_stride;
         const int panel = threadIdx.x >> 6;
         if constexpr (C::NPANEL == 1) {
@@ -299,6 +334,7 @@ __global__ __launch_bounds__(64 * StatCfg<NBK>::NPANEL) void niw_stats_kernel(St
                 default: niw_stats_body<NBK, 3>(A, seg, cnt, slab); break;
             }
         }
+        item = e;
     }
 }
 
@@ -331,7 +367,9 @@ __global__ __launch_bounds__(256) void niw_reduce_kernel(StatsArgs A, int NBK) {
     }
     double s = 0.;
     const int i0 = A.sb.item_start[b], i1 = A.sb.item_start[b + 1];
-    for (int it = i0; it < i1; ++it) s += A.slabs[(int64_t)it * A.slab_stride + off];
+    const int total_items = A.sb.item_start[A.nbins];
+    const int q = (total_items + A.range_groups - 1) / A.range_groups;      // as in niw_stats_kernel
+    for (int it = i0; it < i1; it = (it / q + 1) * q) s += A.slabs[(int64_t)it * A.slab_stride + off];   // segment heads, in order
     out[e] = s;
 }
 
@@ -342,15 +380,22 @@ int64_t niw_slab_stride(int D) {
 
 static int niw_nbk(int D) { return D <= 16 ? 1 : D <= 32 ? 2 : D <= 64 ? 4 : D <= 128 ? 8 : 16; }
 
-hipError_t launch_niw_stats(const StatsArgs &a, hipStream_t s) {
+hipError_t launch_niw_stats(const StatsArgs &a0, hipStream_t s) {
+    StatsArgs a = a0;
     const int NBK = niw_nbk(a.D);
-    const int grid = a.max_items < 1 ? 1 : a.max_items;
+    // two resident waves per SIMD at D = 64 (register budget): 2048 workgroups cover the chip once; every workgroup
+    // gets the same number of items, so nothing is gained from a longer grid
+    static const int groups_env = [] { const char *e = getenv("DPMM_STATS_GROUPS"); return e ? atoi(e) : 0; }();
+    int groups = groups_env > 0 ? groups_env : (NBK <= 4 ? 2048 : 1024);
+    const int max_items = a.max_items < 1 ? 1 : a.max_items;
+    if (groups > max_items) groups = max_items;
+    a.range_groups = groups;
     switch (NBK) {
-        case 1: hipLaunchKernelGGL((niw_stats_kernel<1>), dim3(grid), dim3(64), 0, s, a); break;
-        case 2: hipLaunchKernelGGL((niw_stats_kernel<2>), dim3(grid), dim3(64), 0, s, a); break;
-        case 4: hipLaunchKernelGGL((niw_stats_kernel<4>), dim3(grid), dim3(64), 0, s, a); break;
-        case 8: hipLaunchKernelGGL((niw_stats_kernel<8>), dim3(grid), dim3(128), 0, s, a); break;
-        default: hipLaunchKernelGGL((niw_stats_kernel<16>), dim3(grid), dim3(256), 0, s, a); break;
+        case 1: hipLaunchKernelGGL((niw_stats_kernel<1>), dim3(groups), dim3(64), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((niw_stats_kernel<2>), dim3(groups), dim3(64), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((niw_stats_kernel<4>), dim3(groups), dim3(64), 0, s, a); break;
+        case 8: hipLaunchKernelGGL((niw_stats_kernel<8>), dim3(groups), dim3(128), 0, s, a); break;
+        default: hipLaunchKernelGGL((niw_stats_kernel<16>), dim3(groups), dim3(256), 0, s, a); break;
     }
     hipLaunchKernelGGL(niw_reduce_kernel, dim3((unsigned)((a.packed_stride + 255) / 256), a.nbins), dim3(256), 0, s, a, NBK);
     return hipGetLastError();
