@@ -43,6 +43,7 @@ ABI = [
     ("dpmm_predict", ctypes.c_int, [ctypes.c_void_p, _c_f32p]),
     ("dpmm_set_ground_truth", ctypes.c_int, [ctypes.c_void_p, _c_i64p, ctypes.c_int]),
     ("dpmm_contingency", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_i64p]),
+    ("dpmm_bin_counts", ctypes.c_int, [ctypes.c_void_p, _c_i64p]),
     ("dpmm_debug_loglik", ctypes.c_int, [ctypes.c_void_p, _c_f32p]),
     ("dpmm_sync", ctypes.c_int, [ctypes.c_void_p]),
     ("dpmm_stream", ctypes.c_void_p, [ctypes.c_void_p]),
@@ -263,6 +264,12 @@ class Worker:
         K = self.K if K is None else K
         out = np.zeros((K, self.n_gt), np.int64)
         self._chk(self._lib.dpmm_contingency(self._h, K, _p(out, _c_i64p)))
+        return out
+
+    def bin_counts(self):
+        """(K, 2) Int64: points per (cluster, sub-cluster) of this shard -- the N of the l / r statistics."""
+        out = np.zeros((self.K, 2), np.int64)
+        self._chk(self._lib.dpmm_bin_counts(self._h, _p(out, _c_i64p)))
         return out
 
     # ---- diagnostics

@@ -621,6 +621,21 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx) {
     return DPMM_OK;
 }
 
+int dpmm_bin_counts(dpmm_ctx *c, int64_t *counts) {
+    if (!c || !counts) return DPMM_EINVAL;
+    if (!c->have_points || !c->have_labels || c->K < 1) return fail(c, DPMM_ESTATE, "bin counts need points, labels and parameters (K)");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int nbins = 2 * c->K;
+    if (c->n == 0) { for (int b = 0; b < nbins; ++b) counts[b] = 0; return DPMM_OK; }
+    if (int rc = ensure_pinned(c, sizeof(int32_t) * nbins)) return rc;
+    HIPCHK(c, launch_sort_by_bin(c->dbins, c->n, nbins, c->sb, c->stream));      // hist + scan -> bin_total
+    HIPCHK(c, launch_copy_bytes(c->h_pin, c->sb.bin_total, sizeof(int32_t) * nbins, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int32_t *h = reinterpret_cast<const int32_t *>(c->h_pin);
+    for (int b = 0; b < nbins; ++b) counts[b] = h[b];
+    return DPMM_OK;
+}
+
 int dpmm_suffstats_packed_device(dpmm_ctx *c, const int64_t *idx, int n_idx, double *d_out) {
     if (!c || !d_out) return DPMM_EINVAL;
     if (int rc = run_stats(c, idx, n_idx)) return rc;

@@ -255,6 +255,22 @@ class DPMMSampler:
         self.wk.reset_sublabels(bad + 1, self._next_epoch())
         self.update_suff_stats_posterior(bad)
 
+    def update_stats_and_reset_bad(self):
+        """Steps 5 + 6 of group_step (local_clusters_actions.jl:665-666) with ONE statistics pass: the sub-cluster
+        occupancies (the N of the l / r statistics) come from the sort histogram first, clusters with an empty
+        sub-cluster get their sub-labels re-drawn (reset_bad_clusters!, :501-516), and the statistics / posteriors
+        are then computed once over the final labelling.  Same end state as the reference's full pass + subset pass:
+        a sub-label reset changes neither cluster-level statistics nor any other cluster."""
+        t0 = time.perf_counter()
+        counts = self.comm.reduce_counts(self.wk.bin_counts())
+        bad = np.flatnonzero((counts[:, 0] == 0) | (counts[:, 1] == 0))
+        if len(bad):
+            self.hist[bad] = -np.inf
+            self.splittable[bad] = False
+            self.wk.reset_sublabels(bad + 1, self._next_epoch())
+        self._tic("bad_reset", t0)
+        self.update_suff_stats_posterior()
+
     # ------------------------------------------------------------------ step 7a
     def check_and_split(self, final):
         K = self.K
@@ -400,8 +416,7 @@ class DPMMSampler:
         self.wk.sweep(self._next_epoch(), final)                 # 3 + 4 (asynchronous)
         self._start_noise()                                      # host works while the GPU sweeps
         self._tic("sweep_launch", t0)
-        self.update_suff_stats_posterior()                       # 5
-        self.reset_bad_clusters()                                # 6
+        self.update_stats_and_reset_bad()                        # 5 + 6
         if not no_more_splits:                                   # 7
             t0 = time.perf_counter()
             touched = self.check_and_split(final)

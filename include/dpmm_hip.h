@@ -167,6 +167,15 @@ int dpmm_set_predictive_niw(dpmm_ctx *ctx, int K, const float *m, const float *R
 int dpmm_set_predictive_mult(dpmm_ctx *ctx, int K, const float *logp, const float *weights);
 int dpmm_predict(dpmm_ctx *ctx, float *parr);
 
+/* Sub-cluster occupancy of the shard after a sweep: counts[2k] = #{label == k+1, sub == 1}, counts[2k+1] = #{..., sub == 2}
+ * (Int64, [2K], summable across shards).  These are the N fields of the l / r statistics the reference reads in
+ * reset_bad_clusters! (src/local_clusters_actions.jl:501-516) to find clusters with an empty sub-cluster.  Returning
+ * them BEFORE the statistics pass lets the host reset those sub-labels first (dpmm_reset_sublabels) and run ONE
+ * dpmm_suffstats_packed over the final labelling instead of a full pass plus a subset pass: the reference's state
+ * after its steps 5-6 (:665-666) is reproduced exactly, because a sub-label reset leaves cluster-level statistics and
+ * every other cluster untouched. */
+int dpmm_bin_counts(dpmm_ctx *ctx, int64_t *counts);
+
 /* On-device evaluation (next row of the scope table): with a ground truth the reference gathers all N labels to
  * the master EVERY iteration to compute NMI / VI (src/dp-parallel-sampling.jl:370-377).  Here the ground truth of
  * the shard is uploaded once (Int64, any integer ids in [0, n_gt)), and each call returns only the

@@ -111,6 +111,11 @@ class FakeWorker:
     def set_ground_truth_range(self, gt, n_gt):
         self.gt = np.asarray(gt, np.int64); self.n_gt = int(n_gt)
 
+    def bin_counts(self):
+        out = np.zeros((self.K, 2), np.int64)
+        np.add.at(out, (self.labels - 1, self.sub - 1), 1)
+        return out
+
     def contingency(self, K=None):
         K = self.K if K is None else K
         out = np.zeros((K, self.n_gt), np.int64)
