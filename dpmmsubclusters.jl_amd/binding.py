@@ -22,6 +22,7 @@ ABI = [
     ("dpmm_last_error", ctypes.c_char_p, [ctypes.c_void_p]),
     ("dpmm_upload_points", ctypes.c_int, [ctypes.c_void_p, _c_f32p, ctypes.c_int64]),
     ("dpmm_upload_points_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
+    ("dpmm_upload_points_npy", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int]),
     ("dpmm_init_labels", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32]),
     ("dpmm_set_labels", ctypes.c_int, [ctypes.c_void_p, _c_i64p, _c_i64p]),
     ("dpmm_get_labels", ctypes.c_int, [ctypes.c_void_p, _c_i64p, _c_i64p]),
@@ -139,6 +140,18 @@ class Worker:
         X = _f32(X)
         assert X.ndim == 2 and X.shape[0] == self.n and X.shape[1] >= self.D
         self._chk(self._lib.dpmm_upload_points(self._h, _p(X, _c_f32p), X.shape[1]))
+
+    def upload_points_npy(self, rows, nan_to_zero=True):
+        """rows: (n_local, >= D) array of a Samples x Dimensions .npy file (Float32 or Float64, C-contiguous; a
+        read-only memory map is fine).  Float32 conversion and NaN -> 0 (utils.jl:9-13) happen on the device."""
+        rows = np.asarray(rows)
+        if rows.dtype not in (np.float32, np.float64):
+            rows = rows.astype(np.float32)
+        if not rows.flags.c_contiguous:
+            rows = np.ascontiguousarray(rows)
+        assert rows.ndim == 2 and rows.shape[0] == self.n and rows.shape[1] >= self.D
+        self._chk(self._lib.dpmm_upload_points_npy(self._h, ctypes.c_void_p(rows.ctypes.data), int(rows.dtype == np.float64),
+                                                   rows.shape[1], int(bool(nan_to_zero))))
 
     def upload_points_device(self, ptr, ldx):
         self._chk(self._lib.dpmm_upload_points_device(self._h, ctypes.c_void_p(ptr), ldx))

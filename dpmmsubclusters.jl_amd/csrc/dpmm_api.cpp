@@ -253,6 +253,22 @@ int dpmm_destroy(dpmm_ctx *c) {
     return DPMM_OK;
 }
 
+// after the points are in place: the Multinomial fast path needs to know whether every count is exact in bf16
+static int finish_upload(dpmm_ctx *c) {
+    if (c->prior == DPMM_PRIOR_MULT) {
+        static const bool force_f32 = getenv("DPMM_MULT_FORCE_F32") != nullptr;
+        int *flag = reinterpret_cast<int *>(c->d_small);
+        HIPCHK(c, hipMemsetAsync(flag, 0, sizeof(int), c->stream));
+        HIPCHK(c, launch_bf16_exact_check(c->dX, c->n * c->ldx, flag, c->stream));
+        int h = 1;
+        HIPCHK(c, hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->x_bf16_exact = (h == 0 && !force_f32) ? 1 : 0;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DPMM_OK;
+}
+
 static int upload_common(dpmm_ctx *c, const float *X, int64_t ldx, hipMemcpyKind kind) {
     if (!c) return DPMM_EINVAL;
     if (!X && c->n > 0) return fail(c, DPMM_EINVAL, "X is null");
@@ -261,17 +277,7 @@ static int upload_common(dpmm_ctx *c, const float *X, int64_t ldx, hipMemcpyKind
     if (c->n > 0) {
         if (c->ldx != c->D) HIPCHK(c, hipMemsetAsync(c->dX, 0, sizeof(float) * (size_t)c->n * c->ldx, c->stream));
         HIPCHK(c, hipMemcpy2DAsync(c->dX, sizeof(float) * c->ldx, X, sizeof(float) * ldx, sizeof(float) * c->D, (size_t)c->n, kind, c->stream));
-        if (c->prior == DPMM_PRIOR_MULT) {
-            static const bool force_f32 = getenv("DPMM_MULT_FORCE_F32") != nullptr;
-            int *flag = reinterpret_cast<int *>(c->d_small);
-            HIPCHK(c, hipMemsetAsync(flag, 0, sizeof(int), c->stream));
-            HIPCHK(c, launch_bf16_exact_check(c->dX, c->n * c->ldx, flag, c->stream));
-            int h = 1;
-            HIPCHK(c, hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            c->x_bf16_exact = (h == 0 && !force_f32) ? 1 : 0;
-        }
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (int rc = finish_upload(c)) return rc;
     }
     c->have_points = true;
     return DPMM_OK;
@@ -279,6 +285,33 @@ static int upload_common(dpmm_ctx *c, const float *X, int64_t ldx, hipMemcpyKind
 
 int dpmm_upload_points(dpmm_ctx *c, const float *X, int64_t ldx) { return upload_common(c, X, ldx, hipMemcpyHostToDevice); }
 int dpmm_upload_points_device(dpmm_ctx *c, const float *dX, int64_t ldx) { return upload_common(c, dX, ldx, hipMemcpyDeviceToDevice); }
+
+int dpmm_upload_points_npy(dpmm_ctx *c, const void *rows, int is_f64, int64_t ld, int nan_to_zero) {
+    if (!c) return DPMM_EINVAL;
+    if (!rows && c->n > 0) return fail(c, DPMM_EINVAL, "rows is null");
+    if (ld < c->D) return fail(c, DPMM_EINVAL, "ld < D");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n > 0) {
+        if (c->ldx != c->D) HIPCHK(c, hipMemsetAsync(c->dX, 0, sizeof(float) * (size_t)c->n * c->ldx, c->stream));
+        const size_t esz = is_f64 ? sizeof(double) : sizeof(float);
+        const int64_t chunk_rows = std::max<int64_t>(1, std::min<int64_t>(c->n, ((int64_t)128 << 20) / (int64_t)(esz * (size_t)ld)));
+        void *tmp = nullptr;
+        HIPCHK(c, hipMalloc(&tmp, esz * (size_t)chunk_rows * (size_t)ld));
+        int rc = DPMM_OK;
+        for (int64_t r0 = 0; r0 < c->n && rc == DPMM_OK; r0 += chunk_rows) {
+            const int64_t nr = std::min(chunk_rows, c->n - r0);
+            hipError_t e = hipMemcpyAsync(tmp, (const char *)rows + esz * (size_t)r0 * (size_t)ld, esz * (size_t)nr * (size_t)ld, hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) e = launch_ingest_rows(c->dX + (size_t)r0 * c->ldx, c->ldx, tmp, is_f64, ld, nr, c->D, nan_to_zero, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);       // tmp is reused by the next chunk
+            if (e != hipSuccess) { c->err = std::string("dpmm_upload_points_npy: ") + hipGetErrorString(e); rc = DPMM_EHIP; }
+        }
+        hipFree(tmp);
+        if (rc != DPMM_OK) return rc;
+        if (int rc2 = finish_upload(c)) return rc2;
+    }
+    c->have_points = true;
+    return DPMM_OK;
+}
 
 int dpmm_init_labels(dpmm_ctx *c, int init_clusters, uint32_t epoch) {
     if (!c) return DPMM_EINVAL;

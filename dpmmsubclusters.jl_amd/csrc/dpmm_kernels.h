@@ -80,6 +80,8 @@ hipError_t launch_mult_sweep_bf16(const MultSweepArgs &a, const uint32_t *Lp16, 
 
 // ---- label bookkeeping (labels.hip)
 // dst/src: device or pinned-host pointers, 4-byte aligned; bytes rounded up to a multiple of 4
+hipError_t launch_ingest_rows(float *dst, int64_t ldx, const void *src, int is_f64, int64_t ld, int64_t rows, int D, int nan_to_zero,
+                              hipStream_t s);
 hipError_t launch_copy_bytes(void *dst, const void *src, size_t bytes, hipStream_t s);
 hipError_t launch_init_labels(int32_t *bins, int64_t n, int64_t first_index, int init_clusters, uint64_t seed,
                               uint32_t epoch, hipStream_t s);

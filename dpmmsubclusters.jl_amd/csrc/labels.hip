@@ -150,6 +150,30 @@ hipError_t launch_i64_to_i32(int32_t *dst, const int64_t *src, int64_t n, hipStr
     return hipGetLastError();
 }
 
+// .npy ingestion (utils.jl:5-14): rows of Float32 / Float64 samples -> the ctx layout (Float32, leading dimension ldx),
+// NaN -> 0.  Elementwise, HBM-bound.
+template <typename T>
+__global__ void ingest_rows_kernel(float *__restrict__ dst, int64_t ldx, const T *__restrict__ src, int64_t ld, int64_t rows, int D,
+                                   int nan_to_zero) {
+    const int64_t total = rows * D;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / D;
+        const int d = (int)(e - r * D);
+        float v = (float)src[r * ld + d];
+        if (nan_to_zero && v != v) v = 0.f;
+        dst[r * ldx + d] = v;
+    }
+}
+hipError_t launch_ingest_rows(float *dst, int64_t ldx, const void *src, int is_f64, int64_t ld, int64_t rows, int D, int nan_to_zero,
+                              hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (is_f64)
+        hipLaunchKernelGGL((ingest_rows_kernel<double>), dim3(grid_for(rows * D)), dim3(256), 0, s, dst, ldx, (const double *)src, ld, rows, D, nan_to_zero);
+    else
+        hipLaunchKernelGGL((ingest_rows_kernel<float>), dim3(grid_for(rows * D)), dim3(256), 0, s, dst, ldx, (const float *)src, ld, rows, D, nan_to_zero);
+    return hipGetLastError();
+}
+
 hipError_t launch_init_labels(int32_t *bins, int64_t n, int64_t first, int init_clusters, uint64_t seed, uint32_t epoch, hipStream_t s) {
     hipLaunchKernelGGL(init_labels_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, n, first, init_clusters, seed, epoch);
     return hipGetLastError();

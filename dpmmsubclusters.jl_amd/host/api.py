@@ -8,9 +8,10 @@
 
 Argument meaning, defaults, coercions (Float32 data / Int64 iters, :279-293), the default NIW prior
 (kappa=1, m=0, nu=D+3, psi=I, :272-274) and the 9-tuple / 5-tuple results follow the reference.
-`all_data` is Dimensions x Samples (D x N) as in the reference.  Out of scope here (SURVEY.md
-section 8: next rows): save_model / checkpoints, outlier component, smart splits -- passing a
-non-default value for those raises NotImplementedError rather than being silently ignored.
+`all_data` is Dimensions x Samples (D x N) as in the reference.  Checkpoints (`save_model`), the advanced
+parameter-file mode `dp_parallel(model_params::String)` and `run_model_from_checkpoint` live in host/checkpoint.py.
+Out of scope here (next rows): outlier component, smart splits -- passing a non-default value
+for those raises NotImplementedError rather than being silently ignored.
 
 Distributed: when torch.distributed is initialised (one process per GPU) every rank calls `fit`
 with the SAME full arguments; each rank keeps the contiguous column range
@@ -22,6 +23,7 @@ import numpy as np
 
 from .. import binding
 from . import priors as _priors
+from . import checkpoint as _ckpt
 from .priors import multinomial_hyper, niw_hyperparams
 from .sampler import DPMMSampler, LocalComm
 
@@ -47,46 +49,141 @@ def _shard(N, comm):
     return lo, hi
 
 
-def _make_sampler(all_data, hyper, alpha, seed, burnout, max_clusters, comm, device, nthreads=None, worker_factory=None):
-    X = np.asarray(all_data)
-    if X.ndim != 2:
-        raise ValueError("all_data must be Dimensions x Samples")
-    D, N = X.shape
+def _make_sampler(all_data, hyper, alpha, seed, burnout, max_clusters, comm, device, nthreads=None, worker_factory=None,
+                  rows=None, **sampler_kw):
+    """`all_data`: Dimensions x Samples (basic mode), or `rows`: Samples x Dimensions as stored in a .npy file (advanced
+    mode; cleaned and converted on the GPU by dpmm_upload_points_npy)."""
+    if rows is not None:
+        N, D = rows.shape
+    else:
+        X = np.asarray(all_data)
+        if X.ndim != 2:
+            raise ValueError("all_data must be Dimensions x Samples")
+        D, N = X.shape
     if hyper.dim != D:
         raise ValueError(f"prior dimension {hyper.dim} != data dimension {D}")
     lo, hi = _shard(N, comm)
-    Xs = np.ascontiguousarray(X[:, lo:hi].T, dtype=np.float32)  # (n_local, D): row = point
     if seed is None:
         seed = int(np.random.SeedSequence().generate_state(1)[0])
         seed = comm.broadcast_int(seed) if hasattr(comm, "broadcast_int") else seed
     wk = (worker_factory or binding.Worker)(hyper.kind, D, hi - lo, first_index=lo, device=device, seed=int(seed))
-    wk.upload_points(Xs)
-    return DPMMSampler(wk, hyper, alpha, N, int(seed), burnout=burnout, max_clusters=max_clusters, comm=comm, nthreads=nthreads)
+    if rows is not None:
+        if hasattr(wk, "upload_points_npy"):
+            wk.upload_points_npy(rows[lo:hi])
+        else:
+            wk.upload_points(np.nan_to_num(np.asarray(rows[lo:hi], dtype=np.float32), nan=0.0, posinf=np.inf, neginf=-np.inf))
+    else:
+        wk.upload_points(np.ascontiguousarray(X[:, lo:hi].T, dtype=np.float32))  # (n_local, D): row = point
+    return DPMMSampler(wk, hyper, alpha, N, int(seed), burnout=burnout, max_clusters=max_clusters, comm=comm, nthreads=nthreads,
+                       **sampler_kw)
 
 
-def dp_parallel(all_data, local_hyper_params, alpha_param, iters=100, init_clusters=1, seed=None, verbose=True,
-                save_model=False, burnout=15, gt=None, max_clusters=np.inf, outlier_weight=0, outlier_params=None,
-                smart_splits=False, comm=None, device=None, nthreads=None, worker_factory=None):
-    """Returns (dp_model, iter_count, nmi_score_history, likelihood_history, cluster_count_history)."""
-    if save_model:
-        raise NotImplementedError("checkpointing is outside this build's scope (SURVEY.md 8f)")
+def _check_next_rows(outlier_weight, outlier_params, smart_splits):
     if outlier_weight != 0 or outlier_params is not None:
         raise NotImplementedError("outlier component is outside this build's scope (SURVEY.md 8f)")
     if smart_splits:
         raise NotImplementedError("smart splits are outside this build's scope (SURVEY.md 8f)")
-    if not isinstance(local_hyper_params, _priors.distribution_hyper_params):
-        raise TypeError("local_hyper_params must be a distribution_hyper_params (niw_hyperparams / multinomial_hyper)")
+
+
+def _comm_device(comm, device):
     if comm is None:
         from .comm import default_comm
         comm = default_comm()
     if device is None:
         device = getattr(comm, "device", 0)
+    return comm, device
+
+
+def dp_parallel(all_data, local_hyper_params=None, alpha_param=None, iters=100, init_clusters=1, seed=None, verbose=True,
+                save_model=False, burnout=15, gt=None, max_clusters=np.inf, outlier_weight=0, outlier_params=None,
+                smart_splits=False, comm=None, device=None, nthreads=None, worker_factory=None, save_path="./",
+                save_file_prefix="checkpoint_", model_save_interval=1000):
+    """dp_parallel(all_data, hyper_params, alpha, ...) -- basic mode (dp-parallel-sampling.jl:121-157), or
+    dp_parallel(model_params::String; verbose, gt) -- advanced mode driven by a parameter file (:178-196).
+    Returns (dp_model, iter_count, nmi_score_history, likelihood_history, cluster_count_history).
+    `save_model=True` writes a checkpoint every `model_save_interval` iterations (global_params.jl:36-41 defaults)."""
+    if isinstance(all_data, (str, bytes)) or hasattr(all_data, "__fspath__"):
+        return _dp_parallel_from_params(str(all_data), verbose=verbose, gt=gt, comm=comm, device=device, nthreads=nthreads,
+                                        worker_factory=worker_factory)
+    _check_next_rows(outlier_weight, outlier_params, smart_splits)
+    if not isinstance(local_hyper_params, _priors.distribution_hyper_params):
+        raise TypeError("local_hyper_params must be a distribution_hyper_params (niw_hyperparams / multinomial_hyper)")
+    comm, device = _comm_device(comm, device)
     s = _make_sampler(all_data, local_hyper_params, np.float32(alpha_param), seed, int(burnout), max_clusters, comm, device,
                       nthreads, worker_factory)
     s.init_first_clusters(int(init_clusters))
-    iter_count, nmi, lik, kh = s.run_model(int(iters), 1, verbose=verbose, gt=gt)
+    hook = _ckpt.SaveHook(save_path, save_file_prefix, model_save_interval, "none", 0.0, verbose) if save_model else None
+    iter_count, nmi, lik, kh = s.run_model(int(iters), 1, verbose=verbose, gt=gt, on_iteration=hook)
     labels, sub = comm.gather_labels(s.wk)
-    return dp_parallel_sampling(s, labels, sub), iter_count, nmi, lik, kh
+    model = dp_parallel_sampling(s, labels, sub)
+    model.checkpoints = hook.files if hook else []
+    return model, iter_count, nmi, lik, kh
+
+
+def _sampler_from_params(P, comm, device, nthreads, worker_factory):
+    _check_next_rows(P["outlier_mod"] if P["outlier_hyper_params"] is not None else 0, None, P["smart_splits"])
+    rows = _ckpt.load_data(P["data_path"], P["data_prefix"], swapDimension=False, mmap=True)     # Samples x Dimensions
+    s = _make_sampler(None, P["hyper_params"], np.float32(P["alpha"]), P["random_seed"], int(P["burnout_period"]),
+                      P["max_clusters"], comm, device, nthreads, worker_factory, rows=rows,
+                      argmax_sample_stop=int(P["argmax_sample_stop"]), split_stop=int(P["split_stop"]))
+    s.hard_clustering = bool(P["hard_clustering"])
+    return s
+
+
+def _run_with_params(s, P, first_iter, prev_time, model_params, verbose, gt):
+    hook = None
+    if P["enable_saving"]:
+        hook = _ckpt.SaveHook(P["save_path"], P["save_file_prefix"], P["model_save_interval"], model_params, prev_time, verbose)
+    iter_count, nmi, lik, kh = s.run_model(int(P["iterations"]), first_iter, verbose=verbose, gt=gt, on_iteration=hook)
+    labels, sub = s.comm.gather_labels(s.wk)
+    model = dp_parallel_sampling(s, labels, sub)
+    model.checkpoints = hook.files if hook else []
+    return model, iter_count, nmi, lik, kh
+
+
+def _dp_parallel_from_params(model_params, verbose=True, gt=None, comm=None, device=None, nthreads=None, worker_factory=None):
+    P = _ckpt.read_params(model_params)
+    comm, device = _comm_device(comm, device)
+    s = _sampler_from_params(P, comm, device, nthreads, worker_factory)
+    s.init_first_clusters(int(P["initial_clusters"]))
+    return _run_with_params(s, P, 1, 0.0, model_params, verbose, gt)
+
+
+def run_model_from_checkpoint(filename, verbose=True, gt=None, comm=None, device=None, nthreads=None, worker_factory=None):
+    """run_model_from_checkpoint(filename) (dp-parallel-sampling.jl:428-447): load the point-less group, re-read the
+    parameter file it names, load the data from the same path, restore labels / cluster state and continue at iter+1.
+    Every rank calls it with the same file.  Returns the 5-tuple of dp_parallel."""
+    ck = _ckpt.load_checkpoint(filename)
+    gp = str(ck["global_params"])
+    if gp == "none" or not gp:
+        raise ValueError("this checkpoint was written in basic mode (fit / dp_parallel with arrays): it has no parameter "
+                         "file to reload the data from; use resume_from_checkpoint(filename, all_data, ...) instead")
+    P = _ckpt.read_params(gp)
+    comm, device = _comm_device(comm, device)
+    if P["random_seed"] is None:
+        P["random_seed"] = int(ck["seed"])
+    s = _sampler_from_params(P, comm, device, nthreads, worker_factory)
+    _ckpt.restore_sampler(s, ck)
+    return _run_with_params(s, P, int(ck["iter"]) + 1, float(ck["total_time"]), gp, verbose, gt)
+
+
+def resume_from_checkpoint(filename, all_data, iters, verbose=True, gt=None, burnout=None, max_clusters=np.inf, comm=None,
+                           device=None, nthreads=None, worker_factory=None, save_model=False, save_path="./",
+                           save_file_prefix="checkpoint_", model_save_interval=1000):
+    """Basic-mode counterpart of run_model_from_checkpoint: the caller supplies the data array again (D x N) and the
+    total number of iterations; the chain continues at iter+1 exactly where the checkpoint left it."""
+    ck = _ckpt.load_checkpoint(filename)
+    comm, device = _comm_device(comm, device)
+    hyper = _ckpt._prior_from_dict(ck)
+    s = _make_sampler(all_data, hyper, np.float32(ck["alpha"]), int(ck["seed"]), int(ck["burnout"] if burnout is None else burnout),
+                      max_clusters, comm, device, nthreads, worker_factory)
+    _ckpt.restore_sampler(s, ck)
+    hook = _ckpt.SaveHook(save_path, save_file_prefix, model_save_interval, "none", float(ck["total_time"]), verbose) if save_model else None
+    iter_count, nmi, lik, kh = s.run_model(int(iters), int(ck["iter"]) + 1, verbose=verbose, gt=gt, on_iteration=hook)
+    labels, sub = comm.gather_labels(s.wk)
+    model = dp_parallel_sampling(s, labels, sub)
+    model.checkpoints = hook.files if hook else []
+    return model, iter_count, nmi, lik, kh
 
 
 def fit(all_data, *args, iters=100, init_clusters=1, seed=None, verbose=True, save_model=False, burnout=20, gt=None,

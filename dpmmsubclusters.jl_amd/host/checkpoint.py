@@ -1,0 +1,179 @@
+"""Checkpoint / resume and the advanced (parameter-file) mode -- SURVEY.md section 8(f), rank 3.
+
+Reference behaviour mirrored here (paths relative to the reference checkout):
+  load_data(path; prefix, swapDimension)     src/utils.jl:5-14        .npy Samples x Dimensions, NaN -> 0, transposed
+  init_model()                               src/dp-parallel-sampling.jl:11-33
+  dp_parallel(model_params::String; ...)     src/dp-parallel-sampling.jl:178-196
+  save_model / run_model's save hook         src/dp-parallel-sampling.jl:398-403, 450-455
+  run_model_from_checkpoint(filename)        src/dp-parallel-sampling.jl:428-447
+  pts_less_group / create_pts_less_group     src/ds.jl:60-66, 85-92
+  the parameter file                         src/global_params.jl, docs/src/usage.md:44-72
+
+Differences that cannot be avoided without a Julia runtime, stated once:
+  * the reference's parameter file is Julia source that it `include`s; here it is Python source executed with the same
+    variable names in scope (`α` may also be spelled `alpha`; `DPMMSubClusters.niw_hyperparams`, `Inf`, `nothing`,
+    `zeros`, `I`-free helpers `eye` are provided);
+  * the reference writes JLD2; here a checkpoint is a NumPy `.npz` with the same content: the point-less group (labels,
+    sub-labels, per-cluster statistics / posteriors / parameters / weights / split gate history), the model hyper
+    parameters, `iter`, `total_time` and the path of the parameter file -- plus the sampler's RNG state and epoch
+    counters, which make a resumed run continue the SAME chain bit for bit (the reference re-seeds).
+"""
+import json
+import os
+import time
+
+import numpy as np
+
+from . import priors as _priors
+
+DEFAULTS = dict(                      # src/global_params.jl
+    data_path="", data_prefix="", iterations=100, hard_clustering=False, initial_clusters=1,
+    argmax_sample_stop=5, split_stop=5, random_seed=None, max_split_iter=20, burnout_period=20,
+    max_clusters=np.inf, alpha=10.0, hyper_params=None, outlier_mod=0, outlier_hyper_params=None,
+    enable_saving=True, model_save_interval=1000, save_path="./", overwrite_prec=False,
+    save_file_prefix="checkpoint_", smart_splits=False)
+
+
+def load_data(path, prefix="", swapDimension=True, mmap=False):
+    """utils.jl:5-14.  Returns Dimensions x Samples (a transposed view) with NaN replaced by 0; with
+    `swapDimension=False` the array as stored.  `mmap=True` returns the read-only memory map untouched (no NaN
+    pass on the host): the caller hands row blocks to `Worker.upload_points_npy`, which cleans them on the GPU."""
+    fn = os.path.join(path, prefix + ".npy") if not str(path).endswith(".npy") else path
+    if not os.path.exists(fn):
+        fn = str(path) + prefix + ".npy"            # the reference concatenates path * prefix * ".npy"
+    if mmap:
+        arr = np.load(fn, mmap_mode="r")
+        return arr.T if swapDimension else arr
+    arr = np.load(fn)
+    if np.issubdtype(arr.dtype, np.floating):
+        arr = np.where(np.isnan(arr), arr.dtype.type(0), arr)
+    return arr.T if swapDimension else arr
+
+
+class _NS:
+    pass
+
+
+def read_params(model_params):
+    """Execute a parameter file and return the recognised settings (defaults of src/global_params.jl)."""
+    ns = dict(np=np, niw_hyperparams=_priors.niw_hyperparams, multinomial_hyper=_priors.multinomial_hyper,
+              Inf=np.inf, nothing=None, true=True, false=False, zeros=np.zeros, ones=np.ones, eye=np.eye)
+    mod = _NS()
+    mod.niw_hyperparams = _priors.niw_hyperparams
+    mod.multinomial_hyper = _priors.multinomial_hyper
+    ns["DPMMSubClusters"] = mod
+    with open(model_params) as f:
+        exec(compile(f.read(), model_params, "exec"), ns)
+    out = dict(DEFAULTS)
+    for k in DEFAULTS:
+        if k in ns:
+            out[k] = ns[k]
+    if "α" in ns:
+        out["alpha"] = ns["α"]
+    if out["hyper_params"] is None:
+        raise ValueError(f"{model_params}: hyper_params is not set")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ save / load
+_SAMPLER_ARRAYS = ("N", "sums", "S", "lr_weights", "weights", "splittable", "hist", "points_count")
+
+
+def _prior_to_dict(prior):
+    if prior.kind == _priors.PRIOR_NIW:
+        return dict(prior_kind="niw", prior_kappa=prior.kappa, prior_nu=prior.nu, prior_m=prior.m, prior_psi=prior.psi)
+    return dict(prior_kind="multinomial", prior_alpha=np.asarray(prior.alpha))
+
+
+def _prior_from_dict(d):
+    if str(d["prior_kind"]) == "niw":
+        return _priors.niw_hyperparams(float(d["prior_kappa"]), d["prior_m"], float(d["prior_nu"]), d["prior_psi"])
+    return _priors.multinomial_hyper(d["prior_alpha"])
+
+
+def checkpoint_filename(path, prefix, it):
+    return f"{path}{prefix}_{it}.npz"                 # path * filename * "_" * iter (dp-parallel-sampling.jl:451)
+
+
+def save_model(sampler, path, prefix, it, total_time, global_params="none"):
+    """Collective (every rank calls it): labels are gathered, rank 0 writes the file and returns its name."""
+    labels, sub = sampler.comm.gather_labels(sampler.wk)
+    if getattr(sampler, "leader_mode", False):        # posteriors / parameters live on the leader; it is also the writer
+        pass
+    if sampler.comm.rank != 0:
+        return None
+    d = dict(format="dpmm-checkpoint-1", iter=int(it), total_time=float(total_time), global_params=str(global_params),
+             labels=labels.astype(np.int64), labels_subcluster=sub.astype(np.int64), K=int(sampler.K),
+             alpha=float(sampler.alpha), total_dim=int(sampler.n_total), seed=np.uint64(sampler.seed),
+             burnout=int(sampler.burnout), epoch=int(sampler.epoch), draw_epoch=int(sampler.draw_epoch),
+             rng_state=json.dumps(sampler.rng.bit_generator.state, default=lambda o: o.tolist() if hasattr(o, "tolist") else int(o)))
+    d.update(_prior_to_dict(sampler.prior))
+    for k in _SAMPLER_ARRAYS:
+        v = getattr(sampler, k)
+        if v is not None:
+            d["s_" + k] = np.asarray(v)
+    for k, v in (sampler.post or {}).items():
+        d["post_" + k] = np.asarray(v)
+    for k, v in (sampler.params or {}).items():
+        d["par_" + k] = np.asarray(v)
+    fn = checkpoint_filename(path, prefix, it)
+    os.makedirs(os.path.dirname(os.path.abspath(fn)), exist_ok=True)
+    tmp = fn + ".tmp.npz"
+    np.savez(tmp, **d)
+    os.replace(tmp, fn)
+    return fn
+
+
+def load_checkpoint(filename):
+    with np.load(filename, allow_pickle=False) as z:
+        d = {k: z[k] for k in z.files}
+    if str(d.get("format")) != "dpmm-checkpoint-1":
+        raise ValueError(f"{filename} is not a checkpoint of this package")
+    return d
+
+
+def restore_sampler(sampler, ck):
+    """Put a freshly built sampler (points uploaded, no clusters yet) into the saved state.  `ck` from load_checkpoint."""
+    K = int(ck["K"])
+    sampler._alloc(K)
+    lo = getattr(sampler.wk, "first_index", 0)
+    n = sampler.wk.n
+    sampler.wk.set_labels(ck["labels"][lo:lo + n], ck["labels_subcluster"][lo:lo + n])
+    sampler.wk.set_num_clusters(K)
+    for k in _SAMPLER_ARRAYS:
+        if "s_" + k in ck:
+            setattr(sampler, k, np.array(ck["s_" + k]))
+    post = {k[5:]: np.array(v) for k, v in ck.items() if k.startswith("post_")}
+    sampler.post = post or None
+    par = {k[4:]: np.array(v) for k, v in ck.items() if k.startswith("par_")}
+    sampler.params = par or None
+    sampler.epoch = int(ck["epoch"])
+    sampler.draw_epoch = int(ck["draw_epoch"])
+    st = json.loads(str(ck["rng_state"]))
+    def fix(o):
+        if isinstance(o, dict):
+            return {k: fix(v) for k, v in o.items()}
+        if isinstance(o, list):
+            return np.array(o, dtype=np.uint64)
+        return o
+    sampler.rng.bit_generator.state = fix(st)
+    return sampler
+
+
+class SaveHook:
+    """run_model's `i % model_save_interval == 0 && should_save_model` hook (dp-parallel-sampling.jl:398-403)."""
+
+    def __init__(self, path, prefix, interval, global_params="none", prev_time=0.0, verbose=False):
+        self.path, self.prefix, self.interval = path, prefix, int(interval)
+        self.global_params, self.verbose = global_params, verbose
+        self.start = time.perf_counter() - prev_time
+        self.files = []
+
+    def __call__(self, i, sampler):
+        if self.interval > 0 and i % self.interval == 0:
+            t0 = time.perf_counter()
+            fn = save_model(sampler, self.path, self.prefix, i, time.perf_counter() - self.start, self.global_params)
+            if fn:
+                self.files.append(fn)
+                if self.verbose:
+                    print(f"Saving Model:\n  {time.perf_counter() - t0:.6f} seconds -> {fn}")

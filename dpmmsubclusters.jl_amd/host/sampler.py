@@ -76,6 +76,7 @@ class DPMMSampler:
         self.argmax_sample_stop = argmax_sample_stop
         self.split_stop = split_stop
         self.nthreads = nthreads
+        self.hard_clustering = False   # global_params.jl:8: argmax label assignment in every sweep
         self.rng = np.random.Generator(np.random.Philox(key=self.seed))
         self.epoch = 0          # device-side randomised calls (stream-unique)
         self.draw_epoch = 1 << 20   # host parameter draws: separate, predictable counter (noise is pre-generated)
@@ -413,7 +414,7 @@ class DPMMSampler:
         self.prior.upload(self.wk, self.params, self.lr_weights, self.weights)   # 2
         self._tic("upload_params", t0)
         t0 = time.perf_counter()
-        self.wk.sweep(self._next_epoch(), final)                 # 3 + 4 (asynchronous)
+        self.wk.sweep(self._next_epoch(), bool(final or self.hard_clustering))   # 3 + 4 (asynchronous); LCA:661
         self._start_noise()                                      # host works while the GPU sweeps
         self._tic("sweep_launch", t0)
         self.update_stats_and_reset_bad()                        # 5 + 6

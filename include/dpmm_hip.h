@@ -70,6 +70,12 @@ const char *dpmm_last_error(const dpmm_ctx *ctx); /* ctx may be NULL: last creat
  * from a producer on the GPU; copied into the ctx-owned layout on the ctx stream). */
 int dpmm_upload_points(dpmm_ctx *ctx, const float *X, int64_t ldx);
 int dpmm_upload_points_device(dpmm_ctx *ctx, const float *dX, int64_t ldx);
+/* .npy ingestion (next row of the scope table): `rows` is the Samples x Dimensions array of a .npy file as the
+ * reference's advanced mode reads it (load_data, src/utils.jl:5-14: npzread, NaN -> 0, transpose; then Float32.(...) in
+ * init_model, src/dp-parallel-sampling.jl:19-25) -- n_local rows of D elements, Float32 (is_f64 = 0) or Float64
+ * (is_f64 = 1), row r at rows + r*ld elements, host memory.  Conversion to Float32, the NaN -> 0 replacement (when
+ * nan_to_zero != 0) and the re-layout happen on the device. */
+int dpmm_upload_points_npy(dpmm_ctx *ctx, const void *rows, int is_f64, int64_t ld, int nan_to_zero);
 
 /* labels = rand(1:init_clusters), sub-labels = rand(1:2) (dp-parallel-sampling.jl:49-50). */
 int dpmm_init_labels(dpmm_ctx *ctx, int init_clusters, uint32_t epoch);
