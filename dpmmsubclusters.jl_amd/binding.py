@@ -45,6 +45,9 @@ ABI = [
     ("dpmm_set_ground_truth", ctypes.c_int, [ctypes.c_void_p, _c_i64p, ctypes.c_int]),
     ("dpmm_contingency", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_i64p]),
     ("dpmm_bin_counts", ctypes.c_int, [ctypes.c_void_p, _c_i64p]),
+    ("dpmm_smart_project", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, _c_f64p, _c_f64p, _c_f64p, _c_i64p]),
+    ("dpmm_smart_kmeans_iter", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_double, _c_f64p]),
+    ("dpmm_smart_assign", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_double]),
     ("dpmm_debug_loglik", ctypes.c_int, [ctypes.c_void_p, _c_f32p]),
     ("dpmm_sync", ctypes.c_int, [ctypes.c_void_p]),
     ("dpmm_stream", ctypes.c_void_p, [ctypes.c_void_p]),
@@ -284,6 +287,24 @@ class Worker:
         out = np.zeros((self.K, 2), np.int64)
         self._chk(self._lib.dpmm_bin_counts(self._h, _p(out, _c_i64p)))
         return out
+
+    # ---- smart splits (worker halves of smart_cluster_init!)
+    def smart_project(self, cluster, v, mu):
+        """Projections t = v.(x - mu) of the points of `cluster` (1-based), in arbitrary order (Float64)."""
+        v = np.ascontiguousarray(v, np.float64); mu = np.ascontiguousarray(mu, np.float64)
+        assert v.shape == (self.D,) and mu.shape == (self.D,)
+        vals = np.empty(max(self.n, 1), np.float64)
+        cnt = np.zeros(1, np.int64)
+        self._chk(self._lib.dpmm_smart_project(self._h, int(cluster), _p(v, _c_f64p), _p(mu, _c_f64p), _p(vals, _c_f64p), _p(cnt, _c_i64p)))
+        return vals[:int(cnt[0])]
+
+    def smart_kmeans_iter(self, cluster, m_lo, m_hi):
+        out = np.zeros(4, np.float64)
+        self._chk(self._lib.dpmm_smart_kmeans_iter(self._h, int(cluster), float(m_lo), float(m_hi), _p(out, _c_f64p)))
+        return out
+
+    def smart_assign(self, cluster, m_lo, m_hi):
+        self._chk(self._lib.dpmm_smart_assign(self._h, int(cluster), float(m_lo), float(m_hi)))
 
     # ---- diagnostics
     def debug_loglik(self):

@@ -78,6 +78,7 @@ struct dpmm_ctx {
     int64_t slab_stride = 0;
     double *d_out = nullptr;
     int64_t packed_stride = 0;
+    double *d_proj = nullptr, *d_vals = nullptr, *d_smart = nullptr;   // smart splits: projections [n], compacted copy [n], partials + v + mu
     int32_t *d_small = nullptr;  // index lists for relabel kernels (Int32, <= 4*DPMM_MAX_CLUSTERS)
     std::vector<uint8_t> h_sel;
     // pinned host staging for every per-step transfer (pageable copies stall for tens of ms now and then)
@@ -245,7 +246,7 @@ int dpmm_destroy(dpmm_ctx *c) {
     free_params(c);
     hipFree(c->dX); hipFree(c->dbins); hipFree(c->d_gt); hipFree(c->d_cont);
     hipFree(c->sb.tile_hist); hipFree(c->sb.bin_total); hipFree(c->sb.bin_start); hipFree(c->sb.item_start);
-    hipFree(c->sb.perm); hipFree(c->sb.bin_sel); hipFree(c->sb.perm_total); hipFree(c->d_small);
+    hipFree(c->sb.perm); hipFree(c->sb.bin_sel); hipFree(c->sb.perm_total); hipFree(c->d_small); hipFree(c->d_proj); hipFree(c->d_vals); hipFree(c->d_smart);
     if (c->h_pin) hipHostFree(c->h_pin);
     for (auto &e : c->ev) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -799,6 +800,64 @@ int dpmm_reset_sublabels(dpmm_ctx *c, const int64_t *idx, int n, uint32_t epoch)
         if (int rc = upload_idx(c, idx, nullptr, n, DPMM_MAX_CLUSTERS)) return rc;
     }
     if (c->n > 0) HIPCHK(c, launch_reset_sub(c->dbins, c->n, c->first, idx ? c->d_small : nullptr, idx ? n : 0, c->seed, epoch, c->stream));
+    return DPMM_OK;
+}
+
+static int smart_buffers(dpmm_ctx *c) {
+    if (c->d_proj) return DPMM_OK;
+    const size_t n = (size_t)std::max<int64_t>(c->n, 1);
+    HIPCHK(c, hipMalloc(&c->d_proj, sizeof(double) * n));
+    HIPCHK(c, hipMalloc(&c->d_vals, sizeof(double) * n));
+    HIPCHK(c, hipMalloc(&c->d_smart, sizeof(double) * (4 * (size_t)smart_groups() + 8 + 2 * (size_t)c->D)));
+    return DPMM_OK;
+}
+static int smart_check(dpmm_ctx *c, int64_t cluster) {
+    if (!c->have_points || !c->have_labels) return fail(c, DPMM_ESTATE, "smart split needs points and labels");
+    if (cluster < 1 || cluster > DPMM_MAX_CLUSTERS) return fail(c, DPMM_EINVAL, "cluster index out of range");
+    return DPMM_OK;
+}
+
+int dpmm_smart_project(dpmm_ctx *c, int64_t cluster, const double *v, const double *mu, double *values, int64_t *count) {
+    if (!c || !v || !mu || !count) return DPMM_EINVAL;
+    if (int rc = smart_check(c, cluster)) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = smart_buffers(c)) return rc;
+    *count = 0;
+    if (c->n == 0) return DPMM_OK;
+    double *d_v = c->d_smart + 4 * (size_t)smart_groups() + 8, *d_mu = d_v + c->D;
+    unsigned long long *d_cnt = reinterpret_cast<unsigned long long *>(c->d_smart + 4 * (size_t)smart_groups() + 4);
+    HIPCHK(c, hipMemcpyAsync(d_v, v, sizeof(double) * c->D, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_mu, mu, sizeof(double) * c->D, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), c->stream));
+    HIPCHK(c, launch_smart_project(c->dbins, c->dX, c->ldx, c->n, c->D, (int)(cluster - 1), d_v, d_mu, c->d_proj, c->d_vals, d_cnt, c->stream));
+    unsigned long long h = 0;
+    HIPCHK(c, hipMemcpyAsync(&h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *count = (int64_t)h;
+    if (values && h > 0) HIPCHK(c, hipMemcpy(values, c->d_vals, sizeof(double) * h, hipMemcpyDeviceToHost));
+    return DPMM_OK;
+}
+
+int dpmm_smart_kmeans_iter(dpmm_ctx *c, int64_t cluster, double m_lo, double m_hi, double *out4) {
+    if (!c || !out4) return DPMM_EINVAL;
+    if (int rc = smart_check(c, cluster)) return rc;
+    if (!c->d_proj) return fail(c, DPMM_ESTATE, "dpmm_smart_project has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    out4[0] = out4[1] = out4[2] = out4[3] = 0.;
+    if (c->n == 0) return DPMM_OK;
+    double *d_out = c->d_smart + 4 * (size_t)smart_groups();
+    HIPCHK(c, launch_smart_kmeans(c->dbins, c->d_proj, c->n, (int)(cluster - 1), m_lo, m_hi, c->d_smart, d_out, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out4, d_out, sizeof(double) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DPMM_OK;
+}
+
+int dpmm_smart_assign(dpmm_ctx *c, int64_t cluster, double m_lo, double m_hi) {
+    if (!c) return DPMM_EINVAL;
+    if (int rc = smart_check(c, cluster)) return rc;
+    if (!c->d_proj) return fail(c, DPMM_ESTATE, "dpmm_smart_project has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n > 0) HIPCHK(c, launch_smart_assign(c->dbins, c->d_proj, c->n, (int)(cluster - 1), m_lo, m_hi, c->stream));
     return DPMM_OK;
 }
 

@@ -80,6 +80,12 @@ hipError_t launch_mult_sweep_bf16(const MultSweepArgs &a, const uint32_t *Lp16, 
 
 // ---- label bookkeeping (labels.hip)
 // dst/src: device or pinned-host pointers, 4-byte aligned; bytes rounded up to a multiple of 4
+hipError_t launch_smart_project(const int32_t *bins, const float *X, int64_t ldx, int64_t n, int D, int k, const double *v, const double *mu,
+                                double *proj, double *vals, unsigned long long *counter, hipStream_t s);
+hipError_t launch_smart_kmeans(const int32_t *bins, const double *proj, int64_t n, int k, double m_lo, double m_hi, double *partial, double *out,
+                               hipStream_t s);
+hipError_t launch_smart_assign(int32_t *bins, const double *proj, int64_t n, int k, double m_lo, double m_hi, hipStream_t s);
+int smart_groups();
 hipError_t launch_ingest_rows(float *dst, int64_t ldx, const void *src, int is_f64, int64_t ld, int64_t rows, int D, int nan_to_zero,
                               hipStream_t s);
 hipError_t launch_copy_bytes(void *dst, const void *src, size_t bytes, hipStream_t s);

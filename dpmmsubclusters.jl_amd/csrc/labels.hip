@@ -174,6 +174,92 @@ hipError_t launch_ingest_rows(float *dst, int64_t ldx, const void *src, int is_f
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Smart splits (src/local_clusters_actions.jl:555-653): 1-D 2-means along a direction v inside one cluster.
+//   tranform_points_worker! (:643-653)   t_i = v . (x_i - mu), Float64, for the points with label == k
+//   kmeans_iter_worker!     (:635-641)   side_i = |t_i - m_lo| < |t_i - m_hi| ? 1 : 2; per side (sum of t, count)
+//   set_smart_labels_in_worker! (:629-633) sub-label_i = side_i
+// proj[i] is indexed by point (only entries of the cluster are meaningful); `vals` receives the same values compacted
+// in arbitrary order (the host takes percentiles of them).  The per-side sums are reduced in a FIXED order (one partial
+// per workgroup over a contiguous range, tree inside the workgroup): reproducible run to run.
+__global__ __launch_bounds__(256) void smart_project_kernel(const int32_t *__restrict__ bins, const float *__restrict__ X, int64_t ldx, int64_t n,
+                                                            int D, int k, const double *__restrict__ v, const double *__restrict__ mu,
+                                                            double *__restrict__ proj, double *__restrict__ vals, unsigned long long *counter) {
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < n; i0 += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = i0 + threadIdx.x;
+        const bool mine = i < n && (bins[i] >> 1) == k;
+        double t = 0.;
+        if (mine) {
+            const float *x = X + i * ldx;
+            for (int d = 0; d < D; ++d) t += v[d] * ((double)x[d] - mu[d]);       // v' * (x - mu), left to right as a dot product
+            proj[i] = t;
+        }
+        const unsigned long long m = __ballot(mine);
+        if (m) {
+            const int lane = threadIdx.x & 63;
+            unsigned long long base = 0;
+            if (lane == __ffsll((long long)m) - 1) base = atomicAdd(counter, (unsigned long long)__popcll(m));
+            base = __shfl(base, __ffsll((long long)m) - 1);
+            if (mine) vals[base + __popcll(m & ((1ull << lane) - 1ull))] = t;
+        }
+    }
+}
+
+constexpr int SMART_GROUPS = 1024;
+__global__ __launch_bounds__(256) void smart_kmeans_kernel(const int32_t *__restrict__ bins, const double *__restrict__ proj, int64_t n, int k,
+                                                           double m_lo, double m_hi, double *__restrict__ partial) {
+    __shared__ double sh[4][256];
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = min(n, lo + per);
+    double s1 = 0., c1 = 0., s2 = 0., c2 = 0.;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        if ((bins[i] >> 1) == k) {
+            const double t = proj[i];
+            if (fabs(t - m_lo) < fabs(t - m_hi)) { s1 += t; c1 += 1.; } else { s2 += t; c2 += 1.; }
+        }
+    }
+    sh[0][threadIdx.x] = s1; sh[1][threadIdx.x] = c1; sh[2][threadIdx.x] = s2; sh[3][threadIdx.x] = c2;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            for (int q = 0; q < 4; ++q) sh[q][threadIdx.x] += sh[q][threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) partial[4 * blockIdx.x + threadIdx.x] = sh[threadIdx.x][0];
+}
+__global__ void smart_kmeans_finish_kernel(const double *__restrict__ partial, int groups, double *__restrict__ out) {
+    if (threadIdx.x < 4) {
+        double s = 0.;
+        for (int g = 0; g < groups; ++g) s += partial[4 * g + threadIdx.x];
+        out[threadIdx.x] = s;
+    }
+}
+__global__ void smart_assign_kernel(int32_t *__restrict__ bins, const double *__restrict__ proj, int64_t n, int k, double m_lo, double m_hi) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = bins[i];
+        if ((b >> 1) == k) {
+            const double t = proj[i];
+            bins[i] = 2 * k + ((fabs(t - m_lo) < fabs(t - m_hi)) ? 0 : 1);
+        }
+    }
+}
+hipError_t launch_smart_project(const int32_t *bins, const float *X, int64_t ldx, int64_t n, int D, int k, const double *v, const double *mu,
+                                double *proj, double *vals, unsigned long long *counter, hipStream_t s) {
+    hipLaunchKernelGGL(smart_project_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, X, ldx, n, D, k, v, mu, proj, vals, counter);
+    return hipGetLastError();
+}
+hipError_t launch_smart_kmeans(const int32_t *bins, const double *proj, int64_t n, int k, double m_lo, double m_hi, double *partial, double *out,
+                               hipStream_t s) {
+    hipLaunchKernelGGL(smart_kmeans_kernel, dim3(SMART_GROUPS), dim3(256), 0, s, bins, proj, n, k, m_lo, m_hi, partial);
+    hipLaunchKernelGGL(smart_kmeans_finish_kernel, dim3(1), dim3(64), 0, s, partial, SMART_GROUPS, out);
+    return hipGetLastError();
+}
+hipError_t launch_smart_assign(int32_t *bins, const double *proj, int64_t n, int k, double m_lo, double m_hi, hipStream_t s) {
+    hipLaunchKernelGGL(smart_assign_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, proj, n, k, m_lo, m_hi);
+    return hipGetLastError();
+}
+int smart_groups() { return SMART_GROUPS; }
+
 hipError_t launch_init_labels(int32_t *bins, int64_t n, int64_t first, int init_clusters, uint64_t seed, uint32_t epoch, hipStream_t s) {
     hipLaunchKernelGGL(init_labels_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, n, first, init_clusters, seed, epoch);
     return hipGetLastError();

@@ -106,6 +106,7 @@ def save_model(sampler, path, prefix, it, total_time, global_params="none"):
              labels=labels.astype(np.int64), labels_subcluster=sub.astype(np.int64), K=int(sampler.K),
              alpha=float(sampler.alpha), total_dim=int(sampler.n_total), seed=np.uint64(sampler.seed),
              burnout=int(sampler.burnout), epoch=int(sampler.epoch), draw_epoch=int(sampler.draw_epoch),
+             smart_splits=bool(sampler.smart_splits), max_split_iter=int(sampler.max_split_iter), hard_clustering=bool(sampler.hard_clustering),
              rng_state=json.dumps(sampler.rng.bit_generator.state, default=lambda o: o.tolist() if hasattr(o, "tolist") else int(o)))
     d.update(_prior_to_dict(sampler.prior))
     for k in _SAMPLER_ARRAYS:
@@ -147,6 +148,11 @@ def restore_sampler(sampler, ck):
     sampler.post = post or None
     par = {k[4:]: np.array(v) for k, v in ck.items() if k.startswith("par_")}
     sampler.params = par or None
+    for k in ("smart_splits", "hard_clustering"):
+        if k in ck:
+            setattr(sampler, k, bool(ck[k]))
+    if "max_split_iter" in ck:
+        sampler.max_split_iter = int(ck["max_split_iter"])
     sampler.epoch = int(ck["epoch"])
     sampler.draw_epoch = int(ck["draw_epoch"])
     st = json.loads(str(ck["rng_state"]))

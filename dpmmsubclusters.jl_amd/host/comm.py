@@ -58,6 +58,16 @@ class TorchDistComm:
         self.dist.all_reduce(t)
         return t.cpu().numpy()
 
+    def reduce_f64(self, arr, op="sum"):
+        """All-reduce of a small Float64 vector (`op` in sum / min / max): the 1-D 2-means sums and the percentile
+        extremes of smart splits."""
+        t = self.torch.from_numpy(np.ascontiguousarray(arr, np.float64).copy())
+        if self.backend == "nccl":
+            t = t.to(f"cuda:{self.device}")
+        rop = {"sum": self.dist.ReduceOp.SUM, "min": self.dist.ReduceOp.MIN, "max": self.dist.ReduceOp.MAX}[op]
+        self.dist.all_reduce(t, op=rop)
+        return t.cpu().numpy()
+
     def broadcast(self, arr, src=0):
         """In-place broadcast of a C-contiguous numpy array from rank `src` (leader mode of the sampler)."""
         t = self.torch.from_numpy(arr)

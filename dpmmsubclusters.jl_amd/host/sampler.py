@@ -42,6 +42,9 @@ class LocalComm:
     def reduce_counts(self, table):
         return table
 
+    def reduce_f64(self, arr, op="sum"):
+        return np.asarray(arr, np.float64)
+
     def broadcast(self, arr, src=0):
         return arr
 
@@ -77,6 +80,8 @@ class DPMMSampler:
         self.split_stop = split_stop
         self.nthreads = nthreads
         self.hard_clustering = False   # global_params.jl:8: argmax label assignment in every sweep
+        self.smart_splits = False      # global_params.jl:44 / fit(...; smart_splits): Gaussian prior only
+        self.max_split_iter = 20       # global_params.jl:15
         self.rng = np.random.Generator(np.random.Philox(key=self.seed))
         self.epoch = 0          # device-side randomised calls (stream-unique)
         self.draw_epoch = 1 << 20   # host parameter draws: separate, predictable counter (noise is pre-generated)
@@ -272,6 +277,39 @@ class DPMMSampler:
         self._tic("bad_reset", t0)
         self.update_suff_stats_posterior()
 
+    # ------------------------------------------------------------------ smart splits
+    def smart_cluster_init(self, k):
+        """smart_cluster_init!(group, cluster_num) (local_clusters_actions.jl:555-627), k 0-based.  The direction is taken
+        exactly as the reference takes it -- `F.vectors[argmax(F.values), :]`, i.e. a ROW of the eigenvector matrix of the
+        cluster covariance, and the two seeds are `percentile(t, 0.10)` / `percentile(t, 0.90)` in StatsBase's 0..100
+        convention (the 0.001 and 0.009 quantiles) -- see DESIGN.md for why these two quirks are kept."""
+        N = self.N[k, 0]
+        if not (N > 0) or self.S is None:
+            return
+        XXT = self.S[k, 0] / N
+        mu = self.sums[k, 0] / N
+        M = XXT - np.outer(mu, mu)
+        vals, vecs = np.linalg.eigh(M)                      # Hermitian path of Julia's eigen(): ascending eigenvalues
+        v1 = np.ascontiguousarray(vecs[int(np.argmax(vals)), :])
+        t = self.wk.smart_project(k + 1, v1, mu)
+        lo, hi = np.inf, -np.inf
+        if len(t) > 1:                                       # `length(transformed_pts) > 1`, else the worker returns nothing
+            lo, hi = np.quantile(t, 0.10 * 0.01), np.quantile(t, 0.90 * 0.01)
+        lo = float(self.comm.reduce_f64([lo], "min")[0]); hi = float(self.comm.reduce_f64([hi], "max")[0])
+        if not np.isfinite(lo) and not np.isfinite(hi) and lo > hi:
+            return                                           # no worker had more than one point of this cluster
+        it, converged = 0, False
+        while it < self.max_split_iter and not converged:
+            s = self.comm.reduce_f64(self.wk.smart_kmeans_iter(k + 1, lo, hi), "sum")
+            with np.errstate(invalid="ignore", divide="ignore"):
+                new_lo, new_hi = float(np.float64(s[0]) / np.float64(s[1])), float(np.float64(s[2]) / np.float64(s[3]))
+            if new_lo == lo and new_hi == hi:
+                converged = True
+            else:
+                lo, hi = new_lo, new_hi
+            it += 1
+        self.wk.smart_assign(k + 1, lo, hi)
+
     # ------------------------------------------------------------------ step 7a
     def check_and_split(self, final):
         K = self.K
@@ -301,7 +339,11 @@ class DPMMSampler:
                 self.points_count[k] = int(round(self.N[k, 0]))
         self.wk.set_num_clusters(self.K)
         self.wk.split(acc + 1, new + 1, self._next_epoch())
-        return np.concatenate([acc, new])
+        touched = np.concatenate([acc, new])
+        if self.smart_splits:                                # local_clusters_actions.jl:374-378
+            for k in touched:
+                self.smart_cluster_init(int(k))
+        return touched
 
     def _grow(self, K2):
         K, D = self.K, self.prior.dim
@@ -435,6 +477,10 @@ class DPMMSampler:
         self.wk.reset_sublabels(None, self._next_epoch())   # split_first_cluster_worker!
         self.wk.set_num_clusters(self.K)
         self.update_suff_stats_posterior()
+        if self.smart_splits:                                # dp-parallel-sampling.jl:70-75
+            for k in range(self.K):
+                self.smart_cluster_init(k)
+            self.update_suff_stats_posterior()
         self.sample_clusters()
 
     def start_from_labels(self, labels, sub_labels, K):

@@ -182,6 +182,19 @@ int dpmm_predict(dpmm_ctx *ctx, float *parr);
  * every other cluster untouched. */
 int dpmm_bin_counts(dpmm_ctx *ctx, int64_t *counts);
 
+/* Smart splits (next row of the scope table; opt-in `smart_splits`, Gaussian prior only): the worker halves of
+ * smart_cluster_init! (src/local_clusters_actions.jl:555-627).  The master computes the direction v and the centre mu
+ * from the cluster's statistics (:557-568) and drives at most max_split_iter 1-D 2-means steps (:593-623).
+ *   dpmm_smart_project      tranform_points_worker! (:643-653): t_i = v.(x_i - mu) (Float64) for the points of `cluster`
+ *                           (1-based); `values` (capacity n_local, may be NULL) receives them in arbitrary order so
+ *                           that the caller can take the percentiles (:650), `count` their number.
+ *   dpmm_smart_kmeans_iter  kmeans_iter_worker! (:635-641): out4 = {sum of t on the m_lo side, count, sum on the m_hi
+ *                           side, count}; side 1 iff |t - m_lo| < |t - m_hi|.  Summable across shards.
+ *   dpmm_smart_assign       set_smart_labels_in_worker! (:629-633): sub-label := side. */
+int dpmm_smart_project(dpmm_ctx *ctx, int64_t cluster, const double *v, const double *mu, double *values, int64_t *count);
+int dpmm_smart_kmeans_iter(dpmm_ctx *ctx, int64_t cluster, double m_lo, double m_hi, double *out4);
+int dpmm_smart_assign(dpmm_ctx *ctx, int64_t cluster, double m_lo, double m_hi);
+
 /* On-device evaluation (next row of the scope table): with a ground truth the reference gathers all N labels to
  * the master EVERY iteration to compute NMI / VI (src/dp-parallel-sampling.jl:370-377).  Here the ground truth of
  * the shard is uploaded once (Int64, any integer ids in [0, n_gt)), and each call returns only the

@@ -111,6 +111,23 @@ class FakeWorker:
     def set_ground_truth_range(self, gt, n_gt):
         self.gt = np.asarray(gt, np.int64); self.n_gt = int(n_gt)
 
+    # smart splits (worker halves), straight numpy restatement of local_clusters_actions.jl:629-653
+    def smart_project(self, cluster, v, mu):
+        m = self.labels == cluster
+        self._proj = np.full(self.n, np.nan)
+        self._proj[m] = (self.X[m].astype(np.float64) - np.asarray(mu, np.float64)) @ np.asarray(v, np.float64)
+        return self._proj[m].copy()
+
+    def smart_kmeans_iter(self, cluster, m_lo, m_hi):
+        t = self._proj[self.labels == cluster]
+        side1 = np.abs(t - m_lo) < np.abs(t - m_hi)
+        return np.array([t[side1].sum(), side1.sum(), t[~side1].sum(), (~side1).sum()], np.float64)
+
+    def smart_assign(self, cluster, m_lo, m_hi):
+        m = self.labels == cluster
+        t = self._proj[m]
+        self.sub[m] = np.where(np.abs(t - m_lo) < np.abs(t - m_hi), 1, 2)
+
     def bin_counts(self):
         out = np.zeros((self.K, 2), np.int64)
         np.add.at(out, (self.labels - 1, self.sub - 1), 1)
