@@ -10,9 +10,8 @@ Argument meaning, defaults, coercions (Float32 data / Int64 iters, :279-293), th
 (kappa=1, m=0, nu=D+3, psi=I, :272-274) and the 9-tuple / 5-tuple results follow the reference.
 `all_data` is Dimensions x Samples (D x N) as in the reference.  Checkpoints (`save_model`), the advanced
 parameter-file mode `dp_parallel(model_params::String)` and `run_model_from_checkpoint` live in host/checkpoint.py.
-Smart splits (`smart_splits=True`, Gaussian prior) are driven by DPMMSampler.smart_cluster_init.  Out of scope here
-(next rows): the outlier component -- passing a non-default value for it raises
-NotImplementedError rather than being silently ignored.
+Smart splits (`smart_splits=True`, Gaussian prior) are driven by DPMMSampler.smart_cluster_init; the outlier component
+(`outlier_weight`, `outlier_params`) is cluster 1 of the model with a constant weight, never split, merged or re-drawn.
 
 Distributed: when torch.distributed is initialised (one process per GPU) every rank calls `fit`
 with the SAME full arguments; each rank keeps the contiguous column range
@@ -80,8 +79,13 @@ def _make_sampler(all_data, hyper, alpha, seed, burnout, max_clusters, comm, dev
 
 
 def _check_next_rows(outlier_weight, outlier_params, smart_splits, hyper=None):
-    if outlier_weight != 0 or outlier_params is not None:
-        raise NotImplementedError("outlier component is outside this build's scope (SURVEY.md 8f)")
+    if outlier_weight and outlier_weight > 0:
+        if not isinstance(outlier_params, _priors.distribution_hyper_params):
+            raise TypeError("outlier_weight > 0 needs outlier_params (a distribution_hyper_params of the same family)")
+        if hyper is not None and (outlier_params.kind != hyper.kind or outlier_params.dim != hyper.dim):
+            raise ValueError("outlier_params must be of the same family and dimension as the cluster prior")
+        if not (outlier_weight < 1):
+            raise ValueError("outlier_weight must be in (0, 1)")
     if smart_splits and hyper is not None and hyper.kind != _priors.PRIOR_NIW:
         raise ValueError("smart_splits is available for the Gaussian (niw_hyperparams) prior only, as in the reference")
 
@@ -113,6 +117,8 @@ def dp_parallel(all_data, local_hyper_params=None, alpha_param=None, iters=100, 
     s = _make_sampler(all_data, local_hyper_params, np.float32(alpha_param), seed, int(burnout), max_clusters, comm, device,
                       nthreads, worker_factory)
     s.smart_splits = bool(smart_splits)
+    if outlier_weight and outlier_weight > 0:
+        s.outlier_weight, s.outlier_prior = float(outlier_weight), outlier_params
     s.init_first_clusters(int(init_clusters))
     hook = _ckpt.SaveHook(save_path, save_file_prefix, model_save_interval, "none", 0.0, verbose) if save_model else None
     iter_count, nmi, lik, kh = s.run_model(int(iters), 1, verbose=verbose, gt=gt, on_iteration=hook)
@@ -123,7 +129,8 @@ def dp_parallel(all_data, local_hyper_params=None, alpha_param=None, iters=100, 
 
 
 def _sampler_from_params(P, comm, device, nthreads, worker_factory):
-    _check_next_rows(P["outlier_mod"] if P["outlier_hyper_params"] is not None else 0, None, P["smart_splits"], P["hyper_params"])
+    use_outlier = P["outlier_hyper_params"] is not None and P["outlier_mod"] and P["outlier_mod"] > 0
+    _check_next_rows(P["outlier_mod"] if use_outlier else 0, P["outlier_hyper_params"], P["smart_splits"], P["hyper_params"])
     rows = _ckpt.load_data(P["data_path"], P["data_prefix"], swapDimension=False, mmap=True)     # Samples x Dimensions
     s = _make_sampler(None, P["hyper_params"], np.float32(P["alpha"]), P["random_seed"], int(P["burnout_period"]),
                       P["max_clusters"], comm, device, nthreads, worker_factory, rows=rows,
@@ -131,6 +138,8 @@ def _sampler_from_params(P, comm, device, nthreads, worker_factory):
     s.hard_clustering = bool(P["hard_clustering"])
     s.smart_splits = bool(P["smart_splits"])
     s.max_split_iter = int(P["max_split_iter"])
+    if use_outlier:
+        s.outlier_weight, s.outlier_prior = float(P["outlier_mod"]), P["outlier_hyper_params"]
     return s
 
 

@@ -109,6 +109,11 @@ def save_model(sampler, path, prefix, it, total_time, global_params="none"):
              smart_splits=bool(sampler.smart_splits), max_split_iter=int(sampler.max_split_iter), hard_clustering=bool(sampler.hard_clustering),
              rng_state=json.dumps(sampler.rng.bit_generator.state, default=lambda o: o.tolist() if hasattr(o, "tolist") else int(o)))
     d.update(_prior_to_dict(sampler.prior))
+    if sampler.outlier_weight > 0:
+        d["outlier_weight"] = float(sampler.outlier_weight)
+        d.update({"out_" + k: v for k, v in _prior_to_dict(sampler.outlier_prior).items()})
+        for k, v in (sampler._outlier_params or {}).items():
+            d["outpar_" + k] = np.asarray(v)
     for k in _SAMPLER_ARRAYS:
         v = getattr(sampler, k)
         if v is not None:
@@ -153,6 +158,10 @@ def restore_sampler(sampler, ck):
             setattr(sampler, k, bool(ck[k]))
     if "max_split_iter" in ck:
         sampler.max_split_iter = int(ck["max_split_iter"])
+    if "outlier_weight" in ck:
+        sampler.outlier_weight = float(ck["outlier_weight"])
+        sampler.outlier_prior = _prior_from_dict({k[4:]: v for k, v in ck.items() if k.startswith("out_")})
+        sampler._outlier_params = {k[7:]: np.array(v) for k, v in ck.items() if k.startswith("outpar_")}
     sampler.epoch = int(ck["epoch"])
     sampler.draw_epoch = int(ck["draw_epoch"])
     st = json.loads(str(ck["rng_state"]))

@@ -82,6 +82,9 @@ class DPMMSampler:
         self.hard_clustering = False   # global_params.jl:8: argmax label assignment in every sweep
         self.smart_splits = False      # global_params.jl:44 / fit(...; smart_splits): Gaussian prior only
         self.max_split_iter = 20       # global_params.jl:15
+        self.outlier_weight = 0.0      # outlier_mod: constant weight of an extra, never-splitting component at index 1
+        self.outlier_prior = None      # outlier_hyper_params
+        self._outlier_params = None
         self.rng = np.random.Generator(np.random.Philox(key=self.seed))
         self.epoch = 0          # device-side randomised calls (stream-unique)
         self.draw_epoch = 1 << 20   # host parameter draws: separate, predictable counter (noise is pre-generated)
@@ -185,6 +188,8 @@ class DPMMSampler:
                                               nthreads=self.nthreads)
             self._sync_small()
             self.points_count[sel] = np.rint(self.N[sel, 0]).astype(np.int64)
+            if self.outlier_weight > 0:
+                self.points_count[0] = self.n_total          # create_outlier_local_cluster: never refreshed, never empty
             self._tic("posterior_host", t0)
             return
         un = self.wk.unpack(packed, self.K)
@@ -194,6 +199,8 @@ class DPMMSampler:
         if S is not None:
             self.S[sel] = S[sel]
         self.points_count[sel] = np.rint(N[sel, 0]).astype(np.int64)
+        if self.outlier_weight > 0:
+            self.points_count[0] = self.n_total
         rows = self._rows(sel)
         Nf, sf, Sf = self._stats_flat()
         post = self.prior.posterior(Nf[rows], sf[rows], Sf[rows] if Sf is not None else None, nthreads=self.nthreads)
@@ -234,6 +241,9 @@ class DPMMSampler:
             self.params = self.prior.sample(self.post, self.seed, self.draw_epoch, np.arange(3 * K), nthreads=self.nthreads, noise=noise)
         else:
             self.params = self.prior.sample(self.post, self.seed, self.draw_epoch, np.arange(3 * K), nthreads=self.nthreads)
+        if self.outlier_weight > 0 and self._outlier_params is not None:
+            for key, val in self._outlier_params.items():   # sample_clusters! skips index 1 (local_clusters_actions.jl:424-427)
+                self.params[key][0:3] = val
         self._sync_params()
         self._tic("sample_params_host", t0)
         t0 = time.perf_counter()
@@ -247,8 +257,16 @@ class DPMMSampler:
             now = (self.hist[:, :b].astype(np.float64) * (1.0 / (b - 0.1))).sum(1)
             gate = (now != -np.inf) & ((now - self.hist[:, b - 1]) < 1e-2)
         self.splittable |= gate
-        w = self._dirichlet(np.concatenate([self.N[:, 0], [self.alpha]]))
-        self.weights = w[:K].astype(np.float32)
+        if self.outlier_weight > 0:
+            ow = self.outlier_weight                          # local_clusters_actions.jl:431-436
+            self.lr_weights[0] = 0.5
+            self.splittable[0] = False
+            self.hist[0] = -np.inf
+            w = self._dirichlet(np.concatenate([self.N[1:, 0], [self.alpha]]))
+            self.weights = np.concatenate([[ow], w[:K - 1] * (1.0 - ow)]).astype(np.float32)
+        else:
+            w = self._dirichlet(np.concatenate([self.N[:, 0], [self.alpha]]))
+            self.weights = w[:K].astype(np.float32)
         self._tic("host_misc", t0)
 
     # ------------------------------------------------------------------ step 6
@@ -316,6 +334,8 @@ class DPMMSampler:
         if final:
             return np.zeros(0, np.int64)
         cand = np.flatnonzero(self.splittable & (self.N[:, 0] > 1) & (self.N[:, 1] > 0) & (self.N[:, 2] > 0))
+        if self.outlier_weight > 0:
+            cand = cand[cand != 0]                            # local_clusters_actions.jl:348-350
         if len(cand) == 0:
             return np.zeros(0, np.int64)
         L = self.prior.log_marginal(self.post, self.N.reshape(3 * K)).reshape(K, 3)
@@ -470,13 +490,34 @@ class DPMMSampler:
             self._tic("merge_host", t0)
         self.remove_empty_clusters()                             # 8
 
+    def _create_outlier_cluster(self):
+        """create_outlier_local_cluster (local_clusters_actions.jl:42-61): statistics of ALL points under the outlier prior,
+        one parameter draw shared by the cluster and both sub-clusters, never re-drawn."""
+        op = self.outlier_prior
+        Nt = np.array([self.N[1:, 0].sum()])
+        st = self.sums[1:, 0].sum(0)[None]
+        St = self.S[1:, 0].sum(0)[None] if self.S is not None else None
+        post = op.posterior(Nt, st, St, nthreads=1)
+        self.draw_epoch += 1
+        par = op.sample(post, self.seed, self.draw_epoch, np.arange(1), nthreads=1)
+        if self.leader_mode:
+            for k in sorted(par):
+                self.comm.broadcast(par[k])
+        self._outlier_params = {k: np.array(v[0]) for k, v in par.items()}
+
     def init_first_clusters(self, init_clusters):
         """init_model_from_data labels (dp-parallel-sampling.jl:49-50) + init_first_clusters! (:62-78)."""
-        self._alloc(int(init_clusters))
+        out = 1 if self.outlier_weight > 0 else 0
+        self._alloc(int(init_clusters) + out)
         self.wk.init_labels(int(init_clusters), self._next_epoch())
+        if out:                                              # rand(1:initial_clusters) .+ 1 (dp-parallel-sampling.jl:49)
+            lab, _ = self.wk.get_labels()
+            self.wk.set_labels(lab + 1, None)
         self.wk.reset_sublabels(None, self._next_epoch())   # split_first_cluster_worker!
         self.wk.set_num_clusters(self.K)
         self.update_suff_stats_posterior()
+        if out:
+            self._create_outlier_cluster()
         if self.smart_splits:                                # dp-parallel-sampling.jl:70-75
             for k in range(self.K):
                 self.smart_cluster_init(k)

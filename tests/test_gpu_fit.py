@@ -118,3 +118,12 @@ def test_predict_multinomial(host):
     tab = x.T.astype(np.float64) @ np.log(a / a.sum(1, keepdims=True)).T + np.log(w)
     assert (preds == tab.argmax(1) + 1).mean() > 0.999
     assert (preds == res[0]).mean() > 0.95
+
+
+def test_outlier_component_on_gpu(host):
+    """fit(...; outlier_weight, outlier_params): cluster 1 is the fixed outlier component (local_clusters_actions.jl:42-61)."""
+    import sys as _sys, os as _os
+    _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+    from test_outlier_cpu import run_outlier_fit, check_outlier_result
+    r, out = run_outlier_fit(host)
+    check_outlier_result(r, out)

@@ -84,6 +84,3 @@ def test_fit_with_smart_splits_recovers_clusters(host):
     with pytest.raises(ValueError):
         host.fit(np.abs(x).astype(np.float32), host.multinomial_hyper(np.ones(2)), 10.0, iters=2, smart_splits=True,
                  worker_factory=FakeWorker, verbose=False)
-    with pytest.raises(NotImplementedError):
-        host.fit(x.astype(np.float32), 10.0, iters=2, outlier_weight=0.05, outlier_params=host.niw_hyperparams(1.0, np.zeros(2), 5, np.eye(2)),
-                 worker_factory=FakeWorker, verbose=False)
