@@ -29,9 +29,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense FP32 matrix peak (no TF32/xf32 on gfx950)
-# HBM bytes per point per launch of the D=64 sweep kernel, from the PMC counters (separate rocprofv3 --pmc passes,
-# FETCH_SIZE doubled per the gfx950 correction): profiles/r01b_bench_niw_d64_n1e7_pmc.json -> (2*1316816.5 + 77807.5) KiB / 1e7
-PMC_BYTES_PER_POINT_D64 = (2 * 1316816.5 + 77807.5) * 1024 / 1e7
+# PMC figures of the D=64 sweep kernel at the bench workload (separate rocprofv3 --pmc passes, medians over launches,
+# profiles/r01c_bench_niw_d64_n1e7_pmc.json), per point so that they scale with the shard size:
+#   HBM bytes: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE -> (2*1318148.375 + 81429.0) KiB / 1e7 points
+#   executed matrix flops: SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 -> 314696656 x 512 / 1e7 points (K = 32 clusters)
+PMC_BYTES_PER_POINT_D64 = (2 * 1318148.375 + 81429.0) * 1024 / 1e7
+PMC_EXECUTED_FLOPS_PER_POINT_D64_K32 = 314696656.0 * 512 / 1e7
 
 
 def cpu_baseline(host, X_local, D, K, sampler, budget_points):
@@ -158,6 +161,12 @@ def main():
                      "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                      "traffic": (PMC_BYTES_PER_POINT_D64 * n_local if D == 64 else None),
                      "avg_launch_ms": avg_sweep_ms, "algorithmic_flops_per_launch": flops_per_launch,
+                     # cluster screening skips most of the algorithmic work, which is why `frac` exceeds 1; the flops the
+                     # kernel actually EXECUTES on the matrix pipe (PMC, K=32 bench data) over the live launch time:
+                     "executed_tflops": (PMC_EXECUTED_FLOPS_PER_POINT_D64_K32 * n_local / (avg_sweep_ms * 1e-3) / 1e12
+                                         if (D == 64 and K == 32) else None),
+                     "executed_frac": (PMC_EXECUTED_FLOPS_PER_POINT_D64_K32 * n_local / (avg_sweep_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
+                                       if (D == 64 and K == 32) else None),
                      "stats_kernels_ms": float(np.mean(stats_ms))},
         "host_ms_per_step": {k: 1e3 * v / (args.steps + args.warmup + burnout + 1) for k, v in s.timers.items()},
     }

@@ -461,11 +461,10 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
         return (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)v);
     };
     // Cross-tile prefetch (static tile schedule): while a tile is processed, the wave already fetches the NEXT
-    // tile's point indices (order[]), their previous labels (bins[]) and touches their X lines so that they sit in
-    // L2; the next tile then issues its X gather and its first fragment loads at once instead of walking the
-    // dependent chain order -> bins -> reference cluster -> fragments.
-    int nx_p = -1, nx_bin = -1, sink = 0;
-    float touch_a = 0.f, touch_b = 0.f;
+    // tile's point indices (order[]) and their previous labels (bins[]); the next tile then issues its X gather at
+    // once instead of walking the dependent chain order -> X, order -> bins -> reference cluster -> fragments.
+    // (Also touching the next tile's X lines to pull them into L2 was measured: no gain, +30 % HBM traffic.)
+    int nx_p = -1, nx_bin = -1;
     int64_t nx_tile = -1;
     for (int64_t tile = next_tile(-1); tile < nwtiles; tile = next_tile(tile)) {
         const int64_t wbase = tile * WPTS;
@@ -506,7 +505,6 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                                                   : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
-        sink ^= __builtin_bit_cast(int, touch_a) ^ __builtin_bit_cast(int, touch_b);
         const int64_t tnext = tile + nwaves;
         int pf_p = -1, pf_bin = -1;
         if (!A.tile_counter && tnext < nwtiles) {
@@ -880,11 +878,6 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
         if (A.labels_only) continue;
         STAMP(s3);
 
-        if (pf_p >= 0) {     // pull the next tile's X lines (2 x 128 B per point at D = 64) into L2
-            const float *xq = A.X + (int64_t)pf_p * A.ldx;
-            touch_a = xq[0];
-            if (A.ldx > 32) touch_b = xq[32];
-        }
         // sub-labels: walk the distinct labels of this wave (wave-uniform loop)
         float b0 = -INFINITY, b1 = -INFINITY;
         unsigned long long todo = __ballot(valid);
@@ -916,7 +909,6 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
         T_draw += s3 - s2; T_p2 += s4 - s3; T_tot += s4 - s0; T_x += s1 - s0; ++ntile;
 #endif
     }
-    if (sink == 0x5a5a1234 && A.n < 0) A.bins[0] = sink;     // keeps the L2-touch loads alive; never true
 #ifdef DPMM_STAMPS
     if (lane == 0 && A.dbg) {
         unsigned long long *d = A.dbg + wave_id * 16;

@@ -1,0 +1,12 @@
+"""Median per-dispatch PMC counters per kernel from rocprofv3 csv output (counter_collection.csv files under <dir>/pmc_*)."""
+import csv, glob, json, os, statistics, sys
+from collections import defaultdict
+root = sys.argv[1]
+acc = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            name = row.get("Kernel_Name", "").split("(")[0].replace("void ", "")
+            acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
+out = {k: {c: {"median": statistics.median(v), "n": len(v)} for c, v in cs.items()} for k, cs in acc.items()}
+print(json.dumps(out, indent=1))
