@@ -91,6 +91,8 @@ class DPMMSampler:
         self.K = 0
         self.timers = {}
         self._noise_job = None
+        self._gen = 0             # bumped whenever posteriors / statistics / K change: validates the log-marginal cache
+        self._L_cache = None
         # Leader mode (multi-rank only): rank 0 alone runs the heavy host maths (posterior factorisations, parameter
         # draws, merge log-marginals) with all host threads and broadcasts the small results; every rank still takes
         # the same Metropolis decisions from the same numbers.  Chosen when redundant execution would leave each rank
@@ -120,6 +122,7 @@ class DPMMSampler:
         return (3 * ks[:, None] + np.arange(3)[None, :]).ravel()
 
     def _alloc(self, K):
+        self._touch()
         D = self.prior.dim
         self.K = K
         st = self.prior.empty_stats(3 * K)
@@ -134,6 +137,7 @@ class DPMMSampler:
         self.points_count = np.zeros(K, np.int64)
 
     def _set_post_rows(self, rows, post):
+        self._touch()
         if self.post is None:
             self.post = {k: np.array(v) for k, v in post.items()}
             return
@@ -160,6 +164,17 @@ class DPMMSampler:
         job["thread"].start()
         self._noise_job = job
 
+    def _touch(self):
+        self._gen += 1
+
+    def _log_marginal_all(self):
+        """log_marginal of all 3K statistic sets, cached until the posteriors change (three callers per sweep)."""
+        if self._L_cache is not None and self._L_cache[0] == self._gen and len(self._L_cache[1]) == 3 * self.K:
+            return self._L_cache[1]
+        L = self.prior.log_marginal(self.post, self.N.reshape(3 * self.K))
+        self._L_cache = (self._gen, L)
+        return L
+
     def _take_noise(self, epoch, rows):
         job, self._noise_job = self._noise_job, None
         if job is None:
@@ -175,6 +190,7 @@ class DPMMSampler:
         if ks is not None and len(ks) == 0:
             return
         t0 = time.perf_counter()
+        self._touch()
         idx = None if ks is None else (np.asarray(ks, np.int64) + 1)
         packed = self.comm.reduce_stats(self.wk, idx)
         self._tic("stats_gpu", t0)
@@ -249,7 +265,7 @@ class DPMMSampler:
         t0 = time.perf_counter()
         half = self.alpha / 2
         self.lr_weights = self._dirichlet(self.N[:, 1:3] + half).astype(np.float32)
-        L = self.prior.log_marginal(self.post, self.N.reshape(3 * K)).reshape(K, 3)
+        L = self._log_marginal_all().reshape(K, 3)
         b = self.burnout
         self.hist[:, : b - 1] = self.hist[:, 1:b]
         with np.errstate(invalid="ignore", over="ignore"):
@@ -338,7 +354,7 @@ class DPMMSampler:
             cand = cand[cand != 0]                            # local_clusters_actions.jl:348-350
         if len(cand) == 0:
             return np.zeros(0, np.int64)
-        L = self.prior.log_marginal(self.post, self.N.reshape(3 * K)).reshape(K, 3)
+        L = self._log_marginal_all().reshape(K, 3)
         Nc, Nl, Nr = self.N[cand, 0], self.N[cand, 1], self.N[cand, 2]
         log_hr = np.log(self.alpha) + gammaln(Nl) + L[cand, 1] + gammaln(Nr) + L[cand, 2] - (gammaln(Nc) + L[cand, 0])
         u = self.rng.random(len(cand))
@@ -366,6 +382,7 @@ class DPMMSampler:
         return touched
 
     def _grow(self, K2):
+        self._touch()
         K, D = self.K, self.prior.dim
         add = K2 - K
         self.N = np.concatenate([self.N, np.zeros((add, 3))])
@@ -383,6 +400,7 @@ class DPMMSampler:
         self.K = K2
 
     def _copy_row(self, dst, src):
+        self._touch()
         """Copy one distribution row (statistics, posterior, drawn parameters)."""
         kd, wd = divmod(dst, 3); ks, ws = divmod(src, 3)
         self.N[kd, wd] = self.N[ks, ws]; self.sums[kd, wd] = self.sums[ks, ws]
@@ -402,7 +420,7 @@ class DPMMSampler:
         ii, jj = np.triu_indices(len(ids), 1)
         pi, pj = ids[ii], ids[jj]                     # lexicographic (i<j) order
         Nf, sf, Sf = self._stats_flat()
-        Lc = self.prior.log_marginal(self.post, Nf).reshape(K, 3)[:, 0]
+        Lc = self._log_marginal_all().reshape(K, 3)[:, 0]
         t0 = time.perf_counter()
         if not self.leader_mode or self.is_leader:
             Lp = self.prior.log_marginal_pairs(np.stack([3 * pi, 3 * pj], 1), dict(N=Nf, sums=sf, S=Sf), nthreads=self.nthreads)
@@ -447,6 +465,7 @@ class DPMMSampler:
             self.points_count[j] = 0
             self.N[j, 0] = 0
             self.splittable[j] = False
+            self._touch()
         self._sync_small()
         self.wk.merge(np.asarray(m_i) + 1, np.asarray(m_j) + 1)
 
@@ -455,6 +474,7 @@ class DPMMSampler:
         keep = self.points_count > 0
         if keep.all():
             return
+        self._touch()
         self.wk.remove_empty(self.points_count)
         rows = self._rows(np.flatnonzero(keep))
         self.N = self.N[keep]; self.sums = self.sums[keep]
