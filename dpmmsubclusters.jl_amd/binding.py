@@ -87,6 +87,13 @@ def load_library():
             except Exception as e:
                 raise FileNotFoundError(f"{p} not built and building it failed ({e}): run __graft_entry__.build() "
                                         "(there is no CPU fallback)") from e
+        # PyTorch ships its own libamdhip64 under the same SONAME.  Whichever copy is mapped first serves BOTH users; if
+        # this library pulled in the system copy first, a later `import torch` (multi-GPU runs use torch.distributed)
+        # would find no GPUs.  Mapping torch's copy first keeps one consistent HIP runtime in the process.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover  (torch is optional for single-GPU use)
+            pass
         lib = ctypes.CDLL(p)
         for name, res, args in ABI:
             fn = getattr(lib, name)

@@ -393,7 +393,7 @@ int dpmm_set_params_niw_chol(dpmm_ctx *c, int K, const float *mu, const float *R
     // the pack kernel reads R and mu straight from the pinned staging buffer (no copy-engine transfer)
     HIPCHK(c, launch_copy_bytes(c->d_cst, hp + nR + nmu, sizeof(float) * ncst, c->stream));
     static const bool no_tail = getenv("DPMM_NIW_NO_TAIL") != nullptr;
-    c->have_tail = !no_tail && c->D >= 4 && c->D % 4 == 0 && c->D <= 64 && K > 2;
+    c->have_tail = !no_tail && c->D >= 4 && c->D % 4 == 0 && K > 2;
     HIPCHK(c, launch_niw_pack(hp, hp + nR, c->d_Rp, c->d_mup, c->D, c->NB, 3 * K, c->have_tail ? c->d_tail : nullptr, c->d_cst, c->stream));
     c->have_screen_prep = false;
     if (c->D > 16 && c->D <= 64 && K > 2) {

@@ -61,6 +61,32 @@ struct NiwCfg {
     static constexpr int MAXPASS = (MAXPAIRS + 3) / 4;
 };
 
+// ---------------------------------------------------------------------------------------
+// Tail screen (shared by both sweep kernels).  Rows D-4..D-1 of y = R z need the last four features only (R upper
+// triangular), so q >= |T_k (x_t - m_t)|^2 with the 4x4 tail factor T_k.  The 15 constants of a cluster
+// {T00 T01 T02 T03 | T11 T12 T13 T22 | T23 T33 m0 m1 | m2 m3 cst} are wave-uniform: read through the constant address
+// space they arrive by scalar loads in SGPRs.  Lane = point: `xt` holds the four tail features of the lane's point,
+// `thr` = reference value - margin (+inf for lanes without a point).
+struct TailRec { float v[16]; };
+__device__ __forceinline__ TailRec tail_load(const float *tail, int k) {
+    typedef const float __attribute__((address_space(4))) *cfp4;
+    const cfp4 P = (cfp4)(tail + (size_t)k * 16);
+    TailRec T;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) T.v[q] = P[q];
+    return T;
+}
+__device__ __forceinline__ bool tail_is_far(const TailRec &T, const f32x4 &xt, float thr) {
+    const float z0 = xt.x - T.v[10], z1 = xt.y - T.v[11], z2 = xt.z - T.v[12], z3 = xt.w - T.v[13];
+    const float y3 = T.v[9] * z3;
+    const float y2 = __builtin_fmaf(T.v[7], z2, T.v[8] * z3);
+    const float y1 = __builtin_fmaf(T.v[4], z1, __builtin_fmaf(T.v[5], z2, T.v[6] * z3));
+    const float y0 = __builtin_fmaf(T.v[0], z0, __builtin_fmaf(T.v[1], z1, __builtin_fmaf(T.v[2], z2, T.v[3] * z3)));
+    float q4 = y3 * y3;
+    q4 = __builtin_fmaf(y2, y2, q4); q4 = __builtin_fmaf(y1, y1, q4); q4 = __builtin_fmaf(y0, y0, q4);
+    return __ballot(__builtin_fmaf(-0.5f, q4, T.v[14]) < thr) == ~0ull;     // no branch: one basic block per candidate
+}
+
 template <int NB, int NG, int CH>
 struct QuadEval {
     using C = NiwCfg<NB, NG, CH>;
@@ -176,6 +202,8 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
     using C = NiwCfg<NB, NG, CH>;
     __shared__ __attribute__((aligned(16))) float lds[C::MAXPAIRS * 256];
     __shared__ uint32_t present[DPMM_MAX_CLUSTERS_K / 32];
+    __shared__ uint32_t survm[DPMM_MAX_CLUSTERS_K / 32];   // screened mode: clusters some wave of the workgroup could not exclude
+    __shared__ int sh_k0;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -209,14 +237,11 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
         float *scr = A.scratch + (A.scratch_by_tile ? tile * C::TILE : (int64_t)blockIdx.x * C::TILE) + wave * C::WPTS + lane;
         const int64_t sstride = A.scratch_stride;
 
-        // ---- phase 1: a_k for every cluster
+        // ---- phase 1: a_k for every cluster (or, screened, for the clusters that matter to this workgroup)
         float m_run = -INFINITY;
         int best = 0;
         bool nan_seen = false;
-        ev.template prefetch<0>(A.Rp);
-        for (int k = 0; k < K; ++k) {
-            const float *Rcur = A.Rp + (size_t)(3 * k) * C::MATSZ;
-            const float *Rnext = (k + 1 < K) ? A.Rp + (size_t)(3 * (k + 1)) * C::MATSZ : nullptr;
+        auto eval_cluster = [&](int k, const float *Rnext) {
             f32x4 mu[NB];
 #pragma unroll
             for (int t = 0; t < NB; ++t)
@@ -224,17 +249,86 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
             float q[NG];
 #pragma unroll
             for (int n = 0; n < NG; ++n) q[n] = 0.f;
-            eval_matrix<NB, NG, CH>(ev, lds, Rcur, Rnext, x, mu, q, lane, true);
+            eval_matrix<NB, NG, CH>(ev, lds, A.Rp + (size_t)(3 * k) * C::MATSZ, Rnext, x, mu, q, lane, true);
             const float qs = reduce_select<NG>(q, g);
             const float a = A.tdf ? A.cst[3 * k] - A.tdf[6 * k + 1] * log1pf(qs / A.tdf[6 * k])
                                   : __builtin_fmaf(-0.5f, qs, A.cst[3 * k]);
             if (valid) {
                 scr[(int64_t)k * sstride] = a;
                 if (a != a) {
-                    if (!nan_seen) { nan_seen = true; best = k; }  // Julia argmax: first NaN wins
-                } else {
-                    if (a > m_run) { m_run = a; if (!nan_seen) best = k; }
+                    if (!nan_seen || k < best) { nan_seen = true; best = k; }  // Julia argmax: first NaN wins
+                } else if (a > m_run || (a == m_run && k < best && !nan_seen && m_run != -INFINITY)) {
+                    m_run = a;
+                    if (!nan_seen) best = k;
                 }
+            }
+            return a;
+        };
+        const bool screening = A.tail != nullptr && A.screen_margin > 0.f && !A.tdf && !A.scratch_by_tile && K > 2;
+        int k0 = 0;
+        if (!screening) {
+            ev.template prefetch<0>(A.Rp);
+            for (int k = 0; k < K; ++k)
+                eval_cluster(k, (k + 1 < K) ? A.Rp + (size_t)(3 * (k + 1)) * C::MATSZ : nullptr);
+        } else {
+            // Screened label phase, workgroup-wide (the fragment staging is shared by the four waves):
+            //  (1) reference cluster k0 = previous label of the workgroup's first point, evaluated in full;
+            //  (2) every wave tail-screens all other clusters against its own points; a cluster is evaluated if ANY wave
+            //      could not exclude it (bit in survm); (3) survivors are evaluated in index order.
+            __syncthreads();                                   // survm / sh_k0 of the previous tile are no longer read
+            if (tid < DPMM_MAX_CLUSTERS_K / 32) survm[tid] = 0u;
+            if (wave == 0) {
+                int prev = (valid && A.use_prev) ? (A.bins[myp] >> 1) : -1;
+                if ((unsigned)prev >= (unsigned)K) prev = -1;
+                const unsigned long long pm = __ballot(prev >= 0);
+                int kk = 0;
+                if (pm) kk = __shfl(prev, __ffsll((long long)pm) - 1);
+                if (lane == 0) sh_k0 = kk;
+            }
+            __syncthreads();
+            k0 = sh_k0;
+            ev.template prefetch<0>(A.Rp + (size_t)(3 * k0) * C::MATSZ);
+            const float a0 = eval_cluster(k0, nullptr);
+            const float my_thr = valid ? a0 - A.screen_margin : INFINITY;
+            f32x4 xt = (f32x4){0.f, 0.f, 0.f, 0.f};
+            {
+                const int src = ci + 16 * A.tail_g;
+#pragma unroll
+                for (int n = 0; n < NG; ++n) {
+                    f32x4 v;
+                    v.x = __shfl(x[n][NB - 1].x, src); v.y = __shfl(x[n][NB - 1].y, src);
+                    v.z = __shfl(x[n][NB - 1].z, src); v.w = __shfl(x[n][NB - 1].w, src);
+                    if (g == n) xt = v;                        // owner lane 16 n + ci holds point (n, ci)
+                }
+            }
+            {
+                TailRec Tc = tail_load(A.tail, 0);
+                for (int k = 0; k < K; ++k) {
+                    const TailRec Tn = tail_load(A.tail, k + 1 < K ? k + 1 : k);
+                    if (k != k0 && !tail_is_far(Tc, xt, my_thr) && lane == 0) atomicOr(&survm[k >> 5], 1u << (k & 31));
+                    Tc = Tn;
+                }
+            }
+            __syncthreads();
+            const int nw = (K + 31) >> 5;
+            int w = 0;
+            uint32_t bits = __builtin_amdgcn_readfirstlane(survm[0]);
+            auto next_surv = [&]() -> int {
+                while (bits == 0u) {
+                    ++w;
+                    if (w >= nw) return -1;
+                    bits = __builtin_amdgcn_readfirstlane(survm[w]);
+                }
+                const int b = __builtin_ctz(bits);
+                bits &= bits - 1u;
+                return (w << 5) + b;
+            };
+            int kc = next_surv();
+            if (kc >= 0) ev.template prefetch<0>(A.Rp + (size_t)(3 * kc) * C::MATSZ);
+            while (kc >= 0) {
+                const int kn = next_surv();
+                eval_cluster(kc, kn >= 0 ? A.Rp + (size_t)(3 * kn) * C::MATSZ : nullptr);
+                kc = kn;
             }
         }
 
@@ -248,6 +342,28 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
                 z = best;
             } else if (m_run == -INFINITY) {
                 z = 0;
+            } else if (screening) {
+                // skipped clusters contribute exact zeros: visit the evaluated ones only, in index order (bit-identical
+                // to the full scan over a table holding -inf for them)
+                const int nw = (K + 31) >> 5;
+                float s = 0.f;
+                for (int w = 0; w < nw; ++w) {
+                    uint32_t bb = survm[w] | ((k0 >> 5) == w ? (1u << (k0 & 31)) : 0u);
+                    for (; bb; bb &= bb - 1u) s += exp_det(nan_to_ninf(scr[(int64_t)((w << 5) + __builtin_ctz(bb)) * sstride]) - m_run);
+                }
+                const float t = u01(r.v[0]) * s;
+                float cw = 0.f;
+                z = K - 1;
+                bool found = false;
+                for (int w = 0; w < nw && !found; ++w) {
+                    uint32_t bb = survm[w] | ((k0 >> 5) == w ? (1u << (k0 & 31)) : 0u);
+                    for (; bb; bb &= bb - 1u) {
+                        const int k = (w << 5) + __builtin_ctz(bb);
+                        cw += exp_det(nan_to_ninf(scr[(int64_t)k * sstride]) - m_run);
+                        if (!(cw < t)) { z = k; found = true; break; }
+                    }
+                }
+                if (t <= 0.f) z = 0;      // the full scan stops at k = 0 when the threshold is already met there
             } else {
                 float s = 0.f;
                 for (int k = 0; k < K; ++k) s += exp_det(nan_to_ninf(scr[(int64_t)k * sstride]) - m_run);
@@ -640,31 +756,6 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                 }
             }
             const float my_thr = valid ? my_best - A.screen_margin : INFINITY;
-            // the 16 constants of a cluster are wave-uniform: read through the constant address space they arrive by
-            // scalar loads in SGPRs (no VGPRs, no LDS), one cluster ahead of their use
-            typedef const float __attribute__((address_space(4))) *cfp4;
-            struct Tail { float v[16]; };
-            auto load_tail = [&](int k) -> Tail {
-                const cfp4 P = (cfp4)(A.tail + (size_t)k * 16);
-                Tail T;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) T.v[q] = P[q];
-                return T;
-            };
-            auto tail_far = [&](const Tail &T) -> bool {
-                const f32x4 t0 = (f32x4){T.v[0], T.v[1], T.v[2], T.v[3]}, t1 = (f32x4){T.v[4], T.v[5], T.v[6], T.v[7]};
-                const f32x4 t2 = (f32x4){T.v[8], T.v[9], T.v[10], T.v[11]}, t3 = (f32x4){T.v[12], T.v[13], T.v[14], T.v[15]};
-                const float c = t3.z;
-                const float z0 = xt.x - t2.z, z1 = xt.y - t2.w, z2 = xt.z - t3.x, z3 = xt.w - t3.y;
-                const float y3 = t2.y * z3;
-                const float y2 = __builtin_fmaf(t1.w, z2, t2.x * z3);
-                const float y1 = __builtin_fmaf(t1.x, z1, __builtin_fmaf(t1.y, z2, t1.z * z3));
-                const float y0 = __builtin_fmaf(t0.x, z0, __builtin_fmaf(t0.y, z1, __builtin_fmaf(t0.z, z2, t0.w * z3)));
-                float q4 = y3 * y3;
-                q4 = __builtin_fmaf(y2, y2, q4); q4 = __builtin_fmaf(y1, y1, q4); q4 = __builtin_fmaf(y0, y0, q4);
-                // lanes without a point carry my_thr = +inf: no branch, one basic block per candidate
-                return __ballot(__builtin_fmaf(-0.5f, q4, c) < my_thr) == ~0ull;
-            };
             // far mask: lane j owns cluster (chunk base + j).  The wave is reduced to its worst case first
             // (r_max = farthest point from mu_k0, best_min = lowest reference value), so one vector step tests 64 clusters:
             //   a_k(x) <= cst_k - lam_k/2 (||mu_k - mu_k0|| - r_max)_+^2  <  best_min - margin   for every point x of the wave.
@@ -757,14 +848,14 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                 f32x4 acc[NG];
                 if (tailscr) {
                     int k = pop();
-                    Tail Tc = load_tail(k >= 0 ? k : 0);
+                    TailRec Tc = tail_load(A.tail, k >= 0 ? k : 0);
                     while (k >= 0) {
                         const int kn = pop();
-                        const Tail Tn = load_tail(kn >= 0 ? kn : 0);
+                        const TailRec Tn = tail_load(A.tail, kn >= 0 ? kn : 0);
 #ifdef DPMM_STAMPS
                         ++N_tail;
 #endif
-                        if (!tail_far(Tc)) {
+                        if (!tail_is_far(Tc, xt, my_thr)) {
                             issue(k, acc);
                             finish(k, Tc.v[14], acc);
                         }
