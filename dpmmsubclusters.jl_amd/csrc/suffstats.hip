@@ -415,14 +415,33 @@ __global__ __launch_bounds__(256) void mult_stats_kernel(StatsArgs A) {
         double *slab = A.slabs + (int64_t)item * A.slab_stride;
         for (int d0 = 0; d0 < A.D; d0 += 256 * 4) {
             double s[4] = {0., 0., 0., 0.};
-            for (int p = 0; p < cnt; ++p) {
+            int dq[4];
+            bool okq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int d = d0 + q * 256 + threadIdx.x; okq[q] = d < A.D; dq[q] = okq[q] ? d : 0; }
+            // 8 points per trip, all 32 loads issued before the first add (unconditional, clamped column): the sums stay
+            // in point order, so the result is bit-identical to the one-point-at-a-time loop
+            int p = 0;
+            for (; p + 8 <= cnt; p += 8) {
+                float v[8][4];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float *xp = A.X + (int64_t)A.sb.perm[seg + p + u] * A.ldx;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[u][q] = xp[dq[q]];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) s[q] += (double)v[u][q];
+            }
+            for (; p < cnt; ++p) {
                 const float *xp = A.X + (int64_t)A.sb.perm[seg + p] * A.ldx;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int d = d0 + q * 256 + threadIdx.x;
-                    if (d < A.D) s[q] += (double)xp[d];
-                }
+                for (int q = 0; q < 4; ++q) s[q] += (double)xp[dq[q]];
             }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (!okq[q]) s[q] = 0.;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int d = d0 + q * 256 + threadIdx.x;
