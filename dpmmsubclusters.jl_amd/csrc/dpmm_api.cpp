@@ -509,10 +509,6 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
             a.order = (!table && c->have_perm && !no_order) ? c->sb.perm : nullptr;
             a.order_total = c->sb.perm_total;
         }
-        {
-            static const int stag = [] { const char *e = getenv("DPMM_NIW_STAGGER"); return e ? atoi(e) : 0; }();
-            if (stag > 0 && !table && c->NB <= 4) a.stagger_cycles_per_cluster = stag;   // cycles odd wave slots sleep at start
-        }
 #ifdef DPMM_STAMPS
         if (!g_dbg) { hipMalloc(&g_dbg, sizeof(unsigned long long) * 16 * 4 * 4096); hipMemset(g_dbg, 0, sizeof(unsigned long long) * 16 * 4 * 4096); }
         a.dbg = g_dbg;

@@ -32,8 +32,6 @@ struct NiwSweepArgs {
     uint64_t seed;
     uint32_t epoch;
     int final_argmax;
-    unsigned *tile_counter;   // zeroed before the launch: dynamic tile queue (null: static striding)
-    int stagger_cycles_per_cluster;
     float screen_margin;      // > 0: skip clusters whose a_k is provably below (reference - margin) for a whole wave (NIW, D in 17..64)
     const float *tail;        // [K][16] 4x4 tail factors + tail means of the cluster-level matrices (null: no VALU tail screen)
     int tail_g;               // row group (lane >> 4) whose x registers of the last block hold features D-4..D-1

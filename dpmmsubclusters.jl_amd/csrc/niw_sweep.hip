@@ -477,11 +477,7 @@ __device__ __forceinline__ float quad_stream(const float *__restrict__ Rm, const
                 const f32x4 a = cur[t - bi];
                 f32x4 zz[NG];
 #pragma unroll
-#ifdef DPMM_EXP_NOSUB
-                for (int n = 0; n < NG; ++n) zz[n] = x[n][t];
-#else
                 for (int n = 0; n < NG; ++n) zz[n] = x[n][t] - mu[t];
-#endif
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
 #pragma unroll
@@ -560,29 +556,14 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
         __syncthreads();
     }
 
-    // Waves that share a SIMD would otherwise run in lockstep (same program, same work) and idle the
-    // matrix pipe together during their draw / epilogue phases: odd hardware wave slots start half a
-    // tile late, and tiles are handed out dynamically so the late starters simply take fewer.
-    if (A.stagger_cycles_per_cluster > 0) {
-        const unsigned slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));  // HW_REG_HW_ID.WAVE_ID
-        if (slot & 1u) {
-            const int naps = A.stagger_cycles_per_cluster >> 13;     // here: total cycles to sleep
-            for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
-        }
-    }
-    auto next_tile = [&](int64_t prev) -> int64_t {
-        if (!A.tile_counter) return prev < 0 ? wave_id : prev + nwaves;
-        unsigned v = 0;
-        if (lane == 0) v = atomicAdd(A.tile_counter, 1u);
-        return (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)v);
-    };
+    // (A start stagger of the odd hardware wave slots and a dynamic tile queue were measured twice: no effect.)
     // Cross-tile prefetch (static tile schedule): while a tile is processed, the wave already fetches the NEXT
     // tile's point indices (order[]) and their previous labels (bins[]); the next tile then issues its X gather at
     // once instead of walking the dependent chain order -> X, order -> bins -> reference cluster -> fragments.
     // (Also touching the next tile's X lines to pull them into L2 was measured: no gain, +30 % HBM traffic.)
     int nx_p = -1, nx_bin = -1;
     int64_t nx_tile = -1;
-    for (int64_t tile = next_tile(-1); tile < nwtiles; tile = next_tile(tile)) {
+    for (int64_t tile = wave_id; tile < nwtiles; tile += nwaves) {
         const int64_t wbase = tile * WPTS;
         STAMP(s0);
         const int64_t mypos = wbase + lane;    // position in processing order
@@ -623,7 +604,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
         }
         const int64_t tnext = tile + nwaves;
         int pf_p = -1, pf_bin = -1;
-        if (!A.tile_counter && tnext < nwtiles) {
+        if (tnext < nwtiles) {
             const int64_t posn = tnext * WPTS + lane;
             if (owner && posn < A.n) pf_p = use_order ? A.order[posn] : (int)posn;
         }
@@ -728,11 +709,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
             STAMP(q0b);
             // the last row-block of the reference evaluation prefetches row-block 0 of k0's LEFT sub-cluster matrix:
             // on label-homogeneous waves that is the first matrix of the sub-label phase (rb0_mat tracks what rb0/mu hold)
-#ifdef DPMM_NO_P1
-            const float *Rl0 = nullptr;
-#else
             const float *Rl0 = A.labels_only ? nullptr : A.Rp + (size_t)(3 * k0 + 1) * MATSZ;
-#endif
             const float *ml0 = A.mup + (size_t)(3 * k0 + 1) * DP;
             full_eval(k0, k1 != k0 ? A.Rp + (size_t)(3 * k1) * MATSZ : Rl0, k1 != k0 ? A.mup + (size_t)(3 * k1) * DP : ml0);
             if (k1 != k0) full_eval(k1, Rl0, ml0);
@@ -994,7 +971,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
             kcur = knext;
         }
         if (valid) A.bins[myp] = 2 * z + draw2(b0, b1, u_sub);
-        nx_p = pf_p; nx_bin = pf_bin; nx_tile = (!A.tile_counter && tnext < nwtiles) ? tnext : -1;
+        nx_p = pf_p; nx_bin = pf_bin; nx_tile = tnext < nwtiles ? tnext : -1;
         STAMP(s4);
 #ifdef DPMM_STAMPS
         T_draw += s3 - s2; T_p2 += s4 - s3; T_tot += s4 - s0; T_x += s1 - s0; ++ntile;
