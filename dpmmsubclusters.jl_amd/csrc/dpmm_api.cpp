@@ -219,7 +219,11 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
     c->ntiles = (n_local + c->tile - 1) / c->tile;
     if (c->ntiles < c->sweep_grid) c->sweep_grid = (int)std::max<int64_t>(1, c->ntiles);
     // statistics work items: ~4 per resident wave slot (2 waves/SIMD) so the last round is not mostly empty
-    static const int64_t target_items = [] { const char *e = getenv("DPMM_STATS_ITEMS"); return e ? (int64_t)atoll(e) : (int64_t)8192; }();
+    // work items of the statistics pass: the NIW kernel hands every workgroup a contiguous RANGE of items, so finer items
+    // only improve the balance (ceil(items / groups) granularity) -- 16384 at D <= 64 (1.05 -> 0.85 ms at N = 1e7); slabs
+    // are allocated per item, which is why the large-D kernels (280 KB per slab at D = 256) stay at 8192
+    static const int64_t items_env = [] { const char *e = getenv("DPMM_STATS_ITEMS"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
+    const int64_t target_items = items_env > 0 ? items_env : ((c->prior == DPMM_PRIOR_NIW && c->D <= 64) ? 16384 : 8192);
     c->chunk = (int)std::max<int64_t>(256, ((n_local + target_items - 1) / target_items + 3) / 4 * 4);
     const size_t nalloc = (size_t)std::max<int64_t>(n_local, 1);
     CHK_CREATE(hipMalloc(&c->dX, sizeof(float) * nalloc * (size_t)c->ldx));

@@ -220,7 +220,9 @@ __device__ __forceinline__ void niw_stats_body(const StatsArgs &A, int seg, int 
     auto load_x = [&](const int (&pt)[U], float (&xf)[U][NBK]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const float *xrow = A.X + (int64_t)pt[u] * A.ldx;
+            int pv = pt[u];
+            asm volatile("" : "+v"(pv));     // opaque here: the widening of a freshly loaded index must not be hoisted to its load
+            const float *xrow = A.X + (int64_t)pv * A.ldx;
             if constexpr (NBK >= 4) {
 #pragma unroll
                 for (int c4 = 0; c4 < NBK / 4; ++c4) {
@@ -243,8 +245,12 @@ __device__ __forceinline__ void niw_stats_body(const StatsArgs &A, int seg, int 
     int pt_b[U], pt_c[U];
     float xa[U][NBK], xb[U][NBK], xc[DEEP ? U : 1][DEEP ? NBK : 1];
     auto step = [&](int bt, const float (&xu)[U][NBK], float (&xl)[U][NBK]) {
+        // scheduling fences keep the issue order idx -> x -> MFMAs: left alone, the scheduler hoists the next step's address
+        // arithmetic (which needs the newest indices) into this step and the wait for them drains the x loads as well
         load_idx(bt + AHEAD + 1, pt_c);
+        __builtin_amdgcn_sched_barrier(0);
         load_x(pt_b, xl);                          // batch bt + AHEAD
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const bool rowok = 4 * (bt * U + u) + g < cnt;
@@ -267,6 +273,7 @@ __device__ __forceinline__ void niw_stats_body(const StatsArgs &A, int seg, int 
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) pt_b[u] = pt_c[u];   // indices were issued before this step's x loads: no drain
+        __builtin_amdgcn_sched_barrier(0);
     };
     load_idx(0, pt_b);
     load_x(pt_b, xa);
@@ -274,10 +281,10 @@ __device__ __forceinline__ void niw_stats_body(const StatsArgs &A, int seg, int 
     if constexpr (DEEP) {
         load_x(pt_b, xb);
         load_idx(2, pt_b);
-        for (int bt = 0; bt < nbatch; bt += 3) {
+        for (int bt = 0; bt < nbatch; bt += 3) {     // steps beyond nbatch see masked rows: zero contribution, no branch
             step(bt, xa, xc);
-            if (bt + 1 < nbatch) step(bt + 1, xb, xa);
-            if (bt + 2 < nbatch) step(bt + 2, xc, xb);
+            step(bt + 1, xb, xa);
+            step(bt + 2, xc, xb);
         }
     } else {
         for (int bt = 0; bt < nbatch; bt += 2) {
