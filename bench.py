@@ -50,7 +50,7 @@ def cpu_baseline(host, X_local, D, K, sampler, budget_points):
     mu = p["mu"].astype(np.float32); invS = inv.reshape(3 * K, -1).astype(np.float32); logdet = p["logdet"].astype(np.float32)
     logw = np.log(sampler.weights); loglr = np.log(sampler.lr_weights)
     u0, u1 = orc.uniforms(1, 1, 0, 0, n)
-    cores = min(os.cpu_count() or 1, 64)
+    cores = max(1, min(host.native._cpu_budget(), 64))     # CPUs this process may really use (cgroup quota), not os.cpu_count()
     with threadpool_limits(limits=cores, user_api="blas"):
         orc.sweep_numpy_niw(Xs[:2000], D, mu, invS, logdet, logw, loglr, u0[:2000], u1[:2000])  # warm
         t0 = time.perf_counter()
@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--clusters", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=60000)
+    ap.add_argument("--cpu-sample", type=int, default=800000, help="points of the workload the CPU baseline is timed on (about 10 s of CPU work)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
