@@ -172,13 +172,13 @@ __global__ __launch_bounds__(256, (B_RBP <= 6 ? 2 : 1)) void mult_sweep_bf16_ker
         const int64_t wbase = tile * M_TILE + (int64_t)wave * 64;
         float *scr = A.scratch + (A.scratch_by_tile ? tile * M_TILE : (int64_t)blockIdx.x * M_TILE) + wave * 64;
         const int64_t sstride = A.scratch_stride;
-        const float *xp[M_NG];
+        const float *xp0[M_NG];
         bool pv[M_NG];
 #pragma unroll
         for (int n = 0; n < M_NG; ++n) {
             const int64_t p = wbase + 16 * n + ci;
             pv[n] = p < A.n;
-            xp[n] = A.X + (pv[n] ? p : 0) * A.ldx + 8 * g;
+            xp0[n] = A.X + (pv[n] ? p : 0) * A.ldx;          // row of a valid point (point 0 for the padding lanes)
         }
         for (int rb0 = 0; rb0 < NRB; rb0 += B_RBP) {
             const int nrb = min(B_RBP, NRB - rb0);
@@ -188,22 +188,29 @@ __global__ __launch_bounds__(256, (B_RBP <= 6 ? 2 : 1)) void mult_sweep_bf16_ker
             for (int rb = 0; rb < B_RBP; ++rb)
 #pragma unroll
                 for (int n = 0; n < M_NG; ++n) acc[rb][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            // chunk(ks) lives at Lp16 + (ks * NRB + rb0) * 768 words; the nrb row blocks of a pass are contiguous
-            u32x4 st[(B_RBP * 3 * 256 / 4 + 255) / 256];
+            // chunk(ks) lives at Lp16 + (ks * NRB + rb0) * 768 words; the nrb row blocks of a pass are contiguous.
+            // All loads are UNCONDITIONAL (clamped addresses / indices; masking happens when the values are consumed one
+            // k-step later): a conditional load compiles to a branch with `s_waitcnt vmcnt(0)` behind it.
+            // (Measured and dropped: 128-point tiles at three workgroups per CU and a two-k-step x prefetch -- both spill.)
+            constexpr int NST = (B_RBP * 3 * 256 / 4 + 255) / 256;
+            const int chunk_v4 = chunk_words / 4;
+            u32x4 st[NST];
             auto prefetch = [&](int ks) {
                 const u32x4 *src = reinterpret_cast<const u32x4 *>(Lp16 + ((size_t)ks * NRB + rb0) * 768);
 #pragma unroll
-                for (int p = 0; p < (B_RBP * 3 * 256 / 4 + 255) / 256; ++p) {
-                    const int i4 = p * 256 + tid;
-                    if (i4 * 4 < chunk_words) st[p] = src[i4];
-                }
+                for (int p = 0; p < NST; ++p) st[p] = src[min(p * 256 + tid, chunk_v4 - 1)];     // surplus threads re-read the last vector
+            };
+            auto commit = [&](uint32_t *buf) {
+#pragma unroll
+                for (int p = 0; p < NST; ++p) reinterpret_cast<u32x4 *>(buf)[min(p * 256 + tid, chunk_v4 - 1)] = st[p];   // ... and re-write it
             };
             auto loadx = [&](int ks, f32x4 (&xl)[M_NG], f32x4 (&xh)[M_NG]) {
                 const int e = 32 * ks + 8 * g;
+                const int el = e < A.ldx ? e : 0, eh = e + 4 < A.ldx ? e + 4 : 0;      // in-row offsets, always valid
 #pragma unroll
                 for (int n = 0; n < M_NG; ++n) {
-                    xl[n] = (pv[n] && e < A.ldx) ? *reinterpret_cast<const f32x4 *>(xp[n] + 32 * ks) : (f32x4){0.f, 0.f, 0.f, 0.f};
-                    xh[n] = (pv[n] && e + 4 < A.ldx) ? *reinterpret_cast<const f32x4 *>(xp[n] + 32 * ks + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    xl[n] = *reinterpret_cast<const f32x4 *>(xp0[n] + el);
+                    xh[n] = *reinterpret_cast<const f32x4 *>(xp0[n] + eh);
                 }
             };
             f32x4 xl[M_NG], xh[M_NG];
@@ -212,15 +219,16 @@ __global__ __launch_bounds__(256, (B_RBP <= 6 ? 2 : 1)) void mult_sweep_bf16_ker
             for (int ks = 0; ks < NKS; ++ks) {
                 uint32_t *buf = lds[ks & 1];
                 // the buffer being overwritten was last read two k-steps ago; one barrier per k-step suffices
-#pragma unroll
-                for (int p = 0; p < (B_RBP * 3 * 256 / 4 + 255) / 256; ++p) {
-                    const int i4 = p * 256 + tid;
-                    if (i4 * 4 < chunk_words) reinterpret_cast<u32x4 *>(buf)[i4] = st[p];
-                }
+                commit(buf);
                 __syncthreads();
                 u32x4 xb[M_NG];
+                {
+                    const int e = 32 * ks + 8 * g;
+                    const bool vl = e < A.ldx, vh = e + 4 < A.ldx;
+                    const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int n = 0; n < M_NG; ++n) xb[n] = pack_bf16x8(xl[n], xh[n]);
+                    for (int n = 0; n < M_NG; ++n) xb[n] = pack_bf16x8((pv[n] && vl) ? xl[n] : zero, (pv[n] && vh) ? xh[n] : zero);
+                }
                 if (ks + 1 < NKS) {
                     prefetch(ks + 1);
                     loadx(ks + 1, xl, xh);
