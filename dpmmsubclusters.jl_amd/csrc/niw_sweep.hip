@@ -451,20 +451,30 @@ __device__ __forceinline__ float quad_stream(const float *__restrict__ Rm, const
     float q[NG];
 #pragma unroll
     for (int n = 0; n < NG; ++n) q[n] = 0.f;
-    f32x4 cur[NB], mun[NB];
+    // Fragment schedule (everything is unrolled; F[] are SSA values, nothing is copied).  The MFMA time of a row-block
+    // shrinks with bi (NB - bi pairs) while the L2 latency of its fragments does not, so the later row-blocks are fetched
+    // earlier than "one ahead": rb1 during rb0, ALL remaining row-blocks during rb1, and row-block 0 / mu of the next
+    // matrix during the second-to-last row-block.
+    constexpr int NPF = NB * (NB + 1) / 2;
+    f32x4 F[NPF], nx0[NB], mun[NB];
 #pragma unroll
-    for (int t = 0; t < NB; ++t) { cur[t] = rb0[t]; mun[t] = mu[t]; }
+    for (int t = 0; t < NB; ++t) { F[t] = rb0[t]; nx0[t] = rb0[t]; mun[t] = mu[t]; }
+    auto load_rowblock = [&](int b) {
+#pragma unroll
+        for (int t = 0; t < NB - b; ++t)
+            F[pair_base<NB>(b) + t] = *reinterpret_cast<const f32x4 *>(Rm + (pair_base<NB>(b) + t) * 256 + lane * 4);
+    };
 #pragma unroll
     for (int bi = 0; bi < NB; ++bi) {
-        f32x4 nxt[NB];
-        if (bi + 1 < NB) {
+        if (bi == 0 && NB > 1) load_rowblock(1);
+        if (bi == 1) {
 #pragma unroll
-            for (int t = 0; t < NB - bi - 1; ++t)
-                nxt[t] = *reinterpret_cast<const f32x4 *>(Rm + (pair_base<NB>(bi + 1) + t) * 256 + lane * 4);
-        } else if (Rnext) {
+            for (int b = 2; b < NB; ++b) load_rowblock(b);
+        }
+        if (bi == (NB >= 2 ? NB - 2 : 0) && Rnext) {
 #pragma unroll
             for (int t = 0; t < NB; ++t) {
-                nxt[t] = *reinterpret_cast<const f32x4 *>(Rnext + t * 256 + lane * 4);
+                nx0[t] = *reinterpret_cast<const f32x4 *>(Rnext + t * 256 + lane * 4);
                 mun[t] = *reinterpret_cast<const f32x4 *>(mup_next + 16 * t + 4 * g);
             }
         }
@@ -474,7 +484,7 @@ __device__ __forceinline__ float quad_stream(const float *__restrict__ Rm, const
             for (int n = 0; n < NG; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = bi; t < NB; ++t) {
-                const f32x4 a = cur[t - bi];
+                const f32x4 a = F[pair_base<NB>(bi) + (t - bi)];
                 f32x4 zz[NG];
 #pragma unroll
                 for (int n = 0; n < NG; ++n) zz[n] = x[n][t] - mu[t];
@@ -493,11 +503,9 @@ __device__ __forceinline__ float quad_stream(const float *__restrict__ Rm, const
                 q[n] = __builtin_fmaf(acc[n][3], acc[n][3], q[n]);
             }
         }
-#pragma unroll
-        for (int t = 0; t < NB; ++t) cur[t] = nxt[t];
     }
 #pragma unroll
-    for (int t = 0; t < NB; ++t) { rb0[t] = cur[t]; mu[t] = mun[t]; }
+    for (int t = 0; t < NB; ++t) { rb0[t] = nx0[t]; mu[t] = mun[t]; }
     // Cross-lane sum over the 4 row groups g without leaving the matrix pipe: with A = ones,
     // D[i][c] = sum_g B[g][c], i.e. every lane of column c receives the column total.
     float sel = 0.f;
