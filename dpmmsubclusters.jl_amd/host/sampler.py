@@ -91,6 +91,7 @@ class DPMMSampler:
         self.K = 0
         self.timers = {}
         self._noise_job = None
+        self._executor = None
         self._gen = 0             # bumped whenever posteriors / statistics / K change: validates the log-marginal cache
         self._L_cache = None
         # Leader mode (multi-rank only): rank 0 alone runs the heavy host maths (posterior factorisations, parameter
@@ -153,15 +154,13 @@ class DPMMSampler:
         """Generate the standard-normal part of the NEXT parameter draws on a helper thread while the GPU sweeps."""
         if not hasattr(self.prior, "draw_noise") or (self.leader_mode and not self.is_leader):
             return
-        import threading
+        if self._executor is None:       # one persistent helper thread (creating a thread per sweep costs ~0.1 ms)
+            from concurrent.futures import ThreadPoolExecutor
+            self._executor = ThreadPoolExecutor(max_workers=1, thread_name_prefix="dpmm-noise")
         rows = 3 * (self.K + 4)          # head-room for clusters born from splits
-        job = dict(epoch=self.draw_epoch + 1, rows=rows, out=None)
-
-        def work():
-            job["out"] = self.prior.draw_noise(rows, self.seed, job["epoch"], nthreads=self.nthreads)
-
-        job["thread"] = threading.Thread(target=work, daemon=True)
-        job["thread"].start()
+        epoch = self.draw_epoch + 1
+        job = dict(epoch=epoch, rows=rows)
+        job["future"] = self._executor.submit(self.prior.draw_noise, rows, self.seed, epoch, nthreads=self.nthreads)
         self._noise_job = job
 
     def _touch(self):
@@ -179,10 +178,10 @@ class DPMMSampler:
         job, self._noise_job = self._noise_job, None
         if job is None:
             return None
-        job["thread"].join()
+        out = job["future"].result()
         if job["epoch"] != epoch or job["rows"] < rows:
             return None
-        return job["out"]
+        return out
 
     # ------------------------------------------------------------------ statistics (step 5)
     def update_suff_stats_posterior(self, ks=None):
