@@ -42,6 +42,7 @@ ABI = [
     ("dpmm_set_predictive_niw", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p]),
     ("dpmm_set_predictive_mult", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_f32p, _c_f32p]),
     ("dpmm_predict", ctypes.c_int, [ctypes.c_void_p, _c_f32p]),
+    ("dpmm_predict_points", ctypes.c_int, [ctypes.c_void_p, _c_i64p, _c_f32p]),
     ("dpmm_set_ground_truth", ctypes.c_int, [ctypes.c_void_p, _c_i64p, ctypes.c_int]),
     ("dpmm_contingency", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_i64p]),
     ("dpmm_bin_counts", ctypes.c_int, [ctypes.c_void_p, _c_i64p]),
@@ -251,22 +252,33 @@ class Worker:
             self._chk(self._lib.dpmm_reset_sublabels(self._h, _p(idx, _c_i64p), len(idx), epoch))
 
     # ---- prediction (posterior predictive table)
-    def predict_table_niw(self, m, R, logdet, df, weights):
+    def predict_table_niw(self, m, R, logdet, df, weights, points=False):
         K = len(weights)
         m, R, logdet, df, weights = map(_f32, (m, R, logdet, df, weights))
         assert m.shape == (K, self.D) and R.size == K * self.D * self.D
         self._chk(self._lib.dpmm_set_predictive_niw(self._h, K, _p(m, _c_f32p), _p(R, _c_f32p), _p(logdet, _c_f32p), _p(df, _c_f32p), _p(weights, _c_f32p)))
         self.K = K
+        if points:
+            return self._predict_points(K)
         out = np.empty((K, self.n), np.float32)
         self._chk(self._lib.dpmm_predict(self._h, _p(out, _c_f32p)))
         return out
 
-    def predict_table_mult(self, logp, weights):
+    supports_predict_points = True
+
+    def _predict_points(self, K):
+        lab = np.empty(self.n, np.int64); probs = np.empty((self.n, K), np.float32)
+        self._chk(self._lib.dpmm_predict_points(self._h, _p(lab, _c_i64p), _p(probs, _c_f32p)))
+        return lab, probs
+
+    def predict_table_mult(self, logp, weights, points=False):
         K = len(weights)
         logp, weights = _f32(logp), _f32(weights)
         assert logp.shape == (K, self.D)
         self._chk(self._lib.dpmm_set_predictive_mult(self._h, K, _p(logp, _c_f32p), _p(weights, _c_f32p)))
         self.K = K
+        if points:
+            return self._predict_points(K)
         out = np.empty((K, self.n), np.float32)
         self._chk(self._lib.dpmm_predict(self._h, _p(out, _c_f32p)))
         return out

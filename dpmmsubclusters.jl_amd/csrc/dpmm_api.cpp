@@ -595,6 +595,32 @@ int dpmm_predict(dpmm_ctx *c, float *parr) {
     return dpmm_debug_loglik(c, parr);
 }
 
+int dpmm_predict_points(dpmm_ctx *c, int64_t *labels, float *probs) {
+    if (!c || !labels) return DPMM_EINVAL;
+    if (!c->predictive) return fail(c, DPMM_ESTATE, "dpmm_predict_points needs dpmm_set_predictive_* first");
+    if (!c->have_points || !c->have_params) return fail(c, DPMM_ESTATE, "predict needs points and parameters");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n == 0) return DPMM_OK;
+    const int64_t stride = c->ntiles * c->tile;
+    const int rstep = (c->prior == DPMM_PRIOR_NIW) ? 1 : 3;       // Multinomial: rows 3k are the cluster-level rows
+    float *table = nullptr, *d_probs = nullptr;
+    int64_t *d_lab = nullptr;
+    HIPCHK(c, hipMalloc(&table, sizeof(float) * (size_t)(rstep * c->K) * (size_t)stride));
+    int rc = run_sweep(c, 0, 0, table, stride);
+    hipError_t e = hipSuccess;
+    if (rc == DPMM_OK) {
+        e = hipMalloc(&d_lab, sizeof(int64_t) * (size_t)c->n);
+        if (e == hipSuccess && probs) e = hipMalloc(&d_probs, sizeof(float) * (size_t)c->n * (size_t)c->K);
+        if (e == hipSuccess) e = launch_predict_finish(table, stride, rstep, c->n, c->K, d_lab, d_probs, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(labels, d_lab, sizeof(int64_t) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && probs) e = hipMemcpyAsync(probs, d_probs, sizeof(float) * (size_t)c->n * (size_t)c->K, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { c->err = std::string("dpmm_predict_points: ") + hipGetErrorString(e); rc = DPMM_EHIP; }
+    }
+    hipFree(table); hipFree(d_lab); hipFree(d_probs);
+    return rc;
+}
+
 int dpmm_debug_loglik(dpmm_ctx *c, float *out) {
     if (!c || !out) return DPMM_EINVAL;
     if (!c->have_points || !c->have_params) return fail(c, DPMM_ESTATE, "debug_loglik needs points and parameters");

@@ -84,6 +84,7 @@ hipError_t launch_smart_kmeans(const int32_t *bins, const double *proj, int64_t 
                                hipStream_t s);
 hipError_t launch_smart_assign(int32_t *bins, const double *proj, int64_t n, int k, double m_lo, double m_hi, hipStream_t s);
 int smart_groups();
+hipError_t launch_predict_finish(const float *table, int64_t stride, int rstep, int64_t n, int K, int64_t *labels, float *probs, hipStream_t s);
 hipError_t launch_ingest_rows(float *dst, int64_t ldx, const void *src, int is_f64, int64_t ld, int64_t rows, int D, int nan_to_zero,
                               hipStream_t s);
 hipError_t launch_copy_bytes(void *dst, const void *src, size_t bytes, hipStream_t s);

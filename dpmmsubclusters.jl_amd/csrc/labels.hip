@@ -260,6 +260,43 @@ hipError_t launch_smart_assign(int32_t *bins, const double *proj, int64_t n, int
 }
 int smart_groups() { return SMART_GROUPS; }
 
+// predict_points (src/local_clusters_actions.jl:23-40) finish on the device: row-wise argmax (Julia semantics: the first NaN wins,
+// else the first maximum), NaN -> -inf, subtract the row maximum, exp, divide by the row sum.  table[row(k)][i], row(k) = k * rstep.
+__global__ void predict_finish_kernel(const float *__restrict__ table, int64_t stride, int rstep, int64_t n, int K, int64_t *__restrict__ labels,
+                                      float *__restrict__ probs) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float m = -INFINITY;
+        int best = 0;
+        bool nan_seen = false;
+        for (int k = 0; k < K; ++k) {
+            const float a = table[(int64_t)k * rstep * stride + i];
+            if (a != a) {
+                if (!nan_seen) { nan_seen = true; best = k; }
+            } else if (a > m) {
+                m = a;
+                if (!nan_seen) best = k;
+            }
+        }
+        labels[i] = best + 1;
+        if (probs) {
+            float s = 0.f;
+            float *pr = probs + i * K;
+            for (int k = 0; k < K; ++k) {
+                float a = table[(int64_t)k * rstep * stride + i];
+                if (a != a) a = -INFINITY;
+                const float e = expf(a - m);
+                pr[k] = e;
+                s += e;
+            }
+            for (int k = 0; k < K; ++k) pr[k] = pr[k] / s;
+        }
+    }
+}
+hipError_t launch_predict_finish(const float *table, int64_t stride, int rstep, int64_t n, int K, int64_t *labels, float *probs, hipStream_t s) {
+    hipLaunchKernelGGL(predict_finish_kernel, dim3(grid_for(n)), dim3(256), 0, s, table, stride, rstep, n, K, labels, probs);
+    return hipGetLastError();
+}
+
 hipError_t launch_init_labels(int32_t *bins, int64_t n, int64_t first, int init_clusters, uint64_t seed, uint32_t epoch, hipStream_t s) {
     hipLaunchKernelGGL(init_labels_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, n, first, init_clusters, seed, epoch);
     return hipGetLastError();

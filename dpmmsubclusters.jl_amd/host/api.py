@@ -240,6 +240,8 @@ def predict(dp_model, data, device=None, worker_factory=None):
     wk = (worker_factory or binding.Worker)(s.prior.kind, D, n, first_index=0, device=dev, seed=0)
     try:
         wk.upload_points(X)
+        if getattr(wk, "supports_predict_points", False):     # argmax + normalisation on the device as well
+            return s.prior.predictive_table(wk, s.post, [3 * k for k in range(s.K)], w, points=True)
         parr = s.prior.predictive_table(wk, s.post, [3 * k for k in range(s.K)], w).T.astype(np.float32)   # (n, K)
     finally:
         wk.close()

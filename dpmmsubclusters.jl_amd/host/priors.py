@@ -133,7 +133,7 @@ class niw_hyperparams(distribution_hyper_params):
         return [mv_gaussian(params["mu"][r].copy(), sig[i].astype(np.float32), inv[i].astype(np.float32),
                             float(params["logdet"][r]), params["R"][r].copy()) for i, r in enumerate(rows)]
 
-    def predictive_table(self, worker, post, rows, weights):
+    def predictive_table(self, worker, post, rows, weights, points=False):
         """posterior_predictive! (niw.jl:68-76): MvTDist(nu-D+1, m, ((kappa+1)/(kappa (nu-D+1))) nu psi) per cluster;
         returns parr[k][i] = logpdf + log w_k from the GPU (Student-t mode of the sweep kernel)."""
         D = self.dim
@@ -143,6 +143,8 @@ class niw_hyperparams(distribution_hyper_params):
         Uinv = np.linalg.inv(U)                                # upper triangular: (nu psi)^-1 = Uinv' Uinv
         R = Uinv / np.sqrt(c)[:, None, None]                   # Sigma_t^-1 = R'R
         logdet = D * np.log(c) + 2 * np.log(np.einsum("kii->ki", U)).sum(1)
+        if points:
+            return worker.predict_table_niw(m, R.reshape(len(rows), -1), logdet, df, weights, points=True)
         return worker.predict_table_niw(m, R.reshape(len(rows), -1), logdet, df, weights)
 
     def posterior_hyperparams(self, post, row):
@@ -203,9 +205,11 @@ class multinomial_hyper(distribution_hyper_params):
     def distributions(self, params, rows):
         return [multinomial_dist(params["logp"][r].copy()) for r in rows]
 
-    def predictive_table(self, worker, post, rows, weights):
+    def predictive_table(self, worker, post, rows, weights, points=False):
         """posterior_predictive! (multinomial_prior.jl:45-48): log(alpha'/sum(alpha'))' x"""
         a = post["alpha"][rows].astype(np.float64)
+        if points:
+            return worker.predict_table_mult(np.log(a / a.sum(1, keepdims=True)), weights, points=True)
         return worker.predict_table_mult(np.log(a / a.sum(1, keepdims=True)), weights)
 
     def posterior_hyperparams(self, post, row):

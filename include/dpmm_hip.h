@@ -172,6 +172,10 @@ int dpmm_set_predictive_niw(dpmm_ctx *ctx, int K, const float *m, const float *R
                             const float *df, const float *weights);
 int dpmm_set_predictive_mult(dpmm_ctx *ctx, int K, const float *logp, const float *weights);
 int dpmm_predict(dpmm_ctx *ctx, float *parr);
+/* The rest of predict_points (src/local_clusters_actions.jl:33-40) on the device as well: labels[i] = row-wise argmax (Int64,
+ * 1-based; the first NaN wins as in Julia), probs[i*K + k] = exp(parr - rowmax) / rowsum with NaN -> -Inf (n_local x K,
+ * row-major; may be NULL).  Same table as dpmm_predict; only the labels and the normalised matrix cross the bus. */
+int dpmm_predict_points(dpmm_ctx *ctx, int64_t *labels, float *probs);
 
 /* Sub-cluster occupancy of the shard after a sweep: counts[2k] = #{label == k+1, sub == 1}, counts[2k+1] = #{..., sub == 2}
  * (Int64, [2K], summable across shards).  These are the N fields of the l / r statistics the reference reads in

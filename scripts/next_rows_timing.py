@@ -40,7 +40,7 @@ class M: pass
 m = M(); m.sampler = s
 Xp = np.ascontiguousarray(X[:10 ** 6].T)
 host.predict(m, Xp)
-out["predict_ms_1e6_points_K32 (upload + table + argmax/normalise on host)"] = best(lambda: host.predict(m, Xp), 3)
+out["predict_ms_1e6_points_K32 (context + upload + table + device finish + download)"] = best(lambda: host.predict(m, Xp), 3)
 # .npy ingestion on the device: Float64 rows with NaNs
 rows = X[:2 * 10 ** 6].astype(np.float64); rows[::1000, 3] = np.nan
 w2 = pkg.Worker(pkg.PRIOR_NIW, D, len(rows), device=0, seed=1)

@@ -127,3 +127,26 @@ def test_outlier_component_on_gpu(host):
     from test_outlier_cpu import run_outlier_fit, check_outlier_result
     r, out = run_outlier_fit(host)
     check_outlier_result(r, out)
+
+
+def test_predict_device_finish_equals_host_finish(host, pkg=None):
+    """dpmm_predict_points (argmax + normalisation on the GPU) against the same steps done on the host from dpmm_predict's table."""
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    x, y, _, _ = host.generate_gaussian_data(7001, 6, 5, 60.0, seed=11)
+    res = host.fit(x, 10.0, iters=30, burnout=5, seed=5, verbose=False)
+    s = res[-1].sampler
+    w = s.points_count.astype(np.float64) + s.alpha
+    w = (w / w.sum()).astype(np.float32)
+    X = np.ascontiguousarray(x.T.astype(np.float32))
+    wk = pkg.Worker(s.prior.kind, X.shape[1], X.shape[0], device=0, seed=0)
+    wk.upload_points(X)
+    rows = [3 * k for k in range(s.K)]
+    tab = s.prior.predictive_table(wk, s.post, rows, w).T.astype(np.float32)           # (n, K), host finish below
+    lab_d, probs_d = s.prior.predictive_table(wk, s.post, rows, w, points=True)
+    wk.close()
+    lab_h = tab.argmax(1) + 1
+    p = np.exp(tab - tab.max(1, keepdims=True)); p /= p.sum(1, keepdims=True)
+    assert np.array_equal(lab_d, lab_h)
+    np.testing.assert_allclose(probs_d, p, rtol=2e-6, atol=1e-7)
+    assert probs_d.shape == (X.shape[0], s.K) and lab_d.dtype == np.int64
