@@ -1,0 +1,125 @@
+"""Size-independent properties at BASELINE.json's full sizes (C3 per-node size N = 10^7, D = 64 NIW; C4 N = 10^6, D = 1000
+Multinomial): the oracle cannot run these sizes in seconds, so the checks are invariants of the path itself --
+conservation of counts and moments, shard invariance, bitwise reproducibility, idempotence of the relabel operations."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    from __graft_entry__ import load_package
+    return load_package()
+
+
+@pytest.fixture(scope="module")
+def host(pkg):
+    import importlib
+    return importlib.import_module("dpmmsubclusters_jl_amd.host")
+
+
+def _niw_params(host, X, y, K, D, seed):
+    """One posterior draw per true component (cluster and both sub-clusters), as a sweep would see them."""
+    prior = host.niw_hyperparams(1.0, np.zeros(D), D + 3, np.eye(D))
+    rng = np.random.default_rng(seed)
+    idx = rng.choice(len(X), 200000, replace=False)
+    N = np.zeros(3 * K); sums = np.zeros((3 * K, D)); S = np.zeros((3 * K, D, D))
+    for k in range(K):
+        pts = X[idx][y[idx] == k + 1].astype(np.float64)
+        for w in range(3):
+            sel = pts if w == 0 else pts[w - 1::2]
+            N[3 * k + w] = len(sel); sums[3 * k + w] = sel.sum(0); S[3 * k + w] = sel.T @ sel
+    post = prior.posterior(N, sums, S, nthreads=8)
+    par = prior.sample(post, 7, 1, np.arange(3 * K), nthreads=8)
+    return prior, par
+
+
+def test_c3_full_size_niw_properties(pkg, host):
+    N, D, K = 10 ** 7, 64, 32
+    X, y = host.gaussian_mixture_shard(N, D, K, 100.0, 12345, 0, N)
+    prior, par = _niw_params(host, X, y, K, D, 3)
+    lr = np.full((K, 2), 0.5, np.float32); w = np.full(K, 1.0 / K, np.float32)
+    sub0 = 1 + (np.arange(N) & 1)
+
+    def run(lo, hi, seed=99):
+        wk = pkg.Worker(pkg.PRIOR_NIW, D, hi - lo, first_index=lo, device=0, seed=seed)
+        wk.upload_points(X[lo:hi])
+        wk.set_labels(y[lo:hi], sub0[lo:hi])
+        prior.upload(wk, par, lr, w)
+        wk.sweep(5)
+        lab, sub = wk.get_labels()
+        packed = wk.suffstats_packed(None)
+        return wk, lab, sub, packed
+
+    wk, lab, sub, packed = run(0, N)
+    assert lab.min() >= 1 and lab.max() <= K and set(np.unique(sub)) <= {1, 2}
+    assert (lab == y).mean() > 0.999                              # well separated data: the sweep keeps the components
+    Nk, sums, S = wk.unpack(packed, K)
+    # conservation: counts exactly, first and second moments against an independent Float64 pass over X
+    assert Nk[:, 0].sum() == N and np.array_equal(Nk[:, 0], Nk[:, 1] + Nk[:, 2])
+    assert np.array_equal(Nk[:, 0], np.bincount(lab, minlength=K + 1)[1:])
+    col = np.zeros(D); sq = 0.0
+    for a in range(0, N, 10 ** 6):
+        blk = X[a:a + 10 ** 6].astype(np.float64)
+        col += blk.sum(0); sq += float((blk * blk).sum())
+    np.testing.assert_allclose(sums[:, 0].sum(0), col, rtol=1e-10, atol=1e-6)
+    np.testing.assert_allclose(np.trace(S[:, 0].sum(0)), sq, rtol=1e-10)
+    assert np.allclose(S[:, 0], np.transpose(S[:, 0], (0, 2, 1)))
+    # bitwise reproducibility of labels and statistics (no atomics, fixed reduction order)
+    wk.set_labels(y, sub0); wk.sweep(5)
+    lab2, sub2 = wk.get_labels()
+    assert np.array_equal(lab, lab2) and np.array_equal(sub, sub2)
+    assert np.array_equal(wk.suffstats_packed(None), packed)
+    # idempotence of the relabel operations
+    counts = Nk[:, 0].astype(np.int64)
+    wk.remove_empty(counts)                                       # nothing is empty: labels must not move
+    assert np.array_equal(wk.get_labels()[0], lab)
+    wk.merge(np.array([1]), np.array([2])); wk.set_num_clusters(K)
+    lm, sm = wk.get_labels()
+    assert (lm == 2).sum() == 0 and (lm == 1).sum() == counts[0] + counts[1]
+    assert np.array_equal(sm[lab == 1], np.ones((lab == 1).sum(), np.int64)) and np.array_equal(sm[lab == 2], np.full((lab == 2).sum(), 2))
+    wk.close()
+    # shard invariance at full size: two shards (as two ranks would hold them) give the same labels and the same total statistics
+    h = N // 2 + 12345
+    wa, la, sa, pa = run(0, h)
+    wb, lb, sb, pb = run(h, N)
+    assert np.array_equal(np.concatenate([la, lb]), lab) and np.array_equal(np.concatenate([sa, sb]), sub)
+    Na, suma, Sa = wa.unpack(pa, K); Nb, sumb, Sb = wb.unpack(pb, K)
+    assert np.array_equal(Na + Nb, Nk)
+    np.testing.assert_allclose(suma + sumb, sums, rtol=1e-12, atol=1e-7)
+    np.testing.assert_allclose(Sa + Sb, S, rtol=1e-12, atol=1e-6)
+    wa.close(); wb.close()
+
+
+def test_c4_full_size_multinomial_properties(pkg, host):
+    N, D, K = 10 ** 6, 1000, 32
+    rng = np.random.default_rng(4)
+    P = rng.dirichlet(np.ones(D) * 0.5, size=K)
+    z = rng.integers(0, K, N)
+    X = np.empty((N, D), np.float32)
+    for k in range(K):
+        m = z == k
+        X[m] = rng.multinomial(100, P[k], size=int(m.sum()))
+    logp = np.log(np.maximum(np.repeat(P, 3, axis=0), 1e-30)).astype(np.float32)
+    wk = pkg.Worker(pkg.PRIOR_MULT, D, N, device=0, seed=5)
+    wk.upload_points(X)
+    wk.set_params_mult(logp, np.full((K, 2), 0.5, np.float32), np.full(K, 1.0 / K, np.float32))
+    wk.init_labels(K, 1)
+    wk.sweep(2)
+    lab, sub = wk.get_labels()
+    assert (lab == z + 1).mean() > 0.999 and set(np.unique(sub)) <= {1, 2}
+    Nk, sums = wk.unpack(wk.suffstats_packed(None), K)[:2]
+    assert Nk[:, 0].sum() == N and np.array_equal(Nk[:, 0], np.bincount(lab, minlength=K + 1)[1:])
+    assert np.array_equal(sums[:, 0].sum(1), 100.0 * Nk[:, 0])              # every document has exactly 100 words: exact in Float64
+    assert np.array_equal(sums[:, 0].sum(0), X.astype(np.float64).sum(0))   # counts are integers: exact
+    wk.sweep(2)
+    lab2, _ = wk.get_labels()
+    assert (lab2 == lab).mean() > 0.999                                      # same epoch, same parameters: the labels stay with their components
+    wk.close()
