@@ -312,3 +312,24 @@ def test_large_k_global_table_path(pkg):
     u0, _ = orc.uniforms(3, 2, 0, 0, 4000)
     assert np.array_equal(orc.sample_log_cat(tab, u0), lab)
     wk.close()
+
+
+def test_maximum_cluster_count(pkg):
+    """K = DPMM_MAX_CLUSTERS (1024): far-mask chunks of 64, 32 words of screening bits, 2048 statistic bins; one more is refused."""
+    K = 1024
+    P = make_problem(32, 5000, K, seed=5, sep=2.0)
+    wk = gpu_worker(pkg, P, seed=4)
+    wk.set_labels(P["z"] + 1, 1 + (np.arange(5000) & 1))
+    wk.sweep(3)
+    lab, sub = wk.get_labels()
+    assert lab.min() >= 1 and lab.max() <= K
+    tab = wk.debug_loglik()
+    u0, _ = orc.uniforms(4, 3, 0, 0, 5000)
+    assert np.array_equal(orc.sample_log_cat(tab, u0), lab)
+    N, sums, S = wk.suffstats()
+    assert N[:, 0].sum() == 5000 and np.array_equal(N[:, 0], np.bincount(lab, minlength=K + 1)[1:])
+    cnt = wk.bin_counts()
+    assert np.array_equal(cnt[:, 0], N[:, 1]) and np.array_equal(cnt[:, 1], N[:, 2])
+    with pytest.raises(pkg.DpmmError):
+        wk.set_num_clusters(K + 1)
+    wk.close()
