@@ -1,3 +1,4 @@
+"""Dev helper: does `import torch` still find the GPU after this library initialised HIP? (libamdhip64 load order, see binding.load_library)"""
 import sys
 sys.path.insert(0, ".")
 from __graft_entry__ import load_package

@@ -1,3 +1,4 @@
+"""Dev helper: single- and multi-thread timings of the native host maths (posterior, noise, parameter draws, merge pairs) at K=32, D=64."""
 import sys, time, importlib
 import numpy as np
 sys.path.insert(0, ".")
