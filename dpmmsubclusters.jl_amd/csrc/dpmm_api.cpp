@@ -154,7 +154,7 @@ static int ensure_capacity(dpmm_ctx *c, int K) {
         HIPCHK(c, hipMalloc(&c->d_Rp, sizeof(float) * 3 * cap * NP * 256));
         HIPCHK(c, hipMalloc(&c->d_mup, sizeof(float) * 3 * cap * 16 * c->NB));
         HIPCHK(c, hipMalloc(&c->d_lam, sizeof(float) * cap));
-        HIPCHK(c, hipMalloc(&c->d_tail, sizeof(float) * 16 * cap));
+        HIPCHK(c, hipMalloc(&c->d_tail, sizeof(float) * 16 * (cap + 1)));
         HIPCHK(c, hipMalloc(&c->d_mdist, sizeof(float) * (size_t)cap * cap));
     } else {
         const size_t NT = (size_t)(c->ldx + 15) / 16, NRB = (size_t)(3 * cap + 15) / 16;

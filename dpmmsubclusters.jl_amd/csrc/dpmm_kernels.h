@@ -33,7 +33,7 @@ struct NiwSweepArgs {
     uint32_t epoch;
     int final_argmax;
     float screen_margin;      // > 0: skip clusters whose a_k is provably below (reference - margin) for a whole wave (NIW, D in 17..64)
-    const float *tail;        // [K][16] 4x4 tail factors + tail means of the cluster-level matrices (null: no VALU tail screen)
+    const float *tail;        // [ceil(K/2)][16][2] tail-screen records of the cluster-level matrices, pairs interleaved (null: no tail screen)
     int tail_g;               // row group (lane >> 4) whose x registers of the last block hold features D-4..D-1
     const float *lam;         // [K] lower bounds of lambda_min(Sigma_k^-1) (null: no scalar pre-screen)
     const float *mdist;       // [K][K] distances between the cluster means

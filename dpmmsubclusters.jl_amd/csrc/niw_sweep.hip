@@ -67,24 +67,36 @@ struct NiwCfg {
 // {T00 T01 T02 T03 | T11 T12 T13 T22 | T23 T33 m0 m1 | m2 m3 cst} are wave-uniform: read through the constant address
 // space they arrive by scalar loads in SGPRs.  Lane = point: `xt` holds the four tail features of the lane's point,
 // `thr` = reference value - margin (+inf for lanes without a point).
-struct TailRec { float v[16]; };
-__device__ __forceinline__ TailRec tail_load(const float *tail, int k) {
+// Records are stored for PAIRS of clusters, element i of clusters 2p and 2p+1 side by side ([pair][16][2]): one packed-f32
+// instruction (v_pk_*) then serves both clusters.  Instruction count is what matters here: a wave that shares its SIMD with
+// an MFMA-streaming wave issues about one instruction per two MFMAs (scripts/microbench/issue_overlap.hip), so the phases of
+// the two resident waves do not overlap -- every VALU / SALU instruction saved is ~5 cycles of SIMD time.  For the same
+// reason the next record is NOT prefetched (it would cost 32 more SGPRs, i.e. copies or spills): while this wave waits for
+// its scalar load the other wave runs.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct TailPair { f32x2 v[16]; };
+__device__ __forceinline__ TailPair tail_load_pair(const float *tail, int pair) {
     typedef const float __attribute__((address_space(4))) *cfp4;
-    const cfp4 P = (cfp4)(tail + (size_t)k * 16);
-    TailRec T;
+    const cfp4 P = (cfp4)(tail + (size_t)pair * 32);
+    TailPair T;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) T.v[q] = P[q];
+    for (int q = 0; q < 16; ++q) T.v[q] = (f32x2){P[2 * q], P[2 * q + 1]};
     return T;
 }
-__device__ __forceinline__ bool tail_is_far(const TailRec &T, const f32x4 &xt, float thr) {
-    const float z0 = xt.x - T.v[10], z1 = xt.y - T.v[11], z2 = xt.z - T.v[12], z3 = xt.w - T.v[13];
-    const float y3 = T.v[9] * z3;
-    const float y2 = __builtin_fmaf(T.v[7], z2, T.v[8] * z3);
-    const float y1 = __builtin_fmaf(T.v[4], z1, __builtin_fmaf(T.v[5], z2, T.v[6] * z3));
-    const float y0 = __builtin_fmaf(T.v[0], z0, __builtin_fmaf(T.v[1], z1, __builtin_fmaf(T.v[2], z2, T.v[3] * z3)));
-    float q4 = y3 * y3;
-    q4 = __builtin_fmaf(y2, y2, q4); q4 = __builtin_fmaf(y1, y1, q4); q4 = __builtin_fmaf(y0, y0, q4);
-    return __ballot(__builtin_fmaf(-0.5f, q4, T.v[14]) < thr) == ~0ull;     // no branch: one basic block per candidate
+// bit 0 / bit 1: cluster 2p / 2p+1 is below `thr` for every lane of the wave (lanes without a point carry thr = +inf)
+__device__ __forceinline__ unsigned tail_pair_far(const TailPair &T, const f32x4 &xt, float thr) {
+    const f32x2 x0 = (f32x2){xt.x, xt.x}, x1 = (f32x2){xt.y, xt.y}, x2 = (f32x2){xt.z, xt.z}, x3 = (f32x2){xt.w, xt.w};
+    const f32x2 z0 = x0 - T.v[10], z1 = x1 - T.v[11], z2 = x2 - T.v[12], z3 = x3 - T.v[13];
+    const f32x2 y3 = T.v[9] * z3;
+    const f32x2 y2 = __builtin_elementwise_fma(T.v[7], z2, T.v[8] * z3);
+    const f32x2 y1 = __builtin_elementwise_fma(T.v[4], z1, __builtin_elementwise_fma(T.v[5], z2, T.v[6] * z3));
+    const f32x2 y0 = __builtin_elementwise_fma(T.v[0], z0, __builtin_elementwise_fma(T.v[1], z1, __builtin_elementwise_fma(T.v[2], z2, T.v[3] * z3)));
+    f32x2 q4 = y3 * y3;
+    q4 = __builtin_elementwise_fma(y2, y2, q4); q4 = __builtin_elementwise_fma(y1, y1, q4); q4 = __builtin_elementwise_fma(y0, y0, q4);
+    const f32x2 ub = __builtin_elementwise_fma((f32x2){-0.5f, -0.5f}, q4, T.v[14]);
+    const unsigned fa = (__ballot(ub.x < thr) == ~0ull) ? 1u : 0u;
+    const unsigned fb = (__ballot(ub.y < thr) == ~0ull) ? 2u : 0u;
+    return fa | fb;
 }
 
 template <int NB, int NG, int CH>
@@ -301,12 +313,12 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
                     if (g == n) xt = v;                        // owner lane 16 n + ci holds point (n, ci)
                 }
             }
-            {
-                TailRec Tc = tail_load(A.tail, 0);
-                for (int k = 0; k < K; ++k) {
-                    const TailRec Tn = tail_load(A.tail, k + 1 < K ? k + 1 : k);
-                    if (k != k0 && !tail_is_far(Tc, xt, my_thr) && lane == 0) atomicOr(&survm[k >> 5], 1u << (k & 31));
-                    Tc = Tn;
+            for (int pr = 0; 2 * pr < K; ++pr) {
+                const unsigned far2 = tail_pair_far(tail_load_pair(A.tail, pr), xt, my_thr);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int k = 2 * pr + c;
+                    if (k < K && k != k0 && !((far2 >> c) & 1u) && lane == 0) atomicOr(&survm[k >> 5], 1u << (k & 31));
                 }
             }
             __syncthreads();
@@ -832,20 +844,20 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                 };
                 f32x4 acc[NG];
                 if (tailscr) {
-                    int k = pop();
-                    TailRec Tc = tail_load(A.tail, k >= 0 ? k : 0);
-                    while (k >= 0) {
-                        const int kn = pop();
-                        const TailRec Tn = tail_load(A.tail, kn >= 0 ? kn : 0);
+                    // pairs (2p, 2p+1) of the chunk that still hold a candidate; far clusters lose their candidate bit
+                    const int p0 = base >> 1, p1 = (min(K, base + 64) + 1) >> 1;
+                    for (int pr = p0; pr < p1; ++pr) {
+                        const int sh = 2 * pr - base;
+                        const unsigned bits2 = (unsigned)(cand >> sh) & 3u;
+                        if (!bits2) continue;
 #ifdef DPMM_STAMPS
-                        ++N_tail;
+                        N_tail += __builtin_popcount(bits2);
 #endif
-                        if (!tail_is_far(Tc, xt, my_thr)) {
-                            issue(k, acc);
-                            finish(k, Tc.v[14], acc);
-                        }
-                        k = kn;
-                        Tc = Tn;
+                        cand &= ~((unsigned long long)tail_pair_far(tail_load_pair(A.tail, pr), xt, my_thr) << sh);
+                    }
+                    for (int k = pop(); k >= 0; k = pop()) {
+                        issue(k, acc);
+                        finish(k, cst_of(k), acc);
                     }
                 } else {
                     for (int k = pop(); k >= 0; k = pop()) {
@@ -1092,16 +1104,18 @@ __global__ void niw_pack_kernel(const float *__restrict__ R, const float *__rest
         const int j = (int)(e / DP);
         mup[e] = d < D ? mu[(size_t)j * D + d] : 0.f;
     }
-    // tail[k] = { T00 T01 T02 T03 | T11 T12 T13 T22 | T23 T33 m0 m1 | m2 m3 cst_k 0 } of the cluster-level matrix 3k,
-    // T = R[D-4:D, D-4:D], m = mu[D-4:D]
+    // Tail records of the cluster-level matrices 3k, stored for cluster PAIRS: tail[pair][q][c], c = 0 / 1 for cluster 2 pair + c,
+    // q = { T00 T01 T02 T03 | T11 T12 T13 T22 | T23 T33 m0 m1 | m2 m3 cst_k 0 },  T = R[D-4:D, D-4:D], m = mu[D-4:D].
+    // A padding cluster (odd K) gets cst = -inf: it is "far" for everybody and its candidate bit does not exist anyway.
     if (tail && D >= 4) {
-        const int f0 = D - 4;
-        for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)(nmat / 3) * 16; e += (int64_t)gridDim.x * blockDim.x) {
-            const int q = (int)(e & 15);
-            const size_t j = (size_t)(3 * (e >> 4));
+        const int f0 = D - 4, K = nmat / 3, NPR = (K + 1) / 2;
+        for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)NPR * 32; e += (int64_t)gridDim.x * blockDim.x) {
+            const int c = (int)(e & 1), q = (int)((e >> 1) & 15), k = 2 * (int)(e >> 5) + c;
+            const size_t j = (size_t)(3 * k);
             const int tr[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3}, tc[10] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3};
             float v = 0.f;
-            if (q < 10) v = R[(j * D + f0 + tr[q]) * D + f0 + tc[q]];
+            if (k >= K) v = (q == 14) ? -INFINITY : 0.f;
+            else if (q < 10) v = R[(j * D + f0 + tr[q]) * D + f0 + tc[q]];
             else if (q < 14) v = mu[j * D + f0 + (q - 10)];
             else if (q == 14) v = cst[j];
             tail[e] = v;
