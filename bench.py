@@ -30,10 +30,10 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense FP32 matrix peak (no TF32/xf32 on gfx950)
 # PMC figures of the D=64 sweep kernel at the bench workload (separate rocprofv3 --pmc passes, medians over launches,
-# profiles/r01c_bench_niw_d64_n1e7_pmc.json), per point so that they scale with the shard size:
-#   HBM bytes: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE -> (2*1318148.375 + 81429.0) KiB / 1e7 points
+# profiles/r01e_bench_niw_d64_n1e7_pmc.json), per point so that they scale with the shard size:
+#   HBM bytes: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE -> (2*1318072.3125 + 81211.0) KiB / 1e7 points
 #   executed matrix flops: SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 -> 314696656 x 512 / 1e7 points (K = 32 clusters)
-PMC_BYTES_PER_POINT_D64 = (2 * 1318148.375 + 81429.0) * 1024 / 1e7
+PMC_BYTES_PER_POINT_D64 = (2 * 1318072.3125 + 81211.0) * 1024 / 1e7
 PMC_EXECUTED_FLOPS_PER_POINT_D64_K32 = 314696656.0 * 512 / 1e7
 
 
