@@ -355,10 +355,12 @@ static int niw_sample_impl(int n, int D, const double *kappa, const double *nu, 
     {
         const size_t DD = (size_t)D * D;
         std::vector<std::vector<double>> scratch(nthreads, std::vector<double>(2 * DD + 3 * (size_t)D));
+        std::vector<std::vector<double>> blk(nthreads, std::vector<double>(8 * (size_t)D));
         Pool::get().run(n, nthreads, [&](int i, int slot) {
             struct V { double *p; double *data() { return p; } double &operator[](size_t e) { return p[e]; } };
             double *base = scratch[slot].data();
             V A{base}, Rl{base + DD}, a{base + 2 * DD}, xi{base + 2 * DD + D}, v{base + 2 * DD + 2 * D};
+            (void)a;
             // normals: stream 16 (identical whether pre-generated or not); chi-squares: stream 18
             Philox rng(seed, (uint32_t)ids[i], epoch, 16u), rng_chi(seed, (uint32_t)ids[i], epoch, 18u);
             const double *Ui = U + (size_t)i * D * D;
@@ -369,20 +371,37 @@ static int niw_sample_impl(int n, int D, const double *kappa, const double *nu, 
                 A[(size_t)r * D + r] = sqrt(2.0 * rng_chi.gamma(0.5 * (nu[i] - r)));
             }
             // R = A' U^-1 : row j of R solves r_j U[j:, j:] = A[j:, j]'
+            // JB rows of R at a time share every pass over a row of U (at D = 256 U is 512 KiB: one row of R per pass was
+            // bound by streaming U from L2).  Per row the operations and their order are those of the one-row loop: same bits.
             memset(Rl.data(), 0, sizeof(double) * DD);
             double ld = 0.0;
-            for (int j = 0; j < D; ++j) {
-                for (int r = j; r < D; ++r) a[r] = A[(size_t)r * D + j];
-                double *rj = Rl.data() + (size_t)j * D;
-                for (int c = j; c < D; ++c) {
-                    const double *uc = Ui + (size_t)c * D;
-                    const double val = a[c] / uc[c];
-                    rj[c] = val;
-                    double *ap = a.data();
-#pragma omp simd
-                    for (int cc = c + 1; cc < D; ++cc) ap[cc] -= val * uc[cc];
+            constexpr int JB = 8;
+            for (int j0 = 0; j0 < D; j0 += JB) {
+                const int nb = std::min(JB, D - j0);
+                double *ab = blk[slot].data();                        // [JB][D], row jb = column j0 + jb of A (zero above the diagonal)
+                for (int jb = 0; jb < nb; ++jb) {
+                    double *ar = ab + (size_t)jb * D;
+                    for (int r = 0; r < j0 + jb; ++r) ar[r] = 0.0;
+                    for (int r = j0 + jb; r < D; ++r) ar[r] = A[(size_t)r * D + j0 + jb];
                 }
-                ld += log(rj[j]);
+                for (int c = j0; c < D; ++c) {
+                    const double *uc = Ui + (size_t)c * D;
+                    const double ucc = uc[c];
+                    double val[JB];
+                    for (int jb = 0; jb < nb; ++jb) {
+                        // rows that have not started yet (c < j0 + jb) hold 0 here: val = 0 and the update below is a no-op
+                        val[jb] = (c >= j0 + jb) ? ab[(size_t)jb * D + c] / ucc : 0.0;
+                        if (c >= j0 + jb) Rl[(size_t)(j0 + jb) * D + c] = val[jb];
+                    }
+                    for (int jb = 0; jb < nb; ++jb) {
+                        if (c < j0 + jb) continue;
+                        double *ap = ab + (size_t)jb * D;
+                        const double v = val[jb];
+#pragma omp simd
+                        for (int cc = c + 1; cc < D; ++cc) ap[cc] -= v * uc[cc];
+                    }
+                }
+                for (int jb = 0; jb < nb; ++jb) ld += log(Rl[(size_t)(j0 + jb) * D + j0 + jb]);
             }
             logdet_sigma[i] = (float)(-2.0 * ld);
             // mu = m + R^-1 xi / sqrt(kappa)

@@ -23,3 +23,5 @@ for _ in range(10):
 lab, _ = wk.get_labels()
 print(f"D={D} N={N} K={s.K}: step {1e3 * np.mean(ts):.2f} ms, sweep kernel {np.mean(sw):.2f} ms, stats kernels {np.mean(st):.2f} ms, "
       f"label agreement with generator {np.mean(lab == y):.4f}")
+steps = 15 + 1
+print({k: round(1e3 * v / steps, 2) for k, v in s.timers.items()})
