@@ -262,44 +262,26 @@ def get_labels_histogram(labels):
 
 
 # ----------------------------------------------------------------------------- synthetic inputs
-def generate_gaussian_data(N, D, K, MixtureVar, seed=None):
-    """Recipe of data_generators.jl:19-42: pi ~ Dir(1_K); counts ~ Multinomial(N, pi); mu_k ~ N(0, MixtureVar I);
-    Sigma_k ~ InvWishart(D+2, I); points of a component contiguous.  Returns (x D x N f32, labels, means D x K, covs D x D x K)."""
-    rng = np.random.default_rng(seed)
-    tpi = rng.dirichlet(np.ones(K))
-    tzn = rng.multinomial(N, tpi)
-    x = np.empty((D, N), np.float32)
-    tz = np.empty(N, np.float32)
-    tmean = np.zeros((D, K), np.float32); tcov = np.zeros((D, D, K), np.float32)
-    ind = 0
-    for i in range(K):
-        tmean[:, i] = rng.normal(size=D) * np.sqrt(MixtureVar)
-        # InvWishart(D+2, I): inverse of a Wishart(D+2, I) draw
-        G = rng.normal(size=(D + 2, D))
-        cov = np.linalg.inv(G.T @ G)
-        tcov[:, :, i] = cov
-        L = np.linalg.cholesky(cov)
-        n = tzn[i]
-        x[:, ind:ind + n] = (tmean[:, i][:, None] + L @ rng.normal(size=(D, n))).astype(np.float32)
-        tz[ind:ind + n] = i + 1
-        ind += n
-    return x, tz, tmean, tcov
+def _mixture_spec(N, D, K, MixtureVar, seed):
+    """Component sizes, means and covariance factors of the synthetic Gaussian mixture (the recipe of data_generators.jl:19-42:
+    weights ~ Dir(1_K); sizes ~ Multinomial(N, weights); mean_k ~ N(0, MixtureVar I); cov_k ~ InvWishart(D+2, I))."""
+    rng = np.random.default_rng([int(seed), 0])
+    sizes = rng.multinomial(N, rng.dirichlet(np.ones(K)))
+    means = rng.normal(size=(K, D)) * np.sqrt(MixtureVar)
+    chol = np.empty((K, D, D))
+    for k in range(K):
+        G = rng.normal(size=(D + 2, D))                       # inverse of a Wishart(D+2, I) draw
+        chol[k] = np.linalg.cholesky(np.linalg.inv(G.T @ G))
+    return sizes, means, chol
 
 
 def gaussian_mixture_shard(N, D, K, MixtureVar, seed, lo, hi, chunk=100000):
-    """Columns [lo, hi) of the SAME N-point mixture as `generate_gaussian_data`'s recipe, generated
-    chunk-wise with per-chunk seeds so that every rank of a multi-GPU run can build only its own
-    column range (benchmark input; the dataset does not depend on the number of ranks).
+    """Columns [lo, hi) of the N-point synthetic mixture of `_mixture_spec`, points of a component contiguous (as the
+    reference's generator lays them out), generated chunk-wise with per-chunk seeds so that every rank of a multi-GPU run
+    builds only its own column range (the dataset does not depend on the number of ranks).
     Returns (X (hi-lo, D) float32 row = point, labels (hi-lo,) int64 1-based)."""
-    rng = np.random.default_rng([int(seed), 0])
-    tpi = rng.dirichlet(np.ones(K))
-    tzn = rng.multinomial(N, tpi)
-    means = rng.normal(size=(K, D)) * np.sqrt(MixtureVar)
-    chol = np.empty((K, D, D))
-    for i in range(K):
-        G = rng.normal(size=(D + 2, D))
-        chol[i] = np.linalg.cholesky(np.linalg.inv(G.T @ G))
-    edges = np.concatenate([[0], np.cumsum(tzn)])
+    sizes, means, chol = _mixture_spec(N, D, K, MixtureVar, seed)
+    edges = np.concatenate([[0], np.cumsum(sizes)])
     X = np.empty((hi - lo, D), np.float32)
     lab = np.empty(hi - lo, np.int64)
     c0, c1 = lo // chunk, (hi - 1) // chunk if hi > lo else -1
@@ -315,6 +297,18 @@ def gaussian_mixture_shard(N, D, K, MixtureVar, seed, lo, hi, chunk=100000):
         X[s - lo:e - lo] = out[s - a:e - a]
         lab[s - lo:e - lo] = comp[s - a:e - a] + 1
     return X, lab
+
+
+def generate_gaussian_data(N, D, K, MixtureVar, seed=None):
+    """generate_gaussian_data(N, D, K, MixtureVar) (data_generators.jl:19-42), same return shape:
+    (x D x N Float32, labels (N,) Float32 1-based, means D x K, covariances D x D x K).  The whole range of
+    `gaussian_mixture_shard`, so single- and multi-rank runs see the same points."""
+    if seed is None:
+        seed = int(np.random.SeedSequence().generate_state(1)[0])
+    X, lab = gaussian_mixture_shard(int(N), int(D), int(K), MixtureVar, seed, 0, int(N))
+    _, means, chol = _mixture_spec(int(N), int(D), int(K), MixtureVar, seed)
+    covs = np.einsum("kab,kcb->ack", chol, chol)
+    return np.ascontiguousarray(X.T), lab.astype(np.float32), means.T.astype(np.float32), covs.astype(np.float32)
 
 
 def generate_mnmm_data(N, D, K, trials, seed=None):

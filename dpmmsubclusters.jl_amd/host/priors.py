@@ -84,25 +84,27 @@ class niw_hyperparams(distribution_hyper_params):
         """Fused unpack + calc_posterior + factorisation, in place (native, threaded over clusters x {c,l,r})."""
         native.niw_update_from_packed(packed, sel, self.kappa, self.nu, self.m, self.psi, N, sums, S, post, nthreads=nthreads)
 
-    def log_marginal(self, post, N):
-        """niw.jl:53-62 with lnΓ_D accumulated in Float64 (the reference's utils.jl:66-72 uses a Float32
-        accumulator; that quirk is NOT reproduced -- see DESIGN.md)."""
+    def log_marginal(self, post, N, f32_quirk=False):
+        """niw.jl:53-62.  By default lnΓ_D is accumulated in Float64; `f32_quirk=True` reproduces the reference's
+        log_multivariate_gamma (utils.jl:66-72), whose accumulator is a Float32 local -- the switch that makes a
+        log-posterior trajectory comparable with the reference's own printed values."""
         D = self.dim
         N = np.asarray(N, float)
         v0, k0 = self.nu, self.kappa
         v1, k1 = post["nu"], post["kappa"]
-        return (-N * D * 0.5 * np.log(np.pi) + _lmvgamma(v1 / 2, D) - _lmvgamma(np.float64(v0 / 2), D)
+        lmg = _lmvgamma_f32 if f32_quirk else _lmvgamma
+        return (-N * D * 0.5 * np.log(np.pi) + lmg(v1 / 2, D) - lmg(np.float64(v0 / 2), D)
                 + (v0 / 2) * (D * np.log(v0) + self._logdet_psi) - (v1 / 2) * (D * np.log(v1) + post["logdet_psi"])
                 + (D / 2) * np.log(k0 / k1))
 
-    def log_marginal_pairs(self, pairs, stats, nthreads=None):
+    def log_marginal_pairs(self, pairs, stats, nthreads=None, f32_quirk=False):
         """log_marginal_likelihood of the pooled statistics of cluster pairs (shared_actions.jl:22-27)."""
         N = stats["N"]
         ld = native.niw_logdet_pairs(pairs, self.kappa, self.nu, self.m, self.psi, N, stats["sums"], stats["S"], nthreads=nthreads)
         pairs = np.asarray(pairs).reshape(-1, 2)
         Np = N[pairs[:, 0]] + N[pairs[:, 1]]
         post = dict(nu=self.nu + Np, kappa=self.kappa + Np, logdet_psi=ld)
-        return self.log_marginal(post, Np)
+        return self.log_marginal(post, Np, f32_quirk=f32_quirk)
 
     def sample(self, post, seed, epoch, ids, nthreads=None, noise=None):
         """Batch sample_distribution (niw.jl:34-40): μ, R (invΣ = R'R), logdetΣ as Float32.
@@ -159,6 +161,15 @@ def _lmvgamma(x, D):
     return D * (D - 1) / 4 * np.log(np.pi) + gammaln(x[..., None] + (1 - d) / 2).sum(-1)
 
 
+def _lmvgamma_f32(x, D):
+    """log_multivariate_gamma exactly as utils.jl:66-72 evaluates it: `res::Float32`, every partial sum rounded to Float32."""
+    x = np.atleast_1d(np.asarray(x, float))
+    res = np.full(x.shape, np.float32(D * (D - 1) / 4 * np.log(np.pi)), np.float32)
+    for d in range(1, D + 1):
+        res = (res.astype(np.float64) + gammaln(x + (1 - d) / 2)).astype(np.float32)
+    return res.astype(np.float64)
+
+
 class multinomial_hyper(distribution_hyper_params):
     """multinomial_hyper(α)  -- src/priors/multinomial_prior.jl:6-8 (Dirichlet prior, Float32)."""
     kind = PRIOR_MULT
@@ -179,13 +190,13 @@ class multinomial_hyper(distribution_hyper_params):
         post = np.where((N == 0)[:, None], self.alpha[None, :], post).astype(np.float32)
         return dict(alpha=post)
 
-    def log_marginal(self, post, N):
-        """multinomial_prior.jl:34-39 (Float64 evaluation)."""
+    def log_marginal(self, post, N, f32_quirk=False):
+        """multinomial_prior.jl:34-39 (Float64 evaluation; `f32_quirk` has no counterpart for this prior)."""
         a = self.alpha.astype(np.float64)
         b = post["alpha"].astype(np.float64)
         return gammaln(a.sum()) - gammaln(b.sum(-1)) + (gammaln(b) - gammaln(a)).sum(-1)
 
-    def log_marginal_pairs(self, pairs, stats, nthreads=None):
+    def log_marginal_pairs(self, pairs, stats, nthreads=None, f32_quirk=False):
         pairs = np.asarray(pairs).reshape(-1, 2)
         s = stats["sums"][pairs[:, 0]] + stats["sums"][pairs[:, 1]]
         Np = stats["N"][pairs[:, 0]] + stats["N"][pairs[:, 1]]
