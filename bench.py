@@ -2,15 +2,24 @@
 """Headline benchmark: Gibbs iterations/sec of the restricted-Gibbs sweep, NIW prior, D=64,
 N=10^7 synthetic points in 32 true components, on N GPUs of one node (BASELINE.json metric).
 
-A "step" is one full `group_step` (host posterior draws -> parameter upload -> fused label +
-sub-label sampling kernel -> sort + sufficient statistics kernels -> [all-reduce] -> posterior
+A "step" is one full `group_step` (native master: posterior draws -> parameter hand-over -> fused label +
+sub-label sampling kernel -> sort + sufficient statistics kernels -> [RCCL all-reduce] -> posterior
 update -> split / merge Metropolis steps -> relabel), i.e. exactly the region the reference
 times as `iter_count` (src/dp-parallel-sampling.jl:363-366).  One-time work (data generation,
 upload, initial labels, burn-in until the split/merge gates are open) is outside the timed
 region, as in the reference.
 
 Strong scaling: the N points are fixed and shard over the ranks by contiguous column ranges;
-the one data-path collective is the all-reduce of the packed sufficient statistics.
+the one data-path collective is the all-reduce of the packed sufficient statistics (inside libdpmmhip.so).
+
+Besides the contract fields the JSON line carries
+  roofline      the dominant kernel (NIW sweep) against the FP32-MFMA peak: `achieved` = ALGORITHMIC flops / live launch time
+                (exceeds the peak because exact cluster screening skips work), `frac` = EXECUTED flops / time / peak with the
+                executed work counted ON THE DEVICE in the timed launches (dpmm_last_sweep_work), `dense_*` = the same
+                kernel with screening switched off (every cluster evaluated in full) in the same process;
+  blocks        min / median / max it/s over repeated blocks of `--steps` steps (the headline `value` is the first block);
+  growth        a run of the same data from ONE initial cluster (`init_clusters=1`): whole-run and last-20 it/s + K history;
+  cpu_baseline  the reference algorithm's worker path on the host cores, P worker processes (see oracle/cpu_baseline.py).
 
 Launch: `python bench.py --gpus 1 ...` or
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W`.
@@ -29,34 +38,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense FP32 matrix peak (no TF32/xf32 on gfx950)
-# PMC figures of the D=64 sweep kernel at the bench workload (separate rocprofv3 --pmc passes, medians over launches,
-# profiles/r01e_bench_niw_d64_n1e7_pmc.json), per point so that they scale with the shard size:
-#   HBM bytes: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE -> (2*1318072.3125 + 81211.0) KiB / 1e7 points
-#   executed matrix flops: SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 -> 314696656 x 512 / 1e7 points (K = 32 clusters)
-PMC_BYTES_PER_POINT_D64 = (2 * 1318072.3125 + 81211.0) * 1024 / 1e7
-PMC_EXECUTED_FLOPS_PER_POINT_D64_K32 = 314696656.0 * 512 / 1e7
-
-
-def cpu_baseline(host, X_local, D, K, sampler, budget_points):
-    """Reference-algorithm CPU restatement (oracle/oracle.py: sweep_numpy_niw) timed on a bounded
-    sample of the same workload with the same K parameters; scaled to the full N."""
-    from threadpoolctl import threadpool_limits
-    from oracle import oracle as orc
-    n = min(budget_points, X_local.shape[0])
-    idx = np.linspace(0, X_local.shape[0] - 1, n).astype(np.int64)   # spans all components
-    Xs = np.ascontiguousarray(X_local[idx])
-    p = sampler.params
-    inv, _ = host.native.niw_expand(p["R"], want_sigma=False)
-    mu = p["mu"].astype(np.float32); invS = inv.reshape(3 * K, -1).astype(np.float32); logdet = p["logdet"].astype(np.float32)
-    logw = np.log(sampler.weights); loglr = np.log(sampler.lr_weights)
-    u0, u1 = orc.uniforms(1, 1, 0, 0, n)
-    cores = max(1, min(host.native._cpu_budget(), 64))     # CPUs this process may really use (cgroup quota), not os.cpu_count()
-    with threadpool_limits(limits=cores, user_api="blas"):
-        orc.sweep_numpy_niw(Xs[:2000], D, mu, invS, logdet, logw, loglr, u0[:2000], u1[:2000])  # warm
-        t0 = time.perf_counter()
-        orc.sweep_numpy_niw(Xs, D, mu, invS, logdet, logw, loglr, u0, u1)
-        dt = time.perf_counter() - t0
-    return dt, n, cores
 
 
 def main():
@@ -67,8 +48,12 @@ def main():
     ap.add_argument("--points", type=float, default=1e7, help="total number of points (default: the BASELINE metric's N)")
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--clusters", type=int, default=32)
+    ap.add_argument("--blocks", type=int, default=5, help="extra timed blocks of --steps steps after the headline block (min/median/max)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=800000, help="points of the workload the CPU baseline is timed on (about 10 s of CPU work)")
+    ap.add_argument("--no-growth", action="store_true")
+    ap.add_argument("--no-dense", action="store_true")
+    ap.add_argument("--growth-iters", type=int, default=100)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-clock budget of the CPU baseline sample")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -76,18 +61,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
-    # test hook (not used by the driver): DPMM_BENCH_BACKEND=gloo + DPMM_BENCH_SHARE_DEVICE=1 lets several ranks share
-    # one GPU so that the world_size > 1 code path can be exercised on a single-GPU box
-    backend = os.environ.get("DPMM_BENCH_BACKEND", "nccl")
-    if os.environ.get("DPMM_BENCH_SHARE_DEVICE"):
-        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-        else:
-            dist.init_process_group(backend)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the product has no CPU fallback)")
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
@@ -96,6 +73,7 @@ def main():
     pkg = load_package()
     host = importlib.import_module("dpmmsubclusters_jl_amd.host")
     from dpmmsubclusters_jl_amd.host.comm import default_comm
+    from dpmmsubclusters_jl_amd import binding
 
     N, D, K = int(args.points), args.dim, args.clusters
     comm = default_comm()
@@ -121,25 +99,63 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    sweep_ms, stats_ms, ks = [], [], []
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        s.group_step(False, False)
-        a, b = wk.last_kernel_ms()   # HIP events on the library's stream (stream is idle here: stats were read back)
-        sweep_ms.append(a); stats_ms.append(b); ks.append(s.K)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=(f"cuda:{local_rank}" if backend == "nccl" else "cpu"))
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_block(nsteps, collect=None):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            s.group_step(False, False)
+            if collect is not None:
+                collect()
+        fence()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
 
     n_local = hi - lo
+    sweep_ms, stats_ms, ks, work = [], [], [], []
+
+    def collect():     # HIP events on the library's stream + device-side work counters (the stream is idle here: stats were read back)
+        a, b = wk.last_kernel_ms()
+        sweep_ms.append(a); stats_ms.append(b); ks.append(s.K); work.append(wk.last_sweep_work())
+
+    t_before = dict(s.timers)
+    elapsed = timed_block(args.steps, collect)
+    t_after = dict(s.timers)
+    block_rates = []
+    for _ in range(max(0, args.blocks)):
+        block_rates.append(args.steps / timed_block(args.steps))
+
     k_mean = float(np.mean(ks))
-    flops_per_launch = 2.0 * n_local * D * D * (k_mean + 2)       # likelihood vs K clusters + own left/right
+    flops_alg = 2.0 * n_local * D * D * (k_mean + 2)       # likelihood vs K clusters + own left/right (per point x points)
     avg_sweep_ms = float(np.mean(sweep_ms))
-    achieved = flops_per_launch / (avg_sweep_ms * 1e-3) / 1e12
+    exe = float(np.mean([w["executed_flops"] for w in work]))
+    achieved = flops_alg / (avg_sweep_ms * 1e-3) / 1e12
+    roof = {"kernel": "niw_sweep_direct_kernel<4,4,2>" if D <= 64 else "niw_sweep_kernel", "bound": "mfma",
+            "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": exe / (avg_sweep_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "traffic": None,
+            "avg_launch_ms": avg_sweep_ms, "algorithmic_flops_per_launch": flops_alg, "executed_flops_per_launch": exe,
+            "executed_tflops": exe / (avg_sweep_ms * 1e-3) / 1e12, "pruning_factor": flops_alg / exe if exe else None,
+            "algorithmic_frac": achieved / PEAK_F32_MFMA_TFLOPS,
+            "work_per_launch": {k: float(np.mean([w[k] for w in work])) for k in ("wave_tiles", "full_evals", "screens16", "tail_pairs")},
+            "stats_kernels_ms": float(np.mean(stats_ms))}
+
+    # same kernel, same process, screening off: every cluster is evaluated in full (labels are bit-identical by construction)
+    if not args.no_dense:
+        wk.set_option(binding.OPT_SCREEN_MARGIN, 0.0)
+        dm, dw = [], []
+        for _ in range(3):
+            s.group_step(False, False)
+            dm.append(wk.last_kernel_ms()[0]); dw.append(wk.last_sweep_work()["executed_flops"])
+        wk.set_option(binding.OPT_SCREEN_MARGIN, 50.0)
+        d_ms, d_fl = float(np.mean(dm[1:])), float(np.mean(dw[1:]))
+        roof.update({"dense_launch_ms": d_ms, "dense_executed_tflops": d_fl / (d_ms * 1e-3) / 1e12,
+                     "dense_frac": d_fl / (d_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                     "dense_algorithmic_tflops": flops_alg / (d_ms * 1e-3) / 1e12})
+
     out = {
         "metric": "Gibbs iterations/sec, N=10M D=64 NIW" if (N == 10 ** 7 and D == 64) else f"Gibbs iterations/sec, N={N} D={D} NIW",
         "value": args.steps / elapsed,
@@ -155,26 +171,40 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"NIW D={D} N={N} synthetic GMM, {K} true components, K_t={k_mean:.1f} live clusters, "
                                f"alpha=10, default NIW prior, steady state after {burnout + 1} burn-in sweeps",
-                   "points_per_gpu": n_local, "parallelism": f"points sharded over {world} GPU(s), 1 all-reduce of packed suff-stats per statistics pass"},
-        "roofline": {"kernel": "niw_sweep_direct_kernel<4,4,2>" if D == 64 else "niw_sweep_kernel", "bound": "mfma",
-                     "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                     "traffic": (PMC_BYTES_PER_POINT_D64 * n_local if D == 64 else None),
-                     "avg_launch_ms": avg_sweep_ms, "algorithmic_flops_per_launch": flops_per_launch,
-                     # cluster screening skips most of the algorithmic work, which is why `frac` exceeds 1; the flops the
-                     # kernel actually EXECUTES on the matrix pipe (PMC, K=32 bench data) over the live launch time:
-                     "executed_tflops": (PMC_EXECUTED_FLOPS_PER_POINT_D64_K32 * n_local / (avg_sweep_ms * 1e-3) / 1e12
-                                         if (D == 64 and K == 32) else None),
-                     "executed_frac": (PMC_EXECUTED_FLOPS_PER_POINT_D64_K32 * n_local / (avg_sweep_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
-                                       if (D == 64 and K == 32) else None),
-                     "stats_kernels_ms": float(np.mean(stats_ms))},
-        "host_ms_per_step": {k: 1e3 * v / (args.steps + args.warmup + burnout + 1) for k, v in s.timers.items()},
+                   "points_per_gpu": n_local, "parallelism": f"points sharded over {world} GPU(s), 1 RCCL all-reduce of packed suff-stats per statistics pass"},
+        "roofline": roof,
+        "blocks": {"it_per_s": block_rates, "min": float(np.min(block_rates)) if block_rates else None,
+                   "median": float(np.median(block_rates)) if block_rates else None, "max": float(np.max(block_rates)) if block_rates else None},
+        "host_ms_per_step": {k: 1e3 * (t_after[k] - t_before[k]) / args.steps for k in t_after},
     }
+
+    final_params = (s.params, np.log(s.weights), np.log(s.lr_weights))   # before the growth run re-uses the context's staging
+
+    # growth trajectory (each NIW config also from init_clusters=1): same data, same context, fresh model
+    if not args.no_growth:
+        g = host.DPMMSampler(wk, prior, 10.0, N, sampler_seed, burnout=burnout, comm=comm)
+        g.init_first_clusters(1)
+        fence()
+        it, _, lik, kh = g.run_model(args.growth_iters)
+        fence()
+        tot = float(np.sum(it))
+        if dist is not None:
+            t = torch.tensor([tot, float(np.sum(it[-25:-5]))], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tot, last = float(t[0]), float(t[1])
+        else:
+            last = float(np.sum(it[-25:-5]))
+        out["growth"] = {"init_clusters": 1, "iterations": args.growth_iters, "it_per_s_whole_run": args.growth_iters / tot,
+                         "it_per_s_last20_nonfinal": 20.0 / last, "K_history": [int(k) for k in kh],
+                         "log_posterior_final": g.log_posterior()}
+
     if rank == 0 and not args.no_cpu_baseline and world == 1:
-        dt, n_s, cores = cpu_baseline(host, X, D, K, s, args.cpu_sample)
-        out["cpu_baseline"] = {"value": 1.0 / (dt * N / n_s), "unit": "iterations/s", "cores": cores, "kind": "port",
-                               "sample": f"worker path (label + sub-label sampling + 3 Float64 statistic passes per cluster) of the "
-                                         f"numpy/BLAS restatement on {n_s} of the {N} points, K={K}, {dt:.2f} s measured, scaled linearly to N"}
+        from oracle import cpu_baseline
+        p, logw, loglr = final_params
+        inv, _ = host.native.niw_expand(p["R"], want_sigma=False)
+        out["cpu_baseline"] = cpu_baseline.run_niw(X, D, K, p["mu"].astype(np.float32), inv.reshape(3 * K, -1).astype(np.float32),
+                                                   p["logdet"].astype(np.float32), logw.astype(np.float32), loglr.astype(np.float32), N,
+                                                   seconds=args.cpu_seconds)
     if rank == 0:
         print(json.dumps(out))
     wk.close()

@@ -30,6 +30,7 @@ ABI = [
     ("dpmm_set_params_niw_chol", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p]),
     ("dpmm_set_params_mult", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_f32p, _c_f32p, _c_f32p]),
     ("dpmm_set_num_clusters", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    ("dpmm_num_clusters", ctypes.c_int, [ctypes.c_void_p]),
     ("dpmm_sweep", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int]),
     ("dpmm_packed_stride", ctypes.c_int64, [ctypes.c_void_p]),
     ("dpmm_suffstats_packed_device", ctypes.c_int, [ctypes.c_void_p, _c_i64p, ctypes.c_int, ctypes.c_void_p]),
@@ -53,7 +54,23 @@ ABI = [
     ("dpmm_sync", ctypes.c_int, [ctypes.c_void_p]),
     ("dpmm_stream", ctypes.c_void_p, [ctypes.c_void_p]),
     ("dpmm_last_kernel_ms", ctypes.c_int, [ctypes.c_void_p, _c_f32p, _c_f32p]),
+    ("dpmm_init_labels_from", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint32]),
+    ("dpmm_set_option", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_double]),
+    ("dpmm_params_staging", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.POINTER(ctypes.c_void_p)] * 6),
+    ("dpmm_commit_params", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    ("dpmm_suffstats_host", ctypes.c_int, [ctypes.c_void_p, _c_i64p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    ("dpmm_step_stats", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]),
+    ("dpmm_debug_subloglik", ctypes.c_int, [ctypes.c_void_p, _c_f32p]),
+    ("dpmm_last_sweep_work", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]),
+    ("dpmm_comm_use_library", ctypes.c_int, [ctypes.c_char_p]),
+    ("dpmm_comm_unique_id", ctypes.c_int, [ctypes.c_void_p]),
+    ("dpmm_comm_init", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    ("dpmm_comm_destroy", ctypes.c_int, [ctypes.c_void_p]),
+    ("dpmm_comm_allgather_host", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
 ]
+
+# dpmm_set_option keys (include/dpmm_hip.h)
+OPT_SCREEN_MARGIN, OPT_TAIL_SCREEN, OPT_PRESCREEN, OPT_ORDERED_SWEEP, OPT_MULT_FORCE_F32, OPT_STATS_ITEMS, OPT_STATS_GROUPS, OPT_TRACE_SLOW, OPT_LOGLIK_REF_CONST = range(1, 10)
 
 
 class DpmmError(RuntimeError):
@@ -133,6 +150,16 @@ class Worker:
     def _chk(self, rc):
         if rc != 0:
             raise DpmmError(rc, self._lib.dpmm_last_error(self._h).decode())
+
+    @property
+    def K(self):
+        """Number of clusters the ctx currently knows (the native engine changes it through the C ABI directly)."""
+        h = getattr(self, "_h", None)
+        return int(self._lib.dpmm_num_clusters(h)) if h is not None and h.value else 0
+
+    @K.setter
+    def K(self, value):
+        pass
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -325,7 +352,59 @@ class Worker:
     def smart_assign(self, cluster, m_lo, m_hi):
         self._chk(self._lib.dpmm_smart_assign(self._h, int(cluster), float(m_lo), float(m_hi)))
 
+    # ---- options / collective
+    def set_option(self, option, value):
+        self._chk(self._lib.dpmm_set_option(self._h, int(option), float(value)))
+
+    def _use_torch_rccl(self):
+        """One RCCL per process: when torch is importable, bind the library to torch's own librccl.so."""
+        try:
+            import torch
+            cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+            if os.path.exists(cand):
+                self._lib.dpmm_comm_use_library(cand.encode())
+        except ImportError:
+            pass
+
+    def comm_unique_id(self):
+        self._use_torch_rccl()
+        buf = ctypes.create_string_buffer(128)
+        rc = self._lib.dpmm_comm_unique_id(buf)
+        if rc != 0:
+            raise DpmmError(rc, self._lib.dpmm_last_error(None).decode())
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world):
+        self._use_torch_rccl()
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        self._chk(self._lib.dpmm_comm_init(self._h, buf, int(rank), int(world)))
+
+    def step_stats(self, reset_epoch):
+        """dpmm_step_stats: (packed (2K, stride) float64, bad (K,) uint8) -- copies of the ctx's pinned output."""
+        pk, bad = ctypes.c_void_p(), ctypes.c_void_p()
+        self._chk(self._lib.dpmm_step_stats(self._h, int(reset_epoch), ctypes.byref(pk), ctypes.byref(bad)))
+        packed = np.ctypeslib.as_array(ctypes.cast(pk, _c_f64p), shape=(2 * self.K, self.packed_stride)).copy()
+        flags = np.ctypeslib.as_array(ctypes.cast(bad, ctypes.POINTER(ctypes.c_uint8)), shape=(self.K,)).copy()
+        return packed, flags
+
+    def init_labels_from(self, init_clusters, first_label, epoch):
+        self._chk(self._lib.dpmm_init_labels_from(self._h, int(init_clusters), int(first_label), int(epoch)))
+
+    def last_sweep_work(self):
+        """dict of the executed-work counters of the last NIW sweep (dpmm_last_sweep_work)."""
+        out = (ctypes.c_uint64 * 8)()
+        self._chk(self._lib.dpmm_last_sweep_work(self._h, out))
+        v = [int(x) for x in out]
+        return dict(wave_tiles=v[0], full_evals=v[1], screens16=v[2], tail_pairs=v[3], mfma_per_full=v[4], mfma_per_screen=v[5],
+                    flops_per_mfma=v[6], executed_flops=(v[1] * v[4] + v[2] * v[5]) * v[6])
+
     # ---- diagnostics
+    def debug_subloglik(self):
+        """(2K, n) float32: row 2k+s = log-likelihood under sub-cluster s of cluster k + log lr_weights[k][s]."""
+        out = np.empty((2 * self.K, self.n), np.float32)
+        self._chk(self._lib.dpmm_debug_subloglik(self._h, _p(out, _c_f32p)))
+        return out
+
     def debug_loglik(self):
         out = np.empty((self.K, self.n), np.float32)
         self._chk(self._lib.dpmm_debug_loglik(self._h, _p(out, _c_f32p)))

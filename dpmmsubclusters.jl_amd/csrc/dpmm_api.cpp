@@ -6,6 +6,7 @@
 #include "../../include/dpmm_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -84,19 +85,36 @@ struct dpmm_ctx {
     // pinned host staging for every per-step transfer (pageable copies stall for tens of ms now and then)
     char *h_pin = nullptr;
     size_t h_pin_bytes = 0;
+    // parameter staging (dpmm_params_staging): slot-indexed rows the host writes in place; the pack kernels read it directly
+    char *h_par = nullptr;
+    size_t h_par_bytes = 0;
+    int par_slots = 0;
+    // statistics output (dpmm_step_stats / dpmm_suffstats_host): packed rows + flags, read by the host in place
+    char *h_out = nullptr;
+    size_t h_out_bytes = 0;
+    uint8_t *d_flags = nullptr;        // [DPMM_MAX_CLUSTERS + 1] bad-cluster flags of the current step (+ any)
+    long long *d_counts64 = nullptr;   // [2 * DPMM_MAX_CLUSTERS] global sub-cluster occupancies (multi-GPU)
+    unsigned long long *d_work = nullptr;   // [4] executed-work counters of the last sweep
+    // options (dpmm_set_option)
+    float opt_margin = 50.f;
+    int opt_tail = 1, opt_prescreen = -1, opt_ordered = 1, opt_force_f32 = 0, opt_trace = 0, opt_ref_const = 0;
+    int64_t opt_stats_items = 0;
+    int opt_stats_groups = 0;
+    // collective (dpmm_comm_init)
+    void *comm = nullptr;
+    int rank = 0, world = 1;
 
     std::string err;
 };
 
-static const bool g_trace_slow = getenv("DPMM_TRACE_SLOW") != nullptr;
 static inline double now_ms() {
     timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
 }
 #define HIPCHK(ctx, expr)                                                                               \
     do {                                                                                                \
-        const double t0__ = g_trace_slow ? now_ms() : 0.0;                                              \
+        const double t0__ = (ctx)->opt_trace ? now_ms() : 0.0;                                          \
         hipError_t e__ = (expr);                                                                        \
-        if (g_trace_slow) {                                                                             \
+        if ((ctx)->opt_trace) {                                                                           \
             const double dt__ = now_ms() - t0__;                                                        \
             if (dt__ > 5.0) fprintf(stderr, "[dpmm slow] %.2f ms in %s (line %d)\n", dt__, #expr, __LINE__); \
         }                                                                                               \
@@ -121,6 +139,54 @@ static int ensure_pinned(dpmm_ctx *c, size_t bytes) {
 static int fail(dpmm_ctx *c, int code, const std::string &msg) {
     if (c) c->err = msg; else g_create_error = msg;
     return code;
+}
+
+// ---- RCCL, bound at run time ---------------------------------------------------------------------------------------------
+// The library must load (and `pytest -m "not gpu"` must be able to check its exports) on machines without RCCL, and a
+// process that also uses torch.distributed must end up with ONE copy of librccl: the symbols are looked up with dlopen,
+// first among the libraries already mapped, then by soname, then under /opt/rocm.
+struct UidByValue { char internal[128]; };
+namespace {
+struct Rccl {
+    void *handle = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, /* ncclUniqueId by value */ UidByValue, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string err;
+};
+}  // namespace
+static std::string g_rccl_path;   // dpmm_comm_use_library
+static Rccl &rccl() {
+    static Rccl r;
+    if (r.handle || !r.err.empty()) return r;
+    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    if (!g_rccl_path.empty()) r.handle = dlopen(g_rccl_path.c_str(), RTLD_NOW | RTLD_GLOBAL);
+    if (!r.handle) for (const char *n : names) { r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); if (r.handle) break; }
+    if (!r.handle) for (const char *n : names) { r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (r.handle) break; }
+    if (!r.handle) { r.err = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : ""); return r; }
+    auto sym = [&](const char *n) { void *p = dlsym(r.handle, n); if (!p && r.err.empty()) r.err = std::string("missing RCCL symbol ") + n; return p; };
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    return r;
+}
+enum { kNcclInt64 = 4, kNcclFloat64 = 8, kNcclInt8 = 0, kNcclSum = 0 };   // ncclDataType_t / ncclRedOp_t values of rccl.h
+
+static int comm_allreduce(dpmm_ctx *c, void *dbuf, size_t count, bool f64) {
+    Rccl &r = rccl();
+    const int rc = r.AllReduce(dbuf, dbuf, count, f64 ? kNcclFloat64 : kNcclInt64, kNcclSum, c->comm, c->stream);
+    if (rc != 0) return fail(c, DPMM_ECOMM, std::string("ncclAllReduce: ") + r.GetErrorString(rc));
+    return DPMM_OK;
+}
+static void comm_release(dpmm_ctx *c) {
+    if (c->comm) { rccl().CommDestroy(c->comm); c->comm = nullptr; }
+    c->world = 1; c->rank = 0;
 }
 
 #pragma GCC visibility push(default)
@@ -222,8 +288,7 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
     // work items of the statistics pass: the NIW kernel hands every workgroup a contiguous RANGE of items, so finer items
     // only improve the balance (ceil(items / groups) granularity) -- 16384 at D <= 64 (1.05 -> 0.85 ms at N = 1e7); slabs
     // are allocated per item, which is why the large-D kernels (280 KB per slab at D = 256) stay at 8192
-    static const int64_t items_env = [] { const char *e = getenv("DPMM_STATS_ITEMS"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
-    const int64_t target_items = items_env > 0 ? items_env : ((c->prior == DPMM_PRIOR_NIW && c->D <= 64) ? 16384 : 8192);
+    const int64_t target_items = (c->prior == DPMM_PRIOR_NIW && c->D <= 64) ? 16384 : 8192;
     c->chunk = (int)std::max<int64_t>(256, ((n_local + target_items - 1) / target_items + 3) / 4 * 4);
     const size_t nalloc = (size_t)std::max<int64_t>(n_local, 1);
     CHK_CREATE(hipMalloc(&c->dX, sizeof(float) * nalloc * (size_t)c->ldx));
@@ -238,6 +303,11 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
     CHK_CREATE(hipMalloc(&c->sb.bin_sel, nbmax));
     CHK_CREATE(hipMalloc(&c->sb.perm_total, sizeof(int32_t)));
     CHK_CREATE(hipMalloc(&c->d_small, sizeof(int32_t) * 4 * DPMM_MAX_CLUSTERS));
+    CHK_CREATE(hipMalloc(&c->d_flags, DPMM_MAX_CLUSTERS + 8));
+    CHK_CREATE(hipMemset(c->d_flags, 0, DPMM_MAX_CLUSTERS + 8));
+    CHK_CREATE(hipMalloc(&c->d_counts64, sizeof(long long) * 2 * DPMM_MAX_CLUSTERS));
+    CHK_CREATE(hipMalloc(&c->d_work, sizeof(unsigned long long) * 4));
+    CHK_CREATE(hipMemset(c->d_work, 0, sizeof(unsigned long long) * 4));
 #undef CHK_CREATE
     *out = c;
     return DPMM_OK;
@@ -251,7 +321,11 @@ int dpmm_destroy(dpmm_ctx *c) {
     hipFree(c->dX); hipFree(c->dbins); hipFree(c->d_gt); hipFree(c->d_cont);
     hipFree(c->sb.tile_hist); hipFree(c->sb.bin_total); hipFree(c->sb.bin_start); hipFree(c->sb.item_start);
     hipFree(c->sb.perm); hipFree(c->sb.bin_sel); hipFree(c->sb.perm_total); hipFree(c->d_small); hipFree(c->d_proj); hipFree(c->d_vals); hipFree(c->d_smart);
+    hipFree(c->d_flags); hipFree(c->d_counts64); hipFree(c->d_work);
+    comm_release(c);
     if (c->h_pin) hipHostFree(c->h_pin);
+    if (c->h_par) hipHostFree(c->h_par);
+    if (c->h_out) hipHostFree(c->h_out);
     for (auto &e : c->ev) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -261,7 +335,7 @@ int dpmm_destroy(dpmm_ctx *c) {
 // after the points are in place: the Multinomial fast path needs to know whether every count is exact in bf16
 static int finish_upload(dpmm_ctx *c) {
     if (c->prior == DPMM_PRIOR_MULT) {
-        static const bool force_f32 = getenv("DPMM_MULT_FORCE_F32") != nullptr;
+        const bool force_f32 = c->opt_force_f32 != 0;
         int *flag = reinterpret_cast<int *>(c->d_small);
         HIPCHK(c, hipMemsetAsync(flag, 0, sizeof(int), c->stream));
         HIPCHK(c, launch_bf16_exact_check(c->dX, c->n * c->ldx, flag, c->stream));
@@ -322,7 +396,16 @@ int dpmm_init_labels(dpmm_ctx *c, int init_clusters, uint32_t epoch) {
     if (!c) return DPMM_EINVAL;
     if (init_clusters < 1 || init_clusters > DPMM_MAX_CLUSTERS) return fail(c, DPMM_ELIMIT, "init_clusters out of range");
     HIPCHK(c, hipSetDevice(c->device));
-    if (c->n > 0) HIPCHK(c, launch_init_labels(c->dbins, c->n, c->first, init_clusters, c->seed, epoch, c->stream));
+    if (c->n > 0) HIPCHK(c, launch_init_labels(c->dbins, c->n, c->first, init_clusters, 0, c->seed, epoch, c->stream));
+    c->have_labels = true;
+    return DPMM_OK;
+}
+
+int dpmm_init_labels_from(dpmm_ctx *c, int init_clusters, int first_label, uint32_t epoch) {
+    if (!c) return DPMM_EINVAL;
+    if (first_label < 1 || init_clusters < 1 || first_label - 1 + init_clusters > DPMM_MAX_CLUSTERS) return fail(c, DPMM_ELIMIT, "init_clusters / first_label out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n > 0) HIPCHK(c, launch_init_labels(c->dbins, c->n, c->first, init_clusters, first_label - 1, c->seed, epoch, c->stream));
     c->have_labels = true;
     return DPMM_OK;
 }
@@ -368,13 +451,135 @@ static int check_K(dpmm_ctx *c, int K) {
     return DPMM_OK;
 }
 
-static void build_cst(std::vector<float> &cst, int K, const float *logdet, const float *lr, const float *w) {
-    cst.resize(3 * (size_t)K);
-    for (int k = 0; k < K; ++k) {
-        cst[3 * k] = (logdet ? -0.5f * logdet[3 * k] : 0.f) + logf(w[k]);
-        cst[3 * k + 1] = (logdet ? -0.5f * logdet[3 * k + 1] : 0.f) + logf(lr[2 * k]);
-        cst[3 * k + 2] = (logdet ? -0.5f * logdet[3 * k + 2] : 0.f) + logf(lr[2 * k + 1]);
+// ---- parameter staging: slot-indexed rows in pinned, GPU-addressable host memory ------------------------------------------
+// Layout for `slots` clusters (Float32 unless noted):
+//   NIW : mu [3 slots][D] | R [3 slots][D*D] | logdet [3 slots] | lr [slots][2] | w [slots] | cst [3 slots] | slot map Int32 [slots]
+//   MULT:                   logp [3 slots][D]                   | lr [slots][2] | w [slots] | cst [3 slots] | slot map Int32 [slots]
+struct ParLayout {
+    size_t mu = 0, mat = 0, logdet = 0, lr = 0, w = 0, cst = 0, slot = 0, bytes = 0;
+};
+static ParLayout par_layout(const dpmm_ctx *c, int slots) {
+    ParLayout L;
+    const size_t D = (size_t)c->D, S = (size_t)slots;
+    size_t o = 0;
+    if (c->prior == DPMM_PRIOR_NIW) {
+        L.mu = o; o += sizeof(float) * 3 * S * D;
+        L.mat = o; o += sizeof(float) * 3 * S * D * D;
+        L.logdet = o; o += sizeof(float) * 3 * S;
+    } else {
+        L.mat = o; o += sizeof(float) * 3 * S * D;
     }
+    L.lr = o; o += sizeof(float) * 2 * S;
+    L.w = o; o += sizeof(float) * S;
+    L.cst = o; o += sizeof(float) * 3 * S;
+    L.slot = o; o += sizeof(int32_t) * S;
+    L.bytes = (o + 255) & ~(size_t)255;
+    return L;
+}
+
+int dpmm_params_staging(dpmm_ctx *c, int slots, float **mu, float **mat, float **logdet, float **lr, float **w, int32_t **slot_of_cluster) {
+    if (!c) return DPMM_EINVAL;
+    if (slots < 1 || slots > DPMM_MAX_CLUSTERS) return fail(c, DPMM_ELIMIT, "slots out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (slots > c->par_slots) {
+        int ns = std::max(8, c->par_slots);
+        while (ns < slots) ns *= 2;
+        ns = std::min(ns, DPMM_MAX_CLUSTERS);
+        const ParLayout N = par_layout(c, ns);
+        char *nb = nullptr;
+        HIPCHK(c, hipStreamSynchronize(c->stream));      // a pack kernel may still read the old buffer
+        HIPCHK(c, hipHostMalloc((void **)&nb, N.bytes, hipHostMallocDefault));
+        memset(nb, 0, N.bytes);
+        if (c->h_par) {                                  // contents are preserved (rows are slot-indexed: same offsets inside a region)
+            const ParLayout O = par_layout(c, c->par_slots);
+            const size_t D = (size_t)c->D, S = (size_t)c->par_slots;
+            if (c->prior == DPMM_PRIOR_NIW) {
+                memcpy(nb + N.mu, c->h_par + O.mu, sizeof(float) * 3 * S * D);
+                memcpy(nb + N.mat, c->h_par + O.mat, sizeof(float) * 3 * S * D * D);
+                memcpy(nb + N.logdet, c->h_par + O.logdet, sizeof(float) * 3 * S);
+            } else {
+                memcpy(nb + N.mat, c->h_par + O.mat, sizeof(float) * 3 * S * D);
+            }
+            memcpy(nb + N.lr, c->h_par + O.lr, sizeof(float) * 2 * S);
+            memcpy(nb + N.w, c->h_par + O.w, sizeof(float) * S);
+            memcpy(nb + N.slot, c->h_par + O.slot, sizeof(int32_t) * S);
+            hipHostFree(c->h_par);
+        }
+        c->h_par = nb; c->h_par_bytes = N.bytes; c->par_slots = ns;
+    }
+    const ParLayout L = par_layout(c, c->par_slots);
+    if (mu) *mu = c->prior == DPMM_PRIOR_NIW ? reinterpret_cast<float *>(c->h_par + L.mu) : nullptr;
+    if (mat) *mat = reinterpret_cast<float *>(c->h_par + L.mat);
+    if (logdet) *logdet = c->prior == DPMM_PRIOR_NIW ? reinterpret_cast<float *>(c->h_par + L.logdet) : nullptr;
+    if (lr) *lr = reinterpret_cast<float *>(c->h_par + L.lr);
+    if (w) *w = reinterpret_cast<float *>(c->h_par + L.w);
+    if (slot_of_cluster) *slot_of_cluster = reinterpret_cast<int32_t *>(c->h_par + L.slot);
+    return DPMM_OK;
+}
+
+int dpmm_commit_params(dpmm_ctx *c, int K) {
+    if (!c) return DPMM_EINVAL;
+    if (int rc = check_K(c, K)) return rc;
+    if (!c->h_par || K > c->par_slots) return fail(c, DPMM_ESTATE, "dpmm_commit_params: call dpmm_params_staging(slots >= K) first");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = ensure_capacity(c, K)) return rc;
+    const ParLayout L = par_layout(c, c->par_slots);
+    const float *hmu = reinterpret_cast<const float *>(c->h_par + L.mu), *hmat = reinterpret_cast<const float *>(c->h_par + L.mat);
+    const float *hld = reinterpret_cast<const float *>(c->h_par + L.logdet), *hlr = reinterpret_cast<const float *>(c->h_par + L.lr);
+    const float *hw = reinterpret_cast<const float *>(c->h_par + L.w);
+    float *hcst = reinterpret_cast<float *>(c->h_par + L.cst);
+    const int32_t *hslot = reinterpret_cast<const int32_t *>(c->h_par + L.slot);
+    const bool niw = c->prior == DPMM_PRIOR_NIW;
+    for (int k = 0; k < K; ++k) {
+        const int sl = hslot[k];
+        if (sl < 0 || sl >= c->par_slots) return fail(c, DPMM_EINVAL, "slot_of_cluster entry out of range");
+        // cst[3k] = -logdet/2 + log w_k ; cst[3k+1+s] = -logdet/2 + log lr_w[k][s]   (Float32, as the workers of the reference add them)
+        hcst[3 * k] = (niw ? -0.5f * hld[3 * sl] : 0.f) + logf(hw[k]);
+        hcst[3 * k + 1] = (niw ? -0.5f * hld[3 * sl + 1] : 0.f) + logf(hlr[2 * k]);
+        hcst[3 * k + 2] = (niw ? -0.5f * hld[3 * sl + 2] : 0.f) + logf(hlr[2 * k + 1]);
+    }
+    // the kernels below read the staging buffer in place (no copy-engine transfer); the host may touch it again once a
+    // blocking call (dpmm_step_stats, dpmm_suffstats_*, dpmm_sync) has returned
+    HIPCHK(c, launch_copy_bytes(c->d_cst, hcst, sizeof(float) * 3 * K, c->stream));
+    if (niw) {
+        c->have_tail = c->opt_tail && c->D >= 4 && c->D % 4 == 0 && K > 2;
+        HIPCHK(c, launch_niw_pack(hmat, hmu, c->d_Rp, c->d_mup, c->D, c->NB, 3 * K, c->have_tail ? c->d_tail : nullptr, c->d_cst, hslot, c->stream));
+        c->have_screen_prep = false;
+        if (c->D > 16 && c->D <= 64 && K > 2) {
+            // the vectorised far mask (64 clusters per step) pays once there are many clusters, or when the VALU tail
+            // screen is unavailable (D not a multiple of 4); DPMM_OPT_PRESCREEN forces it off / on
+            const bool want = c->opt_prescreen >= 0 ? c->opt_prescreen != 0 : (!c->have_tail || K > 64);
+            if (want) {
+                HIPCHK(c, launch_niw_screen_prep(hmat, hmu, c->D, K, c->d_lam, c->d_mdist, hslot, c->stream));
+                c->have_screen_prep = true;
+            }
+        }
+    } else {
+        HIPCHK(c, launch_gather_rows(c->d_raw, c->ldx, hmat, c->D, hslot, 3 * K, c->D, c->stream));
+        HIPCHK(c, launch_mult_pack(c->d_raw, c->d_Rp, 3 * K, c->ldx, c->stream));
+        if (c->x_bf16_exact) HIPCHK(c, launch_mult_pack_bf16(c->d_raw, c->d_Lp16, 3 * K, c->ldx, c->stream));
+    }
+    c->K = K;
+    c->have_params = true;
+    c->predictive = false;
+    return DPMM_OK;
+}
+
+// compat entry points: copy the caller's cluster-ordered arrays into the staging rows (identity slot map) and commit
+static int stage_and_commit(dpmm_ctx *c, int K, const float *mu, const float *mat, const float *logdet, const float *lr, const float *w) {
+    float *smu, *smat, *sld, *slr, *sw;
+    int32_t *sslot;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));          // an earlier pack kernel may still read the staging buffer
+    if (int rc = dpmm_params_staging(c, K, &smu, &smat, &sld, &slr, &sw, &sslot)) return rc;
+    const size_t D = (size_t)c->D, W = c->prior == DPMM_PRIOR_NIW ? D * D : D;
+    if (mu) memcpy(smu, mu, sizeof(float) * 3 * K * D);
+    memcpy(smat, mat, sizeof(float) * 3 * K * W);
+    if (logdet) memcpy(sld, logdet, sizeof(float) * 3 * K);
+    memcpy(slr, lr, sizeof(float) * 2 * K);
+    memcpy(sw, w, sizeof(float) * K);
+    for (int k = 0; k < K; ++k) sslot[k] = k;
+    return dpmm_commit_params(c, K);
 }
 
 int dpmm_set_params_niw_chol(dpmm_ctx *c, int K, const float *mu, const float *R, const float *logdet, const float *lr, const float *w) {
@@ -382,46 +587,7 @@ int dpmm_set_params_niw_chol(dpmm_ctx *c, int K, const float *mu, const float *R
     if (c->prior != DPMM_PRIOR_NIW) return fail(c, DPMM_EINVAL, "context was created for another prior");
     if (!mu || !R || !logdet || !lr || !w) return fail(c, DPMM_EINVAL, "null parameter array");
     if (int rc = check_K(c, K)) return rc;
-    HIPCHK(c, hipSetDevice(c->device));
-    if (int rc = ensure_capacity(c, K)) return rc;
-    const size_t D = (size_t)c->D;
-    std::vector<float> cst;
-    build_cst(cst, K, logdet, lr, w);
-    const size_t nR = 3 * (size_t)K * D * D, nmu = 3 * (size_t)K * D, ncst = 3 * (size_t)K;
-    if (int rc = ensure_pinned(c, sizeof(float) * (nR + nmu + ncst))) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // the staging buffer may still feed an earlier copy
-    float *hp = reinterpret_cast<float *>(c->h_pin);
-    memcpy(hp, R, sizeof(float) * nR);
-    memcpy(hp + nR, mu, sizeof(float) * nmu);
-    memcpy(hp + nR + nmu, cst.data(), sizeof(float) * ncst);
-    // the pack kernel reads R and mu straight from the pinned staging buffer (no copy-engine transfer)
-    HIPCHK(c, launch_copy_bytes(c->d_cst, hp + nR + nmu, sizeof(float) * ncst, c->stream));
-    static const bool no_tail = getenv("DPMM_NIW_NO_TAIL") != nullptr;
-    c->have_tail = !no_tail && c->D >= 4 && c->D % 4 == 0 && K > 2;
-    HIPCHK(c, launch_niw_pack(hp, hp + nR, c->d_Rp, c->d_mup, c->D, c->NB, 3 * K, c->have_tail ? c->d_tail : nullptr, c->d_cst, c->stream));
-    c->have_screen_prep = false;
-    if (c->D > 16 && c->D <= 64 && K > 2) {
-        // the vectorised far mask (64 clusters per step) pays once there are many clusters, or when the VALU tail
-        // screen is unavailable (D not a multiple of 4); DPMM_NIW_PRESCREEN=0/1 forces it off/on
-        static const int pre_env = [] { const char *e = getenv("DPMM_NIW_PRESCREEN"); return e ? atoi(e) : -1; }();
-        static const bool no_pre = getenv("DPMM_NIW_NO_PRESCREEN") != nullptr;
-        const bool want = pre_env >= 0 ? pre_env != 0 : (!c->have_tail || K > 64);
-        if (!no_pre && want) {
-            HIPCHK(c, launch_niw_screen_prep(hp, hp + nR, c->D, K, c->d_lam, c->d_mdist, c->stream));
-            c->have_screen_prep = true;
-            if (g_trace_slow) {
-                std::vector<float> l(K), dd((size_t)K * K);
-                hipStreamSynchronize(c->stream);
-                hipMemcpy(l.data(), c->d_lam, sizeof(float) * K, hipMemcpyDeviceToHost);
-                hipMemcpy(dd.data(), c->d_mdist, sizeof(float) * K * K, hipMemcpyDeviceToHost);
-                fprintf(stderr, "[dpmm prep] lam: %g %g %g %g ... dist[0][1..3]: %g %g %g\n", l[0], l[1], l[2], l[K - 1], dd[1], dd[2], dd[3]);
-            }
-        }
-    }
-    c->K = K;
-    c->have_params = true;
-    c->predictive = false;
-    return DPMM_OK;
+    return stage_and_commit(c, K, mu, R, logdet, lr, w);
 }
 
 int dpmm_set_params_niw(dpmm_ctx *c, int K, const float *mu, const float *inv_sigma, const float *logdet, const float *lr, const float *w) {
@@ -455,25 +621,7 @@ int dpmm_set_params_mult(dpmm_ctx *c, int K, const float *logp, const float *lr,
     if (c->prior != DPMM_PRIOR_MULT) return fail(c, DPMM_EINVAL, "context was created for another prior");
     if (!logp || !lr || !w) return fail(c, DPMM_EINVAL, "null parameter array");
     if (int rc = check_K(c, K)) return rc;
-    HIPCHK(c, hipSetDevice(c->device));
-    if (int rc = ensure_capacity(c, K)) return rc;
-    std::vector<float> cst;
-    build_cst(cst, K, nullptr, lr, w);
-    const size_t nlp = 3 * (size_t)K * c->D, ncst = 3 * (size_t)K;
-    if (int rc = ensure_pinned(c, sizeof(float) * (nlp + ncst))) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    float *hp = reinterpret_cast<float *>(c->h_pin);
-    memcpy(hp, logp, sizeof(float) * nlp);
-    memcpy(hp + nlp, cst.data(), sizeof(float) * ncst);
-    if (c->ldx != c->D) HIPCHK(c, hipMemsetAsync(c->d_raw, 0, sizeof(float) * 3 * K * (size_t)c->ldx, c->stream));
-    HIPCHK(c, hipMemcpy2DAsync(c->d_raw, sizeof(float) * c->ldx, hp, sizeof(float) * c->D, sizeof(float) * c->D, (size_t)3 * K, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_cst, hp + nlp, sizeof(float) * ncst, hipMemcpyHostToDevice, c->stream));
-    c->predictive = false;
-    HIPCHK(c, launch_mult_pack(c->d_raw, c->d_Rp, 3 * K, c->ldx, c->stream));
-    if (c->x_bf16_exact) HIPCHK(c, launch_mult_pack_bf16(c->d_raw, c->d_Lp16, 3 * K, c->ldx, c->stream));
-    c->K = K;
-    c->have_params = true;
-    return DPMM_OK;
+    return stage_and_commit(c, K, nullptr, logp, nullptr, lr, w);
 }
 
 int dpmm_set_num_clusters(dpmm_ctx *c, int K) {
@@ -486,10 +634,13 @@ int dpmm_set_num_clusters(dpmm_ctx *c, int K) {
     return DPMM_OK;
 }
 
+int dpmm_num_clusters(const dpmm_ctx *c) { return c ? c->K : 0; }
+
 static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table, int64_t table_stride) {
     if (!c->have_points || !c->have_params) return fail(c, DPMM_ESTATE, "sweep needs points and parameters");
     HIPCHK(c, hipSetDevice(c->device));
     if (c->n == 0) return DPMM_OK;
+    if (c->prior == DPMM_PRIOR_NIW && !table) HIPCHK(c, hipMemsetAsync(c->d_work, 0, sizeof(unsigned long long) * 4, c->stream));
     if (!table) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     if (c->prior == DPMM_PRIOR_NIW) {
         NiwSweepArgs a{};
@@ -502,9 +653,8 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
         a.labels_only = table ? 1 : 0;
         a.bins = c->dbins; a.seed = c->seed; a.epoch = epoch; a.final_argmax = final_argmax;
         {
-            static const bool no_order = getenv("DPMM_NIW_NO_ORDER") != nullptr;
-            static const float margin = [] { const char *e = getenv("DPMM_NIW_SCREEN"); return e ? (float)atof(e) : 50.f; }();
-            a.screen_margin = table ? 0.f : margin;
+            const bool no_order = !c->opt_ordered;
+            a.screen_margin = table ? 0.f : c->opt_margin;
             a.use_prev = c->have_labels ? 1 : 0;
             a.lam = (c->have_screen_prep && !c->predictive) ? c->d_lam : nullptr;
             a.mdist = c->d_mdist;
@@ -512,6 +662,7 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
             a.tail_g = ((c->D - 4) % 16) / 4;
             a.order = (!table && c->have_perm && !no_order) ? c->sb.perm : nullptr;
             a.order_total = c->sb.perm_total;
+            a.work = table ? nullptr : c->d_work;
         }
 #ifdef DPMM_STAMPS
         if (!g_dbg) { hipMalloc(&g_dbg, sizeof(unsigned long long) * 16 * 4 * 4096); hipMemset(g_dbg, 0, sizeof(unsigned long long) * 16 * 4 * 4096); }
@@ -638,6 +789,11 @@ int dpmm_debug_loglik(dpmm_ctx *c, float *out) {
                                         (size_t)c->K, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { c->err = std::string("dpmm_debug_loglik: ") + hipGetErrorString(e); rc = DPMM_EHIP; }
+        else if (c->opt_ref_const && c->prior == DPMM_PRIOR_NIW && !c->predictive) {
+            // mv_gaussian.jl:24 normalises with length(Sigma) = D^2: -(D^2 log 2 pi + logdet)/2; the table carries -logdet/2 only
+            const float k2pi = (float)(-0.5 * (double)c->D * (double)c->D * log(2.0 * M_PI));
+            for (size_t i = 0; i < (size_t)c->K * (size_t)c->n; ++i) out[i] += k2pi;
+        }
     }
     hipFree(table);
     return rc;
@@ -645,37 +801,73 @@ int dpmm_debug_loglik(dpmm_ctx *c, float *out) {
 
 int64_t dpmm_packed_stride(const dpmm_ctx *c) { return c ? c->packed_stride : 0; }
 
-static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx) {
+static int ensure_out(dpmm_ctx *c, size_t bytes) {
+    if (bytes <= c->h_out_bytes) return DPMM_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->h_out) hipHostFree(c->h_out);
+    c->h_out = nullptr; c->h_out_bytes = 0;
+    size_t cap = 1 << 20;
+    while (cap < bytes) cap *= 2;
+    HIPCHK(c, hipHostMalloc((void **)&c->h_out, cap, hipHostMallocDefault));
+    c->h_out_bytes = cap;
+    return DPMM_OK;
+}
+
+// One statistics pass on the ctx stream (asynchronous): [sub-cluster occupancies -> bad-cluster reset ->] sort by bin ->
+// segmented statistics -> packed rows in c->d_out [-> all-reduce over the ranks].
+static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset = false, uint32_t reset_epoch = 0) {
     if (!c->have_points || !c->have_labels || c->K < 1) return fail(c, DPMM_ESTATE, "suffstats need points, labels and parameters (K)");
     HIPCHK(c, hipSetDevice(c->device));
     const int nbins = 2 * c->K;
-    c->h_sel.assign(nbins, idx ? 0 : 1);
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     if (idx) {
+        c->h_sel.assign(nbins, 0);
         for (int j = 0; j < n_idx; ++j) {
             if (idx[j] < 1 || idx[j] > c->K) return fail(c, DPMM_EINVAL, "cluster index out of range");
             c->h_sel[2 * (idx[j] - 1)] = 1;
             c->h_sel[2 * (idx[j] - 1) + 1] = 1;
         }
+        if (int rc = ensure_pinned(c, nbins + 8)) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        memcpy(c->h_pin, c->h_sel.data(), nbins);
+        HIPCHK(c, launch_copy_bytes(c->sb.bin_sel, c->h_pin, nbins, c->stream));
+    } else {
+        HIPCHK(c, hipMemsetAsync(c->sb.bin_sel, 1, nbins, c->stream));
     }
-    const size_t out_bytes = sizeof(double) * 2 * c->K * (size_t)c->packed_stride;
-    if (int rc = ensure_pinned(c, out_bytes + nbins + 8)) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    memcpy(c->h_pin + ((out_bytes + 3) & ~(size_t)3), c->h_sel.data(), nbins);
-    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-    HIPCHK(c, launch_copy_bytes(c->sb.bin_sel, c->h_pin + ((out_bytes + 3) & ~(size_t)3), nbins, c->stream));
     StatsArgs a{};
     a.X = c->dX; a.ldx = c->ldx; a.n = c->n; a.D = c->D; a.nbins = nbins; a.chunk = c->chunk;
     a.max_items = (int)((c->n + c->chunk - 1) / c->chunk) + nbins;
+    a.range_groups = c->opt_stats_groups;
     a.sb = c->sb; a.slabs = c->d_slabs; a.slab_stride = c->slab_stride; a.out = c->d_out; a.packed_stride = c->packed_stride;
     if (c->n > 0) {
         HIPCHK(c, launch_sort_by_bin(c->dbins, c->n, nbins, c->sb, c->stream));
     } else {
         HIPCHK(c, hipMemsetAsync(c->sb.bin_total, 0, sizeof(int32_t) * nbins, c->stream));
     }
+    if (with_reset) {
+        // reset_bad_clusters! (local_clusters_actions.jl:501-516) on the device: occupancies (summed over the ranks) -> flags ->
+        // sub-labels of flagged clusters re-drawn -> histogram again (skipped on the device when nothing was flagged)
+        const long long *gc = nullptr;
+        if (c->comm) {
+            HIPCHK(c, launch_widen_counts(c->sb.bin_total, c->d_counts64, nbins, c->stream));
+            if (int rc = comm_allreduce(c, c->d_counts64, nbins, /*f64=*/false)) return rc;
+            gc = c->d_counts64;
+        }
+        HIPCHK(c, launch_bad_flags(c->sb.bin_total, gc, c->K, c->d_flags, c->stream));
+        if (c->n > 0) {
+            HIPCHK(c, launch_reset_sub_flagged(c->dbins, c->n, c->first, c->d_flags, c->K, c->seed, reset_epoch, c->stream));
+            HIPCHK(c, launch_sort_by_bin(c->dbins, c->n, nbins, c->sb, c->stream, c->d_flags + c->K));
+        }
+    }
     HIPCHK(c, launch_sort_finish(c->dbins, a, c->stream));
     c->have_perm = c->n > 0;
     if (c->prior == DPMM_PRIOR_NIW) HIPCHK(c, launch_niw_stats(a, c->stream));
     else HIPCHK(c, launch_mult_stats(a, c->stream));
+    if (c->comm) {
+        // the one exchange of the sweep: elementwise sum of the per-worker statistics (update_suff_stats_posterior!,
+        // local_clusters_actions.jl:206-254; aggregate_suff_stats); N counts travel as Float64 integers (exact below 2^53)
+        if (int rc = comm_allreduce(c, c->d_out, (size_t)nbins * (size_t)c->packed_stride, /*f64=*/true)) return rc;
+    }
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     c->have_stats_ev = true;
     return DPMM_OK;
@@ -700,30 +892,40 @@ int dpmm_suffstats_packed_device(dpmm_ctx *c, const int64_t *idx, int n_idx, dou
     if (!c || !d_out) return DPMM_EINVAL;
     if (int rc = run_stats(c, idx, n_idx)) return rc;
     HIPCHK(c, hipMemcpyAsync(d_out, c->d_out, sizeof(double) * 2 * c->K * (size_t)c->packed_stride, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // h_sel staging must outlive the copy
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DPMM_OK;
+}
+
+// statistics (summed over the ranks when a communicator is attached) -> pinned host memory the caller reads in place
+int dpmm_suffstats_host(dpmm_ctx *c, const int64_t *idx, int n_idx, const double **packed) {
+    if (!c || !packed) return DPMM_EINVAL;
+    const size_t out_bytes = sizeof(double) * 2 * (size_t)std::max(c->K, 1) * (size_t)c->packed_stride;
+    if (int rc = ensure_out(c, out_bytes + DPMM_MAX_CLUSTERS + 64)) return rc;
+    if (int rc = run_stats(c, idx, n_idx)) return rc;
+    HIPCHK(c, launch_copy_bytes(c->h_out, c->d_out, out_bytes, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *packed = reinterpret_cast<const double *>(c->h_out);
+    return DPMM_OK;
+}
+
+int dpmm_step_stats(dpmm_ctx *c, uint32_t reset_epoch, const double **packed, const uint8_t **bad) {
+    if (!c || !packed || !bad) return DPMM_EINVAL;
+    const size_t out_bytes = sizeof(double) * 2 * (size_t)std::max(c->K, 1) * (size_t)c->packed_stride;
+    if (int rc = ensure_out(c, out_bytes + DPMM_MAX_CLUSTERS + 64)) return rc;
+    if (int rc = run_stats(c, nullptr, 0, true, reset_epoch)) return rc;
+    HIPCHK(c, launch_copy_bytes(c->h_out, c->d_out, out_bytes, c->stream));
+    HIPCHK(c, launch_copy_bytes(c->h_out + out_bytes, c->d_flags, (size_t)c->K + 1, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *packed = reinterpret_cast<const double *>(c->h_out);
+    *bad = reinterpret_cast<const uint8_t *>(c->h_out + out_bytes);
     return DPMM_OK;
 }
 
 int dpmm_suffstats_packed(dpmm_ctx *c, const int64_t *idx, int n_idx, double *out) {
     if (!c || !out) return DPMM_EINVAL;
-    if (int rc = run_stats(c, idx, n_idx)) return rc;
-    const size_t out_bytes = sizeof(double) * 2 * c->K * (size_t)c->packed_stride;
-    HIPCHK(c, launch_copy_bytes(c->h_pin, c->d_out, out_bytes, c->stream));
-    static const bool trace = getenv("DPMM_TRACE_SLOW") != nullptr;
-    timespec t0, t1, t2;
-    if (trace) clock_gettime(CLOCK_MONOTONIC, &t0);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (trace) clock_gettime(CLOCK_MONOTONIC, &t1);
-    memcpy(out, c->h_pin, out_bytes);
-    if (trace) {
-        clock_gettime(CLOCK_MONOTONIC, &t2);
-        const double a = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6, b = (t2.tv_sec - t1.tv_sec) * 1e3 + (t2.tv_nsec - t1.tv_nsec) * 1e-6;
-        if (a + b > 10.0) {
-            float sm = 0, st = 0;
-            hipEventElapsedTime(&sm, c->ev[0], c->ev[1]); hipEventElapsedTime(&st, c->ev[2], c->ev[3]);
-            fprintf(stderr, "[dpmm slow] sync %.2f ms, memcpy %.2f ms; GPU events: sweep %.3f ms stats %.3f ms\n", a, b, sm, st);
-        }
-    }
+    const double *pk = nullptr;
+    if (int rc = dpmm_suffstats_host(c, idx, n_idx, &pk)) return rc;
+    memcpy(out, pk, sizeof(double) * 2 * c->K * (size_t)c->packed_stride);
     return DPMM_OK;
 }
 
@@ -939,6 +1141,178 @@ int dpmm_dev_stamps(dpmm_ctx *c, unsigned long long *out, int nwaves) {
 #endif
 
 void *dpmm_stream(dpmm_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int dpmm_set_option(dpmm_ctx *c, int option, double value) {
+    if (!c) return DPMM_EINVAL;
+    switch (option) {
+        case DPMM_OPT_SCREEN_MARGIN: if (!(value >= 0)) return fail(c, DPMM_EINVAL, "margin < 0"); c->opt_margin = (float)value; return DPMM_OK;
+        case DPMM_OPT_TAIL_SCREEN: c->opt_tail = value != 0; return DPMM_OK;
+        case DPMM_OPT_PRESCREEN: c->opt_prescreen = value < 0 ? -1 : (value != 0); return DPMM_OK;
+        case DPMM_OPT_ORDERED_SWEEP: c->opt_ordered = value != 0; return DPMM_OK;
+        case DPMM_OPT_MULT_FORCE_F32:
+            if (c->have_points) return fail(c, DPMM_ESTATE, "DPMM_OPT_MULT_FORCE_F32 must be set before the points are uploaded");
+            c->opt_force_f32 = value != 0; return DPMM_OK;
+        case DPMM_OPT_STATS_ITEMS:
+            if (c->Kcap > 0) return fail(c, DPMM_ESTATE, "DPMM_OPT_STATS_ITEMS must be set before the first parameters / K");
+            if (value >= 1) c->chunk = (int)std::max<int64_t>(256, ((c->n + (int64_t)value - 1) / (int64_t)value + 3) / 4 * 4);
+            return DPMM_OK;
+        case DPMM_OPT_STATS_GROUPS: c->opt_stats_groups = value > 0 ? (int)value : 0; return DPMM_OK;
+        case DPMM_OPT_TRACE_SLOW: c->opt_trace = value != 0; return DPMM_OK;
+        case DPMM_OPT_LOGLIK_REF_CONST: c->opt_ref_const = value != 0; return DPMM_OK;
+        default: return fail(c, DPMM_EINVAL, "unknown option");
+    }
+}
+
+int dpmm_last_sweep_work(dpmm_ctx *c, uint64_t *out8) {
+    if (!c || !out8) return DPMM_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned long long h[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(h, c->d_work, sizeof(h), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; ++i) out8[i] = h[i];
+    // matrix instructions per unit of work, per WAVE (v_mfma_f32_16x16x4_f32, 2048 flops each)
+    int mf_full = 0, mf_scr = 0;
+    if (c->prior == DPMM_PRIOR_NIW) {
+        const int NB = c->NB, NP = NB * (NB + 1) / 2;
+        const int NG = NB <= 4 ? 4 : 2;                       // points per wave / 16 (launch_niw_sweep configurations)
+        mf_full = NP * 4 * NG + (NB <= 4 ? NG : 0);           // block pairs x 4 k-steps x NG (+ the ones-MFMA row sums of the direct kernel)
+        mf_scr = NB <= 4 ? 4 * NG : 0;
+    }
+    out8[4] = (uint64_t)mf_full; out8[5] = (uint64_t)mf_scr; out8[6] = 2048; out8[7] = 0;
+    return DPMM_OK;
+}
+
+// ---- the collective ------------------------------------------------------------------------------------------------------
+int dpmm_comm_use_library(const char *path) {
+    g_rccl_path = path ? path : "";
+    return DPMM_OK;
+}
+
+int dpmm_comm_unique_id(void *out128) {
+    if (!out128) return DPMM_EINVAL;
+    Rccl &r = rccl();
+    if (!r.handle || !r.err.empty()) return fail(nullptr, DPMM_ECOMM, r.err.empty() ? "RCCL unavailable" : r.err);
+    const int rc = r.GetUniqueId(out128);
+    if (rc != 0) return fail(nullptr, DPMM_ECOMM, std::string("ncclGetUniqueId: ") + r.GetErrorString(rc));
+    return DPMM_OK;
+}
+
+int dpmm_comm_init(dpmm_ctx *c, const void *unique_id128, int rank, int world) {
+    if (!c || !unique_id128) return DPMM_EINVAL;
+    if (world < 1 || rank < 0 || rank >= world) return fail(c, DPMM_EINVAL, "bad rank / world");
+    Rccl &r = rccl();
+    if (!r.handle || !r.err.empty()) return fail(c, DPMM_ECOMM, r.err.empty() ? "RCCL unavailable" : r.err);
+    HIPCHK(c, hipSetDevice(c->device));
+    comm_release(c);
+    UidByValue id;
+    memcpy(id.internal, unique_id128, 128);
+    void *comm = nullptr;
+    const int rc = r.CommInitRank(&comm, world, id, rank);
+    if (rc != 0) return fail(c, DPMM_ECOMM, std::string("ncclCommInitRank: ") + r.GetErrorString(rc));
+    c->comm = comm; c->rank = rank; c->world = world;
+    return DPMM_OK;
+}
+
+int dpmm_comm_destroy(dpmm_ctx *c) {
+    if (!c) return DPMM_EINVAL;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    comm_release(c);
+    return DPMM_OK;
+}
+
+int dpmm_comm_allgather_host(dpmm_ctx *c, const void *mine, int64_t bytes, void *all) {
+    if (!c || !mine || !all || bytes < 0) return DPMM_EINVAL;
+    if (!c->comm || c->world == 1) { memcpy(all, mine, (size_t)bytes); return DPMM_OK; }
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nb = ((size_t)bytes + 7) & ~(size_t)7, tot = nb * (size_t)c->world;
+    if (int rc = ensure_pinned(c, nb + tot)) return rc;
+    char *dbuf = nullptr;
+    HIPCHK(c, hipMalloc(&dbuf, tot));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(c->h_pin, mine, (size_t)bytes);
+    hipError_t e = launch_copy_bytes(dbuf + nb * (size_t)c->rank, c->h_pin, nb, c->stream);
+    int rc = DPMM_OK;
+    if (e == hipSuccess) {
+        Rccl &r = rccl();
+        const int nrc = r.AllGather(dbuf + nb * (size_t)c->rank, dbuf, nb, kNcclInt8, c->comm, c->stream);
+        if (nrc != 0) rc = fail(c, DPMM_ECOMM, std::string("ncclAllGather: ") + r.GetErrorString(nrc));
+    }
+    if (rc == DPMM_OK && e == hipSuccess) e = launch_copy_bytes(c->h_pin + nb, dbuf, tot, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(dbuf);
+    if (e != hipSuccess) { c->err = std::string("dpmm_comm_allgather_host: ") + hipGetErrorString(e); return DPMM_EHIP; }
+    if (rc != DPMM_OK) return rc;
+    for (int rk = 0; rk < c->world; ++rk) memcpy((char *)all + (size_t)rk * (size_t)bytes, c->h_pin + nb + nb * (size_t)rk, (size_t)bytes);
+    return DPMM_OK;
+}
+
+// Sub-cluster log-likelihood table of the CURRENT parameters: out[(2k+s) * n_local + i] = loglik of point i under sub-cluster
+// s of cluster k + log lr_weights[k][s] -- the two values create_subclusters_labels! (local_clusters_actions.jl:83-95) draws from
+// for a point labelled k.  Same arithmetic as the sub-label phase of dpmm_sweep (the sub-cluster matrices are evaluated as
+// the cluster-level rows of a temporary 2K-cluster parameter set, full table, no screening).
+int dpmm_debug_subloglik(dpmm_ctx *c, float *out) {
+    if (!c || !out) return DPMM_EINVAL;
+    if (!c->have_points || !c->have_params || c->predictive) return fail(c, DPMM_ESTATE, "debug_subloglik needs points and sweep parameters");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n == 0) return DPMM_OK;
+    const int K = c->K, K2 = 2 * K;
+    if (K2 > DPMM_MAX_CLUSTERS) return fail(c, DPMM_ELIMIT, "debug_subloglik: 2K > DPMM_MAX_CLUSTERS");
+    const int64_t stride = c->ntiles * c->tile;
+    const bool niw = c->prior == DPMM_PRIOR_NIW;
+    // temporary parameter images: row 3j of the temporary set <- row 3k+1+s of the live one (j = 2k+s)
+    const size_t NP = niw ? (size_t)c->NB * (c->NB + 1) / 2 : 0, matsz = NP * 256, dp = niw ? (size_t)16 * c->NB : 0;
+    float *tRp = nullptr, *tmu = nullptr, *tcst = nullptr, *table = nullptr, *traw = nullptr;
+    uint32_t *tL16 = nullptr;
+    hipError_t e = hipMalloc(&tcst, sizeof(float) * 3 * K2);
+    if (e == hipSuccess) e = hipMalloc(&table, sizeof(float) * (size_t)(niw ? K2 : 3 * K2) * (size_t)stride);
+    int rc = DPMM_OK;
+    float *sRp = c->d_Rp, *smu = c->d_mup, *scst = c->d_cst, *sraw = c->d_raw;
+    uint32_t *sL16 = c->d_Lp16;
+    const int sK = c->K;
+    const bool s_tail = c->have_tail, s_prep = c->have_screen_prep;
+    if (e == hipSuccess && niw) {
+        e = hipMalloc(&tRp, sizeof(float) * 3 * K2 * matsz);
+        if (e == hipSuccess) e = hipMalloc(&tmu, sizeof(float) * 3 * K2 * dp);
+        for (int j = 0; j < K2 && e == hipSuccess; ++j) {
+            const int src = 3 * (j / 2) + 1 + (j % 2);
+            e = hipMemcpyAsync(tRp + (size_t)(3 * j) * matsz, c->d_Rp + (size_t)src * matsz, sizeof(float) * matsz, hipMemcpyDeviceToDevice, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(tmu + (size_t)(3 * j) * dp, c->d_mup + (size_t)src * dp, sizeof(float) * dp, hipMemcpyDeviceToDevice, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(tcst + 3 * j, c->d_cst + src, sizeof(float), hipMemcpyDeviceToDevice, c->stream);
+        }
+        if (e == hipSuccess) { c->d_Rp = tRp; c->d_mup = tmu; c->d_cst = tcst; }
+    } else if (e == hipSuccess) {
+        // Multinomial: re-pack a raw row image with the sub-cluster rows in the cluster-level positions
+        e = hipMalloc(&traw, sizeof(float) * 3 * K2 * (size_t)c->ldx);
+        if (e == hipSuccess) e = hipMemsetAsync(traw, 0, sizeof(float) * 3 * K2 * (size_t)c->ldx, c->stream);
+        const size_t NT = (size_t)(c->ldx + 15) / 16, NRB = (size_t)(3 * K2 + 15) / 16;
+        if (e == hipSuccess) e = hipMalloc(&tRp, sizeof(float) * NRB * NT * 256);
+        if (e == hipSuccess) e = hipMalloc(&tL16, sizeof(uint32_t) * mult_pack_bf16_words(3 * K2, c->ldx));
+        if (e == hipSuccess) e = hipMemsetAsync(tcst, 0, sizeof(float) * 3 * K2, c->stream);
+        for (int j = 0; j < K2 && e == hipSuccess; ++j) {
+            const int src = 3 * (j / 2) + 1 + (j % 2);
+            e = hipMemcpyAsync(traw + (size_t)(3 * j) * c->ldx, c->d_raw + (size_t)src * c->ldx, sizeof(float) * c->ldx, hipMemcpyDeviceToDevice, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(tcst + 3 * j, c->d_cst + src, sizeof(float), hipMemcpyDeviceToDevice, c->stream);
+        }
+        if (e == hipSuccess) e = launch_mult_pack(traw, tRp, 3 * K2, c->ldx, c->stream);
+        if (e == hipSuccess && c->x_bf16_exact) e = launch_mult_pack_bf16(traw, tL16, 3 * K2, c->ldx, c->stream);
+        if (e == hipSuccess) { c->d_Rp = tRp; c->d_cst = tcst; c->d_Lp16 = tL16; c->d_raw = traw; }
+    }
+    if (e == hipSuccess) {
+        c->K = K2; c->have_tail = false; c->have_screen_prep = false;
+        rc = run_sweep(c, 0, 0, table, stride);
+        if (rc == DPMM_OK) {
+            const size_t src_pitch = sizeof(float) * stride * (niw ? 1 : 3);
+            e = hipMemcpy2DAsync(out, sizeof(float) * c->n, table, src_pitch, sizeof(float) * c->n, (size_t)K2, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        }
+    }
+    hipStreamSynchronize(c->stream);
+    c->d_Rp = sRp; c->d_mup = smu; c->d_cst = scst; c->d_Lp16 = sL16; c->d_raw = sraw; c->K = sK; c->have_tail = s_tail; c->have_screen_prep = s_prep;
+    hipFree(tRp); hipFree(tmu); hipFree(tcst); hipFree(table); hipFree(traw); hipFree(tL16);
+    if (e != hipSuccess) { c->err = std::string("dpmm_debug_subloglik: ") + hipGetErrorString(e); return DPMM_EHIP; }
+    return rc;
+}
 
 int dpmm_last_kernel_ms(dpmm_ctx *c, float *sweep_ms, float *stats_ms) {
     if (!c) return DPMM_EINVAL;

@@ -41,13 +41,16 @@ struct NiwSweepArgs {
     int use_prev;             // bins hold labels from a previous sweep (reference clusters of the screen)
     int lds_rows;             // set by the launcher: rows of the a_k table that live in LDS (0: global scratch)
     unsigned long long *dbg;  // diagnostic builds only (DPMM_STAMPS): per-wave phase cycle sums
+    unsigned long long *work; // [4] executed-work counters of this launch (wave tiles, full evaluations per wave, 16-row screens per wave,
+                              // tail-screened cluster pairs per wave), one atomicAdd set per wave at kernel end; may be null
 };
 
 int niw_tile_points(int NB);
 int niw_occupancy(int NB);  // resident 256-thread workgroups per CU the sweep kernel is built for
 hipError_t launch_niw_sweep(int NB, const NiwSweepArgs &a, int grid, hipStream_t s);
-hipError_t launch_niw_screen_prep(const float *R, const float *mu, int D, int K, float *lam, float *dist, hipStream_t s);
-hipError_t launch_niw_pack(const float *R, const float *mu, float *Rp, float *mup, int D, int NB, int nmat, float *tail, const float *cst, hipStream_t s);
+hipError_t launch_niw_screen_prep(const float *R, const float *mu, int D, int K, float *lam, float *dist, const int32_t *slot, hipStream_t s);
+hipError_t launch_niw_pack(const float *R, const float *mu, float *Rp, float *mup, int D, int NB, int nmat, float *tail, const float *cst,
+                           const int32_t *slot, hipStream_t s);
 
 struct MultSweepArgs {
     const float *X;
@@ -88,8 +91,15 @@ hipError_t launch_predict_finish(const float *table, int64_t stride, int rstep, 
 hipError_t launch_ingest_rows(float *dst, int64_t ldx, const void *src, int is_f64, int64_t ld, int64_t rows, int D, int nan_to_zero,
                               hipStream_t s);
 hipError_t launch_copy_bytes(void *dst, const void *src, size_t bytes, hipStream_t s);
-hipError_t launch_init_labels(int32_t *bins, int64_t n, int64_t first_index, int init_clusters, uint64_t seed,
+hipError_t launch_init_labels(int32_t *bins, int64_t n, int64_t first_index, int init_clusters, int label0, uint64_t seed,
                               uint32_t epoch, hipStream_t s);
+// step statistics: flags[k] = 1 when cluster k has an empty sub-cluster (counts: [2K] Int64, global), flags[K] = any;
+// then re-draw the sub-labels of flagged clusters (reset_bad_clusters_worker!)
+hipError_t launch_bad_flags(const int32_t *bin_total, const long long *global_counts, int K, uint8_t *flags, hipStream_t s);
+hipError_t launch_reset_sub_flagged(int32_t *bins, int64_t n, int64_t first_index, const uint8_t *flags, int K, uint64_t seed, uint32_t epoch,
+                                    hipStream_t s);
+hipError_t launch_widen_counts(const int32_t *src, long long *dst, int n, hipStream_t s);
+hipError_t launch_gather_rows(float *dst, int64_t ld_dst, const float *src, int64_t ld_src, const int32_t *slot, int rows, int D, hipStream_t s);
 hipError_t launch_bins_from_i64(int32_t *bins, const int64_t *labels, const int64_t *sub, int64_t n, hipStream_t s);
 hipError_t launch_bins_to_i64(const int32_t *bins, int64_t *labels, int64_t *sub, int64_t n, hipStream_t s);
 hipError_t launch_contingency(const int32_t *bins, const int32_t *gt, int64_t n, int K, int n_gt, unsigned long long *counts, hipStream_t s);
@@ -115,7 +125,8 @@ struct SortBufs {
     int32_t *perm_total;  // [1] number of points placed in perm by the last sort (== n when every label was in range)
 };
 
-hipError_t launch_sort_by_bin(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s);
+// `only_if` (nullable): device byte; when it is 0 the pass is skipped (tile_hist / bin_total keep their contents)
+hipError_t launch_sort_by_bin(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s, const uint8_t *only_if = nullptr);
 struct StatsArgs;
 hipError_t launch_sort_finish(const int32_t *bins, const StatsArgs &a, hipStream_t s);
 

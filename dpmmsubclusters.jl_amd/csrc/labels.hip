@@ -20,10 +20,10 @@ static inline int grid_for(int64_t n, int block = 256) {
     return (int)g;
 }
 
-__global__ void init_labels_kernel(int32_t *bins, int64_t n, int64_t first, int init_clusters, uint64_t seed, uint32_t epoch) {
+__global__ void init_labels_kernel(int32_t *bins, int64_t n, int64_t first, int init_clusters, int label0, uint64_t seed, uint32_t epoch) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const Philox4 r = philox4x32_10(seed, (uint64_t)(first + i), epoch, STREAM_INIT);
-        const int z = (int)(((uint64_t)r.v[0] * (uint64_t)init_clusters) >> 32);
+        const int z = label0 + (int)(((uint64_t)r.v[0] * (uint64_t)init_clusters) >> 32);
         bins[i] = 2 * z + (int)(r.v[1] & 1u);
     }
 }
@@ -99,6 +99,65 @@ __global__ void reset_sub_kernel(int32_t *bins, int64_t n, int64_t first, const 
             bins[i] = 2 * z + (int)(r.v[0] & 1u);
         }
     }
+}
+
+// reset_bad_clusters! without a host round trip: the sub-cluster occupancies (global over all shards) decide on the device
+// which clusters are "bad" (an empty sub-cluster, local_clusters_actions.jl:501-516); flags[K] = any.
+__global__ void bad_flags_kernel(const int32_t *__restrict__ bin_total, const long long *__restrict__ global_counts, int K,
+                                 uint8_t *__restrict__ flags) {
+    __shared__ int any;
+    if (threadIdx.x == 0) any = 0;
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const long long a = global_counts ? global_counts[2 * k] : (long long)bin_total[2 * k];
+        const long long b = global_counts ? global_counts[2 * k + 1] : (long long)bin_total[2 * k + 1];
+        const int bad = (a == 0 || b == 0) ? 1 : 0;
+        flags[k] = (uint8_t)bad;
+        if (bad) atomicOr(&any, 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) flags[K] = (uint8_t)any;
+}
+hipError_t launch_bad_flags(const int32_t *bin_total, const long long *global_counts, int K, uint8_t *flags, hipStream_t s) {
+    hipLaunchKernelGGL(bad_flags_kernel, dim3(1), dim3(256), 0, s, bin_total, global_counts, K, flags);
+    return hipGetLastError();
+}
+__global__ void reset_sub_flagged_kernel(int32_t *bins, int64_t n, int64_t first, const uint8_t *__restrict__ flags, int K, uint64_t seed,
+                                         uint32_t epoch) {
+    if (!flags[K]) return;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int z = bins[i] >> 1;
+        if ((unsigned)z < (unsigned)K && flags[z]) {
+            const Philox4 r = philox4x32_10(seed, (uint64_t)(first + i), epoch, STREAM_RESET);
+            bins[i] = 2 * z + (int)(r.v[0] & 1u);
+        }
+    }
+}
+hipError_t launch_reset_sub_flagged(int32_t *bins, int64_t n, int64_t first, const uint8_t *flags, int K, uint64_t seed, uint32_t epoch,
+                                    hipStream_t s) {
+    hipLaunchKernelGGL(reset_sub_flagged_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, n, first, flags, K, seed, epoch);
+    return hipGetLastError();
+}
+__global__ void widen_counts_kernel(const int32_t *__restrict__ src, long long *__restrict__ dst, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = (long long)src[i];
+}
+hipError_t launch_widen_counts(const int32_t *src, long long *dst, int n, hipStream_t s) {
+    hipLaunchKernelGGL(widen_counts_kernel, dim3(grid_for(n)), dim3(256), 0, s, src, dst, n);
+    return hipGetLastError();
+}
+// dst[3k+w][0..D) = src[3*slot[k]+w][0..D)  (Multinomial parameter rows from the slot-indexed staging; padding beyond D is zeroed)
+__global__ void gather_rows_kernel(float *__restrict__ dst, int64_t ld_dst, const float *__restrict__ src, int64_t ld_src,
+                                   const int32_t *__restrict__ slot, int rows, int D) {
+    const int64_t total = (int64_t)rows * ld_dst;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(e / ld_dst), d = (int)(e - (int64_t)j * ld_dst);
+        const size_t sj = slot ? (size_t)(3 * slot[j / 3] + j % 3) : (size_t)j;
+        dst[e] = d < D ? src[sj * ld_src + d] : 0.f;
+    }
+}
+hipError_t launch_gather_rows(float *dst, int64_t ld_dst, const float *src, int64_t ld_src, const int32_t *slot, int rows, int D, hipStream_t s) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((int64_t)rows * ld_dst)), dim3(256), 0, s, dst, ld_dst, src, ld_src, slot, rows, D);
+    return hipGetLastError();
 }
 
 // Per-step host<->device transfers go through pinned (GPU-addressable) staging and this kernel instead of
@@ -297,8 +356,8 @@ hipError_t launch_predict_finish(const float *table, int64_t stride, int rstep, 
     return hipGetLastError();
 }
 
-hipError_t launch_init_labels(int32_t *bins, int64_t n, int64_t first, int init_clusters, uint64_t seed, uint32_t epoch, hipStream_t s) {
-    hipLaunchKernelGGL(init_labels_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, n, first, init_clusters, seed, epoch);
+hipError_t launch_init_labels(int32_t *bins, int64_t n, int64_t first, int init_clusters, int label0, uint64_t seed, uint32_t epoch, hipStream_t s) {
+    hipLaunchKernelGGL(init_labels_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, n, first, init_clusters, label0, seed, epoch);
     return hipGetLastError();
 }
 hipError_t launch_bins_from_i64(int32_t *bins, const int64_t *labels, const int64_t *sub, int64_t n, hipStream_t s) {

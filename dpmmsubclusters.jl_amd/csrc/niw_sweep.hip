@@ -227,8 +227,10 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
     const bool owner = lane < C::WPTS;  // lane `lane` draws for point `lane` of the wave
 
     QuadEval<NB, NG, CH> ev;
+    unsigned nw_tiles = 0, nw_full = 0, nw_tail = 0;   // executed-work counters of this wave (wave-uniform)
 
     for (int64_t tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
+        ++nw_tiles;
         const int64_t wbase = tile * C::TILE + (int64_t)wave * C::WPTS;  // first point of this wave
         // ---- x tile -> registers (B-operand layout)
         f32x4 x[NG][NB];
@@ -262,6 +264,7 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
 #pragma unroll
             for (int n = 0; n < NG; ++n) q[n] = 0.f;
             eval_matrix<NB, NG, CH>(ev, lds, A.Rp + (size_t)(3 * k) * C::MATSZ, Rnext, x, mu, q, lane, true);
+            ++nw_full;
             const float qs = reduce_select<NG>(q, g);
             const float a = A.tdf ? A.cst[3 * k] - A.tdf[6 * k + 1] * log1pf(qs / A.tdf[6 * k])
                                   : __builtin_fmaf(-0.5f, qs, A.cst[3 * k]);
@@ -314,6 +317,7 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
                 }
             }
             for (int pr = 0; 2 * pr < K; ++pr) {
+                ++nw_tail;
                 const unsigned far2 = tail_pair_far(tail_load_pair(A.tail, pr), xt, my_thr);
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
@@ -430,6 +434,7 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
 #pragma unroll
                 for (int n = 0; n < NG; ++n) q[n] = 0.f;
                 eval_matrix<NB, NG, CH>(ev, lds, Rcur, Rnext, x, mu, q, lane, wave_has);
+                if (wave_has) ++nw_full;
                 const float qs = reduce_select<NG>(q, g);
                 const float b = __builtin_fmaf(-0.5f, qs, A.cst[j]);
                 if (valid && z == kcur) {
@@ -442,6 +447,10 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
             const int sl = draw2(b0, b1, u_sub);
             A.bins[myp] = 2 * z + sl;
         }
+    }
+    if (A.work && lane == 0) {
+        atomicAdd(&A.work[0], (unsigned long long)nw_tiles); atomicAdd(&A.work[1], (unsigned long long)nw_full);
+        atomicAdd(&A.work[3], (unsigned long long)nw_tail);
     }
 }
 
@@ -583,8 +592,10 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
     // (Also touching the next tile's X lines to pull them into L2 was measured: no gain, +30 % HBM traffic.)
     int nx_p = -1, nx_bin = -1;
     int64_t nx_tile = -1;
+    unsigned nw_tiles = 0, nw_full = 0, nw_scr = 0, nw_tail = 0;   // executed-work counters of this wave (wave-uniform)
     for (int64_t tile = wave_id; tile < nwtiles; tile += nwaves) {
         const int64_t wbase = tile * WPTS;
+        ++nw_tiles;
         STAMP(s0);
         const int64_t mypos = wbase + lane;    // position in processing order
         const bool valid = owner && mypos < A.n;
@@ -658,6 +669,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                 const float *Rnext = (k + 1 < K) ? A.Rp + (size_t)(3 * (k + 1)) * MATSZ : nullptr;
                 STAMP(q0);
                 const float qs = quad_stream<NB, NG>(Rcur, Rnext, A.mup + (size_t)(3 * (k + 1)) * DP, rb0, mu, x, lane, g, true, tot_all);
+                ++nw_full;
                 STAMP(q1);
                 const float a = A.tdf ? A.cst[3 * k] - A.tdf[6 * k + 1] * log1pf(qs / A.tdf[6 * k])
                                       : __builtin_fmaf(-0.5f, qs, A.cst[3 * k]);
@@ -689,6 +701,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
             for (int n = 0; n < NG; ++n) bestn[n] = -INFINITY;
             auto full_eval = [&](int k, const float *Rnext, const float *mup_next) {
                 const float qs = quad_stream<NB, NG>(A.Rp + (size_t)(3 * k) * MATSZ, Rnext, mup_next, rb0, mu, x, lane, g, true, tot_all);
+                ++nw_full;
                 const float c = A.cst[3 * k];
 #pragma unroll
                 for (int n = 0; n < NG; ++n) {
@@ -810,6 +823,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                     for (int n = 0; n < NG; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj], zz[n][jj], acc[n], 0, 0, 0);
             };
             auto finish = [&](int k, float c, const f32x4 (&acc)[NG]) {
+                ++nw_scr;
 #ifdef DPMM_STAMPS
                 ++N_scr;
 #endif
@@ -850,6 +864,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                         const int sh = 2 * pr - base;
                         const unsigned bits2 = (unsigned)(cand >> sh) & 3u;
                         if (!bits2) continue;
+                        ++nw_tail;
 #ifdef DPMM_STAMPS
                         N_tail += __builtin_popcount(bits2);
 #endif
@@ -988,6 +1003,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                                                                           knext >= 0 ? A.Rp + (size_t)jn * MATSZ : nullptr,
                                                                           A.mup + (size_t)jn * DP, rb0, mu, x, lane, g, true, tot_all), A.cst[jr]);
             if (valid && z == kcur) { b0 = bl; b1 = br; }
+            nw_full += 2;
             kcur = knext;
         }
         if (valid) A.bins[myp] = 2 * z + draw2(b0, b1, u_sub);
@@ -996,6 +1012,10 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
 #ifdef DPMM_STAMPS
         T_draw += s3 - s2; T_p2 += s4 - s3; T_tot += s4 - s0; T_x += s1 - s0; ++ntile;
 #endif
+    }
+    if (A.work && lane == 0) {
+        atomicAdd(&A.work[0], (unsigned long long)nw_tiles); atomicAdd(&A.work[1], (unsigned long long)nw_full);
+        atomicAdd(&A.work[2], (unsigned long long)nw_scr); atomicAdd(&A.work[3], (unsigned long long)nw_tail);
     }
 #ifdef DPMM_STAMPS
     if (lane == 0 && A.dbg) {
@@ -1031,32 +1051,11 @@ static hipError_t launch_cfg(const NiwSweepArgs &a, int grid, hipStream_t s) {
     return hipGetLastError();
 }
 
-// D=64 configuration (dev-tunable through DPMM_NIW_D64_CFG: "NG,OCC")
-static int d64_ng() {
-    static int ng = [] { const char *e = getenv("DPMM_NIW_D64_CFG"); return e ? atoi(e) : 4; }();
-    return ng;
-}
-static int d64_occ() {
-    static int occ = [] { const char *e = getenv("DPMM_NIW_D64_CFG"); const char *c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : 2; }();
-    return occ;
-}
-static hipError_t niw_direct_d64(const NiwSweepArgs &a, int grid, hipStream_t s) {
-    const int ng = d64_ng(), occ = d64_occ();
-    if (ng == 4) return launch_direct<4, 4, 2>(a, grid, s);
-    if (ng == 2 && occ == 2) return launch_direct<4, 2, 2>(a, grid, s);
-    if (ng == 2 && occ == 3) return launch_direct<4, 2, 3>(a, grid, s);
-    if (ng == 2) return launch_direct<4, 2, 4>(a, grid, s);
-    if (ng == 1) return launch_direct<4, 1, 4>(a, grid, s);
-    return hipErrorInvalidValue;
-}
-int niw_occupancy(int NB) {
-    if (NB == 4) return d64_ng() == 4 ? 2 : d64_occ();
-    return NB <= 8 ? 2 : 1;
-}
+int niw_occupancy(int NB) { return NB <= 8 ? 2 : 1; }
 
 int niw_tile_points(int NB) {
     switch (NB) {
-        case 4: return 64 * d64_ng();
+        case 4: return 256;
         case 1: case 2: return 256;
         case 8: return 128;
         default: return 128;
@@ -1067,7 +1066,7 @@ hipError_t launch_niw_sweep(int NB, const NiwSweepArgs &a, int grid, hipStream_t
     switch (NB) {
         case 1: return launch_direct<1, 4, 4>(a, grid, s);
         case 2: return launch_direct<2, 4, 3>(a, grid, s);
-        case 4: return niw_direct_d64(a, grid, s);
+        case 4: return launch_direct<4, 4, 2>(a, grid, s);
         case 8: return launch_cfg<8, 2, 2>(a, grid, s);
         case 16: return launch_cfg<16, 2, 1>(a, grid, s);
         default: return hipErrorInvalidValue;
@@ -1078,8 +1077,14 @@ hipError_t launch_niw_sweep(int NB, const NiwSweepArgs &a, int grid, hipStream_t
 // Parameter packing: raw R (row-major [3K][D][D], upper triangular) -> MFMA A-fragment image.
 // Rp[j][pair(bi,t)][lane][jj] = R[16 bi + (lane & 15)][16 t + 4 (lane >> 4) + jj], zero beyond D
 // and below the diagonal.  mup[j][DP] = mu zero-padded.
+// `slot` (nullable): packed matrix j = 3k+w is read from source row 3*slot[k]+w (the host keeps a cluster's rows in place for
+// life and only re-orders this map when clusters are removed); cst is always in cluster order.
+__device__ __forceinline__ size_t src_row(const int32_t *__restrict__ slot, int j) {
+    return slot ? (size_t)(3 * slot[j / 3] + j % 3) : (size_t)j;
+}
 __global__ void niw_pack_kernel(const float *__restrict__ R, const float *__restrict__ mu, float *__restrict__ Rp,
-                                float *__restrict__ mup, int D, int NB, int nmat, float *__restrict__ tail, const float *__restrict__ cst) {
+                                float *__restrict__ mup, int D, int NB, int nmat, float *__restrict__ tail, const float *__restrict__ cst,
+                                const int32_t *__restrict__ slot) {
     const int NP = NB * (NB + 1) / 2;
     const int DP = 16 * NB;
     const int64_t total = (int64_t)nmat * NP * 256;
@@ -1095,14 +1100,14 @@ __global__ void niw_pack_kernel(const float *__restrict__ R, const float *__rest
         const int row = 16 * bi + (lane & 15);
         const int col = 16 * t + 4 * (lane >> 4) + jj;
         float v = 0.f;
-        if (row < D && col < D && col >= row) v = R[((size_t)j * D + row) * D + col];
+        if (row < D && col < D && col >= row) v = R[(src_row(slot, j) * D + row) * D + col];
         Rp[e] = v;
     }
     const int64_t totmu = (int64_t)nmat * DP;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < totmu; e += (int64_t)gridDim.x * blockDim.x) {
         const int d = (int)(e % DP);
         const int j = (int)(e / DP);
-        mup[e] = d < D ? mu[(size_t)j * D + d] : 0.f;
+        mup[e] = d < D ? mu[src_row(slot, j) * D + d] : 0.f;
     }
     // Tail records of the cluster-level matrices 3k, stored for cluster PAIRS: tail[pair][q][c], c = 0 / 1 for cluster 2 pair + c,
     // q = { T00 T01 T02 T03 | T11 T12 T13 T22 | T23 T33 m0 m1 | m2 m3 cst_k 0 },  T = R[D-4:D, D-4:D], m = mu[D-4:D].
@@ -1111,13 +1116,13 @@ __global__ void niw_pack_kernel(const float *__restrict__ R, const float *__rest
         const int f0 = D - 4, K = nmat / 3, NPR = (K + 1) / 2;
         for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)NPR * 32; e += (int64_t)gridDim.x * blockDim.x) {
             const int c = (int)(e & 1), q = (int)((e >> 1) & 15), k = 2 * (int)(e >> 5) + c;
-            const size_t j = (size_t)(3 * k);
+            const size_t j = k < K ? src_row(slot, 3 * k) : 0;
             const int tr[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3}, tc[10] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3};
             float v = 0.f;
             if (k >= K) v = (q == 14) ? -INFINITY : 0.f;
             else if (q < 10) v = R[(j * D + f0 + tr[q]) * D + f0 + tc[q]];
             else if (q < 14) v = mu[j * D + f0 + (q - 10)];
-            else if (q == 14) v = cst[j];
+            else if (q == 14) v = cst[3 * k];
             tail[e] = v;
         }
     }
@@ -1128,11 +1133,12 @@ __global__ void niw_pack_kernel(const float *__restrict__ R, const float *__rest
 //   dist[k][j] = || mu_k - mu_j ||_2
 // Thread c solves R v = e_c by back substitution (column c of R^-1); v lives in LDS.
 __global__ __launch_bounds__(256) void niw_screen_prep_kernel(const float *__restrict__ R, const float *__restrict__ mu,
-                                                              int D, int K, float *__restrict__ lam, float *__restrict__ dist) {
+                                                              int D, int K, float *__restrict__ lam, float *__restrict__ dist,
+                                                              const int32_t *__restrict__ slot) {
     extern __shared__ float sh[];            // Rk [D*D] | v [D][D+1] | red[256]
     float *Rk = sh, *v = sh + (size_t)D * D, *red = v + (size_t)D * (D + 1);
     const int k = blockIdx.x, tid = threadIdx.x;
-    const float *Rg = R + (size_t)(3 * k) * D * D;
+    const float *Rg = R + src_row(slot, 3 * k) * D * D;
     for (int e = tid; e < D * D; e += blockDim.x) Rk[e] = Rg[e];
     __syncthreads();
     float ss = 0.f;
@@ -1156,23 +1162,24 @@ __global__ __launch_bounds__(256) void niw_screen_prep_kernel(const float *__res
         const float f = red[0];
         lam[k] = (f > 0.f && f == f && f < INFINITY) ? 0.9f / f : 0.f;   // 0 disables the bound for this cluster
     }
-    const float *mk = mu + (size_t)(3 * k) * D;
+    const float *mk = mu + src_row(slot, 3 * k) * D;
     for (int j = tid; j < K; j += blockDim.x) {
-        const float *mj = mu + (size_t)(3 * j) * D;
+        const float *mj = mu + src_row(slot, 3 * j) * D;
         float d2 = 0.f;
         for (int d = 0; d < D; ++d) { const float t = mk[d] - mj[d]; d2 += t * t; }
         dist[(size_t)k * K + j] = sqrtf(d2);
     }
 }
 
-hipError_t launch_niw_screen_prep(const float *R, const float *mu, int D, int K, float *lam, float *dist, hipStream_t s) {
+hipError_t launch_niw_screen_prep(const float *R, const float *mu, int D, int K, float *lam, float *dist, const int32_t *slot, hipStream_t s) {
     const size_t lds = sizeof(float) * ((size_t)D * D + (size_t)D * (D + 1) + 256);
-    hipLaunchKernelGGL(niw_screen_prep_kernel, dim3(K), dim3(256), lds, s, R, mu, D, K, lam, dist);
+    hipLaunchKernelGGL(niw_screen_prep_kernel, dim3(K), dim3(256), lds, s, R, mu, D, K, lam, dist, slot);
     return hipGetLastError();
 }
 
-hipError_t launch_niw_pack(const float *R, const float *mu, float *Rp, float *mup, int D, int NB, int nmat, float *tail, const float *cst, hipStream_t s) {
-    hipLaunchKernelGGL(niw_pack_kernel, dim3(512), dim3(256), 0, s, R, mu, Rp, mup, D, NB, nmat, tail, cst);
+hipError_t launch_niw_pack(const float *R, const float *mu, float *Rp, float *mup, int D, int NB, int nmat, float *tail, const float *cst,
+                           const int32_t *slot, hipStream_t s) {
+    hipLaunchKernelGGL(niw_pack_kernel, dim3(512), dim3(256), 0, s, R, mu, Rp, mup, D, NB, nmat, tail, cst, slot);
     return hipGetLastError();
 }
 

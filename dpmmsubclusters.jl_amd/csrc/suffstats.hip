@@ -31,8 +31,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------ sort
 __global__ __launch_bounds__(64) void hist_kernel(const int32_t *__restrict__ bins, int64_t n, int nbins, int nt,
-                                                  int32_t *__restrict__ tile_hist) {
+                                                  int32_t *__restrict__ tile_hist, const uint8_t *__restrict__ only_if) {
     extern __shared__ int cnt[];
+    if (only_if && !*only_if) return;
     const int lane = threadIdx.x;
     for (int b = lane; b < nbins; b += 64) cnt[b] = 0;
     __syncthreads();
@@ -49,8 +50,10 @@ __global__ __launch_bounds__(64) void hist_kernel(const int32_t *__restrict__ bi
 }
 
 // exclusive scan over the tiles of one bin (in place) + bin total
-__global__ __launch_bounds__(256) void scan_tiles_kernel(int32_t *__restrict__ tile_hist, int nt, int32_t *__restrict__ bin_total) {
+__global__ __launch_bounds__(256) void scan_tiles_kernel(int32_t *__restrict__ tile_hist, int nt, int32_t *__restrict__ bin_total,
+                                                         const uint8_t *__restrict__ only_if) {
     __shared__ int part[256];
+    if (only_if && !*only_if) return;
     int32_t *row = tile_hist + (int64_t)blockIdx.x * nt;
     const int per = (nt + 255) / 256;
     const int lo = threadIdx.x * per, hi = min(lo + per, nt);
@@ -152,11 +155,11 @@ __global__ __launch_bounds__(64) void scatter_kernel(const int32_t *__restrict__
     }
 }
 
-hipError_t launch_sort_by_bin(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s) {
+hipError_t launch_sort_by_bin(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s, const uint8_t *only_if) {
     const int nt = (int)((n + SORT_TILE - 1) / SORT_TILE);
     if (nt == 0) return hipSuccess;
-    hipLaunchKernelGGL(hist_kernel, dim3(nt), dim3(64), nbins * sizeof(int), s, bins, n, nbins, nt, b.tile_hist);
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(nbins), dim3(256), 0, s, b.tile_hist, nt, b.bin_total);
+    hipLaunchKernelGGL(hist_kernel, dim3(nt), dim3(64), nbins * sizeof(int), s, bins, n, nbins, nt, b.tile_hist, only_if);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(nbins), dim3(256), 0, s, b.tile_hist, nt, b.bin_total, only_if);
     return hipGetLastError();
 }
 
@@ -392,8 +395,7 @@ hipError_t launch_niw_stats(const StatsArgs &a0, hipStream_t s) {
     const int NBK = niw_nbk(a.D);
     // two resident waves per SIMD at D = 64 (register budget): 2048 workgroups cover the chip once; every workgroup
     // gets the same number of items, so nothing is gained from a longer grid
-    static const int groups_env = [] { const char *e = getenv("DPMM_STATS_GROUPS"); return e ? atoi(e) : 0; }();
-    int groups = groups_env > 0 ? groups_env : (NBK <= 4 ? 2048 : 1024);
+    int groups = a.range_groups > 0 ? a.range_groups : (NBK <= 4 ? 2048 : 1024);
     const int max_items = a.max_items < 1 ? 1 : a.max_items;
     if (groups > max_items) groups = max_items;
     a.range_groups = groups;

@@ -218,7 +218,7 @@ def fit(all_data, *args, iters=100, init_clusters=1, seed=None, verbose=True, sa
                                                      smart_splits, **kw)
     s = dp_model.sampler
     clusters = s.prior.distributions(s.params, [3 * k for k in range(s.K)])
-    return (dp_model.labels, clusters, s.weights.copy(), iter_count, nmi, lik, kh, dp_model.labels_subcluster, dp_model)
+    return (dp_model.labels, clusters, s.weights, iter_count, nmi, lik, kh, dp_model.labels_subcluster, dp_model)
 
 
 def predict(dp_model, data, device=None, worker_factory=None):
@@ -227,22 +227,20 @@ def predict(dp_model, data, device=None, worker_factory=None):
     log-density (GPU), labels = row-wise argmax, probabilities = normalised exponentials (NaN -> -Inf).
     `data` is Dimensions x Samples.  Returns (labels (n,) Int64 1-based, probs (n, K) Float32)."""
     s = dp_model.sampler
+    post = s.post
     X = np.ascontiguousarray(np.asarray(data, dtype=np.float32).T)
     n, D = X.shape
     if D != s.prior.dim:
         raise ValueError("data dimension does not match the model")
     w = s.points_count.astype(np.float64) + s.alpha
     w = (w / w.sum()).astype(np.float32)
-    if getattr(s, "leader_mode", False):          # collective: the posteriors live on the leader only
-        for key in sorted(s.post):
-            s.comm.broadcast(s.post[key])
     dev = getattr(s.wk, "device", 0) if device is None else device
     wk = (worker_factory or binding.Worker)(s.prior.kind, D, n, first_index=0, device=dev, seed=0)
     try:
         wk.upload_points(X)
         if getattr(wk, "supports_predict_points", False):     # argmax + normalisation on the device as well
-            return s.prior.predictive_table(wk, s.post, [3 * k for k in range(s.K)], w, points=True)
-        parr = s.prior.predictive_table(wk, s.post, [3 * k for k in range(s.K)], w).T.astype(np.float32)   # (n, K)
+            return s.prior.predictive_table(wk, post, [3 * k for k in range(s.K)], w, points=True)
+        parr = s.prior.predictive_table(wk, post, [3 * k for k in range(s.K)], w).T.astype(np.float32)   # (n, K)
     finally:
         wk.close()
     with np.errstate(invalid="ignore"):

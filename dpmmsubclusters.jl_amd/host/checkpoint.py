@@ -76,7 +76,8 @@ def read_params(model_params):
 
 
 # ------------------------------------------------------------------------------------------------ save / load
-_SAMPLER_ARRAYS = ("N", "sums", "S", "lr_weights", "weights", "splittable", "hist", "points_count")
+# cluster state of the native engine that a checkpoint carries (cluster order; posteriors are recomputed from the statistics)
+_STATE_FIELDS = ("packed", "lr_weights", "weights", "splittable", "hist", "points_count", "counters")
 
 
 def _prior_to_dict(prior):
@@ -96,31 +97,26 @@ def checkpoint_filename(path, prefix, it):
 
 
 def save_model(sampler, path, prefix, it, total_time, global_params="none"):
-    """Collective (every rank calls it): labels are gathered, rank 0 writes the file and returns its name."""
+    """Collective (every rank calls it): labels are gathered, rank 0 writes the file and returns its name.  The file holds
+    what the reference's pts_less_group holds (dp-parallel-sampling.jl:450-455, ds.jl:60-66): labels, sub-labels and the
+    cluster state -- here the packed statistics of every (cluster, sub-cluster), the burn-in histories, weights and the
+    epoch counters of the counter-based RNG, so that a resumed run continues the SAME chain."""
     labels, sub = sampler.comm.gather_labels(sampler.wk)
-    if getattr(sampler, "leader_mode", False):        # posteriors / parameters live on the leader; it is also the writer
-        pass
     if sampler.comm.rank != 0:
         return None
-    d = dict(format="dpmm-checkpoint-1", iter=int(it), total_time=float(total_time), global_params=str(global_params),
+    m = sampler.model
+    d = dict(format="dpmm-checkpoint-2", iter=int(it), total_time=float(total_time), global_params=str(global_params),
              labels=labels.astype(np.int64), labels_subcluster=sub.astype(np.int64), K=int(sampler.K),
              alpha=float(sampler.alpha), total_dim=int(sampler.n_total), seed=np.uint64(sampler.seed),
-             burnout=int(sampler.burnout), epoch=int(sampler.epoch), draw_epoch=int(sampler.draw_epoch),
-             smart_splits=bool(sampler.smart_splits), max_split_iter=int(sampler.max_split_iter), hard_clustering=bool(sampler.hard_clustering),
-             rng_state=json.dumps(sampler.rng.bit_generator.state, default=lambda o: o.tolist() if hasattr(o, "tolist") else int(o)))
+             burnout=int(sampler.burnout), argmax_sample_stop=int(sampler.argmax_sample_stop), split_stop=int(sampler.split_stop),
+             smart_splits=bool(sampler.smart_splits), max_split_iter=int(sampler.max_split_iter), hard_clustering=bool(sampler.hard_clustering))
     d.update(_prior_to_dict(sampler.prior))
     if sampler.outlier_weight > 0:
         d["outlier_weight"] = float(sampler.outlier_weight)
         d.update({"out_" + k: v for k, v in _prior_to_dict(sampler.outlier_prior).items()})
-        for k, v in (sampler._outlier_params or {}).items():
-            d["outpar_" + k] = np.asarray(v)
-    for k in _SAMPLER_ARRAYS:
-        v = getattr(sampler, k)
-        if v is not None:
-            d["s_" + k] = np.asarray(v)
-    for k, v in (sampler.post or {}).items():
-        d["post_" + k] = np.asarray(v)
-    for k, v in (sampler.params or {}).items():
+    for k in _STATE_FIELDS:
+        d["s_" + k] = m.get(k)
+    for k, v in sampler.params.items():
         d["par_" + k] = np.asarray(v)
     fn = checkpoint_filename(path, prefix, it)
     os.makedirs(os.path.dirname(os.path.abspath(fn)), exist_ok=True)
@@ -133,45 +129,38 @@ def save_model(sampler, path, prefix, it, total_time, global_params="none"):
 def load_checkpoint(filename):
     with np.load(filename, allow_pickle=False) as z:
         d = {k: z[k] for k in z.files}
-    if str(d.get("format")) != "dpmm-checkpoint-1":
-        raise ValueError(f"{filename} is not a checkpoint of this package")
+    if str(d.get("format")) != "dpmm-checkpoint-2":
+        raise ValueError(f"{filename} is not a checkpoint of this package (format {d.get('format')})")
     return d
 
 
 def restore_sampler(sampler, ck):
     """Put a freshly built sampler (points uploaded, no clusters yet) into the saved state.  `ck` from load_checkpoint."""
     K = int(ck["K"])
-    sampler._alloc(K)
+    if int(ck["burnout"]) != sampler.burnout:
+        # the burn-in histories are burnout+5 wide and the gate averages over exactly `burnout` entries (shared_actions.jl:51-63)
+        raise ValueError(f"checkpoint was written with burnout={int(ck['burnout'])}; resuming with burnout={sampler.burnout} is not supported")
+    for k in ("smart_splits", "hard_clustering"):
+        if k in ck:
+            setattr(sampler, k, bool(ck[k]))
+    for k in ("max_split_iter", "argmax_sample_stop", "split_stop"):
+        if k in ck:
+            setattr(sampler, k, int(ck[k]))
+    if "outlier_weight" in ck:
+        sampler.outlier_weight = float(ck["outlier_weight"])
+        sampler.outlier_prior = _prior_from_dict({k[4:]: v for k, v in ck.items() if k.startswith("out_")})
+    sampler._configure()
     lo = getattr(sampler.wk, "first_index", 0)
     n = sampler.wk.n
     sampler.wk.set_labels(ck["labels"][lo:lo + n], ck["labels_subcluster"][lo:lo + n])
     sampler.wk.set_num_clusters(K)
-    for k in _SAMPLER_ARRAYS:
-        if "s_" + k in ck:
-            setattr(sampler, k, np.array(ck["s_" + k]))
-    post = {k[5:]: np.array(v) for k, v in ck.items() if k.startswith("post_")}
-    sampler.post = post or None
-    par = {k[4:]: np.array(v) for k, v in ck.items() if k.startswith("par_")}
-    sampler.params = par or None
-    for k in ("smart_splits", "hard_clustering"):
-        if k in ck:
-            setattr(sampler, k, bool(ck[k]))
-    if "max_split_iter" in ck:
-        sampler.max_split_iter = int(ck["max_split_iter"])
-    if "outlier_weight" in ck:
-        sampler.outlier_weight = float(ck["outlier_weight"])
-        sampler.outlier_prior = _prior_from_dict({k[4:]: v for k, v in ck.items() if k.startswith("out_")})
-        sampler._outlier_params = {k[7:]: np.array(v) for k, v in ck.items() if k.startswith("outpar_")}
-    sampler.epoch = int(ck["epoch"])
-    sampler.draw_epoch = int(ck["draw_epoch"])
-    st = json.loads(str(ck["rng_state"]))
-    def fix(o):
-        if isinstance(o, dict):
-            return {k: fix(v) for k, v in o.items()}
-        if isinstance(o, list):
-            return np.array(o, dtype=np.uint64)
-        return o
-    sampler.rng.bit_generator.state = fix(st)
+    m = sampler.model
+    m.set("K", K)
+    for k in _STATE_FIELDS:
+        m.set(k, ck["s_" + k])
+    for k, v in ck.items():
+        if k.startswith("par_"):
+            m.set(k[4:], v)
     return sampler
 
 

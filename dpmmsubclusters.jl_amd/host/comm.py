@@ -1,4 +1,6 @@
-"""Cross-GPU exchange of the sweep: ONE all-reduce(sum) of the packed sufficient statistics.
+"""Cross-GPU plumbing around the sweep.  The exchange itself -- ONE all-reduce(sum) of the packed sufficient statistics per
+statistics pass -- runs INSIDE libdpmmhip.so (dpmm_comm_init + dpmm_step_stats / dpmm_suffstats_host: RCCL on the ctx stream);
+this module ships the RCCL unique id, gathers labels for results, and sums the small evaluation tables.
 
 Replaces the reference's two-level tree reduce of `thin_suff_stats` dicts
 (create_suff_stats_dict_node_leader / update_suff_stats_posterior!,
@@ -33,17 +35,27 @@ class TorchDistComm:
             self._buf = t.empty(n, dtype=t.float64, device=dev)
         return self._buf[:n]
 
-    def reduce_stats(self, worker, idx):
-        n = 2 * worker.K * worker.packed_stride
-        buf = self._buffer(n)
+    def attach(self, worker):
+        """Multi-GPU: create the RCCL communicator INSIDE libdpmmhip.so (dpmm_comm_init); from then on the worker's statistics
+        calls return rows summed over all ranks.  torch.distributed only ships the 128-byte unique id."""
+        if self.backend != "nccl":
+            return
+        uid = [worker.comm_unique_id() if self.rank == 0 else None]
+        self.dist.broadcast_object_list(uid, src=0)
+        worker.comm_init(uid[0], self.rank, self.world)
+
+    def allreduce_np(self, arr):
+        """Sum of a Float64 numpy array over the ranks (CPU test workers; the GPU path reduces inside libdpmmhip.so)."""
+        t = self.torch.from_numpy(np.ascontiguousarray(arr, np.float64).copy())
         if self.backend == "nccl":
-            worker.suffstats_packed_device(buf.data_ptr(), idx)   # stream-synchronised inside
-            self.dist.all_reduce(buf)
-            return buf.cpu().numpy().reshape(2 * worker.K, worker.packed_stride)
-        local = worker.suffstats_packed(idx)
-        buf.copy_(self.torch.from_numpy(local.ravel()))
-        self.dist.all_reduce(buf)
-        return buf.numpy().reshape(2 * worker.K, worker.packed_stride).copy()
+            t = t.to(f"cuda:{self.device}")
+        self.dist.all_reduce(t)
+        return t.cpu().numpy()
+
+    def allgather_bytes(self, buf):
+        objs = [None] * self.world
+        self.dist.all_gather_object(objs, bytes(buf))
+        return objs
 
     def gather_labels(self, worker):
         lab, sub = worker.get_labels()

@@ -1,0 +1,251 @@
+// hostmath.h -- per-distribution dense maths of the master side (shared by the batch entry points in dpmm_host.cpp and
+// the sweep engine in dpmm_model.cpp).  Reference functions restated (paths relative to the reference checkout):
+//   calc_posterior           src/priors/niw.jl:20-31
+//   sample_distribution      src/priors/niw.jl:34-40          (Sigma ~ InvWishart(nu, nu psi), mu ~ N(m, Sigma/kappa))
+//   log_marginal_likelihood  src/priors/niw.jl:53-62, src/priors/multinomial_prior.jl:34-39
+//   log_multivariate_gamma   src/utils.jl:66-72
+//   sample_distribution      src/priors/multinomial_prior.jl:23-25 (log of a Dirichlet draw)
+//
+// Sampling without ever forming Sigma: with Psi = nu psi = U U' (U upper triangular, "reverse" Cholesky) and A
+// lower-triangular Bartlett (A_ii^2 ~ chi2(nu - i), A_ij ~ N(0,1), i > j),
+//   Sigma^-1 = W = (U^-T A)(U^-T A)' ~ Wishart(nu, Psi^-1),   R := A' U^-1  (upper),  W = R'R
+// so the GPU's factor R comes out of one triangular solve, logdet Sigma = -2 sum log R_ii, and
+// mu = m + R^-1 xi / sqrt(kappa).
+#pragma once
+#include <algorithm>
+
+#include "hostlib.h"
+
+namespace dpmmh {
+
+// Psi (row-major, symmetric, D x D) = U U', U upper triangular (row-major, zeros below the diagonal).
+// Returns false when Psi is not positive definite.
+inline bool reverse_cholesky(const double *P, int D, double *U) {
+    memset(U, 0, sizeof(double) * (size_t)D * D);
+    for (int j = D - 1; j >= 0; --j) {
+        double s = P[(size_t)j * D + j];
+        const double *uj = U + (size_t)j * D;
+#pragma omp simd reduction(- : s)
+        for (int k = j + 1; k < D; ++k) s -= uj[k] * uj[k];
+        if (!(s > 0.0)) return false;
+        const double ujj = sqrt(s);
+        U[(size_t)j * D + j] = ujj;
+        const double inv = 1.0 / ujj;
+        for (int i = 0; i < j; ++i) {
+            double t = P[(size_t)i * D + j];
+            const double *ui = U + (size_t)i * D;
+#pragma omp simd reduction(- : t)
+            for (int k = j + 1; k < D; ++k) t -= ui[k] * uj[k];
+            U[(size_t)i * D + j] = t * inv;
+        }
+    }
+    return true;
+}
+
+// log det of a symmetric positive definite matrix (row-major, D x D; destroyed) = 2 sum log diag of its factor;
+// NaN when it is not positive definite.  Same elimination order as reverse_cholesky, factor kept in place.
+inline double logdet_spd_inplace(double *P, int D) {
+    double ld = 0.0;
+    for (int j = D - 1; j >= 0; --j) {
+        double s = P[(size_t)j * D + j];
+        double *uj = P + (size_t)j * D;
+#pragma omp simd reduction(- : s)
+        for (int k = j + 1; k < D; ++k) s -= uj[k] * uj[k];
+        if (!(s > 0.0)) return NAN;
+        const double ujj = sqrt(s);
+        ld += log(ujj);
+        const double inv = 1.0 / ujj;
+        for (int i = 0; i < j; ++i) {
+            double *ui = P + (size_t)i * D;
+            double t = ui[j];
+#pragma omp simd reduction(- : t)
+            for (int k = j + 1; k < D; ++k) t -= ui[k] * uj[k];
+            ui[j] = t * inv;
+        }
+    }
+    return 2.0 * ld;
+}
+
+// priors/niw.jl:20-31 for one statistic set; psi_out symmetric.  N == 0 -> prior.
+inline void niw_posterior_one(int D, double k0, double v0, const double *m0, const double *psi0, double N, const double *sum,
+                              const double *S, double *kap, double *nu, double *m, double *psi) {
+    if (N == 0.0) {
+        *kap = k0; *nu = v0;
+        memcpy(m, m0, sizeof(double) * D);
+        memcpy(psi, psi0, sizeof(double) * (size_t)D * D);
+        return;
+    }
+    const double k1 = k0 + N, v1 = v0 + N;
+    *kap = k1; *nu = v1;
+    for (int a = 0; a < D; ++a) m[a] = (m0[a] * k0 + sum[a]) / k1;
+    for (int a = 0; a < D; ++a)
+        for (int b = 0; b <= a; ++b) {
+            const double sab = 0.5 * (S[(size_t)a * D + b] + S[(size_t)b * D + a]);
+            const double pab = 0.5 * (psi0[(size_t)a * D + b] + psi0[(size_t)b * D + a]);
+            const double v = (v0 * pab + k0 * m0[a] * m0[b] - k1 * m[a] * m[b] + sab) / v1;
+            psi[(size_t)a * D + b] = v;
+            psi[(size_t)b * D + a] = v;
+        }
+}
+
+// Same posterior, from PACKED statistics rows {N, sum[D], lower triangle of S} (include/dpmm_hip.h): the statistic set is
+// cl * (row l) + cr * (row r) (cluster = left + right: cl = cr = 1).  Writes kappa, nu, m and the SCALE matrix
+// P = nu' psi' (full, symmetric) that the factorisation consumes -- the full S is never materialised.
+inline double niw_posterior_packed(int D, double k0, double v0, const double *m0, const double *psi0, const double *l,
+                                   const double *r, double cl, double cr, double *kap, double *nu, double *m, double *P) {
+    const double N = cl * l[0] + cr * r[0];
+    if (N == 0.0) {
+        *kap = k0; *nu = v0;
+        memcpy(m, m0, sizeof(double) * D);
+        for (size_t e = 0; e < (size_t)D * D; ++e) P[e] = psi0[e] * v0;
+        return N;
+    }
+    const double k1 = k0 + N, v1 = v0 + N;
+    *kap = k1; *nu = v1;
+    const double *sl = l + 1, *sr = r + 1, *tl = l + 1 + D, *tr = r + 1 + D;
+    for (int a = 0; a < D; ++a) m[a] = (m0[a] * k0 + (cl * sl[a] + cr * sr[a])) / k1;
+    for (int a = 0; a < D; ++a) {
+        const size_t t0 = (size_t)a * (a + 1) / 2;
+        for (int b = 0; b <= a; ++b) {
+            const double sab = cl * tl[t0 + b] + cr * tr[t0 + b];
+            const double pab = 0.5 * (psi0[(size_t)a * D + b] + psi0[(size_t)b * D + a]);
+            const double v = ((v0 * pab + k0 * m0[a] * m0[b] - k1 * m[a] * m[b] + sab) / v1) * v1;   // psi' then nu' psi' (niw.jl:29,35)
+            P[(size_t)a * D + b] = v;
+            P[(size_t)b * D + a] = v;
+        }
+    }
+    return N;
+}
+
+// utils.jl:66-72.  f32_quirk: the reference's accumulator is a Float32 local.
+inline double log_multivariate_gamma(double x, int D, bool f32_quirk) {
+    int sg;
+    if (f32_quirk) {
+        float res = (float)((double)D * (D - 1) / 4.0 * log(M_PI));
+        for (int d = 1; d <= D; ++d) res = (float)((double)res + lgamma_r(x + (1 - d) / 2.0, &sg));
+        return (double)res;
+    }
+    double res = (double)D * (D - 1) / 4.0 * log(M_PI);
+    for (int d = 1; d <= D; ++d) res += lgamma_r(x + (1 - d) / 2.0, &sg);
+    return res;
+}
+
+// priors/niw.jl:53-62 from scalars.  lmg0 = log_multivariate_gamma(nu0 / 2) (constant of the prior).
+inline double niw_log_marginal(int D, double k0, double v0, double logdet_psi0, double lmg0, double k1, double v1,
+                               double logdet_psi1, double N, bool f32_quirk) {
+    return -N * D * 0.5 * log(M_PI) + log_multivariate_gamma(v1 / 2.0, D, f32_quirk) - lmg0 +
+           (v0 / 2.0) * (D * log(v0) + logdet_psi0) - (v1 / 2.0) * (D * log(v1) + logdet_psi1) + (D / 2.0) * log(k0 / k1);
+}
+
+// One draw (mu, R, logdet Sigma) from a prepared posterior (kappa, nu, m, U with nu psi = U U').  `id`/`epoch` key the random
+// streams (normals: stream 16 -- identical whether pre-generated or not; chi-squares: stream 18).  An / xi_in: optional
+// pre-generated standard normals (strictly-lower Bartlett entries row-major [D][D], and xi [D]).
+// scratch: 2 D^2 + 3 D doubles; blk: 8 D doubles.  mu_out [D], R_out [D*D] (upper, zeros below), Float32.
+inline void niw_draw_one(int D, double kappa, double nu, const double *m, const double *Ui, uint64_t seed, uint32_t id,
+                         uint32_t epoch, const double *An, const double *xi_in, double *scratch, double *blk, float *mu_out,
+                         float *R_out, float *logdet_sigma) {
+    const size_t DD = (size_t)D * D;
+    double *A = scratch, *Rl = scratch + DD, *xi = scratch + 2 * DD + D, *v = scratch + 2 * DD + 2 * (size_t)D;
+    Philox rng(seed, id, epoch, 16u), rng_chi(seed, id, epoch, 18u);
+    // Bartlett factor, lower triangular (A[r][c], r >= c)
+    for (int r = 0; r < D; ++r) {
+        for (int c = 0; c < r; ++c) A[(size_t)r * D + c] = An ? An[(size_t)r * D + c] : rng.normal();
+        A[(size_t)r * D + r] = sqrt(2.0 * rng_chi.gamma(0.5 * (nu - r)));
+    }
+    // R = A' U^-1 : row j of R solves r_j U[j:, j:] = A[j:, j]'
+    // JB rows of R at a time share every pass over a row of U (at D = 256 U is 512 KiB: one row of R per pass was
+    // bound by streaming U from L2).  Per row the operations and their order are those of the one-row loop: same bits.
+    memset(Rl, 0, sizeof(double) * DD);
+    double ld = 0.0;
+    constexpr int JB = 8;
+    for (int j0 = 0; j0 < D; j0 += JB) {
+        const int nb = std::min(JB, D - j0);
+        double *ab = blk;                                     // [JB][D], row jb = column j0 + jb of A (zero above the diagonal)
+        for (int jb = 0; jb < nb; ++jb) {
+            double *ar = ab + (size_t)jb * D;
+            for (int r = 0; r < j0 + jb; ++r) ar[r] = 0.0;
+            for (int r = j0 + jb; r < D; ++r) ar[r] = A[(size_t)r * D + j0 + jb];
+        }
+        for (int c = j0; c < D; ++c) {
+            const double *uc = Ui + (size_t)c * D;
+            const double ucc = uc[c];
+            double val[JB];
+            for (int jb = 0; jb < nb; ++jb) {
+                // rows that have not started yet (c < j0 + jb) hold 0 here: val = 0 and the update below is a no-op
+                val[jb] = (c >= j0 + jb) ? ab[(size_t)jb * D + c] / ucc : 0.0;
+                if (c >= j0 + jb) Rl[(size_t)(j0 + jb) * D + c] = val[jb];
+            }
+            for (int jb = 0; jb < nb; ++jb) {
+                if (c < j0 + jb) continue;
+                double *ap = ab + (size_t)jb * D;
+                const double vv = val[jb];
+#pragma omp simd
+                for (int cc = c + 1; cc < D; ++cc) ap[cc] -= vv * uc[cc];
+            }
+        }
+        for (int jb = 0; jb < nb; ++jb) ld += log(Rl[(size_t)(j0 + jb) * D + j0 + jb]);
+    }
+    *logdet_sigma = (float)(-2.0 * ld);
+    // mu = m + R^-1 xi / sqrt(kappa)
+    for (int d = 0; d < D; ++d) xi[d] = xi_in ? xi_in[d] : rng.normal();
+    for (int r = D - 1; r >= 0; --r) {
+        double s = xi[r];
+        const double *rr = Rl + (size_t)r * D;
+#pragma omp simd reduction(- : s)
+        for (int c = r + 1; c < D; ++c) s -= rr[c] * v[c];
+        v[r] = s / rr[r];
+    }
+    const double isk = 1.0 / sqrt(kappa);
+    for (int d = 0; d < D; ++d) mu_out[d] = (float)(m[d] + v[d] * isk);
+    for (size_t e = 0; e < DD; ++e) R_out[e] = (float)Rl[e];
+}
+inline size_t niw_draw_scratch_doubles(int D) { return 2 * (size_t)D * D + 3 * (size_t)D; }
+
+// Standard-normal noise of one draw (see niw_draw_one): depends on (seed, epoch, id) only.
+inline void niw_noise_one(int D, uint64_t seed, uint32_t id, uint32_t epoch, double *A, double *xi) {
+    Philox rng(seed, id, epoch, 16u);
+    for (int r = 0; r < D; ++r)
+        for (int c = 0; c < r; ++c) A[(size_t)r * D + c] = rng.normal();
+    for (int d = 0; d < D; ++d) xi[d] = rng.normal();
+}
+
+// log of a Dirichlet(alpha) draw (priors/multinomial_prior.jl:23-25): logp[d] = log(g_d / sum g), g_d ~ Gamma(alpha_d).
+// Works with log-gammas so that tiny shapes do not underflow: log g = log Gamma(a+1) draw + log(u)/a.   lg: D doubles.
+inline void dirichlet_log_one(int D, const float *al, uint64_t seed, uint32_t id, uint32_t epoch, double *lg, float *logp) {
+    Philox rng(seed, id, epoch, 17u);
+    double mx = -INFINITY;
+    for (int d = 0; d < D; ++d) {
+        const double a = (double)al[d];
+        double l;
+        if (a < 1.0) l = log(rng.gamma(a + 1.0)) + log(rng.uniform()) / a;
+        else l = log(rng.gamma(a));
+        lg[d] = l;
+        if (l > mx) mx = l;
+    }
+    double s = 0.0;
+    for (int d = 0; d < D; ++d) s += exp(lg[d] - mx);
+    const double lse = mx + log(s);
+    for (int d = 0; d < D; ++d) logp[d] = (float)(lg[d] - lse);
+}
+
+// priors/multinomial_prior.jl:34-39 in Float64: lgamma(sum a0) - lgamma(sum a1) + sum (lgamma(a1_d) - lgamma(a0_d)).
+inline double mult_log_marginal(int D, const float *a0, const float *a1) {
+    int sg;
+    double s0 = 0.0, s1 = 0.0, acc = 0.0;
+    for (int d = 0; d < D; ++d) {
+        s0 += (double)a0[d]; s1 += (double)a1[d];
+        acc += lgamma_r((double)a1[d], &sg) - lgamma_r((double)a0[d], &sg);
+    }
+    return lgamma_r(s0, &sg) - lgamma_r(s1, &sg) + acc;
+}
+
+// A two-category Dirichlet / a K+1-category Dirichlet through Gamma draws (Distributions.jl's Dirichlet sampler is
+// un-vendored; the stream is this library's own): stream 20 + caller-chosen id / epoch.
+inline void dirichlet2(double a, double b, uint64_t seed, uint32_t id, uint32_t epoch, uint32_t stream, float out[2]) {
+    Philox rng(seed, id, epoch, stream);
+    const double g0 = rng.gamma(a), g1 = rng.gamma(b);
+    const double s = g0 + g1;
+    out[0] = (float)(g0 / s); out[1] = (float)(g1 / s);
+}
+
+}  // namespace dpmmh

@@ -151,21 +151,3 @@ def dirichlet_log(alpha, seed, epoch, ids, nthreads=None):
     lib().dpmmh_dirichlet_log(n, D, _p(alpha, _f32p), ctypes.c_uint64(seed), ctypes.c_uint32(epoch), _p(ids, _i32p),
                               _p(out, _f32p), nthreads or default_threads())
     return out
-
-
-def niw_update_from_packed(packed, sel, kappa0, nu0, m0, psi0, N, sums, S, post, nthreads=None):
-    """In-place fused unpack + posterior (see dpmmh_niw_update_from_packed).  N (K,3), sums (K,3,D), S (K,3,D,D) and the
-    arrays of `post` (leading dim 3K) must be C-contiguous float64 and are updated for the clusters in `sel` (None: all)."""
-    K = N.shape[0]; D = sums.shape[-1]
-    packed = np.ascontiguousarray(packed, np.float64)
-    for a in (N, sums, S, post["kappa"], post["nu"], post["m"], post["U"], post["logdet_psi"]):
-        assert a.flags.c_contiguous and a.dtype == np.float64
-    m0 = _d(m0); psi0 = _d(psi0)
-    selp = None; nsel = 0
-    if sel is not None:
-        sel = np.ascontiguousarray(sel, np.int32); selp = _p(sel, _i32p); nsel = len(sel)
-    lib().dpmmh_niw_update_from_packed(K, D, _p(packed, _f64p), ctypes.c_int64(packed.shape[1]), selp, nsel,
-                                       ctypes.c_double(kappa0), ctypes.c_double(nu0), _p(m0, _f64p), _p(psi0, _f64p),
-                                       _p(N, _f64p), _p(sums, _f64p), _p(S, _f64p), _p(post["kappa"], _f64p),
-                                       _p(post["nu"], _f64p), _p(post["m"], _f64p), _p(post["U"], _f64p),
-                                       _p(post["logdet_psi"], _f64p), nthreads or default_threads())

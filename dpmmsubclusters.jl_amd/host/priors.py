@@ -80,10 +80,6 @@ class niw_hyperparams(distribution_hyper_params):
         D = self.dim
         return dict(kappa=np.zeros(n), nu=np.zeros(n), m=np.zeros((n, D)), U=np.zeros((n, D, D)), logdet_psi=np.zeros(n))
 
-    def update_from_packed(self, packed, sel, N, sums, S, post, nthreads=None):
-        """Fused unpack + calc_posterior + factorisation, in place (native, threaded over clusters x {c,l,r})."""
-        native.niw_update_from_packed(packed, sel, self.kappa, self.nu, self.m, self.psi, N, sums, S, post, nthreads=nthreads)
-
     def log_marginal(self, post, N, f32_quirk=False):
         """niw.jl:53-62.  By default lnΓ_D is accumulated in Float64; `f32_quirk=True` reproduces the reference's
         log_multivariate_gamma (utils.jl:66-72), whose accumulator is a Float32 local -- the switch that makes a

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DPMM_ABI_VERSION 1
+#define DPMM_ABI_VERSION 2
 
 typedef struct dpmm_ctx dpmm_ctx;
 
@@ -47,7 +47,22 @@ enum {
     DPMM_ENODEVICE = -2, /* no usable HIP device */
     DPMM_EHIP = -3,      /* HIP runtime error (message has the hipError string) */
     DPMM_ESTATE = -4,    /* call order violated (e.g. sweep before params) */
-    DPMM_ELIMIT = -5     /* K or D beyond what this build supports */
+    DPMM_ELIMIT = -5,    /* K or D beyond what this build supports */
+    DPMM_ECOMM = -6      /* RCCL unavailable or a collective failed (message has the RCCL error string) */
+};
+
+/* Behaviour switches (dpmm_set_option).  The library takes nothing from the environment. */
+enum {
+    DPMM_OPT_SCREEN_MARGIN = 1,   /* NIW sweep: clusters provably more than `value` nats below a point's reference cluster for a whole
+                                     wave are skipped (default 50; 0 evaluates every cluster in full) */
+    DPMM_OPT_TAIL_SCREEN = 2,     /* 0 / 1: the 4-row tail screen in front of the 16-row MFMA screen (default 1) */
+    DPMM_OPT_PRESCREEN = 3,       /* -1 auto (K > 64 or no tail screen) / 0 / 1: triangle-inequality far mask */
+    DPMM_OPT_ORDERED_SWEEP = 4,   /* 0 / 1: visit points in the order of the previous statistics pass (default 1) */
+    DPMM_OPT_MULT_FORCE_F32 = 5,  /* Multinomial: Float32 matrix-core kernel even for bf16-exact count data (before upload) */
+    DPMM_OPT_STATS_ITEMS = 6,     /* work items of the statistics pass (before the first parameters) */
+    DPMM_OPT_STATS_GROUPS = 7,    /* workgroups of the NIW statistics kernel (0: default) */
+    DPMM_OPT_TRACE_SLOW = 8,      /* log HIP calls that block for more than 5 ms to stderr */
+    DPMM_OPT_LOGLIK_REF_CONST = 9 /* dpmm_debug_loglik adds back the reference's -D*D/2*log(2 pi) normaliser (mv_gaussian.jl:24) */
 };
 
 #define DPMM_MAX_CLUSTERS 1024
@@ -77,8 +92,11 @@ int dpmm_upload_points_device(dpmm_ctx *ctx, const float *dX, int64_t ldx);
  * nan_to_zero != 0) and the re-layout happen on the device. */
 int dpmm_upload_points_npy(dpmm_ctx *ctx, const void *rows, int is_f64, int64_t ld, int nan_to_zero);
 
-/* labels = rand(1:init_clusters), sub-labels = rand(1:2) (dp-parallel-sampling.jl:49-50). */
+/* labels = rand(1:init_clusters), sub-labels = rand(1:2) (dp-parallel-sampling.jl:49-50).
+ * _from: labels = first_label - 1 + rand(1:init_clusters) -- `.+ 1` when cluster 1 is the outlier component (:49). */
 int dpmm_init_labels(dpmm_ctx *ctx, int init_clusters, uint32_t epoch);
+int dpmm_init_labels_from(dpmm_ctx *ctx, int init_clusters, int first_label, uint32_t epoch);
+int dpmm_set_option(dpmm_ctx *ctx, int option, double value);
 /* Resume / tests: overwrite or read back this shard's labels (Array(group.labels),
  * dp-parallel-sampling.jl:218,276,371).  Either pointer may be NULL. */
 int dpmm_set_labels(dpmm_ctx *ctx, const int64_t *labels, const int64_t *sub_labels);
@@ -101,6 +119,19 @@ int dpmm_set_params_niw_chol(dpmm_ctx *ctx, int K, const float *mu, const float 
 /* multinomial_dist alpha = log-probabilities (distributions/multinomial_dist.jl:8-10): logp [3K][D] */
 int dpmm_set_params_mult(dpmm_ctx *ctx, int K, const float *logp, const float *lr_weights, const float *weights);
 
+/* The per-sweep path of the same hand-over, without copies: dpmm_params_staging returns pointers into pinned, GPU-addressable
+ * host memory owned by the ctx, sized for `slots` clusters; the master writes its parameter draws there IN PLACE and
+ * dpmm_commit_params(K) packs them for the kernels (which read the staging buffer directly; no synchronisation).
+ *   NIW : mu [3 slots][D], mat = R [3 slots][D*D] (upper-triangular factor), logdet [3 slots]
+ *   MULT: mu = NULL, mat = logp [3 slots][D], logdet = NULL
+ *   lr_weights [K][2], weights [K] and slot_of_cluster [K] in cluster order: cluster k's three rows are rows
+ *   3*slot_of_cluster[k] + w of mu / mat / logdet -- a cluster keeps its rows in place for life, removing clusters only edits the map.
+ * Contents survive a re-allocation (a later call with more slots).  The staging may be written again once a blocking call
+ * of the ctx (dpmm_step_stats, dpmm_suffstats_*, dpmm_sync) has returned. */
+int dpmm_params_staging(dpmm_ctx *ctx, int slots, float **mu, float **mat, float **logdet, float **lr_weights, float **weights,
+                        int32_t **slot_of_cluster);
+int dpmm_commit_params(dpmm_ctx *ctx, int K);
+
 /* Declares the number of clusters K that labels may reference from now on WITHOUT uploading
  * parameters: the master resizes group.local_clusters in check_and_split!
  * (local_clusters_actions.jl:361) and shrinks it in remove_empty_clusters! (:470); reference
@@ -108,6 +139,7 @@ int dpmm_set_params_mult(dpmm_ctx *ctx, int K, const float *logp, const float *l
  * statistics pass that follows a split or a removal.  Parameters must be set again before
  * the next dpmm_sweep. */
 int dpmm_set_num_clusters(dpmm_ctx *ctx, int K);
+int dpmm_num_clusters(const dpmm_ctx *ctx);   /* the K last declared (0 before the first parameters) */
 
 /* One label + sub-label sampling pass over the shard.
  * Replaces sample_labels_worker! (local_clusters_actions.jl:112-134; log_likelihood!
@@ -136,6 +168,15 @@ int dpmm_sweep(dpmm_ctx *ctx, uint32_t epoch, int final_argmax);
 int64_t dpmm_packed_stride(const dpmm_ctx *ctx);
 int dpmm_suffstats_packed_device(dpmm_ctx *ctx, const int64_t *cluster_idx, int n_idx, double *d_out);
 int dpmm_suffstats_packed(dpmm_ctx *ctx, const int64_t *cluster_idx, int n_idx, double *out);
+/* Same statistics, handed over in place: *packed points into pinned host memory of the ctx (valid until its next call).
+ * With a communicator attached (dpmm_comm_init) the rows are the SUM over all ranks -- the all-reduce runs on the ctx
+ * stream between the statistics kernels and the copy (dpmm_suffstats_packed does the same; _device stays local). */
+int dpmm_suffstats_host(dpmm_ctx *ctx, const int64_t *cluster_idx, int n_idx, const double **packed);
+/* Steps 5 + 6 of group_step (local_clusters_actions.jl:665-666) in ONE device pass without a host round trip in between:
+ * sub-cluster occupancies (summed over the ranks) -> clusters with an empty sub-cluster are flagged and the sub-labels of
+ * their points re-drawn with `reset_epoch` (reset_bad_clusters!, :501-516) -> statistics of all K clusters over the final
+ * labelling (summed over the ranks).  *packed as dpmm_suffstats_host, *bad [K] flags; blocks until both are in host memory. */
+int dpmm_step_stats(dpmm_ctx *ctx, uint32_t reset_epoch, const double **packed, const uint8_t **bad);
 /* Expand packed rows (after any cross-GPU sum) into the reference's thin_suff_stats shape
  * (src/ds.jl:37-41), order (cluster, left, right): N [K][3], sum [K][3][D], S [K][3][D][D]
  * (S symmetric; NULL for Multinomial).  Pure host code. */
@@ -158,6 +199,10 @@ int dpmm_reset_sublabels(dpmm_ctx *ctx, const int64_t *idx, int n, uint32_t epoc
  * -D*D/2*log(2 pi) normaliser term (mv_gaussian.jl:24; identical for every cluster, so it
  * never affects a draw; add it back to compare with reference values).  out: [K][n_local]. */
 int dpmm_debug_loglik(dpmm_ctx *ctx, float *out);
+/* Same for the sub-label phase: out [2K][n_local], row 2k+s = loglik of every point under sub-cluster s of cluster k +
+ * log lr_weights[k][s] -- for a point labelled k rows 2k, 2k+1 are exactly the two values create_subclusters_labels!
+ * (local_clusters_actions.jl:83-95) draws from (same arithmetic as dpmm_sweep's sub-label phase). */
+int dpmm_debug_subloglik(dpmm_ctx *ctx, float *out);
 
 /* Prediction for the points held by the ctx (next row of the scope table: predict / predict_points,
  * src/dp-parallel-sampling.jl:532-537, src/local_clusters_actions.jl:23-40, with posterior_predictive!
@@ -215,6 +260,28 @@ void *dpmm_stream(dpmm_ctx *ctx);
  * dpmm_suffstats_* call, measured with HIP events on the ctx stream (0 if none yet).
  * Calling this synchronises the stream. */
 int dpmm_last_kernel_ms(dpmm_ctx *ctx, float *sweep_ms, float *suffstats_ms);
+/* Work the last dpmm_sweep (NIW) really executed, counted on the device (one atomicAdd set per wave):
+ *   out8[0] wave tiles, [1] full quadratic-form evaluations (per wave), [2] 16-row MFMA screens (per wave), [3] tail-screened
+ *   cluster pairs (per wave), [4] matrix instructions per full evaluation, [5] per 16-row screen, [6] flops per matrix
+ *   instruction (v_mfma_f32_16x16x4_f32: 2048), [7] 0.  Executed flops = (out8[1]*out8[4] + out8[2]*out8[5]) * out8[6].
+ * Calling this synchronises the stream. */
+int dpmm_last_sweep_work(dpmm_ctx *ctx, uint64_t *out8);
+
+/* The one exchange of the sweep, inside the library: RCCL all-reduce(sum) of the packed statistics (and of the Int64
+ * sub-cluster occupancies) on the ctx stream.  Replaces create_suff_stats_dict_node_leader / update_suff_stats_posterior!'s
+ * reduce (local_clusters_actions.jl:171-254) and aggregate_suff_stats (priors/niw.jl:64-66, multinomial_prior.jl:41-43).
+ *   dpmm_comm_unique_id   rank 0 creates the 128-byte RCCL id and ships it to the other ranks by any means
+ *   dpmm_comm_init        every rank (one process per GPU) joins; collective
+ * After dpmm_comm_init, dpmm_step_stats / dpmm_suffstats_host / dpmm_suffstats_packed return statistics summed over all ranks.
+ * dpmm_comm_allgather_host gathers `bytes` of host data from every rank (all [world][bytes]); collective. */
+/* RCCL is bound at run time (dlopen): a copy already mapped into the process wins, then the soname, then /opt/rocm/lib.
+ * dpmm_comm_use_library names the file to use instead (before the first dpmm_comm_* call) -- a host that also runs
+ * torch.distributed passes torch's own librccl.so so that the process holds ONE copy. */
+int dpmm_comm_use_library(const char *path);
+int dpmm_comm_unique_id(void *out128);
+int dpmm_comm_init(dpmm_ctx *ctx, const void *unique_id128, int rank, int world);
+int dpmm_comm_destroy(dpmm_ctx *ctx);
+int dpmm_comm_allgather_host(dpmm_ctx *ctx, const void *mine, int64_t bytes, void *all);
 
 #ifdef __cplusplus
 }

@@ -24,6 +24,44 @@ class FakeWorker:
     def init_labels(self, init_clusters, epoch):
         self.labels, self.sub = orc.init_labels(self.n, init_clusters, self.seed, epoch, self.first_index)
 
+    def init_labels_from(self, init_clusters, first_label, epoch):
+        self.init_labels(init_clusters, epoch)
+        self.labels += first_label - 1
+
+    # ---- the engine's worker table (include/dpmm_host.h: dpmmh_worker) over this object
+    def params_staging(self, slots):
+        D = self.D
+        old = getattr(self, "_staging", None)
+        if old is not None and old["slots"] >= slots:
+            return old
+        cap = max(8, slots)
+        niw = self.prior == PRIOR_NIW
+        new = dict(slots=cap, mu=np.zeros((3 * cap, D), np.float32) if niw else None,
+                   mat=np.zeros((3 * cap, D * D if niw else D), np.float32), logdet=np.zeros(3 * cap, np.float32) if niw else None,
+                   lr=np.zeros((cap, 2), np.float32), w=np.zeros(cap, np.float32), slot=np.zeros(cap, np.int32))
+        if old is not None:
+            for k in ("mu", "mat", "logdet", "lr", "w", "slot"):
+                if new[k] is not None:
+                    new[k][:len(old[k])] = old[k]
+        self._staging = new
+        return new
+
+    def commit_params(self, K):
+        st = self._staging
+        rows = (3 * st["slot"][:K].astype(np.int64)[:, None] + np.arange(3)[None, :]).ravel()
+        if self.prior == PRIOR_NIW:
+            self.set_params_niw_chol(st["mu"][rows], st["mat"][rows], st["logdet"][rows], st["lr"][:K], st["w"][:K])
+        else:
+            self.set_params_mult(st["mat"][rows], st["lr"][:K], st["w"][:K])
+
+    def step_stats(self, reset_epoch, global_counts=None):
+        """dpmm_step_stats: occupancies (summed over the ranks by the caller) -> bad flags -> sub-label reset -> statistics."""
+        counts = self.bin_counts() if global_counts is None else np.asarray(global_counts).reshape(self.K, 2)
+        bad = ((counts[:, 0] == 0) | (counts[:, 1] == 0)).astype(np.uint8)
+        if bad.any():
+            self.reset_sublabels(np.flatnonzero(bad) + 1, reset_epoch)
+        return self.suffstats_packed(None), bad
+
     def set_labels(self, labels=None, sub=None):
         if labels is not None:
             self.labels = np.array(labels, np.int64)

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(pkg):
     for name in declared_functions():
         assert hasattr(lib, name), name
     lib.dpmm_abi_version.restype = ctypes.c_int
-    assert lib.dpmm_abi_version() == 1
+    assert lib.dpmm_abi_version() == 2
 
 
 def test_no_cpu_fallback(pkg):

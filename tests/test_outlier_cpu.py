@@ -40,16 +40,25 @@ def run_outlier_fit(host, worker_factory=None, **kw):
 
 
 def check_outlier_result(r, out):
+    """The reference's outlier component (outlier_mod > 0): cluster 1 has its OWN prior (outlier_hyper_params), a constant
+    weight, is never split / merged / removed, and is otherwise an ordinary cluster -- its statistics and posterior follow the
+    points labelled 1 (update_suff_stats_posterior!, local_clusters_actions.jl:237-251) and its distribution is re-drawn every
+    sweep (sample_cluster_params mutates it in place; only the fetch is skipped, :424-427)."""
     labels, clusters, weights, model = r[0], r[1], r[2], r[8]
     s = model.sampler
     assert weights[0] == np.float32(0.05)                           # constant weight, first component
     assert abs(float(weights[1:].sum()) - 0.95) < 0.95 * 0.2       # the rest is Dirichlet mass times (1 - outlier_mod), minus the alpha share
-    assert s.splittable[0] == False and s.points_count[0] == s.n_total   # noqa: E712  never split, never "empty"
-    for k, v in s._outlier_params.items():                          # parameters drawn once, never again
-        assert np.array_equal(s.params[k][0], v) and np.array_equal(s.params[k][1], v) and np.array_equal(s.params[k][2], v)
+    N, sums, S, post = s.N, s.sums, s.S, s.post
+    assert s.points_count[0] == int(N[0, 0]) == int((labels == 1).sum())
+    # rows 0..2 (the outlier's cluster / left / right) carry posteriors under the OUTLIER prior, every other row under the cluster prior
+    want = s.outlier_prior.posterior(N[0], sums[0], S[0])
+    for key in ("kappa", "nu", "m", "logdet_psi"):
+        np.testing.assert_allclose(post[key][0:3], want[key], rtol=1e-12, atol=1e-12)
+    want1 = s.prior.posterior(N[1], sums[1], S[1])
+    np.testing.assert_allclose(post["logdet_psi"][3:6], want1["logdet_psi"], rtol=1e-12, atol=1e-12)
     assert labels.min() >= 1
     is_out = labels == 1
-    # the fixed broad component only ever takes background points (the DP is free to open broad clusters of its own too)
+    # the broad component only ever takes background points (the DP is free to open broad clusters of its own too)
     assert is_out[out].mean() > 0.05 and is_out[~out].mean() < 0.02, (is_out[out].mean(), is_out[~out].mean())
     assert len(np.unique(labels[~out])) >= 3
 
