@@ -83,12 +83,25 @@ def lib_path():
     return os.path.join(_HERE, "lib", "libdpmmhip.so")
 
 
+def locked_make(args, lock_dir):
+    """Run `make` under an exclusive file lock: the ranks of a fresh multi-process launch all reach the lazy build at once and
+    must not write the same .so concurrently."""
+    import fcntl
+    os.makedirs(lock_dir, exist_ok=True)
+    with open(os.path.join(lock_dir, ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            subprocess.check_call(args)
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
+
+
 def build_library(force=False):
     """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
     args = ["make", "-s", "-C", os.path.join(_HERE, "csrc"), "-j4"]
     if force:
         args.append("-B")
-    subprocess.check_call(args)
+    locked_make(args, os.path.join(_HERE, "lib"))
     return lib_path()
 
 

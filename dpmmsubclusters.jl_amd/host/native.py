@@ -21,7 +21,8 @@ def build_library(force=False):
     args = ["make", "-s", "-C", os.path.join(_HERE, "csrc")]
     if force:
         args.append("-B")
-    subprocess.check_call(args)
+    from ..binding import locked_make
+    locked_make(args, os.path.dirname(lib_path()))
     return lib_path()
 
 

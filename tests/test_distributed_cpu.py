@@ -19,7 +19,7 @@ def _problem():
     return x, z + 1
 
 
-def _run(rank, world, port, out):
+def _run(rank, world, port, out, smart=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from __graft_entry__ import load_package
@@ -34,7 +34,8 @@ def _run(rank, world, port, out):
         from dpmmsubclusters_jl_amd.host.comm import TorchDistComm
         comm = TorchDistComm()
     x, y = _problem()
-    res = host.fit(x, 10.0, iters=80, seed=31, burnout=5, verbose=False, gt=y, comm=comm, worker_factory=FakeWorker, nthreads=1)
+    res = host.fit(x, 10.0, iters=80, seed=31, burnout=5, verbose=False, gt=y, comm=comm, worker_factory=FakeWorker, nthreads=1,
+                   smart_splits=smart)
     if rank == 0:
         np.savez(out, labels=res[0], K=np.array(res[6]), nmi=np.array(res[4], float), weights=res[2], sub=res[7])
     if world > 1:
@@ -43,11 +44,11 @@ def _run(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def _spawn(world, port, out):
+def _spawn(world, port, out, smart=False):
     if world == 1:
-        _run(0, 1, port, out)
+        _run(0, 1, port, out, smart)
     else:
-        mp.spawn(_run, args=(world, port, out), nprocs=world, join=True)
+        mp.spawn(_run, args=(world, port, out, smart), nprocs=world, join=True)
 
 
 @pytest.mark.timeout(600)
@@ -61,6 +62,19 @@ def test_two_ranks_match_one_rank(tmp_path):
     assert (a["labels"] != b["labels"]).mean() < 1e-3           # index-keyed RNG: sharding does not change the draws
     assert a["nmi"][-1] > 0.95 and b["nmi"][-1] > 0.95
     np.testing.assert_allclose(a["weights"], b["weights"], rtol=1e-5)
+
+
+@pytest.mark.timeout(600)
+def test_smart_splits_two_ranks_match_one_rank(tmp_path):
+    """smart_cluster_init! across shards: every rank derives the SAME direction and centre from the all-reduced statistics,
+    the percentile seeds and 2-means sums are reduced over the ranks -- the chain must equal the single-rank chain."""
+    o1, o2 = str(tmp_path / "s1.npz"), str(tmp_path / "s2.npz")
+    _spawn(1, 29615, o1, True)
+    _spawn(2, 29616, o2, True)
+    a, b = np.load(o1), np.load(o2)
+    assert np.array_equal(a["K"], b["K"]) and a["K"][-1] == 3
+    assert (a["labels"] != b["labels"]).mean() < 1e-3 and (a["sub"] != b["sub"]).mean() < 5e-3
+    assert b["nmi"][-1] > 0.95
 
 
 def test_fake_worker_matches_packed_contract():

@@ -10,6 +10,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+from oracle import oracle as orc  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 
@@ -41,6 +43,30 @@ def _niw_params(host, X, y, K, D, seed):
     return prior, par
 
 
+def _windows(y, n, width):
+    """Three windows of `width` points: the start, one straddling a component boundary, the end."""
+    b = int(np.flatnonzero(np.diff(y) != 0)[len(np.flatnonzero(np.diff(y) != 0)) // 2]) + 1 if np.any(np.diff(y) != 0) else n // 2
+    mid = max(0, min(n - width, b - width // 2))
+    return [(0, width), (mid, mid + width), (n - width, n)]
+
+
+def _check_niw_windows(host, X, y, par, lr, w, lab, sub, seed, epoch, width, first=0):
+    """The oracle restatement of sample_labels_worker! / create_subclusters_labels! on windows of the full-size run: draws are
+    independent per point given the parameters (index-keyed uniforms), so any window can be checked exactly as the small
+    problems are -- labels equal up to counted boundary flips (<= 2e-4 of the window), sub-labels up to 1e-3."""
+    K = len(w); D = X.shape[1]
+    inv, _ = host.native.niw_expand(par["R"], want_sigma=False)
+    invS = inv.reshape(3 * K, -1).astype(np.float32)
+    for lo, hi in _windows(y, len(X), width):
+        olab, osub = orc.sweep_niw(np.ascontiguousarray(X[lo:hi]), D, par["mu"], invS, par["logdet"], np.log(w), np.log(lr), seed=seed,
+                                   epoch=epoch, first_idx=first + lo)
+        flips = int((lab[lo:hi] != olab).sum())
+        assert flips <= max(2, int(2e-4 * (hi - lo))), (lo, hi, flips)
+        same = lab[lo:hi] == olab
+        sflips = int((sub[lo:hi][same] != osub[same]).sum())
+        assert sflips <= max(2, int(1e-3 * (hi - lo))), (lo, hi, sflips)
+
+
 def test_c3_full_size_niw_properties(pkg, host):
     N, D, K = 10 ** 7, 64, 32
     X, y = host.gaussian_mixture_shard(N, D, K, 100.0, 12345, 0, N)
@@ -60,6 +86,13 @@ def test_c3_full_size_niw_properties(pkg, host):
 
     wk, lab, sub, packed = run(0, N)
     assert lab.min() >= 1 and lab.max() <= K and set(np.unique(sub)) <= {1, 2}
+    # the oracle on three 20 000-point windows of the SECOND sweep: previous labels, the bin-sorted processing order and the
+    # cluster screening (which removes 31 of 32 clusters on this data) are all active then
+    prior.upload(wk, par, lr, w)
+    wk.sweep(6)
+    lab6, sub6 = wk.get_labels()
+    _check_niw_windows(host, X, y, par, lr, w, lab6, sub6, seed=99, epoch=6, width=20000)
+    wk.set_labels(lab, sub)
     assert (lab == y).mean() > 0.999                              # well separated data: the sweep keeps the components
     Nk, sums, S = wk.unpack(packed, K)
     # conservation: counts exactly, first and second moments against an independent Float64 pass over X
@@ -119,7 +152,54 @@ def test_c4_full_size_multinomial_properties(pkg, host):
     assert Nk[:, 0].sum() == N and np.array_equal(Nk[:, 0], np.bincount(lab, minlength=K + 1)[1:])
     assert np.array_equal(sums[:, 0].sum(1), 100.0 * Nk[:, 0])              # every document has exactly 100 words: exact in Float64
     assert np.array_equal(sums[:, 0].sum(0), X.astype(np.float64).sum(0))   # counts are integers: exact
+    # the oracle on three 20 000-point windows (draws are independent per point given the parameters)
+    logw = np.log(np.full(K, 1.0 / K, np.float32)); loglr = np.log(np.full((K, 2), 0.5, np.float32))
+    for lo, hi in ((0, 20000), (N // 2 - 10000, N // 2 + 10000), (N - 20000, N)):
+        olab, osub = orc.sweep_mult(np.ascontiguousarray(X[lo:hi]), D, logp, logw, loglr, 5, 2, lo)
+        assert (lab[lo:hi] != olab).sum() <= 4, (lo, int((lab[lo:hi] != olab).sum()))
+        same = lab[lo:hi] == olab
+        assert (sub[lo:hi][same] != osub[same]).sum() <= 20
     wk.sweep(2)
     lab2, _ = wk.get_labels()
     assert (lab2 == lab).mean() > 0.999                                      # same epoch, same parameters: the labels stay with their components
+    wk.close()
+
+
+def test_c5_shard_size_niw_d256(pkg, host):
+    """BASELINE config 5 at its per-GPU size: NIW D = 256, n = 6.25e5 points (N = 5e6 over 8 GPUs), K = 32 -- the LDS-staged
+    sweep kernel with workgroup-wide screening and the 16-block statistics kernel.  Conservation, reproducibility, and the
+    oracle on three windows of the second sweep."""
+    n, D, K = 625000, 256, 32
+    X, y = host.gaussian_mixture_shard(n, D, K, 100.0, 12345, 0, n)
+    prior, par = _niw_params(host, X, y, K, D, 3)
+    lr = np.full((K, 2), 0.5, np.float32); w = np.full(K, 1.0 / K, np.float32)
+    sub0 = 1 + (np.arange(n) & 1)
+    wk = pkg.Worker(pkg.PRIOR_NIW, D, n, first_index=0, device=0, seed=41)
+    wk.upload_points(X)
+    wk.set_labels(y, sub0)
+    prior.upload(wk, par, lr, w)
+    wk.sweep(5)
+    lab, sub = wk.get_labels()
+    packed = wk.suffstats_packed(None)
+    assert (lab == y).mean() > 0.999 and set(np.unique(sub)) <= {1, 2}
+    Nk, sums, S = wk.unpack(packed, K)
+    assert Nk[:, 0].sum() == n and np.array_equal(Nk[:, 0], np.bincount(lab, minlength=K + 1)[1:])
+    assert np.array_equal(Nk[:, 0], Nk[:, 1] + Nk[:, 2])
+    Xd = X.astype(np.float64)
+    np.testing.assert_allclose(sums[:, 0].sum(0), Xd.sum(0), rtol=1e-10, atol=1e-6)
+    np.testing.assert_allclose(np.trace(S[:, 0].sum(0)), float((Xd * Xd).sum()), rtol=1e-10)
+    k = int(np.argmax(Nk[:, 0]))                                     # one full second-moment matrix against numpy
+    m = lab == k + 1
+    np.testing.assert_allclose(S[k, 0], Xd[m].T @ Xd[m], rtol=1e-11, atol=1e-6)
+    del Xd
+    # second sweep: ordered processing + screening active; bitwise reproducible; oracle windows
+    prior.upload(wk, par, lr, w)
+    wk.sweep(6)
+    lab6, sub6 = wk.get_labels()
+    _check_niw_windows(host, X, y, par, lr, w, lab6, sub6, seed=41, epoch=6, width=1500)
+    wk.set_labels(lab, sub); wk.suffstats_packed(None)
+    prior.upload(wk, par, lr, w)
+    wk.sweep(6)
+    l2, s2 = wk.get_labels()
+    assert np.array_equal(l2, lab6) and np.array_equal(s2, sub6)
     wk.close()

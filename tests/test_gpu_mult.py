@@ -49,6 +49,11 @@ def test_table_and_labels(pkg, D, n, K, trials):
     lab, sub = wk.get_labels()
     u0, u1 = orc.uniforms(seed, epoch, 0, first, n)
     assert np.array_equal(orc.sample_log_cat(tab, u0), lab)           # draw arithmetic: bit-exact
+    if 2 * K <= 1024:                                                 # sub-label draw from the GPU's own left / right values: bit-exact too
+        tab2 = wk.debug_subloglik()
+        i = np.arange(n)
+        pair = np.stack([tab2[2 * (lab - 1), i], tab2[2 * (lab - 1) + 1, i]])
+        assert np.array_equal(orc.sample_log_cat(pair, u1), sub)
     olab, osub = orc.sweep_mult(P["X"], D, P["logp"], np.log(P["w"]), np.log(P["lr"]), seed, epoch, first)
     assert (lab != olab).sum() <= max(2, int(3e-4 * n))
     same = lab == olab

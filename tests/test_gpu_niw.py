@@ -50,6 +50,16 @@ def gpu_worker(pkg, P, seed, first_index=0):
     return wk
 
 
+def assert_sublabels_bit_exact(wk, lab, sub, u1):
+    """The sub-label draw given the GPU's own Float32 left / right values must be bit-exact (same exp_det / scan arithmetic as
+    the oracle): dpmm_debug_subloglik returns, for every point, b_l and b_r of every cluster; a point labelled k draws from
+    rows 2(k-1), 2(k-1)+1 with its second uniform (create_subclusters_labels!, local_clusters_actions.jl:83-95)."""
+    tab2 = wk.debug_subloglik()
+    i = np.arange(len(lab))
+    pair = np.stack([tab2[2 * (lab - 1), i], tab2[2 * (lab - 1) + 1, i]])
+    assert np.array_equal(orc.sample_log_cat(pair, u1), sub)
+
+
 def table_f64(P):
     K, n, D = P["K"], P["n"], P["D"]
     t = np.empty((K, n))
@@ -89,6 +99,7 @@ def test_sweep_labels_vs_oracle(pkg, D, n, K, sorted_points):
     tab = wk.debug_loglik()
     u0, u1 = orc.uniforms(seed, epoch, 0, first, n)
     assert np.array_equal(orc.sample_log_cat(tab, u0), lab)
+    assert_sublabels_bit_exact(wk, lab, sub, u1)
     # (2) against the oracle's independent Float32 evaluation: counted near-boundary flips only
     olab, osub, otab = orc.sweep_niw(P["X"], D, P["mu"], P["invS"], P["logdet"], np.log(P["w"]), np.log(P["lr"]),
                                      seed=seed, epoch=epoch, first_idx=first, want_parr=True)
@@ -104,6 +115,23 @@ def test_sweep_labels_vs_oracle(pkg, D, n, K, sorted_points):
     assert sflips <= max(2, int(5e-4 * n)), sflips
     # the labels must be informative (not a degenerate draw)
     assert (lab == P["z"] + 1).mean() > 1.5 / K
+    wk.close()
+
+
+def test_loglik_reference_normaliser_switch(pkg):
+    """DPMM_OPT_LOGLIK_REF_CONST adds back the reference's -D^2/2 log(2 pi) (mv_gaussian.jl:24 uses length(Sigma) = D^2): the table
+    then equals the oracle's literal restatement of log_likelihood! (plus log w)."""
+    from dpmmsubclusters_jl_amd import binding
+    D, n, K = 6, 800, 3
+    P = make_problem(D, n, K, seed=4)
+    wk = gpu_worker(pkg, P, seed=1)
+    plain = wk.debug_loglik()
+    wk.set_option(binding.OPT_LOGLIK_REF_CONST, 1)
+    ref = wk.debug_loglik()
+    np.testing.assert_allclose(ref - plain, -0.5 * D * D * np.log(2 * np.pi), rtol=0, atol=2e-4)
+    for k in range(K):
+        want = orc.niw_loglik_ref(P["X"], D, P["mu"][3 * k], P["invS"][3 * k], P["logdet"][3 * k]) + np.log(P["w"][k])
+        np.testing.assert_allclose(ref[k], want, rtol=2e-5, atol=2e-3)
     wk.close()
 
 
@@ -291,6 +319,7 @@ def test_many_clusters_and_padded_dims_with_screening(pkg, D, n, K):
     tab = wk.debug_loglik()
     u0, u1 = orc.uniforms(seed, 2, 0, first, n)
     assert np.array_equal(orc.sample_log_cat(tab, u0), lab)
+    assert_sublabels_bit_exact(wk, lab, sub, u1)        # phase 2 of the screened / ordered sweep (rb0 carry-over, prefetch chain)
     olab, osub = orc.sweep_niw(P["X"], D, P["mu"], P["invS"], P["logdet"], np.log(P["w"]), np.log(P["lr"]), seed=seed, epoch=2, first_idx=first)
     assert (lab != olab).sum() <= max(2, int(3e-4 * n))
     same = lab == olab
@@ -307,10 +336,11 @@ def test_large_k_global_table_path(pkg):
     wk.sweep(1); wk.suffstats_packed()
     wk.set_params_niw(P["mu"], P["invS"], P["logdet"], P["lr"], P["w"])
     wk.sweep(2)
-    lab, _ = wk.get_labels()
+    lab, sub = wk.get_labels()
     tab = wk.debug_loglik()
-    u0, _ = orc.uniforms(3, 2, 0, 0, 4000)
+    u0, u1 = orc.uniforms(3, 2, 0, 0, 4000)
     assert np.array_equal(orc.sample_log_cat(tab, u0), lab)
+    assert_sublabels_bit_exact(wk, lab, sub, u1)
     wk.close()
 
 

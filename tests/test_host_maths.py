@@ -159,3 +159,118 @@ def test_dirichlet_log_moments(host):
     np.testing.assert_allclose(p.mean(0), alpha / a0, atol=4e-3)
     var = alpha / a0 * (1 - alpha / a0) / (a0 + 1)
     np.testing.assert_allclose(p.var(0), var, rtol=0.1, atol=2e-4)
+
+
+# --------------------------------------------------------------------------------------------- the native engine's decisions
+def _engine_with_stats(host, D, K, rng, burnout=5, alpha=10.0, f32_quirk=False):
+    """A dpmmh_model (host/csrc/dpmm_model.cpp) holding K clusters with given packed statistics, over the test worker."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from fake_worker import FakeWorker
+    prior = host.niw_hyperparams(1.0, np.zeros(D), D + 3.0, np.eye(D))
+    wk = FakeWorker(0, D, 0)
+    s = host.DPMMSampler(wk, prior, alpha, 10000, seed=7, burnout=burnout, nthreads=2)
+    s.f32_quirk = f32_quirk
+    s._configure()
+    stride = 1 + D + D * (D + 1) // 2
+    packed = np.zeros((2 * K, stride))
+    il = np.tril_indices(D)
+    stats = []
+    for k in range(K):
+        c = rng.normal(size=D) * 6
+        for side in range(2):
+            n = int(rng.integers(30, 300))
+            x = rng.normal(size=(n, D)) * (0.5 + rng.random()) + c + (0.8 if side else -0.8)
+            packed[2 * k + side, 0] = n
+            packed[2 * k + side, 1:1 + D] = x.sum(0)
+            packed[2 * k + side, 1 + D:] = (x.T @ x)[il]
+            stats.append((n, x.sum(0), x.T @ x))
+    s.model.set("K", K)
+    s.model.set("packed", packed)
+    return s, prior, stats
+
+
+def _oracle_L(prior, n, sm, S, f32_quirk=False):
+    pr = (prior.kappa, prior.m, prior.nu, prior.psi)
+    return orc.niw_log_marginal(pr, orc.niw_calc_posterior(*pr, n, sm, S), n, prior.dim, f32_quirk=f32_quirk)
+
+
+@pytest.mark.parametrize("f32_quirk", [False, True])
+def test_engine_split_and_merge_log_hastings_ratios_vs_oracle(host, f32_quirk):
+    """should_split_local! (local_clusters_actions.jl:336-339) and should_merge! (shared_actions.jl:28-30) as the engine evaluates
+    them on fixed statistics == orc.split_log_hr / orc.merge_log_hr on the oracle's posteriors and marginals."""
+    D, K = 4, 5
+    s, prior, stats = _engine_with_stats(host, D, K, np.random.default_rng(2), f32_quirk=f32_quirk)
+    alpha = s.alpha
+    s.model.set("splittable", np.ones(K, np.uint8))
+    got_split = s.model.debug_split_log_hr()
+    got_merge = s.model.debug_merge_log_hr()
+    Lc, Nc = [], []
+    for k in range(K):
+        (nl, sl, Sl), (nr, sr, Sr) = stats[2 * k], stats[2 * k + 1]
+        L_l, L_r = _oracle_L(prior, nl, sl, Sl, f32_quirk), _oracle_L(prior, nr, sr, Sr, f32_quirk)
+        L_c = _oracle_L(prior, nl + nr, sl + sr, Sl + Sr, f32_quirk)
+        Lc.append(L_c); Nc.append(nl + nr)
+        want = orc.split_log_hr(alpha, nl, L_l, nr, L_r, nl + nr, L_c)
+        assert abs(got_split[k] - want) <= 1e-9 * max(1.0, abs(want)), (k, got_split[k], want)
+    # the engine's cached marginals are the oracle's
+    np.testing.assert_allclose(s.log_marginals[:, 0], Lc, rtol=1e-10)
+    for i in range(K):
+        for j in range(i + 1, K):
+            (nli, sli, Sli), (nri, sri, Sri) = stats[2 * i], stats[2 * i + 1]
+            (nlj, slj, Slj), (nrj, srj, Srj) = stats[2 * j], stats[2 * j + 1]
+            L = _oracle_L(prior, Nc[i] + Nc[j], sli + sri + slj + srj, Sli + Sri + Slj + Srj, f32_quirk)
+            want = orc.merge_log_hr(alpha, Nc[i], Lc[i], Nc[j], Lc[j], L)
+            assert abs(got_merge[i, j] - want) <= 1e-9 * max(1.0, abs(want)), (i, j, got_merge[i, j], want)
+    # eligibility: not splittable -> no ratio (NaN); a cluster with an empty sub-cluster is not split (local_clusters_actions.jl:323)
+    s.model.set("splittable", np.array([1, 0, 1, 1, 1], np.uint8))
+    assert np.isnan(s.model.debug_split_log_hr()[1]) and np.isnan(s.model.debug_merge_log_hr()[1, 2]) and np.isnan(s.model.debug_merge_log_hr()[0, 1])
+    # log posterior (dp-parallel-sampling.jl:458-470)
+    want_lp = orc.log_posterior(alpha, 10000, Nc, Lc)
+    assert abs(s.log_posterior() - want_lp) <= 1e-9 * abs(want_lp)
+
+
+def test_engine_burn_in_gate_matches_hand_computation(host):
+    """sample_cluster_params' gate (shared_actions.jl:51-63): shift the Float32 history, append L_l + L_r, average over
+    `burnout` entries with divisor burnout - 0.1, splittable when avg != -Inf and avg - last < 1e-2; never reset here."""
+    D, K, b = 3, 4, 5
+    s, prior, stats = _engine_with_stats(host, D, K, np.random.default_rng(9), burnout=b)
+    L = s.log_marginals
+    last = (L[:, 1] + L[:, 2]).astype(np.float32)
+    H = np.full((K, b + 5), -np.inf, np.float32)
+    H[0, :b] = last[0] + np.float32([-0.05, -0.04, -0.03, -0.02, 0.0])      # plateau: mean just below the newest value -> gate opens
+    H[1, :b] = last[1] + np.float32([-900, -700, -500, -300, 0])            # still climbing: mean far BELOW the newest -> avg - last < 1e-2 -> opens too
+    H[2, :b] = [-np.inf, -np.inf, last[2], last[2], last[2]]                # -Inf inside the window -> mean -Inf -> stays closed
+    H[3, :b] = last[3] + np.float32([5e5, 4e5, 3e5, 2e5, 1e5])              # falling steeply: mean far ABOVE the newest -> avg - last > 1e-2 -> closed
+    # (the divisor is burnout - 0.1, not burnout: avg = sum / 4.9 carries an extra 0.0204 * last, hence the large steps)
+    s.model.set("hist", H)
+    s.model.set("splittable", np.array([0, 0, 0, 1], np.uint8))             # cluster 3 was splittable before: the gate never closes it
+    s.model.sample_clusters()
+    got_h, got_s = s.hist, s.splittable
+    want_s = [None] * K
+    for k in range(K):
+        h = H[k].copy()
+        h[:b - 1] = h[1:b]
+        h[b - 1] = last[k]
+        now = float(np.sum(h[:b].astype(np.float64) * (1.0 / (b - 0.1))))
+        want_s[k] = bool((k == 3) or (now != -np.inf and now - float(h[b - 1]) < 1e-2))
+        assert np.array_equal(got_h[k, :b], h[:b]), k
+    assert got_s.tolist() == want_s == [True, True, False, True]
+    # and a falling history closes nothing but opens nothing either: same state, cluster 3 not splittable beforehand
+    s.model.set("hist", H)
+    s.model.set("splittable", np.zeros(K, np.uint8))
+    s.model.sample_clusters()
+    assert s.splittable.tolist() == [True, True, False, False]
+    # lr_weights ~ Dirichlet(N_l + alpha/2, N_r + alpha/2) and the mixture weights ~ Dirichlet(N_1..N_K, alpha)[1:K]: moments over epochs
+    lrs, ws = [], []
+    for _ in range(400):
+        s.model.sample_clusters()
+        lrs.append(s.lr_weights); ws.append(s.weights)
+    lrs, ws = np.array(lrs), np.array(ws)
+    N = s.N
+    a = N[:, 1:3] + s.alpha / 2
+    np.testing.assert_allclose(lrs.mean(0), a / a.sum(1, keepdims=True), atol=4 * np.sqrt(0.25 / a.sum(1).min() / 400) + 1e-3)
+    conc = np.concatenate([N[:, 0], [s.alpha]])
+    np.testing.assert_allclose(ws.mean(0), (conc / conc.sum())[:K], atol=5e-3)
+    assert np.all(np.abs(lrs.sum(2) - 1) < 1e-6) and np.all(ws.sum(1) < 1.0)
