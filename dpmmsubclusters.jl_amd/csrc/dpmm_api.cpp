@@ -97,6 +97,7 @@ struct dpmm_ctx {
     unsigned long long *d_work = nullptr;   // [4] executed-work counters of the last sweep
     // options (dpmm_set_option)
     float opt_margin = 50.f;
+    int opt_prio = 1;
     int opt_tail = 1, opt_prescreen = -1, opt_ordered = 1, opt_force_f32 = 0, opt_trace = 0, opt_ref_const = 0;
     int64_t opt_stats_items = 0;
     int opt_stats_groups = 0;
@@ -663,6 +664,7 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
             a.order = (!table && c->have_perm && !no_order) ? c->sb.perm : nullptr;
             a.order_total = c->sb.perm_total;
             a.work = table ? nullptr : c->d_work;
+            a.prio = c->opt_prio;
         }
 #ifdef DPMM_STAMPS
         if (!g_dbg) { hipMalloc(&g_dbg, sizeof(unsigned long long) * 16 * 4 * 4096); hipMemset(g_dbg, 0, sizeof(unsigned long long) * 16 * 4 * 4096); }
@@ -1159,6 +1161,7 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
         case DPMM_OPT_STATS_GROUPS: c->opt_stats_groups = value > 0 ? (int)value : 0; return DPMM_OK;
         case DPMM_OPT_TRACE_SLOW: c->opt_trace = value != 0; return DPMM_OK;
         case DPMM_OPT_LOGLIK_REF_CONST: c->opt_ref_const = value != 0; return DPMM_OK;
+        case DPMM_OPT_WAVE_PRIO: c->opt_prio = value != 0; return DPMM_OK;
         default: return fail(c, DPMM_EINVAL, "unknown option");
     }
 }

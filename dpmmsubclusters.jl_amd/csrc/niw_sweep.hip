@@ -465,13 +465,15 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
 // Streaming evaluation of one packed matrix: row-block bi is computed from `cur` while the
 // fragments of the next row-block (or of row-block 0 of the next matrix, plus its mu) are in
 // flight.  On entry rb0/mu hold row-block 0 and mu of THIS matrix; on exit those of Rnext.
+#define DPMM_PRIO_ARG prio
 template <int NB, int NG>
 __device__ __forceinline__ float quad_stream(const float *__restrict__ Rm, const float *__restrict__ Rnext,
                                              const float *__restrict__ mup_next, f32x4 (&rb0)[NB], f32x4 (&mu)[NB],
-                                             const f32x4 (&x)[NG][NB], int lane, int g, bool active, float (&tot_all)[NG]) {
+                                             const f32x4 (&x)[NG][NB], int lane, int g, bool active, float (&tot_all)[NG], int prio = 0) {
     float q[NG];
 #pragma unroll
     for (int n = 0; n < NG; ++n) q[n] = 0.f;
+    if (DPMM_PRIO_ARG) __builtin_amdgcn_s_setprio(0);
     // Fragment schedule (everything is unrolled; F[] are SSA values, nothing is copied).  The MFMA time of a row-block
     // shrinks with bi (NB - bi pairs) while the L2 latency of its fragments does not, so the later row-blocks are fetched
     // earlier than "one ahead": rb1 during rb0, ALL remaining row-blocks during rb1, and row-block 0 / mu of the next
@@ -536,6 +538,7 @@ __device__ __forceinline__ float quad_stream(const float *__restrict__ Rm, const
         tot_all[n] = tot[0];       // quadratic form of point (n, column of this lane): same value in all 4 row-group lanes
         if (g == n) sel = tot[0];
     }
+    if (DPMM_PRIO_ARG) __builtin_amdgcn_s_setprio(2);
     return sel;
 }
 
@@ -563,6 +566,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
     const int tid = threadIdx.x, lane = tid & 63;
     const int ci = lane & 15, g = lane >> 4;
     const int K = A.K;
+    if (A.prio) __builtin_amdgcn_s_setprio(2);
     const bool use_order = A.order != nullptr && *A.order_total == (int32_t)A.n;
     const bool owner = lane < WPTS;
     const int64_t nwtiles = (A.n + WPTS - 1) / WPTS;              // one tile per wave
@@ -668,7 +672,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                 const float *Rcur = A.Rp + (size_t)(3 * k) * MATSZ;
                 const float *Rnext = (k + 1 < K) ? A.Rp + (size_t)(3 * (k + 1)) * MATSZ : nullptr;
                 STAMP(q0);
-                const float qs = quad_stream<NB, NG>(Rcur, Rnext, A.mup + (size_t)(3 * (k + 1)) * DP, rb0, mu, x, lane, g, true, tot_all);
+                const float qs = quad_stream<NB, NG>(Rcur, Rnext, A.mup + (size_t)(3 * (k + 1)) * DP, rb0, mu, x, lane, g, true, tot_all, A.prio);
                 ++nw_full;
                 STAMP(q1);
                 const float a = A.tdf ? A.cst[3 * k] - A.tdf[6 * k + 1] * log1pf(qs / A.tdf[6 * k])
@@ -700,7 +704,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
 #pragma unroll
             for (int n = 0; n < NG; ++n) bestn[n] = -INFINITY;
             auto full_eval = [&](int k, const float *Rnext, const float *mup_next) {
-                const float qs = quad_stream<NB, NG>(A.Rp + (size_t)(3 * k) * MATSZ, Rnext, mup_next, rb0, mu, x, lane, g, true, tot_all);
+                const float qs = quad_stream<NB, NG>(A.Rp + (size_t)(3 * k) * MATSZ, Rnext, mup_next, rb0, mu, x, lane, g, true, tot_all, A.prio);
                 ++nw_full;
                 const float c = A.cst[3 * k];
 #pragma unroll
@@ -998,10 +1002,10 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
             const int knext = next_label();
             const int jl = 3 * kcur + 1, jr = jl + 1, jn = 3 * (knext >= 0 ? knext : 0) + 1;
             const float bl = __builtin_fmaf(-0.5f, quad_stream<NB, NG>(A.Rp + (size_t)jl * MATSZ, A.Rp + (size_t)jr * MATSZ,
-                                                                          A.mup + (size_t)jr * DP, rb0, mu, x, lane, g, true, tot_all), A.cst[jl]);
+                                                                          A.mup + (size_t)jr * DP, rb0, mu, x, lane, g, true, tot_all, A.prio), A.cst[jl]);
             const float br = __builtin_fmaf(-0.5f, quad_stream<NB, NG>(A.Rp + (size_t)jr * MATSZ,
                                                                           knext >= 0 ? A.Rp + (size_t)jn * MATSZ : nullptr,
-                                                                          A.mup + (size_t)jn * DP, rb0, mu, x, lane, g, true, tot_all), A.cst[jr]);
+                                                                          A.mup + (size_t)jn * DP, rb0, mu, x, lane, g, true, tot_all, A.prio), A.cst[jr]);
             if (valid && z == kcur) { b0 = bl; b1 = br; }
             nw_full += 2;
             kcur = knext;

@@ -113,12 +113,15 @@ static int niw_sample_impl(int n, int D, const double *kappa, const double *nu, 
                            float *mu, float *R, float *logdet_sigma, int nthreads) {
     if (nthreads < 1) nthreads = 1;
     const size_t DD = (size_t)D * D;
-    std::vector<std::vector<double>> scratch(nthreads, std::vector<double>(dpmmh::niw_draw_scratch_doubles(D)));
-    std::vector<std::vector<double>> blk(nthreads, std::vector<double>(8 * (size_t)D));
+    std::vector<std::vector<double>> scratch(nthreads, std::vector<double>(dpmmh::niw_draw_scratch_doubles(D) + DD));
     Pool::get().run(n, nthreads, [&](int i, int slot) {
-        dpmmh::niw_draw_one(D, kappa[i], nu[i], m + (size_t)i * D, U + (size_t)i * DD, seed, (uint32_t)ids[i], epoch,
+        double *Lt = scratch[slot].data() + dpmmh::niw_draw_scratch_doubles(D);      // the batch API hands U (upper): L = U'
+        const double *Ui = U + (size_t)i * DD;
+        for (int r = 0; r < D; ++r)
+            for (int c = 0; c < D; ++c) Lt[(size_t)r * D + c] = c <= r ? Ui[(size_t)c * D + r] : 0.0;
+        dpmmh::niw_draw_one(D, kappa[i], nu[i], m + (size_t)i * D, Lt, seed, (uint32_t)ids[i], epoch,
                             A_noise ? A_noise + (size_t)i * DD : nullptr, xi_in ? xi_in + (size_t)i * D : nullptr,
-                            scratch[slot].data(), blk[slot].data(), mu + (size_t)i * D, R + (size_t)i * DD, &logdet_sigma[i]);
+                            scratch[slot].data(), mu + (size_t)i * D, R + (size_t)i * DD, &logdet_sigma[i]);
     });
     return 0;
 }

@@ -120,7 +120,7 @@ struct dpmmh_model {
     // per slot
     std::vector<double> packed;       // [cap][2][stride]
     std::vector<double> kappa, nu, ldpsi, L, Nrow;   // [3 cap]
-    std::vector<double> mean, U;      // [3 cap][D], [3 cap][D*D]   (NIW)
+    std::vector<double> mean, U;      // [3 cap][D], [3 cap][D*D]   (NIW; U holds L = U' of nu psi = U U' = L' L, row-major lower)
     std::vector<float> apost;         // [3 cap][D]                 (Multinomial)
     std::vector<uint8_t> splittable;  // [cap]
     std::vector<float> hist;          // [cap][hist_len]
@@ -207,13 +207,8 @@ struct dpmmh_model {
                                                      mean.data() + (size_t)row * D, P);
         Nrow[row] = N;
         double *Uo = U.data() + (size_t)row * DD;
-        if (dpmmh::reverse_cholesky(P, D, Uo)) {
-            double ld = 0.0;
-            for (int d = 0; d < D; ++d) ld += log(Uo[(size_t)d * D + d]);
-            ldpsi[row] = 2.0 * ld - D * log(nu[row]);
-        } else {
-            ldpsi[row] = NAN;
-        }
+        const double ld = dpmmh::chol_ltl(P, D, Uo);           // nu' psi' = L' L (L = U', stored row-major lower); NaN when not positive definite
+        ldpsi[row] = ld - D * log(nu[row]);
         L[row] = niw_marginal(pr, kappa[row], nu[row], ldpsi[row], N);
     }
     double niw_marginal(const NiwPrior &pr, double k1, double v1, double ld1, double N) const {
@@ -310,16 +305,16 @@ struct dpmmh_model {
         draw_epoch += 1;
         const bool have_noise = kind == DPMMH_PRIOR_NIW && noise_epoch == draw_epoch;
         const size_t DD = (size_t)D * D;
-        std::vector<std::vector<double>> scratch(std::max(1, nthreads)), blk(std::max(1, nthreads));
+        std::vector<std::vector<double>> scratch(std::max(1, nthreads));
         Pool::get().run(3 * K, nthreads, [&](int id, int th) {
             const int k = id / 3, w = id % 3, row = 3 * slot[k] + w;
             if (kind == DPMMH_PRIOR_NIW) {
-                auto &sc = scratch[th]; auto &bk = blk[th];
-                if (sc.empty()) { sc.resize(dpmmh::niw_draw_scratch_doubles(D)); bk.resize(8 * (size_t)D); }
+                auto &sc = scratch[th];
+                if (sc.empty()) sc.resize(dpmmh::niw_draw_scratch_doubles(D));
                 const bool pre = have_noise && id < noise_rows;
                 dpmmh::niw_draw_one(D, kappa[row], nu[row], mean.data() + (size_t)row * D, U.data() + (size_t)row * DD, seed, (uint32_t)id,
                                     draw_epoch, pre ? noise_A.data() + (size_t)id * DD : nullptr, pre ? noise_xi.data() + (size_t)id * D : nullptr,
-                                    sc.data(), bk.data(), st_mu + (size_t)row * D, st_mat + (size_t)row * DD, &st_logdet[row]);
+                                    sc.data(), st_mu + (size_t)row * D, st_mat + (size_t)row * DD, &st_logdet[row]);
             } else {
                 auto &sc = scratch[th];
                 if (sc.empty()) sc.resize(D);
@@ -480,7 +475,7 @@ struct dpmmh_model {
                     const double sab = rows[0][t0 + b] + rows[1][t0 + b] + rows[2][t0 + b] + rows[3][t0 + b];
                     const double pab = 0.5 * (pr.psi[(size_t)a * D + b] + pr.psi[(size_t)b * D + a]);
                     const double v = ((v0 * pab + k0 * pr.m[a] * pr.m[b] - k1 * mm[a] * mm[b] + sab) / v1) * v1;
-                    P[(size_t)a * D + b] = v; P[(size_t)b * D + a] = v;
+                    P[(size_t)a * D + b] = v;               // lower triangle
                 }
             }
             const double ld = dpmmh::logdet_spd_inplace(P, D) - D * log(v1);
@@ -832,7 +827,15 @@ HAPI int64_t dpmmh_model_get(dpmmh_model *m, const char *field, void *out, int64
     }
     if (m->kind == DPMMH_PRIOR_NIW) {
         if (f == "m") return emit(out, cap, rows_d(m->mean, D));
-        if (f == "U") return emit(out, cap, rows_d(m->U, DD));
+        if (f == "U") {          // the factor is stored as L = U' (row-major lower): hand out U (upper) with nu psi = U U'
+            std::vector<double> v = rows_d(m->U, DD), t(DD);
+            for (size_t r3 = 0; r3 < (size_t)3 * K; ++r3) {
+                double *Mx = v.data() + r3 * DD;
+                for (int a = 0; a < D; ++a) for (int b = 0; b < D; ++b) t[(size_t)a * D + b] = Mx[(size_t)b * D + a];
+                memcpy(Mx, t.data(), sizeof(double) * DD);
+            }
+            return emit(out, cap, v);
+        }
         if (m->st_slots > 0) {
             if (f == "mu") return emit(out, cap, rows_f(m->st_mu, D));
             if (f == "R") return emit(out, cap, rows_f(m->st_mat, DD));

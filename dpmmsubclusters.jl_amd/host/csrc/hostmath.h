@@ -15,56 +15,32 @@
 #include <algorithm>
 
 #include "hostlib.h"
+#include "dense.h"
 
 namespace dpmmh {
 
-// Psi (row-major, symmetric, D x D) = U U', U upper triangular (row-major, zeros below the diagonal).
-// Returns false when Psi is not positive definite.
+inline std::vector<double> &dense_scratch(size_t n) {
+    static thread_local std::vector<double> buf;
+    if (buf.size() < n) buf.resize(n);
+    return buf;
+}
+// Psi (row-major, symmetric, D x D; the caller's matrix survives) = U U', U upper triangular (row-major, zeros below the
+// diagonal).  Returns false when Psi is not positive definite.  Batch / compatibility form of chol_ltl (dense.h): U = L'.
 inline bool reverse_cholesky(const double *P, int D, double *U) {
-    memset(U, 0, sizeof(double) * (size_t)D * D);
-    for (int j = D - 1; j >= 0; --j) {
-        double s = P[(size_t)j * D + j];
-        const double *uj = U + (size_t)j * D;
-#pragma omp simd reduction(- : s)
-        for (int k = j + 1; k < D; ++k) s -= uj[k] * uj[k];
-        if (!(s > 0.0)) return false;
-        const double ujj = sqrt(s);
-        U[(size_t)j * D + j] = ujj;
-        const double inv = 1.0 / ujj;
-        for (int i = 0; i < j; ++i) {
-            double t = P[(size_t)i * D + j];
-            const double *ui = U + (size_t)i * D;
-#pragma omp simd reduction(- : t)
-            for (int k = j + 1; k < D; ++k) t -= ui[k] * uj[k];
-            U[(size_t)i * D + j] = t * inv;
-        }
-    }
+    const size_t DD = (size_t)D * D;
+    std::vector<double> &w = dense_scratch(DD);
+    memcpy(w.data(), P, sizeof(double) * DD);
+    const double ld = chol_ltl(w.data(), D, nullptr);
+    memset(U, 0, sizeof(double) * DD);
+    if (!(ld == ld)) return false;
+    for (int j = 0; j < D; ++j)
+        for (int i = 0; i <= j; ++i) U[(size_t)i * D + j] = w[(size_t)j * D + i];
     return true;
 }
 
-// log det of a symmetric positive definite matrix (row-major, D x D; destroyed) = 2 sum log diag of its factor;
-// NaN when it is not positive definite.  Same elimination order as reverse_cholesky, factor kept in place.
-inline double logdet_spd_inplace(double *P, int D) {
-    double ld = 0.0;
-    for (int j = D - 1; j >= 0; --j) {
-        double s = P[(size_t)j * D + j];
-        double *uj = P + (size_t)j * D;
-#pragma omp simd reduction(- : s)
-        for (int k = j + 1; k < D; ++k) s -= uj[k] * uj[k];
-        if (!(s > 0.0)) return NAN;
-        const double ujj = sqrt(s);
-        ld += log(ujj);
-        const double inv = 1.0 / ujj;
-        for (int i = 0; i < j; ++i) {
-            double *ui = P + (size_t)i * D;
-            double t = ui[j];
-#pragma omp simd reduction(- : t)
-            for (int k = j + 1; k < D; ++k) t -= ui[k] * uj[k];
-            ui[j] = t * inv;
-        }
-    }
-    return 2.0 * ld;
-}
+// log det of a symmetric positive definite matrix (row-major, D x D, LOWER triangle read; destroyed); NaN when it is not
+// positive definite.
+inline double logdet_spd_inplace(double *P, int D) { return chol_ltl(P, D, nullptr); }
 
 // priors/niw.jl:20-31 for one statistic set; psi_out symmetric.  N == 0 -> prior.
 inline void niw_posterior_one(int D, double k0, double v0, const double *m0, const double *psi0, double N, const double *sum,
@@ -89,15 +65,16 @@ inline void niw_posterior_one(int D, double k0, double v0, const double *m0, con
 }
 
 // Same posterior, from PACKED statistics rows {N, sum[D], lower triangle of S} (include/dpmm_hip.h): the statistic set is
-// cl * (row l) + cr * (row r) (cluster = left + right: cl = cr = 1).  Writes kappa, nu, m and the SCALE matrix
-// P = nu' psi' (full, symmetric) that the factorisation consumes -- the full S is never materialised.
+// cl * (row l) + cr * (row r) (cluster = left + right: cl = cr = 1).  Writes kappa, nu, m and the lower triangle of the SCALE
+// matrix P = nu' psi' that the factorisation consumes -- the full S is never materialised.
 inline double niw_posterior_packed(int D, double k0, double v0, const double *m0, const double *psi0, const double *l,
                                    const double *r, double cl, double cr, double *kap, double *nu, double *m, double *P) {
     const double N = cl * l[0] + cr * r[0];
     if (N == 0.0) {
         *kap = k0; *nu = v0;
         memcpy(m, m0, sizeof(double) * D);
-        for (size_t e = 0; e < (size_t)D * D; ++e) P[e] = psi0[e] * v0;
+        for (int a = 0; a < D; ++a)
+            for (int b = 0; b <= a; ++b) P[(size_t)a * D + b] = 0.5 * (psi0[(size_t)a * D + b] + psi0[(size_t)b * D + a]) * v0;
         return N;
     }
     const double k1 = k0 + N, v1 = v0 + N;
@@ -110,8 +87,7 @@ inline double niw_posterior_packed(int D, double k0, double v0, const double *m0
             const double sab = cl * tl[t0 + b] + cr * tr[t0 + b];
             const double pab = 0.5 * (psi0[(size_t)a * D + b] + psi0[(size_t)b * D + a]);
             const double v = ((v0 * pab + k0 * m0[a] * m0[b] - k1 * m[a] * m[b] + sab) / v1) * v1;   // psi' then nu' psi' (niw.jl:29,35)
-            P[(size_t)a * D + b] = v;
-            P[(size_t)b * D + a] = v;
+            P[(size_t)a * D + b] = v;                        // b <= a: the LOWER triangle is what the factorisation reads
         }
     }
     return N;
@@ -137,69 +113,49 @@ inline double niw_log_marginal(int D, double k0, double v0, double logdet_psi0, 
            (v0 / 2.0) * (D * log(v0) + logdet_psi0) - (v1 / 2.0) * (D * log(v1) + logdet_psi1) + (D / 2.0) * log(k0 / k1);
 }
 
-// One draw (mu, R, logdet Sigma) from a prepared posterior (kappa, nu, m, U with nu psi = U U').  `id`/`epoch` key the random
-// streams (normals: stream 16 -- identical whether pre-generated or not; chi-squares: stream 18).  An / xi_in: optional
-// pre-generated standard normals (strictly-lower Bartlett entries row-major [D][D], and xi [D]).
-// scratch: 2 D^2 + 3 D doubles; blk: 8 D doubles.  mu_out [D], R_out [D*D] (upper, zeros below), Float32.
-inline void niw_draw_one(int D, double kappa, double nu, const double *m, const double *Ui, uint64_t seed, uint32_t id,
-                         uint32_t epoch, const double *An, const double *xi_in, double *scratch, double *blk, float *mu_out,
-                         float *R_out, float *logdet_sigma) {
+// One draw (mu, R, logdet Sigma) from a prepared posterior (kappa, nu, m, L with nu psi = L' L, L lower triangular = U').
+// `id`/`epoch` key the random streams (normals: stream 16 -- identical whether pre-generated or not; chi-squares: stream 18).
+// An / xi_in: optional pre-generated standard normals (strictly-lower Bartlett entries row-major [D][D], and xi [D]).
+// scratch: D^2 + 2 D doubles.  mu_out [D], R_out [D*D] (upper, zeros below), Float32.
+inline void niw_draw_one(int D, double kappa, double nu, const double *m, const double *Li, uint64_t seed, uint32_t id,
+                         uint32_t epoch, const double *An, const double *xi_in, double *scratch, float *mu_out, float *R_out,
+                         float *logdet_sigma) {
     const size_t DD = (size_t)D * D;
-    double *A = scratch, *Rl = scratch + DD, *xi = scratch + 2 * DD + D, *v = scratch + 2 * DD + 2 * (size_t)D;
+    double *Y = scratch, *xi = scratch + DD, *v = scratch + DD + D;
     Philox rng(seed, id, epoch, 16u), rng_chi(seed, id, epoch, 18u);
-    // Bartlett factor, lower triangular (A[r][c], r >= c)
+    // Bartlett factor A, lower triangular (chi on the diagonal, standard normals below): the right-hand side of  L Y = A
     for (int r = 0; r < D; ++r) {
-        for (int c = 0; c < r; ++c) A[(size_t)r * D + c] = An ? An[(size_t)r * D + c] : rng.normal();
-        A[(size_t)r * D + r] = sqrt(2.0 * rng_chi.gamma(0.5 * (nu - r)));
+        double *yr = Y + (size_t)r * D;
+        if (An) memcpy(yr, An + (size_t)r * D, sizeof(double) * r);
+        else for (int c = 0; c < r; ++c) yr[c] = rng.normal();
+        yr[r] = sqrt(2.0 * rng_chi.gamma(0.5 * (nu - r)));
+        memset(yr + r + 1, 0, sizeof(double) * (D - 1 - r));
     }
-    // R = A' U^-1 : row j of R solves r_j U[j:, j:] = A[j:, j]'
-    // JB rows of R at a time share every pass over a row of U (at D = 256 U is 512 KiB: one row of R per pass was
-    // bound by streaming U from L2).  Per row the operations and their order are those of the one-row loop: same bits.
-    memset(Rl, 0, sizeof(double) * DD);
+    solve_lower_left(Y, Li, D);            // Y = L^-1 A;  R = Y' = A' U^-1 (upper)
     double ld = 0.0;
-    constexpr int JB = 8;
-    for (int j0 = 0; j0 < D; j0 += JB) {
-        const int nb = std::min(JB, D - j0);
-        double *ab = blk;                                     // [JB][D], row jb = column j0 + jb of A (zero above the diagonal)
-        for (int jb = 0; jb < nb; ++jb) {
-            double *ar = ab + (size_t)jb * D;
-            for (int r = 0; r < j0 + jb; ++r) ar[r] = 0.0;
-            for (int r = j0 + jb; r < D; ++r) ar[r] = A[(size_t)r * D + j0 + jb];
-        }
-        for (int c = j0; c < D; ++c) {
-            const double *uc = Ui + (size_t)c * D;
-            const double ucc = uc[c];
-            double val[JB];
-            for (int jb = 0; jb < nb; ++jb) {
-                // rows that have not started yet (c < j0 + jb) hold 0 here: val = 0 and the update below is a no-op
-                val[jb] = (c >= j0 + jb) ? ab[(size_t)jb * D + c] / ucc : 0.0;
-                if (c >= j0 + jb) Rl[(size_t)(j0 + jb) * D + c] = val[jb];
-            }
-            for (int jb = 0; jb < nb; ++jb) {
-                if (c < j0 + jb) continue;
-                double *ap = ab + (size_t)jb * D;
-                const double vv = val[jb];
-#pragma omp simd
-                for (int cc = c + 1; cc < D; ++cc) ap[cc] -= vv * uc[cc];
-            }
-        }
-        for (int jb = 0; jb < nb; ++jb) ld += log(Rl[(size_t)(j0 + jb) * D + j0 + jb]);
-    }
+    for (int j = 0; j < D; ++j) ld += log(Y[(size_t)j * D + j]);
     *logdet_sigma = (float)(-2.0 * ld);
-    // mu = m + R^-1 xi / sqrt(kappa)
+    // mu = m + R^-1 xi / sqrt(kappa):  R v = xi by back substitution, in the column (axpy) form: column c of R = row c of Y
     for (int d = 0; d < D; ++d) xi[d] = xi_in ? xi_in[d] : rng.normal();
-    for (int r = D - 1; r >= 0; --r) {
-        double s = xi[r];
-        const double *rr = Rl + (size_t)r * D;
-#pragma omp simd reduction(- : s)
-        for (int c = r + 1; c < D; ++c) s -= rr[c] * v[c];
-        v[r] = s / rr[r];
+    for (int c = D - 1; c >= 0; --c) {
+        const double *yc = Y + (size_t)c * D;
+        const double vc = xi[c] / yc[c];
+        v[c] = vc;
+#pragma omp simd
+        for (int r = 0; r < c; ++r) xi[r] -= vc * yc[r];
     }
     const double isk = 1.0 / sqrt(kappa);
     for (int d = 0; d < D; ++d) mu_out[d] = (float)(m[d] + v[d] * isk);
-    for (size_t e = 0; e < DD; ++e) R_out[e] = (float)Rl[e];
+    // R = Y' as Float32, 8 x 8 tiles
+    for (int r0 = 0; r0 < D; r0 += 8)
+        for (int c0 = 0; c0 < D; c0 += 8) {
+            const int r1 = std::min(D, r0 + 8), c1 = std::min(D, c0 + 8);
+            if (c0 + 8 <= r0) { for (int r = r0; r < r1; ++r) for (int c = c0; c < c1; ++c) R_out[(size_t)r * D + c] = 0.f; continue; }
+            for (int r = r0; r < r1; ++r)
+                for (int c = c0; c < c1; ++c) R_out[(size_t)r * D + c] = c >= r ? (float)Y[(size_t)c * D + r] : 0.f;
+        }
 }
-inline size_t niw_draw_scratch_doubles(int D) { return 2 * (size_t)D * D + 3 * (size_t)D; }
+inline size_t niw_draw_scratch_doubles(int D) { return (size_t)D * D + 2 * (size_t)D; }
 
 // Standard-normal noise of one draw (see niw_draw_one): depends on (seed, epoch, id) only.
 inline void niw_noise_one(int D, uint64_t seed, uint32_t id, uint32_t epoch, double *A, double *xi) {

@@ -62,7 +62,9 @@ enum {
     DPMM_OPT_STATS_ITEMS = 6,     /* work items of the statistics pass (before the first parameters) */
     DPMM_OPT_STATS_GROUPS = 7,    /* workgroups of the NIW statistics kernel (0: default) */
     DPMM_OPT_TRACE_SLOW = 8,      /* log HIP calls that block for more than 5 ms to stderr */
-    DPMM_OPT_LOGLIK_REF_CONST = 9 /* dpmm_debug_loglik adds back the reference's -D*D/2*log(2 pi) normaliser (mv_gaussian.jl:24) */
+    DPMM_OPT_LOGLIK_REF_CONST = 9,/* dpmm_debug_loglik adds back the reference's -D*D/2*log(2 pi) normaliser (mv_gaussian.jl:24) */
+    DPMM_OPT_WAVE_PRIO = 10       /* 0 / 1: NIW sweep (D <= 64) lowers a wave's issue priority while it streams matrix instructions and
+                                     raises it in its scalar / VALU phases (default 1) */
 };
 
 #define DPMM_MAX_CLUSTERS 1024

@@ -1,0 +1,31 @@
+"""Dev helper: A/B of a dpmm_set_option switch on the headline workload, interleaved rounds in ONE process.
+   python3 scripts/ab_option.py <option id> <value A> <value B> [points] [rounds]"""
+import importlib, sys, time
+import numpy as np
+sys.path.insert(0, ".")
+from __graft_entry__ import load_package
+pkg = load_package()
+host = importlib.import_module("dpmmsubclusters_jl_amd.host")
+opt, va, vb = int(sys.argv[1]), float(sys.argv[2]), float(sys.argv[3])
+N = int(float(sys.argv[4])) if len(sys.argv) > 4 else 10 ** 7
+rounds = int(sys.argv[5]) if len(sys.argv) > 5 else 6
+D, K = 64, 32
+X, y = host.gaussian_mixture_shard(N, D, K, 100.0, 12345, 0, N)
+prior = host.niw_hyperparams(1.0, np.zeros(D), D + 3, np.eye(D))
+wk = pkg.Worker(pkg.PRIOR_NIW, D, N, device=0, seed=123456789)
+wk.upload_points(X)
+s = host.DPMMSampler(wk, prior, 10.0, N, 123456789, burnout=20)
+s.start_from_labels(y, 1 + np.random.default_rng(0).integers(0, 2, N), K)
+for _ in range(10):
+    s.group_step(False, False)
+res = {va: [], vb: []}
+for r in range(rounds):
+    for v in (va, vb):
+        wk.set_option(opt, v)
+        s.group_step(False, False)
+        ms = []
+        for _ in range(5):
+            s.group_step(False, False); ms.append(wk.last_kernel_ms()[0])
+        res[v].append(float(np.median(ms)))
+for v in (va, vb):
+    print(f"option {opt} = {v}: sweep kernel median {np.median(res[v]):.4f} ms  min {np.min(res[v]):.4f}  rounds {np.round(res[v], 4).tolist()}")
