@@ -262,6 +262,9 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
     dpmm_ctx *c = new dpmm_ctx();
     c->prior = prior_kind; c->D = D; c->n = n_local; c->first = first_index; c->device = device; c->seed = seed;
     c->ldx = (D + 3) / 4 * 4;
+    // Multinomial rows are streamed in 128-byte pieces per point: pad the row to a multiple of 32 floats so that no piece straddles
+    // two cache lines (D = 1000: rows of 4000 B made every piece touch two lines, HBM reads 1.2-1.3 x the algorithmic bytes)
+    if (prior_kind == DPMM_PRIOR_MULT && D >= 32) c->ldx = (D + 31) / 32 * 32;
     c->cus = prop.multiProcessorCount;
     auto bail = [&](int code) { std::string m = c->err; dpmm_destroy(c); g_create_error = m; return code; };
 #define CHK_CREATE(expr)                                                                  \
@@ -454,7 +457,7 @@ static int check_K(dpmm_ctx *c, int K) {
 
 // ---- parameter staging: slot-indexed rows in pinned, GPU-addressable host memory ------------------------------------------
 // Layout for `slots` clusters (Float32 unless noted):
-//   NIW : mu [3 slots][D] | R [3 slots][D*D] | logdet [3 slots] | lr [slots][2] | w [slots] | cst [3 slots] | slot map Int32 [slots]
+//   NIW : mu [3 slots][D] | R [3 slots][D(D+1)/2] (packed upper triangle) | logdet [3 slots] | lr [slots][2] | w [slots] | cst [3 slots] | slot map Int32 [slots]
 //   MULT:                   logp [3 slots][D]                   | lr [slots][2] | w [slots] | cst [3 slots] | slot map Int32 [slots]
 struct ParLayout {
     size_t mu = 0, mat = 0, logdet = 0, lr = 0, w = 0, cst = 0, slot = 0, bytes = 0;
@@ -465,7 +468,7 @@ static ParLayout par_layout(const dpmm_ctx *c, int slots) {
     size_t o = 0;
     if (c->prior == DPMM_PRIOR_NIW) {
         L.mu = o; o += sizeof(float) * 3 * S * D;
-        L.mat = o; o += sizeof(float) * 3 * S * D * D;
+        L.mat = o; o += sizeof(float) * 3 * S * (D * (D + 1) / 2);
         L.logdet = o; o += sizeof(float) * 3 * S;
     } else {
         L.mat = o; o += sizeof(float) * 3 * S * D;
@@ -496,7 +499,7 @@ int dpmm_params_staging(dpmm_ctx *c, int slots, float **mu, float **mat, float *
             const size_t D = (size_t)c->D, S = (size_t)c->par_slots;
             if (c->prior == DPMM_PRIOR_NIW) {
                 memcpy(nb + N.mu, c->h_par + O.mu, sizeof(float) * 3 * S * D);
-                memcpy(nb + N.mat, c->h_par + O.mat, sizeof(float) * 3 * S * D * D);
+                memcpy(nb + N.mat, c->h_par + O.mat, sizeof(float) * 3 * S * (D * (D + 1) / 2));
                 memcpy(nb + N.logdet, c->h_par + O.logdet, sizeof(float) * 3 * S);
             } else {
                 memcpy(nb + N.mat, c->h_par + O.mat, sizeof(float) * 3 * S * D);
@@ -573,9 +576,15 @@ static int stage_and_commit(dpmm_ctx *c, int K, const float *mu, const float *ma
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));          // an earlier pack kernel may still read the staging buffer
     if (int rc = dpmm_params_staging(c, K, &smu, &smat, &sld, &slr, &sw, &sslot)) return rc;
-    const size_t D = (size_t)c->D, W = c->prior == DPMM_PRIOR_NIW ? D * D : D;
+    const size_t D = (size_t)c->D;
     if (mu) memcpy(smu, mu, sizeof(float) * 3 * K * D);
-    memcpy(smat, mat, sizeof(float) * 3 * K * W);
+    if (c->prior == DPMM_PRIOR_NIW) {       // full row-major R from the caller -> the packed upper triangle of the staging rows
+        const size_t T = D * (D + 1) / 2;
+        for (size_t j = 0; j < 3 * (size_t)K; ++j)
+            for (size_t r = 0; r < D; ++r) memcpy(smat + j * T + r * D - r * (r - 1) / 2, mat + (j * D + r) * D + r, sizeof(float) * (D - r));
+    } else {
+        memcpy(smat, mat, sizeof(float) * 3 * K * D);
+    }
     if (logdet) memcpy(sld, logdet, sizeof(float) * 3 * K);
     memcpy(slr, lr, sizeof(float) * 2 * K);
     memcpy(sw, w, sizeof(float) * K);

@@ -1078,7 +1078,8 @@ hipError_t launch_niw_sweep(int NB, const NiwSweepArgs &a, int grid, hipStream_t
 }
 
 // ---------------------------------------------------------------------------------------
-// Parameter packing: raw R (row-major [3K][D][D], upper triangular) -> MFMA A-fragment image.
+// Parameter packing: raw R (upper triangular, stored PACKED: row r holds columns r..D-1 at offset r D - r (r-1)/2 of a
+// D (D+1)/2-float record per matrix -- half the bytes of the full square cross the host link) -> MFMA A-fragment image.
 // Rp[j][pair(bi,t)][lane][jj] = R[16 bi + (lane & 15)][16 t + 4 (lane >> 4) + jj], zero beyond D
 // and below the diagonal.  mup[j][DP] = mu zero-padded.
 // `slot` (nullable): packed matrix j = 3k+w is read from source row 3*slot[k]+w (the host keeps a cluster's rows in place for
@@ -1086,11 +1087,15 @@ hipError_t launch_niw_sweep(int NB, const NiwSweepArgs &a, int grid, hipStream_t
 __device__ __forceinline__ size_t src_row(const int32_t *__restrict__ slot, int j) {
     return slot ? (size_t)(3 * slot[j / 3] + j % 3) : (size_t)j;
 }
+__device__ __forceinline__ size_t tri_off(int D, int row, int col) {      // col >= row
+    return (size_t)row * D - (size_t)row * (row - 1) / 2 + (size_t)(col - row);
+}
 __global__ void niw_pack_kernel(const float *__restrict__ R, const float *__restrict__ mu, float *__restrict__ Rp,
                                 float *__restrict__ mup, int D, int NB, int nmat, float *__restrict__ tail, const float *__restrict__ cst,
                                 const int32_t *__restrict__ slot) {
     const int NP = NB * (NB + 1) / 2;
     const int DP = 16 * NB;
+    const size_t TRI = (size_t)D * (D + 1) / 2;
     const int64_t total = (int64_t)nmat * NP * 256;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int jj = (int)(e & 3);
@@ -1104,7 +1109,7 @@ __global__ void niw_pack_kernel(const float *__restrict__ R, const float *__rest
         const int row = 16 * bi + (lane & 15);
         const int col = 16 * t + 4 * (lane >> 4) + jj;
         float v = 0.f;
-        if (row < D && col < D && col >= row) v = R[(src_row(slot, j) * D + row) * D + col];
+        if (row < D && col < D && col >= row) v = R[src_row(slot, j) * TRI + tri_off(D, row, col)];
         Rp[e] = v;
     }
     const int64_t totmu = (int64_t)nmat * DP;
@@ -1124,7 +1129,7 @@ __global__ void niw_pack_kernel(const float *__restrict__ R, const float *__rest
             const int tr[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3}, tc[10] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3};
             float v = 0.f;
             if (k >= K) v = (q == 14) ? -INFINITY : 0.f;
-            else if (q < 10) v = R[(j * D + f0 + tr[q]) * D + f0 + tc[q]];
+            else if (q < 10) v = R[j * TRI + tri_off(D, f0 + tr[q], f0 + tc[q])];
             else if (q < 14) v = mu[j * D + f0 + (q - 10)];
             else if (q == 14) v = cst[3 * k];
             tail[e] = v;
@@ -1142,8 +1147,8 @@ __global__ __launch_bounds__(256) void niw_screen_prep_kernel(const float *__res
     extern __shared__ float sh[];            // Rk [D*D] | v [D][D+1] | red[256]
     float *Rk = sh, *v = sh + (size_t)D * D, *red = v + (size_t)D * (D + 1);
     const int k = blockIdx.x, tid = threadIdx.x;
-    const float *Rg = R + src_row(slot, 3 * k) * D * D;
-    for (int e = tid; e < D * D; e += blockDim.x) Rk[e] = Rg[e];
+    const float *Rg = R + src_row(slot, 3 * k) * ((size_t)D * (D + 1) / 2);
+    for (int e = tid; e < D * D; e += blockDim.x) { const int r = e / D, cc = e % D; Rk[e] = cc >= r ? Rg[tri_off(D, r, cc)] : 0.f; }
     __syncthreads();
     float ss = 0.f;
     for (int c = tid; c < D; c += blockDim.x) {

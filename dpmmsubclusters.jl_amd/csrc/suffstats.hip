@@ -379,7 +379,22 @@ __global__ __launch_bounds__(256) void niw_reduce_kernel(StatsArgs A, int NBK) {
     const int i0 = A.sb.item_start[b], i1 = A.sb.item_start[b + 1];
     const int total_items = A.sb.item_start[A.nbins];
     const int q = (total_items + A.range_groups - 1) / A.range_groups;      // as in niw_stats_kernel
-    for (int it = i0; it < i1; it = (it / q + 1) * q) s += A.slabs[(int64_t)it * A.slab_stride + off];   // segment heads, in order
+    // segment heads, in order; eight loads in flight per trip (the walk is a chain of dependent-latency loads otherwise), summed in
+    // the same order as the one-at-a-time loop
+    int it = i0;
+    while (it < i1) {
+        double v[8];
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool ok = it < i1;
+            v[u] = ok ? A.slabs[(int64_t)it * A.slab_stride + off] : 0.;
+            cnt += ok ? 1 : 0;
+            if (ok) it = (it / q + 1) * q;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (u < cnt) s += v[u];
+    }
     out[e] = s;
 }
 

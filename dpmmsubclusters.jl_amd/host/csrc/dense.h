@@ -32,15 +32,28 @@ constexpr int kBlk = 8;
         (yb)[k_] -= (B)[0] * v0 + (B)[1] * v1 + (B)[2] * v2 + (B)[3] * v3 + (B)[4] * v4 + (B)[5] * v5 + (B)[6] * v6 + (B)[7] * v7;    \
     }
 
+// the same with sixteen vectors: halves the traffic of the updated rows (at D = 256 they stream from L2)
+#define DPMMH_RANK16_2ROWS(ya, yb, A, B, X, ldx, n)                                                                          \
+    _Pragma("omp simd") for (int k_ = 0; k_ < (n); ++k_) {                                                                  \
+        double sa = 0.0, sb = 0.0;                                                                                          \
+        _Pragma("GCC unroll 16") for (int c_ = 0; c_ < 16; ++c_) {                                                                 \
+            const double v = (X)[(size_t)c_ * (ldx) + k_];                                                                  \
+            sa += (A)[c_] * v;                                                                                              \
+            sb += (B)[c_] * v;                                                                                              \
+        }                                                                                                                   \
+        (ya)[k_] -= sa;                                                                                                     \
+        (yb)[k_] -= sb;                                                                                                     \
+    }
+
 // P (row-major D x D, LOWER triangle valid, destroyed) = L' L with L lower triangular.  L (row-major D x D) receives the factor
 // (entries above the diagonal are set to zero) -- or L == nullptr: only the log-determinant is wanted and the factor stays in P's
 // lower triangle.  Returns log det P = 2 sum log L_jj, NaN when P is not positive definite.
 DPMMH_CLONES inline double chol_ltl(double *__restrict__ P, int D, double *__restrict__ Lout) {
     double ld = 0.0;
-    for (int j1 = D; j1 > 0; j1 -= kBlk) {
-        const int j0 = j1 > kBlk ? j1 - kBlk : 0;
-        // rows j1-1 .. j0 of the factor, in place: pending updates of the block's own later rows, then scale by 1 / diagonal
-        for (int j = j1 - 1; j >= j0; --j) {
+    bool ok = true;
+    // rows j1-1 .. j0 of the factor, in place: pending updates of the block's own later rows, then scale by 1 / diagonal
+    auto factor_rows = [&](int j0, int j1) {
+        for (int j = j1 - 1; j >= j0 && ok; --j) {
             double *row = P + (size_t)j * D;
             for (int c = j + 1; c < j1; ++c) {
                 const double *w = P + (size_t)c * D;
@@ -49,34 +62,36 @@ DPMMH_CLONES inline double chol_ltl(double *__restrict__ P, int D, double *__res
                 for (int k = 0; k <= j; ++k) row[k] -= a * w[k];
             }
             const double s = row[j];
-            if (!(s > 0.0)) return NAN;
+            if (!(s > 0.0)) { ok = false; return; }
             const double d = sqrt(s), inv = 1.0 / d;
             ld += log(d);
 #pragma omp simd
             for (int k = 0; k < j; ++k) row[k] *= inv;
             row[j] = d;
         }
-        // trailing rows k < j0:  P[k][0..k] -= sum_{c in block} L[c][k] * L[c][0..k], two rows per pass
-        if (j0 > 0 && j1 - j0 == kBlk) {
-            const double *w0 = P + (size_t)j0 * D, *w1 = w0 + D, *w2 = w1 + D, *w3 = w2 + D, *w4 = w3 + D, *w5 = w4 + D, *w6 = w5 + D, *w7 = w6 + D;
-            int k = 0;
-            for (; k + 1 < j0; k += 2) {
+    };
+    // rows k in [klo, khi):  P[k][0..k] -= sum_{c < nw} W[c][k] * W[c][0..k]  with the nw (<= 8) factor rows W = P + w0 * D
+    auto trail8 = [&](int w0r, int nw, int klo, int khi) {
+        if (nw == kBlk) {
+            const double *w0 = P + (size_t)w0r * D, *w1 = w0 + D, *w2 = w1 + D, *w3 = w2 + D, *w4 = w3 + D, *w5 = w4 + D, *w6 = w5 + D, *w7 = w6 + D;
+            int k = klo;
+            for (; k + 1 < khi; k += 2) {
                 double *ya = P + (size_t)k * D, *yb = ya + D;
                 const double a[kBlk] = {w0[k], w1[k], w2[k], w3[k], w4[k], w5[k], w6[k], w7[k]};
                 const double b[kBlk] = {w0[k + 1], w1[k + 1], w2[k + 1], w3[k + 1], w4[k + 1], w5[k + 1], w6[k + 1], w7[k + 1]};
                 DPMMH_RANK8_2ROWS(ya, yb, a, b, w0, w1, w2, w3, w4, w5, w6, w7, k + 2)     // row k's entry at column k+1 is scratch
             }
-            if (k < j0) {
+            if (k < khi) {
                 double *ya = P + (size_t)k * D;
                 const double a[kBlk] = {w0[k], w1[k], w2[k], w3[k], w4[k], w5[k], w6[k], w7[k]};
 #pragma omp simd
                 for (int q = 0; q <= k; ++q)
                     ya[q] -= a[0] * w0[q] + a[1] * w1[q] + a[2] * w2[q] + a[3] * w3[q] + a[4] * w4[q] + a[5] * w5[q] + a[6] * w6[q] + a[7] * w7[q];
             }
-        } else if (j0 > 0) {    // ragged first block (D not a multiple of 8): plain rank-1 updates
-            for (int c = j0; c < j1; ++c) {
-                const double *w = P + (size_t)c * D;
-                for (int k = 0; k < j0; ++k) {
+        } else {
+            for (int c = 0; c < nw; ++c) {
+                const double *w = P + (size_t)(w0r + c) * D;
+                for (int k = klo; k < khi; ++k) {
                     double *y = P + (size_t)k * D;
                     const double a = w[k];
 #pragma omp simd
@@ -84,7 +99,47 @@ DPMMH_CLONES inline double chol_ltl(double *__restrict__ P, int D, double *__res
                 }
             }
         }
+    };
+    int j1 = D;
+    while (j1 > 0 && ok) {
+        if (j1 >= 2 * kBlk) {
+            // sixteen rows: [j1-8, j1) first (its update reaches the other eight at once), then [j1-16, j1-8); all rows above get ONE
+            // rank-16 update -- half the read-modify-write traffic of two rank-8 sweeps over the trailing triangle
+            const int jm = j1 - kBlk, j0 = j1 - 2 * kBlk;
+            factor_rows(jm, j1);
+            if (!ok) break;
+            trail8(jm, kBlk, j0, jm);
+            factor_rows(j0, jm);
+            if (!ok) break;
+            const double *W = P + (size_t)j0 * D;
+            int k = 0;
+            for (; k + 1 < j0; k += 2) {
+                double *ya = P + (size_t)k * D, *yb = ya + D;
+                double a[16], b[16];
+                for (int c = 0; c < 16; ++c) { a[c] = W[(size_t)c * D + k]; b[c] = W[(size_t)c * D + k + 1]; }
+                DPMMH_RANK16_2ROWS(ya, yb, a, b, W, D, k + 2)
+            }
+            if (k < j0) {
+                double *ya = P + (size_t)k * D;
+                double a[16];
+                for (int c = 0; c < 16; ++c) a[c] = W[(size_t)c * D + k];
+#pragma omp simd
+                for (int q = 0; q <= k; ++q) {
+                    double sa = 0.0;
+                    for (int c = 0; c < 16; ++c) sa += a[c] * W[(size_t)c * D + q];
+                    ya[q] -= sa;
+                }
+            }
+            j1 = j0;
+        } else {
+            const int j0 = j1 > kBlk ? j1 - kBlk : 0;
+            factor_rows(j0, j1);
+            if (!ok) break;
+            if (j0 > 0) trail8(j0, j1 - j0, 0, j0);
+            j1 = j0;
+        }
     }
+    if (!ok) return NAN;
     if (Lout) {
         for (int j = 0; j < D; ++j) {
             memcpy(Lout + (size_t)j * D, P + (size_t)j * D, sizeof(double) * (j + 1));
@@ -101,7 +156,28 @@ DPMMH_CLONES inline void solve_lower_left(double *__restrict__ Y, const double *
     for (int i0 = 0; i0 < D; i0 += kBlk) {
         const int i1 = i0 + kBlk < D ? i0 + kBlk : D;
         // contributions of all earlier row blocks [k0, k0 + 8), k0 < i0 (full blocks: i0 is a multiple of 8)
-        for (int k0 = 0; k0 < i0; k0 += kBlk) {
+        int k0 = 0;
+        for (; k0 + 2 * kBlk <= i0; k0 += 2 * kBlk) {      // two earlier blocks at a time: rank-16 (rows k0..k0+15 are zero beyond column k0+15)
+            const double *X = Y + (size_t)k0 * D;
+            const int len = k0 + 2 * kBlk;
+            int i = i0;
+            for (; i + 1 < i1; i += 2) {
+                double *ya = Y + (size_t)i * D, *yb = ya + D;
+                const double *a = L + (size_t)i * D + k0, *b = a + D;
+                DPMMH_RANK16_2ROWS(ya, yb, a, b, X, D, len)
+            }
+            if (i < i1) {
+                double *ya = Y + (size_t)i * D;
+                const double *a = L + (size_t)i * D + k0;
+#pragma omp simd
+                for (int q = 0; q < len; ++q) {
+                    double sa = 0.0;
+                    for (int c = 0; c < 16; ++c) sa += a[c] * X[(size_t)c * D + q];
+                    ya[q] -= sa;
+                }
+            }
+        }
+        for (; k0 < i0; k0 += kBlk) {
             const double *y0 = Y + (size_t)k0 * D, *y1 = y0 + D, *y2 = y1 + D, *y3 = y2 + D, *y4 = y3 + D, *y5 = y4 + D, *y6 = y5 + D, *y7 = y6 + D;
             const int len = k0 + kBlk;                    // rows k0..k0+7 of Y are zero beyond their diagonals
             int i = i0;

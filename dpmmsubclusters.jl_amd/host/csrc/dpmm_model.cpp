@@ -314,7 +314,7 @@ struct dpmmh_model {
                 const bool pre = have_noise && id < noise_rows;
                 dpmmh::niw_draw_one(D, kappa[row], nu[row], mean.data() + (size_t)row * D, U.data() + (size_t)row * DD, seed, (uint32_t)id,
                                     draw_epoch, pre ? noise_A.data() + (size_t)id * DD : nullptr, pre ? noise_xi.data() + (size_t)id * D : nullptr,
-                                    sc.data(), st_mu + (size_t)row * D, st_mat + (size_t)row * DD, &st_logdet[row]);
+                                    sc.data(), st_mu + (size_t)row * D, st_mat + (size_t)row * T, &st_logdet[row], true);
             } else {
                 auto &sc = scratch[th];
                 if (sc.empty()) sc.resize(D);
@@ -838,7 +838,15 @@ HAPI int64_t dpmmh_model_get(dpmmh_model *m, const char *field, void *out, int64
         }
         if (m->st_slots > 0) {
             if (f == "mu") return emit(out, cap, rows_f(m->st_mu, D));
-            if (f == "R") return emit(out, cap, rows_f(m->st_mat, DD));
+            if (f == "R") {          // staging holds the packed upper triangle: hand out the full square
+                std::vector<float> v((size_t)3 * K * DD, 0.f);
+                for (int k = 0; k < K; ++k) for (int r3 = 0; r3 < 3; ++r3) {
+                    const float *src = m->st_mat + ((size_t)3 * m->slot[k] + r3) * m->T;
+                    float *dst = v.data() + ((size_t)3 * k + r3) * DD;
+                    for (int r = 0; r < D; ++r) memcpy(dst + (size_t)r * D + r, src + (size_t)r * D - (size_t)r * (r - 1) / 2, sizeof(float) * (D - r));
+                }
+                return emit(out, cap, v);
+            }
             if (f == "logdet") return emit(out, cap, rows_f(m->st_logdet, 1));
         }
     } else {
@@ -888,7 +896,16 @@ HAPI int dpmmh_model_set(dpmmh_model *m, const char *field, const void *in, int6
         for (int k = 0; k < K; ++k) for (int r = 0; r < 3; ++r) memcpy(&dst[((size_t)3 * m->slot[k] + r) * w], &src[((size_t)3 * k + r) * w], sizeof(float) * w);
     };
     if (f == "mu" && m->kind == DPMMH_PRIOR_NIW) { if (!need(4LL * 3 * K * D)) return -1; rows_f(m->st_mu, D); return 0; }
-    if (f == "R" && m->kind == DPMMH_PRIOR_NIW) { if (!need((int64_t)(4 * 3 * K * DD))) return -1; rows_f(m->st_mat, DD); return 0; }
+    if (f == "R" && m->kind == DPMMH_PRIOR_NIW) {
+        if (!need((int64_t)(4 * 3 * K * DD))) return -1;
+        const float *src = (const float *)in;
+        for (int k = 0; k < K; ++k) for (int r3 = 0; r3 < 3; ++r3) {
+            float *dst = m->st_mat + ((size_t)3 * m->slot[k] + r3) * m->T;
+            const float *sq = src + ((size_t)3 * k + r3) * DD;
+            for (int r = 0; r < D; ++r) memcpy(dst + (size_t)r * D - (size_t)r * (r - 1) / 2, sq + (size_t)r * D + r, sizeof(float) * (D - r));
+        }
+        return 0;
+    }
     if (f == "logdet" && m->kind == DPMMH_PRIOR_NIW) { if (!need(4LL * 3 * K)) return -1; rows_f(m->st_logdet, 1); return 0; }
     if (f == "logp" && m->kind == DPMMH_PRIOR_MULT) { if (!need(4LL * 3 * K * D)) return -1; rows_f(m->st_mat, D); return 0; }
     if (f == "lr_weights") { if (!need(8LL * K)) return -1; memcpy(m->st_lr, in, bytes); return 0; }

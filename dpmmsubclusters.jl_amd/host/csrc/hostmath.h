@@ -116,10 +116,11 @@ inline double niw_log_marginal(int D, double k0, double v0, double logdet_psi0, 
 // One draw (mu, R, logdet Sigma) from a prepared posterior (kappa, nu, m, L with nu psi = L' L, L lower triangular = U').
 // `id`/`epoch` key the random streams (normals: stream 16 -- identical whether pre-generated or not; chi-squares: stream 18).
 // An / xi_in: optional pre-generated standard normals (strictly-lower Bartlett entries row-major [D][D], and xi [D]).
-// scratch: D^2 + 2 D doubles.  mu_out [D], R_out [D*D] (upper, zeros below), Float32.
+// scratch: D^2 + 2 D doubles.  mu_out [D]; R_out Float32: [D*D] full (upper, zeros below) or, r_packed, the packed upper
+// triangle [D(D+1)/2] of the worker's parameter staging (row r: columns r..D-1 at offset r D - r (r-1)/2).
 inline void niw_draw_one(int D, double kappa, double nu, const double *m, const double *Li, uint64_t seed, uint32_t id,
                          uint32_t epoch, const double *An, const double *xi_in, double *scratch, float *mu_out, float *R_out,
-                         float *logdet_sigma) {
+                         float *logdet_sigma, bool r_packed = false) {
     const size_t DD = (size_t)D * D;
     double *Y = scratch, *xi = scratch + DD, *v = scratch + DD + D;
     Philox rng(seed, id, epoch, 16u), rng_chi(seed, id, epoch, 18u);
@@ -146,14 +147,17 @@ inline void niw_draw_one(int D, double kappa, double nu, const double *m, const 
     }
     const double isk = 1.0 / sqrt(kappa);
     for (int d = 0; d < D; ++d) mu_out[d] = (float)(m[d] + v[d] * isk);
-    // R = Y' as Float32, 8 x 8 tiles
+    // R = Y' as Float32: row r of R = column r of Y from the diagonal down, 8 x 8 tiles (R_out packed or full, see r_packed)
     for (int r0 = 0; r0 < D; r0 += 8)
-        for (int c0 = 0; c0 < D; c0 += 8) {
+        for (int c0 = r0; c0 < D; c0 += 8) {
             const int r1 = std::min(D, r0 + 8), c1 = std::min(D, c0 + 8);
-            if (c0 + 8 <= r0) { for (int r = r0; r < r1; ++r) for (int c = c0; c < c1; ++c) R_out[(size_t)r * D + c] = 0.f; continue; }
-            for (int r = r0; r < r1; ++r)
-                for (int c = c0; c < c1; ++c) R_out[(size_t)r * D + c] = c >= r ? (float)Y[(size_t)c * D + r] : 0.f;
+            for (int r = r0; r < r1; ++r) {
+                float *dst = r_packed ? R_out + (size_t)r * D - (size_t)r * (r - 1) / 2 - r : R_out + (size_t)r * D;     // dst[c], c >= r
+                for (int c = std::max(c0, r); c < c1; ++c) dst[c] = (float)Y[(size_t)c * D + r];
+            }
         }
+    if (!r_packed)
+        for (int r = 1; r < D; ++r) memset(R_out + (size_t)r * D, 0, sizeof(float) * r);
 }
 inline size_t niw_draw_scratch_doubles(int D) { return (size_t)D * D + 2 * (size_t)D; }
 

@@ -124,7 +124,8 @@ int dpmm_set_params_mult(dpmm_ctx *ctx, int K, const float *logp, const float *l
 /* The per-sweep path of the same hand-over, without copies: dpmm_params_staging returns pointers into pinned, GPU-addressable
  * host memory owned by the ctx, sized for `slots` clusters; the master writes its parameter draws there IN PLACE and
  * dpmm_commit_params(K) packs them for the kernels (which read the staging buffer directly; no synchronisation).
- *   NIW : mu [3 slots][D], mat = R [3 slots][D*D] (upper-triangular factor), logdet [3 slots]
+ *   NIW : mu [3 slots][D], mat = R [3 slots][D(D+1)/2] -- the upper-triangular factor PACKED row by row (row r holds
+ *         columns r..D-1 at offset r*D - r*(r-1)/2): half the bytes of the square cross the host link --, logdet [3 slots]
  *   MULT: mu = NULL, mat = logp [3 slots][D], logdet = NULL
  *   lr_weights [K][2], weights [K] and slot_of_cluster [K] in cluster order: cluster k's three rows are rows
  *   3*slot_of_cluster[k] + w of mu / mat / logdet -- a cluster keeps its rows in place for life, removing clusters only edits the map.

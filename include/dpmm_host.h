@@ -50,7 +50,8 @@ typedef struct dpmmh_worker {
     int rank, world;
     /* Persistent host staging for the cluster parameters, sized for `slots` clusters (3 rows each).  Rows are indexed by
      * SLOT (a cluster keeps its slot for life; slot_of_cluster maps the k-th live cluster to its slot):
-     *   NIW : mu [3*slots][D], mat = R [3*slots][D*D] (upper-triangular factor of Sigma^-1), logdet [3*slots]
+     *   NIW : mu [3*slots][D], mat = R [3*slots][D(D+1)/2] (upper-triangular factor of Sigma^-1, packed row by row:
+     *         row r holds columns r..D-1 at offset r*D - r*(r-1)/2), logdet [3*slots]
      *   MULT: mu = NULL, mat = logp [3*slots][D], logdet = NULL
      *   lr [K][2] and w [K] in cluster order; slot_of_cluster [K].
      * Pointers stay valid until the next call with a larger `slots` (contents are preserved).  dpmm_params_staging */

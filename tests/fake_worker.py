@@ -37,7 +37,7 @@ class FakeWorker:
         cap = max(8, slots)
         niw = self.prior == PRIOR_NIW
         new = dict(slots=cap, mu=np.zeros((3 * cap, D), np.float32) if niw else None,
-                   mat=np.zeros((3 * cap, D * D if niw else D), np.float32), logdet=np.zeros(3 * cap, np.float32) if niw else None,
+                   mat=np.zeros((3 * cap, D * (D + 1) // 2 if niw else D), np.float32), logdet=np.zeros(3 * cap, np.float32) if niw else None,
                    lr=np.zeros((cap, 2), np.float32), w=np.zeros(cap, np.float32), slot=np.zeros(cap, np.int32))
         if old is not None:
             for k in ("mu", "mat", "logdet", "lr", "w", "slot"):
@@ -50,7 +50,11 @@ class FakeWorker:
         st = self._staging
         rows = (3 * st["slot"][:K].astype(np.int64)[:, None] + np.arange(3)[None, :]).ravel()
         if self.prior == PRIOR_NIW:
-            self.set_params_niw_chol(st["mu"][rows], st["mat"][rows], st["logdet"][rows], st["lr"][:K], st["w"][:K])
+            D = self.D
+            R = np.zeros((len(rows), D, D), np.float32)            # staging rows hold the packed upper triangle (row r: columns r..D-1)
+            iu = np.triu_indices(D)
+            R[:, iu[0], iu[1]] = st["mat"][rows]
+            self.set_params_niw_chol(st["mu"][rows], R, st["logdet"][rows], st["lr"][:K], st["w"][:K])
         else:
             self.set_params_mult(st["mat"][rows], st["lr"][:K], st["w"][:K])
 
