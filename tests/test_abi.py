@@ -35,6 +35,28 @@ def test_library_exports_every_declared_symbol(pkg):
     assert lib.dpmm_abi_version() == 2
 
 
+def test_host_library_exports_every_declared_symbol(pkg):
+    """include/dpmm_host.h (the master half, libdpmmhost.so): every declared dpmmh_* function is exported; the worker table the
+    Python binding builds has the layout of struct dpmmh_worker (ctx, rank, world, then the function pointers in header order)."""
+    import importlib
+    native = importlib.import_module("dpmmsubclusters_jl_amd.host.native")
+    engine = importlib.import_module("dpmmsubclusters_jl_amd.host.engine")
+    src = open(os.path.join(ROOT, "include", "dpmm_host.h")).read()
+    body = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(dpmmh_[a-z0-9_]+)\s*\(", body)) - {"dpmmh_split_hook"})
+    lib = ctypes.CDLL(native.build_library())
+    for n in names:
+        assert hasattr(lib, n), n
+    lib.dpmmh_abi_version.restype = ctypes.c_int
+    assert lib.dpmmh_abi_version() == 2
+    struct = body[body.index("typedef struct dpmmh_worker {"):body.index("} dpmmh_worker;")]
+    members = re.findall(r"\(\*([a-z_]+)\)\s*\(", struct)
+    assert [f[0] for f in engine.WorkerTable._fields_] == ["ctx", "rank", "world"] + members
+    # every member is bound to a libdpmmhip entry point that the worker header declares
+    assert [m for m, _, _ in engine._NATIVE_MAP] == members
+    assert set(sym for _, sym, _ in engine._NATIVE_MAP) <= set(declared_functions())
+
+
 def test_no_cpu_fallback(pkg):
     import torch
     if torch.cuda.is_available():
