@@ -62,6 +62,10 @@ struct dpmm_ctx {
     float *d_cst = nullptr;   // [3K]
     uint32_t *d_Lp16 = nullptr;  // MULT: 3-plane bf16 split of the log-probabilities (count data fast path)
     int x_bf16_exact = 0;     // MULT: every x is exactly representable in bf16 (checked at upload)
+    uint8_t *dX8 = nullptr;   // MULT: byte copy of the points when every x is an integer in [0, 255] ([n][ld8])
+    int64_t ld8 = 0;
+    int x_u8 = 0;
+    int opt_no_u8 = 0;
     float *d_scratch = nullptr;
     int64_t scratch_stride = 0;
     bool have_params = false;
@@ -227,7 +231,7 @@ static int ensure_capacity(dpmm_ctx *c, int K) {
         const size_t NT = (size_t)(c->ldx + 15) / 16, NRB = (size_t)(3 * cap + 15) / 16;
         HIPCHK(c, hipMalloc(&c->d_raw, sizeof(float) * 3 * cap * (size_t)c->ldx));
         HIPCHK(c, hipMalloc(&c->d_Rp, sizeof(float) * NRB * NT * 256));
-        HIPCHK(c, hipMalloc(&c->d_Lp16, sizeof(uint32_t) * mult_pack_bf16_words(3 * cap, c->ldx)));
+        HIPCHK(c, hipMalloc(&c->d_Lp16, sizeof(uint32_t) * std::max(mult_pack_bf16_words(3 * cap, c->ldx), mult_pack_u8_words(3 * cap, (c->D + 127) / 128 * 128))));
     }
     HIPCHK(c, hipMalloc(&c->d_cst, sizeof(float) * 3 * cap));
     HIPCHK(c, hipMalloc(&c->d_tdf, sizeof(float) * 6 * cap));
@@ -322,7 +326,7 @@ int dpmm_destroy(dpmm_ctx *c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     free_params(c);
-    hipFree(c->dX); hipFree(c->dbins); hipFree(c->d_gt); hipFree(c->d_cont);
+    hipFree(c->dX); hipFree(c->dX8); hipFree(c->dbins); hipFree(c->d_gt); hipFree(c->d_cont);
     hipFree(c->sb.tile_hist); hipFree(c->sb.bin_total); hipFree(c->sb.bin_start); hipFree(c->sb.item_start);
     hipFree(c->sb.perm); hipFree(c->sb.bin_sel); hipFree(c->sb.perm_total); hipFree(c->d_small); hipFree(c->d_proj); hipFree(c->d_vals); hipFree(c->d_smart);
     hipFree(c->d_flags); hipFree(c->d_counts64); hipFree(c->d_work);
@@ -347,6 +351,18 @@ static int finish_upload(dpmm_ctx *c) {
         HIPCHK(c, hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->x_bf16_exact = (h == 0 && !force_f32) ? 1 : 0;
+        c->x_u8 = 0;
+        if (c->x_bf16_exact && !c->opt_no_u8 && c->n > 0) {
+            // small non-negative integers (bag-of-words counts): keep a lossless byte copy and stream 1 byte per element
+            c->ld8 = (c->D + 127) / 128 * 128;
+            if (!c->dX8) HIPCHK(c, hipMalloc(&c->dX8, (size_t)c->n * (size_t)c->ld8));
+            HIPCHK(c, hipMemsetAsync(flag, 0, sizeof(int), c->stream));
+            HIPCHK(c, launch_u8_convert(c->dX, c->ldx, c->D, c->n, c->dX8, c->ld8, flag, c->stream));
+            HIPCHK(c, hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            c->x_u8 = (h == 0) ? 1 : 0;
+            if (!c->x_u8) { hipFree(c->dX8); c->dX8 = nullptr; }
+        }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return DPMM_OK;
@@ -561,7 +577,8 @@ int dpmm_commit_params(dpmm_ctx *c, int K) {
     } else {
         HIPCHK(c, launch_gather_rows(c->d_raw, c->ldx, hmat, c->D, hslot, 3 * K, c->D, c->stream));
         HIPCHK(c, launch_mult_pack(c->d_raw, c->d_Rp, 3 * K, c->ldx, c->stream));
-        if (c->x_bf16_exact) HIPCHK(c, launch_mult_pack_bf16(c->d_raw, c->d_Lp16, 3 * K, c->ldx, c->stream));
+        if (c->x_u8) HIPCHK(c, launch_mult_pack_u8(c->d_raw, c->d_Lp16, 3 * K, c->ldx, c->ld8, c->stream));
+        else if (c->x_bf16_exact) HIPCHK(c, launch_mult_pack_bf16(c->d_raw, c->d_Lp16, 3 * K, c->ldx, c->stream));
     }
     c->K = K;
     c->have_params = true;
@@ -689,7 +706,8 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
         a.scratch_by_tile = table ? 1 : 0;
         a.labels_only = table ? 1 : 0;
         a.bins = c->dbins; a.seed = c->seed; a.epoch = epoch; a.final_argmax = final_argmax;
-        if (c->x_bf16_exact) HIPCHK(c, launch_mult_sweep_bf16(a, c->d_Lp16, c->sweep_grid, c->stream));
+        if (c->x_u8) HIPCHK(c, launch_mult_sweep_u8(a, c->dX8, c->ld8, c->d_Lp16, c->sweep_grid, c->stream));
+        else if (c->x_bf16_exact) HIPCHK(c, launch_mult_sweep_bf16(a, c->d_Lp16, c->sweep_grid, c->stream));
         else HIPCHK(c, launch_mult_sweep(a, c->sweep_grid, c->stream));
     }
     if (!table) {
@@ -873,6 +891,7 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
     HIPCHK(c, launch_sort_finish(c->dbins, a, c->stream));
     c->have_perm = c->n > 0;
     if (c->prior == DPMM_PRIOR_NIW) HIPCHK(c, launch_niw_stats(a, c->stream));
+    else if (c->x_u8) HIPCHK(c, launch_mult_stats_u8(a, c->dX8, c->ld8, c->stream));
     else HIPCHK(c, launch_mult_stats(a, c->stream));
     if (c->comm) {
         // the one exchange of the sweep: elementwise sum of the per-worker statistics (update_suff_stats_posterior!,
@@ -1171,6 +1190,9 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
         case DPMM_OPT_TRACE_SLOW: c->opt_trace = value != 0; return DPMM_OK;
         case DPMM_OPT_LOGLIK_REF_CONST: c->opt_ref_const = value != 0; return DPMM_OK;
         case DPMM_OPT_WAVE_PRIO: c->opt_prio = value != 0; return DPMM_OK;
+        case DPMM_OPT_MULT_NO_U8:
+            if (c->have_points) return fail(c, DPMM_ESTATE, "DPMM_OPT_MULT_NO_U8 must be set before the points are uploaded");
+            c->opt_no_u8 = value != 0; return DPMM_OK;
         default: return fail(c, DPMM_EINVAL, "unknown option");
     }
 }
@@ -1299,7 +1321,7 @@ int dpmm_debug_subloglik(dpmm_ctx *c, float *out) {
         if (e == hipSuccess) e = hipMemsetAsync(traw, 0, sizeof(float) * 3 * K2 * (size_t)c->ldx, c->stream);
         const size_t NT = (size_t)(c->ldx + 15) / 16, NRB = (size_t)(3 * K2 + 15) / 16;
         if (e == hipSuccess) e = hipMalloc(&tRp, sizeof(float) * NRB * NT * 256);
-        if (e == hipSuccess) e = hipMalloc(&tL16, sizeof(uint32_t) * mult_pack_bf16_words(3 * K2, c->ldx));
+        if (e == hipSuccess) e = hipMalloc(&tL16, sizeof(uint32_t) * std::max(mult_pack_bf16_words(3 * K2, c->ldx), mult_pack_u8_words(3 * K2, (c->D + 127) / 128 * 128)));
         if (e == hipSuccess) e = hipMemsetAsync(tcst, 0, sizeof(float) * 3 * K2, c->stream);
         for (int j = 0; j < K2 && e == hipSuccess; ++j) {
             const int src = 3 * (j / 2) + 1 + (j % 2);
@@ -1307,7 +1329,8 @@ int dpmm_debug_subloglik(dpmm_ctx *c, float *out) {
             if (e == hipSuccess) e = hipMemcpyAsync(tcst + 3 * j, c->d_cst + src, sizeof(float), hipMemcpyDeviceToDevice, c->stream);
         }
         if (e == hipSuccess) e = launch_mult_pack(traw, tRp, 3 * K2, c->ldx, c->stream);
-        if (e == hipSuccess && c->x_bf16_exact) e = launch_mult_pack_bf16(traw, tL16, 3 * K2, c->ldx, c->stream);
+        if (e == hipSuccess && c->x_u8) e = launch_mult_pack_u8(traw, tL16, 3 * K2, c->ldx, c->ld8, c->stream);
+        else if (e == hipSuccess && c->x_bf16_exact) e = launch_mult_pack_bf16(traw, tL16, 3 * K2, c->ldx, c->stream);
         if (e == hipSuccess) { c->d_Rp = tRp; c->d_cst = tcst; c->d_Lp16 = tL16; c->d_raw = traw; }
     }
     if (e == hipSuccess) {

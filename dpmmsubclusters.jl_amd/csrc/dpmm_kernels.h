@@ -79,6 +79,11 @@ hipError_t launch_bf16_exact_check(const float *X, int64_t nwords, int *d_flag, 
 size_t mult_pack_bf16_words(int rows, int64_t ldx);
 hipError_t launch_mult_pack_bf16(const float *logp, uint32_t *Lp16, int rows, int64_t ldx, hipStream_t s);
 hipError_t launch_mult_sweep_bf16(const MultSweepArgs &a, const uint32_t *Lp16, int grid, hipStream_t s);
+// u8 path (integer data in [0, 255]): byte copy of the points, parameter planes in the matching feature order, sweep, statistics
+hipError_t launch_u8_convert(const float *X, int64_t ldx, int D, int64_t n, uint8_t *X8, int64_t ld8, int *d_flag, hipStream_t s);
+size_t mult_pack_u8_words(int rows, int64_t ld8);
+hipError_t launch_mult_pack_u8(const float *logp, uint32_t *Lp8, int rows, int64_t ldx, int64_t ld8, hipStream_t s);
+hipError_t launch_mult_sweep_u8(const MultSweepArgs &a, const uint8_t *X8, int64_t ld8, const uint32_t *Lp8, int grid, hipStream_t s);
 
 // ---- label bookkeeping (labels.hip)
 // dst/src: device or pinned-host pointers, 4-byte aligned; bytes rounded up to a multiple of 4
@@ -150,5 +155,6 @@ int64_t niw_slab_stride(int D);
 int64_t mult_slab_stride(int D);
 hipError_t launch_niw_stats(const StatsArgs &a, hipStream_t s);
 hipError_t launch_mult_stats(const StatsArgs &a, hipStream_t s);
+hipError_t launch_mult_stats_u8(const StatsArgs &a, const uint8_t *X8, int64_t ld8, hipStream_t s);
 
 }  // namespace dpmm

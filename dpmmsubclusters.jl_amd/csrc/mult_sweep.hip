@@ -161,6 +161,168 @@ __device__ __forceinline__ u32x4 pack_bf16x8(const f32x4 lo, const f32x4 hi) {
     return r;
 }
 
+// ---------------------------------------------------------------------------------------
+// u8 path.  Bag-of-words data are small non-negative integers: when every x is an integer in [0, 255] (checked at upload) the
+// context also keeps the points as BYTES ([n][ld8], ld8 = roundup(D, 128)) -- a lossless re-encoding of the Float32 matrix the
+// caller handed over -- and the sweep streams 1 byte per element instead of 4.  A k-step covers 128 features (= one 128-byte
+// line per point): lane (i, g) loads the 32 bytes [32 g, 32 g + 32) of point i's line with two 16-byte loads, and the four
+// v_mfma_f32_16x16x32_bf16 "slices" of the k-step contract features {128 ks + 32 g + 8 sl + j}; the parameter planes are packed
+// in exactly that order (mult_pack_u8_kernel), so each lane's bytes are contiguous.  byte -> bf16 is exact (8 significant bits).
+// The slice loop re-uses the bf16 kernel's LDS double buffer (one 1-KiB fragment per row block and plane); x is fetched ONE
+// k-step = four slices ahead.  Same table, same draw code, bit-identical labels (only the summation order over features differs
+// from the Float32-loading kernel, as it already did between the two older kernels).
+__device__ __forceinline__ u32x4 bytes_to_bf16x8(uint32_t w0, uint32_t w1) {
+    auto two = [](uint32_t lo_byte, uint32_t hi_byte) -> uint32_t {
+        const float a = (float)lo_byte, b = (float)hi_byte;          // v_cvt_f32_ubyteN
+        return (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xffff0000u);
+    };
+    u32x4 r;
+    r.x = two(w0 & 0xffu, (w0 >> 8) & 0xffu);
+    r.y = two((w0 >> 16) & 0xffu, w0 >> 24);
+    r.z = two(w1 & 0xffu, (w1 >> 8) & 0xffu);
+    r.w = two((w1 >> 16) & 0xffu, w1 >> 24);
+    return r;
+}
+
+template <int B_RBP>
+__global__ __launch_bounds__(256, (B_RBP <= 6 ? 2 : 1)) void mult_sweep_u8_kernel(MultSweepArgs A, const uint8_t *__restrict__ X8, int64_t ld8,
+                                                                                   const uint32_t *__restrict__ Lp8, int NKS8, int NRB) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2][B_RBP * 3 * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ci = lane & 15, g = lane >> 4;
+    const int K = A.K, rows = 3 * K;
+    const int64_t ntiles = (A.n + M_TILE - 1) / M_TILE;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t wbase = tile * M_TILE + (int64_t)wave * 64;
+        float *scr = A.scratch + (A.scratch_by_tile ? tile * M_TILE : (int64_t)blockIdx.x * M_TILE) + wave * 64;
+        const int64_t sstride = A.scratch_stride;
+        const uint8_t *xp0[M_NG];
+        bool pv[M_NG];
+#pragma unroll
+        for (int n = 0; n < M_NG; ++n) {
+            const int64_t p = wbase + 16 * n + ci;
+            pv[n] = p < A.n;
+            xp0[n] = X8 + (pv[n] ? p : 0) * ld8 + 32 * g;     // row of a valid point (point 0 for the padding lanes), this lane's 32 bytes
+        }
+        for (int rb0 = 0; rb0 < NRB; rb0 += B_RBP) {
+            const int nrb = min(B_RBP, NRB - rb0);
+            const int chunk_words = nrb * 3 * 256;
+            f32x4 acc[B_RBP][M_NG];
+#pragma unroll
+            for (int rb = 0; rb < B_RBP; ++rb)
+#pragma unroll
+                for (int n = 0; n < M_NG; ++n) acc[rb][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            constexpr int NST = (B_RBP * 3 * 256 / 4 + 255) / 256;
+            const int chunk_v4 = chunk_words / 4;
+            const int NSL = 4 * NKS8;                         // slices = LDS chunks of this pass
+            // (requesting the fragments TWO slices ahead -- two register sets -- was measured: 0.78 vs 0.77 ms, with spills: the L2 round
+            // trip of the parameter planes is not what bounds a slice)
+            u32x4 st[NST];
+            auto prefetch = [&](int sl) {                     // chunk(sl) lives at Lp8 + (sl * NRB + rb0) * 768 words
+                const u32x4 *src = reinterpret_cast<const u32x4 *>(Lp8 + ((size_t)sl * NRB + rb0) * 768);
+#pragma unroll
+                for (int p = 0; p < NST; ++p) st[p] = src[min(p * 256 + tid, chunk_v4 - 1)];
+            };
+            auto commit = [&](uint32_t *buf) {
+#pragma unroll
+                for (int p = 0; p < NST; ++p) reinterpret_cast<u32x4 *>(buf)[min(p * 256 + tid, chunk_v4 - 1)] = st[p];
+            };
+            auto loadx = [&](int ks, u32x4 (&xa)[M_NG], u32x4 (&xb)[M_NG]) {     // unconditional: ld8 is a multiple of 128, padding is zero
+#pragma unroll
+                for (int n = 0; n < M_NG; ++n) {
+                    xa[n] = *reinterpret_cast<const u32x4 *>(xp0[n] + 128 * (int64_t)ks);
+                    xb[n] = *reinterpret_cast<const u32x4 *>(xp0[n] + 128 * (int64_t)ks + 16);
+                }
+            };
+            u32x4 xa[M_NG], xb[M_NG], na[M_NG], nb[M_NG];
+            prefetch(0);
+            loadx(0, xa, xb);
+            for (int ks = 0; ks < NKS8; ++ks) {
+                loadx(min(ks + 1, NKS8 - 1), na, nb);        // next k-step's bytes: four slices of matrix work ahead of their use
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int sl = 4 * ks + q;
+                    uint32_t *buf = lds[sl & 1];
+                    commit(buf);
+                    __syncthreads();
+                    prefetch(min(sl + 1, NSL - 1));
+                    u32x4 xq[M_NG];
+#pragma unroll
+                    for (int n = 0; n < M_NG; ++n) {
+                        const u32x4 src = q < 2 ? xa[n] : xb[n];
+                        const uint32_t w0 = (q & 1) ? src.z : src.x, w1 = (q & 1) ? src.w : src.y;
+                        xq[n] = pv[n] ? bytes_to_bf16x8(w0, w1) : (u32x4){0u, 0u, 0u, 0u};
+                    }
+#pragma unroll
+                    for (int rb = 0; rb < B_RBP; ++rb) {
+                        if (rb < nrb) {
+#pragma unroll
+                            for (int pl = 0; pl < 3; ++pl) {
+                                const u32x4 a = *reinterpret_cast<const u32x4 *>(buf + (rb * 3 + pl) * 256 + lane * 4);
+#pragma unroll
+                                for (int n = 0; n < M_NG; ++n)
+                                    acc[rb][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, xq[n]), acc[rb][n], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int n = 0; n < M_NG; ++n) { xa[n] = na[n]; xb[n] = nb[n]; }
+            }
+#pragma unroll
+            for (int rb = 0; rb < B_RBP; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * (rb0 + rb) + 4 * g + r;
+                    if (rb < nrb && row < rows) {
+                        const float cst = A.cst[row];
+#pragma unroll
+                        for (int n = 0; n < M_NG; ++n) scr[(int64_t)row * sstride + 16 * n + ci] = acc[rb][n][r] + cst;
+                    }
+                }
+            __syncthreads();  // LDS buffers are reused by the next pass / tile
+        }
+        __syncthreads();
+        const int64_t myp = wbase + lane;
+        const bool valid = myp < A.n;
+        if (valid && !A.labels_only) {
+            const float *col = scr + lane;
+            const Philox4 rr = philox4x32_10(A.seed, (uint64_t)(A.first_index + myp), A.epoch, STREAM_SWEEP);
+            int z = 0;
+            float m = -INFINITY;
+            int best = 0;
+            bool nan_seen = false;
+            for (int k = 0; k < K; ++k) {
+                const float a = col[(int64_t)(3 * k) * sstride];
+                if (a != a) {
+                    if (!nan_seen) { nan_seen = true; best = k; }
+                } else if (a > m) {
+                    m = a;
+                    if (!nan_seen) best = k;
+                }
+            }
+            if (A.final_argmax) {
+                z = best;
+            } else if (m == -INFINITY) {
+                z = 0;
+            } else {
+                float s = 0.f;
+                for (int k = 0; k < K; ++k) s += exp_det(nan_to_ninf(col[(int64_t)(3 * k) * sstride]) - m);
+                const float t = u01(rr.v[0]) * s;
+                float cw = 0.f;
+                z = K - 1;
+                for (int k = 0; k < K; ++k) {
+                    cw += exp_det(nan_to_ninf(col[(int64_t)(3 * k) * sstride]) - m);
+                    if (!(cw < t)) { z = k; break; }
+                }
+            }
+            const float b0 = col[(int64_t)(3 * z + 1) * sstride], b1 = col[(int64_t)(3 * z + 2) * sstride];
+            A.bins[myp] = 2 * z + draw2(b0, b1, u01(rr.v[1]));
+        }
+        __syncthreads();
+    }
+}
+
 template <int B_RBP>   // row blocks (16 parameter rows each) per pass over the features
 __global__ __launch_bounds__(256, (B_RBP <= 6 ? 2 : 1)) void mult_sweep_bf16_kernel(MultSweepArgs A, const uint32_t *__restrict__ Lp16, int NKS, int NRB) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[2][B_RBP * 3 * 256];
@@ -327,6 +489,74 @@ __global__ void mult_pack_bf16_kernel(const float *__restrict__ logp, uint32_t *
         }
         Lp16[e] = out;
     }
+}
+
+// Lp8[sl][rb][plane][lane][8 bf16], sl = 4 ks + q : element j of lane (i, g) = plane_p(logp[16 rb + i][128 ks + 32 g + 8 q + j])
+__global__ void mult_pack_u8_kernel(const float *__restrict__ logp, uint32_t *__restrict__ Lp8, int rows, int64_t ldx, int NSL, int NRB) {
+    const int64_t total = (int64_t)NSL * NRB * 3 * 256;   // uint32 words, two bf16 each
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(e & 3), lane = (int)((e >> 2) & 63);
+        int64_t t = e >> 8;
+        const int pl = (int)(t % 3); t /= 3;
+        const int rb = (int)(t % NRB), sl = (int)(t / NRB);
+        const int row = 16 * rb + (lane & 15);
+        uint32_t out = 0;
+        for (int h = 0; h < 2; ++h) {
+            const int col = 128 * (sl >> 2) + 32 * (lane >> 4) + 8 * (sl & 3) + 2 * w + h;
+            float v = (row < rows && col < ldx) ? logp[(size_t)row * ldx + col] : 0.f;
+            uint32_t bits = 0;
+            for (int p = 0; p <= pl; ++p) {
+                bits = bf16_rne_bits(v);
+                v -= __uint_as_float(bits << 16);
+            }
+            out |= (bits & 0xffffu) << (16 * h);
+        }
+        Lp8[e] = out;
+    }
+}
+
+// upload: the byte copy of the points ([n][ld8], zero padded) + a flag that is raised when any element is not an integer in [0, 255]
+__global__ void u8_convert_kernel(const float *__restrict__ X, int64_t ldx, int D, int64_t n, uint8_t *__restrict__ X8, int64_t ld8, int *__restrict__ flag) {
+    int bad = 0;
+    const int64_t total = n * ld8;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e / ld8;
+        const int d = (int)(e - i * ld8);
+        uint8_t b = 0;
+        if (d < D) {
+            const float v = X[i * ldx + d];
+            const int iv = (int)v;
+            bad |= !(v >= 0.f && v <= 255.f && (float)iv == v);
+            b = (uint8_t)(iv & 0xff);
+        }
+        X8[e] = b;
+    }
+    if (bad) atomicOr(flag, 1);
+}
+
+hipError_t launch_u8_convert(const float *X, int64_t ldx, int D, int64_t n, uint8_t *X8, int64_t ld8, int *d_flag, hipStream_t s) {
+    hipLaunchKernelGGL(u8_convert_kernel, dim3(4096), dim3(256), 0, s, X, ldx, D, n, X8, ld8, d_flag);
+    return hipGetLastError();
+}
+
+size_t mult_pack_u8_words(int rows, int64_t ld8) {
+    const int NSL = (int)(ld8 / 32), NRB = (rows + 15) / 16;
+    return (size_t)NSL * NRB * 3 * 256;
+}
+
+hipError_t launch_mult_pack_u8(const float *logp, uint32_t *Lp8, int rows, int64_t ldx, int64_t ld8, hipStream_t s) {
+    const int NSL = (int)(ld8 / 32), NRB = (rows + 15) / 16;
+    hipLaunchKernelGGL(mult_pack_u8_kernel, dim3(512), dim3(256), 0, s, logp, Lp8, rows, ldx, NSL, NRB);
+    return hipGetLastError();
+}
+
+hipError_t launch_mult_sweep_u8(const MultSweepArgs &a, const uint8_t *X8, int64_t ld8, const uint32_t *Lp8, int grid, hipStream_t s) {
+    const int NKS8 = (int)(ld8 / 128), NRB = (3 * a.K + 15) / 16;
+    if (NRB <= 2) hipLaunchKernelGGL(mult_sweep_u8_kernel<2>, dim3(grid), dim3(256), 0, s, a, X8, ld8, Lp8, NKS8, NRB);
+    else if (NRB <= 4) hipLaunchKernelGGL(mult_sweep_u8_kernel<4>, dim3(grid), dim3(256), 0, s, a, X8, ld8, Lp8, NKS8, NRB);
+    else if (NRB <= 6) hipLaunchKernelGGL(mult_sweep_u8_kernel<6>, dim3(grid), dim3(256), 0, s, a, X8, ld8, Lp8, NKS8, NRB);
+    else hipLaunchKernelGGL(mult_sweep_u8_kernel<8>, dim3(grid), dim3(256), 0, s, a, X8, ld8, Lp8, NKS8, NRB);
+    return hipGetLastError();
 }
 
 // data check at upload: 1 if every element is exactly representable in bf16 (low 16 mantissa bits zero)

@@ -488,6 +488,52 @@ __global__ __launch_bounds__(256) void mult_reduce_kernel(StatsArgs A) {
     out[e] = s;
 }
 
+// u8 path: the same segmented column sums over the byte copy of the points.  Thread t owns the four dimensions of dword t of a
+// 1024-byte block of the row; the counts are added as INTEGERS (exact; a work item holds far fewer than 2^24 points) and leave
+// as Float64 slabs, so the reduce kernel and the packed rows are unchanged -- and bit-identical to the Float32-reading kernel.
+__global__ __launch_bounds__(256) void mult_stats_u8_kernel(StatsArgs A, const uint8_t *__restrict__ X8, int64_t ld8) {
+    const int total_items = A.sb.item_start[A.nbins];
+    for (int item = blockIdx.x; item < total_items; item += gridDim.x) {
+        const int b = find_bin(A.sb.item_start, A.nbins, item);
+        const int j = item - A.sb.item_start[b];
+        const int bcnt = A.sb.bin_total[b];
+        const int seg = A.sb.bin_start[b] + j * A.chunk;
+        const int cnt = min(A.chunk, bcnt - j * A.chunk);
+        double *slab = A.slabs + (int64_t)item * A.slab_stride;
+        for (int64_t d0 = 0; d0 < ld8; d0 += 1024) {
+            const bool ok = d0 + 4 * threadIdx.x < ld8;
+            const int64_t off = ok ? d0 + 4 * (int64_t)threadIdx.x : 0;
+            uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            int p = 0;
+            for (; p + 8 <= cnt; p += 8) {
+                uint32_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const uint32_t *>(X8 + (int64_t)A.sb.perm[seg + p + u] * ld8 + off);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { s0 += v[u] & 0xffu; s1 += (v[u] >> 8) & 0xffu; s2 += (v[u] >> 16) & 0xffu; s3 += v[u] >> 24; }
+            }
+            for (; p < cnt; ++p) {
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(X8 + (int64_t)A.sb.perm[seg + p] * ld8 + off);
+                s0 += v & 0xffu; s1 += (v >> 8) & 0xffu; s2 += (v >> 16) & 0xffu; s3 += v >> 24;
+            }
+            if (ok) {
+                const int64_t d = d0 + 4 * (int64_t)threadIdx.x;
+                if (d < A.D) slab[d] = (double)s0;
+                if (d + 1 < A.D) slab[d + 1] = (double)s1;
+                if (d + 2 < A.D) slab[d + 2] = (double)s2;
+                if (d + 3 < A.D) slab[d + 3] = (double)s3;
+            }
+        }
+    }
+}
+
+hipError_t launch_mult_stats_u8(const StatsArgs &a, const uint8_t *X8, int64_t ld8, hipStream_t s) {
+    const int grid = a.max_items < 1 ? 1 : a.max_items;
+    hipLaunchKernelGGL(mult_stats_u8_kernel, dim3(grid), dim3(256), 0, s, a, X8, ld8);
+    hipLaunchKernelGGL(mult_reduce_kernel, dim3((unsigned)((a.packed_stride + 255) / 256), a.nbins), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 int64_t mult_slab_stride(int D) { return D; }
 
 hipError_t launch_mult_stats(const StatsArgs &a, hipStream_t s) {

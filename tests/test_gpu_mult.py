@@ -126,3 +126,43 @@ def test_f32_fallback_for_non_count_data(pkg):
     u0, _ = orc.uniforms(5, 1, 0, 0, 3000)
     assert np.array_equal(orc.sample_log_cat(tab, u0), lab)
     wk.close()
+
+
+@pytest.mark.parametrize("D,n,K", [(1000, 6000, 32), (129, 4000, 5), (64, 3000, 3)])
+def test_byte_copy_path_equals_float_paths(pkg, D, n, K):
+    """Integer data in [0, 255] is streamed from a lossless BYTE copy (1 byte per element, 128-feature k-steps).  Against the
+    Float32-reading bf16 kernel (DPMM_OPT_MULT_NO_U8) on the same data: the table agrees to summation-order rounding, the label
+    draws differ only where a CDF edge sits within that rounding, and the statistics -- integer sums -- are bit-identical."""
+    from dpmmsubclusters_jl_amd import binding
+    P = make_problem(D, n, K, 80, seed=3 * D + K)
+    P["X"][::7, 0] = 255.0                                           # the largest byte value is in the data
+    lab0 = (P["z"] + 1).astype(np.int64); sub0 = 1 + (np.arange(n) & 1)
+    out = {}
+    for name, no_u8 in (("u8", 0), ("bf16", 1)):
+        wk = pkg.Worker(pkg.PRIOR_MULT, D, n, first_index=7, device=0, seed=11)
+        wk.set_option(binding.OPT_MULT_NO_U8, no_u8)
+        wk.upload_points(P["X"])
+        wk.set_params_mult(P["logp"], P["lr"], P["w"])
+        tab = wk.debug_loglik()
+        wk.set_labels(lab0, sub0)
+        st = wk.suffstats_packed()
+        wk.sweep(4)
+        lab, sub = wk.get_labels()
+        u0, _ = orc.uniforms(11, 4, 0, 7, n)
+        assert np.array_equal(orc.sample_log_cat(tab, u0), lab)       # each path draws bit-exactly from its own table
+        out[name] = (tab, lab, sub, st, wk.suffstats_packed())
+        wk.close()
+    np.testing.assert_allclose(out["u8"][0], out["bf16"][0], rtol=2e-6, atol=2e-4)
+    assert (out["u8"][1] != out["bf16"][1]).sum() <= max(2, int(2e-4 * n))
+    assert np.array_equal(out["u8"][3], out["bf16"][3])              # statistics of the same labelling: bit-identical
+    want = np.zeros((2 * K, 1 + D))
+    np.add.at(want, 2 * (lab0 - 1) + (sub0 - 1), np.concatenate([np.ones((n, 1)), P["X"].astype(np.float64)], axis=1))
+    assert np.array_equal(out["u8"][3], want)
+    # non-integer or out-of-range data must NOT take the byte path (it falls back to the Float32-reading kernels)
+    Xf = P["X"].copy(); Xf[5, 3] = 256.0
+    wk = pkg.Worker(pkg.PRIOR_MULT, D, n, device=0, seed=11)
+    wk.upload_points(Xf)
+    wk.set_labels(lab0, sub0); wk.set_num_clusters(K)
+    st = wk.suffstats_packed()
+    assert st[2 * (lab0[5] - 1) + (sub0[5] - 1), 1 + 3] == want[2 * (lab0[5] - 1) + (sub0[5] - 1), 1 + 3] - P["X"][5, 3] + 256.0
+    wk.close()
