@@ -196,6 +196,9 @@ __global__ __launch_bounds__(256, (B_RBP <= 6 ? 2 : 1)) void mult_sweep_u8_kerne
         const int64_t wbase = tile * M_TILE + (int64_t)wave * 64;
         float *scr = A.scratch + (A.scratch_by_tile ? tile * M_TILE : (int64_t)blockIdx.x * M_TILE) + wave * 64;
         const int64_t sstride = A.scratch_stride;
+        // single pass over the features and K x 64 floats per wave fit the (then idle) fragment buffers: label table in LDS
+        const bool tab_lds = NRB <= B_RBP && (size_t)K * 64 * 4 * 4 <= sizeof(lds) && !A.labels_only;
+        float *ltab = reinterpret_cast<float *>(&lds[0][0]) + (size_t)wave * K * 64;
         const uint8_t *xp0[M_NG];
         bool pv[M_NG];
 #pragma unroll
@@ -269,6 +272,7 @@ __global__ __launch_bounds__(256, (B_RBP <= 6 ? 2 : 1)) void mult_sweep_u8_kerne
 #pragma unroll
                 for (int n = 0; n < M_NG; ++n) { xa[n] = na[n]; xb[n] = nb[n]; }
             }
+            __syncthreads();  // every wave is done with the fragment buffers: they hold the label table from here on
 #pragma unroll
             for (int rb = 0; rb < B_RBP; ++rb)
 #pragma unroll
@@ -277,15 +281,54 @@ __global__ __launch_bounds__(256, (B_RBP <= 6 ? 2 : 1)) void mult_sweep_u8_kerne
                     if (rb < nrb && row < rows) {
                         const float cst = A.cst[row];
 #pragma unroll
-                        for (int n = 0; n < M_NG; ++n) scr[(int64_t)row * sstride + 16 * n + ci] = acc[rb][n][r] + cst;
+                        for (int n = 0; n < M_NG; ++n) {
+                            const float v = acc[rb][n][r] + cst;
+                            scr[(int64_t)row * sstride + 16 * n + ci] = v;
+                            if (tab_lds && row % 3 == 0) ltab[(row / 3) * 64 + 16 * n + ci] = v;     // cluster-level rows: the label draw reads them from LDS
+                        }
                     }
                 }
-            __syncthreads();  // LDS buffers are reused by the next pass / tile
         }
         __syncthreads();
         const int64_t myp = wbase + lane;
         const bool valid = myp < A.n;
-        if (valid && !A.labels_only) {
+        if (valid && !A.labels_only && tab_lds) {
+            // same arithmetic, same order as the global-table path below (and the CPU oracle); the K values of a point come from LDS
+            // (the global scratch cost ~30 % of the kernel: three passes of K dependent-latency L2 loads per point)
+            const float *col = ltab + lane;
+            const Philox4 rr = philox4x32_10(A.seed, (uint64_t)(A.first_index + myp), A.epoch, STREAM_SWEEP);
+            int z = 0;
+            float m = -INFINITY;
+            int best = 0;
+            bool nan_seen = false;
+            for (int k = 0; k < K; ++k) {
+                const float a = col[k * 64];
+                if (a != a) {
+                    if (!nan_seen) { nan_seen = true; best = k; }
+                } else if (a > m) {
+                    m = a;
+                    if (!nan_seen) best = k;
+                }
+            }
+            if (A.final_argmax) {
+                z = best;
+            } else if (m == -INFINITY) {
+                z = 0;
+            } else {
+                float s = 0.f;
+                for (int k = 0; k < K; ++k) s += exp_det(nan_to_ninf(col[k * 64]) - m);
+                const float t = u01(rr.v[0]) * s;
+                float cw = 0.f;
+                z = K - 1;
+                for (int k = 0; k < K; ++k) {
+                    cw += exp_det(nan_to_ninf(col[k * 64]) - m);
+                    if (!(cw < t)) { z = k; break; }
+                }
+            }
+            const float *gcol = scr + lane;
+            const float b0 = gcol[(int64_t)(3 * z + 1) * sstride], b1 = gcol[(int64_t)(3 * z + 2) * sstride];
+            A.bins[myp] = 2 * z + draw2(b0, b1, u01(rr.v[1]));
+        } else if (valid && !A.labels_only) {
             const float *col = scr + lane;
             const Philox4 rr = philox4x32_10(A.seed, (uint64_t)(A.first_index + myp), A.epoch, STREAM_SWEEP);
             int z = 0;

@@ -121,6 +121,8 @@ __global__ __launch_bounds__(64) void scatter_kernel(const int32_t *__restrict__
                                                      const int32_t *__restrict__ bin_start, int32_t *__restrict__ perm) {
     extern __shared__ int base[];
     const int lane = threadIdx.x;
+    int nbits = 0;
+    while ((1 << nbits) < nbins) ++nbits;
     for (int b = lane; b < nbins; b += 64) base[b] = bin_start[b] + tile_hist[(int64_t)b * nt + blockIdx.x];
     __syncthreads();
     const int64_t tbase = (int64_t)blockIdx.x * SORT_TILE;
@@ -132,18 +134,14 @@ __global__ __launch_bounds__(64) void scatter_kernel(const int32_t *__restrict__
             if ((unsigned)b >= (unsigned)nbins) b = -1;
         }
         const bool valid = b >= 0;
-        unsigned long long todo = __ballot(valid);
-        int rank = 0, cntb = 0;
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const int lb = __shfl(b, leader);
-            const unsigned long long m = __ballot(valid && b == lb);
-            if (valid && b == lb) {
-                rank = __popcll(m & ((1ull << lane) - 1ull));
-                cntb = __popcll(m);
-            }
-            todo &= ~m;
+        // lanes with the same bin, by one ballot per bit of the bin id (a fixed ceil(log2 nbins) steps; the leader-by-leader loop it
+        // replaces took one step per DISTINCT bin in the wave: ~40 on unsorted labels, e.g. bag-of-words data)
+        unsigned long long m = __ballot(valid);
+        for (int bit = 0; bit < nbits; ++bit) {
+            const unsigned long long bal = __ballot(valid && ((b >> bit) & 1));
+            m &= ((b >> bit) & 1) ? bal : ~bal;
         }
+        const int rank = __popcll(m & ((1ull << lane) - 1ull)), cntb = __popcll(m);
         int pos = 0;
         if (valid) pos = base[b] + rank;
         __syncthreads();
