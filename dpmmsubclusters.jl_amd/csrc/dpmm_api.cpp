@@ -96,6 +96,8 @@ struct dpmm_ctx {
     // statistics output (dpmm_step_stats / dpmm_suffstats_host): packed rows + flags, read by the host in place
     char *h_out = nullptr;
     size_t h_out_bytes = 0;
+    char *d_par = nullptr;             // device copy of the staging's mu | R regions (NIW): the pack kernel gathers from HBM, not over the host link
+    size_t d_par_bytes = 0;
     uint8_t *d_flags = nullptr;        // [DPMM_MAX_CLUSTERS + 1] bad-cluster flags of the current step (+ any)
     long long *d_counts64 = nullptr;   // [2 * DPMM_MAX_CLUSTERS] global sub-cluster occupancies (multi-GPU)
     unsigned long long *d_work = nullptr;   // [4] executed-work counters of the last sweep
@@ -329,7 +331,7 @@ int dpmm_destroy(dpmm_ctx *c) {
     hipFree(c->dX); hipFree(c->dX8); hipFree(c->dbins); hipFree(c->d_gt); hipFree(c->d_cont);
     hipFree(c->sb.tile_hist); hipFree(c->sb.bin_total); hipFree(c->sb.bin_start); hipFree(c->sb.item_start);
     hipFree(c->sb.perm); hipFree(c->sb.bin_sel); hipFree(c->sb.perm_total); hipFree(c->d_small); hipFree(c->d_proj); hipFree(c->d_vals); hipFree(c->d_smart);
-    hipFree(c->d_flags); hipFree(c->d_counts64); hipFree(c->d_work);
+    hipFree(c->d_flags); hipFree(c->d_counts64); hipFree(c->d_work); hipFree(c->d_par);
     comm_release(c);
     if (c->h_pin) hipHostFree(c->h_pin);
     if (c->h_par) hipHostFree(c->h_par);
@@ -544,7 +546,7 @@ int dpmm_commit_params(dpmm_ctx *c, int K) {
     HIPCHK(c, hipSetDevice(c->device));
     if (int rc = ensure_capacity(c, K)) return rc;
     const ParLayout L = par_layout(c, c->par_slots);
-    const float *hmu = reinterpret_cast<const float *>(c->h_par + L.mu), *hmat = reinterpret_cast<const float *>(c->h_par + L.mat);
+    const float *hmu = reinterpret_cast<const float *>(c->h_par + L.mu), *hmat = reinterpret_cast<const float *>(c->h_par + L.mat);   // (NIW: re-pointed to the device copy below)
     const float *hld = reinterpret_cast<const float *>(c->h_par + L.logdet), *hlr = reinterpret_cast<const float *>(c->h_par + L.lr);
     const float *hw = reinterpret_cast<const float *>(c->h_par + L.w);
     float *hcst = reinterpret_cast<float *>(c->h_par + L.cst);
@@ -562,6 +564,25 @@ int dpmm_commit_params(dpmm_ctx *c, int K) {
     // blocking call (dpmm_step_stats, dpmm_suffstats_*, dpmm_sync) has returned
     HIPCHK(c, launch_copy_bytes(c->d_cst, hcst, sizeof(float) * 3 * K, c->stream));
     if (niw) {
+        // mu | R of the slots in use: ONE streaming copy over the host link (1 KiB requests), then the gather into the fragment
+        // images reads HBM.  (Letting the pack kernel gather from the pinned buffer directly cost 0.9 ms at D = 256 -- 16-byte
+        // requests over PCIe -- against 0.25 ms for the bulk copy.)
+        int top = 0;
+        for (int k = 0; k < K; ++k) top = std::max(top, hslot[k] + 1);
+        const size_t D = (size_t)c->D, T = D * (D + 1) / 2;
+        const size_t mu_bytes = sizeof(float) * 3 * (size_t)top * D, mat_bytes = sizeof(float) * 3 * (size_t)top * T;
+        const size_t mu_pad = (mu_bytes + 255) & ~(size_t)255;
+        if (mu_pad + mat_bytes + 256 > c->d_par_bytes) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            hipFree(c->d_par); c->d_par = nullptr;
+            const size_t cap = sizeof(float) * 3 * (size_t)c->par_slots * (D + T) + 1024;
+            HIPCHK(c, hipMalloc(&c->d_par, cap));
+            c->d_par_bytes = cap;
+        }
+        HIPCHK(c, launch_copy_bytes16(c->d_par, hmu, mu_bytes, c->stream));
+        HIPCHK(c, launch_copy_bytes16(c->d_par + mu_pad, hmat, mat_bytes, c->stream));
+        hmu = reinterpret_cast<const float *>(c->d_par);
+        hmat = reinterpret_cast<const float *>(c->d_par + mu_pad);
         c->have_tail = c->opt_tail && c->D >= 4 && c->D % 4 == 0 && K > 2;
         HIPCHK(c, launch_niw_pack(hmat, hmu, c->d_Rp, c->d_mup, c->D, c->NB, 3 * K, c->have_tail ? c->d_tail : nullptr, c->d_cst, hslot, c->stream));
         c->have_screen_prep = false;

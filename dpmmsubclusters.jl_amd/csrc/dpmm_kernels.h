@@ -97,6 +97,7 @@ hipError_t launch_predict_finish(const float *table, int64_t stride, int rstep, 
 hipError_t launch_ingest_rows(float *dst, int64_t ldx, const void *src, int is_f64, int64_t ld, int64_t rows, int D, int nan_to_zero,
                               hipStream_t s);
 hipError_t launch_copy_bytes(void *dst, const void *src, size_t bytes, hipStream_t s);
+hipError_t launch_copy_bytes16(void *dst, const void *src, size_t bytes, hipStream_t s);   // 16-byte aligned dst / src, size rounded up to 16
 hipError_t launch_init_labels(int32_t *bins, int64_t n, int64_t first_index, int init_clusters, int label0, uint64_t seed,
                               uint32_t epoch, hipStream_t s);
 // step statistics: flags[k] = 1 when cluster k has an empty sub-cluster (counts: [2K] Int64, global), flags[K] = any;

@@ -165,6 +165,16 @@ hipError_t launch_gather_rows(float *dst, int64_t ld_dst, const float *src, int6
 __global__ void copy_words_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, int64_t nwords) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nwords; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
+// bulk variant for 16-byte aligned blocks (parameter staging -> device): one dwordx4 per lane, a wave moves 1 KiB per request
+__global__ void copy_vec4_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__ src, int64_t nvec) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+hipError_t launch_copy_bytes16(void *dst, const void *src, size_t bytes, hipStream_t s) {
+    const int64_t nv = (int64_t)((bytes + 15) / 16);
+    if (nv == 0) return hipSuccess;
+    hipLaunchKernelGGL(copy_vec4_kernel, dim3(grid_for(nv)), dim3(256), 0, s, (uint4 *)dst, (const uint4 *)src, nv);
+    return hipGetLastError();
+}
 hipError_t launch_copy_bytes(void *dst, const void *src, size_t bytes, hipStream_t s) {
     const int64_t nw = (int64_t)((bytes + 3) / 4);
     if (nw == 0) return hipSuccess;
