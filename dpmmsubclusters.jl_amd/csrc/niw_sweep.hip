@@ -13,14 +13,21 @@
 //     FP32 matrix cores (v_mfma_f32_16x16x4_f32, exact f32 fma chains); only the
 //     16x16 blocks on or above the diagonal are visited (D=64: 10 of 16 blocks).
 //   * one wave owns 16*NG points.  Their x stays in registers for the whole sweep (the
-//     B operand); z = x - mu_k is formed on the fly; the A operand (a pre-packed
-//     fragment image of R_k, 1 KiB per 16x16 block) is staged global -> registers -> LDS
-//     one chunk ahead of the MFMAs and shared by the 4 waves of the workgroup.
-//   * a_k = -1/2 q + (-1/2 logdet_k + log w_k) goes to a per-workgroup scratch row
-//     (L2-resident); each lane then draws the label of "its" point with the deterministic
-//     inverse-CDF scan shared with the CPU oracle, using Philox(seed; global index, epoch).
-//   * sub-labels: the workgroup walks the distinct labels it just drew; for each it
-//     evaluates the left/right sub-cluster forms for its points and draws 1 of 2.
+//     B operand); z = x - mu_k is formed on the fly; the A operand is a pre-packed fragment
+//     image of R_k, 1 KiB per 16x16 block.
+//   * TWO kernels share this file:
+//       niw_sweep_direct_kernel (D <= 64; the benchmark's kernel): no LDS staging, no barriers -- every wave streams the
+//         fragments of a matrix from L2 into registers one row-block ahead of its MFMAs, keeps its a_k table in
+//         wave-private LDS, screens clusters per WAVE (reference evaluation -> 4-row tail screen on the VALU -> 16-row
+//         MFMA screen -> full evaluation of survivors) and walks the distinct labels of its own 64 points for the
+//         sub-labels.  See the comment block in front of it.
+//       niw_sweep_kernel (D = 128, 256): the fragment image of a matrix is staged global -> registers -> LDS one
+//         chunk ahead of the MFMAs and shared by the 4 waves of the workgroup; screening is workgroup-wide; a_k goes to a
+//         per-workgroup scratch row (L2-resident).
+//   * a_k = -1/2 q + (-1/2 logdet_k + log w_k); each lane then draws the label of "its" point with the
+//     deterministic inverse-CDF scan shared with the CPU oracle, using Philox(seed; global index, epoch).
+//   * sub-labels: for each distinct label just drawn, the left/right sub-cluster forms are evaluated for the
+//     points that carry it and 1 of 2 is drawn with the second uniform.
 //
 // Fragment conventions for v_mfma_f32_16x16x4_f32 (lane l: i = l & 15, g = l >> 4):
 //   A[i][k=g], B[k=g][col=i], C/D reg r: row 4g + r, col i.

@@ -55,7 +55,9 @@ class _NS:
 
 
 def read_params(model_params):
-    """Execute a parameter file and return the recognised settings (defaults of src/global_params.jl)."""
+    """Execute a parameter file and return the recognised settings (defaults of src/global_params.jl).
+    The file is EXECUTED (`exec`), exactly as the reference `include`s its Julia parameter file (dp-parallel-sampling.jl:12,181):
+    it is code, not data -- only run parameter files you trust."""
     ns = dict(np=np, niw_hyperparams=_priors.niw_hyperparams, multinomial_hyper=_priors.multinomial_hyper,
               Inf=np.inf, nothing=None, true=True, false=False, zeros=np.zeros, ones=np.ones, eye=np.eye)
     mod = _NS()
