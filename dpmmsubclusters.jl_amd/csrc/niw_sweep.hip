@@ -564,7 +564,10 @@ __device__ __forceinline__ void load_rb0(const float *__restrict__ Rm, const flo
 #else
 #define STAMP(var)
 #endif
-template <int NB, int NG, int OCC>
+// FAST: the steady-state configuration known at launch time (screening with the tail screen, no far mask, LDS table, no
+// Student-t mode, no table output): the mode tests below become compile-time constants -- fewer live scalars (the generic
+// kernel spills > 100 SGPRs into VGPR lanes) and fewer branches per tile.  Same arithmetic, same results.
+template <int NB, int NG, int OCC, bool FAST = false>
 __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs A) {
 #ifdef DPMM_STAMPS
     unsigned long long T_x = 0, T_quad = 0, T_epi = 0, T_draw = 0, T_p2 = 0, T_tot = 0, N_scr = 0, N_tail = 0, T_prep = 0, T_far = 0, T_surv = 0, T_init = 0, T_i1 = 0, T_i2 = 0; int ntile = 0;
@@ -583,7 +586,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
     __shared__ uint32_t eval_bits[4][32];   // per wave: reference clusters + survivors
     extern __shared__ __attribute__((aligned(16))) float lds_tab[];
     // wave-private [K][WPTS] table of a_k in LDS when it fits (A.lds_rows >= K), else the global scratch
-    const bool tab_lds = A.lds_rows >= K && !A.scratch_by_tile;
+    const bool tab_lds = FAST || (A.lds_rows >= K && !A.scratch_by_tile);
     float *ltab = lds_tab + (size_t)(tid >> 6) * A.lds_rows * WPTS + lane;
     // screen operands of all K clusters (last fragment pair 1 KiB + last 16 means), staged once per workgroup
     float *scrA = lds_tab + (size_t)4 * A.lds_rows * WPTS;
@@ -611,7 +614,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
         const int64_t mypos = wbase + lane;    // position in processing order
         const bool valid = owner && mypos < A.n;
         const bool prefetched = nx_tile == tile;
-        const bool screening = NB >= 2 && A.screen_margin > 0.f && !A.tdf && !A.scratch_by_tile && K > 2;
+        const bool screening = FAST || (NB >= 2 && A.screen_margin > 0.f && !A.tdf && !A.scratch_by_tile && K > 2);
         int myp32, binv = -1;
         if (prefetched) {
             myp32 = nx_p; binv = nx_bin;
@@ -654,7 +657,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         STAMP(s1);
-        float *scr = A.scratch + (A.scratch_by_tile ? tile * WPTS : wave_id * WPTS) + lane;
+        float *scr = FAST ? nullptr : A.scratch + (A.scratch_by_tile ? tile * WPTS : wave_id * WPTS) + lane;
         const int64_t sstride = A.scratch_stride;
 
         float m_run = -INFINITY;
@@ -726,7 +729,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
             // Its operands are fetched / formed BEFORE the reference evaluation so that their latency hides behind it.
             STAMP(qb0);
             float rn[NG];
-            const bool prescreen = A.lam != nullptr;
+            const bool prescreen = !FAST && A.lam != nullptr;
             float pc_c = 0.f, pc_l = 0.f, pc_d = 0.f;      // lane j: constants of cluster j (first chunk of 64)
             if (prescreen) {
                 if (lane < K) { pc_c = A.cst[3 * lane]; pc_l = A.lam[lane]; pc_d = A.mdist[(size_t)k0 * K + lane] * 0.99999f; }
@@ -753,17 +756,17 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
             STAMP(q0b);
             // the last row-block of the reference evaluation prefetches row-block 0 of k0's LEFT sub-cluster matrix:
             // on label-homogeneous waves that is the first matrix of the sub-label phase (rb0_mat tracks what rb0/mu hold)
-            const float *Rl0 = A.labels_only ? nullptr : A.Rp + (size_t)(3 * k0 + 1) * MATSZ;
+            const float *Rl0 = (!FAST && A.labels_only) ? nullptr : A.Rp + (size_t)(3 * k0 + 1) * MATSZ;
             const float *ml0 = A.mup + (size_t)(3 * k0 + 1) * DP;
             full_eval(k0, k1 != k0 ? A.Rp + (size_t)(3 * k1) * MATSZ : Rl0, k1 != k0 ? A.mup + (size_t)(3 * k1) * DP : ml0);
             if (k1 != k0) full_eval(k1, Rl0, ml0);
-            rb0_mat = (A.labels_only || !Rl0) ? -1 : 3 * k0 + 1;
+            rb0_mat = ((!FAST && A.labels_only) || !Rl0) ? -1 : 3 * k0 + 1;
             if (pf_p >= 0 && A.use_prev) pf_bin = A.bins[pf_p];     // next tile's previous labels
             STAMP(r1);
             // (2a') VALU tail screen, lane = point: rows D-4..D-1 of y = R z need the last four features only
             // (R upper triangular), so q >= |T_k (x_tail - mu_tail)|^2 with the 4x4 tail factor T_k -- ~25 VALU
             // instructions per cluster for all 64 points, against 16 NG MFMAs for the 16-row screen below.
-            const bool tailscr = A.tail != nullptr;
+            const bool tailscr = FAST || A.tail != nullptr;
             f32x4 xt = (f32x4){0.f, 0.f, 0.f, 0.f};
             float my_best = -INFINITY;
             if (tailscr) {
@@ -989,7 +992,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                 }
             }
         }
-        if (A.labels_only) continue;
+        if (!FAST && A.labels_only) continue;
         STAMP(s3);
 
         // sub-labels: walk the distinct labels of this wave (wave-uniform loop)
@@ -1052,7 +1055,18 @@ static hipError_t launch_direct(const NiwSweepArgs &a, int grid, hipStream_t s) 
         hipFuncSetAttribute((const void *)niw_sweep_direct_kernel<NB, NG, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / OCC);
         attr_set = true;
     }
-    hipLaunchKernelGGL((niw_sweep_direct_kernel<NB, NG, OCC>), dim3(grid), dim3(256), lds_bytes, s, b);
+    const bool fast = NB >= 2 && b.screen_margin > 0.f && !b.tdf && !b.scratch_by_tile && !b.labels_only && b.K > 2 && b.lam == nullptr &&
+                      b.tail != nullptr && b.lds_rows >= b.K && !b.final_argmax;
+    if (fast) {
+        static bool attr_fast = false;
+        if (!attr_fast) {
+            hipFuncSetAttribute((const void *)niw_sweep_direct_kernel<NB, NG, OCC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / OCC);
+            attr_fast = true;
+        }
+        hipLaunchKernelGGL((niw_sweep_direct_kernel<NB, NG, OCC, true>), dim3(grid), dim3(256), lds_bytes, s, b);
+    } else {
+        hipLaunchKernelGGL((niw_sweep_direct_kernel<NB, NG, OCC>), dim3(grid), dim3(256), lds_bytes, s, b);
+    }
     return hipGetLastError();
 }
 
