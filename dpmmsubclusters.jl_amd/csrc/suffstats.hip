@@ -38,11 +38,33 @@ __global__ __launch_bounds__(64) void hist_kernel(const int32_t *__restrict__ bi
     for (int b = lane; b < nbins; b += 64) cnt[b] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
-    for (int it = 0; it < SORT_TILE / 64; ++it) {
-        const int64_t i = base + it * 64 + lane;
-        if (i < n) {
-            const int b = bins[i];
-            if ((unsigned)b < (unsigned)nbins) atomicAdd(&cnt[b], 1);
+    if (base + SORT_TILE <= n) {
+        // full tile: 16-byte loads, all of them in flight before the first is used; 256 points with one common bin (the usual case
+        // after an ordered sweep: neighbours share a label) cost one LDS add instead of 256 same-address atomics
+        const int4 *src = reinterpret_cast<const int4 *>(bins + base);
+        int4 v[SORT_TILE / 256];
+#pragma unroll
+        for (int it = 0; it < SORT_TILE / 256; ++it) v[it] = src[it * 64 + lane];
+#pragma unroll
+        for (int it = 0; it < SORT_TILE / 256; ++it) {
+            const int b0 = __builtin_amdgcn_readfirstlane(v[it].x);
+            const bool same = v[it].x == b0 && v[it].y == b0 && v[it].z == b0 && v[it].w == b0;
+            if (__all(same)) {
+                if (lane == 0 && (unsigned)b0 < (unsigned)nbins) cnt[b0] += 256;
+            } else {
+                if ((unsigned)v[it].x < (unsigned)nbins) atomicAdd(&cnt[v[it].x], 1);
+                if ((unsigned)v[it].y < (unsigned)nbins) atomicAdd(&cnt[v[it].y], 1);
+                if ((unsigned)v[it].z < (unsigned)nbins) atomicAdd(&cnt[v[it].z], 1);
+                if ((unsigned)v[it].w < (unsigned)nbins) atomicAdd(&cnt[v[it].w], 1);
+            }
+        }
+    } else {
+        for (int it = 0; it < SORT_TILE / 64; ++it) {
+            const int64_t i = base + it * 64 + lane;
+            if (i < n) {
+                const int b = bins[i];
+                if ((unsigned)b < (unsigned)nbins) atomicAdd(&cnt[b], 1);
+            }
         }
     }
     __syncthreads();
@@ -126,20 +148,28 @@ __global__ __launch_bounds__(64) void scatter_kernel(const int32_t *__restrict__
     for (int b = lane; b < nbins; b += 64) base[b] = bin_start[b] + tile_hist[(int64_t)b * nt + blockIdx.x];
     __syncthreads();
     const int64_t tbase = (int64_t)blockIdx.x * SORT_TILE;
+    // all loads of the tile in flight before the first is used (one wave per tile: a load per trip would serialise 32 latencies)
+    int bv[SORT_TILE / 64];
+#pragma unroll
     for (int it = 0; it < SORT_TILE / 64; ++it) {
         const int64_t i = tbase + it * 64 + lane;
-        int b = -1;
-        if (i < n) {
-            b = bins[i];
-            if ((unsigned)b >= (unsigned)nbins) b = -1;
-        }
+        bv[it] = bins[i < n ? i : n - 1];
+    }
+#pragma unroll
+    for (int it = 0; it < SORT_TILE / 64; ++it) {
+        const int64_t i = tbase + it * 64 + lane;
+        int b = i < n ? bv[it] : -1;
+        if ((unsigned)b >= (unsigned)nbins) b = -1;
         const bool valid = b >= 0;
         // lanes with the same bin, by one ballot per bit of the bin id (a fixed ceil(log2 nbins) steps; the leader-by-leader loop it
-        // replaces took one step per DISTINCT bin in the wave: ~40 on unsorted labels, e.g. bag-of-words data)
+        // replaces took one step per DISTINCT bin in the wave: ~40 on unsorted labels, e.g. bag-of-words data); a wave with one
+        // common bin (neighbours share a label after an ordered sweep) needs none
         unsigned long long m = __ballot(valid);
-        for (int bit = 0; bit < nbits; ++bit) {
-            const unsigned long long bal = __ballot(valid && ((b >> bit) & 1));
-            m &= ((b >> bit) & 1) ? bal : ~bal;
+        if (!__all(b == __builtin_amdgcn_readfirstlane(b))) {
+            for (int bit = 0; bit < nbits; ++bit) {
+                const unsigned long long bal = __ballot(valid && ((b >> bit) & 1));
+                m &= ((b >> bit) & 1) ? bal : ~bal;
+            }
         }
         const int rank = __popcll(m & ((1ull << lane) - 1ull)), cntb = __popcll(m);
         int pos = 0;
@@ -347,52 +377,66 @@ __global__ __launch_bounds__(64 * StatCfg<NBK>::NPANEL) void niw_stats_kernel(St
 }
 
 // packed row: [0] N, [1..D] sum, [1+D + a(a+1)/2 + b] S[a][b] (a >= b)
-__global__ __launch_bounds__(256) void niw_reduce_kernel(StatsArgs A, int NBK) {
+// block = 64 row elements x REDUCE_PARTS parts: a bin's segment heads (one slab each, <= range_groups + 1 of them, many more for a
+// large cluster than for a small one) are cut into REDUCE_PARTS contiguous runs summed by different threads, eight loads in flight
+// each, and the partial sums are combined in part order -- a fixed summation tree, so the rows stay bitwise reproducible.
+constexpr int REDUCE_PARTS = 4;
+__global__ __launch_bounds__(64 * REDUCE_PARTS) void niw_reduce_kernel(StatsArgs A, int NBK) {
+    __shared__ double part_sum[REDUCE_PARTS][64];
     const int b = blockIdx.y;
-    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (e >= A.packed_stride) return;
+    const int el = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int64_t e = blockIdx.x * 64ll + el;
+    const bool live = e < A.packed_stride;
     double *out = A.out + (int64_t)b * A.packed_stride;
-    if (!A.sb.bin_sel[b]) { out[e] = 0.; return; }
-    if (e == 0) { out[0] = (double)A.sb.bin_total[b]; return; }
+    if (!A.sb.bin_sel[b]) { if (live && part == 0) out[e] = 0.; return; }
     const int NPAIR = NBK * (NBK + 1) / 2;
-    int64_t off;
-    if (e <= A.D) {
-        off = (int64_t)NPAIR * 256 + (e - 1);
-    } else {
-        const int64_t te = e - 1 - A.D;
-        int a = (int)((sqrt(8.0 * (double)te + 1.0) - 1.0) * 0.5);
-        while ((int64_t)(a + 1) * (a + 2) / 2 <= te) ++a;
-        while ((int64_t)a * (a + 1) / 2 > te) --a;
-        const int c = (int)(te - (int64_t)a * (a + 1) / 2);
-        int ia = a / NBK, ba = a % NBK, ib = c / NBK, bb = c % NBK;
-        int R, Cc, pa, pb;
-        if (ba >= bb) { pa = ba; pb = bb; R = ia; Cc = ib; }
-        else { pa = bb; pb = ba; R = ib; Cc = ia; }
-        const int pair = pa * (pa + 1) / 2 + pb;
-        const int lane = Cc + 16 * (R & 3);
-        const int r = R >> 2;
-        off = (int64_t)pair * 256 + r * 64 + lane;
+    int64_t off = 0;
+    if (live && e >= 1) {
+        if (e <= A.D) {
+            off = (int64_t)NPAIR * 256 + (e - 1);
+        } else {
+            const int64_t te = e - 1 - A.D;
+            int a = (int)((sqrt(8.0 * (double)te + 1.0) - 1.0) * 0.5);
+            while ((int64_t)(a + 1) * (a + 2) / 2 <= te) ++a;
+            while ((int64_t)a * (a + 1) / 2 > te) --a;
+            const int c = (int)(te - (int64_t)a * (a + 1) / 2);
+            int ia = a / NBK, ba = a % NBK, ib = c / NBK, bb = c % NBK;
+            int R, Cc, pa, pb;
+            if (ba >= bb) { pa = ba; pb = bb; R = ia; Cc = ib; }
+            else { pa = bb; pb = ba; R = ib; Cc = ia; }
+            const int pair = pa * (pa + 1) / 2 + pb;
+            const int lane = Cc + 16 * (R & 3);
+            const int r = R >> 2;
+            off = (int64_t)pair * 256 + r * 64 + lane;
+        }
     }
-    double s = 0.;
     const int i0 = A.sb.item_start[b], i1 = A.sb.item_start[b + 1];
     const int total_items = A.sb.item_start[A.nbins];
     const int q = (total_items + A.range_groups - 1) / A.range_groups;      // as in niw_stats_kernel
-    // segment heads, in order; eight loads in flight per trip (the walk is a chain of dependent-latency loads otherwise), summed in
-    // the same order as the one-at-a-time loop
-    int it = i0;
-    while (it < i1) {
-        double v[8];
-        int cnt = 0;
+    // segment heads of the bin, in item order: i0, then every multiple of q inside (i0, i1)
+    const int m0 = i0 / q;
+    const int nheads = i1 > i0 ? 1 + max(0, (i1 - 1) / q - m0) : 0;
+    const int h0 = (int)((int64_t)nheads * part / REDUCE_PARTS), h1 = (int)((int64_t)nheads * (part + 1) / REDUCE_PARTS);
+    double s = 0.;
+    if (live && e >= 1) {
+        for (int h = h0; h < h1; h += 8) {
+            double v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const bool ok = it < i1;
-            v[u] = ok ? A.slabs[(int64_t)it * A.slab_stride + off] : 0.;
-            cnt += ok ? 1 : 0;
-            if (ok) it = (it / q + 1) * q;
+            for (int u = 0; u < 8; ++u) {
+                const int hh = h + u;
+                const int it = hh == 0 ? i0 : (m0 + hh) * q;
+                v[u] = hh < h1 ? A.slabs[(int64_t)it * A.slab_stride + off] : 0.;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (h + u < h1) s += v[u];
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) if (u < cnt) s += v[u];
     }
+    part_sum[part][el] = s;
+    __syncthreads();
+    if (part != 0 || !live) return;
+    if (e == 0) { out[0] = (double)A.sb.bin_total[b]; return; }
+#pragma unroll
+    for (int p = 1; p < REDUCE_PARTS; ++p) s += part_sum[p][el];
     out[e] = s;
 }
 
@@ -419,7 +463,7 @@ hipError_t launch_niw_stats(const StatsArgs &a0, hipStream_t s) {
         case 8: hipLaunchKernelGGL((niw_stats_kernel<8>), dim3(groups), dim3(128), 0, s, a); break;
         default: hipLaunchKernelGGL((niw_stats_kernel<16>), dim3(groups), dim3(256), 0, s, a); break;
     }
-    hipLaunchKernelGGL(niw_reduce_kernel, dim3((unsigned)((a.packed_stride + 255) / 256), a.nbins), dim3(256), 0, s, a, NBK);
+    hipLaunchKernelGGL(niw_reduce_kernel, dim3((unsigned)((a.packed_stride + 63) / 64), a.nbins), dim3(64 * REDUCE_PARTS), 0, s, a, NBK);
     return hipGetLastError();
 }
 

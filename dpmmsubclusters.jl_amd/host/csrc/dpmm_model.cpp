@@ -133,6 +133,7 @@ struct dpmmh_model {
     uint32_t epoch = 0;               // device-side randomised calls
     uint32_t draw_epoch = 1u << 20;   // parameter draws (predictable: the noise is generated ahead)
     uint32_t split_epoch = 0, merge_epoch = 0;
+    int64_t bad_total = 0, bad_steps = 0;   // diagnostics: clusters reset as "bad" so far, steps with any
 
     // noise generated while the GPU sweeps
     Helper helper;
@@ -356,10 +357,12 @@ struct dpmmh_model {
         if (W.step_stats(W.ctx, next_epoch(), &pk, &bad)) return wfail("step_stats");
         timers[T_STATS_WAIT] += now_s() - t0; t0 = now_s();
         std::vector<int> ks(K);
+        int nbad = 0;
         for (int k = 0; k < K; ++k) {
             ks[k] = k;
-            if (bad[k]) { splittable[slot[k]] = 0; reset_hist(slot[k]); }     // reset_bad_clusters! (LCA:501-516)
+            if (bad[k]) { splittable[slot[k]] = 0; reset_hist(slot[k]); ++nbad; }     // reset_bad_clusters! (LCA:501-516)
         }
+        bad_total += nbad; bad_steps += nbad ? 1 : 0;
         ingest(pk, ks);
         timers[T_POSTERIOR] += now_s() - t0;
         return 0;
@@ -780,7 +783,7 @@ HAPI int64_t dpmmh_model_get(dpmmh_model *m, const char *field, void *out, int64
     const int K = m->K, D = m->D;
     const size_t DD = (size_t)D * D;
     if (f == "K") return emit<int64_t>(out, cap, {(int64_t)K});
-    if (f == "counters") return emit<int64_t>(out, cap, {(int64_t)m->epoch, (int64_t)m->draw_epoch, (int64_t)m->split_epoch, (int64_t)m->merge_epoch, 0, 0, 0, 0});
+    if (f == "counters") return emit<int64_t>(out, cap, {(int64_t)m->epoch, (int64_t)m->draw_epoch, (int64_t)m->split_epoch, (int64_t)m->merge_epoch, m->bad_total, m->bad_steps, 0, 0});
     if (f == "timers") return emit<double>(out, cap, std::vector<double>(m->timers, m->timers + 16));
     auto rows_d = [&](const std::vector<double> &src, size_t w) {
         std::vector<double> v((size_t)3 * K * w);

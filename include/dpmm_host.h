@@ -124,7 +124,7 @@ double dpmmh_log_posterior(dpmmh_model *m);
 
 /* State access, cluster order.  dpmmh_model_get copies a named field into `out` (capacity in bytes) and returns the
  * number of bytes of the field (negative on error; call with out = NULL to query the size).  Fields:
- *   "K" i64[1]            "counters" i64[8] (device epoch, draw epoch, split epoch, merge epoch, ...)
+ *   "K" i64[1]            "counters" i64[8] (device epoch, draw epoch, split epoch, merge epoch, bad-cluster resets so far, steps with a reset, 0, 0)
  *   "N" f64[3K]           "sums" f64[3K][D]         "S" f64[3K][D][D]      (statistics; cluster row = left + right)
  *   "packed" f64[2K][stride]  (rows l, r of every cluster: the checkpoint form of the statistics)
  *   "kappa","nu","logdet_psi","log_marginal" f64[3K]   "m" f64[3K][D]   "U" f64[3K][D][D] (nu psi = U U')      -- NIW

@@ -49,7 +49,8 @@ t_after = dict(s.timers)
 lab, _ = wk.get_labels()
 out = {"config": f"{kind} D={D} N={N} K={s.K}", "ms_per_step": 1e3 * float(np.mean(ts)), "ms_per_step_min": 1e3 * float(np.min(ts)),
        "sweep_kernel_ms": float(np.mean(sw)), "stats_kernels_ms": float(np.mean(st)), "label_agreement": float(np.mean(lab == y)),
-       "splittable": int(s.splittable.sum()),
+       "splittable": int(s.splittable.sum()), "bad_resets_total_and_steps": [int(v) for v in s.model.get("counters")[4:6]],
+       "min_sub_occupancy": float(np.min(s.N[:, 1:3])), "sub_occupancy_sorted_head": np.sort(np.min(s.N[:, 1:3], axis=1))[:6].tolist(),
        "host_ms_per_step": {k: round(1e3 * (t_after[k] - t_before[k]) / steps, 4) for k in t_after}}
 if kind == "niw":
     out["algorithmic_tflops_sweep"] = 2.0 * N * D * D * (s.K + 2) / (np.mean(sw) * 1e-3) / 1e12
