@@ -98,7 +98,8 @@ struct dpmm_ctx {
     size_t h_out_bytes = 0;
     char *d_par = nullptr;             // device copy of the staging's mu | R regions (NIW): the pack kernel gathers from HBM, not over the host link
     size_t d_par_bytes = 0;
-    uint8_t *d_flags = nullptr;        // [DPMM_MAX_CLUSTERS + 1] bad-cluster flags of the current step (+ any)
+    bool work_zeroed = false;          // the pack kernel cleared d_work and no sweep has run since
+    int sel_all_ones = 0, sel_capacity = 0;   // sb.bin_sel[0..sel_all_ones) are known to be 1 (full passes skip the memset)
     long long *d_counts64 = nullptr;   // [2 * DPMM_MAX_CLUSTERS] global sub-cluster occupancies (multi-GPU)
     unsigned long long *d_work = nullptr;   // [4] executed-work counters of the last sweep
     // options (dpmm_set_option)
@@ -244,7 +245,7 @@ static int ensure_capacity(dpmm_ctx *c, int K) {
     // statistics
     c->max_items = (int)((c->n + c->chunk - 1) / c->chunk) + 2 * cap;
     HIPCHK(c, hipMalloc(&c->d_slabs, sizeof(double) * (size_t)c->max_items * (size_t)c->slab_stride));
-    HIPCHK(c, hipMalloc(&c->d_out, sizeof(double) * 2 * cap * (size_t)c->packed_stride));
+    HIPCHK(c, hipMalloc(&c->d_out, sizeof(double) * 2 * cap * (size_t)c->packed_stride + DPMM_MAX_CLUSTERS + 64));   // rows | bad-cluster flags
     c->Kcap = cap;
     return DPMM_OK;
 }
@@ -311,10 +312,9 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
     CHK_CREATE(hipMalloc(&c->sb.item_start, sizeof(int32_t) * (nbmax + 1)));
     CHK_CREATE(hipMalloc(&c->sb.perm, sizeof(int32_t) * nalloc));
     CHK_CREATE(hipMalloc(&c->sb.bin_sel, nbmax));
+    c->sel_capacity = (int)nbmax;
     CHK_CREATE(hipMalloc(&c->sb.perm_total, sizeof(int32_t)));
     CHK_CREATE(hipMalloc(&c->d_small, sizeof(int32_t) * 4 * DPMM_MAX_CLUSTERS));
-    CHK_CREATE(hipMalloc(&c->d_flags, DPMM_MAX_CLUSTERS + 8));
-    CHK_CREATE(hipMemset(c->d_flags, 0, DPMM_MAX_CLUSTERS + 8));
     CHK_CREATE(hipMalloc(&c->d_counts64, sizeof(long long) * 2 * DPMM_MAX_CLUSTERS));
     CHK_CREATE(hipMalloc(&c->d_work, sizeof(unsigned long long) * 4));
     CHK_CREATE(hipMemset(c->d_work, 0, sizeof(unsigned long long) * 4));
@@ -331,7 +331,7 @@ int dpmm_destroy(dpmm_ctx *c) {
     hipFree(c->dX); hipFree(c->dX8); hipFree(c->dbins); hipFree(c->d_gt); hipFree(c->d_cont);
     hipFree(c->sb.tile_hist); hipFree(c->sb.bin_total); hipFree(c->sb.bin_start); hipFree(c->sb.item_start);
     hipFree(c->sb.perm); hipFree(c->sb.bin_sel); hipFree(c->sb.perm_total); hipFree(c->d_small); hipFree(c->d_proj); hipFree(c->d_vals); hipFree(c->d_smart);
-    hipFree(c->d_flags); hipFree(c->d_counts64); hipFree(c->d_work); hipFree(c->d_par);
+    hipFree(c->d_counts64); hipFree(c->d_work); hipFree(c->d_par);
     comm_release(c);
     if (c->h_pin) hipHostFree(c->h_pin);
     if (c->h_par) hipHostFree(c->h_par);
@@ -485,6 +485,8 @@ static ParLayout par_layout(const dpmm_ctx *c, int slots) {
     const size_t D = (size_t)c->D, S = (size_t)slots;
     size_t o = 0;
     if (c->prior == DPMM_PRIOR_NIW) {
+        // cst | mu | mat are contiguous (every offset a multiple of 16 bytes: slots is a multiple of 8): ONE copy takes them to the device
+        L.cst = o; o += sizeof(float) * 3 * S;
         L.mu = o; o += sizeof(float) * 3 * S * D;
         L.mat = o; o += sizeof(float) * 3 * S * (D * (D + 1) / 2);
         L.logdet = o; o += sizeof(float) * 3 * S;
@@ -493,7 +495,7 @@ static ParLayout par_layout(const dpmm_ctx *c, int slots) {
     }
     L.lr = o; o += sizeof(float) * 2 * S;
     L.w = o; o += sizeof(float) * S;
-    L.cst = o; o += sizeof(float) * 3 * S;
+    if (c->prior != DPMM_PRIOR_NIW) { L.cst = o; o += sizeof(float) * 3 * S; }
     L.slot = o; o += sizeof(int32_t) * S;
     L.bytes = (o + 255) & ~(size_t)255;
     return L;
@@ -562,29 +564,29 @@ int dpmm_commit_params(dpmm_ctx *c, int K) {
     }
     // the kernels below read the staging buffer in place (no copy-engine transfer); the host may touch it again once a
     // blocking call (dpmm_step_stats, dpmm_suffstats_*, dpmm_sync) has returned
-    HIPCHK(c, launch_copy_bytes(c->d_cst, hcst, sizeof(float) * 3 * K, c->stream));
     if (niw) {
-        // mu | R of the slots in use: ONE streaming copy over the host link (1 KiB requests), then the gather into the fragment
+        // cst | mu | R of the slots in use: ONE streaming copy over the host link (1 KiB requests), then the gather into the fragment
         // images reads HBM.  (Letting the pack kernel gather from the pinned buffer directly cost 0.9 ms at D = 256 -- 16-byte
         // requests over PCIe -- against 0.25 ms for the bulk copy.)
         int top = 0;
         for (int k = 0; k < K; ++k) top = std::max(top, hslot[k] + 1);
         const size_t D = (size_t)c->D, T = D * (D + 1) / 2;
-        const size_t mu_bytes = sizeof(float) * 3 * (size_t)top * D, mat_bytes = sizeof(float) * 3 * (size_t)top * T;
-        const size_t mu_pad = (mu_bytes + 255) & ~(size_t)255;
-        if (mu_pad + mat_bytes + 256 > c->d_par_bytes) {
+        const size_t img_bytes = (L.mat - L.cst) + sizeof(float) * 3 * (size_t)top * T;
+        const size_t cap = (L.logdet - L.cst) + 1024;
+        if (cap > c->d_par_bytes) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
             hipFree(c->d_par); c->d_par = nullptr;
-            const size_t cap = sizeof(float) * 3 * (size_t)c->par_slots * (D + T) + 1024;
             HIPCHK(c, hipMalloc(&c->d_par, cap));
             c->d_par_bytes = cap;
         }
-        HIPCHK(c, launch_copy_bytes16(c->d_par, hmu, mu_bytes, c->stream));
-        HIPCHK(c, launch_copy_bytes16(c->d_par + mu_pad, hmat, mat_bytes, c->stream));
-        hmu = reinterpret_cast<const float *>(c->d_par);
-        hmat = reinterpret_cast<const float *>(c->d_par + mu_pad);
+        HIPCHK(c, launch_copy_bytes16(c->d_par, hcst, img_bytes, c->stream));
+        const float *dcst = reinterpret_cast<const float *>(c->d_par);
+        hmu = reinterpret_cast<const float *>(c->d_par + (L.mu - L.cst));
+        hmat = reinterpret_cast<const float *>(c->d_par + (L.mat - L.cst));
         c->have_tail = c->opt_tail && c->D >= 4 && c->D % 4 == 0 && K > 2;
-        HIPCHK(c, launch_niw_pack(hmat, hmu, c->d_Rp, c->d_mup, c->D, c->NB, 3 * K, c->have_tail ? c->d_tail : nullptr, c->d_cst, hslot, c->stream));
+        HIPCHK(c, launch_niw_pack(hmat, hmu, c->d_Rp, c->d_mup, c->D, c->NB, 3 * K, c->have_tail ? c->d_tail : nullptr, dcst, hslot, c->d_cst,
+                                  c->d_work, c->stream));
+        c->work_zeroed = true;
         c->have_screen_prep = false;
         if (c->D > 16 && c->D <= 64 && K > 2) {
             // the vectorised far mask (64 clusters per step) pays once there are many clusters, or when the VALU tail
@@ -596,6 +598,7 @@ int dpmm_commit_params(dpmm_ctx *c, int K) {
             }
         }
     } else {
+        HIPCHK(c, launch_copy_bytes(c->d_cst, hcst, sizeof(float) * 3 * K, c->stream));
         HIPCHK(c, launch_gather_rows(c->d_raw, c->ldx, hmat, c->D, hslot, 3 * K, c->D, c->stream));
         HIPCHK(c, launch_mult_pack(c->d_raw, c->d_Rp, 3 * K, c->ldx, c->stream));
         if (c->x_u8) HIPCHK(c, launch_mult_pack_u8(c->d_raw, c->d_Lp16, 3 * K, c->ldx, c->ld8, c->stream));
@@ -688,7 +691,10 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
     if (!c->have_points || !c->have_params) return fail(c, DPMM_ESTATE, "sweep needs points and parameters");
     HIPCHK(c, hipSetDevice(c->device));
     if (c->n == 0) return DPMM_OK;
-    if (c->prior == DPMM_PRIOR_NIW && !table) HIPCHK(c, hipMemsetAsync(c->d_work, 0, sizeof(unsigned long long) * 4, c->stream));
+    if (c->prior == DPMM_PRIOR_NIW && !table) {
+        if (!c->work_zeroed) HIPCHK(c, hipMemsetAsync(c->d_work, 0, sizeof(unsigned long long) * 4, c->stream));   // usually done by the pack kernel
+        c->work_zeroed = false;
+    }
     if (!table) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     if (c->prior == DPMM_PRIOR_NIW) {
         NiwSweepArgs a{};
@@ -881,8 +887,10 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
         HIPCHK(c, hipStreamSynchronize(c->stream));
         memcpy(c->h_pin, c->h_sel.data(), nbins);
         HIPCHK(c, launch_copy_bytes(c->sb.bin_sel, c->h_pin, nbins, c->stream));
-    } else {
-        HIPCHK(c, hipMemsetAsync(c->sb.bin_sel, 1, nbins, c->stream));
+        c->sel_all_ones = 0;
+    } else if (c->sel_all_ones < nbins) {
+        HIPCHK(c, hipMemsetAsync(c->sb.bin_sel, 1, c->sel_capacity, c->stream));      // stays valid until a subset pass overwrites it
+        c->sel_all_ones = c->sel_capacity;
     }
     StatsArgs a{};
     a.X = c->dX; a.ldx = c->ldx; a.n = c->n; a.D = c->D; a.nbins = nbins; a.chunk = c->chunk;
@@ -903,10 +911,13 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
             if (int rc = comm_allreduce(c, c->d_counts64, nbins, /*f64=*/false)) return rc;
             gc = c->d_counts64;
         }
-        HIPCHK(c, launch_bad_flags(c->sb.bin_total, gc, c->K, c->d_flags, c->stream));
+        // the flags live right behind the packed rows, so that rows + flags reach the master in one copy
+        uint8_t *flags = reinterpret_cast<uint8_t *>(c->d_out) + sizeof(double) * (size_t)nbins * (size_t)c->packed_stride;
         if (c->n > 0) {
-            HIPCHK(c, launch_reset_sub_flagged(c->dbins, c->n, c->first, c->d_flags, c->K, c->seed, reset_epoch, c->stream));
-            HIPCHK(c, launch_sort_by_bin(c->dbins, c->n, nbins, c->sb, c->stream, c->d_flags + c->K));
+            HIPCHK(c, launch_reset_sub_flagged(c->dbins, c->n, c->first, c->sb.bin_total, gc, flags, c->K, c->seed, reset_epoch, c->stream));
+            HIPCHK(c, launch_sort_by_bin(c->dbins, c->n, nbins, c->sb, c->stream, flags + c->K));
+        } else {
+            HIPCHK(c, launch_bad_flags(c->sb.bin_total, gc, c->K, flags, c->stream));
         }
     }
     HIPCHK(c, launch_sort_finish(c->dbins, a, c->stream));
@@ -964,8 +975,7 @@ int dpmm_step_stats(dpmm_ctx *c, uint32_t reset_epoch, const double **packed, co
     const size_t out_bytes = sizeof(double) * 2 * (size_t)std::max(c->K, 1) * (size_t)c->packed_stride;
     if (int rc = ensure_out(c, out_bytes + DPMM_MAX_CLUSTERS + 64)) return rc;
     if (int rc = run_stats(c, nullptr, 0, true, reset_epoch)) return rc;
-    HIPCHK(c, launch_copy_bytes(c->h_out, c->d_out, out_bytes, c->stream));
-    HIPCHK(c, launch_copy_bytes(c->h_out + out_bytes, c->d_flags, (size_t)c->K + 1, c->stream));
+    HIPCHK(c, launch_copy_bytes(c->h_out, c->d_out, out_bytes + (size_t)c->K + 1, c->stream));      // rows | flags
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *packed = reinterpret_cast<const double *>(c->h_out);
     *bad = reinterpret_cast<const uint8_t *>(c->h_out + out_bytes);

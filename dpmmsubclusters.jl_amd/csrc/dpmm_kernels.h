@@ -51,7 +51,7 @@ int niw_occupancy(int NB);  // resident 256-thread workgroups per CU the sweep k
 hipError_t launch_niw_sweep(int NB, const NiwSweepArgs &a, int grid, hipStream_t s);
 hipError_t launch_niw_screen_prep(const float *R, const float *mu, int D, int K, float *lam, float *dist, const int32_t *slot, hipStream_t s);
 hipError_t launch_niw_pack(const float *R, const float *mu, float *Rp, float *mup, int D, int NB, int nmat, float *tail, const float *cst,
-                           const int32_t *slot, hipStream_t s);
+                           const int32_t *slot, float *cst_out, unsigned long long *work, hipStream_t s);
 
 struct MultSweepArgs {
     const float *X;
@@ -103,8 +103,8 @@ hipError_t launch_init_labels(int32_t *bins, int64_t n, int64_t first_index, int
 // step statistics: flags[k] = 1 when cluster k has an empty sub-cluster (counts: [2K] Int64, global), flags[K] = any;
 // then re-draw the sub-labels of flagged clusters (reset_bad_clusters_worker!)
 hipError_t launch_bad_flags(const int32_t *bin_total, const long long *global_counts, int K, uint8_t *flags, hipStream_t s);
-hipError_t launch_reset_sub_flagged(int32_t *bins, int64_t n, int64_t first_index, const uint8_t *flags, int K, uint64_t seed, uint32_t epoch,
-                                    hipStream_t s);
+hipError_t launch_reset_sub_flagged(int32_t *bins, int64_t n, int64_t first, const int32_t *bin_total, const long long *global_counts,
+                                    uint8_t *flags, int K, uint64_t seed, uint32_t epoch, hipStream_t s);
 hipError_t launch_widen_counts(const int32_t *src, long long *dst, int n, hipStream_t s);
 hipError_t launch_gather_rows(float *dst, int64_t ld_dst, const float *src, int64_t ld_src, const int32_t *slot, int rows, int D, hipStream_t s);
 hipError_t launch_bins_from_i64(int32_t *bins, const int64_t *labels, const int64_t *sub, int64_t n, hipStream_t s);

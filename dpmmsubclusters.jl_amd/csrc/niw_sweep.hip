@@ -1113,8 +1113,12 @@ __device__ __forceinline__ size_t tri_off(int D, int row, int col) {      // col
 }
 __global__ void niw_pack_kernel(const float *__restrict__ R, const float *__restrict__ mu, float *__restrict__ Rp,
                                 float *__restrict__ mup, int D, int NB, int nmat, float *__restrict__ tail, const float *__restrict__ cst,
-                                const int32_t *__restrict__ slot) {
+                                const int32_t *__restrict__ slot, float *__restrict__ cst_out, unsigned long long *__restrict__ work) {
     const int NP = NB * (NB + 1) / 2;
+    // riders (save two launches per sweep): the additive constants move from the parameter image to where the sweep kernels read
+    // them, and the executed-work counters of the next sweep start at zero
+    if (cst_out) for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < nmat; e += (int64_t)gridDim.x * blockDim.x) cst_out[e] = cst[e];
+    if (work && blockIdx.x == 0 && threadIdx.x < 4) work[threadIdx.x] = 0ull;
     const int DP = 16 * NB;
     const size_t TRI = (size_t)D * (D + 1) / 2;
     const int64_t total = (int64_t)nmat * NP * 256;
@@ -1208,8 +1212,8 @@ hipError_t launch_niw_screen_prep(const float *R, const float *mu, int D, int K,
 }
 
 hipError_t launch_niw_pack(const float *R, const float *mu, float *Rp, float *mup, int D, int NB, int nmat, float *tail, const float *cst,
-                           const int32_t *slot, hipStream_t s) {
-    hipLaunchKernelGGL(niw_pack_kernel, dim3(512), dim3(256), 0, s, R, mu, Rp, mup, D, NB, nmat, tail, cst, slot);
+                           const int32_t *slot, float *cst_out, unsigned long long *work, hipStream_t s) {
+    hipLaunchKernelGGL(niw_pack_kernel, dim3(512), dim3(256), 0, s, R, mu, Rp, mup, D, NB, nmat, tail, cst, slot, cst_out, work);
     return hipGetLastError();
 }
 
