@@ -23,6 +23,7 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#include <sys/prctl.h>
 
 #include <algorithm>
 #include <string>
@@ -72,15 +73,30 @@ class Helper {
         std::unique_lock<std::mutex> lk(mu_);
         done_.wait(lk, [&] { return !busy_; });
     }
+    // for jobs: sleep until the CLOCK_MONOTONIC time `t_abs` (seconds) unless cancel() comes first; true = the time was reached
+    bool sleep_until(double t_abs) {
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            if (cancel_ || stop_) return false;
+            const double left = t_abs - now_s();
+            if (left <= 0) return true;
+            cv_.wait_for(lk, std::chrono::duration<double>(left));
+        }
+    }
+    void cancel() {
+        { std::lock_guard<std::mutex> lk(mu_); cancel_ = true; }
+        cv_.notify_all();
+    }
   private:
     void loop() {
+        prctl(PR_SET_TIMERSLACK, 1000UL);     // 1 us instead of the default 50 us: sleep_until is used for sub-100-us scheduling
         for (;;) {
             std::function<void()> job;
             {
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_.wait(lk, [&] { return stop_ || (busy_ && job_); });
                 if (stop_) return;
-                job = std::move(job_); job_ = nullptr;
+                job = std::move(job_); job_ = nullptr; cancel_ = false;
             }
             job();
             { std::lock_guard<std::mutex> lk(mu_); busy_ = false; }
@@ -91,7 +107,7 @@ class Helper {
     std::condition_variable cv_, done_;
     std::thread th_;
     std::function<void()> job_;
-    bool busy_ = false, stop_ = false;
+    bool busy_ = false, stop_ = false, cancel_ = false;
 };
 
 // random streams of the master side (the worker uses 0..3, the draws 16..18)
@@ -137,6 +153,9 @@ struct dpmmh_model {
 
     // noise generated while the GPU sweeps
     Helper helper;
+    bool prewake = true;
+    double wait_ema = 0.0, t_stats_back = 0.0;
+    static constexpr double kPrewakeLead = 60e-6;   // seconds before the predicted hand-back
     bool noise_pending = false;
     uint32_t noise_epoch = 0;
     int noise_rows = 0;
@@ -277,18 +296,25 @@ struct dpmmh_model {
     }
 
     // ---------------------------------------------------------------- noise (runs while the GPU sweeps)
-    void start_noise() {
-        if (kind != DPMMH_PRIOR_NIW) return;
+    // ... and wakes the pool shortly before the statistics are expected back (prediction: the previous steps' launch-to-statistics time)
+    void start_noise(double t_launch = 0.0) {
         wait_noise();
+        const bool niw_noise = kind == DPMMH_PRIOR_NIW;
+        const double pre_at = (prewake && nthreads > 1 && t_launch > 0.0 && wait_ema > 0.0) ? t_launch + wait_ema - kPrewakeLead : 0.0;
+        if (!niw_noise && pre_at == 0.0) return;
         const int rows = 3 * (K + 4);   // head-room for clusters born from splits
         const size_t DD = (size_t)D * D;
-        if (noise_A.size() < (size_t)rows * DD) { noise_A.resize((size_t)rows * DD); noise_xi.resize((size_t)rows * D); }
-        noise_epoch = draw_epoch + 1; noise_rows = rows;
+        if (niw_noise) {
+            if (noise_A.size() < (size_t)rows * DD) { noise_A.resize((size_t)rows * DD); noise_xi.resize((size_t)rows * D); }
+            noise_epoch = draw_epoch + 1; noise_rows = rows;
+        }
         const int nt = nthreads;
-        helper.submit([this, rows, DD, nt] {
-            Pool::get().run(rows, nt, [&](int i, int) {
-                dpmmh::niw_noise_one(D, seed, (uint32_t)i, noise_epoch, noise_A.data() + (size_t)i * DD, noise_xi.data() + (size_t)i * D);
-            });
+        helper.submit([this, rows, DD, nt, niw_noise, pre_at] {
+            if (niw_noise)
+                Pool::get().run(rows, nt, [&](int i, int) {
+                    dpmmh::niw_noise_one(D, seed, (uint32_t)i, noise_epoch, noise_A.data() + (size_t)i * DD, noise_xi.data() + (size_t)i * D);
+                });
+            if (pre_at > 0.0 && helper.sleep_until(pre_at)) Pool::get().prewake();
         });
         noise_pending = true;
     }
@@ -355,7 +381,9 @@ struct dpmmh_model {
         double t0 = now_s();
         const double *pk = nullptr; const uint8_t *bad = nullptr;
         if (W.step_stats(W.ctx, next_epoch(), &pk, &bad)) return wfail("step_stats");
-        timers[T_STATS_WAIT] += now_s() - t0; t0 = now_s();
+        t_stats_back = now_s();
+        helper.cancel();                       // a pre-wake still pending is late: drop it
+        timers[T_STATS_WAIT] += t_stats_back - t0; t0 = t_stats_back;
         std::vector<int> ks(K);
         int nbad = 0;
         for (int k = 0; k < K; ++k) {
@@ -577,9 +605,15 @@ struct dpmmh_model {
         if (W.commit_params(W.ctx, K)) return wfail("commit_params");                // 2
         timers[T_COMMIT] += now_s() - t0; t0 = now_s();
         if (W.sweep(W.ctx, next_epoch(), (final || hard) ? 1 : 0)) return wfail("sweep");   // 3 + 4 (asynchronous); LCA:661
-        start_noise();                                                               // the host works while the GPU sweeps
+        const double t_launch = now_s();
+        start_noise(t_launch);                                                       // the host works while the GPU sweeps
         timers[T_SWEEP_LAUNCH] += now_s() - t0;
         if (int rc = update_all_with_reset()) return rc;                             // 5 + 6
+        {
+            // launch-to-statistics time of this step (before the posterior work): the next step's pre-wake prediction
+            const double w = t_stats_back - t_launch;
+            wait_ema = wait_ema > 0.0 ? 0.5 * wait_ema + 0.5 * w : w;
+        }
         if (!no_more_splits) {                                                       // 7
             t0 = now_s();
             std::vector<int> touched;
@@ -671,6 +705,7 @@ HAPI int dpmmh_model_set_option(dpmmh_model *m, int option, double value) {
         case DPMMH_OPT_THREADS: m->nthreads = std::max(1, (int)value); return 0;
         case DPMMH_OPT_SHARE_WORK: m->share_work = value != 0; return 0;
         case DPMMH_OPT_SPIN_US: Pool::get().set_spin_us((int)value); return 0;
+        case DPMMH_OPT_PREWAKE: m->prewake = value != 0; return 0;
         default: return m->fail("unknown option");
     }
 }

@@ -52,6 +52,13 @@ class Pool {
         }
         fn_ = nullptr;
     }
+    // Wake sleeping workers ahead of a job that is about to arrive (the master knows when the GPU will hand the statistics back):
+    // they poll for at most `spin_us` and start at once instead of paying the futex wake-up (20-50 us for a dozen threads) inside the
+    // timed path; if nothing arrives they go back to sleep.
+    void prewake() {
+        { std::lock_guard<std::mutex> lk(mu_); pre_.fetch_add(1, std::memory_order_release); }
+        cv_.notify_all();
+    }
   private:
     Pool() {}
     ~Pool() {
@@ -76,6 +83,7 @@ class Pool {
     }
     void loop(int id) {
         uint64_t seen = 0;                                   // generation of the last job this worker looked at
+        uint64_t seen_pre = 0;                               // last prewake() this worker answered
         for (;;) {
             uint64_t st = state_.load(std::memory_order_acquire);
             if ((st >> 16) == seen) {
@@ -86,8 +94,10 @@ class Pool {
                 }
                 if ((st >> 16) == seen) {
                     std::unique_lock<std::mutex> lk(mu_);
-                    cv_.wait(lk, [&] { return (state_.load(std::memory_order_acquire) >> 16) != seen; });
+                    cv_.wait(lk, [&] { return (state_.load(std::memory_order_acquire) >> 16) != seen || pre_.load(std::memory_order_acquire) != seen_pre; });
                     st = state_.load(std::memory_order_acquire);
+                    seen_pre = pre_.load(std::memory_order_acquire);
+                    if ((st >> 16) == seen) continue;        // prewake: back to the bounded poll
                 }
             }
             seen = st >> 16;                                 // generation and worker count come from ONE snapshot
@@ -108,6 +118,7 @@ class Pool {
     int n_ = 0;
     std::atomic<uint64_t> state_{0};                         // (generation << 16) | workers wanted
     std::atomic<int64_t> spin_ns_{0};
+    std::atomic<uint64_t> pre_{0};
     std::atomic<bool> stop_{false};
 };
 
