@@ -24,25 +24,49 @@ namespace dpmmh {
 
 constexpr int kBlk = 8;
 
-// y[0..n) -= a0*x0[0..n) + ... + a7*x7[0..n)   and the same for a second row: the rank-8, two-row update both kernels share
+// y[0..n) -= a0*x0[0..n) + ... + a7*x7[0..n)   and the same for a second row: the rank-8, two-row update both kernels share.
+// The sums are written as TREES (pairs, then pairs of pairs): a left-to-right chain of eight fused multiply-adds per row leaves the
+// two FMA pipes of the core idle three cycles out of four (latency 4, two chains); four independent partial sums per row fill them.
 #define DPMMH_RANK8_2ROWS(ya, yb, A, B, X0, X1, X2, X3, X4, X5, X6, X7, n)                                                    \
     _Pragma("omp simd") for (int k_ = 0; k_ < (n); ++k_) {                                                                  \
         const double v0 = (X0)[k_], v1 = (X1)[k_], v2 = (X2)[k_], v3 = (X3)[k_], v4 = (X4)[k_], v5 = (X5)[k_], v6 = (X6)[k_], v7 = (X7)[k_]; \
-        (ya)[k_] -= (A)[0] * v0 + (A)[1] * v1 + (A)[2] * v2 + (A)[3] * v3 + (A)[4] * v4 + (A)[5] * v5 + (A)[6] * v6 + (A)[7] * v7;    \
-        (yb)[k_] -= (B)[0] * v0 + (B)[1] * v1 + (B)[2] * v2 + (B)[3] * v3 + (B)[4] * v4 + (B)[5] * v5 + (B)[6] * v6 + (B)[7] * v7;    \
+        (ya)[k_] -= (((A)[0] * v0 + (A)[1] * v1) + ((A)[2] * v2 + (A)[3] * v3)) + (((A)[4] * v4 + (A)[5] * v5) + ((A)[6] * v6 + (A)[7] * v7));    \
+        (yb)[k_] -= (((B)[0] * v0 + (B)[1] * v1) + ((B)[2] * v2 + (B)[3] * v3)) + (((B)[4] * v4 + (B)[5] * v5) + ((B)[6] * v6 + (B)[7] * v7));    \
     }
 
-// the same with sixteen vectors: halves the traffic of the updated rows (at D = 256 they stream from L2)
+// the same with sixteen vectors: halves the traffic of the updated rows (at D = 256 they stream from L2); four partial sums per row
 #define DPMMH_RANK16_2ROWS(ya, yb, A, B, X, ldx, n)                                                                          \
     _Pragma("omp simd") for (int k_ = 0; k_ < (n); ++k_) {                                                                  \
-        double sa = 0.0, sb = 0.0;                                                                                          \
-        _Pragma("GCC unroll 16") for (int c_ = 0; c_ < 16; ++c_) {                                                                 \
-            const double v = (X)[(size_t)c_ * (ldx) + k_];                                                                  \
-            sa += (A)[c_] * v;                                                                                              \
-            sb += (B)[c_] * v;                                                                                              \
+        double sa0 = 0.0, sa1 = 0.0, sa2 = 0.0, sa3 = 0.0, sb0 = 0.0, sb1 = 0.0, sb2 = 0.0, sb3 = 0.0;                        \
+        _Pragma("GCC unroll 4") for (int c_ = 0; c_ < 4; ++c_) {                                                            \
+            const double u0 = (X)[(size_t)c_ * (ldx) + k_], u1 = (X)[(size_t)(c_ + 4) * (ldx) + k_];                          \
+            const double u2 = (X)[(size_t)(c_ + 8) * (ldx) + k_], u3 = (X)[(size_t)(c_ + 12) * (ldx) + k_];                   \
+            sa0 += (A)[c_] * u0; sa1 += (A)[c_ + 4] * u1; sa2 += (A)[c_ + 8] * u2; sa3 += (A)[c_ + 12] * u3;                  \
+            sb0 += (B)[c_] * u0; sb1 += (B)[c_ + 4] * u1; sb2 += (B)[c_ + 8] * u2; sb3 += (B)[c_ + 12] * u3;                  \
         }                                                                                                                   \
-        (ya)[k_] -= sa;                                                                                                     \
-        (yb)[k_] -= sb;                                                                                                     \
+        (ya)[k_] -= (sa0 + sa1) + (sa2 + sa3);                                                                              \
+        (yb)[k_] -= (sb0 + sb1) + (sb2 + sb3);                                                                              \
+    }
+
+// Register-blocked form for long rows (the bulk of the work at D >= 128): FOUR rows x SIXTEEN columns of the updated block live in
+// eight vector accumulators while the sixteen X rows stream past: 8 FMAs per 2 vector loads + 4 broadcasts, eight independent
+// chains -- FMA-bound instead of load-bound (the two-row form issues one load per FMA).  GCC vector extensions: AVX-512 code in the
+// avx512f clone, pairs of AVX2 operations in the default clone.  n must be a multiple of 16.
+typedef double v8d __attribute__((vector_size(64), aligned(8)));
+#define ld8(p) (*reinterpret_cast<const v8d *>(p))
+#define st8(p, v) (*reinterpret_cast<v8d *>(p) = (v))
+#define DPMMH_RANK16_4ROWS(y0, y1, y2, y3, A4 /* [4][16] */, X, ldx, n)                                                      \
+    for (int q_ = 0; q_ < (n); q_ += 16) {                                                                                  \
+        v8d c00 = ld8((y0) + q_), c01 = ld8((y0) + q_ + 8), c10 = ld8((y1) + q_), c11 = ld8((y1) + q_ + 8);                   \
+        v8d c20 = ld8((y2) + q_), c21 = ld8((y2) + q_ + 8), c30 = ld8((y3) + q_), c31 = ld8((y3) + q_ + 8);                   \
+        _Pragma("GCC unroll 16") for (int c_ = 0; c_ < 16; ++c_) {                                                          \
+            const v8d x0 = ld8((X) + (size_t)c_ * (ldx) + q_), x1 = ld8((X) + (size_t)c_ * (ldx) + q_ + 8);                  \
+            const double a0 = (A4)[c_], a1 = (A4)[16 + c_], a2 = (A4)[32 + c_], a3 = (A4)[48 + c_];                           \
+            c00 -= a0 * x0; c01 -= a0 * x1; c10 -= a1 * x0; c11 -= a1 * x1;                                                 \
+            c20 -= a2 * x0; c21 -= a2 * x1; c30 -= a3 * x0; c31 -= a3 * x1;                                                 \
+        }                                                                                                                   \
+        st8((y0) + q_, c00); st8((y0) + q_ + 8, c01); st8((y1) + q_, c10); st8((y1) + q_ + 8, c11);                           \
+        st8((y2) + q_, c20); st8((y2) + q_ + 8, c21); st8((y3) + q_, c30); st8((y3) + q_ + 8, c31);                           \
     }
 
 // P (row-major D x D, LOWER triangle valid, destroyed) = L' L with L lower triangular.  L (row-major D x D) receives the factor
@@ -113,6 +137,19 @@ DPMMH_CLONES inline double chol_ltl(double *__restrict__ P, int D, double *__res
             if (!ok) break;
             const double *W = P + (size_t)j0 * D;
             int k = 0;
+            if (D % 16 == 0) {
+                // four rows at a time over columns 0 .. roundup(k + 4, 16): entries beyond a row's diagonal are scratch
+                for (; k + 3 < j0; k += 4) {
+                    double *ya = P + (size_t)k * D;
+                    double a4[64];
+                    for (int c = 0; c < 16; ++c) {
+                        const double *w = W + (size_t)c * D + k;
+                        a4[c] = w[0]; a4[16 + c] = w[1]; a4[32 + c] = w[2]; a4[48 + c] = w[3];
+                    }
+                    const int n16 = (k + 4 + 15) & ~15;
+                    DPMMH_RANK16_4ROWS(ya, ya + D, ya + 2 * (size_t)D, ya + 3 * (size_t)D, a4, W, D, n16)
+                }
+            }
             for (; k + 1 < j0; k += 2) {
                 double *ya = P + (size_t)k * D, *yb = ya + D;
                 double a[16], b[16];
@@ -161,6 +198,12 @@ DPMMH_CLONES inline void solve_lower_left(double *__restrict__ Y, const double *
             const double *X = Y + (size_t)k0 * D;
             const int len = k0 + 2 * kBlk;
             int i = i0;
+            for (; i + 3 < i1; i += 4) {      // len is a multiple of 16
+                double *ya = Y + (size_t)i * D;
+                double a4[64];
+                for (int r = 0; r < 4; ++r) memcpy(a4 + 16 * r, L + (size_t)(i + r) * D + k0, sizeof(double) * 16);
+                DPMMH_RANK16_4ROWS(ya, ya + D, ya + 2 * (size_t)D, ya + 3 * (size_t)D, a4, X, D, len)
+            }
             for (; i + 1 < i1; i += 2) {
                 double *ya = Y + (size_t)i * D, *yb = ya + D;
                 const double *a = L + (size_t)i * D + k0, *b = a + D;

@@ -45,7 +45,7 @@ inline double now_s() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t
 struct NiwPrior {
     bool set = false;
     double kappa = 0, nu = 0, logdet_psi = 0;
-    std::vector<double> m, psi;
+    std::vector<double> m, psi, psi_lo;   // psi_lo: symmetrised, packed lower triangle (hostmath.h)
 };
 struct MultPrior {
     bool set = false;
@@ -218,16 +218,17 @@ struct dpmmh_model {
 
     // ---------------------------------------------------------------- posterior of one row (calc_posterior + factorisation + marginal)
     // src rows: the statistic set is sum_i coef[i] * rows[i] (packed rows).  Scratch P: D*D doubles.
-    void niw_row(int s, int w, const double *l, const double *r, double *P) {
+    void niw_row(int s, int w, const double *l, const double *r) {
         const NiwPrior &pr = niw_of(s);
         const int row = 3 * s + w;
         const double cl = (w != 2) ? 1.0 : 0.0, cr = (w != 1) ? 1.0 : 0.0;
         const size_t DD = (size_t)D * D;
-        const double N = dpmmh::niw_posterior_packed(D, pr.kappa, pr.nu, pr.m.data(), pr.psi.data(), l, r, cl, cr, &kappa[row], &nu[row],
+        double *P = U.data() + (size_t)row * DD;               // the scale matrix is built and factorised where the factor lives
+        const double N = dpmmh::niw_posterior_packed(D, pr.kappa, pr.nu, pr.m.data(), pr.psi_lo.data(), l, r, cl, cr, &kappa[row], &nu[row],
                                                      mean.data() + (size_t)row * D, P);
         Nrow[row] = N;
-        double *Uo = U.data() + (size_t)row * DD;
-        const double ld = dpmmh::chol_ltl(P, D, Uo);           // nu' psi' = L' L (L = U', stored row-major lower); NaN when not positive definite
+        const double ld = dpmmh::chol_ltl(P, D, nullptr);      // nu' psi' = L' L in place (L = U', row-major lower; entries above the diagonal
+                                                               // are scratch, nobody reads them); NaN when not positive definite
         ldpsi[row] = ld - D * log(nu[row]);
         L[row] = niw_marginal(pr, kappa[row], nu[row], ldpsi[row], N);
     }
@@ -253,16 +254,13 @@ struct dpmmh_model {
     // statistics of clusters `ks` (cluster order) arrive as packed rows src[2k], src[2k+1]: store + posteriors
     void ingest(const double *src, const std::vector<int> &ks) {
         const int n = (int)ks.size();
-        std::vector<std::vector<double>> scratch(std::max(1, nthreads));
-        Pool::get().run(3 * n, nthreads, [&](int item, int th) {
+        Pool::get().run(3 * n, nthreads, [&](int item, int) {
             const int k = ks[item / 3], w = item % 3, s = slot[k];
             const double *l = src + (size_t)(2 * k) * stride, *r = l + stride;
             if (w == 1) memcpy(prow(s, 0), l, sizeof(double) * stride);
             if (w == 2) memcpy(prow(s, 1), r, sizeof(double) * stride);
             if (kind == DPMMH_PRIOR_NIW) {
-                auto &sc = scratch[th];
-                if (sc.size() < (size_t)D * D) sc.resize((size_t)D * D);
-                niw_row(s, w, l, r, sc.data());
+                niw_row(s, w, l, r);
             } else {
                 mult_row(s, w, l, r);
             }
@@ -276,10 +274,9 @@ struct dpmmh_model {
     void refresh_slot(int s, std::vector<double> &sc) {
         for (int w = 0; w < 3; ++w) refresh_row(s, w, sc);
     }
-    void refresh_row(int s, int w, std::vector<double> &sc) {
+    void refresh_row(int s, int w, std::vector<double> &) {
         if (kind == DPMMH_PRIOR_NIW) {
-            if (sc.size() < (size_t)D * D) sc.resize((size_t)D * D);
-            niw_row(s, w, prow(s, 0), prow(s, 1), sc.data());
+            niw_row(s, w, prow(s, 0), prow(s, 1));
         } else {
             mult_row(s, w, prow(s, 0), prow(s, 1));
         }
@@ -341,7 +338,8 @@ struct dpmmh_model {
                 const bool pre = have_noise && id < noise_rows;
                 dpmmh::niw_draw_one(D, kappa[row], nu[row], mean.data() + (size_t)row * D, U.data() + (size_t)row * DD, seed, (uint32_t)id,
                                     draw_epoch, pre ? noise_A.data() + (size_t)id * DD : nullptr, pre ? noise_xi.data() + (size_t)id * D : nullptr,
-                                    sc.data(), st_mu + (size_t)row * D, st_mat + (size_t)row * T, &st_logdet[row], true);
+                                    sc.data(), st_mu + (size_t)row * D, st_mat + (size_t)row * T, &st_logdet[row], true,
+                                    pre ? noise_A.data() + (size_t)id * DD : nullptr);       // solved in place: the helper refills it next step
             } else {
                 auto &sc = scratch[th];
                 if (sc.empty()) sc.resize(D);
@@ -500,13 +498,17 @@ struct dpmmh_model {
             if (N == 0.0) return niw_marginal(pr, pr.kappa, pr.nu, pr.logdet_psi, 0.0);
             const double k0 = pr.kappa, v0 = pr.nu, k1 = k0 + N, v1 = v0 + N;
             for (int a = 0; a < D; ++a) mm[a] = (pr.m[a] * k0 + (rows[0][1 + a] + rows[1][1 + a] + rows[2][1 + a] + rows[3][1 + a])) / k1;
+            const double *m0 = pr.m.data();
             for (int a = 0; a < D; ++a) {
                 const size_t t0 = 1 + (size_t)D + (size_t)a * (a + 1) / 2;
+                const double *r0 = rows[0] + t0, *r1 = rows[1] + t0, *r2 = rows[2] + t0, *r3 = rows[3] + t0;
+                const double *pa = pr.psi_lo.data() + (size_t)a * (a + 1) / 2;
+                double *Pa = P + (size_t)a * D;
+                const double km0a = k0 * m0[a], kma = k1 * mm[a];
+#pragma omp simd
                 for (int b = 0; b <= a; ++b) {
-                    const double sab = rows[0][t0 + b] + rows[1][t0 + b] + rows[2][t0 + b] + rows[3][t0 + b];
-                    const double pab = 0.5 * (pr.psi[(size_t)a * D + b] + pr.psi[(size_t)b * D + a]);
-                    const double v = ((v0 * pab + k0 * pr.m[a] * pr.m[b] - k1 * mm[a] * mm[b] + sab) / v1) * v1;
-                    P[(size_t)a * D + b] = v;               // lower triangle
+                    const double sab = r0[b] + r1[b] + r2[b] + r3[b];
+                    Pa[b] = ((v0 * pa[b] + km0a * m0[b] - kma * mm[b] + sab) / v1) * v1;       // lower triangle
                 }
             }
             const double ld = dpmmh::logdet_spd_inplace(P, D) - D * log(v1);
@@ -676,6 +678,8 @@ HAPI int dpmmh_model_set_prior_niw(dpmmh_model *m, int which, double kappa, cons
     const int D = m->D;
     p.kappa = (double)(float)kappa; p.nu = (double)(float)nu;          // Float32 in the reference (niw.jl:6-11)
     p.m.assign(mean, mean + D); p.psi.assign(psi, psi + (size_t)D * D);
+    p.psi_lo.resize((size_t)D * (D + 1) / 2);
+    dpmmh::pack_sym_lower(D, psi, p.psi_lo.data());
     std::vector<double> tmp(p.psi);
     p.logdet_psi = dpmmh::logdet_spd_inplace(tmp.data(), D);
     p.set = true;
@@ -869,7 +873,7 @@ HAPI int64_t dpmmh_model_get(dpmmh_model *m, const char *field, void *out, int64
             std::vector<double> v = rows_d(m->U, DD), t(DD);
             for (size_t r3 = 0; r3 < (size_t)3 * K; ++r3) {
                 double *Mx = v.data() + r3 * DD;
-                for (int a = 0; a < D; ++a) for (int b = 0; b < D; ++b) t[(size_t)a * D + b] = Mx[(size_t)b * D + a];
+                for (int a = 0; a < D; ++a) for (int b = 0; b < D; ++b) t[(size_t)a * D + b] = b >= a ? Mx[(size_t)b * D + a] : 0.0;
                 memcpy(Mx, t.data(), sizeof(double) * DD);
             }
             return emit(out, cap, v);

@@ -66,15 +66,21 @@ inline void niw_posterior_one(int D, double k0, double v0, const double *m0, con
 
 // Same posterior, from PACKED statistics rows {N, sum[D], lower triangle of S} (include/dpmm_hip.h): the statistic set is
 // cl * (row l) + cr * (row r) (cluster = left + right: cl = cr = 1).  Writes kappa, nu, m and the lower triangle of the SCALE
-// matrix P = nu' psi' that the factorisation consumes -- the full S is never materialised.
-inline double niw_posterior_packed(int D, double k0, double v0, const double *m0, const double *psi0, const double *l,
+// matrix P = nu' psi' that the factorisation consumes -- the full S is never materialised.  psi_lo: the prior's psi, symmetrised
+// (0.5 (psi + psi')) and packed like the statistics (row a: columns 0..a at offset a (a+1)/2), so that every stream of the inner
+// loop is contiguous (a column walk over the full psi cost more than the factorisation at D = 256).
+inline void pack_sym_lower(int D, const double *psi, double *psi_lo) {
+    for (int a = 0; a < D; ++a)
+        for (int b = 0; b <= a; ++b) psi_lo[(size_t)a * (a + 1) / 2 + b] = 0.5 * (psi[(size_t)a * D + b] + psi[(size_t)b * D + a]);
+}
+inline double niw_posterior_packed(int D, double k0, double v0, const double *m0, const double *psi_lo, const double *l,
                                    const double *r, double cl, double cr, double *kap, double *nu, double *m, double *P) {
     const double N = cl * l[0] + cr * r[0];
     if (N == 0.0) {
         *kap = k0; *nu = v0;
         memcpy(m, m0, sizeof(double) * D);
         for (int a = 0; a < D; ++a)
-            for (int b = 0; b <= a; ++b) P[(size_t)a * D + b] = 0.5 * (psi0[(size_t)a * D + b] + psi0[(size_t)b * D + a]) * v0;
+            for (int b = 0; b <= a; ++b) P[(size_t)a * D + b] = psi_lo[(size_t)a * (a + 1) / 2 + b] * v0;
         return N;
     }
     const double k1 = k0 + N, v1 = v0 + N;
@@ -83,11 +89,13 @@ inline double niw_posterior_packed(int D, double k0, double v0, const double *m0
     for (int a = 0; a < D; ++a) m[a] = (m0[a] * k0 + (cl * sl[a] + cr * sr[a])) / k1;
     for (int a = 0; a < D; ++a) {
         const size_t t0 = (size_t)a * (a + 1) / 2;
+        const double *ta = tl + t0, *tb = tr + t0, *pa = psi_lo + t0;
+        double *Pa = P + (size_t)a * D;
+        const double km0a = k0 * m0[a], kma = k1 * m[a];
+#pragma omp simd
         for (int b = 0; b <= a; ++b) {
-            const double sab = cl * tl[t0 + b] + cr * tr[t0 + b];
-            const double pab = 0.5 * (psi0[(size_t)a * D + b] + psi0[(size_t)b * D + a]);
-            const double v = ((v0 * pab + k0 * m0[a] * m0[b] - k1 * m[a] * m[b] + sab) / v1) * v1;   // psi' then nu' psi' (niw.jl:29,35)
-            P[(size_t)a * D + b] = v;                        // b <= a: the LOWER triangle is what the factorisation reads
+            const double sab = cl * ta[b] + cr * tb[b];
+            Pa[b] = ((v0 * pa[b] + km0a * m0[b] - kma * m[b] + sab) / v1) * v1;   // psi' then nu' psi' (niw.jl:29,35); LOWER triangle
         }
     }
     return N;
@@ -120,17 +128,21 @@ inline double niw_log_marginal(int D, double k0, double v0, double logdet_psi0, 
 // triangle [D(D+1)/2] of the worker's parameter staging (row r: columns r..D-1 at offset r D - r (r-1)/2).
 inline void niw_draw_one(int D, double kappa, double nu, const double *m, const double *Li, uint64_t seed, uint32_t id,
                          uint32_t epoch, const double *An, const double *xi_in, double *scratch, float *mu_out, float *R_out,
-                         float *logdet_sigma, bool r_packed = false) {
+                         float *logdet_sigma, bool r_packed = false, double *An_inplace = nullptr) {
     const size_t DD = (size_t)D * D;
-    double *Y = scratch, *xi = scratch + DD, *v = scratch + DD + D;
+    // An_inplace: a pre-generated noise block the caller gives up -- strictly-lower normals, ZEROS above the diagonal (the solve keeps
+    // them zero): the system is solved where the noise lies, no copy of the D x D block
+    double *Y = An_inplace ? An_inplace : scratch, *xi = scratch + DD, *v = scratch + DD + D;
     Philox rng(seed, id, epoch, 16u), rng_chi(seed, id, epoch, 18u);
     // Bartlett factor A, lower triangular (chi on the diagonal, standard normals below): the right-hand side of  L Y = A
     for (int r = 0; r < D; ++r) {
         double *yr = Y + (size_t)r * D;
-        if (An) memcpy(yr, An + (size_t)r * D, sizeof(double) * r);
-        else for (int c = 0; c < r; ++c) yr[c] = rng.normal();
+        if (!An_inplace) {
+            if (An) memcpy(yr, An + (size_t)r * D, sizeof(double) * r);
+            else for (int c = 0; c < r; ++c) yr[c] = rng.normal();
+            memset(yr + r + 1, 0, sizeof(double) * (D - 1 - r));
+        }
         yr[r] = sqrt(2.0 * rng_chi.gamma(0.5 * (nu - r)));
-        memset(yr + r + 1, 0, sizeof(double) * (D - 1 - r));
     }
     solve_lower_left(Y, Li, D);            // Y = L^-1 A;  R = Y' = A' U^-1 (upper)
     double ld = 0.0;
