@@ -376,26 +376,17 @@ __global__ __launch_bounds__(64 * StatCfg<NBK>::NPANEL) void niw_stats_kernel(St
     }
 }
 
-// packed row: [0] N, [1..D] sum, [1+D + a(a+1)/2 + b] S[a][b] (a >= b)
-// block = 64 row elements x REDUCE_PARTS parts: a bin's segment heads (one slab each, <= range_groups + 1 of them, many more for a
-// large cluster than for a small one) are cut into REDUCE_PARTS contiguous runs summed by different threads, eight loads in flight
-// each, and the partial sums are combined in part order -- a fixed summation tree, so the rows stay bitwise reproducible.
-constexpr int REDUCE_PARTS = 4;
-__global__ __launch_bounds__(64 * REDUCE_PARTS) void niw_reduce_kernel(StatsArgs A, int NBK) {
-    __shared__ double part_sum[REDUCE_PARTS][64];
-    const int b = blockIdx.y;
-    const int el = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int64_t e = blockIdx.x * 64ll + el;
-    const bool live = e < A.packed_stride;
-    double *out = A.out + (int64_t)b * A.packed_stride;
-    if (!A.sb.bin_sel[b]) { if (live && part == 0) out[e] = 0.; return; }
+// position of packed-row element e (>= 1) inside a statistics slab (MFMA fragment order), computed once per context
+__global__ void niw_row_offsets_kernel(int32_t *__restrict__ row_off, int D, int NBK, int64_t packed_stride) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= packed_stride) return;
     const int NPAIR = NBK * (NBK + 1) / 2;
     int64_t off = 0;
-    if (live && e >= 1) {
-        if (e <= A.D) {
+    if (e >= 1) {
+        if (e <= D) {
             off = (int64_t)NPAIR * 256 + (e - 1);
         } else {
-            const int64_t te = e - 1 - A.D;
+            const int64_t te = e - 1 - D;
             int a = (int)((sqrt(8.0 * (double)te + 1.0) - 1.0) * 0.5);
             while ((int64_t)(a + 1) * (a + 2) / 2 <= te) ++a;
             while ((int64_t)a * (a + 1) / 2 > te) --a;
@@ -410,6 +401,28 @@ __global__ __launch_bounds__(64 * REDUCE_PARTS) void niw_reduce_kernel(StatsArgs
             off = (int64_t)pair * 256 + r * 64 + lane;
         }
     }
+    row_off[e] = (int32_t)off;
+}
+hipError_t launch_niw_row_offsets(int32_t *row_off, int D, int64_t packed_stride, hipStream_t s) {
+    const int NBK = D <= 16 ? 1 : D <= 32 ? 2 : D <= 64 ? 4 : D <= 128 ? 8 : 16;
+    hipLaunchKernelGGL(niw_row_offsets_kernel, dim3((unsigned)((packed_stride + 255) / 256)), dim3(256), 0, s, row_off, D, NBK, packed_stride);
+    return hipGetLastError();
+}
+
+// packed row: [0] N, [1..D] sum, [1+D + a(a+1)/2 + b] S[a][b] (a >= b)
+// block = 64 row elements x REDUCE_PARTS parts: a bin's segment heads (one slab each, <= range_groups + 1 of them, many more for a
+// large cluster than for a small one) are cut into REDUCE_PARTS contiguous runs summed by different threads, eight loads in flight
+// each, and the partial sums are combined in part order -- a fixed summation tree, so the rows stay bitwise reproducible.
+constexpr int REDUCE_PARTS = 4;
+__global__ __launch_bounds__(64 * REDUCE_PARTS) void niw_reduce_kernel(StatsArgs A, int NBK) {
+    __shared__ double part_sum[REDUCE_PARTS][64];
+    const int b = blockIdx.y;
+    const int el = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int64_t e = blockIdx.x * 64ll + el;
+    const bool live = e < A.packed_stride;
+    double *out = A.out + (int64_t)b * A.packed_stride;
+    if (!A.sb.bin_sel[b]) { if (live && part == 0) out[e] = 0.; return; }
+    const int64_t off = (live && e >= 1) ? (int64_t)A.row_off[e] : 0;      // packed-row element -> position inside a slab (table, built once)
     const int i0 = A.sb.item_start[b], i1 = A.sb.item_start[b + 1];
     const int total_items = A.sb.item_start[A.nbins];
     const int q = (total_items + A.range_groups - 1) / A.range_groups;      // as in niw_stats_kernel
