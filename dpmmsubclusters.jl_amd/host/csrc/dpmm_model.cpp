@@ -298,19 +298,20 @@ struct dpmmh_model {
         wait_noise();
         const bool niw_noise = kind == DPMMH_PRIOR_NIW;
         const double pre_at = (prewake && nthreads > 1 && t_launch > 0.0 && wait_ema > 0.0) ? t_launch + wait_ema - kPrewakeLead : 0.0;
-        if (!niw_noise && pre_at == 0.0) return;
         const int rows = 3 * (K + 4);   // head-room for clusters born from splits
         const size_t DD = (size_t)D * D;
         if (niw_noise) {
             if (noise_A.size() < (size_t)rows * DD) { noise_A.resize((size_t)rows * DD); noise_xi.resize((size_t)rows * D); }
-            noise_epoch = draw_epoch + 1; noise_rows = rows;
+        } else {
+            if (noise_A.size() < (size_t)rows * D) { noise_A.resize((size_t)rows * D); noise_xi.resize((size_t)rows * D); }   // first-trial normals / uniforms
         }
+        noise_epoch = draw_epoch + 1; noise_rows = rows;
         const int nt = nthreads;
         helper.submit([this, rows, DD, nt, niw_noise, pre_at] {
-            if (niw_noise)
-                Pool::get().run(rows, nt, [&](int i, int) {
-                    dpmmh::niw_noise_one(D, seed, (uint32_t)i, noise_epoch, noise_A.data() + (size_t)i * DD, noise_xi.data() + (size_t)i * D);
-                });
+            Pool::get().run(rows, nt, [&](int i, int) {
+                if (niw_noise) dpmmh::niw_noise_one(D, seed, (uint32_t)i, noise_epoch, noise_A.data() + (size_t)i * DD, noise_xi.data() + (size_t)i * D);
+                else dpmmh::dirichlet_noise_one(D, seed, (uint32_t)i, noise_epoch, noise_A.data() + (size_t)i * D, noise_xi.data() + (size_t)i * D);
+            });
             if (pre_at > 0.0 && helper.sleep_until(pre_at)) Pool::get().prewake();
         });
         noise_pending = true;
@@ -327,7 +328,7 @@ struct dpmmh_model {
         wait_noise();
         timers[T_NOISE_WAIT] += now_s() - t0; t0 = now_s();
         draw_epoch += 1;
-        const bool have_noise = kind == DPMMH_PRIOR_NIW && noise_epoch == draw_epoch;
+        const bool have_noise = noise_epoch == draw_epoch && noise_rows > 0;
         const size_t DD = (size_t)D * D;
         std::vector<std::vector<double>> scratch(std::max(1, nthreads));
         Pool::get().run(3 * K, nthreads, [&](int id, int th) {
@@ -343,7 +344,9 @@ struct dpmmh_model {
             } else {
                 auto &sc = scratch[th];
                 if (sc.empty()) sc.resize(D);
-                dpmmh::dirichlet_log_one(D, apost.data() + (size_t)row * D, seed, (uint32_t)id, draw_epoch, sc.data(), st_mat + (size_t)row * D);
+                const bool pre = have_noise && id < noise_rows;
+                dpmmh::dirichlet_log_one(D, apost.data() + (size_t)row * D, seed, (uint32_t)id, draw_epoch, sc.data(), st_mat + (size_t)row * D,
+                                         pre ? noise_A.data() + (size_t)id * D : nullptr, pre ? noise_xi.data() + (size_t)id * D : nullptr);
             }
         });
         timers[T_SAMPLE] += now_s() - t0; t0 = now_s();

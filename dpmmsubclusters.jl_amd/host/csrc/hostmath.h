@@ -183,14 +183,36 @@ inline void niw_noise_one(int D, uint64_t seed, uint32_t id, uint32_t epoch, dou
 
 // log of a Dirichlet(alpha) draw (priors/multinomial_prior.jl:23-25): logp[d] = log(g_d / sum g), g_d ~ Gamma(alpha_d).
 // Works with log-gammas so that tiny shapes do not underflow: log g = log Gamma(a+1) draw + log(u)/a.   lg: D doubles.
-inline void dirichlet_log_one(int D, const float *al, uint64_t seed, uint32_t id, uint32_t epoch, double *lg, float *logp) {
-    Philox rng(seed, id, epoch, 17u);
+// Randomness: stream 19 supplies ONE (normal, uniform) pair per component -- the first Marsaglia-Tsang trial, which is accepted
+// ~98 % of the time; it does not depend on the shapes, so dirichlet_noise_one can produce it ahead of time (px / pu, while the GPU
+// sweeps) and the draw is identical whether it was pre-generated or not.  Retries and the extra uniform of shapes < 1: stream 17.
+inline void dirichlet_noise_one(int D, uint64_t seed, uint32_t id, uint32_t epoch, double *px, double *pu) {
+    Philox rng(seed, id, epoch, 19u);
+    for (int d = 0; d < D; ++d) { px[d] = rng.normal(); pu[d] = rng.uniform(); }
+}
+inline double gamma_first_trial(double a, double x, double u, Philox &retry) {      // shape a >= 1
+    const double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    for (;;) {
+        double v = 1.0 + c * x;
+        if (v > 0.0) {
+            v = v * v * v;
+            if (u < 1.0 - 0.0331 * x * x * x * x) return d * v;
+            if (log(u) < 0.5 * x * x + d * (1.0 - v + log(v))) return d * v;
+        }
+        x = retry.normal(); u = retry.uniform();
+    }
+}
+inline void dirichlet_log_one(int D, const float *al, uint64_t seed, uint32_t id, uint32_t epoch, double *lg, float *logp,
+                              const double *px = nullptr, const double *pu = nullptr) {
+    Philox first(seed, id, epoch, 19u), rng(seed, id, epoch, 17u);
     double mx = -INFINITY;
     for (int d = 0; d < D; ++d) {
         const double a = (double)al[d];
+        const double x = px ? px[d] : first.normal();
+        const double u = pu ? pu[d] : first.uniform();
         double l;
-        if (a < 1.0) l = log(rng.gamma(a + 1.0)) + log(rng.uniform()) / a;
-        else l = log(rng.gamma(a));
+        if (a < 1.0) l = log(gamma_first_trial(a + 1.0, x, u, rng)) + log(rng.uniform()) / a;
+        else l = log(gamma_first_trial(a, x, u, rng));
         lg[d] = l;
         if (l > mx) mx = l;
     }
@@ -200,13 +222,36 @@ inline void dirichlet_log_one(int D, const float *al, uint64_t seed, uint32_t id
     for (int d = 0; d < D; ++d) logp[d] = (float)(lg[d] - lse);
 }
 
+// lgamma at small positive INTEGERS from a table of libm's own values (built once, identical bits): count data with an integer
+// Dirichlet prior evaluates lgamma only there, 2 D times per distribution and per merge pair -- the table turns the master's
+// Multinomial log-marginals from libm-bound into L1-bound.  Anything else goes to lgamma_r.
+class LgammaTable {
+  public:
+    static constexpr int kSize = 1 << 16;
+    static const LgammaTable &get() { static LgammaTable t; return t; }
+    inline double operator()(float a) const {
+        const int i = (int)a;
+        if ((float)i == a && i >= 1 && i < kSize) return tab_[i];
+        int sg;
+        return lgamma_r((double)a, &sg);
+    }
+  private:
+    LgammaTable() : tab_(kSize) {
+        int sg;
+        tab_[0] = INFINITY;
+        for (int i = 1; i < kSize; ++i) tab_[i] = lgamma_r((double)i, &sg);
+    }
+    std::vector<double> tab_;
+};
+
 // priors/multinomial_prior.jl:34-39 in Float64: lgamma(sum a0) - lgamma(sum a1) + sum (lgamma(a1_d) - lgamma(a0_d)).
 inline double mult_log_marginal(int D, const float *a0, const float *a1) {
     int sg;
+    const LgammaTable &lg = LgammaTable::get();
     double s0 = 0.0, s1 = 0.0, acc = 0.0;
     for (int d = 0; d < D; ++d) {
         s0 += (double)a0[d]; s1 += (double)a1[d];
-        acc += lgamma_r((double)a1[d], &sg) - lgamma_r((double)a0[d], &sg);
+        acc += lg(a1[d]) - lg(a0[d]);
     }
     return lgamma_r(s0, &sg) - lgamma_r(s1, &sg) + acc;
 }

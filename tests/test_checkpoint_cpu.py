@@ -101,3 +101,20 @@ def test_advanced_mode_and_run_model_from_checkpoint(host, tmp_path):
     assert len(it2) == 5
     assert np.array_equal(res.labels, full.labels) and res.sampler.K == full.sampler.K
     assert np.allclose(res.sampler.N, full.sampler.N)
+
+
+def test_multinomial_resume_continues_same_chain(host, tmp_path):
+    # the Dirichlet draws use pre-generated first-trial noise in a running chain and generate the same stream inline in the first
+    # sweep after a resume: both must give the same parameters, hence the same labels
+    from fake_worker import FakeWorker
+    rng = np.random.default_rng(3)
+    P = rng.dirichlet(np.ones(12) * 0.3, size=3)
+    y = rng.integers(0, 3, 500)
+    x = np.stack([rng.multinomial(40, P[k]) for k in y]).T.astype(np.float32)      # D x N
+    hyper = host.multinomial_hyper(np.ones(12, np.float32))
+    kw = dict(seed=5, burnout=3, verbose=False, worker_factory=FakeWorker, nthreads=2)
+    full, *_ = host.dp_parallel(x, hyper, 10.0, 9, 1, save_model=True, save_path=str(tmp_path) + "/", model_save_interval=4, **kw)
+    res, it, *_ = host.resume_from_checkpoint(full.checkpoints[0], x, 9, verbose=False, worker_factory=FakeWorker, nthreads=2)
+    assert len(it) == 5
+    assert np.array_equal(res.labels, full.labels) and np.array_equal(res.labels_subcluster, full.labels_subcluster)
+    assert res.sampler.K == full.sampler.K and np.array_equal(res.sampler.weights, full.sampler.weights)
