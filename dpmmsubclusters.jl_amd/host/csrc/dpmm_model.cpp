@@ -159,7 +159,7 @@ struct dpmmh_model {
     bool noise_pending = false;
     uint32_t noise_epoch = 0;
     int noise_rows = 0;
-    std::vector<double> noise_A, noise_xi;
+    std::vector<double> noise_A, noise_xi, noise_cx, noise_cu;   // NIW: Bartlett normals, mean normals, chi first trials; Multinomial: first-trial normals / uniforms
 
     double timers[16] = {0};
     std::string err;
@@ -301,7 +301,10 @@ struct dpmmh_model {
         const int rows = 3 * (K + 4);   // head-room for clusters born from splits
         const size_t DD = (size_t)D * D;
         if (niw_noise) {
-            if (noise_A.size() < (size_t)rows * DD) { noise_A.resize((size_t)rows * DD); noise_xi.resize((size_t)rows * D); }
+            if (noise_A.size() < (size_t)rows * DD) {
+                noise_A.resize((size_t)rows * DD); noise_xi.resize((size_t)rows * D);
+                noise_cx.resize((size_t)rows * D); noise_cu.resize((size_t)rows * D);
+            }
         } else {
             if (noise_A.size() < (size_t)rows * D) { noise_A.resize((size_t)rows * D); noise_xi.resize((size_t)rows * D); }   // first-trial normals / uniforms
         }
@@ -309,7 +312,8 @@ struct dpmmh_model {
         const int nt = nthreads;
         helper.submit([this, rows, DD, nt, niw_noise, pre_at] {
             Pool::get().run(rows, nt, [&](int i, int) {
-                if (niw_noise) dpmmh::niw_noise_one(D, seed, (uint32_t)i, noise_epoch, noise_A.data() + (size_t)i * DD, noise_xi.data() + (size_t)i * D);
+                if (niw_noise) dpmmh::niw_noise_one(D, seed, (uint32_t)i, noise_epoch, noise_A.data() + (size_t)i * DD, noise_xi.data() + (size_t)i * D,
+                                                    noise_cx.data() + (size_t)i * D, noise_cu.data() + (size_t)i * D);
                 else dpmmh::dirichlet_noise_one(D, seed, (uint32_t)i, noise_epoch, noise_A.data() + (size_t)i * D, noise_xi.data() + (size_t)i * D);
             });
             if (pre_at > 0.0 && helper.sleep_until(pre_at)) Pool::get().prewake();
@@ -340,7 +344,8 @@ struct dpmmh_model {
                 dpmmh::niw_draw_one(D, kappa[row], nu[row], mean.data() + (size_t)row * D, U.data() + (size_t)row * DD, seed, (uint32_t)id,
                                     draw_epoch, pre ? noise_A.data() + (size_t)id * DD : nullptr, pre ? noise_xi.data() + (size_t)id * D : nullptr,
                                     sc.data(), st_mu + (size_t)row * D, st_mat + (size_t)row * T, &st_logdet[row], true,
-                                    pre ? noise_A.data() + (size_t)id * DD : nullptr);       // solved in place: the helper refills it next step
+                                    pre ? noise_A.data() + (size_t)id * DD : nullptr,        // solved in place: the helper refills it next step
+                                    pre ? noise_cx.data() + (size_t)id * D : nullptr, pre ? noise_cu.data() + (size_t)id * D : nullptr);
             } else {
                 auto &sc = scratch[th];
                 if (sc.empty()) sc.resize(D);

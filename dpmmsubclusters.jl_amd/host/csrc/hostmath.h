@@ -121,6 +121,21 @@ inline double niw_log_marginal(int D, double k0, double v0, double logdet_psi0, 
            (v0 / 2.0) * (D * log(v0) + logdet_psi0) - (v1 / 2.0) * (D * log(v1) + logdet_psi1) + (D / 2.0) * log(k0 / k1);
 }
 
+// Marsaglia-Tsang Gamma(a, 1), a >= 1, with the FIRST trial's (normal, uniform) pair supplied by the caller (it does not depend on the
+// shape, so it can be generated ahead of time); later trials (~2 % of the draws) come from `retry`.
+inline double gamma_first_trial(double a, double x, double u, Philox &retry) {      // shape a >= 1
+    const double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    for (;;) {
+        double v = 1.0 + c * x;
+        if (v > 0.0) {
+            v = v * v * v;
+            if (u < 1.0 - 0.0331 * x * x * x * x) return d * v;
+            if (log(u) < 0.5 * x * x + d * (1.0 - v + log(v))) return d * v;
+        }
+        x = retry.normal(); u = retry.uniform();
+    }
+}
+
 // One draw (mu, R, logdet Sigma) from a prepared posterior (kappa, nu, m, L with nu psi = L' L, L lower triangular = U').
 // `id`/`epoch` key the random streams (normals: stream 16 -- identical whether pre-generated or not; chi-squares: stream 18).
 // An / xi_in: optional pre-generated standard normals (strictly-lower Bartlett entries row-major [D][D], and xi [D]).
@@ -128,12 +143,14 @@ inline double niw_log_marginal(int D, double k0, double v0, double logdet_psi0, 
 // triangle [D(D+1)/2] of the worker's parameter staging (row r: columns r..D-1 at offset r D - r (r-1)/2).
 inline void niw_draw_one(int D, double kappa, double nu, const double *m, const double *Li, uint64_t seed, uint32_t id,
                          uint32_t epoch, const double *An, const double *xi_in, double *scratch, float *mu_out, float *R_out,
-                         float *logdet_sigma, bool r_packed = false, double *An_inplace = nullptr) {
+                         float *logdet_sigma, bool r_packed = false, double *An_inplace = nullptr, const double *chi_x = nullptr,
+                         const double *chi_u = nullptr) {
     const size_t DD = (size_t)D * D;
     // An_inplace: a pre-generated noise block the caller gives up -- strictly-lower normals, ZEROS above the diagonal (the solve keeps
     // them zero): the system is solved where the noise lies, no copy of the D x D block
     double *Y = An_inplace ? An_inplace : scratch, *xi = scratch + DD, *v = scratch + DD + D;
-    Philox rng(seed, id, epoch, 16u), rng_chi(seed, id, epoch, 18u);
+    // chi-squares: stream 18 holds the first-trial pairs (chi_x / chi_u when pre-generated, the same values inline otherwise), 24 the rest
+    Philox rng(seed, id, epoch, 16u), chi_first(seed, id, epoch, 18u), chi_retry(seed, id, epoch, 24u);
     // Bartlett factor A, lower triangular (chi on the diagonal, standard normals below): the right-hand side of  L Y = A
     for (int r = 0; r < D; ++r) {
         double *yr = Y + (size_t)r * D;
@@ -142,7 +159,14 @@ inline void niw_draw_one(int D, double kappa, double nu, const double *m, const 
             else for (int c = 0; c < r; ++c) yr[c] = rng.normal();
             memset(yr + r + 1, 0, sizeof(double) * (D - 1 - r));
         }
-        yr[r] = sqrt(2.0 * rng_chi.gamma(0.5 * (nu - r)));
+        {
+            const double a = 0.5 * (nu - r);
+            const double x = chi_x ? chi_x[r] : chi_first.normal();
+            const double u = chi_u ? chi_u[r] : chi_first.uniform();
+            const double g = a >= 1.0 ? gamma_first_trial(a, x, u, chi_retry)
+                                      : gamma_first_trial(a + 1.0, x, u, chi_retry) * pow(chi_retry.uniform(), 1.0 / a);
+            yr[r] = sqrt(2.0 * g);
+        }
     }
     solve_lower_left(Y, Li, D);            // Y = L^-1 A;  R = Y' = A' U^-1 (upper)
     double ld = 0.0;
@@ -174,11 +198,15 @@ inline void niw_draw_one(int D, double kappa, double nu, const double *m, const 
 inline size_t niw_draw_scratch_doubles(int D) { return (size_t)D * D + 2 * (size_t)D; }
 
 // Standard-normal noise of one draw (see niw_draw_one): depends on (seed, epoch, id) only.
-inline void niw_noise_one(int D, uint64_t seed, uint32_t id, uint32_t epoch, double *A, double *xi) {
+inline void niw_noise_one(int D, uint64_t seed, uint32_t id, uint32_t epoch, double *A, double *xi, double *chi_x = nullptr, double *chi_u = nullptr) {
     Philox rng(seed, id, epoch, 16u);
     for (int r = 0; r < D; ++r)
         for (int c = 0; c < r; ++c) A[(size_t)r * D + c] = rng.normal();
     for (int d = 0; d < D; ++d) xi[d] = rng.normal();
+    if (chi_x && chi_u) {
+        Philox first(seed, id, epoch, 18u);
+        for (int r = 0; r < D; ++r) { chi_x[r] = first.normal(); chi_u[r] = first.uniform(); }
+    }
 }
 
 // log of a Dirichlet(alpha) draw (priors/multinomial_prior.jl:23-25): logp[d] = log(g_d / sum g), g_d ~ Gamma(alpha_d).
@@ -189,18 +217,6 @@ inline void niw_noise_one(int D, uint64_t seed, uint32_t id, uint32_t epoch, dou
 inline void dirichlet_noise_one(int D, uint64_t seed, uint32_t id, uint32_t epoch, double *px, double *pu) {
     Philox rng(seed, id, epoch, 19u);
     for (int d = 0; d < D; ++d) { px[d] = rng.normal(); pu[d] = rng.uniform(); }
-}
-inline double gamma_first_trial(double a, double x, double u, Philox &retry) {      // shape a >= 1
-    const double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
-    for (;;) {
-        double v = 1.0 + c * x;
-        if (v > 0.0) {
-            v = v * v * v;
-            if (u < 1.0 - 0.0331 * x * x * x * x) return d * v;
-            if (log(u) < 0.5 * x * x + d * (1.0 - v + log(v))) return d * v;
-        }
-        x = retry.normal(); u = retry.uniform();
-    }
 }
 inline void dirichlet_log_one(int D, const float *al, uint64_t seed, uint32_t id, uint32_t epoch, double *lg, float *logp,
                               const double *px = nullptr, const double *pu = nullptr) {
