@@ -40,7 +40,7 @@ struct dpmm_ctx {
     int tile = 0;        // points per sweep workgroup tile
     int64_t ntiles = 0;
     int cus = 256;
-    int sweep_grid = 0;
+    int sweep_grid = 0, sweep_grid_max = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool have_sweep_ev = false, have_stats_ev = false;
@@ -102,7 +102,7 @@ struct dpmm_ctx {
     bool work_zeroed = false;          // the pack kernel cleared d_work and no sweep has run since
     int sel_all_ones = 0, sel_capacity = 0;   // sb.bin_sel[0..sel_all_ones) are known to be 1 (full passes skip the memset)
     long long *d_counts64 = nullptr;   // [2 * DPMM_MAX_CLUSTERS] global sub-cluster occupancies (multi-GPU)
-    unsigned long long *d_work = nullptr;   // [4] executed-work counters of the last sweep
+    unsigned long long *d_work = nullptr;   // [8] executed-work counters of the last sweep [0..3] + its tile queue head [4]
     // options (dpmm_set_option)
     float opt_margin = 50.f;
     int opt_prio = 1;
@@ -298,6 +298,7 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
     }
     c->ntiles = (n_local + c->tile - 1) / c->tile;
     if (c->ntiles < c->sweep_grid) c->sweep_grid = (int)std::max<int64_t>(1, c->ntiles);
+    c->sweep_grid_max = c->sweep_grid;
     // statistics work items: ~4 per resident wave slot (2 waves/SIMD) so the last round is not mostly empty
     // work items of the statistics pass: the NIW kernel hands every workgroup a contiguous RANGE of items, so finer items
     // only improve the balance (ceil(items / groups) granularity) -- 16384 at D <= 64 (1.05 -> 0.85 ms at N = 1e7); slabs
@@ -319,8 +320,8 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
     CHK_CREATE(hipMalloc(&c->sb.perm_total, sizeof(int32_t)));
     CHK_CREATE(hipMalloc(&c->d_small, sizeof(int32_t) * 4 * DPMM_MAX_CLUSTERS));
     CHK_CREATE(hipMalloc(&c->d_counts64, sizeof(long long) * 2 * DPMM_MAX_CLUSTERS));
-    CHK_CREATE(hipMalloc(&c->d_work, sizeof(unsigned long long) * 4));
-    CHK_CREATE(hipMemset(c->d_work, 0, sizeof(unsigned long long) * 4));
+    CHK_CREATE(hipMalloc(&c->d_work, sizeof(unsigned long long) * 8));
+    CHK_CREATE(hipMemset(c->d_work, 0, sizeof(unsigned long long) * 8));
 #undef CHK_CREATE
     *out = c;
     return DPMM_OK;
@@ -695,7 +696,7 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
     HIPCHK(c, hipSetDevice(c->device));
     if (c->n == 0) return DPMM_OK;
     if (c->prior == DPMM_PRIOR_NIW && !table) {
-        if (!c->work_zeroed) HIPCHK(c, hipMemsetAsync(c->d_work, 0, sizeof(unsigned long long) * 4, c->stream));   // usually done by the pack kernel
+        if (!c->work_zeroed) HIPCHK(c, hipMemsetAsync(c->d_work, 0, sizeof(unsigned long long) * 8, c->stream));   // usually done by the pack kernel
         c->work_zeroed = false;
     }
     if (!table) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
@@ -1224,6 +1225,9 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
         case DPMM_OPT_TRACE_SLOW: c->opt_trace = value != 0; return DPMM_OK;
         case DPMM_OPT_LOGLIK_REF_CONST: c->opt_ref_const = value != 0; return DPMM_OK;
         case DPMM_OPT_WAVE_PRIO: c->opt_prio = value != 0; return DPMM_OK;
+        case DPMM_OPT_SWEEP_GRID:
+            if (value > 0) c->sweep_grid = (int)std::min<double>(std::min<double>(value, (double)c->sweep_grid_max), (double)std::max<int64_t>(1, c->ntiles));   // scratch is sized for the default
+            return DPMM_OK;
         case DPMM_OPT_MULT_NO_U8:
             if (c->have_points) return fail(c, DPMM_ESTATE, "DPMM_OPT_MULT_NO_U8 must be set before the points are uploaded");
             c->opt_no_u8 = value != 0; return DPMM_OK;

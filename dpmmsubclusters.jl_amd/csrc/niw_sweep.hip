@@ -236,7 +236,21 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
     QuadEval<NB, NG, CH> ev;
     unsigned nw_tiles = 0, nw_full = 0, nw_tail = 0;   // executed-work counters of this wave (wave-uniform)
 
-    for (int64_t tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
+    // Tiles are handed out through a queue (A.work[4], cleared with the work counters): the cost of a tile varies with the number of
+    // clusters its points cannot exclude (1 to > 10 full evaluations at D = 256), and with a static "tile = workgroup + i * grid"
+    // assignment the slowest workgroup ran 1.9 x the median (2.76 ms kernel, 1.45 ms median workgroup).  Results do not depend on
+    // which workgroup takes a tile (the random stream is keyed by the point).  Without counters (table mode): static assignment.
+    __shared__ long long sh_tile;
+    const bool queue = A.work != nullptr;
+    int64_t tile = blockIdx.x;
+    for (;; tile += gridDim.x) {
+        if (queue) {
+            __syncthreads();                               // everybody has read the previous value
+            if (tid == 0) sh_tile = (long long)atomicAdd(&A.work[4], 1ull);      // in order: a strided order was measured 4 % slower
+            __syncthreads();
+            tile = sh_tile;
+        }
+        if (tile >= A.ntiles) break;
         ++nw_tiles;
         const int64_t wbase = tile * C::TILE + (int64_t)wave * C::WPTS;  // first point of this wave
         // ---- x tile -> registers (B-operand layout)
@@ -1118,7 +1132,7 @@ __global__ void niw_pack_kernel(const float *__restrict__ R, const float *__rest
     // riders (save two launches per sweep): the additive constants move from the parameter image to where the sweep kernels read
     // them, and the executed-work counters of the next sweep start at zero
     if (cst_out) for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < nmat; e += (int64_t)gridDim.x * blockDim.x) cst_out[e] = cst[e];
-    if (work && blockIdx.x == 0 && threadIdx.x < 4) work[threadIdx.x] = 0ull;
+    if (work && blockIdx.x == 0 && threadIdx.x < 8) work[threadIdx.x] = 0ull;     // counters [0..3], tile queue head [4]
     const int DP = 16 * NB;
     const size_t TRI = (size_t)D * (D + 1) / 2;
     const int64_t total = (int64_t)nmat * NP * 256;

@@ -8,7 +8,9 @@ b = importlib.import_module("dpmmsubclusters_jl_amd.binding")
 alt = os.path.abspath("dpmmsubclusters.jl_amd/lib/libdpmmhip_stamps.so")
 b.lib_path = lambda: alt
 host = importlib.import_module("dpmmsubclusters_jl_amd.host")
-N, D, K = 1000000, 64, 32
+D = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+N = int(float(sys.argv[2])) if len(sys.argv) > 2 else 1000000
+K = 32
 X, y = host.gaussian_mixture_shard(N, D, K, 100.0, 12345, 0, N)
 prior = host.niw_hyperparams(1.0, np.zeros(D), D + 3, np.eye(D))
 wk = pkg.Worker(pkg.PRIOR_NIW, D, N, device=0, seed=1)
@@ -24,7 +26,7 @@ buf = np.zeros((nw, 16), np.uint64)
 lib.dpmm_dev_stamps.restype = ctypes.c_int
 used = lib.dpmm_dev_stamps(wk._h, buf.ctypes.data_as(ctypes.c_void_p), nw)
 d = buf[:used].astype(np.float64); d = d[d[:, 8] > 0]
-names = ["x load", "refs(full)", "screen setup", "K-loop", "survivors", "draw", "phase2", "total"]
+names = ["x load", "refs(full)", "screen setup", "K-loop", "survivors", "draw", "phase2", "total"] if D <= 64 else ["x load", "reference eval", "-", "tail screens", "survivors", "draw", "phase2 (sub-labels)", "total"]
 nt = d[:, 8].sum()
 for i, nm in enumerate(names):
     print(f"{nm:14s} cycles/tile {d[:, i].sum() / nt:10.0f}   share {100 * d[:, i].sum() / d[:, 7].sum():5.1f}%")
@@ -32,3 +34,13 @@ print("refs setup (table init, prev labels, first fragments, pre-screen norms) c
 print("  of which: table init + k0:", d[:, 13].sum() / nt, " first fragments + pre-screen constants arrive:", d[:, 14].sum() / nt)
 print("tail-screened clusters per tile:", d[:, 9].sum() / nt)
 print("MFMA-screened clusters per tile:", d[:, 10].sum() / nt)
+tt = d[:, 7]
+print("per-wave total cycles: min %.0f  median %.0f  p90 %.0f  max %.0f ; tiles per wave min %d max %d" % (tt.min(), np.median(tt), np.percentile(tt, 90), tt.max(), d[:, 8].min(), d[:, 8].max()))
+wg = tt.reshape(-1, 4).max(axis=1)
+order = np.argsort(-wg)[:8]
+print("slowest workgroups (index, cycles):", [(int(i), int(wg[i])) for i in order])
+for i, nm in enumerate(names[:7]):
+    print(f"  {nm:22s} per-wave sum: median {np.median(d[:, i]):10.0f}  max {d[:, i].max():10.0f}")
+if D > 64:
+    print("longest single tile per wave: median %.0f  max %.0f cycles;  wave lifetime (first stamp -> last stamp): median %.0f max %.0f; spread of end times %.0f" % (
+        np.median(d[:, 10]), d[:, 10].max(), np.median(d[:, 12] - d[:, 11]), (d[:, 12] - d[:, 11]).max(), d[:, 12].max() - d[:, 12].min()))
