@@ -52,11 +52,29 @@ struct NiwCfg {
     static constexpr int DP = 16 * NB;
     static constexpr int NP = NB * (NB + 1) / 2;     // 16x16 blocks on/above the diagonal
     static constexpr int MATSZ = NP * 256;            // floats per packed matrix
-    static constexpr int NCH = (NB + CH - 1) / CH;    // chunks per matrix
+    // Chunks = runs of whole row blocks holding at most CAP 16x16 blocks, cut greedily from the top (row block bi has NB - bi of
+    // them): D = 256 -> 5 chunks of 31 / 27 / 23 / 27 / 28 blocks, D = 128 -> 3 chunks of 15 / 15 / 6.  (One row block per chunk, as
+    // before, ended in chunks of 3, 2, 1 blocks: 8-24 matrix instructions between two barriers, with the global -> register latency
+    // of the next chunk fully exposed.)  CH is kept as a tag of the configuration.
+    static constexpr int CAP = NB >= 16 ? 32 : 16;
+    __host__ __device__ static constexpr int chunk_row(int c) {     // first row block of chunk c (c == NCH: NB)
+        int r = 0;
+        for (int i = 0; i < c; ++i) {
+            int p = 0;
+            while (r < NB && p + (NB - r) <= CAP) { p += NB - r; ++r; }
+        }
+        return r;
+    }
+    __host__ __device__ static constexpr int count_chunks() {
+        int c = 0;
+        while (chunk_row(c) < NB) ++c;
+        return c;
+    }
+    static constexpr int NCH = count_chunks();        // chunks per matrix
     static constexpr int TILE = 64 * NG;              // points per workgroup tile (4 waves x 16 NG)
     static constexpr int WPTS = 16 * NG;              // points per wave
-    __host__ __device__ static constexpr int row0(int c) { return c * CH; }
-    __host__ __device__ static constexpr int row1(int c) { return (c + 1) * CH < NB ? (c + 1) * CH : NB; }
+    __host__ __device__ static constexpr int row0(int c) { return chunk_row(c); }
+    __host__ __device__ static constexpr int row1(int c) { return chunk_row(c + 1); }
     __host__ __device__ static constexpr int pairs(int c) { return pair_base<NB>(row1(c)) - pair_base<NB>(row0(c)); }
     __host__ __device__ static constexpr int passes(int c) { return (pairs(c) + 3) / 4; }
     __host__ __device__ static constexpr int max_pairs() {
@@ -111,14 +129,19 @@ struct QuadEval {
     using C = NiwCfg<NB, NG, CH>;
     // staging registers: named members + compile-time selector (an indexed array here ends up in
     // scratch memory: the conditional writes defeat SROA)
-    f32x4 st0, st1, st2, st3;
-    static_assert(C::MAXPASS <= 4, "chunk too large for the staging registers");
+    f32x4 st0, st1, st2, st3, st4, st5, st6, st7;
+    int par = 0;       // LDS buffer the NEXT commit goes to (two buffers, one barrier per chunk; runs on across matrices)
+    static_assert(C::MAXPASS <= 8, "chunk too large for the staging registers");
     template <int p>
     __device__ __forceinline__ f32x4 &S() {
         if constexpr (p == 0) return st0;
         else if constexpr (p == 1) return st1;
         else if constexpr (p == 2) return st2;
-        else return st3;
+        else if constexpr (p == 3) return st3;
+        else if constexpr (p == 4) return st4;
+        else if constexpr (p == 5) return st5;
+        else if constexpr (p == 6) return st6;
+        else return st7;
     }
     template <int c, int p>
     __device__ __forceinline__ void prefetch_pass(const f32x4 *src) {
@@ -151,6 +174,13 @@ struct QuadEval {
     template <int c>
     __device__ __forceinline__ void compute(const float *lds, const f32x4 (&x)[NG][NB], const f32x4 (&mu)[NB],
                                             float (&q)[NG], int lane) {
+        // the A fragment of the NEXT block is requested before the matrix instructions of the current one (the chunk's blocks are
+        // contiguous in LDS in visiting order); scheduling fences keep the read there -- left alone, the compiler issues every
+        // ds_read right in front of its first use and the LDS latency (~120 cycles per 8 matrix instructions at one wave per SIMD)
+        // is fully exposed
+        constexpr int P = C::pairs(c);
+        int pic = 0;
+        f32x4 a = *reinterpret_cast<const f32x4 *>(lds + lane * 4);
 #pragma unroll
         for (int bi = C::row0(c); bi < C::row1(c); ++bi) {
             f32x4 acc[NG];
@@ -158,8 +188,9 @@ struct QuadEval {
             for (int n = 0; n < NG; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = bi; t < NB; ++t) {
-                const int pic = pair_base<NB>(bi) + (t - bi) - pair_base<NB>(C::row0(c));
-                const f32x4 a = *reinterpret_cast<const f32x4 *>(lds + pic * 256 + lane * 4);
+                f32x4 an = a;
+                if (pic + 1 < P) an = *reinterpret_cast<const f32x4 *>(lds + (pic + 1) * 256 + lane * 4);
+                __builtin_amdgcn_sched_barrier(0);
                 // rotate over the NG independent accumulators: a dependent MFMA pair needs 40 cycles,
                 // the issue interval is 32
                 f32x4 zz[NG];
@@ -171,6 +202,9 @@ struct QuadEval {
                     for (int n = 0; n < NG; ++n)
                         acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj], zz[n][jj], acc[n], 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                a = an;
+                ++pic;
             }
 #pragma unroll
             for (int n = 0; n < NG; ++n) {
@@ -191,15 +225,18 @@ __device__ __forceinline__ void eval_matrix(QuadEval<NB, NG, CH> &ev, float *lds
                                             const f32x4 (&x)[NG][NB], const f32x4 (&mu)[NB], float (&q)[NG],
                                             int lane, bool active) {
     using C = NiwCfg<NB, NG, CH>;
-    __syncthreads();  // previous chunk's LDS reads are done
-    ev.template commit<c>(lds);
+    // Two LDS buffers: the one written here was last read two chunks ago, and every wave has passed a barrier since it finished
+    // that chunk -- ONE barrier per chunk (commit -> barrier -> prefetch the next chunk -> matrix instructions).
+    float *buf = lds + ev.par * (C::MAXPAIRS * 256);
+    ev.par ^= 1;
+    ev.template commit<c>(buf);
     __syncthreads();
     if constexpr (c + 1 < C::NCH) {
         ev.template prefetch<c + 1>(Rcur);
     } else {
         if (Rnext) ev.template prefetch<0>(Rnext);
     }
-    if (active) ev.template compute<c>(lds, x, mu, q, lane);
+    if (active) ev.template compute<c>(buf, x, mu, q, lane);
     if constexpr (c + 1 < C::NCH) eval_matrix<NB, NG, CH, c + 1>(ev, lds, Rcur, Rnext, x, mu, q, lane, active);
 }
 
@@ -219,7 +256,7 @@ __device__ __forceinline__ float reduce_select(float (&q)[NG], int g) {
 template <int NB, int NG, int CH>
 __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSweepArgs A) {
     using C = NiwCfg<NB, NG, CH>;
-    __shared__ __attribute__((aligned(16))) float lds[C::MAXPAIRS * 256];
+    __shared__ __attribute__((aligned(16))) float lds[2 * C::MAXPAIRS * 256];
     __shared__ uint32_t present[DPMM_MAX_CLUSTERS_K / 32];
     __shared__ uint32_t survm[DPMM_MAX_CLUSTERS_K / 32];   // screened mode: clusters some wave of the workgroup could not exclude
     __shared__ int sh_k0;
