@@ -253,8 +253,16 @@ __device__ __forceinline__ float reduce_select(float (&q)[NG], int g) {
     return sel;
 }
 
+#ifdef DPMM_STAMPS
+#define STAMP(var) unsigned long long var; do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(var)
+#endif
 template <int NB, int NG, int CH>
 __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSweepArgs A) {
+#ifdef DPMM_STAMPS
+    unsigned long long T_x = 0, T_ref = 0, T_tail = 0, T_surv = 0, T_draw = 0, T_p2 = 0, T_tot = 0, T_max = 0, T_first = 0, T_last = 0; int ntile = 0;
+#endif
     using C = NiwCfg<NB, NG, CH>;
     __shared__ __attribute__((aligned(16))) float lds[2 * C::MAXPAIRS * 256];
     __shared__ uint32_t present[DPMM_MAX_CLUSTERS_K / 32];
@@ -289,6 +297,7 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
         }
         if (tile >= A.ntiles) break;
         ++nw_tiles;
+        STAMP(s0);
         const int64_t wbase = tile * C::TILE + (int64_t)wave * C::WPTS;  // first point of this wave
         // ---- x tile -> registers (B-operand layout)
         f32x4 x[NG][NB];
@@ -306,6 +315,10 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
         const int64_t mypos = wbase + lane;  // owner's position in processing order
         const bool valid = owner && mypos < A.n;
         const int64_t myp = (valid && use_order) ? (int64_t)A.order[mypos] : mypos;   // owner's point
+#ifdef DPMM_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        STAMP(s1);
         float *scr = A.scratch + (A.scratch_by_tile ? tile * C::TILE : (int64_t)blockIdx.x * C::TILE) + wave * C::WPTS + lane;
         const int64_t sstride = A.scratch_stride;
 
@@ -339,6 +352,9 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
         };
         const bool screening = A.tail != nullptr && A.screen_margin > 0.f && !A.tdf && !A.scratch_by_tile && K > 2;
         int k0 = 0;
+#ifdef DPMM_STAMPS
+        unsigned long long sv0 = s1;
+#endif
         if (!screening) {
             ev.template prefetch<0>(A.Rp);
             for (int k = 0; k < K; ++k)
@@ -362,6 +378,7 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
             k0 = sh_k0;
             ev.template prefetch<0>(A.Rp + (size_t)(3 * k0) * C::MATSZ);
             const float a0 = eval_cluster(k0, nullptr);
+            STAMP(s2);
             const float my_thr = valid ? a0 - A.screen_margin : INFINITY;
             f32x4 xt = (f32x4){0.f, 0.f, 0.f, 0.f};
             {
@@ -384,6 +401,10 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
                 }
             }
             __syncthreads();
+            STAMP(s3);
+#ifdef DPMM_STAMPS
+            T_ref += s2 - s1; T_tail += s3 - s2; sv0 = s3;
+#endif
             const int nw = (K + 31) >> 5;
             int w = 0;
             uint32_t bits = __builtin_amdgcn_readfirstlane(survm[0]);
@@ -407,6 +428,7 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
         }
 
         // ---- label draw (owner lanes), src/utils.jl:19-31
+        STAMP(s4);
         int z = 0;
         float u_sub = 0.f;
         if (valid) {
@@ -454,6 +476,7 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
 
         // ---- phase 2: sub-labels.  Distinct labels of the workgroup -> LDS bitmap
         __syncthreads();
+        STAMP(s5);
         if (tid < DPMM_MAX_CLUSTERS_K / 32) present[tid] = 0u;
         __syncthreads();
         if (valid) atomicOr(&present[z >> 5], 1u << (z & 31));
@@ -505,11 +528,25 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
             const int sl = draw2(b0, b1, u_sub);
             A.bins[myp] = 2 * z + sl;
         }
+        STAMP(s6);
+#ifdef DPMM_STAMPS
+        T_x += s1 - s0; T_surv += s4 - sv0; T_draw += s5 - s4; T_p2 += s6 - s5; T_tot += s6 - s0; ++ntile;
+        if (s6 - s0 > T_max) T_max = s6 - s0;
+        if (!T_first) T_first = s0;
+        T_last = s6;
+#endif
     }
     if (A.work && lane == 0) {
         atomicAdd(&A.work[0], (unsigned long long)nw_tiles); atomicAdd(&A.work[1], (unsigned long long)nw_full);
         atomicAdd(&A.work[3], (unsigned long long)nw_tail);
     }
+#ifdef DPMM_STAMPS
+    if (A.dbg && lane == 0 && blockIdx.x < 4096) {
+        unsigned long long *d = A.dbg + ((size_t)blockIdx.x * 4 + wave) * 16;
+        d[0] = T_x; d[1] = T_ref; d[2] = 0; d[3] = T_tail; d[4] = T_surv; d[5] = T_draw; d[6] = T_p2; d[7] = T_tot;
+        d[8] = ntile; d[9] = nw_tail; d[10] = T_max; d[11] = T_first; d[12] = T_last; d[13] = 0; d[14] = 0;
+    }
+#endif
 }
 
 
@@ -610,11 +647,6 @@ __device__ __forceinline__ void load_rb0(const float *__restrict__ Rm, const flo
     }
 }
 
-#ifdef DPMM_STAMPS
-#define STAMP(var) unsigned long long var; do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define STAMP(var)
-#endif
 // FAST: the steady-state configuration known at launch time (screening with the tail screen, no far mask, LDS table, no
 // Student-t mode, no table output): the mode tests below become compile-time constants -- fewer live scalars (the generic
 // kernel spills > 100 SGPRs into VGPR lanes) and fewer branches per tile.  Same arithmetic, same results.
