@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
     __shared__ __attribute__((aligned(16))) float lds[2 * C::MAXPAIRS * 256];
     __shared__ uint32_t present[DPMM_MAX_CLUSTERS_K / 32];
     __shared__ uint32_t survm[DPMM_MAX_CLUSTERS_K / 32];   // screened mode: clusters some wave of the workgroup could not exclude
-    __shared__ int sh_k0;
+    __shared__ int sh_first[4], sh_last[4];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
             return a;
         };
         const bool screening = A.tail != nullptr && A.screen_margin > 0.f && !A.tdf && !A.scratch_by_tile && K > 2;
-        int k0 = 0;
+        int k0 = 0, k1 = 0;
 #ifdef DPMM_STAMPS
         unsigned long long sv0 = s1;
 #endif
@@ -361,25 +361,36 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
                 eval_cluster(k, (k + 1 < K) ? A.Rp + (size_t)(3 * (k + 1)) * C::MATSZ : nullptr);
         } else {
             // Screened label phase, workgroup-wide (the fragment staging is shared by the four waves):
-            //  (1) reference cluster k0 = previous label of the workgroup's first point, evaluated in full;
+            //  (1) reference clusters k0 / k1 = previous labels of the workgroup's first and last point, evaluated in full (k1 only
+            //      when it differs: a tile that straddles two clusters of the label-sorted order -- with ONE reference the points
+            //      of the other cluster had a hopeless threshold, nothing could be excluded for them and all K clusters were
+            //      evaluated: 31 such tiles per sweep at K = 32, 1.6 M cycles each against 0.18 M for an ordinary tile);
             //  (2) every wave tail-screens all other clusters against its own points; a cluster is evaluated if ANY wave
             //      could not exclude it (bit in survm); (3) survivors are evaluated in index order.
-            __syncthreads();                                   // survm / sh_k0 of the previous tile are no longer read
+            __syncthreads();                                   // survm / sh_first / sh_last of the previous tile are no longer read
             if (tid < DPMM_MAX_CLUSTERS_K / 32) survm[tid] = 0u;
-            if (wave == 0) {
+            {
                 int prev = (valid && A.use_prev) ? (A.bins[myp] >> 1) : -1;
                 if ((unsigned)prev >= (unsigned)K) prev = -1;
                 const unsigned long long pm = __ballot(prev >= 0);
-                int kk = 0;
-                if (pm) kk = __shfl(prev, __ffsll((long long)pm) - 1);
-                if (lane == 0) sh_k0 = kk;
+                int kf = -1, kl = -1;
+                if (pm) { kf = __shfl(prev, __ffsll((long long)pm) - 1); kl = __shfl(prev, 63 - __clzll((long long)pm)); }
+                if (lane == 0) { sh_first[wave] = kf; sh_last[wave] = kl; }
             }
             __syncthreads();
-            k0 = sh_k0;
+            k0 = 0;
+            for (int wv = 3; wv >= 0; --wv) if (sh_first[wv] >= 0) k0 = sh_first[wv];
+            k1 = k0;
+            for (int wv = 0; wv < 4; ++wv) if (sh_last[wv] >= 0) k1 = sh_last[wv];
+            const int nref = k1 != k0 ? 2 : 1;
+            float aref = -INFINITY;
             ev.template prefetch<0>(A.Rp + (size_t)(3 * k0) * C::MATSZ);
-            const float a0 = eval_cluster(k0, nullptr);
+            for (int rr = 0; rr < nref; ++rr) {       // one call site: the unrolled evaluation exists once for both references
+                const float a = eval_cluster(rr ? k1 : k0, (rr + 1 < nref) ? A.Rp + (size_t)(3 * k1) * C::MATSZ : nullptr);
+                if (a > aref) aref = a;                // a NaN never raises the reference
+            }
             STAMP(s2);
-            const float my_thr = valid ? a0 - A.screen_margin : INFINITY;
+            const float my_thr = valid ? aref - A.screen_margin : INFINITY;
             f32x4 xt = (f32x4){0.f, 0.f, 0.f, 0.f};
             {
                 const int src = ci + 16 * A.tail_g;
@@ -397,7 +408,7 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const int k = 2 * pr + c;
-                    if (k < K && k != k0 && !((far2 >> c) & 1u) && lane == 0) atomicOr(&survm[k >> 5], 1u << (k & 31));
+                    if (k < K && k != k0 && k != k1 && !((far2 >> c) & 1u) && lane == 0) atomicOr(&survm[k >> 5], 1u << (k & 31));
                 }
             }
             __syncthreads();
@@ -444,7 +455,7 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
                 const int nw = (K + 31) >> 5;
                 float s = 0.f;
                 for (int w = 0; w < nw; ++w) {
-                    uint32_t bb = survm[w] | ((k0 >> 5) == w ? (1u << (k0 & 31)) : 0u);
+                    uint32_t bb = survm[w] | ((k0 >> 5) == w ? (1u << (k0 & 31)) : 0u) | ((k1 >> 5) == w ? (1u << (k1 & 31)) : 0u);
                     for (; bb; bb &= bb - 1u) s += exp_det(nan_to_ninf(scr[(int64_t)((w << 5) + __builtin_ctz(bb)) * sstride]) - m_run);
                 }
                 const float t = u01(r.v[0]) * s;
@@ -452,7 +463,7 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
                 z = K - 1;
                 bool found = false;
                 for (int w = 0; w < nw && !found; ++w) {
-                    uint32_t bb = survm[w] | ((k0 >> 5) == w ? (1u << (k0 & 31)) : 0u);
+                    uint32_t bb = survm[w] | ((k0 >> 5) == w ? (1u << (k0 & 31)) : 0u) | ((k1 >> 5) == w ? (1u << (k1 & 31)) : 0u);
                     for (; bb; bb &= bb - 1u) {
                         const int k = (w << 5) + __builtin_ctz(bb);
                         cw += exp_det(nan_to_ninf(scr[(int64_t)k * sstride]) - m_run);
