@@ -693,7 +693,10 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
         __syncthreads();
     }
 
-    // (A start stagger of the odd hardware wave slots and a dynamic tile queue were measured twice: no effect.)
+    // (A start stagger of the odd hardware wave slots was measured twice: no effect.  A tile queue -- which fixed a 1.9x straggler
+    // problem in the LDS-staged kernel -- does not pay here although the slowest wave runs 8 % behind the median at N = 1e7: with every
+    // tile claimed by an atomic, one tile ahead, the kernel went from 1.85 to 2.11 ms (156 k atomics on one address, each at the head
+    // of the in-order VMEM return queue of its wave); static for 15/16 of the tiles and a queue for the rest: 1.87 ms.)
     // Cross-tile prefetch (static tile schedule): while a tile is processed, the wave already fetches the NEXT
     // tile's point indices (order[]) and their previous labels (bins[]); the next tile then issues its X gather at
     // once instead of walking the dependent chain order -> X, order -> bins -> reference cluster -> fragments.
