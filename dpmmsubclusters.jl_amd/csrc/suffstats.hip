@@ -266,15 +266,17 @@ __device__ __forceinline__ void niw_stats_body(const StatsArgs &A, int seg, int 
             }
         }
     };
-    // Software pipeline: x two batches (D <= 128) or one batch (D = 256: no registers left) ahead of the MFMAs, perm
-    // indices one batch further.  In every iteration the index loads are issued BEFORE the x loads that consume the
-    // previous iteration's indices: vmcnt retires in order, so waiting for an index never drains the x loads behind it.
-    constexpr bool DEEP = NBK <= 8;
-    constexpr int AHEAD = DEEP ? 2 : 1;
+    // Software pipeline: x two batches ahead of the MFMAs, perm indices one batch further.  (D = 256 used to run ONE one-k-step
+    // batch ahead: 1 088 matrix-pipe cycles of cover against > 2 000 cycles of HBM latency at one wave per SIMD; a third batch
+    // ahead spills -- every buffer role costs ~40 VGPRs, addresses included, and 256 of the 512 registers are accumulators.)
+    // In every iteration the index loads are issued BEFORE the x loads that consume the previous iteration's indices: vmcnt
+    // retires in order, so waiting for an index never drains the x loads behind it.
+    constexpr int AHEAD = 2;
+    constexpr int NBUF = AHEAD + 1;
     // The x buffers rotate by ROLE (loop unrolled over the buffers), never by copying: a register move of a
     // freshly loaded value would wait for the load it was meant to overlap.
     int pt_b[U], pt_c[U];
-    float xa[U][NBK], xb[U][NBK], xc[DEEP ? U : 1][DEEP ? NBK : 1];
+    float xbuf[NBUF][U][NBK];
     auto step = [&](int bt, const float (&xu)[U][NBK], float (&xl)[U][NBK]) {
         // scheduling fences keep the issue order idx -> x -> MFMAs: left alone, the scheduler hoists the next step's address
         // arithmetic (which needs the newest indices) into this step and the wait for them drains the x loads as well
@@ -306,22 +308,16 @@ __device__ __forceinline__ void niw_stats_body(const StatsArgs &A, int seg, int 
         for (int u = 0; u < U; ++u) pt_b[u] = pt_c[u];   // indices were issued before this step's x loads: no drain
         __builtin_amdgcn_sched_barrier(0);
     };
+    // prologue: batches 0 .. AHEAD-1 in flight, indices of batch AHEAD loaded
     load_idx(0, pt_b);
-    load_x(pt_b, xa);
-    load_idx(1, pt_b);
-    if constexpr (DEEP) {
-        load_x(pt_b, xb);
-        load_idx(2, pt_b);
-        for (int bt = 0; bt < nbatch; bt += 3) {     // steps beyond nbatch see masked rows: zero contribution, no branch
-            step(bt, xa, xc);
-            step(bt + 1, xb, xa);
-            step(bt + 2, xc, xb);
-        }
-    } else {
-        for (int bt = 0; bt < nbatch; bt += 2) {
-            step(bt, xa, xb);
-            if (bt + 1 < nbatch) step(bt + 1, xb, xa);
-        }
+#pragma unroll
+    for (int r = 0; r < AHEAD; ++r) {
+        load_x(pt_b, xbuf[r]);
+        load_idx(r + 1, pt_b);
+    }
+    for (int bt = 0; bt < nbatch; bt += NBUF) {          // steps beyond nbatch see masked rows: zero contribution, no branch
+#pragma unroll
+        for (int r = 0; r < NBUF; ++r) step(bt + r, xbuf[r], xbuf[(r + AHEAD) % NBUF]);
     }
     // slab[pair][r][lane]
 #pragma unroll
@@ -464,8 +460,11 @@ hipError_t launch_niw_stats(const StatsArgs &a0, hipStream_t s) {
     StatsArgs a = a0;
     const int NBK = niw_nbk(a.D);
     // two resident waves per SIMD at D = 64 (register budget): 2048 workgroups cover the chip once; every workgroup
-    // gets the same number of items, so nothing is gained from a longer grid
-    int groups = a.range_groups > 0 ? a.range_groups : (NBK <= 4 ? 2048 : 1024);
+    // gets the same number of items, so nothing is gained from a longer grid.  Measured (scripts/stats_groups_sweep.py): D <= 64:
+    // 2048 at N = 1e7 (0.98 ms; 1024: 1.00, 512: 1.84), but 1024 at n = 1.25e6 (0.19 against 0.22 ms: half the slabs to write and
+    // to reduce); D = 128: 1024 (0.51; 512: 0.84); D = 256 (one workgroup per compute unit fits): 256 (1.17 ms; 512: 1.20, 1024: 1.44).
+    const int dflt = NBK <= 4 ? (a.n >= 2500000 ? 2048 : 1024) : (NBK <= 8 ? 1024 : 256);
+    int groups = a.range_groups > 0 ? a.range_groups : dflt;
     const int max_items = a.max_items < 1 ? 1 : a.max_items;
     if (groups > max_items) groups = max_items;
     a.range_groups = groups;
