@@ -31,6 +31,7 @@ ABI = [
     ("dpmm_set_params_mult", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_f32p, _c_f32p, _c_f32p]),
     ("dpmm_set_num_clusters", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("dpmm_num_clusters", ctypes.c_int, [ctypes.c_void_p]),
+    ("dpmm_numa_node", ctypes.c_int, [ctypes.c_void_p]),
     ("dpmm_sweep", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int]),
     ("dpmm_packed_stride", ctypes.c_int64, [ctypes.c_void_p]),
     ("dpmm_suffstats_packed_device", ctypes.c_int, [ctypes.c_void_p, _c_i64p, ctypes.c_int, ctypes.c_void_p]),
@@ -391,6 +392,10 @@ class Worker:
         self._use_torch_rccl()
         buf = ctypes.create_string_buffer(bytes(unique_id), 128)
         self._chk(self._lib.dpmm_comm_init(self._h, buf, int(rank), int(world)))
+
+    def numa_node(self):
+        """dpmm_numa_node: NUMA node of the host this context's GPU is attached to (-1: unknown)."""
+        return int(self._lib.dpmm_numa_node(self._h))
 
     def step_stats(self, reset_epoch):
         """dpmm_step_stats: (packed (2K, stride) float64, bad (K,) uint8) -- copies of the ctx's pinned output."""

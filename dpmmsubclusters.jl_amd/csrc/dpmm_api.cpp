@@ -691,6 +691,20 @@ int dpmm_set_num_clusters(dpmm_ctx *c, int K) {
 
 int dpmm_num_clusters(const dpmm_ctx *c) { return c ? c->K : 0; }
 
+int dpmm_numa_node(dpmm_ctx *c) {
+    if (!c) return -1;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), c->device) != hipSuccess) return -1;
+    for (char *p = bus; *p; ++p) if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');      // sysfs uses lower-case hex
+    const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/numa_node";
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
+}
+
 static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table, int64_t table_stride) {
     if (!c->have_points || !c->have_params) return fail(c, DPMM_ESTATE, "sweep needs points and parameters");
     HIPCHK(c, hipSetDevice(c->device));

@@ -64,7 +64,10 @@ class Helper {
         wait();
         {
             std::lock_guard<std::mutex> lk(mu_);
-            if (!th_.joinable()) th_ = std::thread([this] { loop(); });
+            if (!th_.joinable()) {
+                th_ = std::thread([this] { loop(); });
+                if (have_affinity_) pthread_setaffinity_np(th_.native_handle(), sizeof(affinity_), &affinity_);
+            }
             job_ = std::move(job); busy_ = true;
         }
         cv_.notify_all();
@@ -87,6 +90,13 @@ class Helper {
         { std::lock_guard<std::mutex> lk(mu_); cancel_ = true; }
         cv_.notify_all();
     }
+    void set_numa_node(int node) {
+        cpu_set_t set;
+        if (!Pool::node_cpus(node, &set)) return;
+        std::lock_guard<std::mutex> lk(mu_);
+        affinity_ = set; have_affinity_ = true;
+        if (th_.joinable()) pthread_setaffinity_np(th_.native_handle(), sizeof(set), &set);
+    }
   private:
     void loop() {
         prctl(PR_SET_TIMERSLACK, 1000UL);     // 1 us instead of the default 50 us: sleep_until is used for sub-100-us scheduling
@@ -107,7 +117,8 @@ class Helper {
     std::condition_variable cv_, done_;
     std::thread th_;
     std::function<void()> job_;
-    bool busy_ = false, stop_ = false, cancel_ = false;
+    bool busy_ = false, stop_ = false, cancel_ = false, have_affinity_ = false;
+    cpu_set_t affinity_;
 };
 
 // random streams of the master side (the worker uses 0..3, the draws 16..18)
@@ -718,6 +729,12 @@ HAPI int dpmmh_model_set_option(dpmmh_model *m, int option, double value) {
         case DPMMH_OPT_SHARE_WORK: m->share_work = value != 0; return 0;
         case DPMMH_OPT_SPIN_US: Pool::get().set_spin_us((int)value); return 0;
         case DPMMH_OPT_PREWAKE: m->prewake = value != 0; return 0;
+        case DPMMH_OPT_NUMA_NODE: {
+            const int node = (int)value;
+            Pool::get().set_numa_node(node);
+            m->helper.set_numa_node(node);
+            return 0;
+        }
         default: return m->fail("unknown option");
     }
 }

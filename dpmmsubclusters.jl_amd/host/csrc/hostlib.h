@@ -1,6 +1,10 @@
 // hostlib.h -- shared pieces of libdpmmhost.so: the passive thread pool and the counter-based RNG.
 #pragma once
 #include <math.h>
+#include <pthread.h>
+#include <sched.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <string.h>
 #include <time.h>
@@ -24,6 +28,40 @@ class Pool {
   public:
     static Pool &get() { static Pool p; return p; }
     void set_spin_us(int us) { spin_ns_.store(us < 0 ? 0 : (int64_t)us * 1000); }
+    // keep the workers (existing and future) on the CPUs of one NUMA node; node < 0 or an unreadable topology: no change
+    void set_numa_node(int node) {
+        cpu_set_t set;
+        if (!node_cpus(node, &set)) return;
+        std::lock_guard<std::mutex> lk(call_mu_);
+        affinity_ = set; have_affinity_ = true;
+        for (auto &t : threads_) pthread_setaffinity_np(t.native_handle(), sizeof(set), &set);
+    }
+    // CPUs of a NUMA node that this process may use (/sys/devices/system/node/nodeN/cpulist intersected with the current mask)
+    static bool node_cpus(int node, cpu_set_t *out) {
+        if (node < 0) return false;
+        char path[96];
+        snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+        FILE *f = fopen(path, "r");
+        if (!f) return false;
+        char buf[4096] = {0};
+        const bool ok = fgets(buf, sizeof(buf), f) != nullptr;
+        fclose(f);
+        if (!ok) return false;
+        cpu_set_t allowed;
+        CPU_ZERO(&allowed);
+        if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return false;
+        CPU_ZERO(out);
+        int n = 0;
+        for (char *p = buf; *p && *p != '\n';) {
+            char *e;
+            long a = strtol(p, &e, 10), b = a;
+            if (e == p) break;
+            if (*e == '-') { p = e + 1; b = strtol(p, &e, 10); }
+            for (long c = a; c <= b && c < CPU_SETSIZE; ++c) if (CPU_ISSET(c, &allowed)) { CPU_SET(c, out); ++n; }
+            p = (*e == ',') ? e + 1 : e;
+        }
+        return n > 0;
+    }
     // run fn(item, slot) for item in [0, n) on up to `nthreads` threads (slot < nthreads identifies the thread)
     void run(int n, int nthreads, const std::function<void(int, int)> &fn) {
         if (n <= 0) return;
@@ -72,6 +110,7 @@ class Pool {
         while ((int)threads_.size() < nworkers) {
             const int id = (int)threads_.size();
             threads_.emplace_back([this, id] { loop(id); });
+            if (have_affinity_) pthread_setaffinity_np(threads_.back().native_handle(), sizeof(affinity_), &affinity_);
         }
     }
     void work(int slot) {
@@ -120,6 +159,8 @@ class Pool {
     std::atomic<int64_t> spin_ns_{0};
     std::atomic<uint64_t> pre_{0};
     std::atomic<bool> stop_{false};
+    cpu_set_t affinity_;
+    bool have_affinity_ = false;
 };
 
 struct Philox {

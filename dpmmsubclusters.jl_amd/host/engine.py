@@ -135,7 +135,7 @@ def python_worker_table(worker, comm=None):
     return t, [worker, keep, cbs]
 
 
-OPT_HARD_CLUSTERING, OPT_F32_QUIRK, OPT_THREADS, OPT_SHARE_WORK, OPT_SPIN_US, OPT_PREWAKE = 1, 2, 3, 4, 5, 6
+OPT_HARD_CLUSTERING, OPT_F32_QUIRK, OPT_THREADS, OPT_SHARE_WORK, OPT_SPIN_US, OPT_PREWAKE, OPT_NUMA_NODE = 1, 2, 3, 4, 5, 6, 7
 
 _FIELDS = {  # name -> (dtype, trailing shape as a function of (K, D, hist_len, stride), rows factor)
     "N": (np.float64, lambda K, D, H, S: (3 * K,)), "sums": (np.float64, lambda K, D, H, S: (3 * K, D)),

@@ -119,6 +119,8 @@ class DPMMSampler:
         m.set_option(_engine.OPT_HARD_CLUSTERING, 1.0 if self.hard_clustering else 0.0)
         m.set_option(_engine.OPT_F32_QUIRK, 1.0 if self.f32_quirk else 0.0)
         m.set_option(_engine.OPT_THREADS, self.nthreads)
+        if hasattr(self.wk, "numa_node"):        # two-socket hosts: the master's threads next to the GPU's host memory
+            m.set_option(_engine.OPT_NUMA_NODE, self.wk.numa_node())
         if self.outlier_weight > 0:
             self._set_prior(1, self.outlier_prior)
             m.set_outlier(self.outlier_weight)

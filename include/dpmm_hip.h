@@ -145,6 +145,9 @@ int dpmm_commit_params(dpmm_ctx *ctx, int K);
  * the next dpmm_sweep. */
 int dpmm_set_num_clusters(dpmm_ctx *ctx, int K);
 int dpmm_num_clusters(const dpmm_ctx *ctx);   /* the K last declared (0 before the first parameters) */
+/* NUMA node of the host the ctx's GPU hangs off (sysfs numa_node of its PCI function), -1 when unknown: the master's threads
+ * read 1-17 MB of device-written rows and stage as much for the device per sweep -- on a two-socket host they belong on that node. */
+int dpmm_numa_node(dpmm_ctx *ctx);
 
 /* One label + sub-label sampling pass over the shard.
  * Replaces sample_labels_worker! (local_clusters_actions.jl:112-134; log_likelihood!

@@ -85,7 +85,8 @@ enum {
     DPMMH_OPT_SHARE_WORK = 4,        /* world > 1: 1 = every rank computes the distributions of "its" slots only and the
                                         results are exchanged (worker.allgather); 0 = every rank computes everything */
     DPMMH_OPT_SPIN_US = 5,           /* bounded polling of the pool's workers between back-to-back parallel regions (default 150) */
-    DPMMH_OPT_PREWAKE = 6            /* 1 (default): wake the pool ~60 us before the statistics of a step are expected back */
+    DPMMH_OPT_PREWAKE = 6,           /* 1 (default): wake the pool ~60 us before the statistics of a step are expected back */
+    DPMMH_OPT_NUMA_NODE = 7          /* >= 0: keep the pool's and the helper's threads on the CPUs of this NUMA node (the GPU's: worker numa_node); -1: leave them alone (default) */
 };
 
 int dpmmh_abi_version(void);
