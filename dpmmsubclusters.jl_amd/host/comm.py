@@ -24,16 +24,6 @@ class TorchDistComm:
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.backend = dist.get_backend()
         self.device = int(os.environ.get("LOCAL_RANK", 0)) if device is None else device
-        if os.environ.get("DPMM_BENCH_SHARE_DEVICE"):
-            self.device = 0
-        self._buf = None
-
-    def _buffer(self, n):
-        t = self.torch
-        if self._buf is None or self._buf.numel() < n:
-            dev = f"cuda:{self.device}" if self.backend == "nccl" else "cpu"
-            self._buf = t.empty(n, dtype=t.float64, device=dev)
-        return self._buf[:n]
 
     def attach(self, worker):
         """Multi-GPU: create the RCCL communicator INSIDE libdpmmhip.so (dpmm_comm_init); from then on the worker's statistics
@@ -79,18 +69,6 @@ class TorchDistComm:
         rop = {"sum": self.dist.ReduceOp.SUM, "min": self.dist.ReduceOp.MIN, "max": self.dist.ReduceOp.MAX}[op]
         self.dist.all_reduce(t, op=rop)
         return t.cpu().numpy()
-
-    def broadcast(self, arr, src=0):
-        """In-place broadcast of a C-contiguous numpy array from rank `src` (leader mode of the sampler)."""
-        t = self.torch.from_numpy(arr)
-        if self.backend == "nccl":
-            d = t.to(f"cuda:{self.device}")
-            self.dist.broadcast(d, src)
-            if self.rank != src:
-                t.copy_(d.cpu())
-        else:
-            self.dist.broadcast(t, src)
-        return arr
 
     def broadcast_int(self, v):
         obj = [int(v)]

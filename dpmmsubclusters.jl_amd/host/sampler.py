@@ -38,9 +38,6 @@ class LocalComm:
     """Single process, single GPU: the statistics come straight off the device."""
     rank, world = 0, 1
 
-    def reduce_stats(self, worker, idx):
-        return worker.suffstats_packed(idx)
-
     def gather_labels(self, worker):
         return worker.get_labels()
 
@@ -49,9 +46,6 @@ class LocalComm:
 
     def reduce_f64(self, arr, op="sum"):
         return np.asarray(arr, np.float64)
-
-    def broadcast(self, arr, src=0):
-        return arr
 
     def attach(self, worker):
         """Single rank: nothing to attach."""
