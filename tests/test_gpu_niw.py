@@ -363,3 +363,33 @@ def test_maximum_cluster_count(pkg):
     with pytest.raises(pkg.DpmmError):
         wk.set_num_clusters(K + 1)
     wk.close()
+
+
+@pytest.mark.parametrize("D,n,K", [(64, 40000, 6), (128, 30000, 5), (256, 20000, 4)])
+def test_tile_schedule_does_not_change_results(pkg, D, n, K):
+    """The random stream is keyed by the point, so neither the number of workgroups (DPMM_OPT_SWEEP_GRID) nor the order in which
+    the tile queue of the D >= 128 kernel hands tiles out may change a label or a sub-label; the second sweep runs with the
+    ordered visiting order and the boundary-tile references active."""
+    from dpmmsubclusters_jl_amd import binding
+    P = make_problem(D, n, K, seed=31, sep=1.2, sorted_points=True)
+    ref = None
+    for grid in (0, 7, 64):
+        wk = gpu_worker(pkg, P, seed=11)
+        if grid:
+            wk.set_option(binding.OPT_SWEEP_GRID, grid)
+        wk.sweep(1)
+        wk.suffstats_packed(None)          # builds the bin-sorted order the next sweep visits the points in
+        wk.sweep(2)
+        got = wk.get_labels()
+        wk.close()
+        if ref is None:
+            ref = got
+        else:
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+
+
+def test_numa_node_query(pkg):
+    P = make_problem(4, 100, 2, seed=1)
+    wk = gpu_worker(pkg, P, seed=1)
+    assert wk.numa_node() >= -1
+    wk.close()

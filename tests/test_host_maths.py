@@ -274,3 +274,26 @@ def test_engine_burn_in_gate_matches_hand_computation(host):
     conc = np.concatenate([N[:, 0], [s.alpha]])
     np.testing.assert_allclose(ws.mean(0), (conc / conc.sum())[:K], atol=5e-3)
     assert np.all(np.abs(lrs.sum(2) - 1) < 1e-6) and np.all(ws.sum(1) < 1.0)
+
+
+def test_numa_option_and_prewake_are_harmless(host):
+    """DPMMH_OPT_NUMA_NODE binds the pool to a node's CPUs (a missing node or an empty intersection is ignored) and
+    DPMMH_OPT_PREWAKE toggles the timed wake-up: neither may change a result."""
+    from fake_worker import FakeWorker
+    engine = importlib.import_module("dpmmsubclusters_jl_amd.host.engine")
+    x, y = host.generate_gaussian_data(400, 2, 3, 60.0, seed=3)[:2]
+    x = x.astype(np.float32)
+    hyper = host.niw_hyperparams(1.0, np.zeros(2), 5, np.eye(2))
+    labels = []
+    for node, pre in ((-1, 1), (0, 0), (9999, 1)):
+        wk = FakeWorker(0, 2, x.shape[1]); wk.upload_points(x.T.copy())
+        s = host.DPMMSampler(wk, hyper, 10.0, x.shape[1], seed=5, burnout=3, nthreads=3)
+        s._configure()
+        s.model.set_option(engine.OPT_NUMA_NODE, node)
+        s.model.set_option(engine.OPT_PREWAKE, pre)
+        s.init_first_clusters(2)
+        for _ in range(6):
+            s.group_step(False, False)
+        labels.append(wk.get_labels())
+    for l in labels[1:]:
+        assert np.array_equal(l[0], labels[0][0]) and np.array_equal(l[1], labels[0][1])
