@@ -32,6 +32,13 @@ ABI = [
     ("dpmm_set_num_clusters", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("dpmm_num_clusters", ctypes.c_int, [ctypes.c_void_p]),
     ("dpmm_numa_node", ctypes.c_int, [ctypes.c_void_p]),
+    ("dpmm_niw_master_setup", ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
+    ("dpmm_step_stats_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]),
+    ("dpmm_suffstats_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
+    ("dpmm_niw_master_posterior", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    ("dpmm_niw_master_draw", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    ("dpmm_niw_master_rows", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    ("dpmm_niw_master_draws", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     ("dpmm_sweep", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int]),
     ("dpmm_packed_stride", ctypes.c_int64, [ctypes.c_void_p]),
     ("dpmm_suffstats_packed_device", ctypes.c_int, [ctypes.c_void_p, _c_i64p, ctypes.c_int, ctypes.c_void_p]),
@@ -396,6 +403,44 @@ class Worker:
     def numa_node(self):
         """dpmm_numa_node: NUMA node of the host this context's GPU is attached to (-1: unknown)."""
         return int(self._lib.dpmm_numa_node(self._h))
+
+    # ---- the master's dense maths on the device (NIW)
+    def master_setup(self, kappa, nu, m, psi):
+        m = np.ascontiguousarray(m, np.float64); psi = np.ascontiguousarray(psi, np.float64)
+        self._chk(self._lib.dpmm_niw_master_setup(self._h, float(kappa), float(nu), m.ctypes.data, psi.ctypes.data))
+
+    def step_stats_device(self, reset_epoch):
+        bad = ctypes.c_void_p()
+        self._chk(self._lib.dpmm_step_stats_device(self._h, int(reset_epoch), ctypes.byref(bad)))
+        return np.ctypeslib.as_array(ctypes.cast(bad, ctypes.POINTER(ctypes.c_uint8)), shape=(self.K,)).copy()
+
+    def suffstats_device(self, cluster_idx=None):
+        idx = None if cluster_idx is None else np.ascontiguousarray(cluster_idx, np.int64)
+        self._chk(self._lib.dpmm_suffstats_device(self._h, None if idx is None else idx.ctypes.data, 0 if idx is None else len(idx)))
+
+    def master_posterior(self, clusters, slots):
+        """dpmm_niw_master_posterior: (n, 3, 4) float64 {N, kappa', nu', log det(nu' psi')} for the listed clusters (1-based)."""
+        slots = np.ascontiguousarray(slots, np.int32)
+        cl = None if clusters is None else np.ascontiguousarray(clusters, np.int64)
+        out = ctypes.c_void_p()
+        self._chk(self._lib.dpmm_niw_master_posterior(self._h, None if cl is None else cl.ctypes.data, slots.ctypes.data, len(slots), ctypes.byref(out)))
+        return np.ctypeslib.as_array(ctypes.cast(out, _c_f64p), shape=(len(slots), 3, 4)).copy()
+
+    def master_draw(self, epoch, slot_of_cluster, lr_weights, weights):
+        sl = np.ascontiguousarray(slot_of_cluster, np.int32)
+        lr = np.ascontiguousarray(lr_weights, np.float32); w = np.ascontiguousarray(weights, np.float32)
+        self._chk(self._lib.dpmm_niw_master_draw(self._h, int(epoch), len(sl), sl.ctypes.data, lr.ctypes.data, w.ctypes.data))
+
+    def master_rows(self, slots):
+        sl = np.ascontiguousarray(slots, np.int32)
+        out = np.empty((len(sl), 2, self.packed_stride), np.float64)
+        self._chk(self._lib.dpmm_niw_master_rows(self._h, sl.ctypes.data, len(sl), out.ctypes.data))
+        return out
+
+    def master_draws(self, K):
+        mu = np.empty((3 * K, self.D), np.float32); R = np.empty((3 * K, self.D, self.D), np.float32); ld = np.empty(3 * K, np.float32)
+        self._chk(self._lib.dpmm_niw_master_draws(self._h, int(K), mu.ctypes.data, R.ctypes.data, ld.ctypes.data))
+        return mu, R, ld
 
     def step_stats(self, reset_epoch):
         """dpmm_step_stats: (packed (2K, stride) float64, bad (K,) uint8) -- copies of the ctx's pinned output."""

@@ -102,6 +102,15 @@ struct dpmm_ctx {
     bool work_zeroed = false;          // the pack kernel cleared d_work and no sweep has run since
     int sel_all_ones = 0, sel_capacity = 0;   // sb.bin_sel[0..sel_all_ones) are known to be 1 (full passes skip the memset)
     long long *d_counts64 = nullptr;   // [2 * DPMM_MAX_CLUSTERS] global sub-cluster occupancies (multi-GPU)
+    // device master (niw_master.hip)
+    bool master = false;
+    NiwMasterArgs ma{};
+    double *d_m0 = nullptr, *d_psi_lo = nullptr, *d_Y = nullptr;
+    float *d_ld_sigma = nullptr;
+    int master_slots = 0, master_K = 0;            // capacities: slots (fac / mean / rows_store), clusters (Y / mu_draw)
+    uint8_t *h_master = nullptr;                   // pinned: jobs | slot map | lr | w | small
+    size_t h_master_bytes = 0;
+    bool draws_on_device = false;
     unsigned long long *d_work = nullptr;   // [8] executed-work counters of the last sweep [0..3] + its tile queue head [4]
     // options (dpmm_set_option)
     float opt_margin = 50.f;
@@ -335,6 +344,9 @@ int dpmm_destroy(dpmm_ctx *c) {
     hipFree(c->dX); hipFree(c->dX8); hipFree(c->dbins); hipFree(c->d_gt); hipFree(c->d_cont);
     hipFree(c->sb.tile_hist); hipFree(c->sb.bin_total); hipFree(c->sb.bin_start); hipFree(c->sb.item_start);
     hipFree(c->sb.perm); hipFree(c->sb.bin_sel); hipFree(c->sb.perm_total); hipFree(c->d_small); hipFree(c->d_proj); hipFree(c->d_vals); hipFree(c->d_smart);
+    hipFree(c->d_m0); hipFree(c->d_psi_lo); hipFree(c->d_Y); hipFree(c->d_ld_sigma);
+    hipFree(c->ma.fac); hipFree(c->ma.mean); hipFree(c->ma.kap); hipFree(c->ma.nu); hipFree(c->ma.rows_store); hipFree(c->ma.mu_draw);
+    if (c->h_master) hipHostFree(c->h_master);
     hipFree(c->d_counts64); hipFree(c->d_row_off); hipFree(c->d_work); hipFree(c->d_par);
     comm_release(c);
     if (c->h_pin) hipHostFree(c->h_pin);
@@ -611,6 +623,7 @@ int dpmm_commit_params(dpmm_ctx *c, int K) {
     c->K = K;
     c->have_params = true;
     c->predictive = false;
+    c->draws_on_device = false;
     return DPMM_OK;
 }
 
@@ -997,6 +1010,185 @@ int dpmm_step_stats(dpmm_ctx *c, uint32_t reset_epoch, const double **packed, co
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *packed = reinterpret_cast<const double *>(c->h_out);
     *bad = reinterpret_cast<const uint8_t *>(c->h_out + out_bytes);
+    return DPMM_OK;
+}
+
+// ---- the master's dense maths on the device --------------------------------------------------------------------------------
+static int master_pinned(dpmm_ctx *c, size_t bytes) {
+    if (bytes <= c->h_master_bytes) return DPMM_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->h_master) hipHostFree(c->h_master);
+    c->h_master = nullptr; c->h_master_bytes = 0;
+    size_t cap = 1 << 16;
+    while (cap < bytes) cap *= 2;
+    HIPCHK(c, hipHostMalloc((void **)&c->h_master, cap, hipHostMallocDefault));
+    c->h_master_bytes = cap;
+    return DPMM_OK;
+}
+// device storage for `slots` slots (posterior state, kept across growth) and K clusters (draw scratch)
+static int master_capacity(dpmm_ctx *c, int slots, int K) {
+    const size_t DP = (size_t)c->ma.DP, stride = (size_t)c->packed_stride;
+    if (slots > c->master_slots) {
+        int ns = std::max(8, c->master_slots);
+        while (ns < slots) ns *= 2;
+        ns = std::min(ns, DPMM_MAX_CLUSTERS);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        double *fac = nullptr, *mean = nullptr, *kap = nullptr, *nu = nullptr, *rows = nullptr;
+        HIPCHK(c, hipMalloc(&fac, sizeof(double) * 3 * ns * DP * DP));
+        HIPCHK(c, hipMalloc(&mean, sizeof(double) * 3 * ns * DP));
+        HIPCHK(c, hipMalloc(&kap, sizeof(double) * 3 * ns));
+        HIPCHK(c, hipMalloc(&nu, sizeof(double) * 3 * ns));
+        HIPCHK(c, hipMalloc(&rows, sizeof(double) * 2 * ns * stride));
+        if (c->master_slots > 0) {
+            const size_t os = (size_t)c->master_slots;
+            HIPCHK(c, hipMemcpy(fac, c->ma.fac, sizeof(double) * 3 * os * DP * DP, hipMemcpyDeviceToDevice));
+            HIPCHK(c, hipMemcpy(mean, c->ma.mean, sizeof(double) * 3 * os * DP, hipMemcpyDeviceToDevice));
+            HIPCHK(c, hipMemcpy(kap, c->ma.kap, sizeof(double) * 3 * os, hipMemcpyDeviceToDevice));
+            HIPCHK(c, hipMemcpy(nu, c->ma.nu, sizeof(double) * 3 * os, hipMemcpyDeviceToDevice));
+            HIPCHK(c, hipMemcpy(rows, c->ma.rows_store, sizeof(double) * 2 * os * stride, hipMemcpyDeviceToDevice));
+        }
+        hipFree(c->ma.fac); hipFree(c->ma.mean); hipFree(c->ma.kap); hipFree(c->ma.nu); hipFree(c->ma.rows_store);
+        c->ma.fac = fac; c->ma.mean = mean; c->ma.kap = kap; c->ma.nu = nu; c->ma.rows_store = rows;
+        c->master_slots = ns;
+    }
+    if (K > c->master_K) {
+        int nk = std::max(8, c->master_K);
+        while (nk < K) nk *= 2;
+        nk = std::min(nk, DPMM_MAX_CLUSTERS);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipFree(c->d_Y); hipFree(c->d_ld_sigma); hipFree(c->ma.mu_draw);
+        c->d_Y = nullptr; c->d_ld_sigma = nullptr; c->ma.mu_draw = nullptr;
+        HIPCHK(c, hipMalloc(&c->d_Y, sizeof(double) * 3 * nk * DP * DP));
+        HIPCHK(c, hipMalloc(&c->d_ld_sigma, sizeof(float) * 3 * nk));
+        HIPCHK(c, hipMalloc(&c->ma.mu_draw, sizeof(float) * 3 * nk * DP));
+        c->master_K = nk;
+    }
+    return DPMM_OK;
+}
+
+int dpmm_niw_master_setup(dpmm_ctx *c, double kappa, double nu, const double *m, const double *psi) {
+    if (!c || !m || !psi) return DPMM_EINVAL;
+    if (c->prior != DPMM_PRIOR_NIW) return fail(c, DPMM_EINVAL, "the device master exists for the NIW prior only");
+    if (c->D > DPMM_MASTER_MAXD) return fail(c, DPMM_ELIMIT, "D exceeds the device master's limit");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int D = c->D;
+    const size_t T = (size_t)D * (D + 1) / 2;
+    std::vector<double> lo(T);
+    for (int a = 0; a < D; ++a)
+        for (int b = 0; b <= a; ++b) lo[(size_t)a * (a + 1) / 2 + b] = 0.5 * (psi[(size_t)a * D + b] + psi[(size_t)b * D + a]);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!c->d_m0) HIPCHK(c, hipMalloc(&c->d_m0, sizeof(double) * D));
+    if (!c->d_psi_lo) HIPCHK(c, hipMalloc(&c->d_psi_lo, sizeof(double) * T));
+    HIPCHK(c, hipMemcpy(c->d_m0, m, sizeof(double) * D, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_psi_lo, lo.data(), sizeof(double) * T, hipMemcpyHostToDevice));
+    c->ma.D = D; c->ma.DP = 16 * ((D + 15) / 16); c->ma.packed_stride = c->packed_stride;
+    c->ma.kappa0 = kappa; c->ma.nu0 = nu; c->ma.m0 = c->d_m0; c->ma.psi_lo = c->d_psi_lo; c->ma.seed = c->seed;
+    c->master = true;
+    return DPMM_OK;
+}
+
+int dpmm_step_stats_device(dpmm_ctx *c, uint32_t reset_epoch, const uint8_t **bad) {
+    if (!c || !bad) return DPMM_EINVAL;
+    if (!c->master) return fail(c, DPMM_ESTATE, "dpmm_niw_master_setup first");
+    const size_t out_bytes = sizeof(double) * 2 * (size_t)std::max(c->K, 1) * (size_t)c->packed_stride;
+    if (int rc = ensure_out(c, DPMM_MAX_CLUSTERS + 64)) return rc;
+    if (int rc = run_stats(c, nullptr, 0, true, reset_epoch)) return rc;
+    HIPCHK(c, launch_copy_bytes(c->h_out, reinterpret_cast<const uint8_t *>(c->d_out) + out_bytes, (size_t)c->K + 1, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *bad = reinterpret_cast<const uint8_t *>(c->h_out);
+    return DPMM_OK;
+}
+
+int dpmm_suffstats_device(dpmm_ctx *c, const int64_t *idx, int n_idx) {
+    if (!c) return DPMM_EINVAL;
+    if (!c->master) return fail(c, DPMM_ESTATE, "dpmm_niw_master_setup first");
+    return run_stats(c, idx, n_idx);
+}
+
+int dpmm_niw_master_posterior(dpmm_ctx *c, const int64_t *clusters, const int32_t *slots, int n, const double **small) {
+    if (!c || !slots || !small || n < 0) return DPMM_EINVAL;
+    if (!c->master) return fail(c, DPMM_ESTATE, "dpmm_niw_master_setup first");
+    if (n == 0) { *small = nullptr; return DPMM_OK; }
+    HIPCHK(c, hipSetDevice(c->device));
+    int top = 0;
+    for (int i = 0; i < n; ++i) {
+        const int64_t k = clusters ? clusters[i] : i + 1;
+        if (k < 1 || k > c->K) return fail(c, DPMM_EINVAL, "cluster index out of range");
+        if (slots[i] < 0 || slots[i] >= DPMM_MAX_CLUSTERS) return fail(c, DPMM_EINVAL, "slot out of range");
+        top = std::max(top, slots[i] + 1);
+    }
+    if (int rc = master_capacity(c, top, 0)) return rc;
+    const size_t jobs_bytes = (sizeof(int32_t) * 2 * (size_t)n + 63) & ~(size_t)63;
+    if (int rc = master_pinned(c, jobs_bytes + sizeof(double) * 12 * (size_t)n)) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));            // nobody reads the pinned block any more
+    int32_t *jobs = reinterpret_cast<int32_t *>(c->h_master);
+    for (int i = 0; i < n; ++i) { jobs[2 * i] = (int32_t)((clusters ? clusters[i] : i + 1) - 1); jobs[2 * i + 1] = slots[i]; }
+    double *sm = reinterpret_cast<double *>(c->h_master + jobs_bytes);
+    HIPCHK(c, launch_niw_master_posterior(c->ma, jobs, n, c->d_out, sm, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *small = sm;
+    return DPMM_OK;
+}
+
+int dpmm_niw_master_draw(dpmm_ctx *c, uint32_t epoch, int K, const int32_t *slot_of_cluster, const float *lr, const float *w) {
+    if (!c || !slot_of_cluster || !lr || !w) return DPMM_EINVAL;
+    if (!c->master) return fail(c, DPMM_ESTATE, "dpmm_niw_master_setup first");
+    if (int rc = check_K(c, K)) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    for (int k = 0; k < K; ++k)
+        if (slot_of_cluster[k] < 0 || slot_of_cluster[k] >= c->master_slots) return fail(c, DPMM_EINVAL, "slot without a posterior on the device");
+    if (int rc = ensure_capacity(c, K)) return rc;
+    if (int rc = master_capacity(c, 0, K)) return rc;
+    // small inputs through a pinned block of their own (the posterior's block may still be read by its caller)
+    const size_t need = sizeof(int32_t) * K + sizeof(float) * 3 * (size_t)K;
+    if (int rc = ensure_pinned(c, need + 64)) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int32_t *hs = reinterpret_cast<int32_t *>(c->h_pin);
+    float *hlr = reinterpret_cast<float *>(c->h_pin + sizeof(int32_t) * K), *hw = hlr + 2 * K;
+    memcpy(hs, slot_of_cluster, sizeof(int32_t) * K);
+    memcpy(hlr, lr, sizeof(float) * 2 * K);
+    memcpy(hw, w, sizeof(float) * K);
+    c->have_tail = c->opt_tail && c->D >= 4 && c->D % 4 == 0 && K > 2;
+    HIPCHK(c, launch_niw_master_draw(c->ma, hs, K, epoch, c->d_Y, c->d_ld_sigma, hlr, hw, c->d_Rp, c->d_mup, c->d_cst,
+                                     c->have_tail ? c->d_tail : nullptr, c->NB, c->d_work, c->stream));
+    c->work_zeroed = true;
+    c->have_screen_prep = false;     // (the K > 64 far mask needs the raw factors: not built on this path; the tail screen is)
+    c->K = K;
+    c->have_params = true;
+    c->predictive = false;
+    c->draws_on_device = true;
+    return DPMM_OK;
+}
+
+int dpmm_niw_master_rows(dpmm_ctx *c, const int32_t *slots, int n, double *out) {
+    if (!c || !slots || !out || n < 0) return DPMM_EINVAL;
+    if (!c->master) return fail(c, DPMM_ESTATE, "dpmm_niw_master_setup first");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t stride = (size_t)c->packed_stride;
+    for (int i = 0; i < n; ++i) {
+        if (slots[i] < 0 || slots[i] >= c->master_slots) return fail(c, DPMM_EINVAL, "slot out of range");
+        HIPCHK(c, hipMemcpy(out + (size_t)i * 2 * stride, c->ma.rows_store + (size_t)slots[i] * 2 * stride, sizeof(double) * 2 * stride, hipMemcpyDeviceToHost));
+    }
+    return DPMM_OK;
+}
+
+int dpmm_niw_master_draws(dpmm_ctx *c, int K, float *mu, float *R, float *logdet) {
+    if (!c || !mu || !R || !logdet) return DPMM_EINVAL;
+    if (!c->master || !c->draws_on_device || K != c->K) return fail(c, DPMM_ESTATE, "no device draws for this K");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t D = (size_t)c->D, DP = (size_t)c->ma.DP;
+    std::vector<double> Y(3 * (size_t)K * DP * DP);
+    std::vector<float> m(3 * (size_t)K * DP);
+    HIPCHK(c, hipMemcpy(Y.data(), c->d_Y, sizeof(double) * Y.size(), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(m.data(), c->ma.mu_draw, sizeof(float) * m.size(), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(logdet, c->d_ld_sigma, sizeof(float) * 3 * (size_t)K, hipMemcpyDeviceToHost));
+    for (size_t j = 0; j < 3 * (size_t)K; ++j) {
+        for (size_t d = 0; d < D; ++d) mu[j * D + d] = m[j * DP + d];
+        for (size_t r = 0; r < D; ++r)
+            for (size_t cc = 0; cc < D; ++cc) R[(j * D + r) * D + cc] = cc >= r ? (float)Y[(j * DP + cc) * DP + r] : 0.f;
+    }
     return DPMM_OK;
 }
 

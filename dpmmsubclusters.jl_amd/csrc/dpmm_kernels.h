@@ -160,4 +160,25 @@ hipError_t launch_niw_stats(const StatsArgs &a, hipStream_t s);
 hipError_t launch_mult_stats(const StatsArgs &a, hipStream_t s);
 hipError_t launch_mult_stats_u8(const StatsArgs &a, const uint8_t *X8, int64_t ld8, hipStream_t s);
 
+// ---- the master's dense maths on the device (niw_master.hip) ----
+#define DPMM_MASTER_MAXD 256
+struct NiwMasterArgs {
+    int D, DP;                    // DP = 16 * ceil(D / 16)
+    int64_t packed_stride;
+    double kappa0, nu0;
+    const double *m0;             // [D]
+    const double *psi_lo;         // prior psi, symmetrised, packed lower triangle [D (D + 1) / 2]
+    double *fac;                  // [rows][DP][DP]  P = nu' psi' -> its factor L (row = 3 slot + w)
+    double *mean;                 // [rows][DP]      m'
+    double *kap, *nu;             // [rows]
+    double *rows_store;           // [slots][2][packed_stride]  statistics of every slot (left, right)
+    float *mu_draw;               // [3 K][DP]       the current draws' means (cluster order)
+    uint64_t seed;
+};
+size_t niw_master_lds_bytes(int DP);
+hipError_t launch_niw_master_posterior(const NiwMasterArgs &a, const int32_t *jobs, int njobs, const double *rows, double *small, hipStream_t s);
+hipError_t launch_niw_master_draw(const NiwMasterArgs &a, const int32_t *slot_of_cluster, int K, uint32_t epoch, double *Y, float *logdet_sigma,
+                                  const float *lr, const float *wts, float *Rp, float *mup, float *cst, float *tail, int NB,
+                                  unsigned long long *work, hipStream_t s);
+
 }  // namespace dpmm

@@ -282,6 +282,29 @@ int dpmm_last_sweep_work(dpmm_ctx *ctx, uint64_t *out8);
  *   dpmm_comm_init        every rank (one process per GPU) joins; collective
  * After dpmm_comm_init, dpmm_step_stats / dpmm_suffstats_host / dpmm_suffstats_packed return statistics summed over all ranks.
  * dpmm_comm_allgather_host gathers `bytes` of host data from every rank (all [world][bytes]); collective. */
+/* ---- the master's dense maths on the device (NIW prior; optional fast path for a master that otherwise works on the host) ----
+ * The 3K posteriors, their factorisations and the parameter draws of a sweep are O(K D^3) and need the full packed rows: at
+ * D = 256 that is 2-3 ms of host time and 30 MB over the host link per sweep.  With these calls the rows stay in HBM:
+ *   dpmm_niw_master_setup       prior (kappa, nu, m [D], psi [D][D] row-major) -> device; enables the calls below
+ *   dpmm_step_stats_device      dpmm_step_stats without the copy of the rows (*bad: [K] flags, pinned)
+ *   dpmm_suffstats_device       dpmm_suffstats_host without the copy (rows of the listed clusters, 1-based; NULL = all)
+ *   dpmm_niw_master_posterior   calc_posterior (src/priors/niw.jl:20-31) + factorisation nu' psi' = L' L for the listed clusters
+ *                               (1-based) of the LAST statistics pass, stored under their slots (rows 3 slot + {0: cluster, 1: left,
+ *                               2: right}); *small: pinned [n][3][4] = {N, kappa', nu', log det(nu' psi')} (NaN: not positive definite)
+ *   dpmm_niw_master_draw        sample_distribution (niw.jl:33-40) for all 3K distributions + the hand-over to the sweep kernels
+ *                               (replaces dpmm_params_staging / dpmm_commit_params for this sweep): Sigma^-1 = R'R ~ Wishart(nu',
+ *                               (nu' psi')^-1), mu ~ N(m', Sigma / kappa'); lr [K][2], w [K] as in dpmm_params_staging.  The random
+ *                               streams are the library's own (Philox, keyed by seed, position in cluster order, epoch).
+ *   dpmm_niw_master_rows        the stored statistics rows of the given slots -> out [n][2][1 + D + D(D+1)/2] (host)
+ *   dpmm_niw_master_draws       the current draws in cluster order: mu [3K][D], R [3K][D][D] (upper triangular, full), logdet [3K] */
+int dpmm_niw_master_setup(dpmm_ctx *ctx, double kappa, double nu, const double *m, const double *psi);
+int dpmm_step_stats_device(dpmm_ctx *ctx, uint32_t reset_epoch, const uint8_t **bad);
+int dpmm_suffstats_device(dpmm_ctx *ctx, const int64_t *cluster_idx, int n_idx);
+int dpmm_niw_master_posterior(dpmm_ctx *ctx, const int64_t *clusters, const int32_t *slots, int n, const double **small);
+int dpmm_niw_master_draw(dpmm_ctx *ctx, uint32_t epoch, int K, const int32_t *slot_of_cluster, const float *lr, const float *w);
+int dpmm_niw_master_rows(dpmm_ctx *ctx, const int32_t *slots, int n, double *out);
+int dpmm_niw_master_draws(dpmm_ctx *ctx, int K, float *mu, float *R, float *logdet);
+
 /* RCCL is bound at run time (dlopen): a copy already mapped into the process wins, then the soname, then /opt/rocm/lib.
  * dpmm_comm_use_library names the file to use instead (before the first dpmm_comm_* call) -- a host that also runs
  * torch.distributed passes torch's own librccl.so so that the process holds ONE copy. */

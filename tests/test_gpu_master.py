@@ -1,0 +1,93 @@
+"""The master's dense maths on the device (csrc/niw_master.hip) against numpy / the host formulas: posterior scalars and
+log-determinants, the distribution of the draws, and the hand-over to the sweep kernels."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    from __graft_entry__ import load_package
+    return load_package()
+
+
+def _setup(pkg, D, n, K, seed):
+    rng = np.random.default_rng(seed)
+    X = (rng.normal(size=(n, D)) * 1.5 + rng.normal(size=(K, D))[rng.integers(0, K, n)] * 4).astype(np.float32)
+    lab = rng.integers(1, K + 1, n); sub = rng.integers(1, 3, n)
+    wk = pkg.Worker(pkg.PRIOR_NIW, D, n, device=0, seed=seed)
+    wk.upload_points(X)
+    wk.set_labels(lab, sub)
+    wk.set_num_clusters(K)
+    A = rng.normal(size=(D, D)); psi = A @ A.T / D + np.eye(D)
+    psi[0, 1] += 0.01                                   # not exactly symmetric: the library symmetrises like the host
+    prior = (1.5, D + 3.0, rng.normal(size=D), psi)
+    return wk, X, lab, sub, prior
+
+
+def _posterior_numpy(prior, X, mask):
+    k0, v0, m0, psi = prior
+    psi = 0.5 * (psi + psi.T)
+    x = X[mask].astype(np.float64)
+    N = len(x)
+    if N == 0:
+        return 0.0, k0, v0, m0, v0 * psi
+    k1, v1 = k0 + N, v0 + N
+    s = x.sum(0); S = x.T @ x
+    m1 = (m0 * k0 + s) / k1
+    P = v0 * psi + k0 * np.outer(m0, m0) - k1 * np.outer(m1, m1) + S
+    return float(N), k1, v1, m1, P
+
+
+@pytest.mark.parametrize("D,n,K", [(2, 500, 3), (20, 3000, 4), (64, 6000, 5), (130, 4000, 3), (256, 3000, 2)])
+def test_posterior_scalars_and_logdet(pkg, D, n, K):
+    wk, X, lab, sub, prior = _setup(pkg, D, n, K, seed=D)
+    wk.master_setup(*prior)
+    wk.suffstats_device(None)
+    slots = np.arange(K, dtype=np.int32)[::-1].copy()       # any slot assignment
+    got = wk.master_posterior(None, slots)
+    for k in range(K):
+        for w, mask in enumerate((lab == k + 1, (lab == k + 1) & (sub == 1), (lab == k + 1) & (sub == 2))):
+            N, k1, v1, m1, P = _posterior_numpy(prior, X, mask)
+            assert got[k, w, 0] == N and got[k, w, 1] == k1 and got[k, w, 2] == v1
+            ld = np.linalg.slogdet(P)[1]
+            assert abs(got[k, w, 3] - ld) <= 1e-9 * max(1.0, abs(ld)), (k, w, got[k, w, 3], ld)
+    rows = wk.master_rows(slots)
+    ref = wk.suffstats_packed(None).reshape(K, 2, -1)
+    assert np.array_equal(rows, ref)
+    wk.close()
+
+
+@pytest.mark.parametrize("D", [3, 20, 70])
+def test_draw_distribution_and_handover(pkg, D):
+    n, K = 4000, 3
+    wk, X, lab, sub, prior = _setup(pkg, D, n, K, seed=100 + D)
+    wk.master_setup(*prior)
+    wk.suffstats_device(None)
+    slots = np.arange(K, dtype=np.int32)
+    wk.master_posterior(None, slots)
+    lr = np.full((K, 2), 0.5, np.float32); w = np.full(K, 1.0 / K, np.float32)
+    N, k1, v1, m1, P = _posterior_numpy(prior, X, lab == 1)
+    Pinv = np.linalg.inv(P)
+    reps = 600
+    W = np.zeros((D, D)); mus = np.zeros((reps, D)); lds = []
+    for ep in range(reps):
+        wk.master_draw(ep + 1, slots, lr, w)
+        mu, R, ld = wk.master_draws(K)
+        R0 = R[0].astype(np.float64)
+        assert np.allclose(np.tril(R0, -1), 0.0)
+        Wd = R0.T @ R0
+        assert abs(-np.linalg.slogdet(Wd)[1] - ld[0]) < 1e-3 * max(1.0, abs(ld[0]))        # logdet Sigma = -logdet(R'R)
+        W += Wd / reps; mus[ep] = mu[0]
+    EW = v1 * Pinv                                        # Wishart(nu', P^-1) mean
+    assert np.max(np.abs(W - EW)) < 0.15 * np.max(np.abs(np.diag(EW)))
+    assert np.max(np.abs(mus.mean(0) - m1)) < 6 * np.sqrt(np.max(np.diag(P)) / ((v1 - D - 1) * k1) / reps) + 1e-3
+    # hand-over: the table the sweep kernels evaluate from the packed images equals the one computed from the draws
+    mu, R, ld = wk.master_draws(K)
+    tab = wk.debug_loglik()
+    z = X[:, None, :].astype(np.float64) - mu[0::3][None].astype(np.float64)
+    y = np.einsum("kab,nkb->nka", R[0::3].astype(np.float64), z)
+    ref = -0.5 * (y ** 2).sum(-1) - 0.5 * ld[0::3][None] + np.log(w)[None]
+    assert np.allclose(tab.T, ref, rtol=2e-5, atol=2e-3)
+    wk.close()
