@@ -77,17 +77,19 @@ __global__ __launch_bounds__(256) void niw_form_kernel(NiwMasterArgs A, const in
         double mv = m0;
         if (N != 0.0 && a < D) mv = (m0 * k0 + (cl * l[1 + a] + cr * r[1 + a])) / k1;
         sm[a] = mv; sm0[a] = m0;
-        m[a] = mv;
+        if (blockIdx.y == 0) m[a] = mv;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && blockIdx.y == 0) {
         double *o = small + (int64_t)(3 * j + w) * 4;
         o[0] = N; o[1] = (N == 0.0) ? k0 : k1; o[2] = (N == 0.0) ? v0 : v1;
         A.kap[row] = o[1]; A.nu[row] = o[2];
     }
     const double *tl = l + 1 + D, *tr = r + 1 + D;
-    for (int64_t e = threadIdx.x; e < (int64_t)DP * DP; e += blockDim.x) {
-        const int a = (int)(e / DP), b = (int)(e - (int64_t)a * DP);
+    // rows a = blockIdx.y, blockIdx.y + gridDim.y, ... of the scale matrix; one thread per column
+    for (int a = blockIdx.y; a < DP; a += gridDim.y)
+    for (int b = threadIdx.x; b < DP; b += blockDim.x) {
+        const int64_t e = (int64_t)a * DP + b;
         double v = 0.0;
         if (b <= a) {
             if (a >= D) v = (a == b) ? 1.0 : 0.0;                   // padding: identity
@@ -166,11 +168,13 @@ __global__ __launch_bounds__(256) void niw_chol_kernel(NiwMasterArgs A, const in
             while (tk * (tk + 1) / 2 > t) --tk;
             const int tq = t - tk * (tk + 1) / 2;
             const int kk = 4 * tk, qq = 4 * tq;
-            double acc[4][4];
+            // the tile of P is requested BEFORE the products (its latency hides behind them); entries above the diagonal of a
+            // diagonal tile are read and written back unchanged (scratch)
+            double acc[4][4], pv[4][4];
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+                for (int b = 0; b < 4; ++b) { acc[a][b] = 0.0; pv[a][b] = P[(int64_t)(kk + a) * DP + qq + b]; }
 #pragma unroll 4
             for (int c = 0; c < 16; ++c) {
                 const double *wr = Wp + c * DP;
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(256) void niw_chol_kernel(NiwMasterArgs A, const in
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
-                    if (qq + b <= kk + a) P[(int64_t)(kk + a) * DP + qq + b] -= acc[a][b];
+                    P[(int64_t)(kk + a) * DP + qq + b] = pv[a][b] - acc[a][b];
         }
         __syncthreads();
     }
@@ -207,21 +211,38 @@ __global__ __launch_bounds__(256) void niw_draw_kernel(NiwMasterArgs A, const in
     double *T = lds;                     // [16][DP]
     double *Ld = lds + 16 * DP;          // [16][17]
     double *xi = Ld + 16 * 17;           // [DP]
-    // Bartlett factor (lower): chi on the diagonal, standard normals below, identity in the padding
-    for (int64_t e = tid; e < (int64_t)DP * DP; e += 256) {
-        const int r = (int)(e / DP), c = (int)(e - (int64_t)r * DP);
-        double v = 0.0;
-        if (r >= D) v = (r == c) ? 1.0 : 0.0;
-        else if (c < r) v = normal_from(philox4x32_10(A.seed, (id << 32) + (uint64_t)e, epoch, STREAM_M_NORMAL));
-        else if (c == r) v = sqrt(2.0 * gamma_mt(0.5 * (nu - r), A.seed, (id << 16) + (uint64_t)r, epoch));
-        Y[e] = v;
+    double *Lp = xi + DP;                // [16][DP]  rows i0 .. i0 + 15 of L, columns < i0
+    // Bartlett factor (lower): chi on the diagonal, standard normals below, identity in the padding.  One generator block gives
+    // the two normals of an element pair (2p, 2p + 1) of a row (Box-Muller, both branches).
+    const int HP = DP / 2;
+    for (int p2 = tid; p2 < DP * HP; p2 += 256) {
+        const int r = p2 / HP, c = 2 * (p2 - r * HP);
+        double n0 = 0.0, n1 = 0.0;
+        if (r >= D) { n0 = (c == r) ? 1.0 : 0.0; n1 = (c + 1 == r) ? 1.0 : 0.0; }
+        else if (c < r) {
+            const Philox4 g = philox4x32_10(A.seed, (id << 32) + (uint64_t)r * DP + c, epoch, STREAM_M_NORMAL);
+            const double u1 = u53(g.v[0], g.v[1]), u2 = u53(g.v[2], g.v[3]);
+            const double rad = sqrt(-2.0 * log(u1));
+            double sn, cs;
+            sincos(6.283185307179586476925 * u2, &sn, &cs);
+            n0 = rad * cs;
+            n1 = (c + 1 < r) ? rad * sn : 0.0;
+        }
+        Y[(int64_t)r * DP + c] = n0; Y[(int64_t)r * DP + c + 1] = n1;
     }
+    __syncthreads();
+    for (int r = tid; r < D; r += 256) Y[(int64_t)r * DP + r] = sqrt(2.0 * gamma_mt(0.5 * (nu - r), A.seed, (id << 16) + (uint64_t)r, epoch));
     for (int d = tid; d < DP; d += 256)
         xi[d] = d < D ? normal_from(philox4x32_10(A.seed, (id << 32) + (uint64_t)d, epoch, STREAM_M_XI)) : 0.0;
     __syncthreads();
     // L Y = A, block row by block row
     for (int ib = 0; ib < NB; ++ib) {
         const int i0 = 16 * ib, ncol = i0 + 16;             // columns 0 .. i0 + 15 of this block row can be non-zero
+        // the block row's part of L (columns < i0) -> LDS once: the products below read it 4 values per inner step
+        for (int a = 0; a < 16; ++a)
+            for (int kk = tid; kk < i0; kk += 256) Lp[a * DP + kk] = L[(int64_t)(i0 + a) * DP + kk];
+        { const int a = tid >> 4, b = tid & 15; Ld[a * 17 + b] = (b <= a) ? L[(int64_t)(i0 + a) * DP + i0 + b] : 0.0; }
+        __syncthreads();
         // T = A(ib, :) - L(ib, < i0) Y(< i0, :)   in 4 x 4 tiles: 4 row groups x ncol / 4 column groups
         const int ntile = 4 * (ncol / 4);
         for (int t = tid; t < ntile; t += 256) {
@@ -232,24 +253,32 @@ __global__ __launch_bounds__(256) void niw_draw_kernel(NiwMasterArgs A, const in
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) acc[a][b] = Y[(int64_t)(r0 + a) * DP + q0 + b];
-            // Y[kk][q] is zero for q > kk: start the inner dimension at the first row that reaches column q0
-            for (int kk = q0; kk < i0; ++kk) {
-                const double l0 = L[(int64_t)(r0 + 0) * DP + kk], l1 = L[(int64_t)(r0 + 1) * DP + kk];
-                const double l2 = L[(int64_t)(r0 + 2) * DP + kk], l3 = L[(int64_t)(r0 + 3) * DP + kk];
-                const double *yk = Y + (int64_t)kk * DP + q0;
-                const double y0 = yk[0], y1 = yk[1], y2 = yk[2], y3 = yk[3];
-                acc[0][0] -= l0 * y0; acc[0][1] -= l0 * y1; acc[0][2] -= l0 * y2; acc[0][3] -= l0 * y3;
-                acc[1][0] -= l1 * y0; acc[1][1] -= l1 * y1; acc[1][2] -= l1 * y2; acc[1][3] -= l1 * y3;
-                acc[2][0] -= l2 * y0; acc[2][1] -= l2 * y1; acc[2][2] -= l2 * y2; acc[2][3] -= l2 * y3;
-                acc[3][0] -= l3 * y0; acc[3][1] -= l3 * y1; acc[3][2] -= l3 * y2; acc[3][3] -= l3 * y3;
+            // Y[kk][q] is zero for q > kk: start the inner dimension at the first row that reaches column q0 (a multiple of 4, as
+            // is i0: the loop runs in steps of four with all loads of a step issued together)
+            const double *lp0 = Lp + (4 * rg) * DP;
+            for (int kk = q0; kk < i0; kk += 4) {
+                double yv[4][4], lv[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double *yk = Y + (int64_t)(kk + u) * DP + q0;
+                    yv[u][0] = yk[0]; yv[u][1] = yk[1]; yv[u][2] = yk[2]; yv[u][3] = yk[3];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) lv[u][a] = lp0[a * DP + kk + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) acc[a][b] -= lv[u][a] * yv[u][b];
             }
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) T[(4 * rg + a) * DP + q0 + b] = acc[a][b];
         }
-        { const int a = tid >> 4, b = tid & 15; Ld[a * 17 + b] = (b <= a) ? L[(int64_t)(i0 + a) * DP + i0 + b] : 0.0; }
         __syncthreads();
+        { const int a = tid >> 4, b = tid & 15; Ld[a * 17 + b] = (b <= a) ? L[(int64_t)(i0 + a) * DP + i0 + b] : 0.0; }
         // 16 x 16 triangular part: one thread per column
         for (int q = tid; q < ncol; q += 256) {
             double y[16];
@@ -357,11 +386,11 @@ __global__ void niw_master_pack_kernel(const double *__restrict__ Yall, const fl
     }
 }
 
-size_t niw_master_lds_bytes(int DP) { return sizeof(double) * ((size_t)16 * DP + 16 * 17 + DP); }
+size_t niw_master_lds_bytes(int DP) { return sizeof(double) * ((size_t)32 * DP + 16 * 17 + DP); }
 
 hipError_t launch_niw_master_posterior(const NiwMasterArgs &a, const int32_t *jobs, int njobs, const double *rows, double *small, hipStream_t s) {
     if (njobs <= 0) return hipSuccess;
-    hipLaunchKernelGGL(niw_form_kernel, dim3(3 * njobs), dim3(256), 0, s, a, jobs, rows, small);
+    hipLaunchKernelGGL(niw_form_kernel, dim3(3 * njobs, a.DP >= 64 ? 16 : 1), dim3(256), 0, s, a, jobs, rows, small);
     static bool attr = false;
     if (!attr) {
         hipFuncSetAttribute((const void *)niw_chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)niw_master_lds_bytes(DPMM_MASTER_MAXD));
