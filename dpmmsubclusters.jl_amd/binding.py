@@ -37,6 +37,7 @@ ABI = [
     ("dpmm_suffstats_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     ("dpmm_niw_master_posterior", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     ("dpmm_niw_master_draw", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    ("dpmm_niw_master_put_rows", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     ("dpmm_niw_master_rows", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     ("dpmm_niw_master_draws", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     ("dpmm_sweep", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int]),

@@ -1160,6 +1160,19 @@ int dpmm_niw_master_draw(dpmm_ctx *c, uint32_t epoch, int K, const int32_t *slot
     return DPMM_OK;
 }
 
+int dpmm_niw_master_put_rows(dpmm_ctx *c, const double *rows, int K) {
+    if (!c || !rows) return DPMM_EINVAL;
+    if (!c->master) return fail(c, DPMM_ESTATE, "dpmm_niw_master_setup first");
+    if (int rc = check_K(c, K)) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = ensure_capacity(c, K)) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(c->d_out, rows, sizeof(double) * 2 * (size_t)K * (size_t)c->packed_stride, hipMemcpyHostToDevice));
+    if (K != c->K) c->have_params = false;
+    c->K = K;
+    return DPMM_OK;
+}
+
 int dpmm_niw_master_rows(dpmm_ctx *c, const int32_t *slots, int n, double *out) {
     if (!c || !slots || !out || n < 0) return DPMM_EINVAL;
     if (!c->master) return fail(c, DPMM_ESTATE, "dpmm_niw_master_setup first");

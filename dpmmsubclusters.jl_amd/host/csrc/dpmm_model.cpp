@@ -164,6 +164,10 @@ struct dpmmh_model {
 
     // noise generated while the GPU sweeps
     Helper helper;
+    // device master (worker.niw_*): dev_state = the device holds the posteriors of every live slot; host_dense = the host's packed
+    // rows / means / factors are current (false while the device is the only one that has seen the latest statistics)
+    int opt_dev_master = -1;
+    bool dev_setup = false, dev_state = false, host_dense = true, dev_draw = false;
     bool prewake = true;
     double wait_ema = 0.0, t_stats_back = 0.0;
     static constexpr double kPrewakeLead = 60e-6;   // seconds before the predicted hand-back
@@ -185,9 +189,9 @@ struct dpmmh_model {
     const NiwPrior &niw_of(int s) const { return (outlier_weight > 0 && K > 0 && s == slot[0] && niw[1].set) ? niw[1] : niw[0]; }
     const MultPrior &mult_of(int s) const { return (outlier_weight > 0 && K > 0 && s == slot[0] && mult[1].set) ? mult[1] : mult[0]; }
     double *prow(int s, int side) { return packed.data() + ((size_t)s * 2 + side) * stride; }
-    double Nl(int s) { return prow(s, 0)[0]; }
-    double Nr(int s) { return prow(s, 1)[0]; }
-    double Nc(int s) { return prow(s, 0)[0] + prow(s, 1)[0]; }
+    double Nl(int s) { return Nrow[3 * s + 1]; }      // (from the posterior scalars: valid whether the rows live on the host or the device)
+    double Nr(int s) { return Nrow[3 * s + 2]; }
+    double Nc(int s) { return Nrow[3 * s + 1] + Nrow[3 * s + 2]; }
     uint32_t next_epoch() { return ++epoch; }
     bool has_outlier() const { return outlier_weight > 0; }
 
@@ -262,6 +266,56 @@ struct dpmmh_model {
         L[row] = dpmmh::mult_log_marginal(D, pr.alpha.data(), ap);
     }
 
+    // ---------------------------------------------------------------- device master
+    bool use_dev() {
+        if (kind != DPMMH_PRIOR_NIW || !W.niw_master_setup || !W.step_stats_device || !W.stats_device || !W.niw_posterior || !W.niw_draw ||
+            !W.niw_put_rows || !W.niw_rows || !W.niw_draws || has_outlier() || D > 256)
+            return false;
+        if (!(opt_dev_master == 1 || (opt_dev_master < 0 && D >= 128))) return false;
+        if (!dev_setup) {
+            const NiwPrior &pr = niw[0];
+            if (W.niw_master_setup(W.ctx, pr.kappa, pr.nu, pr.m.data(), pr.psi.data())) { wfail("niw_master_setup"); return false; }
+            dev_setup = true;
+        }
+        return true;
+    }
+    // posteriors + factorisations of clusters `ks` on the device (from the statistics pass that just ran); scalars come back
+    int ingest_device(const std::vector<int> &ks) {
+        const int n = (int)ks.size();
+        std::vector<int64_t> cl(n);
+        std::vector<int32_t> sl(n);
+        for (int i = 0; i < n; ++i) { cl[i] = ks[i] + 1; sl[i] = slot[ks[i]]; }
+        const double *sm = nullptr;
+        if (W.niw_posterior(W.ctx, cl.data(), sl.data(), n, &sm)) return wfail("niw_posterior");
+        const NiwPrior &pr = niw[0];
+        for (int i = 0; i < n; ++i) {
+            const int s = sl[i];
+            for (int w = 0; w < 3; ++w) {
+                const double *o = sm + (size_t)(3 * i + w) * 4;
+                const int row = 3 * s + w;
+                Nrow[row] = o[0]; kappa[row] = o[1]; nu[row] = o[2];
+                ldpsi[row] = o[3] - D * log(nu[row]);
+                L[row] = niw_marginal(pr, kappa[row], nu[row], ldpsi[row], o[0]);
+            }
+            points_count[s] = (int64_t)llrint(Nrow[3 * s]);
+        }
+        host_dense = false;
+        return 0;
+    }
+    // bring the host's dense state (packed rows, means, factors) up to date from the device's statistics
+    int pull_state() {
+        if (host_dense) return 0;
+        std::vector<int32_t> sl(K);
+        for (int k = 0; k < K; ++k) sl[k] = slot[k];
+        std::vector<double> rows((size_t)K * 2 * stride);
+        if (W.niw_rows(W.ctx, sl.data(), K, rows.data())) return wfail("niw_rows");
+        std::vector<int> ks(K);
+        for (int k = 0; k < K; ++k) ks[k] = k;
+        ingest(rows.data(), ks);
+        host_dense = true;
+        return 0;
+    }
+
     // statistics of clusters `ks` (cluster order) arrive as packed rows src[2k], src[2k+1]: store + posteriors
     void ingest(const double *src, const std::vector<int> &ks) {
         const int n = (int)ks.size();
@@ -307,7 +361,8 @@ struct dpmmh_model {
     // ... and wakes the pool shortly before the statistics are expected back (prediction: the previous steps' launch-to-statistics time)
     void start_noise(double t_launch = 0.0) {
         wait_noise();
-        const bool niw_noise = kind == DPMMH_PRIOR_NIW;
+        const bool niw_dev = kind == DPMMH_PRIOR_NIW && dev_draw;       // device draws make their own noise (a wrong guess costs an inline generation)
+        const bool niw_noise = kind == DPMMH_PRIOR_NIW && !niw_dev;
         const double pre_at = (prewake && nthreads > 1 && t_launch > 0.0 && wait_ema > 0.0) ? t_launch + wait_ema - kPrewakeLead : 0.0;
         const int rows = 3 * (K + 4);   // head-room for clusters born from splits
         const size_t DD = (size_t)D * D;
@@ -319,10 +374,10 @@ struct dpmmh_model {
         } else {
             if (noise_A.size() < (size_t)rows * D) { noise_A.resize((size_t)rows * D); noise_xi.resize((size_t)rows * D); }   // first-trial normals / uniforms
         }
-        noise_epoch = draw_epoch + 1; noise_rows = rows;
+        noise_epoch = draw_epoch + 1; noise_rows = niw_dev ? 0 : rows;
         const int nt = nthreads;
-        helper.submit([this, rows, DD, nt, niw_noise, pre_at] {
-            Pool::get().run(rows, nt, [&](int i, int) {
+        helper.submit([this, rows, DD, nt, niw_noise, niw_dev, pre_at] {
+            if (!niw_dev) Pool::get().run(rows, nt, [&](int i, int) {
                 if (niw_noise) dpmmh::niw_noise_one(D, seed, (uint32_t)i, noise_epoch, noise_A.data() + (size_t)i * DD, noise_xi.data() + (size_t)i * D,
                                                     noise_cx.data() + (size_t)i * D, noise_cu.data() + (size_t)i * D);
                 else dpmmh::dirichlet_noise_one(D, seed, (uint32_t)i, noise_epoch, noise_A.data() + (size_t)i * D, noise_xi.data() + (size_t)i * D);
@@ -345,8 +400,10 @@ struct dpmmh_model {
         draw_epoch += 1;
         const bool have_noise = noise_epoch == draw_epoch && noise_rows > 0;
         const size_t DD = (size_t)D * D;
+        const bool dev = kind == DPMMH_PRIOR_NIW && use_dev() && dev_state;     // the draws happen on the device, after the weights below
+        if (!dev) { if (int rc = pull_state()) return rc; }
         std::vector<std::vector<double>> scratch(std::max(1, nthreads));
-        Pool::get().run(3 * K, nthreads, [&](int id, int th) {
+        if (!dev) Pool::get().run(3 * K, nthreads, [&](int id, int th) {
             const int k = id / 3, w = id % 3, row = 3 * slot[k] + w;
             if (kind == DPMMH_PRIOR_NIW) {
                 auto &sc = scratch[th];
@@ -389,7 +446,13 @@ struct dpmmh_model {
             for (int k = k0; k < K; ++k) st_w[k] = (float)((g[k - k0] / sum) * (1.0 - outlier_weight));
             if (k0) st_w[0] = (float)outlier_weight;
         }
-        timers[T_MISC] += now_s() - t0;
+        timers[T_MISC] += now_s() - t0; t0 = now_s();
+        dev_draw = false;
+        if (dev) {      // sample_distribution for all 3K distributions + the hand-over to the sweep kernels, on the device (asynchronous)
+            if (W.niw_draw(W.ctx, draw_epoch, K, st_slot, st_lr, st_w)) return wfail("niw_draw");
+            dev_draw = true;
+            timers[T_SAMPLE] += now_s() - t0;
+        }
         return 0;
     }
 
@@ -397,7 +460,9 @@ struct dpmmh_model {
     int update_all_with_reset() {
         double t0 = now_s();
         const double *pk = nullptr; const uint8_t *bad = nullptr;
-        if (W.step_stats(W.ctx, next_epoch(), &pk, &bad)) return wfail("step_stats");
+        const bool dev = use_dev();
+        if (dev) { if (W.step_stats_device(W.ctx, next_epoch(), &bad)) return wfail("step_stats_device"); }
+        else if (W.step_stats(W.ctx, next_epoch(), &pk, &bad)) return wfail("step_stats");
         t_stats_back = now_s();
         helper.cancel();                       // a pre-wake still pending is late: drop it
         timers[T_STATS_WAIT] += t_stats_back - t0; t0 = t_stats_back;
@@ -408,7 +473,8 @@ struct dpmmh_model {
             if (bad[k]) { splittable[slot[k]] = 0; reset_hist(slot[k]); ++nbad; }     // reset_bad_clusters! (LCA:501-516)
         }
         bad_total += nbad; bad_steps += nbad ? 1 : 0;
-        ingest(pk, ks);
+        if (dev) { if (int rc = ingest_device(ks)) return rc; dev_state = true; }
+        else { ingest(pk, ks); host_dense = true; dev_state = false; }
         timers[T_POSTERIOR] += now_s() - t0;
         return 0;
     }
@@ -418,20 +484,38 @@ struct dpmmh_model {
         std::vector<int64_t> idx(ks.size());
         for (size_t i = 0; i < ks.size(); ++i) idx[i] = ks[i] + 1;
         const double *pk = nullptr;
+        if (use_dev() && dev_state) {
+            if (W.stats_device(W.ctx, idx.data(), (int)idx.size())) return wfail("stats_device");
+            timers[T_STATS_WAIT] += now_s() - t0; t0 = now_s();
+            if (int rc = ingest_device(ks)) return rc;
+            timers[T_POSTERIOR] += now_s() - t0;
+            return 0;
+        }
+        if (int rc = pull_state()) return rc;
         if (W.stats(W.ctx, idx.data(), (int)idx.size(), &pk)) return wfail("stats");
         timers[T_STATS_WAIT] += now_s() - t0; t0 = now_s();
         ingest(pk, ks);
+        dev_state = false;
         timers[T_POSTERIOR] += now_s() - t0;
         return 0;
     }
     int update_all_plain() {
         double t0 = now_s();
         const double *pk = nullptr;
-        if (W.stats(W.ctx, nullptr, 0, &pk)) return wfail("stats");
-        timers[T_STATS_WAIT] += now_s() - t0; t0 = now_s();
         std::vector<int> ks(K);
         for (int k = 0; k < K; ++k) ks[k] = k;
+        if (use_dev()) {
+            if (W.stats_device(W.ctx, nullptr, 0)) return wfail("stats_device");
+            timers[T_STATS_WAIT] += now_s() - t0; t0 = now_s();
+            if (int rc = ingest_device(ks)) return rc;
+            dev_state = true;
+            timers[T_POSTERIOR] += now_s() - t0;
+            return 0;
+        }
+        if (W.stats(W.ctx, nullptr, 0, &pk)) return wfail("stats");
+        timers[T_STATS_WAIT] += now_s() - t0; t0 = now_s();
         ingest(pk, ks);
+        host_dense = true; dev_state = false;
         timers[T_POSTERIOR] += now_s() - t0;
         return 0;
     }
@@ -476,7 +560,7 @@ struct dpmmh_model {
             copy_row_post(3 * si, 3 * si + 1); copy_row_post(3 * si + 2, 3 * si);
             for (int s : {si, sj}) {
                 splittable[s] = 0; reset_hist(s);
-                points_count[s] = (int64_t)llrint(prow(s, 0)[0]);
+                points_count[s] = (int64_t)llrint(Nrow[3 * s]);
             }
             slot.push_back(sj);
             idx.push_back(i + 1); nidx.push_back(j + 1);
@@ -561,6 +645,7 @@ struct dpmmh_model {
         std::vector<std::pair<int, int>> pairs;
         merge_candidates(pairs);
         if (pairs.empty()) return 0;
+        if (int rc = pull_state()) return rc;          // pooled statistics are formed from the host's rows
         merge_epoch += 1;
         double t0 = now_s();
         std::vector<double> lhr;
@@ -593,6 +678,7 @@ struct dpmmh_model {
             idx.push_back(i + 1); nidx.push_back(j + 1);
         }
         if (idx.empty()) return 0;
+        dev_state = false;                             // merged slots were rebuilt on the host: the next draws come from there
         if (W.merge(W.ctx, idx.data(), nidx.data(), (int)idx.size())) return wfail("merge");
         return 0;
     }
@@ -623,7 +709,7 @@ struct dpmmh_model {
     int group_step(bool no_more_splits, bool final) {
         if (int rc = sample_clusters()) return rc;                                   // 1
         double t0 = now_s();
-        if (W.commit_params(W.ctx, K)) return wfail("commit_params");                // 2
+        if (!dev_draw && W.commit_params(W.ctx, K)) return wfail("commit_params");   // 2 (device draws are handed over where they are made)
         timers[T_COMMIT] += now_s() - t0; t0 = now_s();
         if (W.sweep(W.ctx, next_epoch(), (final || hard) ? 1 : 0)) return wfail("sweep");   // 3 + 4 (asynchronous); LCA:661
         const double t_launch = now_s();
@@ -729,6 +815,7 @@ HAPI int dpmmh_model_set_option(dpmmh_model *m, int option, double value) {
         case DPMMH_OPT_SHARE_WORK: m->share_work = value != 0; return 0;
         case DPMMH_OPT_SPIN_US: Pool::get().set_spin_us((int)value); return 0;
         case DPMMH_OPT_PREWAKE: m->prewake = value != 0; return 0;
+        case DPMMH_OPT_DEVICE_MASTER: m->opt_dev_master = value < 0 ? -1 : (value != 0); if (!m->opt_dev_master) { if (m->pull_state()) return -1; m->dev_state = false; } return 0;
         case DPMMH_OPT_NUMA_NODE: {
             const int node = (int)value;
             Pool::get().set_numa_node(node);
@@ -864,6 +951,15 @@ HAPI int64_t dpmmh_model_get(dpmmh_model *m, const char *field, void *out, int64
     if (f == "nu") return emit(out, cap, rows_d(m->nu, 1));
     if (f == "logdet_psi") return emit(out, cap, rows_d(m->ldpsi, 1));
     if (f == "log_marginal") return emit(out, cap, rows_d(m->L, 1));
+    if (f == "packed" || f == "sums" || f == "S" || f == "m" || f == "U") {
+        if (m->pull_state()) return -1;              // the device may hold the only current copy of the rows
+    }
+    if (m->kind == DPMMH_PRIOR_NIW && m->dev_draw && (f == "mu" || f == "R" || f == "logdet")) {
+        // the current draws were made on the device: fetch them (cluster order)
+        std::vector<float> mu((size_t)3 * K * D), R((size_t)3 * K * DD), ld((size_t)3 * K);
+        if (m->W.niw_draws(m->W.ctx, K, mu.data(), R.data(), ld.data())) return m->wfail("niw_draws");
+        return emit(out, cap, f == "mu" ? mu : (f == "R" ? R : ld));
+    }
     if (f == "packed") {
         std::vector<double> v((size_t)2 * K * m->stride);
         for (int k = 0; k < K; ++k) memcpy(&v[(size_t)2 * k * m->stride], m->prow(m->slot[k], 0), sizeof(double) * 2 * m->stride);
@@ -956,6 +1052,12 @@ HAPI int dpmmh_model_set(dpmmh_model *m, const char *field, const void *in, int6
         std::vector<int> ks(K);
         for (int k = 0; k < K; ++k) ks[k] = k;
         m->ingest((const double *)in, ks);
+        m->host_dense = true; m->dev_state = false; m->dev_draw = false;
+        if (m->use_dev()) {      // the device gets the same rows, so that the next draws come from where a running chain makes them
+            if (m->W.niw_put_rows(m->W.ctx, (const double *)in, K)) return m->wfail("niw_put_rows");
+            if (int rc = m->ingest_device(ks)) return rc;
+            m->dev_state = true; m->host_dense = true;
+        }
         return 0;
     }
     auto rows_f = [&](float *dst, size_t w) {

@@ -19,6 +19,14 @@ F_INT = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_int)
 F_SWEEP = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_uint32, ctypes.c_int)
 F_STEP_STATS = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_uint32, _pp, _pp)
 F_STATS = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _i64p, ctypes.c_int, _pp)
+F_M_SETUP = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_double, ctypes.c_double, _vp, _vp)
+F_M_STEP = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_uint32, _pp)
+F_M_STATS = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _i64p, ctypes.c_int)
+F_M_POST = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _i64p, _vp, ctypes.c_int, _pp)
+F_M_DRAW = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_uint32, ctypes.c_int, _vp, _vp, _vp)
+F_M_PUT = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, ctypes.c_int)
+F_M_ROWS = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, ctypes.c_int, _vp)
+F_M_DRAWS = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp)
 F_SPLIT = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _i64p, _i64p, ctypes.c_int, ctypes.c_uint32)
 F_MERGE = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _i64p, _i64p, ctypes.c_int)
 F_REMOVE = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _i64p, ctypes.c_int)
@@ -35,7 +43,9 @@ class WorkerTable(ctypes.Structure):
                 ("params_staging", F_STAGING), ("commit_params", F_INT), ("set_num_clusters", F_INT), ("sweep", F_SWEEP),
                 ("step_stats", F_STEP_STATS), ("stats", F_STATS), ("split", F_SPLIT), ("merge", F_MERGE),
                 ("remove_empty", F_REMOVE), ("reset_sublabels", F_RESET), ("init_labels", F_INIT), ("allgather", F_GATHER),
-                ("last_error", F_ERR)]
+                ("last_error", F_ERR),
+                ("niw_master_setup", F_M_SETUP), ("step_stats_device", F_M_STEP), ("stats_device", F_M_STATS), ("niw_posterior", F_M_POST),
+                ("niw_draw", F_M_DRAW), ("niw_put_rows", F_M_PUT), ("niw_rows", F_M_ROWS), ("niw_draws", F_M_DRAWS)]
 
 
 _NATIVE_MAP = [("params_staging", "dpmm_params_staging", F_STAGING), ("commit_params", "dpmm_commit_params", F_INT),
@@ -43,7 +53,11 @@ _NATIVE_MAP = [("params_staging", "dpmm_params_staging", F_STAGING), ("commit_pa
                ("step_stats", "dpmm_step_stats", F_STEP_STATS), ("stats", "dpmm_suffstats_host", F_STATS),
                ("split", "dpmm_split", F_SPLIT), ("merge", "dpmm_merge", F_MERGE), ("remove_empty", "dpmm_remove_empty", F_REMOVE),
                ("reset_sublabels", "dpmm_reset_sublabels", F_RESET), ("init_labels", "dpmm_init_labels_from", F_INIT),
-               ("allgather", "dpmm_comm_allgather_host", F_GATHER), ("last_error", "dpmm_last_error", F_ERR)]
+               ("allgather", "dpmm_comm_allgather_host", F_GATHER), ("last_error", "dpmm_last_error", F_ERR),
+               ("niw_master_setup", "dpmm_niw_master_setup", F_M_SETUP), ("step_stats_device", "dpmm_step_stats_device", F_M_STEP),
+               ("stats_device", "dpmm_suffstats_device", F_M_STATS), ("niw_posterior", "dpmm_niw_master_posterior", F_M_POST),
+               ("niw_draw", "dpmm_niw_master_draw", F_M_DRAW), ("niw_put_rows", "dpmm_niw_master_put_rows", F_M_PUT),
+               ("niw_rows", "dpmm_niw_master_rows", F_M_ROWS), ("niw_draws", "dpmm_niw_master_draws", F_M_DRAWS)]
 
 
 def native_worker_table(worker, rank=0, world=1):
@@ -135,7 +149,7 @@ def python_worker_table(worker, comm=None):
     return t, [worker, keep, cbs]
 
 
-OPT_HARD_CLUSTERING, OPT_F32_QUIRK, OPT_THREADS, OPT_SHARE_WORK, OPT_SPIN_US, OPT_PREWAKE, OPT_NUMA_NODE = 1, 2, 3, 4, 5, 6, 7
+OPT_HARD_CLUSTERING, OPT_F32_QUIRK, OPT_THREADS, OPT_SHARE_WORK, OPT_SPIN_US, OPT_PREWAKE, OPT_NUMA_NODE, OPT_DEVICE_MASTER = 1, 2, 3, 4, 5, 6, 7, 8
 
 _FIELDS = {  # name -> (dtype, trailing shape as a function of (K, D, hist_len, stride), rows factor)
     "N": (np.float64, lambda K, D, H, S: (3 * K,)), "sums": (np.float64, lambda K, D, H, S: (3 * K, D)),

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DPMMH_ABI_VERSION 2
+#define DPMMH_ABI_VERSION 3
 
 typedef struct dpmmh_model dpmmh_model;
 
@@ -75,6 +75,18 @@ typedef struct dpmmh_worker {
     /* exchange of small host buffers among the ranks (world > 1 only): all[r*bytes ..] = rank r's `mine`.  dpmm_comm_allgather_host */
     int (*allgather)(void *ctx, const void *mine, int64_t bytes, void *all);
     const char *(*last_error)(void *ctx);                                                         /* dpmm_last_error */
+    /* OPTIONAL group (all or none; NULL when the worker has no device master): the dense per-distribution maths of the NIW
+     * master on the worker's device -- see dpmm_niw_master_* / dpmm_step_stats_device / dpmm_suffstats_device in dpmm_hip.h.
+     * The engine uses it when DPMMH_OPT_DEVICE_MASTER allows (default: D >= 128) and no outlier prior is set; everything it
+     * cannot do there (merge proposals, state access, a restored state) falls back to the host path through niw_rows. */
+    int (*niw_master_setup)(void *ctx, double kappa, double nu, const double *m, const double *psi);
+    int (*step_stats_device)(void *ctx, uint32_t reset_epoch, const uint8_t **bad);
+    int (*stats_device)(void *ctx, const int64_t *cluster_idx, int n_idx);
+    int (*niw_posterior)(void *ctx, const int64_t *clusters, const int32_t *slots, int n, const double **small);
+    int (*niw_draw)(void *ctx, uint32_t epoch, int K, const int32_t *slot_of_cluster, const float *lr, const float *w);
+    int (*niw_put_rows)(void *ctx, const double *rows, int K);
+    int (*niw_rows)(void *ctx, const int32_t *slots, int n, double *out);
+    int (*niw_draws)(void *ctx, int K, float *mu, float *R, float *logdet);
 } dpmmh_worker;
 
 /* Options (dpmmh_model_set_option). */
@@ -86,6 +98,7 @@ enum {
                                         results are exchanged (worker.allgather); 0 = every rank computes everything */
     DPMMH_OPT_SPIN_US = 5,           /* bounded polling of the pool's workers between back-to-back parallel regions (default 150) */
     DPMMH_OPT_PREWAKE = 6,           /* 1 (default): wake the pool ~60 us before the statistics of a step are expected back */
+    DPMMH_OPT_DEVICE_MASTER = 8,     /* NIW posteriors / factorisations / draws on the worker's device: 1 on, 0 off, -1 (default) for D >= 128 */
     DPMMH_OPT_NUMA_NODE = 7          /* >= 0: keep the pool's and the helper's threads on the CPUs of this NUMA node (the GPU's: worker numa_node); -1: leave them alone (default) */
 };
 
