@@ -167,7 +167,7 @@ struct dpmmh_model {
     // device master (worker.niw_*): dev_state = the device holds the posteriors of every live slot; host_dense = the host's packed
     // rows / means / factors are current (false while the device is the only one that has seen the latest statistics)
     int opt_dev_master = -1;
-    bool dev_setup = false, dev_state = false, host_dense = true, dev_draw = false;
+    bool dev_setup = false, dev_state = false, host_dense = true, host_rows = true, dev_draw = false;   // host_rows: the packed rows alone are current
     bool prewake = true;
     double wait_ema = 0.0, t_stats_back = 0.0;
     static constexpr double kPrewakeLead = 60e-6;   // seconds before the predicted hand-back
@@ -299,19 +299,26 @@ struct dpmmh_model {
             }
             points_count[s] = (int64_t)llrint(Nrow[3 * s]);
         }
-        host_dense = false;
+        host_dense = false; host_rows = false;
         return 0;
     }
-    // bring the host's dense state (packed rows, means, factors) up to date from the device's statistics
-    int pull_state() {
-        if (host_dense) return 0;
+    // bring the host's packed rows up to date from the device's statistics (merge proposals, state access) ...
+    int pull_rows() {
+        if (host_rows) return 0;
         std::vector<int32_t> sl(K);
         for (int k = 0; k < K; ++k) sl[k] = slot[k];
         std::vector<double> rows((size_t)K * 2 * stride);
         if (W.niw_rows(W.ctx, sl.data(), K, rows.data())) return wfail("niw_rows");
-        std::vector<int> ks(K);
-        for (int k = 0; k < K; ++k) ks[k] = k;
-        ingest(rows.data(), ks);
+        for (int k = 0; k < K; ++k) memcpy(prow(slot[k], 0), rows.data() + (size_t)k * 2 * stride, sizeof(double) * 2 * stride);
+        host_rows = true;
+        return 0;
+    }
+    // ... and the posteriors (means, factors) computed from them on the host (host draws, accepted merges, access to m / U)
+    int pull_state() {
+        if (host_dense) return 0;
+        if (int rc = pull_rows()) return rc;
+        std::vector<double> none;
+        Pool::get().run(3 * K, nthreads, [&](int item, int) { refresh_row(slot[item / 3], item % 3, none); });
         host_dense = true;
         return 0;
     }
@@ -474,7 +481,7 @@ struct dpmmh_model {
         }
         bad_total += nbad; bad_steps += nbad ? 1 : 0;
         if (dev) { if (int rc = ingest_device(ks)) return rc; dev_state = true; }
-        else { ingest(pk, ks); host_dense = true; dev_state = false; }
+        else { ingest(pk, ks); host_dense = true; host_rows = true; dev_state = false; }
         timers[T_POSTERIOR] += now_s() - t0;
         return 0;
     }
@@ -515,7 +522,7 @@ struct dpmmh_model {
         if (W.stats(W.ctx, nullptr, 0, &pk)) return wfail("stats");
         timers[T_STATS_WAIT] += now_s() - t0; t0 = now_s();
         ingest(pk, ks);
-        host_dense = true; dev_state = false;
+        host_dense = true; host_rows = true; dev_state = false;
         timers[T_POSTERIOR] += now_s() - t0;
         return 0;
     }
@@ -645,7 +652,7 @@ struct dpmmh_model {
         std::vector<std::pair<int, int>> pairs;
         merge_candidates(pairs);
         if (pairs.empty()) return 0;
-        if (int rc = pull_state()) return rc;          // pooled statistics are formed from the host's rows
+        if (int rc = pull_rows()) return rc;           // pooled statistics are formed from the host's rows
         merge_epoch += 1;
         double t0 = now_s();
         std::vector<double> lhr;
@@ -661,6 +668,7 @@ struct dpmmh_model {
             if (used[i] || used[j]) continue;
             const double u = Philox(seed, (uint32_t)(i * 65536 + j), merge_epoch, ST_MERGE).uniform();
             if (!((lhr[p] > log(u)) || (final && lhr[p] > log(0.1)))) continue;
+            if (int rc = pull_state()) return rc;      // an accepted merge rebuilds posteriors on the host (no-op when they are current)
             used[i] = used[j] = 1;
             const int si = slot[i], sj = slot[j];
             // merge_clusters_to_splittable (SA:12-18): left := old cluster i, right := old cluster j, cluster := their sum
@@ -951,9 +959,8 @@ HAPI int64_t dpmmh_model_get(dpmmh_model *m, const char *field, void *out, int64
     if (f == "nu") return emit(out, cap, rows_d(m->nu, 1));
     if (f == "logdet_psi") return emit(out, cap, rows_d(m->ldpsi, 1));
     if (f == "log_marginal") return emit(out, cap, rows_d(m->L, 1));
-    if (f == "packed" || f == "sums" || f == "S" || f == "m" || f == "U") {
-        if (m->pull_state()) return -1;              // the device may hold the only current copy of the rows
-    }
+    if (f == "packed" || f == "sums" || f == "S") { if (m->pull_rows()) return -1; }      // the device may hold the only current copy
+    if (f == "m" || f == "U") { if (m->pull_state()) return -1; }
     if (m->kind == DPMMH_PRIOR_NIW && m->dev_draw && (f == "mu" || f == "R" || f == "logdet")) {
         // the current draws were made on the device: fetch them (cluster order)
         std::vector<float> mu((size_t)3 * K * D), R((size_t)3 * K * DD), ld((size_t)3 * K);
@@ -1052,11 +1059,11 @@ HAPI int dpmmh_model_set(dpmmh_model *m, const char *field, const void *in, int6
         std::vector<int> ks(K);
         for (int k = 0; k < K; ++k) ks[k] = k;
         m->ingest((const double *)in, ks);
-        m->host_dense = true; m->dev_state = false; m->dev_draw = false;
+        m->host_dense = true; m->host_rows = true; m->dev_state = false; m->dev_draw = false;
         if (m->use_dev()) {      // the device gets the same rows, so that the next draws come from where a running chain makes them
             if (m->W.niw_put_rows(m->W.ctx, (const double *)in, K)) return m->wfail("niw_put_rows");
             if (int rc = m->ingest_device(ks)) return rc;
-            m->dev_state = true; m->host_dense = true;
+            m->dev_state = true; m->host_dense = true; m->host_rows = true;
         }
         return 0;
     }
