@@ -46,6 +46,7 @@ struct NiwPrior {
     bool set = false;
     double kappa = 0, nu = 0, logdet_psi = 0;
     std::vector<double> m, psi, psi_lo;   // psi_lo: symmetrised, packed lower triangle (hostmath.h)
+    double lmg0[2] = {0, 0};              // log_multivariate_gamma(nu / 2) in Float64 / Float32-quirk arithmetic
 };
 struct MultPrior {
     bool set = false;
@@ -248,8 +249,8 @@ struct dpmmh_model {
         L[row] = niw_marginal(pr, kappa[row], nu[row], ldpsi[row], N);
     }
     double niw_marginal(const NiwPrior &pr, double k1, double v1, double ld1, double N) const {
-        const double lmg0 = dpmmh::log_multivariate_gamma(pr.nu / 2.0, D, f32_quirk);
-        return dpmmh::niw_log_marginal(D, pr.kappa, pr.nu, pr.logdet_psi, lmg0, k1, v1, ld1, N, f32_quirk);
+        // log Gamma_D(nu0 / 2) is a constant of the prior (D lgamma evaluations): computed when the prior is set, for both arithmetic modes
+        return dpmmh::niw_log_marginal(D, pr.kappa, pr.nu, pr.logdet_psi, pr.lmg0[f32_quirk ? 1 : 0], k1, v1, ld1, N, f32_quirk);
     }
     void mult_row(int s, int w, const double *l, const double *r) {
         const MultPrior &pr = mult_of(s);
@@ -288,17 +289,15 @@ struct dpmmh_model {
         const double *sm = nullptr;
         if (W.niw_posterior(W.ctx, cl.data(), sl.data(), n, &sm)) return wfail("niw_posterior");
         const NiwPrior &pr = niw[0];
-        for (int i = 0; i < n; ++i) {
-            const int s = sl[i];
-            for (int w = 0; w < 3; ++w) {
-                const double *o = sm + (size_t)(3 * i + w) * 4;
-                const int row = 3 * s + w;
-                Nrow[row] = o[0]; kappa[row] = o[1]; nu[row] = o[2];
-                ldpsi[row] = o[3] - D * log(nu[row]);
-                L[row] = niw_marginal(pr, kappa[row], nu[row], ldpsi[row], o[0]);
-            }
-            points_count[s] = (int64_t)llrint(Nrow[3 * s]);
-        }
+        Pool::get().run(3 * n, nthreads, [&](int item, int) {           // D lgamma evaluations per log-marginal: worth the pool at D >= 128
+            const int i = item / 3, w = item % 3;
+            const double *o = sm + (size_t)item * 4;
+            const int row = 3 * sl[i] + w;
+            Nrow[row] = o[0]; kappa[row] = o[1]; nu[row] = o[2];
+            ldpsi[row] = o[3] - D * log(nu[row]);
+            L[row] = niw_marginal(pr, kappa[row], nu[row], ldpsi[row], o[0]);
+        });
+        for (int i = 0; i < n; ++i) points_count[sl[i]] = (int64_t)llrint(Nrow[3 * sl[i]]);
         host_dense = false; host_rows = false;
         return 0;
     }
@@ -795,6 +794,8 @@ HAPI int dpmmh_model_set_prior_niw(dpmmh_model *m, int which, double kappa, cons
     dpmmh::pack_sym_lower(D, psi, p.psi_lo.data());
     std::vector<double> tmp(p.psi);
     p.logdet_psi = dpmmh::logdet_spd_inplace(tmp.data(), D);
+    p.lmg0[0] = dpmmh::log_multivariate_gamma(p.nu / 2.0, D, false);
+    p.lmg0[1] = dpmmh::log_multivariate_gamma(p.nu / 2.0, D, true);
     p.set = true;
     return 0;
 }
