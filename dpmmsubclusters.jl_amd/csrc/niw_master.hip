@@ -241,8 +241,13 @@ __global__ __launch_bounds__(256) void niw_draw_kernel(NiwMasterArgs A, const in
     for (int ib = 0; ib < NB; ++ib) {
         const int i0 = 16 * ib, ncol = i0 + 16;             // columns 0 .. i0 + 15 of this block row can be non-zero
         // the block row's part of L (columns < i0) -> LDS once: the products below read it 4 values per inner step
-        for (int a = 0; a < 16; ++a)
-            for (int kk = tid; kk < i0; kk += 256) Lp[a * DP + kk] = L[(int64_t)(i0 + a) * DP + kk];
+        for (int kk = tid; kk < i0; kk += 256) {          // (i0 <= 240: one trip; the 16 loads of a thread are issued together)
+            double lrow[16];
+#pragma unroll
+            for (int a = 0; a < 16; ++a) lrow[a] = L[(int64_t)(i0 + a) * DP + kk];
+#pragma unroll
+            for (int a = 0; a < 16; ++a) Lp[a * DP + kk] = lrow[a];
+        }
         { const int a = tid >> 4, b = tid & 15; Ld[a * 17 + b] = (b <= a) ? L[(int64_t)(i0 + a) * DP + i0 + b] : 0.0; }
         __syncthreads();
         // T = A(ib, :) - L(ib, < i0) Y(< i0, :)   in 4 x 4 tiles: 4 row groups x ncol / 4 column groups
@@ -258,7 +263,8 @@ __global__ __launch_bounds__(256) void niw_draw_kernel(NiwMasterArgs A, const in
             // Y[kk][q] is zero for q > kk: start the inner dimension at the first row that reaches column q0 (a multiple of 4, as
             // is i0: the loop runs in steps of four with all loads of a step issued together)
             const double *lp0 = Lp + (4 * rg) * DP;
-            for (int kk = q0; kk < i0; kk += 4) {
+            int kk = q0;
+            for (; kk < i0; kk += 4) {
                 double yv[4][4], lv[4][4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -303,35 +309,36 @@ __global__ __launch_bounds__(256) void niw_draw_kernel(NiwMasterArgs A, const in
         for (int o = 32; o > 0; o >>= 1) lg += __shfl_xor(lg, o);
         if (tid == 0) logdet_sigma[blockIdx.x] = (float)(-2.0 * lg);
     }
-    // mu = m' + R^-1 xi / sqrt(kappa'):  R v = xi by back substitution in the column (axpy) form (column c of R = row c of Y), by the
-    // first wave alone: lane l owns elements l, l + 64, ...; no workgroup barriers in the D sequential steps
-    if (tid < 64) {
-        constexpr int PER = DPMM_MASTER_MAXD / 64;
-        double xr[PER], vr[PER];
-#pragma unroll
-        for (int i = 0; i < PER; ++i) { const int r = tid + 64 * i; xr[i] = r < D ? xi[r] : 0.0; vr[i] = 0.0; }
-        for (int c = D - 1; c >= 0; --c) {
-            const double *yc = Y + (int64_t)c * DP;
-            double mine = 0.0;
-#pragma unroll
-            for (int i = 0; i < PER; ++i) if (i == (c >> 6)) mine = xr[i];
-            const double vc = __shfl(mine, c & 63) / yc[c];
-#pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                const int r = tid + 64 * i;
-                if (r == c) vr[i] = vc;
-                if (r < c) xr[i] -= vc * yc[r];
+    // mu = m' + R^-1 xi / sqrt(kappa'):  R v = xi by back substitution in the column (axpy) form (column c of R = row c of Y), blocked by
+    // 16: the 16 x 16 diagonal block is solved from LDS by 16 lanes, the update of the remaining right-hand side is one coalesced pass of
+    // all threads over the block's 16 rows of Y (D sequential steps with a global load in each cost 90 us at D = 256)
+    double *vv = T;                                  // T is free now: v [DP]
+    __syncthreads();
+    for (int cb = NB - 1; cb >= 0; --cb) {
+        const int c0 = 16 * cb;
+        { const int a2 = tid >> 4, b2 = tid & 15; Ld[a2 * 17 + b2] = (b2 <= a2) ? Y[(int64_t)(c0 + a2) * DP + c0 + b2] : 0.0; }
+        __syncthreads();
+        if (tid < 16) {
+            double xb = xi[c0 + tid];
+            for (int a2 = 15; a2 >= 0; --a2) {
+                const double va = __shfl(xb, a2, 16) / Ld[a2 * 17 + a2];
+                if (tid == a2) vv[c0 + a2] = va;
+                if (tid < a2) xb -= va * Ld[a2 * 17 + tid];
             }
         }
-        const double isk = 1.0 / sqrt(kap);
-        const double *m = A.mean + (int64_t)row * DP;
-        float *mu_out = A.mu_draw + (int64_t)blockIdx.x * DP;
+        __syncthreads();
+        for (int r = tid; r < c0; r += 256) {
+            double acc = xi[r];
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int r = tid + 64 * i;
-            if (r < DP) mu_out[r] = r < D ? (float)(m[r] + vr[i] * isk) : 0.f;
+            for (int a2 = 0; a2 < 16; ++a2) acc -= vv[c0 + a2] * Y[(int64_t)(c0 + a2) * DP + r];
+            xi[r] = acc;
         }
+        __syncthreads();
     }
+    const double isk = 1.0 / sqrt(kap);
+    const double *m = A.mean + (int64_t)row * DP;
+    float *mu_out = A.mu_draw + (int64_t)blockIdx.x * DP;
+    for (int d = tid; d < DP; d += 256) mu_out[d] = d < D ? (float)(m[d] + vv[d] * isk) : 0.f;
 }
 
 // ------------------------------------------------------------------------------------------------------------------ pack

@@ -4,6 +4,10 @@ import numpy as np
 sys.path.insert(0, ".")
 from __graft_entry__ import load_package
 pkg = load_package()
+if len(sys.argv) > 4:      # alternative build of the worker library (diagnostic variants)
+    import os
+    b = importlib.import_module("dpmmsubclusters_jl_amd.binding")
+    alt = os.path.abspath(sys.argv[4]); b.lib_path = lambda: alt
 D, n, K = int(sys.argv[1]), int(float(sys.argv[2])), int(sys.argv[3])
 rng = np.random.default_rng(0)
 X = (rng.normal(size=(n, D)) + rng.normal(size=(K, D))[rng.integers(0, K, n)] * 4).astype(np.float32)
