@@ -1176,13 +1176,20 @@ int dpmm_niw_master_put_rows(dpmm_ctx *c, const double *rows, int K) {
 int dpmm_niw_master_rows(dpmm_ctx *c, const int32_t *slots, int n, double *out) {
     if (!c || !slots || !out || n < 0) return DPMM_EINVAL;
     if (!c->master) return fail(c, DPMM_ESTATE, "dpmm_niw_master_setup first");
+    if (n == 0) return DPMM_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    const size_t stride = (size_t)c->packed_stride;
-    for (int i = 0; i < n; ++i) {
+    const size_t stride = (size_t)c->packed_stride, bytes = sizeof(double) * 2 * (size_t)n * stride;
+    for (int i = 0; i < n; ++i)
         if (slots[i] < 0 || slots[i] >= c->master_slots) return fail(c, DPMM_EINVAL, "slot out of range");
-        HIPCHK(c, hipMemcpy(out + (size_t)i * 2 * stride, c->ma.rows_store + (size_t)slots[i] * 2 * stride, sizeof(double) * 2 * stride, hipMemcpyDeviceToHost));
-    }
+    // one gather kernel into pinned memory (n separate copies cost 6 us each), then a host copy to the caller's buffer
+    if (int rc = ensure_out(c, bytes)) return rc;
+    if (int rc = ensure_pinned(c, sizeof(int32_t) * (size_t)n + 64)) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(c->h_pin, slots, sizeof(int32_t) * (size_t)n);
+    HIPCHK(c, launch_niw_rows_gather(c->ma.rows_store, reinterpret_cast<const int32_t *>(c->h_pin), n, (int64_t)stride,
+                                     reinterpret_cast<double *>(c->h_out), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(out, c->h_out, bytes);
     return DPMM_OK;
 }
 

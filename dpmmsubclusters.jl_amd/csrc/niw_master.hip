@@ -19,6 +19,7 @@
 // synchronisation, not arithmetic, is what a 256 x 256 problem costs).  Measured and dropped: 512 threads per workgroup (factorisation
 // 5 % faster, draws 30 % slower), 1024 (half the register budget: spills), an explicit one-step prefetch of the Y rows in the solve's
 // product loop (+7 %: the register hand-over waits for the loads it was meant to overlap).
+#include <algorithm>
 #include "dpmm_device.h"
 #include "dpmm_kernels.h"
 
@@ -393,6 +394,22 @@ __global__ void niw_master_pack_kernel(const double *__restrict__ Yall, const fl
             tail[e] = v;
         }
     }
+}
+
+// rows_store[slots[i]] -> dst[i] (pinned host memory): the statistics rows of the listed slots in one pass
+__global__ void niw_rows_gather_kernel(const double *__restrict__ rows_store, const int32_t *__restrict__ slots, int n, int64_t two_stride,
+                                       double *__restrict__ dst) {
+    const int64_t total = (int64_t)n * two_stride;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e / two_stride);
+        dst[e] = rows_store[(int64_t)slots[i] * two_stride + (e - (int64_t)i * two_stride)];
+    }
+}
+hipError_t launch_niw_rows_gather(const double *rows_store, const int32_t *slots, int n, int64_t stride, double *dst, hipStream_t s) {
+    const int64_t total = (int64_t)n * 2 * stride;
+    const int grid = (int)std::min<int64_t>(4096, (total + 255) / 256);
+    hipLaunchKernelGGL(niw_rows_gather_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, s, rows_store, slots, n, 2 * stride, dst);
+    return hipGetLastError();
 }
 
 size_t niw_master_lds_bytes(int DP) { return sizeof(double) * ((size_t)32 * DP + 16 * 17 + DP); }
