@@ -133,10 +133,24 @@ def main():
     avg_sweep_ms = float(np.mean(sweep_ms))
     exe = float(np.mean([w["executed_flops"] for w in work]))
     achieved = flops_alg / (avg_sweep_ms * 1e-3) / 1e12
-    roof = {"kernel": "niw_sweep_direct_kernel<4,4,2>" if D <= 64 else "niw_sweep_kernel", "bound": "mfma",
+    # HBM bytes per launch of the sweep kernel: PMC counters need rocprofv3, so the figure comes from the committed counter summary of
+    # THIS command on this round's final build (profiles/, collected by scripts/collect_profiles.sh: FETCH_SIZE doubled per the gfx950
+    # note of MI355X_MICROARCH.md + WRITE_SIZE, in KiB) -- only for the configuration it was collected on, else null
+    traffic, traffic_source = None, None
+    pmc_file = os.path.join(ROOT, "profiles", "r02e_bench_pmc_summary.json")
+    if N == 10 ** 7 and D == 64 and world == 1 and os.path.exists(pmc_file):
+        try:
+            pm = json.load(open(pmc_file))
+            for name, c in pm.items():
+                if "niw_sweep_direct_kernel" in name:
+                    traffic = (2.0 * c["FETCH_SIZE"]["median"] + c["WRITE_SIZE"]["median"]) * 1024.0
+                    traffic_source = "profiles/r02e_bench_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, median per launch)"
+        except (OSError, ValueError, KeyError):
+            traffic = None
+    roof = {"kernel": "niw_sweep_direct_kernel<4,4,2,true>" if D <= 64 else "niw_sweep_kernel", "bound": "mfma",
             "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": exe / (avg_sweep_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-            "traffic": None,
+            "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": 4.0 * n_local * D + 4.0 * n_local,
             "avg_launch_ms": avg_sweep_ms, "algorithmic_flops_per_launch": flops_alg, "executed_flops_per_launch": exe,
             "executed_tflops": exe / (avg_sweep_ms * 1e-3) / 1e12, "pruning_factor": flops_alg / exe if exe else None,
             "algorithmic_frac": achieved / PEAK_F32_MFMA_TFLOPS,
