@@ -78,3 +78,16 @@ def test_fit_save_model_and_resume_on_gpu(host, tmp_path):
     assert len(model.checkpoints) == 2
     res, *_ = host.resume_from_checkpoint(model.checkpoints[0], x.astype(np.float32), 10, verbose=False)
     assert np.array_equal(res.labels, r[0]) and res.sampler.K == model.sampler.K
+
+
+def test_resume_continues_the_chain_with_the_device_master(host, tmp_path):
+    """D >= 128: posteriors, factorisations and draws run on the device (csrc/niw_master.hip).  A resumed run uploads the saved
+    statistics rows, so the device produces the same posteriors and -- with the restored epoch counters -- the same draws."""
+    x, y = host.generate_gaussian_data(4000, 130, 3, 60.0, seed=8)[:2]
+    x = x.astype(np.float32)
+    r = host.fit(x, 10.0, iters=10, seed=5, burnout=4, verbose=False, save_model=True, save_path=str(tmp_path) + "/", model_save_interval=5)
+    model = r[8]
+    assert len(model.checkpoints) == 2
+    res, *_ = host.resume_from_checkpoint(model.checkpoints[0], x, 10, verbose=False)
+    assert np.array_equal(res.labels, r[0]) and np.array_equal(res.labels_subcluster, model.labels_subcluster)
+    assert res.sampler.K == model.sampler.K and np.array_equal(res.sampler.weights, model.sampler.weights)
