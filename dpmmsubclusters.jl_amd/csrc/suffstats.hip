@@ -208,7 +208,8 @@ template <int NBK>
 struct StatCfg {
     static constexpr int NPAIR = NBK * (NBK + 1) / 2;
     static constexpr int DP = 16 * NBK;
-    static constexpr int NPANEL = (NBK <= 4) ? 1 : (NBK == 8 ? 2 : 4);
+    static constexpr int NPANEL = (NBK <= 4) ? 1 : (NBK == 8 ? 2 : 4);      // (D = 256 with EIGHT panels of 17 pairs -- two waves per SIMD, 251
+                                                                              // VGPRs, x one batch ahead -- was measured: 1.13 ms, the same as four panels)
     static constexpr int PP = (NPAIR + NPANEL - 1) / NPANEL;  // pairs per panel
 };
 
