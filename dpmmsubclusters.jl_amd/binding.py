@@ -37,6 +37,7 @@ ABI = [
     ("dpmm_suffstats_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     ("dpmm_niw_master_posterior", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     ("dpmm_niw_master_draw", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    ("dpmm_niw_master_pairs", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     ("dpmm_niw_master_put_rows", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     ("dpmm_niw_master_rows", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     ("dpmm_niw_master_draws", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
@@ -431,6 +432,13 @@ class Worker:
         sl = np.ascontiguousarray(slot_of_cluster, np.int32)
         lr = np.ascontiguousarray(lr_weights, np.float32); w = np.ascontiguousarray(weights, np.float32)
         self._chk(self._lib.dpmm_niw_master_draw(self._h, int(epoch), len(sl), sl.ctypes.data, lr.ctypes.data, w.ctypes.data))
+
+    def master_pairs(self, slots_i, slots_j):
+        """dpmm_niw_master_pairs: (n, 4) float64 {N, kappa', nu', log det(nu' psi')} of the pooled statistics of the slot pairs."""
+        a = np.ascontiguousarray(slots_i, np.int32); b = np.ascontiguousarray(slots_j, np.int32)
+        out = ctypes.c_void_p()
+        self._chk(self._lib.dpmm_niw_master_pairs(self._h, a.ctypes.data, b.ctypes.data, len(a), ctypes.byref(out)))
+        return np.ctypeslib.as_array(ctypes.cast(out, _c_f64p), shape=(len(a), 4)).copy()
 
     def master_rows(self, slots):
         sl = np.ascontiguousarray(slots, np.int32)

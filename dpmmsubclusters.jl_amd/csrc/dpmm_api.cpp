@@ -105,7 +105,8 @@ struct dpmm_ctx {
     // device master (niw_master.hip)
     bool master = false;
     NiwMasterArgs ma{};
-    double *d_m0 = nullptr, *d_psi_lo = nullptr, *d_Y = nullptr;
+    double *d_m0 = nullptr, *d_psi_lo = nullptr, *d_Y = nullptr, *d_pairs = nullptr;
+    size_t pair_cap = 0;                           // matrices in d_pairs (pooled pair scratch)
     float *d_ld_sigma = nullptr;
     int master_slots = 0, master_K = 0;            // capacities: slots (fac / mean / rows_store), clusters (Y / mu_draw)
     uint8_t *h_master = nullptr;                   // pinned: jobs | slot map | lr | w | small
@@ -344,7 +345,7 @@ int dpmm_destroy(dpmm_ctx *c) {
     hipFree(c->dX); hipFree(c->dX8); hipFree(c->dbins); hipFree(c->d_gt); hipFree(c->d_cont);
     hipFree(c->sb.tile_hist); hipFree(c->sb.bin_total); hipFree(c->sb.bin_start); hipFree(c->sb.item_start);
     hipFree(c->sb.perm); hipFree(c->sb.bin_sel); hipFree(c->sb.perm_total); hipFree(c->d_small); hipFree(c->d_proj); hipFree(c->d_vals); hipFree(c->d_smart);
-    hipFree(c->d_m0); hipFree(c->d_psi_lo); hipFree(c->d_Y); hipFree(c->d_ld_sigma);
+    hipFree(c->d_m0); hipFree(c->d_psi_lo); hipFree(c->d_Y); hipFree(c->d_ld_sigma); hipFree(c->d_pairs);
     hipFree(c->ma.fac); hipFree(c->ma.mean); hipFree(c->ma.kap); hipFree(c->ma.nu); hipFree(c->ma.rows_store); hipFree(c->ma.mu_draw);
     if (c->h_master) hipHostFree(c->h_master);
     hipFree(c->d_counts64); hipFree(c->d_row_off); hipFree(c->d_work); hipFree(c->d_par);
@@ -1157,6 +1158,34 @@ int dpmm_niw_master_draw(dpmm_ctx *c, uint32_t epoch, int K, const int32_t *slot
     c->have_params = true;
     c->predictive = false;
     c->draws_on_device = true;
+    return DPMM_OK;
+}
+
+int dpmm_niw_master_pairs(dpmm_ctx *c, const int32_t *slots_i, const int32_t *slots_j, int n, const double **small) {
+    if (!c || !slots_i || !slots_j || !small || n < 0) return DPMM_EINVAL;
+    if (!c->master) return fail(c, DPMM_ESTATE, "dpmm_niw_master_setup first");
+    if (n == 0) { *small = nullptr; return DPMM_OK; }
+    HIPCHK(c, hipSetDevice(c->device));
+    for (int i = 0; i < n; ++i)
+        if (slots_i[i] < 0 || slots_i[i] >= c->master_slots || slots_j[i] < 0 || slots_j[i] >= c->master_slots) return fail(c, DPMM_EINVAL, "slot out of range");
+    const size_t DP = (size_t)c->ma.DP;
+    if ((size_t)n > c->pair_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipFree(c->d_pairs); c->d_pairs = nullptr; c->pair_cap = 0;
+        size_t cap = 64;
+        while (cap < (size_t)n) cap *= 2;
+        HIPCHK(c, hipMalloc(&c->d_pairs, sizeof(double) * cap * DP * DP));
+        c->pair_cap = cap;
+    }
+    const size_t idx_bytes = (sizeof(int32_t) * 2 * (size_t)n + 63) & ~(size_t)63;
+    if (int rc = master_pinned(c, idx_bytes + sizeof(double) * 4 * (size_t)n)) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int32_t *pr = reinterpret_cast<int32_t *>(c->h_master);
+    for (int i = 0; i < n; ++i) { pr[2 * i] = slots_i[i]; pr[2 * i + 1] = slots_j[i]; }
+    double *sm = reinterpret_cast<double *>(c->h_master + idx_bytes);
+    HIPCHK(c, launch_niw_master_pairs(c->ma, pr, n, c->d_pairs, sm, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *small = sm;
     return DPMM_OK;
 }
 

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void niw_form_kernel(NiwMasterArgs A, const in
 // pivot is not positive).  One workgroup per job row (blockIdx.x = 3 j + w).
 __global__ __launch_bounds__(256) void niw_chol_kernel(NiwMasterArgs A, const int32_t *__restrict__ jobs, double *__restrict__ small) {
     const int j = blockIdx.x / 3, w = blockIdx.x % 3;
-    const int row = 3 * jobs[2 * j + 1] + w;
+    const int row = jobs ? 3 * jobs[2 * j + 1] + w : (int)blockIdx.x;      // jobs == nullptr: matrix blockIdx.x of A.fac (pair scratch)
     const int DP = A.DP, NB = DP / 16, tid = threadIdx.x;
     double *P = A.fac + (int64_t)row * DP * DP;
     extern __shared__ double lds[];
@@ -394,6 +394,58 @@ __global__ void niw_master_pack_kernel(const double *__restrict__ Yall, const fl
             tail[e] = v;
         }
     }
+}
+
+// Pooled statistics of cluster pairs for the merge proposals (shared_actions.jl:21-27): job p pools the four stored rows of slots
+// pairs[2p], pairs[2p+1]; P = nu' psi' of the pooled set -> scratch matrix p; small[4p + {0,1,2}] = N, kappa', nu'.
+__global__ __launch_bounds__(256) void niw_form_pair_kernel(NiwMasterArgs A, const int32_t *__restrict__ pairs, double *__restrict__ scratch,
+                                                            double *__restrict__ small) {
+    const int p = blockIdx.x;
+    const int D = A.D, DP = A.DP;
+    const int64_t stride = A.packed_stride;
+    const double *r0 = A.rows_store + (int64_t)(2 * pairs[2 * p]) * stride, *r1 = r0 + stride;
+    const double *r2 = A.rows_store + (int64_t)(2 * pairs[2 * p + 1]) * stride, *r3 = r2 + stride;
+    double *P = scratch + (int64_t)p * DP * DP;
+    __shared__ double sm[DPMM_MASTER_MAXD], sm0[DPMM_MASTER_MAXD];
+    const double N = r0[0] + r1[0] + r2[0] + r3[0];
+    const double k0 = A.kappa0, v0 = A.nu0, k1 = k0 + N, v1 = v0 + N;
+    for (int a = threadIdx.x; a < DP; a += blockDim.x) {
+        const double m0 = a < D ? A.m0[a] : 0.0;
+        double mv = m0;
+        if (N != 0.0 && a < D) mv = (m0 * k0 + (r0[1 + a] + r1[1 + a] + r2[1 + a] + r3[1 + a])) / k1;
+        sm[a] = mv; sm0[a] = m0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.y == 0) {
+        double *o = small + (int64_t)p * 4;
+        o[0] = N; o[1] = (N == 0.0) ? k0 : k1; o[2] = (N == 0.0) ? v0 : v1;
+    }
+    for (int a = blockIdx.y; a < DP; a += gridDim.y)
+        for (int b = threadIdx.x; b < DP; b += blockDim.x) {
+            double v = 0.0;
+            if (b <= a) {
+                if (a >= D) v = (a == b) ? 1.0 : 0.0;
+                else {
+                    const int64_t t = (int64_t)a * (a + 1) / 2 + b;
+                    const double pab = A.psi_lo[t];
+                    if (N == 0.0) v = pab * v0;
+                    else {
+                        const int64_t tt = 1 + D + t;
+                        const double sab = r0[tt] + r1[tt] + r2[tt] + r3[tt];
+                        v = ((v0 * pab + (k0 * sm0[a]) * sm0[b] - (k1 * sm[a]) * sm[b] + sab) / v1) * v1;
+                    }
+                }
+            }
+            P[(int64_t)a * DP + b] = v;
+        }
+}
+hipError_t launch_niw_master_pairs(const NiwMasterArgs &a, const int32_t *pairs, int n, double *scratch, double *small, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(niw_form_pair_kernel, dim3(n, a.DP >= 64 ? 16 : 1), dim3(256), 0, s, a, pairs, scratch, small);
+    NiwMasterArgs b = a;
+    b.fac = scratch;                                  // the factorisation kernel in "matrix blockIdx.x of fac" mode
+    hipLaunchKernelGGL(niw_chol_kernel, dim3(n), dim3(256), niw_master_lds_bytes(a.DP), s, b, (const int32_t *)nullptr, small);
+    return hipGetLastError();
 }
 
 // rows_store[slots[i]] -> dst[i] (pinned host memory): the statistics rows of the listed slots in one pass

@@ -168,6 +168,7 @@ struct dpmmh_model {
     // device master (worker.niw_*): dev_state = the device holds the posteriors of every live slot; host_dense = the host's packed
     // rows / means / factors are current (false while the device is the only one that has seen the latest statistics)
     int opt_dev_master = -1;
+    bool dev_pairs_ok = false;
     bool dev_setup = false, dev_state = false, host_dense = true, host_rows = true, dev_draw = false;   // host_rows: the packed rows alone are current
     bool prewake = true;
     double wait_ema = 0.0, t_stats_back = 0.0;
@@ -270,7 +271,7 @@ struct dpmmh_model {
     // ---------------------------------------------------------------- device master
     bool use_dev() {
         if (kind != DPMMH_PRIOR_NIW || !W.niw_master_setup || !W.step_stats_device || !W.stats_device || !W.niw_posterior || !W.niw_draw ||
-            !W.niw_put_rows || !W.niw_rows || !W.niw_draws || has_outlier() || D > 256)
+            !W.niw_pairs || !W.niw_put_rows || !W.niw_rows || !W.niw_draws || has_outlier() || D > 256)
             return false;
         if (!(opt_dev_master == 1 || (opt_dev_master < 0 && D >= 128))) return false;
         if (!dev_setup) {
@@ -642,6 +643,26 @@ struct dpmmh_model {
     }
     void merge_ratios(const std::vector<std::pair<int, int>> &pairs, std::vector<double> &lhr) {
         lhr.resize(pairs.size());
+        if (dev_pairs_ok) {
+            // pooled scale matrices and their log-determinants on the device, from the rows it keeps per slot
+            const int n = (int)pairs.size();
+            std::vector<int32_t> si(n), sj(n);
+            for (int p = 0; p < n; ++p) { si[p] = slot[pairs[p].first]; sj[p] = slot[pairs[p].second]; }
+            const double *sm = nullptr;
+            if (W.niw_pairs(W.ctx, si.data(), sj.data(), n, &sm) == 0) {
+                const NiwPrior &pr = niw[0];
+                Pool::get().run(n, nthreads, [&](int p, int) {
+                    const double *o = sm + (size_t)p * 4;
+                    const double Lp = o[0] == 0.0 ? niw_marginal(pr, pr.kappa, pr.nu, pr.logdet_psi, 0.0)
+                                                  : niw_marginal(pr, o[1], o[2], o[3] - D * log(o[2]), o[0]);
+                    lhr[p] = merge_log_hr(pairs[p].first, pairs[p].second, Lp);
+                });
+                return;
+            }
+            wfail("niw_pairs");      // fall through to the host path (rows are fetched below by the caller's pull_rows)
+            dev_pairs_ok = false;
+            pull_rows();
+        }
         std::vector<std::vector<double>> scratch(std::max(1, nthreads));
         Pool::get().run((int)pairs.size(), nthreads, [&](int p, int th) {
             lhr[p] = merge_log_hr(pairs[p].first, pairs[p].second, pooled_marginal(pairs[p].first, pairs[p].second, scratch[th]));
@@ -651,7 +672,8 @@ struct dpmmh_model {
         std::vector<std::pair<int, int>> pairs;
         merge_candidates(pairs);
         if (pairs.empty()) return 0;
-        if (int rc = pull_rows()) return rc;           // pooled statistics are formed from the host's rows
+        dev_pairs_ok = use_dev() && dev_state && !host_rows;     // the device has the rows: it forms and factorises the pooled matrices
+        if (!dev_pairs_ok) { if (int rc = pull_rows()) return rc; }          // else: pooled statistics are formed from the host's rows
         merge_epoch += 1;
         double t0 = now_s();
         std::vector<double> lhr;

@@ -295,6 +295,8 @@ int dpmm_last_sweep_work(dpmm_ctx *ctx, uint64_t *out8);
  *                               (replaces dpmm_params_staging / dpmm_commit_params for this sweep): Sigma^-1 = R'R ~ Wishart(nu',
  *                               (nu' psi')^-1), mu ~ N(m', Sigma / kappa'); lr [K][2], w [K] as in dpmm_params_staging.  The random
  *                               streams are the library's own (Philox, keyed by seed, position in cluster order, epoch).
+ *   dpmm_niw_master_pairs       pooled statistics of n slot pairs (check_and_merge!'s proposals, shared_actions.jl:21-27) -> *small: pinned
+ *                               [n][4] = {N, kappa', nu', log det(nu' psi')} of the pooled posterior under the cluster prior
  *   dpmm_niw_master_put_rows    rows [2K][1 + D + D(D+1)/2] from the host take the place of a statistics pass (restored state)
  *   dpmm_niw_master_rows        the stored statistics rows of the given slots -> out [n][2][1 + D + D(D+1)/2] (host)
  *   dpmm_niw_master_draws       the current draws in cluster order: mu [3K][D], R [3K][D][D] (upper triangular, full), logdet [3K] */
@@ -303,6 +305,7 @@ int dpmm_step_stats_device(dpmm_ctx *ctx, uint32_t reset_epoch, const uint8_t **
 int dpmm_suffstats_device(dpmm_ctx *ctx, const int64_t *cluster_idx, int n_idx);
 int dpmm_niw_master_posterior(dpmm_ctx *ctx, const int64_t *clusters, const int32_t *slots, int n, const double **small);
 int dpmm_niw_master_draw(dpmm_ctx *ctx, uint32_t epoch, int K, const int32_t *slot_of_cluster, const float *lr, const float *w);
+int dpmm_niw_master_pairs(dpmm_ctx *ctx, const int32_t *slots_i, const int32_t *slots_j, int n, const double **small);
 int dpmm_niw_master_put_rows(dpmm_ctx *ctx, const double *rows, int K);
 int dpmm_niw_master_rows(dpmm_ctx *ctx, const int32_t *slots, int n, double *out);
 int dpmm_niw_master_draws(dpmm_ctx *ctx, int K, float *mu, float *R, float *logdet);

@@ -168,3 +168,21 @@ def test_device_master_matches_host_path_statistics(pkg):
     assert out[0][0] == out[1][0] == Kt and out[0][1] > 0.99 and out[1][1] > 0.99
     # cluster-level log-marginals of the same partition agree (cluster order may differ between the chains)
     assert np.allclose(np.sort(out[0][2].reshape(-1, 3)[:, 0]), np.sort(out[1][2].reshape(-1, 3)[:, 0]), rtol=1e-9)
+
+
+@pytest.mark.parametrize("D", [5, 64, 140])
+def test_pooled_pair_logdets(pkg, D):
+    n, K = 3000, 4
+    wk, X, lab, sub, prior = _setup(pkg, D, n, K, seed=40 + D)
+    wk.master_setup(*prior)
+    wk.suffstats_device(None)
+    slots = np.array([2, 0, 3, 1], np.int32)                 # cluster k lives in slot slots[k]
+    wk.master_posterior(None, slots)
+    pairs = [(0, 1), (0, 3), (2, 3)]
+    got = wk.master_pairs([slots[i] for i, _ in pairs], [slots[j] for _, j in pairs])
+    for p, (i, j) in enumerate(pairs):
+        N, k1, v1, m1, P = _posterior_numpy(prior, X, (lab == i + 1) | (lab == j + 1))
+        ld = np.linalg.slogdet(P)[1]
+        assert got[p, 0] == N and got[p, 1] == k1 and got[p, 2] == v1
+        assert abs(got[p, 3] - ld) <= 1e-9 * max(1.0, abs(ld))
+    wk.close()
