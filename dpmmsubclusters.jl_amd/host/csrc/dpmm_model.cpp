@@ -273,7 +273,7 @@ struct dpmmh_model {
         if (kind != DPMMH_PRIOR_NIW || !W.niw_master_setup || !W.step_stats_device || !W.stats_device || !W.niw_posterior || !W.niw_draw ||
             !W.niw_pairs || !W.niw_put_rows || !W.niw_rows || !W.niw_draws || has_outlier() || D > 256)
             return false;
-        if (!(opt_dev_master == 1 || (opt_dev_master < 0 && D >= 128))) return false;
+        if (!(opt_dev_master == 1 || (opt_dev_master < 0 && D >= 64))) return false;
         if (!dev_setup) {
             const NiwPrior &pr = niw[0];
             if (W.niw_master_setup(W.ctx, pr.kappa, pr.nu, pr.m.data(), pr.psi.data())) { wfail("niw_master_setup"); return false; }

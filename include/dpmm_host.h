@@ -77,7 +77,7 @@ typedef struct dpmmh_worker {
     const char *(*last_error)(void *ctx);                                                         /* dpmm_last_error */
     /* OPTIONAL group (all or none; NULL when the worker has no device master): the dense per-distribution maths of the NIW
      * master on the worker's device -- see dpmm_niw_master_* / dpmm_step_stats_device / dpmm_suffstats_device in dpmm_hip.h.
-     * The engine uses it when DPMMH_OPT_DEVICE_MASTER allows (default: D >= 128) and no outlier prior is set; everything it
+     * The engine uses it when DPMMH_OPT_DEVICE_MASTER allows (default: D >= 64) and no outlier prior is set; everything it
      * cannot do there (merge proposals, state access, a restored state) falls back to the host path through niw_rows. */
     int (*niw_master_setup)(void *ctx, double kappa, double nu, const double *m, const double *psi);
     int (*step_stats_device)(void *ctx, uint32_t reset_epoch, const uint8_t **bad);
@@ -99,7 +99,7 @@ enum {
                                         results are exchanged (worker.allgather); 0 = every rank computes everything */
     DPMMH_OPT_SPIN_US = 5,           /* bounded polling of the pool's workers between back-to-back parallel regions (default 150) */
     DPMMH_OPT_PREWAKE = 6,           /* 1 (default): wake the pool ~60 us before the statistics of a step are expected back */
-    DPMMH_OPT_DEVICE_MASTER = 8,     /* NIW posteriors / factorisations / draws on the worker's device: 1 on, 0 off, -1 (default) for D >= 128 */
+    DPMMH_OPT_DEVICE_MASTER = 8,     /* NIW posteriors / factorisations / draws on the worker's device: 1 on, 0 off, -1 (default) for D >= 64 */
     DPMMH_OPT_NUMA_NODE = 7          /* >= 0: keep the pool's and the helper's threads on the CPUs of this NUMA node (the GPU's: worker numa_node); -1: leave them alone (default) */
 };
 
