@@ -145,7 +145,14 @@ __global__ __launch_bounds__(256) void niw_chol_kernel(NiwMasterArgs A, const in
             }
         }
         __syncthreads();
-        if (tid < 16) { const double d = Dg[tid * 17 + tid]; double lg = log(d); for (int o = 8; o > 0; o >>= 1) lg += __shfl_xor(lg, o, 16); if (tid == 0) s_ld += lg; }
+        if (tid < 16) {
+            const double d = Dg[tid * 17 + tid];
+            Dg[tid * 17 + 16] = 1.0 / d;          // reciprocal pivots (the unused 17th column): the panel multiplies instead of dividing
+            double lg = log(d);
+            for (int o = 8; o > 0; o >>= 1) lg += __shfl_xor(lg, o, 16);
+            if (tid == 0) s_ld += lg;
+        }
+        __syncthreads();
         { const int a = tid >> 4, b = tid & 15; if (b <= a) P[(int64_t)(j0 + a) * DP + j0 + b] = Dg[a * 17 + b]; Wp[a * DP + j0 + b] = (b <= a) ? Dg[a * 17 + b] : 0.0; }
         // (2) panel: columns q < j0, one thread per column: L[j][q] = (P[j][q] - sum_{c > j} L[c][j] L[c][q]) / L[j][j]
         for (int q = tid; q < j0; q += 256) {
@@ -157,7 +164,7 @@ __global__ __launch_bounds__(256) void niw_chol_kernel(NiwMasterArgs A, const in
                 double v = wv[jj];
 #pragma unroll
                 for (int c = jj + 1; c < 16; ++c) v -= Dg[c * 17 + jj] * wv[c];
-                wv[jj] = v / Dg[jj * 17 + jj];
+                wv[jj] = v * Dg[jj * 17 + 16];
             }
 #pragma unroll
             for (int jj = 0; jj < 16; ++jj) { P[(int64_t)(j0 + jj) * DP + q] = wv[jj]; Wp[jj * DP + q] = wv[jj]; }
@@ -250,6 +257,7 @@ __global__ __launch_bounds__(256) void niw_draw_kernel(NiwMasterArgs A, const in
             for (int a = 0; a < 16; ++a) Lp[a * DP + kk] = lrow[a];
         }
         { const int a = tid >> 4, b = tid & 15; Ld[a * 17 + b] = (b <= a) ? L[(int64_t)(i0 + a) * DP + i0 + b] : 0.0; }
+        if (tid < 16) Ld[tid * 17 + 16] = 1.0 / L[(int64_t)(i0 + tid) * DP + i0 + tid];        // reciprocal pivots (17th column)
         __syncthreads();
         // T = A(ib, :) - L(ib, < i0) Y(< i0, :)   in 4 x 4 tiles: 4 row groups x ncol / 4 column groups
         const int ntile = 4 * (ncol / 4);
@@ -287,7 +295,6 @@ __global__ __launch_bounds__(256) void niw_draw_kernel(NiwMasterArgs A, const in
                 for (int b = 0; b < 4; ++b) T[(4 * rg + a) * DP + q0 + b] = acc[a][b];
         }
         __syncthreads();
-        { const int a = tid >> 4, b = tid & 15; Ld[a * 17 + b] = (b <= a) ? L[(int64_t)(i0 + a) * DP + i0 + b] : 0.0; }
         // 16 x 16 triangular part: one thread per column
         for (int q = tid; q < ncol; q += 256) {
             double y[16];
@@ -296,7 +303,7 @@ __global__ __launch_bounds__(256) void niw_draw_kernel(NiwMasterArgs A, const in
                 double v = T[r * DP + q];
 #pragma unroll
                 for (int c = 0; c < r; ++c) v -= Ld[r * 17 + c] * y[c];
-                y[r] = v / Ld[r * 17 + r];
+                y[r] = v * Ld[r * 17 + 16];
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) Y[(int64_t)(i0 + r) * DP + q] = (q <= i0 + r) ? y[r] : 0.0;
@@ -321,8 +328,9 @@ __global__ __launch_bounds__(256) void niw_draw_kernel(NiwMasterArgs A, const in
         __syncthreads();
         if (tid < 16) {
             double xb = xi[c0 + tid];
+            const double inv = 1.0 / Ld[tid * 17 + tid];
             for (int a2 = 15; a2 >= 0; --a2) {
-                const double va = __shfl(xb, a2, 16) / Ld[a2 * 17 + a2];
+                const double va = __shfl(xb, a2, 16) * __shfl(inv, a2, 16);
                 if (tid == a2) vv[c0 + a2] = va;
                 if (tid < a2) xb -= va * Ld[a2 * 17 + tid];
             }
