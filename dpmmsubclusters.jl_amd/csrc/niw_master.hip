@@ -136,9 +136,9 @@ __global__ __launch_bounds__(256) void niw_chol_kernel(NiwMasterArgs A, const in
                 double v = Dg[jj * 17 + kcol];
                 for (int c = jj + 1; c < 16; ++c) v -= Dg[c * 17 + jj] * Dg[c * 17 + kcol];
                 const double piv = __shfl(v, jj, 16);        // lane jj holds the pivot; everybody needs its square root
-                const double d = sqrt(piv);
+                const double inv = rsqrt(piv), d = piv * inv;      // (no division in the 16-step dependent chain)
                 if (!(piv > 0.0) && kcol == 0) s_bad = 1;
-                if (kcol < jj) Dg[jj * 17 + kcol] = v / d;
+                if (kcol < jj) Dg[jj * 17 + kcol] = v * inv;
                 else if (kcol == jj) Dg[jj * 17 + jj] = d;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // row jj is read by the next rows (other lanes wrote it)
                 __builtin_amdgcn_wave_barrier();
