@@ -1100,6 +1100,35 @@ int dpmm_step_stats_device(dpmm_ctx *c, uint32_t reset_epoch, const uint8_t **ba
     return DPMM_OK;
 }
 
+int dpmm_step_master_device(dpmm_ctx *c, uint32_t reset_epoch, const int32_t *slots, const uint8_t **bad, const double **small) {
+    if (!c || !slots || !bad || !small) return DPMM_EINVAL;
+    if (!c->master) return fail(c, DPMM_ESTATE, "dpmm_niw_master_setup first");
+    const int K = c->K;
+    if (K < 1) return fail(c, DPMM_ESTATE, "no clusters");
+    HIPCHK(c, hipSetDevice(c->device));
+    int top = 0;
+    for (int k = 0; k < K; ++k) {
+        if (slots[k] < 0 || slots[k] >= DPMM_MAX_CLUSTERS) return fail(c, DPMM_EINVAL, "slot out of range");
+        top = std::max(top, slots[k] + 1);
+    }
+    if (int rc = master_capacity(c, top, 0)) return rc;
+    const size_t out_bytes = sizeof(double) * 2 * (size_t)K * (size_t)c->packed_stride;
+    if (int rc = ensure_out(c, DPMM_MAX_CLUSTERS + 64)) return rc;
+    const size_t jobs_bytes = (sizeof(int32_t) * 2 * (size_t)K + 63) & ~(size_t)63;
+    if (int rc = master_pinned(c, jobs_bytes + sizeof(double) * 12 * (size_t)K)) return rc;
+    // every user of the pinned block waits for its kernels before returning, so it is free here; no wait -- the sweep is still in flight
+    int32_t *jobs = reinterpret_cast<int32_t *>(c->h_master);
+    for (int k = 0; k < K; ++k) { jobs[2 * k] = k; jobs[2 * k + 1] = slots[k]; }
+    double *sm = reinterpret_cast<double *>(c->h_master + jobs_bytes);
+    if (int rc = run_stats(c, nullptr, 0, true, reset_epoch)) return rc;
+    HIPCHK(c, launch_copy_bytes(c->h_out, reinterpret_cast<const uint8_t *>(c->d_out) + out_bytes, (size_t)K + 1, c->stream));
+    HIPCHK(c, launch_niw_master_posterior(c->ma, jobs, K, c->d_out, sm, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *bad = reinterpret_cast<const uint8_t *>(c->h_out);
+    *small = sm;
+    return DPMM_OK;
+}
+
 int dpmm_suffstats_device(dpmm_ctx *c, const int64_t *idx, int n_idx) {
     if (!c) return DPMM_EINVAL;
     if (!c->master) return fail(c, DPMM_ESTATE, "dpmm_niw_master_setup first");

@@ -270,7 +270,7 @@ struct dpmmh_model {
 
     // ---------------------------------------------------------------- device master
     bool use_dev() {
-        if (kind != DPMMH_PRIOR_NIW || !W.niw_master_setup || !W.step_stats_device || !W.stats_device || !W.niw_posterior || !W.niw_draw ||
+        if (kind != DPMMH_PRIOR_NIW || !W.niw_master_setup || !W.step_stats_device || !W.step_master_device || !W.stats_device || !W.niw_posterior || !W.niw_draw ||
             !W.niw_pairs || !W.niw_put_rows || !W.niw_rows || !W.niw_draws || has_outlier() || D > 256)
             return false;
         if (!(opt_dev_master == 1 || (opt_dev_master < 0 && D >= 64))) return false;
@@ -289,6 +289,11 @@ struct dpmmh_model {
         for (int i = 0; i < n; ++i) { cl[i] = ks[i] + 1; sl[i] = slot[ks[i]]; }
         const double *sm = nullptr;
         if (W.niw_posterior(W.ctx, cl.data(), sl.data(), n, &sm)) return wfail("niw_posterior");
+        return apply_device_posteriors(sl, sm);
+    }
+    // the scalars of n clusters' posteriors (slots sl, rows sm [n][3][4]) -> the engine's per-row state + log-marginals
+    int apply_device_posteriors(const std::vector<int32_t> &sl, const double *sm) {
+        const int n = (int)sl.size();
         const NiwPrior &pr = niw[0];
         Pool::get().run(3 * n, nthreads, [&](int item, int) {           // D lgamma evaluations per log-marginal: worth the pool at D >= 128
             const int i = item / 3, w = item % 3;
@@ -468,7 +473,12 @@ struct dpmmh_model {
         double t0 = now_s();
         const double *pk = nullptr; const uint8_t *bad = nullptr;
         const bool dev = use_dev();
-        if (dev) { if (W.step_stats_device(W.ctx, next_epoch(), &bad)) return wfail("step_stats_device"); }
+        const double *dev_small = nullptr;
+        std::vector<int32_t> dev_slots;
+        if (dev) {      // statistics + all 3K posteriors and factorisations in one stream-ordered sequence, one wait
+            dev_slots.assign(slot.begin(), slot.end());
+            if (W.step_master_device(W.ctx, next_epoch(), dev_slots.data(), &bad, &dev_small)) return wfail("step_master_device");
+        }
         else if (W.step_stats(W.ctx, next_epoch(), &pk, &bad)) return wfail("step_stats");
         t_stats_back = now_s();
         helper.cancel();                       // a pre-wake still pending is late: drop it
@@ -480,7 +490,7 @@ struct dpmmh_model {
             if (bad[k]) { splittable[slot[k]] = 0; reset_hist(slot[k]); ++nbad; }     // reset_bad_clusters! (LCA:501-516)
         }
         bad_total += nbad; bad_steps += nbad ? 1 : 0;
-        if (dev) { if (int rc = ingest_device(ks)) return rc; dev_state = true; }
+        if (dev) { if (int rc = apply_device_posteriors(dev_slots, dev_small)) return rc; dev_state = true; }
         else { ingest(pk, ks); host_dense = true; host_rows = true; dev_state = false; }
         timers[T_POSTERIOR] += now_s() - t0;
         return 0;

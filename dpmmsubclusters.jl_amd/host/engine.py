@@ -21,6 +21,7 @@ F_STEP_STATS = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_uint32, _pp, _pp)
 F_STATS = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _i64p, ctypes.c_int, _pp)
 F_M_SETUP = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_double, ctypes.c_double, _vp, _vp)
 F_M_STEP = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_uint32, _pp)
+F_M_STEPM = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_uint32, _vp, _pp, _pp)
 F_M_STATS = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _i64p, ctypes.c_int)
 F_M_POST = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _i64p, _vp, ctypes.c_int, _pp)
 F_M_DRAW = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_uint32, ctypes.c_int, _vp, _vp, _vp)
@@ -45,7 +46,7 @@ class WorkerTable(ctypes.Structure):
                 ("step_stats", F_STEP_STATS), ("stats", F_STATS), ("split", F_SPLIT), ("merge", F_MERGE),
                 ("remove_empty", F_REMOVE), ("reset_sublabels", F_RESET), ("init_labels", F_INIT), ("allgather", F_GATHER),
                 ("last_error", F_ERR),
-                ("niw_master_setup", F_M_SETUP), ("step_stats_device", F_M_STEP), ("stats_device", F_M_STATS), ("niw_posterior", F_M_POST),
+                ("niw_master_setup", F_M_SETUP), ("step_stats_device", F_M_STEP), ("step_master_device", F_M_STEPM), ("stats_device", F_M_STATS), ("niw_posterior", F_M_POST),
                 ("niw_draw", F_M_DRAW), ("niw_pairs", F_M_PAIRS), ("niw_put_rows", F_M_PUT), ("niw_rows", F_M_ROWS), ("niw_draws", F_M_DRAWS)]
 
 
@@ -55,7 +56,7 @@ _NATIVE_MAP = [("params_staging", "dpmm_params_staging", F_STAGING), ("commit_pa
                ("split", "dpmm_split", F_SPLIT), ("merge", "dpmm_merge", F_MERGE), ("remove_empty", "dpmm_remove_empty", F_REMOVE),
                ("reset_sublabels", "dpmm_reset_sublabels", F_RESET), ("init_labels", "dpmm_init_labels_from", F_INIT),
                ("allgather", "dpmm_comm_allgather_host", F_GATHER), ("last_error", "dpmm_last_error", F_ERR),
-               ("niw_master_setup", "dpmm_niw_master_setup", F_M_SETUP), ("step_stats_device", "dpmm_step_stats_device", F_M_STEP),
+               ("niw_master_setup", "dpmm_niw_master_setup", F_M_SETUP), ("step_stats_device", "dpmm_step_stats_device", F_M_STEP), ("step_master_device", "dpmm_step_master_device", F_M_STEPM),
                ("stats_device", "dpmm_suffstats_device", F_M_STATS), ("niw_posterior", "dpmm_niw_master_posterior", F_M_POST),
                ("niw_draw", "dpmm_niw_master_draw", F_M_DRAW), ("niw_pairs", "dpmm_niw_master_pairs", F_M_PAIRS),
                ("niw_put_rows", "dpmm_niw_master_put_rows", F_M_PUT),

@@ -287,6 +287,8 @@ int dpmm_last_sweep_work(dpmm_ctx *ctx, uint64_t *out8);
  * D = 256 that is 2-3 ms of host time and 30 MB over the host link per sweep.  With these calls the rows stay in HBM:
  *   dpmm_niw_master_setup       prior (kappa, nu, m [D], psi [D][D] row-major) -> device; enables the calls below
  *   dpmm_step_stats_device      dpmm_step_stats without the copy of the rows (*bad: [K] flags, pinned)
+ *   dpmm_step_master_device     dpmm_step_stats_device + dpmm_niw_master_posterior for all K clusters (slots [K]) in one stream-ordered
+ *                               sequence with ONE host wait
  *   dpmm_suffstats_device       dpmm_suffstats_host without the copy (rows of the listed clusters, 1-based; NULL = all)
  *   dpmm_niw_master_posterior   calc_posterior (src/priors/niw.jl:20-31) + factorisation nu' psi' = L' L for the listed clusters
  *                               (1-based) of the LAST statistics pass, stored under their slots (rows 3 slot + {0: cluster, 1: left,
@@ -302,6 +304,7 @@ int dpmm_last_sweep_work(dpmm_ctx *ctx, uint64_t *out8);
  *   dpmm_niw_master_draws       the current draws in cluster order: mu [3K][D], R [3K][D][D] (upper triangular, full), logdet [3K] */
 int dpmm_niw_master_setup(dpmm_ctx *ctx, double kappa, double nu, const double *m, const double *psi);
 int dpmm_step_stats_device(dpmm_ctx *ctx, uint32_t reset_epoch, const uint8_t **bad);
+int dpmm_step_master_device(dpmm_ctx *ctx, uint32_t reset_epoch, const int32_t *slots, const uint8_t **bad, const double **small);
 int dpmm_suffstats_device(dpmm_ctx *ctx, const int64_t *cluster_idx, int n_idx);
 int dpmm_niw_master_posterior(dpmm_ctx *ctx, const int64_t *clusters, const int32_t *slots, int n, const double **small);
 int dpmm_niw_master_draw(dpmm_ctx *ctx, uint32_t epoch, int K, const int32_t *slot_of_cluster, const float *lr, const float *w);

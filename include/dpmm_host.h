@@ -81,6 +81,7 @@ typedef struct dpmmh_worker {
      * cannot do there (merge proposals, state access, a restored state) falls back to the host path through niw_rows. */
     int (*niw_master_setup)(void *ctx, double kappa, double nu, const double *m, const double *psi);
     int (*step_stats_device)(void *ctx, uint32_t reset_epoch, const uint8_t **bad);
+    int (*step_master_device)(void *ctx, uint32_t reset_epoch, const int32_t *slots, const uint8_t **bad, const double **small);
     int (*stats_device)(void *ctx, const int64_t *cluster_idx, int n_idx);
     int (*niw_posterior)(void *ctx, const int64_t *clusters, const int32_t *slots, int n, const double **small);
     int (*niw_draw)(void *ctx, uint32_t epoch, int K, const int32_t *slot_of_cluster, const float *lr, const float *w);
