@@ -112,7 +112,8 @@ struct dpmm_ctx {
     uint8_t *h_master = nullptr;                   // pinned: jobs | slot map | lr | w | small
     size_t h_master_bytes = 0;
     bool draws_on_device = false;
-    unsigned long long *d_work = nullptr;   // [8] executed-work counters of the last sweep [0..3] + its tile queue head [4]
+    unsigned long long *d_work = nullptr;   // [8 + 16 sweep_grid_max]: tile queue head [4]; [8 + 4 w ..] executed-work counters of wave w of the last sweep
+    int work_waves = 0;                      // waves of the last counted sweep launch
     // options (dpmm_set_option)
     float opt_margin = 50.f;
     int opt_prio = 1;
@@ -330,8 +331,8 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
     CHK_CREATE(hipMalloc(&c->sb.perm_total, sizeof(int32_t)));
     CHK_CREATE(hipMalloc(&c->d_small, sizeof(int32_t) * 4 * DPMM_MAX_CLUSTERS));
     CHK_CREATE(hipMalloc(&c->d_counts64, sizeof(long long) * 2 * DPMM_MAX_CLUSTERS));
-    CHK_CREATE(hipMalloc(&c->d_work, sizeof(unsigned long long) * 8));
-    CHK_CREATE(hipMemset(c->d_work, 0, sizeof(unsigned long long) * 8));
+    CHK_CREATE(hipMalloc(&c->d_work, sizeof(unsigned long long) * (8 + 16 * (size_t)std::max(1, c->sweep_grid_max))));
+    CHK_CREATE(hipMemset(c->d_work, 0, sizeof(unsigned long long) * (8 + 16 * (size_t)std::max(1, c->sweep_grid_max))));
 #undef CHK_CREATE
     *out = c;
     return DPMM_OK;
@@ -749,6 +750,7 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
             a.order = (!table && c->have_perm && !no_order) ? c->sb.perm : nullptr;
             a.order_total = c->sb.perm_total;
             a.work = table ? nullptr : c->d_work;
+            if (!table) c->work_waves = 4 * c->sweep_grid;
             a.prio = c->opt_prio;
         }
 #ifdef DPMM_STAMPS
@@ -1522,10 +1524,12 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
 int dpmm_last_sweep_work(dpmm_ctx *c, uint64_t *out8) {
     if (!c || !out8) return DPMM_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
-    unsigned long long h[4] = {0, 0, 0, 0};
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(h, c->d_work, sizeof(h), hipMemcpyDeviceToHost));
-    for (int i = 0; i < 4; ++i) out8[i] = h[i];
+    std::vector<unsigned long long> h(4 * (size_t)c->work_waves);
+    if (!h.empty()) HIPCHK(c, hipMemcpy(h.data(), c->d_work + 8, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; ++i) out8[i] = 0;
+    for (size_t w = 0; w < (size_t)c->work_waves; ++w)
+        for (int i = 0; i < 4; ++i) out8[i] += h[4 * w + i];
     // matrix instructions per unit of work, per WAVE (v_mfma_f32_16x16x4_f32, 2048 flops each)
     int mf_full = 0, mf_scr = 0;
     if (c->prior == DPMM_PRIOR_NIW) {

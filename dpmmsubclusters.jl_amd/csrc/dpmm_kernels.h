@@ -42,8 +42,9 @@ struct NiwSweepArgs {
     int lds_rows;             // set by the launcher: rows of the a_k table that live in LDS (0: global scratch)
     unsigned long long *dbg;  // diagnostic builds only (DPMM_STAMPS): per-wave phase cycle sums
     int prio;                 // 1: s_setprio -- low while the wave streams MFMAs, high in its scalar / VALU phases (DPMM_OPT_WAVE_PRIO)
-    unsigned long long *work; // [4] executed-work counters of this launch (wave tiles, full evaluations per wave, 16-row screens per wave,
-                              // tail-screened cluster pairs per wave), one atomicAdd set per wave at kernel end; may be null
+    unsigned long long *work; // [4] tile queue head of the LDS-staged kernel (cleared before the launch); [8 + 4 w ..]: executed-work counters of
+                              // wave w of this launch (wave tiles, full evaluations, 16-row screens, tail-screened cluster pairs), plain
+                              // stores at kernel end, summed by the reader; may be null
 };
 
 int niw_tile_points(int NB);

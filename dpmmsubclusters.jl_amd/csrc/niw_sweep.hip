@@ -547,9 +547,13 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
         T_last = s6;
 #endif
     }
+    // executed-work counters: one 32-byte slot per wave, plain stores.  (They were four atomic adds per wave on one cache line: waves
+    // finish in bursts -- all those with one tile fewer than the rest at the same moment -- and a burst of same-address device-scope
+    // atomics held up the loads of the waves still running: the last round of the D <= 64 kernel took 4x as long, a constant ~70 us
+    // per launch whatever N, 20 % of the launch at the 8-GPU shard size.)
     if (A.work && lane == 0) {
-        atomicAdd(&A.work[0], (unsigned long long)nw_tiles); atomicAdd(&A.work[1], (unsigned long long)nw_full);
-        atomicAdd(&A.work[3], (unsigned long long)nw_tail);
+        unsigned long long *slot = A.work + 8 + ((size_t)blockIdx.x * 4 + wave) * 4;
+        slot[0] = nw_tiles; slot[1] = nw_full; slot[2] = 0ull; slot[3] = nw_tail;
     }
 #ifdef DPMM_STAMPS
     if (A.dbg && lane == 0 && blockIdx.x < 4096) {
@@ -664,7 +668,7 @@ __device__ __forceinline__ void load_rb0(const float *__restrict__ Rm, const flo
 template <int NB, int NG, int OCC, bool FAST = false>
 __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs A) {
 #ifdef DPMM_STAMPS
-    unsigned long long T_x = 0, T_quad = 0, T_epi = 0, T_draw = 0, T_p2 = 0, T_tot = 0, N_scr = 0, N_tail = 0, T_prep = 0, T_far = 0, T_surv = 0, T_init = 0, T_i1 = 0, T_i2 = 0; int ntile = 0;
+    unsigned long long T_x = 0, T_quad = 0, T_epi = 0, T_draw = 0, T_p2 = 0, T_tot = 0, N_scr = 0, N_tail = 0, T_prep = 0, T_far = 0, T_surv = 0, T_init = 0, T_i1 = 0, T_i2 = 0, T_lastd = 0, T_long = 0, T_longat = 0, T_firstd = 0; int ntile = 0;
 #endif
     constexpr int DP = 16 * NB, NP = NB * (NB + 1) / 2, MATSZ = NP * 256, WPTS = 16 * NG;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1122,17 +1126,20 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
         STAMP(s4);
 #ifdef DPMM_STAMPS
         T_draw += s3 - s2; T_p2 += s4 - s3; T_tot += s4 - s0; T_x += s1 - s0; ++ntile;
+        if (s4 - s0 > T_long) { T_long = s4 - s0; T_longat = s0; }       // longest tile of this wave and when it began
+        if (!T_firstd) T_firstd = s0;
+        T_lastd = s4;
 #endif
     }
-    if (A.work && lane == 0) {
-        atomicAdd(&A.work[0], (unsigned long long)nw_tiles); atomicAdd(&A.work[1], (unsigned long long)nw_full);
-        atomicAdd(&A.work[2], (unsigned long long)nw_scr); atomicAdd(&A.work[3], (unsigned long long)nw_tail);
+    if (A.work && lane == 0) {      // one slot per wave, no atomics (see the LDS-staged kernel)
+        unsigned long long *slot = A.work + 8 + (size_t)wave_id * 4;
+        slot[0] = nw_tiles; slot[1] = nw_full; slot[2] = nw_scr; slot[3] = nw_tail;
     }
 #ifdef DPMM_STAMPS
     if (lane == 0 && A.dbg) {
         unsigned long long *d = A.dbg + wave_id * 16;
         d[0] = T_x; d[1] = T_quad; d[2] = T_prep; d[3] = T_epi; d[4] = T_surv; d[5] = T_draw; d[6] = T_p2; d[7] = T_tot;
-        d[8] = ntile; d[9] = N_tail; d[10] = N_scr; d[11] = T_far; d[12] = T_init; d[13] = T_i1; d[14] = T_i2;
+        d[8] = ntile; d[9] = N_tail; d[10] = N_scr; d[11] = T_long; d[12] = T_init; d[13] = T_longat; d[14] = T_firstd; d[15] = T_lastd;
     }
 #endif
 }

@@ -31,7 +31,6 @@ nt = d[:, 8].sum()
 for i, nm in enumerate(names):
     print(f"{nm:14s} cycles/tile {d[:, i].sum() / nt:10.0f}   share {100 * d[:, i].sum() / d[:, 7].sum():5.1f}%")
 print("refs setup (table init, prev labels, first fragments, pre-screen norms) cycles/tile:", d[:, 12].sum() / nt)
-print("  of which: table init + k0:", d[:, 13].sum() / nt, " first fragments + pre-screen constants arrive:", d[:, 14].sum() / nt)
 print("tail-screened clusters per tile:", d[:, 9].sum() / nt)
 print("MFMA-screened clusters per tile:", d[:, 10].sum() / nt)
 tt = d[:, 7]
@@ -44,3 +43,21 @@ for i, nm in enumerate(names[:7]):
 if D > 64:
     print("longest single tile per wave: median %.0f  max %.0f cycles;  wave lifetime (first stamp -> last stamp): median %.0f max %.0f; spread of end times %.0f" % (
         np.median(d[:, 10]), d[:, 10].max(), np.median(d[:, 12] - d[:, 11]), (d[:, 12] - d[:, 11]).max(), d[:, 12].max() - d[:, 12].min()))
+if D <= 64:
+    idx = np.argsort(-tt)[:12]
+    print("slowest waves: wave | x refs setup Kloop surv draw phase2 total | tiles tail-screened mfma-screened")
+    for i in idx:
+        print(int(i), [int(v) for v in d[i, :8]], [int(v) for v in d[i, 8:11]])
+    med = np.argsort(tt)[len(tt) // 2]
+    print("median wave", int(med), [int(v) for v in d[med, :8]], [int(v) for v in d[med, 8:11]])
+    t0 = d[:, 14].min()
+    print("wave starts (first stamp - earliest): median %.0f max %.0f; ends: median %.0f max %.0f; longest tile: median %.0f p99 %.0f max %.0f" % (
+        np.median(d[:, 14] - t0), (d[:, 14] - t0).max(), np.median(d[:, 15] - t0), (d[:, 15] - t0).max(), np.median(d[:, 11]), np.percentile(d[:, 11], 99), d[:, 11].max()))
+    big = np.argsort(-d[:, 11])[:40]
+    print("longest tiles: (wave, cycles, start offset)", [(int(i), int(d[i, 11]), int(d[i, 13] - t0)) for i in big])
+    rel = (d[:, 13] - d[:, 14])
+    sel = d[:, 11] > 1.8 * np.median(d[:, 11])
+    print("waves with a tile > 1.8 x median longest:", int(sel.sum()), "of", len(d), "; that tile began (cycles after the wave's first stamp) percentiles 0/25/50/75/100:",
+          [int(v) for v in np.percentile(rel[sel], [0, 25, 50, 75, 100])], "; wave lifetime median", int(np.median(d[:, 15] - d[:, 14])))
+    print("histogram of the long tile's start / 61k:", np.bincount((rel[sel] / 61000).astype(int), minlength=12).tolist())
+    print("waves hit, by workgroup index mod 8 (XCD):", np.bincount((np.nonzero(sel)[0] // 4) % 8, minlength=8).tolist())
