@@ -34,7 +34,7 @@ ABI = [
     ("dpmm_numa_node", ctypes.c_int, [ctypes.c_void_p]),
     ("dpmm_niw_master_setup", ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
     ("dpmm_step_stats_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]),
-    ("dpmm_step_master_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]),
+    ("dpmm_step_master_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]),
     ("dpmm_suffstats_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     ("dpmm_niw_master_posterior", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     ("dpmm_niw_master_draw", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),

@@ -105,10 +105,21 @@ struct dpmm_ctx {
     // device master (niw_master.hip)
     bool master = false;
     NiwMasterArgs ma{};
-    double *d_m0 = nullptr, *d_psi_lo = nullptr, *d_Y = nullptr, *d_pairs = nullptr;
+    double *d_m0 = nullptr, *d_psi_lo = nullptr, *d_pairs = nullptr;
+    double *d_Y[2] = {nullptr, nullptr};           // draw outputs, two sets: [draw_cur] belongs to the parameters in use, the other takes the next draws
+    float *d_mu_draw[2] = {nullptr, nullptr};
+    int draw_cur = 0;
     size_t pair_cap = 0;                           // matrices in d_pairs (pooled pair scratch)
-    float *d_ld_sigma = nullptr;
+    float *d_ld_sigma[2] = {nullptr, nullptr};
     int master_slots = 0, master_K = 0;            // capacities: slots (fac / mean / rows_store), clusters (Y / mu_draw)
+    // draws launched ahead (dpmm_step_master_device): a second stream, so that the pair kernels of the merge proposals do not queue behind them
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_master = nullptr, ev_spec = nullptr;      // posteriors done (main stream) / early draws done (stream2)
+    bool spec_inflight = false, spec_valid = false;         // main stream has not waited for ev_spec yet / the early draws are still the ones a draw call would make
+    uint32_t spec_epoch = 0;
+    std::vector<int32_t> spec_slots;
+    int32_t *h_spec[2] = {nullptr, nullptr};                // pinned slot maps of the early draws, alternating (a launch may still read the other one)
+    unsigned spec_parity = 0;
     uint8_t *h_master = nullptr;                   // pinned: jobs | slot map | lr | w | small
     size_t h_master_bytes = 0;
     bool draws_on_device = false;
@@ -346,8 +357,13 @@ int dpmm_destroy(dpmm_ctx *c) {
     hipFree(c->dX); hipFree(c->dX8); hipFree(c->dbins); hipFree(c->d_gt); hipFree(c->d_cont);
     hipFree(c->sb.tile_hist); hipFree(c->sb.bin_total); hipFree(c->sb.bin_start); hipFree(c->sb.item_start);
     hipFree(c->sb.perm); hipFree(c->sb.bin_sel); hipFree(c->sb.perm_total); hipFree(c->d_small); hipFree(c->d_proj); hipFree(c->d_vals); hipFree(c->d_smart);
-    hipFree(c->d_m0); hipFree(c->d_psi_lo); hipFree(c->d_Y); hipFree(c->d_ld_sigma); hipFree(c->d_pairs);
-    hipFree(c->ma.fac); hipFree(c->ma.mean); hipFree(c->ma.kap); hipFree(c->ma.nu); hipFree(c->ma.rows_store); hipFree(c->ma.mu_draw);
+    hipFree(c->d_m0); hipFree(c->d_psi_lo); hipFree(c->d_pairs);
+    for (int i = 0; i < 2; ++i) { hipFree(c->d_Y[i]); hipFree(c->d_ld_sigma[i]); hipFree(c->d_mu_draw[i]); }
+    hipFree(c->ma.fac); hipFree(c->ma.mean); hipFree(c->ma.kap); hipFree(c->ma.nu); hipFree(c->ma.rows_store);
+    if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
+    if (c->ev_master) hipEventDestroy(c->ev_master);
+    if (c->ev_spec) hipEventDestroy(c->ev_spec);
+    for (int i = 0; i < 2; ++i) if (c->h_spec[i]) hipHostFree(c->h_spec[i]);
     if (c->h_master) hipHostFree(c->h_master);
     hipFree(c->d_counts64); hipFree(c->d_row_off); hipFree(c->d_work); hipFree(c->d_par);
     comm_release(c);
@@ -1028,6 +1044,14 @@ static int master_pinned(dpmm_ctx *c, size_t bytes) {
     c->h_master_bytes = cap;
     return DPMM_OK;
 }
+// the main stream waits for draws launched ahead on stream2 (before anything that writes what they read or reads what they write)
+static int spec_join(dpmm_ctx *c) {
+    if (c->spec_inflight) {
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_spec, 0));
+        c->spec_inflight = false;
+    }
+    return DPMM_OK;
+}
 // device storage for `slots` slots (posterior state, kept across growth) and K clusters (draw scratch)
 static int master_capacity(dpmm_ctx *c, int slots, int K) {
     const size_t DP = (size_t)c->ma.DP, stride = (size_t)c->packed_stride;
@@ -1036,6 +1060,8 @@ static int master_capacity(dpmm_ctx *c, int slots, int K) {
         while (ns < slots) ns *= 2;
         ns = std::min(ns, DPMM_MAX_CLUSTERS);
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
+        c->spec_valid = false;
         double *fac = nullptr, *mean = nullptr, *kap = nullptr, *nu = nullptr, *rows = nullptr;
         HIPCHK(c, hipMalloc(&fac, sizeof(double) * 3 * ns * DP * DP));
         HIPCHK(c, hipMalloc(&mean, sizeof(double) * 3 * ns * DP));
@@ -1059,11 +1085,16 @@ static int master_capacity(dpmm_ctx *c, int slots, int K) {
         while (nk < K) nk *= 2;
         nk = std::min(nk, DPMM_MAX_CLUSTERS);
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        hipFree(c->d_Y); hipFree(c->d_ld_sigma); hipFree(c->ma.mu_draw);
-        c->d_Y = nullptr; c->d_ld_sigma = nullptr; c->ma.mu_draw = nullptr;
-        HIPCHK(c, hipMalloc(&c->d_Y, sizeof(double) * 3 * nk * DP * DP));
-        HIPCHK(c, hipMalloc(&c->d_ld_sigma, sizeof(float) * 3 * nk));
-        HIPCHK(c, hipMalloc(&c->ma.mu_draw, sizeof(float) * 3 * nk * DP));
+        if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
+        c->spec_valid = false;
+        for (int i = 0; i < 2; ++i) {
+            hipFree(c->d_Y[i]); hipFree(c->d_ld_sigma[i]); hipFree(c->d_mu_draw[i]);
+            c->d_Y[i] = nullptr; c->d_ld_sigma[i] = nullptr; c->d_mu_draw[i] = nullptr;
+            HIPCHK(c, hipMalloc(&c->d_Y[i], sizeof(double) * 3 * nk * DP * DP));
+            HIPCHK(c, hipMalloc(&c->d_ld_sigma[i], sizeof(float) * 3 * nk));
+            HIPCHK(c, hipMalloc(&c->d_mu_draw[i], sizeof(float) * 3 * nk * DP));
+        }
+        c->draws_on_device = false;
         c->master_K = nk;
     }
     return DPMM_OK;
@@ -1086,6 +1117,14 @@ int dpmm_niw_master_setup(dpmm_ctx *c, double kappa, double nu, const double *m,
     HIPCHK(c, hipMemcpy(c->d_psi_lo, lo.data(), sizeof(double) * T, hipMemcpyHostToDevice));
     c->ma.D = D; c->ma.DP = 16 * ((D + 15) / 16); c->ma.packed_stride = c->packed_stride;
     c->ma.kappa0 = kappa; c->ma.nu0 = nu; c->ma.m0 = c->d_m0; c->ma.psi_lo = c->d_psi_lo; c->ma.seed = c->seed;
+    if (!c->stream2) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_master, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_spec, hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i) HIPCHK(c, hipHostMalloc((void **)&c->h_spec[i], sizeof(int32_t) * DPMM_MAX_CLUSTERS, hipHostMallocDefault));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream2));
+    c->spec_inflight = false; c->spec_valid = false;
     c->master = true;
     return DPMM_OK;
 }
@@ -1102,7 +1141,7 @@ int dpmm_step_stats_device(dpmm_ctx *c, uint32_t reset_epoch, const uint8_t **ba
     return DPMM_OK;
 }
 
-int dpmm_step_master_device(dpmm_ctx *c, uint32_t reset_epoch, const int32_t *slots, const uint8_t **bad, const double **small) {
+int dpmm_step_master_device(dpmm_ctx *c, uint32_t reset_epoch, const int32_t *slots, uint32_t draw_epoch, const uint8_t **bad, const double **small) {
     if (!c || !slots || !bad || !small) return DPMM_EINVAL;
     if (!c->master) return fail(c, DPMM_ESTATE, "dpmm_niw_master_setup first");
     const int K = c->K;
@@ -1113,7 +1152,9 @@ int dpmm_step_master_device(dpmm_ctx *c, uint32_t reset_epoch, const int32_t *sl
         if (slots[k] < 0 || slots[k] >= DPMM_MAX_CLUSTERS) return fail(c, DPMM_EINVAL, "slot out of range");
         top = std::max(top, slots[k] + 1);
     }
-    if (int rc = master_capacity(c, top, 0)) return rc;
+    if (int rc = master_capacity(c, top, draw_epoch ? K : 0)) return rc;
+    if (int rc = spec_join(c)) return rc;                  // unused early draws of the last call still read the factors
+    c->spec_valid = false;
     const size_t out_bytes = sizeof(double) * 2 * (size_t)K * (size_t)c->packed_stride;
     if (int rc = ensure_out(c, DPMM_MAX_CLUSTERS + 64)) return rc;
     const size_t jobs_bytes = (sizeof(int32_t) * 2 * (size_t)K + 63) & ~(size_t)63;
@@ -1125,7 +1166,23 @@ int dpmm_step_master_device(dpmm_ctx *c, uint32_t reset_epoch, const int32_t *sl
     if (int rc = run_stats(c, nullptr, 0, true, reset_epoch)) return rc;
     HIPCHK(c, launch_copy_bytes(c->h_out, reinterpret_cast<const uint8_t *>(c->d_out) + out_bytes, (size_t)K + 1, c->stream));
     HIPCHK(c, launch_niw_master_posterior(c->ma, jobs, K, c->d_out, sm, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_master, c->stream));
+    if (draw_epoch) {
+        // The next parameter draws, launched now on the second stream: they need the posteriors only (not the weights, not the
+        // master's split / merge decisions), so they run while the host works on the scalars this call returns.  If nothing changes
+        // the cluster -> slot map until dpmm_niw_master_draw(draw_epoch, ...), that call finds them done and launches the hand-over alone.
+        int32_t *hs = c->h_spec[c->spec_parity ^= 1u];
+        memcpy(hs, slots, sizeof(int32_t) * K);
+        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_master, 0));
+        NiwMasterArgs ma = c->ma;
+        ma.mu_draw = c->d_mu_draw[c->draw_cur ^ 1];
+        HIPCHK(c, launch_niw_master_draw(ma, hs, K, draw_epoch, c->d_Y[c->draw_cur ^ 1], c->d_ld_sigma[c->draw_cur ^ 1], nullptr, nullptr,
+                                         nullptr, nullptr, nullptr, nullptr, c->NB, nullptr, 1, c->stream2));
+        HIPCHK(c, hipEventRecord(c->ev_spec, c->stream2));
+        c->spec_inflight = true; c->spec_valid = true; c->spec_epoch = draw_epoch;
+        c->spec_slots.assign(slots, slots + K);
+    }
+    HIPCHK(c, hipEventSynchronize(c->ev_master));
     *bad = reinterpret_cast<const uint8_t *>(c->h_out);
     *small = sm;
     return DPMM_OK;
@@ -1150,6 +1207,8 @@ int dpmm_niw_master_posterior(dpmm_ctx *c, const int64_t *clusters, const int32_
         top = std::max(top, slots[i] + 1);
     }
     if (int rc = master_capacity(c, top, 0)) return rc;
+    if (int rc = spec_join(c)) return rc;
+    c->spec_valid = false;                                 // some factors change: draws launched ahead are not the ones to use
     const size_t jobs_bytes = (sizeof(int32_t) * 2 * (size_t)n + 63) & ~(size_t)63;
     if (int rc = master_pinned(c, jobs_bytes + sizeof(double) * 12 * (size_t)n)) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));            // nobody reads the pinned block any more
@@ -1181,8 +1240,16 @@ int dpmm_niw_master_draw(dpmm_ctx *c, uint32_t epoch, int K, const int32_t *slot
     memcpy(hlr, lr, sizeof(float) * 2 * K);
     memcpy(hw, w, sizeof(float) * K);
     c->have_tail = c->opt_tail && c->D >= 4 && c->D % 4 == 0 && K > 2;
-    HIPCHK(c, launch_niw_master_draw(c->ma, hs, K, epoch, c->d_Y, c->d_ld_sigma, hlr, hw, c->d_Rp, c->d_mup, c->d_cst,
-                                     c->have_tail ? c->d_tail : nullptr, c->NB, c->d_work, c->stream));
+    // draws launched ahead by dpmm_step_master_device for this epoch and this cluster -> slot map: only the hand-over is left
+    const bool ahead = c->spec_valid && c->spec_epoch == epoch && (int)c->spec_slots.size() == K &&
+                       memcmp(c->spec_slots.data(), slot_of_cluster, sizeof(int32_t) * K) == 0;
+    if (int rc = spec_join(c)) return rc;
+    c->spec_valid = false;
+    c->draw_cur ^= 1;
+    NiwMasterArgs ma = c->ma;
+    ma.mu_draw = c->d_mu_draw[c->draw_cur];
+    HIPCHK(c, launch_niw_master_draw(ma, hs, K, epoch, c->d_Y[c->draw_cur], c->d_ld_sigma[c->draw_cur], hlr, hw, c->d_Rp, c->d_mup, c->d_cst,
+                                     c->have_tail ? c->d_tail : nullptr, c->NB, c->d_work, ahead ? 2 : 3, c->stream));
     c->work_zeroed = true;
     c->have_screen_prep = false;     // (the K > 64 far mask needs the raw factors: not built on this path; the tail screen is)
     c->K = K;
@@ -1261,9 +1328,9 @@ int dpmm_niw_master_draws(dpmm_ctx *c, int K, float *mu, float *R, float *logdet
     const size_t D = (size_t)c->D, DP = (size_t)c->ma.DP;
     std::vector<double> Y(3 * (size_t)K * DP * DP);
     std::vector<float> m(3 * (size_t)K * DP);
-    HIPCHK(c, hipMemcpy(Y.data(), c->d_Y, sizeof(double) * Y.size(), hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(m.data(), c->ma.mu_draw, sizeof(float) * m.size(), hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(logdet, c->d_ld_sigma, sizeof(float) * 3 * (size_t)K, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(Y.data(), c->d_Y[c->draw_cur], sizeof(double) * Y.size(), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(m.data(), c->d_mu_draw[c->draw_cur], sizeof(float) * m.size(), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(logdet, c->d_ld_sigma[c->draw_cur], sizeof(float) * 3 * (size_t)K, hipMemcpyDeviceToHost));
     for (size_t j = 0; j < 3 * (size_t)K; ++j) {
         for (size_t d = 0; d < D; ++d) mu[j * D + d] = m[j * DP + d];
         for (size_t r = 0; r < D; ++r)

@@ -182,6 +182,6 @@ hipError_t launch_niw_rows_gather(const double *rows_store, const int32_t *slots
 hipError_t launch_niw_master_posterior(const NiwMasterArgs &a, const int32_t *jobs, int njobs, const double *rows, double *small, hipStream_t s);
 hipError_t launch_niw_master_draw(const NiwMasterArgs &a, const int32_t *slot_of_cluster, int K, uint32_t epoch, double *Y, float *logdet_sigma,
                                   const float *lr, const float *wts, float *Rp, float *mup, float *cst, float *tail, int NB,
-                                  unsigned long long *work, hipStream_t s);
+                                  unsigned long long *work, int what, hipStream_t s);
 
 }  // namespace dpmm

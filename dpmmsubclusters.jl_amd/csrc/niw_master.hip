@@ -487,18 +487,20 @@ hipError_t launch_niw_master_posterior(const NiwMasterArgs &a, const int32_t *jo
     return hipGetLastError();
 }
 
+// what: bit 0 = the draws (Y, mu_draw, logdet_sigma from the posteriors), bit 1 = the hand-over to the sweep kernels (needs lr / wts).
+// The two halves may be launched apart (the draws do not depend on the weights): see dpmm_step_master_device.
 hipError_t launch_niw_master_draw(const NiwMasterArgs &a, const int32_t *slot_of_cluster, int K, uint32_t epoch, double *Y, float *logdet_sigma,
                                   const float *lr, const float *wts, float *Rp, float *mup, float *cst, float *tail, int NB,
-                                  unsigned long long *work, hipStream_t s) {
+                                  unsigned long long *work, int what, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
         hipFuncSetAttribute((const void *)niw_chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)niw_master_lds_bytes(DPMM_MASTER_MAXD));
         hipFuncSetAttribute((const void *)niw_draw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)niw_master_lds_bytes(DPMM_MASTER_MAXD));
         attr = true;
     }
-    hipLaunchKernelGGL(niw_draw_kernel, dim3(3 * K), dim3(256), niw_master_lds_bytes(a.DP), s, a, slot_of_cluster, epoch, Y, logdet_sigma);
-    hipLaunchKernelGGL(niw_master_pack_kernel, dim3(512), dim3(256), 0, s, Y, a.mu_draw, logdet_sigma, lr, wts, Rp, mup, cst, tail, a.D, a.DP, NB,
-                       3 * K, work);
+    if (what & 1) hipLaunchKernelGGL(niw_draw_kernel, dim3(3 * K), dim3(256), niw_master_lds_bytes(a.DP), s, a, slot_of_cluster, epoch, Y, logdet_sigma);
+    if (what & 2) hipLaunchKernelGGL(niw_master_pack_kernel, dim3(512), dim3(256), 0, s, Y, a.mu_draw, logdet_sigma, lr, wts, Rp, mup, cst, tail, a.D, a.DP, NB,
+                                     3 * K, work);
     return hipGetLastError();
 }
 

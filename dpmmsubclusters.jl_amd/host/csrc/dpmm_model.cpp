@@ -168,6 +168,7 @@ struct dpmmh_model {
     // device master (worker.niw_*): dev_state = the device holds the posteriors of every live slot; host_dense = the host's packed
     // rows / means / factors are current (false while the device is the only one that has seen the latest statistics)
     int opt_dev_master = -1;
+    int opt_draw_ahead = 1;          // device master: the next draws are launched with the posteriors (DPMMH_OPT_DRAW_AHEAD)
     bool dev_pairs_ok = false;
     bool dev_setup = false, dev_state = false, host_dense = true, host_rows = true, dev_draw = false;   // host_rows: the packed rows alone are current
     bool prewake = true;
@@ -477,7 +478,9 @@ struct dpmmh_model {
         std::vector<int32_t> dev_slots;
         if (dev) {      // statistics + all 3K posteriors and factorisations in one stream-ordered sequence, one wait
             dev_slots.assign(slot.begin(), slot.end());
-            if (W.step_master_device(W.ctx, next_epoch(), dev_slots.data(), &bad, &dev_small)) return wfail("step_master_device");
+            // the epoch of the next parameter draws: the worker launches them right behind the posteriors (they run while this thread
+            // decides splits and merges) and uses them if the cluster -> slot map is still this one when sample_clusters asks
+            if (W.step_master_device(W.ctx, next_epoch(), dev_slots.data(), opt_draw_ahead ? draw_epoch + 1 : 0u, &bad, &dev_small)) return wfail("step_master_device");
         }
         else if (W.step_stats(W.ctx, next_epoch(), &pk, &bad)) return wfail("step_stats");
         t_stats_back = now_s();
@@ -856,6 +859,7 @@ HAPI int dpmmh_model_set_option(dpmmh_model *m, int option, double value) {
         case DPMMH_OPT_SHARE_WORK: m->share_work = value != 0; return 0;
         case DPMMH_OPT_SPIN_US: Pool::get().set_spin_us((int)value); return 0;
         case DPMMH_OPT_PREWAKE: m->prewake = value != 0; return 0;
+        case DPMMH_OPT_DRAW_AHEAD: m->opt_draw_ahead = value != 0; return 0;
         case DPMMH_OPT_DEVICE_MASTER: m->opt_dev_master = value < 0 ? -1 : (value != 0); if (!m->opt_dev_master) { if (m->pull_state()) return -1; m->dev_state = false; } return 0;
         case DPMMH_OPT_NUMA_NODE: {
             const int node = (int)value;

@@ -21,7 +21,7 @@ F_STEP_STATS = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_uint32, _pp, _pp)
 F_STATS = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _i64p, ctypes.c_int, _pp)
 F_M_SETUP = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_double, ctypes.c_double, _vp, _vp)
 F_M_STEP = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_uint32, _pp)
-F_M_STEPM = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_uint32, _vp, _pp, _pp)
+F_M_STEPM = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_uint32, _vp, ctypes.c_uint32, _pp, _pp)
 F_M_STATS = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _i64p, ctypes.c_int)
 F_M_POST = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _i64p, _vp, ctypes.c_int, _pp)
 F_M_DRAW = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_uint32, ctypes.c_int, _vp, _vp, _vp)
@@ -152,7 +152,7 @@ def python_worker_table(worker, comm=None):
     return t, [worker, keep, cbs]
 
 
-OPT_HARD_CLUSTERING, OPT_F32_QUIRK, OPT_THREADS, OPT_SHARE_WORK, OPT_SPIN_US, OPT_PREWAKE, OPT_NUMA_NODE, OPT_DEVICE_MASTER = 1, 2, 3, 4, 5, 6, 7, 8
+OPT_HARD_CLUSTERING, OPT_F32_QUIRK, OPT_THREADS, OPT_SHARE_WORK, OPT_SPIN_US, OPT_PREWAKE, OPT_NUMA_NODE, OPT_DEVICE_MASTER, OPT_DRAW_AHEAD = 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 _FIELDS = {  # name -> (dtype, trailing shape as a function of (K, D, hist_len, stride), rows factor)
     "N": (np.float64, lambda K, D, H, S: (3 * K,)), "sums": (np.float64, lambda K, D, H, S: (3 * K, D)),

@@ -288,7 +288,11 @@ int dpmm_last_sweep_work(dpmm_ctx *ctx, uint64_t *out8);
  *   dpmm_niw_master_setup       prior (kappa, nu, m [D], psi [D][D] row-major) -> device; enables the calls below
  *   dpmm_step_stats_device      dpmm_step_stats without the copy of the rows (*bad: [K] flags, pinned)
  *   dpmm_step_master_device     dpmm_step_stats_device + dpmm_niw_master_posterior for all K clusters (slots [K]) in one stream-ordered
- *                               sequence with ONE host wait
+ *                               sequence with ONE host wait.  draw_epoch != 0: the draws of dpmm_niw_master_draw(draw_epoch, K, slots, ...)
+ *                               are launched as well, on a second stream, and the call returns when the POSTERIORS are done: the draws
+ *                               need neither the weights nor the master's decisions and run while the host works.  The draw call uses
+ *                               them if its epoch and slot map are the ones given here and no posterior changed in between (else it
+ *                               draws again; results are the same either way -- the streams are keyed by epoch and position)
  *   dpmm_suffstats_device       dpmm_suffstats_host without the copy (rows of the listed clusters, 1-based; NULL = all)
  *   dpmm_niw_master_posterior   calc_posterior (src/priors/niw.jl:20-31) + factorisation nu' psi' = L' L for the listed clusters
  *                               (1-based) of the LAST statistics pass, stored under their slots (rows 3 slot + {0: cluster, 1: left,
@@ -304,7 +308,7 @@ int dpmm_last_sweep_work(dpmm_ctx *ctx, uint64_t *out8);
  *   dpmm_niw_master_draws       the current draws in cluster order: mu [3K][D], R [3K][D][D] (upper triangular, full), logdet [3K] */
 int dpmm_niw_master_setup(dpmm_ctx *ctx, double kappa, double nu, const double *m, const double *psi);
 int dpmm_step_stats_device(dpmm_ctx *ctx, uint32_t reset_epoch, const uint8_t **bad);
-int dpmm_step_master_device(dpmm_ctx *ctx, uint32_t reset_epoch, const int32_t *slots, const uint8_t **bad, const double **small);
+int dpmm_step_master_device(dpmm_ctx *ctx, uint32_t reset_epoch, const int32_t *slots, uint32_t draw_epoch, const uint8_t **bad, const double **small);
 int dpmm_suffstats_device(dpmm_ctx *ctx, const int64_t *cluster_idx, int n_idx);
 int dpmm_niw_master_posterior(dpmm_ctx *ctx, const int64_t *clusters, const int32_t *slots, int n, const double **small);
 int dpmm_niw_master_draw(dpmm_ctx *ctx, uint32_t epoch, int K, const int32_t *slot_of_cluster, const float *lr, const float *w);

@@ -81,7 +81,7 @@ typedef struct dpmmh_worker {
      * cannot do there (merge proposals, state access, a restored state) falls back to the host path through niw_rows. */
     int (*niw_master_setup)(void *ctx, double kappa, double nu, const double *m, const double *psi);
     int (*step_stats_device)(void *ctx, uint32_t reset_epoch, const uint8_t **bad);
-    int (*step_master_device)(void *ctx, uint32_t reset_epoch, const int32_t *slots, const uint8_t **bad, const double **small);
+    int (*step_master_device)(void *ctx, uint32_t reset_epoch, const int32_t *slots, uint32_t draw_epoch, const uint8_t **bad, const double **small);
     int (*stats_device)(void *ctx, const int64_t *cluster_idx, int n_idx);
     int (*niw_posterior)(void *ctx, const int64_t *clusters, const int32_t *slots, int n, const double **small);
     int (*niw_draw)(void *ctx, uint32_t epoch, int K, const int32_t *slot_of_cluster, const float *lr, const float *w);
@@ -101,6 +101,7 @@ enum {
     DPMMH_OPT_SPIN_US = 5,           /* bounded polling of the pool's workers between back-to-back parallel regions (default 150) */
     DPMMH_OPT_PREWAKE = 6,           /* 1 (default): wake the pool ~60 us before the statistics of a step are expected back */
     DPMMH_OPT_DEVICE_MASTER = 8,     /* NIW posteriors / factorisations / draws on the worker's device: 1 on, 0 off, -1 (default) for D >= 64 */
+    DPMMH_OPT_DRAW_AHEAD = 9,        /* device master: launch the next parameter draws together with the posteriors (default 1); 0 draws when asked. Same results */
     DPMMH_OPT_NUMA_NODE = 7          /* >= 0: keep the pool's and the helper's threads on the CPUs of this NUMA node (the GPU's: worker numa_node); -1: leave them alone (default) */
 };
 

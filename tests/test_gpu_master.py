@@ -186,3 +186,37 @@ def test_pooled_pair_logdets(pkg, D):
         assert got[p, 0] == N and got[p, 1] == k1 and got[p, 2] == v1
         assert abs(got[p, 3] - ld) <= 1e-9 * max(1.0, abs(ld))
     wk.close()
+
+
+@pytest.mark.parametrize("D", [16, 130])
+def test_draws_launched_ahead_do_not_change_the_chain(pkg, D):
+    """DPMMH_OPT_DRAW_AHEAD launches the next parameter draws together with the posteriors (second stream) and re-draws when a split,
+    a merge or a removal changed the cluster -> slot map in between: labels, sub-labels, K and the parameters handed out are those of
+    the draw-when-asked chain, bit for bit, through growth (splits every few steps), merges and the final argmax sweep."""
+    import importlib
+    host = importlib.import_module("dpmmsubclusters_jl_amd.host")
+    engine = importlib.import_module("dpmmsubclusters_jl_amd.host.engine")
+    N, Kt = 20000, 5
+    X, y = host.gaussian_mixture_shard(N, D, Kt, 100.0, 4242, 0, N)
+    prior = host.niw_hyperparams(1.0, np.zeros(D), D + 3, np.eye(D))
+    out = []
+    for ahead in (1, 0):
+        wk = pkg.Worker(pkg.PRIOR_NIW, D, N, device=0, seed=11)
+        wk.upload_points(X)
+        s = host.DPMMSampler(wk, prior, 10.0, N, 11, burnout=3)
+        s._configure()
+        s.model.set_option(engine.OPT_DEVICE_MASTER, 1)
+        s.model.set_option(engine.OPT_DRAW_AHEAD, ahead)
+        s.init_first_clusters(1)
+        trace = []
+        for it in range(45):
+            s.group_step(it >= 40, False)
+            trace.append(s.K)
+        lab, sub = wk.get_labels()
+        p = s.params
+        out.append((trace, lab.copy(), sub.copy(), p["mu"].copy(), p["R"].copy(), s.model.get("log_marginal").copy()))
+        wk.close()
+    a, b = out
+    assert a[0] == b[0] and max(a[0]) > 1
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
