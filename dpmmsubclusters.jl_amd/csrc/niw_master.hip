@@ -26,6 +26,7 @@
 namespace dpmm {
 
 enum : uint32_t { STREAM_M_NORMAL = 32, STREAM_M_CHI = 33, STREAM_M_XI = 34 };
+typedef double f64x4m __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ double u53(uint32_t a, uint32_t b) {          // (0, 1), 53 bits
     return ((double)((((uint64_t)a << 32) | b) >> 11) + 0.5) * (1.0 / 9007199254740992.0);
@@ -447,8 +448,259 @@ __global__ __launch_bounds__(256) void niw_form_pair_kernel(NiwMasterArgs A, con
             P[(int64_t)a * DP + b] = v;
         }
 }
+// lane s of every quad -> the whole quad (DPP quad_perm, no LDS traffic)
+__device__ __forceinline__ double quad_bcast(double x, int s) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    switch (s) {
+        case 0: lo = __builtin_amdgcn_mov_dpp(lo, 0x00, 0xf, 0xf, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x00, 0xf, 0xf, true); break;
+        case 1: lo = __builtin_amdgcn_mov_dpp(lo, 0x55, 0xf, 0xf, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x55, 0xf, 0xf, true); break;
+        case 2: lo = __builtin_amdgcn_mov_dpp(lo, 0xaa, 0xf, 0xf, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xaa, 0xf, 0xf, true); break;
+        default: lo = __builtin_amdgcn_mov_dpp(lo, 0xff, 0xf, 0xf, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xff, 0xf, 0xf, true); break;
+    }
+    return __hiloint2double(hi, lo);
+}
+
+// 1 / sqrt(x) for a pivot: the hardware estimate + two Newton steps (error ~1 ulp for normal x > 0; NaN / <= 0 propagate to the s_bad
+// test of the caller).  The library rsqrt costs ~3x as much inside a 16-step dependent chain.
+__device__ __forceinline__ double rsqrt_pivot(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = __builtin_fma(y, __builtin_fma(-hx * y, y, 0.5), y);
+    y = __builtin_fma(y, __builtin_fma(-hx * y, y, 0.5), y);
+    return y;
+}
+
+// ------------------------------------------------------------------------------------------------- form + factor, D <= 128
+// The whole scale matrix of a distribution lives in LDS (DP x (DP + 1) doubles: 33 KiB at D = 64, 129 KiB at D = 128): formed from the
+// rows, factorised in place and written out once -- no global round trips between the phases and one launch instead of two (D = 64,
+// 96 distributions: 11 + 41 us -> see DESIGN 3.5).  Same formula for P as niw_form_kernel / niw_form_pair_kernel; the factorisation is
+// right-looking inside a 16-block (every step updates the rest of the block at once: a dependent chain of 16 short steps instead of 16
+// dot products of growing length):
+//   diagonal block   wave 0, lane -> (row a = lane / 4, columns 4 (lane % 4) ..): step jj scales row jj by 1 / sqrt(pivot) and
+//                    subtracts its outer product from the rows above -- one wave in lockstep, LDS operations of a wave complete in
+//                    order, so no barrier inside the 16 steps
+//   panel            one thread per column q < j0: the 16 x 16 triangular solve in registers, right-looking as well
+//   trailing update  4 x 4 register tiles, operands from LDS
+// PAIRS = false: job j = blockIdx.x / 3 (cluster jobs[2j], slot jobs[2j+1]), w = blockIdx.x % 3; writes fac / mean / kap / nu /
+// rows_store like the two kernels it replaces.  PAIRS = true: job p = blockIdx.x pools the four stored rows of slots jobs[2p],
+// jobs[2p+1]; only small[4p + 0..3] is written.
+template <bool PAIRS>
+__global__ __launch_bounds__(256) void niw_post_lds_kernel(NiwMasterArgs A, const int32_t *__restrict__ jobs, const double *__restrict__ rows,
+                                                           double *__restrict__ small) {
+    const int D = A.D, DP = A.DP, NB = DP / 16, LD = DP + 1, tid = threadIdx.x;
+#ifdef DPMM_POST_STAMPS
+    unsigned long long T0 = __builtin_amdgcn_s_memtime(), Tf = 0, Td = 0, Tp = 0, Tt = 0, Ta = 0, Tb = 0;
+#define PSTAMP(x) x
+#else
+#define PSTAMP(x)
+#endif
+    const int64_t stride = A.packed_stride;
+    extern __shared__ double lds[];
+    double *Pm = lds;                    // [DP][LD]
+    double *sm = Pm + (size_t)DP * LD;   // [DP] posterior mean
+    double *sm0 = sm + DP;               // [DP] prior mean
+    double *piv = sm0 + DP;              // [DP] pivots (squares of the diagonal of L)
+    double *dinv = piv + DP;             // [16] reciprocal diagonal of the current block
+    __shared__ int s_bad;
+    const double *r0, *r1, *r2 = nullptr, *r3 = nullptr;
+    double c0 = 1.0, c1 = 1.0;
+    int row = 0, w = 0, slot = 0;
+    if constexpr (PAIRS) {
+        r0 = A.rows_store + (int64_t)(2 * jobs[2 * blockIdx.x]) * stride; r1 = r0 + stride;
+        r2 = A.rows_store + (int64_t)(2 * jobs[2 * blockIdx.x + 1]) * stride; r3 = r2 + stride;
+    } else {
+        const int j = blockIdx.x / 3;
+        w = blockIdx.x % 3;
+        slot = jobs[2 * j + 1];
+        r0 = rows + (int64_t)(2 * jobs[2 * j]) * stride; r1 = r0 + stride;
+        c0 = (w != 2) ? 1.0 : 0.0; c1 = (w != 1) ? 1.0 : 0.0;
+        row = 3 * slot + w;
+    }
+    double N;
+    if constexpr (PAIRS) N = r0[0] + r1[0] + r2[0] + r3[0];
+    else N = c0 * r0[0] + c1 * r1[0];
+    const double k0 = A.kappa0, v0 = A.nu0, k1 = k0 + N, v1 = v0 + N;
+    if (tid == 0) s_bad = 0;
+    if constexpr (!PAIRS) {
+        if (w == 1) {      // keep the statistics of the slot (what the host keeps in its packed rows)
+            double *dst = A.rows_store + (int64_t)(2 * slot) * stride;
+            for (int64_t e = tid; e < 2 * stride; e += 256) dst[e] = r0[e];
+        }
+    }
+    for (int a = tid; a < DP; a += 256) {
+        const double m0 = a < D ? A.m0[a] : 0.0;
+        double mv = m0;
+        if (N != 0.0 && a < D) {
+            double sx;
+            if constexpr (PAIRS) sx = r0[1 + a] + r1[1 + a] + r2[1 + a] + r3[1 + a];
+            else sx = c0 * r0[1 + a] + c1 * r1[1 + a];
+            mv = (m0 * k0 + sx) / k1;
+        }
+        sm[a] = mv; sm0[a] = m0;
+        if constexpr (!PAIRS) A.mean[(int64_t)row * DP + a] = mv;
+    }
+    if (tid == 0) {
+        double *o = small + (int64_t)blockIdx.x * 4;
+        o[0] = N; o[1] = (N == 0.0) ? k0 : k1; o[2] = (N == 0.0) ? v0 : v1;
+        if constexpr (!PAIRS) { A.kap[row] = o[1]; A.nu[row] = o[2]; }
+    }
+    __syncthreads();
+    // ---- form: lower triangle of nu' psi' into LDS (row a: the packed index t runs with b: coalesced)
+    for (int e = tid; e < DP * DP; e += 256) {
+        const int a = e / DP, b = e - a * DP;
+        if (b > a) continue;
+        double v;
+        if (a >= D) v = (a == b) ? 1.0 : 0.0;                   // padding: identity
+        else {
+            const int64_t t = (int64_t)a * (a + 1) / 2 + b;
+            const double pab = A.psi_lo[t];
+            if (N == 0.0) v = pab * v0;
+            else {
+                const int64_t tt = 1 + D + t;
+                double sab;
+                if constexpr (PAIRS) sab = r0[tt] + r1[tt] + r2[tt] + r3[tt];
+                else sab = c0 * r0[tt] + c1 * r1[tt];
+                v = ((v0 * pab + (k0 * sm0[a]) * sm0[b] - (k1 * sm[a]) * sm[b] + sab) / v1) * v1;     // psi' then nu' psi' (niw.jl:29,35)
+            }
+        }
+        Pm[a * LD + b] = v;
+    }
+    __syncthreads();
+    PSTAMP(Tf = __builtin_amdgcn_s_memtime() - T0;)
+    // ---- factor: P = L' L from the last block row up
+    for (int jb = NB - 1; jb >= 0; --jb) {
+        const int j0 = 16 * jb;
+        PSTAMP(Ta = __builtin_amdgcn_s_memtime();)
+        if (tid < 64) {
+            const int a = tid >> 2, cb = 4 * (tid & 3);
+            double *mine = Pm + (j0 + a) * LD + j0 + cb;
+            // The lane's four elements of the SYMMETRIC working block (columns above the diagonal mirrored in): every step then applies
+            // the same update to every lane -- rows >= jj compute garbage that is never stored -- instead of per-lane cases (exec-mask
+            // branches cost more than the arithmetic at one wave per SIMD: an instruction issues every ~5.5 cycles whatever it is).
+            double mv[4];
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2) mv[i2] = (cb + i2 <= a) ? mine[i2] : Pm[(j0 + cb + i2) * LD + j0 + a];
+            // Row jj as every lane needs it: pivot, element a, elements cb .. cb + 3.  The copy of row jj - 1 is loaded one step ahead
+            // (after the stores of step jj + 1, which it must see) and brought up to date in registers with step jj's update, so the LDS
+            // round trip of a step overlaps the reciprocal square root of the previous one.  Entries right of the diagonal of a stored
+            // row are garbage (rows are stored whole): nothing reads them, the write-out masks them.
+            const double *r15 = Pm + (j0 + 15) * LD + j0;
+            double pv = r15[15], ra = r15[a], q[4] = {r15[cb], r15[cb + 1], r15[cb + 2], r15[cb + 3]};
+            bool badp = false;
+#pragma unroll
+            for (int jj = 15; jj >= 0; --jj) {
+                const int jn = jj > 0 ? jj - 1 : 0;
+                const double *rn = Pm + (j0 + jn) * LD + j0;        // row jj - 1 as stored (up to date with the steps > jj)
+                const double n_pv = rn[jn], n_ra = rn[a];
+                const double n_q[4] = {rn[cb], rn[cb + 1], rn[cb + 2], rn[cb + 3]};
+                const double inv = rsqrt_pivot(pv);
+                badp |= !(pv > 0.0);
+                const double f = (ra * inv) * inv;                    // L[jj][a] / L[jj][jj]
+                // new row a = alpha (row a) - beta (row jj):  a < jj: (1, f) the update; a == jj: (1 / L[jj][jj], 0) the finished row;
+                // a > jj: (1, 0) finished earlier, kept.  One unconditional store per step, no divergent code.
+                const double alpha = a == jj ? inv : 1.0, beta = a < jj ? f : 0.0;
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) mv[i2] = __builtin_fma(-beta, q[i2], alpha * mv[i2]);
+                mine[0] = mv[0]; mine[1] = mv[1]; mine[2] = mv[2]; mine[3] = mv[3];
+                if (tid == 0) { piv[j0 + jj] = pv; dinv[jj] = inv; }
+                // row jj - 1 after this step: minus (element jj - 1 of row jj / pivot) x row jj
+                const double qsrc = q[jn & 3];
+                const double qjm = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(qsrc), jn >> 2),
+                                                    __builtin_amdgcn_readlane(__double2loint(qsrc), jn >> 2));   // (lane c < 4 holds columns 4c .. of row jj)
+                const double fn = (qjm * inv) * inv;
+                pv = __builtin_fma(-fn, qjm, n_pv);
+                ra = __builtin_fma(-fn, ra, n_ra);
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) q[i2] = __builtin_fma(-fn, q[i2], n_q[i2]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the next step's look-ahead reads what other lanes wrote in this one
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (badp && tid == 0) s_bad = 1;
+        }
+        __syncthreads();
+        PSTAMP(Tb = __builtin_amdgcn_s_memtime(); Td += Tb - Ta;)
+        if (j0 == 0) break;
+        // panel: column q of rows j0 .. j0 + 15, the 16 x 16 triangular solve right-looking, four lanes per column (lane s of the quad
+        // keeps elements 4 i + s): per step the owner scales its element, the quad gets it by a DPP broadcast, every lane updates its
+        // elements above -- ~10 instructions per step and lane instead of a 136-term chain in one thread
+        for (int q = tid >> 2; q < ((j0 + 63) & ~63); q += 64) {
+            const int sq = tid & 3;
+            const int qc = q < j0 ? q : j0 - 1;                       // (whole quads stay active for the DPP moves; the stores are masked)
+            double wv[4];
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2) wv[i2] = Pm[(j0 + 4 * i2 + sq) * LD + qc];
+#pragma unroll
+            for (int jj = 15; jj >= 0; --jj) {
+                const double *rj = Pm + (j0 + jj) * LD + j0 + sq;
+                const double mine_s = wv[jj >> 2] * dinv[jj];         // meaningful in the owner lane (sq == jj & 3)
+                const double wj = quad_bcast(mine_s, jj & 3);
+                if (sq == (jj & 3)) wv[jj >> 2] = wj;
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2)
+                    if (4 * i2 < jj) {                                // elements 4 i2 + sq < jj
+                        const double upd = __builtin_fma(-rj[4 * i2], wj, wv[i2]);
+                        wv[i2] = (4 * i2 + sq < jj) ? upd : wv[i2];
+                    }
+            }
+            if (q < j0) {
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) Pm[(j0 + 4 * i2 + sq) * LD + q] = wv[i2];
+            }
+        }
+        __syncthreads();
+        PSTAMP(Ta = __builtin_amdgcn_s_memtime(); Tp += Ta - Tb;)
+        // trailing update of the 16 x 16 blocks (kb, qb), qb <= kb < jb: P -= W' W with W = rows j0 .. j0 + 15, on the FP64 matrix
+        // cores (v_mfma_f64_16x16x4_f64: A[i][k = g], B[k = g][col = i], element r of C at row g + 4 r, col i), one block per wave and
+        // trip; diagonal blocks are updated whole (their upper half is scratch: the diagonal phase mirrors the lower half in)
+        {
+            const int wave = tid >> 6, li = tid & 15, lg = (tid >> 4) & 3;
+            for (int t = wave; t < jb * (jb + 1) / 2; t += 4) {
+                int kb = 0;
+                while ((kb + 1) * (kb + 2) / 2 <= t) ++kb;
+                const int qb = t - kb * (kb + 1) / 2;
+                double *cp = Pm + (16 * kb + lg) * LD + 16 * qb + li;
+                f64x4m acc = {cp[0], cp[4 * LD], cp[8 * LD], cp[12 * LD]};
+                const double *wa = Pm + (j0 + lg) * LD + 16 * kb + li, *wb = Pm + (j0 + lg) * LD + 16 * qb + li;
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-wa[4 * t4 * LD], wb[4 * t4 * LD], acc, 0, 0, 0);
+                cp[0] = acc[0]; cp[4 * LD] = acc[1]; cp[8 * LD] = acc[2]; cp[12 * LD] = acc[3];
+            }
+        }
+        __syncthreads();
+        PSTAMP(Tt += __builtin_amdgcn_s_memtime() - Ta;)
+    }
+    PSTAMP(Ta = __builtin_amdgcn_s_memtime();)
+    // ---- log det P = sum log pivot; L out
+    if (tid < 64) {
+        double lg = 0.0;
+        for (int a = tid; a < DP; a += 64) lg += log(piv[a]);
+        for (int o = 32; o > 0; o >>= 1) lg += __shfl_xor(lg, o);
+        if (tid == 0) small[(int64_t)blockIdx.x * 4 + 3] = s_bad ? NAN : lg;
+    }
+    if constexpr (!PAIRS) {
+        double *F = A.fac + (int64_t)row * DP * DP;
+        for (int e = tid; e < DP * DP; e += 256) {
+            const int a = e / DP, b = e - a * DP;
+            F[e] = b <= a ? Pm[a * LD + b] : 0.0;
+        }
+    }
+#ifdef DPMM_POST_STAMPS          // diagnostic build: phase cycles of two workgroups overwrite their scalars (scripts/post_stamps.py)
+    __syncthreads();
+    if (tid == 0 && blockIdx.x == 5) { double *o = small + 5 * 4; o[0] = (double)Tf; o[1] = (double)Td; o[2] = (double)Tp; o[3] = (double)Tt; }
+    if (tid == 0 && blockIdx.x == 6) { double *o = small + 6 * 4; o[0] = (double)(__builtin_amdgcn_s_memtime() - Ta); o[1] = (double)(__builtin_amdgcn_s_memtime() - T0); }
+#endif
+}
+size_t niw_post_lds_bytes(int DP) { return sizeof(double) * ((size_t)DP * (DP + 1) + 3 * (size_t)DP + 16); }
+constexpr int NIW_POST_LDS_MAXDP = 128;
+
 hipError_t launch_niw_master_pairs(const NiwMasterArgs &a, const int32_t *pairs, int n, double *scratch, double *small, hipStream_t s) {
     if (n <= 0) return hipSuccess;
+    if (a.DP <= NIW_POST_LDS_MAXDP) {
+        static bool attr = false;
+        if (!attr) { hipFuncSetAttribute((const void *)niw_post_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)niw_post_lds_bytes(NIW_POST_LDS_MAXDP)); attr = true; }
+        hipLaunchKernelGGL(niw_post_lds_kernel<true>, dim3(n), dim3(256), niw_post_lds_bytes(a.DP), s, a, pairs, (const double *)nullptr, small);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(niw_form_pair_kernel, dim3(n, a.DP >= 64 ? 16 : 1), dim3(256), 0, s, a, pairs, scratch, small);
     NiwMasterArgs b = a;
     b.fac = scratch;                                  // the factorisation kernel in "matrix blockIdx.x of fac" mode
@@ -476,6 +728,12 @@ size_t niw_master_lds_bytes(int DP) { return sizeof(double) * ((size_t)32 * DP +
 
 hipError_t launch_niw_master_posterior(const NiwMasterArgs &a, const int32_t *jobs, int njobs, const double *rows, double *small, hipStream_t s) {
     if (njobs <= 0) return hipSuccess;
+    if (a.DP <= NIW_POST_LDS_MAXDP) {
+        static bool attr_l = false;
+        if (!attr_l) { hipFuncSetAttribute((const void *)niw_post_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)niw_post_lds_bytes(NIW_POST_LDS_MAXDP)); attr_l = true; }
+        hipLaunchKernelGGL(niw_post_lds_kernel<false>, dim3(3 * njobs), dim3(256), niw_post_lds_bytes(a.DP), s, a, jobs, rows, small);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(niw_form_kernel, dim3(3 * njobs, a.DP >= 64 ? 16 : 1), dim3(256), 0, s, a, jobs, rows, small);
     static bool attr = false;
     if (!attr) {

@@ -40,7 +40,7 @@ def _posterior_numpy(prior, X, mask):
     return float(N), k1, v1, m1, P
 
 
-@pytest.mark.parametrize("D,n,K", [(2, 500, 3), (20, 3000, 4), (64, 6000, 5), (130, 4000, 3), (256, 3000, 2)])
+@pytest.mark.parametrize("D,n,K", [(2, 500, 3), (20, 3000, 4), (64, 6000, 5), (100, 3000, 3), (128, 3000, 3), (130, 4000, 3), (256, 3000, 2)])
 def test_posterior_scalars_and_logdet(pkg, D, n, K):
     wk, X, lab, sub, prior = _setup(pkg, D, n, K, seed=D)
     wk.master_setup(*prior)
@@ -170,7 +170,7 @@ def test_device_master_matches_host_path_statistics(pkg):
     assert np.allclose(np.sort(out[0][2].reshape(-1, 3)[:, 0]), np.sort(out[1][2].reshape(-1, 3)[:, 0]), rtol=1e-9)
 
 
-@pytest.mark.parametrize("D", [5, 64, 140])
+@pytest.mark.parametrize("D", [5, 64, 100, 140])
 def test_pooled_pair_logdets(pkg, D):
     n, K = 3000, 4
     wk, X, lab, sub, prior = _setup(pkg, D, n, K, seed=40 + D)
