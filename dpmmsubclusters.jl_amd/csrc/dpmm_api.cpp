@@ -118,8 +118,10 @@ struct dpmm_ctx {
     bool spec_inflight = false, spec_valid = false;         // main stream has not waited for ev_spec yet / the early draws are still the ones a draw call would make
     uint32_t spec_epoch = 0;
     std::vector<int32_t> spec_slots;
-    int32_t *h_spec[2] = {nullptr, nullptr};                // pinned slot maps of the early draws, alternating (a launch may still read the other one)
-    unsigned spec_parity = 0;
+    // index lists of the master kernels (jobs, slot maps) live in device memory and are re-sent only when they change: read from pinned
+    // host memory they cost every workgroup a PCIe round trip (~2 us) before its first useful instruction
+    int32_t *d_jobs = nullptr, *d_dslots = nullptr;          // [2 MAX] jobs of the posterior kernels (main stream) / [MAX] slot map of the draws
+    std::vector<int32_t> jobs_shadow, dslots_shadow;
     uint8_t *h_master = nullptr;                   // pinned: jobs | slot map | lr | w | small
     size_t h_master_bytes = 0;
     bool draws_on_device = false;
@@ -363,7 +365,7 @@ int dpmm_destroy(dpmm_ctx *c) {
     if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
     if (c->ev_master) hipEventDestroy(c->ev_master);
     if (c->ev_spec) hipEventDestroy(c->ev_spec);
-    for (int i = 0; i < 2; ++i) if (c->h_spec[i]) hipHostFree(c->h_spec[i]);
+    hipFree(c->d_jobs); hipFree(c->d_dslots);
     if (c->h_master) hipHostFree(c->h_master);
     hipFree(c->d_counts64); hipFree(c->d_row_off); hipFree(c->d_work); hipFree(c->d_par);
     comm_release(c);
@@ -1052,6 +1054,13 @@ static int spec_join(dpmm_ctx *c) {
     }
     return DPMM_OK;
 }
+// `data` [n] -> the device list `dst` (stream-ordered on the main stream; nothing is sent when the list is the one already there)
+static int device_list(dpmm_ctx *c, int32_t *dst, std::vector<int32_t> &shadow, const int32_t *data, size_t n) {
+    if (shadow.size() == n && (n == 0 || memcmp(shadow.data(), data, sizeof(int32_t) * n) == 0)) return DPMM_OK;
+    shadow.assign(data, data + n);
+    if (n) HIPCHK(c, hipMemcpyAsync(dst, shadow.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));    // pageable source: staged by the runtime before the call returns
+    return DPMM_OK;
+}
 // device storage for `slots` slots (posterior state, kept across growth) and K clusters (draw scratch)
 static int master_capacity(dpmm_ctx *c, int slots, int K) {
     const size_t DP = (size_t)c->ma.DP, stride = (size_t)c->packed_stride;
@@ -1121,7 +1130,8 @@ int dpmm_niw_master_setup(dpmm_ctx *c, double kappa, double nu, const double *m,
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_master, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_spec, hipEventDisableTiming));
-        for (int i = 0; i < 2; ++i) HIPCHK(c, hipHostMalloc((void **)&c->h_spec[i], sizeof(int32_t) * DPMM_MAX_CLUSTERS, hipHostMallocDefault));
+        HIPCHK(c, hipMalloc(&c->d_jobs, sizeof(int32_t) * 2 * DPMM_MAX_CLUSTERS));
+        HIPCHK(c, hipMalloc(&c->d_dslots, sizeof(int32_t) * DPMM_MAX_CLUSTERS));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream2));
     c->spec_inflight = false; c->spec_valid = false;
@@ -1160,19 +1170,20 @@ int dpmm_step_master_device(dpmm_ctx *c, uint32_t reset_epoch, const int32_t *sl
     const size_t jobs_bytes = (sizeof(int32_t) * 2 * (size_t)K + 63) & ~(size_t)63;
     if (int rc = master_pinned(c, jobs_bytes + sizeof(double) * 12 * (size_t)K)) return rc;
     // every user of the pinned block waits for its kernels before returning, so it is free here; no wait -- the sweep is still in flight
-    int32_t *jobs = reinterpret_cast<int32_t *>(c->h_master);
+    std::vector<int32_t> jobs(2 * (size_t)K);
     for (int k = 0; k < K; ++k) { jobs[2 * k] = k; jobs[2 * k + 1] = slots[k]; }
+    if (int rc = device_list(c, c->d_jobs, c->jobs_shadow, jobs.data(), jobs.size())) return rc;
+    if (draw_epoch) if (int rc = device_list(c, c->d_dslots, c->dslots_shadow, slots, (size_t)K)) return rc;
     double *sm = reinterpret_cast<double *>(c->h_master + jobs_bytes);
     if (int rc = run_stats(c, nullptr, 0, true, reset_epoch)) return rc;
     HIPCHK(c, launch_copy_bytes(c->h_out, reinterpret_cast<const uint8_t *>(c->d_out) + out_bytes, (size_t)K + 1, c->stream));
-    HIPCHK(c, launch_niw_master_posterior(c->ma, jobs, K, c->d_out, sm, c->stream));
+    HIPCHK(c, launch_niw_master_posterior(c->ma, c->d_jobs, K, c->d_out, sm, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_master, c->stream));
     if (draw_epoch) {
         // The next parameter draws, launched now on the second stream: they need the posteriors only (not the weights, not the
         // master's split / merge decisions), so they run while the host works on the scalars this call returns.  If nothing changes
         // the cluster -> slot map until dpmm_niw_master_draw(draw_epoch, ...), that call finds them done and launches the hand-over alone.
-        int32_t *hs = c->h_spec[c->spec_parity ^= 1u];
-        memcpy(hs, slots, sizeof(int32_t) * K);
+        const int32_t *hs = c->d_dslots;
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_master, 0));
         NiwMasterArgs ma = c->ma;
         ma.mu_draw = c->d_mu_draw[c->draw_cur ^ 1];
@@ -1212,10 +1223,11 @@ int dpmm_niw_master_posterior(dpmm_ctx *c, const int64_t *clusters, const int32_
     const size_t jobs_bytes = (sizeof(int32_t) * 2 * (size_t)n + 63) & ~(size_t)63;
     if (int rc = master_pinned(c, jobs_bytes + sizeof(double) * 12 * (size_t)n)) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));            // nobody reads the pinned block any more
-    int32_t *jobs = reinterpret_cast<int32_t *>(c->h_master);
+    std::vector<int32_t> jobs(2 * (size_t)n);
     for (int i = 0; i < n; ++i) { jobs[2 * i] = (int32_t)((clusters ? clusters[i] : i + 1) - 1); jobs[2 * i + 1] = slots[i]; }
+    if (int rc = device_list(c, c->d_jobs, c->jobs_shadow, jobs.data(), jobs.size())) return rc;
     double *sm = reinterpret_cast<double *>(c->h_master + jobs_bytes);
-    HIPCHK(c, launch_niw_master_posterior(c->ma, jobs, n, c->d_out, sm, c->stream));
+    HIPCHK(c, launch_niw_master_posterior(c->ma, c->d_jobs, n, c->d_out, sm, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *small = sm;
     return DPMM_OK;
@@ -1234,9 +1246,7 @@ int dpmm_niw_master_draw(dpmm_ctx *c, uint32_t epoch, int K, const int32_t *slot
     const size_t need = sizeof(int32_t) * K + sizeof(float) * 3 * (size_t)K;
     if (int rc = ensure_pinned(c, need + 64)) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    int32_t *hs = reinterpret_cast<int32_t *>(c->h_pin);
     float *hlr = reinterpret_cast<float *>(c->h_pin + sizeof(int32_t) * K), *hw = hlr + 2 * K;
-    memcpy(hs, slot_of_cluster, sizeof(int32_t) * K);
     memcpy(hlr, lr, sizeof(float) * 2 * K);
     memcpy(hw, w, sizeof(float) * K);
     c->have_tail = c->opt_tail && c->D >= 4 && c->D % 4 == 0 && K > 2;
@@ -1245,6 +1255,8 @@ int dpmm_niw_master_draw(dpmm_ctx *c, uint32_t epoch, int K, const int32_t *slot
                        memcmp(c->spec_slots.data(), slot_of_cluster, sizeof(int32_t) * K) == 0;
     if (int rc = spec_join(c)) return rc;
     c->spec_valid = false;
+    if (!ahead) if (int rc = device_list(c, c->d_dslots, c->dslots_shadow, slot_of_cluster, (size_t)K)) return rc;
+    const int32_t *hs = c->d_dslots;
     c->draw_cur ^= 1;
     NiwMasterArgs ma = c->ma;
     ma.mu_draw = c->d_mu_draw[c->draw_cur];

@@ -516,6 +516,19 @@ __global__ __launch_bounds__(256) void niw_post_lds_kernel(NiwMasterArgs A, cons
         c0 = (w != 2) ? 1.0 : 0.0; c1 = (w != 1) ? 1.0 : 0.0;
         row = 3 * slot + w;
     }
+    // the first batch of the form phase is requested before anything waits for a load (scalars, means): one global round trip for all
+    constexpr int FB = 9;                                     // D = 64: 2080 packed elements = 8.1 per thread -> one batch
+    const int T = D * (D + 1) / 2;
+    double ps[FB], sa[FB], sb[FB], sc[PAIRS ? FB : 1], sd[PAIRS ? FB : 1];
+    auto form_loads = [&](int t0) {
+#pragma unroll
+        for (int u = 0; u < FB; ++u) {
+            const int t = t0 + u * 256 + tid, tc = t < T ? t : T - 1;
+            ps[u] = A.psi_lo[tc]; sa[u] = r0[1 + D + tc]; sb[u] = r1[1 + D + tc];
+            if constexpr (PAIRS) { sc[u] = r2[1 + D + tc]; sd[u] = r3[1 + D + tc]; }
+        }
+    };
+    form_loads(0);
     double N;
     if constexpr (PAIRS) N = r0[0] + r1[0] + r2[0] + r3[0];
     else N = c0 * r0[0] + c1 * r1[0];
@@ -545,25 +558,35 @@ __global__ __launch_bounds__(256) void niw_post_lds_kernel(NiwMasterArgs A, cons
         if constexpr (!PAIRS) { A.kap[row] = o[1]; A.nu[row] = o[2]; }
     }
     __syncthreads();
-    // ---- form: lower triangle of nu' psi' into LDS (row a: the packed index t runs with b: coalesced)
-    for (int e = tid; e < DP * DP; e += 256) {
-        const int a = e / DP, b = e - a * DP;
-        if (b > a) continue;
-        double v;
-        if (a >= D) v = (a == b) ? 1.0 : 0.0;                   // padding: identity
-        else {
-            const int64_t t = (int64_t)a * (a + 1) / 2 + b;
-            const double pab = A.psi_lo[t];
-            if (N == 0.0) v = pab * v0;
-            else {
-                const int64_t tt = 1 + D + t;
-                double sab;
-                if constexpr (PAIRS) sab = r0[tt] + r1[tt] + r2[tt] + r3[tt];
-                else sab = c0 * r0[tt] + c1 * r1[tt];
-                v = ((v0 * pab + (k0 * sm0[a]) * sm0[b] - (k1 * sm[a]) * sm[b] + sab) / v1) * v1;     // psi' then nu' psi' (niw.jl:29,35)
+    // ---- form: lower triangle of nu' psi' into LDS.  The loop runs over the PACKED index t of the rows (no idle iterations, fully
+    // coalesced) in batches of FB elements per thread whose loads are all issued before the first is used: one global round trip per
+    // batch instead of one per element (the element-wise loop spent 20 k of this kernel's 65 k cycles waiting at D = 64).
+    {
+        for (int t0 = 0; t0 < T; t0 += 256 * FB) {
+            if (t0 > 0) form_loads(t0);
+#pragma unroll
+            for (int u = 0; u < FB; ++u) {
+                const int t = t0 + u * 256 + tid;
+                if (t >= T) continue;
+                int a = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+                if ((a + 1) * (a + 2) / 2 <= t) ++a;
+                if (a * (a + 1) / 2 > t) --a;
+                const int b = t - a * (a + 1) / 2;
+                double v;
+                if (N == 0.0) v = ps[u] * v0;
+                else {
+                    double sab;
+                    if constexpr (PAIRS) sab = sa[u] + sb[u] + sc[u] + sd[u];
+                    else sab = c0 * sa[u] + c1 * sb[u];
+                    v = ((v0 * ps[u] + (k0 * sm0[a]) * sm0[b] - (k1 * sm[a]) * sm[b] + sab) / v1) * v1;     // psi' then nu' psi' (niw.jl:29,35)
+                }
+                Pm[a * LD + b] = v;
             }
         }
-        Pm[a * LD + b] = v;
+        for (int e = tid; e < (DP - D) * DP; e += 256) {        // padding rows: identity
+            const int a = D + e / DP, b = e % DP;
+            if (b <= a) Pm[a * LD + b] = (a == b) ? 1.0 : 0.0;
+        }
     }
     __syncthreads();
     PSTAMP(Tf = __builtin_amdgcn_s_memtime() - T0;)
@@ -623,28 +646,37 @@ __global__ __launch_bounds__(256) void niw_post_lds_kernel(NiwMasterArgs A, cons
         // panel: column q of rows j0 .. j0 + 15, the 16 x 16 triangular solve right-looking, four lanes per column (lane s of the quad
         // keeps elements 4 i + s): per step the owner scales its element, the quad gets it by a DPP broadcast, every lane updates its
         // elements above -- ~10 instructions per step and lane instead of a 136-term chain in one thread
-        for (int q = tid >> 2; q < ((j0 + 63) & ~63); q += 64) {
+        {
             const int sq = tid & 3;
-            const int qc = q < j0 ? q : j0 - 1;                       // (whole quads stay active for the DPP moves; the stores are masked)
-            double wv[4];
+            // the coefficients a lane needs -- L[jj][4 i + sq] of the diagonal block for 4 i + sq < jj, 30 of them -- and the reciprocal
+            // pivots, all requested before the first step: the 16 steps are then register arithmetic and DPP moves only
+            double cf[16][4], dv[16];
 #pragma unroll
-            for (int i2 = 0; i2 < 4; ++i2) wv[i2] = Pm[(j0 + 4 * i2 + sq) * LD + qc];
-#pragma unroll
-            for (int jj = 15; jj >= 0; --jj) {
-                const double *rj = Pm + (j0 + jj) * LD + j0 + sq;
-                const double mine_s = wv[jj >> 2] * dinv[jj];         // meaningful in the owner lane (sq == jj & 3)
-                const double wj = quad_bcast(mine_s, jj & 3);
-                if (sq == (jj & 3)) wv[jj >> 2] = wj;
+            for (int jj = 0; jj < 16; ++jj) {
+                dv[jj] = dinv[jj];
 #pragma unroll
                 for (int i2 = 0; i2 < 4; ++i2)
-                    if (4 * i2 < jj) {                                // elements 4 i2 + sq < jj
-                        const double upd = __builtin_fma(-rj[4 * i2], wj, wv[i2]);
-                        wv[i2] = (4 * i2 + sq < jj) ? upd : wv[i2];
-                    }
+                    if (4 * i2 < jj) cf[jj][i2] = Pm[(j0 + jj) * LD + j0 + 4 * i2 + sq];
             }
-            if (q < j0) {
+            for (int q = tid >> 2; q < ((j0 + 63) & ~63); q += 64) {
+                const int qc = q < j0 ? q : j0 - 1;                       // (whole quads stay active for the DPP moves; the stores are masked)
+                double wv[4];
 #pragma unroll
-                for (int i2 = 0; i2 < 4; ++i2) Pm[(j0 + 4 * i2 + sq) * LD + q] = wv[i2];
+                for (int i2 = 0; i2 < 4; ++i2) wv[i2] = Pm[(j0 + 4 * i2 + sq) * LD + qc];
+#pragma unroll
+                for (int jj = 15; jj >= 0; --jj) {
+                    const double wj = quad_bcast(wv[jj >> 2] * dv[jj], jj & 3);      // element jj, finished, from its owner lane
+                    if (sq == (jj & 3)) wv[jj >> 2] = wj;
+#pragma unroll
+                    for (int i2 = 0; i2 < 4; ++i2) {
+                        if (4 * i2 + 3 < jj) wv[i2] = __builtin_fma(-cf[jj][i2], wj, wv[i2]);                      // elements 4 i2 + sq < jj for every lane
+                        else if (4 * i2 < jj) wv[i2] = (4 * i2 + sq < jj) ? __builtin_fma(-cf[jj][i2], wj, wv[i2]) : wv[i2];
+                    }
+                }
+                if (q < j0) {
+#pragma unroll
+                    for (int i2 = 0; i2 < 4; ++i2) Pm[(j0 + 4 * i2 + sq) * LD + q] = wv[i2];
+                }
             }
         }
         __syncthreads();
