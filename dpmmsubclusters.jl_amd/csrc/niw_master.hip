@@ -111,6 +111,28 @@ __global__ __launch_bounds__(256) void niw_form_kernel(NiwMasterArgs A, const in
     }
 }
 
+// lane s of every quad -> the whole quad (DPP quad_perm, no LDS traffic)
+__device__ __forceinline__ double quad_bcast(double x, int s) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    switch (s) {
+        case 0: lo = __builtin_amdgcn_mov_dpp(lo, 0x00, 0xf, 0xf, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x00, 0xf, 0xf, true); break;
+        case 1: lo = __builtin_amdgcn_mov_dpp(lo, 0x55, 0xf, 0xf, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x55, 0xf, 0xf, true); break;
+        case 2: lo = __builtin_amdgcn_mov_dpp(lo, 0xaa, 0xf, 0xf, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xaa, 0xf, 0xf, true); break;
+        default: lo = __builtin_amdgcn_mov_dpp(lo, 0xff, 0xf, 0xf, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xff, 0xf, 0xf, true); break;
+    }
+    return __hiloint2double(hi, lo);
+}
+
+// 1 / sqrt(x) for a pivot: the hardware estimate + two Newton steps (error ~1 ulp for normal x > 0; NaN / <= 0 propagate to the s_bad
+// test of the caller).  The library rsqrt costs ~3x as much inside a 16-step dependent chain.
+__device__ __forceinline__ double rsqrt_pivot(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = __builtin_fma(y, __builtin_fma(-hx * y, y, 0.5), y);
+    y = __builtin_fma(y, __builtin_fma(-hx * y, y, 0.5), y);
+    return y;
+}
+
 // ---------------------------------------------------------------------------------------------------------------- factor
 // P (row-major DP x DP, lower triangle) -> L with P = L' L, in place; small[.. + 3] = log det P = 2 sum log L_jj (NaN when a
 // pivot is not positive).  One workgroup per job row (blockIdx.x = 3 j + w).
@@ -121,90 +143,114 @@ __global__ __launch_bounds__(256) void niw_chol_kernel(NiwMasterArgs A, const in
     double *P = A.fac + (int64_t)row * DP * DP;
     extern __shared__ double lds[];
     double *Wp = lds;                    // [16][DP]  factor rows of the current block, columns 0 .. j0 + 15
-    double *Dg = lds + 16 * DP;          // [16][17]  diagonal block
+    double *Dg = lds + 16 * DP;          // [16][17]  diagonal block (symmetric working copy, then the factor; column 16: reciprocal pivots)
     __shared__ double s_ld;
     __shared__ int s_bad;
     if (tid == 0) { s_ld = 0.0; s_bad = 0; }
     __syncthreads();
     for (int jb = NB - 1; jb >= 0; --jb) {
         const int j0 = 16 * jb;
-        // (1) diagonal block -> LDS, factorised from its last row up by the first 16 threads
-        { const int a = tid >> 4, b = tid & 15; Dg[a * 17 + b] = (b <= a) ? P[(int64_t)(j0 + a) * DP + j0 + b] : 0.0; }
+        // (1) diagonal block -> LDS, mirrored into a full symmetric block, factorised from its last row up by wave 0 with the
+        //     look-ahead scheme of niw_post_lds_kernel (every step the same arithmetic in every lane, no divergent code)
+        { const int a = tid >> 4, b = tid & 15; Dg[a * 17 + b] = (b <= a) ? P[(int64_t)(j0 + a) * DP + j0 + b] : P[(int64_t)(j0 + b) * DP + j0 + a]; }
         __syncthreads();
-        if (tid < 16) {
-            const int kcol = tid;
+        if (tid < 64) {
+            const int a = tid >> 2, cb = 4 * (tid & 3);
+            double *mine = Dg + a * 17 + cb;
+            double mv[4] = {mine[0], mine[1], mine[2], mine[3]};
+            const double *r15 = Dg + 15 * 17;
+            double pv = r15[15], ra = r15[a], q[4] = {r15[cb], r15[cb + 1], r15[cb + 2], r15[cb + 3]};
+            bool badp = false;
+            double lg = 0.0;
+#pragma unroll
             for (int jj = 15; jj >= 0; --jj) {
-                double v = Dg[jj * 17 + kcol];
-                for (int c = jj + 1; c < 16; ++c) v -= Dg[c * 17 + jj] * Dg[c * 17 + kcol];
-                const double piv = __shfl(v, jj, 16);        // lane jj holds the pivot; everybody needs its square root
-                const double inv = rsqrt(piv), d = piv * inv;      // (no division in the 16-step dependent chain)
-                if (!(piv > 0.0) && kcol == 0) s_bad = 1;
-                if (kcol < jj) Dg[jj * 17 + kcol] = v * inv;
-                else if (kcol == jj) Dg[jj * 17 + jj] = d;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // row jj is read by the next rows (other lanes wrote it)
+                const int jn = jj > 0 ? jj - 1 : 0;
+                const double *rn = Dg + jn * 17;                    // row jj - 1 as stored (up to date with the steps > jj)
+                const double n_pv = rn[jn], n_ra = rn[a];
+                const double n_q[4] = {rn[cb], rn[cb + 1], rn[cb + 2], rn[cb + 3]};
+                const double inv = rsqrt_pivot(pv);
+                badp |= !(pv > 0.0);
+                if ((tid & 15) == jj) lg = pv;                        // lane jj keeps pivot jj for the log-determinant
+                const double f = (ra * inv) * inv;
+                const double alpha = a == jj ? inv : 1.0, beta = a < jj ? f : 0.0;
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) mv[i2] = __builtin_fma(-beta, q[i2], alpha * mv[i2]);
+                mine[0] = mv[0]; mine[1] = mv[1]; mine[2] = mv[2]; mine[3] = mv[3];
+                if (tid == 0) Dg[jj * 17 + 16] = inv;                 // reciprocal pivots (the unused 17th column): the panel multiplies
+                const double qsrc = q[jn & 3];
+                const double qjm = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(qsrc), jn >> 2),
+                                                    __builtin_amdgcn_readlane(__double2loint(qsrc), jn >> 2));
+                const double fn = (qjm * inv) * inv;
+                pv = __builtin_fma(-fn, qjm, n_pv);
+                ra = __builtin_fma(-fn, ra, n_ra);
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) q[i2] = __builtin_fma(-fn, q[i2], n_q[i2]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
-        }
-        __syncthreads();
-        if (tid < 16) {
-            const double d = Dg[tid * 17 + tid];
-            Dg[tid * 17 + 16] = 1.0 / d;          // reciprocal pivots (the unused 17th column): the panel multiplies instead of dividing
-            double lg = log(d);
-            for (int o = 8; o > 0; o >>= 1) lg += __shfl_xor(lg, o, 16);
-            if (tid == 0) s_ld += lg;
+            if (tid < 16) {
+                double l2 = log(lg);                                  // log det P = sum log pivot
+                for (int o = 8; o > 0; o >>= 1) l2 += __shfl_xor(l2, o, 16);
+                if (tid == 0) { s_ld += l2; if (badp) s_bad = 1; }
+            }
         }
         __syncthreads();
         { const int a = tid >> 4, b = tid & 15; if (b <= a) P[(int64_t)(j0 + a) * DP + j0 + b] = Dg[a * 17 + b]; Wp[a * DP + j0 + b] = (b <= a) ? Dg[a * 17 + b] : 0.0; }
-        // (2) panel: columns q < j0, one thread per column: L[j][q] = (P[j][q] - sum_{c > j} L[c][j] L[c][q]) / L[j][j]
-        for (int q = tid; q < j0; q += 256) {
-            double wv[16];
+        // (2) panel: column q < j0, four lanes per column (lane s of the quad keeps rows j0 + 4 i + s); coefficients of the diagonal
+        //     block and the reciprocal pivots in registers before the first step
+        {
+            const int sq = tid & 3;
+            double cf[16][4], dv[16];
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) wv[jj] = P[(int64_t)(j0 + jj) * DP + q];
+            for (int jj = 0; jj < 16; ++jj) {
+                dv[jj] = Dg[jj * 17 + 16];
 #pragma unroll
-            for (int jj = 15; jj >= 0; --jj) {
-                double v = wv[jj];
-#pragma unroll
-                for (int c = jj + 1; c < 16; ++c) v -= Dg[c * 17 + jj] * wv[c];
-                wv[jj] = v * Dg[jj * 17 + 16];
+                for (int i2 = 0; i2 < 4; ++i2)
+                    if (4 * i2 < jj) cf[jj][i2] = Dg[jj * 17 + 4 * i2 + sq];
             }
+            for (int q = tid >> 2; q < ((j0 + 63) & ~63); q += 64) {
+                const int qc = q < j0 ? q : j0 - 1;
+                double wv[4];
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) { P[(int64_t)(j0 + jj) * DP + q] = wv[jj]; Wp[jj * DP + q] = wv[jj]; }
+                for (int i2 = 0; i2 < 4; ++i2) wv[i2] = P[(int64_t)(j0 + 4 * i2 + sq) * DP + qc];
+#pragma unroll
+                for (int jj = 15; jj >= 0; --jj) {
+                    const double wj = quad_bcast(wv[jj >> 2] * dv[jj], jj & 3);
+                    if (sq == (jj & 3)) wv[jj >> 2] = wj;
+#pragma unroll
+                    for (int i2 = 0; i2 < 4; ++i2) {
+                        if (4 * i2 + 3 < jj) wv[i2] = __builtin_fma(-cf[jj][i2], wj, wv[i2]);
+                        else if (4 * i2 < jj) wv[i2] = (4 * i2 + sq < jj) ? __builtin_fma(-cf[jj][i2], wj, wv[i2]) : wv[i2];
+                    }
+                }
+                if (q < j0) {
+#pragma unroll
+                    for (int i2 = 0; i2 < 4; ++i2) { P[(int64_t)(j0 + 4 * i2 + sq) * DP + q] = wv[i2]; Wp[(4 * i2 + sq) * DP + q] = wv[i2]; }
+                }
+            }
         }
         __syncthreads();
-        // (3) trailing update of rows / columns < j0: P[k][q] -= sum_c W[c][k] W[c][q], q <= k, in 4 x 4 tiles
-        const int nt = j0 / 4;
-        for (int t = tid; t < nt * (nt + 1) / 2; t += 256) {
-            int tk = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-            while ((tk + 1) * (tk + 2) / 2 <= t) ++tk;
-            while (tk * (tk + 1) / 2 > t) --tk;
-            const int tq = t - tk * (tk + 1) / 2;
-            const int kk = 4 * tk, qq = 4 * tq;
-            // the tile of P is requested BEFORE the products (its latency hides behind them); entries above the diagonal of a
-            // diagonal tile are read and written back unchanged (scratch)
-            double acc[4][4], pv[4][4];
+        // (3) trailing update of the 16 x 16 blocks (kb, qb), qb <= kb < jb: P -= W' W on the FP64 matrix cores, one block per wave and
+        //     trip (C straight from / to global memory, A / B operands from the LDS panel); diagonal blocks are updated whole -- their
+        //     upper half is scratch, step (1) mirrors the lower half in
+        {
+            const int wave = tid >> 6, li = tid & 15, lg4 = (tid >> 4) & 3;
+            for (int t = wave; t < jb * (jb + 1) / 2; t += 4) {
+                int kb = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+                while ((kb + 1) * (kb + 2) / 2 <= t) ++kb;
+                while (kb * (kb + 1) / 2 > t) --kb;
+                const int qb = t - kb * (kb + 1) / 2;
+                double *cp = P + (int64_t)(16 * kb + lg4) * DP + 16 * qb + li;
+                f64x4m acc = {cp[0], cp[(int64_t)4 * DP], cp[(int64_t)8 * DP], cp[(int64_t)12 * DP]};
+                const double *wa = Wp + lg4 * DP + 16 * kb + li, *wb = Wp + lg4 * DP + 16 * qb + li;
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) { acc[a][b] = 0.0; pv[a][b] = P[(int64_t)(kk + a) * DP + qq + b]; }
-#pragma unroll 4
-            for (int c = 0; c < 16; ++c) {
-                const double *wr = Wp + c * DP;
-                const double a0 = wr[kk], a1 = wr[kk + 1], a2 = wr[kk + 2], a3 = wr[kk + 3];
-                const double b0 = wr[qq], b1 = wr[qq + 1], b2 = wr[qq + 2], b3 = wr[qq + 3];
-                acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[0][2] += a0 * b2; acc[0][3] += a0 * b3;
-                acc[1][0] += a1 * b0; acc[1][1] += a1 * b1; acc[1][2] += a1 * b2; acc[1][3] += a1 * b3;
-                acc[2][0] += a2 * b0; acc[2][1] += a2 * b1; acc[2][2] += a2 * b2; acc[2][3] += a2 * b3;
-                acc[3][0] += a3 * b0; acc[3][1] += a3 * b1; acc[3][2] += a3 * b2; acc[3][3] += a3 * b3;
+                for (int t4 = 0; t4 < 4; ++t4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-wa[4 * t4 * DP], wb[4 * t4 * DP], acc, 0, 0, 0);
+                cp[0] = acc[0]; cp[(int64_t)4 * DP] = acc[1]; cp[(int64_t)8 * DP] = acc[2]; cp[(int64_t)12 * DP] = acc[3];
             }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    P[(int64_t)(kk + a) * DP + qq + b] = pv[a][b] - acc[a][b];
         }
         __syncthreads();
     }
-    if (tid == 0) small[(int64_t)blockIdx.x * 4 + 3] = s_bad ? NAN : 2.0 * s_ld;
+    if (tid == 0) small[(int64_t)blockIdx.x * 4 + 3] = s_bad ? NAN : s_ld;
 }
 
 // ------------------------------------------------------------------------------------------------------------------ draw
@@ -448,28 +494,6 @@ __global__ __launch_bounds__(256) void niw_form_pair_kernel(NiwMasterArgs A, con
             P[(int64_t)a * DP + b] = v;
         }
 }
-// lane s of every quad -> the whole quad (DPP quad_perm, no LDS traffic)
-__device__ __forceinline__ double quad_bcast(double x, int s) {
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    switch (s) {
-        case 0: lo = __builtin_amdgcn_mov_dpp(lo, 0x00, 0xf, 0xf, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x00, 0xf, 0xf, true); break;
-        case 1: lo = __builtin_amdgcn_mov_dpp(lo, 0x55, 0xf, 0xf, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x55, 0xf, 0xf, true); break;
-        case 2: lo = __builtin_amdgcn_mov_dpp(lo, 0xaa, 0xf, 0xf, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xaa, 0xf, 0xf, true); break;
-        default: lo = __builtin_amdgcn_mov_dpp(lo, 0xff, 0xf, 0xf, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xff, 0xf, 0xf, true); break;
-    }
-    return __hiloint2double(hi, lo);
-}
-
-// 1 / sqrt(x) for a pivot: the hardware estimate + two Newton steps (error ~1 ulp for normal x > 0; NaN / <= 0 propagate to the s_bad
-// test of the caller).  The library rsqrt costs ~3x as much inside a 16-step dependent chain.
-__device__ __forceinline__ double rsqrt_pivot(double x) {
-    double y = __builtin_amdgcn_rsq(x);
-    const double hx = 0.5 * x;
-    y = __builtin_fma(y, __builtin_fma(-hx * y, y, 0.5), y);
-    y = __builtin_fma(y, __builtin_fma(-hx * y, y, 0.5), y);
-    return y;
-}
-
 // ------------------------------------------------------------------------------------------------- form + factor, D <= 128
 // The whole scale matrix of a distribution lives in LDS (DP x (DP + 1) doubles: 33 KiB at D = 64, 129 KiB at D = 128): formed from the
 // rows, factorised in place and written out once -- no global round trips between the phases and one launch instead of two (D = 64,
