@@ -264,11 +264,17 @@ __global__ __launch_bounds__(256) void niw_draw_kernel(NiwMasterArgs A, const in
     double *Y = Yall + (int64_t)blockIdx.x * DP * DP;
     const double nu = A.nu[row], kap = A.kap[row];
     const uint64_t id = (uint64_t)blockIdx.x;          // the streams are keyed by the position in cluster order, like the host's
+#ifdef DPMM_POST_STAMPS
+    unsigned long long D0 = __builtin_amdgcn_s_memtime(), Dn = 0, Ds = 0, Dp = 0, Dt = 0, Da = 0, Db = 0;
+#define DSTAMP(x) x
+#else
+#define DSTAMP(x)
+#endif
     extern __shared__ double lds[];
     double *T = lds;                     // [16][DP]
     double *Ld = lds + 16 * DP;          // [16][17]
     double *xi = Ld + 16 * 17;           // [DP]
-    double *Lp = xi + DP;                // [16][DP]  rows i0 .. i0 + 15 of L, columns < i0
+    double *Lp = xi + DP;                // [DP][17]  rows i0 .. i0 + 15 of L, columns < i0, TRANSPOSED (column kk of L at Lp[kk * 17 + row])
     // Bartlett factor (lower): chi on the diagonal, standard normals below, identity in the padding.  One generator block gives
     // the two normals of an element pair (2p, 2p + 1) of a row (Box-Muller, both branches).
     const int HP = DP / 2;
@@ -292,56 +298,75 @@ __global__ __launch_bounds__(256) void niw_draw_kernel(NiwMasterArgs A, const in
     for (int d = tid; d < DP; d += 256)
         xi[d] = d < D ? normal_from(philox4x32_10(A.seed, (id << 32) + (uint64_t)d, epoch, STREAM_M_XI)) : 0.0;
     __syncthreads();
+    DSTAMP(Dn = __builtin_amdgcn_s_memtime() - D0;)
     // L Y = A, block row by block row
     for (int ib = 0; ib < NB; ++ib) {
         const int i0 = 16 * ib, ncol = i0 + 16;             // columns 0 .. i0 + 15 of this block row can be non-zero
+        DSTAMP(Da = __builtin_amdgcn_s_memtime();)
         // the block row's part of L (columns < i0) -> LDS once: the products below read it 4 values per inner step
         for (int kk = tid; kk < i0; kk += 256) {          // (i0 <= 240: one trip; the 16 loads of a thread are issued together)
             double lrow[16];
 #pragma unroll
             for (int a = 0; a < 16; ++a) lrow[a] = L[(int64_t)(i0 + a) * DP + kk];
 #pragma unroll
-            for (int a = 0; a < 16; ++a) Lp[a * DP + kk] = lrow[a];
+            for (int a = 0; a < 16; ++a) Lp[kk * 17 + a] = lrow[a];
         }
         { const int a = tid >> 4, b = tid & 15; Ld[a * 17 + b] = (b <= a) ? L[(int64_t)(i0 + a) * DP + i0 + b] : 0.0; }
         if (tid < 16) Ld[tid * 17 + 16] = 1.0 / L[(int64_t)(i0 + tid) * DP + i0 + tid];        // reciprocal pivots (17th column)
         __syncthreads();
-        // T = A(ib, :) - L(ib, < i0) Y(< i0, :)   in 4 x 4 tiles: 4 row groups x ncol / 4 column groups
-        const int ntile = 4 * (ncol / 4);
-        for (int t = tid; t < ntile; t += 256) {
-            const int rg = t & 3, cg = t >> 2;
-            const int r0 = i0 + 4 * rg, q0 = 4 * cg;
-            double acc[4][4];
+        DSTAMP(Db = __builtin_amdgcn_s_memtime(); Ds += Db - Da;)
+        // T = A(ib, :) - L(ib, < i0) Y(< i0, :) on the FP64 matrix cores (v_mfma_f64_16x16x4_f64: A[i][k = g] = -L[i0 + i][kk + g] from
+        // the transposed LDS panel (conflict-free), B[k = g][col = i] = Y[kk + g][16 cb + i] from global memory, element r of C at row
+        // g + 4 r, col i).  Column block cb needs the rows kk >= 16 cb only (Y is lower triangular): ib - cb chunks of 16 rows; the
+        // blocks are dealt to the four waves in snake order (similar numbers of chunks), B operands in two register groups of PG
+        // chunks: the loads of one group are in flight while the matrix instructions of the other run (PG x 4 x 64 cycles of cover
+        // against > 1000 cycles from L2).  D = 256: 488 k cycles (4 x 4 register tiles on the vector ALU) -> 146 k.  (A variant in
+        // which a wave owns four column blocks and walks the chunks once -- one A fragment per chunk, one pipeline fill per block row
+        // -- was slower, 195 k: its first chunks have one or two active blocks and wait for every load.)
+        {
+            const int wave = tid >> 6, li = tid & 15, lg = (tid >> 4) & 3;
+            for (int idx = 0; idx <= ib; ++idx) {
+                const int turn = idx & 7;
+                if ((turn < 4 ? turn : 7 - turn) != wave) continue;
+                const int cb = idx;
+                const double *yc = Y + (int64_t)lg * DP + 16 * cb + li;                 // + kk * DP
+                f64x4m acc = {yc[(int64_t)(i0 + 0) * DP], yc[(int64_t)(i0 + 4) * DP], yc[(int64_t)(i0 + 8) * DP], yc[(int64_t)(i0 + 12) * DP]};
+                const double *lp = Lp + lg * 17 + li;                                      // + kk * 17
+                constexpr int PG = 5;
+                const int nch = ib - cb;
+                double bA[PG][4], bB[PG][4];
+                auto loadg = [&](double (&buf)[PG][4], int ch0) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+                    for (int g2 = 0; g2 < PG; ++g2) {
+                        const int ch = ch0 + g2 < nch ? ch0 + g2 : nch - 1;             // clamped: loaded, not used
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = Y[(int64_t)(r0 + a) * DP + q0 + b];
-            // Y[kk][q] is zero for q > kk: start the inner dimension at the first row that reaches column q0 (a multiple of 4, as
-            // is i0: the loop runs in steps of four with all loads of a step issued together)
-            const double *lp0 = Lp + (4 * rg) * DP;
-            int kk = q0;
-            for (; kk < i0; kk += 4) {
-                double yv[4][4], lv[4][4];
+                        for (int u = 0; u < 4; ++u) buf[g2][u] = yc[(int64_t)(16 * (cb + ch) + 4 * u) * DP];
+                    }
+                };
+                auto mm = [&](const double (&buf)[PG][4], int ch0) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const double *yk = Y + (int64_t)(kk + u) * DP + q0;
-                    yv[u][0] = yk[0]; yv[u][1] = yk[1]; yv[u][2] = yk[2]; yv[u][3] = yk[3];
+                    for (int g2 = 0; g2 < PG; ++g2)
+                        if (ch0 + g2 < nch) {
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) lv[u][a] = lp0[a * DP + kk + u];
+                            for (int u = 0; u < 4; ++u)
+                                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-lp[(16 * (cb + ch0 + g2) + 4 * u) * 17], buf[g2][u], acc, 0, 0, 0);
+                        }
+                };
+                if (nch > 0) {
+                    loadg(bA, 0);
+                    for (int ch0 = 0; ch0 < nch; ch0 += 2 * PG) {
+                        if (ch0 + PG < nch) loadg(bB, ch0 + PG);
+                        mm(bA, ch0);
+                        if (ch0 + 2 * PG < nch) loadg(bA, ch0 + 2 * PG);
+                        if (ch0 + PG < nch) mm(bB, ch0 + PG);
+                    }
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int a = 0; a < 4; ++a)
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) acc[a][b] -= lv[u][a] * yv[u][b];
+                double *tp = T + lg * DP + 16 * cb + li;
+                tp[0] = acc[0]; tp[4 * DP] = acc[1]; tp[8 * DP] = acc[2]; tp[12 * DP] = acc[3];
             }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) T[(4 * rg + a) * DP + q0 + b] = acc[a][b];
         }
         __syncthreads();
+        DSTAMP(Da = __builtin_amdgcn_s_memtime(); Dp += Da - Db;)
         // 16 x 16 triangular part: one thread per column
         for (int q = tid; q < ncol; q += 256) {
             double y[16];
@@ -356,7 +381,9 @@ __global__ __launch_bounds__(256) void niw_draw_kernel(NiwMasterArgs A, const in
             for (int r = 0; r < 16; ++r) Y[(int64_t)(i0 + r) * DP + q] = (q <= i0 + r) ? y[r] : 0.0;
         }
         __syncthreads();
+        DSTAMP(Dt += __builtin_amdgcn_s_memtime() - Da;)
     }
+    DSTAMP(Da = __builtin_amdgcn_s_memtime();)
     // log det Sigma = -2 sum log Y_jj (R = Y', Sigma^-1 = R' R)
     if (tid < 64) {
         double lg = 0.0;
@@ -395,6 +422,10 @@ __global__ __launch_bounds__(256) void niw_draw_kernel(NiwMasterArgs A, const in
     const double *m = A.mean + (int64_t)row * DP;
     float *mu_out = A.mu_draw + (int64_t)blockIdx.x * DP;
     for (int d = tid; d < DP; d += 256) mu_out[d] = d < D ? (float)(m[d] + vv[d] * isk) : 0.f;
+#ifdef DPMM_POST_STAMPS      // diagnostic build: phase cycles (scripts/post_stamps.py)
+    __syncthreads();
+    if (tid == 0 && blockIdx.x == 3) { float *o = logdet_sigma + 3; o[0] = (float)Dn; o[1] = (float)Ds; o[2] = (float)Dp; o[3] = (float)Dt; o[4] = (float)(__builtin_amdgcn_s_memtime() - Da); o[5] = (float)(__builtin_amdgcn_s_memtime() - D0); }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------ pack
@@ -780,7 +811,7 @@ hipError_t launch_niw_rows_gather(const double *rows_store, const int32_t *slots
     return hipGetLastError();
 }
 
-size_t niw_master_lds_bytes(int DP) { return sizeof(double) * ((size_t)32 * DP + 16 * 17 + DP); }
+size_t niw_master_lds_bytes(int DP) { return sizeof(double) * ((size_t)34 * DP + 16 * 17); }      // draw: T 16 DP, Ld, xi DP, Lp 17 DP (the factorisation needs less)
 
 hipError_t launch_niw_master_posterior(const NiwMasterArgs &a, const int32_t *jobs, int njobs, const double *rows, double *small, hipStream_t s) {
     if (njobs <= 0) return hipSuccess;
