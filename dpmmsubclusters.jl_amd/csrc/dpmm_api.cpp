@@ -115,6 +115,10 @@ struct dpmm_ctx {
     // draws launched ahead (dpmm_step_master_device): a second stream, so that the pair kernels of the merge proposals do not queue behind them
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_master = nullptr, ev_spec = nullptr;      // posteriors done (main stream) / early draws done (stream2)
+    hipEvent_t ev_noise = nullptr;                          // normals of the next draws generated (stream2)
+    bool noise_inflight = false, noise_valid = false;       // main stream has not waited for ev_noise yet / d_Y[noise_buf] holds the normals of noise_epoch
+    uint32_t noise_epoch = 0;
+    int noise_nmat = 0, noise_buf = 0;
     bool spec_inflight = false, spec_valid = false;         // main stream has not waited for ev_spec yet / the early draws are still the ones a draw call would make
     uint32_t spec_epoch = 0;
     std::vector<int32_t> spec_slots;
@@ -365,6 +369,7 @@ int dpmm_destroy(dpmm_ctx *c) {
     if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
     if (c->ev_master) hipEventDestroy(c->ev_master);
     if (c->ev_spec) hipEventDestroy(c->ev_spec);
+    if (c->ev_noise) hipEventDestroy(c->ev_noise);
     hipFree(c->d_jobs); hipFree(c->d_dslots);
     if (c->h_master) hipHostFree(c->h_master);
     hipFree(c->d_counts64); hipFree(c->d_row_off); hipFree(c->d_work); hipFree(c->d_par);
@@ -1054,6 +1059,18 @@ static int spec_join(dpmm_ctx *c) {
     }
     return DPMM_OK;
 }
+// ... and for the normals generated ahead (before a draw on the main stream: it uses them, or writes the buffer they are written to)
+static int noise_join(dpmm_ctx *c) {
+    if (c->noise_inflight) {
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_noise, 0));
+        c->noise_inflight = false;
+    }
+    return DPMM_OK;
+}
+// the normals of the draws of `epoch` for K clusters are in d_Y[buf] (generated ahead on stream2)
+static bool noise_ready(const dpmm_ctx *c, uint32_t epoch, int K, int buf) {
+    return c->noise_valid && c->noise_epoch == epoch && 3 * K <= c->noise_nmat && c->noise_buf == buf;
+}
 // `data` [n] -> the device list `dst` (stream-ordered on the main stream; nothing is sent when the list is the one already there)
 static int device_list(dpmm_ctx *c, int32_t *dst, std::vector<int32_t> &shadow, const int32_t *data, size_t n) {
     if (shadow.size() == n && (n == 0 || memcmp(shadow.data(), data, sizeof(int32_t) * n) == 0)) return DPMM_OK;
@@ -1070,7 +1087,7 @@ static int master_capacity(dpmm_ctx *c, int slots, int K) {
         ns = std::min(ns, DPMM_MAX_CLUSTERS);
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
-        c->spec_valid = false;
+        c->spec_valid = false; c->noise_valid = false;
         double *fac = nullptr, *mean = nullptr, *kap = nullptr, *nu = nullptr, *rows = nullptr;
         HIPCHK(c, hipMalloc(&fac, sizeof(double) * 3 * ns * DP * DP));
         HIPCHK(c, hipMalloc(&mean, sizeof(double) * 3 * ns * DP));
@@ -1095,7 +1112,7 @@ static int master_capacity(dpmm_ctx *c, int slots, int K) {
         nk = std::min(nk, DPMM_MAX_CLUSTERS);
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
-        c->spec_valid = false;
+        c->spec_valid = false; c->noise_valid = false;
         for (int i = 0; i < 2; ++i) {
             hipFree(c->d_Y[i]); hipFree(c->d_ld_sigma[i]); hipFree(c->d_mu_draw[i]);
             c->d_Y[i] = nullptr; c->d_ld_sigma[i] = nullptr; c->d_mu_draw[i] = nullptr;
@@ -1130,11 +1147,12 @@ int dpmm_niw_master_setup(dpmm_ctx *c, double kappa, double nu, const double *m,
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_master, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_spec, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_noise, hipEventDisableTiming));
         HIPCHK(c, hipMalloc(&c->d_jobs, sizeof(int32_t) * 2 * DPMM_MAX_CLUSTERS));
         HIPCHK(c, hipMalloc(&c->d_dslots, sizeof(int32_t) * DPMM_MAX_CLUSTERS));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream2));
-    c->spec_inflight = false; c->spec_valid = false;
+    c->spec_inflight = false; c->spec_valid = false; c->noise_inflight = false; c->noise_valid = false;
     c->master = true;
     return DPMM_OK;
 }
@@ -1188,7 +1206,9 @@ int dpmm_step_master_device(dpmm_ctx *c, uint32_t reset_epoch, const int32_t *sl
         NiwMasterArgs ma = c->ma;
         ma.mu_draw = c->d_mu_draw[c->draw_cur ^ 1];
         HIPCHK(c, launch_niw_master_draw(ma, hs, K, draw_epoch, c->d_Y[c->draw_cur ^ 1], c->d_ld_sigma[c->draw_cur ^ 1], nullptr, nullptr,
-                                         nullptr, nullptr, nullptr, nullptr, c->NB, nullptr, 1, c->stream2));
+                                         nullptr, nullptr, nullptr, nullptr, c->NB, nullptr,
+                                         1 | (noise_ready(c, draw_epoch, K, c->draw_cur ^ 1) ? 4 : 0), c->stream2));      // (the normals: same stream, earlier)
+        c->noise_valid = false;
         HIPCHK(c, hipEventRecord(c->ev_spec, c->stream2));
         c->spec_inflight = true; c->spec_valid = true; c->spec_epoch = draw_epoch;
         c->spec_slots.assign(slots, slots + K);
@@ -1255,13 +1275,24 @@ int dpmm_niw_master_draw(dpmm_ctx *c, uint32_t epoch, int K, const int32_t *slot
                        memcmp(c->spec_slots.data(), slot_of_cluster, sizeof(int32_t) * K) == 0;
     if (int rc = spec_join(c)) return rc;
     c->spec_valid = false;
+    if (!ahead) if (int rc = noise_join(c)) return rc;
     if (!ahead) if (int rc = device_list(c, c->d_dslots, c->dslots_shadow, slot_of_cluster, (size_t)K)) return rc;
     const int32_t *hs = c->d_dslots;
     c->draw_cur ^= 1;
     NiwMasterArgs ma = c->ma;
     ma.mu_draw = c->d_mu_draw[c->draw_cur];
+    const bool normals = !ahead && noise_ready(c, epoch, K, c->draw_cur);       // (noise_join above made the main stream wait for them)
     HIPCHK(c, launch_niw_master_draw(ma, hs, K, epoch, c->d_Y[c->draw_cur], c->d_ld_sigma[c->draw_cur], hlr, hw, c->d_Rp, c->d_mup, c->d_cst,
-                                     c->have_tail ? c->d_tail : nullptr, c->NB, c->d_work, ahead ? 2 : 3, c->stream));
+                                     c->have_tail ? c->d_tail : nullptr, c->NB, c->d_work, ahead ? 2 : (normals ? 7 : 3), c->stream));
+    // The normals of the NEXT draws (epoch + 1, a few clusters more than now for the splits in between) into the other buffer, on the
+    // second stream: they depend on nothing the master decides, and run beside the sweep instead of in front of it.  Whoever draws
+    // with another epoch, or for more clusters, generates its own.
+    {
+        const int kgen = std::min(K + 4, c->master_K);
+        HIPCHK(c, launch_niw_master_noise(c->ma, 3 * kgen, epoch + 1, c->d_Y[c->draw_cur ^ 1], c->stream2));
+        HIPCHK(c, hipEventRecord(c->ev_noise, c->stream2));
+        c->noise_inflight = true; c->noise_valid = true; c->noise_epoch = epoch + 1; c->noise_nmat = 3 * kgen; c->noise_buf = c->draw_cur ^ 1;
+    }
     c->work_zeroed = true;
     c->have_screen_prep = false;     // (the K > 64 far mask needs the raw factors: not built on this path; the tail screen is)
     c->K = K;

@@ -254,9 +254,44 @@ __global__ __launch_bounds__(256) void niw_chol_kernel(NiwMasterArgs A, const in
 }
 
 // ------------------------------------------------------------------------------------------------------------------ draw
+// The standard normals of the Bartlett factors (everything below the diagonal; zeros on and above it, identity in the padding) of
+// distributions 0 .. gridDim.x - 1 for one epoch: they depend on (seed, epoch, position, element) only -- not on the posteriors, not on the
+// cluster -> slot map -- so they are generated ahead, gridDim.y workgroups per matrix (the draw kernel has one workgroup per matrix and
+// spent 22 % of its time here at D = 256).  One generator block gives the two normals of an element pair (2p, 2p + 1) of a row
+// (Box-Muller, both branches).
+__device__ __forceinline__ void bartlett_pair(const NiwMasterArgs &A, uint64_t id, uint32_t epoch, int r, int c, double &n0, double &n1) {
+    const int D = A.D, DP = A.DP;
+    n0 = 0.0; n1 = 0.0;
+    if (r >= D) { n0 = (c == r) ? 1.0 : 0.0; n1 = (c + 1 == r) ? 1.0 : 0.0; }
+    else if (c < r) {
+        const Philox4 g = philox4x32_10(A.seed, (id << 32) + (uint64_t)r * DP + c, epoch, STREAM_M_NORMAL);
+        const double u1 = u53(g.v[0], g.v[1]), u2 = u53(g.v[2], g.v[3]);
+        const double rad = sqrt(-2.0 * log(u1));
+        double sn, cs;
+        sincos(6.283185307179586476925 * u2, &sn, &cs);
+        n0 = rad * cs;
+        n1 = (c + 1 < r) ? rad * sn : 0.0;
+    }
+}
+__global__ __launch_bounds__(256) void niw_noise_kernel(NiwMasterArgs A, uint32_t epoch, double *__restrict__ Yall) {
+    const int DP = A.DP, HP = DP / 2;
+    double *Y = Yall + (int64_t)blockIdx.x * DP * DP;
+    for (int p2 = blockIdx.y * 256 + threadIdx.x; p2 < DP * HP; p2 += gridDim.y * 256) {
+        const int r = p2 / HP, c = 2 * (p2 - r * HP);
+        double n0, n1;
+        bartlett_pair(A, (uint64_t)blockIdx.x, epoch, r, c, n0, n1);
+        Y[(int64_t)r * DP + c] = n0; Y[(int64_t)r * DP + c + 1] = n1;
+    }
+}
+hipError_t launch_niw_master_noise(const NiwMasterArgs &a, int nmat, uint32_t epoch, double *Y, hipStream_t s) {
+    if (nmat <= 0) return hipSuccess;
+    hipLaunchKernelGGL(niw_noise_kernel, dim3(nmat, a.DP >= 128 ? 8 : (a.DP >= 48 ? 4 : 1)), dim3(256), 0, s, a, epoch, Y);
+    return hipGetLastError();
+}
+
 // One workgroup per distribution (blockIdx.x = 3 k + w in CLUSTER order; slot from slot_of_cluster).  Y (scratch, [3K][DP][DP]).
 __global__ __launch_bounds__(256) void niw_draw_kernel(NiwMasterArgs A, const int32_t *__restrict__ slot_of_cluster, uint32_t epoch,
-                                                       double *__restrict__ Yall, float *__restrict__ logdet_sigma) {
+                                                       double *__restrict__ Yall, float *__restrict__ logdet_sigma, int have_noise) {
     const int k = blockIdx.x / 3, w = blockIdx.x % 3;
     const int row = 3 * slot_of_cluster[k] + w;
     const int D = A.D, DP = A.DP, NB = DP / 16, tid = threadIdx.x;
@@ -275,23 +310,16 @@ __global__ __launch_bounds__(256) void niw_draw_kernel(NiwMasterArgs A, const in
     double *Ld = lds + 16 * DP;          // [16][17]
     double *xi = Ld + 16 * 17;           // [DP]
     double *Lp = xi + DP;                // [DP][17]  rows i0 .. i0 + 15 of L, columns < i0, TRANSPOSED (column kk of L at Lp[kk * 17 + row])
-    // Bartlett factor (lower): chi on the diagonal, standard normals below, identity in the padding.  One generator block gives
-    // the two normals of an element pair (2p, 2p + 1) of a row (Box-Muller, both branches).
-    const int HP = DP / 2;
-    for (int p2 = tid; p2 < DP * HP; p2 += 256) {
-        const int r = p2 / HP, c = 2 * (p2 - r * HP);
-        double n0 = 0.0, n1 = 0.0;
-        if (r >= D) { n0 = (c == r) ? 1.0 : 0.0; n1 = (c + 1 == r) ? 1.0 : 0.0; }
-        else if (c < r) {
-            const Philox4 g = philox4x32_10(A.seed, (id << 32) + (uint64_t)r * DP + c, epoch, STREAM_M_NORMAL);
-            const double u1 = u53(g.v[0], g.v[1]), u2 = u53(g.v[2], g.v[3]);
-            const double rad = sqrt(-2.0 * log(u1));
-            double sn, cs;
-            sincos(6.283185307179586476925 * u2, &sn, &cs);
-            n0 = rad * cs;
-            n1 = (c + 1 < r) ? rad * sn : 0.0;
+    // Bartlett factor (lower): chi on the diagonal, standard normals below, identity in the padding.  The normals are usually there
+    // already (niw_noise_kernel, launched ahead); have_noise == 0: generated here.
+    if (!have_noise) {
+        const int HP = DP / 2;
+        for (int p2 = tid; p2 < DP * HP; p2 += 256) {
+            const int r = p2 / HP, c = 2 * (p2 - r * HP);
+            double n0, n1;
+            bartlett_pair(A, id, epoch, r, c, n0, n1);
+            Y[(int64_t)r * DP + c] = n0; Y[(int64_t)r * DP + c + 1] = n1;
         }
-        Y[(int64_t)r * DP + c] = n0; Y[(int64_t)r * DP + c + 1] = n1;
     }
     __syncthreads();
     for (int r = tid; r < D; r += 256) Y[(int64_t)r * DP + r] = sqrt(2.0 * gamma_mt(0.5 * (nu - r), A.seed, (id << 16) + (uint64_t)r, epoch));
@@ -832,7 +860,8 @@ hipError_t launch_niw_master_posterior(const NiwMasterArgs &a, const int32_t *jo
     return hipGetLastError();
 }
 
-// what: bit 0 = the draws (Y, mu_draw, logdet_sigma from the posteriors), bit 1 = the hand-over to the sweep kernels (needs lr / wts).
+// what: bit 0 = the draws (Y, mu_draw, logdet_sigma from the posteriors), bit 1 = the hand-over to the sweep kernels (needs lr / wts),
+// bit 2 = the normals of this epoch are in Y already (launch_niw_master_noise).
 // The two halves may be launched apart (the draws do not depend on the weights): see dpmm_step_master_device.
 hipError_t launch_niw_master_draw(const NiwMasterArgs &a, const int32_t *slot_of_cluster, int K, uint32_t epoch, double *Y, float *logdet_sigma,
                                   const float *lr, const float *wts, float *Rp, float *mup, float *cst, float *tail, int NB,
@@ -843,7 +872,7 @@ hipError_t launch_niw_master_draw(const NiwMasterArgs &a, const int32_t *slot_of
         hipFuncSetAttribute((const void *)niw_draw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)niw_master_lds_bytes(DPMM_MASTER_MAXD));
         attr = true;
     }
-    if (what & 1) hipLaunchKernelGGL(niw_draw_kernel, dim3(3 * K), dim3(256), niw_master_lds_bytes(a.DP), s, a, slot_of_cluster, epoch, Y, logdet_sigma);
+    if (what & 1) hipLaunchKernelGGL(niw_draw_kernel, dim3(3 * K), dim3(256), niw_master_lds_bytes(a.DP), s, a, slot_of_cluster, epoch, Y, logdet_sigma, (what & 4) ? 1 : 0);
     if (what & 2) hipLaunchKernelGGL(niw_master_pack_kernel, dim3(512), dim3(256), 0, s, Y, a.mu_draw, logdet_sigma, lr, wts, Rp, mup, cst, tail, a.D, a.DP, NB,
                                      3 * K, work);
     return hipGetLastError();
