@@ -328,20 +328,13 @@ __global__ __launch_bounds__(256) void niw_draw_kernel(NiwMasterArgs A, const in
     __syncthreads();
     DSTAMP(Dn = __builtin_amdgcn_s_memtime() - D0;)
     // L Y = A, block row by block row
+    { const int a2 = tid >> 4, b2 = tid & 15; const double dv = L[(int64_t)a2 * DP + b2]; Ld[a2 * 17 + b2] = (b2 <= a2) ? dv : 0.0; if (a2 == b2) Ld[a2 * 17 + 16] = 1.0 / dv; }
+    __syncthreads();
     for (int ib = 0; ib < NB; ++ib) {
         const int i0 = 16 * ib, ncol = i0 + 16;             // columns 0 .. i0 + 15 of this block row can be non-zero
         DSTAMP(Da = __builtin_amdgcn_s_memtime();)
-        // the block row's part of L (columns < i0) -> LDS once: the products below read it 4 values per inner step
-        for (int kk = tid; kk < i0; kk += 256) {          // (i0 <= 240: one trip; the 16 loads of a thread are issued together)
-            double lrow[16];
-#pragma unroll
-            for (int a = 0; a < 16; ++a) lrow[a] = L[(int64_t)(i0 + a) * DP + kk];
-#pragma unroll
-            for (int a = 0; a < 16; ++a) Lp[kk * 17 + a] = lrow[a];
-        }
-        { const int a = tid >> 4, b = tid & 15; Ld[a * 17 + b] = (b <= a) ? L[(int64_t)(i0 + a) * DP + i0 + b] : 0.0; }
-        if (tid < 16) Ld[tid * 17 + 16] = 1.0 / L[(int64_t)(i0 + tid) * DP + i0 + tid];        // reciprocal pivots (17th column)
-        __syncthreads();
+        // (the block row's part of L -- columns < i0 transposed in Lp, diagonal block + reciprocal pivots in Ld -- was staged during the
+        // previous block row's triangular phase; row 0 before the loop)
         DSTAMP(Db = __builtin_amdgcn_s_memtime(); Ds += Db - Da;)
         // T = A(ib, :) - L(ib, < i0) Y(< i0, :) on the FP64 matrix cores (v_mfma_f64_16x16x4_f64: A[i][k = g] = -L[i0 + i][kk + g] from
         // the transposed LDS panel (conflict-free), B[k = g][col = i] = Y[kk + g][16 cb + i] from global memory, element r of C at row
@@ -395,18 +388,41 @@ __global__ __launch_bounds__(256) void niw_draw_kernel(NiwMasterArgs A, const in
         }
         __syncthreads();
         DSTAMP(Da = __builtin_amdgcn_s_memtime(); Dp += Da - Db;)
-        // 16 x 16 triangular part: one thread per column
+        // the NEXT block row's part of L is requested now and written to LDS after the triangular phase (which hides the latency):
+        // columns < i0 + 16 of rows i0 + 16 .. i0 + 31 (thread kk keeps a column), its diagonal block (thread -> element)
+        const int n0 = i0 + 16;
+        const bool more = ib + 1 < NB;
+        double lnx[16], dnx = 0.0;
+        {
+            const int kc = (more && tid < n0) ? tid : 0, rb = more ? n0 : 0;
+#pragma unroll
+            for (int a2 = 0; a2 < 16; ++a2) lnx[a2] = L[(int64_t)(rb + a2) * DP + kc];
+            dnx = L[(int64_t)(rb + (tid >> 4)) * DP + rb + (tid & 15)];
+        }
+        // 16 x 16 triangular part: one thread per column, right-looking (every finished y_r is subtracted from the rows below at once)
         for (int q = tid; q < ncol; q += 256) {
-            double y[16];
+            double t[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] = T[r * DP + q];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                double v = T[r * DP + q];
+                const double yv = t[r] * Ld[r * 17 + 16];
+                t[r] = yv;
 #pragma unroll
-                for (int c = 0; c < r; ++c) v -= Ld[r * 17 + c] * y[c];
-                y[r] = v * Ld[r * 17 + 16];
+                for (int r2 = r + 1; r2 < 16; ++r2) t[r2] = __builtin_fma(-Ld[r2 * 17 + r], yv, t[r2]);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) Y[(int64_t)(i0 + r) * DP + q] = (q <= i0 + r) ? y[r] : 0.0;
+            for (int r = 0; r < 16; ++r) Y[(int64_t)(i0 + r) * DP + q] = (q <= i0 + r) ? t[r] : 0.0;
+        }
+        __syncthreads();
+        if (more) {
+            if (tid < n0) {
+#pragma unroll
+                for (int a2 = 0; a2 < 16; ++a2) Lp[tid * 17 + a2] = lnx[a2];
+            }
+            const int a2 = tid >> 4, b2 = tid & 15;
+            Ld[a2 * 17 + b2] = (b2 <= a2) ? dnx : 0.0;
+            if (a2 == b2) Ld[a2 * 17 + 16] = 1.0 / dnx;
         }
         __syncthreads();
         DSTAMP(Dt += __builtin_amdgcn_s_memtime() - Da;)
@@ -426,22 +442,38 @@ __global__ __launch_bounds__(256) void niw_draw_kernel(NiwMasterArgs A, const in
     __syncthreads();
     for (int cb = NB - 1; cb >= 0; --cb) {
         const int c0 = 16 * cb;
+        // everything this block needs from global memory is requested first: the diagonal block and, for the update pass, the 16 values
+        // of column r of the block's rows (they do not depend on the solve)
         { const int a2 = tid >> 4, b2 = tid & 15; Ld[a2 * 17 + b2] = (b2 <= a2) ? Y[(int64_t)(c0 + a2) * DP + c0 + b2] : 0.0; }
+        double yr[16];
+        const int rr = tid < c0 ? tid : 0;
+#pragma unroll
+        for (int a2 = 0; a2 < 16; ++a2) yr[a2] = Y[(int64_t)(c0 + a2) * DP + rr];
         __syncthreads();
-        if (tid < 16) {
-            double xb = xi[c0 + tid];
-            const double inv = 1.0 / Ld[tid * 17 + tid];
+        if (tid < 64) {
+            // 16 x 16 back substitution by the first 16 lanes (the whole wave runs it: uniform code): lane t keeps x_t and column t of the
+            // block below the diagonal; step a2 broadcasts the finished v_a2 = x_a2 / L_a2a2 with v_readlane (no LDS round trip)
+            const int t16 = tid & 15;
+            double xb = xi[c0 + t16];
+            const double inv = 1.0 / Ld[t16 * 17 + t16];
+            double col[16];
+#pragma unroll
+            for (int a2 = 0; a2 < 16; ++a2) col[a2] = a2 > t16 ? Ld[a2 * 17 + t16] : 0.0;
+            double mine_v = 0.0;
+#pragma unroll
             for (int a2 = 15; a2 >= 0; --a2) {
-                const double va = __shfl(xb, a2, 16) * __shfl(inv, a2, 16);
-                if (tid == a2) vv[c0 + a2] = va;
-                if (tid < a2) xb -= va * Ld[a2 * 17 + tid];
+                const double wq = xb * inv;
+                const double va = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(wq), a2), __builtin_amdgcn_readlane(__double2loint(wq), a2));
+                mine_v = t16 == a2 ? va : mine_v;
+                xb = __builtin_fma(-va, col[a2], xb);
             }
+            if (tid < 16) vv[c0 + tid] = mine_v;
         }
         __syncthreads();
         for (int r = tid; r < c0; r += 256) {
             double acc = xi[r];
 #pragma unroll
-            for (int a2 = 0; a2 < 16; ++a2) acc -= vv[c0 + a2] * Y[(int64_t)(c0 + a2) * DP + r];
+            for (int a2 = 0; a2 < 16; ++a2) acc = __builtin_fma(-vv[c0 + a2], yr[a2], acc);
             xi[r] = acc;
         }
         __syncthreads();
