@@ -137,14 +137,14 @@ def main():
     # THIS command on this round's final build (profiles/, collected by scripts/collect_profiles.sh: FETCH_SIZE doubled per the gfx950
     # note of MI355X_MICROARCH.md + WRITE_SIZE, in KiB) -- only for the configuration it was collected on, else null
     traffic, traffic_source = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "r02e_bench_pmc_summary.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r02f_bench_pmc_summary.json")
     if N == 10 ** 7 and D == 64 and world == 1 and os.path.exists(pmc_file):
         try:
             pm = json.load(open(pmc_file))
             for name, c in pm.items():
                 if "niw_sweep_direct_kernel" in name:
                     traffic = (2.0 * c["FETCH_SIZE"]["median"] + c["WRITE_SIZE"]["median"]) * 1024.0
-                    traffic_source = "profiles/r02e_bench_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, median per launch)"
+                    traffic_source = "profiles/r02f_bench_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, median per launch)"
         except (OSError, ValueError, KeyError):
             traffic = None
     roof = {"kernel": "niw_sweep_direct_kernel<4,4,2,true>" if D <= 64 else "niw_sweep_kernel", "bound": "mfma",
