@@ -21,7 +21,8 @@ def _setup(pkg, D, n, K, seed):
     wk.set_labels(lab, sub)
     wk.set_num_clusters(K)
     A = rng.normal(size=(D, D)); psi = A @ A.T / D + np.eye(D)
-    psi[0, 1] += 0.01                                   # not exactly symmetric: the library symmetrises like the host
+    if D > 1:
+        psi[0, 1] += 0.01                               # not exactly symmetric: the library symmetrises like the host
     prior = (1.5, D + 3.0, rng.normal(size=D), psi)
     return wk, X, lab, sub, prior
 
@@ -220,3 +221,33 @@ def test_draws_launched_ahead_do_not_change_the_chain(pkg, D):
     assert a[0] == b[0] and max(a[0]) > 1
     assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+
+
+@pytest.mark.parametrize("D", [1, 16, 17, 64, 200])
+def test_posterior_of_empty_and_one_sided_clusters(pkg, D):
+    """A cluster whose points all sit in the left sub-cluster, and a cluster without points: the empty distributions get the prior back
+    (N = 0, kappa0, nu0, log det(nu0 psi0)), the others the usual posterior; block sizes around the 16-wide blocking (D = 1, 16, 17)."""
+    n, K = 1500, 3
+    wk, X, lab, sub, prior = _setup(pkg, D, n, K, seed=500 + D)
+    lab = lab.copy(); sub = sub.copy()
+    sub[lab == 1] = 1                      # cluster 1: right sub-cluster empty
+    lab[lab == 3] = 2                      # cluster 3: empty
+    wk.set_labels(lab, sub)
+    wk.master_setup(*prior)
+    wk.suffstats_device(None)
+    slots = np.arange(K, dtype=np.int32)
+    got = wk.master_posterior(None, slots)
+    for k in range(K):
+        for w, mask in enumerate((lab == k + 1, (lab == k + 1) & (sub == 1), (lab == k + 1) & (sub == 2))):
+            N, k1, v1, m1, P = _posterior_numpy(prior, X, mask)
+            assert got[k, w, 0] == N and got[k, w, 1] == k1 and got[k, w, 2] == v1
+            ld = np.linalg.slogdet(P)[1]
+            assert abs(got[k, w, 3] - ld) <= 1e-9 * max(1.0, abs(ld)), (k, w, got[k, w, 3], ld)
+    assert got[0, 2, 0] == 0 and got[2, 0, 0] == 0
+    # draws from those posteriors are finite and upper triangular (the empty ones are draws from the prior)
+    lr = np.full((K, 2), 0.5, np.float32); w = np.full(K, 1.0 / K, np.float32)
+    wk.master_draw(1, slots, lr, w)
+    mu, R, ld = wk.master_draws(K)
+    assert np.all(np.isfinite(mu)) and np.all(np.isfinite(R)) and np.all(np.isfinite(ld))
+    assert np.allclose(np.tril(R.reshape(-1, D, D), -1), 0.0)
+    wk.close()
