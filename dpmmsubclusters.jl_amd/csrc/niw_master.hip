@@ -142,14 +142,27 @@ __global__ __launch_bounds__(256) void niw_chol_kernel(NiwMasterArgs A, const in
     const int DP = A.DP, NB = DP / 16, tid = threadIdx.x;
     double *P = A.fac + (int64_t)row * DP * DP;
     extern __shared__ double lds[];
-    double *Wp = lds;                    // [16][DP]  factor rows of the current block, columns 0 .. j0 + 15
-    double *Dg = lds + 16 * DP;          // [16][17]  diagonal block (symmetric working copy, then the factor; column 16: reciprocal pivots)
+    // row stride DP + 16: the matrix-core operand fetch reads 16 consecutive doubles of rows r, r + 1, r + 2, r + 3 -- with a stride that
+    // is 16 doubles modulo 32 the four rows fall into alternating halves of the 64 banks (two passes, the minimum for 64 x 8 bytes); the
+    // plain stride DP put all four on the same 32 banks (four passes: the trailing update spent more time fetching than multiplying)
+    const int WS = DP + 16;
+    double *Wp = lds;                    // [16][WS]  factor rows of the current block, columns 0 .. j0 + 15
+    double *Dg = lds + 16 * WS;          // [16][17]  diagonal block (symmetric working copy, then the factor; column 16: reciprocal pivots)
     __shared__ double s_ld;
     __shared__ int s_bad;
+    __shared__ uint16_t tri[136];        // block index t of the trailing update -> (kb, qb), qb <= kb: t = kb (kb + 1) / 2 + qb
     if (tid == 0) { s_ld = 0.0; s_bad = 0; }
+    if (tid < 16) for (int qb = 0; qb <= tid; ++qb) tri[tid * (tid + 1) / 2 + qb] = (uint16_t)(tid | (qb << 8));
+#ifdef DPMM_POST_STAMPS
+    unsigned long long C0 = __builtin_amdgcn_s_memtime(), Cd = 0, Cp = 0, Ct = 0, Ca = 0, Cb = 0;
+#define CSTAMP(x) x
+#else
+#define CSTAMP(x)
+#endif
     __syncthreads();
     for (int jb = NB - 1; jb >= 0; --jb) {
         const int j0 = 16 * jb;
+        CSTAMP(Ca = __builtin_amdgcn_s_memtime();)
         // (1) diagonal block -> LDS, mirrored into a full symmetric block, factorised from its last row up by wave 0 with the
         //     look-ahead scheme of niw_post_lds_kernel (every step the same arithmetic in every lane, no divergent code)
         { const int a = tid >> 4, b = tid & 15; Dg[a * 17 + b] = (b <= a) ? P[(int64_t)(j0 + a) * DP + j0 + b] : P[(int64_t)(j0 + b) * DP + j0 + a]; }
@@ -195,7 +208,8 @@ __global__ __launch_bounds__(256) void niw_chol_kernel(NiwMasterArgs A, const in
             }
         }
         __syncthreads();
-        { const int a = tid >> 4, b = tid & 15; if (b <= a) P[(int64_t)(j0 + a) * DP + j0 + b] = Dg[a * 17 + b]; Wp[a * DP + j0 + b] = (b <= a) ? Dg[a * 17 + b] : 0.0; }
+        { const int a = tid >> 4, b = tid & 15; if (b <= a) P[(int64_t)(j0 + a) * DP + j0 + b] = Dg[a * 17 + b]; Wp[a * WS + j0 + b] = (b <= a) ? Dg[a * 17 + b] : 0.0; }
+        CSTAMP(Cb = __builtin_amdgcn_s_memtime(); Cd += Cb - Ca;)
         // (2) panel: column q < j0, four lanes per column (lane s of the quad keeps rows j0 + 4 i + s); coefficients of the diagonal
         //     block and the reciprocal pivots in registers before the first step
         {
@@ -208,11 +222,17 @@ __global__ __launch_bounds__(256) void niw_chol_kernel(NiwMasterArgs A, const in
                 for (int i2 = 0; i2 < 4; ++i2)
                     if (4 * i2 < jj) cf[jj][i2] = Dg[jj * 17 + 4 * i2 + sq];
             }
+            double wnx[4];                                               // the next trip's column, requested before this trip's 16 steps
+            { const int qc0 = (tid >> 2) < j0 ? (tid >> 2) : j0 - 1;
+#pragma unroll
+              for (int i2 = 0; i2 < 4; ++i2) wnx[i2] = P[(int64_t)(j0 + 4 * i2 + sq) * DP + qc0]; }
             for (int q = tid >> 2; q < ((j0 + 63) & ~63); q += 64) {
-                const int qc = q < j0 ? q : j0 - 1;
                 double wv[4];
 #pragma unroll
-                for (int i2 = 0; i2 < 4; ++i2) wv[i2] = P[(int64_t)(j0 + 4 * i2 + sq) * DP + qc];
+                for (int i2 = 0; i2 < 4; ++i2) wv[i2] = wnx[i2];
+                { const int qn = q + 64 < j0 ? q + 64 : j0 - 1;
+#pragma unroll
+                  for (int i2 = 0; i2 < 4; ++i2) wnx[i2] = P[(int64_t)(j0 + 4 * i2 + sq) * DP + qn]; }
 #pragma unroll
                 for (int jj = 15; jj >= 0; --jj) {
                     const double wj = quad_bcast(wv[jj >> 2] * dv[jj], jj & 3);
@@ -225,31 +245,83 @@ __global__ __launch_bounds__(256) void niw_chol_kernel(NiwMasterArgs A, const in
                 }
                 if (q < j0) {
 #pragma unroll
-                    for (int i2 = 0; i2 < 4; ++i2) { P[(int64_t)(j0 + 4 * i2 + sq) * DP + q] = wv[i2]; Wp[(4 * i2 + sq) * DP + q] = wv[i2]; }
+                    for (int i2 = 0; i2 < 4; ++i2) { P[(int64_t)(j0 + 4 * i2 + sq) * DP + q] = wv[i2]; Wp[(4 * i2 + sq) * WS + q] = wv[i2]; }
                 }
             }
         }
         __syncthreads();
+        CSTAMP(Ca = __builtin_amdgcn_s_memtime(); Cp += Ca - Cb;)
         // (3) trailing update of the 16 x 16 blocks (kb, qb), qb <= kb < jb: P -= W' W on the FP64 matrix cores, one block per wave and
         //     trip (C straight from / to global memory, A / B operands from the LDS panel); diagonal blocks are updated whole -- their
         //     upper half is scratch, step (1) mirrors the lower half in
         {
-            const int wave = tid >> 6, li = tid & 15, lg4 = (tid >> 4) & 3;
-            for (int t = wave; t < jb * (jb + 1) / 2; t += 4) {
-                int kb = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
-                while ((kb + 1) * (kb + 2) / 2 <= t) ++kb;
-                while (kb * (kb + 1) / 2 > t) --kb;
-                const int qb = t - kb * (kb + 1) / 2;
-                double *cp = P + (int64_t)(16 * kb + lg4) * DP + 16 * qb + li;
-                f64x4m acc = {cp[0], cp[(int64_t)4 * DP], cp[(int64_t)8 * DP], cp[(int64_t)12 * DP]};
-                const double *wa = Wp + lg4 * DP + 16 * kb + li, *wb = Wp + lg4 * DP + 16 * qb + li;
+            // blocks t = wave, wave + 4, ... in groups of TG: the C loads of a group are all in flight before its matrix instructions
+            // start, and the next group's are requested before this group's results are stored (a block is 4 x 64 matrix-pipe cycles
+            // against > 1000 cycles from L2: one block at a time left the pipe idle 80 % of the phase)
+            constexpr int TG = 6;
+            const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = tid & 15, lg4 = (tid >> 4) & 3;
+            const int nblk = jb * (jb + 1) / 2;
+            // (the wave index as a scalar: everything derived from it -- block indices, LDS and global base addresses -- is then scalar
+            // arithmetic; computed per lane, with a square root and two correction loops per call, it cost more than the matrix work)
+            auto block_of = [&](int t, int &kb, int &qb) {
+                const int e = tri[t];
+                kb = e & 0xff; qb = e >> 8;
+            };
+            f64x4m ca[TG], cn[TG];
+            auto loadc = [&](f64x4m (&c4)[TG], int t0) {
 #pragma unroll
-                for (int t4 = 0; t4 < 4; ++t4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-wa[4 * t4 * DP], wb[4 * t4 * DP], acc, 0, 0, 0);
-                cp[0] = acc[0]; cp[(int64_t)4 * DP] = acc[1]; cp[(int64_t)8 * DP] = acc[2]; cp[(int64_t)12 * DP] = acc[3];
+                for (int g2 = 0; g2 < TG; ++g2) {
+                    const int t = t0 + 4 * g2 < nblk ? t0 + 4 * g2 : (nblk > 0 ? nblk - 1 : 0);        // clamped: loaded, not used
+                    int kb, qb; block_of(t, kb, qb);
+                    const double *cp = P + (int64_t)(16 * kb + lg4) * DP + 16 * qb + li;
+                    c4[g2] = (f64x4m){cp[0], cp[(int64_t)4 * DP], cp[(int64_t)8 * DP], cp[(int64_t)12 * DP]};
+                }
+            };
+            // gfx9 counts loads and stores in ONE in-order queue (vmcnt): a load issued behind a store cannot be waited for without
+            // waiting for the store's acknowledgement (~1.5 k cycles).  Hence per group: all C loads of the NEXT group first, then the
+            // matrix instructions of this group (no memory operation, no branch), then its stores -- waiting for the next group's
+            // loads then allows this group's stores to be outstanding.  Loads are unconditional (clamped block index).
+            auto compute = [&](f64x4m (&c4)[TG], int t0) {
+#pragma unroll
+                for (int g2 = 0; g2 < TG; ++g2) {
+                    const int t = t0 + 4 * g2 < nblk ? t0 + 4 * g2 : nblk - 1;
+                    int kb, qb; block_of(t, kb, qb);
+                    const double *wa = Wp + lg4 * WS + 16 * kb + li, *wb = Wp + lg4 * WS + 16 * qb + li;
+#pragma unroll
+                    for (int t4 = 0; t4 < 4; ++t4) c4[g2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-wa[4 * t4 * WS], wb[4 * t4 * WS], c4[g2], 0, 0, 0);
+                }
+            };
+            auto storec = [&](const f64x4m (&c4)[TG], int t0) {
+#pragma unroll
+                for (int g2 = 0; g2 < TG; ++g2) {
+                    const int t = t0 + 4 * g2;
+                    if (t < nblk) {
+                        int kb, qb; block_of(t, kb, qb);
+                        double *cp = P + (int64_t)(16 * kb + lg4) * DP + 16 * qb + li;
+                        cp[0] = c4[g2][0]; cp[(int64_t)4 * DP] = c4[g2][1]; cp[(int64_t)8 * DP] = c4[g2][2]; cp[(int64_t)12 * DP] = c4[g2][3];
+                    }
+                }
+            };
+            if (wave < nblk) {
+                loadc(ca, wave);
+                for (int t0 = wave; t0 < nblk; t0 += 8 * TG) {
+                    loadc(cn, t0 + 4 * TG);
+                    compute(ca, t0);
+                    storec(ca, t0);
+                    if (t0 + 4 * TG < nblk) {
+                        loadc(ca, t0 + 8 * TG);
+                        compute(cn, t0 + 4 * TG);
+                        storec(cn, t0 + 4 * TG);
+                    }
+                }
             }
         }
         __syncthreads();
+        CSTAMP(Ct += __builtin_amdgcn_s_memtime() - Ca;)
     }
+#ifdef DPMM_POST_STAMPS
+    if (tid == 0 && blockIdx.x == 5 && jobs) { double *o = small + 5 * 4; o[0] = (double)Cd; o[1] = (double)Cp; o[2] = (double)Ct; o[3] = (double)(__builtin_amdgcn_s_memtime() - C0); return; }
+#endif
     if (tid == 0) small[(int64_t)blockIdx.x * 4 + 3] = s_bad ? NAN : s_ld;
 }
 
@@ -871,7 +943,7 @@ hipError_t launch_niw_rows_gather(const double *rows_store, const int32_t *slots
     return hipGetLastError();
 }
 
-size_t niw_master_lds_bytes(int DP) { return sizeof(double) * ((size_t)34 * DP + 16 * 17); }      // draw: T 16 DP, Ld, xi DP, Lp 17 DP (the factorisation needs less)
+size_t niw_master_lds_bytes(int DP) { return sizeof(double) * ((size_t)34 * DP + 16 * 17 + 256); }      // draw: T 16 DP, Ld, xi DP, Lp 17 DP (the factorisation needs less)
 
 hipError_t launch_niw_master_posterior(const NiwMasterArgs &a, const int32_t *jobs, int njobs, const double *rows, double *small, hipStream_t s) {
     if (njobs <= 0) return hipSuccess;

@@ -15,7 +15,10 @@ wk.master_setup(1.0, D + 3.0, np.zeros(D), np.eye(D)); wk.suffstats_device(None)
 slots = np.arange(K, dtype=np.int32)
 for _ in range(3): got = wk.master_posterior(None, slots)
 g = got.reshape(-1, 4)
-print("form %d diag %d panel %d trailing %d | epilogue %d total %d (shader cycles)" % (g[5,0], g[5,1], g[5,2], g[5,3], g[6,0], g[6,1]))
+if D <= 128:
+    print("form %d diag %d panel %d trailing %d | epilogue %d total %d (shader cycles)" % (g[5,0], g[5,1], g[5,2], g[5,3], g[6,0], g[6,1]))
+else:
+    print("factorisation kernel: diag %d panel %d trailing %d total %d (shader cycles)" % (g[5,0], g[5,1], g[5,2], g[5,3]))
 
 lr = np.full((K, 2), 0.5, np.float32); w = np.full(K, 1.0 / K, np.float32)
 for ep in range(3): wk.master_draw(ep + 1, slots, lr, w)
