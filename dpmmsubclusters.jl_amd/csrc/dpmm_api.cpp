@@ -129,11 +129,12 @@ struct dpmm_ctx {
     uint8_t *h_master = nullptr;                   // pinned: jobs | slot map | lr | w | small
     size_t h_master_bytes = 0;
     bool draws_on_device = false;
-    unsigned long long *d_work = nullptr;   // [8 + 16 sweep_grid_max]: tile queue head [4]; [8 + 4 w ..] executed-work counters of wave w of the last sweep
+    unsigned long long *d_work = nullptr;   // [DPMM_WORK_SLOTS + 16 sweep_grid_max]: tile queue heads [4], [8 + 16 q]; [DPMM_WORK_SLOTS + 4 w ..] executed-work counters of wave w of the last sweep
     int work_waves = 0;                      // waves of the last counted sweep launch
     // options (dpmm_set_option)
     float opt_margin = 50.f;
     int opt_prio = 1;
+    int opt_queue_rounds = -1;
     int opt_tail = 1, opt_prescreen = -1, opt_ordered = 1, opt_force_f32 = 0, opt_trace = 0, opt_ref_const = 0;
     int64_t opt_stats_items = 0;
     int opt_stats_groups = 0;
@@ -348,8 +349,8 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
     CHK_CREATE(hipMalloc(&c->sb.perm_total, sizeof(int32_t)));
     CHK_CREATE(hipMalloc(&c->d_small, sizeof(int32_t) * 4 * DPMM_MAX_CLUSTERS));
     CHK_CREATE(hipMalloc(&c->d_counts64, sizeof(long long) * 2 * DPMM_MAX_CLUSTERS));
-    CHK_CREATE(hipMalloc(&c->d_work, sizeof(unsigned long long) * (8 + 16 * (size_t)std::max(1, c->sweep_grid_max))));
-    CHK_CREATE(hipMemset(c->d_work, 0, sizeof(unsigned long long) * (8 + 16 * (size_t)std::max(1, c->sweep_grid_max))));
+    CHK_CREATE(hipMalloc(&c->d_work, sizeof(unsigned long long) * (DPMM_WORK_SLOTS + 16 * (size_t)std::max(1, c->sweep_grid_max))));
+    CHK_CREATE(hipMemset(c->d_work, 0, sizeof(unsigned long long) * (DPMM_WORK_SLOTS + 16 * (size_t)std::max(1, c->sweep_grid_max))));
 #undef CHK_CREATE
     *out = c;
     return DPMM_OK;
@@ -748,7 +749,7 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
     HIPCHK(c, hipSetDevice(c->device));
     if (c->n == 0) return DPMM_OK;
     if (c->prior == DPMM_PRIOR_NIW && !table) {
-        if (!c->work_zeroed) HIPCHK(c, hipMemsetAsync(c->d_work, 0, sizeof(unsigned long long) * 8, c->stream));   // usually done by the pack kernel
+        if (!c->work_zeroed) HIPCHK(c, hipMemsetAsync(c->d_work, 0, sizeof(unsigned long long) * DPMM_WORK_SLOTS, c->stream));   // usually done by the pack kernel
         c->work_zeroed = false;
     }
     if (!table) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
@@ -775,6 +776,7 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
             a.work = table ? nullptr : c->d_work;
             if (!table) c->work_waves = 4 * c->sweep_grid;
             a.prio = c->opt_prio;
+            a.queue_rounds = c->opt_queue_rounds;
         }
 #ifdef DPMM_STAMPS
         if (!g_dbg) { hipMalloc(&g_dbg, sizeof(unsigned long long) * 16 * 4 * 4096); hipMemset(g_dbg, 0, sizeof(unsigned long long) * 16 * 4 * 4096); }
@@ -1621,6 +1623,7 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
         case DPMM_OPT_TRACE_SLOW: c->opt_trace = value != 0; return DPMM_OK;
         case DPMM_OPT_LOGLIK_REF_CONST: c->opt_ref_const = value != 0; return DPMM_OK;
         case DPMM_OPT_WAVE_PRIO: c->opt_prio = value != 0; return DPMM_OK;
+        case DPMM_OPT_SWEEP_QUEUE_ROUNDS: c->opt_queue_rounds = value < 0 ? -1 : (int)value; return DPMM_OK;
         case DPMM_OPT_SWEEP_GRID:
             if (value > 0) c->sweep_grid = (int)std::min<double>(std::min<double>(value, (double)c->sweep_grid_max), (double)std::max<int64_t>(1, c->ntiles));   // scratch is sized for the default
             return DPMM_OK;
@@ -1636,7 +1639,7 @@ int dpmm_last_sweep_work(dpmm_ctx *c, uint64_t *out8) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::vector<unsigned long long> h(4 * (size_t)c->work_waves);
-    if (!h.empty()) HIPCHK(c, hipMemcpy(h.data(), c->d_work + 8, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+    if (!h.empty()) HIPCHK(c, hipMemcpy(h.data(), c->d_work + DPMM_WORK_SLOTS, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
     for (int i = 0; i < 4; ++i) out8[i] = 0;
     for (size_t w = 0; w < (size_t)c->work_waves; ++w)
         for (int i = 0; i < 4; ++i) out8[i] += h[4 * w + i];

@@ -11,6 +11,8 @@ namespace dpmm {
 // The (label, sub-label) pair of the reference (src/ds.jl:54-55) is exactly the
 // sufficient-statistics bin the point contributes to.
 
+constexpr int DPMM_WORK_QUEUES = 8;                               // queue heads of the D <= 64 sweep kernel, 16 u64 apart from work[8]
+constexpr int DPMM_WORK_SLOTS = 8 + 16 * DPMM_WORK_QUEUES;        // first per-wave counter slot
 struct NiwSweepArgs {
     const float *X;      // [n][ldx] points (zero padded to ldx = roundup(D,4))
     int64_t ldx;
@@ -41,8 +43,10 @@ struct NiwSweepArgs {
     int use_prev;             // bins hold labels from a previous sweep (reference clusters of the screen)
     int lds_rows;             // set by the launcher: rows of the a_k table that live in LDS (0: global scratch)
     unsigned long long *dbg;  // diagnostic builds only (DPMM_STAMPS): per-wave phase cycle sums
+    int queue_rounds;         // D <= 64 kernel: rounds of tiles handed out through the queue at the end of the launch (-1: automatic)
     int prio;                 // 1: s_setprio -- low while the wave streams MFMAs, high in its scalar / VALU phases (DPMM_OPT_WAVE_PRIO)
-    unsigned long long *work; // [4] tile queue head of the LDS-staged kernel (cleared before the launch); [8 + 4 w ..]: executed-work counters of
+    unsigned long long *work; // [4] tile queue head of the LDS-staged kernel, [8 + 16 q], q < 8: the eight queue heads of the D <= 64 kernel (one 128-byte
+                              // line each), all cleared before the launch; [DPMM_WORK_SLOTS + 4 w ..]: executed-work counters of
                               // wave w of this launch (wave tiles, full evaluations, 16-row screens, tail-screened cluster pairs), plain
                               // stores at kernel end, summed by the reader; may be null
 };

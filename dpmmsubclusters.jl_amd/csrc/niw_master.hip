@@ -568,7 +568,7 @@ __global__ void niw_master_pack_kernel(const double *__restrict__ Yall, const fl
                                        int nmat, unsigned long long *__restrict__ work) {
     const int NP = NB * (NB + 1) / 2;
     const int DP = 16 * NB;                   // the sweep kernels' padded dimension (>= DPm, the master's)
-    if (work && blockIdx.x == 0 && threadIdx.x < 8) work[threadIdx.x] = 0ull;
+    if (work && blockIdx.x == 0 && threadIdx.x < 8) { work[threadIdx.x] = 0ull; work[8 + 16 * threadIdx.x] = 0ull; }     // counters / queue heads of the next sweep
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < nmat; e += (int64_t)gridDim.x * blockDim.x) {
         const int k = (int)(e / 3), w = (int)(e % 3);
         const float lw = w == 0 ? logf(wts[k]) : logf(lr[2 * k + (w - 1)]);

@@ -552,7 +552,7 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
     // atomics held up the loads of the waves still running: the last round of the D <= 64 kernel took 4x as long, a constant ~70 us
     // per launch whatever N, 20 % of the launch at the 8-GPU shard size.)
     if (A.work && lane == 0) {
-        unsigned long long *slot = A.work + 8 + ((size_t)blockIdx.x * 4 + wave) * 4;
+        unsigned long long *slot = A.work + DPMM_WORK_SLOTS + ((size_t)blockIdx.x * 4 + wave) * 4;
         slot[0] = nw_tiles; slot[1] = nw_full; slot[2] = 0ull; slot[3] = nw_tail;
     }
 #ifdef DPMM_STAMPS
@@ -697,10 +697,17 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
         __syncthreads();
     }
 
-    // (A start stagger of the odd hardware wave slots was measured twice: no effect.  A tile queue -- which fixed a 1.9x straggler
-    // problem in the LDS-staged kernel -- does not pay here although the slowest wave runs 8 % behind the median at N = 1e7: with every
-    // tile claimed by an atomic, one tile ahead, the kernel went from 1.85 to 2.11 ms (156 k atomics on one address, each at the head
-    // of the in-order VMEM return queue of its wave); static for 15/16 of the tiles and a queue for the rest: 1.87 ms.)
+    // Tile schedule: STATIC rounds (tile = wave + r * waves) for most of the launch, then a QUEUE for the last rounds (A.work[4], cleared
+    // with the work counters; non-table sweeps only).  Why: at N = 1e7 every wave but one ends within 3.5 % of the median, and that one
+    // runs 8 % long -- a single tile of the 156 250 in which one point has a hopeless reference costs 30 full evaluations (8 tile times)
+    // and, statically assigned, delays the end of the launch by all of it (per-wave longest-tile stamps, scripts/stamps_bench.py).  With
+    // the last max(2, rounds / 8) rounds handed out tile by tile the other waves absorb it (launches of fewer than 4 rounds stay static:
+    // there the claims cost more than the balance gains; DPMM_OPT_SWEEP_QUEUE_ROUNDS).  A claim is an atomic add with return, issued
+    // one tile AHEAD of its use (the value is read when the tile after next is set up), so its latency is never waited for; it sits in
+    // the in-order VMEM queue in front of the tile's X gather, which takes as long.  Results do not depend on who takes a tile (the
+    // random streams are keyed by the point).  History: claiming EVERY tile (156 k atomics per launch) cost 14 %; that measurement,
+    // like the first 15/16-static attempt (no gain), was taken while the end-of-wave counter atomics still stalled the last rounds.
+    // (A start stagger of the odd hardware wave slots was measured twice: no effect.)
     // Cross-tile prefetch (static tile schedule): while a tile is processed, the wave already fetches the NEXT
     // tile's point indices (order[]) and their previous labels (bins[]); the next tile then issues its X gather at
     // once instead of walking the dependent chain order -> X, order -> bins -> reference cluster -> fragments.
@@ -708,7 +715,37 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
     int nx_p = -1, nx_bin = -1;
     int64_t nx_tile = -1;
     unsigned nw_tiles = 0, nw_full = 0, nw_scr = 0, nw_tail = 0;   // executed-work counters of this wave (wave-uniform)
-    for (int64_t tile = wave_id; tile < nwtiles; tile += nwaves) {
+    const int64_t rounds_all = nwtiles / nwaves;
+    int64_t dyn_rounds = A.queue_rounds >= 0 ? A.queue_rounds : (rounds_all < 4 ? 0 : (rounds_all / 8 > 2 ? rounds_all / 8 : 2));
+    if (dyn_rounds > rounds_all) dyn_rounds = rounds_all;
+    const bool dyn_ok = A.work != nullptr && dyn_rounds > 0;                          // (dyn_rounds == 0: the static schedule, also for the last partial round)
+    const int64_t dyn0 = dyn_ok ? (rounds_all - dyn_rounds) * nwaves : nwtiles;      // tiles >= dyn0 come from the queue
+    // Eight queue heads, one per 128-byte line (same-address atomics are served at ~250 M/s: 2048 waves claiming a tile each per round
+    // through ONE counter cost 8 us per round, a third of a round's work -- measured at the 8-GPU shard size).  Queue q hands out the
+    // tiles dyn0 + 8 c + q; a wave starts at queue (wave & 7) and moves on to the next one when its queue is exhausted.
+    unsigned long long q_pend = 0;            // lane 0: the claim in flight (count c of queue q_cur)
+    bool q_inflight = false;
+    int q_cur = (int)(wave_id & (DPMM_WORK_QUEUES - 1)), q_dead = 0;      // current queue; queues found exhausted in a row
+    auto q_issue = [&]() {
+        if (lane == 0) q_pend = atomicAdd(&A.work[8 + 16 * q_cur], 1ull);
+        q_inflight = true;
+    };
+    auto q_take = [&]() -> int64_t {         // waits for the claim issued one tile ago; an exhausted queue is replaced by the next one
+        for (;;) {
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)q_pend), hi = __builtin_amdgcn_readfirstlane((uint32_t)(q_pend >> 32));
+            q_inflight = false;
+            const int64_t t = dyn0 + (int64_t)(((unsigned long long)hi << 32) | lo) * DPMM_WORK_QUEUES + q_cur;
+            if (t < nwtiles) { q_dead = 0; return t; }
+            if (++q_dead >= DPMM_WORK_QUEUES) return -1;
+            q_cur = (q_cur + 1) & (DPMM_WORK_QUEUES - 1);
+            q_issue();                        // (waited for at once: only at the very end of the launch)
+        }
+    };
+    int64_t tile0, tnext_v = -1;
+    if (!dyn_ok) tile0 = wave_id < nwtiles ? wave_id : -1;
+    else if (wave_id < dyn0) tile0 = wave_id;
+    else { q_issue(); tile0 = q_take(); if (tile0 >= 0) q_issue(); }
+    for (int64_t tile = tile0; tile >= 0; tile = tnext_v) {
         const int64_t wbase = tile * WPTS;
         ++nw_tiles;
         STAMP(s0);
@@ -748,7 +785,16 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                                                   : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
-        const int64_t tnext = tile + nwaves;
+        int64_t tnext;
+        if (!dyn_ok) tnext = tile + nwaves;
+        else if (tile + nwaves < dyn0) tnext = tile + nwaves;                        // static successor
+        else {
+            if (!q_inflight) q_issue();                                               // first tile from the queue: this one claim is waited for
+            tnext = q_take();
+            if (tnext >= 0) q_issue();                                                // the tile after next, read one tile from now
+            else tnext = nwtiles;
+        }
+        tnext_v = tnext < nwtiles ? tnext : -1;
         int pf_p = -1, pf_bin = -1;
         if (tnext < nwtiles) {
             const int64_t posn = tnext * WPTS + lane;
@@ -861,6 +907,23 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
             const float *ml0 = A.mup + (size_t)(3 * k0 + 1) * DP;
             full_eval(k0, k1 != k0 ? A.Rp + (size_t)(3 * k1) * MATSZ : Rl0, k1 != k0 ? A.mup + (size_t)(3 * k1) * DP : ml0);
             if (k1 != k0) full_eval(k1, Rl0, ml0);
+            // Further reference clusters: previous labels of the wave's points other than k0 / k1 -- a tile that covers a whole tiny
+            // cluster (< 62 points) between two others.  Without them those points' reference is hopeless, no cluster can be excluded
+            // for them and all K are evaluated in full: one such tile cost 30 evaluations (8 tile times) and, statically scheduled, ran
+            // 8 % past the end of every other wave at N = 1e7.  Up to two more (four distinct labels per 64 points).
+            int xr0 = -1, xr1 = -1;
+            if (A.use_prev) {
+                int prevl = binv >= 0 ? (binv >> 1) : -1;
+                if ((unsigned)prevl >= (unsigned)K) prevl = -1;
+                unsigned long long oth = __ballot(prevl >= 0 && prevl != k0 && prevl != k1);
+                for (int e = 0; e < 2 && oth; ++e) {
+                    const int kx = __builtin_amdgcn_readfirstlane(__shfl(prevl, __ffsll((long long)oth) - 1));
+                    oth &= ~__ballot(prevl == kx);
+                    load_rb0<NB>(A.Rp + (size_t)(3 * kx) * MATSZ, A.mup + (size_t)(3 * kx) * DP, rb0, mu, lane, g);
+                    full_eval(kx, Rl0, ml0);                          // (prefetches the left sub-cluster's first fragments again: same state as after k0 / k1)
+                    if (e == 0) xr0 = kx; else xr1 = kx;
+                }
+            }
             rb0_mat = ((!FAST && A.labels_only) || !Rl0) ? -1 : 3 * k0 + 1;
             if (pf_p >= 0 && A.use_prev) pf_bin = A.bins[pf_p];     // next tile's previous labels
             STAMP(r1);
@@ -913,7 +976,11 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
             uint32_t *sv = surv_bits[tid >> 6];
             uint32_t *ev = eval_bits[tid >> 6];      // every cluster whose a_k is finite in the table (refs + survivors)
             if (lane < 32) { sv[lane] = 0u; ev[lane] = 0u; }
-            if (lane == 0) { ev[k0 >> 5] |= 1u << (k0 & 31); ev[k1 >> 5] |= 1u << (k1 & 31); }
+            if (lane == 0) {
+                ev[k0 >> 5] |= 1u << (k0 & 31); ev[k1 >> 5] |= 1u << (k1 & 31);
+                if (xr0 >= 0) ev[xr0 >> 5] |= 1u << (xr0 & 31);
+                if (xr1 >= 0) ev[xr1 >> 5] |= 1u << (xr1 & 31);
+            }
             const float margin = A.screen_margin;
             constexpr int LASTP = NP - 1, LB = NB - 1;
             STAMP(r1a);
@@ -962,6 +1029,8 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                 if (prescreen) cand &= ~far_chunk(base);            // also loads ch_c for this chunk
                 if (k0 >= base && k0 < base + 64) cand &= ~(1ull << (k0 - base));
                 if (k1 >= base && k1 < base + 64) cand &= ~(1ull << (k1 - base));
+                if (xr0 >= base && xr0 < base + 64) cand &= ~(1ull << (xr0 - base));
+                if (xr1 >= base && xr1 < base + 64) cand &= ~(1ull << (xr1 - base));
                 auto pop = [&]() -> int {
                     if (!cand) return -1;
                     const int b = __builtin_ctzll(cand);
@@ -1132,7 +1201,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
 #endif
     }
     if (A.work && lane == 0) {      // one slot per wave, no atomics (see the LDS-staged kernel)
-        unsigned long long *slot = A.work + 8 + (size_t)wave_id * 4;
+        unsigned long long *slot = A.work + DPMM_WORK_SLOTS + (size_t)wave_id * 4;
         slot[0] = nw_tiles; slot[1] = nw_full; slot[2] = nw_scr; slot[3] = nw_tail;
     }
 #ifdef DPMM_STAMPS
@@ -1222,7 +1291,7 @@ __global__ void niw_pack_kernel(const float *__restrict__ R, const float *__rest
     // riders (save two launches per sweep): the additive constants move from the parameter image to where the sweep kernels read
     // them, and the executed-work counters of the next sweep start at zero
     if (cst_out) for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < nmat; e += (int64_t)gridDim.x * blockDim.x) cst_out[e] = cst[e];
-    if (work && blockIdx.x == 0 && threadIdx.x < 8) work[threadIdx.x] = 0ull;     // counters [0..3], tile queue head [4]
+    if (work && blockIdx.x == 0 && threadIdx.x < 8) { work[threadIdx.x] = 0ull; work[8 + 16 * threadIdx.x] = 0ull; }     // tile queue heads ([4]; [8 + 16 q])
     const int DP = 16 * NB;
     const size_t TRI = (size_t)D * (D + 1) / 2;
     const int64_t total = (int64_t)nmat * NP * 256;

@@ -17,6 +17,8 @@ wk = pkg.Worker(pkg.PRIOR_NIW, D, N, device=0, seed=1)
 wk.upload_points(X)
 s = host.DPMMSampler(wk, prior, 10.0, N, 1, burnout=20)
 s.start_from_labels(y, 1 + np.random.default_rng(0).integers(0, 2, N), K)
+if len(sys.argv) > 3:
+    wk.set_option(13, float(sys.argv[3]))      # DPMM_OPT_SWEEP_QUEUE_ROUNDS
 for _ in range(6):
     s.group_step(False, False)
 print("kernel ms (stamped build)", wk.last_kernel_ms()[0])
@@ -61,3 +63,14 @@ if D <= 64:
           [int(v) for v in np.percentile(rel[sel], [0, 25, 50, 75, 100])], "; wave lifetime median", int(np.median(d[:, 15] - d[:, 14])))
     print("histogram of the long tile's start / 61k:", np.bincount((rel[sel] / 61000).astype(int), minlength=12).tolist())
     print("waves hit, by workgroup index mod 8 (XCD):", np.bincount((np.nonzero(sel)[0] // 4) % 8, minlength=8).tolist())
+if D <= 64:
+    srt = np.sort(tt)[::-1]
+    print("top-20 per-wave totals / median:", np.round(srt[:20] / np.median(tt), 3).tolist())
+    print("percentiles 50/90/99/99.9/100 of total/median:", np.round(np.percentile(tt, [50, 90, 99, 99.9, 100]) / np.median(tt), 3).tolist())
+    top = np.argsort(-tt)[:12]
+    print("slowest waves: (wave, tiles, total/median, longest tile)", [(int(i), int(d[i, 8]), round(float(tt[i] / np.median(tt)), 3), int(d[i, 11])) for i in top])
+    for ntile in (int(d[:, 8].min()), int(d[:, 8].max())):
+        m = d[:, 8] == ntile
+        print(f"waves with {ntile} tiles: {int(m.sum())}, total median {np.median(tt[m]):.0f} max {tt[m].max():.0f}")
+    w = int(np.argmax(d[:, 11]))
+    print("wave with the longest tile:", w, "phase sums", [int(v) for v in d[w, :8]], "tiles/tail/mfma-screened", [int(v) for v in d[w, 8:11]], "median wave phases", [int(v) for v in np.median(d[:, :8], axis=0)])
