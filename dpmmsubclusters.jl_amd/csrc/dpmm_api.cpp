@@ -340,6 +340,9 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
     c->nt_sort = (int)((n_local + SORT_TILE - 1) / SORT_TILE);
     const size_t nbmax = 2 * DPMM_MAX_CLUSTERS;
     CHK_CREATE(hipMalloc(&c->sb.tile_hist, sizeof(int32_t) * nbmax * (size_t)std::max(1, c->nt_sort)));
+    CHK_CREATE(hipMalloc(&c->sb.tile_cnt, sizeof(int32_t) * nbmax * (size_t)std::max(1, c->nt_sort)));
+    CHK_CREATE(hipMalloc(&c->sb.dirty, (size_t)std::max(1, c->nt_sort)));
+    CHK_CREATE(hipMemset(c->sb.dirty, 0, (size_t)std::max(1, c->nt_sort)));
     CHK_CREATE(hipMalloc(&c->sb.bin_total, sizeof(int32_t) * nbmax));
     CHK_CREATE(hipMalloc(&c->sb.bin_start, sizeof(int32_t) * (nbmax + 1)));
     CHK_CREATE(hipMalloc(&c->sb.item_start, sizeof(int32_t) * (nbmax + 1)));
@@ -362,7 +365,7 @@ int dpmm_destroy(dpmm_ctx *c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     free_params(c);
     hipFree(c->dX); hipFree(c->dX8); hipFree(c->dbins); hipFree(c->d_gt); hipFree(c->d_cont);
-    hipFree(c->sb.tile_hist); hipFree(c->sb.bin_total); hipFree(c->sb.bin_start); hipFree(c->sb.item_start);
+    hipFree(c->sb.tile_hist); hipFree(c->sb.tile_cnt); hipFree(c->sb.dirty); hipFree(c->sb.bin_total); hipFree(c->sb.bin_start); hipFree(c->sb.item_start);
     hipFree(c->sb.perm); hipFree(c->sb.bin_sel); hipFree(c->sb.perm_total); hipFree(c->d_small); hipFree(c->d_proj); hipFree(c->d_vals); hipFree(c->d_smart);
     hipFree(c->d_m0); hipFree(c->d_psi_lo); hipFree(c->d_pairs);
     for (int i = 0; i < 2; ++i) { hipFree(c->d_Y[i]); hipFree(c->d_ld_sigma[i]); hipFree(c->d_mu_draw[i]); }
@@ -973,7 +976,7 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
         // the flags live right behind the packed rows, so that rows + flags reach the master in one copy
         uint8_t *flags = reinterpret_cast<uint8_t *>(c->d_out) + sizeof(double) * (size_t)nbins * (size_t)c->packed_stride;
         if (c->n > 0) {
-            HIPCHK(c, launch_reset_sub_flagged(c->dbins, c->n, c->first, c->sb.bin_total, gc, flags, c->K, c->seed, reset_epoch, c->stream));
+            HIPCHK(c, launch_reset_sub_flagged(c->dbins, c->n, c->first, c->sb.bin_total, gc, c->sb.dirty, flags, c->K, c->seed, reset_epoch, c->stream));
             HIPCHK(c, launch_sort_by_bin(c->dbins, c->n, nbins, c->sb, c->stream, flags + c->K));
         } else {
             HIPCHK(c, launch_bad_flags(c->sb.bin_total, gc, c->K, flags, c->stream));

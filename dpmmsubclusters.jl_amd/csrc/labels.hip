@@ -126,8 +126,8 @@ hipError_t launch_bad_flags(const int32_t *bin_total, const long long *global_co
 // 2K occupancies in LDS, workgroup 0 publishes them (flags[0..K], read by the conditional re-histogram and returned to the master
 // with the statistics); nothing else happens when no cluster is flagged.
 __global__ __launch_bounds__(256) void reset_sub_flagged_kernel(int32_t *bins, int64_t n, int64_t first, const int32_t *__restrict__ bin_total,
-                                                                const long long *__restrict__ global_counts, uint8_t *__restrict__ flags,
-                                                                int K, uint64_t seed, uint32_t epoch) {
+                                                                const long long *__restrict__ global_counts, uint8_t *__restrict__ dirty,
+                                                                uint8_t *__restrict__ flags, int K, uint64_t seed, uint32_t epoch) {
     __shared__ uint8_t f[DPMM_MAX_CLUSTERS_K];
     __shared__ int any;
     if (threadIdx.x == 0) any = 0;
@@ -148,12 +148,13 @@ __global__ __launch_bounds__(256) void reset_sub_flagged_kernel(int32_t *bins, i
         if ((unsigned)z < (unsigned)K && f[z]) {
             const Philox4 r = philox4x32_10(seed, (uint64_t)(first + i), epoch, STREAM_RESET);
             bins[i] = 2 * z + (int)(r.v[0] & 1u);
+            if (dirty) dirty[i / SORT_TILE] = 1;       // the second histogram pass of the step re-counts this tile only
         }
     }
 }
-hipError_t launch_reset_sub_flagged(int32_t *bins, int64_t n, int64_t first, const int32_t *bin_total, const long long *global_counts,
+hipError_t launch_reset_sub_flagged(int32_t *bins, int64_t n, int64_t first, const int32_t *bin_total, const long long *global_counts, uint8_t *dirty,
                                     uint8_t *flags, int K, uint64_t seed, uint32_t epoch, hipStream_t s) {
-    hipLaunchKernelGGL(reset_sub_flagged_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, n, first, bin_total, global_counts, flags, K, seed, epoch);
+    hipLaunchKernelGGL(reset_sub_flagged_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, n, first, bin_total, global_counts, dirty, flags, K, seed, epoch);
     return hipGetLastError();
 }
 __global__ void widen_counts_kernel(const int32_t *__restrict__ src, long long *__restrict__ dst, int n) {

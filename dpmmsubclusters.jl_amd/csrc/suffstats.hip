@@ -31,9 +31,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------ sort
 __global__ __launch_bounds__(64) void hist_kernel(const int32_t *__restrict__ bins, int64_t n, int nbins, int nt,
-                                                  int32_t *__restrict__ tile_hist, const uint8_t *__restrict__ only_if) {
+                                                  int32_t *__restrict__ tile_hist, const uint8_t *__restrict__ only_if, uint8_t *__restrict__ dirty) {
     extern __shared__ int cnt[];
-    if (only_if && !*only_if) return;
+    if (only_if) {      // second pass of a step: only when a cluster was reset, and only the tiles the reset touched
+        if (!*only_if || (dirty && !dirty[blockIdx.x])) return;
+    } else if (dirty && threadIdx.x == 0) dirty[blockIdx.x] = 0;
     const int lane = threadIdx.x;
     for (int b = lane; b < nbins; b += 64) cnt[b] = 0;
     __syncthreads();
@@ -72,15 +74,16 @@ __global__ __launch_bounds__(64) void hist_kernel(const int32_t *__restrict__ bi
 }
 
 // exclusive scan over the tiles of one bin (in place) + bin total
-__global__ __launch_bounds__(256) void scan_tiles_kernel(int32_t *__restrict__ tile_hist, int nt, int32_t *__restrict__ bin_total,
-                                                         const uint8_t *__restrict__ only_if) {
+__global__ __launch_bounds__(256) void scan_tiles_kernel(const int32_t *__restrict__ tile_cnt, int32_t *__restrict__ tile_hist, int nt,
+                                                         int32_t *__restrict__ bin_total, const uint8_t *__restrict__ only_if) {
     __shared__ int part[256];
     if (only_if && !*only_if) return;
+    const int32_t *src = tile_cnt + (int64_t)blockIdx.x * nt;
     int32_t *row = tile_hist + (int64_t)blockIdx.x * nt;
     const int per = (nt + 255) / 256;
     const int lo = threadIdx.x * per, hi = min(lo + per, nt);
     int s = 0;
-    for (int i = lo; i < hi; ++i) s += row[i];
+    for (int i = lo; i < hi; ++i) s += src[i];
     part[threadIdx.x] = s;
     __syncthreads();
     // Hillis-Steele inclusive scan over the 256 partials
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256) void scan_tiles_kernel(int32_t *__restrict__ t
     }
     int run = part[threadIdx.x] - s;  // exclusive prefix of this thread's range
     for (int i = lo; i < hi; ++i) {
-        const int v = row[i];
+        const int v = src[i];
         row[i] = run;
         run += v;
     }
@@ -186,8 +189,8 @@ __global__ __launch_bounds__(64) void scatter_kernel(const int32_t *__restrict__
 hipError_t launch_sort_by_bin(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s, const uint8_t *only_if) {
     const int nt = (int)((n + SORT_TILE - 1) / SORT_TILE);
     if (nt == 0) return hipSuccess;
-    hipLaunchKernelGGL(hist_kernel, dim3(nt), dim3(64), nbins * sizeof(int), s, bins, n, nbins, nt, b.tile_hist, only_if);
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(nbins), dim3(256), 0, s, b.tile_hist, nt, b.bin_total, only_if);
+    hipLaunchKernelGGL(hist_kernel, dim3(nt), dim3(64), nbins * sizeof(int), s, bins, n, nbins, nt, b.tile_cnt, only_if, b.dirty);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(nbins), dim3(256), 0, s, b.tile_cnt, b.tile_hist, nt, b.bin_total, only_if);
     return hipGetLastError();
 }
 
