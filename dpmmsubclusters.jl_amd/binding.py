@@ -81,6 +81,7 @@ ABI = [
 ]
 
 # dpmm_set_option keys (include/dpmm_hip.h)
+MASTER_NSCALARS = 8          # DPMM_MASTER_NSCALARS
 OPT_SCREEN_MARGIN, OPT_TAIL_SCREEN, OPT_PRESCREEN, OPT_ORDERED_SWEEP, OPT_MULT_FORCE_F32, OPT_STATS_ITEMS, OPT_STATS_GROUPS, OPT_TRACE_SLOW, OPT_LOGLIK_REF_CONST, OPT_WAVE_PRIO, OPT_MULT_NO_U8, OPT_SWEEP_GRID, OPT_SWEEP_QUEUE_ROUNDS = range(1, 14)
 
 
@@ -422,12 +423,12 @@ class Worker:
         self._chk(self._lib.dpmm_suffstats_device(self._h, None if idx is None else idx.ctypes.data, 0 if idx is None else len(idx)))
 
     def master_posterior(self, clusters, slots):
-        """dpmm_niw_master_posterior: (n, 3, 4) float64 {N, kappa', nu', log det(nu' psi')} for the listed clusters (1-based)."""
+        """dpmm_niw_master_posterior: (n, 3, 8) float64 {N, kappa', nu', log det(nu' psi'), log Gamma_D(nu' / 2), 3 spare} for the listed clusters (1-based)."""
         slots = np.ascontiguousarray(slots, np.int32)
         cl = None if clusters is None else np.ascontiguousarray(clusters, np.int64)
         out = ctypes.c_void_p()
         self._chk(self._lib.dpmm_niw_master_posterior(self._h, None if cl is None else cl.ctypes.data, slots.ctypes.data, len(slots), ctypes.byref(out)))
-        return np.ctypeslib.as_array(ctypes.cast(out, _c_f64p), shape=(len(slots), 3, 4)).copy()
+        return np.ctypeslib.as_array(ctypes.cast(out, _c_f64p), shape=(len(slots), 3, MASTER_NSCALARS)).copy()
 
     def master_draw(self, epoch, slot_of_cluster, lr_weights, weights):
         sl = np.ascontiguousarray(slot_of_cluster, np.int32)
@@ -435,11 +436,11 @@ class Worker:
         self._chk(self._lib.dpmm_niw_master_draw(self._h, int(epoch), len(sl), sl.ctypes.data, lr.ctypes.data, w.ctypes.data))
 
     def master_pairs(self, slots_i, slots_j):
-        """dpmm_niw_master_pairs: (n, 4) float64 {N, kappa', nu', log det(nu' psi')} of the pooled statistics of the slot pairs."""
+        """dpmm_niw_master_pairs: (n, 8) float64 {N, kappa', nu', log det(nu' psi'), log Gamma_D(nu' / 2), 3 spare} of the pooled statistics of the slot pairs."""
         a = np.ascontiguousarray(slots_i, np.int32); b = np.ascontiguousarray(slots_j, np.int32)
         out = ctypes.c_void_p()
         self._chk(self._lib.dpmm_niw_master_pairs(self._h, a.ctypes.data, b.ctypes.data, len(a), ctypes.byref(out)))
-        return np.ctypeslib.as_array(ctypes.cast(out, _c_f64p), shape=(len(a), 4)).copy()
+        return np.ctypeslib.as_array(ctypes.cast(out, _c_f64p), shape=(len(a), MASTER_NSCALARS)).copy()
 
     def master_rows(self, slots):
         sl = np.ascontiguousarray(slots, np.int32)

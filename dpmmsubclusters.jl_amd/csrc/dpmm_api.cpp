@@ -1191,7 +1191,7 @@ int dpmm_step_master_device(dpmm_ctx *c, uint32_t reset_epoch, const int32_t *sl
     const size_t out_bytes = sizeof(double) * 2 * (size_t)K * (size_t)c->packed_stride;
     if (int rc = ensure_out(c, DPMM_MAX_CLUSTERS + 64)) return rc;
     const size_t jobs_bytes = (sizeof(int32_t) * 2 * (size_t)K + 63) & ~(size_t)63;
-    if (int rc = master_pinned(c, jobs_bytes + sizeof(double) * 12 * (size_t)K)) return rc;
+    if (int rc = master_pinned(c, jobs_bytes + sizeof(double) * 3 * DPMM_MASTER_NSCALARS * (size_t)K)) return rc;
     // every user of the pinned block waits for its kernels before returning, so it is free here; no wait -- the sweep is still in flight
     std::vector<int32_t> jobs(2 * (size_t)K);
     for (int k = 0; k < K; ++k) { jobs[2 * k] = k; jobs[2 * k + 1] = slots[k]; }
@@ -1246,7 +1246,7 @@ int dpmm_niw_master_posterior(dpmm_ctx *c, const int64_t *clusters, const int32_
     if (int rc = spec_join(c)) return rc;
     c->spec_valid = false;                                 // some factors change: draws launched ahead are not the ones to use
     const size_t jobs_bytes = (sizeof(int32_t) * 2 * (size_t)n + 63) & ~(size_t)63;
-    if (int rc = master_pinned(c, jobs_bytes + sizeof(double) * 12 * (size_t)n)) return rc;
+    if (int rc = master_pinned(c, jobs_bytes + sizeof(double) * 3 * DPMM_MASTER_NSCALARS * (size_t)n)) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));            // nobody reads the pinned block any more
     std::vector<int32_t> jobs(2 * (size_t)n);
     for (int i = 0; i < n; ++i) { jobs[2 * i] = (int32_t)((clusters ? clusters[i] : i + 1) - 1); jobs[2 * i + 1] = slots[i]; }
@@ -1324,7 +1324,7 @@ int dpmm_niw_master_pairs(dpmm_ctx *c, const int32_t *slots_i, const int32_t *sl
         c->pair_cap = cap;
     }
     const size_t idx_bytes = (sizeof(int32_t) * 2 * (size_t)n + 63) & ~(size_t)63;
-    if (int rc = master_pinned(c, idx_bytes + sizeof(double) * 4 * (size_t)n)) return rc;
+    if (int rc = master_pinned(c, idx_bytes + sizeof(double) * DPMM_MASTER_NSCALARS * (size_t)n)) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     int32_t *pr = reinterpret_cast<int32_t *>(c->h_master);
     for (int i = 0; i < n; ++i) { pr[2 * i] = slots_i[i]; pr[2 * i + 1] = slots_j[i]; }

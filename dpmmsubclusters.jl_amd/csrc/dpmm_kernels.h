@@ -170,6 +170,9 @@ hipError_t launch_mult_stats_u8(const StatsArgs &a, const uint8_t *X8, int64_t l
 
 // ---- the master's dense maths on the device (niw_master.hip) ----
 #define DPMM_MASTER_MAXD 256
+#ifndef DPMM_MASTER_NSCALARS
+#define DPMM_MASTER_NSCALARS 8      // doubles per distribution in the scalar records: N, kappa', nu', log det(nu' psi'), log Gamma_D(nu' / 2), 3 spare (dpmm_hip.h)
+#endif
 struct NiwMasterArgs {
     int D, DP;                    // DP = 16 * ceil(D / 16)
     int64_t packed_stride;

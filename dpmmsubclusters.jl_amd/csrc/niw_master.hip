@@ -27,6 +27,16 @@ namespace dpmm {
 
 enum : uint32_t { STREAM_M_NORMAL = 32, STREAM_M_CHI = 33, STREAM_M_XI = 34 };
 typedef double f64x4m __attribute__((ext_vector_type(4)));
+constexpr int NS = DPMM_MASTER_NSCALARS;      // doubles per distribution in `small`: N, kappa', nu', log det(nu' psi'), log Gamma_D(nu' / 2), 3 spare
+
+// log Gamma_D(x) = D (D - 1) / 4 log pi + sum_{d=1..D} lgamma(x + (1 - d) / 2)   (utils.jl:66-72), by the 64 lanes of a wave: what the
+// master's log-marginals need besides the log-determinant -- D lgamma evaluations per distribution, a pool job on the host
+__device__ __forceinline__ double log_mv_gamma_wave(double x, int D, int lane) {
+    double t = 0.0;
+    for (int d = 1 + lane; d <= D; d += 64) t += lgamma(x + 0.5 * (double)(1 - d));
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    return t + (double)D * (double)(D - 1) * 0.25 * 1.1447298858494001741434273513530587;
+}
 
 __device__ __forceinline__ double u53(uint32_t a, uint32_t b) {          // (0, 1), 53 bits
     return ((double)((((uint64_t)a << 32) | b) >> 11) + 0.5) * (1.0 / 9007199254740992.0);
@@ -57,7 +67,7 @@ __device__ double gamma_mt(double a, uint64_t seed, uint64_t idx, uint32_t epoch
 
 // ------------------------------------------------------------------------------------------------------------------ form
 // job j: cluster k = jobs[2j] (0-based), slot s = jobs[2j+1]; rows 3s + w, w = 0 (cluster = left + right), 1 (left), 2 (right).
-// small[(3j + w) * 4 + {0,1,2}] = N, kappa', nu'   (entry 3: log det(nu' psi'), written by the factorisation)
+// small[(3j + w) * NS + {0,1,2,4}] = N, kappa', nu', log Gamma_D(nu' / 2)   (entry 3: log det(nu' psi'), written by the factorisation)
 __global__ __launch_bounds__(256) void niw_form_kernel(NiwMasterArgs A, const int32_t *__restrict__ jobs, const double *__restrict__ rows,
                                                        double *__restrict__ small) {
     const int j = blockIdx.x / 3, w = blockIdx.x % 3;
@@ -85,9 +95,13 @@ __global__ __launch_bounds__(256) void niw_form_kernel(NiwMasterArgs A, const in
     }
     __syncthreads();
     if (threadIdx.x == 0 && blockIdx.y == 0) {
-        double *o = small + (int64_t)(3 * j + w) * 4;
+        double *o = small + (int64_t)(3 * j + w) * NS;
         o[0] = N; o[1] = (N == 0.0) ? k0 : k1; o[2] = (N == 0.0) ? v0 : v1;
         A.kap[row] = o[1]; A.nu[row] = o[2];
+    }
+    if (blockIdx.y == 0 && threadIdx.x < 64) {
+        const double lm = log_mv_gamma_wave(0.5 * ((N == 0.0) ? v0 : v1), D, threadIdx.x);
+        if (threadIdx.x == 0) small[(int64_t)(3 * j + w) * NS + 4] = lm;
     }
     const double *tl = l + 1 + D, *tr = r + 1 + D;
     // rows a = blockIdx.y, blockIdx.y + gridDim.y, ... of the scale matrix; one thread per column
@@ -320,9 +334,9 @@ __global__ __launch_bounds__(256) void niw_chol_kernel(NiwMasterArgs A, const in
         CSTAMP(Ct += __builtin_amdgcn_s_memtime() - Ca;)
     }
 #ifdef DPMM_POST_STAMPS
-    if (tid == 0 && blockIdx.x == 5 && jobs) { double *o = small + 5 * 4; o[0] = (double)Cd; o[1] = (double)Cp; o[2] = (double)Ct; o[3] = (double)(__builtin_amdgcn_s_memtime() - C0); return; }
+    if (tid == 0 && blockIdx.x == 5 && jobs) { double *o = small + 5 * NS; o[0] = (double)Cd; o[1] = (double)Cp; o[2] = (double)Ct; o[3] = (double)(__builtin_amdgcn_s_memtime() - C0); return; }
 #endif
-    if (tid == 0) small[(int64_t)blockIdx.x * 4 + 3] = s_bad ? NAN : s_ld;
+    if (tid == 0) small[(int64_t)blockIdx.x * NS + 3] = s_bad ? NAN : s_ld;
 }
 
 // ------------------------------------------------------------------------------------------------------------------ draw
@@ -615,7 +629,7 @@ __global__ void niw_master_pack_kernel(const double *__restrict__ Yall, const fl
 }
 
 // Pooled statistics of cluster pairs for the merge proposals (shared_actions.jl:21-27): job p pools the four stored rows of slots
-// pairs[2p], pairs[2p+1]; P = nu' psi' of the pooled set -> scratch matrix p; small[4p + {0,1,2}] = N, kappa', nu'.
+// pairs[2p], pairs[2p+1]; P = nu' psi' of the pooled set -> scratch matrix p; small[NS p + {0,1,2,4}] = N, kappa', nu', log Gamma_D(nu' / 2).
 __global__ __launch_bounds__(256) void niw_form_pair_kernel(NiwMasterArgs A, const int32_t *__restrict__ pairs, double *__restrict__ scratch,
                                                             double *__restrict__ small) {
     const int p = blockIdx.x;
@@ -635,8 +649,12 @@ __global__ __launch_bounds__(256) void niw_form_pair_kernel(NiwMasterArgs A, con
     }
     __syncthreads();
     if (threadIdx.x == 0 && blockIdx.y == 0) {
-        double *o = small + (int64_t)p * 4;
+        double *o = small + (int64_t)p * NS;
         o[0] = N; o[1] = (N == 0.0) ? k0 : k1; o[2] = (N == 0.0) ? v0 : v1;
+    }
+    if (blockIdx.y == 0 && threadIdx.x < 64) {
+        const double lm = log_mv_gamma_wave(0.5 * ((N == 0.0) ? v0 : v1), D, threadIdx.x);
+        if (threadIdx.x == 0) small[(int64_t)p * NS + 4] = lm;
     }
     for (int a = blockIdx.y; a < DP; a += gridDim.y)
         for (int b = threadIdx.x; b < DP; b += blockDim.x) {
@@ -670,7 +688,7 @@ __global__ __launch_bounds__(256) void niw_form_pair_kernel(NiwMasterArgs A, con
 //   trailing update  4 x 4 register tiles, operands from LDS
 // PAIRS = false: job j = blockIdx.x / 3 (cluster jobs[2j], slot jobs[2j+1]), w = blockIdx.x % 3; writes fac / mean / kap / nu /
 // rows_store like the two kernels it replaces.  PAIRS = true: job p = blockIdx.x pools the four stored rows of slots jobs[2p],
-// jobs[2p+1]; only small[4p + 0..3] is written.
+// jobs[2p+1]; only small[NS p + 0..4] is written.
 template <bool PAIRS>
 __global__ __launch_bounds__(256) void niw_post_lds_kernel(NiwMasterArgs A, const int32_t *__restrict__ jobs, const double *__restrict__ rows,
                                                            double *__restrict__ small) {
@@ -740,7 +758,7 @@ __global__ __launch_bounds__(256) void niw_post_lds_kernel(NiwMasterArgs A, cons
         if constexpr (!PAIRS) A.mean[(int64_t)row * DP + a] = mv;
     }
     if (tid == 0) {
-        double *o = small + (int64_t)blockIdx.x * 4;
+        double *o = small + (int64_t)blockIdx.x * NS;
         o[0] = N; o[1] = (N == 0.0) ? k0 : k1; o[2] = (N == 0.0) ? v0 : v1;
         if constexpr (!PAIRS) { A.kap[row] = o[1]; A.nu[row] = o[2]; }
     }
@@ -894,7 +912,10 @@ __global__ __launch_bounds__(256) void niw_post_lds_kernel(NiwMasterArgs A, cons
         double lg = 0.0;
         for (int a = tid; a < DP; a += 64) lg += log(piv[a]);
         for (int o = 32; o > 0; o >>= 1) lg += __shfl_xor(lg, o);
-        if (tid == 0) small[(int64_t)blockIdx.x * 4 + 3] = s_bad ? NAN : lg;
+        if (tid == 0) small[(int64_t)blockIdx.x * NS + 3] = s_bad ? NAN : lg;
+    } else if (tid < 128) {      // (the second wave, meanwhile)
+        const double lm = log_mv_gamma_wave(0.5 * ((N == 0.0) ? v0 : v1), D, tid - 64);
+        if (tid == 64) small[(int64_t)blockIdx.x * NS + 4] = lm;
     }
     if constexpr (!PAIRS) {
         double *F = A.fac + (int64_t)row * DP * DP;
@@ -905,8 +926,8 @@ __global__ __launch_bounds__(256) void niw_post_lds_kernel(NiwMasterArgs A, cons
     }
 #ifdef DPMM_POST_STAMPS          // diagnostic build: phase cycles of two workgroups overwrite their scalars (scripts/post_stamps.py)
     __syncthreads();
-    if (tid == 0 && blockIdx.x == 5) { double *o = small + 5 * 4; o[0] = (double)Tf; o[1] = (double)Td; o[2] = (double)Tp; o[3] = (double)Tt; }
-    if (tid == 0 && blockIdx.x == 6) { double *o = small + 6 * 4; o[0] = (double)(__builtin_amdgcn_s_memtime() - Ta); o[1] = (double)(__builtin_amdgcn_s_memtime() - T0); }
+    if (tid == 0 && blockIdx.x == 5) { double *o = small + 5 * NS; o[0] = (double)Tf; o[1] = (double)Td; o[2] = (double)Tp; o[3] = (double)Tt; }
+    if (tid == 0 && blockIdx.x == 6) { double *o = small + 6 * NS; o[0] = (double)(__builtin_amdgcn_s_memtime() - Ta); o[1] = (double)(__builtin_amdgcn_s_memtime() - T0); }
 #endif
 }
 size_t niw_post_lds_bytes(int DP) { return sizeof(double) * ((size_t)DP * (DP + 1) + 3 * (size_t)DP + 16); }

@@ -167,6 +167,7 @@ struct dpmmh_model {
     Helper helper;
     // device master (worker.niw_*): dev_state = the device holds the posteriors of every live slot; host_dense = the host's packed
     // rows / means / factors are current (false while the device is the only one that has seen the latest statistics)
+    static constexpr int kDevScalars = 8;      // DPMM_MASTER_NSCALARS of the worker ABI: N, kappa', nu', log det(nu' psi'), log Gamma_D(nu' / 2), spare
     int opt_dev_master = -1;
     int opt_draw_ahead = 1;          // device master: the next draws are launched with the posteriors (DPMMH_OPT_DRAW_AHEAD)
     bool dev_pairs_ok = false;
@@ -292,18 +293,24 @@ struct dpmmh_model {
         if (W.niw_posterior(W.ctx, cl.data(), sl.data(), n, &sm)) return wfail("niw_posterior");
         return apply_device_posteriors(sl, sm);
     }
-    // the scalars of n clusters' posteriors (slots sl, rows sm [n][3][4]) -> the engine's per-row state + log-marginals
+    // the scalars of n clusters' posteriors (slots sl, rows sm [n][3][8]) -> the engine's per-row state + log-marginals
     int apply_device_posteriors(const std::vector<int32_t> &sl, const double *sm) {
         const int n = (int)sl.size();
         const NiwPrior &pr = niw[0];
-        Pool::get().run(3 * n, nthreads, [&](int item, int) {           // D lgamma evaluations per log-marginal: worth the pool at D >= 128
+        // the worker returns log Gamma_D(nu' / 2) with the other scalars (the D lgamma evaluations of a log-marginal): what is left is a
+        // handful of logarithms per distribution, done here -- no pool job, no wake-up (on a busy host that cost up to 0.15 ms per step).
+        // The Float32-accumulator mode of the reference (DPMMH_OPT_F32_QUIRK) recomputes the term on the host.
+        auto one = [&](int item) {
             const int i = item / 3, w = item % 3;
-            const double *o = sm + (size_t)item * 4;
+            const double *o = sm + (size_t)item * kDevScalars;
             const int row = 3 * sl[i] + w;
             Nrow[row] = o[0]; kappa[row] = o[1]; nu[row] = o[2];
             ldpsi[row] = o[3] - D * log(nu[row]);
-            L[row] = niw_marginal(pr, kappa[row], nu[row], ldpsi[row], o[0]);
-        });
+            L[row] = f32_quirk ? niw_marginal(pr, kappa[row], nu[row], ldpsi[row], o[0])
+                               : dpmmh::niw_log_marginal_lmg(D, pr.kappa, pr.nu, pr.logdet_psi, pr.lmg0[0], kappa[row], nu[row], ldpsi[row], o[0], o[4]);
+        };
+        if (f32_quirk) Pool::get().run(3 * n, nthreads, [&](int item, int) { one(item); });
+        else for (int item = 0; item < 3 * n; ++item) one(item);
         for (int i = 0; i < n; ++i) points_count[sl[i]] = (int64_t)llrint(Nrow[3 * sl[i]]);
         host_dense = false; host_rows = false;
         return 0;
@@ -664,12 +671,16 @@ struct dpmmh_model {
             const double *sm = nullptr;
             if (W.niw_pairs(W.ctx, si.data(), sj.data(), n, &sm) == 0) {
                 const NiwPrior &pr = niw[0];
-                Pool::get().run(n, nthreads, [&](int p, int) {
-                    const double *o = sm + (size_t)p * 4;
-                    const double Lp = o[0] == 0.0 ? niw_marginal(pr, pr.kappa, pr.nu, pr.logdet_psi, 0.0)
-                                                  : niw_marginal(pr, o[1], o[2], o[3] - D * log(o[2]), o[0]);
+                auto one = [&](int p) {
+                    const double *o = sm + (size_t)p * kDevScalars;
+                    double Lp;
+                    if (o[0] == 0.0) Lp = niw_marginal(pr, pr.kappa, pr.nu, pr.logdet_psi, 0.0);
+                    else if (f32_quirk) Lp = niw_marginal(pr, o[1], o[2], o[3] - D * log(o[2]), o[0]);
+                    else Lp = dpmmh::niw_log_marginal_lmg(D, pr.kappa, pr.nu, pr.logdet_psi, pr.lmg0[0], o[1], o[2], o[3] - D * log(o[2]), o[0], o[4]);
                     lhr[p] = merge_log_hr(pairs[p].first, pairs[p].second, Lp);
-                });
+                };
+                if (f32_quirk) Pool::get().run(n, nthreads, [&](int p, int) { one(p); });
+                else for (int p = 0; p < n; ++p) one(p);
                 return;
             }
             wfail("niw_pairs");      // fall through to the host path (rows are fetched below by the caller's pull_rows)

@@ -121,6 +121,13 @@ inline double niw_log_marginal(int D, double k0, double v0, double logdet_psi0, 
            (v0 / 2.0) * (D * log(v0) + logdet_psi0) - (v1 / 2.0) * (D * log(v1) + logdet_psi1) + (D / 2.0) * log(k0 / k1);
 }
 
+// the same with log Gamma_D(nu' / 2) supplied (the device master returns it with the other scalars)
+inline double niw_log_marginal_lmg(int D, double k0, double v0, double logdet_psi0, double lmg0, double k1, double v1,
+                                   double logdet_psi1, double N, double lmg1) {
+    return -N * D * 0.5 * log(M_PI) + lmg1 - lmg0 +
+           (v0 / 2.0) * (D * log(v0) + logdet_psi0) - (v1 / 2.0) * (D * log(v1) + logdet_psi1) + (D / 2.0) * log(k0 / k1);
+}
+
 // Marsaglia-Tsang Gamma(a, 1), a >= 1, with the FIRST trial's (normal, uniform) pair supplied by the caller (it does not depend on the
 // shape, so it can be generated ahead of time); later trials (~2 % of the draws) come from `retry`.
 inline double gamma_first_trial(double a, double x, double u, Philox &retry) {      // shape a >= 1

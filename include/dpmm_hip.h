@@ -36,6 +36,7 @@ extern "C" {
 #endif
 
 #define DPMM_ABI_VERSION 2
+#define DPMM_MASTER_NSCALARS 8   /* doubles per distribution in the device master's scalar records (dpmm_niw_master_posterior / _pairs, dpmm_step_master_device) */
 
 typedef struct dpmm_ctx dpmm_ctx;
 
@@ -297,13 +298,14 @@ int dpmm_last_sweep_work(dpmm_ctx *ctx, uint64_t *out8);
  *   dpmm_suffstats_device       dpmm_suffstats_host without the copy (rows of the listed clusters, 1-based; NULL = all)
  *   dpmm_niw_master_posterior   calc_posterior (src/priors/niw.jl:20-31) + factorisation nu' psi' = L' L for the listed clusters
  *                               (1-based) of the LAST statistics pass, stored under their slots (rows 3 slot + {0: cluster, 1: left,
- *                               2: right}); *small: pinned [n][3][4] = {N, kappa', nu', log det(nu' psi')} (NaN: not positive definite)
+ *                               2: right}); *small: pinned [n][3][DPMM_MASTER_NSCALARS] = {N, kappa', nu', log det(nu' psi') (NaN: not positive
+ *                               definite), log Gamma_D(nu' / 2) (utils.jl:66-72: the D lgamma evaluations of a log-marginal), 3 spare}
  *   dpmm_niw_master_draw        sample_distribution (niw.jl:33-40) for all 3K distributions + the hand-over to the sweep kernels
  *                               (replaces dpmm_params_staging / dpmm_commit_params for this sweep): Sigma^-1 = R'R ~ Wishart(nu',
  *                               (nu' psi')^-1), mu ~ N(m', Sigma / kappa'); lr [K][2], w [K] as in dpmm_params_staging.  The random
  *                               streams are the library's own (Philox, keyed by seed, position in cluster order, epoch).
  *   dpmm_niw_master_pairs       pooled statistics of n slot pairs (check_and_merge!'s proposals, shared_actions.jl:21-27) -> *small: pinned
- *                               [n][4] = {N, kappa', nu', log det(nu' psi')} of the pooled posterior under the cluster prior
+ *                               [n][DPMM_MASTER_NSCALARS], same record, of the pooled posterior under the cluster prior
  *   dpmm_niw_master_put_rows    rows [2K][1 + D + D(D+1)/2] from the host take the place of a statistics pass (restored state)
  *   dpmm_niw_master_rows        the stored statistics rows of the given slots -> out [n][2][1 + D + D(D+1)/2] (host)
  *   dpmm_niw_master_draws       the current draws in cluster order: mu [3K][D], R [3K][D][D] (upper triangular, full), logdet [3K] */

@@ -2,6 +2,7 @@
 log-determinants, the distribution of the draws, and the hand-over to the sweep kernels."""
 import numpy as np
 import pytest
+from scipy.special import multigammaln
 
 pytestmark = pytest.mark.gpu
 
@@ -54,6 +55,8 @@ def test_posterior_scalars_and_logdet(pkg, D, n, K):
             assert got[k, w, 0] == N and got[k, w, 1] == k1 and got[k, w, 2] == v1
             ld = np.linalg.slogdet(P)[1]
             assert abs(got[k, w, 3] - ld) <= 1e-9 * max(1.0, abs(ld)), (k, w, got[k, w, 3], ld)
+            lmg = multigammaln(v1 / 2.0, D)                     # log Gamma_D(nu' / 2): the lgamma terms of the log-marginal (utils.jl:66-72)
+            assert abs(got[k, w, 4] - lmg) <= 1e-12 * max(1.0, abs(lmg)), (k, w, got[k, w, 4], lmg)
     rows = wk.master_rows(slots)
     ref = wk.suffstats_packed(None).reshape(K, 2, -1)
     assert np.array_equal(rows, ref)
@@ -186,6 +189,8 @@ def test_pooled_pair_logdets(pkg, D):
         ld = np.linalg.slogdet(P)[1]
         assert got[p, 0] == N and got[p, 1] == k1 and got[p, 2] == v1
         assert abs(got[p, 3] - ld) <= 1e-9 * max(1.0, abs(ld))
+        lmg = multigammaln(v1 / 2.0, D)
+        assert abs(got[p, 4] - lmg) <= 1e-12 * max(1.0, abs(lmg))
     wk.close()
 
 
