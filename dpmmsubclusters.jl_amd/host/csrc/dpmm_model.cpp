@@ -383,7 +383,9 @@ struct dpmmh_model {
         wait_noise();
         const bool niw_dev = kind == DPMMH_PRIOR_NIW && dev_draw;       // device draws make their own noise (a wrong guess costs an inline generation)
         const bool niw_noise = kind == DPMMH_PRIOR_NIW && !niw_dev;
-        const double pre_at = (prewake && nthreads > 1 && t_launch > 0.0 && wait_ema > 0.0) ? t_launch + wait_ema - kPrewakeLead : 0.0;
+        // (no pool job follows the statistics on the device-master path -- the worker returns the lgamma terms too -- so nobody is woken)
+        const bool pool_after_stats = !(niw_dev && !f32_quirk);
+        const double pre_at = (prewake && pool_after_stats && nthreads > 1 && t_launch > 0.0 && wait_ema > 0.0) ? t_launch + wait_ema - kPrewakeLead : 0.0;
         const int rows = 3 * (K + 4);   // head-room for clusters born from splits
         const size_t DD = (size_t)D * D;
         if (niw_noise) {
