@@ -90,6 +90,12 @@ def main():
     # burn-in (setup, untimed): `burnout` sweeps until every cluster's split/merge gate is open
     for _ in range(burnout + 1):
         s.group_step(False, False)
+    # ... and `settle` more (setup, untimed): the first ~100 steps of a process run ~2 % slower than all later ones (clock / power state of a
+    # GPU that was idle during the upload; measured with --warmup 5 against --warmup 100 on one box: 338.9 against 344.4 it/s over the same
+    # 30 timed steps, 200-step blocks afterwards 345-347 either way) -- the metric is the steady-state rate of a long run
+    settle = 100
+    for _ in range(settle):
+        s.group_step(False, False)
     for _ in range(args.warmup):
         s.group_step(False, False)
 
@@ -184,7 +190,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"NIW D={D} N={N} synthetic GMM, {K} true components, K_t={k_mean:.1f} live clusters, "
-                               f"alpha=10, default NIW prior, steady state after {burnout + 1} burn-in sweeps",
+                               f"alpha=10, default NIW prior, steady state after {burnout + 1} burn-in + {settle} settling sweeps",
                    "points_per_gpu": n_local, "parallelism": f"points sharded over {world} GPU(s), 1 RCCL all-reduce of packed suff-stats per statistics pass"},
         "roofline": roof,
         "blocks": {"it_per_s": block_rates, "min": float(np.min(block_rates)) if block_rates else None,
