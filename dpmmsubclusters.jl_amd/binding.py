@@ -38,6 +38,7 @@ ABI = [
     ("dpmm_suffstats_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     ("dpmm_niw_master_posterior", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     ("dpmm_niw_master_draw", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    ("dpmm_niw_master_pairs_ahead", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     ("dpmm_niw_master_pairs", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     ("dpmm_niw_master_put_rows", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     ("dpmm_niw_master_rows", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
@@ -441,6 +442,19 @@ class Worker:
         out = ctypes.c_void_p()
         self._chk(self._lib.dpmm_niw_master_pairs(self._h, a.ctypes.data, b.ctypes.data, len(a), ctypes.byref(out)))
         return np.ctypeslib.as_array(ctypes.cast(out, _c_f64p), shape=(len(a), MASTER_NSCALARS)).copy()
+
+    def master_pairs_ahead(self, slots_i, slots_j):
+        """dpmm_niw_master_pairs_ahead: the pairs the next step_master_device computes behind its posteriors."""
+        a = np.ascontiguousarray(slots_i, np.int32); b = np.ascontiguousarray(slots_j, np.int32)
+        self._chk(self._lib.dpmm_niw_master_pairs_ahead(self._h, a.ctypes.data, b.ctypes.data, len(a)))
+
+    def step_master_device(self, reset_epoch, slots, draw_epoch=0):
+        """dpmm_step_master_device: statistics + all posteriors in one call -> (bad flags (K,), scalars (K, 3, 8))."""
+        sl = np.ascontiguousarray(slots, np.int32)
+        bad = ctypes.c_void_p(); out = ctypes.c_void_p()
+        self._chk(self._lib.dpmm_step_master_device(self._h, int(reset_epoch), sl.ctypes.data, int(draw_epoch), ctypes.byref(bad), ctypes.byref(out)))
+        return (np.ctypeslib.as_array(ctypes.cast(bad, ctypes.POINTER(ctypes.c_uint8)), shape=(self.K,)).copy(),
+                np.ctypeslib.as_array(ctypes.cast(out, _c_f64p), shape=(len(sl), 3, MASTER_NSCALARS)).copy())
 
     def master_rows(self, slots):
         sl = np.ascontiguousarray(slots, np.int32)

@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <ctime>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "dpmm_kernels.h"
@@ -116,6 +117,16 @@ struct dpmm_ctx {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_master = nullptr, ev_spec = nullptr;      // posteriors done (main stream) / early draws done (stream2)
     hipEvent_t ev_noise = nullptr;                          // normals of the next draws generated (stream2)
+    // pooled pair log-determinants launched ahead (dpmm_step_master_device): list in device memory, records in a pinned block of their own
+    hipEvent_t ev_pairs = nullptr;
+    int32_t *d_apairs = nullptr;                            // [2 cap] slot pairs of the launch-ahead job
+    size_t apairs_cap = 0;
+    std::vector<int32_t> apairs_shadow;
+    double *h_apairs = nullptr;                             // pinned [cap][DPMM_MASTER_NSCALARS]
+    bool apairs_inflight = false, apairs_valid = false;     // main stream has not waited for ev_pairs yet / the records answer dpmm_niw_master_pairs
+    std::unordered_map<uint32_t, int> apairs_index;         // (slot_i << 16 | slot_j) -> record
+    std::vector<uint8_t> apairs_dirty;                      // [slot] statistics of the slot changed since the job was launched
+    std::vector<int32_t> apairs_req;                        // request of dpmm_niw_master_pairs_ahead, consumed by the next dpmm_step_master_device
     bool noise_inflight = false, noise_valid = false;       // main stream has not waited for ev_noise yet / d_Y[noise_buf] holds the normals of noise_epoch
     uint32_t noise_epoch = 0;
     int noise_nmat = 0, noise_buf = 0;
@@ -374,6 +385,9 @@ int dpmm_destroy(dpmm_ctx *c) {
     if (c->ev_master) hipEventDestroy(c->ev_master);
     if (c->ev_spec) hipEventDestroy(c->ev_spec);
     if (c->ev_noise) hipEventDestroy(c->ev_noise);
+    if (c->ev_pairs) hipEventDestroy(c->ev_pairs);
+    hipFree(c->d_apairs);
+    if (c->h_apairs) hipHostFree(c->h_apairs);
     hipFree(c->d_jobs); hipFree(c->d_dslots);
     if (c->h_master) hipHostFree(c->h_master);
     hipFree(c->d_counts64); hipFree(c->d_row_off); hipFree(c->d_work); hipFree(c->d_par);
@@ -1062,6 +1076,10 @@ static int spec_join(dpmm_ctx *c) {
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_spec, 0));
         c->spec_inflight = false;
     }
+    if (c->apairs_inflight) {             // (the pair job reads the stored rows a posterior pass is about to replace)
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_pairs, 0));
+        c->apairs_inflight = false;
+    }
     return DPMM_OK;
 }
 // ... and for the normals generated ahead (before a draw on the main stream: it uses them, or writes the buffer they are written to)
@@ -1092,7 +1110,7 @@ static int master_capacity(dpmm_ctx *c, int slots, int K) {
         ns = std::min(ns, DPMM_MAX_CLUSTERS);
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
-        c->spec_valid = false; c->noise_valid = false;
+        c->spec_valid = false; c->noise_valid = false; c->apairs_valid = false;
         double *fac = nullptr, *mean = nullptr, *kap = nullptr, *nu = nullptr, *rows = nullptr;
         HIPCHK(c, hipMalloc(&fac, sizeof(double) * 3 * ns * DP * DP));
         HIPCHK(c, hipMalloc(&mean, sizeof(double) * 3 * ns * DP));
@@ -1117,7 +1135,7 @@ static int master_capacity(dpmm_ctx *c, int slots, int K) {
         nk = std::min(nk, DPMM_MAX_CLUSTERS);
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
-        c->spec_valid = false; c->noise_valid = false;
+        c->spec_valid = false; c->noise_valid = false; c->apairs_valid = false;
         for (int i = 0; i < 2; ++i) {
             hipFree(c->d_Y[i]); hipFree(c->d_ld_sigma[i]); hipFree(c->d_mu_draw[i]);
             c->d_Y[i] = nullptr; c->d_ld_sigma[i] = nullptr; c->d_mu_draw[i] = nullptr;
@@ -1153,11 +1171,13 @@ int dpmm_niw_master_setup(dpmm_ctx *c, double kappa, double nu, const double *m,
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_master, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_spec, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_noise, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_pairs, hipEventDisableTiming));
         HIPCHK(c, hipMalloc(&c->d_jobs, sizeof(int32_t) * 2 * DPMM_MAX_CLUSTERS));
         HIPCHK(c, hipMalloc(&c->d_dslots, sizeof(int32_t) * DPMM_MAX_CLUSTERS));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream2));
     c->spec_inflight = false; c->spec_valid = false; c->noise_inflight = false; c->noise_valid = false;
+    c->apairs_inflight = false; c->apairs_valid = false;
     c->master = true;
     return DPMM_OK;
 }
@@ -1197,11 +1217,51 @@ int dpmm_step_master_device(dpmm_ctx *c, uint32_t reset_epoch, const int32_t *sl
     for (int k = 0; k < K; ++k) { jobs[2 * k] = k; jobs[2 * k + 1] = slots[k]; }
     if (int rc = device_list(c, c->d_jobs, c->jobs_shadow, jobs.data(), jobs.size())) return rc;
     if (draw_epoch) if (int rc = device_list(c, c->d_dslots, c->dslots_shadow, slots, (size_t)K)) return rc;
+    for (int32_t sl : c->apairs_req) if (sl >= top) { c->apairs_req.clear(); break; }      // (a pair of a slot this pass does not cover: no job)
+    const int napairs = (int)(c->apairs_req.size() / 2);
+    c->apairs_valid = false;
+    if (napairs > 0) {
+        if ((size_t)napairs > c->apairs_cap) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream2));
+            size_t cap = 64;
+            while (cap < (size_t)napairs) cap *= 2;
+            hipFree(c->d_apairs); c->d_apairs = nullptr;
+            if (c->h_apairs) hipHostFree(c->h_apairs);
+            c->h_apairs = nullptr; c->apairs_cap = 0; c->apairs_shadow.clear();
+            HIPCHK(c, hipMalloc(&c->d_apairs, sizeof(int32_t) * 2 * cap));
+            HIPCHK(c, hipHostMalloc((void **)&c->h_apairs, sizeof(double) * DPMM_MASTER_NSCALARS * cap, hipHostMallocDefault));
+            c->apairs_cap = cap;
+        }
+        if (c->ma.DP > 128 && (size_t)napairs > c->pair_cap) {      // scratch matrices of the large-D pair kernels
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream2));
+            hipFree(c->d_pairs); c->d_pairs = nullptr; c->pair_cap = 0;
+            size_t cap = 64;
+            while (cap < (size_t)napairs) cap *= 2;
+            HIPCHK(c, hipMalloc(&c->d_pairs, sizeof(double) * cap * (size_t)c->ma.DP * (size_t)c->ma.DP));
+            c->pair_cap = cap;
+        }
+        if (int rc = device_list(c, c->d_apairs, c->apairs_shadow, c->apairs_req.data(), c->apairs_req.size())) return rc;
+    }
     double *sm = reinterpret_cast<double *>(c->h_master + jobs_bytes);
     if (int rc = run_stats(c, nullptr, 0, true, reset_epoch)) return rc;
     HIPCHK(c, launch_copy_bytes(c->h_out, reinterpret_cast<const uint8_t *>(c->d_out) + out_bytes, (size_t)K + 1, c->stream));
     HIPCHK(c, launch_niw_master_posterior(c->ma, c->d_jobs, K, c->d_out, sm, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_master, c->stream));
+    if (napairs > 0) {
+        // The pooled pair log-determinants the master may ask for after its split decisions (dpmm_niw_master_pairs_ahead): they need the
+        // stored rows of this pass only, so they run on the second stream while the host works; dpmm_niw_master_pairs answers from
+        // them when every pair it is asked for is among them and none of their slots got new statistics in between.
+        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_master, 0));
+        HIPCHK(c, launch_niw_master_pairs(c->ma, c->d_apairs, napairs, c->d_pairs, c->h_apairs, c->stream2));
+        HIPCHK(c, hipEventRecord(c->ev_pairs, c->stream2));
+        c->apairs_index.clear();
+        for (int p = 0; p < napairs; ++p) c->apairs_index[((uint32_t)c->apairs_req[2 * p] << 16) | (uint32_t)c->apairs_req[2 * p + 1]] = p;
+        c->apairs_dirty.assign((size_t)c->master_slots, 0);
+        c->apairs_inflight = true; c->apairs_valid = true;
+        c->apairs_req.clear();
+    }
     if (draw_epoch) {
         // The next parameter draws, launched now on the second stream: they need the posteriors only (not the weights, not the
         // master's split / merge decisions), so they run while the host works on the scalars this call returns.  If nothing changes
@@ -1245,6 +1305,7 @@ int dpmm_niw_master_posterior(dpmm_ctx *c, const int64_t *clusters, const int32_
     if (int rc = master_capacity(c, top, 0)) return rc;
     if (int rc = spec_join(c)) return rc;
     c->spec_valid = false;                                 // some factors change: draws launched ahead are not the ones to use
+    for (int i = 0; i < n; ++i) if ((size_t)slots[i] < c->apairs_dirty.size()) c->apairs_dirty[slots[i]] = 1;      // ... nor pooled pairs that involve these slots
     const size_t jobs_bytes = (sizeof(int32_t) * 2 * (size_t)n + 63) & ~(size_t)63;
     if (int rc = master_pinned(c, jobs_bytes + sizeof(double) * 3 * DPMM_MASTER_NSCALARS * (size_t)n)) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));            // nobody reads the pinned block any more
@@ -1307,6 +1368,17 @@ int dpmm_niw_master_draw(dpmm_ctx *c, uint32_t epoch, int K, const int32_t *slot
     return DPMM_OK;
 }
 
+int dpmm_niw_master_pairs_ahead(dpmm_ctx *c, const int32_t *slots_i, const int32_t *slots_j, int n) {
+    if (!c || n < 0 || (n > 0 && (!slots_i || !slots_j))) return DPMM_EINVAL;
+    if (!c->master) return fail(c, DPMM_ESTATE, "dpmm_niw_master_setup first");
+    c->apairs_req.clear();
+    for (int i = 0; i < n; ++i) {
+        if (slots_i[i] < 0 || slots_i[i] >= DPMM_MAX_CLUSTERS || slots_j[i] < 0 || slots_j[i] >= DPMM_MAX_CLUSTERS) { c->apairs_req.clear(); return fail(c, DPMM_EINVAL, "slot out of range"); }
+        c->apairs_req.push_back(slots_i[i]); c->apairs_req.push_back(slots_j[i]);
+    }
+    return DPMM_OK;
+}
+
 int dpmm_niw_master_pairs(dpmm_ctx *c, const int32_t *slots_i, const int32_t *slots_j, int n, const double **small) {
     if (!c || !slots_i || !slots_j || !small || n < 0) return DPMM_EINVAL;
     if (!c->master) return fail(c, DPMM_ESTATE, "dpmm_niw_master_setup first");
@@ -1315,8 +1387,27 @@ int dpmm_niw_master_pairs(dpmm_ctx *c, const int32_t *slots_i, const int32_t *sl
     for (int i = 0; i < n; ++i)
         if (slots_i[i] < 0 || slots_i[i] >= c->master_slots || slots_j[i] < 0 || slots_j[i] >= c->master_slots) return fail(c, DPMM_EINVAL, "slot out of range");
     const size_t DP = (size_t)c->ma.DP;
+    if (c->apairs_valid) {      // launched ahead with the posteriors?
+        bool all = true;
+        std::vector<int> rec((size_t)n);
+        for (int i = 0; i < n && all; ++i) {
+            const auto it = c->apairs_index.find(((uint32_t)slots_i[i] << 16) | (uint32_t)slots_j[i]);
+            all = it != c->apairs_index.end() && !c->apairs_dirty[slots_i[i]] && !c->apairs_dirty[slots_j[i]];
+            if (all) rec[i] = it->second;
+        }
+        if (all) {
+            if (int rc = master_pinned(c, sizeof(double) * DPMM_MASTER_NSCALARS * (size_t)n)) return rc;
+            HIPCHK(c, hipEventSynchronize(c->ev_pairs));
+            double *sm = reinterpret_cast<double *>(c->h_master);      // (free: every user waits for its kernels before it returns)
+            for (int i = 0; i < n; ++i) memcpy(sm + (size_t)i * DPMM_MASTER_NSCALARS, c->h_apairs + (size_t)rec[i] * DPMM_MASTER_NSCALARS, sizeof(double) * DPMM_MASTER_NSCALARS);
+            *small = sm;
+            return DPMM_OK;
+        }
+    }
+    if (int rc = spec_join(c)) return rc;          // (a job launched ahead may still use the scratch matrices)
     if ((size_t)n > c->pair_cap) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream2));
         hipFree(c->d_pairs); c->d_pairs = nullptr; c->pair_cap = 0;
         size_t cap = 64;
         while (cap < (size_t)n) cap *= 2;
@@ -1343,6 +1434,7 @@ int dpmm_niw_master_put_rows(dpmm_ctx *c, const double *rows, int K) {
     if (int rc = ensure_capacity(c, K)) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(c->d_out, rows, sizeof(double) * 2 * (size_t)K * (size_t)c->packed_stride, hipMemcpyHostToDevice));
+    c->apairs_valid = false;
     if (K != c->K) c->have_params = false;
     c->K = K;
     return DPMM_OK;

@@ -487,6 +487,18 @@ struct dpmmh_model {
         std::vector<int32_t> dev_slots;
         if (dev) {      // statistics + all 3K posteriors and factorisations in one stream-ordered sequence, one wait
             dev_slots.assign(slot.begin(), slot.end());
+            // the merge proposals of this step can only involve clusters whose gate is open NOW (splits close gates, they open none):
+            // their pooled log-determinants are launched with the posteriors and are ready when check_and_merge asks
+            if (W.niw_pairs_ahead && opt_draw_ahead) {
+                std::vector<int32_t> ai, aj;
+                for (int i = (has_outlier() ? 1 : 0); i < K && ai.size() <= 1024; ++i) {
+                    if (!splittable[slot[i]]) continue;
+                    for (int j = i + 1; j < K; ++j)
+                        if (splittable[slot[j]]) { ai.push_back(slot[i]); aj.push_back(slot[j]); }
+                }
+                if (ai.size() > 1024) { ai.clear(); aj.clear(); }
+                if (W.niw_pairs_ahead(W.ctx, ai.data(), aj.data(), (int)ai.size())) return wfail("niw_pairs_ahead");
+            }
             // the epoch of the next parameter draws: the worker launches them right behind the posteriors (they run while this thread
             // decides splits and merges) and uses them if the cluster -> slot map is still this one when sample_clusters asks
             if (W.step_master_device(W.ctx, next_epoch(), dev_slots.data(), opt_draw_ahead ? draw_epoch + 1 : 0u, &bad, &dev_small)) return wfail("step_master_device");

@@ -26,6 +26,7 @@ F_M_STATS = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _i64p, ctypes.c_int)
 F_M_POST = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _i64p, _vp, ctypes.c_int, _pp)
 F_M_DRAW = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_uint32, ctypes.c_int, _vp, _vp, _vp)
 F_M_PAIRS = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, _vp, ctypes.c_int, _pp)
+F_M_PAIRSA = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, _vp, ctypes.c_int)
 F_M_PUT = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, ctypes.c_int)
 F_M_ROWS = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, ctypes.c_int, _vp)
 F_M_DRAWS = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp)
@@ -47,7 +48,7 @@ class WorkerTable(ctypes.Structure):
                 ("remove_empty", F_REMOVE), ("reset_sublabels", F_RESET), ("init_labels", F_INIT), ("allgather", F_GATHER),
                 ("last_error", F_ERR),
                 ("niw_master_setup", F_M_SETUP), ("step_stats_device", F_M_STEP), ("step_master_device", F_M_STEPM), ("stats_device", F_M_STATS), ("niw_posterior", F_M_POST),
-                ("niw_draw", F_M_DRAW), ("niw_pairs", F_M_PAIRS), ("niw_put_rows", F_M_PUT), ("niw_rows", F_M_ROWS), ("niw_draws", F_M_DRAWS)]
+                ("niw_draw", F_M_DRAW), ("niw_pairs", F_M_PAIRS), ("niw_pairs_ahead", F_M_PAIRSA), ("niw_put_rows", F_M_PUT), ("niw_rows", F_M_ROWS), ("niw_draws", F_M_DRAWS)]
 
 
 _NATIVE_MAP = [("params_staging", "dpmm_params_staging", F_STAGING), ("commit_params", "dpmm_commit_params", F_INT),
@@ -58,7 +59,7 @@ _NATIVE_MAP = [("params_staging", "dpmm_params_staging", F_STAGING), ("commit_pa
                ("allgather", "dpmm_comm_allgather_host", F_GATHER), ("last_error", "dpmm_last_error", F_ERR),
                ("niw_master_setup", "dpmm_niw_master_setup", F_M_SETUP), ("step_stats_device", "dpmm_step_stats_device", F_M_STEP), ("step_master_device", "dpmm_step_master_device", F_M_STEPM),
                ("stats_device", "dpmm_suffstats_device", F_M_STATS), ("niw_posterior", "dpmm_niw_master_posterior", F_M_POST),
-               ("niw_draw", "dpmm_niw_master_draw", F_M_DRAW), ("niw_pairs", "dpmm_niw_master_pairs", F_M_PAIRS),
+               ("niw_draw", "dpmm_niw_master_draw", F_M_DRAW), ("niw_pairs", "dpmm_niw_master_pairs", F_M_PAIRS), ("niw_pairs_ahead", "dpmm_niw_master_pairs_ahead", F_M_PAIRSA),
                ("niw_put_rows", "dpmm_niw_master_put_rows", F_M_PUT),
                ("niw_rows", "dpmm_niw_master_rows", F_M_ROWS), ("niw_draws", "dpmm_niw_master_draws", F_M_DRAWS)]
 

@@ -306,6 +306,9 @@ int dpmm_last_sweep_work(dpmm_ctx *ctx, uint64_t *out8);
  *                               streams are the library's own (Philox, keyed by seed, position in cluster order, epoch).
  *   dpmm_niw_master_pairs       pooled statistics of n slot pairs (check_and_merge!'s proposals, shared_actions.jl:21-27) -> *small: pinned
  *                               [n][DPMM_MASTER_NSCALARS], same record, of the pooled posterior under the cluster prior
+ *   dpmm_niw_master_pairs_ahead the pairs the master MAY ask for after the next dpmm_step_master_device (all pairs of clusters whose merge
+ *                               gate is open): that call launches them behind the posteriors on the second stream and
+ *                               dpmm_niw_master_pairs answers from them (subset, any order) unless a slot got new statistics in between
  *   dpmm_niw_master_put_rows    rows [2K][1 + D + D(D+1)/2] from the host take the place of a statistics pass (restored state)
  *   dpmm_niw_master_rows        the stored statistics rows of the given slots -> out [n][2][1 + D + D(D+1)/2] (host)
  *   dpmm_niw_master_draws       the current draws in cluster order: mu [3K][D], R [3K][D][D] (upper triangular, full), logdet [3K] */
@@ -315,6 +318,7 @@ int dpmm_step_master_device(dpmm_ctx *ctx, uint32_t reset_epoch, const int32_t *
 int dpmm_suffstats_device(dpmm_ctx *ctx, const int64_t *cluster_idx, int n_idx);
 int dpmm_niw_master_posterior(dpmm_ctx *ctx, const int64_t *clusters, const int32_t *slots, int n, const double **small);
 int dpmm_niw_master_draw(dpmm_ctx *ctx, uint32_t epoch, int K, const int32_t *slot_of_cluster, const float *lr, const float *w);
+int dpmm_niw_master_pairs_ahead(dpmm_ctx *ctx, const int32_t *slots_i, const int32_t *slots_j, int n);
 int dpmm_niw_master_pairs(dpmm_ctx *ctx, const int32_t *slots_i, const int32_t *slots_j, int n, const double **small);
 int dpmm_niw_master_put_rows(dpmm_ctx *ctx, const double *rows, int K);
 int dpmm_niw_master_rows(dpmm_ctx *ctx, const int32_t *slots, int n, double *out);

@@ -86,6 +86,7 @@ typedef struct dpmmh_worker {
     int (*niw_posterior)(void *ctx, const int64_t *clusters, const int32_t *slots, int n, const double **small);
     int (*niw_draw)(void *ctx, uint32_t epoch, int K, const int32_t *slot_of_cluster, const float *lr, const float *w);
     int (*niw_pairs)(void *ctx, const int32_t *slots_i, const int32_t *slots_j, int n, const double **small);
+    int (*niw_pairs_ahead)(void *ctx, const int32_t *slots_i, const int32_t *slots_j, int n);      /* optional on its own (may be NULL): dpmm_niw_master_pairs_ahead */
     int (*niw_put_rows)(void *ctx, const double *rows, int K);
     int (*niw_rows)(void *ctx, const int32_t *slots, int n, double *out);
     int (*niw_draws)(void *ctx, int K, float *mu, float *R, float *logdet);

@@ -256,3 +256,33 @@ def test_posterior_of_empty_and_one_sided_clusters(pkg, D):
     assert np.all(np.isfinite(mu)) and np.all(np.isfinite(R)) and np.all(np.isfinite(ld))
     assert np.allclose(np.tril(R.reshape(-1, D, D), -1), 0.0)
     wk.close()
+
+
+def test_pairs_launched_ahead_answer_subsets_and_fall_back(pkg):
+    """dpmm_niw_master_pairs_ahead + dpmm_step_master_device compute the listed pooled pairs behind the posteriors; dpmm_niw_master_pairs
+    answers any subset of them (any order) with the same records as a direct computation, and computes directly when a pair is not
+    among them or one of its slots got new statistics in between."""
+    D, n, K = 24, 4000, 5
+    wk, X, lab, sub, prior = _setup(pkg, D, n, K, seed=77)
+    wk.master_setup(*prior)
+    slots = np.arange(K, dtype=np.int32)
+    wk.suffstats_device(None)
+    wk.master_posterior(None, slots)
+    allp = [(i, j) for i in range(K) for j in range(i + 1, K)]
+    direct = wk.master_pairs([i for i, _ in allp], [j for _, j in allp])          # nothing launched ahead yet: direct computation
+    wk.master_pairs_ahead([i for i, _ in allp[:7]], [j for _, j in allp[:7]])
+    wk.step_master_device(1, slots, 0)
+    sel = [5, 0, 3]
+    got = wk.master_pairs([allp[p][0] for p in sel], [allp[p][1] for p in sel])   # subset, other order: from the job launched ahead
+    assert np.array_equal(got, direct[sel])
+    got = wk.master_pairs([allp[8][0], allp[1][0]], [allp[8][1], allp[1][1]])     # pair 8 was not requested: computed directly
+    assert np.array_equal(got, direct[[8, 1]])
+    # new statistics for slot 0 (its points move to cluster 2's label): pairs with slot 0 must be recomputed
+    lab2 = lab.copy(); lab2[lab == 1] = 2
+    wk.set_labels(lab2, sub)
+    wk.suffstats_device(None)
+    wk.master_posterior(np.array([1, 2]), slots[:2])
+    got = wk.master_pairs([0, 2], [1, 3])
+    N01 = float((lab2 == 1).sum() + (lab2 == 2).sum())
+    assert got[0, 0] == N01 and got[1, 0] == direct[allp.index((2, 3)), 0]
+    wk.close()
