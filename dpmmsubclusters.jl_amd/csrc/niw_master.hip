@@ -10,15 +10,23 @@
 //   form    P = nu' psi' from the packed rows {N, sum x, lower triangle of sum x x'} and the prior (same formula, same order
 //           of operations as hostmath.h niw_posterior_packed)
 //   factor  P = L' L in place (L lower; U = L' is the "reverse" Cholesky factor P = U U' that the draw needs), blocked by 16:
-//           diagonal block -> panel (one thread per column) -> rank-16 trailing update in 4 x 4 register tiles
-//   draw    Bartlett factor A (chi on the diagonal, standard normals below) from the counter-based generator, L Y = A blocked
-//           by 16 rows (4 x 4 register tiles for the products, one thread per column for the 16 x 16 triangular part),
-//           R = Y' is the upper-triangular factor of a Wishart(nu', P^-1) draw; mu = m' + R^-1 xi / sqrt(kappa')
+//           diagonal block (wave 0, right-looking, the next pivot row kept up to date in registers, no divergent code) -> panel (four
+//           lanes per column, DPP broadcasts) -> rank-16 trailing update of 16 x 16 blocks on the FP64 matrix cores.  D <= 128: one
+//           kernel forms, factorises and writes out with the matrix resident in LDS (niw_post_lds_kernel); larger D: niw_form_kernel
+//           + niw_chol_kernel with the matrix in global memory.  Also returned: log Gamma_D(nu' / 2), the lgamma terms of the master's
+//           log-marginal.
+//   noise   the standard normals of the Bartlett factors depend on (seed, epoch, position, element) only: niw_noise_kernel generates
+//           them for the NEXT epoch on a second stream, several workgroups per matrix
+//   draw    chi on the diagonal, L Y = A blocked by 16 rows (products on the FP64 matrix cores, B operands in two register groups in
+//           flight, one thread per column for the 16 x 16 triangular part), R = Y' is the upper-triangular factor of a
+//           Wishart(nu', P^-1) draw; mu = m' + R^-1 xi / sqrt(kappa') by a blocked back-substitution
 //   pack    R, mu, additive constants -> the fragment images of the sweep kernels (no host staging, no copy)
-// One workgroup of 256 threads per distribution; plain FP64 vector arithmetic (5.6 Mflop per factorisation at D = 256:
-// synchronisation, not arithmetic, is what a 256 x 256 problem costs).  Measured and dropped: 512 threads per workgroup (factorisation
-// 5 % faster, draws 30 % slower), 1024 (half the register budget: spills), an explicit one-step prefetch of the Y rows in the solve's
-// product loop (+7 %: the register hand-over waits for the loads it was meant to overlap).
+// One workgroup of 256 threads per distribution.  At one wave per SIMD an instruction issues every ~5.5 cycles whatever it is: these
+// kernels are written to minimise instructions on the sequential chains (5.6 Mflop per factorisation at D = 256: synchronisation and
+// issue, not arithmetic, is what a 256 x 256 problem costs).  Phase cycles: -DDPMM_POST_STAMPS + scripts/post_stamps.py.  Measured and
+// dropped: 512 threads per workgroup (factorisation 5 % faster, draws 30 % slower), 1024 (half the register budget: spills), an explicit
+// one-step prefetch of the Y rows in the solve's product loop (+7 %), a products variant in which a wave owns four column blocks and
+// walks the chunks once (its first chunks have one or two active blocks and wait for every load).
 #include <algorithm>
 #include "dpmm_device.h"
 #include "dpmm_kernels.h"
