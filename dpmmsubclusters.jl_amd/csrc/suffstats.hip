@@ -252,6 +252,7 @@ __device__ __forceinline__ void niw_stats_body(const StatsArgs &A, int seg, int 
         colok[c] = col < A.ldx;
         coloff[c] = colok[c] ? col : 0;
     }
+    const bool allcols = A.ldx >= 16 * NBK;        // no column of the padded width lies beyond the row
     auto load_x = [&](const int (&pt)[U], float (&xf)[U][NBK]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -292,11 +293,21 @@ __device__ __forceinline__ void niw_stats_body(const StatsArgs &A, int seg, int 
         for (int u = 0; u < U; ++u) {
             const bool rowok = 4 * (bt * U + u) + g < cnt;
             double xd[NBK];
+            // whole k-step inside the item and no padded columns (wave-uniform, the common case): plain conversions -- the masks cost two
+            // instructions per element and this kernel issues ~3.7 vector instructions per matrix instruction as it is
+            if (allcols && 4 * (bt * U + u) + 3 < cnt) {
 #pragma unroll
-            for (int b2 = 0; b2 < NBK; ++b2) {
-                const bool keep = rowok && colok[NBK >= 4 ? b2 / 4 : b2];
-                xd[b2] = (double)(keep ? xu[u][b2] : 0.f);
-                if constexpr (PANEL == 0) xs[b2] += xd[b2];
+                for (int b2 = 0; b2 < NBK; ++b2) xd[b2] = (double)xu[u][b2];
+            } else {
+#pragma unroll
+                for (int b2 = 0; b2 < NBK; ++b2) {
+                    const bool keep = rowok && colok[NBK >= 4 ? b2 / 4 : b2];
+                    xd[b2] = (double)(keep ? xu[u][b2] : 0.f);
+                }
+            }
+            if constexpr (PANEL == 0) {
+#pragma unroll
+                for (int b2 = 0; b2 < NBK; ++b2) xs[b2] += xd[b2];
             }
             // lower block triangle, pair index p(ba,bb) = ba(ba+1)/2 + bb, ba >= bb
 #pragma unroll
