@@ -207,12 +207,17 @@ __device__ __forceinline__ int find_bin(const int32_t *__restrict__ item_start, 
 }
 
 // ------------------------------------------------------------------------------------ NIW statistics
+#ifndef DPMM_STATS16_SB
+#define DPMM_STATS16_SB 4       // k-steps per LDS batch of the D > 128 kernel (two buffers: 64 KiB of LDS; 2: 1.5 % slower)
+#endif
 template <int NBK>
 struct StatCfg {
     static constexpr int NPAIR = NBK * (NBK + 1) / 2;
     static constexpr int DP = 16 * NBK;
-    static constexpr int NPANEL = (NBK <= 4) ? 1 : (NBK == 8 ? 2 : 4);      // (D = 256 with EIGHT panels of 17 pairs -- two waves per SIMD, 251
-                                                                              // VGPRs, x one batch ahead -- was measured: 1.13 ms, the same as four panels)
+    // NBK = 16: EIGHT panels of 17 pairs -- 136 accumulator registers per wave, two waves per SIMD.  (Four panels of 34 need 272: more than
+    // the 256-register accumulation file; with the shared data path of niw_stats_body16 that variant spilled 691 registers.  Eight panels
+    // with every wave loading and converting for itself had measured the same as four: 1.13 ms.)
+    static constexpr int NPANEL = (NBK <= 4) ? 1 : (NBK == 8 ? 2 : 8);
     static constexpr int PP = (NPAIR + NPANEL - 1) / NPANEL;  // pairs per panel
 };
 
@@ -350,6 +355,100 @@ __device__ __forceinline__ void niw_stats_body(const StatsArgs &A, int seg, int 
     }
 }
 
+// D > 128 (NBK = 16, eight panels = eight waves, two per SIMD): the panels SHARE the data path.  The 512 threads load a batch of SB k-steps (4 SB points)
+// once, convert to Float64 once (rows beyond the item and columns beyond the row zeroed there) and store it to LDS in operand order
+// [block b][point p][lane column i]; a wave then fetches the 16 operands of a k-step with 16 conflict-free ds_read_b64 and issues its
+// 17 matrix instructions.  Before, every wave loaded and converted everything itself: 126 vector instructions per 34 matrix
+// instructions, ~110 of them accumulator-file moves (272 accumulator registers + three x buffers + the converted row do not fit next to
+// each other), matrix pipe busy 55 %.  One barrier per batch; the global loads of batch n + 1 are issued before the matrix phase of
+// batch n and consumed after it.  Column sums: the loader thread of a column group adds up its columns.
+template <int PANEL>
+__device__ __forceinline__ void niw_stats_body16(const StatsArgs &A, int seg, int cnt, double *__restrict__ slab, double *__restrict__ xb) {
+    constexpr int NBK = 16, SB = DPMM_STATS16_SB, NPT = 4 * SB;    // k-steps / points per batch
+    using C = StatCfg<NBK>;
+    constexpr int P0 = PANEL * C::PP;
+    constexpr int P1 = (P0 + C::PP < C::NPAIR) ? P0 + C::PP : C::NPAIR;
+    constexpr int NP = P1 - P0;
+    constexpr int BUF = NBK * NPT * 16;                             // doubles per LDS buffer
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int i = lane & 15, g = lane >> 4;
+    // loader role: columns 4 cg .. 4 cg + 3 of point prow of a batch (512 threads = 8 points x 64 column groups)
+    const int cg = tid & 63, prow = tid >> 6;
+    const bool colok = 4 * cg < A.ldx;
+    const int coloff = colok ? 4 * cg : 0;
+    const int li = (4 * cg) >> 4, lb = (4 * cg) & 15;              // lane column and first block of the thread's four columns
+    f64x4 acc[NP > 0 ? NP : 1];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) acc[p] = (f64x4){0., 0., 0., 0.};
+    double xs[4] = {0., 0., 0., 0.};
+    const int nbatch = (cnt + NPT - 1) / NPT;
+    constexpr int HL = NPT / 8;                                     // points per loader thread and batch (rows prow, prow + 8, ...)
+    auto load_idx = [&](int bt, int (&pt)[HL]) {
+#pragma unroll
+        for (int h = 0; h < HL; ++h) pt[h] = A.sb.perm[seg + min(NPT * bt + prow + 8 * h, cnt - 1)];
+    };
+    auto load_x = [&](const int (&pt)[HL], f32x4 (&xv)[HL]) {
+#pragma unroll
+        for (int h = 0; h < HL; ++h) xv[h] = *reinterpret_cast<const f32x4 *>(A.X + (int64_t)pt[h] * A.ldx + coloff);
+    };
+    auto stage = [&](int bt, const f32x4 (&xv)[HL], double *dst) {   // convert + mask + store in operand order + column sums
+#pragma unroll
+        for (int h = 0; h < HL; ++h) {
+            const int p = prow + 8 * h;
+            const bool keep = colok && NPT * bt + p < cnt;
+            const double d0 = keep ? (double)xv[h].x : 0.0, d1 = keep ? (double)xv[h].y : 0.0;
+            const double d2 = keep ? (double)xv[h].z : 0.0, d3 = keep ? (double)xv[h].w : 0.0;
+            xs[0] += d0; xs[1] += d1; xs[2] += d2; xs[3] += d3;
+            double *q = dst + ((lb * NPT + p) * 16 + li);
+            q[0] = d0; q[NPT * 16] = d1; q[2 * NPT * 16] = d2; q[3 * NPT * 16] = d3;
+        }
+    };
+    int pt_a[HL], pt_b[HL];
+    f32x4 xv[HL];
+    load_idx(0, pt_a);
+    load_x(pt_a, xv);
+    load_idx(1, pt_a);
+    stage(0, xv, xb);
+    __syncthreads();
+    for (int bt = 0; bt < nbatch; ++bt) {
+        const double *cur = xb + (bt & 1) * BUF;
+        load_idx(bt + 2, pt_b);                                      // (clamped: harmless beyond the item)
+        __builtin_amdgcn_sched_barrier(0);
+        load_x(pt_a, xv);                                            // batch bt + 1
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < SB; ++ks) {
+            double xd[NBK];
+#pragma unroll
+            for (int b2 = 0; b2 < NBK; ++b2) xd[b2] = cur[(b2 * NPT + 4 * ks + g) * 16 + i];
+#pragma unroll
+            for (int ba = 0; ba < NBK; ++ba)
+#pragma unroll
+                for (int bb = 0; bb <= ba; ++bb) {
+                    const int p = ba * (ba + 1) / 2 + bb;
+                    if (p >= P0 && p < P1) acc[p - P0] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd[ba], xd[bb], acc[p - P0], 0, 0, 0);
+                }
+        }
+        if (bt + 1 < nbatch) stage(bt + 1, xv, xb + ((bt + 1) & 1) * BUF);
+#pragma unroll
+        for (int h = 0; h < HL; ++h) pt_a[h] = pt_b[h];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[(int64_t)(P0 + p) * 256 + r * 64 + lane] = acc[p][r];
+    // column sums: the four loader rows of a column group -> one value per column (fixed order: reproducible)
+    double *red = xb;                                                // [8][256] (the buffers are free: the loop ended with a barrier)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[prow * 256 + 4 * cg + e] = xs[e];
+    __syncthreads();
+    if (tid < 256)
+        slab[(int64_t)C::NPAIR * 256 + tid] = ((red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid])) +
+                                               ((red[1024 + tid] + red[1280 + tid]) + (red[1536 + tid] + red[1792 + tid]));
+    __syncthreads();
+}
+
 // Workgroup w owns the contiguous item range [w q, (w+1) q), q = ceil(total / groups).  Consecutive items of one
 // bin are contiguous in perm, so the range splits into one segment per bin it touches; each segment is accumulated
 // in registers and written as ONE slab, stored at the slot of its first item (its "head").  Heads of bin b are
@@ -376,11 +475,16 @@ __global__ __launch_bounds__(64 * StatCfg<NBK>::NPANEL) void niw_stats_kernel(St
             if (panel == 0) niw_stats_body<NBK, 0>(A, seg, cnt, slab);
             else niw_stats_body<NBK, 1>(A, seg, cnt, slab);
         } else {
+            __shared__ double xb16[2 * 16 * 4 * DPMM_STATS16_SB * 16];      // two operand buffers of niw_stats_body16
             switch (panel) {
-                case 0: niw_stats_body<NBK, 0>(A, seg, cnt, slab); break;
-                case 1: niw_stats_body<NBK, 1>(A, seg, cnt, slab); break;
-                case 2: niw_stats_body<NBK, 2>(A, seg, cnt, slab); break;
-                default: niw_stats_body<NBK, 3>(A, seg, cnt, slab); break;
+                case 0: niw_stats_body16<0>(A, seg, cnt, slab, xb16); break;
+                case 1: niw_stats_body16<1>(A, seg, cnt, slab, xb16); break;
+                case 2: niw_stats_body16<2>(A, seg, cnt, slab, xb16); break;
+                case 3: niw_stats_body16<3>(A, seg, cnt, slab, xb16); break;
+                case 4: niw_stats_body16<4>(A, seg, cnt, slab, xb16); break;
+                case 5: niw_stats_body16<5>(A, seg, cnt, slab, xb16); break;
+                case 6: niw_stats_body16<6>(A, seg, cnt, slab, xb16); break;
+                default: niw_stats_body16<7>(A, seg, cnt, slab, xb16); break;
             }
         }
         item = e;
@@ -488,7 +592,7 @@ hipError_t launch_niw_stats(const StatsArgs &a0, hipStream_t s) {
         case 2: hipLaunchKernelGGL((niw_stats_kernel<2>), dim3(groups), dim3(64), 0, s, a); break;
         case 4: hipLaunchKernelGGL((niw_stats_kernel<4>), dim3(groups), dim3(64), 0, s, a); break;
         case 8: hipLaunchKernelGGL((niw_stats_kernel<8>), dim3(groups), dim3(128), 0, s, a); break;
-        default: hipLaunchKernelGGL((niw_stats_kernel<16>), dim3(groups), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((niw_stats_kernel<16>), dim3(groups), dim3(512), 0, s, a); break;
     }
     hipLaunchKernelGGL(niw_reduce_kernel, dim3((unsigned)((a.packed_stride + 63) / 64), a.nbins), dim3(64 * REDUCE_PARTS), 0, s, a, NBK);
     return hipGetLastError();
