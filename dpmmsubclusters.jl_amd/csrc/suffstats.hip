@@ -217,7 +217,8 @@ struct StatCfg {
     // NBK = 16: EIGHT panels of 17 pairs -- 136 accumulator registers per wave, two waves per SIMD.  (Four panels of 34 need 272: more than
     // the 256-register accumulation file; with the shared data path of niw_stats_body16 that variant spilled 691 registers.  Eight panels
     // with every wave loading and converting for itself had measured the same as four: 1.13 ms.)
-    static constexpr int NPANEL = (NBK <= 4) ? 1 : (NBK == 8 ? 2 : 8);
+    static constexpr int NPANEL = (NBK <= 4) ? 1 : (NBK == 8 ? 4 : 8);      // NBK = 8: four panels of 9 pairs on the shared data path (two of 18, each
+                                                                              // wave loading and converting for itself, before)
     static constexpr int PP = (NPAIR + NPANEL - 1) / NPANEL;  // pairs per panel
 };
 
@@ -355,16 +356,18 @@ __device__ __forceinline__ void niw_stats_body(const StatsArgs &A, int seg, int 
     }
 }
 
-// D > 128 (NBK = 16, eight panels = eight waves, two per SIMD): the panels SHARE the data path.  The 512 threads load a batch of SB k-steps (4 SB points)
+// D > 64 (NBK = 16: eight panels = eight waves, two per SIMD; NBK = 8: four panels): the panels SHARE the data path.  The threads load a batch of SB k-steps (4 SB points)
 // once, convert to Float64 once (rows beyond the item and columns beyond the row zeroed there) and store it to LDS in operand order
 // [block b][point p][lane column i]; a wave then fetches the 16 operands of a k-step with 16 conflict-free ds_read_b64 and issues its
 // 17 matrix instructions.  Before, every wave loaded and converted everything itself: 126 vector instructions per 34 matrix
 // instructions, ~110 of them accumulator-file moves (272 accumulator registers + three x buffers + the converted row do not fit next to
 // each other), matrix pipe busy 55 %.  One barrier per batch; the global loads of batch n + 1 are issued before the matrix phase of
 // batch n and consumed after it.  Column sums: the loader thread of a column group adds up its columns.
-template <int PANEL>
-__device__ __forceinline__ void niw_stats_body16(const StatsArgs &A, int seg, int cnt, double *__restrict__ slab, double *__restrict__ xb) {
-    constexpr int NBK = 16, SB = DPMM_STATS16_SB, NPT = 4 * SB;    // k-steps / points per batch
+template <int NBK, int PANEL>
+__device__ __forceinline__ void niw_stats_body_shared(const StatsArgs &A, int seg, int cnt, double *__restrict__ slab, double *__restrict__ xb) {
+    constexpr int SB = DPMM_STATS16_SB, NPT = 4 * SB;              // k-steps / points per batch
+    constexpr int NCG = 4 * NBK;                                    // column groups (of four columns) per point
+    static_assert(64 * StatCfg<NBK>::NPANEL == 8 * NCG, "eight point rows per loader pass");
     using C = StatCfg<NBK>;
     constexpr int P0 = PANEL * C::PP;
     constexpr int P1 = (P0 + C::PP < C::NPAIR) ? P0 + C::PP : C::NPAIR;
@@ -372,11 +375,11 @@ __device__ __forceinline__ void niw_stats_body16(const StatsArgs &A, int seg, in
     constexpr int BUF = NBK * NPT * 16;                             // doubles per LDS buffer
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = lane & 15, g = lane >> 4;
-    // loader role: columns 4 cg .. 4 cg + 3 of point prow of a batch (512 threads = 8 points x 64 column groups)
-    const int cg = tid & 63, prow = tid >> 6;
+    // loader role: columns 4 cg .. 4 cg + 3 of the points prow, prow + 8, .. of a batch (threads = 8 point rows x NCG column groups)
+    const int cg = tid % NCG, prow = tid / NCG;
     const bool colok = 4 * cg < A.ldx;
     const int coloff = colok ? 4 * cg : 0;
-    const int li = (4 * cg) >> 4, lb = (4 * cg) & 15;              // lane column and first block of the thread's four columns
+    const int li = (4 * cg) / NBK, lb = (4 * cg) % NBK;            // lane column and first block of the thread's four columns (lane i owns columns NBK i ..)
     f64x4 acc[NP > 0 ? NP : 1];
 #pragma unroll
     for (int p = 0; p < NP; ++p) acc[p] = (f64x4){0., 0., 0., 0.};
@@ -439,13 +442,14 @@ __device__ __forceinline__ void niw_stats_body16(const StatsArgs &A, int seg, in
 #pragma unroll
         for (int r = 0; r < 4; ++r) slab[(int64_t)(P0 + p) * 256 + r * 64 + lane] = acc[p][r];
     // column sums: the four loader rows of a column group -> one value per column (fixed order: reproducible)
-    double *red = xb;                                                // [8][256] (the buffers are free: the loop ended with a barrier)
+    constexpr int DPc = 16 * NBK;
+    double *red = xb;                                                // [8][DP] (the buffers are free: the loop ended with a barrier)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) red[prow * 256 + 4 * cg + e] = xs[e];
+    for (int e = 0; e < 4; ++e) red[prow * DPc + 4 * cg + e] = xs[e];
     __syncthreads();
-    if (tid < 256)
-        slab[(int64_t)C::NPAIR * 256 + tid] = ((red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid])) +
-                                               ((red[1024 + tid] + red[1280 + tid]) + (red[1536 + tid] + red[1792 + tid]));
+    if (tid < DPc)
+        slab[(int64_t)C::NPAIR * 256 + tid] = ((red[tid] + red[DPc + tid]) + (red[2 * DPc + tid] + red[3 * DPc + tid])) +
+                                               ((red[4 * DPc + tid] + red[5 * DPc + tid]) + (red[6 * DPc + tid] + red[7 * DPc + tid]));
     __syncthreads();
 }
 
@@ -471,20 +475,26 @@ __global__ __launch_bounds__(64 * StatCfg<NBK>::NPANEL) void niw_stats_kernel(St
         const int panel = threadIdx.x >> 6;
         if constexpr (C::NPANEL == 1) {
             niw_stats_body<NBK, 0>(A, seg, cnt, slab);
-        } else if constexpr (C::NPANEL == 2) {
-            if (panel == 0) niw_stats_body<NBK, 0>(A, seg, cnt, slab);
-            else niw_stats_body<NBK, 1>(A, seg, cnt, slab);
         } else {
-            __shared__ double xb16[2 * 16 * 4 * DPMM_STATS16_SB * 16];      // two operand buffers of niw_stats_body16
-            switch (panel) {
-                case 0: niw_stats_body16<0>(A, seg, cnt, slab, xb16); break;
-                case 1: niw_stats_body16<1>(A, seg, cnt, slab, xb16); break;
-                case 2: niw_stats_body16<2>(A, seg, cnt, slab, xb16); break;
-                case 3: niw_stats_body16<3>(A, seg, cnt, slab, xb16); break;
-                case 4: niw_stats_body16<4>(A, seg, cnt, slab, xb16); break;
-                case 5: niw_stats_body16<5>(A, seg, cnt, slab, xb16); break;
-                case 6: niw_stats_body16<6>(A, seg, cnt, slab, xb16); break;
-                default: niw_stats_body16<7>(A, seg, cnt, slab, xb16); break;
+            __shared__ double xbs[2 * NBK * 4 * DPMM_STATS16_SB * 16];      // two operand buffers of niw_stats_body_shared
+            if constexpr (C::NPANEL == 4) {
+                switch (panel) {
+                    case 0: niw_stats_body_shared<NBK, 0>(A, seg, cnt, slab, xbs); break;
+                    case 1: niw_stats_body_shared<NBK, 1>(A, seg, cnt, slab, xbs); break;
+                    case 2: niw_stats_body_shared<NBK, 2>(A, seg, cnt, slab, xbs); break;
+                    default: niw_stats_body_shared<NBK, 3>(A, seg, cnt, slab, xbs); break;
+                }
+            } else {
+                switch (panel) {
+                    case 0: niw_stats_body_shared<NBK, 0>(A, seg, cnt, slab, xbs); break;
+                    case 1: niw_stats_body_shared<NBK, 1>(A, seg, cnt, slab, xbs); break;
+                    case 2: niw_stats_body_shared<NBK, 2>(A, seg, cnt, slab, xbs); break;
+                    case 3: niw_stats_body_shared<NBK, 3>(A, seg, cnt, slab, xbs); break;
+                    case 4: niw_stats_body_shared<NBK, 4>(A, seg, cnt, slab, xbs); break;
+                    case 5: niw_stats_body_shared<NBK, 5>(A, seg, cnt, slab, xbs); break;
+                    case 6: niw_stats_body_shared<NBK, 6>(A, seg, cnt, slab, xbs); break;
+                    default: niw_stats_body_shared<NBK, 7>(A, seg, cnt, slab, xbs); break;
+                }
             }
         }
         item = e;
@@ -581,8 +591,9 @@ hipError_t launch_niw_stats(const StatsArgs &a0, hipStream_t s) {
     // two resident waves per SIMD at D = 64 (register budget): 2048 workgroups cover the chip once; every workgroup
     // gets the same number of items, so nothing is gained from a longer grid.  Measured (scripts/stats_groups_sweep.py): D <= 64:
     // 2048 at N = 1e7 (0.98 ms; 1024: 1.00, 512: 1.84), but 1024 at n = 1.25e6 (0.19 against 0.22 ms: half the slabs to write and
-    // to reduce); D = 128: 1024 (0.51; 512: 0.84); D = 256 (one workgroup per compute unit fits): 256 (1.17 ms; 512: 1.20, 1024: 1.44).
-    const int dflt = NBK <= 4 ? (a.n >= 2500000 ? 2048 : 1024) : (NBK <= 8 ? 1024 : 256);
+    // to reduce); D = 128 (four panels on the shared data path): 512 (0.50 ms; 256: 0.55, 1024: 0.53, 2048: 0.60); D = 256 (one workgroup per
+    // compute unit fits): 256.
+    const int dflt = NBK <= 4 ? (a.n >= 2500000 ? 2048 : 1024) : (NBK <= 8 ? 512 : 256);
     int groups = a.range_groups > 0 ? a.range_groups : dflt;
     const int max_items = a.max_items < 1 ? 1 : a.max_items;
     if (groups > max_items) groups = max_items;
@@ -591,7 +602,7 @@ hipError_t launch_niw_stats(const StatsArgs &a0, hipStream_t s) {
         case 1: hipLaunchKernelGGL((niw_stats_kernel<1>), dim3(groups), dim3(64), 0, s, a); break;
         case 2: hipLaunchKernelGGL((niw_stats_kernel<2>), dim3(groups), dim3(64), 0, s, a); break;
         case 4: hipLaunchKernelGGL((niw_stats_kernel<4>), dim3(groups), dim3(64), 0, s, a); break;
-        case 8: hipLaunchKernelGGL((niw_stats_kernel<8>), dim3(groups), dim3(128), 0, s, a); break;
+        case 8: hipLaunchKernelGGL((niw_stats_kernel<8>), dim3(groups), dim3(256), 0, s, a); break;
         default: hipLaunchKernelGGL((niw_stats_kernel<16>), dim3(groups), dim3(512), 0, s, a); break;
     }
     hipLaunchKernelGGL(niw_reduce_kernel, dim3((unsigned)((a.packed_stride + 63) / 64), a.nbins), dim3(64 * REDUCE_PARTS), 0, s, a, NBK);
