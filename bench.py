@@ -123,12 +123,14 @@ def main():
     n_local = hi - lo
     sweep_ms, stats_ms, ks, work = [], [], [], []
 
-    def collect():     # HIP events on the library's stream + device-side work counters (the stream is idle here: stats were read back)
+    def collect():     # HIP events on the library's stream (the stream is idle here: stats were read back)
         a, b = wk.last_kernel_ms()
-        sweep_ms.append(a); stats_ms.append(b); ks.append(s.K); work.append(wk.last_sweep_work())
+        sweep_ms.append(a); stats_ms.append(b); ks.append(s.K)
 
     t_before = dict(s.timers)
+    wk.last_sweep_work()              # clear the device's work counters: they add up over the timed launches and are read once afterwards
     elapsed = timed_block(args.steps, collect)
+    work.append(wk.last_sweep_work())     # per-launch averages over exactly the timed launches
     t_after = dict(s.timers)
     block_rates = []
     for _ in range(max(0, args.blocks)):

@@ -479,12 +479,14 @@ class Worker:
         self._chk(self._lib.dpmm_init_labels_from(self._h, int(init_clusters), int(first_label), int(epoch)))
 
     def last_sweep_work(self):
-        """dict of the executed-work counters of the last NIW sweep (dpmm_last_sweep_work)."""
+        """dict of the executed-work counters of the NIW sweeps since the previous call, PER LAUNCH (dpmm_last_sweep_work returns their
+        totals and the number of launches, and clears them): after every sweep = that sweep's; after a timed loop = its average."""
         out = (ctypes.c_uint64 * 8)()
         self._chk(self._lib.dpmm_last_sweep_work(self._h, out))
         v = [int(x) for x in out]
-        return dict(wave_tiles=v[0], full_evals=v[1], screens16=v[2], tail_pairs=v[3], mfma_per_full=v[4], mfma_per_screen=v[5],
-                    flops_per_mfma=v[6], executed_flops=(v[1] * v[4] + v[2] * v[5]) * v[6])
+        n = max(1, v[7])
+        return dict(wave_tiles=v[0] / n, full_evals=v[1] / n, screens16=v[2] / n, tail_pairs=v[3] / n, mfma_per_full=v[4], mfma_per_screen=v[5],
+                    flops_per_mfma=v[6], executed_flops=(v[1] * v[4] + v[2] * v[5]) * v[6] / n, launches=v[7])
 
     # ---- diagnostics
     def debug_subloglik(self):

@@ -141,7 +141,8 @@ struct dpmm_ctx {
     size_t h_master_bytes = 0;
     bool draws_on_device = false;
     unsigned long long *d_work = nullptr;   // [DPMM_WORK_SLOTS + 16 sweep_grid_max]: tile queue heads [4], [8 + 16 q]; [DPMM_WORK_SLOTS + 4 w ..] executed-work counters of wave w of the last sweep
-    int work_waves = 0;                      // waves of the last counted sweep launch
+    int work_waves = 0;                      // most waves of a counted sweep launch since the counters were read
+    long long work_launches = 0;             // counted sweep launches since the counters were read
     // options (dpmm_set_option)
     float opt_margin = 50.f;
     int opt_prio = 1;
@@ -791,7 +792,7 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
             a.order = (!table && c->have_perm && !no_order) ? c->sb.perm : nullptr;
             a.order_total = c->sb.perm_total;
             a.work = table ? nullptr : c->d_work;
-            if (!table) c->work_waves = 4 * c->sweep_grid;
+            if (!table) { c->work_waves = std::max(c->work_waves, 4 * c->sweep_grid); c->work_launches += 1; }
             a.prio = c->opt_prio;
             a.queue_rounds = c->opt_queue_rounds;
         }
@@ -1738,6 +1739,10 @@ int dpmm_last_sweep_work(dpmm_ctx *c, uint64_t *out8) {
     for (int i = 0; i < 4; ++i) out8[i] = 0;
     for (size_t w = 0; w < (size_t)c->work_waves; ++w)
         for (int i = 0; i < 4; ++i) out8[i] += h[4 * w + i];
+    // totals of the launches since the previous call (out8[7] of them); the slots start again from zero
+    const long long launches = c->work_launches;
+    if (!h.empty()) HIPCHK(c, hipMemsetAsync(c->d_work + DPMM_WORK_SLOTS, 0, sizeof(unsigned long long) * h.size(), c->stream));
+    c->work_launches = 0; c->work_waves = 0;
     // matrix instructions per unit of work, per WAVE (v_mfma_f32_16x16x4_f32, 2048 flops each)
     int mf_full = 0, mf_scr = 0;
     if (c->prior == DPMM_PRIOR_NIW) {
@@ -1746,7 +1751,7 @@ int dpmm_last_sweep_work(dpmm_ctx *c, uint64_t *out8) {
         mf_full = NP * 4 * NG + (NB <= 4 ? NG : 0);           // block pairs x 4 k-steps x NG (+ the ones-MFMA row sums of the direct kernel)
         mf_scr = NB <= 4 ? 4 * NG : 0;
     }
-    out8[4] = (uint64_t)mf_full; out8[5] = (uint64_t)mf_scr; out8[6] = 2048; out8[7] = 0;
+    out8[4] = (uint64_t)mf_full; out8[5] = (uint64_t)mf_scr; out8[6] = 2048; out8[7] = (uint64_t)launches;
     return DPMM_OK;
 }
 

@@ -547,13 +547,14 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
         T_last = s6;
 #endif
     }
-    // executed-work counters: one 32-byte slot per wave, plain stores.  (They were four atomic adds per wave on one cache line: waves
+    // executed-work counters: one 32-byte slot per wave, plain read-modify-write by its owner (they add up over launches until
+    // dpmm_last_sweep_work reads and clears them: a benchmark reads once after its timed loop instead of once per step).  (They were four atomic adds per wave on one cache line: waves
     // finish in bursts -- all those with one tile fewer than the rest at the same moment -- and a burst of same-address device-scope
     // atomics held up the loads of the waves still running: the last round of the D <= 64 kernel took 4x as long, a constant ~70 us
     // per launch whatever N, 20 % of the launch at the 8-GPU shard size.)
     if (A.work && lane == 0) {
-        unsigned long long *slot = A.work + DPMM_WORK_SLOTS + ((size_t)blockIdx.x * 4 + wave) * 4;
-        slot[0] = nw_tiles; slot[1] = nw_full; slot[2] = 0ull; slot[3] = nw_tail;
+        unsigned long long *slot = A.work + DPMM_WORK_SLOTS + ((size_t)blockIdx.x * 4 + wave) * 4;      // (accumulates over launches; cleared by the reader)
+        slot[0] += nw_tiles; slot[1] += nw_full; slot[3] += nw_tail;
     }
 #ifdef DPMM_STAMPS
     if (A.dbg && lane == 0 && blockIdx.x < 4096) {
@@ -1201,8 +1202,8 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
 #endif
     }
     if (A.work && lane == 0) {      // one slot per wave, no atomics (see the LDS-staged kernel)
-        unsigned long long *slot = A.work + DPMM_WORK_SLOTS + (size_t)wave_id * 4;
-        slot[0] = nw_tiles; slot[1] = nw_full; slot[2] = nw_scr; slot[3] = nw_tail;
+        unsigned long long *slot = A.work + DPMM_WORK_SLOTS + (size_t)wave_id * 4;      // (accumulates over launches; cleared by the reader)
+        slot[0] += nw_tiles; slot[1] += nw_full; slot[2] += nw_scr; slot[3] += nw_tail;
     }
 #ifdef DPMM_STAMPS
     if (lane == 0 && A.dbg) {

@@ -270,11 +270,12 @@ void *dpmm_stream(dpmm_ctx *ctx);
  * dpmm_suffstats_* call, measured with HIP events on the ctx stream (0 if none yet).
  * Calling this synchronises the stream. */
 int dpmm_last_kernel_ms(dpmm_ctx *ctx, float *sweep_ms, float *suffstats_ms);
-/* Work the last dpmm_sweep (NIW) really executed, counted on the device (one atomicAdd set per wave):
- *   out8[0] wave tiles, [1] full quadratic-form evaluations (per wave), [2] 16-row MFMA screens (per wave), [3] tail-screened
- *   cluster pairs (per wave), [4] matrix instructions per full evaluation, [5] per 16-row screen, [6] flops per matrix
- *   instruction (v_mfma_f32_16x16x4_f32: 2048), [7] 0.  Executed flops = (out8[1]*out8[4] + out8[2]*out8[5]) * out8[6].
- * Calling this synchronises the stream. */
+/* Work the dpmm_sweep calls (NIW) since the previous call really executed, counted on the device (a slot per wave, no atomics):
+ *   TOTALS over out8[7] launches of: out8[0] wave tiles, [1] full quadratic-form evaluations (per wave), [2] 16-row MFMA screens
+ *   (per wave), [3] tail-screened cluster pairs (per wave); [4] matrix instructions per full evaluation, [5] per 16-row screen,
+ *   [6] flops per matrix instruction (v_mfma_f32_16x16x4_f32: 2048).  Executed flops of those launches =
+ *   (out8[1]*out8[4] + out8[2]*out8[5]) * out8[6].  The counters are cleared; calling this synchronises the stream (a benchmark
+ *   calls it once after its timed loop, not once per step). */
 int dpmm_last_sweep_work(dpmm_ctx *ctx, uint64_t *out8);
 
 /* The one exchange of the sweep, inside the library: RCCL all-reduce(sum) of the packed statistics (and of the Int64
