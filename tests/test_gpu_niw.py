@@ -368,15 +368,17 @@ def test_maximum_cluster_count(pkg):
 @pytest.mark.parametrize("D,n,K", [(64, 40000, 6), (128, 30000, 5), (256, 20000, 4)])
 def test_tile_schedule_does_not_change_results(pkg, D, n, K):
     """The random stream is keyed by the point, so neither the number of workgroups (DPMM_OPT_SWEEP_GRID) nor the order in which
-    the tile queue of the D >= 128 kernel hands tiles out may change a label or a sub-label; the second sweep runs with the
-    ordered visiting order and the boundary-tile references active."""
+    the tile queues (D >= 128: every tile; D <= 64: the last DPMM_OPT_SWEEP_QUEUE_ROUNDS rounds, eight queue heads with stealing) hand
+    tiles out may change a label or a sub-label; the second sweep runs with the ordered visiting order and the boundary-tile references
+    active."""
     from dpmmsubclusters_jl_amd import binding
     P = make_problem(D, n, K, seed=31, sep=1.2, sorted_points=True)
     ref = None
-    for grid in (0, 7, 64):
+    for grid, qrounds in ((0, -1), (7, -1), (64, -1), (0, 0), (7, 3), (16, 1000)):
         wk = gpu_worker(pkg, P, seed=11)
         if grid:
             wk.set_option(binding.OPT_SWEEP_GRID, grid)
+        wk.set_option(binding.OPT_SWEEP_QUEUE_ROUNDS, qrounds)       # D <= 64: static schedule / a few rounds / everything from the queues
         wk.sweep(1)
         wk.suffstats_packed(None)          # builds the bin-sorted order the next sweep visits the points in
         wk.sweep(2)
