@@ -1749,7 +1749,7 @@ int dpmm_last_sweep_work(dpmm_ctx *c, uint64_t *out8) {
         const int NB = c->NB, NP = NB * (NB + 1) / 2;
         const int NG = NB <= 4 ? 4 : 2;                       // points per wave / 16 (launch_niw_sweep configurations)
         mf_full = NP * 4 * NG + (NB <= 4 ? NG : 0);           // block pairs x 4 k-steps x NG (+ the ones-MFMA row sums of the direct kernel)
-        mf_scr = NB <= 4 ? 4 * NG : 0;
+        mf_scr = 4 * NG;                                       // the 16-row screen: one block, 4 k-steps, NG point groups
     }
     out8[4] = (uint64_t)mf_full; out8[5] = (uint64_t)mf_scr; out8[6] = 2048; out8[7] = (uint64_t)launches;
     return DPMM_OK;

@@ -267,6 +267,7 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
     __shared__ __attribute__((aligned(16))) float lds[2 * C::MAXPAIRS * 256];
     __shared__ uint32_t present[DPMM_MAX_CLUSTERS_K / 32];
     __shared__ uint32_t survm[DPMM_MAX_CLUSTERS_K / 32];   // screened mode: clusters some wave of the workgroup could not exclude
+    __shared__ uint32_t surv2[DPMM_MAX_CLUSTERS_K / 32];   // ... and still could not after the 16-row screen
     __shared__ int sh_first[4], sh_last[4];
 
     const int tid = threadIdx.x;
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
     const bool owner = lane < C::WPTS;  // lane `lane` draws for point `lane` of the wave
 
     QuadEval<NB, NG, CH> ev;
-    unsigned nw_tiles = 0, nw_full = 0, nw_tail = 0;   // executed-work counters of this wave (wave-uniform)
+    unsigned nw_tiles = 0, nw_full = 0, nw_tail = 0, nw_scr = 0;   // executed-work counters of this wave (wave-uniform)
 
     // Tiles are handed out through a queue (A.work[4], cleared with the work counters): the cost of a tile varies with the number of
     // clusters its points cannot exclude (1 to > 10 full evaluations at D = 256), and with a static "tile = workgroup + i * grid"
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
             //  (2) every wave tail-screens all other clusters against its own points; a cluster is evaluated if ANY wave
             //      could not exclude it (bit in survm); (3) survivors are evaluated in index order.
             __syncthreads();                                   // survm / sh_first / sh_last of the previous tile are no longer read
-            if (tid < DPMM_MAX_CLUSTERS_K / 32) survm[tid] = 0u;
+            if (tid < DPMM_MAX_CLUSTERS_K / 32) { survm[tid] = 0u; surv2[tid] = 0u; }
             {
                 int prev = (valid && A.use_prev) ? (A.bins[myp] >> 1) : -1;
                 if ((unsigned)prev >= (unsigned)K) prev = -1;
@@ -411,6 +412,45 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
                     if (k < K && k != k0 && k != k1 && !((far2 >> c) & 1u) && lane == 0) atomicOr(&survm[k >> 5], 1u << (k & 31));
                 }
             }
+            __syncthreads();
+            // (2b) the clusters the tail screen left over get the 16-row screen of the D <= 64 kernel before anybody evaluates them in
+            // full: the LAST 16 rows of y = R z need the last 16 features only (4 NG matrix instructions, the block's fragment straight
+            // from L2), the sum over a lane's 4 rows is a lower bound of q.  Every wave tests its own points; a cluster stays when some
+            // wave cannot exclude it (surv2).  Before: 0.43 left-over clusters per tile, each a full evaluation of 1088 matrix
+            // instructions -- 11 % of the D = 256 launch.
+            {
+                float thr_n[NG];
+#pragma unroll
+                for (int n = 0; n < NG; ++n) thr_n[n] = __shfl(my_thr, 16 * n + ci);
+                const int nws = (K + 31) >> 5;
+                for (int w2 = 0; w2 < nws; ++w2) {
+                    uint32_t sb = __builtin_amdgcn_readfirstlane(survm[w2]);
+                    for (; sb; sb &= sb - 1u) {
+                        const int k = (w2 << 5) + __builtin_ctz(sb);
+                        const f32x4 a4 = *reinterpret_cast<const f32x4 *>(A.Rp + (size_t)(3 * k) * C::MATSZ + (size_t)(C::NP - 1) * 256 + lane * 4);
+                        const f32x4 m4 = *reinterpret_cast<const f32x4 *>(A.mup + (size_t)(3 * k) * C::DP + 16 * (NB - 1) + 4 * g);
+                        const float ck = A.cst[3 * k];
+                        bool skip = true;
+#pragma unroll
+                        for (int n = 0; n < NG; ++n) {
+                            const f32x4 zz = x[n][NB - 1] - m4;
+                            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[jj], zz[jj], acc, 0, 0, 0);
+                            float ql = acc[0] * acc[0];
+                            ql = __builtin_fmaf(acc[1], acc[1], ql); ql = __builtin_fmaf(acc[2], acc[2], ql); ql = __builtin_fmaf(acc[3], acc[3], ql);
+                            unsigned long long mk = __ballot(__builtin_fmaf(-0.5f, ql, ck) < thr_n[n]);      // a point is covered if ANY of its 4 row-group lanes proves the bound
+                            mk |= mk >> 32;
+                            mk |= mk >> 16;
+                            skip = skip && ((mk & 0xFFFFull) == 0xFFFFull);
+                        }
+                        ++nw_scr;
+                        if (!skip && lane == 0) atomicOr(&surv2[k >> 5], 1u << (k & 31));
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < DPMM_MAX_CLUSTERS_K / 32) survm[tid] = surv2[tid];
             __syncthreads();
             STAMP(s3);
 #ifdef DPMM_STAMPS
@@ -554,7 +594,7 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
     // per launch whatever N, 20 % of the launch at the 8-GPU shard size.)
     if (A.work && lane == 0) {
         unsigned long long *slot = A.work + DPMM_WORK_SLOTS + ((size_t)blockIdx.x * 4 + wave) * 4;      // (accumulates over launches; cleared by the reader)
-        slot[0] += nw_tiles; slot[1] += nw_full; slot[3] += nw_tail;
+        slot[0] += nw_tiles; slot[1] += nw_full; slot[2] += nw_scr; slot[3] += nw_tail;
     }
 #ifdef DPMM_STAMPS
     if (A.dbg && lane == 0 && blockIdx.x < 4096) {
