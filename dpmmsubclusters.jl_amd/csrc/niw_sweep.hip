@@ -286,26 +286,35 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
     // clusters its points cannot exclude (1 to > 10 full evaluations at D = 256), and with a static "tile = workgroup + i * grid"
     // assignment the slowest workgroup ran 1.9 x the median (2.76 ms kernel, 1.45 ms median workgroup).  Results do not depend on
     // which workgroup takes a tile (the random stream is keyed by the point).  Without counters (table mode): static assignment.
-    __shared__ long long sh_tile;
+    // The claim of a tile is issued a tile AHEAD (an atomic with return, in flight during the current tile), and once it has arrived the
+    // workgroup fetches the next tile's entries of the visiting order and previous labels: a tile then starts with its X gather instead
+    // of the chain claim -> order -> X (7.6 % of the D = 256 launch sat in that phase at one wave per SIMD).
+    __shared__ long long sh_tile, sh_next;
     const bool queue = A.work != nullptr;
     int64_t tile = blockIdx.x;
+    long long pend = 0;                                     // thread 0: the claim in flight
+    if (queue && tid == 0) pend = (long long)atomicAdd(&A.work[4], 1ull);      // in order: a strided order was measured 4 % slower
+    int64_t nx_tile = -1;                                   // tile whose order / previous-label entries sit in pf_*
+    int pf_ord[NG], pf_my = -1, pf_bin = -1;
     for (;; tile += gridDim.x) {
         if (queue) {
             __syncthreads();                               // everybody has read the previous value
-            if (tid == 0) sh_tile = (long long)atomicAdd(&A.work[4], 1ull);      // in order: a strided order was measured 4 % slower
+            if (tid == 0) sh_tile = pend;
             __syncthreads();
             tile = sh_tile;
+            if (tid == 0 && tile < A.ntiles) pend = (long long)atomicAdd(&A.work[4], 1ull);
         }
         if (tile >= A.ntiles) break;
         ++nw_tiles;
         STAMP(s0);
         const int64_t wbase = tile * C::TILE + (int64_t)wave * C::WPTS;  // first point of this wave
+        const bool prefetched = queue && nx_tile == tile;
         // ---- x tile -> registers (B-operand layout)
         f32x4 x[NG][NB];
 #pragma unroll
         for (int n = 0; n < NG; ++n) {
             const int64_t pos = wbase + 16 * n + ci;
-            const int64_t p = (pos < A.n && use_order) ? (int64_t)A.order[pos] : pos;
+            const int64_t p = (pos < A.n && use_order) ? (prefetched ? (int64_t)pf_ord[n] : (int64_t)A.order[pos]) : pos;
 #pragma unroll
             for (int t = 0; t < NB; ++t) {
                 const int e = 16 * t + 4 * g;
@@ -315,7 +324,8 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
         }
         const int64_t mypos = wbase + lane;  // owner's position in processing order
         const bool valid = owner && mypos < A.n;
-        const int64_t myp = (valid && use_order) ? (int64_t)A.order[mypos] : mypos;   // owner's point
+        const int64_t myp = (valid && use_order) ? (prefetched ? (int64_t)pf_my : (int64_t)A.order[mypos]) : mypos;   // owner's point
+        const int my_prev_bin = prefetched ? pf_bin : -2;     // (-2: not fetched)
 #ifdef DPMM_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -371,7 +381,7 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
             __syncthreads();                                   // survm / sh_first / sh_last of the previous tile are no longer read
             if (tid < DPMM_MAX_CLUSTERS_K / 32) { survm[tid] = 0u; surv2[tid] = 0u; }
             {
-                int prev = (valid && A.use_prev) ? (A.bins[myp] >> 1) : -1;
+                int prev = (valid && A.use_prev) ? ((my_prev_bin != -2 ? my_prev_bin : A.bins[myp]) >> 1) : -1;
                 if ((unsigned)prev >= (unsigned)K) prev = -1;
                 const unsigned long long pm = __ballot(prev >= 0);
                 int kf = -1, kl = -1;
@@ -526,7 +536,23 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
         if (A.labels_only) continue;  // debug_loglik: table only (uniform branch)
 
         // ---- phase 2: sub-labels.  Distinct labels of the workgroup -> LDS bitmap
+        if (queue && tid == 0) sh_next = pend;               // the next tile (claimed at the top of this one: arrived long ago)
         __syncthreads();
+        if (queue) {      // the next tile's visiting order and previous labels, consumed at the top of the next trip
+            nx_tile = sh_next;
+            if (nx_tile < A.ntiles) {
+                const int64_t nb = nx_tile * C::TILE + (int64_t)wave * C::WPTS;
+#pragma unroll
+                for (int n = 0; n < NG; ++n) {
+                    const int64_t pos = nb + 16 * n + ci;
+                    pf_ord[n] = (pos < A.n && use_order) ? A.order[pos] : 0;
+                }
+                const int64_t mp = nb + lane;
+                const bool nvalid = owner && mp < A.n;
+                pf_my = (nvalid && use_order) ? A.order[mp] : 0;
+                pf_bin = nvalid ? -2 : -1;                   // (-2: previous label to be fetched at the end of this trip, when pf_my has arrived)
+            }
+        }
         STAMP(s5);
         if (tid < DPMM_MAX_CLUSTERS_K / 32) present[tid] = 0u;
         __syncthreads();
@@ -578,6 +604,12 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
         if (valid) {
             const int sl = draw2(b0, b1, u_sub);
             A.bins[myp] = 2 * z + sl;
+        }
+        if (queue && nx_tile >= 0 && nx_tile < A.ntiles && pf_bin == -2) {
+            // the previous label of the owner's point of the NEXT tile (final: this tile's draws touch this tile's points only); the
+            // load is in flight across the tile boundary and consumed after the next X gather
+            const int64_t mp = nx_tile * C::TILE + (int64_t)wave * C::WPTS + lane;
+            pf_bin = A.use_prev ? A.bins[use_order ? (int64_t)pf_my : mp] : -1;
         }
         STAMP(s6);
 #ifdef DPMM_STAMPS
