@@ -51,6 +51,7 @@ struct NiwPrior {
 struct MultPrior {
     bool set = false;
     std::vector<float> alpha;
+    double alpha_sum = 0.0, lg_alpha_sum = 0.0;      // sum alpha_d, sum lgamma(alpha_d): constants of every log-marginal under this prior
 };
 
 // One persistent helper thread: runs a job (the noise generation) while the calling thread blocks on the GPU.
@@ -659,13 +660,22 @@ struct dpmmh_model {
             return niw_marginal(pr, k1, v1, ld, N);
         }
         const MultPrior &pr = mult_of(si);
-        if (sc.size() < (size_t)D) sc.resize(D);
-        std::vector<float> ap(D);
         double N = 0.0;
         for (auto *r : rows) N += r[0];
         if (N == 0.0) return 0.0;
-        for (int d = 0; d < D; ++d) ap[d] = pr.alpha[d] + (float)(rows[0][1 + d] + rows[1][1 + d] + rows[2][1 + d] + rows[3][1 + d]);
-        return dpmmh::mult_log_marginal(D, pr.alpha.data(), ap.data());
+        // multinomial_prior.jl:34-39 for the pooled posterior alpha + sum of the four rows, in one pass: the prior's two sums are
+        // constants, the pooled alpha' is never stored (K (K - 1) / 2 pairs of D lookups each are the master's largest item at D = 1000)
+        const dpmmh::LgammaTable &lg = dpmmh::LgammaTable::get();
+        const float *al = pr.alpha.data();
+        const double *r0 = rows[0] + 1, *r1 = rows[1] + 1, *r2 = rows[2] + 1, *r3 = rows[3] + 1;
+        double s1 = 0.0, acc = 0.0;
+        for (int d = 0; d < D; ++d) {
+            const float a1 = al[d] + (float)(r0[d] + r1[d] + r2[d] + r3[d]);
+            s1 += (double)a1;
+            acc += lg(a1);
+        }
+        int sg;
+        return lgamma_r(pr.alpha_sum, &sg) - lgamma_r(s1, &sg) + (acc - pr.lg_alpha_sum);
     }
     void merge_candidates(std::vector<std::pair<int, int>> &pairs) {
         pairs.clear();
@@ -864,6 +874,12 @@ HAPI int dpmmh_model_set_prior_mult(dpmmh_model *m, int which, const float *alph
     if (!m || which < 0 || which > 1 || !alpha) return -1;
     if (m->kind != DPMMH_PRIOR_MULT) return m->fail("model was created for another prior");
     m->mult[which].alpha.assign(alpha, alpha + m->D);
+    {
+        const dpmmh::LgammaTable &lg = dpmmh::LgammaTable::get();
+        double s0 = 0.0, l0 = 0.0;
+        for (int d = 0; d < m->D; ++d) { s0 += (double)alpha[d]; l0 += lg(alpha[d]); }
+        m->mult[which].alpha_sum = s0; m->mult[which].lg_alpha_sum = l0;
+    }
     m->mult[which].set = true;
     return 0;
 }
