@@ -395,3 +395,21 @@ def test_numa_node_query(pkg):
     wk = gpu_worker(pkg, P, seed=1)
     assert wk.numa_node() >= -1
     wk.close()
+
+
+def test_work_counters_accumulate_until_read(pkg):
+    """dpmm_last_sweep_work returns the totals of the sweeps since the previous call together with their number, and clears them: one
+    read after a loop of launches gives the loop's per-launch average (what bench.py reports), a read after every launch that launch's."""
+    P = make_problem(64, 20000, 6, seed=3, sep=1.5, sorted_points=True)
+    wk = gpu_worker(pkg, P, seed=5)
+    wk.sweep(1)
+    one = wk.last_sweep_work()
+    assert one["launches"] == 1 and one["wave_tiles"] == (20000 + 63) // 64 and one["full_evals"] >= 3 * one["wave_tiles"] - 1e-9
+    assert one["executed_flops"] > 0
+    for ep in (2, 3, 4):
+        wk.sweep(ep)
+    three = wk.last_sweep_work()
+    assert three["launches"] == 3 and three["wave_tiles"] == one["wave_tiles"]
+    none = wk.last_sweep_work()
+    assert none["launches"] == 0 and none["wave_tiles"] == 0 and none["executed_flops"] == 0
+    wk.close()
