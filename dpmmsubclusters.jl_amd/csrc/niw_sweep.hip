@@ -750,9 +750,9 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
     if (A.prio) __builtin_amdgcn_s_setprio(2);
     const bool use_order = A.order != nullptr && *A.order_total == (int32_t)A.n;
     const bool owner = lane < WPTS;
-    const int64_t nwtiles = (A.n + WPTS - 1) / WPTS;              // one tile per wave
-    const int64_t wave_id = (int64_t)blockIdx.x * 4 + (tid >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int nwtiles = (int)((A.n + WPTS - 1) / WPTS);          // one tile per wave (32-bit tile indices: 2^31 tiles of 64 points)
+    const int wave_id = (int)blockIdx.x * 4 + (tid >> 6);
+    const int nwaves = (int)gridDim.x * 4;
     __shared__ uint32_t surv_bits[4][32];   // per wave: clusters that survived the screen (K <= 1024)
     __shared__ uint32_t eval_bits[4][32];   // per wave: reference clusters + survivors
     extern __shared__ __attribute__((aligned(16))) float lds_tab[];
@@ -786,13 +786,13 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
     // once instead of walking the dependent chain order -> X, order -> bins -> reference cluster -> fragments.
     // (Also touching the next tile's X lines to pull them into L2 was measured: no gain, +30 % HBM traffic.)
     int nx_p = -1, nx_bin = -1;
-    int64_t nx_tile = -1;
+    int nx_tile = -1;
     unsigned nw_tiles = 0, nw_full = 0, nw_scr = 0, nw_tail = 0;   // executed-work counters of this wave (wave-uniform)
-    const int64_t rounds_all = nwtiles / nwaves;
-    int64_t dyn_rounds = A.queue_rounds >= 0 ? A.queue_rounds : (rounds_all < 4 ? 0 : (rounds_all / 8 > 2 ? rounds_all / 8 : 2));
+    const int rounds_all = nwtiles / nwaves;
+    int dyn_rounds = A.queue_rounds >= 0 ? A.queue_rounds : (rounds_all < 4 ? 0 : (rounds_all / 8 > 2 ? rounds_all / 8 : 2));
     if (dyn_rounds > rounds_all) dyn_rounds = rounds_all;
     const bool dyn_ok = A.work != nullptr && dyn_rounds > 0;                          // (dyn_rounds == 0: the static schedule, also for the last partial round)
-    const int64_t dyn0 = dyn_ok ? (rounds_all - dyn_rounds) * nwaves : nwtiles;      // tiles >= dyn0 come from the queue
+    const int dyn0 = dyn_ok ? (rounds_all - dyn_rounds) * nwaves : nwtiles;      // tiles >= dyn0 come from the queue
     // Eight queue heads, one per 128-byte line (same-address atomics are served at ~250 M/s: 2048 waves claiming a tile each per round
     // through ONE counter cost 8 us per round, a third of a round's work -- measured at the 8-GPU shard size).  Queue q hands out the
     // tiles dyn0 + 8 c + q; a wave starts at queue (wave & 7) and moves on to the next one when its queue is exhausted.
@@ -803,23 +803,23 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
         if (lane == 0) q_pend = atomicAdd(&A.work[8 + 16 * q_cur], 1ull);
         q_inflight = true;
     };
-    auto q_take = [&]() -> int64_t {         // waits for the claim issued one tile ago; an exhausted queue is replaced by the next one
+    auto q_take = [&]() -> int {         // waits for the claim issued one tile ago; an exhausted queue is replaced by the next one
         for (;;) {
             const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)q_pend), hi = __builtin_amdgcn_readfirstlane((uint32_t)(q_pend >> 32));
             q_inflight = false;
-            const int64_t t = dyn0 + (int64_t)(((unsigned long long)hi << 32) | lo) * DPMM_WORK_QUEUES + q_cur;
-            if (t < nwtiles) { q_dead = 0; return t; }
+            const long long t = (long long)dyn0 + (long long)(((unsigned long long)hi << 32) | lo) * DPMM_WORK_QUEUES + q_cur;
+            if (t < nwtiles) { q_dead = 0; return (int)t; }
             if (++q_dead >= DPMM_WORK_QUEUES) return -1;
             q_cur = (q_cur + 1) & (DPMM_WORK_QUEUES - 1);
             q_issue();                        // (waited for at once: only at the very end of the launch)
         }
     };
-    int64_t tile0, tnext_v = -1;
+    int tile0, tnext_v = -1;
     if (!dyn_ok) tile0 = wave_id < nwtiles ? wave_id : -1;
     else if (wave_id < dyn0) tile0 = wave_id;
     else { q_issue(); tile0 = q_take(); if (tile0 >= 0) q_issue(); }
-    for (int64_t tile = tile0; tile >= 0; tile = tnext_v) {
-        const int64_t wbase = tile * WPTS;
+    for (int tile = tile0; tile >= 0; tile = tnext_v) {
+        const int64_t wbase = (int64_t)tile * WPTS;
         ++nw_tiles;
         STAMP(s0);
         const int64_t mypos = wbase + lane;    // position in processing order
@@ -858,8 +858,8 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                                                   : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
-        int64_t tnext;
-        if (!dyn_ok) tnext = tile + nwaves;
+        int tnext;
+        if (!dyn_ok) tnext = tile + nwaves < nwtiles ? tile + nwaves : nwtiles;
         else if (tile + nwaves < dyn0) tnext = tile + nwaves;                        // static successor
         else {
             if (!q_inflight) q_issue();                                               // first tile from the queue: this one claim is waited for
@@ -870,14 +870,14 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
         tnext_v = tnext < nwtiles ? tnext : -1;
         int pf_p = -1, pf_bin = -1;
         if (tnext < nwtiles) {
-            const int64_t posn = tnext * WPTS + lane;
+            const int64_t posn = (int64_t)tnext * WPTS + lane;
             if (owner && posn < A.n) pf_p = use_order ? A.order[posn] : (int)posn;
         }
 #ifdef DPMM_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         STAMP(s1);
-        float *scr = FAST ? nullptr : A.scratch + (A.scratch_by_tile ? tile * WPTS : wave_id * WPTS) + lane;
+        float *scr = FAST ? nullptr : A.scratch + (A.scratch_by_tile ? (int64_t)tile * WPTS : (int64_t)wave_id * WPTS) + lane;
         const int64_t sstride = A.scratch_stride;
 
         float m_run = -INFINITY;
