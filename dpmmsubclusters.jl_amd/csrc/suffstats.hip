@@ -54,10 +54,32 @@ __global__ __launch_bounds__(64) void hist_kernel(const int32_t *__restrict__ bi
             if (__all(same)) {
                 if (lane == 0 && (unsigned)b0 < (unsigned)nbins) cnt[b0] += 256;
             } else {
-                if ((unsigned)v[it].x < (unsigned)nbins) atomicAdd(&cnt[v[it].x], 1);
-                if ((unsigned)v[it].y < (unsigned)nbins) atomicAdd(&cnt[v[it].y], 1);
-                if ((unsigned)v[it].z < (unsigned)nbins) atomicAdd(&cnt[v[it].z], 1);
-                if ((unsigned)v[it].w < (unsigned)nbins) atomicAdd(&cnt[v[it].w], 1);
+                // the usual case in point order is ONE cluster with its two sub-labels mixed: 256 atomics on two LDS addresses
+                // serialise (the kernel spent 3/4 of its time there).  Count the first few distinct values of the wave with ballots
+                // (a value costs four ballots and one LDS add), whatever is left goes through the atomics.
+                const int vals[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+                unsigned todo = 0xFu;                                   // per lane: components not yet counted
+                for (int round = 0; round < 4; ++round) {
+                    const unsigned long long any = __ballot(todo != 0u);
+                    if (!any) break;
+                    const int leader = __ffsll((long long)any) - 1;
+                    const unsigned tl = (unsigned)__shfl((int)todo, leader);
+                    const int comp = __ffs((int)tl) - 1;
+                    const int lv = comp == 0 ? vals[0] : comp == 1 ? vals[1] : comp == 2 ? vals[2] : vals[3];
+                    const int bv = __shfl(lv, leader);
+                    int c = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool hit = ((todo >> e) & 1u) && vals[e] == bv;
+                        c += __popcll(__ballot(hit));
+                        if (hit) todo &= ~(1u << e);
+                    }
+                    if (lane == 0 && (unsigned)bv < (unsigned)nbins) cnt[bv] += c;
+                    if (c < 32) break;                                  // many different values (unsorted labels): the atomics are cheaper
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (((todo >> e) & 1u) && (unsigned)vals[e] < (unsigned)nbins) atomicAdd(&cnt[vals[e]], 1);
             }
         }
     } else {
@@ -168,21 +190,31 @@ __global__ __launch_bounds__(64) void scatter_kernel(const int32_t *__restrict__
         // replaces took one step per DISTINCT bin in the wave: ~40 on unsorted labels, e.g. bag-of-words data); a wave with one
         // common bin (neighbours share a label after an ordered sweep) needs none
         unsigned long long m = __ballot(valid);
-        if (!__all(b == __builtin_amdgcn_readfirstlane(b))) {
-            for (int bit = 0; bit < nbits; ++bit) {
-                const unsigned long long bal = __ballot(valid && ((b >> bit) & 1));
-                m &= ((b >> bit) & 1) ? bal : ~bal;
+        const int bfirst = __builtin_amdgcn_readfirstlane(b);
+        if (!__all(b == bfirst)) {
+            // two distinct values (one cluster, its two sub-labels mixed -- the usual case in point order): two ballots
+            const unsigned long long m0 = __ballot(b == bfirst), rest = m & ~m0;
+            const int bsecond = __shfl(b, rest ? __ffsll((long long)rest) - 1 : 0);
+            const unsigned long long m1 = __ballot(valid && b == bsecond);
+            if (((m0 & m) | m1) == m) {
+                m = (b == bfirst) ? (m0 & m) : m1;
+            } else {
+                for (int bit = 0; bit < nbits; ++bit) {
+                    const unsigned long long bal = __ballot(valid && ((b >> bit) & 1));
+                    m &= ((b >> bit) & 1) ? bal : ~bal;
+                }
             }
         }
         const int rank = __popcll(m & ((1ull << lane) - 1ull)), cntb = __popcll(m);
         int pos = 0;
         if (valid) pos = base[b] + rank;
-        __syncthreads();
+        // (one wave per workgroup: LDS operations of a wave complete in order -- a wave-level fence instead of a workgroup barrier)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
         if (valid) {
             perm[pos] = (int32_t)i;
             if (rank == 0) base[b] += cntb;
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
     }
 }
 
