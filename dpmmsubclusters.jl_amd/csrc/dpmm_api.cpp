@@ -82,7 +82,8 @@ struct dpmm_ctx {
     int max_items = 0;
     double *d_slabs = nullptr;
     int64_t slab_stride = 0;
-    int32_t *d_row_off = nullptr;      // NIW: packed-row element -> slab position (reduce kernel)
+    int32_t *d_row_off = nullptr;      // NIW: packed-row element -> slab position
+    int32_t *d_inv_off = nullptr;      // NIW: slab position -> packed-row element (reduce kernel)
     double *d_out = nullptr;
     int64_t packed_stride = 0;
     double *d_proj = nullptr, *d_vals = nullptr, *d_smart = nullptr;   // smart splits: projections [n], compacted copy [n], partials + v + mu
@@ -330,7 +331,8 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
         c->packed_stride = 1 + (int64_t)D + (int64_t)D * (D + 1) / 2;
         c->sweep_grid = c->cus * niw_occupancy(c->NB);
         CHK_CREATE(hipMalloc(&c->d_row_off, sizeof(int32_t) * (size_t)c->packed_stride));
-        CHK_CREATE(launch_niw_row_offsets(c->d_row_off, D, c->packed_stride, c->stream));
+        CHK_CREATE(hipMalloc(&c->d_inv_off, sizeof(int32_t) * (size_t)c->slab_stride));
+        CHK_CREATE(launch_niw_row_offsets(c->d_row_off, c->d_inv_off, D, c->packed_stride, c->stream));
     } else {
         c->tile = mult_tile_points();
         c->slab_stride = mult_slab_stride(D);
@@ -391,7 +393,7 @@ int dpmm_destroy(dpmm_ctx *c) {
     if (c->h_apairs) hipHostFree(c->h_apairs);
     hipFree(c->d_jobs); hipFree(c->d_dslots);
     if (c->h_master) hipHostFree(c->h_master);
-    hipFree(c->d_counts64); hipFree(c->d_row_off); hipFree(c->d_work); hipFree(c->d_par);
+    hipFree(c->d_counts64); hipFree(c->d_row_off); hipFree(c->d_inv_off); hipFree(c->d_work); hipFree(c->d_par);
     comm_release(c);
     if (c->h_pin) hipHostFree(c->h_pin);
     if (c->h_par) hipHostFree(c->h_par);
@@ -973,7 +975,7 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
     a.X = c->dX; a.ldx = c->ldx; a.n = c->n; a.D = c->D; a.nbins = nbins; a.chunk = c->chunk;
     a.max_items = (int)((c->n + c->chunk - 1) / c->chunk) + nbins;
     a.range_groups = c->opt_stats_groups;
-    a.sb = c->sb; a.slabs = c->d_slabs; a.slab_stride = c->slab_stride; a.out = c->d_out; a.packed_stride = c->packed_stride; a.row_off = c->d_row_off;
+    a.sb = c->sb; a.slabs = c->d_slabs; a.slab_stride = c->slab_stride; a.out = c->d_out; a.packed_stride = c->packed_stride; a.row_off = c->d_row_off; a.inv_off = c->d_inv_off;
     if (c->n > 0) {
         HIPCHK(c, launch_sort_by_bin(c->dbins, c->n, nbins, c->sb, c->stream));
     } else {

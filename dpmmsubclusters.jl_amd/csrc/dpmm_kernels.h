@@ -160,9 +160,10 @@ struct StatsArgs {
     double *out;           // packed [nbins][packed_stride]
     int64_t packed_stride;
     const int32_t *row_off; // NIW: [packed_stride] packed-row element -> position inside a slab (launch_niw_row_offsets)
+    const int32_t *inv_off; // NIW: [slab_stride] slab position -> packed-row element (-1: none), the inverse table
 };
 int64_t niw_slab_stride(int D);
-hipError_t launch_niw_row_offsets(int32_t *row_off, int D, int64_t packed_stride, hipStream_t s);
+hipError_t launch_niw_row_offsets(int32_t *row_off, int32_t *inv_off, int D, int64_t packed_stride, hipStream_t s);
 int64_t mult_slab_stride(int D);
 hipError_t launch_niw_stats(const StatsArgs &a, hipStream_t s);
 hipError_t launch_mult_stats(const StatsArgs &a, hipStream_t s);

@@ -560,9 +560,17 @@ __global__ void niw_row_offsets_kernel(int32_t *__restrict__ row_off, int D, int
     }
     row_off[e] = (int32_t)off;
 }
-hipError_t launch_niw_row_offsets(int32_t *row_off, int D, int64_t packed_stride, hipStream_t s) {
+__global__ void niw_inv_offsets_kernel(const int32_t *__restrict__ row_off, int32_t *__restrict__ inv_off, int64_t packed_stride, int64_t slab_stride, int phase) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (phase == 0) { if (e < slab_stride) inv_off[e] = -1; }
+    else if (e >= 1 && e < packed_stride) inv_off[row_off[e]] = (int32_t)e;
+}
+hipError_t launch_niw_row_offsets(int32_t *row_off, int32_t *inv_off, int D, int64_t packed_stride, hipStream_t s) {
     const int NBK = D <= 16 ? 1 : D <= 32 ? 2 : D <= 64 ? 4 : D <= 128 ? 8 : 16;
+    const int64_t slab = niw_slab_stride_nbk(NBK);
     hipLaunchKernelGGL(niw_row_offsets_kernel, dim3((unsigned)((packed_stride + 255) / 256)), dim3(256), 0, s, row_off, D, NBK, packed_stride);
+    hipLaunchKernelGGL(niw_inv_offsets_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, s, row_off, inv_off, packed_stride, slab, 0);
+    hipLaunchKernelGGL(niw_inv_offsets_kernel, dim3((unsigned)((packed_stride + 255) / 256)), dim3(256), 0, s, row_off, inv_off, packed_stride, slab, 1);
     return hipGetLastError();
 }
 
@@ -572,14 +580,16 @@ hipError_t launch_niw_row_offsets(int32_t *row_off, int D, int64_t packed_stride
 // each, and the partial sums are combined in part order -- a fixed summation tree, so the rows stay bitwise reproducible.
 constexpr int REDUCE_PARTS = 4;
 __global__ __launch_bounds__(64 * REDUCE_PARTS) void niw_reduce_kernel(StatsArgs A, int NBK) {
+    // a thread owns a slab POSITION (consecutive threads read consecutive doubles of a slab: the gather through row_off touched runs of
+    // at most 16) and writes its sum to the packed-row element the inverse table names; same heads, same parts, same order per element
     __shared__ double part_sum[REDUCE_PARTS][64];
     const int b = blockIdx.y;
     const int el = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int64_t e = blockIdx.x * 64ll + el;
-    const bool live = e < A.packed_stride;
+    const int64_t pos = blockIdx.x * 64ll + el;
+    const int e = pos < A.slab_stride ? A.inv_off[pos] : -1;           // packed-row element of this position (>= 1) or none
+    const bool live = e >= 1;
     double *out = A.out + (int64_t)b * A.packed_stride;
-    if (!A.sb.bin_sel[b]) { if (live && part == 0) out[e] = 0.; return; }
-    const int64_t off = (live && e >= 1) ? (int64_t)A.row_off[e] : 0;      // packed-row element -> position inside a slab (table, built once)
+    if (!A.sb.bin_sel[b]) { if (part == 0) { if (live) out[e] = 0.; if (pos == 0) out[0] = 0.; } return; }
     const int i0 = A.sb.item_start[b], i1 = A.sb.item_start[b + 1];
     const int total_items = A.sb.item_start[A.nbins];
     const int q = (total_items + A.range_groups - 1) / A.range_groups;      // as in niw_stats_kernel
@@ -588,14 +598,14 @@ __global__ __launch_bounds__(64 * REDUCE_PARTS) void niw_reduce_kernel(StatsArgs
     const int nheads = i1 > i0 ? 1 + max(0, (i1 - 1) / q - m0) : 0;
     const int h0 = (int)((int64_t)nheads * part / REDUCE_PARTS), h1 = (int)((int64_t)nheads * (part + 1) / REDUCE_PARTS);
     double s = 0.;
-    if (live && e >= 1) {
+    if (live) {
         for (int h = h0; h < h1; h += 8) {
             double v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int hh = h + u;
                 const int it = hh == 0 ? i0 : (m0 + hh) * q;
-                v[u] = hh < h1 ? A.slabs[(int64_t)it * A.slab_stride + off] : 0.;
+                v[u] = hh < h1 ? A.slabs[(int64_t)it * A.slab_stride + pos] : 0.;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) if (h + u < h1) s += v[u];
@@ -603,8 +613,9 @@ __global__ __launch_bounds__(64 * REDUCE_PARTS) void niw_reduce_kernel(StatsArgs
     }
     part_sum[part][el] = s;
     __syncthreads();
-    if (part != 0 || !live) return;
-    if (e == 0) { out[0] = (double)A.sb.bin_total[b]; return; }
+    if (part != 0) return;
+    if (pos == 0) out[0] = (double)A.sb.bin_total[b];
+    if (!live) return;
 #pragma unroll
     for (int p = 1; p < REDUCE_PARTS; ++p) s += part_sum[p][el];
     out[e] = s;
@@ -637,7 +648,7 @@ hipError_t launch_niw_stats(const StatsArgs &a0, hipStream_t s) {
         case 8: hipLaunchKernelGGL((niw_stats_kernel<8>), dim3(groups), dim3(256), 0, s, a); break;
         default: hipLaunchKernelGGL((niw_stats_kernel<16>), dim3(groups), dim3(512), 0, s, a); break;
     }
-    hipLaunchKernelGGL(niw_reduce_kernel, dim3((unsigned)((a.packed_stride + 63) / 64), a.nbins), dim3(64 * REDUCE_PARTS), 0, s, a, NBK);
+    hipLaunchKernelGGL(niw_reduce_kernel, dim3((unsigned)((a.slab_stride + 63) / 64), a.nbins), dim3(64 * REDUCE_PARTS), 0, s, a, NBK);
     return hipGetLastError();
 }
 
