@@ -1098,10 +1098,10 @@ static bool noise_ready(const dpmm_ctx *c, uint32_t epoch, int K, int buf) {
     return c->noise_valid && c->noise_epoch == epoch && 3 * K <= c->noise_nmat && c->noise_buf == buf;
 }
 // `data` [n] -> the device list `dst` (stream-ordered on the main stream; nothing is sent when the list is the one already there)
-static int device_list(dpmm_ctx *c, int32_t *dst, std::vector<int32_t> &shadow, const int32_t *data, size_t n) {
+static int device_list(dpmm_ctx *c, int32_t *dst, std::vector<int32_t> &shadow, const int32_t *data, size_t n, hipStream_t st = nullptr) {
     if (shadow.size() == n && (n == 0 || memcmp(shadow.data(), data, sizeof(int32_t) * n) == 0)) return DPMM_OK;
     shadow.assign(data, data + n);
-    if (n) HIPCHK(c, hipMemcpyAsync(dst, shadow.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));    // pageable source: staged by the runtime before the call returns
+    if (n) HIPCHK(c, hipMemcpyAsync(dst, shadow.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st ? st : c->stream));    // pageable source: staged by the runtime before the call returns
     return DPMM_OK;
 }
 // device storage for `slots` slots (posterior state, kept across growth) and K clusters (draw scratch)
@@ -1245,7 +1245,9 @@ int dpmm_step_master_device(dpmm_ctx *c, uint32_t reset_epoch, const int32_t *sl
             HIPCHK(c, hipMalloc(&c->d_pairs, sizeof(double) * cap * (size_t)c->ma.DP * (size_t)c->ma.DP));
             c->pair_cap = cap;
         }
-        if (int rc = device_list(c, c->d_apairs, c->apairs_shadow, c->apairs_req.data(), c->apairs_req.size())) return rc;
+        // (on the second stream, where the pair job runs: the list changes with the merge gates, and a copy on the main stream would sit
+        // between the sweep and the statistics kernels)
+        if (int rc = device_list(c, c->d_apairs, c->apairs_shadow, c->apairs_req.data(), c->apairs_req.size(), c->stream2)) return rc;
     }
     double *sm = reinterpret_cast<double *>(c->h_master + jobs_bytes);
     if (int rc = run_stats(c, nullptr, 0, true, reset_epoch)) return rc;
