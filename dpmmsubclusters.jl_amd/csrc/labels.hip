@@ -143,14 +143,22 @@ __global__ __launch_bounds__(256) void reset_sub_flagged_kernel(int32_t *bins, i
     __syncthreads();
     if (blockIdx.x == 0 && threadIdx.x == 0) flags[K] = (uint8_t)any;
     if (!any) return;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int z = bins[i] >> 1;
+    auto one = [&](int64_t i, int bv) {
+        const int z = bv >> 1;
         if ((unsigned)z < (unsigned)K && f[z]) {
             const Philox4 r = philox4x32_10(seed, (uint64_t)(first + i), epoch, STREAM_RESET);
             bins[i] = 2 * z + (int)(r.v[0] & 1u);
             if (dirty) dirty[i / SORT_TILE] = 1;       // the second histogram pass of the step re-counts this tile only
         }
+    };
+    // four labels per load (the pass reads every label to find the few of the flagged clusters)
+    const int64_t n4 = n >> 2;
+    const int4 *b4 = reinterpret_cast<const int4 *>(bins);
+    for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < n4; j += (int64_t)gridDim.x * blockDim.x) {
+        const int4 v = b4[j];
+        one(4 * j, v.x); one(4 * j + 1, v.y); one(4 * j + 2, v.z); one(4 * j + 3, v.w);
     }
+    for (int64_t i = 4 * n4 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) one(i, bins[i]);
 }
 hipError_t launch_reset_sub_flagged(int32_t *bins, int64_t n, int64_t first, const int32_t *bin_total, const long long *global_counts, uint8_t *dirty,
                                     uint8_t *flags, int K, uint64_t seed, uint32_t epoch, hipStream_t s) {
