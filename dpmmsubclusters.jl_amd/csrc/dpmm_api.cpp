@@ -137,6 +137,9 @@ struct dpmm_ctx {
     // index lists of the master kernels (jobs, slot maps) live in device memory and are re-sent only when they change: read from pinned
     // host memory they cost every workgroup a PCIe round trip (~2 us) before its first useful instruction
     int32_t *d_jobs = nullptr, *d_dslots = nullptr;          // [2 MAX] jobs of the posterior kernels (main stream) / [MAX] slot map of the draws
+    int32_t *h_list[4] = {nullptr, nullptr, nullptr, nullptr};   // pinned staging ring of device_list
+    size_t h_list_cap[4] = {0, 0, 0, 0};
+    int h_list_next = 0;
     std::vector<int32_t> jobs_shadow, dslots_shadow;
     uint8_t *h_master = nullptr;                   // pinned: jobs | slot map | lr | w | small
     size_t h_master_bytes = 0;
@@ -392,6 +395,7 @@ int dpmm_destroy(dpmm_ctx *c) {
     hipFree(c->d_apairs);
     if (c->h_apairs) hipHostFree(c->h_apairs);
     hipFree(c->d_jobs); hipFree(c->d_dslots);
+    for (int i = 0; i < 4; ++i) if (c->h_list[i]) hipHostFree(c->h_list[i]);
     if (c->h_master) hipHostFree(c->h_master);
     hipFree(c->d_counts64); hipFree(c->d_row_off); hipFree(c->d_inv_off); hipFree(c->d_work); hipFree(c->d_par);
     comm_release(c);
@@ -1098,10 +1102,27 @@ static bool noise_ready(const dpmm_ctx *c, uint32_t epoch, int K, int buf) {
     return c->noise_valid && c->noise_epoch == epoch && 3 * K <= c->noise_nmat && c->noise_buf == buf;
 }
 // `data` [n] -> the device list `dst` (stream-ordered on the main stream; nothing is sent when the list is the one already there)
+// The copy goes through a ring of pinned staging buffers and the library's own copy kernel, like every per-step transfer: on the test
+// boxes hipMemcpyAsync takes the copy-engine path, which was seen to sit in a stream for 0.7 ms (rocprofv3: `__amd_rocclr_copyBuffer`).
+// A staging slot is reused four changes later; every caller waits for its stream at least once per change.
 static int device_list(dpmm_ctx *c, int32_t *dst, std::vector<int32_t> &shadow, const int32_t *data, size_t n, hipStream_t st = nullptr) {
     if (shadow.size() == n && (n == 0 || memcmp(shadow.data(), data, sizeof(int32_t) * n) == 0)) return DPMM_OK;
     shadow.assign(data, data + n);
-    if (n) HIPCHK(c, hipMemcpyAsync(dst, shadow.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st ? st : c->stream));    // pageable source: staged by the runtime before the call returns
+    if (n == 0) return DPMM_OK;
+    const size_t bytes = sizeof(int32_t) * n;
+    int32_t *&slot = c->h_list[c->h_list_next];
+    size_t &cap = c->h_list_cap[c->h_list_next];
+    c->h_list_next = (c->h_list_next + 1) % 4;
+    if (bytes > cap) {
+        if (slot) HIPCHK(c, hipHostFree(slot));
+        slot = nullptr; cap = 0;
+        size_t nc = 4096;
+        while (nc < bytes) nc *= 2;
+        HIPCHK(c, hipHostMalloc((void **)&slot, nc, hipHostMallocDefault));
+        cap = nc;
+    }
+    memcpy(slot, data, bytes);
+    HIPCHK(c, launch_copy_bytes(dst, slot, bytes, st ? st : c->stream));
     return DPMM_OK;
 }
 // device storage for `slots` slots (posterior state, kept across growth) and K clusters (draw scratch)
