@@ -140,7 +140,8 @@ struct SortBufs {
 };
 
 // `only_if` (nullable): device byte; when it is 0 the pass is skipped (tile_hist / bin_total keep their contents); when it is set the
-// pass is the SECOND one of a step and re-counts only the tiles marked in `dirty` (the first pass clears the marks)
+// pass is the SECOND one of a step and re-counts only the tiles marked in `dirty` (the first pass clears the marks); the byte must be
+// preceded by the nbins / 2 per-cluster reset flags (only_if[-nbins/2 + k]): bins of unflagged clusters are not re-scanned
 hipError_t launch_sort_by_bin(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s, const uint8_t *only_if = nullptr);
 struct StatsArgs;
 hipError_t launch_sort_finish(const int32_t *bins, const StatsArgs &a, hipStream_t s);

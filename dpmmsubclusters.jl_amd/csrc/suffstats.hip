@@ -99,7 +99,9 @@ __global__ __launch_bounds__(64) void hist_kernel(const int32_t *__restrict__ bi
 __global__ __launch_bounds__(256) void scan_tiles_kernel(const int32_t *__restrict__ tile_cnt, int32_t *__restrict__ tile_hist, int nt,
                                                          int32_t *__restrict__ bin_total, const uint8_t *__restrict__ only_if) {
     __shared__ int part[256];
-    if (only_if && !*only_if) return;
+    // second pass of a step (only_if = the "any cluster reset" byte, the per-cluster flags sit in front of it): the reset moved points
+    // between the two bins of the flagged clusters only -- the rows of every other bin are unchanged
+    if (only_if && (!*only_if || !only_if[(int)(blockIdx.x >> 1) - (int)(gridDim.x >> 1)])) return;
     const int32_t *src = tile_cnt + (int64_t)blockIdx.x * nt;
     int32_t *row = tile_hist + (int64_t)blockIdx.x * nt;
     const int per = (nt + 255) / 256;
