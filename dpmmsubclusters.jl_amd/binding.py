@@ -43,6 +43,7 @@ ABI = [
     ("dpmm_niw_master_put_rows", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     ("dpmm_niw_master_rows", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     ("dpmm_niw_master_draws", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    ("dpmm_debug_niw_draw_inputs", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     ("dpmm_sweep", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int]),
     ("dpmm_packed_stride", ctypes.c_int64, [ctypes.c_void_p]),
     ("dpmm_suffstats_packed_device", ctypes.c_int, [ctypes.c_void_p, _c_i64p, ctypes.c_int, ctypes.c_void_p]),
@@ -77,9 +78,14 @@ ABI = [
     ("dpmm_comm_use_library", ctypes.c_int, [ctypes.c_char_p]),
     ("dpmm_comm_unique_id", ctypes.c_int, [ctypes.c_void_p]),
     ("dpmm_comm_init", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    ("dpmm_comm_init_host", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    ("dpmm_comm_info", ctypes.c_int, [ctypes.c_void_p, _c_i64p]),
+    ("dpmm_last_comm_ms", ctypes.c_int, [ctypes.c_void_p, _c_f32p, _c_f32p]),
     ("dpmm_comm_destroy", ctypes.c_int, [ctypes.c_void_p]),
     ("dpmm_comm_allgather_host", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
 ]
+
+HOST_ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int)   # dpmm_host_allreduce_fn
 
 # dpmm_set_option keys (include/dpmm_hip.h)
 MASTER_NSCALARS = 8          # DPMM_MASTER_NSCALARS
@@ -405,6 +411,32 @@ class Worker:
         buf = ctypes.create_string_buffer(bytes(unique_id), 128)
         self._chk(self._lib.dpmm_comm_init(self._h, buf, int(rank), int(world)))
 
+    def comm_init_host(self, rank, world, allreduce):
+        """dpmm_comm_init_host: `allreduce(arr)` sums a 1-D numpy array (float64 or int64, a VIEW of the library's pinned staging)
+        over the ranks IN PLACE.  The statistics calls then return rows summed over the ranks, as with comm_init."""
+        def cb(_, buf, count, is_f64):
+            try:
+                t = ctypes.c_double if is_f64 else ctypes.c_int64
+                allreduce(np.ctypeslib.as_array(ctypes.cast(buf, ctypes.POINTER(t)), shape=(int(count),)))
+                return 0
+            except Exception as e:  # noqa: BLE001 -- must not unwind through the C frames; the library reports DPMM_ECOMM
+                self._comm_error = e
+                return 1
+        self._host_cb = HOST_ALLREDUCE_FN(cb)       # keep the trampoline alive as long as the context
+        self._chk(self._lib.dpmm_comm_init_host(self._h, int(rank), int(world), ctypes.cast(self._host_cb, ctypes.c_void_p), None))
+
+    def comm_info(self):
+        out = np.zeros(8, np.int64)
+        self._chk(self._lib.dpmm_comm_info(self._h, _p(out, _c_i64p)))
+        return dict(world=int(out[0]), rank=int(out[1]), transport={0: "none", 1: "rccl", 2: "host"}[int(out[2])],
+                    counts_bytes=int(out[3]), rows_bytes=int(out[4]), allreduces=int(out[5]))
+
+    def last_comm_ms(self):
+        """(occupancy all-reduce ms, packed-row all-reduce ms) of the last statistics pass (HIP events on the ctx stream)."""
+        a = ctypes.c_float(); b = ctypes.c_float()
+        self._chk(self._lib.dpmm_last_comm_ms(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
     def numa_node(self):
         """dpmm_numa_node: NUMA node of the host this context's GPU is attached to (-1: unknown)."""
         return int(self._lib.dpmm_numa_node(self._h))
@@ -466,6 +498,14 @@ class Worker:
         mu = np.empty((3 * K, self.D), np.float32); R = np.empty((3 * K, self.D, self.D), np.float32); ld = np.empty(3 * K, np.float32)
         self._chk(self._lib.dpmm_niw_master_draws(self._h, int(K), mu.ctypes.data, R.ctypes.data, ld.ctypes.data))
         return mu, R, ld
+
+    def debug_draw_inputs(self, epoch, slot_of_cluster):
+        """dpmm_debug_niw_draw_inputs: (A (3K, D, D) Bartlett factors, xi (3K, D)) the device draw of `epoch` consumes."""
+        sl = np.ascontiguousarray(slot_of_cluster, np.int32)
+        K = len(sl)
+        A = np.empty((3 * K, self.D, self.D), np.float64); xi = np.empty((3 * K, self.D), np.float64)
+        self._chk(self._lib.dpmm_debug_niw_draw_inputs(self._h, int(epoch), K, sl.ctypes.data, A.ctypes.data, xi.ctypes.data))
+        return A, xi
 
     def step_stats(self, reset_epoch):
         """dpmm_step_stats: (packed (2K, stride) float64, bad (K,) uint8) -- copies of the ctx's pinned output."""

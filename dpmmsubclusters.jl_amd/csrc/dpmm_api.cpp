@@ -154,9 +154,17 @@ struct dpmm_ctx {
     int opt_tail = 1, opt_prescreen = -1, opt_ordered = 1, opt_force_f32 = 0, opt_trace = 0, opt_ref_const = 0;
     int64_t opt_stats_items = 0;
     int opt_stats_groups = 0;
-    // collective (dpmm_comm_init)
+    // collective (dpmm_comm_init: RCCL on the ctx stream; dpmm_comm_init_host: a caller-supplied host all-reduce)
     void *comm = nullptr;
     int rank = 0, world = 1;
+    dpmm_host_allreduce_fn host_fn = nullptr;
+    void *host_user = nullptr;
+    char *h_red = nullptr;             // pinned staging of the host transport
+    size_t h_red_bytes = 0;
+    hipEvent_t ev_comm[4] = {nullptr, nullptr, nullptr, nullptr};   // [0,1] around the occupancy all-reduce, [2,3] around the packed rows
+    bool have_comm_ev[2] = {false, false};
+    int64_t comm_bytes[2] = {0, 0};    // payload of the last all-reduce of each kind
+    int64_t comm_calls = 0;            // all-reduces since the communicator was attached
 
     std::string err;
 };
@@ -232,15 +240,47 @@ static Rccl &rccl() {
 }
 enum { kNcclInt64 = 4, kNcclFloat64 = 8, kNcclInt8 = 0, kNcclSum = 0 };   // ncclDataType_t / ncclRedOp_t values of rccl.h
 
-static int comm_allreduce(dpmm_ctx *c, void *dbuf, size_t count, bool f64) {
-    Rccl &r = rccl();
-    const int rc = r.AllReduce(dbuf, dbuf, count, f64 ? kNcclFloat64 : kNcclInt64, kNcclSum, c->comm, c->stream);
-    if (rc != 0) return fail(c, DPMM_ECOMM, std::string("ncclAllReduce: ") + r.GetErrorString(rc));
+static inline bool comm_attached(const dpmm_ctx *c) { return c->comm != nullptr || c->host_fn != nullptr; }
+// In-place all-reduce(sum) of a device buffer over the ranks, stream-ordered on the ctx stream.  `kind`: 0 = Int64 sub-cluster
+// occupancies, 1 = Float64 packed rows (HIP events around each kind: dpmm_last_comm_ms).  Transport: RCCL (dpmm_comm_init) or the
+// caller's host function (dpmm_comm_init_host: device -> pinned, synchronise, fn, pinned -> device).
+static int comm_allreduce(dpmm_ctx *c, void *dbuf, size_t count, int kind) {
+    const bool f64 = kind == 1;
+    if (!c->ev_comm[0]) for (auto &e : c->ev_comm) HIPCHK(c, hipEventCreate(&e));
+    HIPCHK(c, hipEventRecord(c->ev_comm[2 * kind], c->stream));
+    if (c->comm) {
+        Rccl &r = rccl();
+        const int rc = r.AllReduce(dbuf, dbuf, count, f64 ? kNcclFloat64 : kNcclInt64, kNcclSum, c->comm, c->stream);
+        if (rc != 0) return fail(c, DPMM_ECOMM, std::string("ncclAllReduce: ") + r.GetErrorString(rc));
+    } else {
+        const size_t bytes = count * 8;
+        if (bytes > c->h_red_bytes) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->h_red) hipHostFree(c->h_red);
+            c->h_red = nullptr; c->h_red_bytes = 0;
+            size_t cap = 1 << 16;
+            while (cap < bytes) cap *= 2;
+            HIPCHK(c, hipHostMalloc((void **)&c->h_red, cap, hipHostMallocDefault));
+            c->h_red_bytes = cap;
+        }
+        HIPCHK(c, launch_copy_bytes(c->h_red, dbuf, bytes, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const int rc = c->host_fn(c->host_user, c->h_red, (int64_t)count, f64 ? 1 : 0);
+        if (rc != 0) return fail(c, DPMM_ECOMM, "host all-reduce callback failed (code " + std::to_string(rc) + ")");
+        HIPCHK(c, launch_copy_bytes(dbuf, c->h_red, bytes, c->stream));
+    }
+    HIPCHK(c, hipEventRecord(c->ev_comm[2 * kind + 1], c->stream));
+    c->have_comm_ev[kind] = true;
+    c->comm_bytes[kind] = (int64_t)count * 8;
+    ++c->comm_calls;
     return DPMM_OK;
 }
 static void comm_release(dpmm_ctx *c) {
     if (c->comm) { rccl().CommDestroy(c->comm); c->comm = nullptr; }
+    c->host_fn = nullptr; c->host_user = nullptr;
     c->world = 1; c->rank = 0;
+    c->have_comm_ev[0] = c->have_comm_ev[1] = false;
+    c->comm_bytes[0] = c->comm_bytes[1] = 0; c->comm_calls = 0;
 }
 
 #pragma GCC visibility push(default)
@@ -399,6 +439,8 @@ int dpmm_destroy(dpmm_ctx *c) {
     if (c->h_master) hipHostFree(c->h_master);
     hipFree(c->d_counts64); hipFree(c->d_row_off); hipFree(c->d_inv_off); hipFree(c->d_work); hipFree(c->d_par);
     comm_release(c);
+    if (c->h_red) hipHostFree(c->h_red);
+    for (auto &e : c->ev_comm) if (e) hipEventDestroy(e);
     if (c->h_pin) hipHostFree(c->h_pin);
     if (c->h_par) hipHostFree(c->h_par);
     if (c->h_out) hipHostFree(c->h_out);
@@ -989,9 +1031,9 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
         // reset_bad_clusters! (local_clusters_actions.jl:501-516) on the device: occupancies (summed over the ranks) -> flags ->
         // sub-labels of flagged clusters re-drawn -> histogram again (skipped on the device when nothing was flagged)
         const long long *gc = nullptr;
-        if (c->comm) {
+        if (comm_attached(c)) {
             HIPCHK(c, launch_widen_counts(c->sb.bin_total, c->d_counts64, nbins, c->stream));
-            if (int rc = comm_allreduce(c, c->d_counts64, nbins, /*f64=*/false)) return rc;
+            if (int rc = comm_allreduce(c, c->d_counts64, nbins, /*kind=*/0)) return rc;
             gc = c->d_counts64;
         }
         // the flags live right behind the packed rows, so that rows + flags reach the master in one copy
@@ -1008,10 +1050,10 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
     if (c->prior == DPMM_PRIOR_NIW) HIPCHK(c, launch_niw_stats(a, c->stream));
     else if (c->x_u8) HIPCHK(c, launch_mult_stats_u8(a, c->dX8, c->ld8, c->stream));
     else HIPCHK(c, launch_mult_stats(a, c->stream));
-    if (c->comm) {
+    if (comm_attached(c)) {
         // the one exchange of the sweep: elementwise sum of the per-worker statistics (update_suff_stats_posterior!,
         // local_clusters_actions.jl:206-254; aggregate_suff_stats); N counts travel as Float64 integers (exact below 2^53)
-        if (int rc = comm_allreduce(c, c->d_out, (size_t)nbins * (size_t)c->packed_stride, /*f64=*/true)) return rc;
+        if (int rc = comm_allreduce(c, c->d_out, (size_t)nbins * (size_t)c->packed_stride, /*kind=*/1)) return rc;
     }
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     c->have_stats_ev = true;
@@ -1505,6 +1547,31 @@ int dpmm_niw_master_draws(dpmm_ctx *c, int K, float *mu, float *R, float *logdet
     return DPMM_OK;
 }
 
+int dpmm_debug_niw_draw_inputs(dpmm_ctx *c, uint32_t epoch, int K, const int32_t *slot_of_cluster, double *A, double *xi) {
+    if (!c || !slot_of_cluster || !A || !xi) return DPMM_EINVAL;
+    if (!c->master) return fail(c, DPMM_ESTATE, "dpmm_niw_master_setup first");
+    if (K < 1 || K > DPMM_MAX_CLUSTERS) return fail(c, DPMM_EINVAL, "bad K");
+    HIPCHK(c, hipSetDevice(c->device));
+    for (int k = 0; k < K; ++k)
+        if (slot_of_cluster[k] < 0 || slot_of_cluster[k] >= c->master_slots) return fail(c, DPMM_EINVAL, "slot without a posterior on the device");
+    const size_t D = (size_t)c->D, nA = 3 * (size_t)K * D * D, nx = 3 * (size_t)K * D;
+    double *dA = nullptr, *dxi = nullptr;
+    int32_t *dsl = nullptr;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipError_t e = hipMalloc(&dA, sizeof(double) * nA);
+    if (e == hipSuccess) e = hipMalloc(&dxi, sizeof(double) * nx);
+    if (e == hipSuccess) e = hipMalloc(&dsl, sizeof(int32_t) * K);
+    if (e == hipSuccess) e = hipMemset(dA, 0, sizeof(double) * nA);
+    if (e == hipSuccess) e = hipMemcpy(dsl, slot_of_cluster, sizeof(int32_t) * K, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_niw_draw_inputs(c->ma, dsl, K, epoch, dA, dxi, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(A, dA, sizeof(double) * nA, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(xi, dxi, sizeof(double) * nx, hipMemcpyDeviceToHost);
+    hipFree(dA); hipFree(dxi); hipFree(dsl);
+    if (e != hipSuccess) { c->err = std::string("dpmm_debug_niw_draw_inputs: ") + hipGetErrorString(e); return DPMM_EHIP; }
+    return DPMM_OK;
+}
+
 int dpmm_suffstats_packed(dpmm_ctx *c, const int64_t *idx, int n_idx, double *out) {
     if (!c || !out) return DPMM_EINVAL;
     const double *pk = nullptr;
@@ -1811,6 +1878,34 @@ int dpmm_comm_init(dpmm_ctx *c, const void *unique_id128, int rank, int world) {
     return DPMM_OK;
 }
 
+int dpmm_comm_init_host(dpmm_ctx *c, int rank, int world, dpmm_host_allreduce_fn fn, void *user) {
+    if (!c || !fn) return DPMM_EINVAL;
+    if (world < 1 || rank < 0 || rank >= world) return fail(c, DPMM_EINVAL, "bad rank / world");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    comm_release(c);
+    c->host_fn = fn; c->host_user = user; c->rank = rank; c->world = world;
+    return DPMM_OK;
+}
+
+int dpmm_comm_info(dpmm_ctx *c, int64_t *out8) {
+    if (!c || !out8) return DPMM_EINVAL;
+    out8[0] = c->world; out8[1] = c->rank;
+    out8[2] = c->comm ? 1 : (c->host_fn ? 2 : 0);
+    out8[3] = c->comm_bytes[0]; out8[4] = c->comm_bytes[1]; out8[5] = c->comm_calls;
+    out8[6] = out8[7] = 0;
+    return DPMM_OK;
+}
+
+int dpmm_last_comm_ms(dpmm_ctx *c, float *counts_ms, float *rows_ms) {
+    if (!c) return DPMM_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (counts_ms) { *counts_ms = 0.f; if (c->have_comm_ev[0]) HIPCHK(c, hipEventElapsedTime(counts_ms, c->ev_comm[0], c->ev_comm[1])); }
+    if (rows_ms) { *rows_ms = 0.f; if (c->have_comm_ev[1]) HIPCHK(c, hipEventElapsedTime(rows_ms, c->ev_comm[2], c->ev_comm[3])); }
+    return DPMM_OK;
+}
+
 int dpmm_comm_destroy(dpmm_ctx *c) {
     if (!c) return DPMM_EINVAL;
     hipSetDevice(c->device);
@@ -1821,9 +1916,18 @@ int dpmm_comm_destroy(dpmm_ctx *c) {
 
 int dpmm_comm_allgather_host(dpmm_ctx *c, const void *mine, int64_t bytes, void *all) {
     if (!c || !mine || !all || bytes < 0) return DPMM_EINVAL;
-    if (!c->comm || c->world == 1) { memcpy(all, mine, (size_t)bytes); return DPMM_OK; }
+    if (!comm_attached(c) || c->world == 1) { memcpy(all, mine, (size_t)bytes); return DPMM_OK; }
     HIPCHK(c, hipSetDevice(c->device));
     const size_t nb = ((size_t)bytes + 7) & ~(size_t)7, tot = nb * (size_t)c->world;
+    if (!c->comm) {
+        // host transport: every rank contributes its piece in a zeroed [world][nb] buffer; the Int64 sum over the ranks is the gather
+        std::vector<int64_t> buf(tot / 8, 0);
+        memcpy(reinterpret_cast<char *>(buf.data()) + nb * (size_t)c->rank, mine, (size_t)bytes);
+        const int hrc = c->host_fn(c->host_user, buf.data(), (int64_t)(tot / 8), 0);
+        if (hrc != 0) return fail(c, DPMM_ECOMM, "host all-reduce callback failed (code " + std::to_string(hrc) + ")");
+        for (int rk = 0; rk < c->world; ++rk) memcpy((char *)all + (size_t)rk * (size_t)bytes, reinterpret_cast<char *>(buf.data()) + nb * (size_t)rk, (size_t)bytes);
+        return DPMM_OK;
+    }
     if (int rc = ensure_pinned(c, nb + tot)) return rc;
     char *dbuf = nullptr;
     HIPCHK(c, hipMalloc(&dbuf, tot));

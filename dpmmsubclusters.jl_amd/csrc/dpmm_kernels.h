@@ -192,6 +192,7 @@ size_t niw_master_lds_bytes(int DP);
 hipError_t launch_niw_master_pairs(const NiwMasterArgs &a, const int32_t *pairs, int n, double *scratch, double *small, hipStream_t s);
 hipError_t launch_niw_rows_gather(const double *rows_store, const int32_t *slots, int n, int64_t stride, double *dst, hipStream_t s);
 hipError_t launch_niw_master_posterior(const NiwMasterArgs &a, const int32_t *jobs, int njobs, const double *rows, double *small, hipStream_t s);
+hipError_t launch_niw_draw_inputs(const NiwMasterArgs &a, const int32_t *slot_of_cluster, int K, uint32_t epoch, double *Aout, double *xiout, hipStream_t s);
 hipError_t launch_niw_master_noise(const NiwMasterArgs &a, int nmat, uint32_t epoch, double *Y, hipStream_t s);
 hipError_t launch_niw_master_draw(const NiwMasterArgs &a, const int32_t *slot_of_cluster, int K, uint32_t epoch, double *Y, float *logdet_sigma,
                                   const float *lr, const float *wts, float *Rp, float *mup, float *cst, float *tail, int NB,

@@ -582,6 +582,34 @@ __global__ __launch_bounds__(256) void niw_draw_kernel(NiwMasterArgs A, const in
 #endif
 }
 
+// Diagnostic: the random INPUTS of the draw of `epoch` for the distributions in cluster order -- the Bartlett factor A ([3K][D][D], lower:
+// chi_{nu' - r} on the diagonal, standard normals below) and the mean normals xi ([3K][D]) -- produced by the same device functions
+// with the same keys as niw_noise_kernel / niw_draw_kernel.  The draw is a deterministic function of (L, A, xi): tests recompute it in
+// numpy from these (dpmm_debug_niw_draw_inputs).
+__global__ __launch_bounds__(256) void niw_draw_inputs_kernel(NiwMasterArgs A, const int32_t *__restrict__ slot_of_cluster, uint32_t epoch,
+                                                              double *__restrict__ Aout, double *__restrict__ xiout) {
+    const int k = blockIdx.x / 3, w = blockIdx.x % 3;
+    const int row = 3 * slot_of_cluster[k] + w;
+    const int D = A.D, DP = A.DP, HP = DP / 2, tid = threadIdx.x;
+    const double nu = A.nu[row];
+    const uint64_t id = (uint64_t)blockIdx.x;
+    double *Ao = Aout + (int64_t)blockIdx.x * D * D;
+    for (int p2 = tid; p2 < DP * HP; p2 += 256) {
+        const int r = p2 / HP, c = 2 * (p2 - r * HP);
+        double n0, n1;
+        bartlett_pair(A, id, epoch, r, c, n0, n1);
+        if (r < D && c < D && c != r) Ao[(int64_t)r * D + c] = n0;
+        if (r < D && c + 1 < D && c + 1 != r) Ao[(int64_t)r * D + c + 1] = n1;
+    }
+    for (int r = tid; r < D; r += 256) Ao[(int64_t)r * D + r] = sqrt(2.0 * gamma_mt(0.5 * (nu - r), A.seed, (id << 16) + (uint64_t)r, epoch));
+    for (int d = tid; d < D; d += 256)
+        xiout[(int64_t)blockIdx.x * D + d] = normal_from(philox4x32_10(A.seed, (id << 32) + (uint64_t)d, epoch, STREAM_M_XI));
+}
+hipError_t launch_niw_draw_inputs(const NiwMasterArgs &a, const int32_t *slot_of_cluster, int K, uint32_t epoch, double *Aout, double *xiout, hipStream_t s) {
+    hipLaunchKernelGGL(niw_draw_inputs_kernel, dim3(3 * K), dim3(256), 0, s, a, slot_of_cluster, epoch, Aout, xiout);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------------------------ pack
 // Y ([3K][DP][DP] Float64, R = Y') + mu -> the sweep kernels' fragment images (same layout as niw_pack_kernel), constants, tail records
 __global__ void niw_master_pack_kernel(const double *__restrict__ Yall, const float *__restrict__ mu_draw, const float *__restrict__ logdet_sigma,

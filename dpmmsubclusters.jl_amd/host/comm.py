@@ -1,5 +1,6 @@
 """Cross-GPU plumbing around the sweep.  The exchange itself -- ONE all-reduce(sum) of the packed sufficient statistics per
-statistics pass -- runs INSIDE libdpmmhip.so (dpmm_comm_init + dpmm_step_stats / dpmm_suffstats_host: RCCL on the ctx stream);
+statistics pass -- runs INSIDE libdpmmhip.so (dpmm_comm_init + dpmm_step_stats / dpmm_suffstats_host: RCCL on the ctx stream;
+with a non-RCCL process group, dpmm_comm_init_host: the same library path over a host all-reduce of the group);
 this module ships the RCCL unique id, gathers labels for results, and sums the small evaluation tables.
 
 Replaces the reference's two-level tree reduce of `thin_suff_stats` dicts
@@ -26,13 +27,24 @@ class TorchDistComm:
         self.device = int(os.environ.get("LOCAL_RANK", 0)) if device is None else device
 
     def attach(self, worker):
-        """Multi-GPU: create the RCCL communicator INSIDE libdpmmhip.so (dpmm_comm_init); from then on the worker's statistics
-        calls return rows summed over all ranks.  torch.distributed only ships the 128-byte unique id."""
-        if self.backend != "nccl":
+        """Multi-GPU: attach the collective INSIDE libdpmmhip.so; from then on the worker's statistics calls return rows summed
+        over all ranks.  Backend "nccl": an RCCL communicator on the ctx stream (dpmm_comm_init; torch.distributed only ships the
+        128-byte unique id).  Any other backend (gloo: hosts without a GPU fabric, ranks sharing one GPU): the library stages its
+        device buffers through pinned memory and this group's all_reduce sums them (dpmm_comm_init_host) -- same library code path
+        around the transport.  Never silently unattached: a multi-rank run whose statistics stay local would diverge."""
+        if self.world == 1 and self.backend != "nccl":
             return
-        uid = [worker.comm_unique_id() if self.rank == 0 else None]
-        self.dist.broadcast_object_list(uid, src=0)
-        worker.comm_init(uid[0], self.rank, self.world)
+        if self.backend == "nccl":
+            uid = [worker.comm_unique_id() if self.rank == 0 else None]
+            self.dist.broadcast_object_list(uid, src=0)
+            worker.comm_init(uid[0], self.rank, self.world)
+            return
+        if not hasattr(worker, "comm_init_host"):
+            raise RuntimeError(f"backend {self.backend!r}: the worker has no host-transport attachment and world = {self.world}")
+
+        def allreduce(arr):          # arr: numpy view of the library's pinned staging -> summed in place
+            self.dist.all_reduce(self.torch.from_numpy(arr))
+        worker.comm_init_host(self.rank, self.world, allreduce)
 
     def allreduce_np(self, arr):
         """Sum of a Float64 numpy array over the ranks (CPU test workers; the GPU path reduces inside libdpmmhip.so)."""

@@ -283,8 +283,17 @@ int dpmm_last_sweep_work(dpmm_ctx *ctx, uint64_t *out8);
  * reduce (local_clusters_actions.jl:171-254) and aggregate_suff_stats (priors/niw.jl:64-66, multinomial_prior.jl:41-43).
  *   dpmm_comm_unique_id   rank 0 creates the 128-byte RCCL id and ships it to the other ranks by any means
  *   dpmm_comm_init        every rank (one process per GPU) joins; collective
- * After dpmm_comm_init, dpmm_step_stats / dpmm_suffstats_host / dpmm_suffstats_packed return statistics summed over all ranks.
- * dpmm_comm_allgather_host gathers `bytes` of host data from every rank (all [world][bytes]); collective. */
+ *   dpmm_comm_init_host   the same attachment with the caller's OWN transport instead of RCCL: `fn(user, buf, count, is_f64)` sums `count`
+ *                         Float64 (is_f64 = 1) or Int64 (0) values of the HOST buffer `buf` over the ranks in place and returns 0.  The library
+ *                         stages the device buffer through pinned memory around the call (one blocking round trip per all-reduce).  This is
+ *                         what the reference's own Distributed transport does (fetch of host Dicts, local_clusters_actions.jl:231); it exists
+ *                         for hosts without a peer-to-peer fabric between the ranks' GPUs (and lets several ranks share ONE GPU in tests)
+ * After either, dpmm_step_stats / dpmm_suffstats_host / dpmm_suffstats_packed return statistics summed over all ranks.
+ * dpmm_comm_allgather_host gathers `bytes` of host data from every rank (all [world][bytes]); collective.
+ * dpmm_comm_info: out8 = {world, rank, transport (0 none, 1 RCCL, 2 host function), bytes of the last occupancy all-reduce, bytes of the
+ * last packed-row all-reduce, all-reduces since the attachment, 0, 0}.  dpmm_last_comm_ms: HIP-event time of the last all-reduce of each
+ * kind on the ctx stream (0 if none; synchronises the stream). */
+typedef int (*dpmm_host_allreduce_fn)(void *user, void *buf, int64_t count, int is_f64);
 /* ---- the master's dense maths on the device (NIW prior; optional fast path for a master that otherwise works on the host) ----
  * The 3K posteriors, their factorisations and the parameter draws of a sweep are O(K D^3) and need the full packed rows: at
  * D = 256 that is 2-3 ms of host time and 30 MB over the host link per sweep.  With these calls the rows stay in HBM:
@@ -324,6 +333,11 @@ int dpmm_niw_master_pairs(dpmm_ctx *ctx, const int32_t *slots_i, const int32_t *
 int dpmm_niw_master_put_rows(dpmm_ctx *ctx, const double *rows, int K);
 int dpmm_niw_master_rows(dpmm_ctx *ctx, const int32_t *slots, int n, double *out);
 int dpmm_niw_master_draws(dpmm_ctx *ctx, int K, float *mu, float *R, float *logdet);
+/* Diagnostic: the random inputs dpmm_niw_master_draw consumes for `epoch` and this cluster -> slot map, in cluster order: the Bartlett
+ * factors A [3K][D][D] (lower triangular: chi_{nu' - r} on the diagonal, r = 0 .. D-1, standard normals below; Distributions.jl's
+ * Wishart sampler behind niw.jl:35) and the mean normals xi [3K][D].  The draw is the deterministic function
+ * R' = L^-1 A (nu' psi' = L'L, L lower), mu = m' + R^-1 xi / sqrt(kappa') of them: tests recompute it in Float64. */
+int dpmm_debug_niw_draw_inputs(dpmm_ctx *ctx, uint32_t epoch, int K, const int32_t *slot_of_cluster, double *A, double *xi);
 
 /* RCCL is bound at run time (dlopen): a copy already mapped into the process wins, then the soname, then /opt/rocm/lib.
  * dpmm_comm_use_library names the file to use instead (before the first dpmm_comm_* call) -- a host that also runs
@@ -331,6 +345,9 @@ int dpmm_niw_master_draws(dpmm_ctx *ctx, int K, float *mu, float *R, float *logd
 int dpmm_comm_use_library(const char *path);
 int dpmm_comm_unique_id(void *out128);
 int dpmm_comm_init(dpmm_ctx *ctx, const void *unique_id128, int rank, int world);
+int dpmm_comm_init_host(dpmm_ctx *ctx, int rank, int world, dpmm_host_allreduce_fn fn, void *user);
+int dpmm_comm_info(dpmm_ctx *ctx, int64_t *out8);
+int dpmm_last_comm_ms(dpmm_ctx *ctx, float *counts_ms, float *rows_ms);
 int dpmm_comm_destroy(dpmm_ctx *ctx);
 int dpmm_comm_allgather_host(dpmm_ctx *ctx, const void *mine, int64_t bytes, void *all);
 
