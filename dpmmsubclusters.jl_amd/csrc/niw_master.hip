@@ -73,6 +73,12 @@ __device__ double gamma_mt(double a, uint64_t seed, uint64_t idx, uint32_t epoch
     }
 }
 
+// Diagonal of the Bartlett factor of a Wishart(nu, .) draw (Distributions.jl's sampler behind niw.jl:35): A_rr = chi with nu - r degrees
+// of freedom, r = 0 .. D-1 (chi^2_dof = 2 Gamma(dof / 2)); `id` = position of the distribution in cluster order
+__device__ __forceinline__ double bartlett_diag(uint64_t seed, uint64_t id, uint32_t epoch, int r, double nu) {
+    return sqrt(2.0 * gamma_mt(0.5 * (nu - (double)r), seed, (id << 16) + (uint64_t)r, epoch));
+}
+
 // ------------------------------------------------------------------------------------------------------------------ form
 // job j: cluster k = jobs[2j] (0-based), slot s = jobs[2j+1]; rows 3s + w, w = 0 (cluster = left + right), 1 (left), 2 (right).
 // small[(3j + w) * NS + {0,1,2,4}] = N, kappa', nu', log Gamma_D(nu' / 2)   (entry 3: log det(nu' psi'), written by the factorisation)
@@ -416,7 +422,7 @@ __global__ __launch_bounds__(256) void niw_draw_kernel(NiwMasterArgs A, const in
         }
     }
     __syncthreads();
-    for (int r = tid; r < D; r += 256) Y[(int64_t)r * DP + r] = sqrt(2.0 * gamma_mt(0.5 * (nu - r), A.seed, (id << 16) + (uint64_t)r, epoch));
+    for (int r = tid; r < D; r += 256) Y[(int64_t)r * DP + r] = bartlett_diag(A.seed, id, epoch, r, nu);
     for (int d = tid; d < DP; d += 256)
         xi[d] = d < D ? normal_from(philox4x32_10(A.seed, (id << 32) + (uint64_t)d, epoch, STREAM_M_XI)) : 0.0;
     __syncthreads();
@@ -601,7 +607,7 @@ __global__ __launch_bounds__(256) void niw_draw_inputs_kernel(NiwMasterArgs A, c
         if (r < D && c < D && c != r) Ao[(int64_t)r * D + c] = n0;
         if (r < D && c + 1 < D && c + 1 != r) Ao[(int64_t)r * D + c + 1] = n1;
     }
-    for (int r = tid; r < D; r += 256) Ao[(int64_t)r * D + r] = sqrt(2.0 * gamma_mt(0.5 * (nu - r), A.seed, (id << 16) + (uint64_t)r, epoch));
+    for (int r = tid; r < D; r += 256) Ao[(int64_t)r * D + r] = bartlett_diag(A.seed, id, epoch, r, nu);
     for (int d = tid; d < D; d += 256)
         xiout[(int64_t)blockIdx.x * D + d] = normal_from(philox4x32_10(A.seed, (id << 32) + (uint64_t)d, epoch, STREAM_M_XI));
 }

@@ -97,6 +97,127 @@ def test_draw_distribution_and_handover(pkg, D):
     wk.close()
 
 
+def _reverse_chol(P):
+    """L lower triangular with L'L = P (the factor the device keeps: nu' psi' = L'L)."""
+    C = np.linalg.cholesky(P[::-1, ::-1])
+    return np.ascontiguousarray(C[::-1, ::-1].T)
+
+
+def _small_nu_setup(pkg, D, n, K, seed):
+    """K clusters whose RIGHT sub-cluster is empty (posterior = prior, nu = D + 3: the case most sensitive to the degrees of freedom),
+    cluster K entirely empty."""
+    wk, X, lab, sub, prior = _setup(pkg, D, n, K, seed)
+    lab = lab.copy(); sub = np.ones_like(sub)
+    lab[lab == K] = 1
+    wk.set_labels(lab, sub)
+    wk.master_setup(*prior)
+    wk.suffstats_device(None)
+    slots = np.arange(K, dtype=np.int32)
+    wk.master_posterior(None, slots)
+    return wk, X, lab, sub, prior, slots
+
+
+@pytest.mark.parametrize("D", [2, 5, 64, 200])
+def test_device_draw_pinned_at_value_level(pkg, D):
+    """sample_distribution (niw.jl:34-40) on the device is a deterministic function of the factor L (nu' psi' = L'L), the Bartlett
+    factor A and the mean normals xi:  R' = L^-1 A,  log det Sigma = -2 sum log diag(R),  mu = m' + R^-1 xi / sqrt(kappa').
+    Recomputed here in numpy Float64 from the inputs the kernels consumed (dpmm_debug_niw_draw_inputs) and the posteriors of the
+    data -- populated, one-sided and empty distributions; launched-ahead normals and in-kernel normals."""
+    from scipy.linalg import solve_triangular
+    n, K = 3000, 4
+    wk, X, lab, sub, prior, slots = _small_nu_setup(pkg, D, n, K, seed=900 + D)
+    sub2 = np.where(lab == 2, 1 + (np.arange(n) % 2), sub)          # cluster 2 keeps two populated sub-clusters
+    wk.set_labels(lab, sub2)
+    wk.suffstats_device(None)
+    wk.master_posterior(None, slots)
+    lr = np.full((K, 2), 0.5, np.float32); w = np.full(K, 1.0 / K, np.float32)
+    worst = 0.0
+    for epoch in (1, 2, 7):                                          # 2 follows 1: its normals were generated ahead on the second stream
+        wk.master_draw(epoch, slots, lr, w)
+        mu, R, ld = wk.master_draws(K)
+        A, xi = wk.debug_draw_inputs(epoch, slots)
+        assert np.all(np.triu(A, 1) == 0)
+        for k in range(K):
+            for wi, mask in enumerate((lab == k + 1, (lab == k + 1) & (sub2 == 1), (lab == k + 1) & (sub2 == 2))):
+                j = 3 * k + wi
+                N, k1, v1, m1, P = _posterior_numpy(prior, X, mask)
+                L = _reverse_chol(P)
+                Y = solve_triangular(L, A[j], lower=True)
+                Rref = Y.T
+                scale = np.abs(Rref).max()
+                assert np.allclose(R[j], Rref, rtol=1e-6, atol=1e-6 * scale), (epoch, j)
+                ldref = -2.0 * np.log(np.diag(Y)).sum()
+                assert abs(ld[j] - ldref) <= 1e-6 * max(1.0, abs(ldref)), (epoch, j, ld[j], ldref)
+                muref = m1 + solve_triangular(Rref, xi[j], lower=False) / np.sqrt(k1)
+                assert np.allclose(mu[j], muref, rtol=1e-6, atol=1e-6 * max(1.0, np.abs(muref).max())), (epoch, j)
+                worst = max(worst, float(np.abs(R[j] - Rref).max() / scale))
+    print(f"D={D}: max |R - R_ref| / max|R_ref| = {worst:.2e}")
+    wk.close()
+
+
+@pytest.mark.parametrize("D", [2, 5, 64])
+def test_device_draw_inputs_law_at_small_nu(pkg, D):
+    """The Bartlett factor the device draw consumes, at nu = D + 3 (empty sub-cluster => prior): diag^2 of row r (0-based) is
+    chi^2 with nu - r degrees of freedom (mean nu - r, variance 2 (nu - r)), below the diagonal and in xi standard normals --
+    over > 20 000 draws.  An off-by-one in the degrees of freedom moves the row means by 1 = 20 ... 50 standard errors here."""
+    n, K = 1500, 8
+    wk, X, lab, sub, prior, slots = _small_nu_setup(pkg, D, n, K, seed=700 + D)
+    nu = prior[1]
+    reps = 2600
+    d2 = np.zeros(D); d4 = np.zeros(D); cnt = 0
+    off1 = np.zeros((D, D)); off2 = np.zeros((D, D)); x1 = np.zeros(D); x2 = np.zeros(D)
+    for ep in range(1, reps + 1):
+        A, xi = wk.debug_draw_inputs(ep, slots)
+        Ar = A[2::3]                                               # the right sub-clusters: all empty
+        dg = np.einsum("kii->ki", Ar) ** 2
+        d2 += dg.sum(0); d4 += (dg ** 2).sum(0); cnt += len(Ar)
+        off1 += Ar.sum(0); off2 += (Ar ** 2).sum(0)
+        x1 += xi[2::3].sum(0); x2 += (xi[2::3] ** 2).sum(0)
+    assert cnt >= 20000
+    dof = nu - np.arange(D)
+    mean = d2 / cnt; var = d4 / cnt - mean ** 2
+    se = np.sqrt(2 * dof / cnt)
+    assert np.all(np.abs(mean - dof) < 5 * se), (mean - dof) / se
+    assert np.all(np.abs(var - 2 * dof) < 0.12 * 2 * dof)
+    il = np.tril_indices(D, -1)
+    if len(il[0]):
+        assert np.all(np.abs(off1[il] / cnt) < 5 / np.sqrt(cnt)) and np.all(np.abs(off2[il] / cnt - 1) < 5 * np.sqrt(2 / cnt))
+    assert np.all(np.abs(x1 / cnt) < 5 / np.sqrt(cnt)) and np.all(np.abs(x2 / cnt - 1) < 5 * np.sqrt(2 / cnt))
+    # distributions get different variates (streams keyed by the position in cluster order)
+    A, xi = wk.debug_draw_inputs(1, slots)
+    assert len({float(a[0, 0]) for a in A}) == 3 * K and len({float(v[0]) for v in xi}) == 3 * K
+    wk.close()
+
+
+@pytest.mark.parametrize("D", [2, 5, 64])
+def test_device_draw_law_at_small_nu(pkg, D):
+    """End to end at nu = D + 3: Sigma^-1 = R'R ~ Wishart(nu, (nu psi)^-1), E = psi^-1 -- to 5 standard errors of > 20 000 draws
+    (0.6 % at D = 64, 2.2 % at D = 2; a degrees-of-freedom error of one is 1.5 % / 20 %); mu ~ N(m, Sigma / kappa)."""
+    n, K = 1500, 8
+    wk, X, lab, sub, prior, slots = _small_nu_setup(pkg, D, n, K, seed=800 + D)
+    k0, nu, m0, psi = prior
+    psi = 0.5 * (psi + psi.T)
+    lr = np.full((K, 2), 0.5, np.float32); w = np.full(K, 1.0 / K, np.float32)
+    reps = 2600
+    W = np.zeros((D, D)); mus = np.zeros(D); cnt = 0
+    for ep in range(1, reps + 1):
+        wk.master_draw(ep, slots, lr, w)
+        mu, R, ld = wk.master_draws(K)
+        Rr = R[2::3].astype(np.float64)
+        W += np.einsum("kji,kjl->il", Rr, Rr); mus += mu[2::3].sum(0); cnt += len(Rr)
+    assert cnt >= 20000
+    EW = np.linalg.inv(psi)                                        # nu (nu psi)^-1
+    Wm = W / cnt
+    dscale = np.sqrt(np.outer(np.diag(EW), np.diag(EW)))
+    se = np.sqrt((EW ** 2 + dscale ** 2) / nu / cnt)               # Var W_ij = nu (s_ij^2 + s_ii s_jj) with s = EW / nu
+    assert np.all(np.abs(Wm - EW) < 5 * se), np.max(np.abs(Wm - EW) / se)
+    print(f"D={D}: max |E[W] - psi^-1| / se = {np.max(np.abs(Wm - EW) / se):.2f}; relative on the diagonal "
+          f"{np.max(np.abs(np.diag(Wm) / np.diag(EW) - 1)):.4f} (1 / nu = {1 / nu:.4f})")
+    # mean: E = m0; heavy tails at nu = D + 3 (infinite variance of Sigma) -> a loose bar, the value-level test pins mu exactly
+    assert np.all(np.abs(mus / cnt - m0) < 0.2 * np.sqrt(np.max(np.diag(psi)) * nu / 2 / k0))
+    wk.close()
+
+
 def _nmi(a, b):
     from sklearn.metrics import normalized_mutual_info_score
     return normalized_mutual_info_score(a, b)

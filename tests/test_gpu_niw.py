@@ -1,8 +1,8 @@
 """GPU parity tests for the NIW worker path: HIP kernels (through the C ABI) vs the CPU oracle on
 the same seeded inputs.  Tolerances (fp32 contraction on the matrix cores vs the oracle's f32/f64):
-  per-point log-lik: atol 2e-3 + rtol 2e-5 against the Float64 evaluation of the same f32 parameters
-  labels under shared uniforms: exact except counted near-boundary flips (< 2e-4 of points, each
-      explained by a CDF margin below 1e-3 of the row mass)
+  per-point log-lik: atol 1e-3 + rtol 2e-5 against the Float64 evaluation of the same f32 parameters
+  labels under shared uniforms: exact except counted near-boundary flips (<= 5e-5 of points, sub-labels <= 2e-4; at least 2;
+      counts are printed; each label flip explained by a CDF margin below 1e-3 of the row mass)
   draw given the GPU's own table: bit-exact (same exp_det / scan arithmetic)
   N counts and all relabel bookkeeping: bit-exact; sum x, sum xx' vs Float64 oracle: rtol 1e-12
 """
@@ -78,7 +78,8 @@ def test_loglik_table(pkg, D, n, K):
     want = table_f64(P) + 0.5 * D * D * np.log(2 * np.pi)
     scale = np.abs(want).max(axis=0, keepdims=True)
     err = np.abs(got - want)
-    assert np.all(err <= 2e-3 + 2e-5 * np.abs(want)), (err.max(), scale.max())
+    print(f"D={D}: max |loglik err| = {err.max():.2e} (max |value| {np.abs(want).max():.1f})")
+    assert np.all(err <= 1e-3 + 2e-5 * np.abs(want)), (err.max(), scale.max())
     # the differences that matter for a draw: relative to the row maximum
     rel = (got - got.max(0)) - (want - want.max(0))
     near = (want - want.max(0)) > -30
@@ -104,7 +105,7 @@ def test_sweep_labels_vs_oracle(pkg, D, n, K, sorted_points):
     olab, osub, otab = orc.sweep_niw(P["X"], D, P["mu"], P["invS"], P["logdet"], np.log(P["w"]), np.log(P["lr"]),
                                      seed=seed, epoch=epoch, first_idx=first, want_parr=True)
     flips = np.flatnonzero(lab != olab)
-    assert len(flips) <= max(2, int(2e-4 * n)), len(flips)
+    assert len(flips) <= max(2, int(5e-5 * n)), len(flips)
     t64 = table_f64(P)
     p = np.exp(t64 - t64.max(0))
     cdf = np.cumsum(p, 0) / p.sum(0)
@@ -112,7 +113,8 @@ def test_sweep_labels_vs_oracle(pkg, D, n, K, sorted_points):
         assert np.min(np.abs(cdf[:, i] - u0[i])) < 1e-3, (i, u0[i], cdf[:, i])
     same = lab == olab
     sflips = int((sub[same] != osub[same]).sum())
-    assert sflips <= max(2, int(5e-4 * n)), sflips
+    print(f"D={D} n={n}: label flips vs oracle {len(flips)}, sub-label flips {sflips}")
+    assert sflips <= max(2, int(2e-4 * n)), sflips
     # the labels must be informative (not a degenerate draw)
     assert (lab == P["z"] + 1).mean() > 1.5 / K
     wk.close()
@@ -131,7 +133,7 @@ def test_loglik_reference_normaliser_switch(pkg):
     np.testing.assert_allclose(ref - plain, -0.5 * D * D * np.log(2 * np.pi), rtol=0, atol=2e-4)
     for k in range(K):
         want = orc.niw_loglik_ref(P["X"], D, P["mu"][3 * k], P["invS"][3 * k], P["logdet"][3 * k]) + np.log(P["w"][k])
-        np.testing.assert_allclose(ref[k], want, rtol=2e-5, atol=2e-3)
+        np.testing.assert_allclose(ref[k], want, rtol=2e-5, atol=1e-3)
     wk.close()
 
 
@@ -321,9 +323,10 @@ def test_many_clusters_and_padded_dims_with_screening(pkg, D, n, K):
     assert np.array_equal(orc.sample_log_cat(tab, u0), lab)
     assert_sublabels_bit_exact(wk, lab, sub, u1)        # phase 2 of the screened / ordered sweep (rb0 carry-over, prefetch chain)
     olab, osub = orc.sweep_niw(P["X"], D, P["mu"], P["invS"], P["logdet"], np.log(P["w"]), np.log(P["lr"]), seed=seed, epoch=2, first_idx=first)
-    assert (lab != olab).sum() <= max(2, int(3e-4 * n))
     same = lab == olab
-    assert (sub[same] != osub[same]).sum() <= max(2, int(1e-3 * n))
+    print(f"D={D} K={K} n={n}: label flips vs oracle {(lab != olab).sum()}, sub-label flips {(sub[same] != osub[same]).sum()}")
+    assert (lab != olab).sum() <= max(2, int(5e-5 * n))
+    assert (sub[same] != osub[same]).sum() <= max(2, int(2e-4 * n))
     wk.sweep(3, final=True)
     assert np.array_equal(wk.get_labels()[0], orc.argmax_rows(tab))
     wk.close()
