@@ -3,32 +3,42 @@
 N=10^7 synthetic points in 32 true components, on N GPUs of one node (BASELINE.json metric).
 
 A "step" is one full `group_step` (native master: posterior draws -> parameter hand-over -> fused label +
-sub-label sampling kernel -> sort + sufficient statistics kernels -> [RCCL all-reduce] -> posterior
+sub-label sampling kernel -> sort + sufficient statistics kernels -> [all-reduce] -> posterior
 update -> split / merge Metropolis steps -> relabel), i.e. exactly the region the reference
 times as `iter_count` (src/dp-parallel-sampling.jl:363-366).  One-time work (data generation,
 upload, initial labels, burn-in until the split/merge gates are open) is outside the timed
 region, as in the reference.
 
 Strong scaling: the N points are fixed and shard over the ranks by contiguous column ranges;
-the one data-path collective is the all-reduce of the packed sufficient statistics (inside libdpmmhip.so).
+the data-path collective is the all-reduce of the packed sufficient statistics inside libdpmmhip.so (preceded by the
+all-reduce of the 2K Int64 sub-cluster occupancies that decides the bad-cluster reset).
+
+Launch: `python bench.py --gpus N --steps K --warmup W`.  With N > 1 and no launcher in the environment (WORLD_SIZE unset) the
+script starts `python -m torch.distributed.run --nproc-per-node N` on itself as a CHILD process before anything touches the GPU
+and exits with the child's code; under the driver's launcher it finds WORLD_SIZE set and runs as a rank.  A run whose world
+size is not `--gpus` is an error, never a silent 1-GPU bench.  Prints ONE JSON line on rank 0.
 
 Besides the contract fields the JSON line carries
   roofline      the dominant kernel (NIW sweep) against the FP32-MFMA peak: `achieved` = ALGORITHMIC flops / live launch time
                 (exceeds the peak because exact cluster screening skips work), `frac` = EXECUTED flops / time / peak with the
                 executed work counted ON THE DEVICE in the timed launches (dpmm_last_sweep_work), `dense_*` = the same
                 kernel with screening switched off (every cluster evaluated in full) in the same process;
+  comm          what the collective saw: world, transport, bytes per all-reduce, HIP-event time of the two all-reduces per step;
   blocks        min / median / max it/s over repeated blocks of `--steps` steps (the headline `value` is the first block);
-  growth        a run of the same data from ONE initial cluster (`init_clusters=1`): whole-run and last-20 it/s + K history;
+  growth        a run of the same data from ONE initial cluster (`init_clusters=1`): it/s, K history, final log-posterior, NMI;
+  legs          (1 GPU only; `--no-legs` skips) short steady-state runs of the other shapes, each with its own roofline entry:
+                `overlap_var4` / `overlap_var1` (the headline shape with the component means drawn with MixtureVar 4 and 1
+                instead of 100: the middle of the screening range), `c3_shard` (what each of 8 GPUs holds of the headline),
+                `c4` (Multinomial D=1000, N=10^6), `c5_shard` (NIW D=256, n=6.25e5), and `shard8_projection`;
   cpu_baseline  the reference algorithm's worker path on the host cores, P worker processes (see oracle/cpu_baseline.py).
-
-Launch: `python bench.py --gpus 1 ...` or
-`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W`.
-Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,9 +48,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense FP32 matrix peak (no TF32/xf32 on gfx950)
+PEAK_HBM_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E ~8 TB/s (6.29 TB/s measured copy)
+DATA_SEED, SAMPLER_SEED, BURNOUT, ALPHA = 12345, 123456789, 20, 10.0
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -49,61 +61,274 @@ def main():
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--clusters", type=int, default=32)
     ap.add_argument("--blocks", type=int, default=5, help="extra timed blocks of --steps steps after the headline block (min/median/max)")
+    ap.add_argument("--settle", type=int, default=100, help="untimed settling sweeps after the burn-in (reported in the line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-growth", action="store_true")
     ap.add_argument("--no-dense", action="store_true")
-    ap.add_argument("--growth-iters", type=int, default=100)
+    ap.add_argument("--no-legs", action="store_true", help="skip the other-shape legs (overlap, c3_shard, c4, c5_shard)")
+    ap.add_argument("--legs", default="overlap_var4,overlap_var1,c3_shard,c4,c5_shard", help="comma-separated subset of the legs")
+    ap.add_argument("--growth-iters", type=int, default=260)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-clock budget of the CPU baseline sample")
-    args = ap.parse_args()
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="development: all ranks on device 0 over gloo + the library's host transport (boxes with one GPU)")
+    return ap.parse_args()
 
+
+def relaunch_as_ranks(args):
+    """--gpus N > 1 without a launcher: start N ranks as a child process (never exec) BEFORE any GPU call and relay its exit code."""
+    import torch
+    ndev = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    if ndev < args.gpus and not args.share_gpu:
+        sys.exit(f"bench.py --gpus {args.gpus}: only {ndev} GPU(s) visible on this node (refusing to report a smaller run as n_gpus={args.gpus})")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd).returncode)
+
+
+def kernel_source_tag():
+    """sha256 (16 hex digits) over the kernel sources: a committed PMC summary is only quoted while it describes THESE kernels."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "dpmmsubclusters.jl_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(which, kernel_substr):
+    """HBM bytes per launch of a kernel from profiles/latest_<which>_pmc_summary.json (written by scripts/collect_profiles.sh together
+    with the hash of the kernel sources it profiled): 2 x FETCH_SIZE (the gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE, KiB.
+    None when the file is missing or was collected on other kernel sources."""
+    f = os.path.join(ROOT, "profiles", f"latest_{which}_pmc_summary.json")
+    try:
+        pm = json.load(open(f))
+        meta = pm.get("_meta", {})
+        if meta.get("kernel_source_tag") != kernel_source_tag():
+            return None, f"profiles/latest_{which}_pmc_summary.json is stale (collected on kernel sources {meta.get('kernel_source_tag')})"
+        for name, c in pm.items():
+            if kernel_substr in name:
+                return (2.0 * c["FETCH_SIZE"]["median"] + c["WRITE_SIZE"]["median"]) * 1024.0, \
+                    f"profiles/latest_{which}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, median per launch; {meta.get('collected', '')})"
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, None
+
+
+# ----------------------------------------------------------------------------------------------- synthetic inputs on the GPU (legs)
+def gpu_gaussian_mixture(host, torch, N, D, K, mixture_var, seed):
+    """The reference's Gaussian recipe (data_generators.jl:19-42; sizes / means / covariance factors from the product's
+    `_mixture_spec`) with the normals drawn on the device: (X torch (N, D) f32 on cuda, labels (N,) int64 host, 1-based)."""
+    api = importlib.import_module("dpmmsubclusters_jl_amd.host.api")
+    sizes, means, chol = api._mixture_spec(N, D, K, mixture_var, seed)
+    g = torch.Generator(device="cuda"); g.manual_seed(seed)
+    X = torch.randn((N, D), generator=g, device="cuda", dtype=torch.float32)
+    a = 0
+    for k in range(K):
+        b = a + int(sizes[k])
+        if b > a:
+            Lk = torch.from_numpy(chol[k].astype(np.float32)).cuda()
+            X[a:b] = X[a:b] @ Lk.T + torch.from_numpy(means[k].astype(np.float32)).cuda()
+        a = b
+    return X, np.repeat(np.arange(1, K + 1), sizes).astype(np.int64)
+
+
+def gpu_multinomial_mixture(torch, N, D, K, trials, seed):
+    """The reference's bag-of-words recipe (data_generators.jl:59-72: label ~ U{1..K}; component weights ~ Dir(a), a_d ~ U{1..20} except
+    a_k ~ U{30..100}; x ~ Multinomial(trials, p_label)), counts drawn on the device: (X (N, D) f32 cuda, labels host)."""
+    rng = np.random.default_rng(seed)
+    P = np.zeros((K, D))
+    for i in range(K):
+        al = rng.integers(1, 21, D).astype(float)
+        al[i % D] = rng.integers(30, 101)
+        P[i] = rng.dirichlet(al)
+    y = rng.integers(1, K + 1, N)
+    g = torch.Generator(device="cuda"); g.manual_seed(seed)
+    Pt = torch.from_numpy(P.astype(np.float32)).cuda()
+    yt = torch.from_numpy(y - 1).cuda()
+    X = torch.zeros((N, D), device="cuda", dtype=torch.float32)
+    ones = torch.ones((1,), device="cuda", dtype=torch.float32)
+    step = 100000
+    for a in range(0, N, step):
+        b = min(N, a + step)
+        idx = torch.multinomial(Pt[yt[a:b]], trials, replacement=True, generator=g)
+        X[a:b].scatter_add_(1, idx, ones.expand(idx.shape))
+    return X, y.astype(np.int64)
+
+
+def steady_state(pkg, host, torch, prior_kind, prior, X, y, K, steps, settle=30, seed=SAMPLER_SEED):
+    """Upload a device-resident matrix, adopt the generator's labels, burn in until the gates are open, time `steps` group_steps."""
+    N, D = X.shape
+    wk = pkg.Worker(prior_kind, D, N, first_index=0, device=0, seed=seed)
+    wk.upload_points_device(X.data_ptr(), X.stride(0))
+    torch.cuda.synchronize()
+    s = host.DPMMSampler(wk, prior, ALPHA, N, seed, burnout=BURNOUT)
+    s.start_from_labels(y, 1 + np.random.default_rng([DATA_SEED, 7]).integers(0, 2, N), K)
+    for _ in range(BURNOUT + 1 + settle):
+        s.group_step(False, False)
+    wk.sync()
+    if prior_kind == pkg.PRIOR_NIW:
+        wk.last_sweep_work()
+    sw, st, ks = [], [], []
+    t_before = dict(s.timers)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        s.group_step(False, False)
+    wk.sync()
+    el = time.perf_counter() - t0
+    t_after = dict(s.timers)
+    work = wk.last_sweep_work() if prior_kind == pkg.PRIOR_NIW else None
+    for _ in range(5):                                   # kernel times (HIP events; reading them synchronises): outside the timed loop
+        s.group_step(False, False)
+        a, b = wk.last_kernel_ms(); sw.append(a); st.append(b); ks.append(s.K)
+    lab, _ = wk.get_labels()
+    C = np.zeros((int(lab.max()) + 1, K + 1)); np.add.at(C, (lab, y), 1)
+    sampler_mod = importlib.import_module("dpmmsubclusters_jl_amd.host.sampler")
+    nmi, _ = sampler_mod.nmi_vi_from_contingency(C)
+    out = {"n": int(N), "D": int(D), "K_t": float(np.mean(ks)), "steps": steps, "ms_per_step": 1e3 * el / steps, "it_per_s": steps / el,
+           "sweep_kernel_ms": float(np.mean(sw)), "stats_kernels_ms": float(np.mean(st)), "nmi_vs_generator": float(nmi),
+           "host_ms_per_step": {k: round(1e3 * (t_after[k] - t_before[k]) / steps, 4) for k in t_after if t_after[k] - t_before[k] > 0}}
+    wk.close()
+    return out, work
+
+
+def niw_roofline(n, D, k_mean, sweep_ms, work):
+    flops_alg = 2.0 * n * D * D * (k_mean + 2)
+    exe = work["executed_flops"]
+    return {"kernel": "niw_sweep_direct_kernel" if D <= 64 else "niw_sweep_kernel", "bound": "mfma",
+            "achieved": flops_alg / (sweep_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": exe / (sweep_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": sweep_ms,
+            "algorithmic_flops_per_launch": flops_alg, "executed_flops_per_launch": exe, "pruning_factor": flops_alg / exe if exe else None,
+            "full_evals_per_wave_tile": work["full_evals"] / max(1.0, work["wave_tiles"]),
+            "screens16_per_wave_tile": work["screens16"] / max(1.0, work["wave_tiles"]),
+            "tail_pairs_per_wave_tile": work["tail_pairs"] / max(1.0, work["wave_tiles"])}
+
+
+def run_legs(args, pkg, host, torch, one_gpu_ms):
+    legs, want = {}, [x for x in args.legs.split(",") if x]
+    D, K = 64, 32
+    niw64 = host.niw_hyperparams(1.0, np.zeros(D), D + 3, np.eye(D))
+    for name, var in (("overlap_var4", 4.0), ("overlap_var1", 1.0)):
+        if name not in want:
+            continue
+        X, y = gpu_gaussian_mixture(host, torch, 10 ** 7, D, K, var, DATA_SEED)
+        r, work = steady_state(pkg, host, torch, pkg.PRIOR_NIW, niw64, X, y, K, 20)
+        r["workload"] = f"headline shape (NIW D=64 N=1e7 K=32) with component means ~ N(0, {var:g} I) instead of N(0, 100 I); from the generator's labels"
+        r["roofline"] = niw_roofline(r["n"], D, r["K_t"], r["sweep_kernel_ms"], work)
+        legs[name] = r
+        del X
+        torch.cuda.empty_cache()
+    if "c3_shard" in want:
+        n = 1250000
+        X, y = gpu_gaussian_mixture(host, torch, n, D, K, 100.0, DATA_SEED)
+        r, work = steady_state(pkg, host, torch, pkg.PRIOR_NIW, niw64, X, y, K, 100, settle=60)
+        r["workload"] = "what each of 8 GPUs holds of the headline: NIW D=64, n=1.25e6, K=32, one GPU, no collective"
+        r["roofline"] = niw_roofline(n, D, r["K_t"], r["sweep_kernel_ms"], work)
+        legs["c3_shard"] = r
+        # 1 -> 8 projection: a rank of the 8-GPU run does this step plus two all-reduces over xGMI (2K Int64 occupancies, then 2K packed
+        # Float64 rows = 1.1 MB); their time is NOT measured here (one GPU per box) -- the assumption is stated, the driver's SCALE run decides
+        assumed = 0.05
+        legs["shard8_projection"] = {"one_gpu_ms_per_step": one_gpu_ms, "shard_ms_per_step": r["ms_per_step"],
+                                     "assumed_allreduce_ms_per_step": assumed,
+                                     "projected_speedup_1_to_8": one_gpu_ms / (r["ms_per_step"] + assumed),
+                                     "speedup_without_collectives": one_gpu_ms / r["ms_per_step"],
+                                     "note": "projection from one GPU; the two all-reduces per step are assumed, not measured"}
+        del X
+        torch.cuda.empty_cache()
+    if "c4" in want:
+        n, Dm = 10 ** 6, 1000
+        X, y = gpu_multinomial_mixture(torch, n, Dm, K, 100, DATA_SEED)
+        prior = host.multinomial_hyper(np.ones(Dm, np.float32))          # test/save_load_test/multinomial_params.jl:24
+        r, _ = steady_state(pkg, host, torch, pkg.PRIOR_MULT, prior, X, y, K, 50)
+        r["workload"] = "C4: Multinomial D=1000 N=1e6 K=32 (100 trials per point), one GPU"
+        bytes_alg = 4.0 * n * Dm + 16.0 * n
+        t = (r["sweep_kernel_ms"] + r["stats_kernels_ms"]) * 1e-3
+        tr_sweep, src = pmc_traffic("mult", "mult_sweep")
+        tr_stats, _ = pmc_traffic("mult", "mult_stats")
+        r["roofline"] = {"kernel": "mult_sweep_u8_kernel + sort + mult_stats_u8_kernel (one pass over the points each)", "bound": "hbm",
+                         "achieved": bytes_alg / t / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": bytes_alg / t / 1e9 / PEAK_HBM_GBPS,
+                         "algorithmic_bytes_per_step": bytes_alg,
+                         "traffic": (tr_sweep + tr_stats) if (tr_sweep and tr_stats) else None, "traffic_source": src,
+                         "sweep_only_GBps": bytes_alg / (r["sweep_kernel_ms"] * 1e-3) / 1e9}
+        legs["c4"] = r
+        del X
+        torch.cuda.empty_cache()
+    if "c5_shard" in want:
+        n, Dh = 625000, 256
+        X, y = gpu_gaussian_mixture(host, torch, n, Dh, K, 100.0, DATA_SEED)
+        prior = host.niw_hyperparams(1.0, np.zeros(Dh), Dh + 3, np.eye(Dh))
+        r, work = steady_state(pkg, host, torch, pkg.PRIOR_NIW, prior, X, y, K, 30)
+        r["workload"] = "what each of 8 GPUs holds of C5: NIW D=256, n=6.25e5, K=32, one GPU, no collective"
+        r["roofline"] = niw_roofline(n, Dh, r["K_t"], r["sweep_kernel_ms"], work)
+        legs["c5_shard"] = r
+        del X
+        torch.cuda.empty_cache()
+    return legs
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_as_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus} (launch `--nproc-per-node {args.gpus}`, or call bench.py without a launcher)")
     import torch
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if args.share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the product has no CPU fallback)")
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
 
     from __graft_entry__ import load_package
     pkg = load_package()
     host = importlib.import_module("dpmmsubclusters_jl_amd.host")
-    from dpmmsubclusters_jl_amd.host.comm import default_comm
+    from dpmmsubclusters_jl_amd.host.comm import TorchDistComm
     from dpmmsubclusters_jl_amd import binding
 
     N, D, K = int(args.points), args.dim, args.clusters
-    comm = default_comm()
+    comm = TorchDistComm(device=local_rank) if world > 1 else host.LocalComm()
     lo, hi = (N * rank) // world, (N * (rank + 1)) // world
-    data_seed, sampler_seed, burnout = 12345, 123456789, 20
-    X, y = host.gaussian_mixture_shard(N, D, K, 100.0, data_seed, lo, hi)
+    X, y = host.gaussian_mixture_shard(N, D, K, 100.0, DATA_SEED, lo, hi)
 
     prior = host.niw_hyperparams(1.0, np.zeros(D), D + 3, np.eye(D))      # default prior, dp-parallel-sampling.jl:272-274
-    wk = pkg.Worker(pkg.PRIOR_NIW, D, hi - lo, first_index=lo, device=local_rank, seed=sampler_seed)
+    wk = pkg.Worker(pkg.PRIOR_NIW, D, hi - lo, first_index=lo, device=local_rank, seed=SAMPLER_SEED)
     wk.upload_points(X)
-    s = host.DPMMSampler(wk, prior, 10.0, N, sampler_seed, burnout=burnout, comm=comm)
-    sub0 = 1 + (np.random.default_rng([data_seed, 7, rank]).integers(0, 2, hi - lo))
+    s = host.DPMMSampler(wk, prior, ALPHA, N, SAMPLER_SEED, burnout=BURNOUT, comm=comm)
+    sub0 = 1 + (np.random.default_rng([DATA_SEED, 7, rank]).integers(0, 2, hi - lo))
     s.start_from_labels(y, sub0, K)
     # burn-in (setup, untimed): `burnout` sweeps until every cluster's split/merge gate is open
-    for _ in range(burnout + 1):
+    for _ in range(BURNOUT + 1):
         s.group_step(False, False)
-    # ... and `settle` more (setup, untimed): the first ~100 steps of a process run ~2 % slower than all later ones (clock / power state of a
-    # GPU that was idle during the upload; measured with --warmup 5 against --warmup 100 on one box: 338.9 against 344.4 it/s over the same
-    # 30 timed steps, 200-step blocks afterwards 345-347 either way) -- the metric is the steady-state rate of a long run
-    settle = 100
-    for _ in range(settle):
+    # ... and `--settle` more (setup, untimed; reported as `settle`): the first ~100 steps of a process run ~2 % slower than all later ones
+    # (clock / power state of a GPU that was idle during the upload) -- the metric is the steady-state rate of a long run
+    for _ in range(args.settle):
         s.group_step(False, False)
     for _ in range(args.warmup):
         s.group_step(False, False)
 
     def fence():
         torch.cuda.synchronize()
+        wk.sync()
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
+
+    def max_over_ranks(vals):
+        if dist is None:
+            return [float(v) for v in vals]
+        t = torch.tensor(vals, dtype=torch.float64, device="cpu" if args.share_gpu else f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t]
 
     def timed_block(nsteps, collect=None):
         fence()
@@ -113,19 +338,16 @@ def main():
             if collect is not None:
                 collect()
         fence()
-        el = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([el], dtype=torch.float64, device=f"cuda:{local_rank}")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        return el
+        return max_over_ranks([time.perf_counter() - t0])[0]
 
     n_local = hi - lo
-    sweep_ms, stats_ms, ks, work = [], [], [], []
+    sweep_ms, stats_ms, ks, work, comm_ms = [], [], [], [], []
 
     def collect():     # HIP events on the library's stream (the stream is idle here: stats were read back)
         a, b = wk.last_kernel_ms()
         sweep_ms.append(a); stats_ms.append(b); ks.append(s.K)
+        if world > 1:
+            comm_ms.append(wk.last_comm_ms())
 
     t_before = dict(s.timers)
     wk.last_sweep_work()              # clear the device's work counters: they add up over the timed launches and are read once afterwards
@@ -141,20 +363,10 @@ def main():
     avg_sweep_ms = float(np.mean(sweep_ms))
     exe = float(np.mean([w["executed_flops"] for w in work]))
     achieved = flops_alg / (avg_sweep_ms * 1e-3) / 1e12
-    # HBM bytes per launch of the sweep kernel: PMC counters need rocprofv3, so the figure comes from the committed counter summary of
-    # THIS command on this round's final build (profiles/, collected by scripts/collect_profiles.sh: FETCH_SIZE doubled per the gfx950
-    # note of MI355X_MICROARCH.md + WRITE_SIZE, in KiB) -- only for the configuration it was collected on, else null
-    traffic, traffic_source = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "r02f_bench_pmc_summary.json")
-    if N == 10 ** 7 and D == 64 and world == 1 and os.path.exists(pmc_file):
-        try:
-            pm = json.load(open(pmc_file))
-            for name, c in pm.items():
-                if "niw_sweep_direct_kernel" in name:
-                    traffic = (2.0 * c["FETCH_SIZE"]["median"] + c["WRITE_SIZE"]["median"]) * 1024.0
-                    traffic_source = "profiles/r02f_bench_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, median per launch)"
-        except (OSError, ValueError, KeyError):
-            traffic = None
+    # HBM bytes per launch of the sweep kernel: PMC counters need rocprofv3, so the figure comes from the counter summary that
+    # scripts/collect_profiles.sh wrote for THIS command (profiles/latest_bench_pmc_summary.json); it carries the hash of the kernel
+    # sources it was collected on and is not quoted for any other build or configuration
+    traffic, traffic_source = (pmc_traffic("bench", "niw_sweep_direct_kernel") if (N == 10 ** 7 and D == 64 and world == 1) else (None, None))
     roof = {"kernel": "niw_sweep_direct_kernel<4,4,2,true>" if D <= 64 else "niw_sweep_kernel", "bound": "mfma",
             "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": exe / (avg_sweep_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
@@ -163,7 +375,7 @@ def main():
             "executed_tflops": exe / (avg_sweep_ms * 1e-3) / 1e12, "pruning_factor": flops_alg / exe if exe else None,
             "algorithmic_frac": achieved / PEAK_F32_MFMA_TFLOPS,
             "work_per_launch": {k: float(np.mean([w[k] for w in work])) for k in ("wave_tiles", "full_evals", "screens16", "tail_pairs")},
-            "stats_kernels_ms": float(np.mean(stats_ms))}
+            "stats_kernels_ms": float(np.mean(stats_ms)), "kernel_source_tag": kernel_source_tag()}
 
     # same kernel, same process, screening off: every cluster is evaluated in full (labels are bit-identical by construction)
     if not args.no_dense:
@@ -178,6 +390,7 @@ def main():
                      "dense_frac": d_fl / (d_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                      "dense_algorithmic_tflops": flops_alg / (d_ms * 1e-3) / 1e12})
 
+    info = wk.comm_info()
     out = {
         "metric": "Gibbs iterations/sec, N=10M D=64 NIW" if (N == 10 ** 7 and D == 64) else f"Gibbs iterations/sec, N={N} D={D} NIW",
         "value": args.steps / elapsed,
@@ -185,6 +398,7 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
+        "settle": args.settle,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
         "scaling": "strong",
@@ -192,9 +406,16 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"NIW D={D} N={N} synthetic GMM, {K} true components, K_t={k_mean:.1f} live clusters, "
-                               f"alpha=10, default NIW prior, steady state after {burnout + 1} burn-in + {settle} settling sweeps",
-                   "points_per_gpu": n_local, "parallelism": f"points sharded over {world} GPU(s), 1 RCCL all-reduce of packed suff-stats per statistics pass"},
+                               f"alpha=10, default NIW prior, steady state after {BURNOUT + 1} burn-in + {args.settle} settling sweeps",
+                   "points_per_gpu": n_local,
+                   "parallelism": f"points sharded over {world} GPU(s); per statistics pass one all-reduce of the 2K Int64 occupancies and "
+                                  f"one of the packed Float64 suff-stat rows inside libdpmmhip.so"},
         "roofline": roof,
+        "comm": {"world": info["world"], "transport": info["transport"], "occupancy_allreduce_bytes": info["counts_bytes"],
+                 "rows_allreduce_bytes": info["rows_bytes"], "allreduces_since_attach": info["allreduces"],
+                 "occupancy_allreduce_ms": float(np.mean([c[0] for c in comm_ms])) if comm_ms else None,
+                 "rows_allreduce_ms": float(np.mean([c[1] for c in comm_ms])) if comm_ms else None,
+                 "note": "HIP events on the ctx stream around each all-reduce of the timed steps (rank 0); they include waiting for the slowest rank"},
         "blocks": {"it_per_s": block_rates, "min": float(np.min(block_rates)) if block_rates else None,
                    "median": float(np.median(block_rates)) if block_rates else None, "max": float(np.max(block_rates)) if block_rates else None},
         "host_ms_per_step": {k: 1e3 * (t_after[k] - t_before[k]) / args.steps for k in t_after},
@@ -204,21 +425,20 @@ def main():
 
     # growth trajectory (each NIW config also from init_clusters=1): same data, same context, fresh model
     if not args.no_growth:
-        g = host.DPMMSampler(wk, prior, 10.0, N, sampler_seed, burnout=burnout, comm=comm)
+        g = host.DPMMSampler(wk, prior, ALPHA, N, SAMPLER_SEED, burnout=BURNOUT, comm=comm)
         g.init_first_clusters(1)
         fence()
-        it, _, lik, kh = g.run_model(args.growth_iters)
+        it, nmi, _, kh = g.run_model(args.growth_iters, gt=None)
         fence()
-        tot = float(np.sum(it))
-        if dist is not None:
-            t = torch.tensor([tot, float(np.sum(it[-25:-5]))], dtype=torch.float64, device=f"cuda:{local_rank}")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            tot, last = float(t[0]), float(t[1])
-        else:
-            last = float(np.sum(it[-25:-5]))
+        tot, last = max_over_ranks([float(np.sum(it)), float(np.sum(it[-25:-5]))])
+        wk.set_ground_truth_range(y - 1, K)
+        gn, _ = importlib.import_module("dpmmsubclusters_jl_amd.host.sampler").nmi_vi_from_contingency(comm.reduce_counts(wk.contingency(g.K)))
         out["growth"] = {"init_clusters": 1, "iterations": args.growth_iters, "it_per_s_whole_run": args.growth_iters / tot,
-                         "it_per_s_last20_nonfinal": 20.0 / last, "K_history": [int(k) for k in kh],
-                         "log_posterior_final": g.log_posterior()}
+                         "it_per_s_last20_nonfinal": 20.0 / last, "K_history": [int(k) for k in kh], "K_final": int(kh[-1]), "K_true": K,
+                         "log_posterior_final": g.log_posterior(), "nmi_final_vs_generator": float(gn)}
+
+    if rank == 0 and world == 1 and not args.no_legs:
+        out["legs"] = run_legs(args, pkg, host, torch, out["ms_per_step"])
 
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         from oracle import cpu_baseline
@@ -228,9 +448,10 @@ def main():
                                                    p["logdet"].astype(np.float32), logw.astype(np.float32), loglr.astype(np.float32), N,
                                                    seconds=args.cpu_seconds)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     wk.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 
