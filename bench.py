@@ -162,8 +162,8 @@ def steady_state(pkg, host, torch, prior_kind, prior, X, y, K, steps, settle=30,
     """Upload a device-resident matrix, adopt the generator's labels, burn in until the gates are open, time `steps` group_steps."""
     N, D = X.shape
     wk = pkg.Worker(prior_kind, D, N, first_index=0, device=0, seed=seed)
+    torch.cuda.synchronize()            # X was produced on torch's stream; the library copies on its own
     wk.upload_points_device(X.data_ptr(), X.stride(0))
-    torch.cuda.synchronize()
     s = host.DPMMSampler(wk, prior, ALPHA, N, seed, burnout=BURNOUT)
     s.start_from_labels(y, 1 + np.random.default_rng([DATA_SEED, 7]).integers(0, 2, N), K)
     for _ in range(BURNOUT + 1 + settle):

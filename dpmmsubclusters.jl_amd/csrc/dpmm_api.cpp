@@ -151,6 +151,7 @@ struct dpmm_ctx {
     float opt_margin = 50.f;
     int opt_prio = 1;
     int opt_queue_rounds = -1;
+    int opt_ball = 1;
     int opt_tail = 1, opt_prescreen = -1, opt_ordered = 1, opt_force_f32 = 0, opt_trace = 0, opt_ref_const = 0;
     int64_t opt_stats_items = 0;
     int opt_stats_groups = 0;
@@ -314,7 +315,7 @@ static int ensure_capacity(dpmm_ctx *c, int K) {
         HIPCHK(c, hipMalloc(&c->d_Rp, sizeof(float) * 3 * cap * NP * 256));
         HIPCHK(c, hipMalloc(&c->d_mup, sizeof(float) * 3 * cap * 16 * c->NB));
         HIPCHK(c, hipMalloc(&c->d_lam, sizeof(float) * cap));
-        HIPCHK(c, hipMalloc(&c->d_tail, sizeof(float) * 16 * (cap + 1)));
+        HIPCHK(c, hipMalloc(&c->d_tail, sizeof(float) * (16 * (cap + 2) + 16 * cap)));      // pair records | per-cluster ball records
         HIPCHK(c, hipMalloc(&c->d_mdist, sizeof(float) * (size_t)cap * cap));
     } else {
         const size_t NT = (size_t)(c->ldx + 15) / 16, NRB = (size_t)(3 * cap + 15) / 16;
@@ -837,6 +838,7 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
             a.mdist = c->d_mdist;
             a.tail = (c->have_tail && !c->predictive) ? c->d_tail : nullptr;
             a.tail_g = ((c->D - 4) % 16) / 4;
+            a.ball = c->opt_ball;
             a.order = (!table && c->have_perm && !no_order) ? c->sb.perm : nullptr;
             a.order_total = c->sb.perm_total;
             a.work = table ? nullptr : c->d_work;
@@ -1812,6 +1814,7 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
         case DPMM_OPT_LOGLIK_REF_CONST: c->opt_ref_const = value != 0; return DPMM_OK;
         case DPMM_OPT_WAVE_PRIO: c->opt_prio = value != 0; return DPMM_OK;
         case DPMM_OPT_SWEEP_QUEUE_ROUNDS: c->opt_queue_rounds = value < 0 ? -1 : (int)value; return DPMM_OK;
+        case DPMM_OPT_BALL_SCREEN: c->opt_ball = value != 0; return DPMM_OK;
         case DPMM_OPT_SWEEP_GRID:
             if (value > 0) c->sweep_grid = (int)std::min<double>(std::min<double>(value, (double)c->sweep_grid_max), (double)std::max<int64_t>(1, c->ntiles));   // scratch is sized for the default
             return DPMM_OK;

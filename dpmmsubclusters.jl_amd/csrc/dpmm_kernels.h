@@ -35,8 +35,9 @@ struct NiwSweepArgs {
     uint32_t epoch;
     int final_argmax;
     float screen_margin;      // > 0: skip clusters whose a_k is provably below (reference - margin) for a whole wave (NIW, D in 17..64)
-    const float *tail;        // [ceil(K/2)][16][2] tail-screen records of the cluster-level matrices, pairs interleaved (null: no tail screen)
+    const float *tail;        // [ceil(K/2)][16][2] tail-screen records of the cluster-level matrices, pairs interleaved, then [K][16] ball records (null: no tail screen)
     int tail_g;               // row group (lane >> 4) whose x registers of the last block hold features D-4..D-1
+    int ball;                 // 1: cluster-per-lane ball test in front of the per-point tail screen (records [K][16] behind the pair records)
     const float *lam;         // [K] lower bounds of lambda_min(Sigma_k^-1) (null: no scalar pre-screen)
     const float *mdist;       // [K][K] distances between the cluster means
     int screen_lds;           // set by the launcher: screen operands of all K clusters are staged in LDS

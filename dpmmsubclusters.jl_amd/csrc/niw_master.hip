@@ -667,6 +667,22 @@ __global__ void niw_master_pack_kernel(const double *__restrict__ Yall, const fl
             }
             tail[e] = v;
         }
+        // per-cluster records of the ball test, as in niw_pack_kernel: { m | T row 0 | T11 T12 T13 T22 | T23 T33 |T|_F cst }
+        float *ball = tail + 32 * NPR;
+        for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)K * 16; e += (int64_t)gridDim.x * blockDim.x) {
+            const int q = (int)(e & 15), k = (int)(e >> 4);
+            const int64_t j = 3 * (int64_t)k;
+            const int tr[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3}, tc[10] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3};
+            float v;
+            if (q < 4) v = mu_draw[j * DPm + f0 + q];
+            else if (q < 14) v = (float)Yall[j * DPm * DPm + (int64_t)(f0 + tc[q - 4]) * DPm + (f0 + tr[q - 4])];
+            else if (q == 14) {
+                float f = 0.f;
+                for (int i = 0; i < 10; ++i) { const float t = (float)Yall[j * DPm * DPm + (int64_t)(f0 + tc[i]) * DPm + (f0 + tr[i])]; f = __builtin_fmaf(t, t, f); }
+                v = sqrtf(f) * 1.00001f;
+            } else v = -0.5f * logdet_sigma[j] + logf(wts[k]);
+            ball[e] = v;
+        }
     }
 }
 

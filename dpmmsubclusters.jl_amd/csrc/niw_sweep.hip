@@ -124,6 +124,75 @@ __device__ __forceinline__ unsigned tail_pair_far(const TailPair &T, const f32x4
     return fa | fb;
 }
 
+// Ball test in front of the per-point tail screen, lane = CLUSTER.  The wave's points sit in a ball around the tail mean c of its
+// reference cluster (radius r = max_i |x_i,tail - c|, one wave reduction); for every x in that ball
+//   |T_k (x - m_k)| >= |T_k (c - m_k)| - |T_k|_F r,
+// so cst_k - 1/2 max(0, |T_k (c - m_k)| - |T_k|_F r)^2 bounds a_k for ALL points of the wave at once: lane j tests cluster j against the
+// wave's lowest threshold -- ~60 instructions for 64 clusters, where the per-point screen spends ~22 per PAIR of clusters.  On
+// label-homogeneous waves of well-separated data it clears nearly every cluster; whatever is left goes to the per-point screens.
+// Per-cluster records [K][16] = { m0 m1 m2 m3 | T00 T01 T02 T03 | T11 T12 T13 T22 | T23 T33 |T|_F cst } behind the pair records.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, false));
+}
+// max / min over the 64 lanes (NaN operands are ignored by v_max / v_min), wave-uniform result
+__device__ __forceinline__ float wave_max_f32(float v) {
+    v = fmaxf(v, dpp_f32<0xB1, 0xF>(v));       // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_f32<0x4E, 0xF>(v));       // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_f32<0x141, 0xF>(v));      // row_half_mirror
+    v = fmaxf(v, dpp_f32<0x140, 0xF>(v));      // row_mirror: every lane holds the maximum of its row of 16
+    v = fmaxf(v, dpp_f32<0x142, 0xA>(v));      // row_bcast15 -> rows 1, 3
+    v = fmaxf(v, dpp_f32<0x143, 0xC>(v));      // row_bcast31 -> rows 2, 3: lane 63 holds the maximum
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_min_f32(float v) {
+    v = fminf(v, dpp_f32<0xB1, 0xF>(v));
+    v = fminf(v, dpp_f32<0x4E, 0xF>(v));
+    v = fminf(v, dpp_f32<0x141, 0xF>(v));
+    v = fminf(v, dpp_f32<0x140, 0xF>(v));
+    v = fminf(v, dpp_f32<0x142, 0xA>(v));
+    v = fminf(v, dpp_f32<0x143, 0xC>(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__host__ __device__ __forceinline__ const float *ball_records(const float *tail, int K) { return tail + 32 * ((K + 1) >> 1); }
+struct BallWave { f32x4 c; float r, thr; bool ok; };
+// the wave's ball: centre = tail mean of reference cluster k0 (wave-uniform), radius over the valid lanes, lowest threshold.  Not usable
+// (ok = false) when a point's tail features or threshold are not finite: such a point is covered by no ball, and the per-point
+// screens keep every cluster for it.
+__device__ __forceinline__ BallWave ball_of_wave(const float *tail, int K, int k0, const f32x4 &xt, float my_thr, bool valid) {
+    typedef const float __attribute__((address_space(4))) *cfp4;
+    const cfp4 P = (cfp4)(ball_records(tail, K) + 16 * (size_t)k0);
+    BallWave B;
+    B.c = (f32x4){P[0], P[1], P[2], P[3]};
+    const f32x4 dx = xt - B.c;
+    float r2 = dx.x * dx.x;
+    r2 = __builtin_fmaf(dx.y, dx.y, r2); r2 = __builtin_fmaf(dx.z, dx.z, r2); r2 = __builtin_fmaf(dx.w, dx.w, r2);
+    B.ok = __ballot(valid && !(r2 < INFINITY && my_thr == my_thr)) == 0ull;
+    B.r = __builtin_amdgcn_sqrtf(wave_max_f32(valid ? r2 : 0.f)) * 1.00001f;      // (v_sqrt_f32, 1 ulp: covered by the slack factors)
+    B.thr = wave_min_f32(my_thr);
+    return B;
+}
+// lanes j: cluster base + j is below the wave's lowest threshold for every point of the ball
+__device__ __forceinline__ unsigned long long ball_far(const float *tail, int K, int base, int lane, const BallWave &B) {
+    const int j = base + lane;
+    const float *rec = ball_records(tail, K) + 16 * (size_t)(j < K ? j : 0);
+    const f32x4 m = *reinterpret_cast<const f32x4 *>(rec), t0 = *reinterpret_cast<const f32x4 *>(rec + 4);
+    const f32x4 t1 = *reinterpret_cast<const f32x4 *>(rec + 8), t2 = *reinterpret_cast<const f32x4 *>(rec + 12);
+    const f32x4 d = B.c - m;
+    const float y3 = t2.y * d.w;
+    const float y2 = __builtin_fmaf(t1.w, d.z, t2.x * d.w);
+    const float y1 = __builtin_fmaf(t1.x, d.y, __builtin_fmaf(t1.y, d.z, t1.z * d.w));
+    const float y0 = __builtin_fmaf(t0.x, d.x, __builtin_fmaf(t0.y, d.y, __builtin_fmaf(t0.z, d.z, t0.w * d.w)));
+    float qn = y3 * y3;
+    qn = __builtin_fmaf(y2, y2, qn); qn = __builtin_fmaf(y1, y1, qn); qn = __builtin_fmaf(y0, y0, qn);
+    float dn = d.x * d.x;
+    dn = __builtin_fmaf(d.y, d.y, dn); dn = __builtin_fmaf(d.z, d.z, dn); dn = __builtin_fmaf(d.w, d.w, dn);
+    // rounding slack: |T d| is computed to ~1e-6 |T|_F |d|; the margin of the screen (tens of nats) dwarfs it anyway
+    const float lb = fmaxf(__builtin_fmaf(-t2.z, __builtin_fmaf(1e-5f, __builtin_amdgcn_sqrtf(dn), B.r), __builtin_amdgcn_sqrtf(qn) * 0.99999f), 0.f);
+    const float ub = __builtin_fmaf(-0.5f * lb, lb, t2.w);
+    return __ballot(j < K && ub < B.thr);
+}
+
 template <int NB, int NG, int CH>
 struct QuadEval {
     using C = NiwCfg<NB, NG, CH>;
@@ -1017,6 +1086,8 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                 }
             }
             const float my_thr = valid ? my_best - A.screen_margin : INFINITY;
+            BallWave ball; ball.ok = false;
+            if (tailscr && A.ball) ball = ball_of_wave(A.tail, K, k0, xt, my_thr, valid);
             // far mask: lane j owns cluster (chunk base + j).  The wave is reduced to its worst case first
             // (r_max = farthest point from mu_k0, best_min = lowest reference value), so one vector step tests 64 clusters:
             //   a_k(x) <= cst_k - lam_k/2 (||mu_k - mu_k0|| - r_max)_+^2  <  best_min - margin   for every point x of the wave.
@@ -1115,15 +1186,15 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                 };
                 f32x4 acc[NG];
                 if (tailscr) {
+                    if (ball.ok) cand &= ~ball_far(A.tail, K, base, lane, ball);
                     // pairs (2p, 2p+1) of the chunk that still hold a candidate; far clusters lose their candidate bit
-                    const int p0 = base >> 1, p1 = (min(K, base + 64) + 1) >> 1;
-                    for (int pr = p0; pr < p1; ++pr) {
-                        const int sh = 2 * pr - base;
-                        const unsigned bits2 = (unsigned)(cand >> sh) & 3u;
-                        if (!bits2) continue;
+                    for (unsigned long long pend = cand; pend;) {
+                        const int sh = __builtin_ctzll(pend) & ~1;            // (base is a multiple of 64: pair 2p sits at an even bit)
+                        const int pr = (base + sh) >> 1;
+                        pend &= ~(3ull << sh);
                         ++nw_tail;
 #ifdef DPMM_STAMPS
-                        N_tail += __builtin_popcount(bits2);
+                        N_tail += __builtin_popcount((unsigned)(cand >> sh) & 3u);
 #endif
                         cand &= ~((unsigned long long)tail_pair_far(tail_load_pair(A.tail, pr), xt, my_thr) << sh);
                     }
@@ -1404,6 +1475,22 @@ __global__ void niw_pack_kernel(const float *__restrict__ R, const float *__rest
             else if (q < 14) v = mu[j * D + f0 + (q - 10)];
             else if (q == 14) v = cst[3 * k];
             tail[e] = v;
+        }
+        // per-cluster records of the ball test (lane = cluster): { m | T row 0 | T11 T12 T13 T22 | T23 T33 |T|_F cst }
+        float *ball = tail + 32 * NPR;
+        for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)K * 16; e += (int64_t)gridDim.x * blockDim.x) {
+            const int q = (int)(e & 15), k = (int)(e >> 4);
+            const size_t j = src_row(slot, 3 * k);
+            const int tr[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3}, tc[10] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3};
+            float v;
+            if (q < 4) v = mu[j * D + f0 + q];
+            else if (q < 14) v = R[j * TRI + tri_off(D, f0 + tr[q - 4], f0 + tc[q - 4])];
+            else if (q == 14) {
+                float f = 0.f;
+                for (int i = 0; i < 10; ++i) { const float t = R[j * TRI + tri_off(D, f0 + tr[i], f0 + tc[i])]; f = __builtin_fmaf(t, t, f); }
+                v = sqrtf(f) * 1.00001f;
+            } else v = cst[3 * k];
+            ball[e] = v;
         }
     }
 }

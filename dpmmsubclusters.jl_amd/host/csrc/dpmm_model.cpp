@@ -897,7 +897,7 @@ HAPI int dpmmh_model_set_option(dpmmh_model *m, int option, double value) {
         case DPMMH_OPT_HARD_CLUSTERING: m->hard = value != 0; return 0;
         case DPMMH_OPT_F32_QUIRK: m->f32_quirk = value != 0; return 0;
         case DPMMH_OPT_THREADS: m->nthreads = std::max(1, (int)value); return 0;
-        case DPMMH_OPT_SHARE_WORK: m->share_work = value != 0; return 0;
+        case DPMMH_OPT_SHARE_WORK: if (value != 0) return m->fail("DPMMH_OPT_SHARE_WORK: owner-computes sharing of the master's work is not implemented"); m->share_work = false; return 0;
         case DPMMH_OPT_SPIN_US: Pool::get().set_spin_us((int)value); return 0;
         case DPMMH_OPT_PREWAKE: m->prewake = value != 0; return 0;
         case DPMMH_OPT_DRAW_AHEAD: m->opt_draw_ahead = value != 0; return 0;
@@ -1020,7 +1020,10 @@ HAPI int64_t dpmmh_model_get(dpmmh_model *m, const char *field, void *out, int64
     const int K = m->K, D = m->D;
     const size_t DD = (size_t)D * D;
     if (f == "K") return emit<int64_t>(out, cap, {(int64_t)K});
-    if (f == "counters") return emit<int64_t>(out, cap, {(int64_t)m->epoch, (int64_t)m->draw_epoch, (int64_t)m->split_epoch, (int64_t)m->merge_epoch, m->bad_total, m->bad_steps, 0, 0});
+    // counters[6]: bit 0 = the device master is on but the NEXT draws of this chain come from the host (the step that just ended accepted a
+    // merge and rebuilt the merged slots there): host and device draws use different streams, so a resumed run has to know
+    if (f == "counters") return emit<int64_t>(out, cap, {(int64_t)m->epoch, (int64_t)m->draw_epoch, (int64_t)m->split_epoch, (int64_t)m->merge_epoch, m->bad_total, m->bad_steps,
+                                                         (int64_t)((m->kind == DPMMH_PRIOR_NIW && m->use_dev() && !m->dev_state) ? 1 : 0), 0});
     if (f == "timers") return emit<double>(out, cap, std::vector<double>(m->timers, m->timers + 16));
     auto rows_d = [&](const std::vector<double> &src, size_t w) {
         std::vector<double> v((size_t)3 * K * w);
@@ -1129,6 +1132,10 @@ HAPI int dpmmh_model_set(dpmmh_model *m, const char *field, const void *in, int6
         if (!need(64)) return -1;
         const int64_t *c = (const int64_t *)in;
         m->epoch = (uint32_t)c[0]; m->draw_epoch = (uint32_t)c[1]; m->split_epoch = (uint32_t)c[2]; m->merge_epoch = (uint32_t)c[3];
+        if ((c[6] & 1) && m->dev_state) {       // saved right after an accepted merge: the running chain made its next draws on the host
+            if (m->pull_state()) return -1;
+            m->dev_state = false;
+        }
         return 0;
     }
     if (K < 1) return m->fail("set K first");
@@ -1187,6 +1194,9 @@ HAPI int dpmmh_debug_merge_log_hr(dpmmh_model *m, double *out) {
     std::vector<std::pair<int, int>> pairs;
     std::vector<double> lhr;
     m->merge_candidates(pairs);
+    // as check_and_merge: the pooled statistics come from the device when it holds the current rows, else from the host's (pulled if stale)
+    m->dev_pairs_ok = m->use_dev() && m->dev_state && !m->host_rows;
+    if (!m->dev_pairs_ok) if (int rc = m->pull_rows()) return rc;
     m->merge_ratios(pairs, lhr);
     for (size_t p = 0; p < pairs.size(); ++p) out[(size_t)pairs[p].first * K + pairs[p].second] = lhr[p];
     return 0;

@@ -67,6 +67,7 @@ enum {
     DPMM_OPT_MULT_NO_U8 = 11,     /* Multinomial: do not keep the byte copy of integer data in [0, 255] (before upload; A/B and tests) */
     DPMM_OPT_SWEEP_GRID = 12,     /* workgroups of the sweep kernels, at most the default (compute units x resident workgroups per unit); experiments */
     DPMM_OPT_SWEEP_QUEUE_ROUNDS = 13, /* D <= 64 NIW sweep: the last rounds of tiles handed out through the queue; -1 (default): rounds / 8, at least 2, none below 4 rounds; 0: static schedule */
+    DPMM_OPT_BALL_SCREEN = 14,        /* 1 (default): cluster-per-lane ball test in front of the per-point 4-row tail screen of the NIW sweeps; 0: per-point screens only (same labels) */
     DPMM_OPT_WAVE_PRIO = 10       /* 0 / 1: NIW sweep (D <= 64) lowers a wave's issue priority while it streams matrix instructions and
                                      raises it in its scalar / VALU phases (default 1) */
 };

@@ -97,8 +97,8 @@ enum {
     DPMMH_OPT_HARD_CLUSTERING = 1,   /* global_params.jl:8  -- argmax label assignment in every sweep */
     DPMMH_OPT_F32_QUIRK = 2,         /* utils.jl:66-72: accumulate log_multivariate_gamma in Float32 like the reference */
     DPMMH_OPT_THREADS = 3,           /* host threads for the per-distribution maths */
-    DPMMH_OPT_SHARE_WORK = 4,        /* world > 1: 1 = every rank computes the distributions of "its" slots only and the
-                                        results are exchanged (worker.allgather); 0 = every rank computes everything */
+    DPMMH_OPT_SHARE_WORK = 4,        /* reserved (owner-computes sharing of the master's work across ranks): 0 = every rank computes everything
+                                        (the only scheme built); any other value is refused */
     DPMMH_OPT_SPIN_US = 5,           /* bounded polling of the pool's workers between back-to-back parallel regions (default 150) */
     DPMMH_OPT_PREWAKE = 6,           /* 1 (default): wake the pool ~60 us before the statistics of a step are expected back */
     DPMMH_OPT_DEVICE_MASTER = 8,     /* NIW posteriors / factorisations / draws on the worker's device: 1 on, 0 off, -1 (default) for D >= 64 */

@@ -91,3 +91,52 @@ def test_resume_continues_the_chain_with_the_device_master(host, tmp_path):
     res, *_ = host.resume_from_checkpoint(model.checkpoints[0], x, 10, verbose=False)
     assert np.array_equal(res.labels, r[0]) and np.array_equal(res.labels_subcluster, model.labels_subcluster)
     assert res.sampler.K == model.sampler.K and np.array_equal(res.sampler.weights, model.sampler.weights)
+
+
+def test_resume_right_after_an_accepted_merge_with_the_device_master(pkg, host, tmp_path):
+    """An accepted merge rebuilds the merged slots on the HOST, so the running chain makes its next parameter draws there (host
+    streams, not the device's): a checkpoint written at the end of that very step must resume onto the same draws (ADVICE r2;
+    counters[6] carries the flag).  The run starts from 12 initial clusters on 3 components so that merges are accepted; the
+    checkpoint is taken at the first iteration whose cluster count dropped."""
+    import importlib
+    ckpt = importlib.import_module("dpmmsubclusters_jl_amd.host.checkpoint")
+    D, N = 64, 6000
+    X, y = host.gaussian_mixture_shard(N, D, 3, 100.0, 77, 0, N)
+    prior = host.niw_hyperparams(1.0, np.zeros(D), D + 3, np.eye(D))
+
+    def chain():
+        wk = pkg.Worker(pkg.PRIOR_NIW, D, N, device=0, seed=3)
+        wk.upload_points(X)
+        s = host.DPMMSampler(wk, prior, 10.0, N, 3, burnout=3)
+        s.init_first_clusters(12)
+        return wk, s
+
+    wk, s = chain()
+    ks, merge_at, saved = [s.K], None, None
+    for it in range(1, 41):
+        s.group_step(False, False)
+        ks.append(s.K)
+        if merge_at is None and ks[-1] < ks[-2]:
+            merge_at = it
+            flag = int(s.model.get("counters")[6])
+            saved = ckpt.sampler_state(s) if hasattr(ckpt, "sampler_state") else {f: s.model.get(f) for f in ckpt._STATE_FIELDS}
+            saved["K"] = s.K
+            saved["labels"], saved["sub"] = wk.get_labels()
+        if merge_at is not None and it == merge_at + 3:
+            break
+    assert merge_at is not None, ks
+    assert flag & 1, "the step that accepted a merge leaves the next draws to the host"
+    want = wk.get_labels()
+    wk.close()
+    # resume from the state saved right after the merge step
+    wk2, s2 = chain()
+    wk2.set_labels(saved["labels"], saved["sub"])
+    s2.model.set("K", saved["K"])
+    wk2.set_num_clusters(saved["K"])
+    for f in ckpt._STATE_FIELDS:
+        s2.model.set(f, saved[f])
+    for _ in range(3):
+        s2.group_step(False, False)
+    got = wk2.get_labels()
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    wk2.close()
