@@ -89,7 +89,7 @@ HOST_ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_voi
 
 # dpmm_set_option keys (include/dpmm_hip.h)
 MASTER_NSCALARS = 8          # DPMM_MASTER_NSCALARS
-OPT_SCREEN_MARGIN, OPT_TAIL_SCREEN, OPT_PRESCREEN, OPT_ORDERED_SWEEP, OPT_MULT_FORCE_F32, OPT_STATS_ITEMS, OPT_STATS_GROUPS, OPT_TRACE_SLOW, OPT_LOGLIK_REF_CONST, OPT_WAVE_PRIO, OPT_MULT_NO_U8, OPT_SWEEP_GRID, OPT_SWEEP_QUEUE_ROUNDS, OPT_BALL_SCREEN = range(1, 15)
+OPT_SCREEN_MARGIN, OPT_TAIL_SCREEN, OPT_PRESCREEN, OPT_ORDERED_SWEEP, OPT_MULT_FORCE_F32, OPT_STATS_ITEMS, OPT_STATS_GROUPS, OPT_TRACE_SLOW, OPT_LOGLIK_REF_CONST, OPT_WAVE_PRIO, OPT_MULT_NO_U8, OPT_SWEEP_GRID, OPT_SWEEP_QUEUE_ROUNDS, OPT_BALL_SCREEN, OPT_KERNEL_TIMING = range(1, 16)
 
 
 class DpmmError(RuntimeError):
@@ -169,7 +169,10 @@ class Worker:
     """One shard of the points on one GPU: the stand-in for one reference worker process
     (the functions a worker runs on its `localpart`s, src/local_clusters_actions.jl)."""
 
-    def __init__(self, prior, D, n_local, first_index=0, device=0, seed=0):
+    def __init__(self, prior, D, n_local, first_index=0, device=0, seed=0, timing=True):
+        """timing: record HIP events around the sweep / statistics / all-reduces (last_kernel_ms, last_comm_ms).  On by default for
+        this binding (tests, benches, scripts read them); the library's own default -- and what fit / dp_parallel use -- is off:
+        each event costs ~5 us between two kernels."""
         self._lib = load_library()
         self._h = ctypes.c_void_p()
         self.prior, self.D, self.n, self.first_index, self.device = prior, int(D), int(n_local), int(first_index), device
@@ -178,6 +181,9 @@ class Worker:
             raise DpmmError(rc, self._lib.dpmm_last_error(None).decode())
         self.K = 0
         self.packed_stride = int(self._lib.dpmm_packed_stride(self._h))
+        self.timing = bool(timing)
+        if timing:
+            self._chk(self._lib.dpmm_set_option(self._h, OPT_KERNEL_TIMING, 7.0))
 
     def _chk(self, rc):
         if rc != 0:
@@ -547,7 +553,15 @@ class Worker:
     def stream(self):
         return self._lib.dpmm_stream(self._h)
 
+    def set_timing(self, on):
+        """on: False / True (sweep + statistics + all-reduce events) or a bit mask 1 (sweep kernel) | 2 (statistics) | 4 (all-reduces)."""
+        mask = 7 if on is True else int(on)
+        self.timing = mask != 0
+        self.set_option(OPT_KERNEL_TIMING, float(mask))
+
     def last_kernel_ms(self):
+        if not self.timing:
+            raise RuntimeError("kernel timing is off for this Worker (timing=False / set_timing(False)): no events were recorded")
         a = ctypes.c_float(); b = ctypes.c_float()
         self._chk(self._lib.dpmm_last_kernel_ms(self._h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value

@@ -128,6 +128,9 @@ struct dpmm_ctx {
     std::unordered_map<uint32_t, int> apairs_index;         // (slot_i << 16 | slot_j) -> record
     std::vector<uint8_t> apairs_dirty;                      // [slot] statistics of the slot changed since the job was launched
     std::vector<int32_t> apairs_req;                        // request of dpmm_niw_master_pairs_ahead, consumed by the next dpmm_step_master_device
+    bool noise_pending = false;                             // dpmm_niw_master_draw asked for the next normals; launched behind the sweep (noise_flush)
+    uint32_t noise_pend_epoch = 0;
+    int noise_pend_nmat = 0;
     bool noise_inflight = false, noise_valid = false;       // main stream has not waited for ev_noise yet / d_Y[noise_buf] holds the normals of noise_epoch
     uint32_t noise_epoch = 0;
     int noise_nmat = 0, noise_buf = 0;
@@ -152,6 +155,7 @@ struct dpmm_ctx {
     int opt_prio = 1;
     int opt_queue_rounds = -1;
     int opt_ball = 1;
+    int opt_timing = 0;                // bit 0 / 1 / 2: HIP events around the sweep kernel / the statistics pass / the all-reduces (dpmm_last_kernel_ms, dpmm_last_comm_ms)
     int opt_tail = 1, opt_prescreen = -1, opt_ordered = 1, opt_force_f32 = 0, opt_trace = 0, opt_ref_const = 0;
     int64_t opt_stats_items = 0;
     int opt_stats_groups = 0;
@@ -247,8 +251,10 @@ static inline bool comm_attached(const dpmm_ctx *c) { return c->comm != nullptr 
 // caller's host function (dpmm_comm_init_host: device -> pinned, synchronise, fn, pinned -> device).
 static int comm_allreduce(dpmm_ctx *c, void *dbuf, size_t count, int kind) {
     const bool f64 = kind == 1;
-    if (!c->ev_comm[0]) for (auto &e : c->ev_comm) HIPCHK(c, hipEventCreate(&e));
-    HIPCHK(c, hipEventRecord(c->ev_comm[2 * kind], c->stream));
+    if (c->opt_timing & 4) {
+        if (!c->ev_comm[0]) for (auto &e : c->ev_comm) HIPCHK(c, hipEventCreate(&e));
+        HIPCHK(c, hipEventRecord(c->ev_comm[2 * kind], c->stream));
+    }
     if (c->comm) {
         Rccl &r = rccl();
         const int rc = r.AllReduce(dbuf, dbuf, count, f64 ? kNcclFloat64 : kNcclInt64, kNcclSum, c->comm, c->stream);
@@ -270,8 +276,8 @@ static int comm_allreduce(dpmm_ctx *c, void *dbuf, size_t count, int kind) {
         if (rc != 0) return fail(c, DPMM_ECOMM, "host all-reduce callback failed (code " + std::to_string(rc) + ")");
         HIPCHK(c, launch_copy_bytes(dbuf, c->h_red, bytes, c->stream));
     }
-    HIPCHK(c, hipEventRecord(c->ev_comm[2 * kind + 1], c->stream));
-    c->have_comm_ev[kind] = true;
+    if (c->opt_timing & 4) HIPCHK(c, hipEventRecord(c->ev_comm[2 * kind + 1], c->stream));
+    c->have_comm_ev[kind] = (c->opt_timing & 4) != 0;
     c->comm_bytes[kind] = (int64_t)count * 8;
     ++c->comm_calls;
     return DPMM_OK;
@@ -399,8 +405,10 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
     const size_t nbmax = 2 * DPMM_MAX_CLUSTERS;
     CHK_CREATE(hipMalloc(&c->sb.tile_hist, sizeof(int32_t) * nbmax * (size_t)std::max(1, c->nt_sort)));
     CHK_CREATE(hipMalloc(&c->sb.tile_cnt, sizeof(int32_t) * nbmax * (size_t)std::max(1, c->nt_sort)));
-    CHK_CREATE(hipMalloc(&c->sb.dirty, (size_t)std::max(1, c->nt_sort)));
-    CHK_CREATE(hipMemset(c->sb.dirty, 0, (size_t)std::max(1, c->nt_sort)));
+    CHK_CREATE(hipMalloc(&c->sb.fast_total, sizeof(int32_t) * nbmax));
+    CHK_CREATE(hipMemset(c->sb.fast_total, 0, sizeof(int32_t) * nbmax));
+    CHK_CREATE(hipMalloc(&c->sb.ticket, sizeof(unsigned)));
+    CHK_CREATE(hipMemset(c->sb.ticket, 0, sizeof(unsigned)));
     CHK_CREATE(hipMalloc(&c->sb.bin_total, sizeof(int32_t) * nbmax));
     CHK_CREATE(hipMalloc(&c->sb.bin_start, sizeof(int32_t) * (nbmax + 1)));
     CHK_CREATE(hipMalloc(&c->sb.item_start, sizeof(int32_t) * (nbmax + 1)));
@@ -423,7 +431,7 @@ int dpmm_destroy(dpmm_ctx *c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     free_params(c);
     hipFree(c->dX); hipFree(c->dX8); hipFree(c->dbins); hipFree(c->d_gt); hipFree(c->d_cont);
-    hipFree(c->sb.tile_hist); hipFree(c->sb.tile_cnt); hipFree(c->sb.dirty); hipFree(c->sb.bin_total); hipFree(c->sb.bin_start); hipFree(c->sb.item_start);
+    hipFree(c->sb.tile_hist); hipFree(c->sb.tile_cnt); hipFree(c->sb.fast_total); hipFree(c->sb.ticket); hipFree(c->sb.bin_total); hipFree(c->sb.bin_start); hipFree(c->sb.item_start);
     hipFree(c->sb.perm); hipFree(c->sb.bin_sel); hipFree(c->sb.perm_total); hipFree(c->d_small); hipFree(c->d_proj); hipFree(c->d_vals); hipFree(c->d_smart);
     hipFree(c->d_m0); hipFree(c->d_psi_lo); hipFree(c->d_pairs);
     for (int i = 0; i < 2; ++i) { hipFree(c->d_Y[i]); hipFree(c->d_ld_sigma[i]); hipFree(c->d_mu_draw[i]); }
@@ -811,6 +819,7 @@ int dpmm_numa_node(dpmm_ctx *c) {
     return node;
 }
 
+static int noise_flush(dpmm_ctx *c);
 static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table, int64_t table_stride) {
     if (!c->have_points || !c->have_params) return fail(c, DPMM_ESTATE, "sweep needs points and parameters");
     HIPCHK(c, hipSetDevice(c->device));
@@ -819,7 +828,7 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
         if (!c->work_zeroed) HIPCHK(c, hipMemsetAsync(c->d_work, 0, sizeof(unsigned long long) * DPMM_WORK_SLOTS, c->stream));   // usually done by the pack kernel
         c->work_zeroed = false;
     }
-    if (!table) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    if (!table && (c->opt_timing & 1)) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     if (c->prior == DPMM_PRIOR_NIW) {
         NiwSweepArgs a{};
         a.X = c->dX; a.ldx = c->ldx; a.n = c->n; a.first_index = c->first; a.ntiles = c->ntiles; a.K = c->K;
@@ -865,8 +874,9 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
         else HIPCHK(c, launch_mult_sweep(a, c->sweep_grid, c->stream));
     }
     if (!table) {
-        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-        c->have_sweep_ev = true;
+        if (c->master) if (int rc = noise_flush(c)) return rc;
+        if (c->opt_timing & 1) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+        c->have_sweep_ev = (c->opt_timing & 1) != 0;
         c->have_labels = true;
     }
     return DPMM_OK;
@@ -1002,7 +1012,7 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
     if (!c->have_points || !c->have_labels || c->K < 1) return fail(c, DPMM_ESTATE, "suffstats need points, labels and parameters (K)");
     HIPCHK(c, hipSetDevice(c->device));
     const int nbins = 2 * c->K;
-    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    if (c->opt_timing & 2) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     if (idx) {
         c->h_sel.assign(nbins, 0);
         for (int j = 0; j < n_idx; ++j) {
@@ -1024,30 +1034,38 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
     a.max_items = (int)((c->n + c->chunk - 1) / c->chunk) + nbins;
     a.range_groups = c->opt_stats_groups;
     a.sb = c->sb; a.slabs = c->d_slabs; a.slab_stride = c->slab_stride; a.out = c->d_out; a.packed_stride = c->packed_stride; a.row_off = c->d_row_off; a.inv_off = c->d_inv_off;
-    if (c->n > 0) {
-        HIPCHK(c, launch_sort_by_bin(c->dbins, c->n, nbins, c->sb, c->stream));
-    } else {
-        HIPCHK(c, hipMemsetAsync(c->sb.bin_total, 0, sizeof(int32_t) * nbins, c->stream));
-    }
-    if (with_reset) {
-        // reset_bad_clusters! (local_clusters_actions.jl:501-516) on the device: occupancies (summed over the ranks) -> flags ->
-        // sub-labels of flagged clusters re-drawn -> histogram again (skipped on the device when nothing was flagged)
+    if (with_reset && c->n > 0) {
+        // reset_bad_clusters! (local_clusters_actions.jl:501-516) on the device, four launches: histogram (+ running bin totals) ->
+        // [occupancies summed over the ranks] -> flags + sub-labels of flagged clusters re-drawn + touched tiles re-counted -> scan + starts
+        // -> scatter.  The flags live right behind the packed rows, so that rows + flags reach the master in one copy.
+        HIPCHK(c, launch_step_hist(c->dbins, c->n, nbins, c->sb, c->stream));
         const long long *gc = nullptr;
         if (comm_attached(c)) {
-            HIPCHK(c, launch_widen_counts(c->sb.bin_total, c->d_counts64, nbins, c->stream));
+            HIPCHK(c, launch_widen_counts(c->sb.fast_total, c->d_counts64, nbins, c->stream));
             if (int rc = comm_allreduce(c, c->d_counts64, nbins, /*kind=*/0)) return rc;
             gc = c->d_counts64;
         }
-        // the flags live right behind the packed rows, so that rows + flags reach the master in one copy
         uint8_t *flags = reinterpret_cast<uint8_t *>(c->d_out) + sizeof(double) * (size_t)nbins * (size_t)c->packed_stride;
+        HIPCHK(c, launch_step_reset(c->dbins, c->n, c->first, nbins, c->sb, gc, flags, c->K, c->seed, reset_epoch, c->stream));
+        HIPCHK(c, launch_step_scan_scatter(c->dbins, a, c->stream));
+    } else {
         if (c->n > 0) {
-            HIPCHK(c, launch_reset_sub_flagged(c->dbins, c->n, c->first, c->sb.bin_total, gc, c->sb.dirty, flags, c->K, c->seed, reset_epoch, c->stream));
-            HIPCHK(c, launch_sort_by_bin(c->dbins, c->n, nbins, c->sb, c->stream, flags + c->K));
+            HIPCHK(c, launch_sort_by_bin(c->dbins, c->n, nbins, c->sb, c->stream));
         } else {
+            HIPCHK(c, hipMemsetAsync(c->sb.bin_total, 0, sizeof(int32_t) * nbins, c->stream));
+        }
+        if (with_reset) {       // a rank without points: its occupancies are zero, the flags come from the other ranks' counts
+            const long long *gc = nullptr;
+            if (comm_attached(c)) {
+                HIPCHK(c, launch_widen_counts(c->sb.bin_total, c->d_counts64, nbins, c->stream));
+                if (int rc = comm_allreduce(c, c->d_counts64, nbins, /*kind=*/0)) return rc;
+                gc = c->d_counts64;
+            }
+            uint8_t *flags = reinterpret_cast<uint8_t *>(c->d_out) + sizeof(double) * (size_t)nbins * (size_t)c->packed_stride;
             HIPCHK(c, launch_bad_flags(c->sb.bin_total, gc, c->K, flags, c->stream));
         }
+        HIPCHK(c, launch_sort_finish(c->dbins, a, c->stream));
     }
-    HIPCHK(c, launch_sort_finish(c->dbins, a, c->stream));
     c->have_perm = c->n > 0;
     if (c->prior == DPMM_PRIOR_NIW) HIPCHK(c, launch_niw_stats(a, c->stream));
     else if (c->x_u8) HIPCHK(c, launch_mult_stats_u8(a, c->dX8, c->ld8, c->stream));
@@ -1057,8 +1075,8 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
         // local_clusters_actions.jl:206-254; aggregate_suff_stats); N counts travel as Float64 integers (exact below 2^53)
         if (int rc = comm_allreduce(c, c->d_out, (size_t)nbins * (size_t)c->packed_stride, /*kind=*/1)) return rc;
     }
-    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-    c->have_stats_ev = true;
+    if (c->opt_timing & 2) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    c->have_stats_ev = (c->opt_timing & 2) != 0;
     return DPMM_OK;
 }
 
@@ -1139,6 +1157,15 @@ static int noise_join(dpmm_ctx *c) {
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_noise, 0));
         c->noise_inflight = false;
     }
+    return DPMM_OK;
+}
+// the deferred launch of the normals of the next draws (requested by dpmm_niw_master_draw): into the draw buffer that is NOT in use
+static int noise_flush(dpmm_ctx *c) {
+    if (!c->noise_pending) return DPMM_OK;
+    c->noise_pending = false;
+    HIPCHK(c, launch_niw_master_noise(c->ma, c->noise_pend_nmat, c->noise_pend_epoch, c->d_Y[c->draw_cur ^ 1], c->stream2));
+    HIPCHK(c, hipEventRecord(c->ev_noise, c->stream2));
+    c->noise_inflight = true; c->noise_valid = true; c->noise_epoch = c->noise_pend_epoch; c->noise_nmat = c->noise_pend_nmat; c->noise_buf = c->draw_cur ^ 1;
     return DPMM_OK;
 }
 // the normals of the draws of `epoch` for K clusters are in d_Y[buf] (generated ahead on stream2)
@@ -1244,7 +1271,7 @@ int dpmm_niw_master_setup(dpmm_ctx *c, double kappa, double nu, const double *m,
         HIPCHK(c, hipMalloc(&c->d_dslots, sizeof(int32_t) * DPMM_MAX_CLUSTERS));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream2));
-    c->spec_inflight = false; c->spec_valid = false; c->noise_inflight = false; c->noise_valid = false;
+    c->spec_inflight = false; c->spec_valid = false; c->noise_inflight = false; c->noise_valid = false; c->noise_pending = false;
     c->apairs_inflight = false; c->apairs_valid = false;
     c->master = true;
     return DPMM_OK;
@@ -1273,6 +1300,7 @@ int dpmm_step_master_device(dpmm_ctx *c, uint32_t reset_epoch, const int32_t *sl
         if (slots[k] < 0 || slots[k] >= DPMM_MAX_CLUSTERS) return fail(c, DPMM_EINVAL, "slot out of range");
         top = std::max(top, slots[k] + 1);
     }
+    if (int rc = noise_flush(c)) return rc;
     if (int rc = master_capacity(c, top, draw_epoch ? K : 0)) return rc;
     if (int rc = spec_join(c)) return rc;                  // unused early draws of the last call still read the factors
     c->spec_valid = false;
@@ -1396,6 +1424,7 @@ int dpmm_niw_master_draw(dpmm_ctx *c, uint32_t epoch, int K, const int32_t *slot
     HIPCHK(c, hipSetDevice(c->device));
     for (int k = 0; k < K; ++k)
         if (slot_of_cluster[k] < 0 || slot_of_cluster[k] >= c->master_slots) return fail(c, DPMM_EINVAL, "slot without a posterior on the device");
+    if (int rc = noise_flush(c)) return rc;
     if (int rc = ensure_capacity(c, K)) return rc;
     if (int rc = master_capacity(c, 0, K)) return rc;
     // small inputs through a pinned block of their own (the posterior's block may still be read by its caller)
@@ -1423,12 +1452,9 @@ int dpmm_niw_master_draw(dpmm_ctx *c, uint32_t epoch, int K, const int32_t *slot
     // The normals of the NEXT draws (epoch + 1, a few clusters more than now for the splits in between) into the other buffer, on the
     // second stream: they depend on nothing the master decides, and run beside the sweep instead of in front of it.  Whoever draws
     // with another epoch, or for more clusters, generates its own.
-    {
-        const int kgen = std::min(K + 4, c->master_K);
-        HIPCHK(c, launch_niw_master_noise(c->ma, 3 * kgen, epoch + 1, c->d_Y[c->draw_cur ^ 1], c->stream2));
-        HIPCHK(c, hipEventRecord(c->ev_noise, c->stream2));
-        c->noise_inflight = true; c->noise_valid = true; c->noise_epoch = epoch + 1; c->noise_nmat = 3 * kgen; c->noise_buf = c->draw_cur ^ 1;
-    }
+    // (launched by noise_flush right AFTER the sweep kernel of this step: the launch and its event record would otherwise sit on the
+    // host's critical path between the master's decisions and the sweep launch)
+    c->noise_pending = true; c->noise_pend_epoch = epoch + 1; c->noise_pend_nmat = 3 * std::min(K + 4, c->master_K);
     c->work_zeroed = true;
     c->have_screen_prep = false;     // (the K > 64 far mask needs the raw factors: not built on this path; the tail screen is)
     c->K = K;
@@ -1815,6 +1841,12 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
         case DPMM_OPT_WAVE_PRIO: c->opt_prio = value != 0; return DPMM_OK;
         case DPMM_OPT_SWEEP_QUEUE_ROUNDS: c->opt_queue_rounds = value < 0 ? -1 : (int)value; return DPMM_OK;
         case DPMM_OPT_BALL_SCREEN: c->opt_ball = value != 0; return DPMM_OK;
+        case DPMM_OPT_KERNEL_TIMING:
+            c->opt_timing = (int)value & 7;
+            if (!(c->opt_timing & 1)) c->have_sweep_ev = false;
+            if (!(c->opt_timing & 2)) c->have_stats_ev = false;
+            if (!(c->opt_timing & 4)) c->have_comm_ev[0] = c->have_comm_ev[1] = false;
+            return DPMM_OK;
         case DPMM_OPT_SWEEP_GRID:
             if (value > 0) c->sweep_grid = (int)std::min<double>(std::min<double>(value, (double)c->sweep_grid_max), (double)std::max<int64_t>(1, c->ntiles));   // scratch is sized for the default
             return DPMM_OK;

@@ -109,8 +109,6 @@ hipError_t launch_init_labels(int32_t *bins, int64_t n, int64_t first_index, int
 // step statistics: flags[k] = 1 when cluster k has an empty sub-cluster (counts: [2K] Int64, global), flags[K] = any;
 // then re-draw the sub-labels of flagged clusters (reset_bad_clusters_worker!)
 hipError_t launch_bad_flags(const int32_t *bin_total, const long long *global_counts, int K, uint8_t *flags, hipStream_t s);
-hipError_t launch_reset_sub_flagged(int32_t *bins, int64_t n, int64_t first, const int32_t *bin_total, const long long *global_counts, uint8_t *dirty,
-                                    uint8_t *flags, int K, uint64_t seed, uint32_t epoch, hipStream_t s);
 hipError_t launch_widen_counts(const int32_t *src, long long *dst, int n, hipStream_t s);
 hipError_t launch_gather_rows(float *dst, int64_t ld_dst, const float *src, int64_t ld_src, const int32_t *slot, int rows, int D, hipStream_t s);
 hipError_t launch_bins_from_i64(int32_t *bins, const int64_t *labels, const int64_t *sub, int64_t n, hipStream_t s);
@@ -131,7 +129,8 @@ constexpr int SORT_TILE = 2048;  // points per sorting wave
 struct SortBufs {
     int32_t *tile_hist;   // [nbins][ntiles_sort] exclusive prefix over the tiles of a bin (written by the scan from tile_cnt)
     int32_t *tile_cnt;    // [nbins][ntiles_sort] points of bin b in tile t (written by the histogram)
-    uint8_t *dirty;       // [ntiles_sort] tile holds points whose sub-label the reset rewrote: the conditional second pass re-counts only these
+    int32_t *fast_total;  // [nbins] running bin totals of the per-step histogram (integer atomics), cleared by scan_starts_kernel
+    unsigned *ticket;     // [1] workgroups of scan_starts_kernel that are done (the last one computes the starts and clears it)
     int32_t *bin_total;   // [nbins]
     int32_t *bin_start;   // [nbins + 1]
     int32_t *perm;        // [n]
@@ -140,12 +139,13 @@ struct SortBufs {
     int32_t *perm_total;  // [1] number of points placed in perm by the last sort (== n when every label was in range)
 };
 
-// `only_if` (nullable): device byte; when it is 0 the pass is skipped (tile_hist / bin_total keep their contents); when it is set the
-// pass is the SECOND one of a step and re-counts only the tiles marked in `dirty` (the first pass clears the marks); the byte must be
-// preceded by the nbins / 2 per-cluster reset flags (only_if[-nbins/2 + k]): bins of unflagged clusters are not re-scanned
-hipError_t launch_sort_by_bin(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s, const uint8_t *only_if = nullptr);
+hipError_t launch_sort_by_bin(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s);
+hipError_t launch_step_hist(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s);
+hipError_t launch_step_reset(int32_t *bins, int64_t n, int64_t first, int nbins, const SortBufs &b, const long long *global_counts, uint8_t *flags,
+                             int K, uint64_t seed, uint32_t epoch, hipStream_t s);
 struct StatsArgs;
 hipError_t launch_sort_finish(const int32_t *bins, const StatsArgs &a, hipStream_t s);
+hipError_t launch_step_scan_scatter(const int32_t *bins, const StatsArgs &a, hipStream_t s);
 
 struct StatsArgs {
     const float *X;

@@ -122,49 +122,7 @@ hipError_t launch_bad_flags(const int32_t *bin_total, const long long *global_co
     hipLaunchKernelGGL(bad_flags_kernel, dim3(1), dim3(256), 0, s, bin_total, global_counts, K, flags);
     return hipGetLastError();
 }
-// ... and the reset itself, with the flag computation folded in (one launch less per step): every workgroup derives the flags from the
-// 2K occupancies in LDS, workgroup 0 publishes them (flags[0..K], read by the conditional re-histogram and returned to the master
-// with the statistics); nothing else happens when no cluster is flagged.
-__global__ __launch_bounds__(256) void reset_sub_flagged_kernel(int32_t *bins, int64_t n, int64_t first, const int32_t *__restrict__ bin_total,
-                                                                const long long *__restrict__ global_counts, uint8_t *__restrict__ dirty,
-                                                                uint8_t *__restrict__ flags, int K, uint64_t seed, uint32_t epoch) {
-    __shared__ uint8_t f[DPMM_MAX_CLUSTERS_K];
-    __shared__ int any;
-    if (threadIdx.x == 0) any = 0;
-    __syncthreads();
-    for (int k = threadIdx.x; k < K; k += blockDim.x) {
-        const long long a = global_counts ? global_counts[2 * k] : (long long)bin_total[2 * k];
-        const long long b = global_counts ? global_counts[2 * k + 1] : (long long)bin_total[2 * k + 1];
-        const int bad = (a == 0 || b == 0) ? 1 : 0;
-        f[k] = (uint8_t)bad;
-        if (bad) atomicOr(&any, 1);
-        if (blockIdx.x == 0) flags[k] = (uint8_t)bad;
-    }
-    __syncthreads();
-    if (blockIdx.x == 0 && threadIdx.x == 0) flags[K] = (uint8_t)any;
-    if (!any) return;
-    auto one = [&](int64_t i, int bv) {
-        const int z = bv >> 1;
-        if ((unsigned)z < (unsigned)K && f[z]) {
-            const Philox4 r = philox4x32_10(seed, (uint64_t)(first + i), epoch, STREAM_RESET);
-            bins[i] = 2 * z + (int)(r.v[0] & 1u);
-            if (dirty) dirty[i / SORT_TILE] = 1;       // the second histogram pass of the step re-counts this tile only
-        }
-    };
-    // four labels per load (the pass reads every label to find the few of the flagged clusters)
-    const int64_t n4 = n >> 2;
-    const int4 *b4 = reinterpret_cast<const int4 *>(bins);
-    for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < n4; j += (int64_t)gridDim.x * blockDim.x) {
-        const int4 v = b4[j];
-        one(4 * j, v.x); one(4 * j + 1, v.y); one(4 * j + 2, v.z); one(4 * j + 3, v.w);
-    }
-    for (int64_t i = 4 * n4 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) one(i, bins[i]);
-}
-hipError_t launch_reset_sub_flagged(int32_t *bins, int64_t n, int64_t first, const int32_t *bin_total, const long long *global_counts, uint8_t *dirty,
-                                    uint8_t *flags, int K, uint64_t seed, uint32_t epoch, hipStream_t s) {
-    hipLaunchKernelGGL(reset_sub_flagged_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, n, first, bin_total, global_counts, dirty, flags, K, seed, epoch);
-    return hipGetLastError();
-}
+// (the reset itself, with the flag computation folded in, is reset_recount_kernel in suffstats.hip: it re-counts the sort tiles it touches)
 __global__ void widen_counts_kernel(const int32_t *__restrict__ src, long long *__restrict__ dst, int n) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = (long long)src[i];
 }

@@ -30,12 +30,11 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------ sort
+// `fast_total` (nullable): [nbins] running bin totals, added with integer atomics (order-independent, exact) -- the per-step pass needs the
+// sub-cluster occupancies before anything is scanned (bad-cluster flags); scan_starts_kernel clears them again for the next pass.
 __global__ __launch_bounds__(64) void hist_kernel(const int32_t *__restrict__ bins, int64_t n, int nbins, int nt,
-                                                  int32_t *__restrict__ tile_hist, const uint8_t *__restrict__ only_if, uint8_t *__restrict__ dirty) {
+                                                  int32_t *__restrict__ tile_hist, int32_t *__restrict__ fast_total) {
     extern __shared__ int cnt[];
-    if (only_if) {      // second pass of a step: only when a cluster was reset, and only the tiles the reset touched
-        if (!*only_if || (dirty && !dirty[blockIdx.x])) return;
-    } else if (dirty && threadIdx.x == 0) dirty[blockIdx.x] = 0;
     const int lane = threadIdx.x;
     for (int b = lane; b < nbins; b += 64) cnt[b] = 0;
     __syncthreads();
@@ -92,16 +91,70 @@ __global__ __launch_bounds__(64) void hist_kernel(const int32_t *__restrict__ bi
         }
     }
     __syncthreads();
-    for (int b = lane; b < nbins; b += 64) tile_hist[(int64_t)b * nt + blockIdx.x] = cnt[b];
+    for (int b = lane; b < nbins; b += 64) {
+        const int v = cnt[b];
+        tile_hist[(int64_t)b * nt + blockIdx.x] = v;
+        if (fast_total && v) atomicAdd(&fast_total[b], v);
+    }
+}
+
+// reset_bad_clusters! (src/local_clusters_actions.jl:501-516) + the re-count it makes necessary, one wave per sort tile: every workgroup
+// derives the bad-cluster flags from the 2K sub-cluster occupancies (`totals`: this shard's, or `global_counts`: summed over the ranks),
+// workgroup 0 publishes them (flags[0..K), flags[K] = any); a tile that holds points of a flagged cluster re-draws their sub-labels
+// (Philox keyed by the global point index, as reset_sub_flagged_kernel) and re-counts itself -- tile_cnt of every other tile stays what
+// the histogram wrote.  Replaces reset + second histogram + second scan of the per-step pass (three launches fewer).
+__global__ __launch_bounds__(64) void reset_recount_kernel(int32_t *__restrict__ bins, int64_t n, int64_t first, int nbins, int nt,
+                                                           const int32_t *__restrict__ totals, const long long *__restrict__ global_counts,
+                                                           int32_t *__restrict__ tile_cnt, uint8_t *__restrict__ flags, int K, uint64_t seed, uint32_t epoch) {
+    extern __shared__ int cnt[];                 // [nbins] counters | [K] flag bytes
+    uint8_t *f = reinterpret_cast<uint8_t *>(cnt + nbins);
+    const int lane = threadIdx.x;
+    bool anyl = false;
+    for (int k = lane; k < K; k += 64) {
+        const long long a = global_counts ? global_counts[2 * k] : (long long)totals[2 * k];
+        const long long b = global_counts ? global_counts[2 * k + 1] : (long long)totals[2 * k + 1];
+        const bool bad = a == 0 || b == 0;
+        f[k] = bad ? 1 : 0;
+        anyl = anyl || bad;
+        if (blockIdx.x == 0) flags[k] = bad ? 1 : 0;
+    }
+    const bool any = __any(anyl);
+    if (blockIdx.x == 0 && lane == 0) flags[K] = any ? 1 : 0;
+    if (!any) return;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
+    constexpr int PER = SORT_TILE / 64;
+    int v[PER];
+    bool hit = false;
+#pragma unroll
+    for (int it = 0; it < PER; ++it) {
+        const int64_t i = base + it * 64 + lane;
+        v[it] = i < n ? bins[i] : -1;
+        const int z = v[it] >> 1;
+        hit = hit || (v[it] >= 0 && z < K && f[z]);
+    }
+    if (!__any(hit)) return;
+    for (int b = lane; b < nbins; b += 64) cnt[b] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < PER; ++it) {
+        const int64_t i = base + it * 64 + lane;
+        int bv = v[it];
+        const int z = bv >> 1;
+        if (bv >= 0 && z < K && f[z]) {
+            const Philox4 r = philox4x32_10(seed, (uint64_t)(first + i), epoch, STREAM_RESET);
+            bv = 2 * z + (int)(r.v[0] & 1u);
+            bins[i] = bv;
+        }
+        if ((unsigned)bv < (unsigned)nbins) atomicAdd(&cnt[bv], 1);
+    }
+    __syncthreads();
+    for (int b = lane; b < nbins; b += 64) tile_cnt[(int64_t)b * nt + blockIdx.x] = cnt[b];
 }
 
 // exclusive scan over the tiles of one bin (in place) + bin total
-__global__ __launch_bounds__(256) void scan_tiles_kernel(const int32_t *__restrict__ tile_cnt, int32_t *__restrict__ tile_hist, int nt,
-                                                         int32_t *__restrict__ bin_total, const uint8_t *__restrict__ only_if) {
-    __shared__ int part[256];
-    // second pass of a step (only_if = the "any cluster reset" byte, the per-cluster flags sit in front of it): the reset moved points
-    // between the two bins of the flagged clusters only -- the rows of every other bin are unchanged
-    if (only_if && (!*only_if || !only_if[(int)(blockIdx.x >> 1) - (int)(gridDim.x >> 1)])) return;
+__device__ __forceinline__ void scan_one_bin(const int32_t *__restrict__ tile_cnt, int32_t *__restrict__ tile_hist, int nt,
+                                             int32_t *__restrict__ bin_total, int *part) {
     const int32_t *src = tile_cnt + (int64_t)blockIdx.x * nt;
     int32_t *row = tile_hist + (int64_t)blockIdx.x * nt;
     const int per = (nt + 255) / 256;
@@ -125,12 +178,16 @@ __global__ __launch_bounds__(256) void scan_tiles_kernel(const int32_t *__restri
     }
     if (threadIdx.x == 255) bin_total[blockIdx.x] = part[255];
 }
+__global__ __launch_bounds__(256) void scan_tiles_kernel(const int32_t *__restrict__ tile_cnt, int32_t *__restrict__ tile_hist, int nt,
+                                                         int32_t *__restrict__ bin_total) {
+    __shared__ int part[256];
+    scan_one_bin(tile_cnt, tile_hist, nt, bin_total, part);
+}
 
 // bin_start[b] = sum_{b'<b} total ; item_start[b] = sum_{b'<b} ceil(sel*total / chunk)
-__global__ __launch_bounds__(256) void starts_kernel(const int32_t *__restrict__ bin_total, const uint8_t *__restrict__ bin_sel,
-                                                     int nbins, int chunk, int32_t *__restrict__ bin_start,
-                                                     int32_t *__restrict__ item_start, int32_t *__restrict__ perm_total) {
-    __shared__ int pa[256], pb[256];
+__device__ __forceinline__ void starts_body(const int32_t *bin_total, const uint8_t *__restrict__ bin_sel,
+                                            int nbins, int chunk, int32_t *__restrict__ bin_start,
+                                            int32_t *__restrict__ item_start, int32_t *__restrict__ perm_total, int *pa, int *pb) {
     const int per = (nbins + 255) / 256;
     const int lo = threadIdx.x * per, hi = min(lo + per, nbins);
     int sa = 0, sb = 0;
@@ -163,6 +220,33 @@ __global__ __launch_bounds__(256) void starts_kernel(const int32_t *__restrict__
         item_start[nbins] = pb[255];
         if (perm_total) *perm_total = pa[255];
     }
+}
+__global__ __launch_bounds__(256) void starts_kernel(const int32_t *__restrict__ bin_total, const uint8_t *__restrict__ bin_sel,
+                                                     int nbins, int chunk, int32_t *__restrict__ bin_start,
+                                                     int32_t *__restrict__ item_start, int32_t *__restrict__ perm_total) {
+    __shared__ int pa[256], pb[256];
+    starts_body(bin_total, bin_sel, nbins, chunk, bin_start, item_start, perm_total, pa, pb);
+}
+// scan of every bin + the starts in ONE launch: the workgroup that finishes last (a ticket counter) sees every bin total and computes
+// bin_start / item_start; it also clears the ticket and the histogram's running totals for the next pass.
+__global__ __launch_bounds__(256) void scan_starts_kernel(const int32_t *__restrict__ tile_cnt, int32_t *__restrict__ tile_hist, int nt,
+                                                          int32_t *bin_total, const uint8_t *__restrict__ bin_sel, int chunk,
+                                                          int32_t *__restrict__ bin_start, int32_t *__restrict__ item_start,
+                                                          int32_t *__restrict__ perm_total, int32_t *__restrict__ fast_total, unsigned *ticket) {
+    __shared__ int part[256], pb[256];
+    __shared__ unsigned last;
+    const int nbins = (int)gridDim.x;
+    scan_one_bin(tile_cnt, tile_hist, nt, bin_total, part);
+    __threadfence();                                    // bin_total[blockIdx.x] is visible device-wide before the ticket is taken
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == (unsigned)(nbins - 1) ? 1u : 0u;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();                                    // (acquire: the other workgroups' totals, not a stale line of this unit's cache)
+    if (threadIdx.x == 0) *ticket = 0u;
+    if (fast_total) for (int b = threadIdx.x; b < nbins; b += 256) fast_total[b] = 0;
+    __syncthreads();
+    starts_body(bin_total, bin_sel, nbins, chunk, bin_start, item_start, perm_total, part, pb);
 }
 
 __global__ __launch_bounds__(64) void scatter_kernel(const int32_t *__restrict__ bins, int64_t n, int nbins, int nt,
@@ -220,11 +304,25 @@ __global__ __launch_bounds__(64) void scatter_kernel(const int32_t *__restrict__
     }
 }
 
-hipError_t launch_sort_by_bin(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s, const uint8_t *only_if) {
+hipError_t launch_sort_by_bin(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s) {
     const int nt = (int)((n + SORT_TILE - 1) / SORT_TILE);
     if (nt == 0) return hipSuccess;
-    hipLaunchKernelGGL(hist_kernel, dim3(nt), dim3(64), nbins * sizeof(int), s, bins, n, nbins, nt, b.tile_cnt, only_if, b.dirty);
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(nbins), dim3(256), 0, s, b.tile_cnt, b.tile_hist, nt, b.bin_total, only_if);
+    hipLaunchKernelGGL(hist_kernel, dim3(nt), dim3(64), nbins * sizeof(int), s, bins, n, nbins, nt, b.tile_cnt, (int32_t *)nullptr);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(nbins), dim3(256), 0, s, b.tile_cnt, b.tile_hist, nt, b.bin_total);
+    return hipGetLastError();
+}
+// The sort of the per-step pass in four launches (n > 0): histogram (+ running totals) -> [caller: all-reduce of the totals] ->
+// launch_step_reset (flags, sub-label reset, re-count of the touched tiles) -> launch_step_scan_scatter (scan + starts, scatter).
+hipError_t launch_step_hist(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s) {
+    const int nt = (int)((n + SORT_TILE - 1) / SORT_TILE);
+    hipLaunchKernelGGL(hist_kernel, dim3(nt), dim3(64), nbins * sizeof(int), s, bins, n, nbins, nt, b.tile_cnt, b.fast_total);
+    return hipGetLastError();
+}
+hipError_t launch_step_reset(int32_t *bins, int64_t n, int64_t first, int nbins, const SortBufs &b, const long long *global_counts, uint8_t *flags,
+                             int K, uint64_t seed, uint32_t epoch, hipStream_t s) {
+    const int nt = (int)((n + SORT_TILE - 1) / SORT_TILE);
+    hipLaunchKernelGGL(reset_recount_kernel, dim3(nt), dim3(64), nbins * sizeof(int) + ((K + 3) & ~3), s, bins, n, first, nbins, nt, b.fast_total,
+                       global_counts, b.tile_cnt, flags, K, seed, epoch);
     return hipGetLastError();
 }
 
@@ -773,6 +871,14 @@ hipError_t launch_mult_stats(const StatsArgs &a, hipStream_t s) {
 }
 
 // second half of the sort (needs the selection mask and the chunk size of the statistics pass)
+hipError_t launch_step_scan_scatter(const int32_t *bins, const StatsArgs &a, hipStream_t s) {
+    const int nt = (int)((a.n + SORT_TILE - 1) / SORT_TILE);
+    hipLaunchKernelGGL(scan_starts_kernel, dim3(a.nbins), dim3(256), 0, s, a.sb.tile_cnt, a.sb.tile_hist, nt, a.sb.bin_total, a.sb.bin_sel, a.chunk,
+                       a.sb.bin_start, a.sb.item_start, a.sb.perm_total, a.sb.fast_total, a.sb.ticket);
+    hipLaunchKernelGGL(scatter_kernel, dim3(nt), dim3(64), a.nbins * sizeof(int), s, bins, a.n, a.nbins, nt,
+                       a.sb.tile_hist, a.sb.bin_start, a.sb.perm);
+    return hipGetLastError();
+}
 hipError_t launch_sort_finish(const int32_t *bins, const StatsArgs &a, hipStream_t s) {
     const int nt = (int)((a.n + SORT_TILE - 1) / SORT_TILE);
     hipLaunchKernelGGL(starts_kernel, dim3(1), dim3(256), 0, s, a.sb.bin_total, a.sb.bin_sel, a.nbins, a.chunk,

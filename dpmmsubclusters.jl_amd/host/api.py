@@ -66,7 +66,8 @@ def _make_sampler(all_data, hyper, alpha, seed, burnout, max_clusters, comm, dev
     if seed is None:
         seed = int(np.random.SeedSequence().generate_state(1)[0])
         seed = comm.broadcast_int(seed) if hasattr(comm, "broadcast_int") else seed
-    wk = (worker_factory or binding.Worker)(hyper.kind, D, hi - lo, first_index=lo, device=device, seed=int(seed))
+    kw = dict(timing=False) if worker_factory is None else {}      # the product path records no timing events (~5 us each, four per step)
+    wk = (worker_factory or binding.Worker)(hyper.kind, D, hi - lo, first_index=lo, device=device, seed=int(seed), **kw)
     if rows is not None:
         if hasattr(wk, "upload_points_npy"):
             wk.upload_points_npy(rows[lo:hi])

@@ -68,6 +68,8 @@ enum {
     DPMM_OPT_SWEEP_GRID = 12,     /* workgroups of the sweep kernels, at most the default (compute units x resident workgroups per unit); experiments */
     DPMM_OPT_SWEEP_QUEUE_ROUNDS = 13, /* D <= 64 NIW sweep: the last rounds of tiles handed out through the queue; -1 (default): rounds / 8, at least 2, none below 4 rounds; 0: static schedule */
     DPMM_OPT_BALL_SCREEN = 14,        /* 1 (default): cluster-per-lane ball test in front of the per-point 4-row tail screen of the NIW sweeps; 0: per-point screens only (same labels) */
+    DPMM_OPT_KERNEL_TIMING = 15,      /* bit mask: 1 = HIP events around the sweep kernel, 2 = around the statistics pass (dpmm_last_kernel_ms), 4 = around the
+                                         all-reduces (dpmm_last_comm_ms); 0 (default): none -- every event is a barrier packet between two kernels, ~5 us each */
     DPMM_OPT_WAVE_PRIO = 10       /* 0 / 1: NIW sweep (D <= 64) lowers a wave's issue priority while it streams matrix instructions and
                                      raises it in its scalar / VALU phases (default 1) */
 };
@@ -268,7 +270,7 @@ int dpmm_sync(dpmm_ctx *ctx);
  * want to time with HIP events or order other work against it. */
 void *dpmm_stream(dpmm_ctx *ctx);
 /* Milliseconds spent in the dominant kernels during the last dpmm_sweep /
- * dpmm_suffstats_* call, measured with HIP events on the ctx stream (0 if none yet).
+ * dpmm_suffstats_* call, measured with HIP events on the ctx stream (0 if none yet, or when DPMM_OPT_KERNEL_TIMING is off -- the default).
  * Calling this synchronises the stream. */
 int dpmm_last_kernel_ms(dpmm_ctx *ctx, float *sweep_ms, float *suffstats_ms);
 /* Work the dpmm_sweep calls (NIW) since the previous call really executed, counted on the device (a slot per wave, no atomics):
