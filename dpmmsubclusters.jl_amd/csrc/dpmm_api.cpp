@@ -128,6 +128,8 @@ struct dpmm_ctx {
     std::unordered_map<uint32_t, int> apairs_index;         // (slot_i << 16 | slot_j) -> record
     std::vector<uint8_t> apairs_dirty;                      // [slot] statistics of the slot changed since the job was launched
     std::vector<int32_t> apairs_req;                        // request of dpmm_niw_master_pairs_ahead, consumed by the next dpmm_step_master_device
+    char *h_draw = nullptr;                                 // pinned: lr [K][2] | w [K] of dpmm_niw_master_draw
+    bool handover_inflight = false;                         // a hand-over kernel (reads lr / w from h_pin) was launched and the host has not waited behind it
     bool noise_pending = false;                             // dpmm_niw_master_draw asked for the next normals; launched behind the sweep (noise_flush)
     uint32_t noise_pend_epoch = 0;
     int noise_pend_nmat = 0;
@@ -446,6 +448,7 @@ int dpmm_destroy(dpmm_ctx *c) {
     hipFree(c->d_jobs); hipFree(c->d_dslots);
     for (int i = 0; i < 4; ++i) if (c->h_list[i]) hipHostFree(c->h_list[i]);
     if (c->h_master) hipHostFree(c->h_master);
+    if (c->h_draw) hipHostFree(c->h_draw);
     hipFree(c->d_counts64); hipFree(c->d_row_off); hipFree(c->d_inv_off); hipFree(c->d_work); hipFree(c->d_par);
     comm_release(c);
     if (c->h_red) hipHostFree(c->h_red);
@@ -1154,7 +1157,8 @@ static int spec_join(dpmm_ctx *c) {
 // ... and for the normals generated ahead (before a draw on the main stream: it uses them, or writes the buffer they are written to)
 static int noise_join(dpmm_ctx *c) {
     if (c->noise_inflight) {
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_noise, 0));
+        // (usually long done -- they were generated during the sweep: a query instead of a barrier packet in front of the draw kernel)
+        if (hipEventQuery(c->ev_noise) != hipSuccess) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_noise, 0));
         c->noise_inflight = false;
     }
     return DPMM_OK;
@@ -1261,6 +1265,7 @@ int dpmm_niw_master_setup(dpmm_ctx *c, double kappa, double nu, const double *m,
     HIPCHK(c, hipMemcpy(c->d_psi_lo, lo.data(), sizeof(double) * T, hipMemcpyHostToDevice));
     c->ma.D = D; c->ma.DP = 16 * ((D + 15) / 16); c->ma.packed_stride = c->packed_stride;
     c->ma.kappa0 = kappa; c->ma.nu0 = nu; c->ma.m0 = c->d_m0; c->ma.psi_lo = c->d_psi_lo; c->ma.seed = c->seed;
+    if (!c->h_draw) HIPCHK(c, hipHostMalloc((void **)&c->h_draw, sizeof(float) * 3 * DPMM_MAX_CLUSTERS, hipHostMallocDefault));
     if (!c->stream2) {
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_master, hipEventDisableTiming));
@@ -1364,19 +1369,22 @@ int dpmm_step_master_device(dpmm_ctx *c, uint32_t reset_epoch, const int32_t *sl
         // The next parameter draws, launched now on the second stream: they need the posteriors only (not the weights, not the
         // master's split / merge decisions), so they run while the host works on the scalars this call returns.  If nothing changes
         // the cluster -> slot map until dpmm_niw_master_draw(draw_epoch, ...), that call finds them done and launches the hand-over alone.
+        // (On the MAIN stream, right behind the posteriors and behind the event the host waits for: a hand-over across two streams costs
+        // ~15 us of signalling each way -- posteriors -> draws -> pack took 26 + 14 + 27 + 17 + 10 us at the 8-GPU shard size, the gaps
+        // being the two cross-stream waits.  The normals were generated on the second stream during the sweep: that event is long done.)
         const int32_t *hs = c->d_dslots;
-        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_master, 0));
+        const bool have_normals = noise_ready(c, draw_epoch, K, c->draw_cur ^ 1);
+        if (have_normals) if (int rc = noise_join(c)) return rc;
         NiwMasterArgs ma = c->ma;
         ma.mu_draw = c->d_mu_draw[c->draw_cur ^ 1];
         HIPCHK(c, launch_niw_master_draw(ma, hs, K, draw_epoch, c->d_Y[c->draw_cur ^ 1], c->d_ld_sigma[c->draw_cur ^ 1], nullptr, nullptr,
-                                         nullptr, nullptr, nullptr, nullptr, c->NB, nullptr,
-                                         1 | (noise_ready(c, draw_epoch, K, c->draw_cur ^ 1) ? 4 : 0), c->stream2));      // (the normals: same stream, earlier)
+                                         nullptr, nullptr, nullptr, nullptr, c->NB, nullptr, 1 | (have_normals ? 4 : 0), c->stream));
         c->noise_valid = false;
-        HIPCHK(c, hipEventRecord(c->ev_spec, c->stream2));
-        c->spec_inflight = true; c->spec_valid = true; c->spec_epoch = draw_epoch;
+        c->spec_inflight = false; c->spec_valid = true; c->spec_epoch = draw_epoch;
         c->spec_slots.assign(slots, slots + K);
     }
     HIPCHK(c, hipEventSynchronize(c->ev_master));
+    c->handover_inflight = false;          // (recorded behind the last hand-over kernel on the same stream)
     *bad = reinterpret_cast<const uint8_t *>(c->h_out);
     *small = sm;
     return DPMM_OK;
@@ -1428,10 +1436,13 @@ int dpmm_niw_master_draw(dpmm_ctx *c, uint32_t epoch, int K, const int32_t *slot
     if (int rc = ensure_capacity(c, K)) return rc;
     if (int rc = master_capacity(c, 0, K)) return rc;
     // small inputs through a pinned block of their own (the posterior's block may still be read by its caller)
-    const size_t need = sizeof(int32_t) * K + sizeof(float) * 3 * (size_t)K;
-    if (int rc = ensure_pinned(c, need + 64)) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    float *hlr = reinterpret_cast<float *>(c->h_pin + sizeof(int32_t) * K), *hw = hlr + 2 * K;
+    // lr / w through a pinned block of their own (h_draw; the shared staging h_pin belongs to calls that synchronise before they use it).
+    // The previous hand-over kernel reads lr / w from this block: wait only if the host has not waited for anything behind it since
+    // (in the engine's loop it has -- for the posteriors of the step -- and the stream now carries the draws launched ahead, which a
+    // synchronise here would wait out: 27 us on the host's critical path at D = 64)
+    if (c->handover_inflight) HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->handover_inflight = true;
+    float *hlr = reinterpret_cast<float *>(c->h_draw), *hw = hlr + 2 * K;
     memcpy(hlr, lr, sizeof(float) * 2 * K);
     memcpy(hw, w, sizeof(float) * K);
     c->have_tail = c->opt_tail && c->D >= 4 && c->D % 4 == 0 && K > 2;

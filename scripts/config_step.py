@@ -20,6 +20,7 @@ kind = sys.argv[1] if len(sys.argv) > 1 else "niw"
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 N = int(float(sys.argv[3])) if len(sys.argv) > 3 else 625000
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
+timing = not (len(sys.argv) > 5 and sys.argv[5] == "notiming")      # "notiming": no HIP events between the kernels (as fit / dp_parallel run)
 K, burnout = 32, 20
 if kind == "niw":
     X, y = host.gaussian_mixture_shard(N, D, K, 100.0, 12345, 0, N)
@@ -40,11 +41,12 @@ s = host.DPMMSampler(wk, prior, 10.0, N, 1, burnout=burnout)
 s.start_from_labels(y, 1 + np.random.default_rng(0).integers(0, 2, N), K)
 for _ in range(burnout + 5):
     s.group_step(False, False)
+wk.set_timing(timing)
 t_before = dict(s.timers)
 ts, sw, st = [], [], []
 for _ in range(steps):
     t0 = time.perf_counter(); s.group_step(False, False); ts.append(time.perf_counter() - t0)
-    a, b = wk.last_kernel_ms(); sw.append(a); st.append(b)
+    a, b = wk.last_kernel_ms() if timing else (float("nan"), float("nan")); sw.append(a); st.append(b)
 t_after = dict(s.timers)
 lab, _ = wk.get_labels()
 out = {"config": f"{kind} D={D} N={N} K={s.K}", "ms_per_step": 1e3 * float(np.mean(ts)), "ms_per_step_min": 1e3 * float(np.min(ts)),
