@@ -407,8 +407,8 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
     const size_t nbmax = 2 * DPMM_MAX_CLUSTERS;
     CHK_CREATE(hipMalloc(&c->sb.tile_hist, sizeof(int32_t) * nbmax * (size_t)std::max(1, c->nt_sort)));
     CHK_CREATE(hipMalloc(&c->sb.tile_cnt, sizeof(int32_t) * nbmax * (size_t)std::max(1, c->nt_sort)));
-    CHK_CREATE(hipMalloc(&c->sb.fast_total, sizeof(int32_t) * nbmax));
-    CHK_CREATE(hipMemset(c->sb.fast_total, 0, sizeof(int32_t) * nbmax));
+    CHK_CREATE(hipMalloc(&c->sb.fast_total, sizeof(int32_t) * nbmax * FAST_TOTAL_STRIDE));
+    CHK_CREATE(hipMemset(c->sb.fast_total, 0, sizeof(int32_t) * nbmax * FAST_TOTAL_STRIDE));
     CHK_CREATE(hipMalloc(&c->sb.ticket, sizeof(unsigned)));
     CHK_CREATE(hipMemset(c->sb.ticket, 0, sizeof(unsigned)));
     CHK_CREATE(hipMalloc(&c->sb.bin_total, sizeof(int32_t) * nbmax));
@@ -1044,7 +1044,7 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
         HIPCHK(c, launch_step_hist(c->dbins, c->n, nbins, c->sb, c->stream));
         const long long *gc = nullptr;
         if (comm_attached(c)) {
-            HIPCHK(c, launch_widen_counts(c->sb.fast_total, c->d_counts64, nbins, c->stream));
+            HIPCHK(c, launch_widen_counts(c->sb.fast_total, FAST_TOTAL_STRIDE, c->d_counts64, nbins, c->stream));
             if (int rc = comm_allreduce(c, c->d_counts64, nbins, /*kind=*/0)) return rc;
             gc = c->d_counts64;
         }
@@ -1060,7 +1060,7 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
         if (with_reset) {       // a rank without points: its occupancies are zero, the flags come from the other ranks' counts
             const long long *gc = nullptr;
             if (comm_attached(c)) {
-                HIPCHK(c, launch_widen_counts(c->sb.bin_total, c->d_counts64, nbins, c->stream));
+                HIPCHK(c, launch_widen_counts(c->sb.bin_total, 1, c->d_counts64, nbins, c->stream));
                 if (int rc = comm_allreduce(c, c->d_counts64, nbins, /*kind=*/0)) return rc;
                 gc = c->d_counts64;
             }
@@ -1157,8 +1157,9 @@ static int spec_join(dpmm_ctx *c) {
 // ... and for the normals generated ahead (before a draw on the main stream: it uses them, or writes the buffer they are written to)
 static int noise_join(dpmm_ctx *c) {
     if (c->noise_inflight) {
-        // (usually long done -- they were generated during the sweep: a query instead of a barrier packet in front of the draw kernel)
-        if (hipEventQuery(c->ev_noise) != hipSuccess) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_noise, 0));
+        // (a hipEventQuery in place of this barrier packet was tried: right after the record it reported the event's PREVIOUS completion
+        // now and then -- draws from unwritten normals, caught by the moment test)
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_noise, 0));
         c->noise_inflight = false;
     }
     return DPMM_OK;
@@ -1321,6 +1322,7 @@ int dpmm_step_master_device(dpmm_ctx *c, uint32_t reset_epoch, const int32_t *sl
     for (int32_t sl : c->apairs_req) if (sl >= top) { c->apairs_req.clear(); break; }      // (a pair of a slot this pass does not cover: no job)
     const int napairs = (int)(c->apairs_req.size() / 2);
     c->apairs_valid = false;
+    bool fuse_pairs = true;
     if (napairs > 0) {
         if ((size_t)napairs > c->apairs_cap) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1345,14 +1347,33 @@ int dpmm_step_master_device(dpmm_ctx *c, uint32_t reset_epoch, const int32_t *sl
         }
         // (on the second stream, where the pair job runs: the list changes with the merge gates, and a copy on the main stream would sit
         // between the sweep and the statistics kernels)
-        if (int rc = device_list(c, c->d_apairs, c->apairs_shadow, c->apairs_req.data(), c->apairs_req.size(), c->stream2)) return rc;
-    }
+        if (niw_master_can_fuse_pairs(c->ma)) {
+            // D <= 128: the pair jobs ride in the posteriors' launch (below) and name CLUSTERS of this pass
+            std::vector<int32_t> inv((size_t)top, -1), kp(c->apairs_req.size());
+            for (int k = 0; k < K; ++k) inv[slots[k]] = k;
+            for (size_t i = 0; i < kp.size(); ++i) {
+                kp[i] = inv[c->apairs_req[i]];
+                if (kp[i] < 0) { fuse_pairs = false; break; }
+            }
+            if (fuse_pairs) { if (int rc = device_list(c, c->d_apairs, c->apairs_shadow, kp.data(), kp.size())) return rc; }
+        } else fuse_pairs = false;
+        if (!fuse_pairs) if (int rc = device_list(c, c->d_apairs, c->apairs_shadow, c->apairs_req.data(), c->apairs_req.size(), c->stream2)) return rc;
+    } else fuse_pairs = false;
     double *sm = reinterpret_cast<double *>(c->h_master + jobs_bytes);
     if (int rc = run_stats(c, nullptr, 0, true, reset_epoch)) return rc;
     HIPCHK(c, launch_copy_bytes(c->h_out, reinterpret_cast<const uint8_t *>(c->d_out) + out_bytes, (size_t)K + 1, c->stream));
-    HIPCHK(c, launch_niw_master_posterior(c->ma, c->d_jobs, K, c->d_out, sm, c->stream));
+    if (napairs > 0 && fuse_pairs) {
+        // posteriors + the pooled pair log-determinants the master may ask for (dpmm_niw_master_pairs_ahead) in ONE launch: the pairs need
+        // the rows of this pass only.  (On the second stream behind the posteriors they reached the host 12 + 26 us later.)
+        HIPCHK(c, launch_niw_master_posterior_pairs(c->ma, c->d_jobs, K, c->d_out, sm, c->d_apairs, napairs, c->h_apairs, c->stream));
+        c->apairs_index.clear();
+        for (int p = 0; p < napairs; ++p) c->apairs_index[((uint32_t)c->apairs_req[2 * p] << 16) | (uint32_t)c->apairs_req[2 * p + 1]] = p;
+        c->apairs_dirty.assign((size_t)c->master_slots, 0);
+        c->apairs_inflight = false; c->apairs_valid = true;      // (the host waits for ev_master below: the records are there when it returns)
+        c->apairs_req.clear();
+    } else HIPCHK(c, launch_niw_master_posterior(c->ma, c->d_jobs, K, c->d_out, sm, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_master, c->stream));
-    if (napairs > 0) {
+    if (napairs > 0 && !fuse_pairs) {
         // The pooled pair log-determinants the master may ask for after its split decisions (dpmm_niw_master_pairs_ahead): they need the
         // stored rows of this pass only, so they run on the second stream while the host works; dpmm_niw_master_pairs answers from
         // them when every pair it is asked for is among them and none of their slots got new statistics in between.

@@ -109,7 +109,7 @@ hipError_t launch_init_labels(int32_t *bins, int64_t n, int64_t first_index, int
 // step statistics: flags[k] = 1 when cluster k has an empty sub-cluster (counts: [2K] Int64, global), flags[K] = any;
 // then re-draw the sub-labels of flagged clusters (reset_bad_clusters_worker!)
 hipError_t launch_bad_flags(const int32_t *bin_total, const long long *global_counts, int K, uint8_t *flags, hipStream_t s);
-hipError_t launch_widen_counts(const int32_t *src, long long *dst, int n, hipStream_t s);
+hipError_t launch_widen_counts(const int32_t *src, int stride, long long *dst, int n, hipStream_t s);
 hipError_t launch_gather_rows(float *dst, int64_t ld_dst, const float *src, int64_t ld_src, const int32_t *slot, int rows, int D, hipStream_t s);
 hipError_t launch_bins_from_i64(int32_t *bins, const int64_t *labels, const int64_t *sub, int64_t n, hipStream_t s);
 hipError_t launch_bins_to_i64(const int32_t *bins, int64_t *labels, int64_t *sub, int64_t n, hipStream_t s);
@@ -125,11 +125,12 @@ hipError_t launch_reset_sub(int32_t *bins, int64_t n, int64_t first_index, const
 
 // ---- stable counting sort of the points by bin + segmented statistics (suffstats.hip)
 constexpr int SORT_TILE = 2048;  // points per sorting wave
+constexpr int FAST_TOTAL_STRIDE = 32;   // ints between the running totals of two bins (one 128-byte line per bin: the histogram adds with atomics)
 
 struct SortBufs {
     int32_t *tile_hist;   // [nbins][ntiles_sort] exclusive prefix over the tiles of a bin (written by the scan from tile_cnt)
     int32_t *tile_cnt;    // [nbins][ntiles_sort] points of bin b in tile t (written by the histogram)
-    int32_t *fast_total;  // [nbins] running bin totals of the per-step histogram (integer atomics), cleared by scan_starts_kernel
+    int32_t *fast_total;  // [nbins][FAST_TOTAL_STRIDE] (element 0 of each line) running bin totals of the per-step histogram (integer atomics), cleared by scan_starts_kernel
     unsigned *ticket;     // [1] workgroups of scan_starts_kernel that are done (the last one computes the starts and clears it)
     int32_t *bin_total;   // [nbins]
     int32_t *bin_start;   // [nbins + 1]
@@ -193,6 +194,9 @@ size_t niw_master_lds_bytes(int DP);
 hipError_t launch_niw_master_pairs(const NiwMasterArgs &a, const int32_t *pairs, int n, double *scratch, double *small, hipStream_t s);
 hipError_t launch_niw_rows_gather(const double *rows_store, const int32_t *slots, int n, int64_t stride, double *dst, hipStream_t s);
 hipError_t launch_niw_master_posterior(const NiwMasterArgs &a, const int32_t *jobs, int njobs, const double *rows, double *small, hipStream_t s);
+bool niw_master_can_fuse_pairs(const NiwMasterArgs &a);
+hipError_t launch_niw_master_posterior_pairs(const NiwMasterArgs &a, const int32_t *jobs, int njobs, const double *rows, double *small,
+                                             const int32_t *cluster_pairs, int npairs, double *pair_small, hipStream_t s);
 hipError_t launch_niw_draw_inputs(const NiwMasterArgs &a, const int32_t *slot_of_cluster, int K, uint32_t epoch, double *Aout, double *xiout, hipStream_t s);
 hipError_t launch_niw_master_noise(const NiwMasterArgs &a, int nmat, uint32_t epoch, double *Y, hipStream_t s);
 hipError_t launch_niw_master_draw(const NiwMasterArgs &a, const int32_t *slot_of_cluster, int K, uint32_t epoch, double *Y, float *logdet_sigma,

@@ -123,11 +123,11 @@ hipError_t launch_bad_flags(const int32_t *bin_total, const long long *global_co
     return hipGetLastError();
 }
 // (the reset itself, with the flag computation folded in, is reset_recount_kernel in suffstats.hip: it re-counts the sort tiles it touches)
-__global__ void widen_counts_kernel(const int32_t *__restrict__ src, long long *__restrict__ dst, int n) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = (long long)src[i];
+__global__ void widen_counts_kernel(const int32_t *__restrict__ src, int stride, long long *__restrict__ dst, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = (long long)src[(int64_t)i * stride];
 }
-hipError_t launch_widen_counts(const int32_t *src, long long *dst, int n, hipStream_t s) {
-    hipLaunchKernelGGL(widen_counts_kernel, dim3(grid_for(n)), dim3(256), 0, s, src, dst, n);
+hipError_t launch_widen_counts(const int32_t *src, int stride, long long *dst, int n, hipStream_t s) {
+    hipLaunchKernelGGL(widen_counts_kernel, dim3(grid_for(n)), dim3(256), 0, s, src, stride, dst, n);
     return hipGetLastError();
 }
 // dst[3k+w][0..D) = src[3*slot[k]+w][0..D)  (Multinomial parameter rows from the slot-indexed staging; padding beyond D is zeroed)

@@ -748,8 +748,8 @@ __global__ __launch_bounds__(256) void niw_form_pair_kernel(NiwMasterArgs A, con
 // rows_store like the two kernels it replaces.  PAIRS = true: job p = blockIdx.x pools the four stored rows of slots jobs[2p],
 // jobs[2p+1]; only small[NS p + 0..4] is written.
 template <bool PAIRS>
-__global__ __launch_bounds__(256) void niw_post_lds_kernel(NiwMasterArgs A, const int32_t *__restrict__ jobs, const double *__restrict__ rows,
-                                                           double *__restrict__ small) {
+__device__ __forceinline__ void niw_post_lds_body(const NiwMasterArgs &A, const int32_t *__restrict__ jobs, const double *__restrict__ rows,
+                                                  double *__restrict__ small, const int bid) {
     const int D = A.D, DP = A.DP, NB = DP / 16, LD = DP + 1, tid = threadIdx.x;
 #ifdef DPMM_POST_STAMPS
     unsigned long long T0 = __builtin_amdgcn_s_memtime(), Tf = 0, Td = 0, Tp = 0, Tt = 0, Ta = 0, Tb = 0;
@@ -769,11 +769,14 @@ __global__ __launch_bounds__(256) void niw_post_lds_kernel(NiwMasterArgs A, cons
     double c0 = 1.0, c1 = 1.0;
     int row = 0, w = 0, slot = 0;
     if constexpr (PAIRS) {
-        r0 = A.rows_store + (int64_t)(2 * jobs[2 * blockIdx.x]) * stride; r1 = r0 + stride;
-        r2 = A.rows_store + (int64_t)(2 * jobs[2 * blockIdx.x + 1]) * stride; r3 = r2 + stride;
+        // rows == nullptr: jobs name SLOTS, the rows are the stored ones; else jobs name CLUSTERS of the statistics pass `rows` (the pair
+        // jobs launched together with the posteriors of that pass: the stored rows are being written by the neighbours)
+        const double *src = rows ? rows : A.rows_store;
+        r0 = src + (int64_t)(2 * jobs[2 * bid]) * stride; r1 = r0 + stride;
+        r2 = src + (int64_t)(2 * jobs[2 * bid + 1]) * stride; r3 = r2 + stride;
     } else {
-        const int j = blockIdx.x / 3;
-        w = blockIdx.x % 3;
+        const int j = bid / 3;
+        w = bid % 3;
         slot = jobs[2 * j + 1];
         r0 = rows + (int64_t)(2 * jobs[2 * j]) * stride; r1 = r0 + stride;
         c0 = (w != 2) ? 1.0 : 0.0; c1 = (w != 1) ? 1.0 : 0.0;
@@ -816,7 +819,7 @@ __global__ __launch_bounds__(256) void niw_post_lds_kernel(NiwMasterArgs A, cons
         if constexpr (!PAIRS) A.mean[(int64_t)row * DP + a] = mv;
     }
     if (tid == 0) {
-        double *o = small + (int64_t)blockIdx.x * NS;
+        double *o = small + (int64_t)bid * NS;
         o[0] = N; o[1] = (N == 0.0) ? k0 : k1; o[2] = (N == 0.0) ? v0 : v1;
         if constexpr (!PAIRS) { A.kap[row] = o[1]; A.nu[row] = o[2]; }
     }
@@ -970,10 +973,10 @@ __global__ __launch_bounds__(256) void niw_post_lds_kernel(NiwMasterArgs A, cons
         double lg = 0.0;
         for (int a = tid; a < DP; a += 64) lg += log(piv[a]);
         for (int o = 32; o > 0; o >>= 1) lg += __shfl_xor(lg, o);
-        if (tid == 0) small[(int64_t)blockIdx.x * NS + 3] = s_bad ? NAN : lg;
+        if (tid == 0) small[(int64_t)bid * NS + 3] = s_bad ? NAN : lg;
     } else if (tid < 128) {      // (the second wave, meanwhile)
         const double lm = log_mv_gamma_wave(0.5 * ((N == 0.0) ? v0 : v1), D, tid - 64);
-        if (tid == 64) small[(int64_t)blockIdx.x * NS + 4] = lm;
+        if (tid == 64) small[(int64_t)bid * NS + 4] = lm;
     }
     if constexpr (!PAIRS) {
         double *F = A.fac + (int64_t)row * DP * DP;
@@ -984,13 +987,36 @@ __global__ __launch_bounds__(256) void niw_post_lds_kernel(NiwMasterArgs A, cons
     }
 #ifdef DPMM_POST_STAMPS          // diagnostic build: phase cycles of two workgroups overwrite their scalars (scripts/post_stamps.py)
     __syncthreads();
-    if (tid == 0 && blockIdx.x == 5) { double *o = small + 5 * NS; o[0] = (double)Tf; o[1] = (double)Td; o[2] = (double)Tp; o[3] = (double)Tt; }
-    if (tid == 0 && blockIdx.x == 6) { double *o = small + 6 * NS; o[0] = (double)(__builtin_amdgcn_s_memtime() - Ta); o[1] = (double)(__builtin_amdgcn_s_memtime() - T0); }
+    if (tid == 0 && bid == 5) { double *o = small + 5 * NS; o[0] = (double)Tf; o[1] = (double)Td; o[2] = (double)Tp; o[3] = (double)Tt; }
+    if (tid == 0 && bid == 6) { double *o = small + 6 * NS; o[0] = (double)(__builtin_amdgcn_s_memtime() - Ta); o[1] = (double)(__builtin_amdgcn_s_memtime() - T0); }
 #endif
+}
+template <bool PAIRS>
+__global__ __launch_bounds__(256) void niw_post_lds_kernel(NiwMasterArgs A, const int32_t *__restrict__ jobs, const double *__restrict__ rows,
+                                                           double *__restrict__ small) {
+    niw_post_lds_body<PAIRS>(A, jobs, rows, small, (int)blockIdx.x);
+}
+// the 3 njobs posteriors of a statistics pass and npairs pooled pairs of the same pass in ONE launch (the pairs behind the posteriors in the
+// grid): the pair jobs name clusters and read the rows of the pass, so they depend on nothing the posterior workgroups write
+__global__ __launch_bounds__(256) void niw_post_both_kernel(NiwMasterArgs A, const int32_t *__restrict__ jobs, const double *__restrict__ rows,
+                                                            double *__restrict__ small, int nposts, const int32_t *__restrict__ pair_jobs,
+                                                            double *__restrict__ pair_small) {
+    if ((int)blockIdx.x < nposts) niw_post_lds_body<false>(A, jobs, rows, small, (int)blockIdx.x);
+    else niw_post_lds_body<true>(A, pair_jobs, rows, pair_small, (int)blockIdx.x - nposts);
 }
 size_t niw_post_lds_bytes(int DP) { return sizeof(double) * ((size_t)DP * (DP + 1) + 3 * (size_t)DP + 16); }
 constexpr int NIW_POST_LDS_MAXDP = 128;
 
+bool niw_master_can_fuse_pairs(const NiwMasterArgs &a) { return a.DP <= NIW_POST_LDS_MAXDP; }
+// posteriors of njobs clusters + npairs pooled pairs (CLUSTER indices of the same pass) in one launch; D <= 128 only
+hipError_t launch_niw_master_posterior_pairs(const NiwMasterArgs &a, const int32_t *jobs, int njobs, const double *rows, double *small,
+                                             const int32_t *cluster_pairs, int npairs, double *pair_small, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void *)niw_post_both_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)niw_post_lds_bytes(NIW_POST_LDS_MAXDP)); attr = true; }
+    hipLaunchKernelGGL(niw_post_both_kernel, dim3(3 * njobs + npairs), dim3(256), niw_post_lds_bytes(a.DP), s, a, jobs, rows, small, 3 * njobs,
+                       cluster_pairs, pair_small);
+    return hipGetLastError();
+}
 hipError_t launch_niw_master_pairs(const NiwMasterArgs &a, const int32_t *pairs, int n, double *scratch, double *small, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     if (a.DP <= NIW_POST_LDS_MAXDP) {

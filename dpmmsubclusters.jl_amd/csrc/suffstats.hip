@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64) void hist_kernel(const int32_t *__restrict__ bi
     for (int b = lane; b < nbins; b += 64) {
         const int v = cnt[b];
         tile_hist[(int64_t)b * nt + blockIdx.x] = v;
-        if (fast_total && v) atomicAdd(&fast_total[b], v);
+        if (fast_total && v) atomicAdd(&fast_total[b * FAST_TOTAL_STRIDE], v);     // (a line per bin: 5 k tiles x ~3 bins on two lines took 18 us longer)
     }
 }
 
@@ -111,8 +111,8 @@ __global__ __launch_bounds__(64) void reset_recount_kernel(int32_t *__restrict__
     const int lane = threadIdx.x;
     bool anyl = false;
     for (int k = lane; k < K; k += 64) {
-        const long long a = global_counts ? global_counts[2 * k] : (long long)totals[2 * k];
-        const long long b = global_counts ? global_counts[2 * k + 1] : (long long)totals[2 * k + 1];
+        const long long a = global_counts ? global_counts[2 * k] : (long long)totals[(2 * k) * FAST_TOTAL_STRIDE];
+        const long long b = global_counts ? global_counts[2 * k + 1] : (long long)totals[(2 * k + 1) * FAST_TOTAL_STRIDE];
         const bool bad = a == 0 || b == 0;
         f[k] = bad ? 1 : 0;
         anyl = anyl || bad;
@@ -126,10 +126,23 @@ __global__ __launch_bounds__(64) void reset_recount_kernel(int32_t *__restrict__
     constexpr int PER = SORT_TILE / 64;
     int v[PER];
     bool hit = false;
+    const bool full = base + SORT_TILE <= n;       // full tile: 16-byte loads (lane owns four consecutive points per trip), else one point per trip
+    if (full) {
+        const int4 *src = reinterpret_cast<const int4 *>(bins + base);
+#pragma unroll
+        for (int it = 0; it < PER / 4; ++it) {
+            const int4 q = src[it * 64 + lane];
+            v[4 * it] = q.x; v[4 * it + 1] = q.y; v[4 * it + 2] = q.z; v[4 * it + 3] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < PER; ++it) {
+            const int64_t i = base + it * 64 + lane;
+            v[it] = i < n ? bins[i] : -1;
+        }
+    }
 #pragma unroll
     for (int it = 0; it < PER; ++it) {
-        const int64_t i = base + it * 64 + lane;
-        v[it] = i < n ? bins[i] : -1;
         const int z = v[it] >> 1;
         hit = hit || (v[it] >= 0 && z < K && f[z]);
     }
@@ -138,7 +151,7 @@ __global__ __launch_bounds__(64) void reset_recount_kernel(int32_t *__restrict__
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < PER; ++it) {
-        const int64_t i = base + it * 64 + lane;
+        const int64_t i = full ? base + (int64_t)((it >> 2) * 64 + lane) * 4 + (it & 3) : base + it * 64 + lane;
         int bv = v[it];
         const int z = bv >> 1;
         if (bv >= 0 && z < K && f[z]) {
@@ -244,7 +257,7 @@ __global__ __launch_bounds__(256) void scan_starts_kernel(const int32_t *__restr
     if (!last) return;
     __threadfence();                                    // (acquire: the other workgroups' totals, not a stale line of this unit's cache)
     if (threadIdx.x == 0) *ticket = 0u;
-    if (fast_total) for (int b = threadIdx.x; b < nbins; b += 256) fast_total[b] = 0;
+    if (fast_total) for (int b = threadIdx.x; b < nbins; b += 256) fast_total[b * FAST_TOTAL_STRIDE] = 0;
     __syncthreads();
     starts_body(bin_total, bin_sel, nbins, chunk, bin_start, item_start, perm_total, part, pb);
 }
