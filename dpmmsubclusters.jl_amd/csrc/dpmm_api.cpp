@@ -104,6 +104,11 @@ struct dpmm_ctx {
     bool work_zeroed = false;          // the pack kernel cleared d_work and no sweep has run since
     int sel_all_ones = 0, sel_capacity = 0;   // sb.bin_sel[0..sel_all_ones) are known to be 1 (full passes skip the memset)
     long long *d_counts64 = nullptr;   // [2 * DPMM_MAX_CLUSTERS] global sub-cluster occupancies (multi-GPU)
+    // derived sub-cluster statistics of the per-step pass (derive_rows_kernel): cached cluster-level rows + label tracking
+    double *d_ccache = nullptr;        // [Kcap][packed_stride] left + right of every cluster as of the last pass that computed both
+    bool cache_force = true;           // the next per-step pass computes every cluster in full (points uploaded, cache re-allocated, K changed)
+    int cache_K = -1;
+    int opt_derive = 1;
     // device master (niw_master.hip)
     bool master = false;
     NiwMasterArgs ma{};
@@ -301,6 +306,7 @@ const char *dpmm_last_error(const dpmm_ctx *ctx) { return ctx ? ctx->err.c_str()
 
 static void free_params(dpmm_ctx *c) {
     hipFree(c->d_raw); hipFree(c->d_mu); hipFree(c->d_Rp); hipFree(c->d_mup); hipFree(c->d_cst);
+    hipFree(c->d_ccache); c->d_ccache = nullptr;
     hipFree(c->d_scratch); hipFree(c->d_slabs); hipFree(c->d_out); hipFree(c->d_Lp16); hipFree(c->d_tdf); hipFree(c->d_lam); hipFree(c->d_mdist); hipFree(c->d_tail);
     c->d_Lp16 = nullptr; c->d_tdf = nullptr; c->d_lam = nullptr; c->d_mdist = nullptr; c->d_tail = nullptr;
     c->d_raw = c->d_mu = c->d_Rp = c->d_mup = c->d_cst = c->d_scratch = nullptr;
@@ -341,6 +347,9 @@ static int ensure_capacity(dpmm_ctx *c, int K) {
     c->max_items = (int)((c->n + c->chunk - 1) / c->chunk) + 2 * cap;
     HIPCHK(c, hipMalloc(&c->d_slabs, sizeof(double) * (size_t)c->max_items * (size_t)c->slab_stride));
     HIPCHK(c, hipMalloc(&c->d_out, sizeof(double) * 2 * cap * (size_t)c->packed_stride + DPMM_MAX_CLUSTERS + 64));   // rows | bad-cluster flags
+    HIPCHK(c, hipMalloc(&c->d_ccache, sizeof(double) * cap * (size_t)c->packed_stride));
+    HIPCHK(c, hipMemset(c->d_ccache, 0, sizeof(double) * cap * (size_t)c->packed_stride));
+    c->cache_force = true;
     c->Kcap = cap;
     return DPMM_OK;
 }
@@ -411,6 +420,12 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
     CHK_CREATE(hipMemset(c->sb.fast_total, 0, sizeof(int32_t) * nbmax * FAST_TOTAL_STRIDE));
     CHK_CREATE(hipMalloc(&c->sb.ticket, sizeof(unsigned)));
     CHK_CREATE(hipMemset(c->sb.ticket, 0, sizeof(unsigned)));
+    CHK_CREATE(hipMalloc(&c->sb.prev_lab, sizeof(uint16_t) * (((size_t)nalloc + SORT_TILE - 1) / SORT_TILE * SORT_TILE)));
+    CHK_CREATE(hipMemset(c->sb.prev_lab, 0xFF, sizeof(uint16_t) * (((size_t)nalloc + SORT_TILE - 1) / SORT_TILE * SORT_TILE)));
+    CHK_CREATE(hipMalloc(&c->sb.cdirty, DPMM_MAX_CLUSTERS + 8));
+    CHK_CREATE(hipMemset(c->sb.cdirty, 1, DPMM_MAX_CLUSTERS + 8));
+    CHK_CREATE(hipMalloc(&c->sb.cmode, DPMM_MAX_CLUSTERS));
+    CHK_CREATE(hipMemset(c->sb.cmode, 0, DPMM_MAX_CLUSTERS));
     CHK_CREATE(hipMalloc(&c->sb.bin_total, sizeof(int32_t) * nbmax));
     CHK_CREATE(hipMalloc(&c->sb.bin_start, sizeof(int32_t) * (nbmax + 1)));
     CHK_CREATE(hipMalloc(&c->sb.item_start, sizeof(int32_t) * (nbmax + 1)));
@@ -433,7 +448,7 @@ int dpmm_destroy(dpmm_ctx *c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     free_params(c);
     hipFree(c->dX); hipFree(c->dX8); hipFree(c->dbins); hipFree(c->d_gt); hipFree(c->d_cont);
-    hipFree(c->sb.tile_hist); hipFree(c->sb.tile_cnt); hipFree(c->sb.fast_total); hipFree(c->sb.ticket); hipFree(c->sb.bin_total); hipFree(c->sb.bin_start); hipFree(c->sb.item_start);
+    hipFree(c->sb.tile_hist); hipFree(c->sb.tile_cnt); hipFree(c->sb.fast_total); hipFree(c->sb.ticket); hipFree(c->sb.prev_lab); hipFree(c->sb.cdirty); hipFree(c->sb.cmode); hipFree(c->sb.bin_total); hipFree(c->sb.bin_start); hipFree(c->sb.item_start);
     hipFree(c->sb.perm); hipFree(c->sb.bin_sel); hipFree(c->sb.perm_total); hipFree(c->d_small); hipFree(c->d_proj); hipFree(c->d_vals); hipFree(c->d_smart);
     hipFree(c->d_m0); hipFree(c->d_psi_lo); hipFree(c->d_pairs);
     for (int i = 0; i < 2; ++i) { hipFree(c->d_Y[i]); hipFree(c->d_ld_sigma[i]); hipFree(c->d_mu_draw[i]); }
@@ -501,6 +516,7 @@ static int upload_common(dpmm_ctx *c, const float *X, int64_t ldx, hipMemcpyKind
         if (int rc = finish_upload(c)) return rc;
     }
     c->have_points = true;
+    c->cache_force = true;          // the cached cluster-level statistics belong to the old points
     return DPMM_OK;
 }
 
@@ -1028,10 +1044,13 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
         memcpy(c->h_pin, c->h_sel.data(), nbins);
         HIPCHK(c, launch_copy_bytes(c->sb.bin_sel, c->h_pin, nbins, c->stream));
         c->sel_all_ones = 0;
+    } else if (with_reset && c->n > 0 && c->opt_derive) {
+        // (the per-step pass writes the selection of its 2K bins itself: scan_starts_kernel)
     } else if (c->sel_all_ones < nbins) {
         HIPCHK(c, hipMemsetAsync(c->sb.bin_sel, 1, c->sel_capacity, c->stream));      // stays valid until a subset pass overwrites it
         c->sel_all_ones = c->sel_capacity;
     }
+    bool derive = false;
     StatsArgs a{};
     a.X = c->dX; a.ldx = c->ldx; a.n = c->n; a.D = c->D; a.nbins = nbins; a.chunk = c->chunk;
     a.max_items = (int)((c->n + c->chunk - 1) / c->chunk) + nbins;
@@ -1050,7 +1069,12 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
         }
         uint8_t *flags = reinterpret_cast<uint8_t *>(c->d_out) + sizeof(double) * (size_t)nbins * (size_t)c->packed_stride;
         HIPCHK(c, launch_step_reset(c->dbins, c->n, c->first, nbins, c->sb, gc, flags, c->K, c->seed, reset_epoch, c->stream));
-        HIPCHK(c, launch_step_scan_scatter(c->dbins, a, c->stream));
+        // Statistics of the SMALLER sub-cluster only wherever no point entered or left the cluster since its cluster-level row was
+        // cached (labels are tracked by the histogram); the other sub-cluster is cache - computed (derive_rows_kernel below)
+        derive = c->opt_derive != 0;
+        const int force_all = (c->cache_force || c->cache_K != c->K) ? 1 : 0;
+        HIPCHK(c, launch_step_scan_scatter(c->dbins, a, derive ? 1 : 0, force_all, c->stream));
+        if (derive) { c->sel_all_ones = 0; c->cache_force = false; c->cache_K = c->K; }
     } else {
         if (c->n > 0) {
             HIPCHK(c, launch_sort_by_bin(c->dbins, c->n, nbins, c->sb, c->stream));
@@ -1073,6 +1097,7 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
     if (c->prior == DPMM_PRIOR_NIW) HIPCHK(c, launch_niw_stats(a, c->stream));
     else if (c->x_u8) HIPCHK(c, launch_mult_stats_u8(a, c->dX8, c->ld8, c->stream));
     else HIPCHK(c, launch_mult_stats(a, c->stream));
+    if (derive) HIPCHK(c, launch_derive_rows(c->d_out, c->d_ccache, c->sb.cmode, c->sb.cdirty, c->packed_stride, c->K, c->stream));
     if (comm_attached(c)) {
         // the one exchange of the sweep: elementwise sum of the per-worker statistics (update_suff_stats_posterior!,
         // local_clusters_actions.jl:206-254; aggregate_suff_stats); N counts travel as Float64 integers (exact below 2^53)
@@ -1873,6 +1898,7 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
         case DPMM_OPT_WAVE_PRIO: c->opt_prio = value != 0; return DPMM_OK;
         case DPMM_OPT_SWEEP_QUEUE_ROUNDS: c->opt_queue_rounds = value < 0 ? -1 : (int)value; return DPMM_OK;
         case DPMM_OPT_BALL_SCREEN: c->opt_ball = value != 0; return DPMM_OK;
+        case DPMM_OPT_STATS_DERIVE: c->opt_derive = value != 0; c->cache_force = true; return DPMM_OK;
         case DPMM_OPT_KERNEL_TIMING:
             c->opt_timing = (int)value & 7;
             if (!(c->opt_timing & 1)) c->have_sweep_ev = false;

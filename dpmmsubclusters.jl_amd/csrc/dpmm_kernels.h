@@ -132,6 +132,9 @@ struct SortBufs {
     int32_t *tile_cnt;    // [nbins][ntiles_sort] points of bin b in tile t (written by the histogram)
     int32_t *fast_total;  // [nbins][FAST_TOTAL_STRIDE] (element 0 of each line) running bin totals of the per-step histogram (integer atomics), cleared by scan_starts_kernel
     unsigned *ticket;     // [1] workgroups of scan_starts_kernel that are done (the last one computes the starts and clears it)
+    uint16_t *prev_lab;   // [n] cluster label of every point at the previous per-step pass (0xFFFF: none yet); null: no tracking
+    uint8_t *cdirty;      // [DPMM_MAX_CLUSTERS_K + 1] a point entered or left cluster k since then; last element: every cluster
+    uint8_t *cmode;       // [DPMM_MAX_CLUSTERS_K] per-step pass: 0 both sub-clusters computed, 1 / 2 left / right derived from the cached cluster row
     int32_t *bin_total;   // [nbins]
     int32_t *bin_start;   // [nbins + 1]
     int32_t *perm;        // [n]
@@ -146,7 +149,8 @@ hipError_t launch_step_reset(int32_t *bins, int64_t n, int64_t first, int nbins,
                              int K, uint64_t seed, uint32_t epoch, hipStream_t s);
 struct StatsArgs;
 hipError_t launch_sort_finish(const int32_t *bins, const StatsArgs &a, hipStream_t s);
-hipError_t launch_step_scan_scatter(const int32_t *bins, const StatsArgs &a, hipStream_t s);
+hipError_t launch_step_scan_scatter(const int32_t *bins, const StatsArgs &a, int derive, int force_all, hipStream_t s);
+hipError_t launch_derive_rows(double *out, double *cache, const uint8_t *mode, uint8_t *dirty, int64_t stride, int K, hipStream_t s);
 
 struct StatsArgs {
     const float *X;

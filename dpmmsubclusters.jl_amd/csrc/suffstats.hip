@@ -32,13 +32,25 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------ sort
 // `fast_total` (nullable): [nbins] running bin totals, added with integer atomics (order-independent, exact) -- the per-step pass needs the
 // sub-cluster occupancies before anything is scanned (bad-cluster flags); scan_starts_kernel clears them again for the next pass.
+// `prev_lab` / `dirty` (nullable pair): the cluster label every point had at the previous per-step pass, and per-cluster flags "a point
+// entered or left this cluster since then" -- what lets the statistics pass compute only the smaller sub-cluster of an untouched cluster
+// and take the other one from the cached cluster-level row (derive_rows_kernel).  Any path that changes labels is seen here.
 __global__ __launch_bounds__(64) void hist_kernel(const int32_t *__restrict__ bins, int64_t n, int nbins, int nt,
-                                                  int32_t *__restrict__ tile_hist, int32_t *__restrict__ fast_total) {
+                                                  int32_t *__restrict__ tile_hist, int32_t *__restrict__ fast_total,
+                                                  uint16_t *__restrict__ prev_lab, uint8_t *__restrict__ dirty) {
     extern __shared__ int cnt[];
     const int lane = threadIdx.x;
     for (int b = lane; b < nbins; b += 64) cnt[b] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
+    auto track = [&](int64_t i, int bv) {            // rare: a point whose label is not the one it had at the previous pass
+        const unsigned z = (unsigned)bv >> 1, p = prev_lab[i];
+        if ((unsigned)bv < (unsigned)nbins && z != p) {
+            dirty[z] = 1;
+            if (p < DPMM_MAX_CLUSTERS_K) dirty[p] = 1;
+            prev_lab[i] = (uint16_t)z;
+        }
+    };
     if (base + SORT_TILE <= n) {
         // full tile: 16-byte loads, all of them in flight before the first is used; 256 points with one common bin (the usual case
         // after an ordered sweep: neighbours share a label) cost one LDS add instead of 256 same-address atomics
@@ -46,6 +58,21 @@ __global__ __launch_bounds__(64) void hist_kernel(const int32_t *__restrict__ bi
         int4 v[SORT_TILE / 256];
 #pragma unroll
         for (int it = 0; it < SORT_TILE / 256; ++it) v[it] = src[it * 64 + lane];
+        if (prev_lab) {
+            const uint2 *psrc = reinterpret_cast<const uint2 *>(prev_lab + base);         // four 16-bit labels per lane and trip
+            uint2 pv[SORT_TILE / 256];
+#pragma unroll
+            for (int it = 0; it < SORT_TILE / 256; ++it) pv[it] = psrc[it * 64 + lane];
+#pragma unroll
+            for (int it = 0; it < SORT_TILE / 256; ++it) {
+                const unsigned a0 = (unsigned)v[it].x >> 1, a1 = (unsigned)v[it].y >> 1, a2 = (unsigned)v[it].z >> 1, a3 = (unsigned)v[it].w >> 1;
+                const bool same4 = (pv[it].x == (a0 | (a1 << 16))) && (pv[it].y == (a2 | (a3 << 16)));
+                if (!same4) {
+                    const int64_t i0 = base + (int64_t)(it * 64 + lane) * 4;
+                    track(i0, v[it].x); track(i0 + 1, v[it].y); track(i0 + 2, v[it].z); track(i0 + 3, v[it].w);
+                }
+            }
+        }
 #pragma unroll
         for (int it = 0; it < SORT_TILE / 256; ++it) {
             const int b0 = __builtin_amdgcn_readfirstlane(v[it].x);
@@ -87,6 +114,7 @@ __global__ __launch_bounds__(64) void hist_kernel(const int32_t *__restrict__ bi
             if (i < n) {
                 const int b = bins[i];
                 if ((unsigned)b < (unsigned)nbins) atomicAdd(&cnt[b], 1);
+                if (prev_lab) track(i, b);
             }
         }
     }
@@ -198,7 +226,7 @@ __global__ __launch_bounds__(256) void scan_tiles_kernel(const int32_t *__restri
 }
 
 // bin_start[b] = sum_{b'<b} total ; item_start[b] = sum_{b'<b} ceil(sel*total / chunk)
-__device__ __forceinline__ void starts_body(const int32_t *bin_total, const uint8_t *__restrict__ bin_sel,
+__device__ __forceinline__ void starts_body(const int32_t *bin_total, const uint8_t *bin_sel,
                                             int nbins, int chunk, int32_t *__restrict__ bin_start,
                                             int32_t *__restrict__ item_start, int32_t *__restrict__ perm_total, int *pa, int *pb) {
     const int per = (nbins + 255) / 256;
@@ -242,10 +270,14 @@ __global__ __launch_bounds__(256) void starts_kernel(const int32_t *__restrict__
 }
 // scan of every bin + the starts in ONE launch: the workgroup that finishes last (a ticket counter) sees every bin total and computes
 // bin_start / item_start; it also clears the ticket and the histogram's running totals for the next pass.
+// `mode` (nullable; with `dirty` and `force_all`): the last workgroup also decides, per cluster, which bins the statistics kernels compute
+// (bin_sel) -- mode[k] = 0: both sub-clusters (the cluster was touched since its cached row was formed, or is empty, or force_all),
+// 1: only the right one (the left is the larger: derived as cache - right), 2: only the left one.
 __global__ __launch_bounds__(256) void scan_starts_kernel(const int32_t *__restrict__ tile_cnt, int32_t *__restrict__ tile_hist, int nt,
-                                                          int32_t *bin_total, const uint8_t *__restrict__ bin_sel, int chunk,
+                                                          int32_t *bin_total, uint8_t *bin_sel, int chunk,
                                                           int32_t *__restrict__ bin_start, int32_t *__restrict__ item_start,
-                                                          int32_t *__restrict__ perm_total, int32_t *__restrict__ fast_total, unsigned *ticket) {
+                                                          int32_t *__restrict__ perm_total, int32_t *__restrict__ fast_total, unsigned *ticket,
+                                                          uint8_t *__restrict__ mode, const uint8_t *__restrict__ dirty, int force_all) {
     __shared__ int part[256], pb[256];
     __shared__ unsigned last;
     const int nbins = (int)gridDim.x;
@@ -258,6 +290,16 @@ __global__ __launch_bounds__(256) void scan_starts_kernel(const int32_t *__restr
     __threadfence();                                    // (acquire: the other workgroups' totals, not a stale line of this unit's cache)
     if (threadIdx.x == 0) *ticket = 0u;
     if (fast_total) for (int b = threadIdx.x; b < nbins; b += 256) fast_total[b * FAST_TOTAL_STRIDE] = 0;
+    if (mode) {
+        const bool all = force_all || dirty[DPMM_MAX_CLUSTERS_K];
+        for (int k = threadIdx.x; k < nbins / 2; k += 256) {
+            const int nl = bin_total[2 * k], nr = bin_total[2 * k + 1];
+            const int m = (all || dirty[k] || nl + nr == 0) ? 0 : (nl <= nr ? 2 : 1);
+            mode[k] = (uint8_t)m;
+            bin_sel[2 * k] = m != 1;
+            bin_sel[2 * k + 1] = m != 2;
+        }
+    }
     __syncthreads();
     starts_body(bin_total, bin_sel, nbins, chunk, bin_start, item_start, perm_total, part, pb);
 }
@@ -317,10 +359,34 @@ __global__ __launch_bounds__(64) void scatter_kernel(const int32_t *__restrict__
     }
 }
 
+// After the reduce of a per-step pass: the rows of the sub-clusters that were not computed, and the cache they come from.
+//   mode[k] = 0: both rows were computed -> cache[k] = left + right (the cluster-level statistics, valid until a point enters or leaves k)
+//   mode[k] = 1 / 2: left / right = cache[k] - the computed row.  The derived side is the LARGER one: its relative error is that of the
+//   cached sum (~1e-16); N is an integer count and exact either way.  Clears the dirty flags for the next pass.
+__global__ __launch_bounds__(256) void derive_rows_kernel(double *__restrict__ out, double *__restrict__ cache, const uint8_t *__restrict__ mode,
+                                                          uint8_t *__restrict__ dirty, int64_t stride, int K) {
+    const int k = blockIdx.y;
+    const int64_t e = blockIdx.x * 256ll + threadIdx.x;
+    const int m = mode[k];
+    if (e < stride) {
+        double *l = out + (int64_t)(2 * k) * stride, *r = l + stride, *c = cache + (int64_t)k * stride;
+        if (m == 0) c[e] = l[e] + r[e];
+        else if (m == 1) l[e] = c[e] - r[e];
+        else r[e] = c[e] - l[e];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { dirty[k] = 0; if (k == 0) dirty[DPMM_MAX_CLUSTERS_K] = 0; }
+    (void)K;
+}
+hipError_t launch_derive_rows(double *out, double *cache, const uint8_t *mode, uint8_t *dirty, int64_t stride, int K, hipStream_t s) {
+    hipLaunchKernelGGL(derive_rows_kernel, dim3((unsigned)((stride + 255) / 256), K), dim3(256), 0, s, out, cache, mode, dirty, stride, K);
+    return hipGetLastError();
+}
+
 hipError_t launch_sort_by_bin(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s) {
     const int nt = (int)((n + SORT_TILE - 1) / SORT_TILE);
     if (nt == 0) return hipSuccess;
-    hipLaunchKernelGGL(hist_kernel, dim3(nt), dim3(64), nbins * sizeof(int), s, bins, n, nbins, nt, b.tile_cnt, (int32_t *)nullptr);
+    hipLaunchKernelGGL(hist_kernel, dim3(nt), dim3(64), nbins * sizeof(int), s, bins, n, nbins, nt, b.tile_cnt, (int32_t *)nullptr,
+                       (uint16_t *)nullptr, (uint8_t *)nullptr);
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(nbins), dim3(256), 0, s, b.tile_cnt, b.tile_hist, nt, b.bin_total);
     return hipGetLastError();
 }
@@ -328,7 +394,8 @@ hipError_t launch_sort_by_bin(const int32_t *bins, int64_t n, int nbins, const S
 // launch_step_reset (flags, sub-label reset, re-count of the touched tiles) -> launch_step_scan_scatter (scan + starts, scatter).
 hipError_t launch_step_hist(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s) {
     const int nt = (int)((n + SORT_TILE - 1) / SORT_TILE);
-    hipLaunchKernelGGL(hist_kernel, dim3(nt), dim3(64), nbins * sizeof(int), s, bins, n, nbins, nt, b.tile_cnt, b.fast_total);
+    hipLaunchKernelGGL(hist_kernel, dim3(nt), dim3(64), nbins * sizeof(int), s, bins, n, nbins, nt, b.tile_cnt, b.fast_total,
+                       b.prev_lab, b.prev_lab ? b.cdirty : (uint8_t *)nullptr);
     return hipGetLastError();
 }
 hipError_t launch_step_reset(int32_t *bins, int64_t n, int64_t first, int nbins, const SortBufs &b, const long long *global_counts, uint8_t *flags,
@@ -884,10 +951,11 @@ hipError_t launch_mult_stats(const StatsArgs &a, hipStream_t s) {
 }
 
 // second half of the sort (needs the selection mask and the chunk size of the statistics pass)
-hipError_t launch_step_scan_scatter(const int32_t *bins, const StatsArgs &a, hipStream_t s) {
+hipError_t launch_step_scan_scatter(const int32_t *bins, const StatsArgs &a, int derive, int force_all, hipStream_t s) {
     const int nt = (int)((a.n + SORT_TILE - 1) / SORT_TILE);
     hipLaunchKernelGGL(scan_starts_kernel, dim3(a.nbins), dim3(256), 0, s, a.sb.tile_cnt, a.sb.tile_hist, nt, a.sb.bin_total, a.sb.bin_sel, a.chunk,
-                       a.sb.bin_start, a.sb.item_start, a.sb.perm_total, a.sb.fast_total, a.sb.ticket);
+                       a.sb.bin_start, a.sb.item_start, a.sb.perm_total, a.sb.fast_total, a.sb.ticket,
+                       derive ? a.sb.cmode : (uint8_t *)nullptr, a.sb.cdirty, force_all);
     hipLaunchKernelGGL(scatter_kernel, dim3(nt), dim3(64), a.nbins * sizeof(int), s, bins, a.n, a.nbins, nt,
                        a.sb.tile_hist, a.sb.bin_start, a.sb.perm);
     return hipGetLastError();

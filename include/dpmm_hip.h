@@ -68,6 +68,9 @@ enum {
     DPMM_OPT_SWEEP_GRID = 12,     /* workgroups of the sweep kernels, at most the default (compute units x resident workgroups per unit); experiments */
     DPMM_OPT_SWEEP_QUEUE_ROUNDS = 13, /* D <= 64 NIW sweep: the last rounds of tiles handed out through the queue; -1 (default): rounds / 8, at least 2, none below 4 rounds; 0: static schedule */
     DPMM_OPT_BALL_SCREEN = 14,        /* 1 (default): cluster-per-lane ball test in front of the per-point 4-row tail screen of the NIW sweeps; 0: per-point screens only (same labels) */
+    DPMM_OPT_STATS_DERIVE = 16,       /* 1 (default): the per-step statistics pass computes only the SMALLER sub-cluster of every cluster no point entered or
+                                         left since its cluster-level statistics were cached, and takes the other one as cache - computed (Float64; the
+                                         derived side is the larger one); 0: both sub-clusters of every cluster, every pass */
     DPMM_OPT_KERNEL_TIMING = 15,      /* bit mask: 1 = HIP events around the sweep kernel, 2 = around the statistics pass (dpmm_last_kernel_ms), 4 = around the
                                          all-reduces (dpmm_last_comm_ms); 0 (default): none -- every event is a barrier packet between two kernels, ~5 us each */
     DPMM_OPT_WAVE_PRIO = 10       /* 0 / 1: NIW sweep (D <= 64) lowers a wave's issue priority while it streams matrix instructions and

@@ -19,13 +19,22 @@ s.start_from_labels(y, 1 + np.random.default_rng(0).integers(0, 2, N), K)
 for _ in range(10):
     s.group_step(False, False)
 res = {va: [], vb: []}
+st = {va: [], vb: []}
+wall = {va: [], vb: []}
 for r in range(rounds):
     for v in (va, vb):
         wk.set_option(opt, v)
-        s.group_step(False, False)
-        ms = []
+        s.group_step(False, False); s.group_step(False, False)
+        ms, ss = [], []
         for _ in range(5):
-            s.group_step(False, False); ms.append(wk.last_kernel_ms()[0])
-        res[v].append(float(np.median(ms)))
+            s.group_step(False, False); a, b = wk.last_kernel_ms(); ms.append(a); ss.append(b)
+        res[v].append(float(np.median(ms))); st[v].append(float(np.median(ss)))
+        wk.set_timing(False); wk.sync()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            s.group_step(False, False)
+        wk.sync(); wall[v].append((time.perf_counter() - t0) / 20 * 1e3)
+        wk.set_timing(True)
 for v in (va, vb):
-    print(f"option {opt} = {v}: sweep kernel median {np.median(res[v]):.4f} ms  min {np.min(res[v]):.4f}  rounds {np.round(res[v], 4).tolist()}")
+    print(f"option {opt} = {v}: sweep kernel median {np.median(res[v]):.4f} ms  min {np.min(res[v]):.4f}  rounds {np.round(res[v], 4).tolist()}; "
+          f"statistics pass median {np.median(st[v]):.4f} ms; step without timing events median {np.median(wall[v]):.4f} ms  rounds {np.round(wall[v], 4).tolist()}")

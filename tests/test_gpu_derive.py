@@ -1,0 +1,123 @@
+"""The per-step statistics pass computes only the SMALLER sub-cluster of every cluster that no point entered or left since its
+cluster-level statistics were cached, and derives the other one as cache - computed (DPMM_OPT_STATS_DERIVE; the reference recomputes
+all three statistics of every cluster from scratch each sweep, src/local_clusters_actions.jl:149-169, src/priors/niw.jl:42-51).
+
+Bar: the rows a per-step pass hands over equal a from-scratch Float64 pass over the same labels (the oracle, and the library's own
+full pass) to rtol 1e-12 -- through label changes by sweeps, relabel operations (split / merge / remove-empty / set_labels), changes of K,
+a new upload, a second context state; N counts exact."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from test_gpu_niw import make_problem, gpu_worker
+import test_gpu_mult as tm
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    from __graft_entry__ import load_package
+    return load_package()
+
+
+def _check(wk, X, D, K, tag, niw=True):
+    """step_stats (derive on) against the oracle's statistics of the labels it leaves behind, and against the library's full pass."""
+    packed, bad = wk.step_stats(reset_epoch=1000 + len(tag))
+    lab, sub = wk.get_labels()
+    if niw:
+        N, s, S = wk.unpack(packed, K)
+        oN, os_, oS = orc.suffstats_niw(X, D, lab, sub, K)
+        assert np.array_equal(N, oN), tag
+        np.testing.assert_allclose(s, os_, rtol=1e-12, atol=1e-9, err_msg=tag)
+        np.testing.assert_allclose(S, oS, rtol=1e-12, atol=1e-9, err_msg=tag)
+    else:
+        N, s = wk.unpack(packed, K)
+        oN, os_ = orc.suffstats_mult(X, D, lab, sub, K)
+        assert np.array_equal(N, oN) and np.array_equal(s, os_), tag          # integer-valued sums: exact either way
+    full = wk.suffstats_packed(None)
+    np.testing.assert_allclose(packed, full, rtol=1e-12, atol=1e-9, err_msg=tag)
+    return lab, sub, bad
+
+
+@pytest.mark.parametrize("D,n,K", [(64, 30000, 6), (16, 9000, 4), (130, 6000, 3)])
+def test_derived_rows_follow_every_label_change(pkg, D, n, K):
+    from dpmmsubclusters_jl_amd import binding
+    P = make_problem(D, n, K, seed=300 + D, sep=1.5)
+    rng = np.random.default_rng(D)
+    wk = gpu_worker(pkg, P, seed=17)
+    X = P["X"]
+    lab0 = rng.integers(1, K + 1, n); sub0 = 1 + (rng.random(n) < 0.2).astype(np.int64)      # unbalanced sub-clusters
+    wk.set_labels(lab0, sub0)
+    _check(wk, X, D, K, "first pass (every cluster computed in full)")
+    _check(wk, X, D, K, "second pass, nothing changed (every larger sub-cluster derived)")
+    # sub-labels change, labels do not: still derived
+    wk.set_labels(lab0, 1 + (rng.random(n) < 0.7).astype(np.int64))
+    _check(wk, X, D, K, "sub-labels changed")
+    # a real sweep moves labels
+    wk.set_params_niw(P["mu"], P["invS"], P["logdet"], P["lr"], P["w"])
+    wk.sweep(3)
+    lab, sub, _ = _check(wk, X, D, K, "after a sweep")
+    wk.sweep(4)
+    _check(wk, X, D, K, "after a second sweep (few labels move)")
+    # a handful of points swap clusters: counts per cluster unchanged, membership not
+    lab, sub = wk.get_labels()
+    i, j = np.flatnonzero(lab == 1)[:5], np.flatnonzero(lab == 2)[:5]
+    lab2 = lab.copy(); lab2[i] = 2; lab2[j] = 1
+    wk.set_labels(lab2, sub)
+    _check(wk, X, D, K, "five points swapped between clusters 1 and 2")
+    # relabel operations
+    wk.set_num_clusters(K + 1)
+    wk.split(np.array([2]), np.array([K + 1]), epoch=9)
+    _check(wk, X, D, K + 1, "after a split")
+    _check(wk, X, D, K + 1, "pass after the split pass")
+    wk.merge(np.array([1]), np.array([3]))
+    _check(wk, X, D, K + 1, "after a merge (cluster 3 empty)")
+    lab, _ = wk.get_labels()
+    cnt = np.bincount(lab, minlength=K + 2)[1:K + 2]
+    wk.remove_empty(cnt)
+    wk.set_num_clusters(K)
+    _check(wk, X, D, K, "after remove_empty (labels renumbered, K shrank)")
+    _check(wk, X, D, K, "pass after remove_empty")
+    # the option off gives the same rows; back on re-caches
+    wk.set_option(binding.OPT_STATS_DERIVE, 0)
+    _check(wk, X, D, K, "option off")
+    wk.set_option(binding.OPT_STATS_DERIVE, 1)
+    _check(wk, X, D, K, "option on again")
+    _check(wk, X, D, K, "and derived")
+    # new points under the same labels: the cache must not survive
+    X2 = (X + np.float32(0.5)).astype(np.float32)
+    wk.upload_points(X2)
+    _check(wk, X2, D, K, "after a new upload")
+    wk.close()
+
+
+def test_derived_rows_multinomial(pkg):
+    D, n, K = 200, 8000, 5
+    P = tm.make_problem(D, n, K, 40, seed=9)
+    wk = tm.worker(pkg, P, seed=3)
+    rng = np.random.default_rng(1)
+    wk.set_labels(rng.integers(1, K + 1, n), 1 + (rng.random(n) < 0.15).astype(np.int64))
+    _check(wk, P["X"], D, K, "first", niw=False)
+    _check(wk, P["X"], D, K, "second (derived)", niw=False)
+    wk.sweep(2)
+    _check(wk, P["X"], D, K, "after a sweep", niw=False)
+    _check(wk, P["X"], D, K, "again", niw=False)
+    wk.close()
+
+
+def test_bad_cluster_reset_and_derivation_together(pkg):
+    """A cluster whose right sub-cluster is empty is flagged, its sub-labels are re-drawn and -- its labels being unchanged -- its larger
+    half is derived from the cache in the same pass."""
+    D, n, K = 32, 12000, 4
+    P = make_problem(D, n, K, seed=77, sep=2.0)
+    rng = np.random.default_rng(5)
+    wk = gpu_worker(pkg, P, seed=23)
+    lab = rng.integers(1, K + 1, n); sub = rng.integers(1, 3, n)
+    wk.set_labels(lab, sub)
+    _check(wk, P["X"], D, K, "prime")
+    sub2 = sub.copy(); sub2[lab == 2] = 1
+    wk.set_labels(lab, sub2)
+    l2, s2, bad = _check(wk, P["X"], D, K, "cluster 2 one-sided")
+    assert bad[1] == 1 and bad.sum() == 1 and set(np.unique(s2[l2 == 2])) == {1, 2}
+    wk.close()

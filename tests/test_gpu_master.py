@@ -259,7 +259,11 @@ def test_engine_with_device_master_recovers_components(pkg, D, N, Kt):
         wh.close()
     # state access goes through the rows kept on the device
     packed = s.model.get("packed").reshape(s.K, 2, -1)
-    assert np.array_equal(packed, wk.suffstats_packed(None).reshape(s.K, 2, -1))
+    full = wk.suffstats_packed(None).reshape(s.K, 2, -1)
+    assert np.array_equal(packed[:, :, 0], full[:, :, 0])                # N: exact
+    # (the per-step pass derives the larger sub-cluster of an untouched cluster as cached cluster row - smaller sub-cluster: the same
+    # Float64 sums in another association than the full pass)
+    np.testing.assert_allclose(packed, full, rtol=1e-12, atol=1e-9)
     Nn = s.N
     assert np.array_equal(Nn[:, 0], np.bincount(lab, minlength=s.K + 1)[1:].astype(np.float64))
     assert np.isfinite(s.log_posterior())
