@@ -828,6 +828,12 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
     // wave-private [K][WPTS] table of a_k in LDS when it fits (A.lds_rows >= K), else the global scratch
     const bool tab_lds = FAST || (A.lds_rows >= K && !A.scratch_by_tile);
     float *ltab = lds_tab + (size_t)(tid >> 6) * A.lds_rows * WPTS + lane;
+    // K beyond the LDS budget (lds_rows < K): the rows go to the global scratch as before, and a COMPACT copy of the evaluated clusters'
+    // rows (lds_rows slots per wave, slot_of[k] names a cluster's slot) serves the draw of a screened tile -- which visits evaluated
+    // clusters only.  (Without it a K = 256 sweep spent 3 K dependent global accesses per point on -inf rows: 12.7 ms at N = 1e7.)
+    const bool compact = !FAST && !tab_lds && A.lds_rows > 0 && !A.scratch_by_tile;
+    uint8_t *slot_of = reinterpret_cast<uint8_t *>(lds_tab + (size_t)4 * A.lds_rows * WPTS + (A.screen_lds ? (size_t)K * (256 + 16) : 0)) +
+                       (size_t)(tid >> 6) * ((K + 3) & ~3);
     // screen operands of all K clusters (last fragment pair 1 KiB + last 16 means), staged once per workgroup
     float *scrA = lds_tab + (size_t)4 * A.lds_rows * WPTS;
     float *scrM = scrA + (size_t)K * 256;
@@ -955,9 +961,16 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
         f32x4 rb0[NB], mu[NB];
         int rb0_mat = -1;                       // matrix index whose row-block 0 / means sit in rb0 / mu (wave-uniform)
         float tot_all[NG];
+        int nev = 0;                            // clusters recorded for this tile (wave-uniform)
         auto record = [&](int k, float a) {     // table + running max / argmax bookkeeping for the owner lane
             if (tab_lds) ltab[k * WPTS] = a;
-            else if (valid) scr[(int64_t)k * sstride] = a;
+            else {
+                if (valid) scr[(int64_t)k * sstride] = a;
+                if (compact && screening) {
+                    if (nev < A.lds_rows) { ltab[nev * WPTS] = a; if (lane == 0) slot_of[k] = (uint8_t)nev; }
+                    ++nev;
+                }
+            }
             if (a != a) {
                 if (!nan_seen || k < best) { nan_seen = true; best = k; }   // Julia's argmax: the first NaN wins
             } else if (a > m_run || (a == m_run && k < best && !nan_seen && m_run != -INFINITY)) {
@@ -993,8 +1006,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
             STAMP(q0);
             // rows of skipped clusters: the LDS-table draw visits evaluated clusters only (eval_bits), the global-table
             // draw scans all K rows and needs -inf there
-            if (!tab_lds && valid)
-                for (int k = 0; k < K; ++k) scr[(int64_t)k * sstride] = -INFINITY;
+            // (the global-table draw of a screened tile visits evaluated clusters only as well: no -inf rows to write)
             bool pvalid[NG];
 #pragma unroll
             for (int n = 0; n < NG; ++n) pvalid[n] = wbase + 16 * n + ci < A.n;
@@ -1275,6 +1287,27 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                 // is that k -- unless cw >= t already held BEFORE the first evaluated cluster (t == 0): then k = 0.
                 if (t <= 0.f) z = 0;
                 (void)last;
+            } else if (screening) {
+                // table in the global scratch (K beyond the LDS budget): evaluated clusters only, in index order, from the compact LDS copy
+                // when all of them found a slot, else from the scratch rows -- same values, same order, same arithmetic as above
+                const uint32_t *ev = eval_bits[tid >> 6];
+                const int nw = (K + 31) >> 5;
+                const bool from_lds = compact && nev <= A.lds_rows;
+                auto val = [&](int k) -> float { return from_lds ? ltab[(int)slot_of[k] * WPTS] : scr[(int64_t)k * sstride]; };
+                float s = 0.f;
+                for (int w = 0; w < nw; ++w)
+                    for (uint32_t bb = ev[w]; bb; bb &= bb - 1u) s += exp_det(nan_to_ninf(val((w << 5) + __builtin_ctz(bb))) - m_run);
+                const float t = u01(r.v[0]) * s;
+                float cw = 0.f;
+                z = K - 1;
+                bool found = false;
+                for (int w = 0; w < nw && !found; ++w)
+                    for (uint32_t bb = ev[w]; bb; bb &= bb - 1u) {
+                        const int k = (w << 5) + __builtin_ctz(bb);
+                        cw += exp_det(nan_to_ninf(val(k)) - m_run);
+                        if (!(cw < t)) { z = k; found = true; break; }
+                    }
+                if (t <= 0.f) z = 0;
             } else if (tab_lds) {
                 // same arithmetic, same order as the global-table path (and the CPU oracle); 4 table reads in flight
                 float s = 0.f;
@@ -1362,11 +1395,14 @@ static hipError_t launch_direct(const NiwSweepArgs &a, int grid, hipStream_t s) 
     // a_k table in LDS: the CU's 160 KiB split over OCC resident workgroups of 4 waves
     NiwSweepArgs b = a;
     const int budget_rows = (int)((160 * 1024 / OCC - 512) / (4 * 16 * NG * sizeof(float)));
-    b.lds_rows = a.K <= budget_rows ? a.K : 0;
+    // K beyond the budget: min(64, budget / 2) compact slots per wave for the evaluated clusters of a screened tile (+ K slot bytes per wave)
+    b.lds_rows = a.K <= budget_rows ? a.K : (a.scratch_by_tile ? 0 : std::min(64, budget_rows / 2));
     size_t lds_bytes = (size_t)b.lds_rows * 4 * 16 * NG * sizeof(float);
     const size_t screen_bytes = (size_t)a.K * (256 + 16) * sizeof(float);
-    b.screen_lds = (NB >= 2 && a.screen_margin > 0.f && lds_bytes + screen_bytes + 1024 <= (size_t)(160 * 1024 / OCC)) ? 1 : 0;
+    const size_t slot_bytes = a.K > budget_rows ? 4 * (size_t)((a.K + 3) & ~3) : 0;
+    b.screen_lds = (NB >= 2 && a.screen_margin > 0.f && lds_bytes + screen_bytes + slot_bytes + 1024 <= (size_t)(160 * 1024 / OCC)) ? 1 : 0;
     if (b.screen_lds) lds_bytes += screen_bytes;
+    lds_bytes += slot_bytes;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void *)niw_sweep_direct_kernel<NB, NG, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / OCC);

@@ -8,7 +8,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 case $WHAT in
-  bench) SHORT="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-growth --no-dense --blocks 0";;
+  bench) SHORT="python3 bench.py --steps 5 --warmup 1 --settle 10 --no-cpu-baseline --no-growth --no-dense --no-legs --blocks 0";;
   d256)  SHORT="python3 scripts/config_step.py niw 256 625000 5";;
   d128)  SHORT="python3 scripts/config_step.py niw 128 1250000 5";;
   mult)  SHORT="python3 scripts/config_step.py mult 1000 1000000 5";;
