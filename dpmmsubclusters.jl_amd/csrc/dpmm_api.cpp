@@ -499,17 +499,25 @@ static int finish_upload(dpmm_ctx *c) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
             c->x_u8 = (h == 0) ? 1 : 0;
             if (!c->x_u8) { hipFree(c->dX8); c->dX8 = nullptr; }
+            // every Multinomial kernel of a byte-path context reads the byte copy (a lossless re-encoding): the Float32 matrix (4 bytes per
+            // element, 4 GB at D = 1000, N = 1e6) is dead weight from here on; a new upload allocates it again
+            else { HIPCHK(c, hipFree(c->dX)); c->dX = nullptr; }
         }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return DPMM_OK;
 }
 
+static int ensure_points_buffer(dpmm_ctx *c) {       // (a byte-path Multinomial context gave its Float32 matrix back)
+    if (!c->dX) HIPCHK(c, hipMalloc(&c->dX, sizeof(float) * (size_t)std::max<int64_t>(c->n, 1) * (size_t)c->ldx));
+    return DPMM_OK;
+}
 static int upload_common(dpmm_ctx *c, const float *X, int64_t ldx, hipMemcpyKind kind) {
     if (!c) return DPMM_EINVAL;
     if (!X && c->n > 0) return fail(c, DPMM_EINVAL, "X is null");
     if (ldx < c->D) return fail(c, DPMM_EINVAL, "ldx < D");
     HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = ensure_points_buffer(c)) return rc;
     if (c->n > 0) {
         if (c->ldx != c->D) HIPCHK(c, hipMemsetAsync(c->dX, 0, sizeof(float) * (size_t)c->n * c->ldx, c->stream));
         HIPCHK(c, hipMemcpy2DAsync(c->dX, sizeof(float) * c->ldx, X, sizeof(float) * ldx, sizeof(float) * c->D, (size_t)c->n, kind, c->stream));
@@ -528,6 +536,7 @@ int dpmm_upload_points_npy(dpmm_ctx *c, const void *rows, int is_f64, int64_t ld
     if (!rows && c->n > 0) return fail(c, DPMM_EINVAL, "rows is null");
     if (ld < c->D) return fail(c, DPMM_EINVAL, "ld < D");
     HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = ensure_points_buffer(c)) return rc;
     if (c->n > 0) {
         if (c->ldx != c->D) HIPCHK(c, hipMemsetAsync(c->dX, 0, sizeof(float) * (size_t)c->n * c->ldx, c->stream));
         const size_t esz = is_f64 ? sizeof(double) : sizeof(float);
