@@ -121,3 +121,34 @@ def test_bad_cluster_reset_and_derivation_together(pkg):
     l2, s2, bad = _check(wk, P["X"], D, K, "cluster 2 one-sided")
     assert bad[1] == 1 and bad.sum() == 1 and set(np.unique(s2[l2 == 2])) == {1, 2}
     wk.close()
+
+
+@pytest.mark.parametrize("D,N,Kt", [(16, 40000, 6), (64, 60000, 5)])
+def test_engine_chain_with_and_without_derivation(pkg, D, N, Kt):
+    """The whole sampler from ONE initial cluster (labels move, clusters split, merge and are removed all the time while K grows), with the
+    derivation on and off: same K history, same labels, statistics equal to rounding.  D = 64 runs the device master on the derived rows."""
+    import importlib
+    from dpmmsubclusters_jl_amd import binding
+    host = importlib.import_module("dpmmsubclusters_jl_amd.host")
+    X, y = host.gaussian_mixture_shard(N, D, Kt, 100.0, 4321, 0, N)
+    prior = host.niw_hyperparams(1.0, np.zeros(D), D + 3, np.eye(D))
+    out = []
+    for derive in (1, 0):
+        wk = pkg.Worker(pkg.PRIOR_NIW, D, N, device=0, seed=11)
+        wk.upload_points(X)
+        wk.set_option(binding.OPT_STATS_DERIVE, derive)
+        s = host.DPMMSampler(wk, prior, 10.0, N, 11, burnout=5)
+        s.init_first_clusters(1)
+        kh = []
+        for it in range(90):
+            s.group_step(it >= 80, False)
+            kh.append(s.K)
+        lab, sub = wk.get_labels()
+        out.append((kh, lab, sub, s.model.get("packed"), s.log_posterior()))
+        wk.close()
+    (k1, l1, s1, p1, lp1), (k0, l0, s0, p0, lp0) = out
+    assert k1 == k0 and k1[-1] >= Kt - 1, (k1, k0)
+    assert int((l1 != l0).sum()) <= 2 and int((s1 != s0).sum()) <= 4
+    if np.array_equal(l1, l0) and np.array_equal(s1, s0):
+        np.testing.assert_allclose(p1, p0, rtol=1e-11, atol=1e-8)
+        assert abs(lp1 - lp0) <= 1e-9 * abs(lp0)
