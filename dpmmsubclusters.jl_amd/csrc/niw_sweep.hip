@@ -1252,6 +1252,13 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
 
         int z = 0;
         float u_sub = 0.f;
+        bool nev1 = false;                     // exactly one cluster was evaluated for this tile, and it is k0 (wave-uniform)
+        if (tab_lds && screening) {
+            const uint32_t *evw = eval_bits[tid >> 6];
+            int cntb = 0;
+            for (int w = 0; w < ((K + 31) >> 5); ++w) cntb += __builtin_popcount(__builtin_amdgcn_readfirstlane(evw[w]));
+            nev1 = cntb == 1;
+        }
         if (valid) {
             const Philox4 r = philox4x32_10(A.seed, (uint64_t)(A.first_index + myp), A.epoch, STREAM_SWEEP);
             u_sub = u01(r.v[1]);
@@ -1259,6 +1266,11 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                 z = best;
             } else if (m_run == -INFINITY) {
                 z = 0;
+            } else if (tab_lds && screening && nev1) {
+                // ONE evaluated cluster (the usual tile of well-separated data: every other cluster was excluded for the whole wave) and
+                // its value is finite here: the row sum is exp(0) = 1, the scan stops at that cluster -- or at index 0 when u == 0, as the
+                // full scan does (its threshold 0 is met before anything is added)
+                z = (u01(r.v[0]) <= 0.f) ? 0 : k0;
             } else if (tab_lds && screening) {
                 // skipped clusters hold -inf and contribute exact zeros: visit only the evaluated ones, in index order
                 // (bit-identical to the full scan)
