@@ -28,7 +28,7 @@ Besides the contract fields the JSON line carries
   growth        a run of the same data from ONE initial cluster (`init_clusters=1`): it/s, K history, final log-posterior, NMI;
   legs          (1 GPU only; `--no-legs` skips) short steady-state runs of the other shapes, each with its own roofline entry:
                 `overlap_var4` / `overlap_var1` (the headline shape with the component means drawn with MixtureVar 4 and 1
-                instead of 100: the middle of the screening range), `k256` (256 components instead of 32), `c3_shard` (what each of
+                instead of 100: the middle of the screening range), `k256` (256 components instead of 32), `c2` (N=10^6), `c3_shard` (what each of
                 8 GPUs holds of the headline),
                 `c4` (Multinomial D=1000, N=10^6), `c5_shard` (NIW D=256, n=6.25e5), and `shard8_projection`;
   cpu_baseline  the reference algorithm's worker path on the host cores, P worker processes (see oracle/cpu_baseline.py).
@@ -67,7 +67,7 @@ def parse_args():
     ap.add_argument("--no-growth", action="store_true")
     ap.add_argument("--no-dense", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the other-shape legs (overlap, c3_shard, c4, c5_shard)")
-    ap.add_argument("--legs", default="overlap_var4,overlap_var1,k256,c3_shard,c4,c5_shard", help="comma-separated subset of the legs")
+    ap.add_argument("--legs", default="overlap_var4,overlap_var1,k256,c2,c3_shard,c4,c5_shard", help="comma-separated subset of the legs")
     ap.add_argument("--growth-iters", type=int, default=260)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-clock budget of the CPU baseline sample")
     ap.add_argument("--share-gpu", action="store_true",
@@ -230,6 +230,15 @@ def run_legs(args, pkg, host, torch, one_gpu_ms):
         r["workload"] = "headline shape with 256 true components (NIW D=64 N=1e7, MixtureVar 100): K_t = 256 live clusters, 32 640 merge pairs per step"
         r["roofline"] = niw_roofline(r["n"], D, r["K_t"], r["sweep_kernel_ms"], work)
         legs["k256"] = r
+        del X
+        torch.cuda.empty_cache()
+    if "c2" in want:
+        n = 10 ** 6
+        X, y = gpu_gaussian_mixture(host, torch, n, D, K, 100.0, DATA_SEED)
+        r, work = steady_state(pkg, host, torch, pkg.PRIOR_NIW, niw64, X, y, K, 100, settle=60)
+        r["workload"] = "C2: NIW D=64, N=1e6, 32 true components, one GPU (steady state from the generator's labels)"
+        r["roofline"] = niw_roofline(n, D, r["K_t"], r["sweep_kernel_ms"], work)
+        legs["c2"] = r
         del X
         torch.cuda.empty_cache()
     if "c3_shard" in want:

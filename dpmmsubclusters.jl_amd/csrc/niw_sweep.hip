@@ -925,7 +925,12 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
         f32x4 x[NG][NB];
 #pragma unroll
         for (int n = 0; n < NG; ++n) {
+#ifdef DPMM_EXP_XCACHE       // experiment: every tile gathers from the first 4096 points (cache-resident X): what does the HBM gather cost?
+            const int pn0 = __shfl(myp32, 16 * n + ci);
+            const int pn = pn0 >= 0 ? (pn0 & 4095) : pn0;
+#else
             const int pn = __shfl(myp32, 16 * n + ci);
+#endif
 #pragma unroll
             for (int t = 0; t < NB; ++t) {
                 const int e = 16 * t + 4 * g;
