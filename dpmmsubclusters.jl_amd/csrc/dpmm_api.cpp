@@ -1036,7 +1036,8 @@ static int ensure_out(dpmm_ctx *c, size_t bytes) {
 
 // One statistics pass on the ctx stream (asynchronous): [sub-cluster occupancies -> bad-cluster reset ->] sort by bin ->
 // segmented statistics -> packed rows in c->d_out [-> all-reduce over the ranks].
-static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset = false, uint32_t reset_epoch = 0) {
+static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset = false, uint32_t reset_epoch = 0, uint8_t *flags_to = nullptr,
+                     bool *flags_sent = nullptr) {
     if (!c->have_points || !c->have_labels || c->K < 1) return fail(c, DPMM_ESTATE, "suffstats need points, labels and parameters (K)");
     HIPCHK(c, hipSetDevice(c->device));
     const int nbins = 2 * c->K;
@@ -1106,7 +1107,14 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
     if (c->prior == DPMM_PRIOR_NIW) HIPCHK(c, launch_niw_stats(a, c->stream));
     else if (c->x_u8) HIPCHK(c, launch_mult_stats_u8(a, c->dX8, c->ld8, c->stream));
     else HIPCHK(c, launch_mult_stats(a, c->stream));
-    if (derive) HIPCHK(c, launch_derive_rows(c->d_out, c->d_ccache, c->sb.cmode, c->sb.cdirty, c->packed_stride, c->K, c->stream));
+    if (flags_sent) *flags_sent = false;
+    if (derive) {
+        // (flags_to: the caller's pinned block for the bad-cluster flags -- they ride in this launch when no collective follows it)
+        const bool ride = flags_to != nullptr && !comm_attached(c);
+        const uint8_t *fsrc = reinterpret_cast<const uint8_t *>(c->d_out) + sizeof(double) * (size_t)nbins * (size_t)c->packed_stride;
+        HIPCHK(c, launch_derive_rows(c->d_out, c->d_ccache, c->sb.cmode, c->sb.cdirty, c->packed_stride, c->K, fsrc, ride ? flags_to : nullptr, c->stream));
+        if (ride && flags_sent) *flags_sent = true;
+    }
     if (comm_attached(c)) {
         // the one exchange of the sweep: elementwise sum of the per-worker statistics (update_suff_stats_posterior!,
         // local_clusters_actions.jl:206-254; aggregate_suff_stats); N counts travel as Float64 integers (exact below 2^53)
@@ -1394,8 +1402,9 @@ int dpmm_step_master_device(dpmm_ctx *c, uint32_t reset_epoch, const int32_t *sl
         if (!fuse_pairs) if (int rc = device_list(c, c->d_apairs, c->apairs_shadow, c->apairs_req.data(), c->apairs_req.size(), c->stream2)) return rc;
     } else fuse_pairs = false;
     double *sm = reinterpret_cast<double *>(c->h_master + jobs_bytes);
-    if (int rc = run_stats(c, nullptr, 0, true, reset_epoch)) return rc;
-    HIPCHK(c, launch_copy_bytes(c->h_out, reinterpret_cast<const uint8_t *>(c->d_out) + out_bytes, (size_t)K + 1, c->stream));
+    bool flags_sent = false;
+    if (int rc = run_stats(c, nullptr, 0, true, reset_epoch, reinterpret_cast<uint8_t *>(c->h_out), &flags_sent)) return rc;
+    if (!flags_sent) HIPCHK(c, launch_copy_bytes(c->h_out, reinterpret_cast<const uint8_t *>(c->d_out) + out_bytes, (size_t)K + 1, c->stream));
     if (napairs > 0 && fuse_pairs) {
         // posteriors + the pooled pair log-determinants the master may ask for (dpmm_niw_master_pairs_ahead) in ONE launch: the pairs need
         // the rows of this pass only.  (On the second stream behind the posteriors they reached the host 12 + 26 us later.)

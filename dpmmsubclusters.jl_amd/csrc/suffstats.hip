@@ -364,7 +364,10 @@ __global__ __launch_bounds__(64) void scatter_kernel(const int32_t *__restrict__
 //   mode[k] = 1 / 2: left / right = cache[k] - the computed row.  The derived side is the LARGER one: its relative error is that of the
 //   cached sum (~1e-16); N is an integer count and exact either way.  Clears the dirty flags for the next pass.
 __global__ __launch_bounds__(256) void derive_rows_kernel(double *__restrict__ out, double *__restrict__ cache, const uint8_t *__restrict__ mode,
-                                                          uint8_t *__restrict__ dirty, int64_t stride, int K) {
+                                                          uint8_t *__restrict__ dirty, int64_t stride, int K,
+                                                          const uint8_t *__restrict__ flags_src, uint8_t *__restrict__ flags_dst) {
+    // rider: the bad-cluster flags of the pass go to the host's pinned block from here (one launch less than a copy kernel of their own)
+    if (flags_dst && blockIdx.x == 0 && blockIdx.y == 0) for (int i = threadIdx.x; i <= K; i += 256) flags_dst[i] = flags_src[i];
     const int k = blockIdx.y;
     const int64_t e = blockIdx.x * 256ll + threadIdx.x;
     const int m = mode[k];
@@ -375,10 +378,10 @@ __global__ __launch_bounds__(256) void derive_rows_kernel(double *__restrict__ o
         else r[e] = c[e] - l[e];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { dirty[k] = 0; if (k == 0) dirty[DPMM_MAX_CLUSTERS_K] = 0; }
-    (void)K;
 }
-hipError_t launch_derive_rows(double *out, double *cache, const uint8_t *mode, uint8_t *dirty, int64_t stride, int K, hipStream_t s) {
-    hipLaunchKernelGGL(derive_rows_kernel, dim3((unsigned)((stride + 255) / 256), K), dim3(256), 0, s, out, cache, mode, dirty, stride, K);
+hipError_t launch_derive_rows(double *out, double *cache, const uint8_t *mode, uint8_t *dirty, int64_t stride, int K, const uint8_t *flags_src,
+                              uint8_t *flags_dst, hipStream_t s) {
+    hipLaunchKernelGGL(derive_rows_kernel, dim3((unsigned)((stride + 255) / 256), K), dim3(256), 0, s, out, cache, mode, dirty, stride, K, flags_src, flags_dst);
     return hipGetLastError();
 }
 
