@@ -59,15 +59,21 @@ __global__ __launch_bounds__(64) void hist_kernel(const int32_t *__restrict__ bi
 #pragma unroll
         for (int it = 0; it < SORT_TILE / 256; ++it) v[it] = src[it * 64 + lane];
         if (prev_lab) {
-            const uint2 *psrc = reinterpret_cast<const uint2 *>(prev_lab + base);         // four 16-bit labels per lane and trip
+            // four 16-bit labels per lane and trip, all loads in flight with the bins'; ONE wave-level test for the whole tile (nothing
+            // moved: the usual case) in front of the per-point bookkeeping
+            const uint2 *psrc = reinterpret_cast<const uint2 *>(prev_lab + base);
             uint2 pv[SORT_TILE / 256];
 #pragma unroll
             for (int it = 0; it < SORT_TILE / 256; ++it) pv[it] = psrc[it * 64 + lane];
+            unsigned diff = 0u;
 #pragma unroll
             for (int it = 0; it < SORT_TILE / 256; ++it) {
                 const unsigned a0 = (unsigned)v[it].x >> 1, a1 = (unsigned)v[it].y >> 1, a2 = (unsigned)v[it].z >> 1, a3 = (unsigned)v[it].w >> 1;
-                const bool same4 = (pv[it].x == (a0 | (a1 << 16))) && (pv[it].y == (a2 | (a3 << 16)));
-                if (!same4) {
+                diff |= (pv[it].x ^ (a0 | (a1 << 16))) | (pv[it].y ^ (a2 | (a3 << 16)));
+            }
+            if (__any(diff != 0u)) {
+#pragma unroll
+                for (int it = 0; it < SORT_TILE / 256; ++it) {
                     const int64_t i0 = base + (int64_t)(it * 64 + lane) * 4;
                     track(i0, v[it].x); track(i0 + 1, v[it].y); track(i0 + 2, v[it].z); track(i0 + 3, v[it].w);
                 }
