@@ -718,10 +718,17 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
 // fragments of the next row-block (or of row-block 0 of the next matrix, plus its mu) are in
 // flight.  On entry rb0/mu hold row-block 0 and mu of THIS matrix; on exit those of Rnext.
 #define DPMM_PRIO_ARG prio
-template <int NB, int NG>
+// EARLY (survivors of the screens only): after the FIRST row block -- rows 0..15 of y = R z, the rows that see every feature and, for an
+// ill-conditioned Sigma, carry most of the quadratic form (R_ii^2 is the precision of feature i GIVEN the features behind it: largest at
+// the top; the last rows, which the cheap screens use, are marginal precisions) -- the partial sum is a lower bound of q: if
+// cst - q_partial / 2 is below thr[n] for every point, the cluster is excluded after 64 + 4 matrix instructions instead of 164 + 4 and
+// *excluded is set (rb0 / mu then still hold THIS matrix's first row block: the caller reloads).  The accumulation chain of q is the one
+// of the plain evaluation, so a cluster that is not excluded gets bit-identical values.
+template <int NB, int NG, bool EARLY = false>
 __device__ __forceinline__ float quad_stream(const float *__restrict__ Rm, const float *__restrict__ Rnext,
                                              const float *__restrict__ mup_next, f32x4 (&rb0)[NB], f32x4 (&mu)[NB],
-                                             const f32x4 (&x)[NG][NB], int lane, int g, bool active, float (&tot_all)[NG], int prio = 0) {
+                                             const f32x4 (&x)[NG][NB], int lane, int g, bool active, float (&tot_all)[NG], int prio = 0,
+                                             float cst = 0.f, const float *thr = nullptr, bool *excluded = nullptr) {
     float q[NG];
 #pragma unroll
     for (int n = 0; n < NG; ++n) q[n] = 0.f;
@@ -776,6 +783,21 @@ __device__ __forceinline__ float quad_stream(const float *__restrict__ Rm, const
                 q[n] = __builtin_fmaf(acc[n][1], acc[n][1], q[n]);
                 q[n] = __builtin_fmaf(acc[n][2], acc[n][2], q[n]);
                 q[n] = __builtin_fmaf(acc[n][3], acc[n][3], q[n]);
+            }
+        }
+        if constexpr (EARLY && NB > 1) {
+            if (bi == 0) {
+                bool out = true;
+#pragma unroll
+                for (int n = 0; n < NG; ++n) {
+                    const f32x4 tot = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, q[n], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    out = out && (__builtin_fmaf(-0.5f, tot[0], cst) < thr[n]);       // thr[n] = +inf for columns without a point
+                }
+                if (__all(out)) {
+                    *excluded = true;
+                    if (DPMM_PRIO_ARG) __builtin_amdgcn_s_setprio(2);
+                    return 0.f;
+                }
             }
         }
     }
@@ -1245,7 +1267,28 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
             if (kc >= 0) load_rb0<NB>(A.Rp + (size_t)(3 * kc) * MATSZ, A.mup + (size_t)(3 * kc) * DP, rb0, mu, lane, g);
             while (kc >= 0) {
                 const int kn = next_surv();
-                full_eval(kc, kn >= 0 ? A.Rp + (size_t)(3 * kn) * MATSZ : Rl0, kn >= 0 ? A.mup + (size_t)(3 * kn) * DP : ml0);
+                const float *Rn = kn >= 0 ? A.Rp + (size_t)(3 * kn) * MATSZ : Rl0;
+                const float *mn = kn >= 0 ? A.mup + (size_t)(3 * kn) * DP : ml0;
+                // evaluation with an exit after the first row block (see quad_stream<.., EARLY>): thresholds against the best value so far
+                float thr4[NG];
+#pragma unroll
+                for (int n = 0; n < NG; ++n) thr4[n] = pvalid[n] ? bestn[n] - margin : INFINITY;
+                const float c = A.cst[3 * kc];
+                bool excl = false;
+                const float qs = quad_stream<NB, NG, true>(A.Rp + (size_t)(3 * kc) * MATSZ, Rn, mn, rb0, mu, x, lane, g, true, tot_all, A.prio, c, thr4, &excl);
+                if (excl) {
+                    nw_scr += 4;                                              // (64 + 4 matrix instructions: four 16-row screens' worth)
+                    if (lane == 0) ev[kc >> 5] &= ~(1u << (kc & 31));        // never recorded: the draw does not visit it
+                    if (Rn) load_rb0<NB>(Rn, mn, rb0, mu, lane, g);
+                } else {
+                    ++nw_full;
+#pragma unroll
+                    for (int n = 0; n < NG; ++n) {
+                        const float an = __builtin_fmaf(-0.5f, tot_all[n], c);
+                        if (an > bestn[n]) bestn[n] = an;
+                    }
+                    record(kc, __builtin_fmaf(-0.5f, qs, c));
+                }
                 kc = kn;
             }
             STAMP(q1);
