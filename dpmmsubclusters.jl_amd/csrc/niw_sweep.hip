@@ -482,13 +482,25 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
                     if (g == n) xt = v;                        // owner lane 16 n + ci holds point (n, ci)
                 }
             }
-            for (int pr = 0; 2 * pr < K; ++pr) {
-                ++nw_tail;
-                const unsigned far2 = tail_pair_far(tail_load_pair(A.tail, pr), xt, my_thr);
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const int k = 2 * pr + c;
-                    if (k < K && k != k0 && k != k1 && !((far2 >> c) & 1u) && lane == 0) atomicOr(&survm[k >> 5], 1u << (k & 31));
+            // cluster-per-lane ball test first (see ball_far: the wave's points lie in a ball around the tail mean of the first reference
+            // cluster), then the per-point pair screen for the clusters it leaves -- as in the D <= 64 kernel
+            BallWave ball; ball.ok = false;
+            if (A.ball) ball = ball_of_wave(A.tail, K, k0, xt, my_thr, valid);
+            for (int base = 0; base < K; base += 64) {
+                unsigned long long cand = (K - base >= 64) ? ~0ull : ((1ull << (K - base)) - 1ull);
+                if (k0 >= base && k0 < base + 64) cand &= ~(1ull << (k0 - base));
+                if (k1 >= base && k1 < base + 64) cand &= ~(1ull << (k1 - base));
+                if (ball.ok) cand &= ~ball_far(A.tail, K, base, lane, ball);
+                for (unsigned long long pend = cand; pend;) {
+                    const int sh = __builtin_ctzll(pend) & ~1;
+                    pend &= ~(3ull << sh);
+                    ++nw_tail;
+                    cand &= ~((unsigned long long)tail_pair_far(tail_load_pair(A.tail, (base + sh) >> 1), xt, my_thr) << sh);
+                }
+                if (lane == 0) {
+                    const uint32_t lo = (uint32_t)cand, hi = (uint32_t)(cand >> 32);
+                    if (lo) atomicOr(&survm[base >> 5], lo);
+                    if (hi) atomicOr(&survm[(base >> 5) + 1], hi);
                 }
             }
             __syncthreads();
