@@ -191,7 +191,11 @@ int dpmm_suffstats_host(dpmm_ctx *ctx, const int64_t *cluster_idx, int n_idx, co
 /* Steps 5 + 6 of group_step (local_clusters_actions.jl:665-666) in ONE device pass without a host round trip in between:
  * sub-cluster occupancies (summed over the ranks) -> clusters with an empty sub-cluster are flagged and the sub-labels of
  * their points re-drawn with `reset_epoch` (reset_bad_clusters!, :501-516) -> statistics of all K clusters over the final
- * labelling (summed over the ranks).  *packed as dpmm_suffstats_host, *bad [K] flags; blocks until both are in host memory. */
+ * labelling (summed over the ranks).  *packed as dpmm_suffstats_host, *bad [K] flags; blocks until both are in host memory.
+ * With DPMM_OPT_STATS_DERIVE (default) the pass accumulates only the SMALLER sub-cluster of every cluster whose membership did not
+ * change since its cluster-level row was cached (the histogram tracks every point's label between passes) and returns the other one
+ * as cache - accumulated: the same Float64 sums as create_sufficient_statistics (priors/niw.jl:42-51) in another association
+ * (N exact, the rest to ~1e-16 relative); dpmm_suffstats_* always accumulate everything they are asked for. */
 int dpmm_step_stats(dpmm_ctx *ctx, uint32_t reset_epoch, const double **packed, const uint8_t **bad);
 /* Expand packed rows (after any cross-GPU sum) into the reference's thin_suff_stats shape
  * (src/ds.jl:37-41), order (cluster, left, right): N [K][3], sum [K][3][D], S [K][3][D][D]
@@ -323,7 +327,7 @@ typedef int (*dpmm_host_allreduce_fn)(void *user, void *buf, int64_t count, int 
  *   dpmm_niw_master_pairs       pooled statistics of n slot pairs (check_and_merge!'s proposals, shared_actions.jl:21-27) -> *small: pinned
  *                               [n][DPMM_MASTER_NSCALARS], same record, of the pooled posterior under the cluster prior
  *   dpmm_niw_master_pairs_ahead the pairs the master MAY ask for after the next dpmm_step_master_device (all pairs of clusters whose merge
- *                               gate is open): that call launches them behind the posteriors on the second stream and
+ *                               gate is open): that call computes them with the posteriors (same launch at D <= 128, second stream above) and
  *                               dpmm_niw_master_pairs answers from them (subset, any order) unless a slot got new statistics in between
  *   dpmm_niw_master_put_rows    rows [2K][1 + D + D(D+1)/2] from the host take the place of a statistics pass (restored state)
  *   dpmm_niw_master_rows        the stored statistics rows of the given slots -> out [n][2][1 + D + D(D+1)/2] (host)
