@@ -16,7 +16,9 @@ Differences that cannot be avoided without a Julia runtime, stated once:
   * the reference writes JLD2; here a checkpoint is a NumPy `.npz` with the same content: the point-less group (labels,
     sub-labels, per-cluster statistics / posteriors / parameters / weights / split gate history), the model hyper
     parameters, `iter`, `total_time` and the path of the parameter file -- plus the sampler's RNG state and epoch
-    counters, which make a resumed run continue the SAME chain bit for bit (the reference re-seeds).
+    counters, which make a resumed run continue the SAME chain -- same random streams, same decisions; the GPU worker's statistics are
+    equal up to Float64 rounding (a fresh context accumulates every sub-cluster once before it derives any from its cache) -- where the
+    reference re-seeds.
 """
 import json
 import os
