@@ -187,7 +187,12 @@ class Worker:
 
     def _chk(self, rc):
         if rc != 0:
-            raise DpmmError(rc, self._lib.dpmm_last_error(self._h).decode())
+            err = DpmmError(rc, self._lib.dpmm_last_error(self._h).decode())
+            cause = getattr(self, "_comm_error", None)          # an exception inside the host all-reduce callback (comm_init_host)
+            if cause is not None:
+                self._comm_error = None
+                raise err from cause
+            raise err
 
     @property
     def K(self):
