@@ -26,3 +26,28 @@ def test_world_size_must_equal_gpus():
     assert r.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in (r.stderr + r.stdout)
     r = _run(["--gpus", "1", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=4 but --gpus 1" in (r.stderr + r.stdout)
+
+
+def test_counter_traffic_is_quoted_only_for_the_kernel_sources_it_was_collected_on(tmp_path, monkeypatch):
+    """roofline.traffic comes from profiles/latest_*_pmc_summary.json and carries the hash of the kernel sources: a stale file yields
+    None and says why."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    tag = bench.kernel_source_tag()
+    assert len(tag) == 16
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_source_tag", lambda: tag)
+    rec = {"dpmm::niw_sweep_direct_kernel<4, 4, 2, true>": {"FETCH_SIZE": {"median": 1000.0, "n": 3}, "WRITE_SIZE": {"median": 10.0, "n": 3}}}
+    (prof / "latest_bench_pmc_summary.json").write_text(json.dumps(dict(rec, _meta={"kernel_source_tag": tag, "collected": "now"})))
+    t, src = bench.pmc_traffic("bench", "niw_sweep_direct_kernel")
+    assert t == (2 * 1000.0 + 10.0) * 1024.0 and "latest_bench_pmc_summary.json" in src
+    (prof / "latest_bench_pmc_summary.json").write_text(json.dumps(dict(rec, _meta={"kernel_source_tag": "0" * 16})))
+    t, src = bench.pmc_traffic("bench", "niw_sweep_direct_kernel")
+    assert t is None and "stale" in src
+    t, src = bench.pmc_traffic("mult", "mult_sweep")
+    assert t is None and src is None

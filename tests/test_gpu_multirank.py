@@ -147,3 +147,23 @@ def test_attach_refuses_to_stay_local(tmp_path):
     c.rank, c.world, c.backend = 0, 2, "gloo"
     with pytest.raises(RuntimeError):
         c.attach(NoAttach())
+
+
+@pytest.mark.timeout(900)
+def test_bench_starts_its_own_ranks_and_reports_the_collective(tmp_path):
+    """`bench.py --gpus 2` without a launcher: the script starts two ranks itself (child torchrun before any GPU call), the line says
+    n_gpus = 2 and what the collective saw.  On a one-GPU box the two ranks share the device (--share-gpu: gloo + host transport)."""
+    import json
+    import subprocess
+    share = [] if torch.cuda.device_count() >= 2 else ["--share-gpu"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--points", "400000", "--steps", "5", "--warmup", "1",
+                        "--settle", "5", "--blocks", "1", "--no-legs", "--no-cpu-baseline", "--no-dense", "--growth-iters", "40"] + share,
+                       env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["comm"]["world"] == 2 and d["comm"]["transport"] == ("host" if share else "rccl")
+    assert d["comm"]["rows_allreduce_bytes"] == 2 * 32 * (1 + 64 + 64 * 65 // 2) * 8 and d["comm"]["rows_allreduce_ms"] > 0
+    assert d["config"]["points_per_gpu"] == 200000 and d["growth"]["K_final"] >= 2
