@@ -78,4 +78,22 @@ __device__ __forceinline__ int draw2(float b0, float b1, float u) {
     return (cw < t) ? 1 : 0;
 }
 
+// Certified upper bound of the spectral norm of an upper-triangular 4x4 matrix T = {T00 T01 T02 T03 | T11 T12 T13 | T22 T23 | T33}:
+// ||T||_2^2 = lambda_max(G), G = T'T (symmetric positive semi-definite), and lambda_max(G) <= tr(G^4)^(1/4) <= 4^(1/4) lambda_max(G):
+// within 19 % of the norm, where the Frobenius norm can be twice it.  Used by the ball test of the NIW sweeps (the pack kernels).
+__device__ __forceinline__ float tail_opnorm_bound(const float (&t)[10]) {
+    const double T[4][4] = {{t[0], t[1], t[2], t[3]}, {0., t[4], t[5], t[6]}, {0., 0., t[7], t[8]}, {0., 0., 0., t[9]}};
+    double G[4][4], H[4][4];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) { double s = 0.; for (int r = 0; r < 4; ++r) s += T[r][i] * T[r][j]; G[i][j] = s; }
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) { double s = 0.; for (int r = 0; r < 4; ++r) s += G[i][r] * G[r][j]; H[i][j] = s; }       // G^2
+    double tr4 = 0.;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) tr4 += H[i][j] * H[j][i];                                          // tr(G^4) = ||G^2||_F^2
+    const double fro2 = G[0][0] + G[1][1] + G[2][2] + G[3][3];
+    double lam = sqrt(sqrt(tr4));
+    if (!(lam <= fro2)) lam = fro2;                      // (never larger than the Frobenius bound; NaN / Inf fall back to it)
+    return (float)(sqrt(lam) * 1.00001);
+}
+
 }  // namespace dpmm

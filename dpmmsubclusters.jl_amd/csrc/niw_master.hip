@@ -677,9 +677,9 @@ __global__ void niw_master_pack_kernel(const double *__restrict__ Yall, const fl
             if (q < 4) v = mu_draw[j * DPm + f0 + q];
             else if (q < 14) v = (float)Yall[j * DPm * DPm + (int64_t)(f0 + tc[q - 4]) * DPm + (f0 + tr[q - 4])];
             else if (q == 14) {
-                float f = 0.f;
-                for (int i = 0; i < 10; ++i) { const float t = (float)Yall[j * DPm * DPm + (int64_t)(f0 + tc[i]) * DPm + (f0 + tr[i])]; f = __builtin_fmaf(t, t, f); }
-                v = sqrtf(f) * 1.00001f;
+                float t10[10];
+                for (int i = 0; i < 10; ++i) t10[i] = (float)Yall[j * DPm * DPm + (int64_t)(f0 + tc[i]) * DPm + (f0 + tr[i])];
+                v = tail_opnorm_bound(t10);
             } else v = -0.5f * logdet_sigma[j] + logf(wts[k]);
             ball[e] = v;
         }

@@ -126,11 +126,12 @@ __device__ __forceinline__ unsigned tail_pair_far(const TailPair &T, const f32x4
 
 // Ball test in front of the per-point tail screen, lane = CLUSTER.  The wave's points sit in a ball around the tail mean c of its
 // reference cluster (radius r = max_i |x_i,tail - c|, one wave reduction); for every x in that ball
-//   |T_k (x - m_k)| >= |T_k (c - m_k)| - |T_k|_F r,
+//   |T_k (x - m_k)| >= |T_k (c - m_k)| - |T_k|_2 r,
 // so cst_k - 1/2 max(0, |T_k (c - m_k)| - |T_k|_F r)^2 bounds a_k for ALL points of the wave at once: lane j tests cluster j against the
 // wave's lowest threshold -- ~60 instructions for 64 clusters, where the per-point screen spends ~22 per PAIR of clusters.  On
 // label-homogeneous waves of well-separated data it clears nearly every cluster; whatever is left goes to the per-point screens.
-// Per-cluster records [K][16] = { m0 m1 m2 m3 | T00 T01 T02 T03 | T11 T12 T13 T22 | T23 T33 |T|_F cst } behind the pair records.
+// Per-cluster records [K][16] = { m0 m1 m2 m3 | T00 T01 T02 T03 | T11 T12 T13 T22 | T23 T33 b cst } behind the pair records, b >= |T|_2 a
+// certified bound of the spectral norm (tail_opnorm_bound: within 19 %; the Frobenius norm, used first, can be twice the norm).
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ float dpp_f32(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, false));
@@ -1594,9 +1595,9 @@ __global__ void niw_pack_kernel(const float *__restrict__ R, const float *__rest
             if (q < 4) v = mu[j * D + f0 + q];
             else if (q < 14) v = R[j * TRI + tri_off(D, f0 + tr[q - 4], f0 + tc[q - 4])];
             else if (q == 14) {
-                float f = 0.f;
-                for (int i = 0; i < 10; ++i) { const float t = R[j * TRI + tri_off(D, f0 + tr[i], f0 + tc[i])]; f = __builtin_fmaf(t, t, f); }
-                v = sqrtf(f) * 1.00001f;
+                float t10[10];
+                for (int i = 0; i < 10; ++i) t10[i] = R[j * TRI + tri_off(D, f0 + tr[i], f0 + tc[i])];
+                v = tail_opnorm_bound(t10);
             } else v = cst[3 * k];
             ball[e] = v;
         }
