@@ -44,6 +44,10 @@ ABI = [
     ("dpmm_niw_master_rows", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     ("dpmm_niw_master_draws", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     ("dpmm_debug_niw_draw_inputs", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    ("dpmm_mult_master_setup", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    ("dpmm_mult_master_draw", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    ("dpmm_mult_master_draws", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    ("dpmm_mult_master_put_rows", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     ("dpmm_sweep", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int]),
     ("dpmm_packed_stride", ctypes.c_int64, [ctypes.c_void_p]),
     ("dpmm_suffstats_packed_device", ctypes.c_int, [ctypes.c_void_p, _c_i64p, ctypes.c_int, ctypes.c_void_p]),
@@ -509,6 +513,24 @@ class Worker:
         mu = np.empty((3 * K, self.D), np.float32); R = np.empty((3 * K, self.D, self.D), np.float32); ld = np.empty(3 * K, np.float32)
         self._chk(self._lib.dpmm_niw_master_draws(self._h, int(K), mu.ctypes.data, R.ctypes.data, ld.ctypes.data))
         return mu, R, ld
+
+    # ---- the Multinomial master's draws on the device
+    def mult_master_setup(self, alpha, alpha_outlier=None):
+        a = np.ascontiguousarray(alpha, np.float32); b = None if alpha_outlier is None else np.ascontiguousarray(alpha_outlier, np.float32)
+        self._chk(self._lib.dpmm_mult_master_setup(self._h, a.ctypes.data, None if b is None else b.ctypes.data))
+
+    def mult_master_draw(self, epoch, lr_weights, weights, outlier_first=False):
+        lr = np.ascontiguousarray(lr_weights, np.float32); w = np.ascontiguousarray(weights, np.float32)
+        self._chk(self._lib.dpmm_mult_master_draw(self._h, int(epoch), len(w), int(bool(outlier_first)), lr.ctypes.data, w.ctypes.data))
+
+    def mult_master_draws(self, K):
+        out = np.empty((3 * K, self.D), np.float32)
+        self._chk(self._lib.dpmm_mult_master_draws(self._h, int(K), out.ctypes.data))
+        return out
+
+    def mult_master_put_rows(self, rows):
+        r = np.ascontiguousarray(rows, np.float64)
+        self._chk(self._lib.dpmm_mult_master_put_rows(self._h, r.ctypes.data, r.shape[0] // 2))
 
     def debug_draw_inputs(self, epoch, slot_of_cluster):
         """dpmm_debug_niw_draw_inputs: (A (3K, D, D) Bartlett factors, xi (3K, D)) the device draw of `epoch` consumes."""

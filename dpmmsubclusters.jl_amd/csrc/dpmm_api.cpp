@@ -104,6 +104,10 @@ struct dpmm_ctx {
     bool work_zeroed = false;          // the pack kernel cleared d_work and no sweep has run since
     int sel_all_ones = 0, sel_capacity = 0;   // sb.bin_sel[0..sel_all_ones) are known to be 1 (full passes skip the memset)
     long long *d_counts64 = nullptr;   // [2 * DPMM_MAX_CLUSTERS] global sub-cluster occupancies (multi-GPU)
+    // Multinomial master on the device (mult_master.hip): priors, and how many clusters' complete rows the last statistics pass left in d_out
+    float *d_malpha = nullptr;         // [2][ldx]: cluster prior | outlier prior
+    bool mult_master = false, mult_has_alpha1 = false;
+    int rows_full_K = -1;
     // derived sub-cluster statistics of the per-step pass (derive_rows_kernel): cached cluster-level rows + label tracking
     double *d_ccache = nullptr;        // [Kcap][packed_stride] left + right of every cluster as of the last pass that computed both
     bool cache_force = true;           // the next per-step pass computes every cluster in full (points uploaded, cache re-allocated, K changed)
@@ -348,7 +352,7 @@ static int ensure_capacity(dpmm_ctx *c, int K) {
     HIPCHK(c, hipMalloc(&c->d_slabs, sizeof(double) * (size_t)c->max_items * (size_t)c->slab_stride));
     HIPCHK(c, hipMalloc(&c->d_out, sizeof(double) * 2 * cap * (size_t)c->packed_stride + DPMM_MAX_CLUSTERS + 64));   // rows | bad-cluster flags
     HIPCHK(c, hipMalloc(&c->d_ccache, sizeof(double) * cap * (size_t)c->packed_stride));
-    HIPCHK(c, hipMemset(c->d_ccache, 0, sizeof(double) * cap * (size_t)c->packed_stride));
+    HIPCHK(c, hipMemsetAsync(c->d_ccache, 0, sizeof(double) * cap * (size_t)c->packed_stride, c->stream));      // (on the stream its readers run on)
     c->cache_force = true;
     c->Kcap = cap;
     return DPMM_OK;
@@ -417,15 +421,15 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
     CHK_CREATE(hipMalloc(&c->sb.tile_hist, sizeof(int32_t) * nbmax * (size_t)std::max(1, c->nt_sort)));
     CHK_CREATE(hipMalloc(&c->sb.tile_cnt, sizeof(int32_t) * nbmax * (size_t)std::max(1, c->nt_sort)));
     CHK_CREATE(hipMalloc(&c->sb.fast_total, sizeof(int32_t) * nbmax * FAST_TOTAL_STRIDE));
-    CHK_CREATE(hipMemset(c->sb.fast_total, 0, sizeof(int32_t) * nbmax * FAST_TOTAL_STRIDE));
+    CHK_CREATE(hipMemsetAsync(c->sb.fast_total, 0, sizeof(int32_t) * nbmax * FAST_TOTAL_STRIDE, c->stream));
     CHK_CREATE(hipMalloc(&c->sb.ticket, sizeof(unsigned)));
-    CHK_CREATE(hipMemset(c->sb.ticket, 0, sizeof(unsigned)));
+    CHK_CREATE(hipMemsetAsync(c->sb.ticket, 0, sizeof(unsigned), c->stream));
     CHK_CREATE(hipMalloc(&c->sb.prev_lab, sizeof(uint16_t) * (((size_t)nalloc + SORT_TILE - 1) / SORT_TILE * SORT_TILE)));
-    CHK_CREATE(hipMemset(c->sb.prev_lab, 0xFF, sizeof(uint16_t) * (((size_t)nalloc + SORT_TILE - 1) / SORT_TILE * SORT_TILE)));
+    CHK_CREATE(hipMemsetAsync(c->sb.prev_lab, 0xFF, sizeof(uint16_t) * (((size_t)nalloc + SORT_TILE - 1) / SORT_TILE * SORT_TILE), c->stream));
     CHK_CREATE(hipMalloc(&c->sb.cdirty, DPMM_MAX_CLUSTERS + 8));
-    CHK_CREATE(hipMemset(c->sb.cdirty, 1, DPMM_MAX_CLUSTERS + 8));
+    CHK_CREATE(hipMemsetAsync(c->sb.cdirty, 1, DPMM_MAX_CLUSTERS + 8, c->stream));
     CHK_CREATE(hipMalloc(&c->sb.cmode, DPMM_MAX_CLUSTERS));
-    CHK_CREATE(hipMemset(c->sb.cmode, 0, DPMM_MAX_CLUSTERS));
+    CHK_CREATE(hipMemsetAsync(c->sb.cmode, 0, DPMM_MAX_CLUSTERS, c->stream));
     CHK_CREATE(hipMalloc(&c->sb.bin_total, sizeof(int32_t) * nbmax));
     CHK_CREATE(hipMalloc(&c->sb.bin_start, sizeof(int32_t) * (nbmax + 1)));
     CHK_CREATE(hipMalloc(&c->sb.item_start, sizeof(int32_t) * (nbmax + 1)));
@@ -436,7 +440,7 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
     CHK_CREATE(hipMalloc(&c->d_small, sizeof(int32_t) * 4 * DPMM_MAX_CLUSTERS));
     CHK_CREATE(hipMalloc(&c->d_counts64, sizeof(long long) * 2 * DPMM_MAX_CLUSTERS));
     CHK_CREATE(hipMalloc(&c->d_work, sizeof(unsigned long long) * (DPMM_WORK_SLOTS + 16 * (size_t)std::max(1, c->sweep_grid_max))));
-    CHK_CREATE(hipMemset(c->d_work, 0, sizeof(unsigned long long) * (DPMM_WORK_SLOTS + 16 * (size_t)std::max(1, c->sweep_grid_max))));
+    CHK_CREATE(hipMemsetAsync(c->d_work, 0, sizeof(unsigned long long) * (DPMM_WORK_SLOTS + 16 * (size_t)std::max(1, c->sweep_grid_max)), c->stream));
 #undef CHK_CREATE
     *out = c;
     return DPMM_OK;
@@ -464,6 +468,7 @@ int dpmm_destroy(dpmm_ctx *c) {
     for (int i = 0; i < 4; ++i) if (c->h_list[i]) hipHostFree(c->h_list[i]);
     if (c->h_master) hipHostFree(c->h_master);
     if (c->h_draw) hipHostFree(c->h_draw);
+    hipFree(c->d_malpha);
     hipFree(c->d_counts64); hipFree(c->d_row_off); hipFree(c->d_inv_off); hipFree(c->d_work); hipFree(c->d_par);
     comm_release(c);
     if (c->h_red) hipHostFree(c->h_red);
@@ -565,6 +570,7 @@ int dpmm_init_labels(dpmm_ctx *c, int init_clusters, uint32_t epoch) {
     HIPCHK(c, hipSetDevice(c->device));
     if (c->n > 0) HIPCHK(c, launch_init_labels(c->dbins, c->n, c->first, init_clusters, 0, c->seed, epoch, c->stream));
     c->have_labels = true;
+    c->rows_full_K = -1;
     return DPMM_OK;
 }
 
@@ -574,6 +580,7 @@ int dpmm_init_labels_from(dpmm_ctx *c, int init_clusters, int first_label, uint3
     HIPCHK(c, hipSetDevice(c->device));
     if (c->n > 0) HIPCHK(c, launch_init_labels(c->dbins, c->n, c->first, init_clusters, first_label - 1, c->seed, epoch, c->stream));
     c->have_labels = true;
+    c->rows_full_K = -1;
     return DPMM_OK;
 }
 
@@ -593,6 +600,7 @@ int dpmm_set_labels(dpmm_ctx *c, const int64_t *labels, const int64_t *sub) {
     hipFree(tmp);
     if (e != hipSuccess) { c->err = std::string("dpmm_set_labels: ") + hipGetErrorString(e); rc = DPMM_EHIP; }
     else c->have_labels = true;
+    c->rows_full_K = -1;
     return rc;
 }
 
@@ -1122,6 +1130,7 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
     }
     if (c->opt_timing & 2) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     c->have_stats_ev = (c->opt_timing & 2) != 0;
+    c->rows_full_K = idx ? -1 : c->K;           // (a subset pass zeroes the rows it was not asked for)
     return DPMM_OK;
 }
 
@@ -1438,7 +1447,7 @@ int dpmm_step_master_device(dpmm_ctx *c, uint32_t reset_epoch, const int32_t *sl
         // being the two cross-stream waits.  The normals were generated on the second stream during the sweep: that event is long done.)
         const int32_t *hs = c->d_dslots;
         const bool have_normals = noise_ready(c, draw_epoch, K, c->draw_cur ^ 1);
-        if (have_normals) if (int rc = noise_join(c)) return rc;
+        if (int rc = noise_join(c)) return rc;             // (also when its normals are not the ones wanted: the kernel writes the buffer the draws go to)
         NiwMasterArgs ma = c->ma;
         ma.mu_draw = c->d_mu_draw[c->draw_cur ^ 1];
         HIPCHK(c, launch_niw_master_draw(ma, hs, K, draw_epoch, c->d_Y[c->draw_cur ^ 1], c->d_ld_sigma[c->draw_cur ^ 1], nullptr, nullptr,
@@ -1515,7 +1524,7 @@ int dpmm_niw_master_draw(dpmm_ctx *c, uint32_t epoch, int K, const int32_t *slot
                        memcmp(c->spec_slots.data(), slot_of_cluster, sizeof(int32_t) * K) == 0;
     if (int rc = spec_join(c)) return rc;
     c->spec_valid = false;
-    if (!ahead) if (int rc = noise_join(c)) return rc;
+    if (int rc = noise_join(c)) return rc;                 // (no-op when the draws launched ahead already waited for the normals)
     if (!ahead) if (int rc = device_list(c, c->d_dslots, c->dslots_shadow, slot_of_cluster, (size_t)K)) return rc;
     const int32_t *hs = c->d_dslots;
     c->draw_cur ^= 1;
@@ -1650,6 +1659,74 @@ int dpmm_niw_master_draws(dpmm_ctx *c, int K, float *mu, float *R, float *logdet
     return DPMM_OK;
 }
 
+// ---- the Multinomial master's draws on the device ----------------------------------------------------------------------------
+int dpmm_mult_master_setup(dpmm_ctx *c, const float *alpha, const float *alpha_outlier) {
+    if (!c || !alpha) return DPMM_EINVAL;
+    if (c->prior != DPMM_PRIOR_MULT) return fail(c, DPMM_EINVAL, "dpmm_mult_master_setup: the context is not Multinomial");
+    if (c->D > DPMM_MULT_MASTER_MAXD) return fail(c, DPMM_ELIMIT, "D exceeds the device Dirichlet draw's limit");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!c->d_malpha) HIPCHK(c, hipMalloc(&c->d_malpha, sizeof(float) * 2 * (size_t)c->ldx));
+    HIPCHK(c, hipMemsetAsync(c->d_malpha, 0, sizeof(float) * 2 * (size_t)c->ldx, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(c->d_malpha, alpha, sizeof(float) * (size_t)c->D, hipMemcpyHostToDevice));
+    if (alpha_outlier) HIPCHK(c, hipMemcpy(c->d_malpha + c->ldx, alpha_outlier, sizeof(float) * (size_t)c->D, hipMemcpyHostToDevice));
+    c->mult_has_alpha1 = alpha_outlier != nullptr;
+    if (!c->h_draw) HIPCHK(c, hipHostMalloc((void **)&c->h_draw, sizeof(float) * 3 * DPMM_MAX_CLUSTERS, hipHostMallocDefault));
+    c->mult_master = true;
+    return DPMM_OK;
+}
+
+int dpmm_mult_master_put_rows(dpmm_ctx *c, const double *rows, int K) {
+    if (!c || !rows) return DPMM_EINVAL;
+    if (!c->mult_master) return fail(c, DPMM_ESTATE, "dpmm_mult_master_setup first");
+    if (int rc = check_K(c, K)) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = ensure_capacity(c, K)) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(c->d_out, rows, sizeof(double) * 2 * (size_t)K * (size_t)c->packed_stride, hipMemcpyHostToDevice));
+    c->K = K;
+    c->rows_full_K = K;
+    c->cache_force = true;            // (the rows did not come from this context's labels: nothing to derive from)
+    return DPMM_OK;
+}
+
+int dpmm_mult_master_draw(dpmm_ctx *c, uint32_t epoch, int K, int outlier_first, const float *lr, const float *w) {
+    if (!c || !lr || !w) return DPMM_EINVAL;
+    if (!c->mult_master) return fail(c, DPMM_ESTATE, "dpmm_mult_master_setup first");
+    if (int rc = check_K(c, K)) return rc;
+    if (c->rows_full_K != K) return fail(c, DPMM_ESTATE, "dpmm_mult_master_draw: the last statistics pass did not leave the rows of all K clusters");
+    if (outlier_first && !c->mult_has_alpha1) return fail(c, DPMM_ESTATE, "dpmm_mult_master_draw: no outlier prior was set up");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = ensure_capacity(c, K)) return rc;
+    // cst[3k] = log w_k, cst[3k+1+s] = log lr[k][s] through the pinned block (see dpmm_niw_master_draw for the wait)
+    if (c->handover_inflight) HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->handover_inflight = true;
+    float *hcst = reinterpret_cast<float *>(c->h_draw);
+    for (int k = 0; k < K; ++k) { hcst[3 * k] = logf(w[k]); hcst[3 * k + 1] = logf(lr[2 * k]); hcst[3 * k + 2] = logf(lr[2 * k + 1]); }
+    HIPCHK(c, launch_copy_bytes(c->d_cst, hcst, sizeof(float) * 3 * K, c->stream));
+    HIPCHK(c, launch_mult_dirichlet(c->d_out, c->packed_stride, c->d_malpha, c->mult_has_alpha1 ? c->d_malpha + c->ldx : nullptr, outlier_first, c->D, c->ldx,
+                                    K, c->seed, epoch, c->d_raw, c->stream));
+    HIPCHK(c, launch_mult_pack(c->d_raw, c->d_Rp, 3 * K, c->ldx, c->stream));
+    if (c->x_u8) HIPCHK(c, launch_mult_pack_u8(c->d_raw, c->d_Lp16, 3 * K, c->ldx, c->ld8, c->stream));
+    else if (c->x_bf16_exact) HIPCHK(c, launch_mult_pack_bf16(c->d_raw, c->d_Lp16, 3 * K, c->ldx, c->stream));
+    c->K = K;
+    c->have_params = true;
+    c->predictive = false;
+    c->draws_on_device = true;
+    return DPMM_OK;
+}
+
+int dpmm_mult_master_draws(dpmm_ctx *c, int K, float *logp) {
+    if (!c || !logp) return DPMM_EINVAL;
+    if (!c->mult_master || !c->draws_on_device || K != c->K) return fail(c, DPMM_ESTATE, "no device draws for this K");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy2D(logp, sizeof(float) * (size_t)c->D, c->d_raw, sizeof(float) * (size_t)c->ldx, sizeof(float) * (size_t)c->D, 3 * (size_t)K,
+                          hipMemcpyDeviceToHost));
+    return DPMM_OK;
+}
+
 int dpmm_debug_niw_draw_inputs(dpmm_ctx *c, uint32_t epoch, int K, const int32_t *slot_of_cluster, double *A, double *xi) {
     if (!c || !slot_of_cluster || !A || !xi) return DPMM_EINVAL;
     if (!c->master) return fail(c, DPMM_ESTATE, "dpmm_niw_master_setup first");
@@ -1664,7 +1741,7 @@ int dpmm_debug_niw_draw_inputs(dpmm_ctx *c, uint32_t epoch, int K, const int32_t
     hipError_t e = hipMalloc(&dA, sizeof(double) * nA);
     if (e == hipSuccess) e = hipMalloc(&dxi, sizeof(double) * nx);
     if (e == hipSuccess) e = hipMalloc(&dsl, sizeof(int32_t) * K);
-    if (e == hipSuccess) e = hipMemset(dA, 0, sizeof(double) * nA);
+    if (e == hipSuccess) e = hipMemsetAsync(dA, 0, sizeof(double) * nA, c->stream);
     if (e == hipSuccess) e = hipMemcpy(dsl, slot_of_cluster, sizeof(int32_t) * K, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = launch_niw_draw_inputs(c->ma, dsl, K, epoch, dA, dxi, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -1735,6 +1812,7 @@ int dpmm_split(dpmm_ctx *c, const int64_t *idx, const int64_t *new_idx, int n, u
     HIPCHK(c, hipSetDevice(c->device));
     if (int rc = upload_idx(c, idx, new_idx, n, DPMM_MAX_CLUSTERS)) return rc;
     if (c->n > 0) HIPCHK(c, launch_split(c->dbins, c->n, c->first, c->d_small, n, c->seed, epoch, c->stream));
+    c->rows_full_K = -1;              // (the rows of the last pass no longer describe these labels)
     return DPMM_OK;
 }
 
@@ -1746,6 +1824,7 @@ int dpmm_merge(dpmm_ctx *c, const int64_t *idx, const int64_t *new_idx, int n) {
     HIPCHK(c, hipSetDevice(c->device));
     if (int rc = upload_idx(c, idx, new_idx, n, DPMM_MAX_CLUSTERS)) return rc;
     if (c->n > 0) HIPCHK(c, launch_merge(c->dbins, c->n, c->d_small, n, c->stream));
+    c->rows_full_K = -1;
     return DPMM_OK;
 }
 
@@ -1770,6 +1849,7 @@ int dpmm_remove_empty(dpmm_ctx *c, const int64_t *pts_count, int K) {
     memcpy(c->h_pin, map.data(), sizeof(int32_t) * map.size());
     HIPCHK(c, launch_copy_bytes(c->d_small, c->h_pin, sizeof(int32_t) * map.size(), c->stream));
     if (c->n > 0) HIPCHK(c, launch_remap(c->dbins, c->n, c->d_small, c->stream));
+    c->rows_full_K = -1;
     return DPMM_OK;
 }
 
@@ -1782,6 +1862,7 @@ int dpmm_reset_sublabels(dpmm_ctx *c, const int64_t *idx, int n, uint32_t epoch)
         if (int rc = upload_idx(c, idx, nullptr, n, DPMM_MAX_CLUSTERS)) return rc;
     }
     if (c->n > 0) HIPCHK(c, launch_reset_sub(c->dbins, c->n, c->first, idx ? c->d_small : nullptr, idx ? n : 0, c->seed, epoch, c->stream));
+    c->rows_full_K = -1;
     return DPMM_OK;
 }
 

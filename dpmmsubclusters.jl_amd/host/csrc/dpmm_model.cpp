@@ -173,6 +173,9 @@ struct dpmmh_model {
     int opt_draw_ahead = 1;          // device master: the next draws are launched with the posteriors (DPMMH_OPT_DRAW_AHEAD)
     bool dev_pairs_ok = false;
     bool dev_setup = false, dev_state = false, host_dense = true, host_rows = true, dev_draw = false;   // host_rows: the packed rows alone are current
+    // Multinomial (worker.mult_*): the Dirichlet draws happen on the device while the worker's last statistics pass holds the rows of
+    // all K clusters as the engine knows them (mult_rows_current: set by a full pass, cleared by an accepted split / merge / removal)
+    bool mult_dev_setup = false, mult_dev_failed = false, mult_rows_current = false;
     bool prewake = true;
     double wait_ema = 0.0, t_stats_back = 0.0;
     static constexpr double kPrewakeLead = 60e-6;   // seconds before the predicted hand-back
@@ -284,6 +287,15 @@ struct dpmmh_model {
         }
         return true;
     }
+    bool use_mult_dev() {
+        if (kind != DPMMH_PRIOR_MULT || mult_dev_failed || !W.mult_master_setup || !W.mult_draw || !W.mult_draws || !W.mult_put_rows) return false;
+        if (!(opt_dev_master == 1 || (opt_dev_master < 0 && D >= 128))) return false;
+        if (!mult_dev_setup) {
+            if (W.mult_master_setup(W.ctx, mult[0].alpha.data(), mult[1].set ? mult[1].alpha.data() : nullptr)) { wfail("mult_master_setup"); mult_dev_failed = true; return false; }
+            mult_dev_setup = true;
+        }
+        return true;
+    }
     // posteriors + factorisations of clusters `ks` on the device (from the statistics pass that just ran); scalars come back
     int ingest_device(const std::vector<int> &ks) {
         const int n = (int)ks.size();
@@ -382,10 +394,10 @@ struct dpmmh_model {
     // ... and wakes the pool shortly before the statistics are expected back (prediction: the previous steps' launch-to-statistics time)
     void start_noise(double t_launch = 0.0) {
         wait_noise();
-        const bool niw_dev = kind == DPMMH_PRIOR_NIW && dev_draw;       // device draws make their own noise (a wrong guess costs an inline generation)
+        const bool niw_dev = dev_draw;       // device draws (either prior) make their own noise (a wrong guess costs an inline generation)
         const bool niw_noise = kind == DPMMH_PRIOR_NIW && !niw_dev;
         // (no pool job follows the statistics on the device-master path -- the worker returns the lgamma terms too -- so nobody is woken)
-        const bool pool_after_stats = !(niw_dev && !f32_quirk);
+        const bool pool_after_stats = !(kind == DPMMH_PRIOR_NIW && niw_dev && !f32_quirk);
         const double pre_at = (prewake && pool_after_stats && nthreads > 1 && t_launch > 0.0 && wait_ema > 0.0) ? t_launch + wait_ema - kPrewakeLead : 0.0;
         const int rows = 3 * (K + 4);   // head-room for clusters born from splits
         const size_t DD = (size_t)D * D;
@@ -423,7 +435,8 @@ struct dpmmh_model {
         draw_epoch += 1;
         const bool have_noise = noise_epoch == draw_epoch && noise_rows > 0;
         const size_t DD = (size_t)D * D;
-        const bool dev = kind == DPMMH_PRIOR_NIW && use_dev() && dev_state;     // the draws happen on the device, after the weights below
+        const bool mdev = kind == DPMMH_PRIOR_MULT && mult_rows_current && use_mult_dev();
+        const bool dev = mdev || (kind == DPMMH_PRIOR_NIW && use_dev() && dev_state);     // the draws happen on the device, after the weights below
         if (!dev) { if (int rc = pull_state()) return rc; }
         std::vector<std::vector<double>> scratch(std::max(1, nthreads));
         if (!dev) Pool::get().run(3 * K, nthreads, [&](int id, int th) {
@@ -472,7 +485,8 @@ struct dpmmh_model {
         timers[T_MISC] += now_s() - t0; t0 = now_s();
         dev_draw = false;
         if (dev) {      // sample_distribution for all 3K distributions + the hand-over to the sweep kernels, on the device (asynchronous)
-            if (W.niw_draw(W.ctx, draw_epoch, K, st_slot, st_lr, st_w)) return wfail("niw_draw");
+            if (mdev) { if (W.mult_draw(W.ctx, draw_epoch, K, has_outlier() ? 1 : 0, st_lr, st_w)) return wfail("mult_draw"); }
+            else if (W.niw_draw(W.ctx, draw_epoch, K, st_slot, st_lr, st_w)) return wfail("niw_draw");
             dev_draw = true;
             timers[T_SAMPLE] += now_s() - t0;
         }
@@ -516,7 +530,7 @@ struct dpmmh_model {
         }
         bad_total += nbad; bad_steps += nbad ? 1 : 0;
         if (dev) { if (int rc = apply_device_posteriors(dev_slots, dev_small)) return rc; dev_state = true; }
-        else { ingest(pk, ks); host_dense = true; host_rows = true; dev_state = false; }
+        else { ingest(pk, ks); host_dense = true; host_rows = true; dev_state = false; mult_rows_current = true; }
         timers[T_POSTERIOR] += now_s() - t0;
         return 0;
     }
@@ -537,7 +551,7 @@ struct dpmmh_model {
         if (W.stats(W.ctx, idx.data(), (int)idx.size(), &pk)) return wfail("stats");
         timers[T_STATS_WAIT] += now_s() - t0; t0 = now_s();
         ingest(pk, ks);
-        dev_state = false;
+        dev_state = false; mult_rows_current = false;      // (a subset pass: the worker's buffer holds these rows only)
         timers[T_POSTERIOR] += now_s() - t0;
         return 0;
     }
@@ -557,7 +571,7 @@ struct dpmmh_model {
         if (W.stats(W.ctx, nullptr, 0, &pk)) return wfail("stats");
         timers[T_STATS_WAIT] += now_s() - t0; t0 = now_s();
         ingest(pk, ks);
-        host_dense = true; host_rows = true; dev_state = false;
+        host_dense = true; host_rows = true; dev_state = false; mult_rows_current = true;
         timers[T_POSTERIOR] += now_s() - t0;
         return 0;
     }
@@ -586,6 +600,7 @@ struct dpmmh_model {
             if (lhr > log(u)) acc.push_back(k);
         }
         if (acc.empty()) return 0;
+        mult_rows_current = false;
         const int K0 = K;
         std::vector<int64_t> idx, nidx;
         for (size_t a = 0; a < acc.size(); ++a) {
@@ -755,7 +770,7 @@ struct dpmmh_model {
             idx.push_back(i + 1); nidx.push_back(j + 1);
         }
         if (idx.empty()) return 0;
-        dev_state = false;                             // merged slots were rebuilt on the host: the next draws come from there
+        dev_state = false; mult_rows_current = false;  // merged slots were rebuilt on the host: the next draws come from there
         if (W.merge(W.ctx, idx.data(), nidx.data(), (int)idx.size())) return wfail("merge");
         return 0;
     }
@@ -771,6 +786,7 @@ struct dpmmh_model {
         }
         if (!any) return 0;
         if (W.remove_empty(W.ctx, pc.data(), K)) return wfail("remove_empty");
+        mult_rows_current = false;                     // (the worker's rows are in the old cluster order)
         std::vector<int> ns;
         for (int k = 0; k < K; ++k) {
             if (pc[k] > 0) ns.push_back(slot[k]);
@@ -1021,9 +1037,11 @@ HAPI int64_t dpmmh_model_get(dpmmh_model *m, const char *field, void *out, int64
     const size_t DD = (size_t)D * D;
     if (f == "K") return emit<int64_t>(out, cap, {(int64_t)K});
     // counters[6]: bit 0 = the device master is on but the NEXT draws of this chain come from the host (the step that just ended accepted a
-    // merge and rebuilt the merged slots there): host and device draws use different streams, so a resumed run has to know
+    // merge and rebuilt the merged slots there; Multinomial: a split, merge or removal left the worker without the current rows): host and
+    // device draws use different streams, so a resumed run has to know
     if (f == "counters") return emit<int64_t>(out, cap, {(int64_t)m->epoch, (int64_t)m->draw_epoch, (int64_t)m->split_epoch, (int64_t)m->merge_epoch, m->bad_total, m->bad_steps,
-                                                         (int64_t)((m->kind == DPMMH_PRIOR_NIW && m->use_dev() && !m->dev_state) ? 1 : 0), 0});
+                                                         (int64_t)(((m->kind == DPMMH_PRIOR_NIW && m->use_dev() && !m->dev_state) ||
+                                                                    (m->kind == DPMMH_PRIOR_MULT && m->use_mult_dev() && !m->mult_rows_current)) ? 1 : 0), 0});
     if (f == "timers") return emit<double>(out, cap, std::vector<double>(m->timers, m->timers + 16));
     auto rows_d = [&](const std::vector<double> &src, size_t w) {
         std::vector<double> v((size_t)3 * K * w);
@@ -1102,6 +1120,11 @@ HAPI int64_t dpmmh_model_get(dpmmh_model *m, const char *field, void *out, int64
         }
     } else {
         if (f == "alpha_post") return emit(out, cap, rows_f(m->apost.data(), D));
+        if (f == "logp" && m->dev_draw) {      // the current draws were made on the device: fetch them (cluster order)
+            std::vector<float> lp((size_t)3 * K * D);
+            if (m->W.mult_draws(m->W.ctx, K, lp.data())) return m->wfail("mult_draws");
+            return emit(out, cap, lp);
+        }
         if (f == "logp" && m->st_slots > 0) return emit(out, cap, rows_f(m->st_mat, D));
     }
     if (f == "lr_weights" && m->st_slots > 0) return emit(out, cap, std::vector<float>(m->st_lr, m->st_lr + 2 * K));
@@ -1132,6 +1155,7 @@ HAPI int dpmmh_model_set(dpmmh_model *m, const char *field, const void *in, int6
         if (!need(64)) return -1;
         const int64_t *c = (const int64_t *)in;
         m->epoch = (uint32_t)c[0]; m->draw_epoch = (uint32_t)c[1]; m->split_epoch = (uint32_t)c[2]; m->merge_epoch = (uint32_t)c[3];
+        if (c[6] & 1) m->mult_rows_current = false;
         if ((c[6] & 1) && m->dev_state) {       // saved right after an accepted merge: the running chain made its next draws on the host
             if (m->pull_state()) return -1;
             m->dev_state = false;
@@ -1144,7 +1168,11 @@ HAPI int dpmmh_model_set(dpmmh_model *m, const char *field, const void *in, int6
         std::vector<int> ks(K);
         for (int k = 0; k < K; ++k) ks[k] = k;
         m->ingest((const double *)in, ks);
-        m->host_dense = true; m->host_rows = true; m->dev_state = false; m->dev_draw = false;
+        m->host_dense = true; m->host_rows = true; m->dev_state = false; m->dev_draw = false; m->mult_rows_current = false;
+        if (m->use_mult_dev()) {
+            if (m->W.mult_put_rows(m->W.ctx, (const double *)in, K)) return m->wfail("mult_put_rows");
+            m->mult_rows_current = true;
+        }
         if (m->use_dev()) {      // the device gets the same rows, so that the next draws come from where a running chain makes them
             if (m->W.niw_put_rows(m->W.ctx, (const double *)in, K)) return m->wfail("niw_put_rows");
             if (int rc = m->ingest_device(ks)) return rc;

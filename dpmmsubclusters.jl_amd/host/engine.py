@@ -30,6 +30,9 @@ F_M_PAIRSA = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, _vp, ctypes.c_int)
 F_M_PUT = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, ctypes.c_int)
 F_M_ROWS = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, ctypes.c_int, _vp)
 F_M_DRAWS = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp)
+F_MM_SETUP = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, _vp)
+F_MM_DRAW = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, _vp, _vp)
+F_MM_DRAWS = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_int, _vp)
 F_SPLIT = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _i64p, _i64p, ctypes.c_int, ctypes.c_uint32)
 F_MERGE = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _i64p, _i64p, ctypes.c_int)
 F_REMOVE = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _i64p, ctypes.c_int)
@@ -48,7 +51,8 @@ class WorkerTable(ctypes.Structure):
                 ("remove_empty", F_REMOVE), ("reset_sublabels", F_RESET), ("init_labels", F_INIT), ("allgather", F_GATHER),
                 ("last_error", F_ERR),
                 ("niw_master_setup", F_M_SETUP), ("step_stats_device", F_M_STEP), ("step_master_device", F_M_STEPM), ("stats_device", F_M_STATS), ("niw_posterior", F_M_POST),
-                ("niw_draw", F_M_DRAW), ("niw_pairs", F_M_PAIRS), ("niw_pairs_ahead", F_M_PAIRSA), ("niw_put_rows", F_M_PUT), ("niw_rows", F_M_ROWS), ("niw_draws", F_M_DRAWS)]
+                ("niw_draw", F_M_DRAW), ("niw_pairs", F_M_PAIRS), ("niw_pairs_ahead", F_M_PAIRSA), ("niw_put_rows", F_M_PUT), ("niw_rows", F_M_ROWS), ("niw_draws", F_M_DRAWS),
+                ("mult_master_setup", F_MM_SETUP), ("mult_draw", F_MM_DRAW), ("mult_draws", F_MM_DRAWS), ("mult_put_rows", F_M_PUT)]
 
 
 _NATIVE_MAP = [("params_staging", "dpmm_params_staging", F_STAGING), ("commit_params", "dpmm_commit_params", F_INT),
@@ -61,7 +65,9 @@ _NATIVE_MAP = [("params_staging", "dpmm_params_staging", F_STAGING), ("commit_pa
                ("stats_device", "dpmm_suffstats_device", F_M_STATS), ("niw_posterior", "dpmm_niw_master_posterior", F_M_POST),
                ("niw_draw", "dpmm_niw_master_draw", F_M_DRAW), ("niw_pairs", "dpmm_niw_master_pairs", F_M_PAIRS), ("niw_pairs_ahead", "dpmm_niw_master_pairs_ahead", F_M_PAIRSA),
                ("niw_put_rows", "dpmm_niw_master_put_rows", F_M_PUT),
-               ("niw_rows", "dpmm_niw_master_rows", F_M_ROWS), ("niw_draws", "dpmm_niw_master_draws", F_M_DRAWS)]
+               ("niw_rows", "dpmm_niw_master_rows", F_M_ROWS), ("niw_draws", "dpmm_niw_master_draws", F_M_DRAWS),
+               ("mult_master_setup", "dpmm_mult_master_setup", F_MM_SETUP), ("mult_draw", "dpmm_mult_master_draw", F_MM_DRAW),
+               ("mult_draws", "dpmm_mult_master_draws", F_MM_DRAWS), ("mult_put_rows", "dpmm_mult_master_put_rows", F_M_PUT)]
 
 
 def native_worker_table(worker, rank=0, world=1):

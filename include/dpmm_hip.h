@@ -349,6 +349,20 @@ int dpmm_niw_master_draws(dpmm_ctx *ctx, int K, float *mu, float *R, float *logd
  * R' = L^-1 A (nu' psi' = L'L, L lower), mu = m' + R^-1 xi / sqrt(kappa') of them: tests recompute it in Float64. */
 int dpmm_debug_niw_draw_inputs(dpmm_ctx *ctx, uint32_t epoch, int K, const int32_t *slot_of_cluster, double *A, double *xi);
 
+/* ---- the Multinomial master's parameter draws on the device (optional, like the NIW group above) ----
+ *   dpmm_mult_master_setup     prior alpha [D] (and the outlier component's prior, or NULL) -> device; enables the calls below
+ *   dpmm_mult_master_draw      calc_posterior + sample_distribution (src/priors/multinomial_prior.jl:16-25) for all 3K distributions from the
+ *                              rows the LAST full / per-step statistics pass left on the device (K must be that pass's K): alpha' = alpha +
+ *                              Float32(sum x), log p = log Dirichlet(alpha') by Gamma variates (Philox keyed by seed, position in cluster
+ *                              order, epoch), then the hand-over to the sweep kernels (replaces dpmm_params_staging / dpmm_commit_params for
+ *                              this sweep); outlier_first: cluster 1 uses the outlier prior; lr [K][2], w [K] as in dpmm_params_staging
+ *   dpmm_mult_master_draws     the current draws, log-probabilities [3K][D] (host)
+ *   dpmm_mult_master_put_rows  rows [2K][1 + D] from the host take the place of a statistics pass (restored state) */
+int dpmm_mult_master_setup(dpmm_ctx *ctx, const float *alpha, const float *alpha_outlier);
+int dpmm_mult_master_draw(dpmm_ctx *ctx, uint32_t epoch, int K, int outlier_first, const float *lr, const float *w);
+int dpmm_mult_master_draws(dpmm_ctx *ctx, int K, float *logp);
+int dpmm_mult_master_put_rows(dpmm_ctx *ctx, const double *rows, int K);
+
 /* RCCL is bound at run time (dlopen): a copy already mapped into the process wins, then the soname, then /opt/rocm/lib.
  * dpmm_comm_use_library names the file to use instead (before the first dpmm_comm_* call) -- a host that also runs
  * torch.distributed passes torch's own librccl.so so that the process holds ONE copy. */

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DPMMH_ABI_VERSION 3
+#define DPMMH_ABI_VERSION 4
 
 typedef struct dpmmh_model dpmmh_model;
 
@@ -90,6 +90,13 @@ typedef struct dpmmh_worker {
     int (*niw_put_rows)(void *ctx, const double *rows, int K);
     int (*niw_rows)(void *ctx, const int32_t *slots, int n, double *out);
     int (*niw_draws)(void *ctx, int K, float *mu, float *R, float *logdet);
+    /* OPTIONAL group (all or none): the Multinomial master's parameter draws on the worker's device -- dpmm_mult_master_* in dpmm_hip.h.
+     * Used when DPMMH_OPT_DEVICE_MASTER allows (default: D >= 128) and the worker's last statistics pass holds the current rows of all K
+     * clusters (no split, merge or removal since); otherwise the engine draws on the host as before. */
+    int (*mult_master_setup)(void *ctx, const float *alpha, const float *alpha_outlier);
+    int (*mult_draw)(void *ctx, uint32_t epoch, int K, int outlier_first, const float *lr, const float *w);
+    int (*mult_draws)(void *ctx, int K, float *logp);
+    int (*mult_put_rows)(void *ctx, const double *rows, int K);
 } dpmmh_worker;
 
 /* Options (dpmmh_model_set_option). */
@@ -101,7 +108,7 @@ enum {
                                         (the only scheme built); any other value is refused */
     DPMMH_OPT_SPIN_US = 5,           /* bounded polling of the pool's workers between back-to-back parallel regions (default 150) */
     DPMMH_OPT_PREWAKE = 6,           /* 1 (default): wake the pool ~60 us before the statistics of a step are expected back */
-    DPMMH_OPT_DEVICE_MASTER = 8,     /* NIW posteriors / factorisations / draws on the worker's device: 1 on, 0 off, -1 (default) for D >= 64 */
+    DPMMH_OPT_DEVICE_MASTER = 8,     /* NIW posteriors / factorisations / draws (Multinomial: the Dirichlet draws) on the worker's device: 1 on, 0 off, -1 (default): NIW for D >= 64, Multinomial for D >= 128 */
     DPMMH_OPT_DRAW_AHEAD = 9,        /* device master: launch the next parameter draws together with the posteriors (default 1); 0 draws when asked. Same results */
     DPMMH_OPT_NUMA_NODE = 7          /* >= 0: keep the pool's and the helper's threads on the CPUs of this NUMA node (the GPU's: worker numa_node); -1: leave them alone (default) */
 };

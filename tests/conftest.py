@@ -18,3 +18,21 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _box_identity(request):
+    """GPU sessions print where they ran (a failure that follows one box around is a hardware / driver question, not a code one)."""
+    if "gpu" not in (request.config.getoption("-m") or "") or "not gpu" in (request.config.getoption("-m") or ""):
+        yield
+        return
+    import socket
+    import subprocess
+    try:
+        uid = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showuniqueid"], capture_output=True, text=True, timeout=20).stdout
+        uid = " ".join(ln.split(":")[-1].strip() for ln in uid.splitlines() if "Unique ID" in ln and "GPU[" in ln)
+    except Exception as e:  # noqa: BLE001
+        uid = f"rocm-smi failed: {e}"
+    cpu = next((ln.split(":")[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")), "?")
+    print(f"\n[box] host {socket.gethostname()} | {os.cpu_count()} x {cpu} | GPU unique id {uid}", flush=True)
+    yield

@@ -167,3 +167,153 @@ def test_byte_copy_path_equals_float_paths(pkg, D, n, K):
     st = wk.suffstats_packed()
     assert st[2 * (lab0[5] - 1) + (sub0[5] - 1), 1 + 3] == want[2 * (lab0[5] - 1) + (sub0[5] - 1), 1 + 3] - P["X"][5, 3] + 256.0
     wk.close()
+
+
+def test_device_dirichlet_draws_law_and_handover(pkg):
+    """dpmm_mult_master_draw: log.(rand(Dirichlet(alpha'))) with alpha' = alpha + sum x (multinomial_prior.jl:16-25) for all 3K distributions
+    on the device.  Law: E[p_d] = alpha'_d / sum alpha' and E[log p_d] = digamma(alpha'_d) - digamma(sum alpha') -- the latter is what a
+    wrong small-alpha branch (alpha' < 1: prior components without counts) would miss -- to 5 standard errors over 500 draws, for populated,
+    one-sided and empty distributions; rows sum to one; same epoch = same draw; the table the sweep kernels evaluate equals the one computed
+    from the fetched log-probabilities."""
+    from scipy.special import digamma, polygamma
+    D, n, K, trials = 300, 6000, 4, 30
+    P = make_problem(D, n, K, trials, seed=123)
+    rng = np.random.default_rng(7)
+    lab = rng.integers(1, K + 1, n); sub = rng.integers(1, 3, n)
+    sub[lab == 2] = 1                      # cluster 2: right sub-cluster empty -> its draw comes from the prior
+    lab[lab == 4] = 1                      # cluster 4: empty
+    wk = worker(pkg, P, seed=31)
+    wk.set_labels(lab, sub); wk.set_num_clusters(K)
+    alpha = rng.uniform(0.15, 2.5, D).astype(np.float32)       # components below 1: the Gamma(a + 1) U^(1/a) branch
+    wk.mult_master_setup(alpha)
+    wk.suffstats_packed(None)
+    N, sums = orc.suffstats_mult(P["X"], D, lab, sub, K)
+    apost = alpha[None, None, :] + sums.astype(np.float32)      # (K, 3, D), Float32 like the reference
+    apost = np.where(N[:, :, None] == 0, alpha[None, None, :], apost).reshape(3 * K, D).astype(np.float64)
+    lr = np.full((K, 2), 0.5, np.float32); w = np.full(K, 1.0 / K, np.float32)
+    reps = 500
+    m1 = np.zeros((3 * K, D)); l1 = np.zeros((3 * K, D)); l2 = np.zeros((3 * K, D))
+    for ep in range(1, reps + 1):
+        wk.mult_master_draw(ep, lr, w)
+        lp = wk.mult_master_draws(K).astype(np.float64)
+        p = np.exp(lp)
+        assert np.allclose(p.sum(1), 1.0, atol=1e-5)
+        m1 += p; l1 += lp; l2 += lp * lp
+    a0 = apost.sum(1, keepdims=True)
+    Ep = apost / a0
+    se_p = np.sqrt(Ep * (1 - Ep) / (a0 + 1) / reps)
+    assert np.all(np.abs(m1 / reps - Ep) < 5 * se_p + 1e-7), np.max(np.abs(m1 / reps - Ep) / se_p)
+    El = digamma(apost) - digamma(a0)
+    se_l = np.sqrt((polygamma(1, apost) - polygamma(1, a0)) / reps)
+    assert np.all(np.abs(l1 / reps - El) < 5 * se_l + 1e-6), np.max(np.abs(l1 / reps - El) / se_l)
+    # deterministic in (seed, epoch, position); rows of different distributions differ
+    wk.mult_master_draw(3, lr, w); a = wk.mult_master_draws(K)
+    wk.mult_master_draw(4, lr, w); wk.mult_master_draw(3, lr, w); b = wk.mult_master_draws(K)
+    assert np.array_equal(a, b) and not np.array_equal(a[0], a[3])
+    # hand-over: the sweep kernels' table from the packed planes == x . logp + log w from the fetched draws
+    tab = wk.debug_loglik()
+    want = np.stack([P["X"].astype(np.float64) @ b[3 * k].astype(np.float64) + np.log(np.float64(w[k])) for k in range(K)])
+    np.testing.assert_allclose(tab, want, rtol=1e-5, atol=1e-3)
+    # a subset pass leaves incomplete rows: the draw refuses them
+    wk.suffstats_packed(np.array([1]))
+    with pytest.raises(pkg.DpmmError):
+        wk.mult_master_draw(5, lr, w)
+    wk.close()
+
+
+def _mult_chain(pkg, host, engine, x, D, N, dev, init=1, seed=5, burnout=5):
+    hyper = host.multinomial_hyper(np.ones(D, np.float32))
+    wk = pkg.Worker(hyper.kind, D, N, device=0, seed=seed)
+    wk.upload_points(np.ascontiguousarray(x.T))
+    s = host.DPMMSampler(wk, hyper, 10.0, N, seed, burnout=burnout)
+    s.model.set_option(engine.OPT_DEVICE_MASTER, dev)
+    s.init_first_clusters(init)
+    return wk, s
+
+
+def test_engine_uses_the_device_dirichlet_draws(pkg):
+    """The engine's Multinomial master with the draws on the device (DPMMH_OPT_DEVICE_MASTER; default for D >= 128): a step that follows a
+    full statistics pass draws on the device (the worker holds the rows of all K clusters), a step that follows an accepted split / merge /
+    removal draws on the host (counters[6] bit 0 says so beforehand); both chains recover the components; the log-probabilities the engine
+    reports are the ones the device drew (normalised rows)."""
+    import importlib
+    host = importlib.import_module("dpmmsubclusters_jl_amd.host")
+    engine = importlib.import_module("dpmmsubclusters_jl_amd.host.engine")
+    D, N, Kt = 200, 20000, 5
+    x, y, _ = host.generate_mnmm_data(N, D, Kt, 150, seed=3)[:3]
+    x = np.ascontiguousarray(x, np.float32)
+    res = {}
+    for dev in (1, 0):
+        wk, s = _mult_chain(pkg, host, engine, x, D, N, dev)
+        on_dev = on_host = 0
+        ks = [s.K]
+        for it in range(60):
+            host_next = int(s.model.get("counters")[6]) & 1
+            s.group_step(False, False)
+            ks.append(s.K)
+            lp = s.model.get("logp")
+            if ks[-1] == ks[-2]:          # (rows of clusters born or renumbered in this step have no draw yet)
+                assert np.allclose(np.exp(lp.astype(np.float64)).sum(1), 1.0, atol=1e-4)
+            if dev:
+                try:
+                    fetched = wk.mult_master_draws(lp.shape[0] // 3) if not host_next else None
+                except pkg.DpmmError:
+                    fetched = None
+                if not host_next and it > 0:
+                    on_dev += 1
+                else:
+                    on_host += 1
+                if fetched is not None and s.K == lp.shape[0] // 3 and not host_next and it > 0 and ks[-1] == ks[-2]:
+                    assert np.array_equal(fetched, lp)
+        lab, _ = wk.get_labels()
+        from dpmmsubclusters_jl_amd.host.sampler import nmi_vi_from_contingency
+        C = np.zeros((int(lab.max()), int(y.max())))
+        np.add.at(C, (lab - 1, np.asarray(y) - 1), 1)
+        res[dev] = (ks, nmi_vi_from_contingency(C)[0], on_dev, on_host)
+        wk.close()
+    print("device draws:", res[1][2], "steps on the device,", res[1][3], "on the host; K", res[1][0][-1], "NMI", res[1][1], "| host K", res[0][0][-1], "NMI", res[0][1])
+    assert res[1][2] >= 30 and res[1][3] >= 2            # both kinds of step happened (splits on the way to 5 components)
+    for dev in (0, 1):
+        assert res[dev][0][-1] >= Kt - 1 and res[dev][1] > 0.9
+
+
+def test_resume_continues_the_chain_with_device_dirichlet_draws(pkg, tmp_path):
+    """A checkpoint carries the rows and whether the NEXT draws of the running chain were due on the host (counters[6]): a resumed run puts
+    the rows back on the device (dpmm_mult_master_put_rows) and continues onto the same draws -- labels equal after the remaining steps,
+    from a checkpoint taken in a quiet step and from one taken right after a split."""
+    import importlib
+    host = importlib.import_module("dpmmsubclusters_jl_amd.host")
+    engine = importlib.import_module("dpmmsubclusters_jl_amd.host.engine")
+    ckpt = importlib.import_module("dpmmsubclusters_jl_amd.host.checkpoint")
+    D, N = 160, 8000
+    x, y, _ = host.generate_mnmm_data(N, D, 4, 120, seed=9)[:3]
+    x = np.ascontiguousarray(x, np.float32)
+    wk, s = _mult_chain(pkg, host, engine, x, D, N, 1, burnout=3)
+    saved, ks = {}, [s.K]
+    total = 40
+    for it in range(1, total + 1):
+        s.group_step(False, False)
+        ks.append(s.K)
+        flag = int(s.model.get("counters")[6]) & 1
+        kind = "split" if ks[-1] > ks[-2] else ("quiet" if (not flag and it > 8) else None)
+        if kind and kind not in saved and it < total - 3:
+            st = {f: s.model.get(f) for f in ckpt._STATE_FIELDS}
+            st["K"], st["it"], st["flag"] = s.K, it, flag
+            st["labels"], st["sub"] = wk.get_labels()
+            saved[kind] = st
+    want = wk.get_labels()
+    wk.close()
+    assert set(saved) == {"split", "quiet"}, ks
+    assert saved["split"]["flag"] == 1 and saved["quiet"]["flag"] == 0
+    for kind, st in saved.items():
+        wk2, s2 = _mult_chain(pkg, host, engine, x, D, N, 1, burnout=3)
+        wk2.set_labels(st["labels"], st["sub"])
+        s2.model.set("K", st["K"])
+        wk2.set_num_clusters(st["K"])
+        for f in ckpt._STATE_FIELDS:
+            s2.model.set(f, st[f])
+        for _ in range(total - st["it"]):
+            s2.group_step(False, False)
+        got = wk2.get_labels()
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), kind
+        wk2.close()

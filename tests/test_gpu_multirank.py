@@ -28,6 +28,7 @@ CASES = {
     "niw64_host": ("niw", 64, 200000, 6, 60, 8, 0),
     "niw8": ("niw", 8, 60000, 5, 60, 6, -1),
     "mult100": ("mult", 100, 60000, 6, 50, 6, -1),
+    "mult200_dev": ("mult", 200, 40000, 5, 50, 6, 1),      # the Dirichlet draws on each rank's device, from the all-reduced rows
 }
 
 
