@@ -905,6 +905,9 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
         a.scratch_by_tile = table ? 1 : 0;
         a.labels_only = table ? 1 : 0;
         a.bins = c->dbins; a.seed = c->seed; a.epoch = epoch; a.final_argmax = final_argmax;
+        a.use_prev = c->have_labels ? 1 : 0;
+        a.order = (!table && c->have_perm && c->opt_ordered) ? c->sb.perm : nullptr;
+        a.order_total = c->sb.perm_total;
         if (c->x_u8) HIPCHK(c, launch_mult_sweep_u8(a, c->dX8, c->ld8, c->d_Lp16, c->sweep_grid, c->stream));
         else if (c->x_bf16_exact) HIPCHK(c, launch_mult_sweep_bf16(a, c->d_Lp16, c->sweep_grid, c->stream));
         else HIPCHK(c, launch_mult_sweep(a, c->sweep_grid, c->stream));

@@ -76,6 +76,10 @@ struct MultSweepArgs {
     uint64_t seed;
     uint32_t epoch;
     int final_argmax;
+    // u8 kernel: previous labels are valid (row-block selection), bin-sorted visiting order of the last statistics pass (nullable)
+    int use_prev;
+    const int32_t *order;
+    const int32_t *order_total;
 };
 hipError_t launch_mult_sweep(const MultSweepArgs &a, int grid, hipStream_t s);
 hipError_t launch_mult_pack(const float *logp, float *Lp, int rows, int64_t ldx, hipStream_t s);

@@ -15,6 +15,7 @@
 //   B operand: x, float4 per lane straight from HBM: lane (c, g) reads elements 16t+4g.. of point c
 // The 3K x TILE table (+ log weights) goes to a per-workgroup scratch (L2), then every lane
 // draws label and sub-label for one point with the oracle-identical inverse-CDF scan.
+#include <type_traits>
 #include "dpmm_device.h"
 #include "dpmm_kernels.h"
 
@@ -184,125 +185,215 @@ __device__ __forceinline__ u32x4 bytes_to_bf16x8(uint32_t w0, uint32_t w1) {
     return r;
 }
 
+// Which parameter rows a tile needs (round 3).  A point's draw reads the K cluster-level values and, of the 2K sub-cluster values, only
+// the TWO of the cluster it lands in -- and in a running chain that is almost always the cluster it was in.  The u8 planes are therefore
+// packed in two groups of 16-row blocks (mult_pack_u8_kernel): blocks [0, NRBc) hold the K cluster rows, blocks NRBc + j the (left, right)
+// rows of clusters 8j .. 8j+7.  A tile evaluates the cluster blocks plus the sub-cluster blocks of the clusters its points were in (a
+// 128-bit set built from the previous labels; with the bin-sorted visiting order a tile spans one or two of them), draws the labels, and
+// runs a second pass over its points only for sub-cluster blocks a NEW label asks for that the first pass did not cover (rare).  A row's
+// value does not depend on which other rows share its pass (each 16-row block accumulates over the features in the same order), so the
+// labels are the ones the all-rows kernel drew; table mode (debug tables, predict) evaluates every block.  K = 32: 3-4 blocks per tile
+// instead of 6.
 template <int B_RBP>
-__global__ __launch_bounds__(256, (B_RBP <= 6 ? 2 : 1)) void mult_sweep_u8_kernel(MultSweepArgs A, const uint8_t *__restrict__ X8, int64_t ld8,
-                                                                                   const uint32_t *__restrict__ Lp8, int NKS8, int NRB) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2][B_RBP * 3 * 256];
+__global__ __launch_bounds__(256, (B_RBP <= 4 ? 2 : 1)) void mult_sweep_u8_kernel(MultSweepArgs A, const uint8_t *__restrict__ X8, int64_t ld8,
+                                                                                   const uint32_t *__restrict__ Lp8, int NKS8, int NRBc, int NRBs,
+                                                                                   int ltab_ok) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
+    // two fragment buffers (slice sl in buffer sl % 2); between the passes of a tile the same memory holds the tile's K x 256 cluster-level
+    // values (when they fit and the tile needs one pass)
+    constexpr int BUFW = B_RBP * 3 * 256;
+    float *const ltab_all = reinterpret_cast<float *>(dyn_lds);
+    __shared__ uint32_t need[4], miss[4];
+    __shared__ int blist[64 + 128];
+    __shared__ int nlist;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ci = lane & 15, g = lane >> 4;
-    const int K = A.K, rows = 3 * K;
+    const int K = A.K, NRB = NRBc + NRBs;
     const int64_t ntiles = (A.n + M_TILE - 1) / M_TILE;
+    const bool use_order = A.order != nullptr && !A.labels_only && *A.order_total == (int32_t)A.n;
+    const bool tab_fits = ltab_ok && !A.labels_only;
+    float *const ltab = ltab_all + wave * 64;                  // column of point `lane` of this wave: ltab[k * 256 + lane]
+#ifdef DPMM_U8_STAMPS
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+#define U8_STAMP(i) { const unsigned long long t_now = __builtin_readcyclecounter(); st_acc[i] += t_now - t_last; t_last = t_now; }
+#else
+#define U8_STAMP(i)
+#endif
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t wbase = tile * M_TILE + (int64_t)wave * 64;
+#ifdef DPMM_U8_STAMPS
+        unsigned long long t_last = __builtin_readcyclecounter();
+#endif
+        const int64_t i0 = tile * M_TILE + (int64_t)wave * 64;
         float *scr = A.scratch + (A.scratch_by_tile ? tile * M_TILE : (int64_t)blockIdx.x * M_TILE) + wave * 64;
         const int64_t sstride = A.scratch_stride;
-        // single pass over the features and K x 64 floats per wave fit the (then idle) fragment buffers: label table in LDS
-        const bool tab_lds = NRB <= B_RBP && (size_t)K * 64 * 4 * 4 <= sizeof(lds) && !A.labels_only;
-        float *ltab = reinterpret_cast<float *>(&lds[0][0]) + (size_t)wave * K * 64;
+        const bool valid = i0 + lane < A.n;
+        const int myp32 = valid ? (use_order ? A.order[i0 + lane] : (int)(i0 + lane)) : 0;     // (table mode keeps storage order: column = point)
+        const int64_t myp = A.labels_only ? i0 + lane : (int64_t)myp32;
         const uint8_t *xp0[M_NG];
         bool pv[M_NG];
 #pragma unroll
         for (int n = 0; n < M_NG; ++n) {
-            const int64_t p = wbase + 16 * n + ci;
-            pv[n] = p < A.n;
+            const int64_t p = A.labels_only ? i0 + 16 * n + ci : (int64_t)__shfl(myp32, 16 * n + ci);
+            pv[n] = i0 + 16 * n + ci < A.n;
             xp0[n] = X8 + (pv[n] ? p : 0) * ld8 + 32 * g;     // row of a valid point (point 0 for the padding lanes), this lane's 32 bytes
         }
-        for (int rb0 = 0; rb0 < NRB; rb0 += B_RBP) {
-            const int nrb = min(B_RBP, NRB - rb0);
-            const int chunk_words = nrb * 3 * 256;
-            f32x4 acc[B_RBP][M_NG];
+        bool tab_lds = false;                                  // this tile's cluster-level values are in LDS
+        if (tid < 4) { need[tid] = 0u; miss[tid] = 0u; }
+        __syncthreads();
+        if (valid && !A.labels_only && A.use_prev) {
+            const int zp = A.bins[myp] >> 1;
+            if (zp >= 0 && zp < K) atomicOr(&need[zp >> 8], 1u << ((zp >> 3) & 31));
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int c = 0;
+            for (int b = 0; b < NRBc; ++b) blist[c++] = b;
+            for (int j = 0; j < NRBs; ++j)
+                if (A.labels_only || ((need[j >> 5] >> (j & 31)) & 1u)) blist[c++] = NRBc + j;
+            nlist = c;
+        }
+        __syncthreads();
+        // one or more passes over the features for the row blocks blist[0 .. cnt)
+        auto run_passes = [&](const int cnt, const bool first_call) {
+            for (int rb0 = 0; rb0 < cnt; rb0 += B_RBP) {
+                const int nrb = min(B_RBP, cnt - rb0);
+                f32x4 acc[B_RBP][M_NG];
 #pragma unroll
-            for (int rb = 0; rb < B_RBP; ++rb)
+                for (int rb = 0; rb < B_RBP; ++rb)
 #pragma unroll
-                for (int n = 0; n < M_NG; ++n) acc[rb][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            constexpr int NST = (B_RBP * 3 * 256 / 4 + 255) / 256;
-            const int chunk_v4 = chunk_words / 4;
-            const int NSL = 4 * NKS8;                         // slices = LDS chunks of this pass
-            // (requesting the fragments TWO slices ahead -- two register sets -- was measured: 0.78 vs 0.77 ms, with spills: the L2 round
-            // trip of the parameter planes is not what bounds a slice)
-            u32x4 st[NST];
-            auto prefetch = [&](int sl) {                     // chunk(sl) lives at Lp8 + (sl * NRB + rb0) * 768 words
-                const u32x4 *src = reinterpret_cast<const u32x4 *>(Lp8 + ((size_t)sl * NRB + rb0) * 768);
+                    for (int n = 0; n < M_NG; ++n) acc[rb][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                // The pass body is compiled once per number of row blocks NR (1 .. B_RBP): with NR a constant the fragment reads of a slice
+                // are a straight line that runs two reads ahead of the matrix instructions.  (With `if (rb < nrb)` around each block the
+                // compiler emitted read -> wait -> 4 MFMA per plane: 9-12 exposed LDS latencies per slice, 2.3 k of a slice's 2.7 k cycles.)
+                auto pass = [&](auto NRc) {
+                    constexpr int NR = decltype(NRc)::value;
+                    constexpr int CV4 = NR * 192;                  // 16-byte vectors of a slice's fragments: 192 per row block (3 planes x 64 lanes)
+                    constexpr int NST = (CV4 + 255) / 256;
+                    const int NSL = 4 * NKS8;                     // slices = LDS chunks of this pass
+                    u32x4 st[NST];
+                    int boff[NST];                                // where staged vector p of this thread comes from
 #pragma unroll
-                for (int p = 0; p < NST; ++p) st[p] = src[min(p * 256 + tid, chunk_v4 - 1)];
-            };
-            auto commit = [&](uint32_t *buf) {
-#pragma unroll
-                for (int p = 0; p < NST; ++p) reinterpret_cast<u32x4 *>(buf)[min(p * 256 + tid, chunk_v4 - 1)] = st[p];
-            };
-            auto loadx = [&](int ks, u32x4 (&xa)[M_NG], u32x4 (&xb)[M_NG]) {     // unconditional: ld8 is a multiple of 128, padding is zero
-#pragma unroll
-                for (int n = 0; n < M_NG; ++n) {
-                    xa[n] = *reinterpret_cast<const u32x4 *>(xp0[n] + 128 * (int64_t)ks);
-                    xb[n] = *reinterpret_cast<const u32x4 *>(xp0[n] + 128 * (int64_t)ks + 16);
-                }
-            };
-            u32x4 xa[M_NG], xb[M_NG], na[M_NG], nb[M_NG];
-            prefetch(0);
-            loadx(0, xa, xb);
-            for (int ks = 0; ks < NKS8; ++ks) {
-                loadx(min(ks + 1, NKS8 - 1), na, nb);        // next k-step's bytes: four slices of matrix work ahead of their use
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int sl = 4 * ks + q;
-                    uint32_t *buf = lds[sl & 1];
-                    commit(buf);
-                    __syncthreads();
-                    prefetch(min(sl + 1, NSL - 1));
-                    u32x4 xq[M_NG];
-#pragma unroll
-                    for (int n = 0; n < M_NG; ++n) {
-                        const u32x4 src = q < 2 ? xa[n] : xb[n];
-                        const uint32_t w0 = (q & 1) ? src.z : src.x, w1 = (q & 1) ? src.w : src.y;
-                        xq[n] = pv[n] ? bytes_to_bf16x8(w0, w1) : (u32x4){0u, 0u, 0u, 0u};
+                    for (int p = 0; p < NST; ++p) {
+                        const int e = min(p * 256 + tid, CV4 - 1);
+                        boff[p] = blist[rb0 + e / 192] * 192 + e % 192;
                     }
+                    auto prefetch = [&](int sl) {                 // block b of slice sl lives at Lp8 + (sl * NRB + b) * 768 words
+                        const u32x4 *src = reinterpret_cast<const u32x4 *>(Lp8) + (size_t)sl * NRB * 192;
 #pragma unroll
-                    for (int rb = 0; rb < B_RBP; ++rb) {
-                        if (rb < nrb) {
+                        for (int p = 0; p < NST; ++p) st[p] = src[boff[p]];
+                    };
+                    auto commit = [&](uint32_t *buf) {
 #pragma unroll
-                            for (int pl = 0; pl < 3; ++pl) {
-                                const u32x4 a = *reinterpret_cast<const u32x4 *>(buf + (rb * 3 + pl) * 256 + lane * 4);
+                        for (int p = 0; p < NST; ++p) reinterpret_cast<u32x4 *>(buf)[min(p * 256 + tid, CV4 - 1)] = st[p];
+                    };
+                    auto loadx = [&](int ks, u32x4 (&xa)[M_NG], u32x4 (&xb)[M_NG]) {     // unconditional: ld8 is a multiple of 128, padding is zero
+#pragma unroll
+                        for (int n = 0; n < M_NG; ++n) {
+                            xa[n] = *reinterpret_cast<const u32x4 *>(xp0[n] + 128 * (int64_t)ks);
+                            xb[n] = *reinterpret_cast<const u32x4 *>(xp0[n] + 128 * (int64_t)ks + 16);
+                        }
+                    };
+                    u32x4 xa[M_NG], xb[M_NG], na[M_NG], nb[M_NG];
+                    // Slice sl is staged one slice AHEAD of its use: during slice sl every thread commits its part of slice sl + 1 to the other
+                    // buffer, and the workgroup barrier sits at the END of the slice.  A wave that leaves the barrier finds the fragments of its
+                    // next slice complete in LDS -- the chain global load -> ds_write -> barrier -> ds_read -> MFMA of the earlier scheme (the
+                    // barrier between the write and the read of the SAME slice) is off the critical path; the barrier only absorbs the skew of
+                    // the waves' matrix phases.  Two buffers still do: the buffer slice sl + 1 goes to was last read in slice sl - 1, and every
+                    // wave finished that before the barrier this wave has already passed.
+                    prefetch(0);
+                    loadx(0, xa, xb);
+                    int cur = 0;
+                    commit(dyn_lds);
+                    if (NSL > 1) prefetch(1);
+                    __syncthreads();
+                    for (int ks = 0; ks < NKS8; ++ks) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int sl = 4 * ks + q;
+                            uint32_t *buf = dyn_lds + cur * BUFW;
+                            cur ^= 1;
+                            u32x4 a[3];
+                            auto rd = [&](int i) { return *reinterpret_cast<const u32x4 *>(buf + i * 256 + lane * 4); };   // i = 3 rb + plane
+                            a[0] = rd(0);
+                            a[1] = rd(1);
+                            if (sl + 1 < NSL) commit(dyn_lds + cur * BUFW);     // slice sl + 1 (in registers since the previous slice) -> next buffer
+                            if (sl + 2 < NSL) prefetch(sl + 2);
+                            // next k-step's bytes.  Vector loads return in order: issued BEHIND this slice's fragment request they stay in
+                            // flight across the next commit (which waits for that request only) -- two slices of cover instead of one
+                            if (q == 0) loadx(min(ks + 1, NKS8 - 1), na, nb);
+                            u32x4 xq[M_NG];
+#pragma unroll
+                            for (int n = 0; n < M_NG; ++n) {
+                                const u32x4 src = q < 2 ? xa[n] : xb[n];
+                                const uint32_t w0 = (q & 1) ? src.z : src.x, w1 = (q & 1) ? src.w : src.y;
+                                xq[n] = pv[n] ? bytes_to_bf16x8(w0, w1) : (u32x4){0u, 0u, 0u, 0u};
+                            }
+#pragma unroll
+                            for (int i = 0; i < 3 * NR; ++i) {
+                                if (i + 2 < 3 * NR) a[(i + 2) % 3] = rd(i + 2);
 #pragma unroll
                                 for (int n = 0; n < M_NG; ++n)
-                                    acc[rb][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, xq[n]), acc[rb][n], 0, 0, 0);
+                                    acc[i / 3][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i % 3]), __builtin_bit_cast(bf16x8, xq[n]), acc[i / 3][n], 0, 0, 0);
+                            }
+                            __syncthreads();
+                        }
+#pragma unroll
+                        for (int n = 0; n < M_NG; ++n) { xa[n] = na[n]; xb[n] = nb[n]; }
+                    }
+                };
+                switch (nrb) {
+                    case 1: pass(std::integral_constant<int, 1>{}); break;
+                    case 2: pass(std::integral_constant<int, 2>{}); break;
+                    case 3: if constexpr (B_RBP >= 3) pass(std::integral_constant<int, 3>{}); break;
+                    case 4: if constexpr (B_RBP >= 4) pass(std::integral_constant<int, 4>{}); break;
+                    case 5: if constexpr (B_RBP >= 5) pass(std::integral_constant<int, 5>{}); break;
+                    case 6: if constexpr (B_RBP >= 6) pass(std::integral_constant<int, 6>{}); break;
+                    case 7: if constexpr (B_RBP >= 7) pass(std::integral_constant<int, 7>{}); break;
+                    default: if constexpr (B_RBP >= 8) pass(std::integral_constant<int, 8>{}); break;
+                }
+                // (the last slice ended with a barrier: every wave is done with the fragment buffers of this pass)
+                const bool tab_now = tab_fits && first_call && cnt <= B_RBP;
+                if (first_call) tab_lds = tab_now;
+#pragma unroll
+                for (int rb = 0; rb < B_RBP; ++rb) {
+                    if (rb < nrb) {
+                        const int vb = blist[rb0 + rb];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = 4 * g + r;
+                            const int k = NRBs == 0 ? i / 3 : (vb < NRBc ? 16 * vb + i : 8 * (vb - NRBc) + (i >> 1));
+                            const int w = NRBs == 0 ? i % 3 : (vb < NRBc ? 0 : 1 + (i & 1));
+                            if (k < K) {
+                                const int row = 3 * k + w;
+                                const float cst = A.cst[row];
+#pragma unroll
+                                for (int n = 0; n < M_NG; ++n) {
+                                    const float v = acc[rb][n][r] + cst;
+                                    if (w == 0 && tab_now) ltab[k * 256 + 16 * n + ci] = v;      // cluster-level rows: the label draw reads them from LDS
+                                    else scr[(int64_t)row * sstride + 16 * n + ci] = v;
+                                }
                             }
                         }
                     }
                 }
-#pragma unroll
-                for (int n = 0; n < M_NG; ++n) { xa[n] = na[n]; xb[n] = nb[n]; }
             }
-            __syncthreads();  // every wave is done with the fragment buffers: they hold the label table from here on
-#pragma unroll
-            for (int rb = 0; rb < B_RBP; ++rb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * (rb0 + rb) + 4 * g + r;
-                    if (rb < nrb && row < rows) {
-                        const float cst = A.cst[row];
-#pragma unroll
-                        for (int n = 0; n < M_NG; ++n) {
-                            const float v = acc[rb][n][r] + cst;
-                            scr[(int64_t)row * sstride + 16 * n + ci] = v;
-                            if (tab_lds && row % 3 == 0) ltab[(row / 3) * 64 + 16 * n + ci] = v;     // cluster-level rows: the label draw reads them from LDS
-                        }
-                    }
-                }
-        }
+        };
+        U8_STAMP(0)
+        run_passes(nlist, true);
         __syncthreads();
-        const int64_t myp = wbase + lane;
-        const bool valid = myp < A.n;
-        if (valid && !A.labels_only && tab_lds) {
-            // same arithmetic, same order as the global-table path below (and the CPU oracle); the K values of a point come from LDS
-            // (the global scratch cost ~30 % of the kernel: three passes of K dependent-latency L2 loads per point)
-            const float *col = ltab + lane;
-            const Philox4 rr = philox4x32_10(A.seed, (uint64_t)(A.first_index + myp), A.epoch, STREAM_SWEEP);
-            int z = 0;
+        U8_STAMP(1)
+        int z = 0;
+        const Philox4 rr = philox4x32_10(A.seed, (uint64_t)(A.first_index + myp), A.epoch, STREAM_SWEEP);
+        if (valid && !A.labels_only) {
+            // same arithmetic, same order as the other Multinomial kernels (and the CPU oracle); the K values of a point come from LDS when
+            // they fit (the global scratch cost ~30 % of the kernel: three passes of K dependent-latency L2 loads per point)
+            const float *col = tab_lds ? ltab + lane : scr + lane;
+            const int64_t cs = tab_lds ? 256 : 3 * sstride;
             float m = -INFINITY;
             int best = 0;
             bool nan_seen = false;
             for (int k = 0; k < K; ++k) {
-                const float a = col[k * 64];
+                const float a = col[k * cs];
                 if (a != a) {
                     if (!nan_seen) { nan_seen = true; best = k; }
                 } else if (a > m) {
@@ -316,54 +407,46 @@ __global__ __launch_bounds__(256, (B_RBP <= 6 ? 2 : 1)) void mult_sweep_u8_kerne
                 z = 0;
             } else {
                 float s = 0.f;
-                for (int k = 0; k < K; ++k) s += exp_det(nan_to_ninf(col[k * 64]) - m);
+                for (int k = 0; k < K; ++k) s += exp_det(nan_to_ninf(col[k * cs]) - m);
                 const float t = u01(rr.v[0]) * s;
                 float cw = 0.f;
                 z = K - 1;
                 for (int k = 0; k < K; ++k) {
-                    cw += exp_det(nan_to_ninf(col[k * 64]) - m);
+                    cw += exp_det(nan_to_ninf(col[k * cs]) - m);
                     if (!(cw < t)) { z = k; break; }
                 }
             }
-            const float *gcol = scr + lane;
-            const float b0 = gcol[(int64_t)(3 * z + 1) * sstride], b1 = gcol[(int64_t)(3 * z + 2) * sstride];
-            A.bins[myp] = 2 * z + draw2(b0, b1, u01(rr.v[1]));
-        } else if (valid && !A.labels_only) {
-            const float *col = scr + lane;
-            const Philox4 rr = philox4x32_10(A.seed, (uint64_t)(A.first_index + myp), A.epoch, STREAM_SWEEP);
-            int z = 0;
-            float m = -INFINITY;
-            int best = 0;
-            bool nan_seen = false;
-            for (int k = 0; k < K; ++k) {
-                const float a = col[(int64_t)(3 * k) * sstride];
-                if (a != a) {
-                    if (!nan_seen) { nan_seen = true; best = k; }
-                } else if (a > m) {
-                    m = a;
-                    if (!nan_seen) best = k;
+            const int j = z >> 3;
+            if (NRBs > 0 && !((need[j >> 5] >> (j & 31)) & 1u)) atomicOr(&miss[j >> 5], 1u << (j & 31));
+        }
+        if (!A.labels_only) {
+            __syncthreads();
+            U8_STAMP(2)
+            if (miss[0] | miss[1] | miss[2] | miss[3]) {           // (uniform) a new label outside the blocks of the first pass: evaluate those now
+                __syncthreads();
+                if (tid == 0) {
+                    int c = 0;
+                    for (int j2 = 0; j2 < NRBs; ++j2)
+                        if ((miss[j2 >> 5] >> (j2 & 31)) & 1u) blist[c++] = NRBc + j2;
+                    nlist = c;
                 }
+                __syncthreads();
+                run_passes(nlist, false);
+                __syncthreads();
             }
-            if (A.final_argmax) {
-                z = best;
-            } else if (m == -INFINITY) {
-                z = 0;
-            } else {
-                float s = 0.f;
-                for (int k = 0; k < K; ++k) s += exp_det(nan_to_ninf(col[(int64_t)(3 * k) * sstride]) - m);
-                const float t = u01(rr.v[0]) * s;
-                float cw = 0.f;
-                z = K - 1;
-                for (int k = 0; k < K; ++k) {
-                    cw += exp_det(nan_to_ninf(col[(int64_t)(3 * k) * sstride]) - m);
-                    if (!(cw < t)) { z = k; break; }
-                }
+            if (valid) {
+                const float *gcol = scr + lane;
+                const float b0 = gcol[(int64_t)(3 * z + 1) * sstride], b1 = gcol[(int64_t)(3 * z + 2) * sstride];
+                A.bins[myp] = 2 * z + draw2(b0, b1, u01(rr.v[1]));
             }
-            const float b0 = col[(int64_t)(3 * z + 1) * sstride], b1 = col[(int64_t)(3 * z + 2) * sstride];
-            A.bins[myp] = 2 * z + draw2(b0, b1, u01(rr.v[1]));
         }
         __syncthreads();
+        U8_STAMP(3)
     }
+#ifdef DPMM_U8_STAMPS
+    if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 77 || blockIdx.x == 300) && !A.labels_only)
+        printf("u8 stamps block %d: setup %llu passes %llu draw %llu subdraw+fallback %llu\n", (int)blockIdx.x, st_acc[0], st_acc[1], st_acc[2], st_acc[3]);
+#endif
 }
 
 template <int B_RBP>   // row blocks (16 parameter rows each) per pass over the features
@@ -534,19 +617,24 @@ __global__ void mult_pack_bf16_kernel(const float *__restrict__ logp, uint32_t *
     }
 }
 
-// Lp8[sl][rb][plane][lane][8 bf16], sl = 4 ks + q : element j of lane (i, g) = plane_p(logp[16 rb + i][128 ks + 32 g + 8 q + j])
-__global__ void mult_pack_u8_kernel(const float *__restrict__ logp, uint32_t *__restrict__ Lp8, int rows, int64_t ldx, int NSL, int NRB) {
+// Lp8[sl][vb][plane][lane][8 bf16], sl = 4 ks + q : element j of lane (i, g) = plane_p(logp[row(vb, i)][128 ks + 32 g + 8 q + j]) with the row
+// blocks in two groups: vb < NRBc: the cluster row of cluster 16 vb + i (source row 3k); vb = NRBc + j: the left / right row (i odd) of
+// cluster 8 j + i / 2 (source row 3k + 1 + i % 2) -- see mult_sweep_u8_kernel.  3K <= 16 (NRBs = 0): all rows in block 0, in source order
+__global__ void mult_pack_u8_kernel(const float *__restrict__ logp, uint32_t *__restrict__ Lp8, int K, int64_t ldx, int NSL, int NRBc, int NRBs) {
+    const int NRB = NRBc + NRBs;
     const int64_t total = (int64_t)NSL * NRB * 3 * 256;   // uint32 words, two bf16 each
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int w = (int)(e & 3), lane = (int)((e >> 2) & 63);
         int64_t t = e >> 8;
         const int pl = (int)(t % 3); t /= 3;
-        const int rb = (int)(t % NRB), sl = (int)(t / NRB);
-        const int row = 16 * rb + (lane & 15);
+        const int vb = (int)(t % NRB), sl = (int)(t / NRB);
+        const int i = lane & 15;
+        const int k = NRBs == 0 ? i / 3 : (vb < NRBc ? 16 * vb + i : 8 * (vb - NRBc) + (i >> 1));
+        const int row = NRBs == 0 ? i : 3 * k + (vb < NRBc ? 0 : 1 + (i & 1));
         uint32_t out = 0;
         for (int h = 0; h < 2; ++h) {
             const int col = 128 * (sl >> 2) + 32 * (lane >> 4) + 8 * (sl & 3) + 2 * w + h;
-            float v = (row < rows && col < ldx) ? logp[(size_t)row * ldx + col] : 0.f;
+            float v = (k < K && col < ldx) ? logp[(size_t)row * ldx + col] : 0.f;
             uint32_t bits = 0;
             for (int p = 0; p <= pl; ++p) {
                 bits = bf16_rne_bits(v);
@@ -582,24 +670,59 @@ hipError_t launch_u8_convert(const float *X, int64_t ldx, int D, int64_t n, uint
     return hipGetLastError();
 }
 
+// row blocks of the u8 planes for K clusters: cluster blocks, sub-cluster blocks (none when all 3K rows fit one block)
+static inline void u8_blocks(int K, int &NRBc, int &NRBs) {
+    NRBc = (K + 15) / 16;
+    NRBs = 3 * K <= 16 ? 0 : (K + 7) / 8;
+}
+
 size_t mult_pack_u8_words(int rows, int64_t ld8) {
-    const int NSL = (int)(ld8 / 32), NRB = (rows + 15) / 16;
+    int NRBc, NRBs;
+    u8_blocks(rows / 3, NRBc, NRBs);
+    const int NSL = (int)(ld8 / 32), NRB = NRBc + NRBs;
     return (size_t)NSL * NRB * 3 * 256;
 }
 
 hipError_t launch_mult_pack_u8(const float *logp, uint32_t *Lp8, int rows, int64_t ldx, int64_t ld8, hipStream_t s) {
-    const int NSL = (int)(ld8 / 32), NRB = (rows + 15) / 16;
-    hipLaunchKernelGGL(mult_pack_u8_kernel, dim3(512), dim3(256), 0, s, logp, Lp8, rows, ldx, NSL, NRB);
+    const int K = rows / 3, NSL = (int)(ld8 / 32);
+    int NRBc, NRBs;
+    u8_blocks(K, NRBc, NRBs);
+    hipLaunchKernelGGL(mult_pack_u8_kernel, dim3(512), dim3(256), 0, s, logp, Lp8, K, ldx, NSL, NRBc, NRBs);
+    return hipGetLastError();
+}
+
+// dynamic LDS of mult_sweep_u8_kernel<B>: the two fragment buffers, or the tile's K x 256 cluster-level table (it aliases them) if that is larger.
+// A compute unit has 160 KiB: the instantiations that run two workgroups per unit take up to 76 KiB each, the single-workgroup ones up to 152.
+template <int B>
+static hipError_t launch_u8(const MultSweepArgs &a, const uint8_t *X8, int64_t ld8, const uint32_t *Lp8, int grid, hipStream_t s) {
+    const int NKS8 = (int)(ld8 / 128);
+    int NRBc, NRBs;
+    u8_blocks(a.K, NRBc, NRBs);
+    const size_t frag = sizeof(uint32_t) * 2 * B * 3 * 256, tab = sizeof(float) * 256 * (size_t)a.K;
+    const size_t cap = (B <= 4 ? 76 : 152) * 1024;
+    const int ltab_ok = tab <= cap;
+    const size_t lds = ltab_ok && tab > frag ? tab : frag;
+    static size_t attr = 48 * 1024;
+    if (lds > attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mult_sweep_u8_kernel<B>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
+        if (e != hipSuccess) return e;
+        attr = cap;
+    }
+    hipLaunchKernelGGL(mult_sweep_u8_kernel<B>, dim3(grid), dim3(256), lds, s, a, X8, ld8, Lp8, NKS8, NRBc, NRBs, ltab_ok);
     return hipGetLastError();
 }
 
 hipError_t launch_mult_sweep_u8(const MultSweepArgs &a, const uint8_t *X8, int64_t ld8, const uint32_t *Lp8, int grid, hipStream_t s) {
-    const int NKS8 = (int)(ld8 / 128), NRB = (3 * a.K + 15) / 16;
-    if (NRB <= 2) hipLaunchKernelGGL(mult_sweep_u8_kernel<2>, dim3(grid), dim3(256), 0, s, a, X8, ld8, Lp8, NKS8, NRB);
-    else if (NRB <= 4) hipLaunchKernelGGL(mult_sweep_u8_kernel<4>, dim3(grid), dim3(256), 0, s, a, X8, ld8, Lp8, NKS8, NRB);
-    else if (NRB <= 6) hipLaunchKernelGGL(mult_sweep_u8_kernel<6>, dim3(grid), dim3(256), 0, s, a, X8, ld8, Lp8, NKS8, NRB);
-    else hipLaunchKernelGGL(mult_sweep_u8_kernel<8>, dim3(grid), dim3(256), 0, s, a, X8, ld8, Lp8, NKS8, NRB);
-    return hipGetLastError();
+    // row blocks of a typical tile of a running chain: the cluster blocks + two sub-cluster blocks (table mode: all of them)
+    int NRBc, NRBs;
+    u8_blocks(a.K, NRBc, NRBs);
+    // row blocks of a typical tile of a running chain: the cluster blocks + ONE sub-cluster block (a tile of the bin-sorted order that spans two
+    // groups of eight clusters takes a second pass when that exceeds the instantiation); table mode: all of them
+    const int typical = a.labels_only ? NRBc + NRBs : NRBc + (NRBs < 1 ? NRBs : 1);
+    if (typical <= 2) return launch_u8<2>(a, X8, ld8, Lp8, grid, s);
+    if (typical <= 4) return launch_u8<4>(a, X8, ld8, Lp8, grid, s);
+    if (typical <= 6) return launch_u8<6>(a, X8, ld8, Lp8, grid, s);
+    return launch_u8<8>(a, X8, ld8, Lp8, grid, s);
 }
 
 // data check at upload: 1 if every element is exactly representable in bf16 (low 16 mantissa bits zero)

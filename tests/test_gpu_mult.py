@@ -317,3 +317,39 @@ def test_resume_continues_the_chain_with_device_dirichlet_draws(pkg, tmp_path):
         got = wk2.get_labels()
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), kind
         wk2.close()
+
+
+@pytest.mark.parametrize("K,D,n", [(5, 300, 4000), (12, 300, 5000), (40, 260, 6000), (70, 130, 5000)])
+@pytest.mark.parametrize("ordered", [True, False])
+def test_selective_row_blocks_equal_all_rows(pkg, K, D, n, ordered):
+    """The byte kernel evaluates, per tile, the cluster rows + the sub-cluster row blocks of the clusters its points WERE in, and takes a second
+    pass for blocks a new label asks for (mult_sweep_u8_kernel).  With previous labels that are right for ~70 % of the points and random for the
+    rest -- so that tiles take both routes -- in the bin-sorted visiting order and in storage order: labels and sub-labels equal the oracle's
+    draw applied to the all-rows tables of the same kernel (bit-exact), for K below / across / beyond one block of 16 cluster rows."""
+    P = make_problem(D, n, K, 60, seed=11 * K + D)
+    rng = np.random.default_rng(K)
+    prev = (P["z"] + 1).astype(np.int64)
+    wrong = rng.random(n) < 0.3
+    prev[wrong] = rng.integers(1, K + 1, wrong.sum())
+    sub0 = rng.integers(1, 3, n)
+    seed, first = 17, 999
+    wk = worker(pkg, P, seed, first)
+    wk.set_labels(prev, sub0); wk.set_num_clusters(K)
+    if ordered:
+        wk.suffstats_packed()                 # leaves the bin-sorted order of these labels
+    wk.set_params_mult(P["logp"], P["lr"], P["w"])
+    tab = wk.debug_loglik()
+    tab2 = wk.debug_subloglik()
+    for epoch in (1, 2):                       # the second sweep starts from the first one's labels (previous = current almost everywhere)
+        wk.sweep(epoch)
+        lab, sub = wk.get_labels()
+        u0, u1 = orc.uniforms(seed, epoch, 0, first, n)
+        assert np.array_equal(orc.sample_log_cat(tab, u0), lab), (K, ordered, epoch)
+        i = np.arange(n)
+        pair = np.stack([tab2[2 * (lab - 1), i], tab2[2 * (lab - 1) + 1, i]])
+        assert np.array_equal(orc.sample_log_cat(pair, u1), sub), (K, ordered, epoch)
+        if ordered:
+            wk.suffstats_packed()
+            wk.set_params_mult(P["logp"], P["lr"], P["w"])
+    assert (lab != prev).mean() > 0.2          # (the sweep did move the points that started in a wrong cluster)
+    wk.close()
