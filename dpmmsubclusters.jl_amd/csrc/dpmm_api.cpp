@@ -113,6 +113,7 @@ struct dpmm_ctx {
     bool cache_force = true;           // the next per-step pass computes every cluster in full (points uploaded, cache re-allocated, K changed)
     int cache_K = -1;
     int opt_derive = 1;
+    int opt_noise_ahead = 1;           // normals of the next draws on the second stream beside the sweep (DPMM_OPT_NOISE_AHEAD)
     // device master (niw_master.hip)
     bool master = false;
     NiwMasterArgs ma{};
@@ -1541,7 +1542,7 @@ int dpmm_niw_master_draw(dpmm_ctx *c, uint32_t epoch, int K, const int32_t *slot
     // with another epoch, or for more clusters, generates its own.
     // (launched by noise_flush right AFTER the sweep kernel of this step: the launch and its event record would otherwise sit on the
     // host's critical path between the master's decisions and the sweep launch)
-    c->noise_pending = true; c->noise_pend_epoch = epoch + 1; c->noise_pend_nmat = 3 * std::min(K + 4, c->master_K);
+    c->noise_pending = c->opt_noise_ahead != 0; c->noise_pend_epoch = epoch + 1; c->noise_pend_nmat = 3 * std::min(K + 4, c->master_K);
     c->work_zeroed = true;
     c->have_screen_prep = false;     // (the K > 64 far mask needs the raw factors: not built on this path; the tail screen is)
     c->K = K;
@@ -2001,6 +2002,7 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
         case DPMM_OPT_SWEEP_QUEUE_ROUNDS: c->opt_queue_rounds = value < 0 ? -1 : (int)value; return DPMM_OK;
         case DPMM_OPT_BALL_SCREEN: c->opt_ball = value != 0; return DPMM_OK;
         case DPMM_OPT_STATS_DERIVE: c->opt_derive = value != 0; c->cache_force = true; return DPMM_OK;
+        case DPMM_OPT_NOISE_AHEAD: c->opt_noise_ahead = value != 0; return DPMM_OK;
         case DPMM_OPT_KERNEL_TIMING:
             c->opt_timing = (int)value & 7;
             if (!(c->opt_timing & 1)) c->have_sweep_ev = false;
