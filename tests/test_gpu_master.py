@@ -330,9 +330,11 @@ def test_draws_launched_ahead_do_not_change_the_chain(pkg, D):
     N, Kt = 20000, 5
     X, y = host.gaussian_mixture_shard(N, D, Kt, 100.0, 4242, 0, N)
     prior = host.niw_hyperparams(1.0, np.zeros(D), D + 3, np.eye(D))
+    from dpmmsubclusters_jl_amd import binding
     out = []
-    for ahead in (1, 0):
+    for ahead, noise in ((1, 1), (0, 1), (1, 0), (0, 0)):     # DPMM_OPT_NOISE_AHEAD: the normals of the next draws on the second stream, or inline
         wk = pkg.Worker(pkg.PRIOR_NIW, D, N, device=0, seed=11)
+        wk.set_option(binding.OPT_NOISE_AHEAD, noise)
         wk.upload_points(X)
         s = host.DPMMSampler(wk, prior, 10.0, N, 11, burnout=3)
         s._configure()
@@ -347,10 +349,12 @@ def test_draws_launched_ahead_do_not_change_the_chain(pkg, D):
         p = s.params
         out.append((trace, lab.copy(), sub.copy(), p["mu"].copy(), p["R"].copy(), s.model.get("log_marginal").copy()))
         wk.close()
-    a, b = out
-    assert a[0] == b[0] and max(a[0]) > 1
-    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
-    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+    a = out[0]
+    assert max(a[0]) > 1
+    for b in out[1:]:
+        assert a[0] == b[0]
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
 
 
 @pytest.mark.parametrize("D", [1, 16, 17, 64, 200])
