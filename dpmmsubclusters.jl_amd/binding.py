@@ -48,6 +48,8 @@ ABI = [
     ("dpmm_mult_master_draw", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     ("dpmm_mult_master_draws", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     ("dpmm_mult_master_put_rows", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
+    ("dpmm_mult_master_pairs_ahead", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
+    ("dpmm_mult_master_marginals", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int)]),
     ("dpmm_sweep", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int]),
     ("dpmm_packed_stride", ctypes.c_int64, [ctypes.c_void_p]),
     ("dpmm_suffstats_packed_device", ctypes.c_int, [ctypes.c_void_p, _c_i64p, ctypes.c_int, ctypes.c_void_p]),
@@ -527,6 +529,18 @@ class Worker:
         out = np.empty((3 * K, self.D), np.float32)
         self._chk(self._lib.dpmm_mult_master_draws(self._h, int(K), out.ctypes.data))
         return out
+
+    def mult_master_pairs_ahead(self, ki, kj, outlier_first=False):
+        a = np.ascontiguousarray(ki, np.int32); b = np.ascontiguousarray(kj, np.int32)
+        self._chk(self._lib.dpmm_mult_master_pairs_ahead(self._h, int(bool(outlier_first)), a.ctypes.data, b.ctypes.data, len(a)))
+
+    def mult_master_marginals(self, K):
+        """-> (N [3K], log-marginals [3K], pooled log-marginals of the pairs asked for ahead)"""
+        pn, pl, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int()
+        self._chk(self._lib.dpmm_mult_master_marginals(self._h, int(K), ctypes.byref(pn), ctypes.byref(pl), ctypes.byref(n)))
+        nl = np.ctypeslib.as_array(ctypes.cast(pn, ctypes.POINTER(ctypes.c_double)), shape=(3 * K, 2)).copy()
+        pairs = np.ctypeslib.as_array(ctypes.cast(pl, ctypes.POINTER(ctypes.c_double)), shape=(max(n.value, 1),)).copy()[:n.value]
+        return nl[:, 0], nl[:, 1], pairs
 
     def mult_master_put_rows(self, rows):
         r = np.ascontiguousarray(rows, np.float64)

@@ -108,6 +108,14 @@ struct dpmm_ctx {
     float *d_malpha = nullptr;         // [2][ldx]: cluster prior | outlier prior
     bool mult_master = false, mult_has_alpha1 = false;
     int rows_full_K = -1;
+    // ... and its log-marginals (mult_marginal_kernel): prior constants {sum a, sum lgamma(a)} x 2, the pair list asked for ahead of the
+    // next per-step pass, the pinned result block [3K][2] (N, L) | [pairs] and what it currently answers
+    double mult_prior_c[4] = {0, 0, 0, 0};
+    int32_t *d_mpairs = nullptr;
+    std::vector<int32_t> mpairs_req, mpairs_shadow;
+    bool marg_req = false, marg_valid = false;
+    int marg_req_outlier = 0, marg_K = 0, marg_np = 0;
+    double *h_marg = nullptr;
     // derived sub-cluster statistics of the per-step pass (derive_rows_kernel): cached cluster-level rows + label tracking
     double *d_ccache = nullptr;        // [Kcap][packed_stride] left + right of every cluster as of the last pass that computed both
     bool cache_force = true;           // the next per-step pass computes every cluster in full (points uploaded, cache re-allocated, K changed)
@@ -469,7 +477,8 @@ int dpmm_destroy(dpmm_ctx *c) {
     for (int i = 0; i < 4; ++i) if (c->h_list[i]) hipHostFree(c->h_list[i]);
     if (c->h_master) hipHostFree(c->h_master);
     if (c->h_draw) hipHostFree(c->h_draw);
-    hipFree(c->d_malpha);
+    hipFree(c->d_malpha); hipFree(c->d_mpairs);
+    if (c->h_marg) hipHostFree(c->h_marg);
     hipFree(c->d_counts64); hipFree(c->d_row_off); hipFree(c->d_inv_off); hipFree(c->d_work); hipFree(c->d_par);
     comm_release(c);
     if (c->h_red) hipHostFree(c->h_red);
@@ -1053,6 +1062,7 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
     if (!c->have_points || !c->have_labels || c->K < 1) return fail(c, DPMM_ESTATE, "suffstats need points, labels and parameters (K)");
     HIPCHK(c, hipSetDevice(c->device));
     const int nbins = 2 * c->K;
+    c->marg_valid = false;
     if (c->opt_timing & 2) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     if (idx) {
         c->h_sel.assign(nbins, 0);
@@ -1173,11 +1183,13 @@ int dpmm_suffstats_host(dpmm_ctx *c, const int64_t *idx, int n_idx, const double
     return DPMM_OK;
 }
 
+static int mult_marginals_launch(dpmm_ctx *c);
 int dpmm_step_stats(dpmm_ctx *c, uint32_t reset_epoch, const double **packed, const uint8_t **bad) {
     if (!c || !packed || !bad) return DPMM_EINVAL;
     const size_t out_bytes = sizeof(double) * 2 * (size_t)std::max(c->K, 1) * (size_t)c->packed_stride;
     if (int rc = ensure_out(c, out_bytes + DPMM_MAX_CLUSTERS + 64)) return rc;
     if (int rc = run_stats(c, nullptr, 0, true, reset_epoch)) return rc;
+    if (c->marg_req) if (int rc = mult_marginals_launch(c)) return rc;       // the master's log-marginals ride behind the statistics: one wait
     HIPCHK(c, launch_copy_bytes(c->h_out, c->d_out, out_bytes + (size_t)c->K + 1, c->stream));      // rows | flags
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *packed = reinterpret_cast<const double *>(c->h_out);
@@ -1676,6 +1688,15 @@ int dpmm_mult_master_setup(dpmm_ctx *c, const float *alpha, const float *alpha_o
     HIPCHK(c, hipMemcpy(c->d_malpha, alpha, sizeof(float) * (size_t)c->D, hipMemcpyHostToDevice));
     if (alpha_outlier) HIPCHK(c, hipMemcpy(c->d_malpha + c->ldx, alpha_outlier, sizeof(float) * (size_t)c->D, hipMemcpyHostToDevice));
     c->mult_has_alpha1 = alpha_outlier != nullptr;
+    for (int p = 0; p < 2; ++p) {
+        const float *al = p ? alpha_outlier : alpha;
+        double sa = 0.0, sl = 0.0;
+        if (al) for (int d = 0; d < c->D; ++d) { sa += (double)al[d]; sl += lgamma((double)al[d]); }
+        c->mult_prior_c[2 * p] = sa; c->mult_prior_c[2 * p + 1] = sl;
+    }
+    if (!c->d_mpairs) HIPCHK(c, hipMalloc(&c->d_mpairs, sizeof(int32_t) * 2 * DPMM_MULT_MASTER_MAXPAIRS));
+    if (!c->h_marg) HIPCHK(c, hipHostMalloc((void **)&c->h_marg, sizeof(double) * (6 * DPMM_MAX_CLUSTERS + DPMM_MULT_MASTER_MAXPAIRS), hipHostMallocDefault));
+    c->marg_valid = false; c->marg_req = false; c->mpairs_shadow.clear();
     if (!c->h_draw) HIPCHK(c, hipHostMalloc((void **)&c->h_draw, sizeof(float) * 3 * DPMM_MAX_CLUSTERS, hipHostMallocDefault));
     c->mult_master = true;
     return DPMM_OK;
@@ -1691,6 +1712,7 @@ int dpmm_mult_master_put_rows(dpmm_ctx *c, const double *rows, int K) {
     HIPCHK(c, hipMemcpy(c->d_out, rows, sizeof(double) * 2 * (size_t)K * (size_t)c->packed_stride, hipMemcpyHostToDevice));
     c->K = K;
     c->rows_full_K = K;
+    c->marg_valid = false;
     c->cache_force = true;            // (the rows did not come from this context's labels: nothing to derive from)
     return DPMM_OK;
 }
@@ -1728,6 +1750,47 @@ int dpmm_mult_master_draws(dpmm_ctx *c, int K, float *logp) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy2D(logp, sizeof(float) * (size_t)c->D, c->d_raw, sizeof(float) * (size_t)c->ldx, sizeof(float) * (size_t)c->D, 3 * (size_t)K,
                           hipMemcpyDeviceToHost));
+    return DPMM_OK;
+}
+
+// the log-marginal kernel over the rows of the last full pass + the pairs asked for (asynchronous; results in the pinned block)
+static int mult_marginals_launch(dpmm_ctx *c) {
+    c->marg_req = false;
+    const int K = c->K;
+    if (!c->mult_master || c->rows_full_K != K) return DPMM_OK;           // (nothing to answer from: dpmm_mult_master_marginals will say so)
+    if (c->marg_req_outlier && !c->mult_has_alpha1) return DPMM_OK;
+    int np = (int)(c->mpairs_req.size() / 2);
+    for (int32_t k : c->mpairs_req) if (k < 0 || k >= K) { np = 0; break; }
+    if (np > 0) if (int rc = device_list(c, c->d_mpairs, c->mpairs_shadow, c->mpairs_req.data(), 2 * (size_t)np)) return rc;
+    HIPCHK(c, launch_mult_marginals(c->d_out, c->packed_stride, c->d_malpha, c->mult_has_alpha1 ? c->d_malpha + c->ldx : nullptr, c->marg_req_outlier,
+                                    c->D, K, c->d_mpairs, np, c->mult_prior_c, c->h_marg, c->stream));
+    c->marg_valid = true; c->marg_K = K; c->marg_np = np;
+    return DPMM_OK;
+}
+
+int dpmm_mult_master_pairs_ahead(dpmm_ctx *c, int outlier_first, const int32_t *ki, const int32_t *kj, int n) {
+    if (!c || n < 0 || (n > 0 && (!ki || !kj))) return DPMM_EINVAL;
+    if (!c->mult_master) return fail(c, DPMM_ESTATE, "dpmm_mult_master_setup first");
+    c->mpairs_req.clear();
+    if (n <= DPMM_MULT_MASTER_MAXPAIRS)
+        for (int p = 0; p < n; ++p) { c->mpairs_req.push_back(ki[p]); c->mpairs_req.push_back(kj[p]); }
+    c->marg_req = true; c->marg_req_outlier = outlier_first ? 1 : 0;
+    return DPMM_OK;
+}
+
+int dpmm_mult_master_marginals(dpmm_ctx *c, int K, const double **rows_nl, const double **pairs_l, int *npairs) {
+    if (!c || !rows_nl || !pairs_l || !npairs) return DPMM_EINVAL;
+    if (!c->mult_master) return fail(c, DPMM_ESTATE, "dpmm_mult_master_setup first");
+    if (int rc = check_K(c, K)) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!(c->marg_valid && c->marg_K == K && c->rows_full_K == K)) {
+        if (c->rows_full_K != K || K != c->K) return fail(c, DPMM_ESTATE, "dpmm_mult_master_marginals: the last statistics pass did not leave the rows of all K clusters");
+        c->marg_valid = false;
+        if (int rc = mult_marginals_launch(c)) return rc;
+        if (!c->marg_valid) return fail(c, DPMM_ESTATE, "dpmm_mult_master_marginals: no outlier prior was set up");
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));        // (no-op behind dpmm_step_stats, which waited for the kernel with the rows)
+    *rows_nl = c->h_marg; *pairs_l = c->h_marg + 6 * (size_t)K; *npairs = c->marg_np;
     return DPMM_OK;
 }
 
@@ -2217,9 +2280,10 @@ int dpmm_debug_subloglik(dpmm_ctx *c, float *out) {
 int dpmm_last_kernel_ms(dpmm_ctx *c, float *sweep_ms, float *stats_ms) {
     if (!c) return DPMM_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (sweep_ms) { *sweep_ms = 0.f; if (c->have_sweep_ev) HIPCHK(c, hipEventElapsedTime(sweep_ms, c->ev[0], c->ev[1])); }
-    if (stats_ms) { *stats_ms = 0.f; if (c->have_stats_ev) HIPCHK(c, hipEventElapsedTime(stats_ms, c->ev[2], c->ev[3])); }
+    // wait for the closing event of each pair only (not for the stream: the draws launched ahead behind the posteriors are still running when
+    // the engine reads the times of the step that just ended, and a stream synchronise here would put them on the host's critical path)
+    if (sweep_ms) { *sweep_ms = 0.f; if (c->have_sweep_ev) { HIPCHK(c, hipEventSynchronize(c->ev[1])); HIPCHK(c, hipEventElapsedTime(sweep_ms, c->ev[0], c->ev[1])); } }
+    if (stats_ms) { *stats_ms = 0.f; if (c->have_stats_ev) { HIPCHK(c, hipEventSynchronize(c->ev[3])); HIPCHK(c, hipEventElapsedTime(stats_ms, c->ev[2], c->ev[3])); } }
     return DPMM_OK;
 }
 

@@ -185,6 +185,9 @@ hipError_t launch_mult_stats_u8(const StatsArgs &a, const uint8_t *X8, int64_t l
 #define DPMM_MULT_MASTER_MAXD 16384      // the row's log Gamma variates live in LDS (8 bytes each)
 hipError_t launch_mult_dirichlet(const double *rows, int64_t stride, const float *alpha0, const float *alpha1, int outlier_first, int D, int64_t ldx,
                                  int K, uint64_t seed, uint32_t epoch, float *raw, hipStream_t s);
+#define DPMM_MULT_MASTER_MAXPAIRS 8192
+hipError_t launch_mult_marginals(const double *rows, int64_t stride, const float *alpha0, const float *alpha1, int outlier_first, int D, int K,
+                                 const int32_t *pairs, int npairs, const double prior_c[4], double *out, hipStream_t s);
 
 // ---- the master's dense maths on the device (niw_master.hip) ----
 #define DPMM_MASTER_MAXD 256

@@ -1,4 +1,4 @@
-// mult_master.hip -- the Multinomial master's parameter draws on the device.
+// mult_master.hip -- the Multinomial master's parameter draws and log-marginals on the device.
 //
 // Stands in for sample_distribution of the Multinomial prior (src/priors/multinomial_prior.jl:23-25: log.(rand(Dirichlet(alpha')))) with
 // calc_posterior in front of it (:16-21: alpha' = alpha + sum x, the sum held as Float32) for all 3K distributions of a sweep: at D = 1000,
@@ -71,6 +71,63 @@ __global__ __launch_bounds__(256) void mult_dirichlet_kernel(const double *__res
     const double lse = mx + log(red[0]);
     float *out = raw + (int64_t)j * ldx;
     for (int d = tid; d < (int)ldx; d += 256) out[d] = d < D ? (float)(lg[d] - lse) : 0.f;
+}
+
+// Log-marginals of the Multinomial master (src/priors/multinomial_prior.jl:34-39: lgamma(sum a) - lgamma(sum a') + sum (lgamma(a'_d) - lgamma(a_d)),
+// a' = a + Float32(sum x) as calc_posterior forms it) for the 3K distributions of a pass and for the POOLED statistics of cluster pairs
+// (check_and_merge!, src/local_clusters_actions.jl:385-413: left + right of both clusters).  One workgroup per item, Float64 lgamma, tree sums.
+//   item < 3K: distribution 3k + w -> out[2 item] = N, out[2 item + 1] = log-marginal (0 for N = 0: posterior = prior);
+//   item = 3K + p: pair (pairs[2p], pairs[2p+1]) -> out[6K + p].   prior_c = {sum a, sum lgamma(a)} of the cluster prior | the outlier prior
+__global__ __launch_bounds__(256) void mult_marginal_kernel(const double *__restrict__ rows, int64_t stride, const float *__restrict__ alpha0,
+                                                            const float *__restrict__ alpha1, int outlier_first, int D, int K,
+                                                            const int32_t *__restrict__ pairs, double a0_sum, double a0_lg, double a1_sum, double a1_lg,
+                                                            double *__restrict__ out) {
+    __shared__ double r1[256], r2[256];
+    const int item = blockIdx.x, tid = threadIdx.x;
+    const double *src[4] = {nullptr, nullptr, nullptr, nullptr};
+    double coef[4] = {0.0, 0.0, 0.0, 0.0};
+    int kprior;
+    if (item < 3 * K) {
+        const int k = item / 3, w = item % 3;
+        src[0] = rows + (int64_t)(2 * k) * stride; src[1] = src[0] + stride;
+        coef[0] = (w != 2) ? 1.0 : 0.0; coef[1] = (w != 1) ? 1.0 : 0.0;
+        src[2] = src[0]; src[3] = src[0];
+        kprior = k;
+    } else {
+        const int p = item - 3 * K, i = pairs[2 * p], j = pairs[2 * p + 1];
+        src[0] = rows + (int64_t)(2 * i) * stride; src[1] = src[0] + stride;
+        src[2] = rows + (int64_t)(2 * j) * stride; src[3] = src[2] + stride;
+        coef[0] = coef[1] = coef[2] = coef[3] = 1.0;
+        kprior = i;
+    }
+    const bool outl = outlier_first && kprior == 0 && alpha1;
+    const float *alpha = outl ? alpha1 : alpha0;
+    const double N = coef[0] * src[0][0] + coef[1] * src[1][0] + coef[2] * src[2][0] + coef[3] * src[3][0];
+    double s1 = 0.0, acc = 0.0;
+    if (N != 0.0)
+        for (int d = tid; d < D; d += 256) {
+            const float a = alpha[d] + (float)(coef[0] * src[0][1 + d] + coef[1] * src[1][1 + d] + coef[2] * src[2][1 + d] + coef[3] * src[3][1 + d]);
+            s1 += (double)a;
+            acc += lgamma((double)a);
+        }
+    r1[tid] = s1; r2[tid] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { r1[tid] += r1[tid + o]; r2[tid] += r2[tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double L = (N == 0.0) ? 0.0 : lgamma(outl ? a1_sum : a0_sum) - lgamma(r1[0]) + (r2[0] - (outl ? a1_lg : a0_lg));
+        if (item < 3 * K) { out[2 * item] = N; out[2 * item + 1] = L; }
+        else out[6 * K + (item - 3 * K)] = L;
+    }
+}
+
+hipError_t launch_mult_marginals(const double *rows, int64_t stride, const float *alpha0, const float *alpha1, int outlier_first, int D, int K,
+                                 const int32_t *pairs, int npairs, const double prior_c[4], double *out, hipStream_t s) {
+    hipLaunchKernelGGL(mult_marginal_kernel, dim3(3 * K + npairs), dim3(256), 0, s, rows, stride, alpha0, alpha1, outlier_first, D, K, pairs,
+                       prior_c[0], prior_c[1], prior_c[2], prior_c[3], out);
+    return hipGetLastError();
 }
 
 hipError_t launch_mult_dirichlet(const double *rows, int64_t stride, const float *alpha0, const float *alpha1, int outlier_first, int D, int64_t ldx,

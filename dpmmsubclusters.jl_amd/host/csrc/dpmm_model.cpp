@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "hostlib.h"
@@ -176,6 +177,12 @@ struct dpmmh_model {
     // Multinomial (worker.mult_*): the Dirichlet draws happen on the device while the worker's last statistics pass holds the rows of
     // all K clusters as the engine knows them (mult_rows_current: set by a full pass, cleared by an accepted split / merge / removal)
     bool mult_dev_setup = false, mult_dev_failed = false, mult_rows_current = false;
+    // ... and its log-marginals (worker.mult_pairs_ahead / mult_marginals): the pairs asked for ahead of the step's statistics pass (cluster
+    // indices), their pooled log-marginals as the worker returned them, valid until a split / merge / removal changes the clusters
+    std::vector<int32_t> mp_i, mp_j;
+    std::unordered_map<uint32_t, int> mp_index;
+    std::vector<double> mp_L;
+    bool mp_valid = false;
     bool prewake = true;
     double wait_ema = 0.0, t_stats_back = 0.0;
     static constexpr double kPrewakeLead = 60e-6;   // seconds before the predicted hand-back
@@ -368,6 +375,17 @@ struct dpmmh_model {
             points_count[s] = (int64_t)llrint(Nrow[3 * s]);
         }
     }
+    // Multinomial, device marginals: rows to the slots, N and the log-marginals as the worker computed them; the Float32 posterior
+    // parameters (apost) are formed only when somebody needs them (host draws, state access: pull_state)
+    void ingest_mult_marginals(const double *src, const double *nl) {
+        for (int k = 0; k < K; ++k) {
+            const int s = slot[k];
+            memcpy(prow(s, 0), src + (size_t)(2 * k) * stride, sizeof(double) * 2 * stride);
+            for (int w = 0; w < 3; ++w) { Nrow[3 * s + w] = nl[2 * (3 * k + w)]; L[3 * s + w] = nl[2 * (3 * k + w) + 1]; }
+            points_count[s] = (int64_t)llrint(Nrow[3 * s]);
+        }
+        host_dense = false; host_rows = true;
+    }
     // recompute the three posteriors of slot s from its stored statistics
     void refresh_slot(int s, std::vector<double> &sc) {
         for (int w = 0; w < 3; ++w) refresh_row(s, w, sc);
@@ -498,6 +516,7 @@ struct dpmmh_model {
         double t0 = now_s();
         const double *pk = nullptr; const uint8_t *bad = nullptr;
         const bool dev = use_dev();
+        bool mdev_marg = false;
         const double *dev_small = nullptr;
         std::vector<int32_t> dev_slots;
         if (dev) {      // statistics + all 3K posteriors and factorisations in one stream-ordered sequence, one wait
@@ -518,7 +537,22 @@ struct dpmmh_model {
             // decides splits and merges) and uses them if the cluster -> slot map is still this one when sample_clusters asks
             if (W.step_master_device(W.ctx, next_epoch(), dev_slots.data(), opt_draw_ahead ? draw_epoch + 1 : 0u, &bad, &dev_small)) return wfail("step_master_device");
         }
-        else if (W.step_stats(W.ctx, next_epoch(), &pk, &bad)) return wfail("step_stats");
+        else {
+            // Multinomial with the device master: the log-marginals of the 3K distributions and of the pooled statistics of every pair
+            // of clusters whose gate is open NOW (this step can only close gates) ride behind the statistics kernels
+            mdev_marg = use_mult_dev() && W.mult_pairs_ahead && W.mult_marginals;
+            if (mdev_marg) {
+                mp_i.clear(); mp_j.clear(); mp_index.clear(); mp_valid = false;
+                for (int i = (has_outlier() ? 1 : 0); i < K && mp_i.size() <= 8192; ++i) {
+                    if (!splittable[slot[i]]) continue;
+                    for (int j = i + 1; j < K; ++j)
+                        if (splittable[slot[j]]) { mp_index[((uint32_t)i << 16) | (uint32_t)j] = (int)mp_i.size(); mp_i.push_back(i); mp_j.push_back(j); }
+                }
+                if (mp_i.size() > 8192) { mp_i.clear(); mp_j.clear(); mp_index.clear(); }
+                if (W.mult_pairs_ahead(W.ctx, has_outlier() ? 1 : 0, mp_i.data(), mp_j.data(), (int)mp_i.size())) return wfail("mult_pairs_ahead");
+            }
+            if (W.step_stats(W.ctx, next_epoch(), &pk, &bad)) return wfail("step_stats");
+        }
         t_stats_back = now_s();
         helper.cancel();                       // a pre-wake still pending is late: drop it
         timers[T_STATS_WAIT] += t_stats_back - t0; t0 = t_stats_back;
@@ -530,7 +564,16 @@ struct dpmmh_model {
         }
         bad_total += nbad; bad_steps += nbad ? 1 : 0;
         if (dev) { if (int rc = apply_device_posteriors(dev_slots, dev_small)) return rc; dev_state = true; }
-        else { ingest(pk, ks); host_dense = true; host_rows = true; dev_state = false; mult_rows_current = true; }
+        else {
+            const double *nl = nullptr, *pl = nullptr;
+            int np = 0;
+            if (mdev_marg && W.mult_marginals(W.ctx, K, &nl, &pl, &np) == 0 && np == (int)mp_i.size()) {
+                ingest_mult_marginals(pk, nl);
+                mp_L.assign(pl, pl + np);
+                mp_valid = true;
+            } else { ingest(pk, ks); host_dense = true; host_rows = true; }
+            dev_state = false; mult_rows_current = true;
+        }
         timers[T_POSTERIOR] += now_s() - t0;
         return 0;
     }
@@ -600,7 +643,7 @@ struct dpmmh_model {
             if (lhr > log(u)) acc.push_back(k);
         }
         if (acc.empty()) return 0;
-        mult_rows_current = false;
+        mult_rows_current = false; mp_valid = false;
         const int K0 = K;
         std::vector<int64_t> idx, nidx;
         for (size_t a = 0; a < acc.size(); ++a) {
@@ -727,6 +770,19 @@ struct dpmmh_model {
             pull_rows();
         }
         std::vector<std::vector<double>> scratch(std::max(1, nthreads));
+        if (kind == DPMMH_PRIOR_MULT && mp_valid && use_mult_dev()) {      // pooled log-marginals the worker computed behind the statistics; the rest on the host
+            std::vector<int> todo;
+            for (int p = 0; p < (int)pairs.size(); ++p) {
+                const auto it = mp_index.find(((uint32_t)pairs[p].first << 16) | (uint32_t)pairs[p].second);
+                if (it != mp_index.end()) lhr[p] = merge_log_hr(pairs[p].first, pairs[p].second, mp_L[it->second]);
+                else todo.push_back(p);
+            }
+            if (!todo.empty()) Pool::get().run((int)todo.size(), nthreads, [&](int t, int th) {
+                const int p = todo[t];
+                lhr[p] = merge_log_hr(pairs[p].first, pairs[p].second, pooled_marginal(pairs[p].first, pairs[p].second, scratch[th]));
+            });
+            return;
+        }
         Pool::get().run((int)pairs.size(), nthreads, [&](int p, int th) {
             lhr[p] = merge_log_hr(pairs[p].first, pairs[p].second, pooled_marginal(pairs[p].first, pairs[p].second, scratch[th]));
         });
@@ -770,7 +826,7 @@ struct dpmmh_model {
             idx.push_back(i + 1); nidx.push_back(j + 1);
         }
         if (idx.empty()) return 0;
-        dev_state = false; mult_rows_current = false;  // merged slots were rebuilt on the host: the next draws come from there
+        dev_state = false; mult_rows_current = false; mp_valid = false;  // merged slots were rebuilt on the host: the next draws come from there
         if (W.merge(W.ctx, idx.data(), nidx.data(), (int)idx.size())) return wfail("merge");
         return 0;
     }
@@ -786,7 +842,7 @@ struct dpmmh_model {
         }
         if (!any) return 0;
         if (W.remove_empty(W.ctx, pc.data(), K)) return wfail("remove_empty");
-        mult_rows_current = false;                     // (the worker's rows are in the old cluster order)
+        mult_rows_current = false; mp_valid = false;   // (the worker's rows are in the old cluster order)
         std::vector<int> ns;
         for (int k = 0; k < K; ++k) {
             if (pc[k] > 0) ns.push_back(slot[k]);
@@ -1059,7 +1115,7 @@ HAPI int64_t dpmmh_model_get(dpmmh_model *m, const char *field, void *out, int64
     if (f == "logdet_psi") return emit(out, cap, rows_d(m->ldpsi, 1));
     if (f == "log_marginal") return emit(out, cap, rows_d(m->L, 1));
     if (f == "packed" || f == "sums" || f == "S") { if (m->pull_rows()) return -1; }      // the device may hold the only current copy
-    if (f == "m" || f == "U") { if (m->pull_state()) return -1; }
+    if (f == "m" || f == "U" || f == "alpha_post") { if (m->pull_state()) return -1; }
     if (m->kind == DPMMH_PRIOR_NIW && m->dev_draw && (f == "mu" || f == "R" || f == "logdet")) {
         // the current draws were made on the device: fetch them (cluster order)
         std::vector<float> mu((size_t)3 * K * D), R((size_t)3 * K * DD), ld((size_t)3 * K);
@@ -1168,10 +1224,16 @@ HAPI int dpmmh_model_set(dpmmh_model *m, const char *field, const void *in, int6
         std::vector<int> ks(K);
         for (int k = 0; k < K; ++k) ks[k] = k;
         m->ingest((const double *)in, ks);
-        m->host_dense = true; m->host_rows = true; m->dev_state = false; m->dev_draw = false; m->mult_rows_current = false;
+        m->host_dense = true; m->host_rows = true; m->dev_state = false; m->dev_draw = false; m->mult_rows_current = false; m->mp_valid = false;
         if (m->use_mult_dev()) {
             if (m->W.mult_put_rows(m->W.ctx, (const double *)in, K)) return m->wfail("mult_put_rows");
             m->mult_rows_current = true;
+            // (the running chain's log-marginals came from the device: a resumed one takes them from there too)
+            const double *nl = nullptr, *pl = nullptr;
+            int np = 0;
+            if (m->W.mult_pairs_ahead && m->W.mult_marginals && m->W.mult_pairs_ahead(m->W.ctx, m->has_outlier() ? 1 : 0, nullptr, nullptr, 0) == 0 &&
+                m->W.mult_marginals(m->W.ctx, K, &nl, &pl, &np) == 0)
+                m->ingest_mult_marginals((const double *)in, nl);
         }
         if (m->use_dev()) {      // the device gets the same rows, so that the next draws come from where a running chain makes them
             if (m->W.niw_put_rows(m->W.ctx, (const double *)in, K)) return m->wfail("niw_put_rows");

@@ -280,7 +280,7 @@ int dpmm_sync(dpmm_ctx *ctx);
 void *dpmm_stream(dpmm_ctx *ctx);
 /* Milliseconds spent in the dominant kernels during the last dpmm_sweep /
  * dpmm_suffstats_* call, measured with HIP events on the ctx stream (0 if none yet, or when DPMM_OPT_KERNEL_TIMING is off -- the default).
- * Calling this synchronises the stream. */
+ * Calling this waits for the measured kernels (the closing event of each pair), not for later work on the stream. */
 int dpmm_last_kernel_ms(dpmm_ctx *ctx, float *sweep_ms, float *suffstats_ms);
 /* Work the dpmm_sweep calls (NIW) since the previous call really executed, counted on the device (a slot per wave, no atomics):
  *   TOTALS over out8[7] launches of: out8[0] wave tiles, [1] full quadratic-form evaluations (per wave), [2] 16-row MFMA screens
@@ -364,6 +364,16 @@ int dpmm_mult_master_setup(dpmm_ctx *ctx, const float *alpha, const float *alpha
 int dpmm_mult_master_draw(dpmm_ctx *ctx, uint32_t epoch, int K, int outlier_first, const float *lr, const float *w);
 int dpmm_mult_master_draws(dpmm_ctx *ctx, int K, float *logp);
 int dpmm_mult_master_put_rows(dpmm_ctx *ctx, const double *rows, int K);
+/* The Multinomial master's log-marginals on the device (multinomial_prior.jl:34-39; check_and_merge!'s pooled statistics, LCA:385-413).
+ * dpmm_mult_master_pairs_ahead: cluster pairs (0-based indices of the NEXT per-step pass) whose pooled log-marginal the master may ask for
+ *   after that pass; the next dpmm_step_stats launches ONE kernel behind its statistics -- the 3K distributions of the pass + these pairs --
+ *   and waits for it together with the rows.  n = 0 asks for the distributions only; more than 8192 pairs: none are computed.
+ * dpmm_mult_master_marginals: rows_nl -> [3K][2] {N, log-marginal} (cluster, left, right per cluster), pairs_l -> [npairs] in the order they were
+ *   asked for; pointers into a pinned block, valid until the next call that runs a statistics pass.  Without a pass-attached result for
+ *   this K it computes now from the rows of the last full pass (dpmm_mult_master_put_rows counts as one) and waits; DPMM_ESTATE when those
+ *   rows are not there (subset pass, split / merge / removal since). */
+int dpmm_mult_master_pairs_ahead(dpmm_ctx *ctx, int outlier_first, const int32_t *ki, const int32_t *kj, int n);
+int dpmm_mult_master_marginals(dpmm_ctx *ctx, int K, const double **rows_nl, const double **pairs_l, int *npairs);
 
 /* RCCL is bound at run time (dlopen): a copy already mapped into the process wins, then the soname, then /opt/rocm/lib.
  * dpmm_comm_use_library names the file to use instead (before the first dpmm_comm_* call) -- a host that also runs

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DPMMH_ABI_VERSION 4
+#define DPMMH_ABI_VERSION 5
 
 typedef struct dpmmh_model dpmmh_model;
 
@@ -97,6 +97,11 @@ typedef struct dpmmh_worker {
     int (*mult_draw)(void *ctx, uint32_t epoch, int K, int outlier_first, const float *lr, const float *w);
     int (*mult_draws)(void *ctx, int K, float *logp);
     int (*mult_put_rows)(void *ctx, const double *rows, int K);
+    /* OPTIONAL pair (with the group above): the Multinomial log-marginals of a pass and of the merge candidates' pooled statistics on the
+     * device -- dpmm_mult_master_pairs_ahead / dpmm_mult_master_marginals in dpmm_hip.h.  The engine asks ahead of step_stats for the pairs
+     * whose gates are open and reads the results behind it; pairs it did not ask for, and steps after a split, are computed on the host. */
+    int (*mult_pairs_ahead)(void *ctx, int outlier_first, const int32_t *ki, const int32_t *kj, int n);
+    int (*mult_marginals)(void *ctx, int K, const double **rows_nl, const double **pairs_l, int *npairs);
 } dpmmh_worker;
 
 /* Options (dpmmh_model_set_option). */

@@ -48,7 +48,7 @@ def test_host_library_exports_every_declared_symbol(pkg):
     for n in names:
         assert hasattr(lib, n), n
     lib.dpmmh_abi_version.restype = ctypes.c_int
-    assert lib.dpmmh_abi_version() == 4
+    assert lib.dpmmh_abi_version() == 5
     struct = body[body.index("typedef struct dpmmh_worker {"):body.index("} dpmmh_worker;")]
     members = re.findall(r"\(\*([a-z_]+)\)\s*\(", struct)
     assert [f[0] for f in engine.WorkerTable._fields_] == ["ctx", "rank", "world"] + members

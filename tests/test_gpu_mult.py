@@ -353,3 +353,43 @@ def test_selective_row_blocks_equal_all_rows(pkg, K, D, n, ordered):
             wk.set_params_mult(P["logp"], P["lr"], P["w"])
     assert (lab != prev).mean() > 0.2          # (the sweep did move the points that started in a wrong cluster)
     wk.close()
+
+
+def test_device_log_marginals_match_the_host(pkg):
+    """mult_marginal_kernel behind the per-step statistics (DPMMH_OPT_DEVICE_MASTER for the Multinomial prior): N and the log-marginals of the 3K
+    distributions (multinomial_prior.jl:34-39) and the Hastings ratios of every merge candidate (pooled statistics, LCA:385-413) equal the
+    host's Float64 evaluation of the same rows to 1e-10 relative; an accepted split sends the step's pairs back to the host."""
+    import importlib
+    from scipy.special import gammaln
+    host = importlib.import_module("dpmmsubclusters_jl_amd.host")
+    engine = importlib.import_module("dpmmsubclusters_jl_amd.host.engine")
+    D, N = 200, 20000
+    x, y, _ = host.generate_mnmm_data(N, D, 6, 150, seed=3)[:3]
+    x = np.ascontiguousarray(x, np.float32)
+    wk, s = _mult_chain(pkg, host, engine, x, D, N, 1, burnout=4)
+    alpha = np.ones(D, np.float32)
+    checked = 0
+    for it in range(60):
+        s.group_step(False, False)
+        K = s.K
+        hr = s.model.debug_merge_log_hr()
+        if K < 3 or not np.isfinite(hr).any():
+            continue
+        rows = s.model.get("packed").reshape(K, 2, 1 + D)
+        Nd, Ld = s.model.get("N"), s.model.get("log_marginal")
+        l, r = rows[:, 0], rows[:, 1]
+        for w, st in enumerate((l + r, l, r)):
+            ap = (alpha[None, :] + st[:, 1:].astype(np.float32)).astype(np.float64)
+            want = gammaln(alpha.astype(np.float64).sum()) - gammaln(ap.sum(1)) + (gammaln(ap) - gammaln(alpha.astype(np.float64))[None, :]).sum(1)
+            want = np.where(st[:, 0] == 0, 0.0, want)
+            assert np.array_equal(Nd[w::3], st[:, 0])
+            np.testing.assert_allclose(Ld[w::3], want, rtol=1e-10, atol=1e-7)
+        s.model.set_option(engine.OPT_DEVICE_MASTER, 0)          # the same candidates, pooled on the host
+        hr_host = s.model.debug_merge_log_hr()
+        s.model.set_option(engine.OPT_DEVICE_MASTER, 1)
+        assert np.array_equal(np.isfinite(hr), np.isfinite(hr_host))
+        m = np.isfinite(hr)
+        np.testing.assert_allclose(hr[m], hr_host[m], rtol=1e-10, atol=1e-6)
+        checked += int(m.sum())
+    assert checked > 20 and s.K >= 5
+    wk.close()
