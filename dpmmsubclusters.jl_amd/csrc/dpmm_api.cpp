@@ -121,7 +121,7 @@ struct dpmm_ctx {
     bool cache_force = true;           // the next per-step pass computes every cluster in full (points uploaded, cache re-allocated, K changed)
     int cache_K = -1;
     int opt_derive = 1;
-    int opt_noise_ahead = 1;           // normals of the next draws on the second stream beside the sweep (DPMM_OPT_NOISE_AHEAD)
+    int opt_noise_ahead = 0;           // normals of the next draws on the second stream beside the sweep (DPMM_OPT_NOISE_AHEAD)
     // device master (niw_master.hip)
     bool master = false;
     NiwMasterArgs ma{};

@@ -71,8 +71,9 @@ enum {
     DPMM_OPT_STATS_DERIVE = 16,       /* 1 (default): the per-step statistics pass computes only the SMALLER sub-cluster of every cluster no point entered or
                                          left since its cluster-level statistics were cached, and takes the other one as cache - computed (Float64; the
                                          derived side is the larger one); 0: both sub-clusters of every cluster, every pass */
-    DPMM_OPT_NOISE_AHEAD = 17,        /* device master: 1 (default) = the normals of the next parameter draws are generated on a second stream beside the
-                                         sweep; 0 = every draw kernel generates its own (one stream, no cross-stream wait; same draws; +7 us per step) */
+    DPMM_OPT_NOISE_AHEAD = 17,        /* device master: 1 = the normals of the next parameter draws are generated on a second stream beside the sweep
+                                         (-7 us per step at the 8-GPU shard size, nothing at N = 1e7); 0 (default) = every draw kernel generates its
+                                         own: one stream, no cross-stream dependency; same draws either way */
     DPMM_OPT_KERNEL_TIMING = 15,      /* bit mask: 1 = HIP events around the sweep kernel, 2 = around the statistics pass (dpmm_last_kernel_ms), 4 = around the
                                          all-reduces (dpmm_last_comm_ms); 0 (default): none -- every event is a barrier packet between two kernels, ~5 us each */
     DPMM_OPT_WAVE_PRIO = 10       /* 0 / 1: NIW sweep (D <= 64) lowers a wave's issue priority while it streams matrix instructions and
