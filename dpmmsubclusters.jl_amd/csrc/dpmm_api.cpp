@@ -175,6 +175,7 @@ struct dpmm_ctx {
     int opt_prio = 1;
     int opt_queue_rounds = -1;
     int opt_ball = 1;
+    int opt_bracket = 1;               // D <= 64 sweep: certified bf16 bracket of the reference cluster's value instead of its Float32 evaluation where that decides nothing (DPMM_OPT_REF_BRACKET)
     int opt_timing = 0;                // bit 0 / 1 / 2: HIP events around the sweep kernel / the statistics pass / the all-reduces (dpmm_last_kernel_ms, dpmm_last_comm_ms)
     int opt_tail = 1, opt_prescreen = -1, opt_ordered = 1, opt_force_f32 = 0, opt_trace = 0, opt_ref_const = 0;
     int64_t opt_stats_items = 0;
@@ -342,7 +343,7 @@ static int ensure_capacity(dpmm_ctx *c, int K) {
         HIPCHK(c, hipMalloc(&c->d_Rp, sizeof(float) * 3 * cap * NP * 256));
         HIPCHK(c, hipMalloc(&c->d_mup, sizeof(float) * 3 * cap * 16 * c->NB));
         HIPCHK(c, hipMalloc(&c->d_lam, sizeof(float) * cap));
-        HIPCHK(c, hipMalloc(&c->d_tail, sizeof(float) * (16 * (cap + 2) + 16 * cap)));      // pair records | per-cluster ball records
+        HIPCHK(c, hipMalloc(&c->d_tail, sizeof(float) * (16 * (cap + 2) + 16 * cap + (size_t)REFB_WORDS * cap)));      // pair records | per-cluster ball records | bf16 images of the reference bracket
         HIPCHK(c, hipMalloc(&c->d_mdist, sizeof(float) * (size_t)cap * cap));
     } else {
         const size_t NT = (size_t)(c->ldx + 15) / 16, NRB = (size_t)(3 * cap + 15) / 16;
@@ -894,6 +895,7 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
             a.tail = (c->have_tail && !c->predictive) ? c->d_tail : nullptr;
             a.tail_g = ((c->D - 4) % 16) / 4;
             a.ball = c->opt_ball;
+            a.bracket = c->opt_bracket;
             a.order = (!table && c->have_perm && !no_order) ? c->sb.perm : nullptr;
             a.order_total = c->sb.perm_total;
             a.work = table ? nullptr : c->d_work;
@@ -2066,6 +2068,7 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
         case DPMM_OPT_BALL_SCREEN: c->opt_ball = value != 0; return DPMM_OK;
         case DPMM_OPT_STATS_DERIVE: c->opt_derive = value != 0; c->cache_force = true; return DPMM_OK;
         case DPMM_OPT_NOISE_AHEAD: c->opt_noise_ahead = value != 0; return DPMM_OK;
+        case DPMM_OPT_REF_BRACKET: c->opt_bracket = value != 0; return DPMM_OK;
         case DPMM_OPT_KERNEL_TIMING:
             c->opt_timing = (int)value & 7;
             if (!(c->opt_timing & 1)) c->have_sweep_ev = false;

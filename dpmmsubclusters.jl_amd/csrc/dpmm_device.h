@@ -96,4 +96,26 @@ __device__ __forceinline__ float tail_opnorm_bound(const float (&t)[10]) {
     return (float)(sqrt(lam) * 1.00001);
 }
 
+// bf16 bits of a Float32, round to nearest even (finite inputs; a NaN / Inf stays non-finite or becomes one: callers fall back on those)
+__device__ __forceinline__ uint32_t bf16_rne_bits(float v) {
+    const uint32_t u = __float_as_uint(v);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+// bf16 image of a cluster-level factor R (upper triangular, D <= 64, NB = 4) for the reference BRACKET of the D <= 64 sweep
+// (niw_sweep_direct_kernel): six A-operand fragments of v_mfma_f32_16x16x32_bf16, fragment f = (row block bi, feature slice s) in the
+// order (0,0) (0,1) (1,0) (1,1) (2,1) (3,1) -- the others are zero for an upper-triangular matrix -- [6][64 lanes][4 dwords]: dword d of
+// lane (i, g) holds k-slots 8g + 2d, 8g + 2d + 1 of row 16 bi + i, and k-slot j of lane group g is FEATURE 32 s + 4 g + j (j < 4) or
+// 32 s + 16 + 4 g + (j - 4): exactly the features the sweep's x registers x[n][2s], x[n][2s+1] hold for that lane.
+// REFB_WORDS dwords per cluster; element e of a cluster's image -> (row, the two feature indices of its halves)
+__host__ __device__ __forceinline__ void refb_map(int e, int &row, int &col0, int &col1) {
+    const int d = e & 3, lane = (e >> 2) & 63, f = e >> 8;
+    const int bi = f < 2 ? 0 : (f < 4 ? 1 : f - 2), sl = f < 4 ? (f & 1) : 1;
+    const int i = lane & 15, g = lane >> 4;
+    row = 16 * bi + i;
+    const int j0 = 2 * d;                  // (j0, j0 + 1) lie on the same side of 4
+    col0 = 32 * sl + (j0 < 4 ? 4 * g + j0 : 16 + 4 * g + (j0 - 4));
+    col1 = col0 + 1;
+}
+
 }  // namespace dpmm

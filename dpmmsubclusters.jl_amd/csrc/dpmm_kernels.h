@@ -13,6 +13,8 @@ namespace dpmm {
 
 constexpr int DPMM_WORK_QUEUES = 8;                               // queue heads of the D <= 64 sweep kernel, 16 u64 apart from work[8]
 constexpr int DPMM_WORK_SLOTS = 8 + 16 * DPMM_WORK_QUEUES;        // first per-wave counter slot
+constexpr int REFB_FRAGS = 6, REFB_WORDS = REFB_FRAGS * 256;      // dwords of a cluster's bf16 image for the reference bracket (refb_map, dpmm_device.h)
+
 struct NiwSweepArgs {
     const float *X;      // [n][ldx] points (zero padded to ldx = roundup(D,4))
     int64_t ldx;
@@ -38,6 +40,7 @@ struct NiwSweepArgs {
     const float *tail;        // [ceil(K/2)][16][2] tail-screen records of the cluster-level matrices, pairs interleaved, then [K][16] ball records (null: no tail screen)
     int tail_g;               // row group (lane >> 4) whose x registers of the last block hold features D-4..D-1
     int ball;                 // 1: cluster-per-lane ball test in front of the per-point tail screen (records [K][16] behind the pair records)
+    int bracket;              // 1: D in 49..64, homogeneous waves: certified bf16 bracket of the reference cluster's value first; its Float32 evaluation only if a cluster survives the screens (bf16 images behind the ball records)
     const float *lam;         // [K] lower bounds of lambda_min(Sigma_k^-1) (null: no scalar pre-screen)
     const float *mdist;       // [K][K] distances between the cluster means
     int screen_lds;           // set by the launcher: screen operands of all K clusters are staged in LDS

@@ -588,11 +588,6 @@ __global__ __launch_bounds__(256, (B_RBP <= 6 ? 2 : 1)) void mult_sweep_bf16_ker
     }
 }
 
-__device__ __forceinline__ uint32_t bf16_rne_bits(float v) {  // round to nearest even, finite inputs
-    const uint32_t u = __float_as_uint(v);
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-
 // Lp16[ks][rb][plane][lane][8 bf16] : element j of lane (i, g) = plane_p(logp[16 rb + i][32 ks + 8 g + j])
 __global__ void mult_pack_bf16_kernel(const float *__restrict__ logp, uint32_t *__restrict__ Lp16, int rows, int64_t ldx, int NKS, int NRB) {
     const int64_t total = (int64_t)NKS * NRB * 3 * 256;   // uint32 words, two bf16 each

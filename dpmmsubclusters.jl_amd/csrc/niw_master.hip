@@ -683,6 +683,18 @@ __global__ void niw_master_pack_kernel(const double *__restrict__ Yall, const fl
             } else v = -0.5f * logdet_sigma[j] + logf(wts[k]);
             ball[e] = v;
         }
+        // bf16 image of the cluster-level factors for the reference bracket of the D <= 64 sweep (refb_map, dpmm_device.h)
+        if (NB == 4) {
+            uint32_t *refb = reinterpret_cast<uint32_t *>(ball + 16 * (size_t)K);
+            for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)K * REFB_WORDS; e += (int64_t)gridDim.x * blockDim.x) {
+                const int64_t j = 3 * (e / REFB_WORDS);
+                int row, c0, c1;
+                refb_map((int)(e % REFB_WORDS), row, c0, c1);
+                const float v0 = (row < D && c0 < D && c0 >= row) ? (float)Yall[j * DPm * DPm + (int64_t)c0 * DPm + row] : 0.f;
+                const float v1 = (row < D && c1 < D && c1 >= row) ? (float)Yall[j * DPm * DPm + (int64_t)c1 * DPm + row] : 0.f;
+                refb[e] = bf16_rne_bits(v0) | (bf16_rne_bits(v1) << 16);
+            }
+        }
     }
 }
 

@@ -194,6 +194,76 @@ __device__ __forceinline__ unsigned long long ball_far(const float *tail, int K,
     return __ballot(j < K && ub < B.thr);
 }
 
+// Reference BRACKET (D in 49 .. 64).  On a wave whose points all carried label k0 the cluster-level value a_k0(x) = cst - q(x) / 2,
+// q = |R (x - mu)|^2, usually decides nothing: every other cluster is excluded by the screens and the draw returns k0 whatever the value
+// is.  The screens only need a LOWER bound of it.  Two bf16 matrix passes give a certified one at ~1/7 of the Float32 evaluation's cycles:
+//   y^ = R~ z~ (R~, z~ = bf16 roundings of R and z = x - mu; bf16 products are exact in the Float32 accumulator),  e^ = |R~| |z~|,
+//   |y_i - y^_i| <= |R - R~||z| + |R~||z - z~| + accumulation <= (2^-8 (1 + 2^-7) + 64 * 2^-24) e_i  <=  REFB_C e^_i,
+//   q <= sum_i (|y^_i| + REFB_C e^_i)^2 =: q_hi   (the lane's four rows per block, then the ones-MFMA sum over the four row groups).
+// On the bench's clusters (condition number 35 000) q_hi - q is ~7 (median) of q ~ 64: the thresholds move by a few nats of a 50-nat
+// margin.  A non-finite x or parameter makes q_hi non-finite, every screen comparison false, and the wave takes the Float32 path.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+constexpr float REFB_C = 0.00395f;
+__host__ __device__ __forceinline__ const uint32_t *refb_records(const float *tail, int K) {
+    return reinterpret_cast<const uint32_t *>(ball_records(tail, K) + 16 * (size_t)K);
+}
+__device__ __forceinline__ uint32_t pack_bf16_pair(float a, float b) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));      // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+}
+template <int NG>
+__device__ __forceinline__ void ref_bracket(const uint32_t *__restrict__ Rb, const f32x4 (&x)[NG][4], const f32x4 (&mu)[4], int lane, float (&qhi)[NG]) {
+    static_assert(NG % 2 == 0, "point groups are taken two at a time");
+    const u32x4_t *F = reinterpret_cast<const u32x4_t *>(Rb) + lane;          // fragment f of this lane: F[64 f]
+    const u32x4_t absm = (u32x4_t){0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu};
+    // two point groups at a time (the six fragments are re-read per pair, from L1 / L2): the bf16 operands of all four groups plus both
+    // accumulator sets are 72 registers that the kernel does not have
+#pragma unroll
+    for (int n0 = 0; n0 < NG; n0 += 2) {
+        u32x4_t zb[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                const f32x4 lo = x[n0 + h][2 * sl] - mu[2 * sl], hi = x[n0 + h][2 * sl + 1] - mu[2 * sl + 1];
+                zb[h][sl] = (u32x4_t){pack_bf16_pair(lo.x, lo.y), pack_bf16_pair(lo.z, lo.w), pack_bf16_pair(hi.x, hi.y), pack_bf16_pair(hi.z, hi.w)};
+            }
+        float part[2] = {0.f, 0.f};
+#pragma unroll
+        for (int bi = 0; bi < 4; ++bi) {
+            f32x4 y[2], e[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { y[h] = (f32x4){0.f, 0.f, 0.f, 0.f}; e[h] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                const int f = bi == 0 ? sl : (bi == 1 ? 2 + sl : (sl == 1 ? bi + 2 : -1));
+                if (f < 0) continue;
+                const u32x4_t a = F[64 * f], aa = a & absm;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    y[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, zb[h][sl]), y[h], 0, 0, 0);
+                    e[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aa), __builtin_bit_cast(bf16x8_t, zb[h][sl] & absm), e[h], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float t = __builtin_fmaf(REFB_C, e[h][r], fabsf(y[h][r]));
+                    part[h] = __builtin_fmaf(t, t, part[h]);
+                }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 tot = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, part[h], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);      // sum over the four row groups of a column
+            qhi[n0 + h] = __builtin_fmaf(tot[0], 1.0001f, 1e-20f);
+        }
+    }
+}
+
 template <int NB, int NG, int CH>
 struct QuadEval {
     using C = NiwCfg<NB, NG, CH>;
@@ -1099,14 +1169,33 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
             // on label-homogeneous waves that is the first matrix of the sub-label phase (rb0_mat tracks what rb0/mu hold)
             const float *Rl0 = (!FAST && A.labels_only) ? nullptr : A.Rp + (size_t)(3 * k0 + 1) * MATSZ;
             const float *ml0 = A.mup + (size_t)(3 * k0 + 1) * DP;
+            // Reference bracket (see ref_bracket): every point of the wave was in k0 -> bestn = the LOWER end of a certified bracket of
+            // a_k0; nothing is recorded.  The Float32 evaluation follows behind the screens only if some cluster survives them.
+            bool bracketed = false;
+            if constexpr (FAST && NB == 4) {
+                if (A.bracket && k1 == k0 && A.use_prev) {
+                    const int prevl0 = binv >= 0 ? (binv >> 1) : -1;
+                    if (__ballot(valid && prevl0 != k0) == 0ull) {
+                        float qhi[NG];
+                        ref_bracket<NG>(refb_records(A.tail, K) + (size_t)k0 * REFB_WORDS, x, mu, lane, qhi);
+                        const float c0 = A.cst[3 * k0];
+#pragma unroll
+                        for (int n = 0; n < NG; ++n) bestn[n] = __builtin_fmaf(-0.5f, qhi[n], c0);
+                        bracketed = true;
+                        nw_scr += 2;                                          // (48 bf16 matrix instructions: the cycles of 1.5 sixteen-row screens)
+                    }
+                }
+            }
+            if (!bracketed) {
             full_eval(k0, k1 != k0 ? A.Rp + (size_t)(3 * k1) * MATSZ : Rl0, k1 != k0 ? A.mup + (size_t)(3 * k1) * DP : ml0);
             if (k1 != k0) full_eval(k1, Rl0, ml0);
+            }
             // Further reference clusters: previous labels of the wave's points other than k0 / k1 -- a tile that covers a whole tiny
             // cluster (< 62 points) between two others.  Without them those points' reference is hopeless, no cluster can be excluded
             // for them and all K are evaluated in full: one such tile cost 30 evaluations (8 tile times) and, statically scheduled, ran
             // 8 % past the end of every other wave at N = 1e7.  Up to two more (four distinct labels per 64 points).
             int xr0 = -1, xr1 = -1;
-            if (A.use_prev) {
+            if (A.use_prev && !bracketed) {
                 int prevl = binv >= 0 ? (binv >> 1) : -1;
                 if ((unsigned)prevl >= (unsigned)K) prevl = -1;
                 unsigned long long oth = __ballot(prevl >= 0 && prevl != k0 && prevl != k1);
@@ -1262,8 +1351,21 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                 }
             }
             STAMP(r2);
-            // (3) survivors, with one-matrix lookahead for the fragment prefetch
             const int nwords = (K + 31) >> 5;
+            if (bracketed) {
+                uint32_t any = 0u;
+                for (int w2 = 0; w2 < nwords; ++w2) any |= __builtin_amdgcn_readfirstlane(sv[w2]);
+                if (any == 0u) {
+                    // nobody can compete with k0 for any point of the wave: the draw returns k0 (or index 0 for u = 0) whatever the exact
+                    // value is -- the one-cluster draw below never reads the table.  A finite stand-in keeps the bookkeeping of the draw.
+                    m_run = 0.f; best = k0;
+                    if (Rl0) { load_rb0<NB>(Rl0, ml0, rb0, mu, lane, g); rb0_mat = 3 * k0 + 1; } else rb0_mat = -1;
+                } else {
+                    load_rb0<NB>(A.Rp + (size_t)(3 * k0) * MATSZ, A.mup + (size_t)(3 * k0) * DP, rb0, mu, lane, g);      // (re-read: not kept across the bracket and the screens)
+                    full_eval(k0, Rl0, ml0);             // the exact value: table entry for the draw, thresholds of the survivors' evaluations
+                }
+            }
+            // (3) survivors, with one-matrix lookahead for the fragment prefetch
             int w = 0;
             uint32_t bits = __builtin_amdgcn_readfirstlane(sv[0]);
             auto next_surv = [&]() -> int {
@@ -1600,6 +1702,19 @@ __global__ void niw_pack_kernel(const float *__restrict__ R, const float *__rest
                 v = tail_opnorm_bound(t10);
             } else v = cst[3 * k];
             ball[e] = v;
+        }
+        // bf16 image of the cluster-level factors for the reference bracket (refb_map), D in 49 .. 64 only
+        if (NB == 4) {
+            uint32_t *refb = reinterpret_cast<uint32_t *>(ball + 16 * (size_t)K);
+            for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)K * REFB_WORDS; e += (int64_t)gridDim.x * blockDim.x) {
+                const int k = (int)(e / REFB_WORDS);
+                int row, c0, c1;
+                refb_map((int)(e % REFB_WORDS), row, c0, c1);
+                const size_t j = src_row(slot, 3 * k);
+                const float v0 = (row < D && c0 < D && c0 >= row) ? R[j * TRI + tri_off(D, row, c0)] : 0.f;
+                const float v1 = (row < D && c1 < D && c1 >= row) ? R[j * TRI + tri_off(D, row, c1)] : 0.f;
+                refb[e] = bf16_rne_bits(v0) | (bf16_rne_bits(v1) << 16);
+            }
         }
     }
 }
