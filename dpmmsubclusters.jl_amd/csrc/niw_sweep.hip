@@ -994,6 +994,9 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
             q_issue();                        // (waited for at once: only at the very end of the launch)
         }
     };
+    // reference bracket: after two waves' worth of tiles in a row on which it decided nothing (overlapping clusters: something always survives
+    // the screens) the wave goes straight to the Float32 evaluation for the next eight tiles, then tries again
+    int br_fail = 0, br_skip = 0;
     int tile0, tnext_v = -1;
     if (!dyn_ok) tile0 = wave_id < nwtiles ? wave_id : -1;
     else if (wave_id < dyn0) tile0 = wave_id;
@@ -1173,7 +1176,8 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
             // a_k0; nothing is recorded.  The Float32 evaluation follows behind the screens only if some cluster survives them.
             bool bracketed = false;
             if constexpr (FAST && NB == 4) {
-                if (A.bracket && k1 == k0 && A.use_prev) {
+                if (A.bracket && k1 == k0 && A.use_prev && br_skip > 0) --br_skip;
+                else if (A.bracket && k1 == k0 && A.use_prev) {
                     const int prevl0 = binv >= 0 ? (binv >> 1) : -1;
                     if (__ballot(valid && prevl0 != k0) == 0ull) {
                         float qhi[NG];
@@ -1359,8 +1363,10 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                     // nobody can compete with k0 for any point of the wave: the draw returns k0 (or index 0 for u = 0) whatever the exact
                     // value is -- the one-cluster draw below never reads the table.  A finite stand-in keeps the bookkeeping of the draw.
                     m_run = 0.f; best = k0;
+                    br_fail = 0;
                     if (Rl0) { load_rb0<NB>(Rl0, ml0, rb0, mu, lane, g); rb0_mat = 3 * k0 + 1; } else rb0_mat = -1;
                 } else {
+                    if (++br_fail >= 2) { br_fail = 0; br_skip = 8; }
                     load_rb0<NB>(A.Rp + (size_t)(3 * k0) * MATSZ, A.mup + (size_t)(3 * k0) * DP, rb0, mu, lane, g);      // (re-read: not kept across the bracket and the screens)
                     full_eval(k0, Rl0, ml0);             // the exact value: table entry for the draw, thresholds of the survivors' evaluations
                 }
