@@ -219,8 +219,12 @@ __device__ __forceinline__ void ref_bracket(const uint32_t *__restrict__ Rb, con
     static_assert(NG % 2 == 0, "point groups are taken two at a time");
     const u32x4_t *F = reinterpret_cast<const u32x4_t *>(Rb) + lane;          // fragment f of this lane: F[64 f]
     const u32x4_t absm = (u32x4_t){0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu};
-    // two point groups at a time (the six fragments are re-read per pair, from L1 / L2): the bf16 operands of all four groups plus both
-    // accumulator sets are 72 registers that the kernel does not have
+    // the six fragments are requested first (their L2 latency runs under the conversion of z) and serve both pairs of point groups (held
+    // from the top of the tile, under the gather of x, they cost 52 spilled registers);
+    // two point groups at a time: the bf16 operands of all four groups plus both accumulator sets are registers the kernel does not have
+    u32x4_t a[6];
+#pragma unroll
+    for (int f = 0; f < 6; ++f) a[f] = F[64 * f];
 #pragma unroll
     for (int n0 = 0; n0 < NG; n0 += 2) {
         u32x4_t zb[2][2];
@@ -241,10 +245,10 @@ __device__ __forceinline__ void ref_bracket(const uint32_t *__restrict__ Rb, con
             for (int sl = 0; sl < 2; ++sl) {
                 const int f = bi == 0 ? sl : (bi == 1 ? 2 + sl : (sl == 1 ? bi + 2 : -1));
                 if (f < 0) continue;
-                const u32x4_t a = F[64 * f], aa = a & absm;
+                const u32x4_t aa = a[f] & absm;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    y[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, zb[h][sl]), y[h], 0, 0, 0);
+                    y[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[f]), __builtin_bit_cast(bf16x8_t, zb[h][sl]), y[h], 0, 0, 0);
                     e[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aa), __builtin_bit_cast(bf16x8_t, zb[h][sl] & absm), e[h], 0, 0, 0);
                 }
             }
@@ -1176,18 +1180,22 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
             // a_k0; nothing is recorded.  The Float32 evaluation follows behind the screens only if some cluster survives them.
             bool bracketed = false;
             if constexpr (FAST && NB == 4) {
-                if (A.bracket && k1 == k0 && A.use_prev && br_skip > 0) --br_skip;
-                else if (A.bracket && k1 == k0 && A.use_prev) {
-                    const int prevl0 = binv >= 0 ? (binv >> 1) : -1;
-                    if (__ballot(valid && prevl0 != k0) == 0ull) {
-                        float qhi[NG];
-                        ref_bracket<NG>(refb_records(A.tail, K) + (size_t)k0 * REFB_WORDS, x, mu, lane, qhi);
-                        const float c0 = A.cst[3 * k0];
-#pragma unroll
-                        for (int n = 0; n < NG; ++n) bestn[n] = __builtin_fmaf(-0.5f, qhi[n], c0);
-                        bracketed = true;
-                        nw_scr += 2;                                          // (48 bf16 matrix instructions: the cycles of 1.5 sixteen-row screens)
+                bool try_bracket = false;
+                if (A.bracket && k1 == k0 && A.use_prev) {
+                    if (br_skip > 0) --br_skip;
+                    else {
+                        const int prevl0 = binv >= 0 ? (binv >> 1) : -1;
+                        try_bracket = __ballot(valid && prevl0 != k0) == 0ull;      // every point of the wave was in k0
                     }
+                }
+                if (try_bracket) {
+                    float qhi[NG];
+                    ref_bracket<NG>(refb_records(A.tail, K) + (size_t)k0 * REFB_WORDS, x, mu, lane, qhi);
+                    const float c0 = A.cst[3 * k0];
+#pragma unroll
+                    for (int n = 0; n < NG; ++n) bestn[n] = __builtin_fmaf(-0.5f, qhi[n], c0);
+                    bracketed = true;
+                    nw_scr += 2;                                              // (48 bf16 matrix instructions: the cycles of 1.5 sixteen-row screens)
                 }
             }
             if (!bracketed) {
