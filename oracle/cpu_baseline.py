@@ -14,7 +14,7 @@ The master part times calc_posterior + log_marginal_likelihood for the 3K statis
 check_and_merge! in numpy (serial, as the reference's master is).
 
 `julia` is probed first: if a Julia with DPMMSubClusters is on the box the genuine reference
-would be timed instead; this image has none, so kind is "port-multiprocess".
+would be timed instead; this image has none, so kind is "port" (`parallelism`: "multiprocess").
 """
 import json
 import os
@@ -130,7 +130,7 @@ def run_niw(X, D, K, mu, invS, logdet, logw, loglr, N_total, seconds=20.0, procs
     wall = max(o["t1"] for o in outs) - start_at
     master = _master_seconds(D, K, np.random.default_rng(0))
     per_iter = wall * (N_total / m) + master
-    return {"value": 1.0 / per_iter, "unit": "iterations/s", "cores": P, "kind": "port-multiprocess",
+    return {"value": 1.0 / per_iter, "unit": "iterations/s", "cores": P, "kind": "port", "parallelism": "multiprocess",
             "cpu_model": cpu_model(), "julia_found": bool(julia),
             "sample": f"{P} worker processes x {per_proc} points (= {m} of the {N_total} points, {100.0 * m / N_total:.1f} %), one BLAS thread "
                       f"each, K={K}: {wall:.2f} s wall for the sample (latest start +{late:.2f} s), scaled linearly to N, plus {master:.3f} s of "
