@@ -1075,6 +1075,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
         float m_run = -INFINITY;
         int best = 0;
         bool nan_seen = false;
+        bool ref_skipped = false;               // bracketed reference and no survivor (wave-uniform): k0's value was never computed
         f32x4 rb0[NB], mu[NB];
         int rb0_mat = -1;                       // matrix index whose row-block 0 / means sit in rb0 / mu (wave-uniform)
         float tot_all[NG];
@@ -1179,9 +1180,9 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
             // Reference bracket (see ref_bracket): every point of the wave was in k0 -> bestn = the LOWER end of a certified bracket of
             // a_k0; nothing is recorded.  The Float32 evaluation follows behind the screens only if some cluster survives them.
             bool bracketed = false;
-            if constexpr (FAST && NB == 4) {
+            if constexpr (NB == 4) {
                 bool try_bracket = false;
-                if (A.bracket && k1 == k0 && A.use_prev) {
+                if (A.bracket && k1 == k0 && A.use_prev && (FAST || (A.tail != nullptr && !A.labels_only))) {
                     if (br_skip > 0) --br_skip;
                     else {
                         const int prevl0 = binv >= 0 ? (binv >> 1) : -1;
@@ -1371,6 +1372,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                     // nobody can compete with k0 for any point of the wave: the draw returns k0 (or index 0 for u = 0) whatever the exact
                     // value is -- the one-cluster draw below never reads the table.  A finite stand-in keeps the bookkeeping of the draw.
                     m_run = 0.f; best = k0;
+                    ref_skipped = true;
                     br_fail = 0;
                     if (Rl0) { load_rb0<NB>(Rl0, ml0, rb0, mu, lane, g); rb0_mat = 3 * k0 + 1; } else rb0_mat = -1;
                 } else {
@@ -1443,6 +1445,8 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                 z = best;
             } else if (m_run == -INFINITY) {
                 z = 0;
+            } else if (ref_skipped) {
+                z = (u01(r.v[0]) <= 0.f) ? 0 : k0;       // bracketed reference, nobody survived: one cluster of weight exp(0) = 1 (its value was never computed)
             } else if (tab_lds && screening && nev1) {
                 // ONE evaluated cluster (the usual tile of well-separated data: every other cluster was excluded for the whole wave) and
                 // its value is finite here: the row sum is exp(0) = 1, the scan stops at that cluster -- or at index 0 when u == 0, as the

@@ -418,15 +418,15 @@ def test_work_counters_accumulate_until_read(pkg):
     wk.close()
 
 
-@pytest.mark.parametrize("D,sep", [(64, 40.0), (64, 0.6), (52, 40.0), (60, 0.8), (64, 6.0)])
-def test_reference_bracket_does_not_change_labels(pkg, D, sep):
+@pytest.mark.parametrize("D,sep,K", [(64, 40.0, 7), (64, 0.6, 7), (52, 40.0, 7), (60, 0.8, 7), (64, 6.0, 7), (64, 40.0, 100), (64, 1.0, 100)])
+def test_reference_bracket_does_not_change_labels(pkg, D, sep, K):
     """DPMM_OPT_REF_BRACKET (D in 49 .. 64): on a wave whose points all carried the same label the reference cluster's value is first
     bracketed with two bf16 matrix passes and a certified rounding bound; its Float32 evaluation runs only if another cluster survives the
     screens against the bracket's lower end.  Labels and sub-labels must be those of the always-evaluate kernel, bit for bit -- on separated
     clusters (the evaluation is skipped on most waves: fewer full evaluations are counted) and on overlapping ones (survivors: the exact
     value is computed after all), with D below 64 (zero-padded features), and they equal the oracle's draw on the kernel's own table."""
     from dpmmsubclusters_jl_amd import binding
-    n, K = 30000, 7
+    n = 30000                                          # (K = 100: beyond the LDS table's rows -- the generic kernel with the compact table)
     P = make_problem(D, n, K, seed=5 + D, sep=sep, sorted_points=True)
     out = {}
     for br in (1, 0):
@@ -453,7 +453,7 @@ def test_reference_bracket_does_not_change_labels(pkg, D, sep):
     for a, b in zip(out[1][0], out[0][0]):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     f1, f0 = out[1][1]["full_evals"], out[0][1]["full_evals"]
-    print(f"D={D} sep={sep}: full evaluations per wave tile {f1 / out[1][1]['wave_tiles']:.2f} with the bracket, {f0 / out[0][1]['wave_tiles']:.2f} without")
+    print(f"D={D} sep={sep} K={K}: full evaluations per wave tile {f1 / out[1][1]['wave_tiles']:.2f} with the bracket, {f0 / out[0][1]['wave_tiles']:.2f} without")
     assert f1 <= f0
     if sep >= 40.0:
         assert f1 < 0.8 * f0
