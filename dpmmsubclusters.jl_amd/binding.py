@@ -73,6 +73,7 @@ ABI = [
     ("dpmm_sync", ctypes.c_int, [ctypes.c_void_p]),
     ("dpmm_stream", ctypes.c_void_p, [ctypes.c_void_p]),
     ("dpmm_last_kernel_ms", ctypes.c_int, [ctypes.c_void_p, _c_f32p, _c_f32p]),
+    ("dpmm_debug_counters", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int]),
     ("dpmm_init_labels_from", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint32]),
     ("dpmm_set_option", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_double]),
     ("dpmm_params_staging", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.POINTER(ctypes.c_void_p)] * 6),
@@ -212,6 +213,14 @@ class Worker:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
+            try:
+                early = self.debug_counters()[0]
+            except Exception:
+                early = 0
+            if early:
+                import sys
+                print("dpmm worker: %d event wait(s) returned before the posterior records had reached host memory "
+                      "(waited out; results unaffected)" % early, file=sys.stderr, flush=True)
             self._lib.dpmm_destroy(self._h)
             self._h = ctypes.c_void_p()
 
@@ -606,3 +615,9 @@ class Worker:
         a = ctypes.c_float(); b = ctypes.c_float()
         self._chk(self._lib.dpmm_last_kernel_ms(self._h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
+
+    def debug_counters(self):
+        """Health counters of the worker (include/dpmm_hip.h dpmm_debug_counters): [0] = event waits that returned early."""
+        out = (ctypes.c_int64 * 4)()
+        self._chk(self._lib.dpmm_debug_counters(self._h, out, 4))
+        return list(out)

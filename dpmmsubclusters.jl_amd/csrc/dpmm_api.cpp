@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -21,6 +22,19 @@
 #include "dpmm_kernels.h"
 
 using namespace dpmm;
+
+#ifdef DPMM_POISON
+// Diagnostic build (scripts/build_variant.sh poison -DDPMM_POISON=0xFF): every device allocation of this file is filled with the poison byte
+// before anybody uses it -- a kernel that reads memory nobody wrote then reads NaNs / -1 on EVERY box, not only on one whose memory holds
+// another process's leftovers (how a one-in-twenty chain divergence on fresh boxes was tracked down).
+template <typename T>
+static hipError_t hipMallocPoisoned(T **p, size_t n) {
+    hipError_t e = hipMalloc(p, n);
+    if (e == hipSuccess && n > 0) { e = hipMemset(*p, DPMM_POISON, n); if (e == hipSuccess) e = hipDeviceSynchronize(); }
+    return e;
+}
+#define hipMalloc hipMallocPoisoned
+#endif
 
 static_assert(DPMM_MAX_CLUSTERS == DPMM_MAX_CLUSTERS_K, "header / kernel limits out of sync");
 
@@ -121,6 +135,7 @@ struct dpmm_ctx {
     bool cache_force = true;           // the next per-step pass computes every cluster in full (points uploaded, cache re-allocated, K changed)
     int cache_K = -1;
     int opt_derive = 1;
+    int64_t dbg_early_wait = 0;        // event waits that returned before the posteriors' records were in host memory (dpmm_debug_counters)
     int opt_noise_ahead = 0;           // normals of the next draws on the second stream beside the sweep (DPMM_OPT_NOISE_AHEAD)
     // device master (niw_master.hip)
     bool master = false;
@@ -1364,6 +1379,21 @@ int dpmm_step_stats_device(dpmm_ctx *c, uint32_t reset_epoch, const uint8_t **ba
     return DPMM_OK;
 }
 
+static const uint64_t MASTER_MARK = 0x7ff8dead0000beefull;
+static bool master_marks_left(const double *sm, int K) {
+    const volatile uint64_t *w = reinterpret_cast<const volatile uint64_t *>(sm);
+    for (int64_t r = 0; r < 3 * (int64_t)K; ++r)
+        for (int e = 0; e < 5; ++e) if (w[r * DPMM_MASTER_NSCALARS + e] == MASTER_MARK) return true;
+    return false;
+}
+
+int dpmm_debug_counters(dpmm_ctx *c, int64_t *out, int n) {
+    if (!c || !out || n < 1) return DPMM_EINVAL;
+    for (int i = 0; i < n; ++i) out[i] = 0;
+    out[0] = c->dbg_early_wait;
+    return DPMM_OK;
+}
+
 int dpmm_step_master_device(dpmm_ctx *c, uint32_t reset_epoch, const int32_t *slots, uint32_t draw_epoch, const uint8_t **bad, const double **small) {
     if (!c || !slots || !bad || !small) return DPMM_EINVAL;
     if (!c->master) return fail(c, DPMM_ESTATE, "dpmm_niw_master_setup first");
@@ -1429,6 +1459,11 @@ int dpmm_step_master_device(dpmm_ctx *c, uint32_t reset_epoch, const int32_t *sl
         if (!fuse_pairs) if (int rc = device_list(c, c->d_apairs, c->apairs_shadow, c->apairs_req.data(), c->apairs_req.size(), c->stream2)) return rc;
     } else fuse_pairs = false;
     double *sm = reinterpret_cast<double *>(c->h_master + jobs_bytes);
+    // Witness of the event wait below: every scalar record the posteriors write starts out as a marker no kernel produces (a NaN with a
+    // payload; the kernels' own NaN is the plain quiet one).  A record still carrying it after the wait means the wait returned before
+    // the kernels' stores reached host memory: counted (dpmm_debug_counters) and waited out.
+    for (int64_t r = 0; r < 3 * (int64_t)K; ++r)
+        for (int e = 0; e < 5; ++e) std::memcpy(&sm[r * DPMM_MASTER_NSCALARS + e], &MASTER_MARK, 8);
     bool flags_sent = false;
     if (int rc = run_stats(c, nullptr, 0, true, reset_epoch, reinterpret_cast<uint8_t *>(c->h_out), &flags_sent)) return rc;
     if (!flags_sent) HIPCHK(c, launch_copy_bytes(c->h_out, reinterpret_cast<const uint8_t *>(c->d_out) + out_bytes, (size_t)K + 1, c->stream));
@@ -1475,6 +1510,14 @@ int dpmm_step_master_device(dpmm_ctx *c, uint32_t reset_epoch, const int32_t *sl
         c->spec_slots.assign(slots, slots + K);
     }
     HIPCHK(c, hipEventSynchronize(c->ev_master));
+    if (master_marks_left(sm, K)) {
+        ++c->dbg_early_wait;
+        const auto t0 = std::chrono::steady_clock::now();
+        while (master_marks_left(sm, K)) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) return fail(c, DPMM_EHIP, "posterior records missing 5 s after the event wait returned");
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+    }
     c->handover_inflight = false;          // (recorded behind the last hand-over kernel on the same stream)
     *bad = reinterpret_cast<const uint8_t *>(c->h_out);
     *small = sm;

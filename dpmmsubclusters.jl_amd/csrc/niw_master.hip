@@ -53,11 +53,15 @@ __device__ __forceinline__ double normal_from(const Philox4 &r) {        // one 
     const double u1 = u53(r.v[0], r.v[1]), u2 = u53(r.v[2], r.v[3]);
     return sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925 * u2);
 }
-// Marsaglia-Tsang Gamma(a, 1), a >= 1; trial t of element `idx` uses generator blocks (idx, 2t) and (idx, 2t + 1)
-__device__ double gamma_mt(double a, uint64_t seed, uint64_t idx, uint32_t epoch) {
-    if (a < 1.0) {      // Gamma(a) = Gamma(a + 1) U^(1/a)
+// Marsaglia-Tsang Gamma(a, 1); trial t of element `idx` uses generator blocks (idx, 2t) and (idx, 2t + 1).  a < 1: Gamma(a) = Gamma(a + 1)
+// U^(1/a), U from block (idx, 63).  (Written without recursion and inlined: as a real call the kernel carried a dynamic stack and kept
+// its uniform values in lanes of a spill register across the call.)
+__device__ __forceinline__ double gamma_mt(double a, uint64_t seed, uint64_t idx, uint32_t epoch) {
+    double boost = 1.0;
+    if (a < 1.0) {
         const Philox4 ru = philox4x32_10(seed, idx * 64 + 63, epoch, STREAM_M_CHI);
-        return gamma_mt(a + 1.0, seed, idx, epoch) * pow(u53(ru.v[0], ru.v[1]), 1.0 / a);
+        boost = pow(u53(ru.v[0], ru.v[1]), 1.0 / a);
+        a += 1.0;
     }
     const double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
     for (uint32_t t = 0;; ++t) {
@@ -67,9 +71,9 @@ __device__ double gamma_mt(double a, uint64_t seed, uint64_t idx, uint32_t epoch
         double v = 1.0 + c * x;
         if (v <= 0.0) continue;
         v = v * v * v;
-        if (u < 1.0 - 0.0331 * x * x * x * x) return d * v;
-        if (log(u) < 0.5 * x * x + d * (1.0 - v + log(v))) return d * v;
-        if (t > 60) return d * v;      // unreachable in practice (acceptance > 95 %): bounded for safety
+        if (u < 1.0 - 0.0331 * x * x * x * x) return (d * v) * boost;
+        if (log(u) < 0.5 * x * x + d * (1.0 - v + log(v))) return (d * v) * boost;
+        if (t > 60) return (d * v) * boost;      // unreachable in practice (acceptance > 95 %): bounded for safety
     }
 }
 
@@ -864,6 +868,15 @@ __device__ __forceinline__ void niw_post_lds_body(const NiwMasterArgs &A, const 
         for (int e = tid; e < (DP - D) * DP; e += 256) {        // padding rows: identity
             const int a = D + e / DP, b = e % DP;
             if (b <= a) Pm[a * LD + b] = (a == b) ? 1.0 : 0.0;
+        }
+        // The strict upper halves of the diagonal blocks start as zeros.  The factorisation reads rows of a diagonal block WHOLE (its first
+        // look-ahead fetches row 14 before any lane has stored a mirrored row) and multiplies what it finds right of the diagonal by a
+        // zero coefficient for the rows that are finished: with whatever an earlier kernel left in LDS there, a NaN or Inf bit pattern
+        // turned L[15][15] of the block into NaN (0 x NaN) -- silently, the pivots and the log-determinant were already taken.  Seen as
+        // a chain that differed on a GPU whose previous tenant had left such patterns behind.
+        for (int e = tid; e < NB * 256; e += 256) {
+            const int blk = e >> 8, a = (e >> 4) & 15, b = e & 15;
+            if (b > a) Pm[(16 * blk + a) * LD + 16 * blk + b] = 0.0;
         }
     }
     __syncthreads();

@@ -286,6 +286,10 @@ void *dpmm_stream(dpmm_ctx *ctx);
  * dpmm_suffstats_* call, measured with HIP events on the ctx stream (0 if none yet, or when DPMM_OPT_KERNEL_TIMING is off -- the default).
  * Calling this waits for the measured kernels (the closing event of each pair), not for later work on the stream. */
 int dpmm_last_kernel_ms(dpmm_ctx *ctx, float *sweep_ms, float *suffstats_ms);
+/* Health counters of this ctx since creation (n >= 1 entries written, the rest 0):
+ *   out[0] = dpmm_step_master_device calls whose event wait returned before the posteriors' records had reached host memory (the call
+ *            then waits them out; a non-zero count is a runtime / driver anomaly worth reporting, the results are unaffected). */
+int dpmm_debug_counters(dpmm_ctx *ctx, int64_t *out, int n);
 /* Work the dpmm_sweep calls (NIW) since the previous call really executed, counted on the device (a slot per wave, no atomics):
  *   TOTALS over out8[7] launches of: out8[0] wave tiles, [1] full quadratic-form evaluations (per wave), [2] 16-row MFMA screens
  *   (per wave), [3] tail-screened cluster pairs (per wave); [4] matrix instructions per full evaluation, [5] per 16-row screen,
