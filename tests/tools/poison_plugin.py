@@ -1,6 +1,6 @@
 """pytest plugin: the whole GPU suite with LDS + register files refilled with a pattern before every worker library call.
 
-    PYTHONPATH=tests POISON_PAT=0xffffffff python -m pytest -p tools.poison_plugin tests -m gpu -q --deselect tests/test_gpu_multirank.py
+    PYTHONPATH=tests POISON_PAT=0xffffffff python -m pytest -p tools.poison_plugin tests -m gpu -q --deselect tests/test_gpu_multirank.py --deselect tests/test_gpu_uninit.py
 
 (POISON_WHAT: bit 0 LDS, bit 1 registers; default 3.  The multi-rank tests start their own processes, which the plugin does not reach.)"""
 import importlib
