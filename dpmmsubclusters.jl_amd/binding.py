@@ -74,6 +74,7 @@ ABI = [
     ("dpmm_stream", ctypes.c_void_p, [ctypes.c_void_p]),
     ("dpmm_last_kernel_ms", ctypes.c_int, [ctypes.c_void_p, _c_f32p, _c_f32p]),
     ("dpmm_debug_counters", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int]),
+    ("dpmm_debug_set_prelaunch_hook", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     ("dpmm_init_labels_from", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint32]),
     ("dpmm_set_option", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_double]),
     ("dpmm_params_staging", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.POINTER(ctypes.c_void_p)] * 6),

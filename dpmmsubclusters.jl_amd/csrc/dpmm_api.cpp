@@ -21,6 +21,10 @@
 
 #include "dpmm_kernels.h"
 
+namespace dpmm {      // test hook in front of every kernel launch (dpmm_kernels.h DPMM_LAUNCH, dpmm_debug_set_prelaunch_hook)
+void (*g_prelaunch)(void *) = nullptr;
+void *g_prelaunch_arg = nullptr;
+}
 using namespace dpmm;
 
 #ifdef DPMM_POISON
@@ -1385,6 +1389,12 @@ static bool master_marks_left(const double *sm, int K) {
     for (int64_t r = 0; r < 3 * (int64_t)K; ++r)
         for (int e = 0; e < 5; ++e) if (w[r * DPMM_MASTER_NSCALARS + e] == MASTER_MARK) return true;
     return false;
+}
+
+int dpmm_debug_set_prelaunch_hook(void (*fn)(void *), void *arg) {
+    dpmm::g_prelaunch_arg = arg;
+    dpmm::g_prelaunch = fn;
+    return DPMM_OK;
 }
 
 int dpmm_debug_counters(dpmm_ctx *c, int64_t *out, int n) {

@@ -223,4 +223,12 @@ hipError_t launch_niw_master_draw(const NiwMasterArgs &a, const int32_t *slot_of
                                   const float *lr, const float *wts, float *Rp, float *mup, float *cst, float *tail, int NB,
                                   unsigned long long *work, int what, hipStream_t s);
 
+// Test hook (dpmm_debug_set_prelaunch_hook): called on the host in front of EVERY kernel launch of the library.  tests/tools/poison.py
+// installs a function that waits for the device and refills the LDS and the register files of every CU with a NaN pattern, so that a
+// kernel reading LDS or registers it never wrote sees that instead of the (finite) leftovers of the library's own previous kernel.
+extern void (*g_prelaunch)(void *);
+extern void *g_prelaunch_arg;
+inline void prelaunch() { if (g_prelaunch) g_prelaunch(g_prelaunch_arg); }
+#define DPMM_LAUNCH(...) do { ::dpmm::prelaunch(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 }  // namespace dpmm

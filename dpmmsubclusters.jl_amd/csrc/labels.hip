@@ -119,7 +119,7 @@ __global__ void bad_flags_kernel(const int32_t *__restrict__ bin_total, const lo
     if (threadIdx.x == 0) flags[K] = (uint8_t)any;
 }
 hipError_t launch_bad_flags(const int32_t *bin_total, const long long *global_counts, int K, uint8_t *flags, hipStream_t s) {
-    hipLaunchKernelGGL(bad_flags_kernel, dim3(1), dim3(256), 0, s, bin_total, global_counts, K, flags);
+    DPMM_LAUNCH(bad_flags_kernel, dim3(1), dim3(256), 0, s, bin_total, global_counts, K, flags);
     return hipGetLastError();
 }
 // (the reset itself, with the flag computation folded in, is reset_recount_kernel in suffstats.hip: it re-counts the sort tiles it touches)
@@ -127,7 +127,7 @@ __global__ void widen_counts_kernel(const int32_t *__restrict__ src, int stride,
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = (long long)src[(int64_t)i * stride];
 }
 hipError_t launch_widen_counts(const int32_t *src, int stride, long long *dst, int n, hipStream_t s) {
-    hipLaunchKernelGGL(widen_counts_kernel, dim3(grid_for(n)), dim3(256), 0, s, src, stride, dst, n);
+    DPMM_LAUNCH(widen_counts_kernel, dim3(grid_for(n)), dim3(256), 0, s, src, stride, dst, n);
     return hipGetLastError();
 }
 // dst[3k+w][0..D) = src[3*slot[k]+w][0..D)  (Multinomial parameter rows from the slot-indexed staging; padding beyond D is zeroed)
@@ -141,7 +141,7 @@ __global__ void gather_rows_kernel(float *__restrict__ dst, int64_t ld_dst, cons
     }
 }
 hipError_t launch_gather_rows(float *dst, int64_t ld_dst, const float *src, int64_t ld_src, const int32_t *slot, int rows, int D, hipStream_t s) {
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((int64_t)rows * ld_dst)), dim3(256), 0, s, dst, ld_dst, src, ld_src, slot, rows, D);
+    DPMM_LAUNCH(gather_rows_kernel, dim3(grid_for((int64_t)rows * ld_dst)), dim3(256), 0, s, dst, ld_dst, src, ld_src, slot, rows, D);
     return hipGetLastError();
 }
 
@@ -157,13 +157,13 @@ __global__ void copy_vec4_kernel(uint4 *__restrict__ dst, const uint4 *__restric
 hipError_t launch_copy_bytes16(void *dst, const void *src, size_t bytes, hipStream_t s) {
     const int64_t nv = (int64_t)((bytes + 15) / 16);
     if (nv == 0) return hipSuccess;
-    hipLaunchKernelGGL(copy_vec4_kernel, dim3(grid_for(nv)), dim3(256), 0, s, (uint4 *)dst, (const uint4 *)src, nv);
+    DPMM_LAUNCH(copy_vec4_kernel, dim3(grid_for(nv)), dim3(256), 0, s, (uint4 *)dst, (const uint4 *)src, nv);
     return hipGetLastError();
 }
 hipError_t launch_copy_bytes(void *dst, const void *src, size_t bytes, hipStream_t s) {
     const int64_t nw = (int64_t)((bytes + 3) / 4);
     if (nw == 0) return hipSuccess;
-    hipLaunchKernelGGL(copy_words_kernel, dim3(grid_for(nw)), dim3(256), 0, s, (uint32_t *)dst, (const uint32_t *)src, nw);
+    DPMM_LAUNCH(copy_words_kernel, dim3(grid_for(nw)), dim3(256), 0, s, (uint32_t *)dst, (const uint32_t *)src, nw);
     return hipGetLastError();
 }
 
@@ -193,14 +193,14 @@ __global__ void contingency_kernel(const int32_t *__restrict__ bins, const int32
 hipError_t launch_contingency(const int32_t *bins, const int32_t *gt, int64_t n, int K, int n_gt, unsigned long long *counts, hipStream_t s) {
     const int cells = K * n_gt;
     const size_t lds = cells <= 8192 ? sizeof(unsigned) * cells : 0;
-    hipLaunchKernelGGL(contingency_kernel, dim3(grid_for(n)), dim3(256), lds, s, bins, gt, n, K, n_gt, counts);
+    DPMM_LAUNCH(contingency_kernel, dim3(grid_for(n)), dim3(256), lds, s, bins, gt, n, K, n_gt, counts);
     return hipGetLastError();
 }
 __global__ void i64_to_i32_kernel(int32_t *dst, const int64_t *src, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = (int32_t)src[i];
 }
 hipError_t launch_i64_to_i32(int32_t *dst, const int64_t *src, int64_t n, hipStream_t s) {
-    hipLaunchKernelGGL(i64_to_i32_kernel, dim3(grid_for(n)), dim3(256), 0, s, dst, src, n);
+    DPMM_LAUNCH(i64_to_i32_kernel, dim3(grid_for(n)), dim3(256), 0, s, dst, src, n);
     return hipGetLastError();
 }
 
@@ -222,9 +222,9 @@ hipError_t launch_ingest_rows(float *dst, int64_t ldx, const void *src, int is_f
                               hipStream_t s) {
     if (rows <= 0) return hipSuccess;
     if (is_f64)
-        hipLaunchKernelGGL((ingest_rows_kernel<double>), dim3(grid_for(rows * D)), dim3(256), 0, s, dst, ldx, (const double *)src, ld, rows, D, nan_to_zero);
+        DPMM_LAUNCH((ingest_rows_kernel<double>), dim3(grid_for(rows * D)), dim3(256), 0, s, dst, ldx, (const double *)src, ld, rows, D, nan_to_zero);
     else
-        hipLaunchKernelGGL((ingest_rows_kernel<float>), dim3(grid_for(rows * D)), dim3(256), 0, s, dst, ldx, (const float *)src, ld, rows, D, nan_to_zero);
+        DPMM_LAUNCH((ingest_rows_kernel<float>), dim3(grid_for(rows * D)), dim3(256), 0, s, dst, ldx, (const float *)src, ld, rows, D, nan_to_zero);
     return hipGetLastError();
 }
 
@@ -299,17 +299,17 @@ __global__ void smart_assign_kernel(int32_t *__restrict__ bins, const double *__
 }
 hipError_t launch_smart_project(const int32_t *bins, const float *X, int64_t ldx, int64_t n, int D, int k, const double *v, const double *mu,
                                 double *proj, double *vals, unsigned long long *counter, hipStream_t s) {
-    hipLaunchKernelGGL(smart_project_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, X, ldx, n, D, k, v, mu, proj, vals, counter);
+    DPMM_LAUNCH(smart_project_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, X, ldx, n, D, k, v, mu, proj, vals, counter);
     return hipGetLastError();
 }
 hipError_t launch_smart_kmeans(const int32_t *bins, const double *proj, int64_t n, int k, double m_lo, double m_hi, double *partial, double *out,
                                hipStream_t s) {
-    hipLaunchKernelGGL(smart_kmeans_kernel, dim3(SMART_GROUPS), dim3(256), 0, s, bins, proj, n, k, m_lo, m_hi, partial);
-    hipLaunchKernelGGL(smart_kmeans_finish_kernel, dim3(1), dim3(64), 0, s, partial, SMART_GROUPS, out);
+    DPMM_LAUNCH(smart_kmeans_kernel, dim3(SMART_GROUPS), dim3(256), 0, s, bins, proj, n, k, m_lo, m_hi, partial);
+    DPMM_LAUNCH(smart_kmeans_finish_kernel, dim3(1), dim3(64), 0, s, partial, SMART_GROUPS, out);
     return hipGetLastError();
 }
 hipError_t launch_smart_assign(int32_t *bins, const double *proj, int64_t n, int k, double m_lo, double m_hi, hipStream_t s) {
-    hipLaunchKernelGGL(smart_assign_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, proj, n, k, m_lo, m_hi);
+    DPMM_LAUNCH(smart_assign_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, proj, n, k, m_lo, m_hi);
     return hipGetLastError();
 }
 int smart_groups() { return SMART_GROUPS; }
@@ -347,36 +347,36 @@ __global__ void predict_finish_kernel(const float *__restrict__ table, int64_t s
     }
 }
 hipError_t launch_predict_finish(const float *table, int64_t stride, int rstep, int64_t n, int K, int64_t *labels, float *probs, hipStream_t s) {
-    hipLaunchKernelGGL(predict_finish_kernel, dim3(grid_for(n)), dim3(256), 0, s, table, stride, rstep, n, K, labels, probs);
+    DPMM_LAUNCH(predict_finish_kernel, dim3(grid_for(n)), dim3(256), 0, s, table, stride, rstep, n, K, labels, probs);
     return hipGetLastError();
 }
 
 hipError_t launch_init_labels(int32_t *bins, int64_t n, int64_t first, int init_clusters, int label0, uint64_t seed, uint32_t epoch, hipStream_t s) {
-    hipLaunchKernelGGL(init_labels_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, n, first, init_clusters, label0, seed, epoch);
+    DPMM_LAUNCH(init_labels_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, n, first, init_clusters, label0, seed, epoch);
     return hipGetLastError();
 }
 hipError_t launch_bins_from_i64(int32_t *bins, const int64_t *labels, const int64_t *sub, int64_t n, hipStream_t s) {
-    hipLaunchKernelGGL(bins_from_i64_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, labels, sub, n);
+    DPMM_LAUNCH(bins_from_i64_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, labels, sub, n);
     return hipGetLastError();
 }
 hipError_t launch_bins_to_i64(const int32_t *bins, int64_t *labels, int64_t *sub, int64_t n, hipStream_t s) {
-    hipLaunchKernelGGL(bins_to_i64_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, labels, sub, n);
+    DPMM_LAUNCH(bins_to_i64_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, labels, sub, n);
     return hipGetLastError();
 }
 hipError_t launch_split(int32_t *bins, int64_t n, int64_t first, const int32_t *pairs, int m, uint64_t seed, uint32_t epoch, hipStream_t s) {
-    hipLaunchKernelGGL(split_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, n, first, pairs, m, seed, epoch);
+    DPMM_LAUNCH(split_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, n, first, pairs, m, seed, epoch);
     return hipGetLastError();
 }
 hipError_t launch_merge(int32_t *bins, int64_t n, const int32_t *pairs, int m, hipStream_t s) {
-    hipLaunchKernelGGL(merge_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, n, pairs, m);
+    DPMM_LAUNCH(merge_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, n, pairs, m);
     return hipGetLastError();
 }
 hipError_t launch_remap(int32_t *bins, int64_t n, const int32_t *map, hipStream_t s) {
-    hipLaunchKernelGGL(remap_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, n, map);
+    DPMM_LAUNCH(remap_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, n, map);
     return hipGetLastError();
 }
 hipError_t launch_reset_sub(int32_t *bins, int64_t n, int64_t first, const int32_t *idx, int m, uint64_t seed, uint32_t epoch, hipStream_t s) {
-    hipLaunchKernelGGL(reset_sub_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, n, first, idx, m, seed, epoch);
+    DPMM_LAUNCH(reset_sub_kernel, dim3(grid_for(n)), dim3(256), 0, s, bins, n, first, idx, m, seed, epoch);
     return hipGetLastError();
 }
 

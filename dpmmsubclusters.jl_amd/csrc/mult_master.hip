@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void mult_marginal_kernel(const double *__rest
 
 hipError_t launch_mult_marginals(const double *rows, int64_t stride, const float *alpha0, const float *alpha1, int outlier_first, int D, int K,
                                  const int32_t *pairs, int npairs, const double prior_c[4], double *out, hipStream_t s) {
-    hipLaunchKernelGGL(mult_marginal_kernel, dim3(3 * K + npairs), dim3(256), 0, s, rows, stride, alpha0, alpha1, outlier_first, D, K, pairs,
+    DPMM_LAUNCH(mult_marginal_kernel, dim3(3 * K + npairs), dim3(256), 0, s, rows, stride, alpha0, alpha1, outlier_first, D, K, pairs,
                        prior_c[0], prior_c[1], prior_c[2], prior_c[3], out);
     return hipGetLastError();
 }
@@ -134,7 +134,7 @@ hipError_t launch_mult_dirichlet(const double *rows, int64_t stride, const float
                                  int K, uint64_t seed, uint32_t epoch, float *raw, hipStream_t s) {
     static bool attr = false;
     if (!attr) { hipFuncSetAttribute((const void *)mult_dirichlet_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * DPMM_MULT_MASTER_MAXD); attr = true; }
-    hipLaunchKernelGGL(mult_dirichlet_kernel, dim3(3 * K), dim3(256), sizeof(double) * (size_t)D, s, rows, stride, alpha0, alpha1, outlier_first, D, ldx,
+    DPMM_LAUNCH(mult_dirichlet_kernel, dim3(3 * K), dim3(256), sizeof(double) * (size_t)D, s, rows, stride, alpha0, alpha1, outlier_first, D, ldx,
                        seed, epoch, raw);
     return hipGetLastError();
 }

@@ -661,7 +661,7 @@ __global__ void u8_convert_kernel(const float *__restrict__ X, int64_t ldx, int 
 }
 
 hipError_t launch_u8_convert(const float *X, int64_t ldx, int D, int64_t n, uint8_t *X8, int64_t ld8, int *d_flag, hipStream_t s) {
-    hipLaunchKernelGGL(u8_convert_kernel, dim3(4096), dim3(256), 0, s, X, ldx, D, n, X8, ld8, d_flag);
+    DPMM_LAUNCH(u8_convert_kernel, dim3(4096), dim3(256), 0, s, X, ldx, D, n, X8, ld8, d_flag);
     return hipGetLastError();
 }
 
@@ -682,7 +682,7 @@ hipError_t launch_mult_pack_u8(const float *logp, uint32_t *Lp8, int rows, int64
     const int K = rows / 3, NSL = (int)(ld8 / 32);
     int NRBc, NRBs;
     u8_blocks(K, NRBc, NRBs);
-    hipLaunchKernelGGL(mult_pack_u8_kernel, dim3(512), dim3(256), 0, s, logp, Lp8, K, ldx, NSL, NRBc, NRBs);
+    DPMM_LAUNCH(mult_pack_u8_kernel, dim3(512), dim3(256), 0, s, logp, Lp8, K, ldx, NSL, NRBc, NRBs);
     return hipGetLastError();
 }
 
@@ -703,7 +703,7 @@ static hipError_t launch_u8(const MultSweepArgs &a, const uint8_t *X8, int64_t l
         if (e != hipSuccess) return e;
         attr = cap;
     }
-    hipLaunchKernelGGL(mult_sweep_u8_kernel<B>, dim3(grid), dim3(256), lds, s, a, X8, ld8, Lp8, NKS8, NRBc, NRBs, ltab_ok);
+    DPMM_LAUNCH(mult_sweep_u8_kernel<B>, dim3(grid), dim3(256), lds, s, a, X8, ld8, Lp8, NKS8, NRBc, NRBs, ltab_ok);
     return hipGetLastError();
 }
 
@@ -729,7 +729,7 @@ __global__ void bf16_exact_kernel(const float *__restrict__ X, int64_t nwords, i
 }
 
 hipError_t launch_bf16_exact_check(const float *X, int64_t nwords, int *d_flag, hipStream_t s) {
-    hipLaunchKernelGGL(bf16_exact_kernel, dim3(2048), dim3(256), 0, s, X, nwords, d_flag);
+    DPMM_LAUNCH(bf16_exact_kernel, dim3(2048), dim3(256), 0, s, X, nwords, d_flag);
     return hipGetLastError();
 }
 
@@ -740,16 +740,16 @@ size_t mult_pack_bf16_words(int rows, int64_t ldx) {
 
 hipError_t launch_mult_pack_bf16(const float *logp, uint32_t *Lp16, int rows, int64_t ldx, hipStream_t s) {
     const int NKS = (int)((ldx + 31) / 32), NRB = (rows + 15) / 16;
-    hipLaunchKernelGGL(mult_pack_bf16_kernel, dim3(512), dim3(256), 0, s, logp, Lp16, rows, ldx, NKS, NRB);
+    DPMM_LAUNCH(mult_pack_bf16_kernel, dim3(512), dim3(256), 0, s, logp, Lp16, rows, ldx, NKS, NRB);
     return hipGetLastError();
 }
 
 hipError_t launch_mult_sweep_bf16(const MultSweepArgs &a, const uint32_t *Lp16, int grid, hipStream_t s) {
     const int NKS = (int)((a.ldx + 31) / 32), NRB = (3 * a.K + 15) / 16;
-    if (NRB <= 2) hipLaunchKernelGGL(mult_sweep_bf16_kernel<2>, dim3(grid), dim3(256), 0, s, a, Lp16, NKS, NRB);
-    else if (NRB <= 4) hipLaunchKernelGGL(mult_sweep_bf16_kernel<4>, dim3(grid), dim3(256), 0, s, a, Lp16, NKS, NRB);
-    else if (NRB <= 6) hipLaunchKernelGGL(mult_sweep_bf16_kernel<6>, dim3(grid), dim3(256), 0, s, a, Lp16, NKS, NRB);
-    else hipLaunchKernelGGL(mult_sweep_bf16_kernel<8>, dim3(grid), dim3(256), 0, s, a, Lp16, NKS, NRB);
+    if (NRB <= 2) DPMM_LAUNCH(mult_sweep_bf16_kernel<2>, dim3(grid), dim3(256), 0, s, a, Lp16, NKS, NRB);
+    else if (NRB <= 4) DPMM_LAUNCH(mult_sweep_bf16_kernel<4>, dim3(grid), dim3(256), 0, s, a, Lp16, NKS, NRB);
+    else if (NRB <= 6) DPMM_LAUNCH(mult_sweep_bf16_kernel<6>, dim3(grid), dim3(256), 0, s, a, Lp16, NKS, NRB);
+    else DPMM_LAUNCH(mult_sweep_bf16_kernel<8>, dim3(grid), dim3(256), 0, s, a, Lp16, NKS, NRB);
     return hipGetLastError();
 }
 
@@ -757,13 +757,13 @@ int mult_tile_points() { return M_TILE; }
 
 hipError_t launch_mult_pack(const float *logp, float *Lp, int rows, int64_t ldx, hipStream_t s) {
     const int NT = (int)((ldx + 15) / 16), NRB = (rows + 15) / 16;
-    hipLaunchKernelGGL(mult_pack_kernel, dim3(512), dim3(256), 0, s, logp, Lp, rows, ldx, NT, NRB);
+    DPMM_LAUNCH(mult_pack_kernel, dim3(512), dim3(256), 0, s, logp, Lp, rows, ldx, NT, NRB);
     return hipGetLastError();
 }
 
 hipError_t launch_mult_sweep(const MultSweepArgs &a, int grid, hipStream_t s) {
     const int NT = (int)((a.ldx + 15) / 16), NRB = (3 * a.K + 15) / 16;
-    hipLaunchKernelGGL(mult_sweep_kernel, dim3(grid), dim3(256), 0, s, a, a.logp, NT, NRB);
+    DPMM_LAUNCH(mult_sweep_kernel, dim3(grid), dim3(256), 0, s, a, a.logp, NT, NRB);
     return hipGetLastError();
 }
 

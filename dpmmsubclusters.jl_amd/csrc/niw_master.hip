@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void niw_noise_kernel(NiwMasterArgs A, uint32_
 }
 hipError_t launch_niw_master_noise(const NiwMasterArgs &a, int nmat, uint32_t epoch, double *Y, hipStream_t s) {
     if (nmat <= 0) return hipSuccess;
-    hipLaunchKernelGGL(niw_noise_kernel, dim3(nmat, a.DP >= 128 ? 8 : (a.DP >= 48 ? 4 : 1)), dim3(256), 0, s, a, epoch, Y);
+    DPMM_LAUNCH(niw_noise_kernel, dim3(nmat, a.DP >= 128 ? 8 : (a.DP >= 48 ? 4 : 1)), dim3(256), 0, s, a, epoch, Y);
     return hipGetLastError();
 }
 
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256) void niw_draw_inputs_kernel(NiwMasterArgs A, c
         xiout[(int64_t)blockIdx.x * D + d] = normal_from(philox4x32_10(A.seed, (id << 32) + (uint64_t)d, epoch, STREAM_M_XI));
 }
 hipError_t launch_niw_draw_inputs(const NiwMasterArgs &a, const int32_t *slot_of_cluster, int K, uint32_t epoch, double *Aout, double *xiout, hipStream_t s) {
-    hipLaunchKernelGGL(niw_draw_inputs_kernel, dim3(3 * K), dim3(256), 0, s, a, slot_of_cluster, epoch, Aout, xiout);
+    DPMM_LAUNCH(niw_draw_inputs_kernel, dim3(3 * K), dim3(256), 0, s, a, slot_of_cluster, epoch, Aout, xiout);
     return hipGetLastError();
 }
 
@@ -1038,7 +1038,7 @@ hipError_t launch_niw_master_posterior_pairs(const NiwMasterArgs &a, const int32
                                              const int32_t *cluster_pairs, int npairs, double *pair_small, hipStream_t s) {
     static bool attr = false;
     if (!attr) { hipFuncSetAttribute((const void *)niw_post_both_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)niw_post_lds_bytes(NIW_POST_LDS_MAXDP)); attr = true; }
-    hipLaunchKernelGGL(niw_post_both_kernel, dim3(3 * njobs + npairs), dim3(256), niw_post_lds_bytes(a.DP), s, a, jobs, rows, small, 3 * njobs,
+    DPMM_LAUNCH(niw_post_both_kernel, dim3(3 * njobs + npairs), dim3(256), niw_post_lds_bytes(a.DP), s, a, jobs, rows, small, 3 * njobs,
                        cluster_pairs, pair_small);
     return hipGetLastError();
 }
@@ -1047,13 +1047,13 @@ hipError_t launch_niw_master_pairs(const NiwMasterArgs &a, const int32_t *pairs,
     if (a.DP <= NIW_POST_LDS_MAXDP) {
         static bool attr = false;
         if (!attr) { hipFuncSetAttribute((const void *)niw_post_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)niw_post_lds_bytes(NIW_POST_LDS_MAXDP)); attr = true; }
-        hipLaunchKernelGGL(niw_post_lds_kernel<true>, dim3(n), dim3(256), niw_post_lds_bytes(a.DP), s, a, pairs, (const double *)nullptr, small);
+        DPMM_LAUNCH(niw_post_lds_kernel<true>, dim3(n), dim3(256), niw_post_lds_bytes(a.DP), s, a, pairs, (const double *)nullptr, small);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(niw_form_pair_kernel, dim3(n, a.DP >= 64 ? 16 : 1), dim3(256), 0, s, a, pairs, scratch, small);
+    DPMM_LAUNCH(niw_form_pair_kernel, dim3(n, a.DP >= 64 ? 16 : 1), dim3(256), 0, s, a, pairs, scratch, small);
     NiwMasterArgs b = a;
     b.fac = scratch;                                  // the factorisation kernel in "matrix blockIdx.x of fac" mode
-    hipLaunchKernelGGL(niw_chol_kernel, dim3(n), dim3(256), niw_master_lds_bytes(a.DP), s, b, (const int32_t *)nullptr, small);
+    DPMM_LAUNCH(niw_chol_kernel, dim3(n), dim3(256), niw_master_lds_bytes(a.DP), s, b, (const int32_t *)nullptr, small);
     return hipGetLastError();
 }
 
@@ -1069,7 +1069,7 @@ __global__ void niw_rows_gather_kernel(const double *__restrict__ rows_store, co
 hipError_t launch_niw_rows_gather(const double *rows_store, const int32_t *slots, int n, int64_t stride, double *dst, hipStream_t s) {
     const int64_t total = (int64_t)n * 2 * stride;
     const int grid = (int)std::min<int64_t>(4096, (total + 255) / 256);
-    hipLaunchKernelGGL(niw_rows_gather_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, s, rows_store, slots, n, 2 * stride, dst);
+    DPMM_LAUNCH(niw_rows_gather_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, s, rows_store, slots, n, 2 * stride, dst);
     return hipGetLastError();
 }
 
@@ -1080,17 +1080,17 @@ hipError_t launch_niw_master_posterior(const NiwMasterArgs &a, const int32_t *jo
     if (a.DP <= NIW_POST_LDS_MAXDP) {
         static bool attr_l = false;
         if (!attr_l) { hipFuncSetAttribute((const void *)niw_post_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)niw_post_lds_bytes(NIW_POST_LDS_MAXDP)); attr_l = true; }
-        hipLaunchKernelGGL(niw_post_lds_kernel<false>, dim3(3 * njobs), dim3(256), niw_post_lds_bytes(a.DP), s, a, jobs, rows, small);
+        DPMM_LAUNCH(niw_post_lds_kernel<false>, dim3(3 * njobs), dim3(256), niw_post_lds_bytes(a.DP), s, a, jobs, rows, small);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(niw_form_kernel, dim3(3 * njobs, a.DP >= 64 ? 16 : 1), dim3(256), 0, s, a, jobs, rows, small);
+    DPMM_LAUNCH(niw_form_kernel, dim3(3 * njobs, a.DP >= 64 ? 16 : 1), dim3(256), 0, s, a, jobs, rows, small);
     static bool attr = false;
     if (!attr) {
         hipFuncSetAttribute((const void *)niw_chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)niw_master_lds_bytes(DPMM_MASTER_MAXD));
         hipFuncSetAttribute((const void *)niw_draw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)niw_master_lds_bytes(DPMM_MASTER_MAXD));
         attr = true;
     }
-    hipLaunchKernelGGL(niw_chol_kernel, dim3(3 * njobs), dim3(256), niw_master_lds_bytes(a.DP), s, a, jobs, small);
+    DPMM_LAUNCH(niw_chol_kernel, dim3(3 * njobs), dim3(256), niw_master_lds_bytes(a.DP), s, a, jobs, small);
     return hipGetLastError();
 }
 
@@ -1106,8 +1106,8 @@ hipError_t launch_niw_master_draw(const NiwMasterArgs &a, const int32_t *slot_of
         hipFuncSetAttribute((const void *)niw_draw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)niw_master_lds_bytes(DPMM_MASTER_MAXD));
         attr = true;
     }
-    if (what & 1) hipLaunchKernelGGL(niw_draw_kernel, dim3(3 * K), dim3(256), niw_master_lds_bytes(a.DP), s, a, slot_of_cluster, epoch, Y, logdet_sigma, (what & 4) ? 1 : 0);
-    if (what & 2) hipLaunchKernelGGL(niw_master_pack_kernel, dim3(512), dim3(256), 0, s, Y, a.mu_draw, logdet_sigma, lr, wts, Rp, mup, cst, tail, a.D, a.DP, NB,
+    if (what & 1) DPMM_LAUNCH(niw_draw_kernel, dim3(3 * K), dim3(256), niw_master_lds_bytes(a.DP), s, a, slot_of_cluster, epoch, Y, logdet_sigma, (what & 4) ? 1 : 0);
+    if (what & 2) DPMM_LAUNCH(niw_master_pack_kernel, dim3(512), dim3(256), 0, s, Y, a.mu_draw, logdet_sigma, lr, wts, Rp, mup, cst, tail, a.D, a.DP, NB,
                                      3 * K, work);
     return hipGetLastError();
 }

@@ -1609,16 +1609,16 @@ static hipError_t launch_direct(const NiwSweepArgs &a, int grid, hipStream_t s) 
             hipFuncSetAttribute((const void *)niw_sweep_direct_kernel<NB, NG, OCC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / OCC);
             attr_fast = true;
         }
-        hipLaunchKernelGGL((niw_sweep_direct_kernel<NB, NG, OCC, true>), dim3(grid), dim3(256), lds_bytes, s, b);
+        DPMM_LAUNCH((niw_sweep_direct_kernel<NB, NG, OCC, true>), dim3(grid), dim3(256), lds_bytes, s, b);
     } else {
-        hipLaunchKernelGGL((niw_sweep_direct_kernel<NB, NG, OCC>), dim3(grid), dim3(256), lds_bytes, s, b);
+        DPMM_LAUNCH((niw_sweep_direct_kernel<NB, NG, OCC>), dim3(grid), dim3(256), lds_bytes, s, b);
     }
     return hipGetLastError();
 }
 
 template <int NB, int NG, int CH>
 static hipError_t launch_cfg(const NiwSweepArgs &a, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((niw_sweep_kernel<NB, NG, CH>), dim3(grid), dim3(256), 0, s, a);
+    DPMM_LAUNCH((niw_sweep_kernel<NB, NG, CH>), dim3(grid), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -1782,13 +1782,13 @@ __global__ __launch_bounds__(256) void niw_screen_prep_kernel(const float *__res
 
 hipError_t launch_niw_screen_prep(const float *R, const float *mu, int D, int K, float *lam, float *dist, const int32_t *slot, hipStream_t s) {
     const size_t lds = sizeof(float) * ((size_t)D * D + (size_t)D * (D + 1) + 256);
-    hipLaunchKernelGGL(niw_screen_prep_kernel, dim3(K), dim3(256), lds, s, R, mu, D, K, lam, dist, slot);
+    DPMM_LAUNCH(niw_screen_prep_kernel, dim3(K), dim3(256), lds, s, R, mu, D, K, lam, dist, slot);
     return hipGetLastError();
 }
 
 hipError_t launch_niw_pack(const float *R, const float *mu, float *Rp, float *mup, int D, int NB, int nmat, float *tail, const float *cst,
                            const int32_t *slot, float *cst_out, unsigned long long *work, hipStream_t s) {
-    hipLaunchKernelGGL(niw_pack_kernel, dim3(512), dim3(256), 0, s, R, mu, Rp, mup, D, NB, nmat, tail, cst, slot, cst_out, work);
+    DPMM_LAUNCH(niw_pack_kernel, dim3(512), dim3(256), 0, s, R, mu, Rp, mup, D, NB, nmat, tail, cst, slot, cst_out, work);
     return hipGetLastError();
 }
 

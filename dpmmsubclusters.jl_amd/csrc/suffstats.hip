@@ -387,30 +387,30 @@ __global__ __launch_bounds__(256) void derive_rows_kernel(double *__restrict__ o
 }
 hipError_t launch_derive_rows(double *out, double *cache, const uint8_t *mode, uint8_t *dirty, int64_t stride, int K, const uint8_t *flags_src,
                               uint8_t *flags_dst, hipStream_t s) {
-    hipLaunchKernelGGL(derive_rows_kernel, dim3((unsigned)((stride + 255) / 256), K), dim3(256), 0, s, out, cache, mode, dirty, stride, K, flags_src, flags_dst);
+    DPMM_LAUNCH(derive_rows_kernel, dim3((unsigned)((stride + 255) / 256), K), dim3(256), 0, s, out, cache, mode, dirty, stride, K, flags_src, flags_dst);
     return hipGetLastError();
 }
 
 hipError_t launch_sort_by_bin(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s) {
     const int nt = (int)((n + SORT_TILE - 1) / SORT_TILE);
     if (nt == 0) return hipSuccess;
-    hipLaunchKernelGGL(hist_kernel, dim3(nt), dim3(64), nbins * sizeof(int), s, bins, n, nbins, nt, b.tile_cnt, (int32_t *)nullptr,
+    DPMM_LAUNCH(hist_kernel, dim3(nt), dim3(64), nbins * sizeof(int), s, bins, n, nbins, nt, b.tile_cnt, (int32_t *)nullptr,
                        (uint16_t *)nullptr, (uint8_t *)nullptr);
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(nbins), dim3(256), 0, s, b.tile_cnt, b.tile_hist, nt, b.bin_total);
+    DPMM_LAUNCH(scan_tiles_kernel, dim3(nbins), dim3(256), 0, s, b.tile_cnt, b.tile_hist, nt, b.bin_total);
     return hipGetLastError();
 }
 // The sort of the per-step pass in four launches (n > 0): histogram (+ running totals) -> [caller: all-reduce of the totals] ->
 // launch_step_reset (flags, sub-label reset, re-count of the touched tiles) -> launch_step_scan_scatter (scan + starts, scatter).
 hipError_t launch_step_hist(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s) {
     const int nt = (int)((n + SORT_TILE - 1) / SORT_TILE);
-    hipLaunchKernelGGL(hist_kernel, dim3(nt), dim3(64), nbins * sizeof(int), s, bins, n, nbins, nt, b.tile_cnt, b.fast_total,
+    DPMM_LAUNCH(hist_kernel, dim3(nt), dim3(64), nbins * sizeof(int), s, bins, n, nbins, nt, b.tile_cnt, b.fast_total,
                        b.prev_lab, b.prev_lab ? b.cdirty : (uint8_t *)nullptr);
     return hipGetLastError();
 }
 hipError_t launch_step_reset(int32_t *bins, int64_t n, int64_t first, int nbins, const SortBufs &b, const long long *global_counts, uint8_t *flags,
                              int K, uint64_t seed, uint32_t epoch, hipStream_t s) {
     const int nt = (int)((n + SORT_TILE - 1) / SORT_TILE);
-    hipLaunchKernelGGL(reset_recount_kernel, dim3(nt), dim3(64), nbins * sizeof(int) + ((K + 3) & ~3), s, bins, n, first, nbins, nt, b.fast_total,
+    DPMM_LAUNCH(reset_recount_kernel, dim3(nt), dim3(64), nbins * sizeof(int) + ((K + 3) & ~3), s, bins, n, first, nbins, nt, b.fast_total,
                        global_counts, b.tile_cnt, flags, K, seed, epoch);
     return hipGetLastError();
 }
@@ -757,9 +757,9 @@ __global__ void niw_inv_offsets_kernel(const int32_t *__restrict__ row_off, int3
 hipError_t launch_niw_row_offsets(int32_t *row_off, int32_t *inv_off, int D, int64_t packed_stride, hipStream_t s) {
     const int NBK = D <= 16 ? 1 : D <= 32 ? 2 : D <= 64 ? 4 : D <= 128 ? 8 : 16;
     const int64_t slab = niw_slab_stride_nbk(NBK);
-    hipLaunchKernelGGL(niw_row_offsets_kernel, dim3((unsigned)((packed_stride + 255) / 256)), dim3(256), 0, s, row_off, D, NBK, packed_stride);
-    hipLaunchKernelGGL(niw_inv_offsets_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, s, row_off, inv_off, packed_stride, slab, 0);
-    hipLaunchKernelGGL(niw_inv_offsets_kernel, dim3((unsigned)((packed_stride + 255) / 256)), dim3(256), 0, s, row_off, inv_off, packed_stride, slab, 1);
+    DPMM_LAUNCH(niw_row_offsets_kernel, dim3((unsigned)((packed_stride + 255) / 256)), dim3(256), 0, s, row_off, D, NBK, packed_stride);
+    DPMM_LAUNCH(niw_inv_offsets_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, s, row_off, inv_off, packed_stride, slab, 0);
+    DPMM_LAUNCH(niw_inv_offsets_kernel, dim3((unsigned)((packed_stride + 255) / 256)), dim3(256), 0, s, row_off, inv_off, packed_stride, slab, 1);
     return hipGetLastError();
 }
 
@@ -831,13 +831,13 @@ hipError_t launch_niw_stats(const StatsArgs &a0, hipStream_t s) {
     if (groups > max_items) groups = max_items;
     a.range_groups = groups;
     switch (NBK) {
-        case 1: hipLaunchKernelGGL((niw_stats_kernel<1>), dim3(groups), dim3(64), 0, s, a); break;
-        case 2: hipLaunchKernelGGL((niw_stats_kernel<2>), dim3(groups), dim3(64), 0, s, a); break;
-        case 4: hipLaunchKernelGGL((niw_stats_kernel<4>), dim3(groups), dim3(64), 0, s, a); break;
-        case 8: hipLaunchKernelGGL((niw_stats_kernel<8>), dim3(groups), dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL((niw_stats_kernel<16>), dim3(groups), dim3(512), 0, s, a); break;
+        case 1: DPMM_LAUNCH((niw_stats_kernel<1>), dim3(groups), dim3(64), 0, s, a); break;
+        case 2: DPMM_LAUNCH((niw_stats_kernel<2>), dim3(groups), dim3(64), 0, s, a); break;
+        case 4: DPMM_LAUNCH((niw_stats_kernel<4>), dim3(groups), dim3(64), 0, s, a); break;
+        case 8: DPMM_LAUNCH((niw_stats_kernel<8>), dim3(groups), dim3(256), 0, s, a); break;
+        default: DPMM_LAUNCH((niw_stats_kernel<16>), dim3(groups), dim3(512), 0, s, a); break;
     }
-    hipLaunchKernelGGL(niw_reduce_kernel, dim3((unsigned)((a.slab_stride + 63) / 64), a.nbins), dim3(64 * REDUCE_PARTS), 0, s, a, NBK);
+    DPMM_LAUNCH(niw_reduce_kernel, dim3((unsigned)((a.slab_stride + 63) / 64), a.nbins), dim3(64 * REDUCE_PARTS), 0, s, a, NBK);
     return hipGetLastError();
 }
 
@@ -945,8 +945,8 @@ __global__ __launch_bounds__(256) void mult_stats_u8_kernel(StatsArgs A, const u
 
 hipError_t launch_mult_stats_u8(const StatsArgs &a, const uint8_t *X8, int64_t ld8, hipStream_t s) {
     const int grid = a.max_items < 1 ? 1 : a.max_items;
-    hipLaunchKernelGGL(mult_stats_u8_kernel, dim3(grid), dim3(256), 0, s, a, X8, ld8);
-    hipLaunchKernelGGL(mult_reduce_kernel, dim3((unsigned)((a.packed_stride + 255) / 256), a.nbins), dim3(256), 0, s, a);
+    DPMM_LAUNCH(mult_stats_u8_kernel, dim3(grid), dim3(256), 0, s, a, X8, ld8);
+    DPMM_LAUNCH(mult_reduce_kernel, dim3((unsigned)((a.packed_stride + 255) / 256), a.nbins), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -954,27 +954,27 @@ int64_t mult_slab_stride(int D) { return D; }
 
 hipError_t launch_mult_stats(const StatsArgs &a, hipStream_t s) {
     const int grid = a.max_items < 1 ? 1 : a.max_items;
-    hipLaunchKernelGGL(mult_stats_kernel, dim3(grid), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(mult_reduce_kernel, dim3((unsigned)((a.packed_stride + 255) / 256), a.nbins), dim3(256), 0, s, a);
+    DPMM_LAUNCH(mult_stats_kernel, dim3(grid), dim3(256), 0, s, a);
+    DPMM_LAUNCH(mult_reduce_kernel, dim3((unsigned)((a.packed_stride + 255) / 256), a.nbins), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
 // second half of the sort (needs the selection mask and the chunk size of the statistics pass)
 hipError_t launch_step_scan_scatter(const int32_t *bins, const StatsArgs &a, int derive, int force_all, hipStream_t s) {
     const int nt = (int)((a.n + SORT_TILE - 1) / SORT_TILE);
-    hipLaunchKernelGGL(scan_starts_kernel, dim3(a.nbins), dim3(256), 0, s, a.sb.tile_cnt, a.sb.tile_hist, nt, a.sb.bin_total, a.sb.bin_sel, a.chunk,
+    DPMM_LAUNCH(scan_starts_kernel, dim3(a.nbins), dim3(256), 0, s, a.sb.tile_cnt, a.sb.tile_hist, nt, a.sb.bin_total, a.sb.bin_sel, a.chunk,
                        a.sb.bin_start, a.sb.item_start, a.sb.perm_total, a.sb.fast_total, a.sb.ticket,
                        derive ? a.sb.cmode : (uint8_t *)nullptr, a.sb.cdirty, force_all);
-    hipLaunchKernelGGL(scatter_kernel, dim3(nt), dim3(64), a.nbins * sizeof(int), s, bins, a.n, a.nbins, nt,
+    DPMM_LAUNCH(scatter_kernel, dim3(nt), dim3(64), a.nbins * sizeof(int), s, bins, a.n, a.nbins, nt,
                        a.sb.tile_hist, a.sb.bin_start, a.sb.perm);
     return hipGetLastError();
 }
 hipError_t launch_sort_finish(const int32_t *bins, const StatsArgs &a, hipStream_t s) {
     const int nt = (int)((a.n + SORT_TILE - 1) / SORT_TILE);
-    hipLaunchKernelGGL(starts_kernel, dim3(1), dim3(256), 0, s, a.sb.bin_total, a.sb.bin_sel, a.nbins, a.chunk,
+    DPMM_LAUNCH(starts_kernel, dim3(1), dim3(256), 0, s, a.sb.bin_total, a.sb.bin_sel, a.nbins, a.chunk,
                        a.sb.bin_start, a.sb.item_start, a.sb.perm_total);
     if (nt > 0)
-        hipLaunchKernelGGL(scatter_kernel, dim3(nt), dim3(64), a.nbins * sizeof(int), s, bins, a.n, a.nbins, nt,
+        DPMM_LAUNCH(scatter_kernel, dim3(nt), dim3(64), a.nbins * sizeof(int), s, bins, a.n, a.nbins, nt,
                            a.sb.tile_hist, a.sb.bin_start, a.sb.perm);
     return hipGetLastError();
 }

@@ -290,6 +290,10 @@ int dpmm_last_kernel_ms(dpmm_ctx *ctx, float *sweep_ms, float *suffstats_ms);
  *   out[0] = dpmm_step_master_device calls whose event wait returned before the posteriors' records had reached host memory (the call
  *            then waits them out; a non-zero count is a runtime / driver anomaly worth reporting, the results are unaffected). */
 int dpmm_debug_counters(dpmm_ctx *ctx, int64_t *out, int n);
+/* Test hook, process-wide: fn(arg) is called on the host in front of every kernel launch of the library (fn == NULL: off, the default).
+ * tests/tools/poison.py uses it to refill LDS and the register files with a NaN pattern between the library's own kernels
+ * (tests/test_gpu_uninit.py); fn may synchronise the device and launch kernels of its own on other streams. */
+int dpmm_debug_set_prelaunch_hook(void (*fn)(void *), void *arg);
 /* Work the dpmm_sweep calls (NIW) since the previous call really executed, counted on the device (a slot per wave, no atomics):
  *   TOTALS over out8[7] launches of: out8[0] wave tiles, [1] full quadratic-form evaluations (per wave), [2] 16-row MFMA screens
  *   (per wave), [3] tail-screened cluster pairs (per wave); [4] matrix instructions per full evaluation, [5] per 16-row screen,

@@ -31,34 +31,38 @@ def mods(pkg):
 
 @pytest.mark.parametrize("pattern", PATTERNS)
 @pytest.mark.parametrize("D", [2, 5, 64, 200])
-def test_posteriors_and_draws_ignore_lds_and_register_contents(pkg, D, pattern):
-    """Posterior scalars, the factor behind them and the draws (mu, R, log det) of populated, one-sided and empty distributions."""
+def test_posteriors_and_draws_ignore_lds_and_register_contents(pkg, mods, D, pattern):
+    """Posterior scalars, the factor behind them and the draws (mu, R, log det) of populated, one-sided and empty distributions: clean,
+    with the pattern refilled before every library call, and with it refilled before every kernel launch inside the library."""
+    import contextlib
     import test_gpu_master as tm
     n, K = 3000, 4
     lr = np.full((K, 2), 0.5, np.float32); w = np.full(K, 1.0 / K, np.float32)
     out = []
-    for dirty in (False, True):
-        wk, X, lab, sub, prior = tm._setup(pkg, D, n, K, seed=900 + D)
-        lab = lab.copy(); sub = np.ones_like(sub); lab[lab == K] = 1
-        wk.set_labels(lab, sub)
-        wk.master_setup(*prior)
-        slots = np.arange(K, dtype=np.int32)
-        if dirty: poison.poison(pattern)
-        wk.suffstats_device(None)
-        if dirty: poison.poison(pattern)
-        scal = np.array(wk.master_posterior(None, slots)).copy()
-        draws = []
-        for epoch in (1, 2):
+    for dirty in (False, True, "kernels"):
+        with (poison.poisoned_kernel_launches(mods[0], pattern) if dirty == "kernels" else contextlib.nullcontext()):
+            wk, X, lab, sub, prior = tm._setup(pkg, D, n, K, seed=900 + D)
+            lab = lab.copy(); sub = np.ones_like(sub); lab[lab == K] = 1
+            wk.set_labels(lab, sub)
+            wk.master_setup(*prior)
+            slots = np.arange(K, dtype=np.int32)
             if dirty: poison.poison(pattern)
-            wk.master_draw(epoch, slots, lr, w)
-            draws.append([np.array(a).copy() for a in wk.master_draws(K)])
-        wk.close()
-        out.append((scal, draws))
-    (s0, d0), (s1, d1) = out
-    assert np.array_equal(s0, s1, equal_nan=True)
-    for a, b in zip(d0, d1):
-        for u, v in zip(a, b):
-            assert np.all(np.isfinite(u)) and np.array_equal(u, v)
+            wk.suffstats_device(None)
+            if dirty: poison.poison(pattern)
+            scal = np.array(wk.master_posterior(None, slots)).copy()
+            draws = []
+            for epoch in (1, 2):
+                if dirty: poison.poison(pattern)
+                wk.master_draw(epoch, slots, lr, w)
+                draws.append([np.array(a).copy() for a in wk.master_draws(K)])
+            wk.close()
+            out.append((scal, draws))
+    s0, d0 = out[0]
+    for s1, d1 in out[1:]:
+        assert np.array_equal(s0, s1, equal_nan=True)
+        for a, b in zip(d0, d1):
+            for u, v in zip(a, b):
+                assert np.all(np.isfinite(u)) and np.array_equal(u, v)
 
 
 def _chain(pkg, mods, kind, iters):
@@ -83,6 +87,21 @@ def _chain(pkg, mods, kind, iters):
     lab, sub = np.array(lab).copy(), np.array(sub).copy()
     wk.close()
     return kh, lab, sub
+
+
+@pytest.mark.parametrize("kind", ["niw8", "niw64", "niw128", "mult200"])
+def test_chain_unchanged_with_poison_before_every_kernel_launch(pkg, mods, kind):
+    """The same with the pattern refilled in front of EVERY kernel launch inside the library (its test hook): no kernel sees the leftovers
+    of the library's own previous kernel either (Int32 -1 sentinels and masks left in LDS are NaNs when a later kernel reads them as
+    Float64)."""
+    binding, host, engine = mods
+    iters = 16
+    clean = _chain(pkg, mods, kind, iters)
+    with poison.poisoned_kernel_launches(binding, 0xffffffff) as launches:
+        dirty = _chain(pkg, mods, kind, iters)
+    assert launches[0] > 8 * iters, launches
+    assert clean[0] == dirty[0], (clean[0], dirty[0])
+    assert np.array_equal(clean[1], dirty[1]) and np.array_equal(clean[2], dirty[2])
 
 
 @pytest.mark.parametrize("kind", ["niw8", "niw64", "niw128", "mult200"])
