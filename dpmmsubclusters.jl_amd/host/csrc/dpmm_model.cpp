@@ -428,6 +428,9 @@ struct dpmmh_model {
             if (noise_A.size() < (size_t)rows * D) { noise_A.resize((size_t)rows * D); noise_xi.resize((size_t)rows * D); }   // first-trial normals / uniforms
         }
         noise_epoch = draw_epoch + 1; noise_rows = niw_dev ? 0 : rows;
+        // nothing to generate and nobody to wake (the device-master path): no helper job at all -- the next step would otherwise wait for
+        // the helper thread to have RUN its empty job, and one late wake-up of that thread was a 2.7 ms stall of a 2 ms step
+        if (niw_dev && pre_at <= 0.0) return;
         const int nt = nthreads;
         helper.submit([this, rows, DD, nt, niw_noise, niw_dev, pre_at] {
             if (!niw_dev) Pool::get().run(rows, nt, [&](int i, int) {
