@@ -30,7 +30,8 @@ using namespace dpmm;
 #ifdef DPMM_POISON
 // Diagnostic build (scripts/build_variant.sh poison -DDPMM_POISON=0xFF): every device allocation of this file is filled with the poison byte
 // before anybody uses it -- a kernel that reads memory nobody wrote then reads NaNs / -1 on EVERY box, not only on one whose memory holds
-// another process's leftovers (how a one-in-twenty chain divergence on fresh boxes was tracked down).
+// another process's leftovers.  (Built while a one-in-twenty chain divergence on fresh boxes was tracked down: it ruled device MEMORY out;
+// the cause was a never-written LDS word, found with tests/tools/poison.py -- DESIGN section 5.)
 template <typename T>
 static hipError_t hipMallocPoisoned(T **p, size_t n) {
     hipError_t e = hipMalloc(p, n);
