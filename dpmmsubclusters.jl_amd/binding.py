@@ -1,4 +1,4 @@
-"""ctypes binding of include/dpmm_hip.h.  No fallback: if libdpmmhip.so is missing or no
+"""ctypes binding of include/dpmm_hip.h and its companions dpmm_hip_master.h / dpmm_hip_debug.h.  No fallback: if libdpmmhip.so is missing or no
 gfx950 device is usable, construction raises -- nothing here computes on the CPU."""
 import ctypes
 import os
@@ -14,7 +14,7 @@ _c_i64p = ctypes.POINTER(ctypes.c_int64)
 _c_f32p = ctypes.POINTER(ctypes.c_float)
 _c_f64p = ctypes.POINTER(ctypes.c_double)
 
-# every symbol include/dpmm_hip.h declares: (name, restype, argtypes)
+# every symbol the three worker headers declare: (name, restype, argtypes)
 ABI = [
     ("dpmm_abi_version", ctypes.c_int, []),
     ("dpmm_create", ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_uint64]),
@@ -82,6 +82,7 @@ ABI = [
     ("dpmm_suffstats_host", ctypes.c_int, [ctypes.c_void_p, _c_i64p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     ("dpmm_step_stats", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]),
     ("dpmm_debug_subloglik", ctypes.c_int, [ctypes.c_void_p, _c_f32p]),
+    ("dpmm_debug_ref_bracket", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, _c_f32p, _c_f32p]),
     ("dpmm_last_sweep_work", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]),
     ("dpmm_comm_use_library", ctypes.c_int, [ctypes.c_char_p]),
     ("dpmm_comm_unique_id", ctypes.c_int, [ctypes.c_void_p]),
@@ -591,6 +592,12 @@ class Worker:
         out = np.empty((2 * self.K, self.n), np.float32)
         self._chk(self._lib.dpmm_debug_subloglik(self._h, _p(out, _c_f32p)))
         return out
+
+    def debug_ref_bracket(self, cluster, c_override=0.0):
+        """(q_hi, q): per point, the reference bracket's upper end and the Float32 quadratic form of `cluster` (1-based); include/dpmm_hip_debug.h."""
+        qhi = np.empty(self.n, np.float32); q = np.empty(self.n, np.float32)
+        self._chk(self._lib.dpmm_debug_ref_bracket(self._h, int(cluster), ctypes.c_float(c_override), _p(qhi, _c_f32p), _p(q, _c_f32p)))
+        return qhi, q
 
     def debug_loglik(self):
         out = np.empty((self.K, self.n), np.float32)

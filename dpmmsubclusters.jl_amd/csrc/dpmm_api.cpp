@@ -1,9 +1,11 @@
-// dpmm_api.cpp -- C ABI of libdpmmhip.so (see include/dpmm_hip.h for the contract and the
+// dpmm_api.cpp -- C ABI of libdpmmhip.so (see include/dpmm_hip.h -- and its companions dpmm_hip_master.h, dpmm_hip_debug.h -- for the contract and the
 // reference functions each entry point replaces).  Host-side glue only: device memory
 // ownership, parameter staging, kernel sequencing on ONE stream, error mapping.
 // There is no CPU fallback anywhere in this file: without a usable gfx950 device
 // dpmm_create fails with DPMM_ENODEVICE.
 #include "../../include/dpmm_hip.h"
+#include "../../include/dpmm_hip_master.h"
+#include "../../include/dpmm_hip_debug.h"
 
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
@@ -541,6 +543,9 @@ static int finish_upload(dpmm_ctx *c) {
         }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    // new points: the cached cluster-level statistics (derive_rows_kernel) and the rows a device master would draw from belong to the old ones
+    c->cache_force = true;
+    c->rows_full_K = -1;
     return DPMM_OK;
 }
 
@@ -560,7 +565,8 @@ static int upload_common(dpmm_ctx *c, const float *X, int64_t ldx, hipMemcpyKind
         if (int rc = finish_upload(c)) return rc;
     }
     c->have_points = true;
-    c->cache_force = true;          // the cached cluster-level statistics belong to the old points
+    c->cache_force = true;          // (also for n == 0; finish_upload does it for every path that moved points)
+    c->rows_full_K = -1;
     return DPMM_OK;
 }
 
@@ -592,6 +598,8 @@ int dpmm_upload_points_npy(dpmm_ctx *c, const void *rows, int is_f64, int64_t ld
         if (int rc2 = finish_upload(c)) return rc2;
     }
     c->have_points = true;
+    c->cache_force = true;
+    c->rows_full_K = -1;
     return DPMM_OK;
 }
 
@@ -2332,6 +2340,29 @@ int dpmm_debug_subloglik(dpmm_ctx *c, float *out) {
     hipFree(tRp); hipFree(tmu); hipFree(tcst); hipFree(table); hipFree(traw); hipFree(tL16);
     if (e != hipSuccess) { c->err = std::string("dpmm_debug_subloglik: ") + hipGetErrorString(e); return DPMM_EHIP; }
     return rc;
+}
+
+// Diagnostic for the reference bracket of the D <= 64 sweep (niw_sweep.hip, ref_bracket): q_hi[i] = the bracket's certified upper end of
+// q_k(x_i) = |R_k (x_i - mu_k)|^2 for the cluster-level factor of `cluster` (1-based) and q[i] = the Float32 evaluation the sweep would
+// make in its place -- same device functions and operand images as the sweep.  c_override > 0 replaces the library's rounding constant.
+int dpmm_debug_ref_bracket(dpmm_ctx *c, int64_t cluster, float c_override, float *q_hi, float *q) {
+    if (!c || !q_hi || !q) return DPMM_EINVAL;
+    if (c->prior != DPMM_PRIOR_NIW || c->NB != 4) return fail(c, DPMM_ESTATE, "the reference bracket exists for the NIW prior with D in 33..64 only");
+    if (!c->have_points || !c->have_params || c->predictive || !c->have_tail) return fail(c, DPMM_ESTATE, "debug_ref_bracket needs points and sweep parameters with tail records (D % 4 == 0, K > 2)");
+    if (cluster < 1 || cluster > c->K) return fail(c, DPMM_EINVAL, "cluster index out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n == 0) return DPMM_OK;
+    float *d = nullptr;
+    HIPCHK(c, hipMalloc(&d, sizeof(float) * 2 * (size_t)c->n));
+    NiwSweepArgs a{};
+    a.X = c->dX; a.ldx = c->ldx; a.n = c->n; a.K = c->K; a.Rp = c->d_Rp; a.mup = c->d_mup; a.tail = c->d_tail;
+    hipError_t e = launch_niw_refb_debug(a, (int)cluster - 1, c_override, d, d + c->n, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(q_hi, d, sizeof(float) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(q, d + c->n, sizeof(float) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    if (e != hipSuccess) { c->err = std::string("dpmm_debug_ref_bracket: ") + hipGetErrorString(e); return DPMM_EHIP; }
+    return DPMM_OK;
 }
 
 int dpmm_last_kernel_ms(dpmm_ctx *c, float *sweep_ms, float *stats_ms) {

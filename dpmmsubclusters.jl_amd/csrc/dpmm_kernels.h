@@ -58,6 +58,7 @@ struct NiwSweepArgs {
 int niw_tile_points(int NB);
 int niw_occupancy(int NB);  // resident 256-thread workgroups per CU the sweep kernel is built for
 hipError_t launch_niw_sweep(int NB, const NiwSweepArgs &a, int grid, hipStream_t s);
+hipError_t launch_niw_refb_debug(const NiwSweepArgs &a, int k, float c_override, float *qhi_out, float *q_out, hipStream_t s);   // needs X, ldx, n, K, Rp, mup, tail
 hipError_t launch_niw_screen_prep(const float *R, const float *mu, int D, int K, float *lam, float *dist, const int32_t *slot, hipStream_t s);
 hipError_t launch_niw_pack(const float *R, const float *mu, float *Rp, float *mup, int D, int NB, int nmat, float *tail, const float *cst,
                            const int32_t *slot, float *cst_out, unsigned long long *work, hipStream_t s);

@@ -197,15 +197,28 @@ __device__ __forceinline__ unsigned long long ball_far(const float *tail, int K,
 // Reference BRACKET (D in 49 .. 64).  On a wave whose points all carried label k0 the cluster-level value a_k0(x) = cst - q(x) / 2,
 // q = |R (x - mu)|^2, usually decides nothing: every other cluster is excluded by the screens and the draw returns k0 whatever the value
 // is.  The screens only need a LOWER bound of it.  Two bf16 matrix passes give a certified one at ~1/7 of the Float32 evaluation's cycles:
-//   y^ = R~ z~ (R~, z~ = bf16 roundings of R and z = x - mu; bf16 products are exact in the Float32 accumulator),  e^ = |R~| |z~|,
-//   |y_i - y^_i| <= |R - R~||z| + |R~||z - z~| + accumulation <= (2^-8 (1 + 2^-7) + 64 * 2^-24) e_i  <=  REFB_C e^_i,
-//   q <= sum_i (|y^_i| + REFB_C e^_i)^2 =: q_hi   (the lane's four rows per block, then the ones-MFMA sum over the four row groups).
-// On the bench's clusters (condition number 35 000) q_hi - q is ~7 (median) of q ~ 64: the thresholds move by a few nats of a 50-nat
-// margin.  A non-finite x or parameter makes q_hi non-finite, every screen comparison false, and the wave takes the Float32 path.
+//   y^ = R~ z~ (R~, z~ = bf16 round-to-nearest-even of R and of the Float32 z = x - mu; bf16 products are exact in the Float32
+//   accumulator),  e^ = |R~| |z~|.
+// bf16 carries 8 significand bits: ONE rounding has unit round-off u = 2^-8, |R - R~| <= u |R~| and |z - z~| <= u |z~| (half an ulp of
+// the operand's binade, and the rounded value is never below that binade's base).  BOTH operands are rounded:
+//   |y_i - y^_i| <= sum_j |R - R~||z| + |R~||z - z~| <= sum_j u |R~| (1 + u) |z~| + u |R~||z~| = (2u + u^2) e^_i = 0.0078278 e^_i
+// (worst case R = z = 1 + 2^-8 -> R~ = z~ = 1: y - y^ = 0.0078278).  Float32 accumulation of the 64 exact products in y^ and e^ and the
+// rounding of the Float32 evaluation this bracket stands in for (another summation order of the same 64 terms, |R||z| <= (1 + u)^2
+// e^) add 3 * 64 * 2^-24 = 1.2e-5:
+//   |y_i (as the Float32 evaluation computes it)| <= |y^_i| + REFB_C e^_i,   REFB_C = 0.00785 > 0.0078278 + 0.0000115,
+//   q <= sum_i (|y^_i| + REFB_C e^_i)^2 (1 + 1e-4) =: q_hi   (the lane's four rows per block, then the ones-MFMA sum over the four row
+// groups; the factor covers the ~30 Float32 roundings of the two sums of squares).  Subnormal z that the conversion may flush are an
+// absolute error of 2^-126 |R~| per term -- nothing next to the 1e-20 added at the end for any factor the Float32 evaluation itself can
+// handle.  Checked per point on adversarial operands (every entry just below a bf16 midpoint, displaced trailing features, far
+// outliers) by tests/test_gpu_niw.py::test_reference_bracket_is_an_upper_bound through dpmm_debug_ref_bracket.
+// (Round 3 shipped REFB_C = 0.00395 = u (1 + 2u) + ..., i.e. ONE rounding of half the size: q_hi < q on exactly those operands.  It changed
+// no label -- the screens' 50-nat margin has ~32 nats of slack -- but it was not a bound.)
+// On the bench's clusters (condition number 35 000) q_hi - q is ~14 of q ~ 64: the thresholds move by a few nats of a 50-nat margin.
+// A non-finite x or parameter makes q_hi non-finite, every screen comparison false, and the wave takes the Float32 path.
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef short bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-constexpr float REFB_C = 0.00395f;
+constexpr float REFB_C = 0.00785f;
 __host__ __device__ __forceinline__ const uint32_t *refb_records(const float *tail, int K) {
     return reinterpret_cast<const uint32_t *>(ball_records(tail, K) + 16 * (size_t)K);
 }
@@ -215,7 +228,8 @@ __device__ __forceinline__ uint32_t pack_bf16_pair(float a, float b) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));      // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
 }
 template <int NG>
-__device__ __forceinline__ void ref_bracket(const uint32_t *__restrict__ Rb, const f32x4 (&x)[NG][4], const f32x4 (&mu)[4], int lane, float (&qhi)[NG]) {
+__device__ __forceinline__ void ref_bracket(const uint32_t *__restrict__ Rb, const f32x4 (&x)[NG][4], const f32x4 (&mu)[4], int lane, float (&qhi)[NG],
+                                            const float refb_c = REFB_C) {
     static_assert(NG % 2 == 0, "point groups are taken two at a time");
     const u32x4_t *F = reinterpret_cast<const u32x4_t *>(Rb) + lane;          // fragment f of this lane: F[64 f]
     const u32x4_t absm = (u32x4_t){0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu};
@@ -256,7 +270,7 @@ __device__ __forceinline__ void ref_bracket(const uint32_t *__restrict__ Rb, con
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float t = __builtin_fmaf(REFB_C, e[h][r], fabsf(y[h][r]));
+                    const float t = __builtin_fmaf(refb_c, e[h][r], fabsf(y[h][r]));
                     part[h] = __builtin_fmaf(t, t, part[h]);
                 }
         }
@@ -1642,6 +1656,46 @@ hipError_t launch_niw_sweep(int NB, const NiwSweepArgs &a, int grid, hipStream_t
         case 16: return launch_cfg<16, 2, 1>(a, grid, s);
         default: return hipErrorInvalidValue;
     }
+}
+
+// Diagnostic (dpmm_debug_ref_bracket): for every point of the shard, the bracket's upper end q_hi and the Float32 quadratic form q of
+// cluster k's cluster-level factor -- the SAME device functions (ref_bracket, quad_stream), operand images and register layout as the
+// sweep kernel, storage order, one wave per 64 points.  `c_override` > 0 replaces REFB_C (a test shows that round 3's constant fails).
+__global__ __launch_bounds__(256) void niw_refb_debug_kernel(const float *__restrict__ X, int64_t ldx, int64_t n, const float *__restrict__ Rm,
+                                                             const float *__restrict__ mup, const uint32_t *__restrict__ Rb, float c_override,
+                                                             float *__restrict__ qhi_out, float *__restrict__ q_out) {
+    constexpr int NB = 4, NG = 4;
+    const int lane = threadIdx.x & 63, ci = lane & 15, g = lane >> 4;
+    const int64_t wbase = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    if (wbase >= n) return;
+    f32x4 x[NG][NB];
+#pragma unroll
+    for (int nn = 0; nn < NG; ++nn) {
+        const int64_t p = wbase + 16 * nn + ci;
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+            const int e = 16 * t + 4 * g;
+            x[nn][t] = (p < n && e < ldx) ? *reinterpret_cast<const f32x4 *>(X + p * ldx + e) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    f32x4 rb0[NB], mu[NB];
+    load_rb0<NB>(Rm, mup, rb0, mu, lane, g);
+    float qhi[NG], tot_all[NG];
+    ref_bracket<NG>(Rb, x, mu, lane, qhi, c_override > 0.f ? c_override : REFB_C);
+    quad_stream<NB, NG>(Rm, nullptr, mup, rb0, mu, x, lane, g, true, tot_all, 0);
+#pragma unroll
+    for (int nn = 0; nn < NG; ++nn) {
+        const int64_t p = wbase + 16 * nn + ci;
+        if (g == nn && p < n) { qhi_out[p] = qhi[nn]; q_out[p] = tot_all[nn]; }
+    }
+}
+hipError_t launch_niw_refb_debug(const NiwSweepArgs &a, int k, float c_override, float *qhi_out, float *q_out, hipStream_t s) {
+    constexpr int NP = 10, MATSZ = NP * 256, DP = 64;
+    const unsigned grid = (unsigned)((a.n + 255) / 256);
+    if (grid == 0) return hipSuccess;
+    DPMM_LAUNCH(niw_refb_debug_kernel, dim3(grid), dim3(256), 0, s, a.X, a.ldx, a.n, a.Rp + (size_t)(3 * k) * MATSZ, a.mup + (size_t)(3 * k) * DP,
+                refb_records(a.tail, a.K) + (size_t)k * REFB_WORDS, c_override, qhi_out, q_out);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------

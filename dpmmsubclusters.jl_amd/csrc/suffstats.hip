@@ -44,9 +44,12 @@ __global__ __launch_bounds__(64) void hist_kernel(const int32_t *__restrict__ bi
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
     auto track = [&](int64_t i, int bv) {            // rare: a point whose label is not the one it had at the previous pass
-        const unsigned z = (unsigned)bv >> 1, p = prev_lab[i];
-        if ((unsigned)bv < (unsigned)nbins && z != p) {
-            dirty[z] = 1;
+        // (a label outside [0, K) -- perm_total != n acknowledges that they can occur -- still LEAVES the cluster the point was in: that
+        // cluster's cached row is stale whether or not the new bin is counted)
+        const bool inr = (unsigned)bv < (unsigned)nbins;
+        const unsigned z = inr ? (unsigned)bv >> 1 : 0xFFFFu, p = prev_lab[i];
+        if (z != p) {
+            if (inr) dirty[z] = 1;
             if (p < DPMM_MAX_CLUSTERS_K) dirty[p] = 1;
             prev_lab[i] = (uint16_t)z;
         }

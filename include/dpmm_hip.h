@@ -36,7 +36,6 @@ extern "C" {
 #endif
 
 #define DPMM_ABI_VERSION 2
-#define DPMM_MASTER_NSCALARS 8   /* doubles per distribution in the device master's scalar records (dpmm_niw_master_posterior / _pairs, dpmm_step_master_device) */
 
 typedef struct dpmm_ctx dpmm_ctx;
 
@@ -220,15 +219,6 @@ int dpmm_merge(dpmm_ctx *ctx, const int64_t *idx, const int64_t *new_idx, int n)
 int dpmm_remove_empty(dpmm_ctx *ctx, const int64_t *pts_count, int K);
 int dpmm_reset_sublabels(dpmm_ctx *ctx, const int64_t *idx, int n, uint32_t epoch);
 
-/* Diagnostics / parity: run the label phase of the last-set parameters and return the
- * Float32 table parr[k][i] = loglik_k(x_i) + log w_k WITHOUT the reference's constant
- * -D*D/2*log(2 pi) normaliser term (mv_gaussian.jl:24; identical for every cluster, so it
- * never affects a draw; add it back to compare with reference values).  out: [K][n_local]. */
-int dpmm_debug_loglik(dpmm_ctx *ctx, float *out);
-/* Same for the sub-label phase: out [2K][n_local], row 2k+s = loglik of every point under sub-cluster s of cluster k +
- * log lr_weights[k][s] -- for a point labelled k rows 2k, 2k+1 are exactly the two values create_subclusters_labels!
- * (local_clusters_actions.jl:83-95) draws from (same arithmetic as dpmm_sweep's sub-label phase). */
-int dpmm_debug_subloglik(dpmm_ctx *ctx, float *out);
 
 /* Prediction for the points held by the ctx (next row of the scope table: predict / predict_points,
  * src/dp-parallel-sampling.jl:532-537, src/local_clusters_actions.jl:23-40, with posterior_predictive!
@@ -282,25 +272,6 @@ int dpmm_sync(dpmm_ctx *ctx);
 /* The HIP stream (hipStream_t) all work of this ctx is queued on, for callers that
  * want to time with HIP events or order other work against it. */
 void *dpmm_stream(dpmm_ctx *ctx);
-/* Milliseconds spent in the dominant kernels during the last dpmm_sweep /
- * dpmm_suffstats_* call, measured with HIP events on the ctx stream (0 if none yet, or when DPMM_OPT_KERNEL_TIMING is off -- the default).
- * Calling this waits for the measured kernels (the closing event of each pair), not for later work on the stream. */
-int dpmm_last_kernel_ms(dpmm_ctx *ctx, float *sweep_ms, float *suffstats_ms);
-/* Health counters of this ctx since creation (n >= 1 entries written, the rest 0):
- *   out[0] = dpmm_step_master_device calls whose event wait returned before the posteriors' records had reached host memory (the call
- *            then waits them out; a non-zero count is a runtime / driver anomaly worth reporting, the results are unaffected). */
-int dpmm_debug_counters(dpmm_ctx *ctx, int64_t *out, int n);
-/* Test hook, process-wide: fn(arg) is called on the host in front of every kernel launch of the library (fn == NULL: off, the default).
- * tests/tools/poison.py uses it to refill LDS and the register files with a NaN pattern between the library's own kernels
- * (tests/test_gpu_uninit.py); fn may synchronise the device and launch kernels of its own on other streams. */
-int dpmm_debug_set_prelaunch_hook(void (*fn)(void *), void *arg);
-/* Work the dpmm_sweep calls (NIW) since the previous call really executed, counted on the device (a slot per wave, no atomics):
- *   TOTALS over out8[7] launches of: out8[0] wave tiles, [1] full quadratic-form evaluations (per wave), [2] 16-row MFMA screens
- *   (per wave), [3] tail-screened cluster pairs (per wave); [4] matrix instructions per full evaluation, [5] per 16-row screen,
- *   [6] flops per matrix instruction (v_mfma_f32_16x16x4_f32: 2048).  Executed flops of those launches =
- *   (out8[1]*out8[4] + out8[2]*out8[5]) * out8[6].  The counters are cleared; calling this synchronises the stream (a benchmark
- *   calls it once after its timed loop, not once per step). */
-int dpmm_last_sweep_work(dpmm_ctx *ctx, uint64_t *out8);
 
 /* The one exchange of the sweep, inside the library: RCCL all-reduce(sum) of the packed statistics (and of the Int64
  * sub-cluster occupancies) on the ctx stream.  Replaces create_suff_stats_dict_node_leader / update_suff_stats_posterior!'s
@@ -318,74 +289,6 @@ int dpmm_last_sweep_work(dpmm_ctx *ctx, uint64_t *out8);
  * last packed-row all-reduce, all-reduces since the attachment, 0, 0}.  dpmm_last_comm_ms: HIP-event time of the last all-reduce of each
  * kind on the ctx stream (0 if none; synchronises the stream). */
 typedef int (*dpmm_host_allreduce_fn)(void *user, void *buf, int64_t count, int is_f64);
-/* ---- the master's dense maths on the device (NIW prior; optional fast path for a master that otherwise works on the host) ----
- * The 3K posteriors, their factorisations and the parameter draws of a sweep are O(K D^3) and need the full packed rows: at
- * D = 256 that is 2-3 ms of host time and 30 MB over the host link per sweep.  With these calls the rows stay in HBM:
- *   dpmm_niw_master_setup       prior (kappa, nu, m [D], psi [D][D] row-major) -> device; enables the calls below
- *   dpmm_step_stats_device      dpmm_step_stats without the copy of the rows (*bad: [K] flags, pinned)
- *   dpmm_step_master_device     dpmm_step_stats_device + dpmm_niw_master_posterior for all K clusters (slots [K]) in one stream-ordered
- *                               sequence with ONE host wait.  draw_epoch != 0: the draws of dpmm_niw_master_draw(draw_epoch, K, slots, ...)
- *                               are launched as well, on a second stream, and the call returns when the POSTERIORS are done: the draws
- *                               need neither the weights nor the master's decisions and run while the host works.  The draw call uses
- *                               them if its epoch and slot map are the ones given here and no posterior changed in between (else it
- *                               draws again; results are the same either way -- the streams are keyed by epoch and position)
- *   dpmm_suffstats_device       dpmm_suffstats_host without the copy (rows of the listed clusters, 1-based; NULL = all)
- *   dpmm_niw_master_posterior   calc_posterior (src/priors/niw.jl:20-31) + factorisation nu' psi' = L' L for the listed clusters
- *                               (1-based) of the LAST statistics pass, stored under their slots (rows 3 slot + {0: cluster, 1: left,
- *                               2: right}); *small: pinned [n][3][DPMM_MASTER_NSCALARS] = {N, kappa', nu', log det(nu' psi') (NaN: not positive
- *                               definite), log Gamma_D(nu' / 2) (utils.jl:66-72: the D lgamma evaluations of a log-marginal), 3 spare}
- *   dpmm_niw_master_draw        sample_distribution (niw.jl:33-40) for all 3K distributions + the hand-over to the sweep kernels
- *                               (replaces dpmm_params_staging / dpmm_commit_params for this sweep): Sigma^-1 = R'R ~ Wishart(nu',
- *                               (nu' psi')^-1), mu ~ N(m', Sigma / kappa'); lr [K][2], w [K] as in dpmm_params_staging.  The random
- *                               streams are the library's own (Philox, keyed by seed, position in cluster order, epoch).
- *   dpmm_niw_master_pairs       pooled statistics of n slot pairs (check_and_merge!'s proposals, shared_actions.jl:21-27) -> *small: pinned
- *                               [n][DPMM_MASTER_NSCALARS], same record, of the pooled posterior under the cluster prior
- *   dpmm_niw_master_pairs_ahead the pairs the master MAY ask for after the next dpmm_step_master_device (all pairs of clusters whose merge
- *                               gate is open): that call computes them with the posteriors (same launch at D <= 128, second stream above) and
- *                               dpmm_niw_master_pairs answers from them (subset, any order) unless a slot got new statistics in between
- *   dpmm_niw_master_put_rows    rows [2K][1 + D + D(D+1)/2] from the host take the place of a statistics pass (restored state)
- *   dpmm_niw_master_rows        the stored statistics rows of the given slots -> out [n][2][1 + D + D(D+1)/2] (host)
- *   dpmm_niw_master_draws       the current draws in cluster order: mu [3K][D], R [3K][D][D] (upper triangular, full), logdet [3K] */
-int dpmm_niw_master_setup(dpmm_ctx *ctx, double kappa, double nu, const double *m, const double *psi);
-int dpmm_step_stats_device(dpmm_ctx *ctx, uint32_t reset_epoch, const uint8_t **bad);
-int dpmm_step_master_device(dpmm_ctx *ctx, uint32_t reset_epoch, const int32_t *slots, uint32_t draw_epoch, const uint8_t **bad, const double **small);
-int dpmm_suffstats_device(dpmm_ctx *ctx, const int64_t *cluster_idx, int n_idx);
-int dpmm_niw_master_posterior(dpmm_ctx *ctx, const int64_t *clusters, const int32_t *slots, int n, const double **small);
-int dpmm_niw_master_draw(dpmm_ctx *ctx, uint32_t epoch, int K, const int32_t *slot_of_cluster, const float *lr, const float *w);
-int dpmm_niw_master_pairs_ahead(dpmm_ctx *ctx, const int32_t *slots_i, const int32_t *slots_j, int n);
-int dpmm_niw_master_pairs(dpmm_ctx *ctx, const int32_t *slots_i, const int32_t *slots_j, int n, const double **small);
-int dpmm_niw_master_put_rows(dpmm_ctx *ctx, const double *rows, int K);
-int dpmm_niw_master_rows(dpmm_ctx *ctx, const int32_t *slots, int n, double *out);
-int dpmm_niw_master_draws(dpmm_ctx *ctx, int K, float *mu, float *R, float *logdet);
-/* Diagnostic: the random inputs dpmm_niw_master_draw consumes for `epoch` and this cluster -> slot map, in cluster order: the Bartlett
- * factors A [3K][D][D] (lower triangular: chi_{nu' - r} on the diagonal, r = 0 .. D-1, standard normals below; Distributions.jl's
- * Wishart sampler behind niw.jl:35) and the mean normals xi [3K][D].  The draw is the deterministic function
- * R' = L^-1 A (nu' psi' = L'L, L lower), mu = m' + R^-1 xi / sqrt(kappa') of them: tests recompute it in Float64. */
-int dpmm_debug_niw_draw_inputs(dpmm_ctx *ctx, uint32_t epoch, int K, const int32_t *slot_of_cluster, double *A, double *xi);
-
-/* ---- the Multinomial master's parameter draws on the device (optional, like the NIW group above) ----
- *   dpmm_mult_master_setup     prior alpha [D] (and the outlier component's prior, or NULL) -> device; enables the calls below
- *   dpmm_mult_master_draw      calc_posterior + sample_distribution (src/priors/multinomial_prior.jl:16-25) for all 3K distributions from the
- *                              rows the LAST full / per-step statistics pass left on the device (K must be that pass's K): alpha' = alpha +
- *                              Float32(sum x), log p = log Dirichlet(alpha') by Gamma variates (Philox keyed by seed, position in cluster
- *                              order, epoch), then the hand-over to the sweep kernels (replaces dpmm_params_staging / dpmm_commit_params for
- *                              this sweep); outlier_first: cluster 1 uses the outlier prior; lr [K][2], w [K] as in dpmm_params_staging
- *   dpmm_mult_master_draws     the current draws, log-probabilities [3K][D] (host)
- *   dpmm_mult_master_put_rows  rows [2K][1 + D] from the host take the place of a statistics pass (restored state) */
-int dpmm_mult_master_setup(dpmm_ctx *ctx, const float *alpha, const float *alpha_outlier);
-int dpmm_mult_master_draw(dpmm_ctx *ctx, uint32_t epoch, int K, int outlier_first, const float *lr, const float *w);
-int dpmm_mult_master_draws(dpmm_ctx *ctx, int K, float *logp);
-int dpmm_mult_master_put_rows(dpmm_ctx *ctx, const double *rows, int K);
-/* The Multinomial master's log-marginals on the device (multinomial_prior.jl:34-39; check_and_merge!'s pooled statistics, LCA:385-413).
- * dpmm_mult_master_pairs_ahead: cluster pairs (0-based indices of the NEXT per-step pass) whose pooled log-marginal the master may ask for
- *   after that pass; the next dpmm_step_stats launches ONE kernel behind its statistics -- the 3K distributions of the pass + these pairs --
- *   and waits for it together with the rows.  n = 0 asks for the distributions only; more than 8192 pairs: none are computed.
- * dpmm_mult_master_marginals: rows_nl -> [3K][2] {N, log-marginal} (cluster, left, right per cluster), pairs_l -> [npairs] in the order they were
- *   asked for; pointers into a pinned block, valid until the next call that runs a statistics pass.  Without a pass-attached result for
- *   this K it computes now from the rows of the last full pass (dpmm_mult_master_put_rows counts as one) and waits; DPMM_ESTATE when those
- *   rows are not there (subset pass, split / merge / removal since). */
-int dpmm_mult_master_pairs_ahead(dpmm_ctx *ctx, int outlier_first, const int32_t *ki, const int32_t *kj, int n);
-int dpmm_mult_master_marginals(dpmm_ctx *ctx, int K, const double **rows_nl, const double **pairs_l, int *npairs);
 
 /* RCCL is bound at run time (dlopen): a copy already mapped into the process wins, then the soname, then /opt/rocm/lib.
  * dpmm_comm_use_library names the file to use instead (before the first dpmm_comm_* call) -- a host that also runs
@@ -395,7 +298,6 @@ int dpmm_comm_unique_id(void *out128);
 int dpmm_comm_init(dpmm_ctx *ctx, const void *unique_id128, int rank, int world);
 int dpmm_comm_init_host(dpmm_ctx *ctx, int rank, int world, dpmm_host_allreduce_fn fn, void *user);
 int dpmm_comm_info(dpmm_ctx *ctx, int64_t *out8);
-int dpmm_last_comm_ms(dpmm_ctx *ctx, float *counts_ms, float *rows_ms);
 int dpmm_comm_destroy(dpmm_ctx *ctx);
 int dpmm_comm_allgather_host(dpmm_ctx *ctx, const void *mine, int64_t bytes, void *all);
 

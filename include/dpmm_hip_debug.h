@@ -1,0 +1,64 @@
+/*
+ * dpmm_hip_debug.h -- optional companion of dpmm_hip.h: diagnostics, timers and test hooks of libdpmmhip.so.
+ * Nothing here is on the sweep's path; tests/ and bench.py are the callers.
+ */
+#ifndef DPMM_HIP_DEBUG_H
+#define DPMM_HIP_DEBUG_H
+
+#include "dpmm_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Diagnostics / parity: run the label phase of the last-set parameters and return the
+ * Float32 table parr[k][i] = loglik_k(x_i) + log w_k WITHOUT the reference's constant
+ * -D*D/2*log(2 pi) normaliser term (mv_gaussian.jl:24; identical for every cluster, so it
+ * never affects a draw; add it back to compare with reference values).  out: [K][n_local]. */
+int dpmm_debug_loglik(dpmm_ctx *ctx, float *out);
+/* Same for the sub-label phase: out [2K][n_local], row 2k+s = loglik of every point under sub-cluster s of cluster k +
+ * log lr_weights[k][s] -- for a point labelled k rows 2k, 2k+1 are exactly the two values create_subclusters_labels!
+ * (local_clusters_actions.jl:83-95) draws from (same arithmetic as dpmm_sweep's sub-label phase). */
+int dpmm_debug_subloglik(dpmm_ctx *ctx, float *out);
+
+/* Diagnostic: the random inputs dpmm_niw_master_draw consumes for `epoch` and this cluster -> slot map, in cluster order: the Bartlett
+ * factors A [3K][D][D] (lower triangular: chi_{nu' - r} on the diagonal, r = 0 .. D-1, standard normals below; Distributions.jl's
+ * Wishart sampler behind niw.jl:35) and the mean normals xi [3K][D].  The draw is the deterministic function
+ * R' = L^-1 A (nu' psi' = L'L, L lower), mu = m' + R^-1 xi / sqrt(kappa') of them: tests recompute it in Float64. */
+int dpmm_debug_niw_draw_inputs(dpmm_ctx *ctx, uint32_t epoch, int K, const int32_t *slot_of_cluster, double *A, double *xi);
+
+/* Reference bracket of the D <= 64 NIW sweep (DPMM_OPT_REF_BRACKET; csrc/niw_sweep.hip ref_bracket): for every point of the shard,
+ * q_hi[i] = the bracket's certified upper end of q(x_i) = |R (x_i - mu)|^2 for the cluster-level factor of `cluster` (1-based), computed by
+ * the two bf16 matrix passes the sweep uses, and q[i] = the Float32 evaluation it stands in for (sample_labels_worker!'s
+ * log_likelihood!, src/local_clusters_actions.jl:112-134, src/distributions/mv_gaussian.jl:21-25).  The sweep's exactness argument is
+ * q_hi[i] >= q[i] for every point; c_override > 0 replaces the library's rounding constant (tests show a too-small one failing).
+ * NIW with D in 33..64, D % 4 == 0 and K > 2 only (DPMM_ESTATE otherwise). */
+int dpmm_debug_ref_bracket(dpmm_ctx *ctx, int64_t cluster, float c_override, float *q_hi, float *q);
+
+/* Milliseconds spent in the dominant kernels during the last dpmm_sweep /
+ * dpmm_suffstats_* call, measured with HIP events on the ctx stream (0 if none yet, or when DPMM_OPT_KERNEL_TIMING is off -- the default).
+ * Calling this waits for the measured kernels (the closing event of each pair), not for later work on the stream. */
+int dpmm_last_kernel_ms(dpmm_ctx *ctx, float *sweep_ms, float *suffstats_ms);
+/* Work the dpmm_sweep calls (NIW) since the previous call really executed, counted on the device (a slot per wave, no atomics):
+ *   TOTALS over out8[7] launches of: out8[0] wave tiles, [1] full quadratic-form evaluations (per wave), [2] 16-row MFMA screens
+ *   (per wave), [3] tail-screened cluster pairs (per wave); [4] matrix instructions per full evaluation, [5] per 16-row screen,
+ *   [6] flops per matrix instruction (v_mfma_f32_16x16x4_f32: 2048).  Executed flops of those launches =
+ *   (out8[1]*out8[4] + out8[2]*out8[5]) * out8[6].  The counters are cleared; calling this synchronises the stream (a benchmark
+ *   calls it once after its timed loop, not once per step). */
+int dpmm_last_sweep_work(dpmm_ctx *ctx, uint64_t *out8);
+/* HIP-event time of the last all-reduce of each kind on the ctx stream (0 if none; synchronises the stream); DPMM_OPT_KERNEL_TIMING bit 4. */
+int dpmm_last_comm_ms(dpmm_ctx *ctx, float *counts_ms, float *rows_ms);
+
+/* Health counters of this ctx since creation (n >= 1 entries written, the rest 0):
+ *   out[0] = dpmm_step_master_device calls whose event wait returned before the posteriors' records had reached host memory (the call
+ *            then waits them out; a non-zero count is a runtime / driver anomaly worth reporting, the results are unaffected). */
+int dpmm_debug_counters(dpmm_ctx *ctx, int64_t *out, int n);
+/* Test hook, process-wide: fn(arg) is called on the host in front of every kernel launch of the library (fn == NULL: off, the default).
+ * tests/tools/poison.py uses it to refill LDS and the register files with a NaN pattern between the library's own kernels
+ * (tests/test_gpu_uninit.py); fn may synchronise the device and launch kernels of its own on other streams. */
+int dpmm_debug_set_prelaunch_hook(void (*fn)(void *), void *arg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

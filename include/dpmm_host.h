@@ -76,7 +76,7 @@ typedef struct dpmmh_worker {
     int (*allgather)(void *ctx, const void *mine, int64_t bytes, void *all);
     const char *(*last_error)(void *ctx);                                                         /* dpmm_last_error */
     /* OPTIONAL group (all or none; NULL when the worker has no device master): the dense per-distribution maths of the NIW
-     * master on the worker's device -- see dpmm_niw_master_* / dpmm_step_stats_device / dpmm_suffstats_device in dpmm_hip.h.
+     * master on the worker's device -- see dpmm_niw_master_* / dpmm_step_stats_device / dpmm_suffstats_device in dpmm_hip_master.h.
      * The engine uses it when DPMMH_OPT_DEVICE_MASTER allows (default: D >= 64) and no outlier prior is set; everything it
      * cannot do there (merge proposals, state access, a restored state) falls back to the host path through niw_rows. */
     int (*niw_master_setup)(void *ctx, double kappa, double nu, const double *m, const double *psi);
@@ -90,7 +90,7 @@ typedef struct dpmmh_worker {
     int (*niw_put_rows)(void *ctx, const double *rows, int K);
     int (*niw_rows)(void *ctx, const int32_t *slots, int n, double *out);
     int (*niw_draws)(void *ctx, int K, float *mu, float *R, float *logdet);
-    /* OPTIONAL group (all or none): the Multinomial master's parameter draws on the worker's device -- dpmm_mult_master_* in dpmm_hip.h.
+    /* OPTIONAL group (all or none): the Multinomial master's parameter draws on the worker's device -- dpmm_mult_master_* in dpmm_hip_master.h.
      * Used when DPMMH_OPT_DEVICE_MASTER allows (default: D >= 128) and the worker's last statistics pass holds the current rows of all K
      * clusters (no split, merge or removal since); otherwise the engine draws on the host as before. */
     int (*mult_master_setup)(void *ctx, const float *alpha, const float *alpha_outlier);
@@ -98,7 +98,7 @@ typedef struct dpmmh_worker {
     int (*mult_draws)(void *ctx, int K, float *logp);
     int (*mult_put_rows)(void *ctx, const double *rows, int K);
     /* OPTIONAL pair (with the group above): the Multinomial log-marginals of a pass and of the merge candidates' pooled statistics on the
-     * device -- dpmm_mult_master_pairs_ahead / dpmm_mult_master_marginals in dpmm_hip.h.  The engine asks ahead of step_stats for the pairs
+     * device -- dpmm_mult_master_pairs_ahead / dpmm_mult_master_marginals in dpmm_hip_master.h.  The engine asks ahead of step_stats for the pairs
      * whose gates are open and reads the results behind it; pairs it did not ask for, and steps after a split, are computed on the host. */
     int (*mult_pairs_ahead)(void *ctx, int outlier_first, const int32_t *ki, const int32_t *kj, int n);
     int (*mult_marginals)(void *ctx, int K, const double **rows_nl, const double **pairs_l, int *npairs);

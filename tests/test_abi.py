@@ -1,5 +1,5 @@
 """CPU-side checks of the drop-in boundary: libdpmmhip.so loads, exports every symbol that
-include/dpmm_hip.h declares, and refuses to work without a GPU (no CPU fallback)."""
+include/dpmm_hip.h (+ dpmm_hip_master.h, dpmm_hip_debug.h) declare, and refuses to work without a GPU (no CPU fallback)."""
 import ctypes
 import os
 import re
@@ -16,10 +16,30 @@ def pkg():
     return p
 
 
-def declared_functions():
-    src = open(os.path.join(ROOT, "include", "dpmm_hip.h")).read()
+WORKER_HEADERS = ("dpmm_hip.h", "dpmm_hip_master.h", "dpmm_hip_debug.h")     # drop-in surface | optional device master | diagnostics
+
+
+def declared_in(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(dpmm_[a-z0-9_]+)\s*\(", src)))
+
+
+def declared_functions():
+    return sorted(set(n for h in WORKER_HEADERS for n in declared_in(h)))
+
+
+def test_the_three_worker_headers_partition_the_abi(pkg):
+    """Every exported entry point is declared in exactly one header; the drop-in header carries no device-master and no diagnostic entry."""
+    per = {h: declared_in(h) for h in WORKER_HEADERS}
+    allnames = [n for h in WORKER_HEADERS for n in per[h]]
+    assert len(allnames) == len(set(allnames))
+    assert not [n for n in per["dpmm_hip.h"] if "_master" in n or n.startswith("dpmm_debug_") or n.startswith("dpmm_last_") and n != "dpmm_last_error"]
+    assert all("_master" in n or n in ("dpmm_step_stats_device", "dpmm_suffstats_device") for n in per["dpmm_hip_master.h"])
+    assert len(per["dpmm_hip.h"]) <= 52
+    for h in WORKER_HEADERS:      # each header compiles on its own as C
+        import subprocess
+        subprocess.check_call(["gcc", "-std=c99", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", h)])
 
 
 def test_header_and_binding_agree(pkg):

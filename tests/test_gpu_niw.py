@@ -457,3 +457,116 @@ def test_reference_bracket_does_not_change_labels(pkg, D, sep, K):
     assert f1 <= f0
     if sep >= 40.0:
         assert f1 < 0.8 * f0
+
+
+def _below_bf16_midpoint(rng, shape, lo_exp, hi_exp, worst=0.5):
+    """Float32 values just BELOW a bf16 rounding midpoint: (1 + m / 128 + 1 / 256) 2^e stepped one Float32 ulp towards zero, so that
+    round-to-nearest-even drops 2^-8 / (1 + m / 128) of the value -- the whole unit round-off for m = 0 (a fraction `worst` of the entries)."""
+    m = rng.integers(0, 128, shape)
+    m[rng.random(shape) < worst] = 0
+    e = rng.integers(lo_exp, hi_exp, shape)
+    v = ((1.0 + m / 128.0 + 1.0 / 256.0) * np.exp2(e)).astype(np.float32)
+    return np.nextafter(v, np.float32(0))
+
+
+def _bracket_problem(kind, D, n, seed):
+    """Adversarial operands for the reference bracket: cluster 1 has mu = 0 (z = x exactly) and the upper-triangular factor R[0]."""
+    rng = np.random.default_rng(seed)
+    K = 4
+    R = np.zeros((3 * K, D, D), np.float32)
+    mu = (rng.normal(size=(3 * K, D)) * 30).astype(np.float32)
+    mu[0:3] = 0
+    mu[1, :] = 0.25; mu[2, :] = -0.25
+    if kind == "midpoints":
+        # every entry of R and of x just below a bf16 midpoint, all positive: every product loses (1 + u)^2 - 1, nothing cancels
+        for j in range(3 * K):
+            R[j] = np.triu(_below_bf16_midpoint(rng, (D, D), -6, -3))
+        X = _below_bf16_midpoint(rng, (n, D), -2, 2)
+    elif kind == "trailing":
+        # random factor; points displaced along ONE trailing feature: the last rows of R z have one or two terms, |y^| = e^ there
+        for j in range(3 * K):
+            A = rng.normal(size=(D, D)) * 0.2 + np.eye(D) * (1 + rng.random(D))
+            R[j] = np.triu(A).astype(np.float32)
+        X = (rng.normal(size=(n, D)) * 0.05).astype(np.float32)
+        feat = D - 1 - rng.integers(0, 3, n)
+        X[np.arange(n), feat] = np.sign(rng.normal(size=n)).astype(np.float32) * _below_bf16_midpoint(rng, n, 0, 5)
+        R[0][np.arange(D - 3, D), np.arange(D - 3, D)] = _below_bf16_midpoint(rng, 3, -1, 2)
+    else:  # "outlier": ordinary points plus far ones, q up to ~1e5 and beyond
+        for j in range(3 * K):
+            A = rng.normal(size=(D, D)) * 0.2 + np.eye(D) * (1 + rng.random(D))
+            R[j] = np.triu(A).astype(np.float32)
+        X = rng.normal(size=(n, D)).astype(np.float32)
+        far = rng.random(n) < 0.05
+        X[far] *= np.float32(40.0)
+        X[::97] *= np.float32(1e4)
+    logdet = np.array([-2.0 * np.log(np.abs(np.diag(R[j, :D, :D]).astype(np.float64))).sum() for j in range(3 * K)], np.float32)
+    w = np.full(K, 1.0 / K, np.float32); lr = np.full((K, 2), 0.5, np.float32)
+    return dict(D=D, n=n, K=K, X=X, mu=mu, R=R, logdet=logdet, w=w, lr=lr)
+
+
+@pytest.mark.parametrize("kind,D", [("midpoints", 64), ("midpoints", 52), ("trailing", 64), ("trailing", 60), ("outlier", 64)])
+def test_reference_bracket_is_an_upper_bound(pkg, kind, D):
+    """The exactness argument of the default D <= 64 sweep (sample_labels_worker!, local_clusters_actions.jl:112-134): the bf16 bracket's upper
+    end q_hi must not fall below the Float32 quadratic form q it stands in for -- for EVERY point, on operands chosen against the bound
+    (both bf16 roundings at their full unit round-off 2^-8 and of the same sign; rows of R z with a single term; far outliers).
+    dpmm_debug_ref_bracket runs the sweep's own device functions on the sweep's own operand images.  Round 3's constant (0.00395: one
+    rounding of half the size) FAILS this test on the midpoint operands; the library's (2u + u^2 + accumulation = 0.00785) passes."""
+    n = 6000
+    P = _bracket_problem(kind, D, n, seed=11 + D)
+    wk = pkg.Worker(pkg.PRIOR_NIW, D, n, device=0, seed=3)
+    wk.upload_points(P["X"])
+    wk.set_params_niw_chol(P["mu"], P["R"], P["logdet"], P["lr"], P["w"])
+    qhi, q = wk.debug_ref_bracket(1)
+    z = P["X"].astype(np.float64) - P["mu"][0].astype(np.float64)
+    q64 = ((z @ P["R"][0].astype(np.float64).T) ** 2).sum(axis=1)
+    fin = np.isfinite(q)
+    assert fin.sum() >= 0.9 * n
+    np.testing.assert_allclose(q[fin], q64[fin], rtol=3e-5)                       # the Float32 evaluation itself
+    bad = np.isfinite(qhi) & fin & ((qhi < q) | (qhi < q64))
+    worst = float(np.min((qhi[fin] - q[fin]) / q[fin]))
+    print(f"{kind} D={D}: min (q_hi - q) / q = {worst:.3e}, median {float(np.median((qhi[fin] - q[fin]) / q[fin])):.3e}, "
+          f"q range {q[fin].min():.3g} .. {q[fin].max():.3g}")
+    assert not bad.any(), f"{int(bad.sum())} points with q_hi < q (worst relative deficit {worst:.3e})"
+    assert not np.isfinite(qhi[~fin]).any()                                       # overflow: not finite either -> the sweep takes the Float32 path
+    assert float(np.median((qhi[fin] - q[fin]) / q[fin])) < 0.5                   # ... and still a useful bound (random signs: e^ is several |y^|)
+    if kind == "midpoints":
+        # the same operands against round 3's constant: the bound is violated (this is what "certified" missed)
+        qhi_old, q_old = wk.debug_ref_bracket(1, c_override=0.00395)
+        assert np.array_equal(q_old, q)
+        assert (qhi_old < q).sum() > 0.5 * n
+    wk.close()
+
+
+@pytest.mark.parametrize("kind", ["midpoints", "trailing", "outlier"])
+def test_reference_bracket_labels_on_adversarial_operands(pkg, kind):
+    """Same operands through the sweep itself: labels and sub-labels with the bracket on equal those with it off, bit for bit."""
+    from dpmmsubclusters_jl_amd import binding
+    D, n = 64, 8000
+    P = _bracket_problem(kind, D, n, seed=29)
+    rng = np.random.default_rng(1)
+    # half of the points sit around the other clusters' means so that every cluster has label-homogeneous waves
+    own = rng.integers(0, P["K"], n); own[: n // 2] = 0
+    X = P["X"].copy()
+    X[own > 0] = (P["mu"][3 * own[own > 0]] + rng.normal(size=(int((own > 0).sum()), D)) * 0.3).astype(np.float32)
+    order = np.argsort(own, kind="stable"); X = X[order]; own = own[order]
+    out = {}
+    for br in (1, 0):
+        wk = pkg.Worker(pkg.PRIOR_NIW, D, n, device=0, seed=17)
+        wk.upload_points(X)
+        wk.set_option(binding.OPT_REF_BRACKET, br)
+        wk.set_labels(own + 1, 1 + (np.arange(n) & 1))
+        wk.suffstats_packed(None)
+        wk.set_params_niw_chol(P["mu"], P["R"], P["logdet"], P["lr"], P["w"])
+        wk.last_sweep_work()
+        labs = []
+        for ep in (1, 2):
+            wk.sweep(ep)
+            labs.append(wk.get_labels())
+            wk.suffstats_packed(None)
+            wk.set_params_niw_chol(P["mu"], P["R"], P["logdet"], P["lr"], P["w"])
+        out[br] = (labs, wk.last_sweep_work())
+        wk.close()
+    for a, b in zip(out[1][0], out[0][0]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    print(f"{kind}: full evaluations per wave tile {out[1][1]['full_evals'] / out[1][1]['wave_tiles']:.2f} with the bracket, "
+          f"{out[0][1]['full_evals'] / out[0][1]['wave_tiles']:.2f} without")
