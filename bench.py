@@ -66,6 +66,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-growth", action="store_true")
     ap.add_argument("--no-dense", action="store_true")
+    ap.add_argument("--no-host-master", action="store_true", help="skip the leg with the master's maths on the host")
     ap.add_argument("--no-legs", action="store_true", help="skip the other-shape legs (overlap, c3_shard, c4, c5_shard)")
     ap.add_argument("--legs", default="overlap_var4,overlap_var1,k256,c2,c3_shard,c4,c5_shard", help="comma-separated subset of the legs")
     ap.add_argument("--growth-iters", type=int, default=260)
@@ -75,11 +76,34 @@ def parse_args():
     return ap.parse_args()
 
 
+def visible_gpus():
+    """GPUs this process may use, counted WITHOUT touching HIP (torch.cuda.device_count() falls back to hipGetDeviceCount when amdsmi is
+    missing, which initialises the runtime in a parent that is about to start children): the KFD topology's nodes with SIMDs, narrowed by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES.  None when the topology cannot be read -- the ranks' own world / device checks then decide."""
+    if not os.path.isdir("/sys/class/kfd"):
+        return 0                                 # no amdgpu compute driver on this host at all
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        n = 0
+        for d in os.listdir(base):
+            props = open(os.path.join(base, d, "properties")).read().split("\n")
+            kv = dict(l.split(None, 1) for l in props if " " in l)
+            if int(kv.get("simd_count", "0")) > 0:
+                n += 1
+    except (OSError, ValueError):
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def relaunch_as_ranks(args):
     """--gpus N > 1 without a launcher: start N ranks as a child process (never exec) BEFORE any GPU call and relay its exit code."""
-    import torch
-    ndev = torch.cuda.device_count()          # counting devices does not initialise the GPU
-    if ndev < args.gpus and not args.share_gpu:
+    # (the parent never initialises HIP: the devices are counted from sysfs)
+    ndev = visible_gpus()
+    if ndev is not None and ndev < args.gpus and not args.share_gpu:
         sys.exit(f"bench.py --gpus {args.gpus}: only {ndev} GPU(s) visible on this node (refusing to report a smaller run as n_gpus={args.gpus})")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -116,6 +140,26 @@ def pmc_traffic(which, kernel_substr):
     except (OSError, ValueError, KeyError):
         pass
     return None, None
+
+
+def pmc_matrix_pipe(which, kernel_substr, launch_ms):
+    """What the PMC summary of THIS build says about the kernel's matrix pipe: busy share (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMD-normalised
+    cycles over GRBM_GUI_ACTIVE / 8 XCDs) and the Float32 matrix rate SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 flops / the live launch time --
+    the figure `frac` (device-counted Float32 matrix instructions) has to agree with.  {} when the file is stale or missing."""
+    f = os.path.join(ROOT, "profiles", f"latest_{which}_pmc_summary.json")
+    try:
+        pm = json.load(open(f))
+        if pm.get("_meta", {}).get("kernel_source_tag") != kernel_source_tag():
+            return {}
+        for name, c in pm.items():
+            if kernel_substr in name and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+                busy = (c["SQ_VALU_MFMA_BUSY_CYCLES"]["median"] / 1024.0) / (c["GRBM_GUI_ACTIVE"]["median"] / 8.0)
+                mops = c["SQ_INSTS_VALU_MFMA_MOPS_F32"]["median"]
+                return {"mfma_busy": busy, "pmc_f32_mops_per_launch": mops,
+                        "pmc_frac": mops * 512.0 / (launch_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
+    except (OSError, ValueError, KeyError, ZeroDivisionError):
+        pass
+    return {}
 
 
 # ----------------------------------------------------------------------------------------------- synthetic inputs on the GPU (legs)
@@ -159,13 +203,19 @@ def gpu_multinomial_mixture(torch, N, D, K, trials, seed):
     return X, y.astype(np.int64)
 
 
-def steady_state(pkg, host, torch, prior_kind, prior, X, y, K, steps, settle=30, seed=SAMPLER_SEED):
-    """Upload a device-resident matrix, adopt the generator's labels, burn in until the gates are open, time `steps` group_steps."""
+def steady_state(pkg, host, torch, prior_kind, prior, X, y, K, steps, settle=30, seed=SAMPLER_SEED, rccl_one_rank=False, engine_opts=()):
+    """Upload a device-resident matrix, adopt the generator's labels, burn in until the gates are open, time `steps` group_steps.
+    rccl_one_rank: attach a ONE-rank RCCL communicator to the worker first -- every statistics pass then runs the library's collective
+    path (occupancy all-reduce, packed-row all-reduce: RCCL's kernels and launches, no wire).  engine_opts: (option, value) pairs."""
     N, D = X.shape
     wk = pkg.Worker(prior_kind, D, N, first_index=0, device=0, seed=seed)
     torch.cuda.synchronize()            # X was produced on torch's stream; the library copies on its own
     wk.upload_points_device(X.data_ptr(), X.stride(0))
+    if rccl_one_rank:
+        wk.comm_init(wk.comm_unique_id(), 0, 1)
     s = host.DPMMSampler(wk, prior, ALPHA, N, seed, burnout=BURNOUT)
+    for opt, val in engine_opts:
+        s.model.set_option(opt, val)
     s.start_from_labels(y, 1 + np.random.default_rng([DATA_SEED, 7]).integers(0, 2, N), K)
     for _ in range(BURNOUT + 1 + settle):
         s.group_step(False, False)
@@ -206,7 +256,9 @@ def niw_roofline(n, D, k_mean, sweep_ms, work):
             "algorithmic_flops_per_launch": flops_alg, "executed_flops_per_launch": exe, "pruning_factor": flops_alg / exe if exe else None,
             "full_evals_per_wave_tile": work["full_evals"] / max(1.0, work["wave_tiles"]),
             "screens16_per_wave_tile": work["screens16"] / max(1.0, work["wave_tiles"]),
-            "tail_pairs_per_wave_tile": work["tail_pairs"] / max(1.0, work["wave_tiles"])}
+            "tail_pairs_per_wave_tile": work["tail_pairs"] / max(1.0, work["wave_tiles"]),
+            "brackets_per_wave_tile": work["brackets"] / max(1.0, work["wave_tiles"]),
+            "bf16_mfma_per_tile": work["brackets"] * work["bf16_mfma_per_bracket"] / max(1.0, work["wave_tiles"])}
 
 
 def run_legs(args, pkg, host, torch, one_gpu_ms):
@@ -248,14 +300,29 @@ def run_legs(args, pkg, host, torch, one_gpu_ms):
         r["workload"] = "what each of 8 GPUs holds of the headline: NIW D=64, n=1.25e6, K=32, one GPU, no collective"
         r["roofline"] = niw_roofline(n, D, r["K_t"], r["sweep_kernel_ms"], work)
         legs["c3_shard"] = r
-        # 1 -> 8 projection: a rank of the 8-GPU run does this step plus two all-reduces over xGMI (2K Int64 occupancies, then 2K packed
-        # Float64 rows = 1.1 MB); their time is NOT measured here (one GPU per box) -- the assumption is stated, the driver's SCALE run decides
-        assumed = 0.05
+        # 1 -> 8 projection.  A rank of the 8-GPU run does this step plus the collectives of a statistics pass over xGMI.  What CAN be
+        # measured on one GPU is measured: the same step with a ONE-rank RCCL communicator attached runs RCCL's own kernels and launches
+        # for every all-reduce of the pass (no wire, no peers to wait for) -- `shard_ms_per_step_rccl_1rank`.  What cannot (the wire time
+        # of 2K 1.1 MB rows over 7 xGMI links and the wait for the slowest rank) stays an ASSUMPTION, stated as such: 1.1 MB through a ring
+        # of 8 at ~50 GB/s of bus bandwidth for messages of this size ~ 0.04 ms, minus the launch cost already inside the measured figure.
+        try:
+            r1, _ = steady_state(pkg, host, torch, pkg.PRIOR_NIW, niw64, X, y, K, 100, settle=60, rccl_one_rank=True)
+            rccl_ms, rccl_err = r1["ms_per_step"], None
+        except Exception as e:      # RCCL not loadable on this box: say so, keep the assumption
+            rccl_ms, rccl_err = None, repr(e)[:200]
+        assumed_wire = 0.03
+        assumed_total = 0.05
+        with_comm = (rccl_ms + assumed_wire) if rccl_ms is not None else (r["ms_per_step"] + assumed_total)
         legs["shard8_projection"] = {"one_gpu_ms_per_step": one_gpu_ms, "shard_ms_per_step": r["ms_per_step"],
-                                     "assumed_allreduce_ms_per_step": assumed,
-                                     "projected_speedup_1_to_8": one_gpu_ms / (r["ms_per_step"] + assumed),
+                                     "shard_ms_per_step_rccl_1rank": rccl_ms, "rccl_1rank_error": rccl_err,
+                                     "measured_collective_launch_ms_per_step": (rccl_ms - r["ms_per_step"]) if rccl_ms is not None else None,
+                                     "assumed_wire_ms_per_step": assumed_wire if rccl_ms is not None else None,
+                                     "assumed_allreduce_ms_per_step": assumed_total if rccl_ms is None else None,
+                                     "projected_speedup_1_to_8": one_gpu_ms / with_comm,
                                      "speedup_without_collectives": one_gpu_ms / r["ms_per_step"],
-                                     "note": "projection from one GPU; the two all-reduces per step are assumed, not measured"}
+                                     "target_shard_plus_collectives_ms_for_6x": one_gpu_ms / 6.0,
+                                     "note": "projection from one GPU: the collectives' kernels and launches are measured with a one-rank RCCL "
+                                             "communicator, their wire time is assumed; the driver's SCALE run decides"}
         del X
         torch.cuda.empty_cache()
     if "c4" in want:
@@ -264,15 +331,26 @@ def run_legs(args, pkg, host, torch, one_gpu_ms):
         prior = host.multinomial_hyper(np.ones(Dm, np.float32))          # test/save_load_test/multinomial_params.jl:24
         r, _ = steady_state(pkg, host, torch, pkg.PRIOR_MULT, prior, X, y, K, 50)
         r["workload"] = "C4: Multinomial D=1000 N=1e6 K=32 (100 trials per point), one GPU"
-        bytes_alg = 4.0 * n * Dm + 16.0 * n
+        # Bytes: SURVEY 8d's per-unit figure is for Float32 points (4 n D + 16 n); the context keeps count data as a LOSSLESS byte copy
+        # ([n][roundup(D, 128)] u8) and every Multinomial kernel streams that, so the bytes the dominant kernel has to move are
+        # n (ld8 + 4 [visiting order] + 4 [previous bin] + 4 [new bin]).  `frac` prices THOSE against the kernel's own launch time (it cannot
+        # exceed 1); the Float32 figure over the whole pass is kept as `survey_*` and the counter traffic as `traffic_frac`.
+        ld8 = (Dm + 127) // 128 * 128
+        bytes_f32 = 4.0 * n * Dm + 16.0 * n
+        bytes_u8 = float(n) * (ld8 + 12.0)
+        t_sweep = r["sweep_kernel_ms"] * 1e-3
         t = (r["sweep_kernel_ms"] + r["stats_kernels_ms"]) * 1e-3
         tr_sweep, src = pmc_traffic("mult", "mult_sweep")
         tr_stats, _ = pmc_traffic("mult", "mult_stats")
-        r["roofline"] = {"kernel": "mult_sweep_u8_kernel + sort + mult_stats_u8_kernel (one pass over the points each)", "bound": "hbm",
-                         "achieved": bytes_alg / t / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": bytes_alg / t / 1e9 / PEAK_HBM_GBPS,
-                         "algorithmic_bytes_per_step": bytes_alg,
-                         "traffic": (tr_sweep + tr_stats) if (tr_sweep and tr_stats) else None, "traffic_source": src,
-                         "sweep_only_GBps": bytes_alg / (r["sweep_kernel_ms"] * 1e-3) / 1e9}
+        r["roofline"] = {"kernel": "mult_sweep_u8_kernel", "bound": "hbm",
+                         "achieved": bytes_u8 / t_sweep / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": bytes_u8 / t_sweep / 1e9 / PEAK_HBM_GBPS,
+                         "algorithmic_bytes_per_launch": bytes_u8, "avg_launch_ms": r["sweep_kernel_ms"],
+                         "traffic": tr_sweep, "traffic_source": src,
+                         "traffic_frac": (tr_sweep / t_sweep / 1e9 / PEAK_HBM_GBPS) if tr_sweep else None,
+                         "pass_traffic": (tr_sweep + tr_stats) if (tr_sweep and tr_stats) else None,
+                         "pass_traffic_frac": ((tr_sweep + tr_stats) / t / 1e9 / PEAK_HBM_GBPS) if (tr_sweep and tr_stats) else None,
+                         "survey_float32_bytes_per_step": bytes_f32, "survey_GBps_sweep_plus_stats": bytes_f32 / t / 1e9,
+                         "survey_frac_sweep_plus_stats": bytes_f32 / t / 1e9 / PEAK_HBM_GBPS}
         legs["c4"] = r
         del X
         torch.cuda.empty_cache()
@@ -407,8 +485,13 @@ def main():
             "avg_launch_ms": avg_sweep_ms, "algorithmic_flops_per_launch": flops_alg, "executed_flops_per_launch": exe,
             "executed_tflops": exe / (avg_sweep_ms * 1e-3) / 1e12, "pruning_factor": flops_alg / exe if exe else None,
             "algorithmic_frac": achieved / PEAK_F32_MFMA_TFLOPS,
-            "work_per_launch": {k: float(np.mean([w[k] for w in work])) for k in ("wave_tiles", "full_evals", "screens16", "tail_pairs")},
+            "work_per_launch": {k: float(np.mean([w[k] for w in work])) for k in ("wave_tiles", "full_evals", "screens16", "tail_pairs", "brackets")},
+            "bf16_mfma_per_tile": float(np.mean([w["brackets"] * w["bf16_mfma_per_bracket"] / max(1.0, w["wave_tiles"]) for w in work])),
+            "frac_definition": "Float32 matrix instructions counted on the device in the timed launches x 2048 flops / live launch time / peak "
+                               "(= SQ_INSTS_VALU_MFMA_MOPS_F32 x 512: `pmc_frac`); the reference brackets' bf16 instructions are counted apart",
             "stats_kernels_ms": float(np.mean(stats_ms)), "kernel_source_tag": kernel_source_tag()}
+    if N == 10 ** 7 and D == 64 and world == 1:
+        roof.update(pmc_matrix_pipe("bench", "niw_sweep_direct_kernel", avg_sweep_ms))
 
     # same kernel, same process, screening off: every cluster is evaluated in full (labels are bit-identical by construction)
     if not args.no_dense:
@@ -441,8 +524,7 @@ def main():
         "config": {"workload": f"NIW D={D} N={N} synthetic GMM, {K} true components, K_t={k_mean:.1f} live clusters, "
                                f"alpha=10, default NIW prior, steady state after {BURNOUT + 1} burn-in + {args.settle} settling sweeps",
                    "points_per_gpu": n_local,
-                   "parallelism": f"points sharded over {world} GPU(s); per statistics pass one all-reduce of the 2K Int64 occupancies and "
-                                  f"one of the packed Float64 suff-stat rows inside libdpmmhip.so"},
+                   "parallelism": f"points sharded over {world} GPU(s); all-reduces of a statistics pass inside libdpmmhip.so: see comm"},
         "roofline": roof,
         "comm": {"world": info["world"], "transport": info["transport"], "occupancy_allreduce_bytes": info["counts_bytes"],
                  "rows_allreduce_bytes": info["rows_bytes"], "allreduces_since_attach": info["allreduces"],
@@ -469,6 +551,36 @@ def main():
         out["growth"] = {"init_clusters": 1, "iterations": args.growth_iters, "it_per_s_whole_run": args.growth_iters / tot,
                          "it_per_s_last20_nonfinal": 20.0 / last, "K_history": [int(k) for k in kh], "K_final": int(kh[-1]), "K_true": K,
                          "log_posterior_final": g.log_posterior(), "nmi_final_vs_generator": float(gn)}
+        # labels MOVING: the 40 iterations from iteration 100 of this run (K still growing, splits accepted, whole clusters relabelled: the
+        # cached cluster rows of the derived statistics are invalidated every few steps) -- the other end of the frozen-label steady state
+        if args.growth_iters >= 140:
+            mid = max_over_ranks([float(np.sum(it[100:140]))])[0]
+            out["growth"]["moving_labels"] = {"iterations": "100..139", "it_per_s": 40.0 / mid, "K_at_100": int(kh[100]), "K_at_139": int(kh[139]),
+                                              "K_changes": int(np.count_nonzero(np.diff(np.asarray(kh[100:140]))))}
+
+    # the configuration north_star words: posterior parameter draws and split / merge steps on the HOST (DPMMH_OPT_DEVICE_MASTER = 0) --
+    # same data, same context, same steady state; the headline runs the engine's default for D >= 64 (device master, dpmm_hip_master.h)
+    if not args.no_host_master:
+        engine = importlib.import_module("dpmmsubclusters_jl_amd.host.engine")
+        hm = host.DPMMSampler(wk, prior, ALPHA, N, SAMPLER_SEED, burnout=BURNOUT, comm=comm)
+        hm.model.set_option(engine.OPT_DEVICE_MASTER, 0)
+        hm.start_from_labels(y, sub0, K)
+        for _ in range(BURNOUT + 1 + 30):
+            hm.group_step(False, False)
+        wk.set_timing(0)
+        hb = dict(hm.timers)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            hm.group_step(False, False)
+        fence()
+        el = max_over_ranks([time.perf_counter() - t0])[0]
+        ha = dict(hm.timers)
+        wk.set_timing(7)
+        out["host_master"] = {"it_per_s": args.steps / el, "ms_per_step": 1e3 * el / args.steps, "K_t": int(hm.K),
+                              "host_ms_per_step": {k: round(1e3 * (ha[k] - hb[k]) / args.steps, 4) for k in ha if ha[k] - hb[k] > 0},
+                              "note": "DPMMH_OPT_DEVICE_MASTER = 0: posteriors, factorisations, parameter draws and every Metropolis step on the host "
+                                      "(src/shared_actions.jl:41-66, src/priors/niw.jl:20-40), parameters through dpmm_params_staging / dpmm_commit_params"}
 
     if rank == 0 and world == 1 and not args.no_legs:
         out["legs"] = run_legs(args, pkg, host, torch, out["ms_per_step"])
@@ -481,6 +593,25 @@ def main():
                                                    p["logdet"].astype(np.float32), logw.astype(np.float32), loglr.astype(np.float32), N,
                                                    seconds=args.cpu_seconds)
     if rank == 0:
+        # the numbers a reader of the driver's record needs beside the headline, inside a block the driver keeps (`config`)
+        also = {}
+        if "host_master" in out:
+            also["host_master_it_per_s"] = out["host_master"]["it_per_s"]
+        if "growth" in out:
+            gr = out["growth"]
+            also["growth"] = {"it_per_s_whole_run": gr["it_per_s_whole_run"], "K_final": gr["K_final"], "K_true": gr["K_true"],
+                              "nmi": gr["nmi_final_vs_generator"], "moving_labels_it_per_s": gr.get("moving_labels", {}).get("it_per_s")}
+        lg = out.get("legs", {})
+        if "shard8_projection" in lg:
+            pj = lg["shard8_projection"]
+            also["shard8"] = {k: pj.get(k) for k in ("shard_ms_per_step", "shard_ms_per_step_rccl_1rank", "assumed_wire_ms_per_step",
+                                                     "projected_speedup_1_to_8", "speedup_without_collectives")}
+        for name in ("overlap_var4", "overlap_var1", "k256", "c2", "c4", "c5_shard"):
+            if name in lg:
+                also[name + "_ms_per_step"] = lg[name]["ms_per_step"]
+        if "c4" in lg:
+            also["c4_traffic_frac"] = lg["c4"]["roofline"].get("traffic_frac")
+        out["config"]["also_measured"] = also
         print(json.dumps(out), flush=True)
     wk.close()
     if dist is not None:

@@ -579,12 +579,14 @@ class Worker:
     def last_sweep_work(self):
         """dict of the executed-work counters of the NIW sweeps since the previous call, PER LAUNCH (dpmm_last_sweep_work returns their
         totals and the number of launches, and clears them): after every sweep = that sweep's; after a timed loop = its average."""
-        out = (ctypes.c_uint64 * 8)()
+        out = (ctypes.c_uint64 * 12)()
         self._chk(self._lib.dpmm_last_sweep_work(self._h, out))
         v = [int(x) for x in out]
         n = max(1, v[7])
+        # executed_flops: Float32 matrix work only (= SQ_INSTS_VALU_MFMA_MOPS_F32 x 512); the reference brackets' bf16 work beside it
         return dict(wave_tiles=v[0] / n, full_evals=v[1] / n, screens16=v[2] / n, tail_pairs=v[3] / n, mfma_per_full=v[4], mfma_per_screen=v[5],
-                    flops_per_mfma=v[6], executed_flops=(v[1] * v[4] + v[2] * v[5]) * v[6] / n, launches=v[7])
+                    flops_per_mfma=v[6], executed_flops=(v[1] * v[4] + v[2] * v[5]) * v[6] / n, launches=v[7],
+                    brackets=v[8] / n, bf16_mfma_per_bracket=v[9], bf16_flops=v[8] * v[9] * v[10] / n)
 
     # ---- diagnostics
     def debug_subloglik(self):

@@ -189,7 +189,7 @@ struct dpmm_ctx {
     uint8_t *h_master = nullptr;                   // pinned: jobs | slot map | lr | w | small
     size_t h_master_bytes = 0;
     bool draws_on_device = false;
-    unsigned long long *d_work = nullptr;   // [DPMM_WORK_SLOTS + 16 sweep_grid_max]: tile queue heads [4], [8 + 16 q]; [DPMM_WORK_SLOTS + 4 w ..] executed-work counters of wave w of the last sweep
+    unsigned long long *d_work = nullptr;   // [DPMM_WORK_SLOTS + 4 DPMM_WORK_PER_WAVE sweep_grid_max]: tile queue heads [4], [8 + 16 q]; [DPMM_WORK_SLOTS + DPMM_WORK_PER_WAVE w ..] executed-work counters of wave w of the last sweep
     int work_waves = 0;                      // most waves of a counted sweep launch since the counters were read
     long long work_launches = 0;             // counted sweep launches since the counters were read
     // options (dpmm_set_option)
@@ -444,7 +444,10 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
     // only improve the balance (ceil(items / groups) granularity) -- 16384 at D <= 64 (1.05 -> 0.85 ms at N = 1e7); slabs
     // are allocated per item, which is why the large-D kernels (280 KB per slab at D = 256) stay at 8192
     const int64_t target_items = (c->prior == DPMM_PRIOR_NIW && c->D <= 64) ? 16384 : 8192;
-    c->chunk = (int)std::max<int64_t>(256, ((n_local + target_items - 1) / target_items + 3) / 4 * 4);
+    // (at least 64 points per item for the one-wave D <= 64 kernel -- at the 8-GPU shard size 256-point items left 2 200 items for the
+    // chip's 2 048 wave slots and the kernel ran at a third of its rate --, 256 for the multi-panel kernels, whose batches are 16 points)
+    const int64_t min_chunk = (c->prior == DPMM_PRIOR_NIW && c->D <= 64) ? 64 : 256;
+    c->chunk = (int)std::max<int64_t>(min_chunk, ((n_local + target_items - 1) / target_items + 3) / 4 * 4);
     const size_t nalloc = (size_t)std::max<int64_t>(n_local, 1);
     CHK_CREATE(hipMalloc(&c->dX, sizeof(float) * nalloc * (size_t)c->ldx));
     CHK_CREATE(hipMalloc(&c->dbins, sizeof(int32_t) * nalloc));
@@ -471,8 +474,8 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
     CHK_CREATE(hipMalloc(&c->sb.perm_total, sizeof(int32_t)));
     CHK_CREATE(hipMalloc(&c->d_small, sizeof(int32_t) * 4 * DPMM_MAX_CLUSTERS));
     CHK_CREATE(hipMalloc(&c->d_counts64, sizeof(long long) * 2 * DPMM_MAX_CLUSTERS));
-    CHK_CREATE(hipMalloc(&c->d_work, sizeof(unsigned long long) * (DPMM_WORK_SLOTS + 16 * (size_t)std::max(1, c->sweep_grid_max))));
-    CHK_CREATE(hipMemsetAsync(c->d_work, 0, sizeof(unsigned long long) * (DPMM_WORK_SLOTS + 16 * (size_t)std::max(1, c->sweep_grid_max)), c->stream));
+    CHK_CREATE(hipMalloc(&c->d_work, sizeof(unsigned long long) * (DPMM_WORK_SLOTS + 4 * DPMM_WORK_PER_WAVE * (size_t)std::max(1, c->sweep_grid_max))));
+    CHK_CREATE(hipMemsetAsync(c->d_work, 0, sizeof(unsigned long long) * (DPMM_WORK_SLOTS + 4 * DPMM_WORK_PER_WAVE * (size_t)std::max(1, c->sweep_grid_max)), c->stream));
 #undef CHK_CREATE
     *out = c;
     return DPMM_OK;
@@ -2120,7 +2123,7 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
             c->opt_force_f32 = value != 0; return DPMM_OK;
         case DPMM_OPT_STATS_ITEMS:
             if (c->Kcap > 0) return fail(c, DPMM_ESTATE, "DPMM_OPT_STATS_ITEMS must be set before the first parameters / K");
-            if (value >= 1) c->chunk = (int)std::max<int64_t>(256, ((c->n + (int64_t)value - 1) / (int64_t)value + 3) / 4 * 4);
+            if (value >= 1) c->chunk = (int)std::max<int64_t>((c->prior == DPMM_PRIOR_NIW && c->D <= 64) ? 64 : 256, ((c->n + (int64_t)value - 1) / (int64_t)value + 3) / 4 * 4);
             return DPMM_OK;
         case DPMM_OPT_STATS_GROUPS: c->opt_stats_groups = value > 0 ? (int)value : 0; return DPMM_OK;
         case DPMM_OPT_TRACE_SLOW: c->opt_trace = value != 0; return DPMM_OK;
@@ -2147,16 +2150,18 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
     }
 }
 
-int dpmm_last_sweep_work(dpmm_ctx *c, uint64_t *out8) {
-    if (!c || !out8) return DPMM_EINVAL;
+int dpmm_last_sweep_work(dpmm_ctx *c, uint64_t *out12) {
+    if (!c || !out12) return DPMM_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    std::vector<unsigned long long> h(4 * (size_t)c->work_waves);
+    std::vector<unsigned long long> h((size_t)DPMM_WORK_PER_WAVE * (size_t)c->work_waves);
     if (!h.empty()) HIPCHK(c, hipMemcpy(h.data(), c->d_work + DPMM_WORK_SLOTS, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
-    for (int i = 0; i < 4; ++i) out8[i] = 0;
-    for (size_t w = 0; w < (size_t)c->work_waves; ++w)
-        for (int i = 0; i < 4; ++i) out8[i] += h[4 * w + i];
-    // totals of the launches since the previous call (out8[7] of them); the slots start again from zero
+    for (int i = 0; i < 12; ++i) out12[i] = 0;
+    for (size_t w = 0; w < (size_t)c->work_waves; ++w) {
+        for (int i = 0; i < 4; ++i) out12[i] += h[DPMM_WORK_PER_WAVE * w + i];
+        out12[8] += h[DPMM_WORK_PER_WAVE * w + 4];
+    }
+    // totals of the launches since the previous call (out12[7] of them); the slots start again from zero
     const long long launches = c->work_launches;
     if (!h.empty()) HIPCHK(c, hipMemsetAsync(c->d_work + DPMM_WORK_SLOTS, 0, sizeof(unsigned long long) * h.size(), c->stream));
     c->work_launches = 0; c->work_waves = 0;
@@ -2168,7 +2173,8 @@ int dpmm_last_sweep_work(dpmm_ctx *c, uint64_t *out8) {
         mf_full = NP * 4 * NG + (NB <= 4 ? NG : 0);           // block pairs x 4 k-steps x NG (+ the ones-MFMA row sums of the direct kernel)
         mf_scr = 4 * NG;                                       // the 16-row screen: one block, 4 k-steps, NG point groups
     }
-    out8[4] = (uint64_t)mf_full; out8[5] = (uint64_t)mf_scr; out8[6] = 2048; out8[7] = (uint64_t)launches;
+    out12[4] = (uint64_t)mf_full; out12[5] = (uint64_t)mf_scr; out12[6] = 2048; out12[7] = (uint64_t)launches;
+    out12[9] = 48; out12[10] = 16384;                          // a reference bracket: 6 fragments x 2 passes x 4 point groups of v_mfma_f32_16x16x32_bf16 (2 * 16 * 16 * 32 flops each)
     return DPMM_OK;
 }
 

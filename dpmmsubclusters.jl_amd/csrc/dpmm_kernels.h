@@ -13,6 +13,7 @@ namespace dpmm {
 
 constexpr int DPMM_WORK_QUEUES = 8;                               // queue heads of the D <= 64 sweep kernel, 16 u64 apart from work[8]
 constexpr int DPMM_WORK_SLOTS = 8 + 16 * DPMM_WORK_QUEUES;        // first per-wave counter slot
+constexpr int DPMM_WORK_PER_WAVE = 8;                             // u64 per wave slot (one 64-byte half line): wave tiles, full evaluations, 16-row screens, tail pairs, reference brackets, 3 spare
 constexpr int REFB_FRAGS = 6, REFB_WORDS = REFB_FRAGS * 256;      // dwords of a cluster's bf16 image for the reference bracket (refb_map, dpmm_device.h)
 
 struct NiwSweepArgs {
@@ -50,8 +51,8 @@ struct NiwSweepArgs {
     int queue_rounds;         // D <= 64 kernel: rounds of tiles handed out through the queue at the end of the launch (-1: automatic)
     int prio;                 // 1: s_setprio -- low while the wave streams MFMAs, high in its scalar / VALU phases (DPMM_OPT_WAVE_PRIO)
     unsigned long long *work; // [4] tile queue head of the LDS-staged kernel, [8 + 16 q], q < 8: the eight queue heads of the D <= 64 kernel (one 128-byte
-                              // line each), all cleared before the launch; [DPMM_WORK_SLOTS + 4 w ..]: executed-work counters of
-                              // wave w of this launch (wave tiles, full evaluations, 16-row screens, tail-screened cluster pairs), plain
+                              // line each), all cleared before the launch; [DPMM_WORK_SLOTS + DPMM_WORK_PER_WAVE w ..]: executed-work counters of
+                              // wave w of this launch (wave tiles, full evaluations, 16-row screens, tail-screened cluster pairs, reference brackets), plain
                               // stores at kernel end, summed by the reader; may be null
 };
 

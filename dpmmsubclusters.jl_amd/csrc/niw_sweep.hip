@@ -795,7 +795,7 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
     // atomics held up the loads of the waves still running: the last round of the D <= 64 kernel took 4x as long, a constant ~70 us
     // per launch whatever N, 20 % of the launch at the 8-GPU shard size.)
     if (A.work && lane == 0) {
-        unsigned long long *slot = A.work + DPMM_WORK_SLOTS + ((size_t)blockIdx.x * 4 + wave) * 4;      // (accumulates over launches; cleared by the reader)
+        unsigned long long *slot = A.work + DPMM_WORK_SLOTS + ((size_t)blockIdx.x * 4 + wave) * DPMM_WORK_PER_WAVE;      // (accumulates over launches; cleared by the reader)
         slot[0] += nw_tiles; slot[1] += nw_full; slot[2] += nw_scr; slot[3] += nw_tail;
     }
 #ifdef DPMM_STAMPS
@@ -985,7 +985,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
     // (Also touching the next tile's X lines to pull them into L2 was measured: no gain, +30 % HBM traffic.)
     int nx_p = -1, nx_bin = -1;
     int nx_tile = -1;
-    unsigned nw_tiles = 0, nw_full = 0, nw_scr = 0, nw_tail = 0;   // executed-work counters of this wave (wave-uniform)
+    unsigned nw_tiles = 0, nw_full = 0, nw_scr = 0, nw_tail = 0, nw_br = 0;   // executed-work counters of this wave (wave-uniform)
     const int rounds_all = nwtiles / nwaves;
     int dyn_rounds = A.queue_rounds >= 0 ? A.queue_rounds : (rounds_all < 4 ? 0 : (rounds_all / 8 > 2 ? rounds_all / 8 : 2));
     if (dyn_rounds > rounds_all) dyn_rounds = rounds_all;
@@ -1210,7 +1210,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
 #pragma unroll
                     for (int n = 0; n < NG; ++n) bestn[n] = __builtin_fmaf(-0.5f, qhi[n], c0);
                     bracketed = true;
-                    nw_scr += 2;                                              // (48 bf16 matrix instructions: the cycles of 1.5 sixteen-row screens)
+                    ++nw_br;                                                  // (48 bf16 matrix instructions, counted on their own: not Float32 matrix work)
                 }
             }
             if (!bracketed) {
@@ -1585,8 +1585,8 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
 #endif
     }
     if (A.work && lane == 0) {      // one slot per wave, no atomics (see the LDS-staged kernel)
-        unsigned long long *slot = A.work + DPMM_WORK_SLOTS + (size_t)wave_id * 4;      // (accumulates over launches; cleared by the reader)
-        slot[0] += nw_tiles; slot[1] += nw_full; slot[2] += nw_scr; slot[3] += nw_tail;
+        unsigned long long *slot = A.work + DPMM_WORK_SLOTS + (size_t)wave_id * DPMM_WORK_PER_WAVE;      // (accumulates over launches; cleared by the reader)
+        slot[0] += nw_tiles; slot[1] += nw_full; slot[2] += nw_scr; slot[3] += nw_tail; slot[4] += nw_br;
     }
 #ifdef DPMM_STAMPS
     if (lane == 0 && A.dbg) {

@@ -677,17 +677,27 @@ __device__ __forceinline__ void niw_stats_body_shared(const StatsArgs &A, int se
     __syncthreads();
 }
 
-// Workgroup w owns the contiguous item range [w q, (w+1) q), q = ceil(total / groups).  Consecutive items of one
-// bin are contiguous in perm, so the range splits into one segment per bin it touches; each segment is accumulated
-// in registers and written as ONE slab, stored at the slot of its first item (its "head").  Heads of bin b are
-// item_start[b] and every multiple of q inside the bin -- the reduce kernel walks exactly those.
+// Workgroup w owns the contiguous item range [B(w), B(w+1)), B(w) = floor(w T / G) -- T items over G = min(groups, T) workgroups, so
+// that two ranges differ by at most ONE item.  (Round 3 cut ranges of q = ceil(T / groups) items: with the derived statistics a pass
+// at the 8-GPU shard size has T = 2 200 items for 1 024 groups, q = 3, and 733 workgroups did all the work on a third of the chip
+// while the rest had none: 0.124 ms where T / groups of the N = 1e7 pass predicts 0.05.)  Consecutive items of one bin are contiguous
+// in perm, so the range splits into one segment per bin it touches; each segment is accumulated in registers and written as ONE
+// slab, stored at the slot of its first item (its "head").  Heads of bin b are item_start[b] and every B(w) strictly inside the
+// bin -- the reduce kernel walks exactly those (range_bound / range_heads below: both kernels use the same two functions).
+__device__ __forceinline__ int range_bound(int w, int T, int G) { return (int)(((long long)w * T) / G); }
+// boundaries B(w) with i0 < B(w) < i1: w in [wa, wb] (empty when wb < wa).  B(w) > i0 <=> w T >= (i0 + 1) G;  B(w) < i1 <=> w T < i1 G.
+__device__ __forceinline__ void range_heads(int i0, int i1, int T, int G, int &wa, int &wb) {
+    wa = (int)((((long long)i0 + 1) * G + T - 1) / T);
+    wb = (int)(((long long)i1 * G + T - 1) / T) - 1;
+}
 template <int NBK>
 __global__ __launch_bounds__(64 * StatCfg<NBK>::NPANEL) void niw_stats_kernel(StatsArgs A) {
     using C = StatCfg<NBK>;
     const int total_items = A.sb.item_start[A.nbins];
-    const int q = (total_items + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int it0 = (int)blockIdx.x * q;
-    const int it1 = min(total_items, it0 + q);
+    const int G = min((int)gridDim.x, total_items);
+    if ((int)blockIdx.x >= G) return;
+    const int it0 = range_bound((int)blockIdx.x, total_items, G);
+    const int it1 = range_bound((int)blockIdx.x + 1, total_items, G);
     for (int item = it0; item < it1;) {
         const int b = find_bin(A.sb.item_start, A.nbins, item);
         const int e = min(it1, A.sb.item_start[b + 1]);
@@ -784,10 +794,11 @@ __global__ __launch_bounds__(64 * REDUCE_PARTS) void niw_reduce_kernel(StatsArgs
     if (!A.sb.bin_sel[b]) { if (part == 0) { if (live) out[e] = 0.; if (pos == 0) out[0] = 0.; } return; }
     const int i0 = A.sb.item_start[b], i1 = A.sb.item_start[b + 1];
     const int total_items = A.sb.item_start[A.nbins];
-    const int q = (total_items + A.range_groups - 1) / A.range_groups;      // as in niw_stats_kernel
-    // segment heads of the bin, in item order: i0, then every multiple of q inside (i0, i1)
-    const int m0 = i0 / q;
-    const int nheads = i1 > i0 ? 1 + max(0, (i1 - 1) / q - m0) : 0;
+    const int G = min(A.range_groups, total_items);                          // as in niw_stats_kernel
+    // segment heads of the bin, in item order: i0, then every workgroup boundary strictly inside (i0, i1)
+    int wa = 1, wb = 0;
+    if (i1 > i0) range_heads(i0, i1, total_items, G, wa, wb);
+    const int nheads = i1 > i0 ? 1 + max(0, wb - wa + 1) : 0;
     const int h0 = (int)((int64_t)nheads * part / REDUCE_PARTS), h1 = (int)((int64_t)nheads * (part + 1) / REDUCE_PARTS);
     double s = 0.;
     if (live) {
@@ -796,7 +807,7 @@ __global__ __launch_bounds__(64 * REDUCE_PARTS) void niw_reduce_kernel(StatsArgs
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int hh = h + u;
-                const int it = hh == 0 ? i0 : (m0 + hh) * q;
+                const int it = hh == 0 ? i0 : range_bound(wa + hh - 1, total_items, G);
                 v[u] = hh < h1 ? A.slabs[(int64_t)it * A.slab_stride + pos] : 0.;
             }
 #pragma unroll
@@ -823,12 +834,13 @@ static int niw_nbk(int D) { return D <= 16 ? 1 : D <= 32 ? 2 : D <= 64 ? 4 : D <
 hipError_t launch_niw_stats(const StatsArgs &a0, hipStream_t s) {
     StatsArgs a = a0;
     const int NBK = niw_nbk(a.D);
-    // two resident waves per SIMD at D = 64 (register budget): 2048 workgroups cover the chip once; every workgroup
-    // gets the same number of items, so nothing is gained from a longer grid.  Measured (scripts/stats_groups_sweep.py): D <= 64:
-    // 2048 at N = 1e7 (0.98 ms; 1024: 1.00, 512: 1.84), but 1024 at n = 1.25e6 (0.19 against 0.22 ms: half the slabs to write and
-    // to reduce); D = 128 (four panels on the shared data path): 512 (0.50 ms; 256: 0.55, 1024: 0.53, 2048: 0.60); D = 256 (one workgroup per
-    // compute unit fits): 256.
-    const int dflt = NBK <= 4 ? (a.n >= 2500000 ? 2048 : 1024) : (NBK <= 8 ? 512 : 256);
+    // two resident waves per SIMD at D = 64 (register budget): 2048 workgroups cover the chip once; ranges are balanced to one item, so
+    // nothing is gained from a longer grid.  Measured (scripts/stats_groups_sweep.py): D <= 64: 2048 at N = 1e7 (0.98 ms; 1024: 1.00,
+    // 512: 1.84); D = 128 (four panels on the shared data path): 512 (0.50 ms; 256: 0.55, 1024: 0.53, 2048: 0.60); D = 256 (one
+    // workgroup per compute unit fits): 256.  Small passes: a workgroup per ~128 points at least (a slab is 21 KB at D = 64 -- as much
+    // as 80 points of input -- and every one is written, read back and summed by the reduce).
+    int dflt = NBK <= 4 ? 2048 : (NBK <= 8 ? 512 : 256);
+    if (NBK <= 4) { const int64_t by_points = (a.n + 127) / 128; if (by_points < dflt) dflt = (int)(by_points < 64 ? 64 : by_points); }
     int groups = a.range_groups > 0 ? a.range_groups : dflt;
     const int max_items = a.max_items < 1 ? 1 : a.max_items;
     if (groups > max_items) groups = max_items;

@@ -1,7 +1,7 @@
 """GPU parity tests for the NIW worker path: HIP kernels (through the C ABI) vs the CPU oracle on
 the same seeded inputs.  Tolerances (fp32 contraction on the matrix cores vs the oracle's f32/f64):
   per-point log-lik: atol 1e-3 + rtol 2e-5 against the Float64 evaluation of the same f32 parameters
-  labels under shared uniforms: exact except counted near-boundary flips (<= 5e-5 of points, sub-labels <= 2e-4; at least 2;
+  labels under shared uniforms: exact except counted near-boundary flips (< 1e-5 of points, at least 1; sub-labels <= 1e-4, at least 2;
       counts are printed; each label flip explained by a CDF margin below 1e-3 of the row mass)
   draw given the GPU's own table: bit-exact (same exp_det / scan arithmetic)
   N counts and all relabel bookkeeping: bit-exact; sum x, sum xx' vs Float64 oracle: rtol 1e-12
@@ -105,7 +105,7 @@ def test_sweep_labels_vs_oracle(pkg, D, n, K, sorted_points):
     olab, osub, otab = orc.sweep_niw(P["X"], D, P["mu"], P["invS"], P["logdet"], np.log(P["w"]), np.log(P["lr"]),
                                      seed=seed, epoch=epoch, first_idx=first, want_parr=True)
     flips = np.flatnonzero(lab != olab)
-    assert len(flips) <= max(2, int(5e-5 * n)), len(flips)
+    assert len(flips) <= max(1, int(1e-5 * n)), len(flips)
     t64 = table_f64(P)
     p = np.exp(t64 - t64.max(0))
     cdf = np.cumsum(p, 0) / p.sum(0)
@@ -114,7 +114,7 @@ def test_sweep_labels_vs_oracle(pkg, D, n, K, sorted_points):
     same = lab == olab
     sflips = int((sub[same] != osub[same]).sum())
     print(f"D={D} n={n}: label flips vs oracle {len(flips)}, sub-label flips {sflips}")
-    assert sflips <= max(2, int(2e-4 * n)), sflips
+    assert sflips <= max(2, int(1e-4 * n)), sflips
     # the labels must be informative (not a degenerate draw)
     assert (lab == P["z"] + 1).mean() > 1.5 / K
     wk.close()
@@ -325,8 +325,8 @@ def test_many_clusters_and_padded_dims_with_screening(pkg, D, n, K):
     olab, osub = orc.sweep_niw(P["X"], D, P["mu"], P["invS"], P["logdet"], np.log(P["w"]), np.log(P["lr"]), seed=seed, epoch=2, first_idx=first)
     same = lab == olab
     print(f"D={D} K={K} n={n}: label flips vs oracle {(lab != olab).sum()}, sub-label flips {(sub[same] != osub[same]).sum()}")
-    assert (lab != olab).sum() <= max(2, int(5e-5 * n))
-    assert (sub[same] != osub[same]).sum() <= max(2, int(2e-4 * n))
+    assert (lab != olab).sum() <= max(1, int(1e-5 * n))
+    assert (sub[same] != osub[same]).sum() <= max(2, int(1e-4 * n))
     wk.sweep(3, final=True)
     assert np.array_equal(wk.get_labels()[0], orc.argmax_rows(tab))
     wk.close()
@@ -554,8 +554,9 @@ def test_reference_bracket_labels_on_adversarial_operands(pkg, kind):
         wk = pkg.Worker(pkg.PRIOR_NIW, D, n, device=0, seed=17)
         wk.upload_points(X)
         wk.set_option(binding.OPT_REF_BRACKET, br)
+        wk.set_params_niw_chol(P["mu"], P["R"], P["logdet"], P["lr"], P["w"])
         wk.set_labels(own + 1, 1 + (np.arange(n) & 1))
-        wk.suffstats_packed(None)
+        wk.suffstats_packed(None)                      # the bin-sorted visiting order: waves of one label
         wk.set_params_niw_chol(P["mu"], P["R"], P["logdet"], P["lr"], P["w"])
         wk.last_sweep_work()
         labs = []
