@@ -98,7 +98,8 @@ struct dpmm_ctx {
 
     // sort + stats
     SortBufs sb{};
-    int nt_sort = 0;
+    int nt_sort = 0;          // tiles the sort tables are allocated for
+    int sort_tile_min = SORT_TILE;   // smallest sort tile the tables can hold
     int chunk = 512;
     int max_items = 0;
     double *d_slabs = nullptr;
@@ -381,7 +382,9 @@ static int ensure_capacity(dpmm_ctx *c, int K) {
     HIPCHK(c, hipMalloc(&c->d_scratch, sizeof(float) * (size_t)rows * (size_t)c->scratch_stride));
     // statistics
     c->max_items = (int)((c->n + c->chunk - 1) / c->chunk) + 2 * cap;
-    HIPCHK(c, hipMalloc(&c->d_slabs, sizeof(double) * (size_t)c->max_items * (size_t)c->slab_stride));
+    // NIW: one slab per SLOT (a workgroup of the statistics kernel, or a bin whose first item lies inside a workgroup's range); Multinomial: per item
+    const size_t nslabs = c->prior == DPMM_PRIOR_NIW ? (size_t)NIW_STATS_MAX_GROUPS + 2 * (size_t)cap : (size_t)c->max_items;
+    HIPCHK(c, hipMalloc(&c->d_slabs, sizeof(double) * nslabs * (size_t)c->slab_stride));
     HIPCHK(c, hipMalloc(&c->d_out, sizeof(double) * 2 * cap * (size_t)c->packed_stride + DPMM_MAX_CLUSTERS + 64));   // rows | bad-cluster flags
     HIPCHK(c, hipMalloc(&c->d_ccache, sizeof(double) * cap * (size_t)c->packed_stride));
     HIPCHK(c, hipMemsetAsync(c->d_ccache, 0, sizeof(double) * cap * (size_t)c->packed_stride, c->stream));      // (on the stream its readers run on)
@@ -444,14 +447,22 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
     // only improve the balance (ceil(items / groups) granularity) -- 16384 at D <= 64 (1.05 -> 0.85 ms at N = 1e7); slabs
     // are allocated per item, which is why the large-D kernels (280 KB per slab at D = 256) stay at 8192
     const int64_t target_items = (c->prior == DPMM_PRIOR_NIW && c->D <= 64) ? 16384 : 8192;
-    // (at least 64 points per item for the one-wave D <= 64 kernel -- at the 8-GPU shard size 256-point items left 2 200 items for the
-    // chip's 2 048 wave slots and the kernel ran at a third of its rate --, 256 for the multi-panel kernels, whose batches are 16 points)
-    const int64_t min_chunk = (c->prior == DPMM_PRIOR_NIW && c->D <= 64) ? 64 : 256;
-    c->chunk = (int)std::max<int64_t>(min_chunk, ((n_local + target_items - 1) / target_items + 3) / 4 * 4);
+    // NIW: the statistics kernel balances its workgroups' ranges to ONE item and slabs are per slot, not per item -- items only set the
+    // granularity of the balance: 32 points (8 k-steps) for the one-wave D <= 64 kernels, 256 for the multi-panel kernels (16-point batches).
+    // Multinomial: one workgroup and one slab per item: 8192 items.
+    const int64_t min_chunk = (c->prior == DPMM_PRIOR_NIW && c->D <= 64) ? 32 : 256;
+    const int64_t target_items2 = (c->prior == DPMM_PRIOR_NIW && c->D <= 64) ? 65536 : target_items;
+    c->chunk = (int)std::max<int64_t>(min_chunk, ((n_local + target_items2 - 1) / target_items2 + 3) / 4 * 4);
     const size_t nalloc = (size_t)std::max<int64_t>(n_local, 1);
     CHK_CREATE(hipMalloc(&c->dX, sizeof(float) * nalloc * (size_t)c->ldx));
     CHK_CREATE(hipMalloc(&c->dbins, sizeof(int32_t) * nalloc));
-    c->nt_sort = (int)((n_local + SORT_TILE - 1) / SORT_TILE);
+    // sort tiles: 512 points per sorting wave below 4e6 points (the tile kernels are one-wave latency chains: at the 8-GPU shard size four
+    // times as many waves of a quarter of the trips each), 2048 above; the tables are sized for whichever is in use (DPMM_OPT_SORT_TILE
+    // may switch while the shard is small enough for the small tile's tables)
+    c->sb.tile = n_local <= 4000000 ? SORT_TILE_SMALL : SORT_TILE;
+    const int alloc_tile = n_local <= 16000000 ? SORT_TILE_SMALL : SORT_TILE;
+    c->sort_tile_min = alloc_tile;
+    c->nt_sort = (int)((n_local + alloc_tile - 1) / alloc_tile);
     const size_t nbmax = 2 * DPMM_MAX_CLUSTERS;
     CHK_CREATE(hipMalloc(&c->sb.tile_hist, sizeof(int32_t) * nbmax * (size_t)std::max(1, c->nt_sort)));
     CHK_CREATE(hipMalloc(&c->sb.tile_cnt, sizeof(int32_t) * nbmax * (size_t)std::max(1, c->nt_sort)));
@@ -1159,17 +1170,22 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
         HIPCHK(c, launch_sort_finish(c->dbins, a, c->stream));
     }
     c->have_perm = c->n > 0;
-    if (c->prior == DPMM_PRIOR_NIW) HIPCHK(c, launch_niw_stats(a, c->stream));
-    else if (c->x_u8) HIPCHK(c, launch_mult_stats_u8(a, c->dX8, c->ld8, c->stream));
-    else HIPCHK(c, launch_mult_stats(a, c->stream));
     if (flags_sent) *flags_sent = false;
-    if (derive) {
-        // (flags_to: the caller's pinned block for the bad-cluster flags -- they ride in this launch when no collective follows it)
-        const bool ride = flags_to != nullptr && !comm_attached(c);
-        const uint8_t *fsrc = reinterpret_cast<const uint8_t *>(c->d_out) + sizeof(double) * (size_t)nbins * (size_t)c->packed_stride;
-        HIPCHK(c, launch_derive_rows(c->d_out, c->d_ccache, c->sb.cmode, c->sb.cdirty, c->packed_stride, c->K, fsrc, ride ? flags_to : nullptr, c->stream));
-        if (ride && flags_sent) *flags_sent = true;
+    // (flags_to: the caller's pinned block for the bad-cluster flags -- they ride in the derivation's launch when no collective follows it)
+    const bool ride = derive && flags_to != nullptr && !comm_attached(c);
+    const uint8_t *fsrc = reinterpret_cast<const uint8_t *>(c->d_out) + sizeof(double) * (size_t)nbins * (size_t)c->packed_stride;
+    if (c->prior == DPMM_PRIOR_NIW) {
+        if (derive) {       // the reduce kernel derives the rows that were not computed (one launch and one round trip of the rows less)
+            a.mode = c->sb.cmode; a.cache = c->d_ccache; a.dirty = c->sb.cdirty; a.K = c->K;
+            a.flags_src = ride ? fsrc : nullptr; a.flags_dst = ride ? flags_to : nullptr;
+        }
+        HIPCHK(c, launch_niw_stats(a, c->stream));
+    } else {
+        if (c->x_u8) HIPCHK(c, launch_mult_stats_u8(a, c->dX8, c->ld8, c->stream));
+        else HIPCHK(c, launch_mult_stats(a, c->stream));
+        if (derive) HIPCHK(c, launch_derive_rows(c->d_out, c->d_ccache, c->sb.cmode, c->sb.cdirty, c->packed_stride, c->K, fsrc, ride ? flags_to : nullptr, c->stream));
     }
+    if (ride && flags_sent) *flags_sent = true;
     if (comm_attached(c)) {
         // the one exchange of the sweep: elementwise sum of the per-worker statistics (update_suff_stats_posterior!,
         // local_clusters_actions.jl:206-254; aggregate_suff_stats); N counts travel as Float64 integers (exact below 2^53)
@@ -2123,7 +2139,7 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
             c->opt_force_f32 = value != 0; return DPMM_OK;
         case DPMM_OPT_STATS_ITEMS:
             if (c->Kcap > 0) return fail(c, DPMM_ESTATE, "DPMM_OPT_STATS_ITEMS must be set before the first parameters / K");
-            if (value >= 1) c->chunk = (int)std::max<int64_t>((c->prior == DPMM_PRIOR_NIW && c->D <= 64) ? 64 : 256, ((c->n + (int64_t)value - 1) / (int64_t)value + 3) / 4 * 4);
+            if (value >= 1) c->chunk = (int)std::max<int64_t>((c->prior == DPMM_PRIOR_NIW && c->D <= 64) ? 32 : 256, ((c->n + (int64_t)value - 1) / (int64_t)value + 3) / 4 * 4);
             return DPMM_OK;
         case DPMM_OPT_STATS_GROUPS: c->opt_stats_groups = value > 0 ? (int)value : 0; return DPMM_OK;
         case DPMM_OPT_TRACE_SLOW: c->opt_trace = value != 0; return DPMM_OK;
@@ -2134,6 +2150,12 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
         case DPMM_OPT_STATS_DERIVE: c->opt_derive = value != 0; c->cache_force = true; return DPMM_OK;
         case DPMM_OPT_NOISE_AHEAD: c->opt_noise_ahead = value != 0; return DPMM_OK;
         case DPMM_OPT_REF_BRACKET: c->opt_bracket = value != 0; return DPMM_OK;
+        case DPMM_OPT_SORT_TILE: {
+            const int t = (int)value;
+            if (t != SORT_TILE && t != SORT_TILE_SMALL) return fail(c, DPMM_EINVAL, "DPMM_OPT_SORT_TILE: 512 or 2048");
+            if (t < c->sort_tile_min) return fail(c, DPMM_ELIMIT, "DPMM_OPT_SORT_TILE: the sort tables of this shard hold 2048-point tiles only");
+            c->sb.tile = t; return DPMM_OK;          // (the tile tables are rebuilt by every pass; perm stays a valid order)
+        }
         case DPMM_OPT_KERNEL_TIMING:
             c->opt_timing = (int)value & 7;
             if (!(c->opt_timing & 1)) c->have_sweep_ev = false;

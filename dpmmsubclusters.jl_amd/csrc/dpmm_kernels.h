@@ -133,10 +133,12 @@ hipError_t launch_reset_sub(int32_t *bins, int64_t n, int64_t first_index, const
                             uint32_t epoch, hipStream_t s);
 
 // ---- stable counting sort of the points by bin + segmented statistics (suffstats.hip)
-constexpr int SORT_TILE = 2048;  // points per sorting wave
+constexpr int SORT_TILE = 2048;  // points per sorting wave of big shards (SortBufs::tile: 2048 or SORT_TILE_SMALL)
+constexpr int SORT_TILE_SMALL = 512;
 constexpr int FAST_TOTAL_STRIDE = 32;   // ints between the running totals of two bins (one 128-byte line per bin: the histogram adds with atomics)
 
 struct SortBufs {
+    int tile;             // points per sorting wave of this context's passes: SORT_TILE or SORT_TILE_SMALL
     int32_t *tile_hist;   // [nbins][ntiles_sort] exclusive prefix over the tiles of a bin (written by the scan from tile_cnt)
     int32_t *tile_cnt;    // [nbins][ntiles_sort] points of bin b in tile t (written by the histogram)
     int32_t *fast_total;  // [nbins][FAST_TOTAL_STRIDE] (element 0 of each line) running bin totals of the per-step histogram (integer atomics), cleared by scan_starts_kernel
@@ -172,13 +174,19 @@ struct StatsArgs {
     int max_items;
     int range_groups;      // NIW: workgroups of the statistics kernel; each owns a contiguous range of items (0: one item per workgroup)
     SortBufs sb;
-    double *slabs;         // [max_items][slab_stride]
+    double *slabs;         // NIW: [NIW_STATS_MAX_GROUPS + nbins][slab_stride] (slots, suffstats.hip head_slot); Multinomial: [max_items][slab_stride]
     int64_t slab_stride;
     double *out;           // packed [nbins][packed_stride]
     int64_t packed_stride;
     const int32_t *row_off; // NIW: [packed_stride] packed-row element -> position inside a slab (launch_niw_row_offsets)
     const int32_t *inv_off; // NIW: [slab_stride] slab position -> packed-row element (-1: none), the inverse table
+    // NIW per-step pass with derived statistics: the reduce kernel forms the rows that were not computed (null mode: plain reduce)
+    const uint8_t *mode;    // [K] 0 both computed -> cache = left + right, 1 / 2: left / right = cache - computed
+    double *cache;          // [K][packed_stride]
+    uint8_t *dirty;         // [DPMM_MAX_CLUSTERS_K + 1] cleared for the next pass
+    const uint8_t *flags_src; uint8_t *flags_dst; int K;    // rider: bad-cluster flags -> the caller's pinned block (null: none)
 };
+constexpr int NIW_STATS_MAX_GROUPS = 4096;   // workgroups of the NIW statistics kernel at most; slab slots = this + 2 K (suffstats.hip head_slot)
 int64_t niw_slab_stride(int D);
 hipError_t launch_niw_row_offsets(int32_t *row_off, int32_t *inv_off, int D, int64_t packed_stride, hipStream_t s);
 int64_t mult_slab_stride(int D);

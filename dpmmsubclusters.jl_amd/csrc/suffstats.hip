@@ -35,6 +35,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // `prev_lab` / `dirty` (nullable pair): the cluster label every point had at the previous per-step pass, and per-cluster flags "a point
 // entered or left this cluster since then" -- what lets the statistics pass compute only the smaller sub-cluster of an untouched cluster
 // and take the other one from the cached cluster-level row (derive_rows_kernel).  Any path that changes labels is seen here.
+template <int TILE>
 __global__ __launch_bounds__(64) void hist_kernel(const int32_t *__restrict__ bins, int64_t n, int nbins, int nt,
                                                   int32_t *__restrict__ tile_hist, int32_t *__restrict__ fast_total,
                                                   uint16_t *__restrict__ prev_lab, uint8_t *__restrict__ dirty) {
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(64) void hist_kernel(const int32_t *__restrict__ bi
     const int lane = threadIdx.x;
     for (int b = lane; b < nbins; b += 64) cnt[b] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
+    const int64_t base = (int64_t)blockIdx.x * TILE;
     auto track = [&](int64_t i, int bv) {            // rare: a point whose label is not the one it had at the previous pass
         // (a label outside [0, K) -- perm_total != n acknowledges that they can occur -- still LEAVES the cluster the point was in: that
         // cluster's cached row is stale whether or not the new bin is counted)
@@ -54,36 +55,36 @@ __global__ __launch_bounds__(64) void hist_kernel(const int32_t *__restrict__ bi
             prev_lab[i] = (uint16_t)z;
         }
     };
-    if (base + SORT_TILE <= n) {
+    if (base + TILE <= n) {
         // full tile: 16-byte loads, all of them in flight before the first is used; 256 points with one common bin (the usual case
         // after an ordered sweep: neighbours share a label) cost one LDS add instead of 256 same-address atomics
         const int4 *src = reinterpret_cast<const int4 *>(bins + base);
-        int4 v[SORT_TILE / 256];
+        int4 v[TILE / 256];
 #pragma unroll
-        for (int it = 0; it < SORT_TILE / 256; ++it) v[it] = src[it * 64 + lane];
+        for (int it = 0; it < TILE / 256; ++it) v[it] = src[it * 64 + lane];
         if (prev_lab) {
             // four 16-bit labels per lane and trip, all loads in flight with the bins'; ONE wave-level test for the whole tile (nothing
             // moved: the usual case) in front of the per-point bookkeeping
             const uint2 *psrc = reinterpret_cast<const uint2 *>(prev_lab + base);
-            uint2 pv[SORT_TILE / 256];
+            uint2 pv[TILE / 256];
 #pragma unroll
-            for (int it = 0; it < SORT_TILE / 256; ++it) pv[it] = psrc[it * 64 + lane];
+            for (int it = 0; it < TILE / 256; ++it) pv[it] = psrc[it * 64 + lane];
             unsigned diff = 0u;
 #pragma unroll
-            for (int it = 0; it < SORT_TILE / 256; ++it) {
+            for (int it = 0; it < TILE / 256; ++it) {
                 const unsigned a0 = (unsigned)v[it].x >> 1, a1 = (unsigned)v[it].y >> 1, a2 = (unsigned)v[it].z >> 1, a3 = (unsigned)v[it].w >> 1;
                 diff |= (pv[it].x ^ (a0 | (a1 << 16))) | (pv[it].y ^ (a2 | (a3 << 16)));
             }
             if (__any(diff != 0u)) {
 #pragma unroll
-                for (int it = 0; it < SORT_TILE / 256; ++it) {
+                for (int it = 0; it < TILE / 256; ++it) {
                     const int64_t i0 = base + (int64_t)(it * 64 + lane) * 4;
                     track(i0, v[it].x); track(i0 + 1, v[it].y); track(i0 + 2, v[it].z); track(i0 + 3, v[it].w);
                 }
             }
         }
 #pragma unroll
-        for (int it = 0; it < SORT_TILE / 256; ++it) {
+        for (int it = 0; it < TILE / 256; ++it) {
             const int b0 = __builtin_amdgcn_readfirstlane(v[it].x);
             const bool same = v[it].x == b0 && v[it].y == b0 && v[it].z == b0 && v[it].w == b0;
             if (__all(same)) {
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(64) void hist_kernel(const int32_t *__restrict__ bi
             }
         }
     } else {
-        for (int it = 0; it < SORT_TILE / 64; ++it) {
+        for (int it = 0; it < TILE / 64; ++it) {
             const int64_t i = base + it * 64 + lane;
             if (i < n) {
                 const int b = bins[i];
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(64) void hist_kernel(const int32_t *__restrict__ bi
 // workgroup 0 publishes them (flags[0..K), flags[K] = any); a tile that holds points of a flagged cluster re-draws their sub-labels
 // (Philox keyed by the global point index, as reset_sub_flagged_kernel) and re-counts itself -- tile_cnt of every other tile stays what
 // the histogram wrote.  Replaces reset + second histogram + second scan of the per-step pass (three launches fewer).
+template <int TILE>
 __global__ __launch_bounds__(64) void reset_recount_kernel(int32_t *__restrict__ bins, int64_t n, int64_t first, int nbins, int nt,
                                                            const int32_t *__restrict__ totals, const long long *__restrict__ global_counts,
                                                            int32_t *__restrict__ tile_cnt, uint8_t *__restrict__ flags, int K, uint64_t seed, uint32_t epoch) {
@@ -159,11 +161,11 @@ __global__ __launch_bounds__(64) void reset_recount_kernel(int32_t *__restrict__
     if (blockIdx.x == 0 && lane == 0) flags[K] = any ? 1 : 0;
     if (!any) return;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
-    constexpr int PER = SORT_TILE / 64;
+    const int64_t base = (int64_t)blockIdx.x * TILE;
+    constexpr int PER = TILE / 64;
     int v[PER];
     bool hit = false;
-    const bool full = base + SORT_TILE <= n;       // full tile: 16-byte loads (lane owns four consecutive points per trip), else one point per trip
+    const bool full = base + TILE <= n;       // full tile: 16-byte loads (lane owns four consecutive points per trip), else one point per trip
     if (full) {
         const int4 *src = reinterpret_cast<const int4 *>(bins + base);
 #pragma unroll
@@ -313,6 +315,7 @@ __global__ __launch_bounds__(256) void scan_starts_kernel(const int32_t *__restr
     starts_body(bin_total, bin_sel, nbins, chunk, bin_start, item_start, perm_total, part, pb);
 }
 
+template <int TILE>
 __global__ __launch_bounds__(64) void scatter_kernel(const int32_t *__restrict__ bins, int64_t n, int nbins, int nt,
                                                      const int32_t *__restrict__ tile_hist,
                                                      const int32_t *__restrict__ bin_start, int32_t *__restrict__ perm) {
@@ -322,16 +325,16 @@ __global__ __launch_bounds__(64) void scatter_kernel(const int32_t *__restrict__
     while ((1 << nbits) < nbins) ++nbits;
     for (int b = lane; b < nbins; b += 64) base[b] = bin_start[b] + tile_hist[(int64_t)b * nt + blockIdx.x];
     __syncthreads();
-    const int64_t tbase = (int64_t)blockIdx.x * SORT_TILE;
+    const int64_t tbase = (int64_t)blockIdx.x * TILE;
     // all loads of the tile in flight before the first is used (one wave per tile: a load per trip would serialise 32 latencies)
-    int bv[SORT_TILE / 64];
+    int bv[TILE / 64];
 #pragma unroll
-    for (int it = 0; it < SORT_TILE / 64; ++it) {
+    for (int it = 0; it < TILE / 64; ++it) {
         const int64_t i = tbase + it * 64 + lane;
         bv[it] = bins[i < n ? i : n - 1];
     }
 #pragma unroll
-    for (int it = 0; it < SORT_TILE / 64; ++it) {
+    for (int it = 0; it < TILE / 64; ++it) {
         const int64_t i = tbase + it * 64 + lane;
         int b = i < n ? bv[it] : -1;
         if ((unsigned)b >= (unsigned)nbins) b = -1;
@@ -394,27 +397,36 @@ hipError_t launch_derive_rows(double *out, double *cache, const uint8_t *mode, u
     return hipGetLastError();
 }
 
+// Sort tile = points per sorting wave (SortBufs::tile): 2048 for big shards, 512 below ~4e6 points -- at the 8-GPU shard size the three
+// tile kernels are latency chains of one wave per tile (8 / 32 dependent trips per wave at 2048 points: 12 us each for 5 MB of labels).
+#define DPMM_TILE_DISPATCH(tile, CALL512, CALL2048) do { if ((tile) == 512) { CALL512; } else { CALL2048; } } while (0)
+static inline int sort_nt(int64_t n, const SortBufs &b) { return (int)((n + b.tile - 1) / b.tile); }
 hipError_t launch_sort_by_bin(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s) {
-    const int nt = (int)((n + SORT_TILE - 1) / SORT_TILE);
+    const int nt = sort_nt(n, b);
     if (nt == 0) return hipSuccess;
-    DPMM_LAUNCH(hist_kernel, dim3(nt), dim3(64), nbins * sizeof(int), s, bins, n, nbins, nt, b.tile_cnt, (int32_t *)nullptr,
-                       (uint16_t *)nullptr, (uint8_t *)nullptr);
+    DPMM_TILE_DISPATCH(b.tile,
+        DPMM_LAUNCH(hist_kernel<512>, dim3(nt), dim3(64), nbins * sizeof(int), s, bins, n, nbins, nt, b.tile_cnt, (int32_t *)nullptr, (uint16_t *)nullptr, (uint8_t *)nullptr),
+        DPMM_LAUNCH(hist_kernel<2048>, dim3(nt), dim3(64), nbins * sizeof(int), s, bins, n, nbins, nt, b.tile_cnt, (int32_t *)nullptr, (uint16_t *)nullptr, (uint8_t *)nullptr));
     DPMM_LAUNCH(scan_tiles_kernel, dim3(nbins), dim3(256), 0, s, b.tile_cnt, b.tile_hist, nt, b.bin_total);
     return hipGetLastError();
 }
 // The sort of the per-step pass in four launches (n > 0): histogram (+ running totals) -> [caller: all-reduce of the totals] ->
 // launch_step_reset (flags, sub-label reset, re-count of the touched tiles) -> launch_step_scan_scatter (scan + starts, scatter).
 hipError_t launch_step_hist(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s) {
-    const int nt = (int)((n + SORT_TILE - 1) / SORT_TILE);
-    DPMM_LAUNCH(hist_kernel, dim3(nt), dim3(64), nbins * sizeof(int), s, bins, n, nbins, nt, b.tile_cnt, b.fast_total,
-                       b.prev_lab, b.prev_lab ? b.cdirty : (uint8_t *)nullptr);
+    const int nt = sort_nt(n, b);
+    uint8_t *dirty = b.prev_lab ? b.cdirty : (uint8_t *)nullptr;
+    DPMM_TILE_DISPATCH(b.tile,
+        DPMM_LAUNCH(hist_kernel<512>, dim3(nt), dim3(64), nbins * sizeof(int), s, bins, n, nbins, nt, b.tile_cnt, b.fast_total, b.prev_lab, dirty),
+        DPMM_LAUNCH(hist_kernel<2048>, dim3(nt), dim3(64), nbins * sizeof(int), s, bins, n, nbins, nt, b.tile_cnt, b.fast_total, b.prev_lab, dirty));
     return hipGetLastError();
 }
 hipError_t launch_step_reset(int32_t *bins, int64_t n, int64_t first, int nbins, const SortBufs &b, const long long *global_counts, uint8_t *flags,
                              int K, uint64_t seed, uint32_t epoch, hipStream_t s) {
-    const int nt = (int)((n + SORT_TILE - 1) / SORT_TILE);
-    DPMM_LAUNCH(reset_recount_kernel, dim3(nt), dim3(64), nbins * sizeof(int) + ((K + 3) & ~3), s, bins, n, first, nbins, nt, b.fast_total,
-                       global_counts, b.tile_cnt, flags, K, seed, epoch);
+    const int nt = sort_nt(n, b);
+    const size_t lds = nbins * sizeof(int) + ((K + 3) & ~3);
+    DPMM_TILE_DISPATCH(b.tile,
+        DPMM_LAUNCH(reset_recount_kernel<512>, dim3(nt), dim3(64), lds, s, bins, n, first, nbins, nt, b.fast_total, global_counts, b.tile_cnt, flags, K, seed, epoch),
+        DPMM_LAUNCH(reset_recount_kernel<2048>, dim3(nt), dim3(64), lds, s, bins, n, first, nbins, nt, b.fast_total, global_counts, b.tile_cnt, flags, K, seed, epoch));
     return hipGetLastError();
 }
 
@@ -690,6 +702,14 @@ __device__ __forceinline__ void range_heads(int i0, int i1, int T, int G, int &w
     wa = (int)((((long long)i0 + 1) * G + T - 1) / T);
     wb = (int)(((long long)i1 * G + T - 1) / T) - 1;
 }
+// Slab SLOTS (the items used to name them: one 21 KB slab per item id, i.e. n / chunk of them allocated -- which tied the granularity of
+// the balance to the memory the context holds): the head at a workgroup boundary B(w) lives in slot w, a head at the start of a bin that
+// falls INSIDE a workgroup's range in slot NIW_STATS_MAX_GROUPS + bin.  NIW_STATS_MAX_GROUPS + 2 K slots whatever the item size.
+__device__ __forceinline__ int range_owner(int item, int T, int G) { return (int)((((long long)item + 1) * G + T - 1) / T) - 1; }   // w with B(w) <= item < B(w+1)
+__device__ __forceinline__ int head_slot(int item, int bin, int T, int G) {
+    const int w = range_owner(item, T, G);
+    return range_bound(w, T, G) == item ? w : NIW_STATS_MAX_GROUPS + bin;
+}
 template <int NBK>
 __global__ __launch_bounds__(64 * StatCfg<NBK>::NPANEL) void niw_stats_kernel(StatsArgs A) {
     using C = StatCfg<NBK>;
@@ -705,7 +725,7 @@ __global__ __launch_bounds__(64 * StatCfg<NBK>::NPANEL) void niw_stats_kernel(St
         const int bcnt = A.sb.bin_total[b];
         const int seg = A.sb.bin_start[b] + j * A.chunk;
         const int cnt = min((e - item) * A.chunk, bcnt - j * A.chunk);
-        double *slab = A.slabs + (int64_t)item * A.slab_stride;
+        double *slab = A.slabs + (int64_t)(item == it0 ? (int)blockIdx.x : NIW_STATS_MAX_GROUPS + b) * A.slab_stride;
         const int panel = threadIdx.x >> 6;
         if constexpr (C::NPANEL == 1) {
             niw_stats_body<NBK, 0>(A, seg, cnt, slab);
@@ -781,47 +801,78 @@ hipError_t launch_niw_row_offsets(int32_t *row_off, int32_t *inv_off, int D, int
 // large cluster than for a small one) are cut into REDUCE_PARTS contiguous runs summed by different threads, eight loads in flight
 // each, and the partial sums are combined in part order -- a fixed summation tree, so the rows stay bitwise reproducible.
 constexpr int REDUCE_PARTS = 4;
+// One workgroup = 64 slab positions of ONE CLUSTER (both of its bins, one after the other: in a derived pass only one of them was
+// computed).  With `A.mode` (per-step pass with derived statistics) the derivation of the sub-cluster that was NOT computed happens right
+// here, on the sums the thread just formed, instead of in a launch of its own behind this one (derive_rows_kernel: still used by the
+// Multinomial path): mode[k] = 0: cache[k] = left + right; 1 / 2: left / right = cache[k] - the computed row.  N comes from the bin totals
+// either way (integers, known for every bin whether or not it was selected).  Same heads, same parts, same order per element as before:
+// bitwise the same rows.
 __global__ __launch_bounds__(64 * REDUCE_PARTS) void niw_reduce_kernel(StatsArgs A, int NBK) {
     // a thread owns a slab POSITION (consecutive threads read consecutive doubles of a slab: the gather through row_off touched runs of
-    // at most 16) and writes its sum to the packed-row element the inverse table names; same heads, same parts, same order per element
-    __shared__ double part_sum[REDUCE_PARTS][64];
-    const int b = blockIdx.y;
+    // at most 16) and writes its sum to the packed-row element the inverse table names
+    __shared__ double part_sum[2][REDUCE_PARTS][64];
+    const int k = blockIdx.y;
     const int el = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int64_t pos = blockIdx.x * 64ll + el;
     const int e = pos < A.slab_stride ? A.inv_off[pos] : -1;           // packed-row element of this position (>= 1) or none
     const bool live = e >= 1;
-    double *out = A.out + (int64_t)b * A.packed_stride;
-    if (!A.sb.bin_sel[b]) { if (part == 0) { if (live) out[e] = 0.; if (pos == 0) out[0] = 0.; } return; }
-    const int i0 = A.sb.item_start[b], i1 = A.sb.item_start[b + 1];
     const int total_items = A.sb.item_start[A.nbins];
     const int G = min(A.range_groups, total_items);                          // as in niw_stats_kernel
-    // segment heads of the bin, in item order: i0, then every workgroup boundary strictly inside (i0, i1)
-    int wa = 1, wb = 0;
-    if (i1 > i0) range_heads(i0, i1, total_items, G, wa, wb);
-    const int nheads = i1 > i0 ? 1 + max(0, wb - wa + 1) : 0;
-    const int h0 = (int)((int64_t)nheads * part / REDUCE_PARTS), h1 = (int)((int64_t)nheads * (part + 1) / REDUCE_PARTS);
-    double s = 0.;
-    if (live) {
-        for (int h = h0; h < h1; h += 8) {
-            double v[8];
+    bool sel[2];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int hh = h + u;
-                const int it = hh == 0 ? i0 : range_bound(wa + hh - 1, total_items, G);
-                v[u] = hh < h1 ? A.slabs[(int64_t)it * A.slab_stride + pos] : 0.;
+    for (int sd = 0; sd < 2; ++sd) {
+        const int b = 2 * k + sd;
+        sel[sd] = A.sb.bin_sel[b] != 0;
+        double s = 0.;
+        if (sel[sd] && live) {
+            const int i0 = A.sb.item_start[b], i1 = A.sb.item_start[b + 1];
+            // segment heads of the bin, in item order: i0, then every workgroup boundary strictly inside (i0, i1)
+            int wa = 1, wb = 0;
+            if (i1 > i0) range_heads(i0, i1, total_items, G, wa, wb);
+            const int nheads = i1 > i0 ? 1 + max(0, wb - wa + 1) : 0;
+            const int slot0 = i1 > i0 ? head_slot(i0, b, total_items, G) : 0;
+            const int h0 = (int)((int64_t)nheads * part / REDUCE_PARTS), h1 = (int)((int64_t)nheads * (part + 1) / REDUCE_PARTS);
+            for (int h = h0; h < h1; h += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int hh = h + u;
+                    const int slot = hh == 0 ? slot0 : wa + hh - 1;
+                    v[u] = hh < h1 ? A.slabs[(int64_t)slot * A.slab_stride + pos] : 0.;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (h + u < h1) s += v[u];
             }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) if (h + u < h1) s += v[u];
         }
+        part_sum[sd][part][el] = s;
     }
-    part_sum[part][el] = s;
     __syncthreads();
     if (part != 0) return;
-    if (pos == 0) out[0] = (double)A.sb.bin_total[b];
+    double *outl = A.out + (int64_t)(2 * k) * A.packed_stride, *outr = outl + A.packed_stride;
+    const int m = A.mode ? (int)A.mode[k] : -1;
+    double *c = A.mode ? A.cache + (int64_t)k * A.packed_stride : nullptr;
+    if (pos == 0) {
+        // element 0 = N: the bin totals, exact for computed and derived rows alike
+        const double nl = (double)A.sb.bin_total[2 * k], nr = (double)A.sb.bin_total[2 * k + 1];
+        outl[0] = (m >= 0 || sel[0]) ? nl : 0.;
+        outr[0] = (m >= 0 || sel[1]) ? nr : 0.;
+        if (m == 0) c[0] = nl + nr;
+        if (A.mode) {
+            A.dirty[k] = 0;
+            if (k == 0) A.dirty[DPMM_MAX_CLUSTERS_K] = 0;
+        }
+    }
+    // rider: the bad-cluster flags of the pass go to the host's pinned block from here (no copy kernel of their own)
+    if (A.flags_dst && blockIdx.x == 0 && k == 0) for (int i = el; i <= A.K; i += 64) A.flags_dst[i] = A.flags_src[i];
     if (!live) return;
+    double sl = part_sum[0][0][el], sr = part_sum[1][0][el];
 #pragma unroll
-    for (int p = 1; p < REDUCE_PARTS; ++p) s += part_sum[p][el];
-    out[e] = s;
+    for (int p = 1; p < REDUCE_PARTS; ++p) { sl += part_sum[0][p][el]; sr += part_sum[1][p][el]; }
+    if (m == 0) c[e] = sl + sr;
+    else if (m == 1) sl = c[e] - sr;
+    else if (m == 2) sr = c[e] - sl;
+    outl[e] = sl;                                                        // (a bin that was neither selected nor derived: zero)
+    outr[e] = sr;
 }
 
 int64_t niw_slab_stride(int D) {
@@ -838,12 +889,12 @@ hipError_t launch_niw_stats(const StatsArgs &a0, hipStream_t s) {
     // nothing is gained from a longer grid.  Measured (scripts/stats_groups_sweep.py): D <= 64: 2048 at N = 1e7 (0.98 ms; 1024: 1.00,
     // 512: 1.84); D = 128 (four panels on the shared data path): 512 (0.50 ms; 256: 0.55, 1024: 0.53, 2048: 0.60); D = 256 (one
     // workgroup per compute unit fits): 256.  Small passes: a workgroup per ~128 points at least (a slab is 21 KB at D = 64 -- as much
-    // as 80 points of input -- and every one is written, read back and summed by the reduce).
-    int dflt = NBK <= 4 ? 2048 : (NBK <= 8 ? 512 : 256);
+    // as 80 points of input -- and every one is written, read back and summed by the reduce: 1024 groups below 2.5e6 points, where the
+    // reduce of 2048 slabs costs more than the second wave per SIMD gains).
+    int dflt = NBK <= 4 ? (a.n >= 2500000 ? 2048 : 1024) : (NBK <= 8 ? 512 : 256);
     if (NBK <= 4) { const int64_t by_points = (a.n + 127) / 128; if (by_points < dflt) dflt = (int)(by_points < 64 ? 64 : by_points); }
     int groups = a.range_groups > 0 ? a.range_groups : dflt;
-    const int max_items = a.max_items < 1 ? 1 : a.max_items;
-    if (groups > max_items) groups = max_items;
+    if (groups > NIW_STATS_MAX_GROUPS) groups = NIW_STATS_MAX_GROUPS;
     a.range_groups = groups;
     switch (NBK) {
         case 1: DPMM_LAUNCH((niw_stats_kernel<1>), dim3(groups), dim3(64), 0, s, a); break;
@@ -852,7 +903,7 @@ hipError_t launch_niw_stats(const StatsArgs &a0, hipStream_t s) {
         case 8: DPMM_LAUNCH((niw_stats_kernel<8>), dim3(groups), dim3(256), 0, s, a); break;
         default: DPMM_LAUNCH((niw_stats_kernel<16>), dim3(groups), dim3(512), 0, s, a); break;
     }
-    DPMM_LAUNCH(niw_reduce_kernel, dim3((unsigned)((a.slab_stride + 63) / 64), a.nbins), dim3(64 * REDUCE_PARTS), 0, s, a, NBK);
+    DPMM_LAUNCH(niw_reduce_kernel, dim3((unsigned)((a.slab_stride + 63) / 64), a.nbins / 2), dim3(64 * REDUCE_PARTS), 0, s, a, NBK);
     return hipGetLastError();
 }
 
@@ -975,22 +1026,24 @@ hipError_t launch_mult_stats(const StatsArgs &a, hipStream_t s) {
 }
 
 // second half of the sort (needs the selection mask and the chunk size of the statistics pass)
+static void launch_scatter(const int32_t *bins, const StatsArgs &a, int nt, hipStream_t s) {
+    DPMM_TILE_DISPATCH(a.sb.tile,
+        DPMM_LAUNCH(scatter_kernel<512>, dim3(nt), dim3(64), a.nbins * sizeof(int), s, bins, a.n, a.nbins, nt, a.sb.tile_hist, a.sb.bin_start, a.sb.perm),
+        DPMM_LAUNCH(scatter_kernel<2048>, dim3(nt), dim3(64), a.nbins * sizeof(int), s, bins, a.n, a.nbins, nt, a.sb.tile_hist, a.sb.bin_start, a.sb.perm));
+}
 hipError_t launch_step_scan_scatter(const int32_t *bins, const StatsArgs &a, int derive, int force_all, hipStream_t s) {
-    const int nt = (int)((a.n + SORT_TILE - 1) / SORT_TILE);
+    const int nt = sort_nt(a.n, a.sb);
     DPMM_LAUNCH(scan_starts_kernel, dim3(a.nbins), dim3(256), 0, s, a.sb.tile_cnt, a.sb.tile_hist, nt, a.sb.bin_total, a.sb.bin_sel, a.chunk,
                        a.sb.bin_start, a.sb.item_start, a.sb.perm_total, a.sb.fast_total, a.sb.ticket,
                        derive ? a.sb.cmode : (uint8_t *)nullptr, a.sb.cdirty, force_all);
-    DPMM_LAUNCH(scatter_kernel, dim3(nt), dim3(64), a.nbins * sizeof(int), s, bins, a.n, a.nbins, nt,
-                       a.sb.tile_hist, a.sb.bin_start, a.sb.perm);
+    launch_scatter(bins, a, nt, s);
     return hipGetLastError();
 }
 hipError_t launch_sort_finish(const int32_t *bins, const StatsArgs &a, hipStream_t s) {
-    const int nt = (int)((a.n + SORT_TILE - 1) / SORT_TILE);
+    const int nt = sort_nt(a.n, a.sb);
     DPMM_LAUNCH(starts_kernel, dim3(1), dim3(256), 0, s, a.sb.bin_total, a.sb.bin_sel, a.nbins, a.chunk,
                        a.sb.bin_start, a.sb.item_start, a.sb.perm_total);
-    if (nt > 0)
-        DPMM_LAUNCH(scatter_kernel, dim3(nt), dim3(64), a.nbins * sizeof(int), s, bins, a.n, a.nbins, nt,
-                           a.sb.tile_hist, a.sb.bin_start, a.sb.perm);
+    if (nt > 0) launch_scatter(bins, a, nt, s);
     return hipGetLastError();
 }
 

@@ -76,6 +76,7 @@ enum {
     DPMM_OPT_REF_BRACKET = 18,        /* 1 (default): D in 49..64 sweep, waves whose points all had the same label: the reference cluster's value is first BRACKETED
                                          (two bf16 matrix passes with a certified rounding bound, ~1/7 of a Float32 evaluation) and evaluated in Float32 only
                                          if some other cluster survives the screens against the bracket's lower end; same labels; 0: always evaluated */
+    DPMM_OPT_SORT_TILE = 19,          /* points per sorting wave of the statistics passes: 512 (default below 4e6 points per shard) or 2048 */
     DPMM_OPT_KERNEL_TIMING = 15,      /* bit mask: 1 = HIP events around the sweep kernel, 2 = around the statistics pass (dpmm_last_kernel_ms), 4 = around the
                                          all-reduces (dpmm_last_comm_ms); 0 (default): none -- every event is a barrier packet between two kernels, ~5 us each */
     DPMM_OPT_WAVE_PRIO = 10       /* 0 / 1: NIW sweep (D <= 64) lowers a wave's issue priority while it streams matrix instructions and
