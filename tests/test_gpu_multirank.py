@@ -26,7 +26,7 @@ CASES = {
     # name: (prior, D, N, true components, iterations, burnout, device master option (-1 auto / 0 / 1))
     "niw64_dev": ("niw", 64, 200000, 6, 60, 8, 1),
     "niw64_host": ("niw", 64, 200000, 6, 60, 8, 0),
-    "niw8": ("niw", 8, 60000, 5, 60, 6, -1),
+    "niw8": ("niw", 8, 60001, 5, 60, 6, -1),           # (N % 2, N % 3, N % 8 all non-zero)
     "mult100": ("mult", 100, 60000, 6, 50, 6, -1),
     "mult200_dev": ("mult", 200, 40000, 5, 50, 6, 1),      # the Dirichlet draws on each rank's device, from the all-reduced rows
 }
@@ -43,7 +43,22 @@ def _data(host, case):
     return np.ascontiguousarray(x, np.float32), np.asarray(y), hyper
 
 
-def _run(rank, world, port, out, case, backend):
+# how the N points are cut into `world` contiguous shards: None = the product's even split (N r // world); else explicit boundaries
+LAYOUTS = {
+    "even2": (2, None),
+    "uneven3": (3, None),                         # N % 3 != 0 in the cases below: shards of different sizes
+    "empty3": (3, lambda N: [0, N // 2, N, N]),   # the last rank holds NO points (n_local = 0): its rows are zeros, its engine still decides
+    "tiny3": (3, lambda N: [0, 7, N - 5, N]),     # shards of 7 and 5 points next to a big one: tiles, items and slabs of almost nothing
+    "even8": (8, None),                           # what the driver's 8-GPU run does, eight ranks on ONE device over the host transport
+}
+
+
+def _bounds(layout, N):
+    world, f = LAYOUTS[layout]
+    return f(N) if f is not None else [(N * r) // world for r in range(world + 1)]
+
+
+def _run(rank, world, port, out, case, backend, layout="even2"):
     sys.path.insert(0, ROOT)
     from __graft_entry__ import load_package
     pkg = load_package()
@@ -63,7 +78,8 @@ def _run(rank, world, port, out, case, backend):
             dist.init_process_group("gloo", rank=rank, world_size=world)
         comm = TorchDistComm(device=device)
     x, y, hyper = _data(host, case)
-    lo, hi = (N * rank) // world, (N * (rank + 1)) // world
+    bnd = _bounds(layout, N) if world > 1 else [0, N]
+    lo, hi = bnd[rank], bnd[rank + 1]
     wk = pkg.Worker(hyper.kind, D, hi - lo, first_index=lo, device=device, seed=99)
     wk.upload_points(np.ascontiguousarray(x[:, lo:hi].T))
     s = host.DPMMSampler(wk, hyper, 10.0, N, 99, burnout=burnout, comm=comm)
@@ -85,14 +101,14 @@ def _run(rank, world, port, out, case, backend):
         dist.destroy_process_group()
 
 
-def _spawn(world, port, out, case, backend):
-    mp.spawn(_run, args=(world, port, out, case, backend), nprocs=world, join=True)
+def _spawn(world, port, out, case, backend, layout="even2"):
+    mp.spawn(_run, args=(world, port, out, case, backend, layout), nprocs=world, join=True)
 
 
-def _compare(a, b, case, transport):
+def _compare(a, b, case, transport, world=2):
     prior, D, N, K, iters, burnout, dev = CASES[case]
     stride = 1 + D + (D * (D + 1) // 2 if prior == "niw" else 0)
-    assert int(b["world"]) == 2 and str(b["transport"]) == transport
+    assert int(b["world"]) == world and str(b["transport"]) == transport
     assert int(b["rows_bytes"]) == 2 * int(b["K"][-1]) * stride * 8           # the last pass all-reduced the packed rows of 2K bins
     assert int(b["counts_bytes"]) == 2 * int(b["K"][-1]) * 8
     assert int(b["allreduces"]) >= 2 * iters                                  # occupancies + rows, every step
@@ -102,13 +118,13 @@ def _compare(a, b, case, transport):
     sflips = int(((a["sub"] != b["sub"]) & (a["labels"] == b["labels"])).sum())
     print(f"{case}/{transport}: K history equal (final {b['K'][-1]}), label flips {flips}/{N}, sub-label flips {sflips}, "
           f"all-reduce ms (counts, rows) {b['comm_ms']}")
-    # the statistics are Float64 sums over the shards in a different association than the one-rank pass: parameters agree to ~1e-13,
-    # so a draw can differ only where a uniform falls within that of a CDF edge
-    assert flips <= max(2, N // 20000) and sflips <= max(2, N // 10000)
-    if flips == 0 and sflips == 0:
-        np.testing.assert_allclose(a["rows"], b["rows"], rtol=1e-11, atol=1e-9)
-        np.testing.assert_allclose(a["weights"], b["weights"], rtol=1e-6)
-        assert abs(float(a["logpost"]) - float(b["logpost"])) <= 1e-9 * abs(float(a["logpost"]))
+    # The statistics are Float64 sums over the shards in another association than the one-rank pass: rows and parameters agree to ~1e-13
+    # relative, so a draw differs only where a uniform falls within that of a CDF edge -- not once in these chains (measured: 0 flips in
+    # every case of rounds 3 and 4).  The test asserts what is measured: the SAME chain.
+    assert flips == 0 and sflips == 0, (flips, sflips)
+    np.testing.assert_allclose(a["rows"], b["rows"], rtol=1e-11, atol=1e-9)
+    np.testing.assert_allclose(a["weights"], b["weights"], rtol=1e-6)
+    assert abs(float(a["logpost"]) - float(b["logpost"])) <= 1e-9 * abs(float(a["logpost"]))
 
 
 @pytest.mark.timeout(900)
@@ -121,6 +137,26 @@ def test_two_ranks_share_one_gpu_host_transport(tmp_path, case):
     _spawn(1, port, o1, case, "gloo")
     _spawn(2, port + 1, o2, case, "gloo")
     _compare(np.load(o1), np.load(o2), case, "host")
+
+
+MORE_RANKS = [("niw8", "uneven3"), ("niw8", "empty3"), ("niw64_dev", "tiny3"), ("mult100", "empty3"), ("niw8", "even8"), ("niw64_dev", "even8"),
+              ("mult200_dev", "even8")]
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("case,layout", MORE_RANKS)
+def test_more_ranks_and_ragged_shards_share_one_gpu(tmp_path, case, layout):
+    """World sizes 3 and 8, N % world != 0, a rank WITHOUT points and shards of a handful of points -- through the library's own collective path
+    (host transport: all ranks on device 0).  The chain must be the one-rank chain: K history, every label and sub-label, rows to 1e-11.
+    The driver's first real 8-rank run must not be the first 8-rank run of this code."""
+    if torch.cuda.device_count() < 1:
+        pytest.skip("no GPU")
+    world = LAYOUTS[layout][0]
+    o1, o2 = str(tmp_path / "r1.npz"), str(tmp_path / "rw.npz")
+    port = 29800 + 3 * MORE_RANKS.index((case, layout))
+    _spawn(1, port, o1, case, "gloo")
+    _spawn(world, port + 1, o2, case, "gloo", layout)
+    _compare(np.load(o1), np.load(o2), case, "host", world)
 
 
 @pytest.mark.timeout(900)
@@ -168,3 +204,21 @@ def test_bench_starts_its_own_ranks_and_reports_the_collective(tmp_path):
     assert d["comm"]["world"] == 2 and d["comm"]["transport"] == ("host" if share else "rccl")
     assert d["comm"]["rows_allreduce_bytes"] == 2 * 32 * (1 + 64 + 64 * 65 // 2) * 8 and d["comm"]["rows_allreduce_ms"] > 0
     assert d["config"]["points_per_gpu"] == 200000 and d["growth"]["K_final"] >= 2
+
+
+@pytest.mark.timeout(1500)
+def test_bench_with_eight_ranks_on_one_gpu(tmp_path):
+    """`bench.py --gpus 8 --share-gpu`: the whole 8-rank bench path (own launcher, barrier + max-over-ranks timing, the collective's report,
+    growth run, host-master leg) on one device over the host transport, small N."""
+    import json
+    import subprocess
+    if torch.cuda.device_count() < 1:
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--share-gpu", "--points", "800000", "--steps", "5", "--warmup", "1",
+                        "--settle", "5", "--blocks", "1", "--no-legs", "--no-cpu-baseline", "--no-dense", "--growth-iters", "40"],
+                       env=env, capture_output=True, text=True, timeout=1400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["value"] > 0 and d["comm"]["world"] == 8 and d["comm"]["transport"] == "host"
+    assert d["config"]["points_per_gpu"] == 100000 and d["growth"]["K_final"] >= 2 and d["host_master"]["it_per_s"] > 0

@@ -1,10 +1,13 @@
-"""The Julia `ccall` stub in INTEGRATION.md cannot be executed here (no Julia in the image), so its array comprehensions are
-checked mechanically: each `Float32[... for ...]` line of `set_params!` is parsed, its iteration order is emulated with
+"""The Julia bindings under julia/ (gpu_engine.jl: master + worker native; gpu_worker.jl: worker side only) cannot be executed here (no
+Julia in the image), so they are checked mechanically.  (1) Array comprehensions: each `Float32[... for ...]` line of `set_params!` is parsed, its iteration order is emulated with
 itertools following Julia's rules (a flattened generator `for a in A for b in B` nests left to right -- the rightmost `for`
 runs fastest; a product `for a in A, b in B` fills column-major -- the LEFTMOST variable runs fastest), and the resulting
 memory order is compared with the layouts include/dpmm_hip.h prescribes and the ctypes binding sends:
     mu [3K][D], inv_sigma [3K][D][D], logdet [3K], lr_weights [K][2], logp [3K][D].
-(Round 1 shipped a stub whose mu / inv / logp comprehensions put the distribution index fastest.)"""
+(Round 1 shipped a stub whose mu / inv / logp comprehensions put the distribution index fastest.)
+(2) Every symbol a file names in a `ccall` / `dlsym` is declared in the header it binds; (3) every ccall passes as many argument TYPES
+and as many VALUES as the C prototype has parameters; (4) `WorkerTable` has the members of `struct dpmmh_worker` in header order and
+`native_table` fills them with the entry points the header names next to each member."""
 import itertools
 import os
 import re
@@ -14,8 +17,15 @@ import numpy as np
 from __graft_entry__ import ROOT
 
 
+JL_FILES = ("gpu_engine.jl", "gpu_worker.jl", "host_transport_mpi.jl")
+
+
+def _jl(name):
+    return open(os.path.join(ROOT, "julia", name)).read()
+
+
 def _stub_lines():
-    txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    txt = _jl("gpu_worker.jl")
     out = {}
     for m in re.finditer(r"^\s*(\w+)\s*=\s*Float32\[(.+?)\]\s*(?:#.*)?$", txt, flags=re.M):
         out.setdefault(m.group(1), []).append(m.group(2))
@@ -94,3 +104,96 @@ def test_binding_sends_row_major_3k_by_d():
     """binding.Worker.set_params_* pass C-contiguous (3K, D) / (3K, D*D) arrays: row 3k+w, feature fastest."""
     src = open(os.path.join(ROOT, "dpmmsubclusters.jl_amd", "binding.py")).read()
     assert "mu.shape == (3 * K, self.D)" in src and "logp.shape == (3 * K, self.D)" in src and "np.ascontiguousarray" in src
+
+
+# ---------------------------------------------------------------------------------------------- symbols and prototypes
+def _c_prototypes():
+    """name -> number of parameters, from the four public headers."""
+    protos = {}
+    for h in ("dpmm_hip.h", "dpmm_hip_master.h", "dpmm_hip_debug.h", "dpmm_host.h"):
+        src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", h)).read(), flags=re.S)
+        src = src[:src.index("typedef struct dpmmh_worker {")] + src[src.index("} dpmmh_worker;"):] if "typedef struct dpmmh_worker {" in src else src
+        for m in re.finditer(r"\b(dpmmh?_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+            args = m.group(2).strip()
+            # split on top-level commas (function-pointer parameters hold commas of their own)
+            depth, n = 0, 1 if args and args != "void" else 0
+            for ch in args:
+                depth += ch == "("
+                depth -= ch == ")"
+                if ch == "," and depth == 0:
+                    n += 1
+            protos[m.group(1)] = n
+    return protos
+
+
+def _split_top(sx):
+    out, depth, cur = [], 0, ""
+    for ch in sx:
+        depth += ch in "([{"
+        depth -= ch in ")]}"
+        if ch == "," and depth == 0:
+            out.append(cur.strip()); cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def _ccalls(txt):
+    """[(symbol, n_types, n_values)] of every ccall( ... ) in a Julia source."""
+    res = []
+    for m in re.finditer(r"ccall\(", txt):
+        i, depth = m.end(), 1
+        while depth:
+            depth += txt[i] in "([{"
+            depth -= txt[i] in ")]}"
+            i += 1
+        parts = _split_top(txt[m.end():i - 1])
+        sym = re.search(r":(dpmmh?_[a-z0-9_]+)", parts[0])
+        if sym is None:                     # ccall(step, ...) with step = dlsym(libhost, :dpmmh_group_step) just above
+            var = parts[0].strip()
+            sym = re.search(rf"\b{re.escape(var)}\s*=\s*[^\n]*:(dpmmh?_[a-z0-9_]+)", txt)
+        assert sym is not None, parts[0]
+        types = parts[2].strip()
+        assert types.startswith("(") and types.endswith(")"), types
+        ntypes = len([t for t in _split_top(types[1:-1]) if t])
+        res.append((sym.group(1), ntypes, len(parts) - 3))
+    return res
+
+
+def test_julia_files_name_only_declared_symbols_with_the_declared_arity():
+    protos = _c_prototypes()
+    seen = set()
+    for f in JL_FILES:
+        txt = _jl(f)
+        for name in re.findall(r":(dpmmh?_[a-z0-9_]+)", txt):
+            assert name in protos, (f, name)
+            seen.add(name)
+        for sym, ntypes, nvals in _ccalls(txt):
+            assert ntypes == protos[sym] and nvals == protos[sym], (f, sym, ntypes, nvals, protos[sym])
+    # the worker-side file stays on the drop-in surface: nothing of the device master, nothing of the diagnostics
+    hip_only = set(re.findall(r":(dpmm_[a-z0-9_]+)", _jl("gpu_worker.jl")))
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "dpmm_hip.h")).read(), flags=re.S)
+    assert hip_only <= set(re.findall(r"\b(dpmm_[a-z0-9_]+)\s*\(", src)), hip_only
+    assert {"dpmm_create", "dpmm_sweep", "dpmm_step_stats", "dpmm_comm_init", "dpmmh_group_step", "dpmmh_model_bind_worker"} <= seen
+
+
+def test_worker_table_mirrors_struct_dpmmh_worker():
+    txt = _jl("gpu_engine.jl")
+    body = txt[txt.index("struct WorkerTable"):]
+    body = body[:body.index("\nend")]
+    fields = re.findall(r"(\w+)::", body)
+    hsrc = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "dpmm_host.h")).read(), flags=re.S)
+    struct = hsrc[hsrc.index("typedef struct dpmmh_worker {"):hsrc.index("} dpmmh_worker;")]
+    members = re.findall(r"\(\*([a-z_]+)\)\s*\(", struct)
+    assert fields == ["ctx", "rank", "world"] + members
+    # native_table fills the members, in order, with the entry point the header comment names for each
+    import importlib
+    from __graft_entry__ import load_package
+    load_package()
+    engine = importlib.import_module("dpmmsubclusters_jl_amd.host.engine")
+    call = txt[txt.index("native_table(ctx, rank, world) = WorkerTable("):]
+    call = call[:call.index("\n\n")]
+    syms = re.findall(r"hip\(:(dpmm_[a-z0-9_]+)\)", call)
+    assert syms == [sym for _, sym, _ in engine._NATIVE_MAP]
