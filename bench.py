@@ -458,7 +458,9 @@ def main():
     wk.set_timing(1)
     t_before = dict(s.timers)
     wk.last_sweep_work()              # clear the device's work counters: they add up over the timed launches and are read once afterwards
+    ci0 = wk.comm_info()
     elapsed = timed_block(args.steps, collect)
+    ci1 = wk.comm_info()
     work.append(wk.last_sweep_work())     # per-launch averages over exactly the timed launches
     t_after = dict(s.timers)
     wk.set_timing(7)
@@ -528,6 +530,8 @@ def main():
         "roofline": roof,
         "comm": {"world": info["world"], "transport": info["transport"], "occupancy_allreduce_bytes": info["counts_bytes"],
                  "rows_allreduce_bytes": info["rows_bytes"], "allreduces_since_attach": info["allreduces"],
+                 "one_collective_per_step_pass": info["one_collective"],
+                 "allreduces_per_step_in_timed_block": (ci1["allreduces"] - ci0["allreduces"]) / args.steps,
                  "occupancy_allreduce_ms": float(np.mean([c[0] for c in comm_ms])) if comm_ms else None,
                  "rows_allreduce_ms": float(np.mean([c[1] for c in comm_ms])) if comm_ms else None,
                  "note": "HIP events on the ctx stream around each all-reduce of the timed steps (rank 0); they include waiting for the slowest rank"},

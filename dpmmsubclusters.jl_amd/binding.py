@@ -98,7 +98,7 @@ HOST_ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_voi
 
 # dpmm_set_option keys (include/dpmm_hip.h)
 MASTER_NSCALARS = 8          # DPMM_MASTER_NSCALARS
-OPT_SCREEN_MARGIN, OPT_TAIL_SCREEN, OPT_PRESCREEN, OPT_ORDERED_SWEEP, OPT_MULT_FORCE_F32, OPT_STATS_ITEMS, OPT_STATS_GROUPS, OPT_TRACE_SLOW, OPT_LOGLIK_REF_CONST, OPT_WAVE_PRIO, OPT_MULT_NO_U8, OPT_SWEEP_GRID, OPT_SWEEP_QUEUE_ROUNDS, OPT_BALL_SCREEN, OPT_KERNEL_TIMING, OPT_STATS_DERIVE, OPT_NOISE_AHEAD, OPT_REF_BRACKET, OPT_SORT_TILE = range(1, 20)
+OPT_SCREEN_MARGIN, OPT_TAIL_SCREEN, OPT_PRESCREEN, OPT_ORDERED_SWEEP, OPT_MULT_FORCE_F32, OPT_STATS_ITEMS, OPT_STATS_GROUPS, OPT_TRACE_SLOW, OPT_LOGLIK_REF_CONST, OPT_WAVE_PRIO, OPT_MULT_NO_U8, OPT_SWEEP_GRID, OPT_SWEEP_QUEUE_ROUNDS, OPT_BALL_SCREEN, OPT_KERNEL_TIMING, OPT_STATS_DERIVE, OPT_NOISE_AHEAD, OPT_REF_BRACKET, OPT_SORT_TILE, OPT_ONE_COLLECTIVE = range(1, 21)
 
 
 class DpmmError(RuntimeError):
@@ -457,7 +457,7 @@ class Worker:
         out = np.zeros(8, np.int64)
         self._chk(self._lib.dpmm_comm_info(self._h, _p(out, _c_i64p)))
         return dict(world=int(out[0]), rank=int(out[1]), transport={0: "none", 1: "rccl", 2: "host"}[int(out[2])],
-                    counts_bytes=int(out[3]), rows_bytes=int(out[4]), allreduces=int(out[5]))
+                    counts_bytes=int(out[3]), rows_bytes=int(out[4]), allreduces=int(out[5]), one_collective=bool(out[7]))
 
     def last_comm_ms(self):
         """(occupancy all-reduce ms, packed-row all-reduce ms) of the last statistics pass (HIP events on the ctx stream)."""

@@ -214,6 +214,11 @@ struct dpmm_ctx {
     bool have_comm_ev[2] = {false, false};
     int64_t comm_bytes[2] = {0, 0};    // payload of the last all-reduce of each kind
     int64_t comm_calls = 0;            // all-reduces since the communicator was attached
+    // ONE collective per per-step pass (DPMM_OPT_ONE_COLLECTIVE; NIW, communicator attached): see run_stats
+    int opt_one_collective = 1;
+    uint8_t *d_cside = nullptr;        // [DPMM_MAX_CLUSTERS] clusters whose sub-labels this shard reset speculatively: the side its points were on (1 / 2), 0: none
+    double *d_red = nullptr;           // [3 Kcap][packed_stride]: what travels -- 2K rows of the labels as swept | K re-drawn left rows -- input of the finalize kernel
+    bool last_pass_one_collective = false;
 
     std::string err;
 };
@@ -344,6 +349,7 @@ const char *dpmm_last_error(const dpmm_ctx *ctx) { return ctx ? ctx->err.c_str()
 static void free_params(dpmm_ctx *c) {
     hipFree(c->d_raw); hipFree(c->d_mu); hipFree(c->d_Rp); hipFree(c->d_mup); hipFree(c->d_cst);
     hipFree(c->d_ccache); c->d_ccache = nullptr;
+    hipFree(c->d_red); c->d_red = nullptr;
     hipFree(c->d_scratch); hipFree(c->d_slabs); hipFree(c->d_out); hipFree(c->d_Lp16); hipFree(c->d_tdf); hipFree(c->d_lam); hipFree(c->d_mdist); hipFree(c->d_tail);
     c->d_Lp16 = nullptr; c->d_tdf = nullptr; c->d_lam = nullptr; c->d_mdist = nullptr; c->d_tail = nullptr;
     c->d_raw = c->d_mu = c->d_Rp = c->d_mup = c->d_cst = c->d_scratch = nullptr;
@@ -386,6 +392,7 @@ static int ensure_capacity(dpmm_ctx *c, int K) {
     const size_t nslabs = c->prior == DPMM_PRIOR_NIW ? (size_t)NIW_STATS_MAX_GROUPS + 2 * (size_t)cap : (size_t)c->max_items;
     HIPCHK(c, hipMalloc(&c->d_slabs, sizeof(double) * nslabs * (size_t)c->slab_stride));
     HIPCHK(c, hipMalloc(&c->d_out, sizeof(double) * 2 * cap * (size_t)c->packed_stride + DPMM_MAX_CLUSTERS + 64));   // rows | bad-cluster flags
+    HIPCHK(c, hipMalloc(&c->d_red, sizeof(double) * 3 * (size_t)cap * (size_t)c->packed_stride));
     HIPCHK(c, hipMalloc(&c->d_ccache, sizeof(double) * cap * (size_t)c->packed_stride));
     HIPCHK(c, hipMemsetAsync(c->d_ccache, 0, sizeof(double) * cap * (size_t)c->packed_stride, c->stream));      // (on the stream its readers run on)
     c->cache_force = true;
@@ -485,6 +492,8 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
     CHK_CREATE(hipMalloc(&c->sb.perm_total, sizeof(int32_t)));
     CHK_CREATE(hipMalloc(&c->d_small, sizeof(int32_t) * 4 * DPMM_MAX_CLUSTERS));
     CHK_CREATE(hipMalloc(&c->d_counts64, sizeof(long long) * 2 * DPMM_MAX_CLUSTERS));
+    CHK_CREATE(hipMalloc(&c->d_cside, DPMM_MAX_CLUSTERS));
+    CHK_CREATE(hipMemsetAsync(c->d_cside, 0, DPMM_MAX_CLUSTERS, c->stream));
     CHK_CREATE(hipMalloc(&c->d_work, sizeof(unsigned long long) * (DPMM_WORK_SLOTS + 4 * DPMM_WORK_PER_WAVE * (size_t)std::max(1, c->sweep_grid_max))));
     CHK_CREATE(hipMemsetAsync(c->d_work, 0, sizeof(unsigned long long) * (DPMM_WORK_SLOTS + 4 * DPMM_WORK_PER_WAVE * (size_t)std::max(1, c->sweep_grid_max)), c->stream));
 #undef CHK_CREATE
@@ -516,7 +525,7 @@ int dpmm_destroy(dpmm_ctx *c) {
     if (c->h_draw) hipHostFree(c->h_draw);
     hipFree(c->d_malpha); hipFree(c->d_mpairs);
     if (c->h_marg) hipHostFree(c->h_marg);
-    hipFree(c->d_counts64); hipFree(c->d_row_off); hipFree(c->d_inv_off); hipFree(c->d_work); hipFree(c->d_par);
+    hipFree(c->d_counts64); hipFree(c->d_cside); hipFree(c->d_row_off); hipFree(c->d_inv_off); hipFree(c->d_work); hipFree(c->d_par);
     comm_release(c);
     if (c->h_red) hipHostFree(c->h_red);
     for (auto &e : c->ev_comm) if (e) hipEventDestroy(e);
@@ -1101,12 +1110,25 @@ static int ensure_out(dpmm_ctx *c, size_t bytes) {
 
 // One statistics pass on the ctx stream (asynchronous): [sub-cluster occupancies -> bad-cluster reset ->] sort by bin ->
 // segmented statistics -> packed rows in c->d_out [-> all-reduce over the ranks].
+// with_reset (the per-step pass) has two forms when a communicator is attached:
+//   two collectives (DPMM_OPT_ONE_COLLECTIVE = 0, Multinomial): histogram -> ALL-REDUCE of the 2K Int64 occupancies -> flags + reset +
+//       re-count -> scan / scatter -> statistics -> ALL-REDUCE of the 2K packed rows.  The first collective sits in the middle of the sort chain.
+//   one collective (NIW, default): the reset is applied SPECULATIVELY to this shard's candidates -- clusters with exactly one empty
+//       sub-cluster HERE; a cluster that is bad globally is a candidate on every rank that holds points of it -- and ONE ALL-REDUCE
+//       carries 3K rows: the 2K rows of the labels AS SWEPT (for a candidate: everything on the side its points were on, rebuilt from
+//       left' + right') and K re-drawn left rows X.  Behind it niw_finalize_rows_kernel reads the verdict off the rows' own N column:
+//       bad cluster -> (X, left + right - X), anything else -> the rows as they are; a shard's candidate that is not bad gets its
+//       sub-labels back (all of its points were on one side).  No history, no second pass, 1.5x the bytes of a 1.1 MB message.
+//   Same end state as the reference's full pass + subset pass (update_suff_stats_posterior! + reset_bad_clusters!,
+//   src/local_clusters_actions.jl:665-666, 501-516) either way; tests/test_gpu_multirank.py: the chains are the one-rank chain.
 static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset = false, uint32_t reset_epoch = 0, uint8_t *flags_to = nullptr,
                      bool *flags_sent = nullptr) {
     if (!c->have_points || !c->have_labels || c->K < 1) return fail(c, DPMM_ESTATE, "suffstats need points, labels and parameters (K)");
     HIPCHK(c, hipSetDevice(c->device));
     const int nbins = 2 * c->K;
     c->marg_valid = false;
+    const bool one_coll = with_reset && comm_attached(c) && c->opt_one_collective && c->prior == DPMM_PRIOR_NIW;
+    c->last_pass_one_collective = one_coll;
     if (c->opt_timing & 2) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     if (idx) {
         c->h_sel.assign(nbins, 0);
@@ -1131,20 +1153,21 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
     a.X = c->dX; a.ldx = c->ldx; a.n = c->n; a.D = c->D; a.nbins = nbins; a.chunk = c->chunk;
     a.max_items = (int)((c->n + c->chunk - 1) / c->chunk) + nbins;
     a.range_groups = c->opt_stats_groups;
-    a.sb = c->sb; a.slabs = c->d_slabs; a.slab_stride = c->slab_stride; a.out = c->d_out; a.packed_stride = c->packed_stride; a.row_off = c->d_row_off; a.inv_off = c->d_inv_off;
+    a.sb = c->sb; a.slabs = c->d_slabs; a.slab_stride = c->slab_stride; a.out = one_coll ? c->d_red : c->d_out; a.packed_stride = c->packed_stride; a.row_off = c->d_row_off; a.inv_off = c->d_inv_off;
     if (with_reset && c->n > 0) {
         // reset_bad_clusters! (local_clusters_actions.jl:501-516) on the device, four launches: histogram (+ running bin totals) ->
         // [occupancies summed over the ranks] -> flags + sub-labels of flagged clusters re-drawn + touched tiles re-counted -> scan + starts
         // -> scatter.  The flags live right behind the packed rows, so that rows + flags reach the master in one copy.
         HIPCHK(c, launch_step_hist(c->dbins, c->n, nbins, c->sb, c->stream));
         const long long *gc = nullptr;
-        if (comm_attached(c)) {
+        if (comm_attached(c) && !one_coll) {
             HIPCHK(c, launch_widen_counts(c->sb.fast_total, FAST_TOTAL_STRIDE, c->d_counts64, nbins, c->stream));
             if (int rc = comm_allreduce(c, c->d_counts64, nbins, /*kind=*/0)) return rc;
             gc = c->d_counts64;
         }
         uint8_t *flags = reinterpret_cast<uint8_t *>(c->d_out) + sizeof(double) * (size_t)nbins * (size_t)c->packed_stride;
-        HIPCHK(c, launch_step_reset(c->dbins, c->n, c->first, nbins, c->sb, gc, flags, c->K, c->seed, reset_epoch, c->stream));
+        // (one collective: this shard's own occupancies decide which clusters are reset speculatively; the verdict follows the all-reduce)
+        HIPCHK(c, launch_step_reset(c->dbins, c->n, c->first, nbins, c->sb, gc, flags, c->K, c->seed, reset_epoch, one_coll ? c->d_cside : nullptr, c->stream));
         // Statistics of the SMALLER sub-cluster only wherever no point entered or left the cluster since its cluster-level row was
         // cached (labels are tracked by the histogram); the other sub-cluster is cache - computed (derive_rows_kernel below)
         derive = c->opt_derive != 0;
@@ -1157,7 +1180,9 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
         } else {
             HIPCHK(c, hipMemsetAsync(c->sb.bin_total, 0, sizeof(int32_t) * nbins, c->stream));
         }
-        if (with_reset) {       // a rank without points: its occupancies are zero, the flags come from the other ranks' counts
+        if (with_reset && one_coll) {
+            HIPCHK(c, hipMemsetAsync(c->d_cside, 0, (size_t)c->K, c->stream));      // a rank without points has no candidates and adds zeros
+        } else if (with_reset) {       // a rank without points: its occupancies are zero, the flags come from the other ranks' counts
             const long long *gc = nullptr;
             if (comm_attached(c)) {
                 HIPCHK(c, launch_widen_counts(c->sb.bin_total, 1, c->d_counts64, nbins, c->stream));
@@ -1171,6 +1196,27 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
     }
     c->have_perm = c->n > 0;
     if (flags_sent) *flags_sent = false;
+    if (one_coll) {
+        uint8_t *flags = reinterpret_cast<uint8_t *>(c->d_out) + sizeof(double) * (size_t)nbins * (size_t)c->packed_stride;
+        const size_t nred = 3 * (size_t)c->K * (size_t)c->packed_stride;
+        if (c->n > 0) {
+            if (derive) { a.mode = c->sb.cmode; a.cache = c->d_ccache; a.dirty = c->sb.cdirty; a.K = c->K; }
+            a.cside = c->d_cside; a.zero2 = flags + c->K;
+            HIPCHK(c, launch_niw_stats(a, c->stream));
+        } else {
+            HIPCHK(c, hipMemsetAsync(c->d_red, 0, sizeof(double) * nred, c->stream));
+            HIPCHK(c, hipMemsetAsync(flags + c->K, 0, 2, c->stream));
+        }
+        // the one exchange of the sweep (update_suff_stats_posterior!, local_clusters_actions.jl:206-254; aggregate_suff_stats)
+        if (int rc = comm_allreduce(c, c->d_red, nred, /*kind=*/1)) return rc;
+        HIPCHK(c, launch_niw_finalize_rows(c->d_red, c->d_out, c->packed_stride, c->K, c->d_cside, flags, c->stream));
+        HIPCHK(c, launch_niw_undo_reset(c->dbins, c->n, c->K, flags, c->d_cside, c->stream));
+        c->comm_bytes[0] = 0;
+        if (c->opt_timing & 2) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+        c->have_stats_ev = (c->opt_timing & 2) != 0;
+        c->rows_full_K = c->K;
+        return DPMM_OK;
+    }
     // (flags_to: the caller's pinned block for the bad-cluster flags -- they ride in the derivation's launch when no collective follows it)
     const bool ride = derive && flags_to != nullptr && !comm_attached(c);
     const uint8_t *fsrc = reinterpret_cast<const uint8_t *>(c->d_out) + sizeof(double) * (size_t)nbins * (size_t)c->packed_stride;
@@ -2150,6 +2196,7 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
         case DPMM_OPT_STATS_DERIVE: c->opt_derive = value != 0; c->cache_force = true; return DPMM_OK;
         case DPMM_OPT_NOISE_AHEAD: c->opt_noise_ahead = value != 0; return DPMM_OK;
         case DPMM_OPT_REF_BRACKET: c->opt_bracket = value != 0; return DPMM_OK;
+        case DPMM_OPT_ONE_COLLECTIVE: c->opt_one_collective = value != 0; return DPMM_OK;
         case DPMM_OPT_SORT_TILE: {
             const int t = (int)value;
             if (t != SORT_TILE && t != SORT_TILE_SMALL) return fail(c, DPMM_EINVAL, "DPMM_OPT_SORT_TILE: 512 or 2048");
@@ -2246,7 +2293,8 @@ int dpmm_comm_info(dpmm_ctx *c, int64_t *out8) {
     out8[0] = c->world; out8[1] = c->rank;
     out8[2] = c->comm ? 1 : (c->host_fn ? 2 : 0);
     out8[3] = c->comm_bytes[0]; out8[4] = c->comm_bytes[1]; out8[5] = c->comm_calls;
-    out8[6] = out8[7] = 0;
+    out8[6] = 0;
+    out8[7] = c->last_pass_one_collective ? 1 : 0;      // the last per-step pass used ONE collective (DPMM_OPT_ONE_COLLECTIVE)
     return DPMM_OK;
 }
 

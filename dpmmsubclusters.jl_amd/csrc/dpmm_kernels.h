@@ -157,7 +157,9 @@ struct SortBufs {
 hipError_t launch_sort_by_bin(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s);
 hipError_t launch_step_hist(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s);
 hipError_t launch_step_reset(int32_t *bins, int64_t n, int64_t first, int nbins, const SortBufs &b, const long long *global_counts, uint8_t *flags,
-                             int K, uint64_t seed, uint32_t epoch, hipStream_t s);
+                             int K, uint64_t seed, uint32_t epoch, uint8_t *cside, hipStream_t s);     // cside != null: speculative reset of this shard's candidates
+hipError_t launch_niw_finalize_rows(const double *red, double *out, int64_t stride, int K, const uint8_t *cside, uint8_t *flags, hipStream_t s);
+hipError_t launch_niw_undo_reset(int32_t *bins, int64_t n, int K, const uint8_t *flags, const uint8_t *cside, hipStream_t s);
 struct StatsArgs;
 hipError_t launch_sort_finish(const int32_t *bins, const StatsArgs &a, hipStream_t s);
 hipError_t launch_step_scan_scatter(const int32_t *bins, const StatsArgs &a, int derive, int force_all, hipStream_t s);
@@ -185,6 +187,9 @@ struct StatsArgs {
     double *cache;          // [K][packed_stride]
     uint8_t *dirty;         // [DPMM_MAX_CLUSTERS_K + 1] cleared for the next pass
     const uint8_t *flags_src; uint8_t *flags_dst; int K;    // rider: bad-cluster flags -> the caller's pinned block (null: none)
+    // one-collective per-step pass: `out` has 3K rows -- [2K rows of the labels as swept | K re-drawn left rows] -- cside [K] says which
+    // clusters' sub-labels were reset speculatively on this shard (suffstats.hip reset_recount_kernel); zero2 = two flag bytes to clear
+    const uint8_t *cside; uint8_t *zero2;
 };
 constexpr int NIW_STATS_MAX_GROUPS = 4096;   // workgroups of the NIW statistics kernel at most; slab slots = this + 2 K (suffstats.hip head_slot)
 int64_t niw_slab_stride(int D);

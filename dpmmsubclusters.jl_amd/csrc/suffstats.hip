@@ -20,6 +20,7 @@
 //
 // f64 MFMA fragment conventions (lane l: i = l & 15, g = l >> 4): A[i][k=g], B[k=g][col=i],
 // C/D element r (0..3): row g + 4r, col i.
+#include <algorithm>
 #include <cstdlib>
 #include "dpmm_device.h"
 #include "dpmm_kernels.h"
@@ -141,10 +142,17 @@ __global__ __launch_bounds__(64) void hist_kernel(const int32_t *__restrict__ bi
 // workgroup 0 publishes them (flags[0..K), flags[K] = any); a tile that holds points of a flagged cluster re-draws their sub-labels
 // (Philox keyed by the global point index, as reset_sub_flagged_kernel) and re-counts itself -- tile_cnt of every other tile stays what
 // the histogram wrote.  Replaces reset + second histogram + second scan of the per-step pass (three launches fewer).
+// `cside` (nullable; the one-collective pass of a multi-rank run, run_stats in dpmm_api.cpp): the GLOBAL occupancies are not known yet, so
+// the reset is applied SPECULATIVELY to this shard's candidates -- clusters with exactly one empty sub-cluster HERE (a cluster that is bad
+// globally is one of them on every rank that holds points of it) -- and cside[k] records which side the shard's points were on (1: all
+// left, 2: all right, 0: not a candidate): enough to rebuild the rows of the labels as swept (the non-empty side carries left' + right')
+// and to undo the reset of a candidate that turns out not to be bad (all of its points go back to that side).  flags[] then holds the
+// candidates, not the verdict: niw_finalize_rows_kernel writes the verdict behind the all-reduce.
 template <int TILE>
 __global__ __launch_bounds__(64) void reset_recount_kernel(int32_t *__restrict__ bins, int64_t n, int64_t first, int nbins, int nt,
                                                            const int32_t *__restrict__ totals, const long long *__restrict__ global_counts,
-                                                           int32_t *__restrict__ tile_cnt, uint8_t *__restrict__ flags, int K, uint64_t seed, uint32_t epoch) {
+                                                           int32_t *__restrict__ tile_cnt, uint8_t *__restrict__ flags, int K, uint64_t seed, uint32_t epoch,
+                                                           uint8_t *__restrict__ cside) {
     extern __shared__ int cnt[];                 // [nbins] counters | [K] flag bytes
     uint8_t *f = reinterpret_cast<uint8_t *>(cnt + nbins);
     const int lane = threadIdx.x;
@@ -152,10 +160,13 @@ __global__ __launch_bounds__(64) void reset_recount_kernel(int32_t *__restrict__
     for (int k = lane; k < K; k += 64) {
         const long long a = global_counts ? global_counts[2 * k] : (long long)totals[(2 * k) * FAST_TOTAL_STRIDE];
         const long long b = global_counts ? global_counts[2 * k + 1] : (long long)totals[(2 * k + 1) * FAST_TOTAL_STRIDE];
-        const bool bad = a == 0 || b == 0;
+        const bool bad = cside ? ((a == 0) != (b == 0)) : (a == 0 || b == 0);
         f[k] = bad ? 1 : 0;
         anyl = anyl || bad;
-        if (blockIdx.x == 0) flags[k] = bad ? 1 : 0;
+        if (blockIdx.x == 0) {
+            flags[k] = bad ? 1 : 0;
+            if (cside) cside[k] = bad ? (b == 0 ? 1 : 2) : 0;
+        }
     }
     const bool any = __any(anyl);
     if (blockIdx.x == 0 && lane == 0) flags[K] = any ? 1 : 0;
@@ -421,12 +432,12 @@ hipError_t launch_step_hist(const int32_t *bins, int64_t n, int nbins, const Sor
     return hipGetLastError();
 }
 hipError_t launch_step_reset(int32_t *bins, int64_t n, int64_t first, int nbins, const SortBufs &b, const long long *global_counts, uint8_t *flags,
-                             int K, uint64_t seed, uint32_t epoch, hipStream_t s) {
+                             int K, uint64_t seed, uint32_t epoch, uint8_t *cside, hipStream_t s) {
     const int nt = sort_nt(n, b);
     const size_t lds = nbins * sizeof(int) + ((K + 3) & ~3);
     DPMM_TILE_DISPATCH(b.tile,
-        DPMM_LAUNCH(reset_recount_kernel<512>, dim3(nt), dim3(64), lds, s, bins, n, first, nbins, nt, b.fast_total, global_counts, b.tile_cnt, flags, K, seed, epoch),
-        DPMM_LAUNCH(reset_recount_kernel<2048>, dim3(nt), dim3(64), lds, s, bins, n, first, nbins, nt, b.fast_total, global_counts, b.tile_cnt, flags, K, seed, epoch));
+        DPMM_LAUNCH(reset_recount_kernel<512>, dim3(nt), dim3(64), lds, s, bins, n, first, nbins, nt, b.fast_total, global_counts, b.tile_cnt, flags, K, seed, epoch, cside),
+        DPMM_LAUNCH(reset_recount_kernel<2048>, dim3(nt), dim3(64), lds, s, bins, n, first, nbins, nt, b.fast_total, global_counts, b.tile_cnt, flags, K, seed, epoch, cside));
     return hipGetLastError();
 }
 
@@ -853,10 +864,16 @@ __global__ __launch_bounds__(64 * REDUCE_PARTS) void niw_reduce_kernel(StatsArgs
     double *c = A.mode ? A.cache + (int64_t)k * A.packed_stride : nullptr;
     if (pos == 0) {
         // element 0 = N: the bin totals, exact for computed and derived rows alike
-        const double nl = (double)A.sb.bin_total[2 * k], nr = (double)A.sb.bin_total[2 * k + 1];
+        double nl = (double)A.sb.bin_total[2 * k], nr = (double)A.sb.bin_total[2 * k + 1];
+        if (m == 0) c[0] = nl + nr;
+        if (A.cside) {
+            const int cs = A.cside[k];
+            A.out[(int64_t)(A.nbins + k) * A.packed_stride] = cs ? nl : 0.;
+            if (cs) { const double t = nl + nr; nl = cs == 1 ? t : 0.; nr = cs == 2 ? t : 0.; }
+            if (k == 0) { A.zero2[0] = 0; A.zero2[1] = 0; }          // flags[K] (any bad), flags[K + 1] (some candidate was not bad): set by the finalize kernel
+        }
         outl[0] = (m >= 0 || sel[0]) ? nl : 0.;
         outr[0] = (m >= 0 || sel[1]) ? nr : 0.;
-        if (m == 0) c[0] = nl + nr;
         if (A.mode) {
             A.dirty[k] = 0;
             if (k == 0) A.dirty[DPMM_MAX_CLUSTERS_K] = 0;
@@ -871,8 +888,63 @@ __global__ __launch_bounds__(64 * REDUCE_PARTS) void niw_reduce_kernel(StatsArgs
     if (m == 0) c[e] = sl + sr;
     else if (m == 1) sl = c[e] - sr;
     else if (m == 2) sr = c[e] - sl;
+    if (A.cside) {
+        // one-collective pass: sl / sr belong to the SPECULATIVELY reset sub-labels of a candidate (cside[k] != 0).  What travels is (a) the
+        // rows of the labels as swept -- everything on the side the shard's points were on -- and (b) the re-drawn left row X
+        const int cs = A.cside[k];
+        A.out[(int64_t)(A.nbins + k) * A.packed_stride + e] = cs ? sl : 0.;
+        if (cs) { const double t = sl + sr; sl = cs == 1 ? t : 0.; sr = cs == 2 ? t : 0.; }
+    }
     outl[e] = sl;                                                        // (a bin that was neither selected nor derived: zero)
     outr[e] = sr;
+}
+
+// One-collective per-step pass, behind the all-reduce of `red` = [2K rows of the labels as swept | K re-drawn left rows X] (all summed over
+// the ranks): reset_bad_clusters! (src/local_clusters_actions.jl:501-516) decided from the GLOBAL occupancies in the rows' own N column.
+// Cluster k is bad when N_l = 0 or N_r = 0; then EVERY rank holding points of it had it as a candidate, applied the reset and added its
+// part of X: left' = X, right' = (left + right) - X (one side of a bad cluster is empty: left + right is its cluster-level row).  Otherwise
+// the rows are taken as they are, and a shard on which k was a candidate undoes its reset (flags[K + 1], niw_undo_reset_kernel).
+// Reads `red`, writes `out` + flags (flags[K], flags[K + 1] were cleared by the reduce kernel).
+__global__ __launch_bounds__(256) void niw_finalize_rows_kernel(const double *__restrict__ red, double *__restrict__ out, int64_t stride, int K,
+                                                                const uint8_t *__restrict__ cside, uint8_t *__restrict__ flags) {
+    const int k = blockIdx.y;
+    const int64_t e = blockIdx.x * 256ll + threadIdx.x;
+    const double *l = red + (int64_t)(2 * k) * stride, *r = l + stride;
+    const bool bad = l[0] == 0. || r[0] == 0.;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        flags[k] = bad ? 1 : 0;
+        if (bad) flags[K] = 1;
+        if (!bad && cside[k]) flags[K + 1] = 1;
+    }
+    if (e >= stride) return;
+    double *ol = out + (int64_t)(2 * k) * stride, *orr = ol + stride;
+    if (bad) {
+        const double x = red[(int64_t)(2 * K + k) * stride + e];
+        ol[e] = x;
+        orr[e] = (l[e] + r[e]) - x;
+    } else {
+        ol[e] = l[e];
+        orr[e] = r[e];
+    }
+}
+hipError_t launch_niw_finalize_rows(const double *red, double *out, int64_t stride, int K, const uint8_t *cside, uint8_t *flags, hipStream_t s) {
+    DPMM_LAUNCH(niw_finalize_rows_kernel, dim3((unsigned)((stride + 255) / 256), K), dim3(256), 0, s, red, out, stride, K, cside, flags);
+    return hipGetLastError();
+}
+// A candidate of this shard that is not bad globally: all of its points go back to the side they were on (cside: 1 left, 2 right).
+__global__ void niw_undo_reset_kernel(int32_t *__restrict__ bins, int64_t n, int K, const uint8_t *__restrict__ flags, const uint8_t *__restrict__ cside) {
+    if (!flags[K + 1]) return;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = bins[i];
+        const int z = b >> 1;
+        if (b >= 0 && z < K && cside[z] && !flags[z]) bins[i] = 2 * z + (cside[z] - 1);
+    }
+}
+hipError_t launch_niw_undo_reset(int32_t *bins, int64_t n, int K, const uint8_t *flags, const uint8_t *cside, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
+    DPMM_LAUNCH(niw_undo_reset_kernel, dim3(grid), dim3(256), 0, s, bins, n, K, flags, cside);
+    return hipGetLastError();
 }
 
 int64_t niw_slab_stride(int D) {

@@ -77,6 +77,10 @@ enum {
                                          (two bf16 matrix passes with a certified rounding bound, ~1/7 of a Float32 evaluation) and evaluated in Float32 only
                                          if some other cluster survives the screens against the bracket's lower end; same labels; 0: always evaluated */
     DPMM_OPT_SORT_TILE = 19,          /* points per sorting wave of the statistics passes: 512 (default below 4e6 points per shard) or 2048 */
+    DPMM_OPT_ONE_COLLECTIVE = 20,     /* 1 (default): NIW per-step pass (dpmm_step_stats*) with a communicator attached: ONE all-reduce of 3K packed rows -- the 2K rows
+                                         of the labels as swept + K re-drawn left rows of the clusters each shard reset speculatively (those with exactly one
+                                         empty sub-cluster on the shard); the bad-cluster verdict comes out of the reduced rows' N column, a shard's candidate
+                                         that is not bad gets its sub-labels back.  0: occupancy all-reduce -> reset -> statistics -> row all-reduce.  Same chain. */
     DPMM_OPT_KERNEL_TIMING = 15,      /* bit mask: 1 = HIP events around the sweep kernel, 2 = around the statistics pass (dpmm_last_kernel_ms), 4 = around the
                                          all-reduces (dpmm_last_comm_ms); 0 (default): none -- every event is a barrier packet between two kernels, ~5 us each */
     DPMM_OPT_WAVE_PRIO = 10       /* 0 / 1: NIW sweep (D <= 64) lowers a wave's issue priority while it streams matrix instructions and
@@ -287,7 +291,7 @@ void *dpmm_stream(dpmm_ctx *ctx);
  * After either, dpmm_step_stats / dpmm_suffstats_host / dpmm_suffstats_packed return statistics summed over all ranks.
  * dpmm_comm_allgather_host gathers `bytes` of host data from every rank (all [world][bytes]); collective.
  * dpmm_comm_info: out8 = {world, rank, transport (0 none, 1 RCCL, 2 host function), bytes of the last occupancy all-reduce, bytes of the
- * last packed-row all-reduce, all-reduces since the attachment, 0, 0}.  dpmm_last_comm_ms: HIP-event time of the last all-reduce of each
+ * last packed-row all-reduce, all-reduces since the attachment, 0, 1 if the last per-step pass used one collective (DPMM_OPT_ONE_COLLECTIVE)}.  dpmm_last_comm_ms: HIP-event time of the last all-reduce of each
  * kind on the ctx stream (0 if none; synchronises the stream). */
 typedef int (*dpmm_host_allreduce_fn)(void *user, void *buf, int64_t count, int is_f64);
 

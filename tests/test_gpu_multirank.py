@@ -29,6 +29,9 @@ CASES = {
     "niw8": ("niw", 8, 60001, 5, 60, 6, -1),           # (N % 2, N % 3, N % 8 all non-zero)
     "mult100": ("mult", 100, 60000, 6, 50, 6, -1),
     "mult200_dev": ("mult", 200, 40000, 5, 50, 6, 1),      # the Dirichlet draws on each rank's device, from the all-reduced rows
+    # DPMM_OPT_ONE_COLLECTIVE = 0: the classic per-step pass (occupancy all-reduce -> reset -> statistics -> row all-reduce) stays covered
+    "niw64_dev_classic": ("niw", 64, 200000, 6, 60, 8, 1),
+    "niw8_classic": ("niw", 8, 60001, 5, 60, 6, -1),
 }
 
 
@@ -82,6 +85,9 @@ def _run(rank, world, port, out, case, backend, layout="even2"):
     lo, hi = bnd[rank], bnd[rank + 1]
     wk = pkg.Worker(hyper.kind, D, hi - lo, first_index=lo, device=device, seed=99)
     wk.upload_points(np.ascontiguousarray(x[:, lo:hi].T))
+    if case.endswith("_classic"):
+        from dpmmsubclusters_jl_amd import binding
+        wk.set_option(binding.OPT_ONE_COLLECTIVE, 0)
     s = host.DPMMSampler(wk, hyper, 10.0, N, 99, burnout=burnout, comm=comm)
     if dev >= 0:
         s.model.set_option(engine.OPT_DEVICE_MASTER, dev)
@@ -94,7 +100,7 @@ def _run(rank, world, port, out, case, backend, layout="even2"):
     if rank == 0:
         np.savez(out, labels=lab, sub=sub, K=np.array(kh), nmi=np.array(nmi, float), rows=rows, weights=s.weights,
                  logpost=s.log_posterior(), world=info["world"], allreduces=info["allreduces"], rows_bytes=info["rows_bytes"],
-                 counts_bytes=info["counts_bytes"], transport=info["transport"], comm_ms=np.array(cms))
+                 counts_bytes=info["counts_bytes"], transport=info["transport"], comm_ms=np.array(cms), one_collective=info["one_collective"])
     wk.close()
     if world > 1:
         dist.barrier()
@@ -109,15 +115,19 @@ def _compare(a, b, case, transport, world=2):
     prior, D, N, K, iters, burnout, dev = CASES[case]
     stride = 1 + D + (D * (D + 1) // 2 if prior == "niw" else 0)
     assert int(b["world"]) == world and str(b["transport"]) == transport
-    assert int(b["rows_bytes"]) == 2 * int(b["K"][-1]) * stride * 8           # the last pass all-reduced the packed rows of 2K bins
-    assert int(b["counts_bytes"]) == 2 * int(b["K"][-1]) * 8
-    assert int(b["allreduces"]) >= 2 * iters                                  # occupancies + rows, every step
+    one = prior == "niw" and not case.endswith("_classic")                   # DPMM_OPT_ONE_COLLECTIVE (default) applies to the NIW per-step pass
+    if one:     # ONE all-reduce per step: 3K rows (2K of the labels as swept + K re-drawn left rows); subset passes after splits add theirs
+        assert bool(b["one_collective"]) and int(b["rows_bytes"]) == 3 * int(b["K"][-1]) * stride * 8
+        assert iters <= int(b["allreduces"]) < iters + 16
+    else:
+        assert int(b["rows_bytes"]) == 2 * int(b["K"][-1]) * stride * 8 and int(b["counts_bytes"]) == 2 * int(b["K"][-1]) * 8
+        assert int(b["allreduces"]) >= 2 * iters                              # occupancies + rows, every step
     assert np.array_equal(a["K"], b["K"]), (a["K"], b["K"])                   # identical split / merge decisions
     assert a["K"][-1] >= K - 1 and b["nmi"][-1] > 0.9
     flips = int((a["labels"] != b["labels"]).sum())
     sflips = int(((a["sub"] != b["sub"]) & (a["labels"] == b["labels"])).sum())
     print(f"{case}/{transport}: K history equal (final {b['K'][-1]}), label flips {flips}/{N}, sub-label flips {sflips}, "
-          f"all-reduce ms (counts, rows) {b['comm_ms']}")
+          f"all-reduce ms (counts, rows) {b['comm_ms']}, all-reduces {int(b['allreduces'])} in {iters} steps")
     # The statistics are Float64 sums over the shards in another association than the one-rank pass: rows and parameters agree to ~1e-13
     # relative, so a draw differs only where a uniform falls within that of a CDF edge -- not once in these chains (measured: 0 flips in
     # every case of rounds 3 and 4).  The test asserts what is measured: the SAME chain.
@@ -202,7 +212,8 @@ def test_bench_starts_its_own_ranks_and_reports_the_collective(tmp_path):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
     assert d["comm"]["world"] == 2 and d["comm"]["transport"] == ("host" if share else "rccl")
-    assert d["comm"]["rows_allreduce_bytes"] == 2 * 32 * (1 + 64 + 64 * 65 // 2) * 8 and d["comm"]["rows_allreduce_ms"] > 0
+    assert d["comm"]["rows_allreduce_bytes"] == 3 * 32 * (1 + 64 + 64 * 65 // 2) * 8 and d["comm"]["rows_allreduce_ms"] > 0
+    assert d["comm"]["one_collective_per_step_pass"] and d["comm"]["allreduces_per_step_in_timed_block"] == 1.0
     assert d["config"]["points_per_gpu"] == 200000 and d["growth"]["K_final"] >= 2
 
 
