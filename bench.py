@@ -258,7 +258,9 @@ def niw_roofline(n, D, k_mean, sweep_ms, work):
             "screens16_per_wave_tile": work["screens16"] / max(1.0, work["wave_tiles"]),
             "tail_pairs_per_wave_tile": work["tail_pairs"] / max(1.0, work["wave_tiles"]),
             "brackets_per_wave_tile": work["brackets"] / max(1.0, work["wave_tiles"]),
-            "bf16_mfma_per_tile": work["brackets"] * work["bf16_mfma_per_bracket"] / max(1.0, work["wave_tiles"])}
+            "bf16_bottom_screens_per_wave_tile": work["bf16_bottom_screens"] / max(1.0, work["wave_tiles"]),
+            "bf16_top_screens_per_wave_tile": work["bf16_top_screens"] / max(1.0, work["wave_tiles"]),
+            "bf16_mfma_per_tile": work["bf16_mfma"] / max(1.0, work["wave_tiles"])}
 
 
 def run_legs(args, pkg, host, torch, one_gpu_ms):
@@ -488,7 +490,7 @@ def main():
             "executed_tflops": exe / (avg_sweep_ms * 1e-3) / 1e12, "pruning_factor": flops_alg / exe if exe else None,
             "algorithmic_frac": achieved / PEAK_F32_MFMA_TFLOPS,
             "work_per_launch": {k: float(np.mean([w[k] for w in work])) for k in ("wave_tiles", "full_evals", "screens16", "tail_pairs", "brackets")},
-            "bf16_mfma_per_tile": float(np.mean([w["brackets"] * w["bf16_mfma_per_bracket"] / max(1.0, w["wave_tiles"]) for w in work])),
+            "bf16_mfma_per_tile": float(np.mean([w["bf16_mfma"] / max(1.0, w["wave_tiles"]) for w in work])),
             "frac_definition": "Float32 matrix instructions counted on the device in the timed launches x 2048 flops / live launch time / peak "
                                "(= SQ_INSTS_VALU_MFMA_MOPS_F32 x 512: `pmc_frac`); the reference brackets' bf16 instructions are counted apart",
             "stats_kernels_ms": float(np.mean(stats_ms)), "kernel_source_tag": kernel_source_tag()}

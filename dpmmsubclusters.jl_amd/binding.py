@@ -98,7 +98,7 @@ HOST_ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_voi
 
 # dpmm_set_option keys (include/dpmm_hip.h)
 MASTER_NSCALARS = 8          # DPMM_MASTER_NSCALARS
-OPT_SCREEN_MARGIN, OPT_TAIL_SCREEN, OPT_PRESCREEN, OPT_ORDERED_SWEEP, OPT_MULT_FORCE_F32, OPT_STATS_ITEMS, OPT_STATS_GROUPS, OPT_TRACE_SLOW, OPT_LOGLIK_REF_CONST, OPT_WAVE_PRIO, OPT_MULT_NO_U8, OPT_SWEEP_GRID, OPT_SWEEP_QUEUE_ROUNDS, OPT_BALL_SCREEN, OPT_KERNEL_TIMING, OPT_STATS_DERIVE, OPT_NOISE_AHEAD, OPT_REF_BRACKET, OPT_SORT_TILE, OPT_ONE_COLLECTIVE = range(1, 21)
+OPT_SCREEN_MARGIN, OPT_TAIL_SCREEN, OPT_PRESCREEN, OPT_ORDERED_SWEEP, OPT_MULT_FORCE_F32, OPT_STATS_ITEMS, OPT_STATS_GROUPS, OPT_TRACE_SLOW, OPT_LOGLIK_REF_CONST, OPT_WAVE_PRIO, OPT_MULT_NO_U8, OPT_SWEEP_GRID, OPT_SWEEP_QUEUE_ROUNDS, OPT_BALL_SCREEN, OPT_KERNEL_TIMING, OPT_STATS_DERIVE, OPT_NOISE_AHEAD, OPT_REF_BRACKET, OPT_SORT_TILE, OPT_ONE_COLLECTIVE, OPT_BF16_SCREENS = range(1, 22)
 
 
 class DpmmError(RuntimeError):
@@ -579,14 +579,15 @@ class Worker:
     def last_sweep_work(self):
         """dict of the executed-work counters of the NIW sweeps since the previous call, PER LAUNCH (dpmm_last_sweep_work returns their
         totals and the number of launches, and clears them): after every sweep = that sweep's; after a timed loop = its average."""
-        out = (ctypes.c_uint64 * 12)()
+        out = (ctypes.c_uint64 * 16)()
         self._chk(self._lib.dpmm_last_sweep_work(self._h, out))
         v = [int(x) for x in out]
         n = max(1, v[7])
-        # executed_flops: Float32 matrix work only (= SQ_INSTS_VALU_MFMA_MOPS_F32 x 512); the reference brackets' bf16 work beside it
+        # executed_flops: Float32 matrix work only (= SQ_INSTS_VALU_MFMA_MOPS_F32 x 512); the bf16 work (brackets, screens) beside it
         return dict(wave_tiles=v[0] / n, full_evals=v[1] / n, screens16=v[2] / n, tail_pairs=v[3] / n, mfma_per_full=v[4], mfma_per_screen=v[5],
                     flops_per_mfma=v[6], executed_flops=(v[1] * v[4] + v[2] * v[5]) * v[6] / n, launches=v[7],
-                    brackets=v[8] / n, bf16_mfma_per_bracket=v[9], bf16_flops=v[8] * v[9] * v[10] / n)
+                    brackets=v[8] / n, bf16_mfma_per_bracket=v[9], bf16_bottom_screens=v[11] / n, bf16_top_screens=v[13] / n,
+                    bf16_mfma=(v[8] * v[9] + v[11] * v[12] + v[13] * v[14]) / n, bf16_flops=(v[8] * v[9] + v[11] * v[12] + v[13] * v[14]) * v[10] / n)
 
     # ---- diagnostics
     def debug_subloglik(self):

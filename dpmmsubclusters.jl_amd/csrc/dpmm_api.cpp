@@ -198,6 +198,7 @@ struct dpmm_ctx {
     int opt_prio = 1;
     int opt_queue_rounds = -1;
     int opt_ball = 1;
+    int opt_bf16scr = 1;               // D <= 64 sweep: bf16 screens in front of the Float32 16-row screen / of a survivor's first row block (DPMM_OPT_BF16_SCREENS)
     int opt_bracket = 1;               // D <= 64 sweep: certified bf16 bracket of the reference cluster's value instead of its Float32 evaluation where that decides nothing (DPMM_OPT_REF_BRACKET)
     int opt_timing = 0;                // bit 0 / 1 / 2: HIP events around the sweep kernel / the statistics pass / the all-reduces (dpmm_last_kernel_ms, dpmm_last_comm_ms)
     int opt_tail = 1, opt_prescreen = -1, opt_ordered = 1, opt_force_f32 = 0, opt_trace = 0, opt_ref_const = 0;
@@ -947,6 +948,7 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
             a.tail_g = ((c->D - 4) % 16) / 4;
             a.ball = c->opt_ball;
             a.bracket = c->opt_bracket;
+            a.bf16scr = (c->opt_bf16scr && c->NB == 4 && a.tail != nullptr) ? 1 : 0;
             a.order = (!table && c->have_perm && !no_order) ? c->sb.perm : nullptr;
             a.order_total = c->sb.perm_total;
             a.work = table ? nullptr : c->d_work;
@@ -2196,6 +2198,7 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
         case DPMM_OPT_STATS_DERIVE: c->opt_derive = value != 0; c->cache_force = true; return DPMM_OK;
         case DPMM_OPT_NOISE_AHEAD: c->opt_noise_ahead = value != 0; return DPMM_OK;
         case DPMM_OPT_REF_BRACKET: c->opt_bracket = value != 0; return DPMM_OK;
+        case DPMM_OPT_BF16_SCREENS: c->opt_bf16scr = value != 0; return DPMM_OK;
         case DPMM_OPT_ONE_COLLECTIVE: c->opt_one_collective = value != 0; return DPMM_OK;
         case DPMM_OPT_SORT_TILE: {
             const int t = (int)value;
@@ -2219,18 +2222,20 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
     }
 }
 
-int dpmm_last_sweep_work(dpmm_ctx *c, uint64_t *out12) {
-    if (!c || !out12) return DPMM_EINVAL;
+int dpmm_last_sweep_work(dpmm_ctx *c, uint64_t *out16) {
+    if (!c || !out16) return DPMM_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::vector<unsigned long long> h((size_t)DPMM_WORK_PER_WAVE * (size_t)c->work_waves);
     if (!h.empty()) HIPCHK(c, hipMemcpy(h.data(), c->d_work + DPMM_WORK_SLOTS, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
-    for (int i = 0; i < 12; ++i) out12[i] = 0;
+    for (int i = 0; i < 16; ++i) out16[i] = 0;
     for (size_t w = 0; w < (size_t)c->work_waves; ++w) {
-        for (int i = 0; i < 4; ++i) out12[i] += h[DPMM_WORK_PER_WAVE * w + i];
-        out12[8] += h[DPMM_WORK_PER_WAVE * w + 4];
+        for (int i = 0; i < 4; ++i) out16[i] += h[DPMM_WORK_PER_WAVE * w + i];
+        out16[8] += h[DPMM_WORK_PER_WAVE * w + 4];
+        out16[11] += h[DPMM_WORK_PER_WAVE * w + 5];
+        out16[13] += h[DPMM_WORK_PER_WAVE * w + 6];
     }
-    // totals of the launches since the previous call (out12[7] of them); the slots start again from zero
+    // totals of the launches since the previous call (out16[7] of them); the slots start again from zero
     const long long launches = c->work_launches;
     if (!h.empty()) HIPCHK(c, hipMemsetAsync(c->d_work + DPMM_WORK_SLOTS, 0, sizeof(unsigned long long) * h.size(), c->stream));
     c->work_launches = 0; c->work_waves = 0;
@@ -2242,8 +2247,9 @@ int dpmm_last_sweep_work(dpmm_ctx *c, uint64_t *out12) {
         mf_full = NP * 4 * NG + (NB <= 4 ? NG : 0);           // block pairs x 4 k-steps x NG (+ the ones-MFMA row sums of the direct kernel)
         mf_scr = 4 * NG;                                       // the 16-row screen: one block, 4 k-steps, NG point groups
     }
-    out12[4] = (uint64_t)mf_full; out12[5] = (uint64_t)mf_scr; out12[6] = 2048; out12[7] = (uint64_t)launches;
-    out12[9] = 48; out12[10] = 16384;                          // a reference bracket: 6 fragments x 2 passes x 4 point groups of v_mfma_f32_16x16x32_bf16 (2 * 16 * 16 * 32 flops each)
+    out16[4] = (uint64_t)mf_full; out16[5] = (uint64_t)mf_scr; out16[6] = 2048; out16[7] = (uint64_t)launches;
+    out16[9] = 48; out16[10] = 16384;
+    out16[12] = 8; out16[14] = 16;                           // bf16 matrix instructions of a bottom / top screen (+ 4 Float32 row sums per top screen)                          // a reference bracket: 6 fragments x 2 passes x 4 point groups of v_mfma_f32_16x16x32_bf16 (2 * 16 * 16 * 32 flops each)
     return DPMM_OK;
 }
 

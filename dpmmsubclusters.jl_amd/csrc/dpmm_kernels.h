@@ -41,6 +41,7 @@ struct NiwSweepArgs {
     const float *tail;        // [ceil(K/2)][16][2] tail-screen records of the cluster-level matrices, pairs interleaved, then [K][16] ball records (null: no tail screen)
     int tail_g;               // row group (lane >> 4) whose x registers of the last block hold features D-4..D-1
     int ball;                 // 1: cluster-per-lane ball test in front of the per-point tail screen (records [K][16] behind the pair records)
+    int bf16scr;              // 1: D in 33..64 with tail records: bf16 screens in front of the Float32 16-row screen and of every survivor's first row block (DPMM_OPT_BF16_SCREENS)
     int bracket;              // 1: D in 49..64, homogeneous waves: certified bf16 bracket of the reference cluster's value first; its Float32 evaluation only if a cluster survives the screens (bf16 images behind the ball records)
     const float *lam;         // [K] lower bounds of lambda_min(Sigma_k^-1) (null: no scalar pre-screen)
     const float *mdist;       // [K][K] distances between the cluster means

@@ -282,6 +282,92 @@ __device__ __forceinline__ void ref_bracket(const uint32_t *__restrict__ Rb, con
     }
 }
 
+// bf16 SCREENS (D in 33 .. 64, DPMM_OPT_BF16_SCREENS): the same certified bound as the bracket, the other way round.  For the rows of a
+// block row of y = R z,  |y_r| >= |y^_r| - REFB_C e^_r,  so  q >= sum_r max(0, |y^_r| - REFB_C e^_r)^2  is a LOWER bound of the quadratic form from
+// two bf16 matrix passes -- and cst - q_lb / 2 an upper bound of a_k, the only thing a screen needs.  Both screens sit IN FRONT of the
+// Float32 test they imitate and only ever skip it: a cluster they exclude would have been excluded by the Float32 test as well (their
+// bound is the weaker one), a cluster they let through takes the Float32 test as before.  The set of evaluated clusters, the table and
+// the labels are those of the kernel without them, bit for bit.
+//   bottom: rows 48 .. 63 (block row 3: the last 16 features only) -- fragment 5 of the cluster's bf16 image; 8 matrix instructions of
+//           16 cycles against the Float32 screen's 16 of 32; per lane its own four rows, as the Float32 screen;
+//   top:    rows 0 .. 15 (block row 0: all 64 features) -- fragments 0, 1; 16 matrix instructions + 4 row sums against the 64 + 4 Float32
+//           ones of the evaluation's first row block (quad_stream<.., EARLY>); for the clusters the bottom screen lets through, still in
+//           front of their Float32 16-row screen (every exclusion here is one the Float32 tests would have made: the order is free).
+// Overlapping clusters (component means at MixtureVar 4 / 1 instead of 100) are where they pay: there the 4-row bounds exclude nothing
+// and a tile runs ~30 sixteen-row screens (MixtureVar 4), or ~19 evaluations that leave after their first row block (MixtureVar 1).
+template <int NG>
+__device__ __forceinline__ bool bf16_bottom_excludes(const u32x4_t a, const f32x4 (&x3)[NG], const f32x4 m4, float cst, const float (&thr)[NG]) {
+    static_assert(NG % 2 == 0, "point groups are taken two at a time");
+    const u32x4_t absm = (u32x4_t){0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu};
+    const u32x4_t aa = a & absm;              // a: fragment 5 of the cluster's bf16 image -- block row 3 x features 32 .. 63 (zero for 32 .. 47)
+    bool skip = true;
+#pragma unroll
+    for (int n0 = 0; n0 < NG; n0 += 2) {
+        f32x4 y[2], e[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 z = x3[n0 + h] - m4;
+            const u32x4_t zb = (u32x4_t){0u, 0u, pack_bf16_pair(z.x, z.y), pack_bf16_pair(z.z, z.w)};      // k-slots 0 .. 3: features 32 .. 47, zero rows of the fragment
+            y[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, zb), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            e[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aa), __builtin_bit_cast(bf16x8_t, zb & absm), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float ql = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float t = fmaxf(__builtin_fmaf(-REFB_C, e[h][r], fabsf(y[h][r])), 0.f);
+                ql = __builtin_fmaf(t, t, ql);
+            }
+            // (a NaN anywhere makes the comparison false: not excluded.  thr = +inf for columns without a point)
+            unsigned long long mk = __ballot(__builtin_fmaf(-0.5f * 0.9999f, ql, cst) < thr[n0 + h]);
+            mk |= mk >> 32;
+            mk |= mk >> 16;
+            skip = skip && ((mk & 0xFFFFull) == 0xFFFFull);     // every point: one of its four row-group lanes proves the bound
+        }
+    }
+    return skip;
+}
+template <int NG>
+__device__ __forceinline__ bool bf16_top_excludes(const uint32_t *__restrict__ Rb, const f32x4 (&x)[NG][4], const f32x4 (&mu)[4], int lane, float cst,
+                                                  const float (&thr)[NG]) {
+    static_assert(NG % 2 == 0, "point groups are taken two at a time");
+    const u32x4_t absm = (u32x4_t){0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu};
+    const u32x4_t a0 = reinterpret_cast<const u32x4_t *>(Rb)[lane], a1 = reinterpret_cast<const u32x4_t *>(Rb)[64 + lane];      // block row 0 x features 0 .. 31 | 32 .. 63
+    const u32x4_t aa0 = a0 & absm, aa1 = a1 & absm;
+    bool out = true;
+#pragma unroll
+    for (int n0 = 0; n0 < NG; n0 += 2) {
+        float part[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            u32x4_t zb[2];
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                const f32x4 lo = x[n0 + h][2 * sl] - mu[2 * sl], hi = x[n0 + h][2 * sl + 1] - mu[2 * sl + 1];
+                zb[sl] = (u32x4_t){pack_bf16_pair(lo.x, lo.y), pack_bf16_pair(lo.z, lo.w), pack_bf16_pair(hi.x, hi.y), pack_bf16_pair(hi.z, hi.w)};
+            }
+            f32x4 y = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a0), __builtin_bit_cast(bf16x8_t, zb[0]), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            f32x4 e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aa0), __builtin_bit_cast(bf16x8_t, zb[0] & absm), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            y = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a1), __builtin_bit_cast(bf16x8_t, zb[1]), y, 0, 0, 0);
+            e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aa1), __builtin_bit_cast(bf16x8_t, zb[1] & absm), e, 0, 0, 0);
+            float ql = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float t = fmaxf(__builtin_fmaf(-REFB_C, e[r], fabsf(y[r])), 0.f);
+                ql = __builtin_fmaf(t, t, ql);
+            }
+            part[h] = ql;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 tot = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, part[h], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);      // sum over the four row groups of a column
+            out = out && (__builtin_fmaf(-0.5f * 0.9999f, tot[0], cst) < thr[n0 + h]);
+        }
+    }
+    return __all(out);
+}
+
 template <int NB, int NG, int CH>
 struct QuadEval {
     using C = NiwCfg<NB, NG, CH>;
@@ -985,7 +1071,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
     // (Also touching the next tile's X lines to pull them into L2 was measured: no gain, +30 % HBM traffic.)
     int nx_p = -1, nx_bin = -1;
     int nx_tile = -1;
-    unsigned nw_tiles = 0, nw_full = 0, nw_scr = 0, nw_tail = 0, nw_br = 0;   // executed-work counters of this wave (wave-uniform)
+    unsigned nw_tiles = 0, nw_full = 0, nw_scr = 0, nw_tail = 0, nw_br = 0, nw_bb = 0, nw_bt = 0;   // executed-work counters of this wave (wave-uniform); nw_bb / nw_bt: bf16 bottom / top screens
     const int rounds_all = nwtiles / nwaves;
     int dyn_rounds = A.queue_rounds >= 0 ? A.queue_rounds : (rounds_all < 4 ? 0 : (rounds_all / 8 > 2 ? rounds_all / 8 : 2));
     if (dyn_rounds > rounds_all) dyn_rounds = rounds_all;
@@ -1366,6 +1452,48 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
 #endif
                         cand &= ~((unsigned long long)tail_pair_far(tail_load_pair(A.tail, pr), xt, my_thr) << sh);
                     }
+                    if constexpr (NB == 4) {
+                        if (A.bf16scr) {
+                            // bf16 screens of the remaining candidates, software-pipelined: the operands of the NEXT candidate (fragment, tail means,
+                            // constant: dependent L2 / LDS / scalar loads) are requested before the current one is tested -- a screen is ~120 vector
+                            // instructions and 8 short matrix instructions, the loads' latency was as long again
+                            float thrb[NG];
+                            f32x4 x3[NG];
+#pragma unroll
+                            for (int n = 0; n < NG; ++n) { thrb[n] = pvalid[n] ? bestn[n] - margin : INFINITY; x3[n] = x[n][LB]; }
+                            const u32x4_t *Rb0 = reinterpret_cast<const u32x4_t *>(refb_records(A.tail, K));
+                            auto loadk = [&](int k, u32x4_t &a, f32x4 &m4, float &ck) {
+                                a = Rb0[(size_t)k * (REFB_WORDS / 4) + 64 * 5 + lane];
+                                m4 = A.screen_lds ? *reinterpret_cast<const f32x4 *>(scrM + (size_t)k * 16 + 4 * g)
+                                                  : *reinterpret_cast<const f32x4 *>(A.mup + (size_t)(3 * k) * DP + 16 * LB + 4 * g);
+                                ck = cst_of(k);
+                            };
+                            u32x4_t a_c, a_n = (u32x4_t){0u, 0u, 0u, 0u};
+                            f32x4 m_c, m_n = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            float c_c, c_n = 0.f;
+                            int k = pop();
+                            if (k >= 0) loadk(k, a_c, m_c, c_c);
+                            while (k >= 0) {
+                                const int kn = pop();
+                                if (kn >= 0) loadk(kn, a_n, m_n, c_n);
+                                ++nw_bb;
+                                bool gone = bf16_bottom_excludes<NG>(a_c, x3, m_c, c_c, thrb);
+                                if (!gone) {
+                                    // passed the bottom rows: the top rows (block row 0 sees every feature) before any Float32 work
+                                    f32x4 muk[4];
+#pragma unroll
+                                    for (int t = 0; t < 4; ++t) muk[t] = *reinterpret_cast<const f32x4 *>(A.mup + (size_t)(3 * k) * DP + 16 * t + 4 * g);
+                                    ++nw_bt;
+                                    gone = bf16_top_excludes<NG>(refb_records(A.tail, K) + (size_t)k * REFB_WORDS, x, muk, lane, c_c, thrb);
+                                }
+                                if (!gone) {
+                                    issue(k, acc);
+                                    finish(k, c_c, acc);
+                                }
+                                k = kn; a_c = a_n; m_c = m_n; c_c = c_n;
+                            }
+                        }
+                    }
                     for (int k = pop(); k >= 0; k = pop()) {
                         issue(k, acc);
                         finish(k, cst_of(k), acc);
@@ -1586,7 +1714,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
     }
     if (A.work && lane == 0) {      // one slot per wave, no atomics (see the LDS-staged kernel)
         unsigned long long *slot = A.work + DPMM_WORK_SLOTS + (size_t)wave_id * DPMM_WORK_PER_WAVE;      // (accumulates over launches; cleared by the reader)
-        slot[0] += nw_tiles; slot[1] += nw_full; slot[2] += nw_scr; slot[3] += nw_tail; slot[4] += nw_br;
+        slot[0] += nw_tiles; slot[1] += nw_full; slot[2] += nw_scr; slot[3] += nw_tail; slot[4] += nw_br; slot[5] += nw_bb; slot[6] += nw_bt;
     }
 #ifdef DPMM_STAMPS
     if (lane == 0 && A.dbg) {

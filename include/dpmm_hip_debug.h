@@ -40,14 +40,15 @@ int dpmm_debug_ref_bracket(dpmm_ctx *ctx, int64_t cluster, float c_override, flo
  * Calling this waits for the measured kernels (the closing event of each pair), not for later work on the stream. */
 int dpmm_last_kernel_ms(dpmm_ctx *ctx, float *sweep_ms, float *suffstats_ms);
 /* Work the dpmm_sweep calls (NIW) since the previous call really executed, counted on the device (a slot per wave, no atomics):
- *   TOTALS over out12[7] launches of: out12[0] wave tiles, [1] full quadratic-form evaluations (per wave), [2] 16-row MFMA screens
+ *   TOTALS over out16[7] launches of: out16[0] wave tiles, [1] full quadratic-form evaluations (per wave), [2] Float32 16-row MFMA screens
  *   (per wave; an evaluation left after its first row block counts as four), [3] tail-screened cluster pairs (per wave), [8] reference
- *   brackets (per wave: bf16 matrix work, NOT part of the Float32 figure); [4] Float32 matrix instructions per full evaluation, [5] per
- *   16-row screen, [6] flops per Float32 matrix instruction (v_mfma_f32_16x16x4_f32: 2048), [9] bf16 matrix instructions per bracket,
- *   [10] flops per bf16 matrix instruction (v_mfma_f32_16x16x32_bf16: 16384), [11] 0.  Executed Float32 matrix flops of those launches =
- *   (out12[1]*out12[4] + out12[2]*out12[5]) * out12[6] -- the figure SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 reports.  The counters are cleared;
+ *   brackets, [11] bf16 bottom screens, [13] bf16 top screens (per wave: bf16 matrix work, NOT part of the Float32 figure);
+ *   [4] Float32 matrix instructions per full evaluation, [5] per 16-row screen, [6] flops per Float32 matrix instruction
+ *   (v_mfma_f32_16x16x4_f32: 2048), [9] / [12] / [14] bf16 matrix instructions per bracket / bottom screen / top screen, [10] flops per
+ *   bf16 matrix instruction (v_mfma_f32_16x16x32_bf16: 16384), [15] 0.  Executed Float32 matrix flops of those launches =
+ *   (out16[1]*out16[4] + out16[2]*out16[5]) * out16[6] -- the figure SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 reports.  The counters are cleared;
  *   calling this synchronises the stream (a benchmark calls it once after its timed loop, not once per step). */
-int dpmm_last_sweep_work(dpmm_ctx *ctx, uint64_t *out12);
+int dpmm_last_sweep_work(dpmm_ctx *ctx, uint64_t *out16);
 /* HIP-event time of the last all-reduce of each kind on the ctx stream (0 if none; synchronises the stream); DPMM_OPT_KERNEL_TIMING bit 4. */
 int dpmm_last_comm_ms(dpmm_ctx *ctx, float *counts_ms, float *rows_ms);
 

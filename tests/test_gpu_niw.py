@@ -571,3 +571,43 @@ def test_reference_bracket_labels_on_adversarial_operands(pkg, kind):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     print(f"{kind}: full evaluations per wave tile {out[1][1]['full_evals'] / out[1][1]['wave_tiles']:.2f} with the bracket, "
           f"{out[0][1]['full_evals'] / out[0][1]['wave_tiles']:.2f} without")
+
+
+@pytest.mark.parametrize("D,sep,K", [(64, 6.0, 7), (64, 2.0, 12), (64, 0.8, 7), (52, 2.0, 7), (36, 3.0, 9), (64, 1.5, 100), (64, 40.0, 7)])
+def test_bf16_screens_do_not_change_labels(pkg, D, sep, K):
+    """DPMM_OPT_BF16_SCREENS (D in 33 .. 64): a certified bf16 LOWER bound of the last / first block row's part of the quadratic form in front of
+    the Float32 16-row screen / of a survivor's evaluation.  They only skip Float32 tests that would have excluded the cluster as well, so the
+    set of evaluated clusters, the table and the labels are those of the kernel without them -- bit for bit, on overlapping clusters (where
+    they do most of the screening), on separated ones, with zero-padded features, and beyond the LDS table's rows."""
+    from dpmmsubclusters_jl_amd import binding
+    n = 30000
+    P = make_problem(D, n, K, seed=40 + D + K, sep=sep, sorted_points=True)
+    out = {}
+    for on in (1, 0):
+        wk = gpu_worker(pkg, P, seed=23)
+        wk.set_option(binding.OPT_BF16_SCREENS, on)
+        wk.set_labels(P["z"] + 1, 1 + (np.arange(n) & 1))
+        wk.suffstats_packed(None)                      # the bin-sorted visiting order
+        wk.set_params_niw(P["mu"], P["invS"], P["logdet"], P["lr"], P["w"])
+        wk.last_sweep_work()
+        labs = []
+        for ep in (1, 2):
+            wk.sweep(ep)
+            labs.append(wk.get_labels())
+            wk.suffstats_packed(None)
+            wk.set_params_niw(P["mu"], P["invS"], P["logdet"], P["lr"], P["w"])
+        work = wk.last_sweep_work()
+        if on:
+            tab = wk.debug_loglik()
+            u0, u1 = orc.uniforms(23, 2, 0, 0, n)
+            assert np.array_equal(orc.sample_log_cat(tab, u0), labs[1][0])
+        out[on] = (labs, work)
+        wk.close()
+    for a, b in zip(out[1][0], out[0][0]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    w1, w0 = out[1][1], out[0][1]
+    t = w1["wave_tiles"]
+    print(f"D={D} sep={sep} K={K}: per wave tile -- Float32 screens {w0['screens16'] / t:.2f} -> {w1['screens16'] / t:.2f}, bf16 bottom {w1['bf16_bottom_screens'] / t:.2f}, "
+          f"bf16 top {w1['bf16_top_screens'] / t:.2f}, full evaluations {w0['full_evals'] / t:.2f} -> {w1['full_evals'] / t:.2f}")
+    assert w1["full_evals"] == w0["full_evals"]                        # the same clusters reach a full evaluation
+    assert w1["screens16"] <= w0["screens16"] and w0["bf16_bottom_screens"] == 0 and w0["bf16_top_screens"] == 0
