@@ -609,5 +609,7 @@ def test_bf16_screens_do_not_change_labels(pkg, D, sep, K):
     t = w1["wave_tiles"]
     print(f"D={D} sep={sep} K={K}: per wave tile -- Float32 screens {w0['screens16'] / t:.2f} -> {w1['screens16'] / t:.2f}, bf16 bottom {w1['bf16_bottom_screens'] / t:.2f}, "
           f"bf16 top {w1['bf16_top_screens'] / t:.2f}, full evaluations {w0['full_evals'] / t:.2f} -> {w1['full_evals'] / t:.2f}")
-    assert w1["full_evals"] == w0["full_evals"]                        # the same clusters reach a full evaluation
+    # never MORE Float32 work: a cluster the bf16 screens exclude is one the Float32 tests would have excluded; fewer full evaluations where the
+    # top screen removes the last survivor of a bracketed wave (the reference cluster's own Float32 evaluation is then skipped as well)
+    assert w1["full_evals"] <= w0["full_evals"]
     assert w1["screens16"] <= w0["screens16"] and w0["bf16_bottom_screens"] == 0 and w0["bf16_top_screens"] == 0
