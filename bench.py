@@ -71,6 +71,7 @@ def parse_args():
     ap.add_argument("--legs", default="overlap_var4,overlap_var1,k256,c2,c3_shard,c4,c5_shard", help="comma-separated subset of the legs")
     ap.add_argument("--growth-iters", type=int, default=260)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-clock budget of the CPU baseline sample")
+    ap.add_argument("--comm-timeout", type=float, default=300.0, help="seconds a rank waits in a collective before it gives up (dead peer)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="development: all ranks on device 0 over gloo + the library's host transport (boxes with one GPU)")
     return ap.parse_args()
@@ -382,11 +383,15 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        # a rank that dies must end the run with a non-zero exit, not hang it: bounded waits in the process group (host transport: gloo's
+        # all_reduce raises -> the library's callback fails -> DPMM_ECOMM) and in the library (RCCL: DPMM_OPT_COMM_TIMEOUT_MS, set below)
+        import datetime
+        tmo = datetime.timedelta(seconds=args.comm_timeout)
         if args.share_gpu:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=tmo)
         else:
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), timeout=tmo)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the product has no CPU fallback)")
 
@@ -404,6 +409,7 @@ def main():
     prior = host.niw_hyperparams(1.0, np.zeros(D), D + 3, np.eye(D))      # default prior, dp-parallel-sampling.jl:272-274
     wk = pkg.Worker(pkg.PRIOR_NIW, D, hi - lo, first_index=lo, device=local_rank, seed=SAMPLER_SEED)
     wk.upload_points(X)
+    wk.set_option(binding.OPT_COMM_TIMEOUT_MS, 1e3 * args.comm_timeout)
     s = host.DPMMSampler(wk, prior, ALPHA, N, SAMPLER_SEED, burnout=BURNOUT, comm=comm)
     sub0 = 1 + (np.random.default_rng([DATA_SEED, 7, rank]).integers(0, 2, hi - lo))
     s.start_from_labels(y, sub0, K)

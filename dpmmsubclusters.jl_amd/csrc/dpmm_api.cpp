@@ -11,6 +11,10 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -215,6 +219,18 @@ struct dpmm_ctx {
     bool have_comm_ev[2] = {false, false};
     int64_t comm_bytes[2] = {0, 0};    // payload of the last all-reduce of each kind
     int64_t comm_calls = 0;            // all-reduces since the communicator was attached
+    // Bounded waits behind a collective (RCCL transport; DPMM_OPT_COMM_TIMEOUT_MS): a rank that dies between two all-reduces leaves the
+    // others inside an RCCL kernel that never ends -- and the reference has the same flaw (its master waits on `fetch`).
+    // A watchdog thread per communicator measures how long the host has been blocked on the ctx stream; past the deadline it aborts
+    // the communicator (ncclCommAbort: the kernel returns), the blocked call comes back, sees `comm_aborted` and fails with DPMM_ECOMM --
+    // on every surviving rank -- instead of hanging until somebody kills the job.  The host transport's callback owns its own time-out.
+    int comm_timeout_ms = 120000;
+    std::thread *watchdog = nullptr;
+    std::mutex wd_mu;
+    std::condition_variable wd_cv;
+    bool wd_stop = false;
+    std::atomic<int64_t> wd_wait_since{0};      // steady-clock ms when the host began to block on the stream; 0: not blocked
+    std::atomic<bool> comm_aborted{false};
     // ONE collective per per-step pass (DPMM_OPT_ONE_COLLECTIVE; NIW, communicator attached): see run_stats
     int opt_one_collective = 1;
     uint8_t *d_cside = nullptr;        // [DPMM_MAX_CLUSTERS] clusters whose sub-labels this shard reset speculatively: the side its points were on (1 / 2), 0: none
@@ -235,15 +251,38 @@ static inline double now_ms() {
             const double dt__ = now_ms() - t0__;                                                        \
             if (dt__ > 5.0) fprintf(stderr, "[dpmm slow] %.2f ms in %s (line %d)\n", dt__, #expr, __LINE__); \
         }                                                                                               \
+        if ((ctx)->comm_aborted.load(std::memory_order_relaxed)) {                                       \
+            (ctx)->err = "collective timed out: a peer rank is gone or stuck (communicator aborted after DPMM_OPT_COMM_TIMEOUT_MS)"; \
+            return DPMM_ECOMM;                                                                          \
+        }                                                                                               \
         if (e__ != hipSuccess) {                                                                        \
             (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                            \
             return DPMM_EHIP;                                                                           \
         }                                                                                               \
     } while (0)
 
+static inline int64_t steady_ms() {
+    return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+// Blocking waits on the ctx stream go through these two: with an RCCL communicator attached the watchdog sees how long they last.
+static inline hipError_t sync_stream(dpmm_ctx *c, hipStream_t st) {
+    if (!c->watchdog) return hipStreamSynchronize(st);
+    c->wd_wait_since.store(steady_ms() | 1, std::memory_order_relaxed);
+    const hipError_t e = hipStreamSynchronize(st);
+    c->wd_wait_since.store(0, std::memory_order_relaxed);
+    return e;
+}
+static inline hipError_t sync_event(dpmm_ctx *c, hipEvent_t ev) {
+    if (!c->watchdog) return hipEventSynchronize(ev);
+    c->wd_wait_since.store(steady_ms() | 1, std::memory_order_relaxed);
+    const hipError_t e = hipEventSynchronize(ev);
+    c->wd_wait_since.store(0, std::memory_order_relaxed);
+    return e;
+}
+
 static int ensure_pinned(dpmm_ctx *c, size_t bytes) {
     if (bytes <= c->h_pin_bytes) return DPMM_OK;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     if (c->h_pin) hipHostFree(c->h_pin);
     c->h_pin = nullptr; c->h_pin_bytes = 0;
     size_t cap = 1 << 20;
@@ -269,6 +308,7 @@ struct Rccl {
     int (*GetUniqueId)(void *) = nullptr;
     int (*CommInitRank)(void **, int, /* ncclUniqueId by value */ UidByValue, int) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
+    int (*CommAbort)(void *) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
@@ -288,6 +328,7 @@ static Rccl &rccl() {
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.handle, "ncclCommAbort"));      // (optional: the watchdog needs it)
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
     r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
@@ -312,7 +353,7 @@ static int comm_allreduce(dpmm_ctx *c, void *dbuf, size_t count, int kind) {
     } else {
         const size_t bytes = count * 8;
         if (bytes > c->h_red_bytes) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, sync_stream(c, c->stream));
             if (c->h_red) hipHostFree(c->h_red);
             c->h_red = nullptr; c->h_red_bytes = 0;
             size_t cap = 1 << 16;
@@ -321,7 +362,7 @@ static int comm_allreduce(dpmm_ctx *c, void *dbuf, size_t count, int kind) {
             c->h_red_bytes = cap;
         }
         HIPCHK(c, launch_copy_bytes(c->h_red, dbuf, bytes, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, sync_stream(c, c->stream));
         const int rc = c->host_fn(c->host_user, c->h_red, (int64_t)count, f64 ? 1 : 0);
         if (rc != 0) return fail(c, DPMM_ECOMM, "host all-reduce callback failed (code " + std::to_string(rc) + ")");
         HIPCHK(c, launch_copy_bytes(dbuf, c->h_red, bytes, c->stream));
@@ -332,8 +373,35 @@ static int comm_allreduce(dpmm_ctx *c, void *dbuf, size_t count, int kind) {
     ++c->comm_calls;
     return DPMM_OK;
 }
+static void watchdog_stop(dpmm_ctx *c) {
+    if (!c->watchdog) return;
+    { std::lock_guard<std::mutex> lk(c->wd_mu); c->wd_stop = true; }
+    c->wd_cv.notify_all();
+    c->watchdog->join();
+    delete c->watchdog;
+    c->watchdog = nullptr;
+    c->wd_stop = false;
+}
+static void watchdog_start(dpmm_ctx *c) {
+    if (c->watchdog || !rccl().CommAbort) return;
+    c->watchdog = new std::thread([c]() {
+        std::unique_lock<std::mutex> lk(c->wd_mu);
+        while (!c->wd_stop) {
+            c->wd_cv.wait_for(lk, std::chrono::milliseconds(20));
+            if (c->wd_stop) break;
+            const int64_t since = c->wd_wait_since.load(std::memory_order_relaxed);
+            const int limit = c->comm_timeout_ms;
+            if (since != 0 && limit > 0 && steady_ms() - since > limit && !c->comm_aborted.load()) {
+                c->comm_aborted.store(true);
+                rccl().CommAbort(c->comm);          // the collective's kernel returns, the blocked host call with it
+            }
+        }
+    });
+}
 static void comm_release(dpmm_ctx *c) {
-    if (c->comm) { rccl().CommDestroy(c->comm); c->comm = nullptr; }
+    watchdog_stop(c);
+    if (c->comm) { if (!c->comm_aborted.load()) rccl().CommDestroy(c->comm); c->comm = nullptr; }      // (ncclCommAbort released an aborted one)
+    c->comm_aborted.store(false);
     c->host_fn = nullptr; c->host_user = nullptr;
     c->world = 1; c->rank = 0;
     c->have_comm_ev[0] = c->have_comm_ev[1] = false;
@@ -363,7 +431,7 @@ static int ensure_capacity(dpmm_ctx *c, int K) {
     int cap = std::max(8, c->Kcap);
     while (cap < K) cap *= 2;
     cap = std::min(cap, DPMM_MAX_CLUSTERS);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     free_params(c);
     const size_t D = (size_t)c->D;
     if (c->prior == DPMM_PRIOR_NIW) {
@@ -505,7 +573,7 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
 int dpmm_destroy(dpmm_ctx *c) {
     if (!c) return DPMM_OK;
     hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->stream && !c->comm_aborted.load()) hipStreamSynchronize(c->stream);
     free_params(c);
     hipFree(c->dX); hipFree(c->dX8); hipFree(c->dbins); hipFree(c->d_gt); hipFree(c->d_cont);
     hipFree(c->sb.tile_hist); hipFree(c->sb.tile_cnt); hipFree(c->sb.fast_total); hipFree(c->sb.ticket); hipFree(c->sb.prev_lab); hipFree(c->sb.cdirty); hipFree(c->sb.cmode); hipFree(c->sb.bin_total); hipFree(c->sb.bin_start); hipFree(c->sb.item_start);
@@ -548,7 +616,7 @@ static int finish_upload(dpmm_ctx *c) {
         HIPCHK(c, launch_bf16_exact_check(c->dX, c->n * c->ldx, flag, c->stream));
         int h = 1;
         HIPCHK(c, hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, sync_stream(c, c->stream));
         c->x_bf16_exact = (h == 0 && !force_f32) ? 1 : 0;
         c->x_u8 = 0;
         if (c->x_bf16_exact && !c->opt_no_u8 && c->n > 0) {
@@ -558,7 +626,7 @@ static int finish_upload(dpmm_ctx *c) {
             HIPCHK(c, hipMemsetAsync(flag, 0, sizeof(int), c->stream));
             HIPCHK(c, launch_u8_convert(c->dX, c->ldx, c->D, c->n, c->dX8, c->ld8, flag, c->stream));
             HIPCHK(c, hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, sync_stream(c, c->stream));
             c->x_u8 = (h == 0) ? 1 : 0;
             if (!c->x_u8) { hipFree(c->dX8); c->dX8 = nullptr; }
             // every Multinomial kernel of a byte-path context reads the byte copy (a lossless re-encoding): the Float32 matrix (4 bytes per
@@ -566,7 +634,7 @@ static int finish_upload(dpmm_ctx *c) {
             else { HIPCHK(c, hipFree(c->dX)); c->dX = nullptr; }
         }
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     // new points: the cached cluster-level statistics (derive_rows_kernel) and the rows a device master would draw from belong to the old ones
     c->cache_force = true;
     c->rows_full_K = -1;
@@ -614,7 +682,7 @@ int dpmm_upload_points_npy(dpmm_ctx *c, const void *rows, int is_f64, int64_t ld
             const int64_t nr = std::min(chunk_rows, c->n - r0);
             hipError_t e = hipMemcpyAsync(tmp, (const char *)rows + esz * (size_t)r0 * (size_t)ld, esz * (size_t)nr * (size_t)ld, hipMemcpyHostToDevice, c->stream);
             if (e == hipSuccess) e = launch_ingest_rows(c->dX + (size_t)r0 * c->ldx, c->ldx, tmp, is_f64, ld, nr, c->D, nan_to_zero, c->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);       // tmp is reused by the next chunk
+            if (e == hipSuccess) e = sync_stream(c, c->stream);       // tmp is reused by the next chunk
             if (e != hipSuccess) { c->err = std::string("dpmm_upload_points_npy: ") + hipGetErrorString(e); rc = DPMM_EHIP; }
         }
         hipFree(tmp);
@@ -659,7 +727,7 @@ int dpmm_set_labels(dpmm_ctx *c, const int64_t *labels, const int64_t *sub) {
     if (labels) e = hipMemcpyAsync(tmp, labels, sizeof(int64_t) * c->n, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess && sub) e = hipMemcpyAsync(tmp + c->n, sub, sizeof(int64_t) * c->n, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = launch_bins_from_i64(c->dbins, labels ? tmp : nullptr, sub ? tmp + c->n : nullptr, c->n, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = sync_stream(c, c->stream);
     hipFree(tmp);
     if (e != hipSuccess) { c->err = std::string("dpmm_set_labels: ") + hipGetErrorString(e); rc = DPMM_EHIP; }
     else c->have_labels = true;
@@ -677,7 +745,7 @@ int dpmm_get_labels(dpmm_ctx *c, int64_t *labels, int64_t *sub) {
     hipError_t e = launch_bins_to_i64(c->dbins, tmp, tmp + c->n, c->n, c->stream);
     if (e == hipSuccess && labels) e = hipMemcpyAsync(labels, tmp, sizeof(int64_t) * c->n, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess && sub) e = hipMemcpyAsync(sub, tmp + c->n, sizeof(int64_t) * c->n, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = sync_stream(c, c->stream);
     hipFree(tmp);
     if (e != hipSuccess) { c->err = std::string("dpmm_get_labels: ") + hipGetErrorString(e); return DPMM_EHIP; }
     return DPMM_OK;
@@ -727,7 +795,7 @@ int dpmm_params_staging(dpmm_ctx *c, int slots, float **mu, float **mat, float *
         ns = std::min(ns, DPMM_MAX_CLUSTERS);
         const ParLayout N = par_layout(c, ns);
         char *nb = nullptr;
-        HIPCHK(c, hipStreamSynchronize(c->stream));      // a pack kernel may still read the old buffer
+        HIPCHK(c, sync_stream(c, c->stream));      // a pack kernel may still read the old buffer
         HIPCHK(c, hipHostMalloc((void **)&nb, N.bytes, hipHostMallocDefault));
         memset(nb, 0, N.bytes);
         if (c->h_par) {                                  // contents are preserved (rows are slot-indexed: same offsets inside a region)
@@ -790,7 +858,7 @@ int dpmm_commit_params(dpmm_ctx *c, int K) {
         const size_t img_bytes = (L.mat - L.cst) + sizeof(float) * 3 * (size_t)top * T;
         const size_t cap = (L.logdet - L.cst) + 1024;
         if (cap > c->d_par_bytes) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, sync_stream(c, c->stream));
             hipFree(c->d_par); c->d_par = nullptr;
             HIPCHK(c, hipMalloc(&c->d_par, cap));
             c->d_par_bytes = cap;
@@ -832,7 +900,7 @@ static int stage_and_commit(dpmm_ctx *c, int K, const float *mu, const float *ma
     float *smu, *smat, *sld, *slr, *sw;
     int32_t *sslot;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));          // an earlier pack kernel may still read the staging buffer
+    HIPCHK(c, sync_stream(c, c->stream));          // an earlier pack kernel may still read the staging buffer
     if (int rc = dpmm_params_staging(c, K, &smu, &smat, &sld, &slr, &sw, &sslot)) return rc;
     const size_t D = (size_t)c->D;
     if (mu) memcpy(smu, mu, sizeof(float) * 3 * K * D);
@@ -1014,12 +1082,12 @@ int dpmm_set_predictive_niw(dpmm_ctx *c, int K, const float *m, const float *R, 
         tdf[6 * k + 1] = (float)(0.5 * (v + D));
     }
     if (int rc = ensure_pinned(c, sizeof(float) * 9 * K)) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     memcpy(c->h_pin, cst.data(), sizeof(float) * 3 * K);
     memcpy(c->h_pin + sizeof(float) * 3 * K, tdf.data(), sizeof(float) * 6 * K);
     HIPCHK(c, launch_copy_bytes(c->d_cst, c->h_pin, sizeof(float) * 3 * K, c->stream));
     HIPCHK(c, launch_copy_bytes(c->d_tdf, c->h_pin + sizeof(float) * 3 * K, sizeof(float) * 6 * K, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     c->predictive = true;
     return DPMM_OK;
 }
@@ -1062,7 +1130,7 @@ int dpmm_predict_points(dpmm_ctx *c, int64_t *labels, float *probs) {
         if (e == hipSuccess) e = launch_predict_finish(table, stride, rstep, c->n, c->K, d_lab, d_probs, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(labels, d_lab, sizeof(int64_t) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess && probs) e = hipMemcpyAsync(probs, d_probs, sizeof(float) * (size_t)c->n * (size_t)c->K, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = sync_stream(c, c->stream);
         if (e != hipSuccess) { c->err = std::string("dpmm_predict_points: ") + hipGetErrorString(e); rc = DPMM_EHIP; }
     }
     hipFree(table); hipFree(d_lab); hipFree(d_probs);
@@ -1084,7 +1152,7 @@ int dpmm_debug_loglik(dpmm_ctx *c, float *out) {
         const size_t src_pitch = sizeof(float) * stride * (c->prior == DPMM_PRIOR_MULT ? 3 : 1);
         hipError_t e = hipMemcpy2DAsync(out, sizeof(float) * c->n, table, src_pitch, sizeof(float) * c->n,
                                         (size_t)c->K, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = sync_stream(c, c->stream);
         if (e != hipSuccess) { c->err = std::string("dpmm_debug_loglik: ") + hipGetErrorString(e); rc = DPMM_EHIP; }
         else if (c->opt_ref_const && c->prior == DPMM_PRIOR_NIW && !c->predictive) {
             // mv_gaussian.jl:24 normalises with length(Sigma) = D^2: -(D^2 log 2 pi + logdet)/2; the table carries -logdet/2 only
@@ -1100,7 +1168,7 @@ int64_t dpmm_packed_stride(const dpmm_ctx *c) { return c ? c->packed_stride : 0;
 
 static int ensure_out(dpmm_ctx *c, size_t bytes) {
     if (bytes <= c->h_out_bytes) return DPMM_OK;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     if (c->h_out) hipHostFree(c->h_out);
     c->h_out = nullptr; c->h_out_bytes = 0;
     size_t cap = 1 << 20;
@@ -1140,7 +1208,7 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
             c->h_sel[2 * (idx[j] - 1) + 1] = 1;
         }
         if (int rc = ensure_pinned(c, nbins + 8)) return rc;
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, sync_stream(c, c->stream));
         memcpy(c->h_pin, c->h_sel.data(), nbins);
         HIPCHK(c, launch_copy_bytes(c->sb.bin_sel, c->h_pin, nbins, c->stream));
         c->sel_all_ones = 0;
@@ -1254,7 +1322,7 @@ int dpmm_bin_counts(dpmm_ctx *c, int64_t *counts) {
     if (int rc = ensure_pinned(c, sizeof(int32_t) * nbins)) return rc;
     HIPCHK(c, launch_sort_by_bin(c->dbins, c->n, nbins, c->sb, c->stream));      // hist + scan -> bin_total
     HIPCHK(c, launch_copy_bytes(c->h_pin, c->sb.bin_total, sizeof(int32_t) * nbins, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     const int32_t *h = reinterpret_cast<const int32_t *>(c->h_pin);
     for (int b = 0; b < nbins; ++b) counts[b] = h[b];
     return DPMM_OK;
@@ -1264,7 +1332,7 @@ int dpmm_suffstats_packed_device(dpmm_ctx *c, const int64_t *idx, int n_idx, dou
     if (!c || !d_out) return DPMM_EINVAL;
     if (int rc = run_stats(c, idx, n_idx)) return rc;
     HIPCHK(c, hipMemcpyAsync(d_out, c->d_out, sizeof(double) * 2 * c->K * (size_t)c->packed_stride, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     return DPMM_OK;
 }
 
@@ -1275,7 +1343,7 @@ int dpmm_suffstats_host(dpmm_ctx *c, const int64_t *idx, int n_idx, const double
     if (int rc = ensure_out(c, out_bytes + DPMM_MAX_CLUSTERS + 64)) return rc;
     if (int rc = run_stats(c, idx, n_idx)) return rc;
     HIPCHK(c, launch_copy_bytes(c->h_out, c->d_out, out_bytes, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     *packed = reinterpret_cast<const double *>(c->h_out);
     return DPMM_OK;
 }
@@ -1288,7 +1356,7 @@ int dpmm_step_stats(dpmm_ctx *c, uint32_t reset_epoch, const double **packed, co
     if (int rc = run_stats(c, nullptr, 0, true, reset_epoch)) return rc;
     if (c->marg_req) if (int rc = mult_marginals_launch(c)) return rc;       // the master's log-marginals ride behind the statistics: one wait
     HIPCHK(c, launch_copy_bytes(c->h_out, c->d_out, out_bytes + (size_t)c->K + 1, c->stream));      // rows | flags
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     *packed = reinterpret_cast<const double *>(c->h_out);
     *bad = reinterpret_cast<const uint8_t *>(c->h_out + out_bytes);
     return DPMM_OK;
@@ -1297,7 +1365,7 @@ int dpmm_step_stats(dpmm_ctx *c, uint32_t reset_epoch, const double **packed, co
 // ---- the master's dense maths on the device --------------------------------------------------------------------------------
 static int master_pinned(dpmm_ctx *c, size_t bytes) {
     if (bytes <= c->h_master_bytes) return DPMM_OK;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     if (c->h_master) hipHostFree(c->h_master);
     c->h_master = nullptr; c->h_master_bytes = 0;
     size_t cap = 1 << 16;
@@ -1372,7 +1440,7 @@ static int master_capacity(dpmm_ctx *c, int slots, int K) {
         int ns = std::max(8, c->master_slots);
         while (ns < slots) ns *= 2;
         ns = std::min(ns, DPMM_MAX_CLUSTERS);
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, sync_stream(c, c->stream));
         if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
         c->spec_valid = false; c->noise_valid = false; c->apairs_valid = false;
         double *fac = nullptr, *mean = nullptr, *kap = nullptr, *nu = nullptr, *rows = nullptr;
@@ -1397,7 +1465,7 @@ static int master_capacity(dpmm_ctx *c, int slots, int K) {
         int nk = std::max(8, c->master_K);
         while (nk < K) nk *= 2;
         nk = std::min(nk, DPMM_MAX_CLUSTERS);
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, sync_stream(c, c->stream));
         if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
         c->spec_valid = false; c->noise_valid = false; c->apairs_valid = false;
         for (int i = 0; i < 2; ++i) {
@@ -1423,7 +1491,7 @@ int dpmm_niw_master_setup(dpmm_ctx *c, double kappa, double nu, const double *m,
     std::vector<double> lo(T);
     for (int a = 0; a < D; ++a)
         for (int b = 0; b <= a; ++b) lo[(size_t)a * (a + 1) / 2 + b] = 0.5 * (psi[(size_t)a * D + b] + psi[(size_t)b * D + a]);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     if (!c->d_m0) HIPCHK(c, hipMalloc(&c->d_m0, sizeof(double) * D));
     if (!c->d_psi_lo) HIPCHK(c, hipMalloc(&c->d_psi_lo, sizeof(double) * T));
     HIPCHK(c, hipMemcpy(c->d_m0, m, sizeof(double) * D, hipMemcpyHostToDevice));
@@ -1454,7 +1522,7 @@ int dpmm_step_stats_device(dpmm_ctx *c, uint32_t reset_epoch, const uint8_t **ba
     if (int rc = ensure_out(c, DPMM_MAX_CLUSTERS + 64)) return rc;
     if (int rc = run_stats(c, nullptr, 0, true, reset_epoch)) return rc;
     HIPCHK(c, launch_copy_bytes(c->h_out, reinterpret_cast<const uint8_t *>(c->d_out) + out_bytes, (size_t)c->K + 1, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     *bad = reinterpret_cast<const uint8_t *>(c->h_out);
     return DPMM_OK;
 }
@@ -1510,7 +1578,7 @@ int dpmm_step_master_device(dpmm_ctx *c, uint32_t reset_epoch, const int32_t *sl
     bool fuse_pairs = true;
     if (napairs > 0) {
         if ((size_t)napairs > c->apairs_cap) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, sync_stream(c, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream2));
             size_t cap = 64;
             while (cap < (size_t)napairs) cap *= 2;
@@ -1522,7 +1590,7 @@ int dpmm_step_master_device(dpmm_ctx *c, uint32_t reset_epoch, const int32_t *sl
             c->apairs_cap = cap;
         }
         if (c->ma.DP > 128 && (size_t)napairs > c->pair_cap) {      // scratch matrices of the large-D pair kernels
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, sync_stream(c, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream2));
             hipFree(c->d_pairs); c->d_pairs = nullptr; c->pair_cap = 0;
             size_t cap = 64;
@@ -1595,13 +1663,13 @@ int dpmm_step_master_device(dpmm_ctx *c, uint32_t reset_epoch, const int32_t *sl
         c->spec_inflight = false; c->spec_valid = true; c->spec_epoch = draw_epoch;
         c->spec_slots.assign(slots, slots + K);
     }
-    HIPCHK(c, hipEventSynchronize(c->ev_master));
+    HIPCHK(c, sync_event(c, c->ev_master));
     if (master_marks_left(sm, K)) {
         ++c->dbg_early_wait;
         const auto t0 = std::chrono::steady_clock::now();
         while (master_marks_left(sm, K)) {
             if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) return fail(c, DPMM_EHIP, "posterior records missing 5 s after the event wait returned");
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, sync_stream(c, c->stream));
         }
     }
     c->handover_inflight = false;          // (recorded behind the last hand-over kernel on the same stream)
@@ -1634,13 +1702,13 @@ int dpmm_niw_master_posterior(dpmm_ctx *c, const int64_t *clusters, const int32_
     for (int i = 0; i < n; ++i) if ((size_t)slots[i] < c->apairs_dirty.size()) c->apairs_dirty[slots[i]] = 1;      // ... nor pooled pairs that involve these slots
     const size_t jobs_bytes = (sizeof(int32_t) * 2 * (size_t)n + 63) & ~(size_t)63;
     if (int rc = master_pinned(c, jobs_bytes + sizeof(double) * 3 * DPMM_MASTER_NSCALARS * (size_t)n)) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));            // nobody reads the pinned block any more
+    HIPCHK(c, sync_stream(c, c->stream));            // nobody reads the pinned block any more
     std::vector<int32_t> jobs(2 * (size_t)n);
     for (int i = 0; i < n; ++i) { jobs[2 * i] = (int32_t)((clusters ? clusters[i] : i + 1) - 1); jobs[2 * i + 1] = slots[i]; }
     if (int rc = device_list(c, c->d_jobs, c->jobs_shadow, jobs.data(), jobs.size())) return rc;
     double *sm = reinterpret_cast<double *>(c->h_master + jobs_bytes);
     HIPCHK(c, launch_niw_master_posterior(c->ma, c->d_jobs, n, c->d_out, sm, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     *small = sm;
     return DPMM_OK;
 }
@@ -1660,7 +1728,7 @@ int dpmm_niw_master_draw(dpmm_ctx *c, uint32_t epoch, int K, const int32_t *slot
     // The previous hand-over kernel reads lr / w from this block: wait only if the host has not waited for anything behind it since
     // (in the engine's loop it has -- for the posteriors of the step -- and the stream now carries the draws launched ahead, which a
     // synchronise here would wait out: 27 us on the host's critical path at D = 64)
-    if (c->handover_inflight) HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->handover_inflight) HIPCHK(c, sync_stream(c, c->stream));
     c->handover_inflight = true;
     float *hlr = reinterpret_cast<float *>(c->h_draw), *hw = hlr + 2 * K;
     memcpy(hlr, lr, sizeof(float) * 2 * K);
@@ -1733,7 +1801,7 @@ int dpmm_niw_master_pairs(dpmm_ctx *c, const int32_t *slots_i, const int32_t *sl
     }
     if (int rc = spec_join(c)) return rc;          // (a job launched ahead may still use the scratch matrices)
     if ((size_t)n > c->pair_cap) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, sync_stream(c, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream2));
         hipFree(c->d_pairs); c->d_pairs = nullptr; c->pair_cap = 0;
         size_t cap = 64;
@@ -1743,12 +1811,12 @@ int dpmm_niw_master_pairs(dpmm_ctx *c, const int32_t *slots_i, const int32_t *sl
     }
     const size_t idx_bytes = (sizeof(int32_t) * 2 * (size_t)n + 63) & ~(size_t)63;
     if (int rc = master_pinned(c, idx_bytes + sizeof(double) * DPMM_MASTER_NSCALARS * (size_t)n)) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     int32_t *pr = reinterpret_cast<int32_t *>(c->h_master);
     for (int i = 0; i < n; ++i) { pr[2 * i] = slots_i[i]; pr[2 * i + 1] = slots_j[i]; }
     double *sm = reinterpret_cast<double *>(c->h_master + idx_bytes);
     HIPCHK(c, launch_niw_master_pairs(c->ma, pr, n, c->d_pairs, sm, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     *small = sm;
     return DPMM_OK;
 }
@@ -1759,7 +1827,7 @@ int dpmm_niw_master_put_rows(dpmm_ctx *c, const double *rows, int K) {
     if (int rc = check_K(c, K)) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     if (int rc = ensure_capacity(c, K)) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     HIPCHK(c, hipMemcpy(c->d_out, rows, sizeof(double) * 2 * (size_t)K * (size_t)c->packed_stride, hipMemcpyHostToDevice));
     c->apairs_valid = false;
     if (K != c->K) c->have_params = false;
@@ -1778,11 +1846,11 @@ int dpmm_niw_master_rows(dpmm_ctx *c, const int32_t *slots, int n, double *out) 
     // one gather kernel into pinned memory (n separate copies cost 6 us each), then a host copy to the caller's buffer
     if (int rc = ensure_out(c, bytes)) return rc;
     if (int rc = ensure_pinned(c, sizeof(int32_t) * (size_t)n + 64)) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     memcpy(c->h_pin, slots, sizeof(int32_t) * (size_t)n);
     HIPCHK(c, launch_niw_rows_gather(c->ma.rows_store, reinterpret_cast<const int32_t *>(c->h_pin), n, (int64_t)stride,
                                      reinterpret_cast<double *>(c->h_out), c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     memcpy(out, c->h_out, bytes);
     return DPMM_OK;
 }
@@ -1791,7 +1859,7 @@ int dpmm_niw_master_draws(dpmm_ctx *c, int K, float *mu, float *R, float *logdet
     if (!c || !mu || !R || !logdet) return DPMM_EINVAL;
     if (!c->master || !c->draws_on_device || K != c->K) return fail(c, DPMM_ESTATE, "no device draws for this K");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     const size_t D = (size_t)c->D, DP = (size_t)c->ma.DP;
     std::vector<double> Y(3 * (size_t)K * DP * DP);
     std::vector<float> m(3 * (size_t)K * DP);
@@ -1812,10 +1880,10 @@ int dpmm_mult_master_setup(dpmm_ctx *c, const float *alpha, const float *alpha_o
     if (c->prior != DPMM_PRIOR_MULT) return fail(c, DPMM_EINVAL, "dpmm_mult_master_setup: the context is not Multinomial");
     if (c->D > DPMM_MULT_MASTER_MAXD) return fail(c, DPMM_ELIMIT, "D exceeds the device Dirichlet draw's limit");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     if (!c->d_malpha) HIPCHK(c, hipMalloc(&c->d_malpha, sizeof(float) * 2 * (size_t)c->ldx));
     HIPCHK(c, hipMemsetAsync(c->d_malpha, 0, sizeof(float) * 2 * (size_t)c->ldx, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     HIPCHK(c, hipMemcpy(c->d_malpha, alpha, sizeof(float) * (size_t)c->D, hipMemcpyHostToDevice));
     if (alpha_outlier) HIPCHK(c, hipMemcpy(c->d_malpha + c->ldx, alpha_outlier, sizeof(float) * (size_t)c->D, hipMemcpyHostToDevice));
     c->mult_has_alpha1 = alpha_outlier != nullptr;
@@ -1839,7 +1907,7 @@ int dpmm_mult_master_put_rows(dpmm_ctx *c, const double *rows, int K) {
     if (int rc = check_K(c, K)) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     if (int rc = ensure_capacity(c, K)) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     HIPCHK(c, hipMemcpy(c->d_out, rows, sizeof(double) * 2 * (size_t)K * (size_t)c->packed_stride, hipMemcpyHostToDevice));
     c->K = K;
     c->rows_full_K = K;
@@ -1857,7 +1925,7 @@ int dpmm_mult_master_draw(dpmm_ctx *c, uint32_t epoch, int K, int outlier_first,
     HIPCHK(c, hipSetDevice(c->device));
     if (int rc = ensure_capacity(c, K)) return rc;
     // cst[3k] = log w_k, cst[3k+1+s] = log lr[k][s] through the pinned block (see dpmm_niw_master_draw for the wait)
-    if (c->handover_inflight) HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->handover_inflight) HIPCHK(c, sync_stream(c, c->stream));
     c->handover_inflight = true;
     float *hcst = reinterpret_cast<float *>(c->h_draw);
     for (int k = 0; k < K; ++k) { hcst[3 * k] = logf(w[k]); hcst[3 * k + 1] = logf(lr[2 * k]); hcst[3 * k + 2] = logf(lr[2 * k + 1]); }
@@ -1878,7 +1946,7 @@ int dpmm_mult_master_draws(dpmm_ctx *c, int K, float *logp) {
     if (!c || !logp) return DPMM_EINVAL;
     if (!c->mult_master || !c->draws_on_device || K != c->K) return fail(c, DPMM_ESTATE, "no device draws for this K");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     HIPCHK(c, hipMemcpy2D(logp, sizeof(float) * (size_t)c->D, c->d_raw, sizeof(float) * (size_t)c->ldx, sizeof(float) * (size_t)c->D, 3 * (size_t)K,
                           hipMemcpyDeviceToHost));
     return DPMM_OK;
@@ -1920,7 +1988,7 @@ int dpmm_mult_master_marginals(dpmm_ctx *c, int K, const double **rows_nl, const
         if (int rc = mult_marginals_launch(c)) return rc;
         if (!c->marg_valid) return fail(c, DPMM_ESTATE, "dpmm_mult_master_marginals: no outlier prior was set up");
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));        // (no-op behind dpmm_step_stats, which waited for the kernel with the rows)
+    HIPCHK(c, sync_stream(c, c->stream));        // (no-op behind dpmm_step_stats, which waited for the kernel with the rows)
     *rows_nl = c->h_marg; *pairs_l = c->h_marg + 6 * (size_t)K; *npairs = c->marg_np;
     return DPMM_OK;
 }
@@ -1935,14 +2003,14 @@ int dpmm_debug_niw_draw_inputs(dpmm_ctx *c, uint32_t epoch, int K, const int32_t
     const size_t D = (size_t)c->D, nA = 3 * (size_t)K * D * D, nx = 3 * (size_t)K * D;
     double *dA = nullptr, *dxi = nullptr;
     int32_t *dsl = nullptr;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     hipError_t e = hipMalloc(&dA, sizeof(double) * nA);
     if (e == hipSuccess) e = hipMalloc(&dxi, sizeof(double) * nx);
     if (e == hipSuccess) e = hipMalloc(&dsl, sizeof(int32_t) * K);
     if (e == hipSuccess) e = hipMemsetAsync(dA, 0, sizeof(double) * nA, c->stream);
     if (e == hipSuccess) e = hipMemcpy(dsl, slot_of_cluster, sizeof(int32_t) * K, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = launch_niw_draw_inputs(c->ma, dsl, K, epoch, dA, dxi, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = sync_stream(c, c->stream);
     if (e == hipSuccess) e = hipMemcpy(A, dA, sizeof(double) * nA, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(xi, dxi, sizeof(double) * nx, hipMemcpyDeviceToHost);
     hipFree(dA); hipFree(dxi); hipFree(dsl);
@@ -1996,7 +2064,7 @@ static int upload_idx(dpmm_ctx *c, const int64_t *a, const int64_t *b, int n, in
         }
     }
     if (int rc = ensure_pinned(c, sizeof(int32_t) * h.size())) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     memcpy(c->h_pin, h.data(), sizeof(int32_t) * h.size());
     HIPCHK(c, launch_copy_bytes(c->d_small, c->h_pin, sizeof(int32_t) * h.size(), c->stream));
     return DPMM_OK;
@@ -2043,7 +2111,7 @@ int dpmm_remove_empty(dpmm_ctx *c, const int64_t *pts_count, int K) {
         map[l - 1] = v - 1;
     }
     if (int rc = ensure_pinned(c, sizeof(int32_t) * map.size())) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     memcpy(c->h_pin, map.data(), sizeof(int32_t) * map.size());
     HIPCHK(c, launch_copy_bytes(c->d_small, c->h_pin, sizeof(int32_t) * map.size(), c->stream));
     if (c->n > 0) HIPCHK(c, launch_remap(c->dbins, c->n, c->d_small, c->stream));
@@ -2093,7 +2161,7 @@ int dpmm_smart_project(dpmm_ctx *c, int64_t cluster, const double *v, const doub
     HIPCHK(c, launch_smart_project(c->dbins, c->dX, c->ldx, c->n, c->D, (int)(cluster - 1), d_v, d_mu, c->d_proj, c->d_vals, d_cnt, c->stream));
     unsigned long long h = 0;
     HIPCHK(c, hipMemcpyAsync(&h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     *count = (int64_t)h;
     if (values && h > 0) HIPCHK(c, hipMemcpy(values, c->d_vals, sizeof(double) * h, hipMemcpyDeviceToHost));
     return DPMM_OK;
@@ -2109,7 +2177,7 @@ int dpmm_smart_kmeans_iter(dpmm_ctx *c, int64_t cluster, double m_lo, double m_h
     double *d_out = c->d_smart + 4 * (size_t)smart_groups();
     HIPCHK(c, launch_smart_kmeans(c->dbins, c->d_proj, c->n, (int)(cluster - 1), m_lo, m_hi, c->d_smart, d_out, c->stream));
     HIPCHK(c, hipMemcpyAsync(out4, d_out, sizeof(double) * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     return DPMM_OK;
 }
 
@@ -2134,7 +2202,7 @@ int dpmm_set_ground_truth(dpmm_ctx *c, const int64_t *gt, int n_gt) {
         HIPCHK(c, hipMalloc(&tmp, sizeof(int64_t) * (size_t)c->n));
         hipError_t e = hipMemcpyAsync(tmp, gt, sizeof(int64_t) * c->n, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = launch_i64_to_i32(c->d_gt, tmp, c->n, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = sync_stream(c, c->stream);
         hipFree(tmp);
         if (e != hipSuccess) { c->err = std::string("dpmm_set_ground_truth: ") + hipGetErrorString(e); return DPMM_EHIP; }
     }
@@ -2152,7 +2220,7 @@ int dpmm_contingency(dpmm_ctx *c, int K, int64_t *counts) {
     HIPCHK(c, hipMemsetAsync(c->d_cont, 0, bytes, c->stream));
     if (c->n > 0) HIPCHK(c, launch_contingency(c->dbins, c->d_gt, c->n, K, c->n_gt, c->d_cont, c->stream));
     HIPCHK(c, launch_copy_bytes(c->h_pin, c->d_cont, bytes, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     memcpy(counts, c->h_pin, bytes);
     return DPMM_OK;
 }
@@ -2160,7 +2228,7 @@ int dpmm_contingency(dpmm_ctx *c, int K, int64_t *counts) {
 int dpmm_sync(dpmm_ctx *c) {
     if (!c) return DPMM_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     return DPMM_OK;
 }
 
@@ -2198,6 +2266,7 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
         case DPMM_OPT_STATS_DERIVE: c->opt_derive = value != 0; c->cache_force = true; return DPMM_OK;
         case DPMM_OPT_NOISE_AHEAD: c->opt_noise_ahead = value != 0; return DPMM_OK;
         case DPMM_OPT_REF_BRACKET: c->opt_bracket = value != 0; return DPMM_OK;
+        case DPMM_OPT_COMM_TIMEOUT_MS: c->comm_timeout_ms = value > 0 ? (int)std::min(value, 2.0e9) : 0; return DPMM_OK;
         case DPMM_OPT_BF16_SCREENS: c->opt_bf16scr = value != 0; return DPMM_OK;
         case DPMM_OPT_ONE_COLLECTIVE: c->opt_one_collective = value != 0; return DPMM_OK;
         case DPMM_OPT_SORT_TILE: {
@@ -2225,7 +2294,7 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
 int dpmm_last_sweep_work(dpmm_ctx *c, uint64_t *out16) {
     if (!c || !out16) return DPMM_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     std::vector<unsigned long long> h((size_t)DPMM_WORK_PER_WAVE * (size_t)c->work_waves);
     if (!h.empty()) HIPCHK(c, hipMemcpy(h.data(), c->d_work + DPMM_WORK_SLOTS, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
     for (int i = 0; i < 16; ++i) out16[i] = 0;
@@ -2281,6 +2350,7 @@ int dpmm_comm_init(dpmm_ctx *c, const void *unique_id128, int rank, int world) {
     const int rc = r.CommInitRank(&comm, world, id, rank);
     if (rc != 0) return fail(c, DPMM_ECOMM, std::string("ncclCommInitRank: ") + r.GetErrorString(rc));
     c->comm = comm; c->rank = rank; c->world = world;
+    watchdog_start(c);
     return DPMM_OK;
 }
 
@@ -2288,7 +2358,7 @@ int dpmm_comm_init_host(dpmm_ctx *c, int rank, int world, dpmm_host_allreduce_fn
     if (!c || !fn) return DPMM_EINVAL;
     if (world < 1 || rank < 0 || rank >= world) return fail(c, DPMM_EINVAL, "bad rank / world");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     comm_release(c);
     c->host_fn = fn; c->host_user = user; c->rank = rank; c->world = world;
     return DPMM_OK;
@@ -2307,7 +2377,7 @@ int dpmm_comm_info(dpmm_ctx *c, int64_t *out8) {
 int dpmm_last_comm_ms(dpmm_ctx *c, float *counts_ms, float *rows_ms) {
     if (!c) return DPMM_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     if (counts_ms) { *counts_ms = 0.f; if (c->have_comm_ev[0]) HIPCHK(c, hipEventElapsedTime(counts_ms, c->ev_comm[0], c->ev_comm[1])); }
     if (rows_ms) { *rows_ms = 0.f; if (c->have_comm_ev[1]) HIPCHK(c, hipEventElapsedTime(rows_ms, c->ev_comm[2], c->ev_comm[3])); }
     return DPMM_OK;
@@ -2316,7 +2386,7 @@ int dpmm_last_comm_ms(dpmm_ctx *c, float *counts_ms, float *rows_ms) {
 int dpmm_comm_destroy(dpmm_ctx *c) {
     if (!c) return DPMM_EINVAL;
     hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->stream && !c->comm_aborted.load()) sync_stream(c, c->stream);
     comm_release(c);
     return DPMM_OK;
 }
@@ -2338,7 +2408,7 @@ int dpmm_comm_allgather_host(dpmm_ctx *c, const void *mine, int64_t bytes, void 
     if (int rc = ensure_pinned(c, nb + tot)) return rc;
     char *dbuf = nullptr;
     HIPCHK(c, hipMalloc(&dbuf, tot));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     memcpy(c->h_pin, mine, (size_t)bytes);
     hipError_t e = launch_copy_bytes(dbuf + nb * (size_t)c->rank, c->h_pin, nb, c->stream);
     int rc = DPMM_OK;
@@ -2348,7 +2418,7 @@ int dpmm_comm_allgather_host(dpmm_ctx *c, const void *mine, int64_t bytes, void 
         if (nrc != 0) rc = fail(c, DPMM_ECOMM, std::string("ncclAllGather: ") + r.GetErrorString(nrc));
     }
     if (rc == DPMM_OK && e == hipSuccess) e = launch_copy_bytes(c->h_pin + nb, dbuf, tot, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = sync_stream(c, c->stream);
     hipFree(dbuf);
     if (e != hipSuccess) { c->err = std::string("dpmm_comm_allgather_host: ") + hipGetErrorString(e); return DPMM_EHIP; }
     if (rc != DPMM_OK) return rc;
@@ -2414,7 +2484,7 @@ int dpmm_debug_subloglik(dpmm_ctx *c, float *out) {
         if (rc == DPMM_OK) {
             const size_t src_pitch = sizeof(float) * stride * (niw ? 1 : 3);
             e = hipMemcpy2DAsync(out, sizeof(float) * c->n, table, src_pitch, sizeof(float) * c->n, (size_t)K2, hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e == hipSuccess) e = sync_stream(c, c->stream);
         }
     }
     hipStreamSynchronize(c->stream);
@@ -2441,7 +2511,7 @@ int dpmm_debug_ref_bracket(dpmm_ctx *c, int64_t cluster, float c_override, float
     hipError_t e = launch_niw_refb_debug(a, (int)cluster - 1, c_override, d, d + c->n, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(q_hi, d, sizeof(float) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(q, d + c->n, sizeof(float) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = sync_stream(c, c->stream);
     hipFree(d);
     if (e != hipSuccess) { c->err = std::string("dpmm_debug_ref_bracket: ") + hipGetErrorString(e); return DPMM_EHIP; }
     return DPMM_OK;

@@ -77,6 +77,8 @@ enum {
                                          (two bf16 matrix passes with a certified rounding bound, ~1/7 of a Float32 evaluation) and evaluated in Float32 only
                                          if some other cluster survives the screens against the bracket's lower end; same labels; 0: always evaluated */
     DPMM_OPT_SORT_TILE = 19,          /* points per sorting wave of the statistics passes: 512 (default below 4e6 points per shard) or 2048 */
+    DPMM_OPT_COMM_TIMEOUT_MS = 22,    /* RCCL transport: the longest a host call may block on the ctx stream behind a collective (default 120 000 ms; 0: for ever).
+                                         Past it a watchdog aborts the communicator and the call -- on every surviving rank -- fails with DPMM_ECOMM */
     DPMM_OPT_BF16_SCREENS = 21,       /* 1 (default): D in 33..64 NIW sweep: a bf16 lower bound of the last block row's part of the quadratic form (8 matrix
                                          instructions) in front of every Float32 16-row screen (16), and of the first block row's part (16 + 4) in front of every
                                          survivor's evaluation; they only skip Float32 tests that would have excluded the cluster too: same labels; 0: off */

@@ -233,3 +233,107 @@ def test_bench_with_eight_ranks_on_one_gpu(tmp_path):
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 8 and d["value"] > 0 and d["comm"]["world"] == 8 and d["comm"]["transport"] == "host"
     assert d["config"]["points_per_gpu"] == 100000 and d["growth"]["K_final"] >= 2 and d["host_master"]["it_per_s"] > 0
+
+
+# ---------------------------------------------------------------------------------------------- a dead peer is an error, not a hang
+def _dying_rank(rank, world, port, out):
+    """Two ranks over the host transport; rank 1 leaves after three sweeps without saying goodbye."""
+    sys.path.insert(0, ROOT)
+    import datetime
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    host = importlib.import_module("dpmmsubclusters_jl_amd.host")
+    from dpmmsubclusters_jl_amd.host.comm import TorchDistComm
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=20))
+    comm = TorchDistComm(device=0)
+    N, D = 40000, 8
+    x, y, _, _ = host.generate_gaussian_data(N, D, 4, 100.0, seed=5)
+    x = np.ascontiguousarray(x, np.float32)
+    lo, hi = (N * rank) // world, (N * (rank + 1)) // world
+    wk = pkg.Worker(0, D, hi - lo, first_index=lo, device=0, seed=3)
+    wk.upload_points(np.ascontiguousarray(x[:, lo:hi].T))
+    s = host.DPMMSampler(wk, host.niw_hyperparams(1.0, np.zeros(D), D + 3, np.eye(D)), 10.0, N, 3, burnout=5, comm=comm)
+    s.init_first_clusters(1)
+    res = "no error"
+    try:
+        for it in range(12):
+            if rank == 1 and it == 3:
+                os._exit(0)                      # gone: no barrier, no destroy
+            s.group_step(False, False)
+    except Exception as e:  # noqa: BLE001
+        res = f"{type(e).__name__}: {e}"
+    with open(out, "w") as f:
+        f.write(res)
+    os._exit(0)
+
+
+@pytest.mark.timeout(300)
+def test_dead_peer_becomes_ecomm_not_a_hang(tmp_path):
+    """A rank that dies between two sweeps: the survivor's next statistics pass fails with DPMM_ECOMM (-6) within the transport's time-out
+    instead of waiting for ever (the reference's master would: SURVEY section 5)."""
+    if torch.cuda.device_count() < 1:
+        pytest.skip("no GPU")
+    import time
+    out = str(tmp_path / "rank0.txt")
+    ctx = mp.get_context("spawn")
+    ps = [ctx.Process(target=_dying_rank, args=(r, 2, 29900, out)) for r in range(2)]
+    t0 = time.time()
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(240)
+    assert not any(p.is_alive() for p in ps), "a rank is still waiting for its dead peer"
+    txt = open(out).read()
+    print(f"survivor after {time.time() - t0:.1f} s: {txt[:300]}")
+    # (through the native engine the worker's DPMM_ECOMM arrives as the engine's error carrying the worker's message)
+    assert ("Error" in txt) and ("all-reduce callback failed" in txt or "error -6" in txt), txt
+
+
+def _aborting_rank(out):
+    sys.path.insert(0, ROOT)
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    host = importlib.import_module("dpmmsubclusters_jl_amd.host")
+    from dpmmsubclusters_jl_amd import binding
+    N, D = 2000000, 64
+    X, y = host.gaussian_mixture_shard(N, D, 32, 100.0, 12345, 0, N)
+    wk = pkg.Worker(0, D, N, device=0, seed=3)
+    wk.upload_points(X)
+    wk.set_option(binding.OPT_SCREEN_MARGIN, 0)                  # every cluster evaluated in full: a step of ~5 ms, i.e. host waits well past 1 ms
+    wk.comm_init(wk.comm_unique_id(), 0, 1)                      # a one-rank RCCL communicator: the library's collective path and its watchdog
+    s = host.DPMMSampler(wk, host.niw_hyperparams(1.0, np.zeros(D), D + 3, np.eye(D)), 10.0, N, 3, burnout=5)
+    s.start_from_labels(y, 1 + (np.arange(N) & 1), 32)
+    res = []
+    try:
+        for _ in range(3):
+            s.group_step(False, False)
+        res.append("three steps fine")
+        wk.set_option(binding.OPT_COMM_TIMEOUT_MS, 1)            # every wait of a step is now "too long": the watchdog's next look (every 20 ms) aborts
+        for _ in range(4000):
+            s.group_step(False, False)
+        res.append("no error")
+    except Exception as e:  # noqa: BLE001
+        res.append(f"{type(e).__name__}: {e}")
+    with open(out, "w") as f:
+        f.write(" | ".join(res))
+    os._exit(0)
+
+
+@pytest.mark.timeout(300)
+def test_rccl_watchdog_aborts_a_wait_past_its_deadline(tmp_path):
+    """DPMM_OPT_COMM_TIMEOUT_MS on the RCCL transport: a host call that blocks on the ctx stream longer than the limit gets its communicator
+    aborted by the watchdog and returns DPMM_ECOMM.  With one GPU there is no peer to kill, so the limit is set absurdly low (1 ms) on a
+    one-rank communicator instead: the same watchdog, the same ncclCommAbort, the same error path."""
+    if torch.cuda.device_count() < 1:
+        pytest.skip("no GPU")
+    out = str(tmp_path / "res.txt")
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_aborting_rank, args=(out,))
+    p.start()
+    p.join(240)
+    assert not p.is_alive(), "the process hangs"
+    txt = open(out).read()
+    print(txt[:300])
+    assert txt.startswith("three steps fine") and "Error" in txt and "timed out" in txt, txt
