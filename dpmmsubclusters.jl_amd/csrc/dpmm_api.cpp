@@ -232,7 +232,7 @@ struct dpmm_ctx {
     std::atomic<int64_t> wd_wait_since{0};      // steady-clock ms when the host began to block on the stream; 0: not blocked
     std::atomic<bool> comm_aborted{false};
     // ONE collective per per-step pass (DPMM_OPT_ONE_COLLECTIVE; NIW, communicator attached): see run_stats
-    int opt_one_collective = 1;
+    int opt_one_collective = -1;       // -1: automatic (rows short enough that half a message more is cheaper than a second collective), 0 / 1
     uint8_t *d_cside = nullptr;        // [DPMM_MAX_CLUSTERS] clusters whose sub-labels this shard reset speculatively: the side its points were on (1 / 2), 0: none
     double *d_red = nullptr;           // [3 Kcap][packed_stride]: what travels -- 2K rows of the labels as swept | K re-drawn left rows -- input of the finalize kernel
     bool last_pass_one_collective = false;
@@ -1197,7 +1197,10 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
     HIPCHK(c, hipSetDevice(c->device));
     const int nbins = 2 * c->K;
     c->marg_valid = false;
-    const bool one_coll = with_reset && comm_attached(c) && c->opt_one_collective && c->prior == DPMM_PRIOR_NIW;
+    // automatic: the one-collective form sends 3K rows instead of 2K -- 0.55 MB more at D = 64, K = 32 (a few us of wire) against a whole
+    // latency-bound collective in the middle of the sort chain; at D = 256 the extra K rows are 8.4 MB (~80 us): the classic form stays
+    const bool one_auto = c->packed_stride <= 4096;
+    const bool one_coll = with_reset && comm_attached(c) && c->prior == DPMM_PRIOR_NIW && (c->opt_one_collective < 0 ? one_auto : c->opt_one_collective != 0);
     c->last_pass_one_collective = one_coll;
     if (c->opt_timing & 2) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     if (idx) {
@@ -2268,7 +2271,7 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
         case DPMM_OPT_REF_BRACKET: c->opt_bracket = value != 0; return DPMM_OK;
         case DPMM_OPT_COMM_TIMEOUT_MS: c->comm_timeout_ms = value > 0 ? (int)std::min(value, 2.0e9) : 0; return DPMM_OK;
         case DPMM_OPT_BF16_SCREENS: c->opt_bf16scr = value != 0; return DPMM_OK;
-        case DPMM_OPT_ONE_COLLECTIVE: c->opt_one_collective = value != 0; return DPMM_OK;
+        case DPMM_OPT_ONE_COLLECTIVE: c->opt_one_collective = value < 0 ? -1 : (value != 0); return DPMM_OK;
         case DPMM_OPT_SORT_TILE: {
             const int t = (int)value;
             if (t != SORT_TILE && t != SORT_TILE_SMALL) return fail(c, DPMM_EINVAL, "DPMM_OPT_SORT_TILE: 512 or 2048");

@@ -82,7 +82,7 @@ enum {
     DPMM_OPT_BF16_SCREENS = 21,       /* 1 (default): D in 33..64 NIW sweep: a bf16 lower bound of the last block row's part of the quadratic form (8 matrix
                                          instructions) in front of every Float32 16-row screen (16), and of the first block row's part (16 + 4) in front of every
                                          survivor's evaluation; they only skip Float32 tests that would have excluded the cluster too: same labels; 0: off */
-    DPMM_OPT_ONE_COLLECTIVE = 20,     /* 1 (default): NIW per-step pass (dpmm_step_stats*) with a communicator attached: ONE all-reduce of 3K packed rows -- the 2K rows
+    DPMM_OPT_ONE_COLLECTIVE = 20,     /* -1 (default): automatic = 1 while a packed row has at most 4096 doubles (D <= 88), else 0.  1: NIW per-step pass (dpmm_step_stats*) with a communicator attached: ONE all-reduce of 3K packed rows -- the 2K rows
                                          of the labels as swept + K re-drawn left rows of the clusters each shard reset speculatively (those with exactly one
                                          empty sub-cluster on the shard); the bad-cluster verdict comes out of the reduced rows' N column, a shard's candidate
                                          that is not bad gets its sub-labels back.  0: occupancy all-reduce -> reset -> statistics -> row all-reduce.  Same chain. */
