@@ -236,6 +236,7 @@ struct dpmm_ctx {
     uint8_t *d_cside = nullptr;        // [DPMM_MAX_CLUSTERS] clusters whose sub-labels this shard reset speculatively: the side its points were on (1 / 2), 0: none
     double *d_red = nullptr;           // [3 Kcap][packed_stride]: what travels -- 2K rows of the labels as swept | K re-drawn left rows -- input of the finalize kernel
     bool last_pass_one_collective = false;
+    bool undo_pending = false;         // niw_undo_reset_kernel of the last one-collective pass not launched yet (flush_undo)
 
     std::string err;
 };
@@ -1178,6 +1179,16 @@ static int ensure_out(dpmm_ctx *c, size_t bytes) {
     return DPMM_OK;
 }
 
+// One-collective pass: the sub-labels of this shard's candidates that turned out not to be bad go back to the side they were on.  Labels
+// only -- nothing the master waits for -- so the kernel is queued behind the posteriors / the copy of the rows, before the call returns
+// (every later reader of the labels is stream-ordered behind it).
+static int flush_undo(dpmm_ctx *c) {
+    if (!c->undo_pending) return DPMM_OK;
+    c->undo_pending = false;
+    const uint8_t *flags = reinterpret_cast<const uint8_t *>(c->d_out) + sizeof(double) * 2 * (size_t)c->K * (size_t)c->packed_stride;
+    HIPCHK(c, launch_niw_undo_reset(c->dbins, c->n, c->K, flags, c->d_cside, c->stream));
+    return DPMM_OK;
+}
 // One statistics pass on the ctx stream (asynchronous): [sub-cluster occupancies -> bad-cluster reset ->] sort by bin ->
 // segmented statistics -> packed rows in c->d_out [-> all-reduce over the ranks].
 // with_reset (the per-step pass) has two forms when a communicator is attached:
@@ -1282,8 +1293,13 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
         }
         // the one exchange of the sweep (update_suff_stats_posterior!, local_clusters_actions.jl:206-254; aggregate_suff_stats)
         if (int rc = comm_allreduce(c, c->d_red, nred, /*kind=*/1)) return rc;
-        HIPCHK(c, launch_niw_finalize_rows(c->d_red, c->d_out, c->packed_stride, c->K, c->d_cside, flags, c->stream));
-        HIPCHK(c, launch_niw_undo_reset(c->dbins, c->n, c->K, flags, c->d_cside, c->stream));
+        // (flags_to: the caller's pinned block -- the verdict rides in this launch; its "any" byte starts at 0: the kernel only sets it, and
+        // nothing of the stream reads or writes the block before this kernel)
+        if (flags_to) flags_to[c->K] = 0;
+        HIPCHK(c, launch_niw_finalize_rows(c->d_red, c->d_out, c->packed_stride, c->K, c->d_cside, flags, flags_to, c->stream));
+        if (flags_to && flags_sent) *flags_sent = true;
+        // the undo of the candidates that are not bad touches labels only: queued by the caller BEHIND what the master is waiting for
+        c->undo_pending = true;
         c->comm_bytes[0] = 0;
         if (c->opt_timing & 2) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
         c->have_stats_ev = (c->opt_timing & 2) != 0;
@@ -1359,6 +1375,7 @@ int dpmm_step_stats(dpmm_ctx *c, uint32_t reset_epoch, const double **packed, co
     if (int rc = run_stats(c, nullptr, 0, true, reset_epoch)) return rc;
     if (c->marg_req) if (int rc = mult_marginals_launch(c)) return rc;       // the master's log-marginals ride behind the statistics: one wait
     HIPCHK(c, launch_copy_bytes(c->h_out, c->d_out, out_bytes + (size_t)c->K + 1, c->stream));      // rows | flags
+    if (int rc = flush_undo(c)) return rc;
     HIPCHK(c, sync_stream(c, c->stream));
     *packed = reinterpret_cast<const double *>(c->h_out);
     *bad = reinterpret_cast<const uint8_t *>(c->h_out + out_bytes);
@@ -1525,6 +1542,7 @@ int dpmm_step_stats_device(dpmm_ctx *c, uint32_t reset_epoch, const uint8_t **ba
     if (int rc = ensure_out(c, DPMM_MAX_CLUSTERS + 64)) return rc;
     if (int rc = run_stats(c, nullptr, 0, true, reset_epoch)) return rc;
     HIPCHK(c, launch_copy_bytes(c->h_out, reinterpret_cast<const uint8_t *>(c->d_out) + out_bytes, (size_t)c->K + 1, c->stream));
+    if (int rc = flush_undo(c)) return rc;
     HIPCHK(c, sync_stream(c, c->stream));
     *bad = reinterpret_cast<const uint8_t *>(c->h_out);
     return DPMM_OK;
@@ -1666,6 +1684,7 @@ int dpmm_step_master_device(dpmm_ctx *c, uint32_t reset_epoch, const int32_t *sl
         c->spec_inflight = false; c->spec_valid = true; c->spec_epoch = draw_epoch;
         c->spec_slots.assign(slots, slots + K);
     }
+    if (int rc = flush_undo(c)) return rc;      // (behind the posteriors, the event and the draws launched ahead)
     HIPCHK(c, sync_event(c, c->ev_master));
     if (master_marks_left(sm, K)) {
         ++c->dbg_early_wait;

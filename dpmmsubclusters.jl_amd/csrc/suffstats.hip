@@ -906,7 +906,7 @@ __global__ __launch_bounds__(64 * REDUCE_PARTS) void niw_reduce_kernel(StatsArgs
 // the rows are taken as they are, and a shard on which k was a candidate undoes its reset (flags[K + 1], niw_undo_reset_kernel).
 // Reads `red`, writes `out` + flags (flags[K], flags[K + 1] were cleared by the reduce kernel).
 __global__ __launch_bounds__(256) void niw_finalize_rows_kernel(const double *__restrict__ red, double *__restrict__ out, int64_t stride, int K,
-                                                                const uint8_t *__restrict__ cside, uint8_t *__restrict__ flags) {
+                                                                const uint8_t *__restrict__ cside, uint8_t *__restrict__ flags, uint8_t *__restrict__ flags_host) {
     const int k = blockIdx.y;
     const int64_t e = blockIdx.x * 256ll + threadIdx.x;
     const double *l = red + (int64_t)(2 * k) * stride, *r = l + stride;
@@ -915,6 +915,8 @@ __global__ __launch_bounds__(256) void niw_finalize_rows_kernel(const double *__
         flags[k] = bad ? 1 : 0;
         if (bad) flags[K] = 1;
         if (!bad && cside[k]) flags[K + 1] = 1;
+        // rider: the verdict goes to the caller's pinned block from here (flags_host[K] = "any" was cleared by the host before the launch)
+        if (flags_host) { flags_host[k] = bad ? 1 : 0; if (bad) flags_host[K] = 1; }
     }
     if (e >= stride) return;
     double *ol = out + (int64_t)(2 * k) * stride, *orr = ol + stride;
@@ -927,8 +929,8 @@ __global__ __launch_bounds__(256) void niw_finalize_rows_kernel(const double *__
         orr[e] = r[e];
     }
 }
-hipError_t launch_niw_finalize_rows(const double *red, double *out, int64_t stride, int K, const uint8_t *cside, uint8_t *flags, hipStream_t s) {
-    DPMM_LAUNCH(niw_finalize_rows_kernel, dim3((unsigned)((stride + 255) / 256), K), dim3(256), 0, s, red, out, stride, K, cside, flags);
+hipError_t launch_niw_finalize_rows(const double *red, double *out, int64_t stride, int K, const uint8_t *cside, uint8_t *flags, uint8_t *flags_host, hipStream_t s) {
+    DPMM_LAUNCH(niw_finalize_rows_kernel, dim3((unsigned)((stride + 255) / 256), K), dim3(256), 0, s, red, out, stride, K, cside, flags, flags_host);
     return hipGetLastError();
 }
 // A candidate of this shard that is not bad globally: all of its points go back to the side they were on (cside: 1 left, 2 right).

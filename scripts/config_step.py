@@ -21,6 +21,7 @@ D = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 N = int(float(sys.argv[3])) if len(sys.argv) > 3 else 625000
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 timing = not (len(sys.argv) > 5 and sys.argv[5] == "notiming")      # "notiming": no HIP events between the kernels (as fit / dp_parallel run)
+rccl1 = len(sys.argv) > 6 and sys.argv[6] == "rccl1"                  # attach a ONE-rank RCCL communicator: the library's collective path, no wire
 K, burnout = 32, 20
 if kind == "niw":
     X, y = host.gaussian_mixture_shard(N, D, K, 100.0, 12345, 0, N)
@@ -37,6 +38,8 @@ else:
     prior = host.multinomial_hyper(np.ones(D, np.float32))      # test/save_load_test/multinomial_params.jl:24
     wk = pkg.Worker(pkg.PRIOR_MULT, D, N, device=0, seed=1)
 wk.upload_points(X)
+if rccl1:
+    wk.comm_init(wk.comm_unique_id(), 0, 1)
 s = host.DPMMSampler(wk, prior, 10.0, N, 1, burnout=burnout)
 s.start_from_labels(y, 1 + np.random.default_rng(0).integers(0, 2, N), K)
 for _ in range(burnout + 5):
