@@ -724,17 +724,40 @@ __device__ __forceinline__ int head_slot(int item, int bin, int T, int G) {
 template <int NBK>
 __global__ __launch_bounds__(64 * StatCfg<NBK>::NPANEL) void niw_stats_kernel(StatsArgs A) {
     using C = StatCfg<NBK>;
-    const int total_items = A.sb.item_start[A.nbins];
+    // The three small tables of the sort (item_start, bin_total, bin_start: nbins + 1 entries) in REGISTERS, two entries per lane, fetched
+    // with one round trip: the total, the binary search of find_bin and the look-ups behind it were ~10 dependent L2 latencies in front of
+    // a workgroup's first matrix instruction -- a fifth of the kernel at the 8-GPU shard size (550 points per workgroup).  nbins <= 127.
+    const bool regtab = A.nbins < 128;
+    const int tl = threadIdx.x & 63;
+    int ts0 = 0, ts1 = 0, tt0 = 0, tt1 = 0, tb0 = 0, tb1 = 0;
+    if (regtab) {
+        const int e0 = min(tl, A.nbins), e1 = min(tl + 64, A.nbins);
+        ts0 = A.sb.item_start[e0]; ts1 = A.sb.item_start[e1];
+        tt0 = A.sb.bin_total[min(e0, A.nbins - 1)]; tt1 = A.sb.bin_total[min(e1, A.nbins - 1)];
+        tb0 = A.sb.bin_start[e0]; tb1 = A.sb.bin_start[e1];
+    }
+    const int total_items = regtab ? (A.nbins < 64 ? __shfl(ts0, A.nbins) : __shfl(ts1, A.nbins - 64)) : A.sb.item_start[A.nbins];
     const int G = min((int)gridDim.x, total_items);
     if ((int)blockIdx.x >= G) return;
     const int it0 = range_bound((int)blockIdx.x, total_items, G);
     const int it1 = range_bound((int)blockIdx.x + 1, total_items, G);
+    auto tab = [&](int v0, int v1, int idx) -> int { return idx < 64 ? __shfl(v0, idx) : __shfl(v1, idx - 64); };
     for (int item = it0; item < it1;) {
-        const int b = find_bin(A.sb.item_start, A.nbins, item);
-        const int e = min(it1, A.sb.item_start[b + 1]);
-        const int j = item - A.sb.item_start[b];
-        const int bcnt = A.sb.bin_total[b];
-        const int seg = A.sb.bin_start[b] + j * A.chunk;
+        int b, istart_b, istart_b1, bcnt, bstart;
+        if (regtab) {
+            // largest b < nbins with item_start[b] <= item (empty bins share a start with their successor: the LAST one wins, it holds the item)
+            const unsigned long long m0 = __ballot(tl < A.nbins && ts0 <= item), m1 = __ballot(tl + 64 < A.nbins && ts1 <= item);
+            b = m1 ? 127 - __clzll((long long)m1) : 63 - __clzll((long long)m0);
+            istart_b = tab(ts0, ts1, b); istart_b1 = tab(ts0, ts1, b + 1);
+            bcnt = tab(tt0, tt1, b); bstart = tab(tb0, tb1, b);
+        } else {
+            b = find_bin(A.sb.item_start, A.nbins, item);
+            istart_b = A.sb.item_start[b]; istart_b1 = A.sb.item_start[b + 1];
+            bcnt = A.sb.bin_total[b]; bstart = A.sb.bin_start[b];
+        }
+        const int e = min(it1, istart_b1);
+        const int j = item - istart_b;
+        const int seg = bstart + j * A.chunk;
         const int cnt = min((e - item) * A.chunk, bcnt - j * A.chunk);
         double *slab = A.slabs + (int64_t)(item == it0 ? (int)blockIdx.x : NIW_STATS_MAX_GROUPS + b) * A.slab_stride;
         const int panel = threadIdx.x >> 6;
