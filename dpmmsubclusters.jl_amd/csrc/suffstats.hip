@@ -224,22 +224,27 @@ __device__ __forceinline__ void scan_one_bin(const int32_t *__restrict__ tile_cn
     const int lo = threadIdx.x * per, hi = min(lo + per, nt);
     int s = 0;
     for (int i = lo; i < hi; ++i) s += src[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over the 256 partials
-    for (int off = 1; off < 256; off <<= 1) {
-        int v = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
+    // inclusive scan over the 256 partials: inside each wave with shuffles (no barrier), the four wave totals through LDS (ONE barrier;
+    // the Hillis-Steele loop this replaces had sixteen)
+    int inc = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(inc, off);
+        if ((threadIdx.x & 63) >= off) inc += v;
     }
-    int run = part[threadIdx.x] - s;  // exclusive prefix of this thread's range
+    if ((threadIdx.x & 63) == 63) part[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    const int w = threadIdx.x >> 6;
+    const int before = (w > 0 ? part[0] : 0) + (w > 1 ? part[1] : 0) + (w > 2 ? part[2] : 0);
+    inc += before;
+    if (threadIdx.x == 255) part[255] = inc;       // (the total, where the callers read it)
+    int run = inc - s;  // exclusive prefix of this thread's range
     for (int i = lo; i < hi; ++i) {
         const int v = src[i];
         row[i] = run;
         run += v;
     }
-    if (threadIdx.x == 255) bin_total[blockIdx.x] = part[255];
+    if (threadIdx.x == 255) bin_total[blockIdx.x] = inc;
 }
 __global__ __launch_bounds__(256) void scan_tiles_kernel(const int32_t *__restrict__ tile_cnt, int32_t *__restrict__ tile_hist, int nt,
                                                          int32_t *__restrict__ bin_total) {
@@ -259,18 +264,24 @@ __device__ __forceinline__ void starts_body(const int32_t *bin_total, const uint
         sa += t;
         sb += bin_sel[b] ? (t + chunk - 1) / chunk : 0;
     }
-    pa[threadIdx.x] = sa;
-    pb[threadIdx.x] = sb;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        int va = (threadIdx.x >= off) ? pa[threadIdx.x - off] : 0;
-        int vb = (threadIdx.x >= off) ? pb[threadIdx.x - off] : 0;
-        __syncthreads();
-        pa[threadIdx.x] += va;
-        pb[threadIdx.x] += vb;
-        __syncthreads();
+    int ia = sa, ib = sb;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int va = __shfl_up(ia, off), vb = __shfl_up(ib, off);
+        if ((threadIdx.x & 63) >= off) { ia += va; ib += vb; }
     }
-    int ra = pa[threadIdx.x] - sa, rb = pb[threadIdx.x] - sb;
+    __syncthreads();                                   // (pa / pb may still be read by the caller's previous use)
+    if ((threadIdx.x & 63) == 63) { pa[threadIdx.x >> 6] = ia; pb[threadIdx.x >> 6] = ib; }
+    __syncthreads();
+    {
+        const int w = threadIdx.x >> 6;
+        ia += (w > 0 ? pa[0] : 0) + (w > 1 ? pa[1] : 0) + (w > 2 ? pa[2] : 0);
+        ib += (w > 0 ? pb[0] : 0) + (w > 1 ? pb[1] : 0) + (w > 2 ? pb[2] : 0);
+    }
+    __syncthreads();
+    if (threadIdx.x == 255) { pa[255] = ia; pb[255] = ib; }
+    __syncthreads();
+    int ra = ia - sa, rb = ib - sb;
     for (int b = lo; b < hi; ++b) {
         bin_start[b] = ra;
         item_start[b] = rb;
