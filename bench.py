@@ -51,6 +51,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense FP32 matrix peak (no TF32/xf32 on gfx950)
 PEAK_HBM_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E ~8 TB/s (6.29 TB/s measured copy)
 DATA_SEED, SAMPLER_SEED, BURNOUT, ALPHA = 12345, 123456789, 20, 10.0
+WORKER_OPTS = []              # --worker-opt ID=VALUE ...: (option, value) pairs set on every worker of the run
 
 
 def parse_args():
@@ -71,6 +72,8 @@ def parse_args():
     ap.add_argument("--legs", default="overlap_var4,overlap_var1,k256,c2,c3_shard,c4,c5_shard", help="comma-separated subset of the legs")
     ap.add_argument("--growth-iters", type=int, default=260)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-clock budget of the CPU baseline sample")
+    ap.add_argument("--worker-opt", action="append", default=[], metavar="ID=VALUE",
+                    help="dpmm_set_option on every worker this run creates (A/B of a library switch on the bench's own legs); reported in config")
     ap.add_argument("--comm-timeout", type=float, default=300.0, help="seconds a rank waits in a collective before it gives up (dead peer)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="development: all ranks on device 0 over gloo + the library's host transport (boxes with one GPU)")
@@ -214,6 +217,8 @@ def steady_state(pkg, host, torch, prior_kind, prior, X, y, K, steps, settle=30,
     wk.upload_points_device(X.data_ptr(), X.stride(0))
     if rccl_one_rank:
         wk.comm_init(wk.comm_unique_id(), 0, 1)
+    for opt, val in WORKER_OPTS:
+        wk.set_option(opt, val)
     s = host.DPMMSampler(wk, prior, ALPHA, N, seed, burnout=BURNOUT)
     for opt, val in engine_opts:
         s.model.set_option(opt, val)
@@ -372,6 +377,7 @@ def run_legs(args, pkg, host, torch, one_gpu_ms):
 
 def main():
     args = parse_args()
+    WORKER_OPTS.extend((int(kv.split("=")[0]), float(kv.split("=")[1])) for kv in args.worker_opt)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_as_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -410,6 +416,8 @@ def main():
     wk = pkg.Worker(pkg.PRIOR_NIW, D, hi - lo, first_index=lo, device=local_rank, seed=SAMPLER_SEED)
     wk.upload_points(X)
     wk.set_option(binding.OPT_COMM_TIMEOUT_MS, 1e3 * args.comm_timeout)
+    for opt, val in WORKER_OPTS:
+        wk.set_option(opt, val)
     s = host.DPMMSampler(wk, prior, ALPHA, N, SAMPLER_SEED, burnout=BURNOUT, comm=comm)
     sub0 = 1 + (np.random.default_rng([DATA_SEED, 7, rank]).integers(0, 2, hi - lo))
     s.start_from_labels(y, sub0, K)
@@ -533,7 +541,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"NIW D={D} N={N} synthetic GMM, {K} true components, K_t={k_mean:.1f} live clusters, "
                                f"alpha=10, default NIW prior, steady state after {BURNOUT + 1} burn-in + {args.settle} settling sweeps",
-                   "points_per_gpu": n_local,
+                   "points_per_gpu": n_local, "worker_options_overridden": {str(o): v for o, v in WORKER_OPTS} or None,
                    "parallelism": f"points sharded over {world} GPU(s); all-reduces of a statistics pass inside libdpmmhip.so: see comm"},
         "roofline": roof,
         "comm": {"world": info["world"], "transport": info["transport"], "occupancy_allreduce_bytes": info["counts_bytes"],

@@ -1,5 +1,5 @@
 """Dev helper: A/B of a dpmm_set_option switch on the headline workload, interleaved rounds in ONE process.
-   python3 scripts/ab_option.py <option id> <value A> <value B> [points] [rounds]"""
+   python3 scripts/ab_option.py <option id> <value A> <value B> [points] [rounds] [id=value ...]     (further options, set once for both legs)"""
 import importlib, sys, time
 import numpy as np
 sys.path.insert(0, ".")
@@ -18,6 +18,8 @@ s = host.DPMMSampler(wk, prior, 10.0, N, 123456789, burnout=20)
 s.start_from_labels(y, 1 + np.random.default_rng(0).integers(0, 2, N), K)
 for _ in range(10):
     s.group_step(False, False)
+for kv in sys.argv[6:]:
+    wk.set_option(int(kv.split("=")[0]), float(kv.split("=")[1]))
 res = {va: [], vb: []}
 st = {va: [], vb: []}
 wall = {va: [], vb: []}

@@ -17,8 +17,8 @@ wk = pkg.Worker(pkg.PRIOR_NIW, D, N, device=0, seed=1)
 wk.upload_points(X)
 s = host.DPMMSampler(wk, prior, 10.0, N, 1, burnout=20)
 s.start_from_labels(y, 1 + np.random.default_rng(0).integers(0, 2, N), K)
-if len(sys.argv) > 3:
-    wk.set_option(13, float(sys.argv[3]))      # DPMM_OPT_SWEEP_QUEUE_ROUNDS
+for kv in sys.argv[3:]:                        # id=value ... (dpmm_set_option)
+    wk.set_option(int(kv.split("=")[0]), float(kv.split("=")[1]))
 for _ in range(6):
     s.group_step(False, False)
 print("kernel ms (stamped build)", wk.last_kernel_ms()[0])
