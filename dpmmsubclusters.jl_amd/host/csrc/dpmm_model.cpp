@@ -27,7 +27,6 @@
 
 #include <algorithm>
 #include <string>
-#include <unordered_map>
 #include <vector>
 
 #include "hostlib.h"
@@ -180,7 +179,6 @@ struct dpmmh_model {
     // ... and its log-marginals (worker.mult_pairs_ahead / mult_marginals): the pairs asked for ahead of the step's statistics pass (cluster
     // indices), their pooled log-marginals as the worker returned them, valid until a split / merge / removal changes the clusters
     std::vector<int32_t> mp_i, mp_j;
-    std::unordered_map<uint32_t, int> mp_index;
     std::vector<double> mp_L;
     bool mp_valid = false;
     bool prewake = true;
@@ -545,13 +543,13 @@ struct dpmmh_model {
             // of clusters whose gate is open NOW (this step can only close gates) ride behind the statistics kernels
             mdev_marg = use_mult_dev() && W.mult_pairs_ahead && W.mult_marginals;
             if (mdev_marg) {
-                mp_i.clear(); mp_j.clear(); mp_index.clear(); mp_valid = false;
+                mp_i.clear(); mp_j.clear(); mp_valid = false;
                 for (int i = (has_outlier() ? 1 : 0); i < K && mp_i.size() <= 8192; ++i) {
                     if (!splittable[slot[i]]) continue;
                     for (int j = i + 1; j < K; ++j)
-                        if (splittable[slot[j]]) { mp_index[((uint32_t)i << 16) | (uint32_t)j] = (int)mp_i.size(); mp_i.push_back(i); mp_j.push_back(j); }
+                        if (splittable[slot[j]]) { mp_i.push_back(i); mp_j.push_back(j); }
                 }
-                if (mp_i.size() > 8192) { mp_i.clear(); mp_j.clear(); mp_index.clear(); }
+                if (mp_i.size() > 8192) { mp_i.clear(); mp_j.clear(); }
                 if (W.mult_pairs_ahead(W.ctx, has_outlier() ? 1 : 0, mp_i.data(), mp_j.data(), (int)mp_i.size())) return wfail("mult_pairs_ahead");
             }
             if (W.step_stats(W.ctx, next_epoch(), &pk, &bad)) return wfail("step_stats");
@@ -684,11 +682,23 @@ struct dpmmh_model {
     }
 
     // ---------------------------------------------------------------- step 7c: check_and_merge! (LCA:385-413, SA:21-38)
+    // SA:28-30.  The terms that depend on ONE cluster (or on alpha alone) are looked up: K (K - 1) / 2 pairs share 2 K + 3 log-gamma values
+    // (merge_cache, refreshed by check_and_merge); the sum keeps the order it had with every term evaluated in place, so the ratio is the
+    // same double.
+    std::vector<double> mc_lgN, mc_lgNa;        // lgamma(N_k), lgamma(N_k + alpha / 2) by cluster index
+    double mc_head = 0.0;                       // -log(alpha) + lgamma(alpha) - 2 lgamma(alpha / 2)
+    void merge_cache() {
+        int sg;
+        const double a = alpha;
+        mc_head = -log(a) + lgamma_r(a, &sg) - 2 * lgamma_r(0.5 * a, &sg);
+        mc_lgN.resize(K); mc_lgNa.resize(K);
+        for (int k = 0; k < K; ++k) { const double N = Nc(slot[k]); mc_lgN[k] = lgamma_r(N, &sg); mc_lgNa[k] = lgamma_r(N + 0.5 * a, &sg); }
+    }
     double merge_log_hr(int i, int j, double Lp) {
         int sg;
-        const double a = alpha, Ni = Nc(slot[i]), Nj = Nc(slot[j]), Np = Ni + Nj;
-        return -log(a) + lgamma_r(a, &sg) - 2 * lgamma_r(0.5 * a, &sg) + lgamma_r(Np, &sg) - lgamma_r(Np + a, &sg) +
-               lgamma_r(Ni + 0.5 * a, &sg) - lgamma_r(Ni, &sg) - lgamma_r(Nj, &sg) + lgamma_r(Nj + 0.5 * a, &sg) + Lp - L[3 * slot[i]] - L[3 * slot[j]];
+        const double a = alpha, Np = Nc(slot[i]) + Nc(slot[j]);
+        return mc_head + lgamma_r(Np, &sg) - lgamma_r(Np + a, &sg) +
+               mc_lgNa[i] - mc_lgN[i] - mc_lgN[j] + mc_lgNa[j] + Lp - L[3 * slot[i]] - L[3 * slot[j]];
     }
     // log_marginal_likelihood of the pooled statistics of clusters (i, j) under cluster i's prior (SA:22-27)
     double pooled_marginal(int i, int j, std::vector<double> &sc) {
@@ -748,6 +758,7 @@ struct dpmmh_model {
     }
     void merge_ratios(const std::vector<std::pair<int, int>> &pairs, std::vector<double> &lhr) {
         lhr.resize(pairs.size());
+        merge_cache();
         if (dev_pairs_ok) {
             // pooled scale matrices and their log-determinants on the device, from the rows it keeps per slot
             const int n = (int)pairs.size();
@@ -774,10 +785,13 @@ struct dpmmh_model {
         }
         std::vector<std::vector<double>> scratch(std::max(1, nthreads));
         if (kind == DPMMH_PRIOR_MULT && mp_valid && use_mult_dev()) {      // pooled log-marginals the worker computed behind the statistics; the rest on the host
+            // both lists are in lexicographic order (the candidates are those of the pairs computed ahead whose gates are still open): one walk
             std::vector<int> todo;
+            size_t q = 0;
             for (int p = 0; p < (int)pairs.size(); ++p) {
-                const auto it = mp_index.find(((uint32_t)pairs[p].first << 16) | (uint32_t)pairs[p].second);
-                if (it != mp_index.end()) lhr[p] = merge_log_hr(pairs[p].first, pairs[p].second, mp_L[it->second]);
+                const int i = pairs[p].first, j = pairs[p].second;
+                while (q < mp_i.size() && (mp_i[q] < i || (mp_i[q] == i && mp_j[q] < j))) ++q;
+                if (q < mp_i.size() && mp_i[q] == i && mp_j[q] == j) lhr[p] = merge_log_hr(i, j, mp_L[q]);
                 else todo.push_back(p);
             }
             if (!todo.empty()) Pool::get().run((int)todo.size(), nthreads, [&](int t, int th) {
@@ -809,6 +823,9 @@ struct dpmmh_model {
         for (size_t p = 0; p < pairs.size(); ++p) {
             const int i = pairs[p].first, j = pairs[p].second;
             if (used[i] || used[j]) continue;
+            // (the uniform is keyed by the pair, not drawn from a running stream, and is at least 2^-54: a ratio below log(2^-54) = -37.4 --
+            // two distinct clusters sit at -1e4 and beyond -- is refused whatever it would have been, and log(0.1) is above that too)
+            if (lhr[p] < -38.0) continue;
             const double u = Philox(seed, (uint32_t)(i * 65536 + j), merge_epoch, ST_MERGE).uniform();
             if (!((lhr[p] > log(u)) || (final && lhr[p] > log(0.1)))) continue;
             if (int rc = pull_state()) return rc;      // an accepted merge rebuilds posteriors on the host (no-op when they are current)
