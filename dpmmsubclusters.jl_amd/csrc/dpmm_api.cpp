@@ -148,7 +148,7 @@ struct dpmm_ctx {
     int cache_K = -1;
     int opt_derive = 1;
     int64_t dbg_early_wait = 0;        // event waits that returned before the posteriors' records were in host memory (dpmm_debug_counters)
-    int opt_noise_ahead = 0;           // normals of the next draws on the second stream beside the sweep (DPMM_OPT_NOISE_AHEAD)
+    int opt_noise_ahead = -1;          // normals of the next draws on the second stream beside the sweep (DPMM_OPT_NOISE_AHEAD): -1 = for D >= 128
     // device master (niw_master.hip)
     bool master = false;
     NiwMasterArgs ma{};
@@ -1775,7 +1775,7 @@ int dpmm_niw_master_draw(dpmm_ctx *c, uint32_t epoch, int K, const int32_t *slot
     // with another epoch, or for more clusters, generates its own.
     // (launched by noise_flush right AFTER the sweep kernel of this step: the launch and its event record would otherwise sit on the
     // host's critical path between the master's decisions and the sweep launch)
-    c->noise_pending = c->opt_noise_ahead != 0; c->noise_pend_epoch = epoch + 1; c->noise_pend_nmat = 3 * std::min(K + 4, c->master_K);
+    c->noise_pending = c->opt_noise_ahead < 0 ? c->D >= 128 : c->opt_noise_ahead != 0; c->noise_pend_epoch = epoch + 1; c->noise_pend_nmat = 3 * std::min(K + 4, c->master_K);
     c->work_zeroed = true;
     c->have_screen_prep = false;     // (the K > 64 far mask needs the raw factors: not built on this path; the tail screen is)
     c->K = K;
@@ -2286,7 +2286,7 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
         case DPMM_OPT_SWEEP_QUEUE_ROUNDS: c->opt_queue_rounds = value < 0 ? -1 : (int)value; return DPMM_OK;
         case DPMM_OPT_BALL_SCREEN: c->opt_ball = value != 0; return DPMM_OK;
         case DPMM_OPT_STATS_DERIVE: c->opt_derive = value != 0; c->cache_force = true; return DPMM_OK;
-        case DPMM_OPT_NOISE_AHEAD: c->opt_noise_ahead = value != 0; return DPMM_OK;
+        case DPMM_OPT_NOISE_AHEAD: c->opt_noise_ahead = value < 0 ? -1 : (value != 0); return DPMM_OK;
         case DPMM_OPT_REF_BRACKET: c->opt_bracket = value != 0; return DPMM_OK;
         case DPMM_OPT_COMM_TIMEOUT_MS: c->comm_timeout_ms = value > 0 ? (int)std::min(value, 2.0e9) : 0; return DPMM_OK;
         case DPMM_OPT_BF16_SCREENS: c->opt_bf16scr = value != 0; return DPMM_OK;

@@ -71,8 +71,9 @@ enum {
                                          left since its cluster-level statistics were cached, and takes the other one as cache - computed (Float64; the
                                          derived side is the larger one); 0: both sub-clusters of every cluster, every pass */
     DPMM_OPT_NOISE_AHEAD = 17,        /* device master: 1 = the normals of the next parameter draws are generated on a second stream beside the sweep
-                                         (-7 us per step at the 8-GPU shard size, nothing at N = 1e7); 0 (default) = every draw kernel generates its
-                                         own: one stream, no cross-stream dependency; same draws either way */
+                                         (measured per step: D = 256 shard 2.16 -> 2.09 ms, D = 128 1.10 -> 1.08, D = 64 shard -7 us, nothing at N = 1e7);
+                                         0 = every draw kernel generates its own: one stream, no cross-stream dependency; -1 (default) = 1 for D >= 128;
+                                         same draws either way */
     DPMM_OPT_REF_BRACKET = 18,        /* 1 (default): D in 49..64 sweep, waves whose points all had the same label: the reference cluster's value is first BRACKETED
                                          (two bf16 matrix passes with a certified rounding bound, ~1/7 of a Float32 evaluation) and evaluated in Float32 only
                                          if some other cluster survives the screens against the bracket's lower end; same labels; 0: always evaluated */
