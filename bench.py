@@ -266,6 +266,7 @@ def niw_roofline(n, D, k_mean, sweep_ms, work):
             "brackets_per_wave_tile": work["brackets"] / max(1.0, work["wave_tiles"]),
             "bf16_bottom_screens_per_wave_tile": work["bf16_bottom_screens"] / max(1.0, work["wave_tiles"]),
             "bf16_top_screens_per_wave_tile": work["bf16_top_screens"] / max(1.0, work["wave_tiles"]),
+            "direction_screens_per_wave_tile": work.get("direction_screens", 0.0) / max(1.0, work["wave_tiles"]),
             "bf16_mfma_per_tile": work["bf16_mfma"] / max(1.0, work["wave_tiles"])}
 
 

@@ -98,7 +98,7 @@ HOST_ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_voi
 
 # dpmm_set_option keys (include/dpmm_hip.h)
 MASTER_NSCALARS = 8          # DPMM_MASTER_NSCALARS
-OPT_SCREEN_MARGIN, OPT_TAIL_SCREEN, OPT_PRESCREEN, OPT_ORDERED_SWEEP, OPT_MULT_FORCE_F32, OPT_STATS_ITEMS, OPT_STATS_GROUPS, OPT_TRACE_SLOW, OPT_LOGLIK_REF_CONST, OPT_WAVE_PRIO, OPT_MULT_NO_U8, OPT_SWEEP_GRID, OPT_SWEEP_QUEUE_ROUNDS, OPT_BALL_SCREEN, OPT_KERNEL_TIMING, OPT_STATS_DERIVE, OPT_NOISE_AHEAD, OPT_REF_BRACKET, OPT_SORT_TILE, OPT_ONE_COLLECTIVE, OPT_BF16_SCREENS, OPT_COMM_TIMEOUT_MS = range(1, 23)
+OPT_SCREEN_MARGIN, OPT_TAIL_SCREEN, OPT_PRESCREEN, OPT_ORDERED_SWEEP, OPT_MULT_FORCE_F32, OPT_STATS_ITEMS, OPT_STATS_GROUPS, OPT_TRACE_SLOW, OPT_LOGLIK_REF_CONST, OPT_WAVE_PRIO, OPT_MULT_NO_U8, OPT_SWEEP_GRID, OPT_SWEEP_QUEUE_ROUNDS, OPT_BALL_SCREEN, OPT_KERNEL_TIMING, OPT_STATS_DERIVE, OPT_NOISE_AHEAD, OPT_REF_BRACKET, OPT_SORT_TILE, OPT_ONE_COLLECTIVE, OPT_BF16_SCREENS, OPT_COMM_TIMEOUT_MS, OPT_DIRECTION_SCREEN = range(1, 24)
 
 
 class DpmmError(RuntimeError):
@@ -583,11 +583,14 @@ class Worker:
         self._chk(self._lib.dpmm_last_sweep_work(self._h, out))
         v = [int(x) for x in out]
         n = max(1, v[7])
+        sp = 8 * ((self.K + 15) // 16)      # bf16 matrix instructions of one direction screen: two per 16 clusters and point group
         # executed_flops: Float32 matrix work only (= SQ_INSTS_VALU_MFMA_MOPS_F32 x 512); the bf16 work (brackets, screens) beside it
         return dict(wave_tiles=v[0] / n, full_evals=v[1] / n, screens16=v[2] / n, tail_pairs=v[3] / n, mfma_per_full=v[4], mfma_per_screen=v[5],
                     flops_per_mfma=v[6], executed_flops=(v[1] * v[4] + v[2] * v[5]) * v[6] / n, launches=v[7],
                     brackets=v[8] / n, bf16_mfma_per_bracket=v[9], bf16_bottom_screens=v[11] / n, bf16_top_screens=v[13] / n,
-                    bf16_mfma=(v[8] * v[9] + v[11] * v[12] + v[13] * v[14]) / n, bf16_flops=(v[8] * v[9] + v[11] * v[12] + v[13] * v[14]) * v[10] / n)
+                    direction_screens=v[15] / n,
+                    bf16_mfma=(v[8] * v[9] + v[11] * v[12] + v[13] * v[14] + v[15] * sp) / n,
+                    bf16_flops=(v[8] * v[9] + v[11] * v[12] + v[13] * v[14] + v[15] * sp) * v[10] / n)
 
     # ---- diagnostics
     def debug_subloglik(self):

@@ -148,7 +148,7 @@ struct dpmm_ctx {
     int cache_K = -1;
     int opt_derive = 1;
     int64_t dbg_early_wait = 0;        // event waits that returned before the posteriors' records were in host memory (dpmm_debug_counters)
-    int opt_noise_ahead = -1;          // normals of the next draws on the second stream beside the sweep (DPMM_OPT_NOISE_AHEAD): -1 = for D >= 128
+    int opt_noise_ahead = -1;          // normals of the next draws on the second stream beside the sweep (DPMM_OPT_NOISE_AHEAD): -1 = for D >= 128 or shards below 4e6 points
     // device master (niw_master.hip)
     bool master = false;
     NiwMasterArgs ma{};
@@ -202,6 +202,13 @@ struct dpmm_ctx {
     int opt_prio = 1;
     int opt_queue_rounds = -1;
     int opt_ball = 1;
+    // direction screen of the D in 33..64 sweep (direction_far, niw_sweep.hip; DPMM_OPT_DIRECTION_SCREEN): tables per parameter set, built only while
+    // the sweeps report tiles with many candidates (h_need: one word per wave of the last sweep, written by the kernel into pinned memory)
+    uint32_t *d_sp_frag = nullptr;
+    float *d_sp_cons = nullptr;
+    uint32_t *h_need = nullptr;
+    int opt_direction = -1;             // -1: by the previous sweep's candidate counts, 0: never, 1: always
+    bool sp_ready = false, sp_regime = false;
     int opt_bf16scr = 1;               // D <= 64 sweep: bf16 screens in front of the Float32 16-row screen / of a survivor's first row block (DPMM_OPT_BF16_SCREENS)
     int opt_bracket = 1;               // D <= 64 sweep: certified bf16 bracket of the reference cluster's value instead of its Float32 evaluation where that decides nothing (DPMM_OPT_REF_BRACKET)
     int opt_timing = 0;                // bit 0 / 1 / 2: HIP events around the sweep kernel / the statistics pass / the all-reduces (dpmm_last_kernel_ms, dpmm_last_comm_ms)
@@ -564,6 +571,12 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
     CHK_CREATE(hipMalloc(&c->d_counts64, sizeof(long long) * 2 * DPMM_MAX_CLUSTERS));
     CHK_CREATE(hipMalloc(&c->d_cside, DPMM_MAX_CLUSTERS));
     CHK_CREATE(hipMemsetAsync(c->d_cside, 0, DPMM_MAX_CLUSTERS, c->stream));
+    if (c->prior == DPMM_PRIOR_NIW && c->NB == 4) {
+        CHK_CREATE(hipMalloc(&c->d_sp_frag, sizeof(uint32_t) * (size_t)SP_MAXK * SP_FRAG_WORDS));
+        CHK_CREATE(hipMalloc(&c->d_sp_cons, sizeof(float) * (size_t)SP_MAXK * SP_CONS_FLOATS));
+        CHK_CREATE(hipHostMalloc((void **)&c->h_need, sizeof(uint32_t) * 4 * (size_t)std::max(1, c->sweep_grid_max), hipHostMallocDefault));
+        memset(c->h_need, 0, sizeof(uint32_t) * 4 * (size_t)std::max(1, c->sweep_grid_max));
+    }
     CHK_CREATE(hipMalloc(&c->d_work, sizeof(unsigned long long) * (DPMM_WORK_SLOTS + 4 * DPMM_WORK_PER_WAVE * (size_t)std::max(1, c->sweep_grid_max))));
     CHK_CREATE(hipMemsetAsync(c->d_work, 0, sizeof(unsigned long long) * (DPMM_WORK_SLOTS + 4 * DPMM_WORK_PER_WAVE * (size_t)std::max(1, c->sweep_grid_max)), c->stream));
 #undef CHK_CREATE
@@ -595,6 +608,8 @@ int dpmm_destroy(dpmm_ctx *c) {
     if (c->h_draw) hipHostFree(c->h_draw);
     hipFree(c->d_malpha); hipFree(c->d_mpairs);
     if (c->h_marg) hipHostFree(c->h_marg);
+    hipFree(c->d_sp_frag); hipFree(c->d_sp_cons);
+    if (c->h_need) hipHostFree(c->h_need);
     hipFree(c->d_counts64); hipFree(c->d_cside); hipFree(c->d_row_off); hipFree(c->d_inv_off); hipFree(c->d_work); hipFree(c->d_par);
     comm_release(c);
     if (c->h_red) hipHostFree(c->h_red);
@@ -826,6 +841,8 @@ int dpmm_params_staging(dpmm_ctx *c, int slots, float **mu, float **mat, float *
     return DPMM_OK;
 }
 
+static int direction_tables(dpmm_ctx *c, int K);
+
 int dpmm_commit_params(dpmm_ctx *c, int K) {
     if (!c) return DPMM_EINVAL;
     if (int rc = check_K(c, K)) return rc;
@@ -882,6 +899,7 @@ int dpmm_commit_params(dpmm_ctx *c, int K) {
                 c->have_screen_prep = true;
             }
         }
+        if (int rc = direction_tables(c, K)) return rc;
     } else {
         HIPCHK(c, launch_copy_bytes(c->d_cst, hcst, sizeof(float) * 3 * K, c->stream));
         HIPCHK(c, launch_gather_rows(c->d_raw, c->ldx, hmat, c->D, hslot, 3 * K, c->D, c->stream));
@@ -893,6 +911,27 @@ int dpmm_commit_params(dpmm_ctx *c, int K) {
     c->have_params = true;
     c->predictive = false;
     c->draws_on_device = false;
+    return DPMM_OK;
+}
+
+// Direction screen: the tables of a new parameter set (one small kernel right behind the pack kernels, on the ctx stream).  Built only while
+// it pays -- automatic mode: the tiles of the previous sweep kept three or more candidates behind the 4-row tests on average (the waves
+// write their counts into pinned memory; that sweep has been waited for by whoever brings new parameters), with hysteresis: on from 3 per
+// tile, off below 1.5.
+static int direction_tables(dpmm_ctx *c, int K) {
+    c->sp_ready = false;
+    if (c->prior != DPMM_PRIOR_NIW || c->NB != 4 || !c->d_sp_frag || K < 3 || K > SP_MAXK || !c->have_tail || !c->opt_bf16scr || c->opt_margin <= 0.f) return DPMM_OK;
+    bool want = c->opt_direction > 0;
+    if (c->opt_direction < 0) {
+        unsigned long long many = 0, tiles = 0;
+        const int nw = 4 * c->sweep_grid;
+        for (int w = 0; w < nw; ++w) { const uint32_t v = c->h_need[w]; many += v >> 16; tiles += v & 0xFFFFu; }
+        if (tiles > 0) c->sp_regime = c->sp_regime ? (many * 2 >= tiles * 3) : (many >= tiles * 3);
+        want = c->sp_regime;
+    }
+    if (!want) return DPMM_OK;
+    HIPCHK(c, launch_niw_direction(c->d_Rp, c->d_mup, c->d_cst, c->D, K, c->d_sp_frag, c->d_sp_cons, c->stream));
+    c->sp_ready = true;
     return DPMM_OK;
 }
 
@@ -1018,6 +1057,8 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
             a.ball = c->opt_ball;
             a.bracket = c->opt_bracket;
             a.bf16scr = (c->opt_bf16scr && c->NB == 4 && a.tail != nullptr) ? 1 : 0;
+            if (c->sp_ready && a.bf16scr && !table) { a.sp_frag = c->d_sp_frag; a.sp_cons = c->d_sp_cons; }
+            a.need = (table || c->opt_direction == 0) ? nullptr : c->h_need;
             a.order = (!table && c->have_perm && !no_order) ? c->sb.perm : nullptr;
             a.order_total = c->sb.perm_total;
             a.work = table ? nullptr : c->d_work;
@@ -1770,12 +1811,13 @@ int dpmm_niw_master_draw(dpmm_ctx *c, uint32_t epoch, int K, const int32_t *slot
     const bool normals = !ahead && noise_ready(c, epoch, K, c->draw_cur);       // (noise_join above made the main stream wait for them)
     HIPCHK(c, launch_niw_master_draw(ma, hs, K, epoch, c->d_Y[c->draw_cur], c->d_ld_sigma[c->draw_cur], hlr, hw, c->d_Rp, c->d_mup, c->d_cst,
                                      c->have_tail ? c->d_tail : nullptr, c->NB, c->d_work, ahead ? 2 : (normals ? 7 : 3), c->stream));
+    if (int rc = direction_tables(c, K)) return rc;
     // The normals of the NEXT draws (epoch + 1, a few clusters more than now for the splits in between) into the other buffer, on the
     // second stream: they depend on nothing the master decides, and run beside the sweep instead of in front of it.  Whoever draws
     // with another epoch, or for more clusters, generates its own.
     // (launched by noise_flush right AFTER the sweep kernel of this step: the launch and its event record would otherwise sit on the
     // host's critical path between the master's decisions and the sweep launch)
-    c->noise_pending = c->opt_noise_ahead < 0 ? c->D >= 128 : c->opt_noise_ahead != 0; c->noise_pend_epoch = epoch + 1; c->noise_pend_nmat = 3 * std::min(K + 4, c->master_K);
+    c->noise_pending = c->opt_noise_ahead < 0 ? (c->D >= 128 || c->n < 4000000) : c->opt_noise_ahead != 0; c->noise_pend_epoch = epoch + 1; c->noise_pend_nmat = 3 * std::min(K + 4, c->master_K);
     c->work_zeroed = true;
     c->have_screen_prep = false;     // (the K > 64 far mask needs the raw factors: not built on this path; the tail screen is)
     c->K = K;
@@ -2290,6 +2332,10 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
         case DPMM_OPT_REF_BRACKET: c->opt_bracket = value != 0; return DPMM_OK;
         case DPMM_OPT_COMM_TIMEOUT_MS: c->comm_timeout_ms = value > 0 ? (int)std::min(value, 2.0e9) : 0; return DPMM_OK;
         case DPMM_OPT_BF16_SCREENS: c->opt_bf16scr = value != 0; return DPMM_OK;
+        case DPMM_OPT_DIRECTION_SCREEN:
+            c->opt_direction = value < 0 ? -1 : (value != 0);
+            if (c->opt_direction == 0) { c->sp_ready = false; c->sp_regime = false; }
+            return DPMM_OK;
         case DPMM_OPT_ONE_COLLECTIVE: c->opt_one_collective = value < 0 ? -1 : (value != 0); return DPMM_OK;
         case DPMM_OPT_SORT_TILE: {
             const int t = (int)value;
@@ -2325,6 +2371,7 @@ int dpmm_last_sweep_work(dpmm_ctx *c, uint64_t *out16) {
         out16[8] += h[DPMM_WORK_PER_WAVE * w + 4];
         out16[11] += h[DPMM_WORK_PER_WAVE * w + 5];
         out16[13] += h[DPMM_WORK_PER_WAVE * w + 6];
+        out16[15] += h[DPMM_WORK_PER_WAVE * w + 7];          // direction screens (8 bf16 matrix instructions per 16 clusters + 4 Float32 row sums each)
     }
     // totals of the launches since the previous call (out16[7] of them); the slots start again from zero
     const long long launches = c->work_launches;

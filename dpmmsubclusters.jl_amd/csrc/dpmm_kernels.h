@@ -48,6 +48,9 @@ struct NiwSweepArgs {
     int screen_lds;           // set by the launcher: screen operands of all K clusters are staged in LDS
     int use_prev;             // bins hold labels from a previous sweep (reference clusters of the screen)
     int lds_rows;             // set by the launcher: rows of the a_k table that live in LDS (0: global scratch)
+    const uint32_t *sp_frag;  // direction screen (D in 33..64, K <= 64; null: none): [K][4][2][64][4] bf16 fragments of the pair directions w, k0 major (launch_niw_direction)
+    const float *sp_cons;     // [K][3][64]: per reference cluster k0 the constants {b, e, cst} of every cluster (direction_far, niw_sweep.hip)
+    uint32_t *need;           // [waves] (pinned host memory, may be null): (candidates this wave's tiles kept behind the 4-row tests, saturating) << 16 | tiles
     unsigned long long *dbg;  // diagnostic builds only (DPMM_STAMPS): per-wave phase cycle sums
     int queue_rounds;         // D <= 64 kernel: rounds of tiles handed out through the queue at the end of the launch (-1: automatic)
     int prio;                 // 1: s_setprio -- low while the wave streams MFMAs, high in its scalar / VALU phases (DPMM_OPT_WAVE_PRIO)
@@ -64,6 +67,10 @@ hipError_t launch_niw_refb_debug(const NiwSweepArgs &a, int k, float c_override,
 hipError_t launch_niw_screen_prep(const float *R, const float *mu, int D, int K, float *lam, float *dist, const int32_t *slot, hipStream_t s);
 hipError_t launch_niw_pack(const float *R, const float *mu, float *Rp, float *mup, int D, int NB, int nmat, float *tail, const float *cst,
                            const int32_t *slot, float *cst_out, unsigned long long *work, hipStream_t s);
+// Tables of the direction screen from the sweep's own images (Rp, mup, cst of the K cluster-level distributions; D in 33..64, K <= SP_MAXK):
+// frag [K][SP_FRAG_WORDS], cons [K][SP_CONS_FLOATS]
+constexpr int SP_MAXK = 64, SP_FRAG_WORDS = 4 * 2 * 256, SP_CONS_FLOATS = 3 * 64;
+hipError_t launch_niw_direction(const float *Rp, const float *mup, const float *cst, int D, int K, uint32_t *frag, float *cons, hipStream_t s);
 
 struct MultSweepArgs {
     const float *X;

@@ -368,6 +368,73 @@ __device__ __forceinline__ bool bf16_top_excludes(const uint32_t *__restrict__ R
     return __all(out);
 }
 
+// DIRECTION screen (D in 33 .. 64, K <= 64; DPMM_OPT_DIRECTION_SCREEN): every remaining candidate of a tile at once, each along the ONE
+// direction that separates it from the wave's reference cluster k0.  For a unit vector u,  q_k(x) = |R_k (x - mu_k)|^2 >= (u' R_k (x - mu_k))^2;
+// with d = mu_k0 - mu_k, b = |R_k d|, u = R_k d / b and w = R_k' u (launch_niw_direction: one 64-vector and two scalars per ordered pair)
+//     u' R_k (x - mu_k) = w . z0 + b,      z0 = x - mu_k0,
+// b is the Mahalanobis distance of the reference cluster's mean from cluster k and w . z0 the point's own offset along that direction -- for
+// a point of k0 a few of ITS standard deviations.  The K dot products of a point are ONE bf16 matrix product per 16 clusters and 32 features,
+// w . z0 = s^ +- e |z0| with e = c |w| (the bracket's rounding constant c: sum |a_i||b_i| <= |a||b|), so
+//     a_k(x) <= cst_k - 0.4995 t^2,   t = |s^ + b| - e |z0|,  counted only when t >= 2 % of b
+// (the Float32 roundings of b, of |u| = 1 and of d are a few 1e-6 of b: below the 1e-3 taken off t^2 once t is a percent of b; a test that
+// decides anything has t^2 / 2 > 50 nats).
+// The reference generator's clusters (covariances ~ InvWishart(D + 2, I): condition numbers of 1e4) are separated by hundreds of such units
+// at MixtureVar 4 and 1 although no 4-feature bound separates them: there this one test removes what took ~30 sixteen-row screens (and ~20
+// first-row-block screens) per tile.  It only ever removes candidates, each exclusion is one the Float32 evaluation would have made, so the
+// table, the evaluated set and the labels are those of the kernel without it.  Returns the mask of excluded clusters (bit k).
+// 16 (K <= 32) or 32 bf16 matrix instructions + 4 row sums per tile, ~400 vector instructions.
+template <int NG>
+__device__ __forceinline__ unsigned long long direction_far(const uint32_t *__restrict__ frag, const float *__restrict__ cons, const float *__restrict__ mup0,
+                                                            const f32x4 (&x)[NG][4], const float (&thr)[NG], int lane, int g, int K) {
+    f32x4 m0[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) m0[t] = *reinterpret_cast<const f32x4 *>(mup0 + 16 * t + 4 * g);
+    u32x4_t zb[NG][2];
+    float nz[NG];
+#pragma unroll
+    for (int n = 0; n < NG; ++n) {
+        float part = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            const f32x4 lo = x[n][2 * sl] - m0[2 * sl], hi = x[n][2 * sl + 1] - m0[2 * sl + 1];
+            part = __builtin_fmaf(lo.x, lo.x, part); part = __builtin_fmaf(lo.y, lo.y, part); part = __builtin_fmaf(lo.z, lo.z, part); part = __builtin_fmaf(lo.w, lo.w, part);
+            part = __builtin_fmaf(hi.x, hi.x, part); part = __builtin_fmaf(hi.y, hi.y, part); part = __builtin_fmaf(hi.z, hi.z, part); part = __builtin_fmaf(hi.w, hi.w, part);
+            zb[n][sl] = (u32x4_t){pack_bf16_pair(lo.x, lo.y), pack_bf16_pair(lo.z, lo.w), pack_bf16_pair(hi.x, hi.y), pack_bf16_pair(hi.z, hi.w)};
+        }
+        const f32x4 tot = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, part, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);      // |z0|^2 of point (n, lane & 15)
+        nz[n] = __builtin_sqrtf(tot[0]) * 1.00001f;
+    }
+    unsigned long long far = 0ull;
+    const int nblk = (K + 15) >> 4;
+    for (int blk = 0; blk < nblk; ++blk) {
+        const u32x4_t a0 = reinterpret_cast<const u32x4_t *>(frag)[(2 * blk) * 64 + lane], a1 = reinterpret_cast<const u32x4_t *>(frag)[(2 * blk + 1) * 64 + lane];
+        const f32x4 cB = *reinterpret_cast<const f32x4 *>(cons + 16 * blk + 4 * g), cE = *reinterpret_cast<const f32x4 *>(cons + 64 + 16 * blk + 4 * g),
+                    cK = *reinterpret_cast<const f32x4 *>(cons + 128 + 16 * blk + 4 * g);
+        bool ok[4] = {true, true, true, true};
+        const f32x4 tau = cB * 0.02f;
+#pragma unroll
+        for (int n = 0; n < NG; ++n) {
+            f32x4 sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a0), __builtin_bit_cast(bf16x8_t, zb[n][0]), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a1), __builtin_bit_cast(bf16x8_t, zb[n][1]), sv, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {       // cluster 16 blk + 4 g + r against point (n, lane & 15); thr = +inf for a column without a point, NaN excludes nothing
+                float t = __builtin_fmaf(-cE[r], nz[n], fabsf(sv[r] + cB[r]));
+                t = t >= tau[r] ? t : 0.f;                                   // (NaN: 0)
+                const float ub = __builtin_fmaf(-0.4995f * t, t, cK[r]);
+                ok[r] = ok[r] && (ub < thr[n]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned long long m = __ballot(ok[r]);
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg)
+                if (((m >> (16 * gg)) & 0xFFFFull) == 0xFFFFull) far |= 1ull << (16 * blk + 4 * gg + r);
+        }
+    }
+    return K >= 64 ? far : far & ((1ull << K) - 1ull);
+}
+
 template <int NB, int NG, int CH>
 struct QuadEval {
     using C = NiwCfg<NB, NG, CH>;
@@ -1016,7 +1083,9 @@ __device__ __forceinline__ void load_rb0(const float *__restrict__ Rm, const flo
 // FAST: the steady-state configuration known at launch time (screening with the tail screen, no far mask, LDS table, no
 // Student-t mode, no table output): the mode tests below become compile-time constants -- fewer live scalars (the generic
 // kernel spills > 100 SGPRs into VGPR lanes) and fewer branches per tile.  Same arithmetic, same results.
-template <int NB, int NG, int OCC, bool FAST = false>
+// DIR: the instantiation with the direction screen (direction_far) in it -- a kernel of its own because its registers (the tile's z0 as bf16
+// for all four point groups) would cost the common kernel 40 spilled registers and 15 % of its time for a branch it never takes.
+template <int NB, int NG, int OCC, bool FAST = false, bool DIR = false>
 __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs A) {
 #ifdef DPMM_STAMPS
     unsigned long long T_x = 0, T_quad = 0, T_epi = 0, T_draw = 0, T_p2 = 0, T_tot = 0, N_scr = 0, N_tail = 0, T_prep = 0, T_far = 0, T_surv = 0, T_init = 0, T_i1 = 0, T_i2 = 0, T_lastd = 0, T_long = 0, T_longat = 0, T_firstd = 0; int ntile = 0;
@@ -1072,6 +1141,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
     int nx_p = -1, nx_bin = -1;
     int nx_tile = -1;
     unsigned nw_tiles = 0, nw_full = 0, nw_scr = 0, nw_tail = 0, nw_br = 0, nw_bb = 0, nw_bt = 0;   // executed-work counters of this wave (wave-uniform); nw_bb / nw_bt: bf16 bottom / top screens
+    unsigned nw_sp = 0, nw_cand = 0;          // direction screens run (DIR); candidates behind the 4-row tests (DIR: counted; else = nw_bb, every one gets a bottom screen)
     const int rounds_all = nwtiles / nwaves;
     int dyn_rounds = A.queue_rounds >= 0 ? A.queue_rounds : (rounds_all < 4 ? 0 : (rounds_all / 8 > 2 ? rounds_all / 8 : 2));
     if (dyn_rounds > rounds_all) dyn_rounds = rounds_all;
@@ -1461,6 +1531,17 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                             f32x4 x3[NG];
 #pragma unroll
                             for (int n = 0; n < NG; ++n) { thrb[n] = pvalid[n] ? bestn[n] - margin : INFINITY; x3[n] = x[n][LB]; }
+                            // three or more candidates left by the 4-row tests: all of them at once, each along its own direction (direction_far); the
+                            // number of candidates is what the library decides on for the NEXT sweep (without the screen it is the number of bottom screens)
+                            if constexpr (DIR) {
+                                const int nc = __builtin_popcountll(cand);
+                                nw_cand += (unsigned)nc;
+                                if (nc >= 3) {
+                                    ++nw_sp;
+                                    cand &= ~direction_far<NG>(A.sp_frag + (size_t)k0 * SP_FRAG_WORDS, A.sp_cons + (size_t)k0 * SP_CONS_FLOATS,
+                                                              A.mup + (size_t)(3 * k0) * DP, x, thrb, lane, g, K);
+                                }
+                            }
                             const u32x4_t *Rb0 = reinterpret_cast<const u32x4_t *>(refb_records(A.tail, K));
                             auto loadk = [&](int k, u32x4_t &a, f32x4 &m4, float &ck) {
                                 a = Rb0[(size_t)k * (REFB_WORDS / 4) + 64 * 5 + lane];
@@ -1714,7 +1795,11 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
     }
     if (A.work && lane == 0) {      // one slot per wave, no atomics (see the LDS-staged kernel)
         unsigned long long *slot = A.work + DPMM_WORK_SLOTS + (size_t)wave_id * DPMM_WORK_PER_WAVE;      // (accumulates over launches; cleared by the reader)
-        slot[0] += nw_tiles; slot[1] += nw_full; slot[2] += nw_scr; slot[3] += nw_tail; slot[4] += nw_br; slot[5] += nw_bb; slot[6] += nw_bt;
+        slot[0] += nw_tiles; slot[1] += nw_full; slot[2] += nw_scr; slot[3] += nw_tail; slot[4] += nw_br; slot[5] += nw_bb; slot[6] += nw_bt; slot[7] += nw_sp;
+    }
+    if (A.need && lane == 0) {                // (this launch only: plain store into the host's pinned block)
+        const unsigned nc = DIR ? nw_cand : nw_bb;
+        A.need[wave_id] = ((nc < 65535u ? nc : 65535u) << 16) | (nw_tiles < 65535u ? nw_tiles : 65535u);
     }
 #ifdef DPMM_STAMPS
     if (lane == 0 && A.dbg) {
@@ -1745,6 +1830,17 @@ static hipError_t launch_direct(const NiwSweepArgs &a, int grid, hipStream_t s) 
     }
     const bool fast = NB >= 2 && b.screen_margin > 0.f && !b.tdf && !b.scratch_by_tile && !b.labels_only && b.K > 2 && b.lam == nullptr &&
                       b.tail != nullptr && b.lds_rows >= b.K && !b.final_argmax;
+    if constexpr (NB == 4) {
+        if (fast && b.sp_frag && b.sp_cons && b.bf16scr && b.K <= SP_MAXK) {
+            static bool attr_dir = false;
+            if (!attr_dir) {
+                hipFuncSetAttribute((const void *)niw_sweep_direct_kernel<NB, NG, OCC, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / OCC);
+                attr_dir = true;
+            }
+            DPMM_LAUNCH((niw_sweep_direct_kernel<NB, NG, OCC, true, true>), dim3(grid), dim3(256), lds_bytes, s, b);
+            return hipGetLastError();
+        }
+    }
     if (fast) {
         static bool attr_fast = false;
         if (!attr_fast) {
@@ -1965,6 +2061,105 @@ __global__ __launch_bounds__(256) void niw_screen_prep_kernel(const float *__res
 hipError_t launch_niw_screen_prep(const float *R, const float *mu, int D, int K, float *lam, float *dist, const int32_t *slot, hipStream_t s) {
     const size_t lds = sizeof(float) * ((size_t)D * D + (size_t)D * (D + 1) + 256);
     DPMM_LAUNCH(niw_screen_prep_kernel, dim3(K), dim3(256), lds, s, R, mu, D, K, lam, dist, slot);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// Tables of the direction screen (direction_far), from the images the sweep itself reads (D in 33 .. 64: NB = 4, NP = 10, DP = 64).
+// One workgroup per cluster k, four threads per reference cluster k0 (K <= 64): R_k (the Float32 values of the fragment image) in LDS,
+//     d = mu_k0 - mu_k,   y = R_k d  (Float64 sums),   b = |y|,   u = y / b,   w = R_k' u,
+// w as the bf16 A-operand row of cluster k in k0's fragment table (k-slots in the order of the bracket's image, refb_map), and the constants
+//     B = b,      E = (c + 1e-6) |w| (1 + 1e-5),      cst_k.
+// A pair without a direction (k = k0, b not finite or zero) and the rows of clusters that do not exist get E = inf: t = 0, nothing excluded.
+__global__ __launch_bounds__(256) void niw_direction_kernel(const float *__restrict__ Rp, const float *__restrict__ mup, const float *__restrict__ cst,
+                                                            int D, int K, uint32_t *__restrict__ frag, float *__restrict__ cons) {
+    __shared__ float Rk[64 * 65];              // R_k, row stride 65
+    __shared__ float dl[64][65];               // d of every k0, then u, then w
+    __shared__ float muk[64];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const float *img = Rp + (size_t)(3 * k) * 2560;
+    for (int e = tid; e < 64 * 65; e += 256) Rk[e] = 0.f;
+    if (tid < 64) muk[tid] = mup[(size_t)(3 * k) * 64 + tid];
+    __syncthreads();
+    for (int e = tid; e < 2560; e += 256) {
+        const int jj = e & 3, ln = (e >> 2) & 63, pair = e >> 8;
+        int bi = 0, rem = pair;
+        while (rem >= 4 - bi) { rem -= 4 - bi; ++bi; }
+        Rk[(16 * bi + (ln & 15)) * 65 + 16 * (bi + rem) + 4 * (ln >> 4) + jj] = img[e];
+    }
+    for (int e = tid; e < 64 * 64; e += 256) {
+        const int k0 = e >> 6, c = e & 63;
+        dl[k0][c] = k0 < K ? mup[(size_t)(3 * k0) * 64 + c] - muk[c] : 0.f;
+    }
+    __syncthreads();
+    const int k0 = tid >> 2, p = tid & 3;       // rows / columns 16 p .. 16 p + 15 of reference cluster k0's pair
+    double y[16];
+    double ss = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = 16 * p + i;
+        double acc = 0.0;
+        for (int c = r; c < 64; ++c) acc = __builtin_fma((double)Rk[r * 65 + c], (double)dl[k0][c], acc);      // (upper triangular)
+        y[i] = acc;
+        ss = __builtin_fma(acc, acc, ss);
+    }
+    ss += __shfl_xor(ss, 1);
+    ss += __shfl_xor(ss, 2);
+    const double b = sqrt(ss);
+    const bool live = k0 < K && k0 != k && b > 0.0 && b < 1e30;
+    __syncthreads();                             // every d has been read
+    const double ib = live ? 1.0 / b : 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dl[k0][16 * p + i] = (float)(y[i] * ib);       // u (Float32: its norm is 1 within 1e-6)
+    __syncthreads();
+    float w[16];
+    double ww = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = 16 * p + i;
+        double acc = 0.0;
+        for (int r = 0; r <= c; ++r) acc = __builtin_fma((double)Rk[r * 65 + c], (double)dl[k0][r], acc);
+        w[i] = (float)acc;
+        ww = __builtin_fma(acc, acc, ww);
+    }
+    ww += __shfl_xor(ww, 1);
+    ww += __shfl_xor(ww, 2);
+    __syncthreads();                             // every u has been read
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dl[k0][16 * p + i] = live ? w[i] : 0.f;
+    __syncthreads();
+    if (p == 0 && k0 < K) {                      // constants of cluster k in reference cluster k0's table
+        float *co = cons + (size_t)k0 * SP_CONS_FLOATS;
+        const float nw = (float)sqrt(ww) * 1.00001f;
+        co[k] = live ? (float)b : 0.f;
+        co[64 + k] = live ? (REFB_C + 1e-6f) * nw : INFINITY;          // (inf: t = 0, nothing excluded along a direction that does not exist)
+        co[128 + k] = cst[3 * k];
+    }
+    if (k == 0 && tid < 64 * 3) {                // rows of clusters that do not exist: never excluded (they have no candidate bit either)
+        for (int q = 0; q < K; ++q) {
+            float *co = cons + (size_t)q * SP_CONS_FLOATS;
+            const int a = tid / 64, j = tid % 64;
+            if (j >= K) co[64 * a + j] = a == 1 ? INFINITY : (a == 2 ? INFINITY : 0.f);
+        }
+    }
+    // row (k & 15) of block (k >> 4) in every k0's fragment table: [blk][sl][lane = (i, g)][4 dwords]
+    const int blk = k >> 4, irow = k & 15;
+    for (int e = tid; e < K * 2 * 4 * 4; e += 256) {          // (k0, sl, g, d)
+        const int d = e & 3, g = (e >> 2) & 3, sl = (e >> 4) & 1, q = e >> 5, j0 = 2 * d;
+        const int col = 32 * sl + (j0 < 4 ? 4 * g + j0 : 16 + 4 * g + (j0 - 4));
+        frag[(size_t)q * SP_FRAG_WORDS + (((blk * 2 + sl) * 64) + (16 * g + irow)) * 4 + d] = bf16_rne_bits(dl[q][col]) | (bf16_rne_bits(dl[q][col + 1]) << 16);
+    }
+    // blocks beyond the last cluster's row inside block (K - 1) >> 4 keep whatever they held: their constants are inf (above)
+    if (k == K - 1) {
+        for (int e = tid; e < K * 2 * 4 * 4 * 16; e += 256) {  // zero rows K .. 16 ceil(K / 16) - 1 of the last block in every k0's table
+            const int d = e & 3, g = (e >> 2) & 3, sl = (e >> 4) & 1, rr = (e >> 5) & 15, q = e >> 9;
+            if (rr > irow) frag[(size_t)q * SP_FRAG_WORDS + (((blk * 2 + sl) * 64) + (16 * g + rr)) * 4 + d] = 0u;
+        }
+    }
+}
+hipError_t launch_niw_direction(const float *Rp, const float *mup, const float *cst, int D, int K, uint32_t *frag, float *cons, hipStream_t s) {
+    if (K < 1 || K > SP_MAXK || D < 33 || D > 64) return hipErrorInvalidValue;
+    DPMM_LAUNCH(niw_direction_kernel, dim3(K), dim3(256), 0, s, Rp, mup, cst, D, K, frag, cons);
     return hipGetLastError();
 }
 

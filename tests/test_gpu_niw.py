@@ -613,3 +613,78 @@ def test_bf16_screens_do_not_change_labels(pkg, D, sep, K):
     # top screen removes the last survivor of a bracketed wave (the reference cluster's own Float32 evaluation is then skipped as well)
     assert w1["full_evals"] <= w0["full_evals"]
     assert w1["screens16"] <= w0["screens16"] and w0["bf16_bottom_screens"] == 0 and w0["bf16_top_screens"] == 0
+
+
+@pytest.mark.parametrize("D,sep,K", [(64, 2.0, 12), (64, 1.0, 20), (64, 0.8, 7), (52, 2.0, 7), (36, 3.0, 9), (64, 1.5, 60), (64, 40.0, 7), (64, 0.3, 5)])
+def test_direction_screen_does_not_change_labels(pkg, D, sep, K):
+    """DPMM_OPT_DIRECTION_SCREEN (D in 33 .. 64, K <= 64): q_k(x) >= |x - mu_k|^2 / lambda_max(Sigma_k) for all candidates of a tile at once, the
+    distances through one bf16 matrix product against the reference cluster's mean.  It only removes candidates the Float32 tests behind it
+    would have excluded, so the table and the labels are those of the kernel without it, bit for bit: on overlapping clusters of every
+    degree (where it does most of the screening), with zero-padded features, on separated clusters (where it never runs) and on clusters so
+    close that it can exclude nothing."""
+    from dpmmsubclusters_jl_amd import binding
+    n = 30000
+    P = make_problem(D, n, K, seed=140 + D + K, sep=sep, sorted_points=True)
+    out = {}
+    for on in (1, 0):
+        wk = gpu_worker(pkg, P, seed=29)
+        wk.set_option(binding.OPT_DIRECTION_SCREEN, on)
+        wk.set_labels(P["z"] + 1, 1 + (np.arange(n) & 1))
+        wk.suffstats_packed(None)                      # the bin-sorted visiting order
+        wk.set_params_niw(P["mu"], P["invS"], P["logdet"], P["lr"], P["w"])
+        wk.last_sweep_work()
+        labs = []
+        for ep in (1, 2):
+            wk.sweep(ep)
+            labs.append(wk.get_labels())
+            wk.suffstats_packed(None)
+            wk.set_params_niw(P["mu"], P["invS"], P["logdet"], P["lr"], P["w"])
+        work = wk.last_sweep_work()
+        if on:
+            tab = wk.debug_loglik()                    # (margin 0, no screens: the full table)
+            u0, u1 = orc.uniforms(29, 2, 0, 0, n)
+            assert np.array_equal(orc.sample_log_cat(tab, u0), labs[1][0])
+        out[on] = (labs, work)
+        wk.close()
+    for a, b in zip(out[1][0], out[0][0]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    w1, w0 = out[1][1], out[0][1]
+    t = w1["wave_tiles"]
+    print(f"D={D} sep={sep} K={K}: per wave tile -- direction screens {w1['direction_screens'] / t:.2f}; bf16 bottom {w0['bf16_bottom_screens'] / t:.2f} -> "
+          f"{w1['bf16_bottom_screens'] / t:.2f}, bf16 top {w0['bf16_top_screens'] / t:.2f} -> {w1['bf16_top_screens'] / t:.2f}, "
+          f"Float32 screens {w0['screens16'] / t:.2f} -> {w1['screens16'] / t:.2f}, full evaluations {w0['full_evals'] / t:.2f} -> {w1['full_evals'] / t:.2f}")
+    assert w0["direction_screens"] == 0
+    # never more work behind it: every cluster it removes skips its 16-row screens
+    assert w1["bf16_bottom_screens"] <= w0["bf16_bottom_screens"] and w1["screens16"] <= w0["screens16"] and w1["full_evals"] <= w0["full_evals"]
+
+
+def test_direction_screen_switches_itself_on_and_off(pkg):
+    """Automatic mode: the tables are built for the sweep AFTER one whose tiles kept three or more candidates on average behind the 4-row
+    tests (overlapping clusters), and no longer once they keep fewer than 1.5 (separated clusters)."""
+    D, n, K = 64, 20000, 10
+    Pov = make_problem(D, n, K, seed=7, sep=1.5, sorted_points=True)
+    wk = gpu_worker(pkg, Pov, seed=3)
+    wk.set_labels(Pov["z"] + 1, 1 + (np.arange(n) & 1))
+    wk.suffstats_packed(None)
+    counts = []
+    for ep in (1, 2, 3):
+        wk.set_params_niw(Pov["mu"], Pov["invS"], Pov["logdet"], Pov["lr"], Pov["w"])
+        wk.last_sweep_work()
+        wk.sweep(ep)
+        wk.sync()
+        counts.append(wk.last_sweep_work()["direction_screens"])
+    assert counts[0] == 0 and counts[1] > 0 and counts[2] > 0, counts
+    # the same worker on separated clusters: nothing left for it, one sweep later it is off
+    Psep = make_problem(D, n, K, seed=8, sep=40.0, sorted_points=True)
+    wk.upload_points(Psep["X"])
+    wk.set_labels(Psep["z"] + 1, 1 + (np.arange(n) & 1))
+    wk.suffstats_packed(None)
+    counts = []
+    for ep in (4, 5, 6):
+        wk.set_params_niw(Psep["mu"], Psep["invS"], Psep["logdet"], Psep["lr"], Psep["w"])
+        wk.last_sweep_work()
+        wk.sweep(ep)
+        wk.sync()
+        counts.append(wk.last_sweep_work()["direction_screens"])
+    assert counts[-1] == 0, counts
+    wk.close()
