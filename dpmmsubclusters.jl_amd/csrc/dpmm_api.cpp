@@ -209,6 +209,7 @@ struct dpmm_ctx {
     uint32_t *h_need = nullptr;
     int opt_direction = -1;             // -1: by the previous sweep's candidate counts, 0: never, 1: always
     bool sp_ready = false, sp_regime = false;
+    unsigned sp_count = 0;             // parameter sets since the screen came on: every 32nd sweep measures (tail pairs first), the others run it first
     int opt_bf16scr = 1;               // D <= 64 sweep: bf16 screens in front of the Float32 16-row screen / of a survivor's first row block (DPMM_OPT_BF16_SCREENS)
     int opt_bracket = 1;               // D <= 64 sweep: certified bf16 bracket of the reference cluster's value instead of its Float32 evaluation where that decides nothing (DPMM_OPT_REF_BRACKET)
     int opt_timing = 0;                // bit 0 / 1 / 2: HIP events around the sweep kernel / the statistics pass / the all-reduces (dpmm_last_kernel_ms, dpmm_last_comm_ms)
@@ -925,11 +926,17 @@ static int direction_tables(dpmm_ctx *c, int K) {
     if (c->opt_direction < 0) {
         unsigned long long many = 0, tiles = 0;
         const int nw = 4 * c->sweep_grid;
-        for (int w = 0; w < nw; ++w) { const uint32_t v = c->h_need[w]; many += v >> 16; tiles += v & 0xFFFFu; }
+        unsigned long long many_ub = 0, tiles_ub = 0;        // sweeps that ran the screen in front of the tail pairs: counted there, an upper bound
+        for (int w = 0; w < nw; ++w) {
+            const uint32_t v = c->h_need[w];
+            if (v & 0x8000u) { many_ub += v >> 16; tiles_ub += v & 0x7FFFu; } else { many += v >> 16; tiles += v & 0x7FFFu; }
+        }
         if (tiles > 0) c->sp_regime = c->sp_regime ? (many * 2 >= tiles * 3) : (many >= tiles * 3);
+        else if (tiles_ub > 0 && many_ub * 2 < tiles_ub * 3) c->sp_regime = false;        // even the upper bound is below the switch-off level
         want = c->sp_regime;
     }
-    if (!want) return DPMM_OK;
+    if (!want) { c->sp_count = 0; return DPMM_OK; }
+    c->sp_count += 1;
     HIPCHK(c, launch_niw_direction(c->d_Rp, c->d_mup, c->d_cst, c->D, K, c->d_sp_frag, c->d_sp_cons, c->stream));
     c->sp_ready = true;
     return DPMM_OK;
@@ -1057,7 +1064,7 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
             a.ball = c->opt_ball;
             a.bracket = c->opt_bracket;
             a.bf16scr = (c->opt_bf16scr && c->NB == 4 && a.tail != nullptr) ? 1 : 0;
-            if (c->sp_ready && a.bf16scr && !table) { a.sp_frag = c->d_sp_frag; a.sp_cons = c->d_sp_cons; }
+            if (c->sp_ready && a.bf16scr && !table) { a.sp_frag = c->d_sp_frag; a.sp_cons = c->d_sp_cons; if (c->opt_direction > 0 || c->sp_count % 32u != 1u) a.bf16scr |= 2; }
             a.need = (table || c->opt_direction == 0) ? nullptr : c->h_need;
             a.order = (!table && c->have_perm && !no_order) ? c->sb.perm : nullptr;
             a.order_total = c->sb.perm_total;

@@ -41,7 +41,9 @@ struct NiwSweepArgs {
     const float *tail;        // [ceil(K/2)][16][2] tail-screen records of the cluster-level matrices, pairs interleaved, then [K][16] ball records (null: no tail screen)
     int tail_g;               // row group (lane >> 4) whose x registers of the last block hold features D-4..D-1
     int ball;                 // 1: cluster-per-lane ball test in front of the per-point tail screen (records [K][16] behind the pair records)
-    int bf16scr;              // 1: D in 33..64 with tail records: bf16 screens in front of the Float32 16-row screen and of every survivor's first row block (DPMM_OPT_BF16_SCREENS)
+    int bf16scr;              // bit 0: D in 33..64 with tail records: bf16 screens in front of the Float32 16-row screen and of every survivor's first row block (DPMM_OPT_BF16_SCREENS);
+                              // bit 1 (with sp_frag): the direction screen runs in FRONT of the tail-pair tests (the sweeps between two measuring ones).
+                              // (A field of its own for bit 1 cost the common kernel 32 spilled registers: the argument block's size decides how the compiler lays out its scalars.)
     int bracket;              // 1: D in 49..64, homogeneous waves: certified bf16 bracket of the reference cluster's value first; its Float32 evaluation only if a cluster survives the screens (bf16 images behind the ball records)
     const float *lam;         // [K] lower bounds of lambda_min(Sigma_k^-1) (null: no scalar pre-screen)
     const float *mdist;       // [K][K] distances between the cluster means
@@ -50,7 +52,8 @@ struct NiwSweepArgs {
     int lds_rows;             // set by the launcher: rows of the a_k table that live in LDS (0: global scratch)
     const uint32_t *sp_frag;  // direction screen (D in 33..64, K <= 64; null: none): [K][4][2][64][4] bf16 fragments of the pair directions w, k0 major (launch_niw_direction)
     const float *sp_cons;     // [K][3][64]: per reference cluster k0 the constants {b, e, cst} of every cluster (direction_far, niw_sweep.hip)
-    uint32_t *need;           // [waves] (pinned host memory, may be null): (candidates this wave's tiles kept behind the 4-row tests, saturating) << 16 | tiles
+    uint32_t *need;           // [waves] (pinned host memory, may be null): (candidates this wave's tiles kept behind the 4-row tests, saturating) << 16 | tiles (15 bits);
+                              // bit 15: counted in FRONT of the tail-pair tests (direction screen first): an upper bound
     unsigned long long *dbg;  // diagnostic builds only (DPMM_STAMPS): per-wave phase cycle sums
     int queue_rounds;         // D <= 64 kernel: rounds of tiles handed out through the queue at the end of the launch (-1: automatic)
     int prio;                 // 1: s_setprio -- low while the wave streams MFMAs, high in its scalar / VALU phases (DPMM_OPT_WAVE_PRIO)

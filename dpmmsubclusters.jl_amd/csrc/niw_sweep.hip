@@ -1512,16 +1512,18 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                 if (tailscr) {
                     if (ball.ok) cand &= ~ball_far(A.tail, K, base, lane, ball);
                     // pairs (2p, 2p+1) of the chunk that still hold a candidate; far clusters lose their candidate bit
-                    for (unsigned long long pend = cand; pend;) {
-                        const int sh = __builtin_ctzll(pend) & ~1;            // (base is a multiple of 64: pair 2p sits at an even bit)
-                        const int pr = (base + sh) >> 1;
-                        pend &= ~(3ull << sh);
-                        ++nw_tail;
-#ifdef DPMM_STAMPS
-                        N_tail += __builtin_popcount((unsigned)(cand >> sh) & 3u);
-#endif
-                        cand &= ~((unsigned long long)tail_pair_far(tail_load_pair(A.tail, pr), xt, my_thr) << sh);
+#define DPMM_TAIL_PAIRS()                                                                                                            \
+                    for (unsigned long long pend = cand; pend;) {                                                                \
+                        const int sh = __builtin_ctzll(pend) & ~1;            /* (base is a multiple of 64: pair 2p sits at an even bit) */ \
+                        const int pr = (base + sh) >> 1;                                                                         \
+                        pend &= ~(3ull << sh);                                                                                   \
+                        ++nw_tail;                                                                                               \
+                        cand &= ~((unsigned long long)tail_pair_far(tail_load_pair(A.tail, pr), xt, my_thr) << sh);             \
                     }
+                    // (DIR, (A.bf16scr & 2): the direction screen runs in FRONT of the tail pairs -- in the regime that switched it on they exclude
+                    // nothing and cost 16 pair tests per tile; every 32nd sweep keeps the usual order and counts what the 4-row tests leave)
+                    if constexpr (!DIR) { DPMM_TAIL_PAIRS() }
+                    else if (!(A.bf16scr & 2)) { DPMM_TAIL_PAIRS() }
                     if constexpr (NB == 4) {
                         if (A.bf16scr) {
                             // bf16 screens of the remaining candidates, software-pipelined: the operands of the NEXT candidate (fragment, tail means,
@@ -1535,12 +1537,13 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                             // number of candidates is what the library decides on for the NEXT sweep (without the screen it is the number of bottom screens)
                             if constexpr (DIR) {
                                 const int nc = __builtin_popcountll(cand);
-                                nw_cand += (unsigned)nc;
+                                nw_cand += (unsigned)nc;                  // (direction first: before the tail pairs -- an upper bound of what they leave)
                                 if (nc >= 3) {
                                     ++nw_sp;
                                     cand &= ~direction_far<NG>(A.sp_frag + (size_t)k0 * SP_FRAG_WORDS, A.sp_cons + (size_t)k0 * SP_CONS_FLOATS,
                                                               A.mup + (size_t)(3 * k0) * DP, x, thrb, lane, g, K);
                                 }
+                                if ((A.bf16scr & 2)) { DPMM_TAIL_PAIRS() }
                             }
                             const u32x4_t *Rb0 = reinterpret_cast<const u32x4_t *>(refb_records(A.tail, K));
                             auto loadk = [&](int k, u32x4_t &a, f32x4 &m4, float &ck) {
@@ -1799,7 +1802,9 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
     }
     if (A.need && lane == 0) {                // (this launch only: plain store into the host's pinned block)
         const unsigned nc = DIR ? nw_cand : nw_bb;
-        A.need[wave_id] = ((nc < 65535u ? nc : 65535u) << 16) | (nw_tiles < 65535u ? nw_tiles : 65535u);
+        uint32_t word = ((nc < 65535u ? nc : 65535u) << 16) | (nw_tiles < 32767u ? nw_tiles : 32767u);
+        if constexpr (DIR) { if ((A.bf16scr & 2)) word = (word & 0xFFFF7FFFu) | 0x8000u; }      // (bit 15: counted in front of the tail pairs, an upper bound)
+        A.need[wave_id] = word;
     }
 #ifdef DPMM_STAMPS
     if (lane == 0 && A.dbg) {
@@ -1809,6 +1814,8 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
     }
 #endif
 }
+
+#undef DPMM_TAIL_PAIRS
 
 template <int NB, int NG, int OCC>
 static hipError_t launch_direct(const NiwSweepArgs &a, int grid, hipStream_t s) {
