@@ -210,6 +210,9 @@ struct dpmm_ctx {
     int opt_direction = -1;             // -1: by the previous sweep's candidate counts, 0: never, 1: always
     bool sp_ready = false, sp_regime = false;
     unsigned sp_count = 0;             // parameter sets since the screen came on: every 32nd sweep measures (tail pairs first), the others run it first
+    bool sp_last = false;              // the last sweep ran the DIR kernel (its yield words are valid)
+    int sp_K = -1;                     // number of clusters of the last parameter set the tables were built for
+    int sp_cooldown = 0;               // parameter sets the screen stays off after it removed less than a quarter of what it was given
     int opt_bf16scr = 1;               // D <= 64 sweep: bf16 screens in front of the Float32 16-row screen / of a survivor's first row block (DPMM_OPT_BF16_SCREENS)
     int opt_bracket = 1;               // D <= 64 sweep: certified bf16 bracket of the reference cluster's value instead of its Float32 evaluation where that decides nothing (DPMM_OPT_REF_BRACKET)
     int opt_timing = 0;                // bit 0 / 1 / 2: HIP events around the sweep kernel / the statistics pass / the all-reduces (dpmm_last_kernel_ms, dpmm_last_comm_ms)
@@ -575,8 +578,8 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
     if (c->prior == DPMM_PRIOR_NIW && c->NB == 4) {
         CHK_CREATE(hipMalloc(&c->d_sp_frag, sizeof(uint32_t) * (size_t)SP_MAXK * SP_FRAG_WORDS));
         CHK_CREATE(hipMalloc(&c->d_sp_cons, sizeof(float) * (size_t)SP_MAXK * SP_CONS_FLOATS));
-        CHK_CREATE(hipHostMalloc((void **)&c->h_need, sizeof(uint32_t) * 4 * (size_t)std::max(1, c->sweep_grid_max), hipHostMallocDefault));
-        memset(c->h_need, 0, sizeof(uint32_t) * 4 * (size_t)std::max(1, c->sweep_grid_max));
+        CHK_CREATE(hipHostMalloc((void **)&c->h_need, sizeof(uint32_t) * 8 * (size_t)std::max(1, c->sweep_grid_max), hipHostMallocDefault));
+        memset(c->h_need, 0, sizeof(uint32_t) * 8 * (size_t)std::max(1, c->sweep_grid_max));
     }
     CHK_CREATE(hipMalloc(&c->d_work, sizeof(unsigned long long) * (DPMM_WORK_SLOTS + 4 * DPMM_WORK_PER_WAVE * (size_t)std::max(1, c->sweep_grid_max))));
     CHK_CREATE(hipMemsetAsync(c->d_work, 0, sizeof(unsigned long long) * (DPMM_WORK_SLOTS + 4 * DPMM_WORK_PER_WAVE * (size_t)std::max(1, c->sweep_grid_max)), c->stream));
@@ -916,9 +919,10 @@ int dpmm_commit_params(dpmm_ctx *c, int K) {
 }
 
 // Direction screen: the tables of a new parameter set (one small kernel right behind the pack kernels, on the ctx stream).  Built only while
-// it pays -- automatic mode: the tiles of the previous sweep kept three or more candidates behind the 4-row tests on average (the waves
-// write their counts into pinned memory; that sweep has been waited for by whoever brings new parameters), with hysteresis: on from 3 per
-// tile, off below 1.5.
+// it pays -- automatic mode: the tiles of the previous sweep kept eight or more candidates behind the 4-row tests on average (the waves
+// write their counts into pinned memory; that sweep has been waited for by whoever brings new parameters), with hysteresis: on from 8 per
+// tile, off below 4.  While it is on, the sweeps run the screen in front of the 4-row pair tests; the first sweep, every 32nd and the one
+// after a change of K keep the usual order and count.
 static int direction_tables(dpmm_ctx *c, int K) {
     c->sp_ready = false;
     if (c->prior != DPMM_PRIOR_NIW || c->NB != 4 || !c->d_sp_frag || K < 3 || K > SP_MAXK || !c->have_tail || !c->opt_bf16scr || c->opt_margin <= 0.f) return DPMM_OK;
@@ -927,16 +931,25 @@ static int direction_tables(dpmm_ctx *c, int K) {
         unsigned long long many = 0, tiles = 0;
         const int nw = 4 * c->sweep_grid;
         unsigned long long many_ub = 0, tiles_ub = 0;        // sweeps that ran the screen in front of the tail pairs: counted there, an upper bound
+        unsigned long long given = 0, removed = 0;            // the last sweep's direction screens, if it ran any
         for (int w = 0; w < nw; ++w) {
-            const uint32_t v = c->h_need[w];
+            const uint32_t v = c->h_need[2 * w];
             if (v & 0x8000u) { many_ub += v >> 16; tiles_ub += v & 0x7FFFu; } else { many += v >> 16; tiles += v & 0x7FFFu; }
+            if (c->sp_last) { const uint32_t y = c->h_need[2 * w + 1]; given += y & 0xFFFFu; removed += y >> 16; }
         }
-        if (tiles > 0) c->sp_regime = c->sp_regime ? (many * 2 >= tiles * 3) : (many >= tiles * 3);
-        else if (tiles_ub > 0 && many_ub * 2 < tiles_ub * 3) c->sp_regime = false;        // even the upper bound is below the switch-off level
+        // (break-even measured on the growth run: at 4.3 candidates per tile the screen costs 3 % of the step, at 28 it saves a third)
+        if (tiles > 0) c->sp_regime = c->sp_regime ? (many >= tiles * 4) : (many >= tiles * 8);
+        else if (tiles_ub > 0 && many_ub < tiles_ub * 4) c->sp_regime = false;        // even the upper bound is below the switch-off level
+        // clusters that overlap along every direction (a chain that is still growing: one cluster over several components): the screen is
+        // given candidates and removes few -- off for 64 parameter sets, then it may try again
+        if (c->sp_last && given > 0 && removed * 4 < given) { c->sp_regime = false; c->sp_cooldown = 64; }
+        if (c->sp_cooldown > 0) { c->sp_cooldown -= 1; c->sp_regime = false; }
         want = c->sp_regime;
     }
+    c->sp_last = false;
     if (!want) { c->sp_count = 0; return DPMM_OK; }
-    c->sp_count += 1;
+    c->sp_count = (K != c->sp_K) ? 1u : c->sp_count + 1u;      // (a new number of clusters: measure again)
+    c->sp_K = K;
     HIPCHK(c, launch_niw_direction(c->d_Rp, c->d_mup, c->d_cst, c->D, K, c->d_sp_frag, c->d_sp_cons, c->stream));
     c->sp_ready = true;
     return DPMM_OK;
@@ -1064,7 +1077,7 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
             a.ball = c->opt_ball;
             a.bracket = c->opt_bracket;
             a.bf16scr = (c->opt_bf16scr && c->NB == 4 && a.tail != nullptr) ? 1 : 0;
-            if (c->sp_ready && a.bf16scr && !table) { a.sp_frag = c->d_sp_frag; a.sp_cons = c->d_sp_cons; if (c->opt_direction > 0 || c->sp_count % 32u != 1u) a.bf16scr |= 2; }
+            if (c->sp_ready && a.bf16scr && !table) { c->sp_last = true; a.sp_frag = c->d_sp_frag; a.sp_cons = c->d_sp_cons; if (c->opt_direction > 0 || c->sp_count % 32u != 1u) a.bf16scr |= 2; }
             a.need = (table || c->opt_direction == 0) ? nullptr : c->h_need;
             a.order = (!table && c->have_perm && !no_order) ? c->sb.perm : nullptr;
             a.order_total = c->sb.perm_total;

@@ -52,8 +52,9 @@ struct NiwSweepArgs {
     int lds_rows;             // set by the launcher: rows of the a_k table that live in LDS (0: global scratch)
     const uint32_t *sp_frag;  // direction screen (D in 33..64, K <= 64; null: none): [K][4][2][64][4] bf16 fragments of the pair directions w, k0 major (launch_niw_direction)
     const float *sp_cons;     // [K][3][64]: per reference cluster k0 the constants {b, e, cst} of every cluster (direction_far, niw_sweep.hip)
-    uint32_t *need;           // [waves] (pinned host memory, may be null): (candidates this wave's tiles kept behind the 4-row tests, saturating) << 16 | tiles (15 bits);
-                              // bit 15: counted in FRONT of the tail-pair tests (direction screen first): an upper bound
+    uint32_t *need;           // [waves][2] (pinned host memory, may be null): [0] = (candidates this wave's tiles kept behind the 4-row tests, saturating) << 16 | tiles
+                              // (15 bits), bit 15: counted in FRONT of the tail-pair tests (direction screen first): an upper bound;
+                              // [1] (written by the DIR kernel only) = (candidates its direction screens removed) << 16 | candidates they were given
     unsigned long long *dbg;  // diagnostic builds only (DPMM_STAMPS): per-wave phase cycle sums
     int queue_rounds;         // D <= 64 kernel: rounds of tiles handed out through the queue at the end of the launch (-1: automatic)
     int prio;                 // 1: s_setprio -- low while the wave streams MFMAs, high in its scalar / VALU phases (DPMM_OPT_WAVE_PRIO)

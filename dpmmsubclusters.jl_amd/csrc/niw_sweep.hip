@@ -368,7 +368,7 @@ __device__ __forceinline__ bool bf16_top_excludes(const uint32_t *__restrict__ R
     return __all(out);
 }
 
-// DIRECTION screen (D in 33 .. 64, K <= 64; DPMM_OPT_DIRECTION_SCREEN): every remaining candidate of a tile at once, each along the ONE
+// DIRECTION screen (D in 33 .. 64, K <= 64; DPMM_OPT_DIRECTION_SCREEN): every remaining candidate of a tile (six or more) at once, each along the ONE
 // direction that separates it from the wave's reference cluster k0.  For a unit vector u,  q_k(x) = |R_k (x - mu_k)|^2 >= (u' R_k (x - mu_k))^2;
 // with d = mu_k0 - mu_k, b = |R_k d|, u = R_k d / b and w = R_k' u (launch_niw_direction: one 64-vector and two scalars per ordered pair)
 //     u' R_k (x - mu_k) = w . z0 + b,      z0 = x - mu_k0,
@@ -1142,6 +1142,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
     int nx_tile = -1;
     unsigned nw_tiles = 0, nw_full = 0, nw_scr = 0, nw_tail = 0, nw_br = 0, nw_bb = 0, nw_bt = 0;   // executed-work counters of this wave (wave-uniform); nw_bb / nw_bt: bf16 bottom / top screens
     unsigned nw_sp = 0, nw_cand = 0;          // direction screens run (DIR); candidates behind the 4-row tests (DIR: counted; else = nw_bb, every one gets a bottom screen)
+    unsigned nw_dcand = 0, nw_dexcl = 0;      // DIR: candidates the direction screens were given, and how many of them they removed (the screen's yield)
     const int rounds_all = nwtiles / nwaves;
     int dyn_rounds = A.queue_rounds >= 0 ? A.queue_rounds : (rounds_all < 4 ? 0 : (rounds_all / 8 > 2 ? rounds_all / 8 : 2));
     if (dyn_rounds > rounds_all) dyn_rounds = rounds_all;
@@ -1533,15 +1534,17 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                             f32x4 x3[NG];
 #pragma unroll
                             for (int n = 0; n < NG; ++n) { thrb[n] = pvalid[n] ? bestn[n] - margin : INFINITY; x3[n] = x[n][LB]; }
-                            // three or more candidates left by the 4-row tests: all of them at once, each along its own direction (direction_far); the
+                            // six or more candidates left by the 4-row tests: all of them at once, each along its own direction (direction_far); the
                             // number of candidates is what the library decides on for the NEXT sweep (without the screen it is the number of bottom screens)
                             if constexpr (DIR) {
                                 const int nc = __builtin_popcountll(cand);
                                 nw_cand += (unsigned)nc;                  // (direction first: before the tail pairs -- an upper bound of what they leave)
-                                if (nc >= 3) {
+                                if (nc >= 6) {                            // (below: the candidates' own 16-row screens are cheaper, ~1/6 of this one each)
                                     ++nw_sp;
                                     cand &= ~direction_far<NG>(A.sp_frag + (size_t)k0 * SP_FRAG_WORDS, A.sp_cons + (size_t)k0 * SP_CONS_FLOATS,
                                                               A.mup + (size_t)(3 * k0) * DP, x, thrb, lane, g, K);
+                                    nw_dcand += (unsigned)nc;
+                                    nw_dexcl += (unsigned)(nc - __builtin_popcountll(cand));
                                 }
                                 if ((A.bf16scr & 2)) { DPMM_TAIL_PAIRS() }
                             }
@@ -1804,7 +1807,8 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
         const unsigned nc = DIR ? nw_cand : nw_bb;
         uint32_t word = ((nc < 65535u ? nc : 65535u) << 16) | (nw_tiles < 32767u ? nw_tiles : 32767u);
         if constexpr (DIR) { if ((A.bf16scr & 2)) word = (word & 0xFFFF7FFFu) | 0x8000u; }      // (bit 15: counted in front of the tail pairs, an upper bound)
-        A.need[wave_id] = word;
+        A.need[2 * wave_id] = word;
+        if constexpr (DIR) A.need[2 * wave_id + 1] = ((nw_dexcl < 65535u ? nw_dexcl : 65535u) << 16) | (nw_dcand < 65535u ? nw_dcand : 65535u);
     }
 #ifdef DPMM_STAMPS
     if (lane == 0 && A.dbg) {

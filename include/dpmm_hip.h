@@ -81,12 +81,13 @@ enum {
     DPMM_OPT_SORT_TILE = 19,          /* points per sorting wave of the statistics passes: 512 (default below 4e6 points per shard) or 2048 */
     DPMM_OPT_COMM_TIMEOUT_MS = 22,    /* RCCL transport: the longest a host call may block on the ctx stream behind a collective (default 120 000 ms; 0: for ever).
                                          Past it a watchdog aborts the communicator and the call -- on every surviving rank -- fails with DPMM_ECOMM */
-    DPMM_OPT_DIRECTION_SCREEN = 23,   /* D in 33..64 NIW sweep, K <= 64: a tile that keeps three or more candidate clusters behind the 4-row tests puts ALL of them
+    DPMM_OPT_DIRECTION_SCREEN = 23,   /* D in 33..64 NIW sweep, K <= 64: a tile that keeps six or more candidate clusters behind the 4-row tests puts ALL of them
                                          through one bound each -- along the direction u = R_k (mu_k0 - mu_k) / b that separates cluster k from the wave's reference
                                          cluster k0: q_k(x) >= (w . (x - mu_k0) + b)^2, the K dot products of a point from one bf16 matrix product (16-32 matrix
                                          instructions per tile instead of 8-24 per CLUSTER) -- before the 16-row screens; needs one small kernel per parameter set
                                          (K^2 direction vectors).  It only removes candidates the Float32 evaluation would have excluded: same labels.
-                                         -1 (default): on while the previous sweep's tiles kept 3 or more candidates on average (off again below 1.5);
+                                         -1 (default): on while the previous sweep's tiles kept 8 or more candidates on average (off again below 4, or when it removes
+                                         less than a quarter of what it is given);
                                          0: never; 1: always */
     DPMM_OPT_BF16_SCREENS = 21,       /* 1 (default): D in 33..64 NIW sweep: a bf16 lower bound of the last block row's part of the quadratic form (8 matrix
                                          instructions) in front of every Float32 16-row screen (16), and of the first block row's part (16 + 4) in front of every

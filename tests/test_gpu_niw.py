@@ -659,9 +659,9 @@ def test_direction_screen_does_not_change_labels(pkg, D, sep, K):
 
 
 def test_direction_screen_switches_itself_on_and_off(pkg):
-    """Automatic mode: the tables are built for the sweep AFTER one whose tiles kept three or more candidates on average behind the 4-row
-    tests (overlapping clusters), and no longer once they keep fewer than 1.5 (separated clusters)."""
-    D, n, K = 64, 20000, 10
+    """Automatic mode: the tables are built for the sweep AFTER one whose tiles kept eight or more candidates on average behind the 4-row
+    tests (overlapping clusters), and no longer once they keep fewer than 4 (separated clusters)."""
+    D, n, K = 64, 20000, 14
     Pov = make_problem(D, n, K, seed=7, sep=1.5, sorted_points=True)
     wk = gpu_worker(pkg, Pov, seed=3)
     wk.set_labels(Pov["z"] + 1, 1 + (np.arange(n) & 1))
