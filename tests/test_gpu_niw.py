@@ -688,3 +688,40 @@ def test_direction_screen_switches_itself_on_and_off(pkg):
         counts.append(wk.last_sweep_work()["direction_screens"])
     assert counts[-1] == 0, counts
     wk.close()
+
+
+def test_direction_screen_whole_chain_with_the_device_master(pkg):
+    """The same chain with the direction screen forced on and switched off: 30 steps of the native engine (device master: the tables are
+    built from the images the draw kernels write) on overlapping components of the reference generator (MixtureVar 2) -- labels,
+    sub-labels and cluster counts identical, and the screen did run."""
+    import importlib
+    from dpmmsubclusters_jl_amd import binding
+    host = importlib.import_module("dpmmsubclusters_jl_amd.host")
+    N, D, K = 200000, 64, 12
+    X, y = host.gaussian_mixture_shard(N, D, K, 2.0, 77, 0, N)
+    prior = host.niw_hyperparams(1.0, np.zeros(D), D + 3, np.eye(D))
+    out = {}
+    for mode in (1, 0):
+        wk = pkg.Worker(pkg.PRIOR_NIW, D, N, device=0, seed=5)
+        wk.upload_points(X)
+        wk.set_option(binding.OPT_DIRECTION_SCREEN, mode)
+        s = host.DPMMSampler(wk, prior, 10.0, N, 5, burnout=5)
+        s.start_from_labels(y, 1 + np.random.default_rng(1).integers(0, 2, N), K)
+        ks, snaps = [], []
+        wk.last_sweep_work()
+        for it in range(30):
+            s.group_step(False, False)
+            ks.append(s.K)
+            if it % 10 == 9:
+                snaps.append(wk.get_labels())
+        work = wk.last_sweep_work()
+        out[mode] = (ks, snaps, work)
+        wk.close()
+    assert out[1][0] == out[0][0]
+    for a, b in zip(out[1][1], out[0][1]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    t = out[1][2]["wave_tiles"]
+    print(f"direction screens per wave tile {out[1][2]['direction_screens'] / t:.2f}; bf16 bottom screens {out[0][2]['bf16_bottom_screens'] / t:.2f} -> "
+          f"{out[1][2]['bf16_bottom_screens'] / t:.2f}")
+    assert out[1][2]["direction_screens"] > 0 and out[0][2]["direction_screens"] == 0
+    assert out[1][2]["bf16_bottom_screens"] < out[0][2]["bf16_bottom_screens"]
