@@ -725,3 +725,34 @@ def test_direction_screen_whole_chain_with_the_device_master(pkg):
           f"{out[1][2]['bf16_bottom_screens'] / t:.2f}")
     assert out[1][2]["direction_screens"] > 0 and out[0][2]["direction_screens"] == 0
     assert out[1][2]["bf16_bottom_screens"] < out[0][2]["bf16_bottom_screens"]
+
+
+def test_direction_screen_growth_chain_is_the_same_chain(pkg):
+    """From ONE cluster on overlapping components (MixtureVar 4): splits and merges change K, the screen switches itself on and off in between
+    (automatic mode: candidate counts, yield, measuring sweeps) -- the chain must be the one with the screen off: same K history, same labels."""
+    import importlib
+    from dpmmsubclusters_jl_amd import binding
+    host = importlib.import_module("dpmmsubclusters_jl_amd.host")
+    N, D, K = 300000, 64, 16
+    X, y = host.gaussian_mixture_shard(N, D, K, 4.0, 99, 0, N)
+    prior = host.niw_hyperparams(1.0, np.zeros(D), D + 3, np.eye(D))
+    out = {}
+    for mode in (-1, 0):
+        wk = pkg.Worker(pkg.PRIOR_NIW, D, N, device=0, seed=11)
+        wk.upload_points(X)
+        wk.set_option(binding.OPT_DIRECTION_SCREEN, mode)
+        s = host.DPMMSampler(wk, prior, 10.0, N, 11, burnout=8)
+        s.init_first_clusters(1)
+        ks, ran = [], 0.0
+        wk.last_sweep_work()
+        for it in range(120):
+            s.group_step(False, False)
+            ks.append(s.K)
+            if it % 20 == 19:
+                ran += wk.last_sweep_work()["direction_screens"]
+        out[mode] = (ks, wk.get_labels(), ran)
+        wk.close()
+    print("K history (every 10th):", out[-1][0][::10], "; direction screens run in automatic mode:", out[-1][2] > 0)
+    assert out[-1][0] == out[0][0]
+    assert np.array_equal(out[-1][1][0], out[0][1][0]) and np.array_equal(out[-1][1][1], out[0][1][1])
+    assert out[0][2] == 0
