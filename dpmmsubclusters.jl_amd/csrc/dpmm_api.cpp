@@ -1077,7 +1077,7 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
             a.ball = c->opt_ball;
             a.bracket = c->opt_bracket;
             a.bf16scr = (c->opt_bf16scr && c->NB == 4 && a.tail != nullptr) ? 1 : 0;
-            if (c->sp_ready && a.bf16scr && !table && !final_argmax) { c->sp_last = true;      // (the conditions of launch_direct's DIR instantiation: K <= 64 fits the LDS table) a.sp_frag = c->d_sp_frag; a.sp_cons = c->d_sp_cons; if (c->opt_direction > 0 || c->sp_count % 32u != 1u) a.bf16scr |= 2; }
+            if (c->sp_ready && a.bf16scr && !table && !final_argmax) { c->sp_last = true; /* (the conditions of launch_direct's DIR instantiation: K <= 64 fits the LDS table) */ a.sp_frag = c->d_sp_frag; a.sp_cons = c->d_sp_cons; if (c->opt_direction > 0 || c->sp_count % 32u != 1u) a.bf16scr |= 2; }
             a.need = (table || c->opt_direction == 0) ? nullptr : c->h_need;
             a.order = (!table && c->have_perm && !no_order) ? c->sb.perm : nullptr;
             a.order_total = c->sb.perm_total;
