@@ -83,6 +83,7 @@ ABI = [
     ("dpmm_step_stats", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]),
     ("dpmm_debug_subloglik", ctypes.c_int, [ctypes.c_void_p, _c_f32p]),
     ("dpmm_debug_ref_bracket", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, _c_f32p, _c_f32p]),
+    ("dpmm_debug_bracket_big", ctypes.c_int, [ctypes.c_void_p, _c_f32p, ctypes.POINTER(ctypes.c_uint32)]),
     ("dpmm_last_sweep_work", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]),
     ("dpmm_comm_use_library", ctypes.c_int, [ctypes.c_char_p]),
     ("dpmm_comm_unique_id", ctypes.c_int, [ctypes.c_void_p]),
@@ -604,6 +605,12 @@ class Worker:
         qhi = np.empty(self.n, np.float32); q = np.empty(self.n, np.float32)
         self._chk(self._lib.dpmm_debug_ref_bracket(self._h, int(cluster), ctypes.c_float(c_override), _p(qhi, _c_f32p), _p(q, _c_f32p)))
         return qhi, q
+
+    def debug_bracket_big(self):
+        """(aref (n,), tile_flags (ceil(n / 128),)): what the D > 64 sweep reads from the bracket launch in front of it; include/dpmm_hip_debug.h."""
+        aref = np.empty(self.n, np.float32); fl = np.empty((self.n + 127) // 128, np.uint32)
+        self._chk(self._lib.dpmm_debug_bracket_big(self._h, _p(aref, _c_f32p), fl.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))))
+        return aref, fl
 
     def debug_loglik(self):
         out = np.empty((self.K, self.n), np.float32)

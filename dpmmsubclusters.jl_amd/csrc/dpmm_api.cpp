@@ -205,6 +205,10 @@ struct dpmm_ctx {
     // direction screen of the D in 33..64 sweep (direction_far, niw_sweep.hip; DPMM_OPT_DIRECTION_SCREEN): tables per parameter set, built only while
     // the sweeps report tiles with many candidates (h_need: one word per wave of the last sweep, written by the kernel into pinned memory)
     uint32_t *d_sp_frag = nullptr;
+    uint32_t *d_refb_big = nullptr;    // D = 128, 256: bf16 images of the cluster-level factors (reference bracket of the LDS-staged kernels), per parameter set
+    bool have_refb_big = false;
+    uint32_t *d_brk_flag = nullptr;    // [tiles of 128 points] 1 + k0 where the tile is label-homogeneous, else 0 (niw_bracket_big_kernel)
+    float *d_brk_aref = nullptr;       // [positions of the visiting order] the bracket's lower end of a_k0
     float *d_sp_cons = nullptr;
     uint32_t *h_need = nullptr;
     int opt_direction = -1;             // -1: by the previous sweep's candidate counts, 0: never, 1: always
@@ -431,8 +435,8 @@ static void free_params(dpmm_ctx *c) {
     hipFree(c->d_raw); hipFree(c->d_mu); hipFree(c->d_Rp); hipFree(c->d_mup); hipFree(c->d_cst);
     hipFree(c->d_ccache); c->d_ccache = nullptr;
     hipFree(c->d_red); c->d_red = nullptr;
-    hipFree(c->d_scratch); hipFree(c->d_slabs); hipFree(c->d_out); hipFree(c->d_Lp16); hipFree(c->d_tdf); hipFree(c->d_lam); hipFree(c->d_mdist); hipFree(c->d_tail);
-    c->d_Lp16 = nullptr; c->d_tdf = nullptr; c->d_lam = nullptr; c->d_mdist = nullptr; c->d_tail = nullptr;
+    hipFree(c->d_scratch); hipFree(c->d_slabs); hipFree(c->d_out); hipFree(c->d_Lp16); hipFree(c->d_tdf); hipFree(c->d_lam); hipFree(c->d_mdist); hipFree(c->d_tail); hipFree(c->d_refb_big);
+    c->d_Lp16 = nullptr; c->d_tdf = nullptr; c->d_lam = nullptr; c->d_mdist = nullptr; c->d_tail = nullptr; c->d_refb_big = nullptr; c->have_refb_big = false;
     c->d_raw = c->d_mu = c->d_Rp = c->d_mup = c->d_cst = c->d_scratch = nullptr;
     c->d_slabs = c->d_out = nullptr;
 }
@@ -453,6 +457,7 @@ static int ensure_capacity(dpmm_ctx *c, int K) {
         HIPCHK(c, hipMalloc(&c->d_Rp, sizeof(float) * 3 * cap * NP * 256));
         HIPCHK(c, hipMalloc(&c->d_mup, sizeof(float) * 3 * cap * 16 * c->NB));
         HIPCHK(c, hipMalloc(&c->d_lam, sizeof(float) * cap));
+        if (c->NB == 8 || c->NB == 16) HIPCHK(c, hipMalloc(&c->d_refb_big, sizeof(uint32_t) * cap * niw_refb_big_words(c->NB)));
         HIPCHK(c, hipMalloc(&c->d_tail, sizeof(float) * (16 * (cap + 2) + 16 * cap + (size_t)REFB_WORDS * cap)));      // pair records | per-cluster ball records | bf16 images of the reference bracket
         HIPCHK(c, hipMalloc(&c->d_mdist, sizeof(float) * (size_t)cap * cap));
     } else {
@@ -612,7 +617,7 @@ int dpmm_destroy(dpmm_ctx *c) {
     if (c->h_draw) hipHostFree(c->h_draw);
     hipFree(c->d_malpha); hipFree(c->d_mpairs);
     if (c->h_marg) hipHostFree(c->h_marg);
-    hipFree(c->d_sp_frag); hipFree(c->d_sp_cons);
+    hipFree(c->d_sp_frag); hipFree(c->d_sp_cons); hipFree(c->d_brk_flag); hipFree(c->d_brk_aref);
     if (c->h_need) hipHostFree(c->h_need);
     hipFree(c->d_counts64); hipFree(c->d_cside); hipFree(c->d_row_off); hipFree(c->d_inv_off); hipFree(c->d_work); hipFree(c->d_par);
     comm_release(c);
@@ -925,6 +930,11 @@ int dpmm_commit_params(dpmm_ctx *c, int K) {
 // after a change of K keep the usual order and count.
 static int direction_tables(dpmm_ctx *c, int K) {
     c->sp_ready = false;
+    c->have_refb_big = false;
+    if (c->prior == DPMM_PRIOR_NIW && (c->NB == 8 || c->NB == 16) && c->d_refb_big && c->opt_bracket && c->have_tail && K > 2) {
+        HIPCHK(c, launch_niw_refb_big(c->d_Rp, c->NB, K, c->d_refb_big, c->stream));      // D = 128, 256: the reference bracket's images
+        c->have_refb_big = true;
+    }
     if (c->prior != DPMM_PRIOR_NIW || c->NB != 4 || !c->d_sp_frag || K < 3 || K > SP_MAXK || !c->have_tail || !c->opt_bf16scr || c->opt_margin <= 0.f) return DPMM_OK;
     bool want = c->opt_direction > 0;
     if (c->opt_direction < 0) {
@@ -1079,6 +1089,17 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
             a.bf16scr = (c->opt_bf16scr && c->NB == 4 && a.tail != nullptr) ? 1 : 0;
             if (c->sp_ready && a.bf16scr && !table && !final_argmax) { c->sp_last = true; /* (the conditions of launch_direct's DIR instantiation: K <= 64 fits the LDS table) */ a.sp_frag = c->d_sp_frag; a.sp_cons = c->d_sp_cons; if (c->opt_direction > 0 || c->sp_count % 32u != 1u) a.bf16scr |= 2; }
             a.need = (table || c->opt_direction == 0) ? nullptr : c->h_need;
+            if (c->have_refb_big && a.tail != nullptr && !table && a.bracket && a.use_prev && a.screen_margin > 0.f && !final_argmax) {
+                // D = 128, 256: the reference bracket as a launch of its own in front of the sweep (niw_bracket_big_kernel): per tile whether all
+                // its points were in one cluster, per point the lower end of a certified bracket of that cluster's value
+                if (!c->d_brk_flag) {
+                    const size_t nt = (size_t)((c->n + 127) / 128);
+                    HIPCHK(c, hipMalloc(&c->d_brk_flag, sizeof(uint32_t) * std::max<size_t>(nt, 1)));
+                    HIPCHK(c, hipMalloc(&c->d_brk_aref, sizeof(float) * std::max<size_t>(nt * 128, 1)));
+                }
+                HIPCHK(c, launch_niw_bracket_big(c->NB, a, c->d_refb_big, c->d_brk_flag, c->d_brk_aref, c->stream));
+                a.sp_frag = c->d_brk_flag; a.sp_cons = c->d_brk_aref;
+            }
             a.order = (!table && c->have_perm && !no_order) ? c->sb.perm : nullptr;
             a.order_total = c->sb.perm_total;
             a.work = table ? nullptr : c->d_work;
@@ -2406,7 +2427,7 @@ int dpmm_last_sweep_work(dpmm_ctx *c, uint64_t *out16) {
         mf_scr = 4 * NG;                                       // the 16-row screen: one block, 4 k-steps, NG point groups
     }
     out16[4] = (uint64_t)mf_full; out16[5] = (uint64_t)mf_scr; out16[6] = 2048; out16[7] = (uint64_t)launches;
-    out16[9] = 48; out16[10] = 16384;
+    out16[9] = c->NB == 16 ? 288 : (c->NB == 8 ? 80 : 48); out16[10] = 16384;      // bf16 matrix instructions of a reference bracket per wave tile
     out16[12] = 8; out16[14] = 16;                           // bf16 matrix instructions of a bottom / top screen (+ 4 Float32 row sums per top screen)                          // a reference bracket: 6 fragments x 2 passes x 4 point groups of v_mfma_f32_16x16x32_bf16 (2 * 16 * 16 * 32 flops each)
     return DPMM_OK;
 }
@@ -2603,6 +2624,30 @@ int dpmm_debug_ref_bracket(dpmm_ctx *c, int64_t cluster, float c_override, float
     if (e == hipSuccess) e = sync_stream(c, c->stream);
     hipFree(d);
     if (e != hipSuccess) { c->err = std::string("dpmm_debug_ref_bracket: ") + hipGetErrorString(e); return DPMM_EHIP; }
+    return DPMM_OK;
+}
+
+int dpmm_debug_bracket_big(dpmm_ctx *c, float *aref, uint32_t *tile_flags) {
+    if (!c || !aref || !tile_flags) return DPMM_EINVAL;
+    if (c->prior != DPMM_PRIOR_NIW || (c->NB != 8 && c->NB != 16)) return fail(c, DPMM_ESTATE, "this bracket exists for the NIW prior with D = 65 .. 256 only");
+    if (!c->have_points || !c->have_params || c->predictive || !c->have_refb_big || !c->have_labels)
+        return fail(c, DPMM_ESTATE, "debug_bracket_big needs points, labels and sweep parameters with tail records (D % 4 == 0, K > 2, DPMM_OPT_REF_BRACKET on)");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n == 0) return DPMM_OK;
+    const size_t nt = (size_t)((c->n + 127) / 128);
+    float *d = nullptr; uint32_t *f = nullptr;
+    HIPCHK(c, hipMalloc(&d, sizeof(float) * nt * 128));
+    if (hipMalloc(&f, sizeof(uint32_t) * nt) != hipSuccess) { hipFree(d); return fail(c, DPMM_EHIP, "hipMalloc"); }
+    NiwSweepArgs a{};
+    a.X = c->dX; a.ldx = c->ldx; a.n = c->n; a.K = c->K; a.mup = c->d_mup; a.cst = c->d_cst; a.bins = c->dbins;
+    a.order = (c->have_perm && c->opt_ordered) ? c->sb.perm : nullptr; a.order_total = c->sb.perm_total;
+    hipError_t e = hipMemsetAsync(d, 0, sizeof(float) * nt * 128, c->stream);
+    if (e == hipSuccess) e = launch_niw_bracket_big(c->NB, a, c->d_refb_big, f, d, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(aref, d, sizeof(float) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(tile_flags, f, sizeof(uint32_t) * nt, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = sync_stream(c, c->stream);
+    hipFree(d); hipFree(f);
+    if (e != hipSuccess) { c->err = std::string("dpmm_debug_bracket_big: ") + hipGetErrorString(e); return DPMM_EHIP; }
     return DPMM_OK;
 }
 

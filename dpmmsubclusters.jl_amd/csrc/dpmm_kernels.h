@@ -50,8 +50,10 @@ struct NiwSweepArgs {
     int screen_lds;           // set by the launcher: screen operands of all K clusters are staged in LDS
     int use_prev;             // bins hold labels from a previous sweep (reference clusters of the screen)
     int lds_rows;             // set by the launcher: rows of the a_k table that live in LDS (0: global scratch)
-    const uint32_t *sp_frag;  // direction screen (D in 33..64, K <= 64; null: none): [K][4][2][64][4] bf16 fragments of the pair directions w, k0 major (launch_niw_direction)
-    const float *sp_cons;     // [K][3][64]: per reference cluster k0 the constants {b, e, cst} of every cluster (direction_far, niw_sweep.hip)
+    const uint32_t *sp_frag;  // direction screen (D in 33..64, K <= 64; null: none): [K][4][2][64][4] bf16 fragments of the pair directions w, k0 major (launch_niw_direction);
+                              // D = 128, 256: one word per 128-point tile, 1 + k0 where launch_niw_bracket_big bracketed the tile's reference cluster, else 0 (null: none)
+    const float *sp_cons;     // [K][3][64]: per reference cluster k0 the constants {b, e, cst} of every cluster (direction_far, niw_sweep.hip);
+                              // D = 128, 256: per position of the visiting order the bracket's lower end of a_k0 (launch_niw_bracket_big)
     uint32_t *need;           // [waves][2] (pinned host memory, may be null): [0] = (candidates this wave's tiles kept behind the 4-row tests, saturating) << 16 | tiles
                               // (15 bits), bit 15: counted in FRONT of the tail-pair tests (direction screen first): an upper bound;
                               // [1] (written by the DIR kernel only) = (candidates its direction screens removed) << 16 | candidates they were given
@@ -74,6 +76,12 @@ hipError_t launch_niw_pack(const float *R, const float *mu, float *Rp, float *mu
 // Tables of the direction screen from the sweep's own images (Rp, mup, cst of the K cluster-level distributions; D in 33..64, K <= SP_MAXK):
 // frag [K][SP_FRAG_WORDS], cons [K][SP_CONS_FLOATS]
 constexpr int SP_MAXK = 64, SP_FRAG_WORDS = 4 * 2 * 256, SP_CONS_FLOATS = 3 * 64;
+// bf16 images of the K cluster-level factors for the reference bracket of the LDS-staged kernels (NB = 8, 16), from the Float32 fragment
+// image: out [K][niw_refb_big_words(NB)]  (passed to the sweep as NiwSweepArgs::sp_frag)
+inline size_t niw_refb_big_words(int NB) { size_t c = 0; for (int bi = 0; bi < NB; ++bi) c += NB / 2 - bi / 2; return c * 256; }
+hipError_t launch_niw_refb_big(const float *Rp, int NB, int K, uint32_t *out, hipStream_t s);
+// the bracket itself, in front of the sweep launch (same NiwSweepArgs: X, order, bins, mup, cst): tile_flag [ceil(n / 128)], aref [128 ceil(n / 128)]
+hipError_t launch_niw_bracket_big(int NB, const NiwSweepArgs &a, const uint32_t *refb, uint32_t *tile_flag, float *aref, hipStream_t s);
 hipError_t launch_niw_direction(const float *Rp, const float *mup, const float *cst, int D, int K, uint32_t *frag, float *cons, hipStream_t s);
 
 struct MultSweepArgs {

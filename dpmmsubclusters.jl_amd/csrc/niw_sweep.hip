@@ -435,6 +435,143 @@ __device__ __forceinline__ unsigned long long direction_far(const uint32_t *__re
     return K >= 64 ? far : far & ((1ull << K) - 1ull);
 }
 
+// Reference bracket of the LDS-staged kernels (D = 128, 256: NB = 8, 16): the same certified bound as ref_bracket -- q <= sum_r (|y^_r| + c e^_r)^2
+// from two bf16 matrix passes, y^ = R~ z~, e^ = |R~||z~| -- over the bf16 image of the cluster-level factor: fragments (block row bi, 32-feature
+// slice sl >= bi / 2) in that order, each [64 lanes][4 dwords] with the k-slots of refb_map (launch_niw_refb_big converts the Float32
+// fragment image; NB = 16: 72 fragments = 72 KiB per cluster against the 136 KiB of the Float32 image).  Every wave streams the fragments
+// itself from L2 (no staging, no barrier: 4 x 72 KiB per 128-point tile) one block row ahead of the matrix instructions: 2 x 72 x NG
+// instructions of 16 cycles against the evaluation's 136 x 4 x NG of 32.  c: the bracket's constant with the accumulation term of up to
+// 256 products per row.
+constexpr float REFB_C_BIG = 0.00790f;       // 2^-7 (1 + 2^-8) + 3 * 256 * 2^-24 = 0.0078736
+template <int NB>
+__host__ __device__ constexpr int refb_big_frags() { int c = 0; for (int bi = 0; bi < NB; ++bi) c += NB / 2 - bi / 2; return c; }
+// The bracket of the LDS-staged kernels as a launch of its own, one workgroup per 128-point tile of the sweep (same tiles, same visiting
+// order): k0 = the previous label of the tile's first point; if EVERY point of the tile had label k0, the bracket's lower end of a_k0 for
+// every point -> aref[position], tile_flag[tile] = 1 + k0; else tile_flag[tile] = 0 (the sweep evaluates its references as before).
+// Inside the sweep kernel the same arithmetic cost more than it saved at D = 256 (178 spilled registers).  Here a wave converts its 32
+// points to the bf16 operands z~ (all the registers it keeps: x itself is dropped) and the workgroup shares the fragments through LDS --
+// chunks of CHF fragments, two buffers, the next chunk requested before this one's matrix instructions -- so a tile reads its 72 KiB image
+// once (every wave streaming it for itself: 1.4 GB from L2 per launch at the C5 shard, 0.35 ms).  It reads X a second time (0.64 GB).
+template <int NB, int NG>
+__global__ __launch_bounds__(256) void niw_bracket_big_kernel(const float *__restrict__ X, int64_t ldx, int64_t n, const int32_t *__restrict__ order,
+                                                              const int32_t *__restrict__ order_total, const int32_t *__restrict__ bins, int K,
+                                                              const float *__restrict__ mup, const float *__restrict__ cst,
+                                                              const uint32_t *__restrict__ refb, uint32_t *__restrict__ tile_flag, float *__restrict__ aref) {
+    constexpr int WPTS = 16 * NG, TILE = 4 * WPTS, DP = 16 * NB, NSL = NB / 2, NF = refb_big_frags<NB>();
+    constexpr int CHF = 4;                                   // fragments per chunk: 4 KiB = one 16-byte vector per thread
+    static_assert(NF % CHF == 0, "whole chunks");
+    __shared__ __attribute__((aligned(16))) uint32_t fbuf[2][CHF * 256];
+    __shared__ int sh_first[4], sh_bad[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ci = lane & 15, g = lane >> 4;
+    const int64_t tile = blockIdx.x;
+    const bool use_order = order != nullptr && *order_total == (int32_t)n;
+    const int64_t wbase = tile * TILE + (int64_t)wave * WPTS, mypos = wbase + lane;
+    const bool valid = lane < WPTS && mypos < n;
+    const int64_t myp = (valid && use_order) ? (int64_t)order[mypos] : mypos;
+    int prev = valid ? (bins[myp] >> 1) : -1;
+    if ((unsigned)prev >= (unsigned)K) prev = -1;
+    {
+        const unsigned long long pm = __ballot(prev >= 0);
+        const int kf = pm ? __shfl(prev, __ffsll((long long)pm) - 1) : -1;
+        if (lane == 0) sh_first[wave] = kf;
+    }
+    __syncthreads();
+    int k0 = 0;
+    for (int wv = 3; wv >= 0; --wv) if (sh_first[wv] >= 0) k0 = sh_first[wv];
+    {
+        const bool bad = __ballot(valid && prev != k0) != 0ull;
+        if (lane == 0) sh_bad[wave] = bad ? 1 : 0;
+    }
+    __syncthreads();
+    const bool homog = (sh_bad[0] | sh_bad[1] | sh_bad[2] | sh_bad[3]) == 0 && (sh_first[0] >= 0 || sh_first[1] >= 0 || sh_first[2] >= 0 || sh_first[3] >= 0);
+    if (tid == 0) tile_flag[tile] = homog ? (uint32_t)(k0 + 1) : 0u;
+    if (!homog) return;                                      // (workgroup-uniform)
+    // the image of k0: chunk c = fragments CHF c .. CHF c + CHF - 1, thread tid moves vector tid of the chunk's 256
+    const u32x4_t *img = reinterpret_cast<const u32x4_t *>(refb + (size_t)k0 * (NF * 256));
+    constexpr int NCHK = NF / CHF, AHEAD = 4;                // chunks requested ahead of the one being multiplied (registers: one vector each)
+    u32x4_t st[AHEAD];
+#pragma unroll
+    for (int q = 0; q < AHEAD; ++q) st[q] = img[(size_t)(q < NCHK ? q : NCHK - 1) * 256 + tid];      // chunks 0 .. AHEAD - 1, under the gather of x
+    // z~ = bf16(x - mu_k0) of this wave's points, slice by slice (x is not kept)
+    const float *mu0 = mup + (size_t)(3 * k0) * DP;
+    u32x4_t zb[NG][NSL];
+    {
+        int64_t prow[NG];
+        bool pok[NG];
+#pragma unroll
+        for (int nn = 0; nn < NG; ++nn) {
+            const int64_t pos = wbase + 16 * nn + ci;
+            pok[nn] = pos < n;
+            prow[nn] = (pok[nn] && use_order) ? (int64_t)order[pos] : pos;
+        }
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl) {
+            const int e0 = 32 * sl + 4 * g, e1 = e0 + 16;
+            const f32x4 m0 = *reinterpret_cast<const f32x4 *>(mu0 + e0), m1 = *reinterpret_cast<const f32x4 *>(mu0 + e1);
+#pragma unroll
+            for (int nn = 0; nn < NG; ++nn) {
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 x0 = (pok[nn] && e0 < ldx) ? *reinterpret_cast<const f32x4 *>(X + prow[nn] * ldx + e0) : zero;
+                const f32x4 x1 = (pok[nn] && e1 < ldx) ? *reinterpret_cast<const f32x4 *>(X + prow[nn] * ldx + e1) : zero;
+                const f32x4 lo = x0 - m0, hi = x1 - m1;
+                zb[nn][sl] = (u32x4_t){pack_bf16_pair(lo.x, lo.y), pack_bf16_pair(lo.z, lo.w), pack_bf16_pair(hi.x, hi.y), pack_bf16_pair(hi.z, hi.w)};
+            }
+        }
+    }
+    const u32x4_t absm = (u32x4_t){0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu};
+    float part[NG];
+    f32x4 y[NG], e[NG];
+#pragma unroll
+    for (int nn = 0; nn < NG; ++nn) { part[nn] = 0.f; y[nn] = (f32x4){0.f, 0.f, 0.f, 0.f}; e[nn] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    reinterpret_cast<u32x4_t *>(fbuf[0])[tid] = st[0];
+    if (AHEAD < NCHK) st[0] = img[(size_t)AHEAD * 256 + tid];
+    __syncthreads();
+    // fragment f = (block row bi, slice sl >= bi / 2): everything below is unrolled, (bi, sl) are constants per fragment
+    int fbase = 0, f = 0;
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi) {
+        const int s0 = bi / 2, cnt = NSL - s0;
+#pragma unroll
+        for (int i = 0; i < NSL; ++i) {
+            if (i < cnt) {
+                const int c = f / CHF, j = f % CHF;
+                const u32x4_t a = reinterpret_cast<const u32x4_t *>(fbuf[c & 1])[j * 64 + lane], aa = a & absm;
+#pragma unroll
+                for (int nn = 0; nn < NG; ++nn) {
+                    y[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, zb[nn][s0 + i]), y[nn], 0, 0, 0);
+                    e[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aa), __builtin_bit_cast(bf16x8_t, zb[nn][s0 + i] & absm), e[nn], 0, 0, 0);
+                }
+                if (j == CHF - 1 && c + 1 < NCHK) {           // end of the chunk: the next one goes to the other buffer (last read a chunk ago) ...
+                    reinterpret_cast<u32x4_t *>(fbuf[(c + 1) & 1])[tid] = st[(c + 1) % AHEAD];
+                    if (c + 1 + AHEAD < NCHK) st[(c + 1) % AHEAD] = img[(size_t)(c + 1 + AHEAD) * 256 + tid];      // ... and its register takes chunk c + 1 + AHEAD
+                    __syncthreads();
+                }
+                ++f;
+            }
+        }
+#pragma unroll
+        for (int nn = 0; nn < NG; ++nn) {                                       // the block row's 16 rows are complete
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float t = __builtin_fmaf(REFB_C_BIG, e[nn][r], fabsf(y[nn][r]));
+                part[nn] = __builtin_fmaf(t, t, part[nn]);
+            }
+            y[nn] = (f32x4){0.f, 0.f, 0.f, 0.f}; e[nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        fbase += cnt;
+    }
+    (void)fbase;
+    float sel = 0.f;
+#pragma unroll
+    for (int nn = 0; nn < NG; ++nn) {                                           // sum over the four row groups of a column
+        float v = part[nn];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (g == nn) sel = __builtin_fmaf(v, 1.0001f, 1e-20f);                 // owner lane 16 n + ci: point (n, ci)
+    }
+    if (valid) aref[mypos] = __builtin_fmaf(-0.5f, sel, cst[3 * k0]);
+}
+
 template <int NB, int NG, int CH>
 struct QuadEval {
     using C = NiwCfg<NB, NG, CH>;
@@ -591,7 +728,7 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
     const bool owner = lane < C::WPTS;  // lane `lane` draws for point `lane` of the wave
 
     QuadEval<NB, NG, CH> ev;
-    unsigned nw_tiles = 0, nw_full = 0, nw_tail = 0, nw_scr = 0;   // executed-work counters of this wave (wave-uniform)
+    unsigned nw_tiles = 0, nw_full = 0, nw_tail = 0, nw_scr = 0, nw_br = 0;   // executed-work counters of this wave (wave-uniform)
 
     // Tiles are handed out through a queue (A.work[4], cleared with the work counters): the cost of a tile varies with the number of
     // clusters its points cannot exclude (1 to > 10 full evaluations at D = 256), and with a static "tile = workgroup + i * grid"
@@ -674,6 +811,7 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
         };
         const bool screening = A.tail != nullptr && A.screen_margin > 0.f && !A.tdf && !A.scratch_by_tile && K > 2;
         int k0 = 0, k1 = 0;
+        bool ref_skipped_tile = false;          // bracketed reference and no survivor (workgroup-uniform): k0's value was never computed
 #ifdef DPMM_STAMPS
         unsigned long long sv0 = s1;
 #endif
@@ -706,10 +844,25 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
             for (int wv = 0; wv < 4; ++wv) if (sh_last[wv] >= 0) k1 = sh_last[wv];
             const int nref = k1 != k0 ? 2 : 1;
             float aref = -INFINITY;
+            // Reference bracket (niw_bracket_big_kernel, a launch of its own in front of this one): every point of the WORKGROUP was in k0 -> aref =
+            // the lower end of a certified bracket of a_k0, nothing is recorded; k0's Float32 evaluation follows behind the screens only if some
+            // cluster survives them for some wave (else the draw returns k0 whatever the exact value is: the one-cluster draw below).
+            bool bracketed = false, ref_skipped = false;
+            if constexpr (NB >= 8) {
+                // (launch_niw_bracket_big ran in front of this launch: A.sp_frag = one word per tile -- 1 + k0 where every point of the tile
+                // was in k0, else 0 --, A.sp_cons = the bracket's lower end of a_k0 per position of the visiting order)
+                if (A.sp_frag != nullptr && nref == 1 && A.sp_frag[tile] == (uint32_t)(k0 + 1)) {
+                    bracketed = true;
+                    aref = valid ? A.sp_cons[mypos] : -INFINITY;
+                    ++nw_br;
+                }
+            }
+            if (!bracketed) {
             ev.template prefetch<0>(A.Rp + (size_t)(3 * k0) * C::MATSZ);
             for (int rr = 0; rr < nref; ++rr) {       // one call site: the unrolled evaluation exists once for both references
                 const float a = eval_cluster(rr ? k1 : k0, (rr + 1 < nref) ? A.Rp + (size_t)(3 * k1) * C::MATSZ : nullptr);
                 if (a > aref) aref = a;                // a NaN never raises the reference
+            }
             }
             STAMP(s2);
             const float my_thr = valid ? aref - A.screen_margin : INFINITY;
@@ -802,13 +955,22 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
                 bits &= bits - 1u;
                 return (w << 5) + b;
             };
-            int kc = next_surv();
+            int kc = next_surv(), kpend = -1;
+            if (bracketed) {
+                if (kc >= 0) { kpend = kc; kc = k0; }      // somebody survived: the exact value of k0 (table entry of the draw) first, through the same call site
+                else {
+                    ref_skipped = true;
+                    m_run = 0.f; best = k0;          // (a finite stand-in: the one-cluster draw never reads the table)
+                }
+            }
             if (kc >= 0) ev.template prefetch<0>(A.Rp + (size_t)(3 * kc) * C::MATSZ);
             while (kc >= 0) {
-                const int kn = next_surv();
+                int kn;
+                if (kpend >= 0) { kn = kpend; kpend = -1; } else kn = next_surv();
                 eval_cluster(kc, kn >= 0 ? A.Rp + (size_t)(3 * kn) * C::MATSZ : nullptr);
                 kc = kn;
             }
+            ref_skipped_tile = ref_skipped;
         }
 
         // ---- label draw (owner lanes), src/utils.jl:19-31
@@ -820,6 +982,9 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
             u_sub = u01(r.v[1]);
             if (A.final_argmax) {
                 z = best;
+            } else if (ref_skipped_tile) {
+                // one evaluated cluster, k0: s = exp_det(0) = 1, t = u, the scan stops at k0 -- or at index 0 when t <= 0, as the full scan does
+                z = (u01(r.v[0]) * 1.0f <= 0.f) ? 0 : k0;
             } else if (m_run == -INFINITY) {
                 z = 0;
             } else if (screening) {
@@ -949,7 +1114,7 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
     // per launch whatever N, 20 % of the launch at the 8-GPU shard size.)
     if (A.work && lane == 0) {
         unsigned long long *slot = A.work + DPMM_WORK_SLOTS + ((size_t)blockIdx.x * 4 + wave) * DPMM_WORK_PER_WAVE;      // (accumulates over launches; cleared by the reader)
-        slot[0] += nw_tiles; slot[1] += nw_full; slot[2] += nw_scr; slot[3] += nw_tail;
+        slot[0] += nw_tiles; slot[1] += nw_full; slot[2] += nw_scr; slot[3] += nw_tail; slot[4] += nw_br;
     }
 #ifdef DPMM_STAMPS
     if (A.dbg && lane == 0 && blockIdx.x < 4096) {
@@ -2072,6 +2237,46 @@ __global__ __launch_bounds__(256) void niw_screen_prep_kernel(const float *__res
 hipError_t launch_niw_screen_prep(const float *R, const float *mu, int D, int K, float *lam, float *dist, const int32_t *slot, hipStream_t s) {
     const size_t lds = sizeof(float) * ((size_t)D * D + (size_t)D * (D + 1) + 256);
     DPMM_LAUNCH(niw_screen_prep_kernel, dim3(K), dim3(256), lds, s, R, mu, D, K, lam, dist, slot);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// bf16 image of the cluster-level factors for ref_bracket_big (NB = 8, 16), from the Float32 fragment image both pack kernels write:
+// fragment (bi, sl), lane (i, g), dword d = k-slots 2 d, 2 d + 1 = features 32 sl + 4 g + 2 d (+1) for d < 2 -- block (bi, t = 2 sl) of the
+// Float32 image, same lane, elements 2 d, 2 d + 1 -- and 32 sl + 16 + 4 g + 2 (d - 2) (+1) for d >= 2 -- block (bi, 2 sl + 1), elements
+// 2 d - 4, 2 d - 3; a block left of the diagonal (t < bi) is not stored: zero.
+__global__ void niw_refb_big_kernel(const float *__restrict__ Rp, int NB, int K, uint32_t *__restrict__ out) {
+    const int NP = NB * (NB + 1) / 2, NSL = NB / 2;
+    int nfr = 0;
+    for (int bi = 0; bi < NB; ++bi) nfr += NSL - bi / 2;
+    const int64_t total = (int64_t)K * nfr * 256;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(e & 3), ln = (int)((e >> 2) & 63);
+        const int64_t fk = e >> 8;
+        const int f = (int)(fk % nfr), k = (int)(fk / nfr);
+        int bi = 0, rem = f;
+        while (rem >= NSL - bi / 2) { rem -= NSL - bi / 2; ++bi; }
+        const int sl = bi / 2 + rem, t = 2 * sl + (d >> 1), j = 2 * (d & 1);
+        float v0 = 0.f, v1 = 0.f;
+        if (t >= bi) {
+            const int pair = bi * NB - bi * (bi - 1) / 2 + (t - bi);            // pair_base(bi) + (t - bi)
+            const float *src = Rp + ((size_t)(3 * k) * NP + pair) * 256 + ln * 4 + j;
+            v0 = src[0]; v1 = src[1];
+        }
+        out[e] = bf16_rne_bits(v0) | (bf16_rne_bits(v1) << 16);
+    }
+}
+hipError_t launch_niw_bracket_big(int NB, const NiwSweepArgs &a, const uint32_t *refb, uint32_t *tile_flag, float *aref, hipStream_t s) {
+    const int ntiles = (int)((a.n + 127) / 128);       // 4 waves x 32 points, as niw_sweep_kernel<8 | 16, 2, .>
+    if (ntiles == 0) return hipSuccess;
+    if (NB == 16) DPMM_LAUNCH((niw_bracket_big_kernel<16, 2>), dim3(ntiles), dim3(256), 0, s, a.X, a.ldx, a.n, a.order, a.order_total, a.bins, a.K, a.mup, a.cst, refb, tile_flag, aref);
+    else if (NB == 8) DPMM_LAUNCH((niw_bracket_big_kernel<8, 2>), dim3(ntiles), dim3(256), 0, s, a.X, a.ldx, a.n, a.order, a.order_total, a.bins, a.K, a.mup, a.cst, refb, tile_flag, aref);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+hipError_t launch_niw_refb_big(const float *Rp, int NB, int K, uint32_t *out, hipStream_t s) {
+    if ((NB != 8 && NB != 16) || K < 1) return hipErrorInvalidValue;
+    DPMM_LAUNCH(niw_refb_big_kernel, dim3(256), dim3(256), 0, s, Rp, NB, K, out);
     return hipGetLastError();
 }
 

@@ -75,7 +75,8 @@ enum {
                                          0.383, nothing at N = 1e7); 0 = every draw kernel generates its own: one stream, no cross-stream dependency;
                                          -1 (default) = 1 for D >= 128 or fewer than 4e6 points on this worker, else 0;
                                          same draws either way */
-    DPMM_OPT_REF_BRACKET = 18,        /* 1 (default): D in 49..64 sweep, waves whose points all had the same label: the reference cluster's value is first BRACKETED
+    DPMM_OPT_REF_BRACKET = 18,        /* 1 (default): D in 49..64 sweep, waves whose points all had the same label (D in 65..256: 128-point tiles, in a launch of its own
+                                         in front of the sweep): the reference cluster's value is first BRACKETED
                                          (two bf16 matrix passes with a certified rounding bound, ~1/7 of a Float32 evaluation) and evaluated in Float32 only
                                          if some other cluster survives the screens against the bracket's lower end; same labels; 0: always evaluated */
     DPMM_OPT_SORT_TILE = 19,          /* points per sorting wave of the statistics passes: 512 (default below 4e6 points per shard) or 2048 */

@@ -34,6 +34,11 @@ int dpmm_debug_niw_draw_inputs(dpmm_ctx *ctx, uint32_t epoch, int K, const int32
  * q_hi[i] >= q[i] for every point; c_override > 0 replaces the library's rounding constant (tests show a too-small one failing).
  * NIW with D in 33..64, D % 4 == 0 and K > 2 only (DPMM_ESTATE otherwise). */
 int dpmm_debug_ref_bracket(dpmm_ctx *ctx, int64_t cluster, float c_override, float *q_hi, float *q);
+/* D = 65 .. 256 (the LDS-staged sweep kernels): the reference bracket runs as a launch of its own in front of the sweep (niw_bracket_big_kernel).
+   This runs it on the current labels and parameters and returns what the sweep would read: tile_flags[ceil(n / 128)] = 1 + k0 (0-based k0)
+   for a 128-point tile of the visiting order whose points all carry label k0 + 1, else 0; aref[n] = per POSITION of the visiting order
+   (storage order before the first statistics pass) the bracket's lower end of a_k0 = cst - q_hi / 2 (tiles with flag 0: 0). */
+int dpmm_debug_bracket_big(dpmm_ctx *ctx, float *aref, uint32_t *tile_flags);
 
 /* Milliseconds spent in the dominant kernels during the last dpmm_sweep /
  * dpmm_suffstats_* call, measured with HIP events on the ctx stream (0 if none yet, or when DPMM_OPT_KERNEL_TIMING is off -- the default).

@@ -418,15 +418,16 @@ def test_work_counters_accumulate_until_read(pkg):
     wk.close()
 
 
-@pytest.mark.parametrize("D,sep,K", [(64, 40.0, 7), (64, 0.6, 7), (52, 40.0, 7), (60, 0.8, 7), (64, 6.0, 7), (64, 40.0, 100), (64, 1.0, 100)])
+@pytest.mark.parametrize("D,sep,K", [(64, 40.0, 7), (64, 0.6, 7), (52, 40.0, 7), (60, 0.8, 7), (64, 6.0, 7), (64, 40.0, 100), (64, 1.0, 100),
+                                     (128, 40.0, 6), (128, 0.8, 5), (100, 40.0, 6), (256, 40.0, 5), (256, 1.0, 4), (200, 3.0, 5)])
 def test_reference_bracket_does_not_change_labels(pkg, D, sep, K):
-    """DPMM_OPT_REF_BRACKET (D in 49 .. 64): on a wave whose points all carried the same label the reference cluster's value is first
+    """DPMM_OPT_REF_BRACKET (D in 49 .. 64; D in 65 .. 256 as a launch of its own per 128-point tile): on a wave whose points all carried the same label the reference cluster's value is first
     bracketed with two bf16 matrix passes and a certified rounding bound; its Float32 evaluation runs only if another cluster survives the
     screens against the bracket's lower end.  Labels and sub-labels must be those of the always-evaluate kernel, bit for bit -- on separated
     clusters (the evaluation is skipped on most waves: fewer full evaluations are counted) and on overlapping ones (survivors: the exact
     value is computed after all), with D below 64 (zero-padded features), and they equal the oracle's draw on the kernel's own table."""
     from dpmmsubclusters_jl_amd import binding
-    n = 30000                                          # (K = 100: beyond the LDS table's rows -- the generic kernel with the compact table)
+    n = 30000 if D <= 64 else 12000                    # (K = 100: beyond the LDS table's rows -- the generic kernel with the compact table)
     P = make_problem(D, n, K, seed=5 + D, sep=sep, sorted_points=True)
     out = {}
     for br in (1, 0):
@@ -756,3 +757,26 @@ def test_direction_screen_growth_chain_is_the_same_chain(pkg):
     assert out[-1][0] == out[0][0]
     assert np.array_equal(out[-1][1][0], out[0][1][0]) and np.array_equal(out[-1][1][1], out[0][1][1])
     assert out[0][2] == 0
+
+
+@pytest.mark.parametrize("kind,D", [("midpoints", 128), ("midpoints", 256), ("trailing", 256), ("outlier", 256), ("outlier", 100)])
+def test_big_bracket_is_a_lower_bound_of_the_reference_value(pkg, kind, D):
+    """D in 65 .. 256: the bracket launch in front of the sweep (niw_bracket_big_kernel) writes, for every point of a label-homogeneous
+    128-point tile, a LOWER bound of a_k0 = cst - q / 2 from two bf16 matrix passes over 72 (D = 256) fragments and a certified rounding
+    constant.  On operands chosen against the bound (every entry of R and x just below a bf16 midpoint and of one sign; points displaced
+    along one trailing feature; far outliers) it must stay below the Float32 value of the kernel's own table for every point."""
+    n = 4096
+    P = _bracket_problem(kind, D, n, seed=3 + D)
+    wk = pkg.Worker(pkg.PRIOR_NIW, D, n, device=0, seed=2)
+    wk.upload_points(P["X"])
+    wk.set_labels(np.ones(n, np.int64), 1 + (np.arange(n) & 1))          # every point in cluster 1: every tile is homogeneous
+    wk.set_params_niw_chol(P["mu"], P["R"], P["logdet"], P["lr"], P["w"])
+    aref, flags = wk.debug_bracket_big()
+    assert np.all(flags == 1)                                            # 1 + k0, k0 = 0
+    tab = wk.debug_loglik()[0].astype(np.float64)                        # a_1 of every point, Float32 evaluation (includes log w)
+    fin = np.isfinite(tab)
+    gap = tab[fin] - aref[fin].astype(np.float64)
+    print(f"{kind} D={D}: bracket width (a - a_lower) min {gap.min():.3g}, median {np.median(gap):.3g}, max {gap.max():.3g}; |a| up to {np.abs(tab[fin]).max():.3g}")
+    assert np.all(gap >= -1e-6 * np.abs(tab[fin])), gap.min()
+    assert np.median(gap / np.maximum(1.0, np.abs(tab[fin]))) < 0.2      # ... and it is a bracket, not a trivial bound
+    wk.close()
