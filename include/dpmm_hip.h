@@ -82,6 +82,11 @@ enum {
     DPMM_OPT_SORT_TILE = 19,          /* points per sorting wave of the statistics passes: 512 (default below 4e6 points per shard) or 2048 */
     DPMM_OPT_COMM_TIMEOUT_MS = 22,    /* RCCL transport: the longest a host call may block on the ctx stream behind a collective (default 120 000 ms; 0: for ever).
                                          Past it a watchdog aborts the communicator and the call -- on every surviving rank -- fails with DPMM_ECOMM */
+    DPMM_OPT_F32_STATS = 24,          /* 0 (default): sufficient statistics in Float64 throughout, as the reference (priors/niw.jl:42-51).  1: NIW, D <= 64, the per-step pass:
+                                         the second moments of x - mu_k (the cluster's current mean) on the Float32 matrix cores, 64 points at a time, the
+                                         64-point sums added -- and the shift undone -- in Float64: the statistics kernel runs at twice its Float64 rate, the
+                                         scatter matrices agree with the Float64 path to ~1e-6 of sqrt(S_aa S_bb) (tests/test_gpu_niw.py); the chain is a
+                                         different, equally valid one.  Subset passes and passes after K changed stay Float64. */
     DPMM_OPT_DIRECTION_SCREEN = 23,   /* D in 33..64 NIW sweep, K <= 64: a tile that keeps six or more candidate clusters behind the 4-row tests puts ALL of them
                                          through one bound each -- along the direction u = R_k (mu_k0 - mu_k) / b that separates cluster k from the wave's reference
                                          cluster k0: q_k(x) >= (w . (x - mu_k0) + b)^2, the K dot products of a point from one bf16 matrix product (16-32 matrix
