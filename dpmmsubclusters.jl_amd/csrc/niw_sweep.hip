@@ -815,10 +815,15 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
 #ifdef DPMM_STAMPS
         unsigned long long sv0 = s1;
 #endif
+        // (ONE cluster, no table asked for: the draw returns index 0 whatever its value -- utils.jl:19-31 over one element -- so the value is not
+        // computed: every fit from init_clusters = 1 spends its first `burnout` sweeps here, two evaluations per tile instead of three)
+        const bool lone = K == 1 && !A.tdf && !A.labels_only && !A.scratch_by_tile;
         if (!screening) {
+            if (!lone) {
             ev.template prefetch<0>(A.Rp);
             for (int k = 0; k < K; ++k)
                 eval_cluster(k, (k + 1 < K) ? A.Rp + (size_t)(3 * (k + 1)) * C::MATSZ : nullptr);
+            }
         } else {
             // Screened label phase, workgroup-wide (the fragment staging is shared by the four waves):
             //  (1) reference clusters k0 / k1 = previous labels of the workgroup's first and last point, evaluated in full (k1 only
@@ -1432,9 +1437,12 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                 if (!nan_seen) best = k;
             }
         };
+        // (ONE cluster, no table asked for: the draw returns index 0 whatever its value -- utils.jl:19-31 over one element -- so the value is not
+        // computed: every fit from init_clusters = 1 spends its first `burnout` sweeps here, two evaluations per tile instead of three)
+        const bool lone = !FAST && K == 1 && !A.tdf && !A.labels_only && !A.scratch_by_tile;
         if (!screening) {
-            load_rb0<NB>(A.Rp, A.mup, rb0, mu, lane, g);
-            for (int k = 0; k < K; ++k) {
+            if (!lone) load_rb0<NB>(A.Rp, A.mup, rb0, mu, lane, g);
+            for (int k = 0; k < (lone ? 0 : K); ++k) {
                 const float *Rcur = A.Rp + (size_t)(3 * k) * MATSZ;
                 const float *Rnext = (k + 1 < K) ? A.Rp + (size_t)(3 * (k + 1)) * MATSZ : nullptr;
                 STAMP(q0);

@@ -27,5 +27,5 @@ def cb(i, s):
 g.run_model(int(sys.argv[3]) if len(sys.argv) > 3 else 160, gt=None, on_iteration=cb)
 print("iter  K   ms(incl. counter read)  direction  bf16-bottom  bf16-top  f32-screens  full-evals  tail-pairs   (per wave tile)")
 for r in rows:
-    if r[0] >= 20:
+    if r[0] >= (int(sys.argv[4]) if len(sys.argv) > 4 else 20):
         print("%4d %3d %8.3f   %6.2f %8.2f %8.2f %8.2f %8.2f %8.2f" % r)
