@@ -896,7 +896,7 @@ int dpmm_commit_params(dpmm_ctx *c, int K) {
         const float *dcst = reinterpret_cast<const float *>(c->d_par);
         hmu = reinterpret_cast<const float *>(c->d_par + (L.mu - L.cst));
         hmat = reinterpret_cast<const float *>(c->d_par + (L.mat - L.cst));
-        c->have_tail = c->opt_tail && c->D >= 4 && c->D % 4 == 0 && K > 2;
+        c->have_tail = c->opt_tail && c->D >= 4 && c->D % 4 == 0 && K > 1;
         HIPCHK(c, launch_niw_pack(hmat, hmu, c->d_Rp, c->d_mup, c->D, c->NB, 3 * K, c->have_tail ? c->d_tail : nullptr, dcst, hslot, c->d_cst,
                                   c->d_work, c->stream));
         c->work_zeroed = true;
@@ -934,7 +934,7 @@ static int direction_tables(dpmm_ctx *c, int K) {
     c->sp_ready = false;
     c->centre_K = c->prior == DPMM_PRIOR_NIW ? K : -1;          // (called behind both pack kernels: d_mup holds the K cluster means now)
     c->have_refb_big = false;
-    if (c->prior == DPMM_PRIOR_NIW && (c->NB == 8 || c->NB == 16) && c->d_refb_big && c->opt_bracket && c->have_tail && K > 2) {
+    if (c->prior == DPMM_PRIOR_NIW && (c->NB == 8 || c->NB == 16) && c->d_refb_big && c->opt_bracket && c->have_tail && K > 1) {
         HIPCHK(c, launch_niw_refb_big(c->d_Rp, c->NB, K, c->d_refb_big, c->stream));      // D = 128, 256: the reference bracket's images
         c->have_refb_big = true;
     }
@@ -1850,7 +1850,7 @@ int dpmm_niw_master_draw(dpmm_ctx *c, uint32_t epoch, int K, const int32_t *slot
     float *hlr = reinterpret_cast<float *>(c->h_draw), *hw = hlr + 2 * K;
     memcpy(hlr, lr, sizeof(float) * 2 * K);
     memcpy(hw, w, sizeof(float) * K);
-    c->have_tail = c->opt_tail && c->D >= 4 && c->D % 4 == 0 && K > 2;
+    c->have_tail = c->opt_tail && c->D >= 4 && c->D % 4 == 0 && K > 1;
     // draws launched ahead by dpmm_step_master_device for this epoch and this cluster -> slot map: only the hand-over is left
     const bool ahead = c->spec_valid && c->spec_epoch == epoch && (int)c->spec_slots.size() == K &&
                        memcmp(c->spec_slots.data(), slot_of_cluster, sizeof(int32_t) * K) == 0;

@@ -809,7 +809,7 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void niw_sweep_kernel(NiwSw
             }
             return a;
         };
-        const bool screening = A.tail != nullptr && A.screen_margin > 0.f && !A.tdf && !A.scratch_by_tile && K > 2;
+        const bool screening = A.tail != nullptr && A.screen_margin > 0.f && !A.tdf && !A.scratch_by_tile && K > 1;
         int k0 = 0, k1 = 0;
         bool ref_skipped_tile = false;          // bracketed reference and no survivor (workgroup-uniform): k0's value was never computed
 #ifdef DPMM_STAMPS
@@ -1353,7 +1353,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
         const int64_t mypos = wbase + lane;    // position in processing order
         const bool valid = owner && mypos < A.n;
         const bool prefetched = nx_tile == tile;
-        const bool screening = FAST || (NB >= 2 && A.screen_margin > 0.f && !A.tdf && !A.scratch_by_tile && K > 2);
+        const bool screening = FAST || (NB >= 2 && A.screen_margin > 0.f && !A.tdf && !A.scratch_by_tile && K > 1);
         int myp32, binv = -1;
         if (prefetched) {
             myp32 = nx_p; binv = nx_bin;
@@ -2012,7 +2012,7 @@ static hipError_t launch_direct(const NiwSweepArgs &a, int grid, hipStream_t s) 
         hipFuncSetAttribute((const void *)niw_sweep_direct_kernel<NB, NG, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / OCC);
         attr_set = true;
     }
-    const bool fast = NB >= 2 && b.screen_margin > 0.f && !b.tdf && !b.scratch_by_tile && !b.labels_only && b.K > 2 && b.lam == nullptr &&
+    const bool fast = NB >= 2 && b.screen_margin > 0.f && !b.tdf && !b.scratch_by_tile && !b.labels_only && b.K > 1 && b.lam == nullptr &&
                       b.tail != nullptr && b.lds_rows >= b.K && !b.final_argmax;
     if constexpr (NB == 4) {
         if (fast && b.sp_frag && b.sp_cons && b.bf16scr && b.K <= SP_MAXK) {
