@@ -22,9 +22,10 @@ N = int(float(sys.argv[3])) if len(sys.argv) > 3 else 625000
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 timing = not (len(sys.argv) > 5 and sys.argv[5] == "notiming")      # "notiming": no HIP events between the kernels (as fit / dp_parallel run)
 rccl1 = len(sys.argv) > 6 and sys.argv[6] == "rccl1"                  # attach a ONE-rank RCCL communicator: the library's collective path, no wire
+mixvar = float(sys.argv[7]) if len(sys.argv) > 7 else 100.0           # variance of the component means (4 / 1: overlapping clusters, the direction screen's regime)
 K, burnout = 32, 20
 if kind == "niw":
-    X, y = host.gaussian_mixture_shard(N, D, K, 100.0, 12345, 0, N)
+    X, y = host.gaussian_mixture_shard(N, D, K, mixvar, 12345, 0, N)
     prior = host.niw_hyperparams(1.0, np.zeros(D), D + 3, np.eye(D))
     wk = pkg.Worker(pkg.PRIOR_NIW, D, N, device=0, seed=1)
 else:
