@@ -2290,17 +2290,18 @@ hipError_t launch_niw_refb_big(const float *Rp, int NB, int K, uint32_t *out, hi
 
 // ---------------------------------------------------------------------------------------
 // Tables of the direction screen (direction_far), from the images the sweep itself reads (D in 33 .. 64: NB = 4, NP = 10, DP = 64).
-// One workgroup per cluster k, four threads per reference cluster k0 (K <= 64): R_k (the Float32 values of the fragment image) in LDS,
+// One workgroup per (cluster k, 16 reference clusters k0), sixteen threads per k0: R_k (the Float32 values of the fragment image) in LDS,
 //     d = mu_k0 - mu_k,   y = R_k d  (Float64 sums),   b = |y|,   u = y / b,   w = R_k' u,
 // w as the bf16 A-operand row of cluster k in k0's fragment table (k-slots in the order of the bracket's image, refb_map), and the constants
 //     B = b,      E = (c + 1e-6) |w| (1 + 1e-5),      cst_k.
 // A pair without a direction (k = k0, b not finite or zero) and the rows of clusters that do not exist get E = inf: t = 0, nothing excluded.
 __global__ __launch_bounds__(256) void niw_direction_kernel(const float *__restrict__ Rp, const float *__restrict__ mup, const float *__restrict__ cst,
                                                             int D, int K, uint32_t *__restrict__ frag, float *__restrict__ cons) {
+    // workgroup (k, y): cluster k against the 16 reference clusters k0 = 16 y .. 16 y + 15, sixteen threads per k0 (four rows / columns each)
     __shared__ float Rk[64 * 65];              // R_k, row stride 65
-    __shared__ float dl[64][65];               // d of every k0, then u, then w
+    __shared__ float dl[16][65];               // d of the workgroup's k0, then u, then w
     __shared__ float muk[64];
-    const int k = blockIdx.x, tid = threadIdx.x;
+    const int k = blockIdx.x, q0 = 16 * blockIdx.y, tid = threadIdx.x;
     const float *img = Rp + (size_t)(3 * k) * 2560;
     for (int e = tid; e < 64 * 65; e += 256) Rk[e] = 0.f;
     if (tid < 64) muk[tid] = mup[(size_t)(3 * k) * 64 + tid];
@@ -2311,46 +2312,44 @@ __global__ __launch_bounds__(256) void niw_direction_kernel(const float *__restr
         while (rem >= 4 - bi) { rem -= 4 - bi; ++bi; }
         Rk[(16 * bi + (ln & 15)) * 65 + 16 * (bi + rem) + 4 * (ln >> 4) + jj] = img[e];
     }
-    for (int e = tid; e < 64 * 64; e += 256) {
-        const int k0 = e >> 6, c = e & 63;
-        dl[k0][c] = k0 < K ? mup[(size_t)(3 * k0) * 64 + c] - muk[c] : 0.f;
+    for (int e = tid; e < 16 * 64; e += 256) {
+        const int ql = e >> 6, c = e & 63;
+        dl[ql][c] = q0 + ql < K ? mup[(size_t)(3 * (q0 + ql)) * 64 + c] - muk[c] : 0.f;
     }
     __syncthreads();
-    const int k0 = tid >> 2, p = tid & 3;       // rows / columns 16 p .. 16 p + 15 of reference cluster k0's pair
-    double y[16];
+    const int ql = tid >> 4, p = tid & 15, k0 = q0 + ql;       // rows / columns 4 p .. 4 p + 3 of reference cluster k0's pair
+    double y[4];
     double ss = 0.0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int r = 16 * p + i;
+    for (int i = 0; i < 4; ++i) {
+        const int r = 4 * p + i;
         double acc = 0.0;
-        for (int c = r; c < 64; ++c) acc = __builtin_fma((double)Rk[r * 65 + c], (double)dl[k0][c], acc);      // (upper triangular)
+        for (int c = r; c < 64; ++c) acc = __builtin_fma((double)Rk[r * 65 + c], (double)dl[ql][c], acc);      // (upper triangular)
         y[i] = acc;
         ss = __builtin_fma(acc, acc, ss);
     }
-    ss += __shfl_xor(ss, 1);
-    ss += __shfl_xor(ss, 2);
+    for (int o = 1; o < 16; o <<= 1) ss += __shfl_xor(ss, o);
     const double b = sqrt(ss);
     const bool live = k0 < K && k0 != k && b > 0.0 && b < 1e30;
     __syncthreads();                             // every d has been read
     const double ib = live ? 1.0 / b : 0.0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) dl[k0][16 * p + i] = (float)(y[i] * ib);       // u (Float32: its norm is 1 within 1e-6)
+    for (int i = 0; i < 4; ++i) dl[ql][4 * p + i] = (float)(y[i] * ib);       // u (Float32: its norm is 1 within 1e-6)
     __syncthreads();
-    float w[16];
+    float w[4];
     double ww = 0.0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int c = 16 * p + i;
+    for (int i = 0; i < 4; ++i) {
+        const int c = 4 * p + i;
         double acc = 0.0;
-        for (int r = 0; r <= c; ++r) acc = __builtin_fma((double)Rk[r * 65 + c], (double)dl[k0][r], acc);
+        for (int r = 0; r <= c; ++r) acc = __builtin_fma((double)Rk[r * 65 + c], (double)dl[ql][r], acc);
         w[i] = (float)acc;
         ww = __builtin_fma(acc, acc, ww);
     }
-    ww += __shfl_xor(ww, 1);
-    ww += __shfl_xor(ww, 2);
+    for (int o = 1; o < 16; o <<= 1) ww += __shfl_xor(ww, o);
     __syncthreads();                             // every u has been read
 #pragma unroll
-    for (int i = 0; i < 16; ++i) dl[k0][16 * p + i] = live ? w[i] : 0.f;
+    for (int i = 0; i < 4; ++i) dl[ql][4 * p + i] = live ? w[i] : 0.f;
     __syncthreads();
     if (p == 0 && k0 < K) {                      // constants of cluster k in reference cluster k0's table
         float *co = cons + (size_t)k0 * SP_CONS_FLOATS;
@@ -2360,30 +2359,30 @@ __global__ __launch_bounds__(256) void niw_direction_kernel(const float *__restr
         co[128 + k] = cst[3 * k];
     }
     if (k == 0 && tid < 64 * 3) {                // rows of clusters that do not exist: never excluded (they have no candidate bit either)
-        for (int q = 0; q < K; ++q) {
+        for (int q = q0; q < min(K, q0 + 16); ++q) {
             float *co = cons + (size_t)q * SP_CONS_FLOATS;
             const int a = tid / 64, j = tid % 64;
             if (j >= K) co[64 * a + j] = a == 1 ? INFINITY : (a == 2 ? INFINITY : 0.f);
         }
     }
-    // row (k & 15) of block (k >> 4) in every k0's fragment table: [blk][sl][lane = (i, g)][4 dwords]
+    // row (k & 15) of block (k >> 4) in the fragment table of each of the workgroup's k0: [blk][sl][lane = (i, g)][4 dwords]
     const int blk = k >> 4, irow = k & 15;
-    for (int e = tid; e < K * 2 * 4 * 4; e += 256) {          // (k0, sl, g, d)
-        const int d = e & 3, g = (e >> 2) & 3, sl = (e >> 4) & 1, q = e >> 5, j0 = 2 * d;
+    const int nq = min(16, K - q0);
+    for (int e = tid; e < nq * 2 * 4 * 4; e += 256) {         // (k0, sl, g, d)
+        const int d = e & 3, g = (e >> 2) & 3, sl = (e >> 4) & 1, qq = e >> 5, j0 = 2 * d;
         const int col = 32 * sl + (j0 < 4 ? 4 * g + j0 : 16 + 4 * g + (j0 - 4));
-        frag[(size_t)q * SP_FRAG_WORDS + (((blk * 2 + sl) * 64) + (16 * g + irow)) * 4 + d] = bf16_rne_bits(dl[q][col]) | (bf16_rne_bits(dl[q][col + 1]) << 16);
+        frag[(size_t)(q0 + qq) * SP_FRAG_WORDS + (((blk * 2 + sl) * 64) + (16 * g + irow)) * 4 + d] = bf16_rne_bits(dl[qq][col]) | (bf16_rne_bits(dl[qq][col + 1]) << 16);
     }
-    // blocks beyond the last cluster's row inside block (K - 1) >> 4 keep whatever they held: their constants are inf (above)
     if (k == K - 1) {
-        for (int e = tid; e < K * 2 * 4 * 4 * 16; e += 256) {  // zero rows K .. 16 ceil(K / 16) - 1 of the last block in every k0's table
-            const int d = e & 3, g = (e >> 2) & 3, sl = (e >> 4) & 1, rr = (e >> 5) & 15, q = e >> 9;
-            if (rr > irow) frag[(size_t)q * SP_FRAG_WORDS + (((blk * 2 + sl) * 64) + (16 * g + rr)) * 4 + d] = 0u;
+        for (int e = tid; e < nq * 2 * 4 * 4 * 16; e += 256) {  // zero rows K .. 16 ceil(K / 16) - 1 of the last block in each of these k0's tables
+            const int d = e & 3, g = (e >> 2) & 3, sl = (e >> 4) & 1, rr = (e >> 5) & 15, qq = e >> 9;
+            if (rr > irow) frag[(size_t)(q0 + qq) * SP_FRAG_WORDS + (((blk * 2 + sl) * 64) + (16 * g + rr)) * 4 + d] = 0u;
         }
     }
 }
 hipError_t launch_niw_direction(const float *Rp, const float *mup, const float *cst, int D, int K, uint32_t *frag, float *cons, hipStream_t s) {
     if (K < 1 || K > SP_MAXK || D < 33 || D > 64) return hipErrorInvalidValue;
-    DPMM_LAUNCH(niw_direction_kernel, dim3(K), dim3(256), 0, s, Rp, mup, cst, D, K, frag, cons);
+    DPMM_LAUNCH(niw_direction_kernel, dim3(K, (K + 15) / 16), dim3(256), 0, s, Rp, mup, cst, D, K, frag, cons);
     return hipGetLastError();
 }
 
