@@ -389,6 +389,48 @@ __global__ __launch_bounds__(256, (B_RBP <= 4 ? 2 : 1)) void mult_sweep_u8_kerne
             // they fit (the global scratch cost ~30 % of the kernel: three passes of K dependent-latency L2 loads per point)
             const float *col = tab_lds ? ltab + lane : scr + lane;
             const int64_t cs = tab_lds ? 256 : 3 * sstride;
+            float e[32];
+            bool in_regs = false;
+            if (tab_lds && K <= 32 && !A.final_argmax) {
+                // the point's K values in registers: one batch of LDS reads, each exponential taken once, no data-dependent exit (the three
+                // dependent-latency passes below were 16 % of the kernel at K = 32).  Rows past K count as -inf; sums run in
+                // the same order over the same values (+0.f past K), and the running sum is monotone, so the first k with !(cw < t) is the
+                // number of k with cw < t.  A NaN anywhere (never in practice) leaves the point to the general loops.
+                bool nan_any = false;
+                float m = -INFINITY;
+                int Kv = K;
+                asm volatile("" : "+v"(Kv));                       // per-lane compare: 32 uniform conditions would be hoisted out of the tile loop into SGPRs
+#pragma unroll
+                for (int k = 0; k < 32; ++k) {
+                    const float a = col[k * 256];                    // rows past K: whatever the fragment buffers left there (the launcher allocates 32 rows)
+                    e[k] = k < Kv ? a : -INFINITY;
+                    nan_any |= e[k] != e[k];
+                    m = fmaxf(m, e[k]);
+                }
+                if (!nan_any) {
+                    in_regs = true;
+                    if (m == -INFINITY) {
+                        z = 0;
+                    } else {
+                        float s = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 32; ++k) {
+                            e[k] = exp_det(e[k] - m);
+                            s += e[k];
+                        }
+                        const float t = u01(rr.v[0]) * s;
+                        float cw = 0.f;
+                        int below = 0;
+#pragma unroll
+                        for (int k = 0; k < 32; ++k) {
+                            cw += e[k];
+                            below += cw < t ? 1 : 0;
+                        }
+                        z = below < K - 1 ? below : K - 1;
+                    }
+                }
+            }
+            if (!in_regs) {
             float m = -INFINITY;
             int best = 0;
             bool nan_seen = false;
@@ -415,6 +457,7 @@ __global__ __launch_bounds__(256, (B_RBP <= 4 ? 2 : 1)) void mult_sweep_u8_kerne
                     cw += exp_det(nan_to_ninf(col[k * cs]) - m);
                     if (!(cw < t)) { z = k; break; }
                 }
+            }
             }
             const int j = z >> 3;
             if (NRBs > 0 && !((need[j >> 5] >> (j & 31)) & 1u)) atomicOr(&miss[j >> 5], 1u << (j & 31));
@@ -696,7 +739,8 @@ static hipError_t launch_u8(const MultSweepArgs &a, const uint8_t *X8, int64_t l
     const size_t frag = sizeof(uint32_t) * 2 * B * 3 * 256, tab = sizeof(float) * 256 * (size_t)a.K;
     const size_t cap = (B <= 4 ? 76 : 152) * 1024;
     const int ltab_ok = tab <= cap;
-    const size_t lds = ltab_ok && tab > frag ? tab : frag;
+    size_t lds = ltab_ok && tab > frag ? tab : frag;
+    if (ltab_ok && a.K <= 32 && lds < 32 * 1024) lds = 32 * 1024;      // the register draw reads 32 rows of the table whatever K is (rows past K are ignored)
     static size_t attr = 48 * 1024;
     if (lds > attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mult_sweep_u8_kernel<B>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);

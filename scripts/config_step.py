@@ -5,7 +5,7 @@
 Prints one JSON line: ms per step, kernel times (HIP events), host timers per step, algorithmic bytes / flops rates.
 Run under `rocprofv3 --kernel-trace --stats` / `--pmc ...` for the tracked profiles (scripts/collect_profiles.sh)."""
 import importlib
-import json
+import json, os
 import sys
 import time
 
@@ -38,6 +38,9 @@ else:
         X[m] = rng.multinomial(100, P[k], size=int(m.sum()))
     prior = host.multinomial_hyper(np.ones(D, np.float32))      # test/save_load_test/multinomial_params.jl:24
     wk = pkg.Worker(pkg.PRIOR_MULT, D, N, device=0, seed=1)
+for kv in os.environ.get("DPMM_STEP_OPTS", "").split(","):           # e.g. DPMM_STEP_OPTS=12=256,4=0 : library options (include/dpmm_hip.h) before the upload
+    if kv:
+        wk.set_option(int(kv.split("=")[0]), float(kv.split("=")[1]))
 wk.upload_points(X)
 if rccl1:
     wk.comm_init(wk.comm_unique_id(), 0, 1)
