@@ -336,6 +336,13 @@ struct dpmmh_model {
     // bring the host's packed rows up to date from the device's statistics (merge proposals, state access) ...
     int pull_rows() {
         if (host_rows) return 0;
+        if (kind == DPMMH_PRIOR_MULT) {
+            if (!mult_pending) return fail("the Multinomial rows of the last statistics pass are gone");
+            for (int k = 0; k < K; ++k) memcpy(prow(slot[k], 0), mult_pending + (size_t)(2 * k) * stride, sizeof(double) * 2 * stride);
+            mult_pending = nullptr;
+            host_rows = true;
+            return 0;
+        }
         std::vector<int32_t> sl(K);
         for (int k = 0; k < K; ++k) sl[k] = slot[k];
         std::vector<double> rows((size_t)K * 2 * stride);
@@ -375,14 +382,19 @@ struct dpmmh_model {
     }
     // Multinomial, device marginals: rows to the slots, N and the log-marginals as the worker computed them; the Float32 posterior
     // parameters (apost) are formed only when somebody needs them (host draws, state access: pull_state)
+    // The rows themselves stay in the worker's pinned block (`mult_pending`) until somebody asks (pull_rows: an accepted split or merge, a pair the
+    // worker did not evaluate, state access): 2K rows of D + 1 doubles are half a megabyte at D = 1000, 22 us of every step spent copying
+    // what a steady-state step never reads.  The block is the worker's until its next statistics call (update_all_with_reset drops the pointer,
+    // update_subset pulls first).
+    const double *mult_pending = nullptr;
     void ingest_mult_marginals(const double *src, const double *nl) {
         for (int k = 0; k < K; ++k) {
             const int s = slot[k];
-            memcpy(prow(s, 0), src + (size_t)(2 * k) * stride, sizeof(double) * 2 * stride);
             for (int w = 0; w < 3; ++w) { Nrow[3 * s + w] = nl[2 * (3 * k + w)]; L[3 * s + w] = nl[2 * (3 * k + w) + 1]; }
             points_count[s] = (int64_t)llrint(Nrow[3 * s]);
         }
-        host_dense = false; host_rows = true;
+        mult_pending = src;
+        host_dense = false; host_rows = false;
     }
     // recompute the three posteriors of slot s from its stored statistics
     void refresh_slot(int s, std::vector<double> &sc) {
@@ -552,6 +564,7 @@ struct dpmmh_model {
                 if (mp_i.size() > 8192) { mp_i.clear(); mp_j.clear(); }
                 if (W.mult_pairs_ahead(W.ctx, has_outlier() ? 1 : 0, mp_i.data(), mp_j.data(), (int)mp_i.size())) return wfail("mult_pairs_ahead");
             }
+            mult_pending = nullptr;                 // (the pass rewrites the pinned block; every row is replaced by what it returns)
             if (W.step_stats(W.ctx, next_epoch(), &pk, &bad)) return wfail("step_stats");
         }
         t_stats_back = now_s();
@@ -612,6 +625,7 @@ struct dpmmh_model {
             timers[T_POSTERIOR] += now_s() - t0;
             return 0;
         }
+        mult_pending = nullptr;
         if (W.stats(W.ctx, nullptr, 0, &pk)) return wfail("stats");
         timers[T_STATS_WAIT] += now_s() - t0; t0 = now_s();
         ingest(pk, ks);
@@ -644,6 +658,7 @@ struct dpmmh_model {
             if (lhr > log(u)) acc.push_back(k);
         }
         if (acc.empty()) return 0;
+        if (kind == DPMMH_PRIOR_MULT) { if (int rc = pull_rows()) return rc; }      // the right halves move to new slots below
         mult_rows_current = false; mp_valid = false;
         const int K0 = K;
         std::vector<int64_t> idx, nidx;
@@ -694,9 +709,17 @@ struct dpmmh_model {
         mc_lgN.resize(K); mc_lgNa.resize(K);
         for (int k = 0; k < K; ++k) { const double N = Nc(slot[k]); mc_lgN[k] = lgamma_r(N, &sg); mc_lgNa[k] = lgamma_r(N + 0.5 * a, &sg); }
     }
+    bool mc_exact = false;                      // dpmmh_debug_merge_log_hr: every ratio in full
     double merge_log_hr(int i, int j, double Lp) {
         int sg;
         const double a = alpha, Np = Nc(slot[i]) + Nc(slot[j]);
+        // lgamma(Np) - lgamma(Np + alpha) <= 0: when the other terms alone are far below what any uniform accepts (check_and_merge refuses below
+        // -38; the 22 in between is head-room for the rounding of sums of order 1e6), the two log-gammas of the pair -- all that is left of the
+        // K (K - 1) / 2 x 3 of the formula, and 20 us per step at K = 32 -- are not taken.  The value returned is then a bound, not the ratio.
+        if (!mc_exact) {
+            const double rest = mc_head + mc_lgNa[i] - mc_lgN[i] - mc_lgN[j] + mc_lgNa[j] + Lp - L[3 * slot[i]] - L[3 * slot[j]];
+            if (rest < -60.0) return rest;
+        }
         return mc_head + lgamma_r(Np, &sg) - lgamma_r(Np + a, &sg) +
                mc_lgNa[i] - mc_lgN[i] - mc_lgN[j] + mc_lgNa[j] + Lp - L[3 * slot[i]] - L[3 * slot[j]];
     }
@@ -794,6 +817,7 @@ struct dpmmh_model {
                 if (q < mp_i.size() && mp_i[q] == i && mp_j[q] == j) lhr[p] = merge_log_hr(i, j, mp_L[q]);
                 else todo.push_back(p);
             }
+            if (!todo.empty() && pull_rows()) { for (int p : todo) lhr[p] = -INFINITY; return; }      // (no rows: no merge of those pairs; the failure is recorded)
             if (!todo.empty()) Pool::get().run((int)todo.size(), nthreads, [&](int t, int th) {
                 const int p = todo[t];
                 lhr[p] = merge_log_hr(pairs[p].first, pairs[p].second, pooled_marginal(pairs[p].first, pairs[p].second, scratch[th]));
@@ -809,7 +833,9 @@ struct dpmmh_model {
         merge_candidates(pairs);
         if (pairs.empty()) return 0;
         dev_pairs_ok = use_dev() && dev_state && !host_rows;     // the device has the rows: it forms and factorises the pooled matrices
-        if (!dev_pairs_ok) { if (int rc = pull_rows()) return rc; }          // else: pooled statistics are formed from the host's rows
+        // else: pooled statistics are formed from the host's rows (Multinomial with the worker's pair marginals: only for pairs it did not evaluate
+        // and for accepted merges)
+        if (!dev_pairs_ok && !(kind == DPMMH_PRIOR_MULT && mp_valid && use_mult_dev())) { if (int rc = pull_rows()) return rc; }
         merge_epoch += 1;
         double t0 = now_s();
         std::vector<double> lhr;
@@ -861,6 +887,7 @@ struct dpmmh_model {
             any |= !keep;
         }
         if (!any) return 0;
+        if (kind == DPMMH_PRIOR_MULT) { if (int rc = pull_rows()) return rc; }      // (pending rows are in the cluster order that ends here)
         if (W.remove_empty(W.ctx, pc.data(), K)) return wfail("remove_empty");
         mult_rows_current = false; mp_valid = false;   // (the worker's rows are in the old cluster order)
         std::vector<int> ns;
@@ -1254,6 +1281,7 @@ HAPI int dpmmh_model_set(dpmmh_model *m, const char *field, const void *in, int6
             if (m->W.mult_pairs_ahead && m->W.mult_marginals && m->W.mult_pairs_ahead(m->W.ctx, m->has_outlier() ? 1 : 0, nullptr, nullptr, 0) == 0 &&
                 m->W.mult_marginals(m->W.ctx, K, &nl, &pl, &np) == 0)
                 m->ingest_mult_marginals((const double *)in, nl);
+            m->mult_pending = nullptr; m->host_rows = true;      // (the rows went in through ingest above; `in` is the caller's)
         }
         if (m->use_dev()) {      // the device gets the same rows, so that the next draws come from where a running chain makes them
             if (m->W.niw_put_rows(m->W.ctx, (const double *)in, K)) return m->wfail("niw_put_rows");
@@ -1307,7 +1335,9 @@ HAPI int dpmmh_debug_merge_log_hr(dpmmh_model *m, double *out) {
     // as check_and_merge: the pooled statistics come from the device when it holds the current rows, else from the host's (pulled if stale)
     m->dev_pairs_ok = m->use_dev() && m->dev_state && !m->host_rows;
     if (!m->dev_pairs_ok) if (int rc = m->pull_rows()) return rc;
+    m->mc_exact = true;
     m->merge_ratios(pairs, lhr);
+    m->mc_exact = false;
     for (size_t p = 0; p < pairs.size(); ++p) out[(size_t)pairs[p].first * K + pairs[p].second] = lhr[p];
     return 0;
 }
