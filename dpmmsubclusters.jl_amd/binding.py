@@ -84,6 +84,7 @@ ABI = [
     ("dpmm_debug_subloglik", ctypes.c_int, [ctypes.c_void_p, _c_f32p]),
     ("dpmm_debug_ref_bracket", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, _c_f32p, _c_f32p]),
     ("dpmm_debug_bracket_big", ctypes.c_int, [ctypes.c_void_p, _c_f32p, ctypes.POINTER(ctypes.c_uint32)]),
+    ("dpmm_debug_mult_draws_ahead", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong)]),
     ("dpmm_last_sweep_work", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]),
     ("dpmm_comm_use_library", ctypes.c_int, [ctypes.c_char_p]),
     ("dpmm_comm_unique_id", ctypes.c_int, [ctypes.c_void_p]),
@@ -99,7 +100,7 @@ HOST_ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_voi
 
 # dpmm_set_option keys (include/dpmm_hip.h)
 MASTER_NSCALARS = 8          # DPMM_MASTER_NSCALARS
-OPT_SCREEN_MARGIN, OPT_TAIL_SCREEN, OPT_PRESCREEN, OPT_ORDERED_SWEEP, OPT_MULT_FORCE_F32, OPT_STATS_ITEMS, OPT_STATS_GROUPS, OPT_TRACE_SLOW, OPT_LOGLIK_REF_CONST, OPT_WAVE_PRIO, OPT_MULT_NO_U8, OPT_SWEEP_GRID, OPT_SWEEP_QUEUE_ROUNDS, OPT_BALL_SCREEN, OPT_KERNEL_TIMING, OPT_STATS_DERIVE, OPT_NOISE_AHEAD, OPT_REF_BRACKET, OPT_SORT_TILE, OPT_ONE_COLLECTIVE, OPT_BF16_SCREENS, OPT_COMM_TIMEOUT_MS, OPT_DIRECTION_SCREEN, OPT_F32_STATS = range(1, 25)
+OPT_SCREEN_MARGIN, OPT_TAIL_SCREEN, OPT_PRESCREEN, OPT_ORDERED_SWEEP, OPT_MULT_FORCE_F32, OPT_STATS_ITEMS, OPT_STATS_GROUPS, OPT_TRACE_SLOW, OPT_LOGLIK_REF_CONST, OPT_WAVE_PRIO, OPT_MULT_NO_U8, OPT_SWEEP_GRID, OPT_SWEEP_QUEUE_ROUNDS, OPT_BALL_SCREEN, OPT_KERNEL_TIMING, OPT_STATS_DERIVE, OPT_NOISE_AHEAD, OPT_REF_BRACKET, OPT_SORT_TILE, OPT_ONE_COLLECTIVE, OPT_BF16_SCREENS, OPT_COMM_TIMEOUT_MS, OPT_DIRECTION_SCREEN, OPT_F32_STATS, OPT_MULT_DRAWS_AHEAD = range(1, 26)
 
 
 class DpmmError(RuntimeError):
@@ -611,6 +612,12 @@ class Worker:
         aref = np.empty(self.n, np.float32); fl = np.empty((self.n + 127) // 128, np.uint32)
         self._chk(self._lib.dpmm_debug_bracket_big(self._h, _p(aref, _c_f32p), fl.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))))
         return aref, fl
+
+    def debug_mult_draws_ahead(self):
+        """dpmm_mult_master_draw calls that took the draws launched ahead by dpmm_step_stats; include/dpmm_hip_debug.h."""
+        v = ctypes.c_longlong(0)
+        self._chk(self._lib.dpmm_debug_mult_draws_ahead(self._h, ctypes.byref(v)))
+        return int(v.value)
 
     def debug_loglik(self):
         out = np.empty((self.K, self.n), np.float32)

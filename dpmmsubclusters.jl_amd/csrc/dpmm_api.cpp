@@ -87,6 +87,18 @@ struct dpmm_ctx {
     float *d_mup = nullptr;   // NIW padded mu
     float *d_cst = nullptr;   // [3K]
     uint32_t *d_Lp16 = nullptr;  // MULT: 3-plane bf16 split of the log-probabilities (count data fast path)
+    // MULT, device master: the NEXT parameter draws, made right behind the per-step statistics (while the host decides splits and merges) into
+    // a second set of buffers; dpmm_mult_master_draw swaps the sets when its epoch / K / outlier flag are the ones guessed and the rows have
+    // not changed since (else it draws as before)
+    float *d_raw2 = nullptr, *d_Rp2 = nullptr;
+    uint32_t *d_Lp16_2 = nullptr;
+    bool mspec_valid = false;
+    uint32_t mspec_epoch = 0, mdraw_epoch = 0;
+    int mspec_K = 0, mspec_outlier = 0, opt_mult_draws_ahead = 1;
+    bool mdraw_seen = false;           // a dpmm_mult_master_draw has run: its epoch + 1 is the guess
+    long long mspec_used = 0;          // draws taken from the set made ahead (dpmm_debug / tests)
+    hipEvent_t ev_rows = nullptr;      // dpmm_step_stats: rows and flags are in the pinned block (the draws launched ahead follow it)
+    bool marg_behind_ev = false;       // the log-marginals in the pinned block were complete at ev_rows (no need to wait for the stream)
     int x_bf16_exact = 0;     // MULT: every x is exactly representable in bf16 (checked at upload)
     uint8_t *dX8 = nullptr;   // MULT: byte copy of the points when every x is an integer in [0, 255] ([n][ld8])
     int64_t ld8 = 0;
@@ -438,6 +450,7 @@ static void free_params(dpmm_ctx *c) {
     hipFree(c->d_ccache); c->d_ccache = nullptr;
     hipFree(c->d_red); c->d_red = nullptr;
     hipFree(c->d_scratch); hipFree(c->d_slabs); hipFree(c->d_out); hipFree(c->d_Lp16); hipFree(c->d_tdf); hipFree(c->d_lam); hipFree(c->d_mdist); hipFree(c->d_tail); hipFree(c->d_refb_big);
+    hipFree(c->d_raw2); hipFree(c->d_Rp2); hipFree(c->d_Lp16_2); c->d_raw2 = c->d_Rp2 = nullptr; c->d_Lp16_2 = nullptr; c->mspec_valid = false;
     c->d_Lp16 = nullptr; c->d_tdf = nullptr; c->d_lam = nullptr; c->d_mdist = nullptr; c->d_tail = nullptr; c->d_refb_big = nullptr; c->have_refb_big = false;
     c->d_raw = c->d_mu = c->d_Rp = c->d_mup = c->d_cst = c->d_scratch = nullptr;
     c->d_slabs = c->d_out = nullptr;
@@ -467,6 +480,9 @@ static int ensure_capacity(dpmm_ctx *c, int K) {
         HIPCHK(c, hipMalloc(&c->d_raw, sizeof(float) * 3 * cap * (size_t)c->ldx));
         HIPCHK(c, hipMalloc(&c->d_Rp, sizeof(float) * NRB * NT * 256));
         HIPCHK(c, hipMalloc(&c->d_Lp16, sizeof(uint32_t) * std::max(mult_pack_bf16_words(3 * cap, c->ldx), mult_pack_u8_words(3 * cap, (c->D + 127) / 128 * 128))));
+        HIPCHK(c, hipMalloc(&c->d_raw2, sizeof(float) * 3 * cap * (size_t)c->ldx));
+        HIPCHK(c, hipMalloc(&c->d_Rp2, sizeof(float) * NRB * NT * 256));
+        HIPCHK(c, hipMalloc(&c->d_Lp16_2, sizeof(uint32_t) * std::max(mult_pack_bf16_words(3 * cap, c->ldx), mult_pack_u8_words(3 * cap, (c->D + 127) / 128 * 128))));
     }
     HIPCHK(c, hipMalloc(&c->d_cst, sizeof(float) * 3 * cap));
     HIPCHK(c, hipMalloc(&c->d_tdf, sizeof(float) * 6 * cap));
@@ -611,6 +627,7 @@ int dpmm_destroy(dpmm_ctx *c) {
     if (c->ev_spec) hipEventDestroy(c->ev_spec);
     if (c->ev_noise) hipEventDestroy(c->ev_noise);
     if (c->ev_pairs) hipEventDestroy(c->ev_pairs);
+    if (c->ev_rows) hipEventDestroy(c->ev_rows);
     hipFree(c->d_apairs);
     if (c->h_apairs) hipHostFree(c->h_apairs);
     hipFree(c->d_jobs); hipFree(c->d_dslots);
@@ -1293,6 +1310,7 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
     HIPCHK(c, hipSetDevice(c->device));
     const int nbins = 2 * c->K;
     c->marg_valid = false;
+    c->mspec_valid = false;            // (draws made ahead belong to the rows this pass replaces)
     // automatic: the one-collective form sends 3K rows instead of 2K -- 0.55 MB more at D = 64, K = 32 (a few us of wire) against a whole
     // latency-bound collective in the middle of the sort chain; at D = 256 the extra K rows are 8.4 MB (~80 us): the classic form stays
     const bool one_auto = c->packed_stride <= 4096;
@@ -1469,9 +1487,28 @@ int dpmm_step_stats(dpmm_ctx *c, uint32_t reset_epoch, const double **packed, co
     if (int rc = ensure_out(c, out_bytes + DPMM_MAX_CLUSTERS + 64)) return rc;
     if (int rc = run_stats(c, nullptr, 0, true, reset_epoch)) return rc;
     if (c->marg_req) if (int rc = mult_marginals_launch(c)) return rc;       // the master's log-marginals ride behind the statistics: one wait
+    const bool with_marg = c->marg_valid && c->marg_K == c->K;            // the device master is running (the host asked for the log-marginals)
     HIPCHK(c, launch_copy_bytes(c->h_out, c->d_out, out_bytes + (size_t)c->K + 1, c->stream));      // rows | flags
     if (int rc = flush_undo(c)) return rc;
-    HIPCHK(c, sync_stream(c, c->stream));
+    // Multinomial device master: the next Dirichlet draws + their hand-over images go out NOW, behind an event the host waits for instead of
+    // the stream -- they run while it decides splits and merges (a quiet step then only uploads the weights; 24 us of kernels off the path)
+    if (with_marg && c->opt_mult_draws_ahead && c->mdraw_seen && c->draws_on_device && c->rows_full_K == c->K && c->d_raw2 &&
+        (!c->marg_req_outlier || c->mult_has_alpha1)) {
+        if (!c->ev_rows) HIPCHK(c, hipEventCreateWithFlags(&c->ev_rows, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(c->ev_rows, c->stream));
+        const int K = c->K;
+        const uint32_t epoch = c->mdraw_epoch + 1;
+        HIPCHK(c, launch_mult_dirichlet(c->d_out, c->packed_stride, c->d_malpha, c->mult_has_alpha1 ? c->d_malpha + c->ldx : nullptr, c->marg_req_outlier, c->D, c->ldx,
+                                        K, c->seed, epoch, c->d_raw2, c->stream));
+        HIPCHK(c, launch_mult_pack(c->d_raw2, c->d_Rp2, 3 * K, c->ldx, c->stream));
+        if (c->x_u8) HIPCHK(c, launch_mult_pack_u8(c->d_raw2, c->d_Lp16_2, 3 * K, c->ldx, c->ld8, c->stream));
+        else if (c->x_bf16_exact) HIPCHK(c, launch_mult_pack_bf16(c->d_raw2, c->d_Lp16_2, 3 * K, c->ldx, c->stream));
+        c->mspec_valid = true; c->mspec_epoch = epoch; c->mspec_K = K; c->mspec_outlier = c->marg_req_outlier;
+        HIPCHK(c, sync_event(c, c->ev_rows));
+        c->marg_behind_ev = true;
+    } else {
+        HIPCHK(c, sync_stream(c, c->stream));
+    }
     *packed = reinterpret_cast<const double *>(c->h_out);
     *bad = reinterpret_cast<const uint8_t *>(c->h_out + out_bytes);
     return DPMM_OK;
@@ -2030,6 +2067,7 @@ int dpmm_mult_master_put_rows(dpmm_ctx *c, const double *rows, int K) {
     c->K = K;
     c->rows_full_K = K;
     c->marg_valid = false;
+    c->mspec_valid = false;
     c->cache_force = true;            // (the rows did not come from this context's labels: nothing to derive from)
     return DPMM_OK;
 }
@@ -2048,15 +2086,29 @@ int dpmm_mult_master_draw(dpmm_ctx *c, uint32_t epoch, int K, int outlier_first,
     float *hcst = reinterpret_cast<float *>(c->h_draw);
     for (int k = 0; k < K; ++k) { hcst[3 * k] = logf(w[k]); hcst[3 * k + 1] = logf(lr[2 * k]); hcst[3 * k + 2] = logf(lr[2 * k + 1]); }
     HIPCHK(c, launch_copy_bytes(c->d_cst, hcst, sizeof(float) * 3 * K, c->stream));
-    HIPCHK(c, launch_mult_dirichlet(c->d_out, c->packed_stride, c->d_malpha, c->mult_has_alpha1 ? c->d_malpha + c->ldx : nullptr, outlier_first, c->D, c->ldx,
-                                    K, c->seed, epoch, c->d_raw, c->stream));
-    HIPCHK(c, launch_mult_pack(c->d_raw, c->d_Rp, 3 * K, c->ldx, c->stream));
-    if (c->x_u8) HIPCHK(c, launch_mult_pack_u8(c->d_raw, c->d_Lp16, 3 * K, c->ldx, c->ld8, c->stream));
-    else if (c->x_bf16_exact) HIPCHK(c, launch_mult_pack_bf16(c->d_raw, c->d_Lp16, 3 * K, c->ldx, c->stream));
+    if (c->mspec_valid && c->mspec_epoch == epoch && c->mspec_K == K && c->mspec_outlier == (outlier_first ? 1 : 0)) {
+        // made behind the statistics pass (dpmm_step_stats) from these very rows: the two sets of buffers change places
+        std::swap(c->d_raw, c->d_raw2); std::swap(c->d_Rp, c->d_Rp2); std::swap(c->d_Lp16, c->d_Lp16_2);
+        c->mspec_used += 1;
+    } else {
+        HIPCHK(c, launch_mult_dirichlet(c->d_out, c->packed_stride, c->d_malpha, c->mult_has_alpha1 ? c->d_malpha + c->ldx : nullptr, outlier_first, c->D, c->ldx,
+                                        K, c->seed, epoch, c->d_raw, c->stream));
+        HIPCHK(c, launch_mult_pack(c->d_raw, c->d_Rp, 3 * K, c->ldx, c->stream));
+        if (c->x_u8) HIPCHK(c, launch_mult_pack_u8(c->d_raw, c->d_Lp16, 3 * K, c->ldx, c->ld8, c->stream));
+        else if (c->x_bf16_exact) HIPCHK(c, launch_mult_pack_bf16(c->d_raw, c->d_Lp16, 3 * K, c->ldx, c->stream));
+    }
+    c->mspec_valid = false;
+    c->mdraw_epoch = epoch; c->mdraw_seen = true;
     c->K = K;
     c->have_params = true;
     c->predictive = false;
     c->draws_on_device = true;
+    return DPMM_OK;
+}
+
+int dpmm_debug_mult_draws_ahead(dpmm_ctx *c, long long *used) {
+    if (!c || !used) return DPMM_EINVAL;
+    *used = c->mspec_used;
     return DPMM_OK;
 }
 
@@ -2073,6 +2125,7 @@ int dpmm_mult_master_draws(dpmm_ctx *c, int K, float *logp) {
 // the log-marginal kernel over the rows of the last full pass + the pairs asked for (asynchronous; results in the pinned block)
 static int mult_marginals_launch(dpmm_ctx *c) {
     c->marg_req = false;
+    c->marg_behind_ev = false;
     const int K = c->K;
     if (!c->mult_master || c->rows_full_K != K) return DPMM_OK;           // (nothing to answer from: dpmm_mult_master_marginals will say so)
     if (c->marg_req_outlier && !c->mult_has_alpha1) return DPMM_OK;
@@ -2106,7 +2159,8 @@ int dpmm_mult_master_marginals(dpmm_ctx *c, int K, const double **rows_nl, const
         if (int rc = mult_marginals_launch(c)) return rc;
         if (!c->marg_valid) return fail(c, DPMM_ESTATE, "dpmm_mult_master_marginals: no outlier prior was set up");
     }
-    HIPCHK(c, sync_stream(c, c->stream));        // (no-op behind dpmm_step_stats, which waited for the kernel with the rows)
+    if (c->marg_behind_ev) HIPCHK(c, sync_event(c, c->ev_rows));      // (dpmm_step_stats waited for it already; the stream still carries the draws launched ahead)
+    else HIPCHK(c, sync_stream(c, c->stream));        // (no-op behind dpmm_step_stats, which waited for the kernel with the rows)
     *rows_nl = c->h_marg; *pairs_l = c->h_marg + 6 * (size_t)K; *npairs = c->marg_np;
     return DPMM_OK;
 }
@@ -2379,6 +2433,7 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
         case DPMM_OPT_TRACE_SLOW: c->opt_trace = value != 0; return DPMM_OK;
         case DPMM_OPT_LOGLIK_REF_CONST: c->opt_ref_const = value != 0; return DPMM_OK;
         case DPMM_OPT_WAVE_PRIO: c->opt_prio = value != 0; return DPMM_OK;
+        case DPMM_OPT_MULT_DRAWS_AHEAD: c->opt_mult_draws_ahead = value != 0; c->mspec_valid = false; return DPMM_OK;
         case DPMM_OPT_SWEEP_QUEUE_ROUNDS: c->opt_queue_rounds = value < 0 ? -1 : (int)value; return DPMM_OK;
         case DPMM_OPT_BALL_SCREEN: c->opt_ball = value != 0; return DPMM_OK;
         case DPMM_OPT_STATS_DERIVE: c->opt_derive = value != 0; c->cache_force = true; return DPMM_OK;

@@ -87,6 +87,11 @@ enum {
                                          64-point sums added -- and the shift undone -- in Float64: the statistics kernel runs at twice its Float64 rate, the
                                          scatter matrices agree with the Float64 path to ~1e-6 of sqrt(S_aa S_bb) (tests/test_gpu_niw.py); the chain is a
                                          different, equally valid one.  Subset passes and passes after K changed stay Float64. */
+    DPMM_OPT_MULT_DRAWS_AHEAD = 25,   /* 1 (default): Multinomial device master: dpmm_step_stats launches the NEXT Dirichlet draws and their hand-over images
+                                       * behind the statistics (the epoch after the last dpmm_mult_master_draw, the same K and outlier flag), into a second set of
+                                       * buffers, and returns when the rows are on the host -- the draws run while the caller decides splits and merges.
+                                       * dpmm_mult_master_draw takes them when its arguments are the ones guessed and the rows have not changed; else it draws
+                                       * as before.  0: always draw inside dpmm_mult_master_draw (same values either way) */
     DPMM_OPT_DIRECTION_SCREEN = 23,   /* D in 33..64 NIW sweep, K <= 64: a tile that keeps six or more candidate clusters behind the 4-row tests puts ALL of them
                                          through one bound each -- along the direction u = R_k (mu_k0 - mu_k) / b that separates cluster k from the wave's reference
                                          cluster k0: q_k(x) >= (w . (x - mu_k0) + b)^2, the K dot products of a point from one bf16 matrix product (16-32 matrix

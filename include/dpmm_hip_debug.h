@@ -39,6 +39,8 @@ int dpmm_debug_ref_bracket(dpmm_ctx *ctx, int64_t cluster, float c_override, flo
    for a 128-point tile of the visiting order whose points all carry label k0 + 1, else 0; aref[n] = per POSITION of the visiting order
    (storage order before the first statistics pass) the bracket's lower end of a_k0 = cst - q_hi / 2 (tiles with flag 0: 0). */
 int dpmm_debug_bracket_big(dpmm_ctx *ctx, float *aref, uint32_t *tile_flags);
+/* Multinomial device master: how many dpmm_mult_master_draw calls took the draws dpmm_step_stats had launched ahead (DPMM_OPT_MULT_DRAWS_AHEAD). */
+int dpmm_debug_mult_draws_ahead(dpmm_ctx *ctx, long long *used);
 
 /* Milliseconds spent in the dominant kernels during the last dpmm_sweep /
  * dpmm_suffstats_* call, measured with HIP events on the ctx stream (0 if none yet, or when DPMM_OPT_KERNEL_TIMING is off -- the default).

@@ -393,3 +393,35 @@ def test_device_log_marginals_match_the_host(pkg):
         checked += int(m.sum())
     assert checked > 20 and s.K >= 5
     wk.close()
+
+
+def test_draws_launched_ahead_are_the_draws_of_the_next_step(pkg):
+    """DPMM_OPT_MULT_DRAWS_AHEAD (default 1): dpmm_step_stats launches the next Dirichlet draws behind the statistics into a second set of
+    buffers and dpmm_mult_master_draw swaps the sets when its arguments are the ones guessed.  The chain -- K history, labels, sub-labels, the
+    log-probabilities of every step -- is the chain with the option off; quiet steps take the draws made ahead, steps that follow a split,
+    merge or removal do not."""
+    import importlib
+    host = importlib.import_module("dpmmsubclusters_jl_amd.host")
+    engine = importlib.import_module("dpmmsubclusters_jl_amd.host.engine")
+    D, N, Kt = 200, 20000, 5
+    x, y, _ = host.generate_mnmm_data(N, D, Kt, 150, seed=3)[:3]
+    x = np.ascontiguousarray(x, np.float32)
+    res = {}
+    for ahead in (1, 0):
+        wk, s = _mult_chain(pkg, host, engine, x, D, N, 1)
+        wk.set_option(importlib.import_module("dpmmsubclusters_jl_amd.binding").OPT_MULT_DRAWS_AHEAD, ahead)
+        ks, lps = [s.K], []
+        for it in range(50):
+            s.group_step(False, False)
+            ks.append(s.K)
+            lps.append(s.model.get("logp").copy())
+        res[ahead] = (ks, wk.get_labels(), lps, wk.debug_mult_draws_ahead())
+        wk.close()
+    assert res[1][0] == res[0][0]
+    assert np.array_equal(res[1][1][0], res[0][1][0]) and np.array_equal(res[1][1][1], res[0][1][1])
+    for i, (a, b) in enumerate(zip(res[1][2], res[0][2])):
+        if res[1][0][i + 1] == res[1][0][i]:            # (rows of clusters born or renumbered in this step have no draw yet: whatever the buffer held)
+            assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True), i
+    changes = sum(1 for i in range(1, len(res[1][0])) if res[1][0][i] != res[1][0][i - 1])
+    print("draws taken from the set made ahead:", res[1][3], "of 50 steps;", changes, "steps changed K")
+    assert res[0][3] == 0 and 30 <= res[1][3] <= 50 - changes
