@@ -36,15 +36,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // `prev_lab` / `dirty` (nullable pair): the cluster label every point had at the previous per-step pass, and per-cluster flags "a point
 // entered or left this cluster since then" -- what lets the statistics pass compute only the smaller sub-cluster of an untouched cluster
 // and take the other one from the cached cluster-level row (derive_rows_kernel).  Any path that changes labels is seen here.
-template <int TILE>
-__global__ __launch_bounds__(64) void hist_kernel(const int32_t *__restrict__ bins, int64_t n, int nbins, int nt,
-                                                  int32_t *__restrict__ tile_hist, int32_t *__restrict__ fast_total,
-                                                  uint16_t *__restrict__ prev_lab, uint8_t *__restrict__ dirty) {
-    extern __shared__ int cnt[];
-    const int lane = threadIdx.x;
+// W waves per workgroup, one sort tile each: the bin totals go to `fast_total` once per WORKGROUP.  With labels in no particular storage order
+// every tile holds every bin, and one wave per workgroup meant tiles x bins atomics on `nbins` addresses (N = 1e6, K = 32: 125 k atomics, 2 k
+// in a row per address at ~13 ns each = the kernel's 26 us; 33 us at N = 1e7).
+template <int TILE, int W>
+__global__ __launch_bounds__(64 * W) void hist_kernel(const int32_t *__restrict__ bins, int64_t n, int nbins, int nt,
+                                                      int32_t *__restrict__ tile_hist, int32_t *__restrict__ fast_total,
+                                                      uint16_t *__restrict__ prev_lab, uint8_t *__restrict__ dirty) {
+    extern __shared__ int cnt_all[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int *const cnt = cnt_all + wave * nbins;
+    const int tile = blockIdx.x * W + wave;
     for (int b = lane; b < nbins; b += 64) cnt[b] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * TILE;
+    const int64_t base = (int64_t)tile * TILE;
+    if (tile < nt) {
     auto track = [&](int64_t i, int bv) {            // rare: a point whose label is not the one it had at the previous pass
         // (a label outside [0, K) -- perm_total != n acknowledges that they can occur -- still LEAVES the cluster the point was in: that
         // cluster's cached row is stale whether or not the new bin is counted)
@@ -129,12 +135,17 @@ __global__ __launch_bounds__(64) void hist_kernel(const int32_t *__restrict__ bi
             }
         }
     }
-    __syncthreads();
-    for (int b = lane; b < nbins; b += 64) {
-        const int v = cnt[b];
-        tile_hist[(int64_t)b * nt + blockIdx.x] = v;
-        if (fast_total && v) atomicAdd(&fast_total[b * FAST_TOTAL_STRIDE], v);     // (a line per bin: 5 k tiles x ~3 bins on two lines took 18 us longer)
     }
+    __syncthreads();
+    if (tile < nt)
+        for (int b = lane; b < nbins; b += 64) tile_hist[(int64_t)b * nt + tile] = cnt[b];
+    if (fast_total)
+        for (int b = threadIdx.x; b < nbins; b += 64 * W) {
+            int v = 0;
+#pragma unroll
+            for (int w = 0; w < W; ++w) v += cnt_all[w * nbins + b];
+            if (v) atomicAdd(&fast_total[b * FAST_TOTAL_STRIDE], v);               // (a line per bin: 5 k tiles x ~3 bins on two lines took 18 us longer)
+        }
 }
 
 // reset_bad_clusters! (src/local_clusters_actions.jl:501-516) + the re-count it makes necessary, one wave per sort tile: every workgroup
@@ -423,12 +434,19 @@ hipError_t launch_derive_rows(double *out, double *cache, const uint8_t *mode, u
 // tile kernels are latency chains of one wave per tile (8 / 32 dependent trips per wave at 2048 points: 12 us each for 5 MB of labels).
 #define DPMM_TILE_DISPATCH(tile, CALL512, CALL2048) do { if ((tile) == 512) { CALL512; } else { CALL2048; } } while (0)
 static inline int sort_nt(int64_t n, const SortBufs &b) { return (int)((n + b.tile - 1) / b.tile); }
+template <int TILE>
+static inline void launch_hist(const int32_t *bins, int64_t n, int nbins, int nt, int32_t *tile_cnt, int32_t *fast_total, uint16_t *prev_lab, uint8_t *dirty,
+                               hipStream_t s) {
+    // eight tiles per workgroup while eight count arrays fit comfortably in LDS (K <= 512), else one
+    if (nbins <= 1024) DPMM_LAUNCH((hist_kernel<TILE, 8>), dim3((nt + 7) / 8), dim3(512), 8 * nbins * sizeof(int), s, bins, n, nbins, nt, tile_cnt, fast_total, prev_lab, dirty);
+    else DPMM_LAUNCH((hist_kernel<TILE, 1>), dim3(nt), dim3(64), nbins * sizeof(int), s, bins, n, nbins, nt, tile_cnt, fast_total, prev_lab, dirty);
+}
 hipError_t launch_sort_by_bin(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s) {
     const int nt = sort_nt(n, b);
     if (nt == 0) return hipSuccess;
     DPMM_TILE_DISPATCH(b.tile,
-        DPMM_LAUNCH(hist_kernel<512>, dim3(nt), dim3(64), nbins * sizeof(int), s, bins, n, nbins, nt, b.tile_cnt, (int32_t *)nullptr, (uint16_t *)nullptr, (uint8_t *)nullptr),
-        DPMM_LAUNCH(hist_kernel<2048>, dim3(nt), dim3(64), nbins * sizeof(int), s, bins, n, nbins, nt, b.tile_cnt, (int32_t *)nullptr, (uint16_t *)nullptr, (uint8_t *)nullptr));
+        launch_hist<512>(bins, n, nbins, nt, b.tile_cnt, (int32_t *)nullptr, (uint16_t *)nullptr, (uint8_t *)nullptr, s),
+        launch_hist<2048>(bins, n, nbins, nt, b.tile_cnt, (int32_t *)nullptr, (uint16_t *)nullptr, (uint8_t *)nullptr, s));
     DPMM_LAUNCH(scan_tiles_kernel, dim3(nbins), dim3(256), 0, s, b.tile_cnt, b.tile_hist, nt, b.bin_total);
     return hipGetLastError();
 }
@@ -438,8 +456,8 @@ hipError_t launch_step_hist(const int32_t *bins, int64_t n, int nbins, const Sor
     const int nt = sort_nt(n, b);
     uint8_t *dirty = b.prev_lab ? b.cdirty : (uint8_t *)nullptr;
     DPMM_TILE_DISPATCH(b.tile,
-        DPMM_LAUNCH(hist_kernel<512>, dim3(nt), dim3(64), nbins * sizeof(int), s, bins, n, nbins, nt, b.tile_cnt, b.fast_total, b.prev_lab, dirty),
-        DPMM_LAUNCH(hist_kernel<2048>, dim3(nt), dim3(64), nbins * sizeof(int), s, bins, n, nbins, nt, b.tile_cnt, b.fast_total, b.prev_lab, dirty));
+        launch_hist<512>(bins, n, nbins, nt, b.tile_cnt, b.fast_total, b.prev_lab, dirty, s),
+        launch_hist<2048>(bins, n, nbins, nt, b.tile_cnt, b.fast_total, b.prev_lab, dirty, s));
     return hipGetLastError();
 }
 hipError_t launch_step_reset(int32_t *bins, int64_t n, int64_t first, int nbins, const SortBufs &b, const long long *global_counts, uint8_t *flags,
