@@ -425,3 +425,42 @@ def test_draws_launched_ahead_are_the_draws_of_the_next_step(pkg):
     changes = sum(1 for i in range(1, len(res[1][0])) if res[1][0][i] != res[1][0][i - 1])
     print("draws taken from the set made ahead:", res[1][3], "of 50 steps;", changes, "steps changed K")
     assert res[0][3] == 0 and 30 <= res[1][3] <= 50 - changes
+
+
+def test_master_rows_follow_the_labels_through_merges_and_removals(pkg):
+    """The Multinomial device master leaves a step's rows in the worker's pinned block and pulls them only when it must (accepted split / merge /
+    removal, state access).  From 14 random clusters on 4-component data the chain merges and removes its way down: after EVERY step the rows the
+    model reports ("packed": [N, sum x] per cluster and side) are the counts of the labels the worker holds, recomputed here with numpy --
+    exactly (integer data)."""
+    import importlib
+    host = importlib.import_module("dpmmsubclusters_jl_amd.host")
+    engine = importlib.import_module("dpmmsubclusters_jl_amd.host.engine")
+    D, N, Kt = 160, 6000, 4
+    x, y, _ = host.generate_mnmm_data(N, D, Kt, 120, seed=11)[:3]
+    x = np.ascontiguousarray(x, np.float32)            # (D, N)
+    wk, s = _mult_chain(pkg, host, engine, x, D, N, 1, init=14, burnout=3)
+    X = x.T.astype(np.float64)
+    ks = [s.K]
+    for it in range(45):
+        s.group_step(False, False)
+        ks.append(s.K)
+        rows = np.asarray(s.model.get("packed"), np.float64).reshape(2 * s.K, -1)
+        lab, sub = wk.get_labels()
+        for k in range(s.K):
+            for side in (1, 2):
+                m = (lab == k + 1) & (sub == side)
+                want = np.concatenate([[m.sum()], X[m].sum(0)])
+                assert np.array_equal(rows[2 * k + side - 1][: D + 1], want), (it, k, side, ks)
+    checked = wk.get_labels()
+    wk.close()
+    print("K history:", ks)
+    assert ks[0] == 14 and min(ks) < 14 and ks[-1] <= 8        # merges / removals happened
+    # the same chain when nobody asks for the rows in between (they are pulled only by the accepted merges / removals themselves)
+    wk, s = _mult_chain(pkg, host, engine, x, D, N, 1, init=14, burnout=3)
+    ks2 = [s.K]
+    for it in range(45):
+        s.group_step(False, False)
+        ks2.append(s.K)
+    quiet = wk.get_labels()
+    wk.close()
+    assert ks2 == ks and np.array_equal(quiet[0], checked[0]) and np.array_equal(quiet[1], checked[1])
