@@ -50,6 +50,8 @@ ABI = [
     ("dpmm_mult_master_put_rows", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     ("dpmm_mult_master_pairs_ahead", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     ("dpmm_mult_master_marginals", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int)]),
+    ("dpmm_mult_master_rows_on_demand", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    ("dpmm_mult_master_rows_wait", ctypes.c_int, [ctypes.c_void_p]),
     ("dpmm_sweep", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int]),
     ("dpmm_packed_stride", ctypes.c_int64, [ctypes.c_void_p]),
     ("dpmm_suffstats_packed_device", ctypes.c_int, [ctypes.c_void_p, _c_i64p, ctypes.c_int, ctypes.c_void_p]),

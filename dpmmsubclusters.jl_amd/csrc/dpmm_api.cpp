@@ -98,6 +98,10 @@ struct dpmm_ctx {
     bool mdraw_seen = false;           // a dpmm_mult_master_draw has run: its epoch + 1 is the guess
     long long mspec_used = 0;          // draws taken from the set made ahead (dpmm_debug / tests)
     hipEvent_t ev_rows = nullptr;      // dpmm_step_stats: rows and flags are in the pinned block (the draws launched ahead follow it)
+    bool rows_on_demand = false, rows_late = false;   // dpmm_mult_master_rows_on_demand: with draws launched ahead the rows reach the pinned block BEHIND them (ev_rows2)
+    hipEvent_t ev_rows2 = nullptr;
+    hipEvent_t ev_cst = nullptr;       // dpmm_mult_master_draw: behind the copy that reads the pinned weights
+    bool cst_inflight = false;
     bool marg_behind_ev = false;       // the log-marginals in the pinned block were complete at ev_rows (no need to wait for the stream)
     int x_bf16_exact = 0;     // MULT: every x is exactly representable in bf16 (checked at upload)
     uint8_t *dX8 = nullptr;   // MULT: byte copy of the points when every x is an integer in [0, 255] ([n][ld8])
@@ -628,6 +632,8 @@ int dpmm_destroy(dpmm_ctx *c) {
     if (c->ev_noise) hipEventDestroy(c->ev_noise);
     if (c->ev_pairs) hipEventDestroy(c->ev_pairs);
     if (c->ev_rows) hipEventDestroy(c->ev_rows);
+    if (c->ev_rows2) hipEventDestroy(c->ev_rows2);
+    if (c->ev_cst) hipEventDestroy(c->ev_cst);
     hipFree(c->d_apairs);
     if (c->h_apairs) hipHostFree(c->h_apairs);
     hipFree(c->d_jobs); hipFree(c->d_dslots);
@@ -1272,6 +1278,7 @@ int64_t dpmm_packed_stride(const dpmm_ctx *c) { return c ? c->packed_stride : 0;
 static int ensure_out(dpmm_ctx *c, size_t bytes) {
     if (bytes <= c->h_out_bytes) return DPMM_OK;
     HIPCHK(c, sync_stream(c, c->stream));
+    c->rows_late = false;
     if (c->h_out) hipHostFree(c->h_out);
     c->h_out = nullptr; c->h_out_bytes = 0;
     size_t cap = 1 << 20;
@@ -1488,12 +1495,16 @@ int dpmm_step_stats(dpmm_ctx *c, uint32_t reset_epoch, const double **packed, co
     if (int rc = run_stats(c, nullptr, 0, true, reset_epoch)) return rc;
     if (c->marg_req) if (int rc = mult_marginals_launch(c)) return rc;       // the master's log-marginals ride behind the statistics: one wait
     const bool with_marg = c->marg_valid && c->marg_K == c->K;            // the device master is running (the host asked for the log-marginals)
-    HIPCHK(c, launch_copy_bytes(c->h_out, c->d_out, out_bytes + (size_t)c->K + 1, c->stream));      // rows | flags
+    const bool ahead = with_marg && c->opt_mult_draws_ahead && c->mdraw_seen && c->draws_on_device && c->rows_full_K == c->K && c->d_raw2 &&
+                       (!c->marg_req_outlier || c->mult_has_alpha1);
+    const bool late = ahead && c->rows_on_demand;       // the caller reads the rows through dpmm_mult_master_rows_wait only: flags now, rows behind the draws
+    c->rows_late = false;
+    if (late) HIPCHK(c, launch_copy_bytes(c->h_out + out_bytes, reinterpret_cast<const uint8_t *>(c->d_out) + out_bytes, (size_t)c->K + 1, c->stream));
+    else HIPCHK(c, launch_copy_bytes(c->h_out, c->d_out, out_bytes + (size_t)c->K + 1, c->stream));      // rows | flags
     if (int rc = flush_undo(c)) return rc;
     // Multinomial device master: the next Dirichlet draws + their hand-over images go out NOW, behind an event the host waits for instead of
     // the stream -- they run while it decides splits and merges (a quiet step then only uploads the weights; 24 us of kernels off the path)
-    if (with_marg && c->opt_mult_draws_ahead && c->mdraw_seen && c->draws_on_device && c->rows_full_K == c->K && c->d_raw2 &&
-        (!c->marg_req_outlier || c->mult_has_alpha1)) {
+    if (ahead) {
         if (!c->ev_rows) HIPCHK(c, hipEventCreateWithFlags(&c->ev_rows, hipEventDisableTiming));
         HIPCHK(c, hipEventRecord(c->ev_rows, c->stream));
         const int K = c->K;
@@ -1504,6 +1515,14 @@ int dpmm_step_stats(dpmm_ctx *c, uint32_t reset_epoch, const double **packed, co
         if (c->x_u8) HIPCHK(c, launch_mult_pack_u8(c->d_raw2, c->d_Lp16_2, 3 * K, c->ldx, c->ld8, c->stream));
         else if (c->x_bf16_exact) HIPCHK(c, launch_mult_pack_bf16(c->d_raw2, c->d_Lp16_2, 3 * K, c->ldx, c->stream));
         c->mspec_valid = true; c->mspec_epoch = epoch; c->mspec_K = K; c->mspec_outlier = c->marg_req_outlier;
+        if (late) {
+            // (on the same stream, behind the draws: a second stream for the half megabyte was measured no faster -- the Dirichlet kernel slows
+            //  down beside the copy by what the copy takes)
+            if (!c->ev_rows2) HIPCHK(c, hipEventCreateWithFlags(&c->ev_rows2, hipEventDisableTiming));
+            HIPCHK(c, launch_copy_bytes(c->h_out, c->d_out, out_bytes, c->stream));
+            HIPCHK(c, hipEventRecord(c->ev_rows2, c->stream));
+            c->rows_late = true;
+        }
         HIPCHK(c, sync_event(c, c->ev_rows));
         c->marg_behind_ev = true;
     } else {
@@ -2080,12 +2099,16 @@ int dpmm_mult_master_draw(dpmm_ctx *c, uint32_t epoch, int K, int outlier_first,
     if (outlier_first && !c->mult_has_alpha1) return fail(c, DPMM_ESTATE, "dpmm_mult_master_draw: no outlier prior was set up");
     HIPCHK(c, hipSetDevice(c->device));
     if (int rc = ensure_capacity(c, K)) return rc;
-    // cst[3k] = log w_k, cst[3k+1+s] = log lr[k][s] through the pinned block (see dpmm_niw_master_draw for the wait)
-    if (c->handover_inflight) HIPCHK(c, sync_stream(c, c->stream));
-    c->handover_inflight = true;
+    // cst[3k] = log w_k, cst[3k+1+s] = log lr[k][s] through the pinned block.  The block is re-used once the copy of the PREVIOUS call has read
+    // it: an event behind that copy, not the stream -- the stream may be carrying the draws launched ahead and the late rows, and waiting for
+    // those here would put them back on the host's path
+    if (!c->ev_cst) HIPCHK(c, hipEventCreateWithFlags(&c->ev_cst, hipEventDisableTiming));
+    if (c->cst_inflight) HIPCHK(c, sync_event(c, c->ev_cst));
     float *hcst = reinterpret_cast<float *>(c->h_draw);
     for (int k = 0; k < K; ++k) { hcst[3 * k] = logf(w[k]); hcst[3 * k + 1] = logf(lr[2 * k]); hcst[3 * k + 2] = logf(lr[2 * k + 1]); }
     HIPCHK(c, launch_copy_bytes(c->d_cst, hcst, sizeof(float) * 3 * K, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_cst, c->stream));
+    c->cst_inflight = true;
     if (c->mspec_valid && c->mspec_epoch == epoch && c->mspec_K == K && c->mspec_outlier == (outlier_first ? 1 : 0)) {
         // made behind the statistics pass (dpmm_step_stats) from these very rows: the two sets of buffers change places
         std::swap(c->d_raw, c->d_raw2); std::swap(c->d_Rp, c->d_Rp2); std::swap(c->d_Lp16, c->d_Lp16_2);
@@ -2103,6 +2126,23 @@ int dpmm_mult_master_draw(dpmm_ctx *c, uint32_t epoch, int K, int outlier_first,
     c->have_params = true;
     c->predictive = false;
     c->draws_on_device = true;
+    return DPMM_OK;
+}
+
+int dpmm_mult_master_rows_on_demand(dpmm_ctx *c, int on) {
+    if (!c) return DPMM_EINVAL;
+    if (!c->mult_master) return fail(c, DPMM_ESTATE, "dpmm_mult_master_setup first");
+    c->rows_on_demand = on != 0;
+    return DPMM_OK;
+}
+
+int dpmm_mult_master_rows_wait(dpmm_ctx *c) {
+    if (!c) return DPMM_EINVAL;
+    if (c->rows_late) {
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, sync_event(c, c->ev_rows2));
+        c->rows_late = false;
+    }
     return DPMM_OK;
 }
 

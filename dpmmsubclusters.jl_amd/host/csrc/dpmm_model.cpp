@@ -298,6 +298,8 @@ struct dpmmh_model {
         if (!mult_dev_setup) {
             if (W.mult_master_setup(W.ctx, mult[0].alpha.data(), mult[1].set ? mult[1].alpha.data() : nullptr)) { wfail("mult_master_setup"); mult_dev_failed = true; return false; }
             mult_dev_setup = true;
+            // (this engine reads a step's rows only through pull_rows: the worker may deliver them behind the draws it launches ahead)
+            if (W.mult_rows_on_demand && W.mult_rows_wait && W.mult_pairs_ahead && W.mult_marginals) W.mult_rows_on_demand(W.ctx, 1);
         }
         return true;
     }
@@ -338,6 +340,7 @@ struct dpmmh_model {
         if (host_rows) return 0;
         if (kind == DPMMH_PRIOR_MULT) {
             if (!mult_pending) return fail("the Multinomial rows of the last statistics pass are gone");
+            if (W.mult_rows_wait && W.mult_rows_wait(W.ctx)) return wfail("mult_rows_wait");
             for (int k = 0; k < K; ++k) memcpy(prow(slot[k], 0), mult_pending + (size_t)(2 * k) * stride, sizeof(double) * 2 * stride);
             mult_pending = nullptr;
             host_rows = true;

@@ -35,6 +35,8 @@ F_MM_DRAW = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_uint32, ctypes.c_int, c
 F_MM_DRAWS = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_int, _vp)
 F_MM_PAIRSA = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int)
 F_MM_MARG = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_int, _pp, _pp, ctypes.POINTER(ctypes.c_int))
+F_MM_ROWSD = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_int)
+F_MM_ROWSW = ctypes.CFUNCTYPE(ctypes.c_int, _vp)
 F_SPLIT = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _i64p, _i64p, ctypes.c_int, ctypes.c_uint32)
 F_MERGE = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _i64p, _i64p, ctypes.c_int)
 F_REMOVE = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _i64p, ctypes.c_int)
@@ -55,7 +57,8 @@ class WorkerTable(ctypes.Structure):
                 ("niw_master_setup", F_M_SETUP), ("step_stats_device", F_M_STEP), ("step_master_device", F_M_STEPM), ("stats_device", F_M_STATS), ("niw_posterior", F_M_POST),
                 ("niw_draw", F_M_DRAW), ("niw_pairs", F_M_PAIRS), ("niw_pairs_ahead", F_M_PAIRSA), ("niw_put_rows", F_M_PUT), ("niw_rows", F_M_ROWS), ("niw_draws", F_M_DRAWS),
                 ("mult_master_setup", F_MM_SETUP), ("mult_draw", F_MM_DRAW), ("mult_draws", F_MM_DRAWS), ("mult_put_rows", F_M_PUT),
-                ("mult_pairs_ahead", F_MM_PAIRSA), ("mult_marginals", F_MM_MARG)]
+                ("mult_pairs_ahead", F_MM_PAIRSA), ("mult_marginals", F_MM_MARG),
+                ("mult_rows_on_demand", F_MM_ROWSD), ("mult_rows_wait", F_MM_ROWSW)]
 
 
 _NATIVE_MAP = [("params_staging", "dpmm_params_staging", F_STAGING), ("commit_params", "dpmm_commit_params", F_INT),
@@ -71,7 +74,8 @@ _NATIVE_MAP = [("params_staging", "dpmm_params_staging", F_STAGING), ("commit_pa
                ("niw_rows", "dpmm_niw_master_rows", F_M_ROWS), ("niw_draws", "dpmm_niw_master_draws", F_M_DRAWS),
                ("mult_master_setup", "dpmm_mult_master_setup", F_MM_SETUP), ("mult_draw", "dpmm_mult_master_draw", F_MM_DRAW),
                ("mult_draws", "dpmm_mult_master_draws", F_MM_DRAWS), ("mult_put_rows", "dpmm_mult_master_put_rows", F_M_PUT),
-               ("mult_pairs_ahead", "dpmm_mult_master_pairs_ahead", F_MM_PAIRSA), ("mult_marginals", "dpmm_mult_master_marginals", F_MM_MARG)]
+               ("mult_pairs_ahead", "dpmm_mult_master_pairs_ahead", F_MM_PAIRSA), ("mult_marginals", "dpmm_mult_master_marginals", F_MM_MARG),
+               ("mult_rows_on_demand", "dpmm_mult_master_rows_on_demand", F_MM_ROWSD), ("mult_rows_wait", "dpmm_mult_master_rows_wait", F_MM_ROWSW)]
 
 
 def native_worker_table(worker, rank=0, world=1):

@@ -82,6 +82,12 @@ int dpmm_mult_master_put_rows(dpmm_ctx *ctx, const double *rows, int K);
  *   rows are not there (subset pass, split / merge / removal since). */
 int dpmm_mult_master_pairs_ahead(dpmm_ctx *ctx, int outlier_first, const int32_t *ki, const int32_t *kj, int n);
 int dpmm_mult_master_marginals(dpmm_ctx *ctx, int K, const double **rows_nl, const double **pairs_l, int *npairs);
+/* A master that reads the rows of dpmm_step_stats only now and then (the log-marginals above decide a quiet step) says so once:
+ * dpmm_mult_master_rows_on_demand(ctx, 1).  From then on, in a step whose draws are launched ahead (DPMM_OPT_MULT_DRAWS_AHEAD), dpmm_step_stats
+ * returns when the FLAGS and the log-marginals are on the host; the rows follow behind the draws, and *packed must not be read before
+ * dpmm_mult_master_rows_wait(ctx) has returned (a no-op in every other step).  Off by default: dpmm_step_stats then returns with the rows. */
+int dpmm_mult_master_rows_on_demand(dpmm_ctx *ctx, int on);
+int dpmm_mult_master_rows_wait(dpmm_ctx *ctx);
 
 #ifdef __cplusplus
 }

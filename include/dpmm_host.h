@@ -102,6 +102,10 @@ typedef struct dpmmh_worker {
      * whose gates are open and reads the results behind it; pairs it did not ask for, and steps after a split, are computed on the host. */
     int (*mult_pairs_ahead)(void *ctx, int outlier_first, const int32_t *ki, const int32_t *kj, int n);
     int (*mult_marginals)(void *ctx, int K, const double **rows_nl, const double **pairs_l, int *npairs);
+    /* OPTIONAL pair (with the two above; may be NULL): dpmm_mult_master_rows_on_demand / dpmm_mult_master_rows_wait -- the engine declares once that
+     * it reads step_stats' rows only through rows_wait (an accepted split / merge / removal, state access); the worker may then deliver them late. */
+    int (*mult_rows_on_demand)(void *ctx, int on);
+    int (*mult_rows_wait)(void *ctx);
 } dpmmh_worker;
 
 /* Options (dpmmh_model_set_option). */

@@ -17,7 +17,7 @@ const libhost = Libdl.dlopen("libdpmmhost.so")
 hip(sym) = Libdl.dlsym(libhip, sym)
 
 # struct dpmmh_worker: ctx, rank, world, then 13 + 11 + 4 + 2 function pointers in the order of include/dpmm_host.h (the eleven niw_* /
-# *_device entries -- the NIW master's dense maths on the device -- and the six mult_* entries -- the Multinomial master's Dirichlet
+# *_device entries -- the NIW master's dense maths on the device -- and the eight mult_* entries -- the Multinomial master's Dirichlet
 # draws and log-marginals on the device -- are optional, each as a group: C_NULL for all of a group keeps that work on the host)
 struct WorkerTable
     ctx::Ptr{Cvoid}; rank::Cint; world::Cint
@@ -27,7 +27,7 @@ struct WorkerTable
     niw_master_setup::Ptr{Cvoid}; step_stats_device::Ptr{Cvoid}; step_master_device::Ptr{Cvoid}; stats_device::Ptr{Cvoid}; niw_posterior::Ptr{Cvoid}
     niw_draw::Ptr{Cvoid}; niw_pairs::Ptr{Cvoid}; niw_pairs_ahead::Ptr{Cvoid}; niw_put_rows::Ptr{Cvoid}; niw_rows::Ptr{Cvoid}; niw_draws::Ptr{Cvoid}
     mult_master_setup::Ptr{Cvoid}; mult_draw::Ptr{Cvoid}; mult_draws::Ptr{Cvoid}; mult_put_rows::Ptr{Cvoid}
-    mult_pairs_ahead::Ptr{Cvoid}; mult_marginals::Ptr{Cvoid}
+    mult_pairs_ahead::Ptr{Cvoid}; mult_marginals::Ptr{Cvoid}; mult_rows_on_demand::Ptr{Cvoid}; mult_rows_wait::Ptr{Cvoid}
 end
 native_table(ctx, rank, world) = WorkerTable(ctx, rank, world,
     hip(:dpmm_params_staging), hip(:dpmm_commit_params), hip(:dpmm_set_num_clusters), hip(:dpmm_sweep),
@@ -36,7 +36,7 @@ native_table(ctx, rank, world) = WorkerTable(ctx, rank, world,
     hip(:dpmm_niw_master_setup), hip(:dpmm_step_stats_device), hip(:dpmm_step_master_device), hip(:dpmm_suffstats_device), hip(:dpmm_niw_master_posterior),
     hip(:dpmm_niw_master_draw), hip(:dpmm_niw_master_pairs), hip(:dpmm_niw_master_pairs_ahead), hip(:dpmm_niw_master_put_rows), hip(:dpmm_niw_master_rows), hip(:dpmm_niw_master_draws),
     hip(:dpmm_mult_master_setup), hip(:dpmm_mult_master_draw), hip(:dpmm_mult_master_draws), hip(:dpmm_mult_master_put_rows),
-    hip(:dpmm_mult_master_pairs_ahead), hip(:dpmm_mult_master_marginals))
+    hip(:dpmm_mult_master_pairs_ahead), hip(:dpmm_mult_master_marginals), hip(:dpmm_mult_master_rows_on_demand), hip(:dpmm_mult_master_rows_wait))
 
 # fit(all_data::AbstractArray{Float32,2}, hyper::niw_hyperparams, α; iters, init_clusters, seed, burnout, ...)  -- one process per GPU
 function gpu_fit(pts::Matrix{Float32}, hyper::niw_hyperparams, α::Float32; iters = 100, init_clusters = 1, seed = 1, burnout = 20,
