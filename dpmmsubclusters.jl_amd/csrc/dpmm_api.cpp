@@ -93,6 +93,7 @@ struct dpmm_ctx {
     float *d_raw2 = nullptr, *d_Rp2 = nullptr;
     uint32_t *d_Lp16_2 = nullptr;
     bool mspec_valid = false;
+    bool rp_current = true, rp2_current = true;   // the Float32 fragment image (d_Rp / d_Rp2) matches d_raw / d_raw2: the device master skips it for byte / bf16 data; the Float32 sweep packs it on demand
     uint32_t mspec_epoch = 0, mdraw_epoch = 0;
     int mspec_K = 0, mspec_outlier = 0, opt_mult_draws_ahead = 1;
     bool mdraw_seen = false;           // a dpmm_mult_master_draw has run: its epoch + 1 is the guess
@@ -661,6 +662,7 @@ int dpmm_destroy(dpmm_ctx *c) {
 static int finish_upload(dpmm_ctx *c) {
     if (c->prior == DPMM_PRIOR_MULT) {
         const bool force_f32 = c->opt_force_f32 != 0;
+        const int was_u8 = c->x_u8, was_bf16 = c->x_bf16_exact;
         int *flag = reinterpret_cast<int *>(c->d_small);
         HIPCHK(c, hipMemsetAsync(flag, 0, sizeof(int), c->stream));
         HIPCHK(c, launch_bf16_exact_check(c->dX, c->n * c->ldx, flag, c->stream));
@@ -682,6 +684,15 @@ static int finish_upload(dpmm_ctx *c) {
             // every Multinomial kernel of a byte-path context reads the byte copy (a lossless re-encoding): the Float32 matrix (4 bytes per
             // element, 4 GB at D = 1000, N = 1e6) is dead weight from here on; a new upload allocates it again
             else { HIPCHK(c, hipFree(c->dX)); c->dX = nullptr; }
+        }
+        // parameters that stay in place across the upload were packed for the OLD points' sweep kernel (byte planes / bf16 planes / Float32
+        // fragments): when the new points take another kernel, the images it reads are made from the raw rows now
+        if (c->have_params && c->d_raw && (was_u8 != c->x_u8 || was_bf16 != c->x_bf16_exact)) {
+            HIPCHK(c, launch_mult_pack(c->d_raw, c->d_Rp, 3 * c->K, c->ldx, c->stream));
+            c->rp_current = true;
+            if (c->x_u8) HIPCHK(c, launch_mult_pack_u8(c->d_raw, c->d_Lp16, 3 * c->K, c->ldx, c->ld8, c->stream));
+            else if (c->x_bf16_exact) HIPCHK(c, launch_mult_pack_bf16(c->d_raw, c->d_Lp16, 3 * c->K, c->ldx, c->stream));
+            c->mspec_valid = false;
         }
     }
     HIPCHK(c, sync_stream(c, c->stream));
@@ -938,6 +949,7 @@ int dpmm_commit_params(dpmm_ctx *c, int K) {
         HIPCHK(c, launch_copy_bytes(c->d_cst, hcst, sizeof(float) * 3 * K, c->stream));
         HIPCHK(c, launch_gather_rows(c->d_raw, c->ldx, hmat, c->D, hslot, 3 * K, c->D, c->stream));
         HIPCHK(c, launch_mult_pack(c->d_raw, c->d_Rp, 3 * K, c->ldx, c->stream));
+        c->rp_current = true;
         if (c->x_u8) HIPCHK(c, launch_mult_pack_u8(c->d_raw, c->d_Lp16, 3 * K, c->ldx, c->ld8, c->stream));
         else if (c->x_bf16_exact) HIPCHK(c, launch_mult_pack_bf16(c->d_raw, c->d_Lp16, 3 * K, c->ldx, c->stream));
     }
@@ -1152,7 +1164,10 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
         a.order_total = c->sb.perm_total;
         if (c->x_u8) HIPCHK(c, launch_mult_sweep_u8(a, c->dX8, c->ld8, c->d_Lp16, c->sweep_grid, c->stream));
         else if (c->x_bf16_exact) HIPCHK(c, launch_mult_sweep_bf16(a, c->d_Lp16, c->sweep_grid, c->stream));
-        else HIPCHK(c, launch_mult_sweep(a, c->sweep_grid, c->stream));
+        else {
+            if (!c->rp_current) { HIPCHK(c, launch_mult_pack(c->d_raw, c->d_Rp, 3 * c->K, c->ldx, c->stream)); c->rp_current = true; }      // (skipped by a device-master draw)
+            HIPCHK(c, launch_mult_sweep(a, c->sweep_grid, c->stream));
+        }
     }
     if (!table) {
         if (c->master) if (int rc = noise_flush(c)) return rc;
@@ -1511,13 +1526,14 @@ int dpmm_step_stats(dpmm_ctx *c, uint32_t reset_epoch, const double **packed, co
         const uint32_t epoch = c->mdraw_epoch + 1;
         HIPCHK(c, launch_mult_dirichlet(c->d_out, c->packed_stride, c->d_malpha, c->mult_has_alpha1 ? c->d_malpha + c->ldx : nullptr, c->marg_req_outlier, c->D, c->ldx,
                                         K, c->seed, epoch, c->d_raw2, c->stream));
-        HIPCHK(c, launch_mult_pack(c->d_raw2, c->d_Rp2, 3 * K, c->ldx, c->stream));
+        c->rp2_current = !(c->x_u8 || c->x_bf16_exact);                 // (only the Float32 sweep kernel reads that image)
+        if (c->rp2_current) HIPCHK(c, launch_mult_pack(c->d_raw2, c->d_Rp2, 3 * K, c->ldx, c->stream));
         if (c->x_u8) HIPCHK(c, launch_mult_pack_u8(c->d_raw2, c->d_Lp16_2, 3 * K, c->ldx, c->ld8, c->stream));
         else if (c->x_bf16_exact) HIPCHK(c, launch_mult_pack_bf16(c->d_raw2, c->d_Lp16_2, 3 * K, c->ldx, c->stream));
         c->mspec_valid = true; c->mspec_epoch = epoch; c->mspec_K = K; c->mspec_outlier = c->marg_req_outlier;
         if (late) {
-            // (on the same stream, behind the draws: a second stream for the half megabyte was measured no faster -- the Dirichlet kernel slows
-            //  down beside the copy by what the copy takes)
+            // (on the same stream, behind the draws.  A second stream was measured twice and is no faster: beside the Dirichlet kernel the copy
+            //  slows that kernel down by what the copy takes, behind the draws it shares the PCIe link with the upload of the next weights)
             if (!c->ev_rows2) HIPCHK(c, hipEventCreateWithFlags(&c->ev_rows2, hipEventDisableTiming));
             HIPCHK(c, launch_copy_bytes(c->h_out, c->d_out, out_bytes, c->stream));
             HIPCHK(c, hipEventRecord(c->ev_rows2, c->stream));
@@ -2111,12 +2127,13 @@ int dpmm_mult_master_draw(dpmm_ctx *c, uint32_t epoch, int K, int outlier_first,
     c->cst_inflight = true;
     if (c->mspec_valid && c->mspec_epoch == epoch && c->mspec_K == K && c->mspec_outlier == (outlier_first ? 1 : 0)) {
         // made behind the statistics pass (dpmm_step_stats) from these very rows: the two sets of buffers change places
-        std::swap(c->d_raw, c->d_raw2); std::swap(c->d_Rp, c->d_Rp2); std::swap(c->d_Lp16, c->d_Lp16_2);
+        std::swap(c->d_raw, c->d_raw2); std::swap(c->d_Rp, c->d_Rp2); std::swap(c->d_Lp16, c->d_Lp16_2); std::swap(c->rp_current, c->rp2_current);
         c->mspec_used += 1;
     } else {
         HIPCHK(c, launch_mult_dirichlet(c->d_out, c->packed_stride, c->d_malpha, c->mult_has_alpha1 ? c->d_malpha + c->ldx : nullptr, outlier_first, c->D, c->ldx,
                                         K, c->seed, epoch, c->d_raw, c->stream));
-        HIPCHK(c, launch_mult_pack(c->d_raw, c->d_Rp, 3 * K, c->ldx, c->stream));
+        c->rp_current = !(c->x_u8 || c->x_bf16_exact);
+        if (c->rp_current) HIPCHK(c, launch_mult_pack(c->d_raw, c->d_Rp, 3 * K, c->ldx, c->stream));
         if (c->x_u8) HIPCHK(c, launch_mult_pack_u8(c->d_raw, c->d_Lp16, 3 * K, c->ldx, c->ld8, c->stream));
         else if (c->x_bf16_exact) HIPCHK(c, launch_mult_pack_bf16(c->d_raw, c->d_Lp16, 3 * K, c->ldx, c->stream));
     }
@@ -2666,6 +2683,7 @@ int dpmm_debug_subloglik(dpmm_ctx *c, float *out) {
     if (e == hipSuccess) e = hipMalloc(&table, sizeof(float) * (size_t)(niw ? K2 : 3 * K2) * (size_t)stride);
     int rc = DPMM_OK;
     float *sRp = c->d_Rp, *smu = c->d_mup, *scst = c->d_cst, *sraw = c->d_raw;
+    const bool s_rp_current = c->rp_current;
     uint32_t *sL16 = c->d_Lp16;
     const int sK = c->K;
     const bool s_tail = c->have_tail, s_prep = c->have_screen_prep;
@@ -2695,7 +2713,7 @@ int dpmm_debug_subloglik(dpmm_ctx *c, float *out) {
         if (e == hipSuccess) e = launch_mult_pack(traw, tRp, 3 * K2, c->ldx, c->stream);
         if (e == hipSuccess && c->x_u8) e = launch_mult_pack_u8(traw, tL16, 3 * K2, c->ldx, c->ld8, c->stream);
         else if (e == hipSuccess && c->x_bf16_exact) e = launch_mult_pack_bf16(traw, tL16, 3 * K2, c->ldx, c->stream);
-        if (e == hipSuccess) { c->d_Rp = tRp; c->d_cst = tcst; c->d_Lp16 = tL16; c->d_raw = traw; }
+        if (e == hipSuccess) { c->d_Rp = tRp; c->d_cst = tcst; c->d_Lp16 = tL16; c->d_raw = traw; c->rp_current = true; }
     }
     if (e == hipSuccess) {
         c->K = K2; c->have_tail = false; c->have_screen_prep = false;
@@ -2707,7 +2725,7 @@ int dpmm_debug_subloglik(dpmm_ctx *c, float *out) {
         }
     }
     hipStreamSynchronize(c->stream);
-    c->d_Rp = sRp; c->d_mup = smu; c->d_cst = scst; c->d_Lp16 = sL16; c->d_raw = sraw; c->K = sK; c->have_tail = s_tail; c->have_screen_prep = s_prep;
+    c->d_Rp = sRp; c->d_mup = smu; c->d_cst = scst; c->d_Lp16 = sL16; c->d_raw = sraw; c->rp_current = s_rp_current; c->K = sK; c->have_tail = s_tail; c->have_screen_prep = s_prep;
     hipFree(tRp); hipFree(tmu); hipFree(tcst); hipFree(table); hipFree(traw); hipFree(tL16);
     if (e != hipSuccess) { c->err = std::string("dpmm_debug_subloglik: ") + hipGetErrorString(e); return DPMM_EHIP; }
     return rc;

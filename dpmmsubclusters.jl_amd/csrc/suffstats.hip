@@ -1248,7 +1248,16 @@ __global__ __launch_bounds__(256) void mult_reduce_kernel(StatsArgs A) {
     if (e == 0) { out[0] = (double)A.sb.bin_total[b]; return; }
     double s = 0.;
     const int i0 = A.sb.item_start[b], i1 = A.sb.item_start[b + 1];
-    for (int it = i0; it < i1; ++it) s += A.slabs[(int64_t)it * A.slab_stride + (e - 1)];
+    // eight loads in flight, added in item order (the same sum as one at a time: a bin has 30 - 60 items at N = 1e6, each a trip to L2)
+    int it = i0;
+    for (; it + 8 <= i1; it += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = A.slabs[(int64_t)(it + u) * A.slab_stride + (e - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; it < i1; ++it) s += A.slabs[(int64_t)it * A.slab_stride + (e - 1)];
     out[e] = s;
 }
 

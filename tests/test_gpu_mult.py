@@ -464,3 +464,23 @@ def test_master_rows_follow_the_labels_through_merges_and_removals(pkg):
     quiet = wk.get_labels()
     wk.close()
     assert ks2 == ks and np.array_equal(quiet[0], checked[0]) and np.array_equal(quiet[1], checked[1])
+
+
+def test_parameters_survive_a_new_upload_of_another_kind_of_data(pkg):
+    """The parameter images are packed for the sweep kernel of the points in place (byte planes for small counts, bf16 planes for bf16-exact
+    data, Float32 fragments otherwise).  A new upload that changes the kind re-packs them from the raw rows: the log-likelihood table of the
+    new points with the OLD parameters is x . logp + log w in every order of the three kinds."""
+    P = make_problem(130, 1500, 6, 40, seed=5)
+    rng = np.random.default_rng(1)
+    kinds = {"bytes": P["X"], "bf16": P["X"] * 256.0, "f32": (P["X"] + rng.random(P["X"].shape).astype(np.float32) * 0.37).astype(np.float32)}
+    for order in (("bytes", "f32", "bf16", "bytes"), ("f32", "bytes"), ("bf16", "f32")):
+        wk = pkg.Worker(pkg.PRIOR_MULT, P["D"], P["n"], device=0, seed=3)
+        wk.upload_points(kinds[order[0]])
+        wk.set_params_mult(P["logp"], P["lr"], P["w"])
+        for name in order:
+            if name != order[0] or name == order[-1]:
+                wk.upload_points(kinds[name])
+            X = kinds[name].astype(np.float64)
+            want = np.stack([X @ P["logp"][3 * k].astype(np.float64) + np.log(np.float64(P["w"][k])) for k in range(P["K"])])
+            np.testing.assert_allclose(wk.debug_loglik(), want, rtol=2e-5, atol=2e-3 * max(1.0, float(np.abs(want).max()) / 1e3), err_msg=f"{order} at {name}")
+        wk.close()
