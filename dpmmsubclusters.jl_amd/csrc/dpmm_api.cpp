@@ -99,9 +99,10 @@ struct dpmm_ctx {
     bool mdraw_seen = false;           // a dpmm_mult_master_draw has run: its epoch + 1 is the guess
     long long mspec_used = 0;          // draws taken from the set made ahead (dpmm_debug / tests)
     hipEvent_t ev_rows = nullptr;      // dpmm_step_stats: rows and flags are in the pinned block (the draws launched ahead follow it)
-    bool rows_on_demand = false, rows_late = false;   // dpmm_mult_master_rows_on_demand: with draws launched ahead the rows reach the pinned block BEHIND them (ev_rows2)
-    hipEvent_t ev_rows2 = nullptr;
-    hipEvent_t ev_cst = nullptr;       // dpmm_mult_master_draw: behind the copy that reads the pinned weights
+    bool rows_on_demand = false, rows_late = false;   // dpmm_mult_master_rows_on_demand: with draws launched ahead the rows reach the pinned block BEHIND them
+    // dpmm_mult_master_draw re-uses its pinned weights once the host has waited for the main stream (or for ev_rows, recorded later on it) since
+    // the copy that read them -- a generation count instead of an event of its own (an event record costs ~5 us of stream time in front of the sweep)
+    unsigned long long sync_gen = 0, cst_gen = 0;
     bool cst_inflight = false;
     bool marg_behind_ev = false;       // the log-marginals in the pinned block were complete at ev_rows (no need to wait for the stream)
     int x_bf16_exact = 0;     // MULT: every x is exactly representable in bf16 (checked at upload)
@@ -301,6 +302,7 @@ static inline int64_t steady_ms() {
 }
 // Blocking waits on the ctx stream go through these two: with an RCCL communicator attached the watchdog sees how long they last.
 static inline hipError_t sync_stream(dpmm_ctx *c, hipStream_t st) {
+    if (st == c->stream) c->sync_gen += 1;        // (everything queued on the main stream so far has run when this returns)
     if (!c->watchdog) return hipStreamSynchronize(st);
     c->wd_wait_since.store(steady_ms() | 1, std::memory_order_relaxed);
     const hipError_t e = hipStreamSynchronize(st);
@@ -633,8 +635,6 @@ int dpmm_destroy(dpmm_ctx *c) {
     if (c->ev_noise) hipEventDestroy(c->ev_noise);
     if (c->ev_pairs) hipEventDestroy(c->ev_pairs);
     if (c->ev_rows) hipEventDestroy(c->ev_rows);
-    if (c->ev_rows2) hipEventDestroy(c->ev_rows2);
-    if (c->ev_cst) hipEventDestroy(c->ev_cst);
     hipFree(c->d_apairs);
     if (c->h_apairs) hipHostFree(c->h_apairs);
     hipFree(c->d_jobs); hipFree(c->d_dslots);
@@ -1507,14 +1507,17 @@ int dpmm_step_stats(dpmm_ctx *c, uint32_t reset_epoch, const double **packed, co
     if (!c || !packed || !bad) return DPMM_EINVAL;
     const size_t out_bytes = sizeof(double) * 2 * (size_t)std::max(c->K, 1) * (size_t)c->packed_stride;
     if (int rc = ensure_out(c, out_bytes + DPMM_MAX_CLUSTERS + 64)) return rc;
-    if (int rc = run_stats(c, nullptr, 0, true, reset_epoch)) return rc;
+    // (a step that will deliver the rows late lets the flags ride to the pinned block with the kernel that derives the rows: one copy fewer)
+    const bool maybe_late = c->rows_on_demand && c->marg_req && c->opt_mult_draws_ahead && c->mdraw_seen && c->draws_on_device && c->d_raw2;
+    bool flags_sent = false;
+    if (int rc = run_stats(c, nullptr, 0, true, reset_epoch, maybe_late ? reinterpret_cast<uint8_t *>(c->h_out + out_bytes) : nullptr, &flags_sent)) return rc;
     if (c->marg_req) if (int rc = mult_marginals_launch(c)) return rc;       // the master's log-marginals ride behind the statistics: one wait
     const bool with_marg = c->marg_valid && c->marg_K == c->K;            // the device master is running (the host asked for the log-marginals)
     const bool ahead = with_marg && c->opt_mult_draws_ahead && c->mdraw_seen && c->draws_on_device && c->rows_full_K == c->K && c->d_raw2 &&
                        (!c->marg_req_outlier || c->mult_has_alpha1);
     const bool late = ahead && c->rows_on_demand;       // the caller reads the rows through dpmm_mult_master_rows_wait only: flags now, rows behind the draws
     c->rows_late = false;
-    if (late) HIPCHK(c, launch_copy_bytes(c->h_out + out_bytes, reinterpret_cast<const uint8_t *>(c->d_out) + out_bytes, (size_t)c->K + 1, c->stream));
+    if (late) { if (!flags_sent) HIPCHK(c, launch_copy_bytes(c->h_out + out_bytes, reinterpret_cast<const uint8_t *>(c->d_out) + out_bytes, (size_t)c->K + 1, c->stream)); }
     else HIPCHK(c, launch_copy_bytes(c->h_out, c->d_out, out_bytes + (size_t)c->K + 1, c->stream));      // rows | flags
     if (int rc = flush_undo(c)) return rc;
     // Multinomial device master: the next Dirichlet draws + their hand-over images go out NOW, behind an event the host waits for instead of
@@ -1533,13 +1536,13 @@ int dpmm_step_stats(dpmm_ctx *c, uint32_t reset_epoch, const double **packed, co
         c->mspec_valid = true; c->mspec_epoch = epoch; c->mspec_K = K; c->mspec_outlier = c->marg_req_outlier;
         if (late) {
             // (on the same stream, behind the draws.  A second stream was measured twice and is no faster: beside the Dirichlet kernel the copy
-            //  slows that kernel down by what the copy takes, behind the draws it shares the PCIe link with the upload of the next weights)
-            if (!c->ev_rows2) HIPCHK(c, hipEventCreateWithFlags(&c->ev_rows2, hipEventDisableTiming));
+            //  slows that kernel down by what the copy takes, behind the draws it shares the PCIe link with the upload of the next weights.
+            //  No event of its own either: dpmm_mult_master_rows_wait is rare and waits for the stream)
             HIPCHK(c, launch_copy_bytes(c->h_out, c->d_out, out_bytes, c->stream));
-            HIPCHK(c, hipEventRecord(c->ev_rows2, c->stream));
             c->rows_late = true;
         }
         HIPCHK(c, sync_event(c, c->ev_rows));
+        c->sync_gen += 1;                  // (the weights' copy of this step was queued long before ev_rows)
         c->marg_behind_ev = true;
     } else {
         HIPCHK(c, sync_stream(c, c->stream));
@@ -2116,15 +2119,13 @@ int dpmm_mult_master_draw(dpmm_ctx *c, uint32_t epoch, int K, int outlier_first,
     HIPCHK(c, hipSetDevice(c->device));
     if (int rc = ensure_capacity(c, K)) return rc;
     // cst[3k] = log w_k, cst[3k+1+s] = log lr[k][s] through the pinned block.  The block is re-used once the copy of the PREVIOUS call has read
-    // it: an event behind that copy, not the stream -- the stream may be carrying the draws launched ahead and the late rows, and waiting for
-    // those here would put them back on the host's path
-    if (!c->ev_cst) HIPCHK(c, hipEventCreateWithFlags(&c->ev_cst, hipEventDisableTiming));
-    if (c->cst_inflight) HIPCHK(c, sync_event(c, c->ev_cst));
+    // it -- known from the host's waits since, not by waiting for the stream here: the stream may be carrying the draws launched ahead and the late
+    // rows, and waiting for those would put them back on the host's path
+    if (c->cst_inflight && c->cst_gen == c->sync_gen) HIPCHK(c, sync_stream(c, c->stream));     // (never in the engine's loop: dpmm_step_stats waited in between)
     float *hcst = reinterpret_cast<float *>(c->h_draw);
     for (int k = 0; k < K; ++k) { hcst[3 * k] = logf(w[k]); hcst[3 * k + 1] = logf(lr[2 * k]); hcst[3 * k + 2] = logf(lr[2 * k + 1]); }
     HIPCHK(c, launch_copy_bytes(c->d_cst, hcst, sizeof(float) * 3 * K, c->stream));
-    HIPCHK(c, hipEventRecord(c->ev_cst, c->stream));
-    c->cst_inflight = true;
+    c->cst_inflight = true; c->cst_gen = c->sync_gen;
     if (c->mspec_valid && c->mspec_epoch == epoch && c->mspec_K == K && c->mspec_outlier == (outlier_first ? 1 : 0)) {
         // made behind the statistics pass (dpmm_step_stats) from these very rows: the two sets of buffers change places
         std::swap(c->d_raw, c->d_raw2); std::swap(c->d_Rp, c->d_Rp2); std::swap(c->d_Lp16, c->d_Lp16_2); std::swap(c->rp_current, c->rp2_current);
@@ -2157,7 +2158,7 @@ int dpmm_mult_master_rows_wait(dpmm_ctx *c) {
     if (!c) return DPMM_EINVAL;
     if (c->rows_late) {
         HIPCHK(c, hipSetDevice(c->device));
-        HIPCHK(c, sync_event(c, c->ev_rows2));
+        HIPCHK(c, sync_stream(c, c->stream));
         c->rows_late = false;
     }
     return DPMM_OK;

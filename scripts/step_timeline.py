@@ -1,5 +1,5 @@
 """Kernel timeline of ONE steady-state step from a rocprofv3 kernel trace (csv): start offset, duration and the gap in front of every
-kernel between two consecutive sweep launches (the last complete step of the trace), plus totals.
+kernel between two consecutive sweep launches (the step of median length among the last 21 complete steps of the trace), plus totals.
    rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -o t -- python3 scripts/config_step.py niw 64 1250000 100
    python3 scripts/step_timeline.py gpurun_out/tl [sweep-kernel-substring]"""
 import csv, glob, os, sys
@@ -12,7 +12,11 @@ with open(f) as fh:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "").replace("dpmm::", ""), r.get("Stream_Id", r.get("Queue_Id", ""))))
 rows.sort()
 sw = [i for i, r in enumerate(rows) if key in r[2] and "pack" not in r[2]]
-a, b = sw[-3], sw[-2]
+# the step of MEDIAN length among the last 21 complete ones (one step alone can be a host hiccup: the gaps are the host's)
+cand = [(rows[sw[i + 1]][0] - rows[sw[i]][0], i) for i in range(max(0, len(sw) - 23), len(sw) - 2)]
+cand.sort()
+mid = cand[len(cand) // 2][1] if cand else len(sw) - 3
+a, b = sw[mid], sw[mid + 1]
 t0 = rows[a][0]
 prev_end = None
 busy = 0
