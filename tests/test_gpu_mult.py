@@ -484,3 +484,43 @@ def test_parameters_survive_a_new_upload_of_another_kind_of_data(pkg):
             want = np.stack([X @ P["logp"][3 * k].astype(np.float64) + np.log(np.float64(P["w"][k])) for k in range(P["K"])])
             np.testing.assert_allclose(wk.debug_loglik(), want, rtol=2e-5, atol=2e-3 * max(1.0, float(np.abs(want).max()) / 1e3), err_msg=f"{order} at {name}")
         wk.close()
+
+
+def test_outlier_component_with_the_device_master(pkg):
+    """fit(...; outlier_weight, outlier_params) on Multinomial data wide enough for the device master (D >= 128): cluster 1 is the fixed outlier
+    component with its own prior (local_clusters_actions.jl:42-61, :424-437), drawn on the device with the others (outlier_first).  The chain is
+    the same with the draws launched ahead and with them made inside dpmm_mult_master_draw, the outlier keeps its constant weight, and the
+    components are recovered."""
+    import importlib
+    host = importlib.import_module("dpmmsubclusters_jl_amd.host")
+    binding = importlib.import_module("dpmmsubclusters_jl_amd.binding")
+    D, N, Kt = 160, 6000, 3
+    x, y, _ = host.generate_mnmm_data(N, D, Kt, 120, seed=13)[:3]
+    x = np.ascontiguousarray(x, np.float32)
+    rng = np.random.default_rng(2)
+    out = rng.random(N) < 0.05
+    x[:, out] = rng.multinomial(120, np.ones(D) / D, size=int(out.sum())).T          # uniform bags of words: nobody's component
+    hyper = host.multinomial_hyper(np.ones(D, np.float32))
+    ohyper = host.multinomial_hyper(np.full(D, 50.0, np.float32))
+    res = {}
+    for ahead in (1, 0):
+        made = []
+
+        def factory(*a, **kw):
+            wk = binding.Worker(*a, **kw)
+            wk.set_option(binding.OPT_MULT_DRAWS_AHEAD, ahead)
+            made.append(wk)
+            return wk
+        r = host.fit(x, hyper, 10.0, iters=60, seed=21, burnout=5, verbose=False, outlier_weight=0.05, outlier_params=ohyper, worker_factory=factory)
+        res[ahead] = (np.asarray(r[0]).copy(), np.asarray(r[2]).copy(), made[0].debug_mult_draws_ahead())
+    assert np.array_equal(res[1][0], res[0][0]) and np.array_equal(res[1][1], res[0][1])
+    labels, weights = res[1][0], res[1][1]
+    assert weights[0] == np.float32(0.05)
+    print("draws taken ahead:", res[1][2], "| clusters", len(weights), "| outliers labelled 1:", float((labels[out] == 1).mean()), "| others labelled 1:", float((labels[~out] == 1).mean()))
+    assert res[0][2] == 0 and res[1][2] >= 20
+    assert (labels[out] == 1).mean() > 0.8 and (labels[~out] == 1).mean() < 0.05
+    from dpmmsubclusters_jl_amd.host.sampler import nmi_vi_from_contingency
+    keep = ~out
+    C = np.zeros((int(labels.max()), int(np.asarray(y).max())))
+    np.add.at(C, (labels[keep] - 1, np.asarray(y)[keep] - 1), 1)
+    assert nmi_vi_from_contingency(C)[0] > 0.9
