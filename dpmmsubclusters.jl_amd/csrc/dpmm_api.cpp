@@ -1355,7 +1355,7 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
         HIPCHK(c, launch_copy_bytes(c->sb.bin_sel, c->h_pin, nbins, c->stream));
         c->sel_all_ones = 0;
     } else if (with_reset && c->n > 0 && c->opt_derive) {
-        // (the per-step pass writes the selection of its 2K bins itself: scan_starts_kernel)
+        // (the per-step pass writes the selection of its 2K bins itself: starts_step_kernel)
     } else if (c->sel_all_ones < nbins) {
         HIPCHK(c, hipMemsetAsync(c->sb.bin_sel, 1, c->sel_capacity, c->stream));      // stays valid until a subset pass overwrites it
         c->sel_all_ones = c->sel_capacity;

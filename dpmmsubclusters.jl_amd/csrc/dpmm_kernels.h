@@ -162,7 +162,7 @@ struct SortBufs {
     int32_t *tile_hist;   // [nbins][ntiles_sort] exclusive prefix over the tiles of a bin (written by the scan from tile_cnt)
     int32_t *tile_cnt;    // [nbins][ntiles_sort] points of bin b in tile t (written by the histogram)
     int32_t *fast_total;  // [nbins][FAST_TOTAL_STRIDE] (element 0 of each line) running bin totals of the per-step histogram (integer atomics), cleared by scan_starts_kernel
-    unsigned *ticket;     // [1] workgroups of scan_starts_kernel that are done (the last one computes the starts and clears it)
+    unsigned *ticket;     // [1] unused since the per-step scan and the starts are two launches (kept: the buffers are allocated as a set)
     uint16_t *prev_lab;   // [n] cluster label of every point at the previous per-step pass (0xFFFF: none yet); null: no tracking
     uint8_t *cdirty;      // [DPMM_MAX_CLUSTERS_K + 1] a point entered or left cluster k since then; last element: every cluster
     uint8_t *cmode;       // [DPMM_MAX_CLUSTERS_K] per-step pass: 0 both sub-clusters computed, 1 / 2 left / right derived from the cached cluster row

@@ -32,7 +32,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------ sort
 // `fast_total` (nullable): [nbins] running bin totals, added with integer atomics (order-independent, exact) -- the per-step pass needs the
-// sub-cluster occupancies before anything is scanned (bad-cluster flags); scan_starts_kernel clears them again for the next pass.
+// sub-cluster occupancies before anything is scanned (bad-cluster flags); starts_step_kernel clears them again for the next pass.
 // `prev_lab` / `dirty` (nullable pair): the cluster label every point had at the previous per-step pass, and per-cluster flags "a point
 // entered or left this cluster since then" -- what lets the statistics pass compute only the smaller sub-cluster of an untouched cluster
 // and take the other one from the cached cluster-level row (derive_rows_kernel).  Any path that changes labels is seen here.
@@ -312,27 +312,17 @@ __global__ __launch_bounds__(256) void starts_kernel(const int32_t *__restrict__
     __shared__ int pa[256], pb[256];
     starts_body(bin_total, bin_sel, nbins, chunk, bin_start, item_start, perm_total, pa, pb);
 }
-// scan of every bin + the starts in ONE launch: the workgroup that finishes last (a ticket counter) sees every bin total and computes
-// bin_start / item_start; it also clears the ticket and the histogram's running totals for the next pass.
-// `mode` (nullable; with `dirty` and `force_all`): the last workgroup also decides, per cluster, which bins the statistics kernels compute
+// The starts of the per-step pass, one workgroup behind scan_tiles_kernel: bin_start / item_start from the bin totals; it also clears the
+// histogram's running totals for the next pass and decides, per cluster, which bins the statistics kernels compute
 // (bin_sel) -- mode[k] = 0: both sub-clusters (the cluster was touched since its cached row was formed, or is empty, or force_all),
 // 1: only the right one (the left is the larger: derived as cache - right), 2: only the left one.
-__global__ __launch_bounds__(256) void scan_starts_kernel(const int32_t *__restrict__ tile_cnt, int32_t *__restrict__ tile_hist, int nt,
-                                                          int32_t *bin_total, uint8_t *bin_sel, int chunk,
+// (Rounds 2 - 4 had scan + starts in ONE launch, the workgroup that finished last doing this part: the ticket needs an agent-scope release fence
+// in every workgroup, which on this part is an L2 write-back each -- 13 - 17 us for the one launch against 5 + 5 for the two.)
+__global__ __launch_bounds__(256) void starts_step_kernel(int32_t *bin_total, uint8_t *bin_sel, int nbins, int chunk,
                                                           int32_t *__restrict__ bin_start, int32_t *__restrict__ item_start,
-                                                          int32_t *__restrict__ perm_total, int32_t *__restrict__ fast_total, unsigned *ticket,
+                                                          int32_t *__restrict__ perm_total, int32_t *__restrict__ fast_total,
                                                           uint8_t *__restrict__ mode, const uint8_t *__restrict__ dirty, int force_all) {
     __shared__ int part[256], pb[256];
-    __shared__ unsigned last;
-    const int nbins = (int)gridDim.x;
-    scan_one_bin(tile_cnt, tile_hist, nt, bin_total, part);
-    __threadfence();                                    // bin_total[blockIdx.x] is visible device-wide before the ticket is taken
-    __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == (unsigned)(nbins - 1) ? 1u : 0u;
-    __syncthreads();
-    if (!last) return;
-    __threadfence();                                    // (acquire: the other workgroups' totals, not a stale line of this unit's cache)
-    if (threadIdx.x == 0) *ticket = 0u;
     if (fast_total) for (int b = threadIdx.x; b < nbins; b += 256) fast_total[b * FAST_TOTAL_STRIDE] = 0;
     if (mode) {
         const bool all = force_all || dirty[DPMM_MAX_CLUSTERS_K];
@@ -1324,9 +1314,9 @@ static void launch_scatter(const int32_t *bins, const StatsArgs &a, int nt, hipS
 }
 hipError_t launch_step_scan_scatter(const int32_t *bins, const StatsArgs &a, int derive, int force_all, hipStream_t s) {
     const int nt = sort_nt(a.n, a.sb);
-    DPMM_LAUNCH(scan_starts_kernel, dim3(a.nbins), dim3(256), 0, s, a.sb.tile_cnt, a.sb.tile_hist, nt, a.sb.bin_total, a.sb.bin_sel, a.chunk,
-                       a.sb.bin_start, a.sb.item_start, a.sb.perm_total, a.sb.fast_total, a.sb.ticket,
-                       derive ? a.sb.cmode : (uint8_t *)nullptr, a.sb.cdirty, force_all);
+    DPMM_LAUNCH(scan_tiles_kernel, dim3(a.nbins), dim3(256), 0, s, a.sb.tile_cnt, a.sb.tile_hist, nt, a.sb.bin_total);
+    DPMM_LAUNCH(starts_step_kernel, dim3(1), dim3(256), 0, s, a.sb.bin_total, a.sb.bin_sel, a.nbins, a.chunk, a.sb.bin_start, a.sb.item_start,
+                a.sb.perm_total, a.sb.fast_total, derive ? a.sb.cmode : (uint8_t *)nullptr, a.sb.cdirty, force_all);
     launch_scatter(bins, a, nt, s);
     return hipGetLastError();
 }
