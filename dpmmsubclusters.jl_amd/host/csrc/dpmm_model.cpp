@@ -588,7 +588,11 @@ struct dpmmh_model {
                 ingest_mult_marginals(pk, nl);
                 mp_L.assign(pl, pl + np);
                 mp_valid = true;
-            } else { ingest(pk, ks); host_dense = true; host_rows = true; }
+            } else {
+                // (the worker may have launched the draws ahead and be delivering the rows behind them: they are read HERE, so wait for them)
+                if (W.mult_rows_wait && W.mult_rows_wait(W.ctx)) return wfail("mult_rows_wait");
+                ingest(pk, ks); host_dense = true; host_rows = true;
+            }
             dev_state = false; mult_rows_current = true;
         }
         timers[T_POSTERIOR] += now_s() - t0;
