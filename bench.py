@@ -231,11 +231,16 @@ def steady_state(pkg, host, torch, prior_kind, prior, X, y, K, steps, settle=30,
     wk.set_timing(False)                 # the timed loop runs as fit / dp_parallel run it: no timing events between the kernels
     sw, st, ks = [], [], []
     t_before = dict(s.timers)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        s.group_step(False, False)
-    wk.sync()
-    el = time.perf_counter() - t0
+    # five back-to-back blocks of `steps` steps, the MEDIAN block reported: a leg of 100 steps of 0.4 ms is a 40 ms window, and one host
+    # hiccup of a millisecond in it is 2.5 % (the legs ran 3 % slower here than the same shapes through scripts/config_step.py)
+    blocks = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            s.group_step(False, False)
+        wk.sync()
+        blocks.append(time.perf_counter() - t0)
+    el = float(np.median(blocks))
     t_after = dict(s.timers)
     work = wk.last_sweep_work() if prior_kind == pkg.PRIOR_NIW else None
     wk.set_timing(True)
@@ -248,7 +253,8 @@ def steady_state(pkg, host, torch, prior_kind, prior, X, y, K, steps, settle=30,
     nmi, _ = sampler_mod.nmi_vi_from_contingency(C)
     out = {"n": int(N), "D": int(D), "K_t": float(np.mean(ks)), "steps": steps, "ms_per_step": 1e3 * el / steps, "it_per_s": steps / el,
            "sweep_kernel_ms": float(np.mean(sw)), "stats_kernels_ms": float(np.mean(st)), "nmi_vs_generator": float(nmi),
-           "host_ms_per_step": {k: round(1e3 * (t_after[k] - t_before[k]) / steps, 4) for k in t_after if t_after[k] - t_before[k] > 0}}
+           "ms_per_step_blocks": [round(1e3 * b / steps, 4) for b in blocks],
+           "host_ms_per_step": {k: round(1e3 * (t_after[k] - t_before[k]) / (5 * steps), 4) for k in t_after if t_after[k] - t_before[k] > 0}}
     wk.close()
     return out, work
 
