@@ -169,7 +169,7 @@ def test_shard_invariance(pkg):
 
 
 @pytest.mark.parametrize("D,n,K", [(2, 1000, 5), (3, 5000, 4), (16, 4000, 3), (40, 3000, 5), (64, 30000, 8),
-                                   (128, 5000, 4), (200, 3000, 3), (256, 4000, 2)])
+                                   (128, 5000, 4), (200, 3000, 3), (256, 4000, 2), (2, 30000, 600)])     # K = 600: more than 1024 bins (one sort tile per workgroup)
 def test_suffstats_vs_oracle(pkg, D, n, K):
     rng = np.random.default_rng(D + n)
     X = (rng.normal(size=(n, D)) * 2 + rng.normal(size=D) * 5).astype(np.float32)
@@ -201,6 +201,14 @@ def test_suffstats_vs_oracle(pkg, D, n, K):
             assert not N2[k].any() and not S2[k].any()
     # run-to-run bitwise reproducibility
     assert np.array_equal(wk.suffstats_packed(), wk.suffstats_packed())
+    # the per-step pass (histogram with running totals, bad-cluster flags, derived rows) returns the same rows when nothing is reset: a
+    # cluster is flagged when one of its sub-clusters is empty, and a flagged cluster WITH points has its sub-labels re-drawn
+    flagged_with_points = [(oN[k, 1] == 0) != (oN[k, 2] == 0) for k in range(K)]
+    if not any(flagged_with_points):
+        full = wk.suffstats_packed()
+        rows, bad = wk.step_stats(7)
+        assert np.array_equal(bad != 0, (oN[:, 1] == 0) | (oN[:, 2] == 0))
+        np.testing.assert_allclose(rows, full, rtol=1e-12, atol=1e-9)
     wk.close()
 
 
