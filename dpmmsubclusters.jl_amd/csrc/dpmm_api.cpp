@@ -1127,6 +1127,10 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
             a.bf16scr = (c->opt_bf16scr && c->NB == 4 && a.tail != nullptr) ? 1 : 0;
             if (c->sp_ready && a.bf16scr && !table && !final_argmax) { c->sp_last = true; /* (the conditions of launch_direct's DIR instantiation: K <= 64 fits the LDS table) */ a.sp_frag = c->d_sp_frag; a.sp_cons = c->d_sp_cons; if (c->opt_direction > 0 || c->sp_count % 32u != 1u) a.bf16scr |= 2; }
             a.need = (table || c->opt_direction == 0) ? nullptr : c->h_need;
+            // the visiting order is set BEFORE the bracket launch: its tiles and thresholds are indexed by visiting position and
+            // must be those the sweep walks (a bracket computed in storage order would hand a point another point's threshold)
+            a.order = (!table && c->have_perm && !no_order) ? c->sb.perm : nullptr;
+            a.order_total = c->sb.perm_total;
             if (c->have_refb_big && a.tail != nullptr && !table && a.bracket && a.use_prev && a.screen_margin > 0.f && !final_argmax) {
                 // D = 128, 256: the reference bracket as a launch of its own in front of the sweep (niw_bracket_big_kernel): per tile whether all
                 // its points were in one cluster, per point the lower end of a certified bracket of that cluster's value
@@ -1138,8 +1142,6 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
                 HIPCHK(c, launch_niw_bracket_big(c->NB, a, c->d_refb_big, c->d_brk_flag, c->d_brk_aref, c->stream));
                 a.sp_frag = c->d_brk_flag; a.sp_cons = c->d_brk_aref;
             }
-            a.order = (!table && c->have_perm && !no_order) ? c->sb.perm : nullptr;
-            a.order_total = c->sb.perm_total;
             a.work = table ? nullptr : c->d_work;
             if (!table) { c->work_waves = std::max(c->work_waves, 4 * c->sweep_grid); c->work_launches += 1; }
             a.prio = c->opt_prio;

@@ -44,7 +44,7 @@ struct NiwSweepArgs {
     int bf16scr;              // bit 0: D in 33..64 with tail records: bf16 screens in front of the Float32 16-row screen and of every survivor's first row block (DPMM_OPT_BF16_SCREENS);
                               // bit 1 (with sp_frag): the direction screen runs in FRONT of the tail-pair tests (the sweeps between two measuring ones).
                               // (A field of its own for bit 1 cost the common kernel 32 spilled registers: the argument block's size decides how the compiler lays out its scalars.)
-    int bracket;              // 1: D in 49..64, homogeneous waves: certified bf16 bracket of the reference cluster's value first; its Float32 evaluation only if a cluster survives the screens (bf16 images behind the ball records)
+    int bracket;              // 1: D in 33..64, homogeneous waves: certified bf16 bracket of the reference cluster's value first; its Float32 evaluation only if a cluster survives the screens (bf16 images behind the ball records)
     const float *lam;         // [K] lower bounds of lambda_min(Sigma_k^-1) (null: no scalar pre-screen)
     const float *mdist;       // [K][K] distances between the cluster means
     int screen_lds;           // set by the launcher: screen operands of all K clusters are staged in LDS

@@ -194,7 +194,7 @@ __device__ __forceinline__ unsigned long long ball_far(const float *tail, int K,
     return __ballot(j < K && ub < B.thr);
 }
 
-// Reference BRACKET (D in 49 .. 64).  On a wave whose points all carried label k0 the cluster-level value a_k0(x) = cst - q(x) / 2,
+// Reference BRACKET (D in 33 .. 64).  On a wave whose points all carried label k0 the cluster-level value a_k0(x) = cst - q(x) / 2,
 // q = |R (x - mu)|^2, usually decides nothing: every other cluster is excluded by the screens and the draw returns k0 whatever the value
 // is.  The screens only need a LOWER bound of it.  Two bf16 matrix passes give a certified one at ~1/7 of the Float32 evaluation's cycles:
 //   y^ = R~ z~ (R~, z~ = bf16 round-to-nearest-even of R and of the Float32 z = x - mu; bf16 products are exact in the Float32
@@ -1953,11 +1953,12 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
         while (kcur >= 0) {
             const int knext = next_label();
             const int jl = 3 * kcur + 1, jr = jl + 1, jn = 3 * (knext >= 0 ? knext : 0) + 1;
+            const float cl = A.cst[jl], cr = A.cst[jr];      // (requested in front of the evaluations: fetched behind them, each was an exposed L2 round trip)
             const float bl = __builtin_fmaf(-0.5f, quad_stream<NB, NG>(A.Rp + (size_t)jl * MATSZ, A.Rp + (size_t)jr * MATSZ,
-                                                                          A.mup + (size_t)jr * DP, rb0, mu, x, lane, g, true, tot_all, A.prio), A.cst[jl]);
+                                                                          A.mup + (size_t)jr * DP, rb0, mu, x, lane, g, true, tot_all, A.prio), cl);
             const float br = __builtin_fmaf(-0.5f, quad_stream<NB, NG>(A.Rp + (size_t)jr * MATSZ,
                                                                           knext >= 0 ? A.Rp + (size_t)jn * MATSZ : nullptr,
-                                                                          A.mup + (size_t)jn * DP, rb0, mu, x, lane, g, true, tot_all, A.prio), A.cst[jr]);
+                                                                          A.mup + (size_t)jn * DP, rb0, mu, x, lane, g, true, tot_all, A.prio), cr);
             if (valid && z == kcur) { b0 = bl; b1 = br; }
             nw_full += 2;
             kcur = knext;
@@ -2183,7 +2184,7 @@ __global__ void niw_pack_kernel(const float *__restrict__ R, const float *__rest
             } else v = cst[3 * k];
             ball[e] = v;
         }
-        // bf16 image of the cluster-level factors for the reference bracket (refb_map), D in 49 .. 64 only
+        // bf16 image of the cluster-level factors for the reference bracket (refb_map), D in 33 .. 64 only (NB = 4)
         if (NB == 4) {
             uint32_t *refb = reinterpret_cast<uint32_t *>(ball + 16 * (size_t)K);
             for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)K * REFB_WORDS; e += (int64_t)gridDim.x * blockDim.x) {

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DPMM_ABI_VERSION 2
+#define DPMM_ABI_VERSION 3   /* 3 (round 5): dpmm_last_sweep_work fills 16 words (was 8 in version 2), DPMM_OPT_NOISE_AHEAD's -1 = automatic, options 18..25 */
 
 typedef struct dpmm_ctx dpmm_ctx;
 
@@ -75,7 +75,7 @@ enum {
                                          0.383, nothing at N = 1e7); 0 = every draw kernel generates its own: one stream, no cross-stream dependency;
                                          -1 (default) = 1 for D >= 128 or fewer than 4e6 points on this worker, else 0;
                                          same draws either way */
-    DPMM_OPT_REF_BRACKET = 18,        /* 1 (default): D in 49..64 sweep, waves whose points all had the same label (D in 65..256: 128-point tiles, in a launch of its own
+    DPMM_OPT_REF_BRACKET = 18,        /* 1 (default): D in 33..64 sweep, waves whose points all had the same label (D in 65..256: 128-point tiles, in a launch of its own
                                          in front of the sweep): the reference cluster's value is first BRACKETED
                                          (two bf16 matrix passes with a certified rounding bound, ~1/7 of a Float32 evaluation) and evaluated in Float32 only
                                          if some other cluster survives the screens against the bracket's lower end; same labels; 0: always evaluated */

@@ -6,7 +6,7 @@
 # Julia process per GPU.  Everything inside a sweep is ONE ccall: dpmmh_group_step (include/dpmm_host.h), which drives libdpmmhip.so
 # (include/dpmm_hip.h, dpmm_hip_master.h) through a table of C function pointers.
 #
-# UNEXECUTED: the build image has no Julia.  Written against DPMMH_ABI_VERSION 5 / DPMM_ABI_VERSION 2; the same call sequence runs end to
+# UNEXECUTED: the build image has no Julia.  Written against DPMMH_ABI_VERSION 5 / DPMM_ABI_VERSION 3; the same call sequence runs end to
 # end through the ctypes binding (dpmmsubclusters.jl_amd/host/engine.py), and tests/test_integration_layout.py checks this file
 # mechanically: every symbol it names is exported, the WorkerTable has the members of struct dpmmh_worker in header order, every ccall
 # passes as many arguments as its C prototype declares.

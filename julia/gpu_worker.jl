@@ -5,7 +5,7 @@
 # This is the DROP-IN surface of include/dpmm_hip.h alone (no dpmm_hip_master.h, no debug entry): parameters in the reference's own
 # thin_cluster_params form, statistics back in the reference's thin_suff_stats form.
 #
-# UNEXECUTED: the build image has no Julia.  Written against DPMM_ABI_VERSION 2; tests/test_integration_layout.py parses this file: the
+# UNEXECUTED: the build image has no Julia.  Written against DPMM_ABI_VERSION 3; tests/test_integration_layout.py parses this file: the
 # array comprehensions of set_params! are emulated and compared with the ABI's memory layouts, every symbol is checked against the
 # header, every ccall's argument count against its C prototype.
 const libdpmm = "libdpmmhip.so"          # on LD_LIBRARY_PATH / dlopen path

@@ -52,7 +52,7 @@ def test_library_exports_every_declared_symbol(pkg):
     for name in declared_functions():
         assert hasattr(lib, name), name
     lib.dpmm_abi_version.restype = ctypes.c_int
-    assert lib.dpmm_abi_version() == 2
+    assert lib.dpmm_abi_version() == 3
 
 
 def test_host_library_exports_every_declared_symbol(pkg):

@@ -430,7 +430,7 @@ def test_work_counters_accumulate_until_read(pkg):
                                      (128, 40.0, 6), (128, 0.8, 5), (100, 40.0, 6), (256, 40.0, 5), (256, 1.0, 4), (200, 3.0, 5),
                                      (64, 40.0, 2), (64, 0.5, 2), (32, 40.0, 2), (256, 40.0, 2), (16, 3.0, 2)])
 def test_reference_bracket_does_not_change_labels(pkg, D, sep, K):
-    """DPMM_OPT_REF_BRACKET (D in 49 .. 64; D in 65 .. 256 as a launch of its own per 128-point tile): on a wave whose points all carried the same label the reference cluster's value is first
+    """DPMM_OPT_REF_BRACKET (D in 33 .. 64; D in 65 .. 256 as a launch of its own per 128-point tile): on a wave whose points all carried the same label the reference cluster's value is first
     bracketed with two bf16 matrix passes and a certified rounding bound; its Float32 evaluation runs only if another cluster survives the
     screens against the bracket's lower end.  Labels and sub-labels must be those of the always-evaluate kernel, bit for bit -- on separated
     clusters (the evaluation is skipped on most waves: fewer full evaluations are counted) and on overlapping ones (survivors: the exact
@@ -465,8 +465,57 @@ def test_reference_bracket_does_not_change_labels(pkg, D, sep, K):
     f1, f0 = out[1][1]["full_evals"], out[0][1]["full_evals"]
     print(f"D={D} sep={sep} K={K}: full evaluations per wave tile {f1 / out[1][1]['wave_tiles']:.2f} with the bracket, {f0 / out[0][1]['wave_tiles']:.2f} without")
     assert f1 <= f0
-    if sep >= 40.0 and D >= 49:                       # (below D = 49 there is no bracket: the option changes nothing)
+    if sep >= 40.0 and D >= 33:                       # (D <= 32 has no bracket: the option changes nothing there)
         assert f1 < 0.8 * f0
+
+
+@pytest.mark.parametrize("D", [128, 256, 100])
+def test_big_bracket_follows_the_visiting_order(pkg, D):
+    """D = 65 .. 256: niw_bracket_big_kernel writes one flag per 128-point tile and one threshold per POSITION of the visiting order, and the
+    sweep reads them by position -- both launches must walk the same order.  (Round 4 launched the bracket before the sweep's order was
+    set: thresholds in storage order, read in bin-sorted order.)  The case that exposes it: storage order shuffled, EVERY point labelled
+    cluster 1 (one dominant cluster over two components, as early in a chain), component B several sd out in cluster 1's tail and tightly
+    fitted by cluster 2, the sweep run behind a statistics pass (perm != identity).  A tail point that receives a central point's threshold
+    excludes cluster 2 and is forced to k0 without an evaluation.  Labels must be bit-equal with the bracket on and off and equal to the
+    oracle's draw on the kernel's own table (sample_labels_worker!, local_clusters_actions.jl:112-134)."""
+    from dpmmsubclusters_jl_amd import binding
+    rng = np.random.default_rng(900 + D)
+    n, K = 16384 + 77, 2
+    mus = np.zeros((3 * K, D)); Sig = np.empty((3 * K, D, D))
+    shift = np.zeros(D); shift[: D // 2] = 6.0 / np.sqrt(D // 2) * 3.0      # component B: 6 sd (x3 on the broad cluster's scale) away from cluster 1's mean
+    mus[3:6] = shift
+    for j in range(3 * K):
+        d = rng.normal(size=D) * 0.05
+        mus[j] += d if j % 3 else 0.0
+        Sig[j] = np.eye(D) * (9.0 if j < 3 else 0.04)                         # cluster 1 broad (sd 3), cluster 2 tight (sd 0.2)
+    invS = np.linalg.inv(Sig); logdet = np.linalg.slogdet(Sig)[1]
+    comp = (rng.random(n) < 0.35).astype(np.int64)                            # shuffled storage order: components interleaved
+    X = np.where(comp[:, None] == 0, rng.normal(size=(n, D)) * 3.0, shift + rng.normal(size=(n, D)) * 0.2).astype(np.float32)
+    w = np.array([0.6, 0.4], np.float32); lr = np.full((K, 2), 0.5, np.float32)
+    args = (mus.astype(np.float32), invS.reshape(3 * K, -1).astype(np.float32), logdet.astype(np.float32), lr, w)
+    out = {}
+    for br in (1, 0):
+        wk = pkg.Worker(pkg.PRIOR_NIW, D, n, first_index=0, device=0, seed=33)
+        wk.upload_points(X)
+        wk.set_option(binding.OPT_REF_BRACKET, br)
+        wk.set_params_niw(*args)
+        wk.set_labels(np.ones(n, np.int64), 1 + (rng.permutation(n) & 1) if br else out["sub0"])
+        if br: out["sub0"] = wk.get_labels()[1]
+        wk.suffstats_packed(None)                                             # perm: sub-label 1 first, then sub-label 2 -- not the identity
+        wk.set_params_niw(*args)
+        wk.sweep(3)
+        lab, sub = wk.get_labels()
+        if br:
+            tab = wk.debug_loglik()
+            u0, u1 = orc.uniforms(33, 3, 0, 0, n)
+            want = orc.sample_log_cat(tab, u0)
+            bad = np.flatnonzero(want != lab)
+            assert len(bad) == 0, (len(bad), comp[bad][:10], lab[bad][:10])
+            assert_sublabels_bit_exact(wk, lab, sub, u1)
+            assert (lab[comp == 1] == 2).mean() > 0.99                         # the tail component moves to the cluster that fits it
+        out[br] = (lab, sub)
+        wk.close()
+    assert np.array_equal(out[1][0], out[0][0]) and np.array_equal(out[1][1], out[0][1])
 
 
 def _below_bf16_midpoint(rng, shape, lo_exp, hi_exp, worst=0.5):
