@@ -256,10 +256,19 @@ struct dpmm_ctx {
     int64_t comm_calls = 0;            // all-reduces since the communicator was attached
     // Bounded waits behind a collective (RCCL transport; DPMM_OPT_COMM_TIMEOUT_MS): a rank that dies between two all-reduces leaves the
     // others inside an RCCL kernel that never ends -- and the reference has the same flaw (its master waits on `fetch`).
-    // A watchdog thread per communicator measures how long the host has been blocked on the ctx stream; past the deadline it aborts
-    // the communicator (ncclCommAbort: the kernel returns), the blocked call comes back, sees `comm_aborted` and fails with DPMM_ECOMM --
-    // on every surviving rank -- instead of hanging until somebody kills the job.  The host transport's callback owns its own time-out.
-    int comm_timeout_ms = 120000;
+    // A watchdog thread per communicator measures how long the host has been blocked on the ctx stream BEHIND AN ENQUEUED COLLECTIVE
+    // (`coll_pending`: set when an all-reduce is enqueued, cleared when a wait for the whole stream has returned -- waits on a stream that
+    // holds no collective, e.g. an upload or a checkpoint, are never timed); past the deadline it aborts the communicator (ncclCommAbort:
+    // the kernel returns), the blocked call comes back and fails with DPMM_ECOMM -- on every surviving rank -- instead of hanging until
+    // somebody kills the job.  A peer that is merely SLOW (a long host-side pause between two steps) looks the same from here as one that
+    // is gone, and the reference would simply wait: the default limit is therefore half an hour, far beyond any pause of a healthy job.
+    // `wd_wait_since` is written, and the abort performed, under `wd_mu`: the host thread that comes back from its wait either clears the
+    // mark before the watchdog looks, or finds the communicator aborted -- it never enqueues on a communicator that is being aborted.
+    // After an abort only the collectives refuse (DPMM_ECOMM); entry points that use none (dpmm_get_labels, dpmm_sync) keep working, so
+    // that the state can still be saved.  The host transport's callback owns its own time-out.
+    int comm_timeout_ms = 1800000;
+    bool coll_pending = false;         // an RCCL collective was enqueued and no full wait on the ctx stream has returned since
+    bool abort_reported = false;       // the call that was blocked when the watchdog fired has returned DPMM_ECOMM
     std::thread *watchdog = nullptr;
     std::mutex wd_mu;
     std::condition_variable wd_cv;
@@ -287,7 +296,7 @@ static inline double now_ms() {
             const double dt__ = now_ms() - t0__;                                                        \
             if (dt__ > 5.0) fprintf(stderr, "[dpmm slow] %.2f ms in %s (line %d)\n", dt__, #expr, __LINE__); \
         }                                                                                               \
-        if ((ctx)->comm_aborted.load(std::memory_order_relaxed)) {                                       \
+        if (e__ == hipErrorLaunchTimeOut && (ctx)->comm_aborted.load(std::memory_order_relaxed)) {      /* (sync_stream / sync_event: the watchdog fired during this wait) */ \
             (ctx)->err = "collective timed out: a peer rank is gone or stuck (communicator aborted after DPMM_OPT_COMM_TIMEOUT_MS)"; \
             return DPMM_ECOMM;                                                                          \
         }                                                                                               \
@@ -301,19 +310,31 @@ static inline int64_t steady_ms() {
     return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 // Blocking waits on the ctx stream go through these two: with an RCCL communicator attached the watchdog sees how long they last.
+static inline void wd_arm(dpmm_ctx *c) {
+    std::lock_guard<std::mutex> lk(c->wd_mu);
+    c->wd_wait_since.store(steady_ms() | 1, std::memory_order_relaxed);
+}
+// true: the watchdog aborted the communicator while this wait was armed (reported once, by the call that was blocked)
+static inline bool wd_disarm(dpmm_ctx *c) {
+    std::lock_guard<std::mutex> lk(c->wd_mu);      // (an abort in progress finishes first: the caller then sees it)
+    c->wd_wait_since.store(0, std::memory_order_relaxed);
+    if (c->comm_aborted.load() && !c->abort_reported) { c->abort_reported = true; return true; }
+    return false;
+}
 static inline hipError_t sync_stream(dpmm_ctx *c, hipStream_t st) {
     if (st == c->stream) c->sync_gen += 1;        // (everything queued on the main stream so far has run when this returns)
-    if (!c->watchdog) return hipStreamSynchronize(st);
-    c->wd_wait_since.store(steady_ms() | 1, std::memory_order_relaxed);
-    const hipError_t e = hipStreamSynchronize(st);
-    c->wd_wait_since.store(0, std::memory_order_relaxed);
+    if (!c->watchdog || !c->coll_pending) return hipStreamSynchronize(st);
+    wd_arm(c);
+    hipError_t e = hipStreamSynchronize(st);
+    if (wd_disarm(c)) e = hipErrorLaunchTimeOut;
+    else if (e == hipSuccess && st == c->stream) c->coll_pending = false;      // the stream is empty: no collective left on it
     return e;
 }
 static inline hipError_t sync_event(dpmm_ctx *c, hipEvent_t ev) {
-    if (!c->watchdog) return hipEventSynchronize(ev);
-    c->wd_wait_since.store(steady_ms() | 1, std::memory_order_relaxed);
-    const hipError_t e = hipEventSynchronize(ev);
-    c->wd_wait_since.store(0, std::memory_order_relaxed);
+    if (!c->watchdog || !c->coll_pending) return hipEventSynchronize(ev);
+    wd_arm(c);
+    hipError_t e = hipEventSynchronize(ev);
+    if (wd_disarm(c)) e = hipErrorLaunchTimeOut;
     return e;
 }
 
@@ -385,8 +406,10 @@ static int comm_allreduce(dpmm_ctx *c, void *dbuf, size_t count, int kind) {
     }
     if (c->comm) {
         Rccl &r = rccl();
+        if (c->comm_aborted.load()) return fail(c, DPMM_ECOMM, "the communicator was aborted after a collective timed out: attach a new one (dpmm_comm_release, dpmm_comm_init)");
         const int rc = r.AllReduce(dbuf, dbuf, count, f64 ? kNcclFloat64 : kNcclInt64, kNcclSum, c->comm, c->stream);
         if (rc != 0) return fail(c, DPMM_ECOMM, std::string("ncclAllReduce: ") + r.GetErrorString(rc));
+        c->coll_pending = true;
     } else {
         const size_t bytes = count * 8;
         if (bytes > c->h_red_bytes) {
@@ -439,6 +462,7 @@ static void comm_release(dpmm_ctx *c) {
     watchdog_stop(c);
     if (c->comm) { if (!c->comm_aborted.load()) rccl().CommDestroy(c->comm); c->comm = nullptr; }      // (ncclCommAbort released an aborted one)
     c->comm_aborted.store(false);
+    c->coll_pending = false; c->abort_reported = false;
     c->host_fn = nullptr; c->host_user = nullptr;
     c->world = 1; c->rank = 0;
     c->have_comm_ev[0] = c->have_comm_ev[1] = false;
@@ -578,7 +602,7 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
     // times as many waves of a quarter of the trips each), 2048 above; the tables are sized for whichever is in use (DPMM_OPT_SORT_TILE
     // may switch while the shard is small enough for the small tile's tables)
     c->sb.tile = n_local <= 4000000 ? SORT_TILE_SMALL : SORT_TILE;
-    const int alloc_tile = n_local <= 16000000 ? SORT_TILE_SMALL : SORT_TILE;
+    const int alloc_tile = c->sb.tile;           // (DPMM_OPT_SORT_TILE re-allocates when it selects the smaller tile: at N = 1e7 the small tile's tables are 320 MB, these 80 MB)
     c->sort_tile_min = alloc_tile;
     c->nt_sort = (int)((n_local + alloc_tile - 1) / alloc_tile);
     const size_t nbmax = 2 * DPMM_MAX_CLUSTERS;
@@ -985,6 +1009,7 @@ static int direction_tables(dpmm_ctx *c, int K) {
             if (v & 0x8000u) { many_ub += v >> 16; tiles_ub += v & 0x7FFFu; } else { many += v >> 16; tiles += v & 0x7FFFu; }
             if (c->sp_last) { const uint32_t y = c->h_need[2 * w + 1]; given += y & 0xFFFFu; removed += y >> 16; }
         }
+        memset(c->h_need, 0, sizeof(uint32_t) * 2 * (size_t)nw);      // (read once: a later launch on a smaller grid, or one that does not count, leaves zeros -- "no tiles")
         // (break-even measured on the growth run: at 4.3 candidates per tile the screen costs 3 % of the step, at 28 it saves a third)
         if (tiles > 0) c->sp_regime = c->sp_regime ? (many >= tiles * 4) : (many >= tiles * 8);
         else if (tiles_ub > 0 && many_ub < tiles_ub * 4) c->sp_regime = false;        // even the upper bound is below the switch-off level
@@ -1125,7 +1150,7 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
             a.ball = c->opt_ball;
             a.bracket = c->opt_bracket;
             a.bf16scr = (c->opt_bf16scr && c->NB == 4 && a.tail != nullptr) ? 1 : 0;
-            if (c->sp_ready && a.bf16scr && !table && !final_argmax) { c->sp_last = true; /* (the conditions of launch_direct's DIR instantiation: K <= 64 fits the LDS table) */ a.sp_frag = c->d_sp_frag; a.sp_cons = c->d_sp_cons; if (c->opt_direction > 0 || c->sp_count % 32u != 1u) a.bf16scr |= 2; }
+            if (c->sp_ready && a.bf16scr && !table && !final_argmax) { c->sp_last = a.lam == nullptr && a.tdf == nullptr && a.screen_margin > 0.f && c->K > 1 && c->K <= SP_MAXK; /* (exactly the conditions of launch_direct's DIR instantiation -- the kernel that writes the yield words; K <= 64 fits the LDS table) */ a.sp_frag = c->d_sp_frag; a.sp_cons = c->d_sp_cons; if (c->opt_direction > 0 || c->sp_count % 32u != 1u) a.bf16scr |= 2; }
             a.need = (table || c->opt_direction == 0) ? nullptr : c->h_need;
             // the visiting order is set BEFORE the bracket launch: its tiles and thresholds are indexed by visiting position and
             // must be those the sweep walks (a bracket computed in storage order would hand a point another point's threshold)
@@ -2510,7 +2535,19 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
         case DPMM_OPT_SORT_TILE: {
             const int t = (int)value;
             if (t != SORT_TILE && t != SORT_TILE_SMALL) return fail(c, DPMM_EINVAL, "DPMM_OPT_SORT_TILE: 512 or 2048");
-            if (t < c->sort_tile_min) return fail(c, DPMM_ELIMIT, "DPMM_OPT_SORT_TILE: the sort tables of this shard hold 2048-point tiles only");
+            if (t < c->sort_tile_min) {          // tables for the smaller tile: allocated when asked for (behind everything that still reads the old ones)
+                if (c->n > 16000000) return fail(c, DPMM_ELIMIT, "DPMM_OPT_SORT_TILE: 512-point tiles are limited to shards of 16e6 points");
+                HIPCHK(c, hipSetDevice(c->device));
+                HIPCHK(c, sync_stream(c, c->stream));
+                const int nt = (int)((c->n + t - 1) / t);
+                const size_t nbmax = 2 * DPMM_MAX_CLUSTERS;
+                int32_t *th = nullptr, *tc = nullptr;
+                HIPCHK(c, hipMalloc(&th, sizeof(int32_t) * nbmax * (size_t)std::max(1, nt)));
+                if (hipMalloc(&tc, sizeof(int32_t) * nbmax * (size_t)std::max(1, nt)) != hipSuccess) { hipFree(th); return fail(c, DPMM_EHIP, "DPMM_OPT_SORT_TILE: out of device memory for the 512-point tile tables"); }
+                hipFree(c->sb.tile_hist); hipFree(c->sb.tile_cnt);
+                c->sb.tile_hist = th; c->sb.tile_cnt = tc;
+                c->nt_sort = nt; c->sort_tile_min = t;
+            }
             c->sb.tile = t; return DPMM_OK;          // (the tile tables are rebuilt by every pass; perm stays a valid order)
         }
         case DPMM_OPT_KERNEL_TIMING:

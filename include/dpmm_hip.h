@@ -80,8 +80,11 @@ enum {
                                          (two bf16 matrix passes with a certified rounding bound, ~1/7 of a Float32 evaluation) and evaluated in Float32 only
                                          if some other cluster survives the screens against the bracket's lower end; same labels; 0: always evaluated */
     DPMM_OPT_SORT_TILE = 19,          /* points per sorting wave of the statistics passes: 512 (default below 4e6 points per shard) or 2048 */
-    DPMM_OPT_COMM_TIMEOUT_MS = 22,    /* RCCL transport: the longest a host call may block on the ctx stream behind a collective (default 120 000 ms; 0: for ever).
-                                         Past it a watchdog aborts the communicator and the call -- on every surviving rank -- fails with DPMM_ECOMM */
+    DPMM_OPT_COMM_TIMEOUT_MS = 22,    /* RCCL transport: the longest a host call may block on the ctx stream behind a collective (default 1 800 000 ms = half an hour -- a peer that
+                                         pauses on its host looks like a dead one from here, and the reference would wait; 0: for ever).  Only waits on a stream that holds
+                                         an enqueued collective are timed.  Past the limit a watchdog aborts the communicator and the blocked call -- on every surviving
+                                         rank -- fails with DPMM_ECOMM; later collectives refuse with DPMM_ECOMM until dpmm_comm_release, calls without a collective
+                                         (dpmm_get_labels, dpmm_sync) keep working */
     DPMM_OPT_F32_STATS = 24,          /* 0 (default): sufficient statistics in Float64 throughout, as the reference (priors/niw.jl:42-51).  1: NIW, D <= 64, the per-step pass:
                                          the second moments of x - mu_k (the cluster's current mean) on the Float32 matrix cores, 64 points at a time, the
                                          64-point sums added -- and the shift undone -- in Float64: the statistics kernel runs at twice its Float64 rate, the
