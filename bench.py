@@ -10,8 +10,8 @@ upload, initial labels, burn-in until the split/merge gates are open) is outside
 region, as in the reference.
 
 Strong scaling: the N points are fixed and shard over the ranks by contiguous column ranges;
-the data-path collective is the all-reduce of the packed sufficient statistics inside libdpmmhip.so (preceded by the
-all-reduce of the 2K Int64 sub-cluster occupancies that decides the bad-cluster reset).
+the data-path collective is ONE all-reduce per step inside libdpmmhip.so: 3K packed rows of sufficient statistics (the 2K rows of the
+labels as swept + K re-drawn left rows of the clusters a shard reset speculatively; the bad-cluster verdict is read off the reduced rows).
 
 Launch: `python bench.py --gpus N --steps K --warmup W`.  With N > 1 and no launcher in the environment (WORLD_SIZE unset) the
 script starts `python -m torch.distributed.run --nproc-per-node N` on itself as a CHILD process before anything touches the GPU
@@ -23,12 +23,13 @@ Besides the contract fields the JSON line carries
                 (exceeds the peak because exact cluster screening skips work), `frac` = EXECUTED flops / time / peak with the
                 executed work counted ON THE DEVICE in the timed launches (dpmm_last_sweep_work), `dense_*` = the same
                 kernel with screening switched off (every cluster evaluated in full) in the same process;
-  comm          what the collective saw: world, transport, bytes per all-reduce, HIP-event time of the two all-reduces per step;
+  comm          what the collective saw: world, transport, bytes per all-reduce, all-reduces per step in the timed block (1.0), their HIP-event time;
   blocks        min / median / max it/s over repeated blocks of `--steps` steps (the headline `value` is the first block);
   growth        a run of the same data from ONE initial cluster (`init_clusters=1`): it/s, K history, final log-posterior, NMI;
   legs          (1 GPU only; `--no-legs` skips) short steady-state runs of the other shapes, each with its own roofline entry:
                 `overlap_var4` / `overlap_var1` (the headline shape with the component means drawn with MixtureVar 4 and 1
-                instead of 100: the middle of the screening range), `k256` (256 components instead of 32), `c2` (N=10^6), `c3_shard` (what each of
+                instead of 100: the middle of the screening range), `inseparable` (the sweep kernel alone on 32 clusters whose means are 0.4 of a
+                component's standard deviation apart: no screen can exclude anything -- the worst case, next to the dense leg), `k256` (256 components instead of 32), `c2` (N=10^6), `c3_shard` (what each of
                 8 GPUs holds of the headline),
                 `c4` (Multinomial D=1000, N=10^6), `c5_shard` (NIW D=256, n=6.25e5), and `shard8_projection`;
   cpu_baseline  the reference algorithm's worker path on the host cores, P worker processes (see oracle/cpu_baseline.py).
@@ -69,7 +70,7 @@ def parse_args():
     ap.add_argument("--no-dense", action="store_true")
     ap.add_argument("--no-host-master", action="store_true", help="skip the leg with the master's maths on the host")
     ap.add_argument("--no-legs", action="store_true", help="skip the other-shape legs (overlap, c3_shard, c4, c5_shard)")
-    ap.add_argument("--legs", default="overlap_var4,overlap_var1,k256,c2,c3_shard,c4,c5_shard", help="comma-separated subset of the legs")
+    ap.add_argument("--legs", default="overlap_var4,overlap_var1,inseparable,k256,c2,c3_shard,c4,c5_shard", help="comma-separated subset of the legs")
     ap.add_argument("--growth-iters", type=int, default=260)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-clock budget of the CPU baseline sample")
     ap.add_argument("--worker-opt", action="append", default=[], metavar="ID=VALUE",
@@ -259,6 +260,63 @@ def steady_state(pkg, host, torch, prior_kind, prior, X, y, K, steps, settle=30,
     return out, work
 
 
+def inseparable_leg(pkg, torch, n, D, K, sep=0.4, cond=10.0):
+    """The screening's worst case as a driver-run number: the sweep kernel on K clusters that no bound separates -- means sep = 0.4 standard
+    deviations apart, covariances with a spectrum spread of `cond` in random rotations (the regime of scripts/fuzz_screens.py's cases 5, 10, 17:
+    33-46 evaluations per tile of K = 25-42) -- with FIXED parameters (a chain would merge such clusters away), previous labels = the generating
+    components, bin-sorted visiting order.  Reports the sweep kernel's launch time (HIP events), evaluations per tile and the executed fraction."""
+    rng = np.random.default_rng([DATA_SEED, 11])
+    mus = rng.normal(size=(3 * K, D)) * sep
+    for k in range(K):
+        d = rng.normal(size=D) * 0.4
+        mus[3 * k + 1] = mus[3 * k] + d; mus[3 * k + 2] = mus[3 * k] - d
+    Sig = np.empty((3 * K, D, D))
+    for j in range(3 * K):
+        Q, _ = np.linalg.qr(rng.normal(size=(D, D)))
+        ev = np.exp(rng.uniform(-0.5 * np.log(cond), 0.5 * np.log(cond), D))
+        Sig[j] = (Q * ev) @ Q.T
+    invS = np.linalg.inv(Sig); invS = 0.5 * (invS + invS.transpose(0, 2, 1))
+    logdet = np.linalg.slogdet(Sig)[1]
+    sizes = np.full(K, n // K); sizes[: n - sizes.sum()] += 1
+    g = torch.Generator(device="cuda"); g.manual_seed(DATA_SEED + 11)
+    X = torch.randn((n, D), generator=g, device="cuda", dtype=torch.float32)
+    a = 0
+    for k in range(K):
+        b = a + int(sizes[k])
+        Lk = torch.from_numpy(np.linalg.cholesky(Sig[3 * k]).astype(np.float32)).cuda()
+        X[a:b] = X[a:b] @ Lk.T + torch.from_numpy(mus[3 * k].astype(np.float32)).cuda()
+        a = b
+    z = np.repeat(np.arange(1, K + 1), sizes).astype(np.int64)
+    w = np.full(K, 1.0 / K, np.float32); lr = np.full((K, 2), 0.5, np.float32)
+    par = (mus.astype(np.float32), invS.reshape(3 * K, -1).astype(np.float32), logdet.astype(np.float32), lr, w)
+    wk = pkg.Worker(pkg.PRIOR_NIW, D, n, first_index=0, device=0, seed=SAMPLER_SEED)
+    torch.cuda.synchronize()
+    wk.upload_points_device(X.data_ptr(), X.stride(0))
+    for opt, val in WORKER_OPTS:
+        wk.set_option(opt, val)
+    wk.set_params_niw(*par)
+    wk.set_labels(z, 1 + (np.arange(n) & 1))
+    wk.suffstats_packed(None)
+    wk.set_timing(True)
+    ms = []
+    for ep in range(1, 6):
+        wk.set_params_niw(*par)
+        if ep == 2:
+            wk.last_sweep_work()                  # (counted from the second sweep on: previous labels = the kernel's own draws)
+        wk.sweep(ep); wk.sync()
+        ms.append(wk.last_kernel_ms()[0])
+        wk.suffstats_packed(None)
+    work = wk.last_sweep_work()
+    lab, _ = wk.get_labels()
+    wk.close()
+    sweep_ms = float(np.median(ms[1:]))
+    return {"n": int(n), "D": int(D), "K_t": float(K), "sweep_kernel_ms": sweep_ms, "sweep_kernel_ms_all": [round(v, 3) for v in ms],
+            "labels_kept_fraction": float((lab == z).mean()),
+            "workload": f"sweep kernel alone, NIW D={D} N={n:g} K={K} FIXED parameters: component means {sep} sd apart, covariance spectra spread {cond:g} in random rotations "
+                        "(inseparable clusters: no screen excludes anything)",
+            "roofline": niw_roofline(n, D, float(K), sweep_ms, work)}
+
+
 def niw_roofline(n, D, k_mean, sweep_ms, work):
     flops_alg = 2.0 * n * D * D * (k_mean + 2)
     exe = work["executed_flops"]
@@ -289,6 +347,9 @@ def run_legs(args, pkg, host, torch, one_gpu_ms):
         r["roofline"] = niw_roofline(r["n"], D, r["K_t"], r["sweep_kernel_ms"], work)
         legs[name] = r
         del X
+        torch.cuda.empty_cache()
+    if "inseparable" in want:
+        legs["inseparable"] = inseparable_leg(pkg, torch, 10 ** 7, D, K)
         torch.cuda.empty_cache()
     if "k256" in want:
         Kb = 256
@@ -659,6 +720,9 @@ def main():
         for name in ("overlap_var4", "overlap_var1", "k256", "c2", "c4", "c5_shard"):
             if name in lg:
                 also[name + "_ms_per_step"] = lg[name]["ms_per_step"]
+        if "inseparable" in lg:
+            also["inseparable_sweep_kernel_ms"] = lg["inseparable"]["sweep_kernel_ms"]
+            also["inseparable_full_evals_per_tile"] = lg["inseparable"]["roofline"]["full_evals_per_wave_tile"]
         if "c4" in lg:
             also["c4_traffic_frac"] = lg["c4"]["roofline"].get("traffic_frac")
         out["config"]["also_measured"] = also

@@ -133,14 +133,15 @@ def test_c3_full_size_niw_properties(pkg, host):
 
 
 def test_c4_full_size_multinomial_properties(pkg, host):
+    """BASELINE config 4 at full size: Multinomial D = 1000, N = 1e6, K = 32, data from the reference generator's recipe (generate_mnmm_data,
+    data_generators.jl:59-72: per component Dirichlet(a), a_d ~ U{1..20} with one entry ~ U{30..100}; 100 trials per document) -- the data
+    the bench leg uses.  Conservation (exact integers), and the oracle on three 20 000-point windows with the budgets DESIGN section 5 states
+    for every sweep test: labels max(1, 1e-5 w), sub-labels max(2, 1e-4 w); the measured counts are printed."""
     N, D, K = 10 ** 6, 1000, 32
-    rng = np.random.default_rng(4)
-    P = rng.dirichlet(np.ones(D) * 0.5, size=K)
-    z = rng.integers(0, K, N)
-    X = np.empty((N, D), np.float32)
-    for k in range(K):
-        m = z == k
-        X[m] = rng.multinomial(100, P[k], size=int(m.sum()))
+    x, labels, clusters = host.generate_mnmm_data(N, D, K, 100, seed=4)
+    X = np.ascontiguousarray(x.T); del x
+    z = labels - 1
+    P = clusters.T
     logp = np.log(np.maximum(np.repeat(P, 3, axis=0), 1e-30)).astype(np.float32)
     wk = pkg.Worker(pkg.PRIOR_MULT, D, N, device=0, seed=5)
     wk.upload_points(X)
@@ -156,10 +157,14 @@ def test_c4_full_size_multinomial_properties(pkg, host):
     # the oracle on three 20 000-point windows (draws are independent per point given the parameters)
     logw = np.log(np.full(K, 1.0 / K, np.float32)); loglr = np.log(np.full((K, 2), 0.5, np.float32))
     for lo, hi in ((0, 20000), (N // 2 - 10000, N // 2 + 10000), (N - 20000, N)):
+        w = hi - lo
         olab, osub = orc.sweep_mult(np.ascontiguousarray(X[lo:hi]), D, logp, logw, loglr, 5, 2, lo)
-        assert (lab[lo:hi] != olab).sum() <= 4, (lo, int((lab[lo:hi] != olab).sum()))
+        flips = int((lab[lo:hi] != olab).sum())
         same = lab[lo:hi] == olab
-        assert (sub[lo:hi][same] != osub[same]).sum() <= 20
+        sflips = int((sub[lo:hi][same] != osub[same]).sum())
+        print(f"C4 window [{lo}, {hi}): label flips vs oracle {flips} (budget {max(1, int(1e-5 * w))}), sub-label flips {sflips} (budget {max(2, int(1e-4 * w))})")
+        assert flips <= max(1, int(1e-5 * w)), (lo, flips)
+        assert sflips <= max(2, int(1e-4 * w)), (lo, sflips)
     wk.sweep(2)
     lab2, _ = wk.get_labels()
     assert (lab2 == lab).mean() > 0.999                                      # same epoch, same parameters: the labels stay with their components

@@ -676,8 +676,9 @@ def test_bf16_screens_do_not_change_labels(pkg, D, sep, K):
 
 @pytest.mark.parametrize("D,sep,K", [(64, 2.0, 12), (64, 1.0, 20), (64, 0.8, 7), (52, 2.0, 7), (36, 3.0, 9), (64, 1.5, 60), (64, 40.0, 7), (64, 0.3, 5)])
 def test_direction_screen_does_not_change_labels(pkg, D, sep, K):
-    """DPMM_OPT_DIRECTION_SCREEN (D in 33 .. 64, K <= 64): q_k(x) >= |x - mu_k|^2 / lambda_max(Sigma_k) for all candidates of a tile at once, the
-    distances through one bf16 matrix product against the reference cluster's mean.  It only removes candidates the Float32 tests behind it
+    """DPMM_OPT_DIRECTION_SCREEN (D in 33 .. 64, K <= 64): q_k(x) >= (u' R_k (x - mu_k))^2 along the ONE direction u = R_k d / |R_k d|, d = mu_k0 - mu_k,
+    that separates candidate k from the tile's reference cluster k0 -- all candidates of a tile at once, their K dot products w . (x - mu_k0) through
+    one bf16 matrix product with a certified rounding bound (niw_sweep.hip, direction_far).  It only removes candidates the Float32 tests behind it
     would have excluded, so the table and the labels are those of the kernel without it, bit for bit: on overlapping clusters of every
     degree (where it does most of the screening), with zero-padded features, on separated clusters (where it never runs) and on clusters so
     close that it can exclude nothing."""

@@ -197,3 +197,51 @@ def test_worker_table_mirrors_struct_dpmmh_worker():
     call = call[:call.index("\n\n")]
     syms = re.findall(r"hip\(:(dpmm_[a-z0-9_]+)\)", call)
     assert syms == [sym for _, sym, _ in engine._NATIVE_MAP]
+
+
+# ---------------------------------------------------------------------------------------------- fit / dp_parallel surface
+# keyword arguments of the reference's fit (src/dp-parallel-sampling.jl:215-216) = positional tail of dp_parallel (:121-134), in order
+REF_FIT_KEYWORDS = ["iters", "init_clusters", "seed", "verbose", "save_model", "burnout", "gt", "max_clusters", "outlier_weight",
+                    "outlier_params", "smart_splits"]
+
+
+def _jl_function(txt, name):
+    """(signature text, body text) of `function name(...) ... end` (first method)."""
+    i = txt.index(f"function {name}(")
+    j, depth = i + len(f"function {name}("), 1
+    while depth:
+        depth += txt[j] == "("
+        depth -= txt[j] == ")"
+        j += 1
+    end = txt.index("\nend\n", j)
+    return txt[i:j], txt[j:end]
+
+
+def test_julia_fit_consumes_every_argument_of_the_reference_signature():
+    """gpu_fit / gpu_dp_parallel (julia/gpu_engine.jl) take the reference's arguments -- same names, same order, same defaults where the
+    reference states one -- and USE each of them: a name that only appears in the signature (round 4: gt, verbose, save_model,
+    max_clusters were accepted and dropped) fails here.  The histories run_model returns must be filled, not literal empty arrays."""
+    txt = _jl("gpu_engine.jl")
+    sig_fit, body_fit = _jl_function(txt, "gpu_fit")
+    sig_dp, body_dp = _jl_function(txt, "gpu_dp_parallel")
+    pos = [m.group(1) for m in re.finditer(r"(\w+)(?:::[\w{},. ]+)?\s*=", sig_dp.split(";")[0])]
+    assert pos == REF_FIT_KEYWORDS, pos                                    # dp_parallel: positional, in the reference's order
+    for kw in REF_FIT_KEYWORDS:
+        assert re.search(rf"\b{kw}\b(?:::[\w{{}}]+)?\s*=", sig_fit), ("gpu_fit lacks keyword", kw)
+        assert re.search(rf"\b{kw}\b", body_fit), ("gpu_fit drops", kw)
+        assert len(re.findall(rf"\b{kw}\b", body_dp)) >= 1, ("gpu_dp_parallel drops", kw)
+    for default in ("iters::Int64 = 100", "init_clusters::Int64 = 1", "seed = nothing", "verbose = true", "save_model = false", "gt = nothing",
+                    "max_clusters = Inf", "outlier_weight = 0", "outlier_params = nothing", "smart_splits = false"):
+        assert default in sig_fit and default in sig_dp, default
+    assert "burnout = 20" in sig_fit and "burnout = 15" in sig_dp          # (the reference's two defaults: :216 and :129)
+    # both methods dispatch on the abstract prior type, and both priors have a set_prior! method
+    assert "local_hyper_params::distribution_hyper_params" in sig_fit and "local_hyper_params::distribution_hyper_params" in sig_dp
+    assert "set_prior!(model, which, h::niw_hyperparams)" in txt and "set_prior!(model, which, h::multinomial_hyper)" in txt
+    # run_model!: every flag acts, every history is pushed per iteration
+    sig_rm, body_rm = _jl_function(txt, "run_model!")
+    for name in ("verbose", "gt", "max_clusters", "save_model"):
+        assert re.search(rf"\b{name}\b", sig_rm) and re.search(rf"\b{name}\b", body_rm), name
+    for hist in ("iter_count", "nmi_score_history", "liklihood_history", "cluster_count_history"):
+        assert f"push!({hist}," in body_rm, hist
+    assert "K >= max_clusters" in body_rm and ":dpmm_contingency" in body_rm and ":dpmmh_log_posterior" in body_rm
+    assert "Float64[], Float64[], Int[]" not in txt
