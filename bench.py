@@ -646,27 +646,6 @@ def main():
             out["growth"]["moving_labels"] = {"iterations": "100..139", "it_per_s": 40.0 / mid, "K_at_100": int(kh[100]), "K_at_139": int(kh[139]),
                                               "K_changes": int(np.count_nonzero(np.diff(np.asarray(kh[100:140]))))}
 
-    # DPMM_OPT_F32_STATS (off by default: the reference keeps its statistics in Float64): the headline shape with the second moments accumulated
-    # in centred Float32 -- the only lever on the statistics kernel, which sits at its Float64 pipe's rate
-    if not args.no_legs and world == 1 and rank == 0:
-        from dpmmsubclusters_jl_amd import binding as _b
-        wk.set_option(_b.OPT_F32_STATS, 1)
-        fs = host.DPMMSampler(wk, prior, ALPHA, N, SAMPLER_SEED, burnout=BURNOUT, comm=comm)       # same data, same context, the headline's start
-        fs.start_from_labels(y, sub0, K)
-        for _ in range(BURNOUT + 1 + 30):
-            fs.group_step(False, False)
-        wk.set_timing(0)
-        wk.sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            fs.group_step(False, False)
-        wk.sync()
-        el32 = time.perf_counter() - t0
-        wk.set_timing(7)
-        wk.set_option(_b.OPT_F32_STATS, 0)
-        out["f32_stats"] = {"it_per_s": args.steps / el32, "ms_per_step": 1e3 * el32 / args.steps, "K_t": int(fs.K),
-                            "note": "DPMM_OPT_F32_STATS = 1 (not the default): same kernels otherwise; scatter matrices within 1e-7 of the Float64 pass (tests/test_gpu_niw.py)"}
-
     # the configuration north_star words: posterior parameter draws and split / merge steps on the HOST (DPMMH_OPT_DEVICE_MASTER = 0) --
     # same data, same context, same steady state; the headline runs the engine's default for D >= 64 (device master, dpmm_hip_master.h)
     if not args.no_host_master:
@@ -710,8 +689,6 @@ def main():
             gr = out["growth"]
             also["growth"] = {"it_per_s_whole_run": gr["it_per_s_whole_run"], "K_final": gr["K_final"], "K_true": gr["K_true"],
                               "nmi": gr["nmi_final_vs_generator"], "moving_labels_it_per_s": gr.get("moving_labels", {}).get("it_per_s")}
-        if "f32_stats" in out:
-            also["f32_stats_it_per_s"] = out["f32_stats"]["it_per_s"]
         lg = out.get("legs", {})
         if "shard8_projection" in lg:
             pj = lg["shard8_projection"]

@@ -235,8 +235,6 @@ struct dpmm_ctx {
     bool sp_last = false;              // the last sweep ran the DIR kernel (its yield words are valid)
     int sp_K = -1;                     // number of clusters of the last parameter set the tables were built for
     int sp_cooldown = 0;               // parameter sets the screen stays off after it removed less than a quarter of what it was given
-    int opt_f32_stats = 0;             // DPMM_OPT_F32_STATS: per-step pass at D <= 64 with centred Float32 second moments (suffstats.hip niw_stats_body_f32)
-    int centre_K = -1;                 // number of clusters d_mup holds the means of (the centres of that pass); -1: none
     int opt_bf16scr = 1;               // D <= 64 sweep: bf16 screens in front of the Float32 16-row screen / of a survivor's first row block (DPMM_OPT_BF16_SCREENS)
     int opt_bracket = 1;               // D <= 64 sweep: certified bf16 bracket of the reference cluster's value instead of its Float32 evaluation where that decides nothing (DPMM_OPT_REF_BRACKET)
     int opt_timing = 0;                // bit 0 / 1 / 2: HIP events around the sweep kernel / the statistics pass / the all-reduces (dpmm_last_kernel_ms, dpmm_last_comm_ms)
@@ -991,7 +989,6 @@ int dpmm_commit_params(dpmm_ctx *c, int K) {
 // after a change of K keep the usual order and count.
 static int direction_tables(dpmm_ctx *c, int K) {
     c->sp_ready = false;
-    c->centre_K = c->prior == DPMM_PRIOR_NIW ? K : -1;          // (called behind both pack kernels: d_mup holds the K cluster means now)
     c->have_refb_big = false;
     if (c->prior == DPMM_PRIOR_NIW && (c->NB == 8 || c->NB == 16) && c->d_refb_big && c->opt_bracket && c->have_tail && K > 1) {
         HIPCHK(c, launch_niw_refb_big(c->d_Rp, c->NB, K, c->d_refb_big, c->stream));      // D = 128, 256: the reference bracket's images
@@ -1363,10 +1360,7 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
     // automatic: the one-collective form sends 3K rows instead of 2K -- 0.55 MB more at D = 64, K = 32 (a few us of wire) against a whole
     // latency-bound collective in the middle of the sort chain; at D = 256 the extra K rows are 8.4 MB (~80 us): the classic form stays
     const bool one_auto = c->packed_stride <= 4096;
-    // DPMM_OPT_F32_STATS: the per-step pass of an NIW model at D <= 64 whose K clusters are the ones of the parameter set on the device (their
-    // means are the centres); every other pass -- subsets after a split, a pass after K changed, D > 64 -- takes the Float64 path
-    const bool f32s = c->opt_f32_stats && with_reset && !idx && c->prior == DPMM_PRIOR_NIW && c->NB <= 4 && c->n > 0 && c->centre_K == c->K && !c->predictive;
-    const bool one_coll = !f32s && with_reset && comm_attached(c) && c->prior == DPMM_PRIOR_NIW && (c->opt_one_collective < 0 ? one_auto : c->opt_one_collective != 0);
+    const bool one_coll = with_reset && comm_attached(c) && c->prior == DPMM_PRIOR_NIW && (c->opt_one_collective < 0 ? one_auto : c->opt_one_collective != 0);
     c->last_pass_one_collective = one_coll;
     if (c->opt_timing & 2) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     if (idx) {
@@ -1464,14 +1458,7 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
     // (flags_to: the caller's pinned block for the bad-cluster flags -- they ride in the derivation's launch when no collective follows it)
     const bool ride = derive && flags_to != nullptr && !comm_attached(c);
     const uint8_t *fsrc = reinterpret_cast<const uint8_t *>(c->d_out) + sizeof(double) * (size_t)nbins * (size_t)c->packed_stride;
-    if (c->prior == DPMM_PRIOR_NIW && f32s) {
-        // centred Float32 accumulation: plain reduce of the centred rows -> the shift undone in Float64 -> the rows that were not computed
-        // derived as on the Multinomial path (the reduce kernel's own derivation would mix centred and plain rows)
-        a.centre = c->d_mup; a.centre_stride = 3 * 16 * c->NB;
-        HIPCHK(c, launch_niw_stats(a, c->stream));
-        HIPCHK(c, launch_niw_uncentre(c->d_out, c->packed_stride, c->K, c->D, a.centre, a.centre_stride, c->stream));
-        if (derive) HIPCHK(c, launch_derive_rows(c->d_out, c->d_ccache, c->sb.cmode, c->sb.cdirty, c->packed_stride, c->K, fsrc, ride ? flags_to : nullptr, c->stream));
-    } else if (c->prior == DPMM_PRIOR_NIW) {
+    if (c->prior == DPMM_PRIOR_NIW) {
         if (derive) {       // the reduce kernel derives the rows that were not computed (one launch and one round trip of the rows less)
             a.mode = c->sb.cmode; a.cache = c->d_ccache; a.dirty = c->sb.cdirty; a.K = c->K;
             a.flags_src = ride ? fsrc : nullptr; a.flags_dst = ride ? flags_to : nullptr;
@@ -2526,7 +2513,6 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
         case DPMM_OPT_REF_BRACKET: c->opt_bracket = value != 0; return DPMM_OK;
         case DPMM_OPT_COMM_TIMEOUT_MS: c->comm_timeout_ms = value > 0 ? (int)std::min(value, 2.0e9) : 0; return DPMM_OK;
         case DPMM_OPT_BF16_SCREENS: c->opt_bf16scr = value != 0; return DPMM_OK;
-        case DPMM_OPT_F32_STATS: c->opt_f32_stats = value != 0; c->cache_force = true; return DPMM_OK;      // (cached cluster rows of the other arithmetic are not mixed in)
         case DPMM_OPT_DIRECTION_SCREEN:
             c->opt_direction = value < 0 ? -1 : (value != 0);
             if (c->opt_direction == 0) { c->sp_ready = false; c->sp_regime = false; }

@@ -210,13 +210,7 @@ struct StatsArgs {
     // one-collective per-step pass: `out` has 3K rows -- [2K rows of the labels as swept | K re-drawn left rows] -- cside [K] says which
     // clusters' sub-labels were reset speculatively on this shard (suffstats.hip reset_recount_kernel); zero2 = two flag bytes to clear
     const uint8_t *cside; uint8_t *zero2;
-    // DPMM_OPT_F32_STATS (NIW, D <= 64, per-step pass): second moments of x - centre[k] accumulated in Float32 on the matrix cores, 64 points
-    // at a time, the 64-point sums added in Float64; the reduce then sums CENTRED rows and launch_niw_uncentre restores {N, sum x, sum x x'}
-    const float *centre;    // [K] rows of `centre_stride` floats: the cluster-level means of the current parameter set (null: Float64 path)
-    int centre_stride;
 };
-// rows [2K][stride] of centred statistics {N, sum (x - c), lower triangle of sum (x - c)(x - c)'} -> {N, sum x, lower triangle of sum x x'}, c = centre row of the cluster (Float64)
-hipError_t launch_niw_uncentre(double *out, int64_t stride, int K, int D, const float *centre, int centre_stride, hipStream_t s);
 constexpr int NIW_STATS_MAX_GROUPS = 4096;   // workgroups of the NIW statistics kernel at most; slab slots = this + 2 K (suffstats.hip head_slot)
 int64_t niw_slab_stride(int D);
 hipError_t launch_niw_row_offsets(int32_t *row_off, int32_t *inv_off, int D, int64_t packed_stride, hipStream_t s);

@@ -629,125 +629,6 @@ __device__ __forceinline__ void niw_stats_body(const StatsArgs &A, int seg, int 
 // instructions, ~110 of them accumulator-file moves (272 accumulator registers + three x buffers + the converted row do not fit next to
 // each other), matrix pipe busy 55 %.  One barrier per batch; the global loads of batch n + 1 are issued before the matrix phase of
 // batch n and consumed after it.  Column sums: the loader thread of a column group adds up its columns.
-// DPMM_OPT_F32_STATS (NBK <= 4): the same walk over a segment as niw_stats_body, the outer products of x' = x - c (c: the cluster's current
-// mean, `cvec`) on the Float32 matrix cores -- v_mfma_f32_16x16x4_f32 runs at twice the rate of the Float64 instruction, and the
-// statistics kernel sits at its pipe's rate -- in sub-segments of 64 points: a Float32 accumulator sees at most 64 products (relative error
-// below 64 * 2^-24 of sum |x'_a x'_b|, ~5e-7 in practice), then it is added to the Float64 accumulator and cleared.  Centred because
-// sum x x' - N m m' cancels |m|^2 / sigma^2 of the digits otherwise (1e4 in the tight directions of the reference generator's clusters);
-// the column sums of x' stay Float64.  The slab holds the CENTRED sums; launch_niw_uncentre undoes the shift on the reduced rows.
-template <int NBK>
-__device__ __forceinline__ void niw_stats_body_f32(const StatsArgs &A, int seg, int cnt, double *__restrict__ slab, const float *__restrict__ cvec) {
-    using C = StatCfg<NBK>;
-    constexpr int NP = C::NPAIR;
-    typedef float f32x4s __attribute__((ext_vector_type(4)));
-    const int lane = threadIdx.x & 63;
-    const int i = lane & 15, g = lane >> 4;
-    f64x4 acc[NP];
-    f32x4s a32[NP];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) { acc[p] = (f64x4){0., 0., 0., 0.}; a32[p] = (f32x4s){0.f, 0.f, 0.f, 0.f}; }
-    double xs[NBK];
-#pragma unroll
-    for (int b = 0; b < NBK; ++b) xs[b] = 0.;
-    constexpr int U = 4;                                   // k-steps (of 4 points) per batch: 16 points
-    const int nsteps = (cnt + 3) >> 2;
-    const int nbatch = (nsteps + U - 1) / U;
-    auto load_idx = [&](int b, int (&pt)[U]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) pt[u] = A.sb.perm[seg + min(4 * (b * U + u) + g, cnt - 1)];
-    };
-    bool colok[NBK >= 4 ? NBK / 4 : NBK];
-    int coloff[NBK >= 4 ? NBK / 4 : NBK];
-    float cf[NBK];
-#pragma unroll
-    for (int c = 0; c < (NBK >= 4 ? NBK / 4 : NBK); ++c) {
-        const int col = NBK * i + (NBK >= 4 ? 4 * c : c);
-        colok[c] = col < A.ldx;
-        coloff[c] = colok[c] ? col : 0;
-    }
-#pragma unroll
-    for (int b2 = 0; b2 < NBK; ++b2) { const int col = NBK * i + b2; cf[b2] = col < A.D ? cvec[col] : 0.f; }
-    auto load_x = [&](const int (&pt)[U], float (&xf)[U][NBK]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            int pv = pt[u];
-            asm volatile("" : "+v"(pv));
-            const float *xrow = A.X + (int64_t)pv * A.ldx;
-            if constexpr (NBK >= 4) {
-#pragma unroll
-                for (int c4 = 0; c4 < NBK / 4; ++c4) {
-                    const f32x4 v = *reinterpret_cast<const f32x4 *>(xrow + coloff[c4]);
-                    xf[u][4 * c4 + 0] = v.x; xf[u][4 * c4 + 1] = v.y; xf[u][4 * c4 + 2] = v.z; xf[u][4 * c4 + 3] = v.w;
-                }
-            } else {
-#pragma unroll
-                for (int b2 = 0; b2 < NBK; ++b2) xf[u][b2] = xrow[coloff[b2]];
-            }
-        }
-    };
-    constexpr int AHEAD = 2, NBUF = AHEAD + 1;
-    int pt_b[U], pt_c[U];
-    float xbuf[NBUF][U][NBK];
-    auto flush = [&]() {
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[p][r] += (double)a32[p][r];
-            a32[p] = (f32x4s){0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    auto step = [&](int bt, const float (&xu)[U][NBK], float (&xl)[U][NBK]) {
-        load_idx(bt + AHEAD + 1, pt_c);
-        __builtin_amdgcn_sched_barrier(0);
-        load_x(pt_b, xl);                          // batch bt + AHEAD
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool rowok = 4 * (bt * U + u) + g < cnt;
-            float xc[NBK];
-#pragma unroll
-            for (int b2 = 0; b2 < NBK; ++b2) {
-                const bool keep = rowok && colok[NBK >= 4 ? b2 / 4 : b2] && (NBK * i + b2 < A.D);
-                xc[b2] = keep ? xu[u][b2] - cf[b2] : 0.f;
-                xs[b2] += (double)xc[b2];
-            }
-#pragma unroll
-            for (int ba = 0; ba < NBK; ++ba)
-#pragma unroll
-                for (int bb = 0; bb <= ba; ++bb)
-                    a32[ba * (ba + 1) / 2 + bb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[ba], xc[bb], a32[ba * (ba + 1) / 2 + bb], 0, 0, 0);
-        }
-        if ((bt & 3) == 3) flush();                // every 4 batches = 64 points
-#pragma unroll
-        for (int u = 0; u < U; ++u) pt_b[u] = pt_c[u];
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    load_idx(0, pt_b);
-#pragma unroll
-    for (int r = 0; r < AHEAD; ++r) {
-        load_x(pt_b, xbuf[r]);
-        load_idx(r + 1, pt_b);
-    }
-    for (int bt = 0; bt < nbatch; bt += NBUF) {
-#pragma unroll
-        for (int r = 0; r < NBUF; ++r) step(bt + r, xbuf[r], xbuf[(r + AHEAD) % NBUF]);
-    }
-    flush();
-    // the Float32 instruction leaves element r of lane (i, g) at row 4 g + r of the block (the Float64 one at row g + 4 r): the slab position
-    // of row R, column i is [R >> 2][i + 16 (R & 3)]
-#pragma unroll
-    for (int p = 0; p < NP; ++p)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) slab[(int64_t)p * 256 + g * 64 + (i + 16 * r)] = acc[p][r];
-#pragma unroll
-    for (int b = 0; b < NBK; ++b) {
-        double v = xs[b];
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        if (g == 0) slab[(int64_t)C::NPAIR * 256 + NBK * i + b] = v;
-    }
-}
-
 template <int NBK, int PANEL>
 __device__ __forceinline__ void niw_stats_body_shared(const StatsArgs &A, int seg, int cnt, double *__restrict__ slab, double *__restrict__ xb) {
     constexpr int SB = DPMM_STATS16_SB, NPT = 4 * SB;              // k-steps / points per batch
@@ -859,7 +740,7 @@ __device__ __forceinline__ int head_slot(int item, int bin, int T, int G) {
     const int w = range_owner(item, T, G);
     return range_bound(w, T, G) == item ? w : NIW_STATS_MAX_GROUPS + bin;
 }
-template <int NBK, bool F32 = false>
+template <int NBK>
 __global__ __launch_bounds__(64 * StatCfg<NBK>::NPANEL) void niw_stats_kernel(StatsArgs A) {
     using C = StatCfg<NBK>;
     // The three small tables of the sort (item_start, bin_total, bin_start: nbins + 1 entries) in REGISTERS, two entries per lane, fetched
@@ -900,8 +781,7 @@ __global__ __launch_bounds__(64 * StatCfg<NBK>::NPANEL) void niw_stats_kernel(St
         double *slab = A.slabs + (int64_t)(item == it0 ? (int)blockIdx.x : NIW_STATS_MAX_GROUPS + b) * A.slab_stride;
         const int panel = threadIdx.x >> 6;
         if constexpr (C::NPANEL == 1) {
-            if constexpr (F32) niw_stats_body_f32<NBK>(A, seg, cnt, slab, A.centre + (size_t)(b >> 1) * A.centre_stride);
-            else niw_stats_body<NBK, 0>(A, seg, cnt, slab);
+            niw_stats_body<NBK, 0>(A, seg, cnt, slab);
         } else {
             __shared__ double xbs[2 * NBK * 4 * DPMM_STATS16_SB * 16];      // two operand buffers of niw_stats_body_shared
             if constexpr (C::NPANEL == 4) {
@@ -1132,15 +1012,6 @@ hipError_t launch_niw_stats(const StatsArgs &a0, hipStream_t s) {
     int groups = a.range_groups > 0 ? a.range_groups : dflt;
     if (groups > NIW_STATS_MAX_GROUPS) groups = NIW_STATS_MAX_GROUPS;
     a.range_groups = groups;
-    if (a.centre && NBK <= 4) {          // DPMM_OPT_F32_STATS: centred Float32 second moments (the rows are un-centred by the caller behind the reduce)
-        switch (NBK) {
-            case 1: DPMM_LAUNCH((niw_stats_kernel<1, true>), dim3(groups), dim3(64), 0, s, a); break;
-            case 2: DPMM_LAUNCH((niw_stats_kernel<2, true>), dim3(groups), dim3(64), 0, s, a); break;
-            default: DPMM_LAUNCH((niw_stats_kernel<4, true>), dim3(groups), dim3(64), 0, s, a); break;
-        }
-        DPMM_LAUNCH(niw_reduce_kernel, dim3((unsigned)((a.slab_stride + 63) / 64), a.nbins / 2), dim3(64 * REDUCE_PARTS), 0, s, a, NBK);
-        return hipGetLastError();
-    }
     switch (NBK) {
         case 1: DPMM_LAUNCH((niw_stats_kernel<1>), dim3(groups), dim3(64), 0, s, a); break;
         case 2: DPMM_LAUNCH((niw_stats_kernel<2>), dim3(groups), dim3(64), 0, s, a); break;
@@ -1149,33 +1020,6 @@ hipError_t launch_niw_stats(const StatsArgs &a0, hipStream_t s) {
         default: DPMM_LAUNCH((niw_stats_kernel<16>), dim3(groups), dim3(512), 0, s, a); break;
     }
     DPMM_LAUNCH(niw_reduce_kernel, dim3((unsigned)((a.slab_stride + 63) / 64), a.nbins / 2), dim3(64 * REDUCE_PARTS), 0, s, a, NBK);
-    return hipGetLastError();
-}
-
-// DPMM_OPT_F32_STATS: the reduced rows of a pass hold {N, s' = sum (x - c), S' = sum (x - c)(x - c)'} -- c the cluster's centre, Float32 values
-// read as Float64 -- and become {N, s' + N c, S' + c s'' + s' c' + N c c'} here (Float64; one workgroup per row, the row's s' in LDS first:
-// every second-moment element needs two of them).  Exact up to Float64 rounding whatever c is; rows that were not computed are zero and stay zero.
-__global__ __launch_bounds__(256) void niw_uncentre_kernel(double *__restrict__ out, int64_t stride, int D, const float *__restrict__ centre, int centre_stride) {
-    __shared__ double sp[256], cc[256];
-    double *row = out + (int64_t)blockIdx.x * stride;
-    const float *c = centre + (size_t)(blockIdx.x >> 1) * centre_stride;
-    const double N = row[0];
-    for (int a = threadIdx.x; a < D; a += 256) { sp[a] = row[1 + a]; cc[a] = (double)c[a]; }
-    __syncthreads();
-    const int T = D * (D + 1) / 2;
-    for (int t = threadIdx.x; t < T; t += 256) {
-        int a = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-        while ((a + 1) * (a + 2) / 2 <= t) ++a;
-        while (a * (a + 1) / 2 > t) --a;
-        const int b = t - a * (a + 1) / 2;
-        double *e = row + 1 + D + t;
-        *e = *e + (cc[a] * sp[b] + sp[a] * cc[b]) + N * cc[a] * cc[b];
-    }
-    for (int a = threadIdx.x; a < D; a += 256) row[1 + a] = sp[a] + N * cc[a];
-}
-hipError_t launch_niw_uncentre(double *out, int64_t stride, int K, int D, const float *centre, int centre_stride, hipStream_t s) {
-    if (D > 256) return hipErrorInvalidValue;
-    DPMM_LAUNCH(niw_uncentre_kernel, dim3(2 * K), dim3(256), 0, s, out, stride, D, centre, centre_stride);
     return hipGetLastError();
 }
 

@@ -85,11 +85,7 @@ enum {
                                          an enqueued collective are timed.  Past the limit a watchdog aborts the communicator and the blocked call -- on every surviving
                                          rank -- fails with DPMM_ECOMM; later collectives refuse with DPMM_ECOMM until dpmm_comm_release, calls without a collective
                                          (dpmm_get_labels, dpmm_sync) keep working */
-    DPMM_OPT_F32_STATS = 24,          /* 0 (default): sufficient statistics in Float64 throughout, as the reference (priors/niw.jl:42-51).  1: NIW, D <= 64, the per-step pass:
-                                         the second moments of x - mu_k (the cluster's current mean) on the Float32 matrix cores, 64 points at a time, the
-                                         64-point sums added -- and the shift undone -- in Float64: the statistics kernel runs at twice its Float64 rate, the
-                                         scatter matrices agree with the Float64 path to ~1e-6 of sqrt(S_aa S_bb) (tests/test_gpu_niw.py); the chain is a
-                                         different, equally valid one.  Subset passes and passes after K changed stay Float64. */
+    /* 24: was DPMM_OPT_F32_STATS (rounds 4: centred Float32 second moments, +4 % on the headline); removed in round 5 -- the statistics are Float64 throughout, as the reference's (priors/niw.jl:42-51) */
     DPMM_OPT_MULT_DRAWS_AHEAD = 25,   /* 1 (default): Multinomial device master: dpmm_step_stats launches the NEXT Dirichlet draws and their hand-over images
                                        * behind the statistics (the epoch after the last dpmm_mult_master_draw, the same K and outlier flag), into a second set of
                                        * buffers, and returns when the rows are on the host -- the draws run while the caller decides splits and merges.

@@ -839,55 +839,3 @@ def test_big_bracket_is_a_lower_bound_of_the_reference_value(pkg, kind, D):
     assert np.all(gap >= -1e-6 * np.abs(tab[fin])), gap.min()
     assert np.median(gap / np.maximum(1.0, np.abs(tab[fin]))) < 0.2      # ... and it is a bracket, not a trivial bound
     wk.close()
-
-
-@pytest.mark.parametrize("D,offset", [(64, 0.0), (64, 50.0), (40, 10.0), (20, 3.0), (8, 100.0)])
-def test_f32_statistics_agree_with_float64(pkg, D, offset):
-    """DPMM_OPT_F32_STATS: the per-step pass with the second moments of x - mu_k accumulated in Float32 (64 points at a time) and everything
-    else in Float64.  Against the Float64 pass on the same labels: N exact, sum x to 1e-9 of its scale, and the SCATTER matrices
-    S - s s' / N (what the posterior's psi' is made of) to 1e-6 of sqrt(S_aa S_bb) elementwise (measured: < 1e-7) -- also when the data sit far from the
-    origin (offset = 50 standard deviations: uncentred Float32 products would lose 2500 x the digits there), over several sweeps with
-    derived rows (only the smaller sub-cluster of an untouched cluster is computed), and the chain keeps running."""
-    from dpmmsubclusters_jl_amd import binding
-    n, K = 60000, 6
-    P = make_problem(D, n, K, seed=300 + D, sep=6.0, sorted_points=False)
-    P["X"] = (P["X"] + np.float32(offset)).astype(np.float32)
-    P["mu"] = (P["mu"] + np.float32(offset)).astype(np.float32)
-    rows = {}
-    for f32 in (1, 0):
-        wk = gpu_worker(pkg, P, seed=31)
-        wk.set_option(binding.OPT_F32_STATS, f32)
-        wk.set_labels(P["z"] + 1, 1 + (np.arange(n) & 1))
-        wk.set_params_niw(P["mu"], P["invS"], P["logdet"], P["lr"], P["w"])
-        got = []
-        for ep in (1, 2, 3):
-            wk.sweep(ep)
-            packed, bad = wk.step_stats(100 + ep)
-            got.append((packed.copy(), wk.get_labels()))
-            wk.set_params_niw(P["mu"], P["invS"], P["logdet"], P["lr"], P["w"])
-        rows[f32] = (got, wk.unpack)
-        if f32 == 0:
-            wk.close()
-        else:
-            wk_keep = wk
-    worst = 0.0
-    for (pa, la), (pb, lb) in zip(rows[1][0], rows[0][0]):
-        assert np.array_equal(la[0], lb[0]) and np.array_equal(la[1], lb[1])          # same parameters, same uniforms: same labels -> same statistics to compare
-        Na, sa, Sa = wk_keep.unpack(pa)
-        Nb, sb, Sb = wk_keep.unpack(pb)
-        assert np.array_equal(Na, Nb)
-        scale = np.abs(sb).max() + 1.0
-        assert np.abs(sa - sb).max() <= 1e-9 * scale * n
-        for k in range(K):
-            for w in (1, 2):
-                N = Nb[k, w]
-                if N < 2:
-                    continue
-                Ca = Sa[k, w] - np.outer(sa[k, w], sa[k, w]) / N
-                Cb = Sb[k, w] - np.outer(sb[k, w], sb[k, w]) / N
-                d = np.sqrt(np.abs(np.diag(Cb)))
-                rel = np.abs(Ca - Cb) / (np.outer(d, d) + 1e-300)
-                worst = max(worst, float(rel.max()))
-    print(f"D={D} offset={offset}: worst |scatter_f32 - scatter_f64| / sqrt(S_aa S_bb) = {worst:.2e}")
-    assert worst < 1e-6
-    wk_keep.close()
