@@ -317,6 +317,17 @@ def inseparable_leg(pkg, torch, n, D, K, sep=0.4, cond=10.0):
             "roofline": niw_roofline(n, D, float(K), sweep_ms, work)}
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def niw_roofline(n, D, k_mean, sweep_ms, work):
     flops_alg = 2.0 * n * D * D * (k_mean + 2)
     exe = work["executed_flops"]
@@ -666,6 +677,7 @@ def main():
         ha = dict(hm.timers)
         wk.set_timing(7)
         out["host_master"] = {"it_per_s": args.steps / el, "ms_per_step": 1e3 * el / args.steps, "K_t": int(hm.K),
+                              "ratio_to_headline": (args.steps / el) / out["value"], "cpu_model": _cpu_model(), "host_threads": int(hm.nthreads),
                               "host_ms_per_step": {k: round(1e3 * (ha[k] - hb[k]) / args.steps, 4) for k in ha if ha[k] - hb[k] > 0},
                               "note": "DPMMH_OPT_DEVICE_MASTER = 0: posteriors, factorisations, parameter draws and every Metropolis step on the host "
                                       "(src/shared_actions.jl:41-66, src/priors/niw.jl:20-40), parameters through dpmm_params_staging / dpmm_commit_params"}
@@ -685,6 +697,8 @@ def main():
         also = {}
         if "host_master" in out:
             also["host_master_it_per_s"] = out["host_master"]["it_per_s"]
+            also["host_master_ratio_to_headline"] = out["host_master"]["ratio_to_headline"]
+            also["host_cpu_model"] = out["host_master"]["cpu_model"]
         if "growth" in out:
             gr = out["growth"]
             also["growth"] = {"it_per_s_whole_run": gr["it_per_s_whole_run"], "K_final": gr["K_final"], "K_true": gr["K_true"],

@@ -1840,8 +1840,12 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
             for (int w = 0; w < ((K + 31) >> 5); ++w) cntb += __builtin_popcount(__builtin_amdgcn_readfirstlane(evw[w]));
             nev1 = cntb == 1;
         }
+        // (the key is made opaque per tile: otherwise the compiler hoists the ten round keys out of the tile loop as 20 loop-invariant scalars,
+        // spills them to vector lanes and fetches them back with 20 vector instructions per tile -- in the loop they are 20 scalar additions)
+        uint32_t seed_lo = (uint32_t)A.seed, seed_hi = (uint32_t)(A.seed >> 32);
+        asm volatile("" : "+s"(seed_lo), "+s"(seed_hi));
         if (valid) {
-            const Philox4 r = philox4x32_10(A.seed, (uint64_t)(A.first_index + myp), A.epoch, STREAM_SWEEP);
+            const Philox4 r = philox4x32_10(((uint64_t)seed_hi << 32) | seed_lo, (uint64_t)(A.first_index + myp), A.epoch, STREAM_SWEEP);
             u_sub = u01(r.v[1]);
             if (A.final_argmax) {
                 z = best;
