@@ -1360,7 +1360,7 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
     // automatic: the one-collective form sends 3K rows instead of 2K -- 0.55 MB more at D = 64, K = 32 (a few us of wire) against a whole
     // latency-bound collective in the middle of the sort chain; at D = 256 the extra K rows are 8.4 MB (~80 us): the classic form stays
     const bool one_auto = c->packed_stride <= 4096;
-    const bool one_coll = with_reset && comm_attached(c) && c->prior == DPMM_PRIOR_NIW && (c->opt_one_collective < 0 ? one_auto : c->opt_one_collective != 0);
+    const bool one_coll = with_reset && comm_attached(c) && (c->opt_one_collective < 0 ? one_auto : c->opt_one_collective != 0);      // (both priors since round 5)
     c->last_pass_one_collective = one_coll;
     if (c->opt_timing & 2) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     if (idx) {
@@ -1386,7 +1386,7 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
     a.X = c->dX; a.ldx = c->ldx; a.n = c->n; a.D = c->D; a.nbins = nbins; a.chunk = c->chunk;
     a.max_items = (int)((c->n + c->chunk - 1) / c->chunk) + nbins;
     a.range_groups = c->opt_stats_groups;
-    a.sb = c->sb; a.slabs = c->d_slabs; a.slab_stride = c->slab_stride; a.out = one_coll ? c->d_red : c->d_out; a.packed_stride = c->packed_stride; a.row_off = c->d_row_off; a.inv_off = c->d_inv_off;
+    a.sb = c->sb; a.slabs = c->d_slabs; a.slab_stride = c->slab_stride; a.out = (one_coll && c->prior == DPMM_PRIOR_NIW) ? c->d_red : c->d_out; a.packed_stride = c->packed_stride; a.row_off = c->d_row_off; a.inv_off = c->d_inv_off;      // (a.out, NIW one-collective pass: the reduce kernel writes the 3K travelling rows itself)
     if (with_reset && c->n > 0) {
         // reset_bad_clusters! (local_clusters_actions.jl:501-516) on the device, four launches: histogram (+ running bin totals) ->
         // [occupancies summed over the ranks] -> flags + sub-labels of flagged clusters re-drawn + touched tiles re-counted -> scan + starts
@@ -1432,10 +1432,16 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
     if (one_coll) {
         uint8_t *flags = reinterpret_cast<uint8_t *>(c->d_out) + sizeof(double) * (size_t)nbins * (size_t)c->packed_stride;
         const size_t nred = 3 * (size_t)c->K * (size_t)c->packed_stride;
-        if (c->n > 0) {
+        if (c->n > 0 && c->prior == DPMM_PRIOR_NIW) {
             if (derive) { a.mode = c->sb.cmode; a.cache = c->d_ccache; a.dirty = c->sb.cdirty; a.K = c->K; }
             a.cside = c->d_cside; a.zero2 = flags + c->K;
             HIPCHK(c, launch_niw_stats(a, c->stream));
+        } else if (c->n > 0) {
+            // Multinomial: the usual statistics + derivation of the speculatively reset labels into d_out, then the travelling rows from them
+            if (c->x_u8) HIPCHK(c, launch_mult_stats_u8(a, c->dX8, c->ld8, c->stream));
+            else HIPCHK(c, launch_mult_stats(a, c->stream));
+            if (derive) HIPCHK(c, launch_derive_rows(c->d_out, c->d_ccache, c->sb.cmode, c->sb.cdirty, c->packed_stride, c->K, flags, nullptr, c->stream));
+            HIPCHK(c, launch_onecoll_rows(c->d_out, c->d_red, c->packed_stride, c->K, c->d_cside, flags, c->stream));
         } else {
             HIPCHK(c, hipMemsetAsync(c->d_red, 0, sizeof(double) * nred, c->stream));
             HIPCHK(c, hipMemsetAsync(flags + c->K, 0, 2, c->stream));

@@ -178,6 +178,8 @@ hipError_t launch_sort_by_bin(const int32_t *bins, int64_t n, int nbins, const S
 hipError_t launch_step_hist(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s);
 hipError_t launch_step_reset(int32_t *bins, int64_t n, int64_t first, int nbins, const SortBufs &b, const long long *global_counts, uint8_t *flags,
                              int K, uint64_t seed, uint32_t epoch, uint8_t *cside, hipStream_t s);     // cside != null: speculative reset of this shard's candidates
+// rows [2K][stride] of the speculatively reset labels -> red [3K][stride] (the travelling rows of the one-collective pass; Multinomial: its reduce does not write them itself)
+hipError_t launch_onecoll_rows(const double *rows, double *red, int64_t stride, int K, const uint8_t *cside, uint8_t *flags, hipStream_t s);
 hipError_t launch_niw_finalize_rows(const double *red, double *out, int64_t stride, int K, const uint8_t *cside, uint8_t *flags, uint8_t *flags_host, hipStream_t s);
 hipError_t launch_niw_undo_reset(int32_t *bins, int64_t n, int K, const uint8_t *flags, const uint8_t *cside, hipStream_t s);
 struct StatsArgs;

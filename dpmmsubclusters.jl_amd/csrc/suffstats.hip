@@ -971,6 +971,28 @@ __global__ __launch_bounds__(256) void niw_finalize_rows_kernel(const double *__
         orr[e] = r[e];
     }
 }
+// One-collective per-step pass of a prior whose reduce does not write the travelling rows itself (Multinomial): rows [2K][stride] of the
+// SPECULATIVELY reset labels (computed or derived) -> red = [2K rows of the labels as swept | K re-drawn left rows X], exactly what
+// niw_reduce_kernel emits for the NIW prior: for a candidate (cside[k] = 1 / 2: all of the shard's points of k were on that side) the side
+// its points were on carries left' + right', the other one zeros, X = left'; for every other cluster the rows as they are and X = 0.
+// flags[K], flags[K + 1] are cleared for the finalize kernel.
+__global__ __launch_bounds__(256) void onecoll_rows_kernel(const double *__restrict__ rows, double *__restrict__ red, int64_t stride, int K,
+                                                           const uint8_t *__restrict__ cside, uint8_t *__restrict__ flags) {
+    const int k = blockIdx.y;
+    const int64_t e = blockIdx.x * 256ll + threadIdx.x;
+    if (k == 0 && blockIdx.x == 0 && threadIdx.x == 0) { flags[K] = 0; flags[K + 1] = 0; }
+    if (e >= stride) return;
+    double sl = rows[(int64_t)(2 * k) * stride + e], sr = rows[(int64_t)(2 * k + 1) * stride + e];
+    const int cs = cside[k];
+    red[(int64_t)(2 * K + k) * stride + e] = cs ? sl : 0.;
+    if (cs) { const double t = sl + sr; sl = cs == 1 ? t : 0.; sr = cs == 2 ? t : 0.; }
+    red[(int64_t)(2 * k) * stride + e] = sl;
+    red[(int64_t)(2 * k + 1) * stride + e] = sr;
+}
+hipError_t launch_onecoll_rows(const double *rows, double *red, int64_t stride, int K, const uint8_t *cside, uint8_t *flags, hipStream_t s) {
+    DPMM_LAUNCH(onecoll_rows_kernel, dim3((unsigned)((stride + 255) / 256), K), dim3(256), 0, s, rows, red, stride, K, cside, flags);
+    return hipGetLastError();
+}
 hipError_t launch_niw_finalize_rows(const double *red, double *out, int64_t stride, int K, const uint8_t *cside, uint8_t *flags, uint8_t *flags_host, hipStream_t s) {
     DPMM_LAUNCH(niw_finalize_rows_kernel, dim3((unsigned)((stride + 255) / 256), K), dim3(256), 0, s, red, out, stride, K, cside, flags, flags_host);
     return hipGetLastError();

@@ -32,6 +32,7 @@ CASES = {
     # DPMM_OPT_ONE_COLLECTIVE = 0: the classic per-step pass (occupancy all-reduce -> reset -> statistics -> row all-reduce) stays covered
     "niw64_dev_classic": ("niw", 64, 200000, 6, 60, 8, 1),
     "niw8_classic": ("niw", 8, 60001, 5, 60, 6, -1),
+    "mult100_classic": ("mult", 100, 60000, 6, 50, 6, -1),
 }
 
 
@@ -115,7 +116,7 @@ def _compare(a, b, case, transport, world=2):
     prior, D, N, K, iters, burnout, dev = CASES[case]
     stride = 1 + D + (D * (D + 1) // 2 if prior == "niw" else 0)
     assert int(b["world"]) == world and str(b["transport"]) == transport
-    one = prior == "niw" and not case.endswith("_classic")                   # DPMM_OPT_ONE_COLLECTIVE (default) applies to the NIW per-step pass
+    one = not case.endswith("_classic")                                      # DPMM_OPT_ONE_COLLECTIVE (default while a packed row has <= 4096 doubles): both priors since round 5
     if one:     # ONE all-reduce per step: 3K rows (2K of the labels as swept + K re-drawn left rows); subset passes after splits add theirs
         assert bool(b["one_collective"]) and int(b["rows_bytes"]) == 3 * int(b["K"][-1]) * stride * 8
         assert iters <= int(b["allreduces"]) < iters + 16
