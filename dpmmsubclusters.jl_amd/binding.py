@@ -140,6 +140,9 @@ def build_library(force=False):
 _LIB = None
 
 
+ABI_VERSION = 3      # DPMM_ABI_VERSION of include/dpmm_hip.h this file is written against
+
+
 def load_library():
     global _LIB
     if _LIB is None:
@@ -162,6 +165,8 @@ def load_library():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        if lib.dpmm_abi_version() != ABI_VERSION:      # (dpmm_last_sweep_work fills 16 words since version 3: an older library would be handed too long a buffer, a newer one may overflow ours)
+            raise ImportError(f"{p}: DPMM_ABI_VERSION {lib.dpmm_abi_version()}, this binding is written for {ABI_VERSION} (include/dpmm_hip.h)")
         _LIB = lib
     return _LIB
 

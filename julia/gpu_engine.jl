@@ -18,6 +18,8 @@ using Serialization
 const libhip  = Libdl.dlopen("libdpmmhip.so")
 const libhost = Libdl.dlopen("libdpmmhost.so")
 hip(sym) = Libdl.dlsym(libhip, sym)
+@assert ccall(hip(:dpmm_abi_version), Cint, ()) == 3 "libdpmmhip.so: DPMM_ABI_VERSION differs from the one this file is written for (include/dpmm_hip.h)"
+@assert ccall(Libdl.dlsym(libhost, :dpmmh_abi_version), Cint, ()) == 5 "libdpmmhost.so: DPMMH_ABI_VERSION differs from the one this file is written for (include/dpmm_host.h)"
 
 # struct dpmmh_worker: ctx, rank, world, then 13 + 11 + 4 + 2 function pointers in the order of include/dpmm_host.h (the eleven niw_* /
 # *_device entries -- the NIW master's dense maths on the device -- and the eight mult_* entries -- the Multinomial master's Dirichlet
