@@ -74,6 +74,7 @@ ABI = [
     ("dpmm_debug_loglik", ctypes.c_int, [ctypes.c_void_p, _c_f32p]),
     ("dpmm_sync", ctypes.c_int, [ctypes.c_void_p]),
     ("dpmm_stream", ctypes.c_void_p, [ctypes.c_void_p]),
+    ("dpmm_last_sweep_parts_ms", ctypes.c_int, [ctypes.c_void_p, _c_f32p]),
     ("dpmm_last_kernel_ms", ctypes.c_int, [ctypes.c_void_p, _c_f32p, _c_f32p]),
     ("dpmm_debug_counters", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int]),
     ("dpmm_debug_set_prelaunch_hook", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
@@ -102,7 +103,7 @@ HOST_ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_voi
 
 # dpmm_set_option keys (include/dpmm_hip.h)
 MASTER_NSCALARS = 8          # DPMM_MASTER_NSCALARS
-OPT_SCREEN_MARGIN, OPT_TAIL_SCREEN, OPT_PRESCREEN, OPT_ORDERED_SWEEP, OPT_MULT_FORCE_F32, OPT_STATS_ITEMS, OPT_STATS_GROUPS, OPT_TRACE_SLOW, OPT_LOGLIK_REF_CONST, OPT_WAVE_PRIO, OPT_MULT_NO_U8, OPT_SWEEP_GRID, OPT_SWEEP_QUEUE_ROUNDS, OPT_BALL_SCREEN, OPT_KERNEL_TIMING, OPT_STATS_DERIVE, OPT_NOISE_AHEAD, OPT_REF_BRACKET, OPT_SORT_TILE, OPT_ONE_COLLECTIVE, OPT_BF16_SCREENS, OPT_COMM_TIMEOUT_MS, OPT_DIRECTION_SCREEN, _OPT_RESERVED_24, OPT_MULT_DRAWS_AHEAD = range(1, 26)
+OPT_SCREEN_MARGIN, OPT_TAIL_SCREEN, OPT_PRESCREEN, OPT_ORDERED_SWEEP, OPT_MULT_FORCE_F32, OPT_STATS_ITEMS, OPT_STATS_GROUPS, OPT_TRACE_SLOW, OPT_LOGLIK_REF_CONST, OPT_WAVE_PRIO, OPT_MULT_NO_U8, OPT_SWEEP_GRID, OPT_SWEEP_QUEUE_ROUNDS, OPT_BALL_SCREEN, OPT_KERNEL_TIMING, OPT_STATS_DERIVE, OPT_NOISE_AHEAD, OPT_REF_BRACKET, OPT_SORT_TILE, OPT_ONE_COLLECTIVE, OPT_BF16_SCREENS, OPT_COMM_TIMEOUT_MS, OPT_DIRECTION_SCREEN, _OPT_RESERVED_24, OPT_MULT_DRAWS_AHEAD, OPT_B3_SUBLABELS, OPT_LEAN_TILES = range(1, 28)
 
 
 class DpmmError(RuntimeError):
@@ -594,12 +595,13 @@ class Worker:
         n = max(1, v[7])
         sp = 8 * ((self.K + 15) // 16)      # bf16 matrix instructions of one direction screen: two per 16 clusters and point group
         # executed_flops: Float32 matrix work only (= SQ_INSTS_VALU_MFMA_MOPS_F32 x 512); the bf16 work (brackets, screens) beside it
+        dirs, b3 = v[15] & 0xFFFFFFFF, v[15] >> 32      # direction screens | bf16 three-plane sub-cluster evaluations (144 bf16 matrix instructions + 4 Float32 row sums each)
+        bf16 = v[8] * v[9] + v[11] * v[12] + v[13] * v[14] + dirs * sp + b3 * 144
         return dict(wave_tiles=v[0] / n, full_evals=v[1] / n, screens16=v[2] / n, tail_pairs=v[3] / n, mfma_per_full=v[4], mfma_per_screen=v[5],
-                    flops_per_mfma=v[6], executed_flops=(v[1] * v[4] + v[2] * v[5]) * v[6] / n, launches=v[7],
+                    flops_per_mfma=v[6], executed_flops=(v[1] * v[4] + v[2] * v[5] + 4 * b3) * v[6] / n, launches=v[7],
                     brackets=v[8] / n, bf16_mfma_per_bracket=v[9], bf16_bottom_screens=v[11] / n, bf16_top_screens=v[13] / n,
-                    direction_screens=v[15] / n,
-                    bf16_mfma=(v[8] * v[9] + v[11] * v[12] + v[13] * v[14] + v[15] * sp) / n,
-                    bf16_flops=(v[8] * v[9] + v[11] * v[12] + v[13] * v[14] + v[15] * sp) * v[10] / n)
+                    direction_screens=dirs / n, b3_evals=b3 / n,
+                    bf16_mfma=bf16 / n, bf16_flops=bf16 * v[10] / n)
 
     # ---- diagnostics
     def debug_subloglik(self):
@@ -640,9 +642,15 @@ class Worker:
 
     def set_timing(self, on):
         """on: False / True (sweep + statistics + all-reduce events) or a bit mask 1 (sweep kernel) | 2 (statistics) | 4 (all-reduces)."""
-        mask = 7 if on is True else int(on)
+        mask = 7 if on is True else int(on)      # (bit 3 = 8: the three parts of a D <= 64 sweep, last_sweep_parts_ms)
         self.timing = mask != 0
         self.set_option(OPT_KERNEL_TIMING, float(mask))
+
+    def last_sweep_parts_ms(self):
+        """(lean, labels, sub-labels) milliseconds of the last sweep's three launches (timing bits 0 and 3; zeros otherwise)."""
+        out = np.zeros(3, np.float32)
+        self._chk(self._lib.dpmm_last_sweep_parts_ms(self._h, _p(out, _c_f32p)))
+        return [float(v) for v in out]
 
     def last_kernel_ms(self):
         if not self.timing:

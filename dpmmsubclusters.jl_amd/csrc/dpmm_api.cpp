@@ -69,6 +69,8 @@ struct dpmm_ctx {
     int sweep_grid = 0, sweep_grid_max = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_part[2] = {nullptr, nullptr};   // DPMM_OPT_KERNEL_TIMING bit 3: behind niw_lean_kernel / behind the LSTORE sweep kernel (dpmm_last_sweep_parts_ms)
+    int have_parts = 0;                           // 0: no three-kernel sweep timed yet; 1: labels + sub-labels (no lean kernel); 2: lean + labels + sub-labels
     bool have_sweep_ev = false, have_stats_ev = false;
 
     float *dX = nullptr;
@@ -235,6 +237,12 @@ struct dpmm_ctx {
     bool sp_last = false;              // the last sweep ran the DIR kernel (its yield words are valid)
     int sp_K = -1;                     // number of clusters of the last parameter set the tables were built for
     int sp_cooldown = 0;               // parameter sets the screen stays off after it removed less than a quarter of what it was given
+    int opt_b3 = 1;                    // DPMM_OPT_B3_SUBLABELS: D in 33..64: sub-cluster evaluations through three-plane bf16 images, in kernels of their own (niw_lean.hip)
+    bool have_b3 = false;              // the images behind the bracket's in d_tail belong to the parameter set on the device
+    int opt_lean = 1;                  // DPMM_OPT_LEAN_TILES: tiles the cheap screens settle completely in niw_lean_kernel (-1 automatic is 1 with a regime switch; 0 never)
+    uint32_t *d_hard = nullptr;        // [1 + ceil(n / 64)]: count | wave tiles the lean kernel left to the general path
+    uint32_t *h_hard = nullptr;        // pinned: the count of the LAST sweep's list (read by the next sweep's regime decision, never waited for)
+    int lean_off = 0;                  // sweeps left without the lean kernel (a sweep that left more than 30 % of its tiles switches it off for 15)
     int opt_bf16scr = 1;               // D <= 64 sweep: bf16 screens in front of the Float32 16-row screen / of a survivor's first row block (DPMM_OPT_BF16_SCREENS)
     int opt_bracket = 1;               // D <= 64 sweep: certified bf16 bracket of the reference cluster's value instead of its Float32 evaluation where that decides nothing (DPMM_OPT_REF_BRACKET)
     int opt_timing = 0;                // bit 0 / 1 / 2: HIP events around the sweep kernel / the statistics pass / the all-reduces (dpmm_last_kernel_ms, dpmm_last_comm_ms)
@@ -502,7 +510,7 @@ static int ensure_capacity(dpmm_ctx *c, int K) {
         HIPCHK(c, hipMalloc(&c->d_mup, sizeof(float) * 3 * cap * 16 * c->NB));
         HIPCHK(c, hipMalloc(&c->d_lam, sizeof(float) * cap));
         if (c->NB == 8 || c->NB == 16) HIPCHK(c, hipMalloc(&c->d_refb_big, sizeof(uint32_t) * cap * niw_refb_big_words(c->NB)));
-        HIPCHK(c, hipMalloc(&c->d_tail, sizeof(float) * (16 * (cap + 2) + 16 * cap + (size_t)REFB_WORDS * cap)));      // pair records | per-cluster ball records | bf16 images of the reference bracket
+        HIPCHK(c, hipMalloc(&c->d_tail, sizeof(float) * (c->NB == 4 ? niw_tail_floats(cap) : 16 * (cap + 2) + 16 * cap + (size_t)REFB_WORDS * cap)));      // pair records | per-cluster ball records | bf16 images of the reference bracket | (NB = 4) three-plane images + offsets of niw_lean.hip
         HIPCHK(c, hipMalloc(&c->d_mdist, sizeof(float) * (size_t)cap * cap));
     } else {
         const size_t NT = (size_t)(c->ldx + 15) / 16, NRB = (size_t)(3 * cap + 15) / 16;
@@ -630,8 +638,15 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
     if (c->prior == DPMM_PRIOR_NIW && c->NB == 4) {
         CHK_CREATE(hipMalloc(&c->d_sp_frag, sizeof(uint32_t) * (size_t)SP_MAXK * SP_FRAG_WORDS));
         CHK_CREATE(hipMalloc(&c->d_sp_cons, sizeof(float) * (size_t)SP_MAXK * SP_CONS_FLOATS));
-        CHK_CREATE(hipHostMalloc((void **)&c->h_need, sizeof(uint32_t) * 8 * (size_t)std::max(1, c->sweep_grid_max), hipHostMallocDefault));
-        memset(c->h_need, 0, sizeof(uint32_t) * 8 * (size_t)std::max(1, c->sweep_grid_max));
+        // ([8 grid]: two words per wave of the sweep kernel | [4 grid]: tiles the lean kernel settled, per wave)
+        CHK_CREATE(hipHostMalloc((void **)&c->h_need, sizeof(uint32_t) * 12 * (size_t)std::max(1, c->sweep_grid_max), hipHostMallocDefault));
+        memset(c->h_need, 0, sizeof(uint32_t) * 12 * (size_t)std::max(1, c->sweep_grid_max));
+        if (c->NB == 4) {
+            CHK_CREATE(hipMalloc(&c->d_hard, sizeof(uint32_t) * (size_t)(2 + (n_local + 63) / 64)));
+            CHK_CREATE(hipMemsetAsync(c->d_hard, 0, sizeof(uint32_t) * 2, c->stream));
+            CHK_CREATE(hipHostMalloc((void **)&c->h_hard, 64, hipHostMallocDefault));
+            memset(c->h_hard, 0, 64);
+        }
     }
     CHK_CREATE(hipMalloc(&c->d_work, sizeof(unsigned long long) * (DPMM_WORK_SLOTS + 4 * DPMM_WORK_PER_WAVE * (size_t)std::max(1, c->sweep_grid_max))));
     CHK_CREATE(hipMemsetAsync(c->d_work, 0, sizeof(unsigned long long) * (DPMM_WORK_SLOTS + 4 * DPMM_WORK_PER_WAVE * (size_t)std::max(1, c->sweep_grid_max)), c->stream));
@@ -652,6 +667,7 @@ int dpmm_destroy(dpmm_ctx *c) {
     for (int i = 0; i < 2; ++i) { hipFree(c->d_Y[i]); hipFree(c->d_ld_sigma[i]); hipFree(c->d_mu_draw[i]); }
     hipFree(c->ma.fac); hipFree(c->ma.mean); hipFree(c->ma.kap); hipFree(c->ma.nu); hipFree(c->ma.rows_store);
     if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
+    for (auto &e : c->ev_part) if (e) hipEventDestroy(e);
     if (c->ev_master) hipEventDestroy(c->ev_master);
     if (c->ev_spec) hipEventDestroy(c->ev_spec);
     if (c->ev_noise) hipEventDestroy(c->ev_noise);
@@ -667,6 +683,8 @@ int dpmm_destroy(dpmm_ctx *c) {
     if (c->h_marg) hipHostFree(c->h_marg);
     hipFree(c->d_sp_frag); hipFree(c->d_sp_cons); hipFree(c->d_brk_flag); hipFree(c->d_brk_aref);
     if (c->h_need) hipHostFree(c->h_need);
+    if (c->h_hard) hipHostFree(c->h_hard);
+    hipFree(c->d_hard);
     hipFree(c->d_counts64); hipFree(c->d_cside); hipFree(c->d_row_off); hipFree(c->d_inv_off); hipFree(c->d_work); hipFree(c->d_par);
     comm_release(c);
     if (c->h_red) hipHostFree(c->h_red);
@@ -990,6 +1008,11 @@ int dpmm_commit_params(dpmm_ctx *c, int K) {
 static int direction_tables(dpmm_ctx *c, int K) {
     c->sp_ready = false;
     c->have_refb_big = false;
+    c->have_b3 = false;
+    if (c->prior == DPMM_PRIOR_NIW && c->NB == 4 && c->opt_b3 && c->have_tail && !c->predictive) {
+        HIPCHK(c, launch_niw_b3_pack(c->d_Rp, c->d_mup, K, c->d_tail, c->stream));      // the sub-cluster factors' bf16 planes + offsets (niw_lean.hip)
+        c->have_b3 = true;
+    }
     if (c->prior == DPMM_PRIOR_NIW && (c->NB == 8 || c->NB == 16) && c->d_refb_big && c->opt_bracket && c->have_tail && K > 1) {
         HIPCHK(c, launch_niw_refb_big(c->d_Rp, c->NB, K, c->d_refb_big, c->stream));      // D = 128, 256: the reference bracket's images
         c->have_refb_big = true;
@@ -1005,8 +1028,10 @@ static int direction_tables(dpmm_ctx *c, int K) {
             const uint32_t v = c->h_need[2 * w];
             if (v & 0x8000u) { many_ub += v >> 16; tiles_ub += v & 0x7FFFu; } else { many += v >> 16; tiles += v & 0x7FFFu; }
             if (c->sp_last) { const uint32_t y = c->h_need[2 * w + 1]; given += y & 0xFFFFu; removed += y >> 16; }
+            tiles += c->h_need[8 * (size_t)c->sweep_grid_max + w];      // tiles niw_lean_kernel settled (no candidate behind the 4-row tests)
         }
-        memset(c->h_need, 0, sizeof(uint32_t) * 2 * (size_t)nw);      // (read once: a later launch on a smaller grid, or one that does not count, leaves zeros -- "no tiles")
+        memset(c->h_need, 0, sizeof(uint32_t) * 2 * (size_t)nw);
+        memset(c->h_need + 8 * (size_t)c->sweep_grid_max, 0, sizeof(uint32_t) * (size_t)nw);      // (read once: a later launch on a smaller grid, or one that does not count, leaves zeros -- "no tiles")
         // (break-even measured on the growth run: at 4.3 candidates per tile the screen costs 3 % of the step, at 28 it saves a third)
         if (tiles > 0) c->sp_regime = c->sp_regime ? (many >= tiles * 4) : (many >= tiles * 8);
         else if (tiles_ub > 0 && many_ub < tiles_ub * 4) c->sp_regime = false;        // even the upper bound is below the switch-off level
@@ -1173,6 +1198,38 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
         if (!g_dbg) { hipMalloc(&g_dbg, sizeof(unsigned long long) * 16 * 4 * 4096); hipMemset(g_dbg, 0, sizeof(unsigned long long) * 16 * 4 * 4096); }
         a.dbg = g_dbg;
 #endif
+        const bool b3 = c->NB == 4 && c->have_b3 && c->opt_b3 && !table && !c->predictive && a.tail != nullptr;
+        if (b3) {
+            // bf16 sub-label evaluation active (niw_lean.hip): the sweep kernel draws and STORES the labels (LSTORE instantiations), the sub-labels of
+            // the same tiles follow in a launch of their own -- every sub-cluster value of a sweep then comes from the same arithmetic
+            // First the tiles the cheap screens settle completely (niw_lean_kernel: labels and sub-labels in one go); what it leaves goes through
+            // the list.  A sweep that left more than 30 % of its tiles (overlapping clusters: the screens' later stages do the work) switches the
+            // lean kernel off for 15 sweeps -- every path gives the same labels and sub-labels, so the decision is free to be local.
+            const bool lean_ok = c->opt_lean != 0 && c->opt_bracket && a.use_prev && a.screen_margin > 0.f && !final_argmax && a.lam == nullptr && c->K > 1 && c->d_hard;
+            const int64_t nwt = (c->n + 63) / 64;
+            if (lean_ok && c->lean_off == 0 && (int64_t)c->h_hard[0] * 10 > nwt * 3) c->lean_off = 15;      // (the count of the last sweep that ran the lean kernel)
+            const bool use_lean = lean_ok && c->lean_off == 0;
+            if (lean_ok && c->lean_off > 0) { c->lean_off -= 1; c->h_hard[0] = 0; }
+            const uint32_t *list = nullptr;
+            const bool parts = (c->opt_timing & 8) != 0 && (c->opt_timing & 1) != 0;
+            if (parts && !c->ev_part[0]) for (auto &e : c->ev_part) HIPCHK(c, hipEventCreate(&e));
+            if (use_lean) {
+                HIPCHK(c, hipMemsetAsync(c->d_hard, 0, sizeof(uint32_t), c->stream));
+                uint32_t *need2 = a.need ? c->h_need + 8 * (size_t)c->sweep_grid_max : nullptr;
+                HIPCHK(c, launch_niw_lean(a, c->d_hard, need2, c->sweep_grid, c->stream));
+                if (parts) HIPCHK(c, hipEventRecord(c->ev_part[0], c->stream));
+                HIPCHK(c, launch_copy_bytes(c->h_hard, c->d_hard, sizeof(uint32_t), c->stream));
+                list = c->d_hard;
+            }
+            a.bf16scr |= 4;
+            a.tdf = reinterpret_cast<const float *>(list);                         // (the LSTORE instantiations' tile list: null = all tiles)
+            HIPCHK(c, launch_niw_sweep(c->NB, a, c->sweep_grid, c->stream));
+            if (parts) HIPCHK(c, hipEventRecord(c->ev_part[1], c->stream));
+            c->have_parts = parts ? (use_lean ? 2 : 1) : 0;
+            a.bf16scr &= 3;
+            a.tdf = nullptr;
+            HIPCHK(c, launch_niw_sub(a, list, c->sweep_grid, c->stream));
+        } else
         HIPCHK(c, launch_niw_sweep(c->NB, a, c->sweep_grid, c->stream));
     } else {
         MultSweepArgs a{};
@@ -2519,6 +2576,8 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
         case DPMM_OPT_REF_BRACKET: c->opt_bracket = value != 0; return DPMM_OK;
         case DPMM_OPT_COMM_TIMEOUT_MS: c->comm_timeout_ms = value > 0 ? (int)std::min(value, 2.0e9) : 0; return DPMM_OK;
         case DPMM_OPT_BF16_SCREENS: c->opt_bf16scr = value != 0; return DPMM_OK;
+        case DPMM_OPT_LEAN_TILES: c->opt_lean = value != 0; c->lean_off = 0; return DPMM_OK;
+        case DPMM_OPT_B3_SUBLABELS: c->opt_b3 = value != 0; if (!c->opt_b3) c->have_b3 = false; return DPMM_OK;      // (switching it ON takes effect with the next parameter set: its images are packed behind the parameters)
         case DPMM_OPT_DIRECTION_SCREEN:
             c->opt_direction = value < 0 ? -1 : (value != 0);
             if (c->opt_direction == 0) { c->sp_ready = false; c->sp_regime = false; }
@@ -2543,7 +2602,7 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
             c->sb.tile = t; return DPMM_OK;          // (the tile tables are rebuilt by every pass; perm stays a valid order)
         }
         case DPMM_OPT_KERNEL_TIMING:
-            c->opt_timing = (int)value & 7;
+            c->opt_timing = (int)value & 15;
             if (!(c->opt_timing & 1)) c->have_sweep_ev = false;
             if (!(c->opt_timing & 2)) c->have_stats_ev = false;
             if (!(c->opt_timing & 4)) c->have_comm_ev[0] = c->have_comm_ev[1] = false;
@@ -2570,7 +2629,7 @@ int dpmm_last_sweep_work(dpmm_ctx *c, uint64_t *out16) {
         out16[8] += h[DPMM_WORK_PER_WAVE * w + 4];
         out16[11] += h[DPMM_WORK_PER_WAVE * w + 5];
         out16[13] += h[DPMM_WORK_PER_WAVE * w + 6];
-        out16[15] += h[DPMM_WORK_PER_WAVE * w + 7];          // direction screens (8 bf16 matrix instructions per 16 clusters + 4 Float32 row sums each)
+        out16[15] += h[DPMM_WORK_PER_WAVE * w + 7];          // low half: direction screens (8 bf16 matrix instructions per 16 clusters + 4 Float32 row sums each); high half: bf16 three-plane sub-cluster evaluations (niw_lean.hip)
     }
     // totals of the launches since the previous call (out16[7] of them); the slots start again from zero
     const long long launches = c->work_launches;
@@ -2704,6 +2763,19 @@ int dpmm_debug_subloglik(dpmm_ctx *c, float *out) {
     HIPCHK(c, hipSetDevice(c->device));
     if (c->n == 0) return DPMM_OK;
     const int K = c->K, K2 = 2 * K;
+    if (c->prior == DPMM_PRIOR_NIW && c->have_b3 && c->opt_b3 && c->have_tail) {
+        // the sweeps' sub-label phase runs the three-plane bf16 evaluation (niw_lean.hip): the same device functions, for every point and cluster
+        NiwSweepArgs a{};
+        a.X = c->dX; a.ldx = c->ldx; a.n = c->n; a.K = K; a.mup = c->d_mup; a.cst = c->d_cst; a.tail = c->d_tail;
+        float *tab = nullptr;
+        hipError_t e = hipMalloc(&tab, sizeof(float) * (size_t)K2 * (size_t)c->n);
+        if (e == hipSuccess) e = launch_niw_b3_debug(a, tab, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(out, tab, sizeof(float) * (size_t)K2 * (size_t)c->n, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = sync_stream(c, c->stream);
+        hipFree(tab);
+        if (e != hipSuccess) { c->err = std::string("dpmm_debug_subloglik: ") + hipGetErrorString(e); return DPMM_EHIP; }
+        return DPMM_OK;
+    }
     if (K2 > DPMM_MAX_CLUSTERS) return fail(c, DPMM_ELIMIT, "debug_subloglik: 2K > DPMM_MAX_CLUSTERS");
     const int64_t stride = c->ntiles * c->tile;
     const bool niw = c->prior == DPMM_PRIOR_NIW;
@@ -2807,6 +2879,20 @@ int dpmm_debug_bracket_big(dpmm_ctx *c, float *aref, uint32_t *tile_flags) {
     if (e == hipSuccess) e = sync_stream(c, c->stream);
     hipFree(d); hipFree(f);
     if (e != hipSuccess) { c->err = std::string("dpmm_debug_bracket_big: ") + hipGetErrorString(e); return DPMM_EHIP; }
+    return DPMM_OK;
+}
+
+int dpmm_last_sweep_parts_ms(dpmm_ctx *c, float *out3) {
+    if (!c || !out3) return DPMM_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    out3[0] = out3[1] = out3[2] = 0.f;
+    if (!c->have_sweep_ev || c->have_parts == 0) return DPMM_OK;
+    HIPCHK(c, hipEventSynchronize(c->ev[1]));
+    if (c->have_parts == 2) {
+        HIPCHK(c, hipEventElapsedTime(&out3[0], c->ev[0], c->ev_part[0]));
+        HIPCHK(c, hipEventElapsedTime(&out3[1], c->ev_part[0], c->ev_part[1]));
+    } else HIPCHK(c, hipEventElapsedTime(&out3[1], c->ev[0], c->ev_part[1]));
+    HIPCHK(c, hipEventElapsedTime(&out3[2], c->ev_part[1], c->ev[1]));
     return DPMM_OK;
 }
 

@@ -118,4 +118,18 @@ __host__ __device__ __forceinline__ void refb_map(int e, int &row, int &col0, in
     col1 = col0 + 1;
 }
 
+// THREE-PLANE bf16 split of a Float32 (the sub-cluster evaluations of niw_lean.hip): v = h + m + l exactly, h = bf16(v), m = bf16(v - h),
+// l = bf16(v - h - m) (each round-to-nearest-even; the residuals are exact in Float32 and the third one fits 8 bits: 3 x 8 significand bits =
+// the 24 of the Float32).  plane 0 / 1 / 2 -> bits of h / m / l.  Non-finite v: every plane non-finite.
+__host__ __device__ __forceinline__ uint32_t bf16x3_plane_bits(float v, int plane) {
+    auto rne = [](float f) -> uint32_t { uint32_t u; __builtin_memcpy(&u, &f, 4); return ((u + 0x7fffu + ((u >> 16) & 1u)) >> 16) & 0xffffu; };
+    auto up = [](uint32_t b) -> float { const uint32_t u = b << 16; float f; __builtin_memcpy(&f, &u, 4); return f; };
+    const uint32_t h = rne(v);
+    if (plane == 0) return h;
+    const float r1 = v - up(h);
+    const uint32_t m = rne(r1);
+    if (plane == 1) return m;
+    return rne(r1 - up(m));
+}
+
 }  // namespace dpmm

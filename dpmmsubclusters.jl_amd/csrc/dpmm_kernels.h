@@ -15,6 +15,8 @@ constexpr int DPMM_WORK_QUEUES = 8;                               // queue heads
 constexpr int DPMM_WORK_SLOTS = 8 + 16 * DPMM_WORK_QUEUES;        // first per-wave counter slot
 constexpr int DPMM_WORK_PER_WAVE = 8;                             // u64 per wave slot (one 64-byte half line): wave tiles, full evaluations, 16-row screens, tail pairs, reference brackets, 3 spare
 constexpr int REFB_FRAGS = 6, REFB_WORDS = REFB_FRAGS * 256;      // dwords of a cluster's bf16 image for the reference bracket (refb_map, dpmm_device.h)
+constexpr int B3_WORDS = 3 * REFB_WORDS;                           // dwords of a matrix's three-plane bf16 image (planes h | m | l, each in the bracket's fragment layout): niw_lean.hip
+constexpr int B3_DVEC = 64;                                        // floats of a sub-cluster's offset vector d = R_s (mu_k - mu_s)
 
 struct NiwSweepArgs {
     const float *X;      // [n][ldx] points (zero padded to ldx = roundup(D,4))
@@ -82,6 +84,17 @@ inline size_t niw_refb_big_words(int NB) { size_t c = 0; for (int bi = 0; bi < N
 hipError_t launch_niw_refb_big(const float *Rp, int NB, int K, uint32_t *out, hipStream_t s);
 // the bracket itself, in front of the sweep launch (same NiwSweepArgs: X, order, bins, mup, cst): tile_flag [ceil(n / 128)], aref [128 ceil(n / 128)]
 hipError_t launch_niw_bracket_big(int NB, const NiwSweepArgs &a, const uint32_t *refb, uint32_t *tile_flag, float *aref, hipStream_t s);
+// ---- niw_lean.hip: the bf16 three-plane evaluation of the sub-cluster quadratic forms (NB = 4)
+// images [3K][B3_WORDS] and offset vectors [3K][B3_DVEC] of the 2K sub-cluster factors from the Float32 fragment image, written behind the bracket's images in `tail`
+hipError_t launch_niw_b3_pack(const float *Rp, const float *mup, int K, float *tail, hipStream_t s);
+inline size_t niw_tail_floats(size_t cap) { return 16 * (cap + 2) + 16 * cap + (size_t)REFB_WORDS * cap + 3 * cap * (size_t)B3_WORDS + 3 * cap * (size_t)B3_DVEC; }      // pair records | ball records | bracket images | b3 images | b3 offsets
+// out [2K][n]: both sub-cluster values of every point under every cluster (needs X, ldx, n, K, mup, cst, tail)
+hipError_t launch_niw_b3_debug(const NiwSweepArgs &a, float *out, hipStream_t s);
+// the sub-label phase alone for the wave tiles of `list` (list[0] = count, list[1 ..] = tile indices; null: all tiles); labels are read from bins
+hipError_t launch_niw_sub(const NiwSweepArgs &a, const uint32_t *list, int grid, hipStream_t s);
+// whole tiles where bracket + ball + tail screens settle them (every point had label k0, nothing else can compete): labels AND sub-labels; every
+// other tile is appended to list ([0] = count, cleared by the caller; [1 ..] = wave-tile indices) and left untouched.  need2 [4 grid] (nullable, pinned): tiles settled per wave
+hipError_t launch_niw_lean(const NiwSweepArgs &a, uint32_t *list, uint32_t *need2, int grid, hipStream_t s);
 hipError_t launch_niw_direction(const float *Rp, const float *mup, const float *cst, int D, int K, uint32_t *frag, float *cons, hipStream_t s);
 
 struct MultSweepArgs {

@@ -1,0 +1,475 @@
+// niw_lean.hip -- the bf16 three-plane evaluation of the SUB-CLUSTER quadratic forms (D in 33 .. 64) and the kernels built on it.
+//
+// Stands in for (reference paths relative to the reference checkout):
+//   sample_sub_clusters_worker! / create_subclusters_labels!   src/local_clusters_actions.jl:70-95
+//   log_likelihood!(::mv_gaussian)                              src/distributions/mv_gaussian.jl:21-25
+//   and, for the tiles the cheap screens settle completely, sample_labels_worker! (src/local_clusters_actions.jl:112-134)
+//
+// Why a file of its own.  Every FP32-input matrix instruction holds the SIMD's vector issue port for its whole duration
+// (scripts/microbench/mfma_shapes_issue.hip: a v_fma_f32 of the same wave behind a v_mfma_f32_16x16x4_f32 adds its full 5-9 cycles to the
+// 32, the other wave of the SIMD gets one vector instruction per one to four of them); v_mfma_f32_16x16x32_bf16 hides two fillers
+// completely and lets the other wave issue at full rate.  The D <= 64 sweep spent 10.5 k of a tile's 23 k SIMD cycles in the two Float32
+// sub-cluster evaluations.  On the bf16 pipe they are 4.6 k cycles that overlap vector work -- but their operands (96 registers for
+// the planes of z, 48 of fragments: 230 registers for the phase alone) do not fit beside what niw_sweep_direct_kernel keeps live: inside
+// that kernel every variant spilled 100-140 vector registers and ran 30-50 % slower (docs/experiments/r05_bf16x3_sublabels.patch).  Here the
+// evaluation lives in kernels that carry nothing else:
+//   niw_lean_kernel   a whole tile in one go where the screens settle it: every point of the wave had label k0, the certified bf16 bracket
+//                     of a_k0 + the ball test + the 4-row tail screens exclude every other cluster for every point -- then z = k0 by the
+//                     same proof as in niw_sweep_direct_kernel (its `ref_skipped` draw) and only the sub-labels need values.  One
+//                     conversion of z = x - mu_k0 into planes serves the bracket (plane h) and both sub-cluster evaluations.  Tiles it
+//                     cannot settle go to a list and are left untouched.
+//   niw_sub_kernel    the sub-label phase alone for the tiles of that list (or all tiles), behind niw_sweep_direct_kernel<.., LSTORE>
+//                     which draws their labels and stores them.
+// INVARIANT kept: a sub-cluster value is a function of (point, matrix) alone -- z is taken relative to the mean of the point's OWN (new)
+// cluster, whatever tile or kernel the point is in -- so shards, tile schedules, debug tables and the two kernels give the same bits.
+//
+// The arithmetic.  Float32 values split EXACTLY into three bf16 planes, v = h + m + l (bf16x3_plane_bits: 3 x 8 significand bits); bf16 x bf16
+// products are exact in the Float32 accumulator; of the nine plane products the six with weight >= 2^-16 are kept,
+//     y = Rh zh + (Rh zm + Rm zh) + (Rh zl + Rm zm + Rl zh),
+// the three dropped ones are below 2^-24 |R||z| per term -- the size of ONE Float32 rounding of the product, which the Float32 chain commits
+// on every term.  z = x - mu_k (one Float32 subtraction per feature, as the reference's x - mu), converted once per label and shared by the
+// left and the right evaluation:  R_s (x - mu_s) = R_s z + d_s,  d_s = R_s (mu_k - mu_s)  (niw_b3_pack_kernel: Float64 sums, rounded once;
+// |mu_k - mu_s| is a sub-cluster's offset inside its own cluster, d_s is of the size of y itself: nothing cancels), d_s the accumulator's
+// initial value.  Per matrix and 64 points: 144 bf16 matrix instructions of 16 cycles instead of 164 Float32 ones of 32.
+// Image of a matrix: planes h | m | l, each the six fragments of refb_map ([64 lanes][4 dwords]): B3_WORDS dwords, behind the bracket's
+// images in the `tail` buffer (b3_images / b3_offsets).
+#include "dpmm_device.h"
+#include "dpmm_kernels.h"
+#include "niw_device.h"
+
+namespace dpmm {
+
+__host__ __device__ __forceinline__ const uint32_t *b3_images(const float *tail, int K) { return refb_records(tail, K) + (size_t)K * REFB_WORDS; }
+__host__ __device__ __forceinline__ const float *b3_offsets(const float *tail, int K) { return reinterpret_cast<const float *>(b3_images(tail, K) + (size_t)3 * K * B3_WORDS); }
+
+struct B3Z { u32x4_t p[4][2][3]; };      // [point group][32-feature slice][plane]: the B operands of the wave's 64 points (96 registers)
+
+__device__ __forceinline__ void b3_split_pair(float a, float b, uint32_t &ph, uint32_t &pm, uint32_t &pl) {
+    ph = pack_bf16_pair(a, b);
+    const float ra = a - __uint_as_float(ph << 16), rb = b - __uint_as_float(ph & 0xffff0000u);        // exact
+    pm = pack_bf16_pair(ra, rb);
+    const float sa = ra - __uint_as_float(pm << 16), sb = rb - __uint_as_float(pm & 0xffff0000u);      // exact; fits 8 bits
+    pl = pack_bf16_pair(sa, sb);
+}
+// z = x - mk for all four point groups (mk: a cluster-level mean in the x registers' layout), split into planes
+__device__ __forceinline__ void b3_convert(const f32x4 (&x)[4][4], const f32x4 (&mk)[4], B3Z &Z) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            const f32x4 lo = x[n][2 * sl] - mk[2 * sl], hi = x[n][2 * sl + 1] - mk[2 * sl + 1];
+            uint32_t H[4], M[4], L[4];
+            b3_split_pair(lo.x, lo.y, H[0], M[0], L[0]);
+            b3_split_pair(lo.z, lo.w, H[1], M[1], L[1]);
+            b3_split_pair(hi.x, hi.y, H[2], M[2], L[2]);
+            b3_split_pair(hi.z, hi.w, H[3], M[3], L[3]);
+            Z.p[n][sl][0] = (u32x4_t){H[0], H[1], H[2], H[3]};
+            Z.p[n][sl][1] = (u32x4_t){M[0], M[1], M[2], M[3]};
+            Z.p[n][sl][2] = (u32x4_t){L[0], L[1], L[2], L[3]};
+        }
+}
+// Both sub-cluster values of the wave's points for cluster k (wave-uniform) from the planes of z = x - mu_k: bl / br = cst - |R_s z + d_s|^2 / 2
+// for "this lane's point" (point lane & 15 of point group lane >> 4).  ONE pipeline over the eight row blocks of the two matrices (left
+// 0..3, right 0..3): the fragments of a row block (two 32-feature slices for row blocks 0 and 1, one for 2 and 3; three planes each) and its
+// four offsets are requested two row blocks ahead of their matrix instructions.
+// (B3Head: the first two row blocks' fragments, their offsets and the two constants -- a caller with other work in front of the evaluation
+// requests them there: b3_head)
+struct B3Head { u32x4_t a[2][2][3]; f32x4 d[2]; float cl, cr; };
+__device__ __forceinline__ B3Head b3_head(const float *__restrict__ tail, const float *__restrict__ cst, int K, int k, int lane, int g) {
+    const u32x4_t *F = reinterpret_cast<const u32x4_t *>(b3_images(tail, K) + (size_t)(3 * k + 1) * B3_WORDS) + lane;
+    const float *dvec = b3_offsets(tail, K) + (size_t)(3 * k + 1) * B3_DVEC;
+    B3Head H;
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) H.a[bi][s2][p] = F[64 * (6 * p + 2 * bi + s2)];
+        H.d[bi] = *reinterpret_cast<const f32x4 *>(dvec + 16 * bi + 4 * g);
+    }
+    H.cl = cst[3 * k + 1]; H.cr = cst[3 * k + 2];
+    return H;
+}
+__device__ __forceinline__ void b3_eval(const float *__restrict__ tail, int K, int k, const B3Z &Z, const B3Head &H, int lane, int g, float &bl, float &br) {
+    const uint32_t *img = b3_images(tail, K) + (size_t)(3 * k + 1) * B3_WORDS;
+    const float *dvec = b3_offsets(tail, K) + (size_t)(3 * k + 1) * B3_DVEC;
+    const u32x4_t *F = reinterpret_cast<const u32x4_t *>(img) + lane;          // fragment f of plane p of matrix m: F[64 (18 m + 6 p + f)]
+    constexpr int F0[4] = {0, 2, 4, 5};                                        // first fragment of a row block (refb_map's order: (0,0) (0,1) (1,0) (1,1) (2,1) (3,1))
+    u32x4_t Af[8][2][3];                                                       // [block 4 m + bi][slice of the block][plane]; SSA values: nothing is copied
+    f32x4 dv[8];
+    auto load_block = [&](int b8) {
+        const int m = b8 >> 2, bi = b8 & 3;
+#pragma unroll
+        for (int s2 = 0; s2 < (bi < 2 ? 2 : 1); ++s2)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) Af[b8][s2][p] = F[64 * (18 * m + 6 * p + F0[bi] + s2)];
+        dv[b8] = *reinterpret_cast<const f32x4 *>(dvec + B3_DVEC * m + 16 * bi + 4 * g);
+    };
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) Af[bi][s2][p] = H.a[bi][s2][p];
+        dv[bi] = H.d[bi];
+    }
+    const float cl = H.cl, cr = H.cr;
+    auto terms = [&](f32x4 acc, const u32x4_t (&a)[3], const u32x4_t (&z)[3]) -> f32x4 {       // small terms first
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[2]), __builtin_bit_cast(bf16x8_t, z[0]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[0]), __builtin_bit_cast(bf16x8_t, z[2]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[1]), __builtin_bit_cast(bf16x8_t, z[1]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[1]), __builtin_bit_cast(bf16x8_t, z[0]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[0]), __builtin_bit_cast(bf16x8_t, z[1]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[0]), __builtin_bit_cast(bf16x8_t, z[0]), acc, 0, 0, 0);
+        return acc;
+    };
+    float q[4] = {0.f, 0.f, 0.f, 0.f};
+    float sel_l = 0.f, sel_r = 0.f;
+#pragma unroll
+    for (int b8 = 0; b8 < 8; ++b8) {
+        const int bi = b8 & 3;
+        if (b8 + 2 < 8) load_block(b8 + 2);
+        __builtin_amdgcn_sched_barrier(0);          // (the requests stay in front of this row block's matrix instructions; none of a later row block joins them)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            f32x4 acc = dv[b8];
+            if (bi < 2) { acc = terms(acc, Af[b8][0], Z.p[n][0]); acc = terms(acc, Af[b8][1], Z.p[n][1]); }
+            else acc = terms(acc, Af[b8][0], Z.p[n][1]);
+            q[n] = __builtin_fmaf(acc[0], acc[0], q[n]); q[n] = __builtin_fmaf(acc[1], acc[1], q[n]);
+            q[n] = __builtin_fmaf(acc[2], acc[2], q[n]); q[n] = __builtin_fmaf(acc[3], acc[3], q[n]);
+        }
+        if (bi == 3) {                              // a matrix is complete: sum over the four row groups of a column (the ones-MFMA), this lane's point
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const f32x4 tot = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, q[n], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                if (g == n) { if (b8 == 3) sel_l = tot[0]; else sel_r = tot[0]; }
+                q[n] = 0.f;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    bl = __builtin_fmaf(-0.5f, sel_l, cl);
+    br = __builtin_fmaf(-0.5f, sel_r, cr);
+}
+// the cluster-level mean of cluster k in the x registers' layout
+__device__ __forceinline__ void b3_mean(const float *__restrict__ mup, int k, int g, f32x4 (&mk)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) mk[t] = *reinterpret_cast<const f32x4 *>(mup + (size_t)(3 * k) * 64 + 16 * t + 4 * g);
+}
+// the lane's 16 bytes of every (point group, 16-feature slice) of the B operand, as the sweep kernels hold x: point (n, ci) = p[16 n + ci]
+__device__ __forceinline__ void gather_x64(const float *__restrict__ X, int64_t ldx, int myp32, int ci, int g, f32x4 (&x)[4][4]) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int pn = __shfl(myp32, 16 * n + ci);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int e = 16 * t + 4 * g;
+            x[n][t] = (pn >= 0 && e < ldx) ? *reinterpret_cast<const f32x4 *>(X + (int64_t)pn * ldx + e) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ images
+// Three-plane bf16 images and offset vectors of the 2K sub-cluster factors from the Float32 fragment image both pack kernels write
+// (NB = 4: Rp [3K][10][64][4], mup [3K][64]); one workgroup per sub-cluster matrix.
+__global__ __launch_bounds__(256) void niw_b3_pack_kernel(const float *__restrict__ Rp, const float *__restrict__ mup, float *__restrict__ tail, int K) {
+    constexpr int NP = 10;
+    uint32_t *img = const_cast<uint32_t *>(b3_images(tail, K));
+    float *dvec = const_cast<float *>(b3_offsets(tail, K));
+    const int k = blockIdx.x >> 1, j = 3 * k + 1 + (blockIdx.x & 1);
+    const float *Rj = Rp + (size_t)j * NP * 256;
+    auto elem = [&](int row, int col) -> float {            // R[row][col] out of the fragment image (0 below the diagonal)
+        const int bi = row >> 4, t = col >> 4;
+        if (t < bi) return 0.f;
+        const int pair = pair_base<4>(bi) + (t - bi);
+        const int ln = (row & 15) + 16 * ((col & 15) >> 2);
+        return Rj[(size_t)pair * 256 + ln * 4 + (col & 3)];
+    };
+    if (blockIdx.y < 3) {               // one plane of the matrix: 1536 dwords, six per thread
+        const int plane = blockIdx.y;
+        uint32_t *out = img + (size_t)j * B3_WORDS + (size_t)plane * REFB_WORDS;
+        for (int e = threadIdx.x; e < REFB_WORDS; e += 256) {
+            int row, c0, c1;
+            refb_map(e, row, c0, c1);
+            out[e] = bf16x3_plane_bits(elem(row, c0), plane) | (bf16x3_plane_bits(elem(row, c1), plane) << 16);
+        }
+    } else {                            // the offsets d = R_s (mu_k - mu_s): four threads per row, 16 columns each, Float64
+        const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
+        double acc = 0.0;
+#pragma unroll 4
+        for (int c = 16 * part; c < 16 * part + 16; ++c)
+            if (c >= row) acc += (double)elem(row, c) * ((double)mup[(size_t)(3 * k) * 64 + c] - (double)mup[(size_t)j * 64 + c]);
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        if (part == 0) dvec[(size_t)j * B3_DVEC + row] = (float)acc;
+    }
+}
+hipError_t launch_niw_b3_pack(const float *Rp, const float *mup, int K, float *tail, hipStream_t s) {
+    if (K < 1) return hipSuccess;
+    DPMM_LAUNCH(niw_b3_pack_kernel, dim3(2 * K, 4), dim3(256), 0, s, Rp, mup, tail, K);
+    return hipGetLastError();
+}
+
+// Diagnostic (dpmm_debug_subloglik while the bf16 evaluation is active): for every point of the shard and every cluster k the two values a
+// sweep would compute if the point's label were k -- out[(2k + s) n + i] -- through the same device functions, one wave per 64 points
+__global__ __launch_bounds__(256) void niw_b3_debug_kernel(NiwSweepArgs A, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63, ci = lane & 15, g = lane >> 4;
+    const int64_t wbase = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    if (wbase >= A.n) return;
+    const int myp32 = wbase + lane < A.n ? (int)(wbase + lane) : -1;
+    for (int k = 0; k < A.K; ++k) {
+        f32x4 x[4][4], mk[4];
+        gather_x64(A.X, A.ldx, myp32, ci, g, x);
+        b3_mean(A.mup, k, g, mk);
+        B3Z Z;
+        b3_convert(x, mk, Z);
+        float bl, br;
+        const B3Head H = b3_head(A.tail, A.cst, A.K, k, lane, g);
+        b3_eval(A.tail, A.K, k, Z, H, lane, g, bl, br);
+        if (myp32 >= 0) { out[(int64_t)(2 * k) * A.n + myp32] = bl; out[(int64_t)(2 * k + 1) * A.n + myp32] = br; }
+    }
+}
+hipError_t launch_niw_b3_debug(const NiwSweepArgs &a, float *out, hipStream_t s) {
+    if (!a.tail || a.n <= 0) return hipErrorInvalidValue;
+    DPMM_LAUNCH(niw_b3_debug_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------ sub-labels alone
+// The sub-label phase of the tiles named in `list` (list[0] = their number, list[1 ..] = wave-tile indices; null: every tile): the new labels are
+// in bins (niw_sweep_direct_kernel<.., LSTORE> stored 2 z + old sub-label), the second uniform of the point's Philox draw decides between left
+// and right (create_subclusters_labels!, local_clusters_actions.jl:83-95).  One wave per tile of 64 positions of the visiting order.
+__global__ __launch_bounds__(256, 2) void niw_sub_kernel(NiwSweepArgs A, const uint32_t *__restrict__ list) {
+    const int lane = threadIdx.x & 63, ci = lane & 15, g = lane >> 4;
+    const bool use_order = A.order != nullptr && *A.order_total == (int32_t)A.n;
+    const int64_t nwtiles = (A.n + 63) / 64;
+    const int64_t count = list ? (int64_t)list[0] : nwtiles;
+    const int wave_id = (int)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int)gridDim.x * 4;
+    unsigned nw_b3 = 0;
+    for (int64_t idx = wave_id; idx < count; idx += nwaves) {
+        const int64_t tile = list ? (int64_t)list[1 + idx] : idx;
+        const int64_t pos = tile * 64 + lane;
+        const bool valid = pos < A.n;
+        const int myp32 = valid ? (use_order ? A.order[pos] : (int)pos) : -1;
+        const int zb = valid ? A.bins[myp32] : -1;
+        int z = zb >> 1;
+        if ((unsigned)z >= (unsigned)A.K) z = -1;                       // (a label outside [0, K): left alone)
+        float u_sub = 0.f;
+        if (z >= 0) u_sub = u01(philox4x32_10(A.seed, (uint64_t)(A.first_index + myp32), A.epoch, STREAM_SWEEP).v[1]);
+        float b0 = -INFINITY, b1 = -INFINITY;
+        unsigned long long todo = __ballot(z >= 0);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int k = __builtin_amdgcn_readfirstlane(__shfl(z, leader));
+            todo &= ~__ballot(z == k);
+            f32x4 x[4][4], mk[4];
+            gather_x64(A.X, A.ldx, myp32, ci, g, x);
+            b3_mean(A.mup, k, g, mk);
+            const B3Head H = b3_head(A.tail, A.cst, A.K, k, lane, g);       // (requested with x: the conversion covers their round trip)
+            __builtin_amdgcn_sched_barrier(0);
+            B3Z Z;
+            b3_convert(x, mk, Z);
+            float bl, br;
+            b3_eval(A.tail, A.K, k, Z, H, lane, g, bl, br);
+            if (z == k) { b0 = bl; b1 = br; }
+            nw_b3 += 2;
+        }
+        if (z >= 0) A.bins[myp32] = 2 * z + draw2(b0, b1, u_sub);
+    }
+    if (A.work && lane == 0) A.work[DPMM_WORK_SLOTS + (size_t)wave_id * DPMM_WORK_PER_WAVE + 7] += (unsigned long long)nw_b3 << 32;
+}
+hipError_t launch_niw_sub(const NiwSweepArgs &a, const uint32_t *list, int grid, hipStream_t s) {
+    if (!a.tail || a.n <= 0) return hipErrorInvalidValue;
+    DPMM_LAUNCH(niw_sub_kernel, dim3(grid), dim3(256), 0, s, a, list);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------ the lean kernel
+// The reference bracket of niw_sweep_direct_kernel (ref_bracket, niw_sweep.hip) on operands that already exist: plane h of z = x - mu_k0 IS
+// the bracket's bf16 operand (same subtraction, same v_cvt_pk_bf16_f32), so q_hi comes out bit for bit as there.
+__device__ __forceinline__ void ref_bracket_planes(const u32x4_t (&a)[6], const B3Z &Z, float (&qhi)[4]) {      // a: the six fragments of k0's bracket image (this lane's)
+    const u32x4_t absm = (u32x4_t){0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu};
+#pragma unroll
+    for (int n0 = 0; n0 < 4; n0 += 2) {
+        float part[2] = {0.f, 0.f};
+#pragma unroll
+        for (int bi = 0; bi < 4; ++bi) {
+            f32x4 y[2], e[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { y[h] = (f32x4){0.f, 0.f, 0.f, 0.f}; e[h] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                const int f = bi == 0 ? sl : (bi == 1 ? 2 + sl : (sl == 1 ? bi + 2 : -1));
+                if (f < 0) continue;
+                const u32x4_t aa = a[f] & absm;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const u32x4_t zb = Z.p[n0 + h][sl][0];
+                    y[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[f]), __builtin_bit_cast(bf16x8_t, zb), y[h], 0, 0, 0);
+                    e[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aa), __builtin_bit_cast(bf16x8_t, zb & absm), e[h], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float t = __builtin_fmaf(REFB_C, e[h][r], fabsf(y[h][r]));
+                    part[h] = __builtin_fmaf(t, t, part[h]);
+                }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 tot = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, part[h], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);      // sum over the four row groups of a column
+            qhi[n0 + h] = __builtin_fmaf(tot[0], 1.0001f, 1e-20f);
+        }
+    }
+}
+
+// A whole tile (64 positions of the visiting order) in one go WHERE THE SCREENS SETTLE IT: every point of the wave had label k0; the certified
+// bracket of a_k0 (lower end), the ball test and the 4-row tail screens -- the first stages of niw_sweep_direct_kernel's cascade, same
+// records, same thresholds -- exclude every other cluster for every point.  Then that kernel's draw returns k0 whatever a_k0 is (its
+// `ref_skipped` branch; index 0 for a uniform of exactly 0 -- such a tile is left to it), and what remains is the sub-label phase on planes
+// that exist already.  Every other tile (mixed previous labels, a candidate left, no previous labels) is appended to `list` ([0] = count,
+// cleared before the launch) and left untouched: niw_sweep_direct_kernel<.., LSTORE> + niw_sub_kernel take it.  The outcome is that of the
+// one-kernel path: a tile is settled here only if every later screen there would find nothing to do either.
+__global__ __launch_bounds__(256, 2) void niw_lean_kernel(NiwSweepArgs A, uint32_t *__restrict__ list, uint32_t *__restrict__ need2) {
+    const int lane = threadIdx.x & 63, ci = lane & 15, g = lane >> 4;
+    const bool use_order = A.order != nullptr && *A.order_total == (int32_t)A.n;
+    const int K = A.K;
+    const int64_t nwtiles = (A.n + 63) / 64;
+    const int wave_id = (int)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int)gridDim.x * 4;
+    unsigned nw_easy = 0, nw_br = 0, nw_tail = 0, nw_hard = 0, nw_bb = 0;
+    // the point indices and previous labels of the NEXT tile are fetched while this one is processed (order -> bins is a dependent chain of
+    // two HBM round trips in front of the X gather otherwise)
+    int nx_p = -1, nx_bin = -1;
+    bool have_nx = false;
+    for (int64_t tile = wave_id; tile < nwtiles; tile += nwaves) {
+        const int64_t pos = tile * 64 + lane;
+        const bool valid = pos < A.n;
+        int myp32, binv;
+        if (have_nx) { myp32 = nx_p; binv = nx_bin; }
+        else {
+            myp32 = valid ? (use_order ? A.order[pos] : (int)pos) : -1;
+            binv = valid ? A.bins[myp32] : -1;
+        }
+        int pf_p = -1, pf_bin = -1;
+        {
+            const int64_t posn = (tile + nwaves) * 64 + lane;
+            if (tile + nwaves < nwtiles && posn < A.n) pf_p = use_order ? A.order[posn] : (int)posn;
+        }
+        int prev = binv >= 0 ? (binv >> 1) : -1;
+        if ((unsigned)prev >= (unsigned)K) prev = -1;
+        const unsigned long long pm = __ballot(prev >= 0);
+        bool hard = pm == 0ull;
+        int k0 = 0;
+        if (!hard) {
+            k0 = __builtin_amdgcn_readfirstlane(__shfl(prev, __ffsll((long long)pm) - 1));
+            hard = __ballot(valid && prev != k0) != 0ull;
+        }
+        B3Z Z;
+        B3Head H;
+        if (!hard) {
+            f32x4 xt = (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 x3[4];                                           // the last 16 features (the bf16 bottom screens' operand)
+            u32x4_t abr[6];                                        // k0's bracket fragments: requested with x, used behind the conversion
+            {
+                f32x4 x[4][4], mk[4];
+                gather_x64(A.X, A.ldx, myp32, ci, g, x);
+                b3_mean(A.mup, k0, g, mk);
+                {
+                    const u32x4_t *F = reinterpret_cast<const u32x4_t *>(refb_records(A.tail, K) + (size_t)k0 * REFB_WORDS) + lane;
+#pragma unroll
+                    for (int f = 0; f < 6; ++f) abr[f] = F[64 * f];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // the last four features of "this lane's point" (the tail screens' operand), as niw_sweep_direct_kernel takes them
+                const int src = ci + 16 * A.tail_g;
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    f32x4 v;
+                    v.x = __shfl(x[n][3].x, src); v.y = __shfl(x[n][3].y, src); v.z = __shfl(x[n][3].z, src); v.w = __shfl(x[n][3].w, src);
+                    if (g == n) xt = v;
+                }
+#pragma unroll
+                for (int n = 0; n < 4; ++n) x3[n] = x[n][3];
+                b3_convert(x, mk, Z);                          // x's last use (but for x3)
+            }
+            if (pf_p >= 0) pf_bin = A.bins[pf_p];              // the next tile's previous labels (its indices have arrived with x)
+            float qhi[4];
+            ref_bracket_planes(abr, Z, qhi);
+            ++nw_br;
+            const float c0 = A.cst[3 * k0];
+            float my_best = -INFINITY;
+            float thrb[4];                                         // per point group: threshold of the column's point (+inf for a column without a point)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const float bn = __builtin_fmaf(-0.5f, qhi[n], c0);
+                if (g == n) my_best = bn;
+                thrb[n] = (tile * 64 + 16 * n + ci < A.n) ? bn - A.screen_margin : INFINITY;
+            }
+            const float my_thr = valid ? my_best - A.screen_margin : INFINITY;
+            BallWave ball; ball.ok = false;
+            if (A.ball) ball = ball_of_wave(A.tail, K, k0, xt, my_thr, valid);
+            for (int base = 0; base < K && !hard; base += 64) {
+                unsigned long long cand = (K - base >= 64) ? ~0ull : ((1ull << (K - base)) - 1ull);
+                if (k0 >= base && k0 < base + 64) cand &= ~(1ull << (k0 - base));
+                if (ball.ok) cand &= ~ball_far(A.tail, K, base, lane, ball);
+                for (unsigned long long pend = cand; pend;) {
+                    const int sh = __builtin_ctzll(pend) & ~1;            // (base is a multiple of 64: pair 2p sits at an even bit)
+                    const int pr = (base + sh) >> 1;
+                    pend &= ~(3ull << sh);
+                    ++nw_tail;
+                    cand &= ~((unsigned long long)tail_pair_far(tail_load_pair(A.tail, pr), xt, my_thr) << sh);
+                }
+                // what the 4-row tests leave (0.8 clusters per tile on the bench data): the bf16 bottom screen, as niw_sweep_direct_kernel runs it
+                // next (fragment 5 of the candidate's bracket image, its last 16 means, its constant); a candidate that passes it is left to that kernel
+                if (A.bf16scr) {
+                    const u32x4_t *Rb0 = reinterpret_cast<const u32x4_t *>(refb_records(A.tail, K));
+                    while (cand) {
+                        const int k = base + __builtin_ctzll(cand);
+                        const u32x4_t a5 = Rb0[(size_t)k * (REFB_WORDS / 4) + 64 * 5 + lane];
+                        const f32x4 m4 = *reinterpret_cast<const f32x4 *>(A.mup + (size_t)(3 * k) * 64 + 48 + 4 * g);
+                        ++nw_bb;
+                        if (!bf16_bottom_excludes<4>(a5, x3, m4, A.cst[3 * k], thrb)) break;
+                        cand &= cand - 1ull;
+                    }
+                }
+                hard = cand != 0ull;
+            }
+        }
+        float u_sub = 0.f;
+        if (!hard) {
+            H = b3_head(A.tail, A.cst, K, k0, lane, g);           // the sub-label evaluation's first fragments: in flight under the uniforms' arithmetic
+            __builtin_amdgcn_sched_barrier(0);
+            float u0 = 1.f;
+            if (valid) {
+                const Philox4 r = philox4x32_10(A.seed, (uint64_t)(A.first_index + myp32), A.epoch, STREAM_SWEEP);
+                u0 = u01(r.v[0]); u_sub = u01(r.v[1]);
+            }
+            hard = __ballot(valid && u0 <= 0.f) != 0ull;       // (a uniform of exactly 0 draws index 0, not k0: once in 2^24 points -- the general path)
+        }
+        if (hard) {
+            if (lane == 0) { const uint32_t at = atomicAdd(&list[0], 1u); list[1 + at] = (uint32_t)tile; }
+            ++nw_hard;
+            if (pf_p >= 0 && pf_bin < 0) pf_bin = A.bins[pf_p];        // (a tile that left before the bracket)
+        } else {
+            float bl, br;
+            b3_eval(A.tail, K, k0, Z, H, lane, g, bl, br);
+            if (valid) A.bins[myp32] = 2 * k0 + draw2(bl, br, u_sub);
+            ++nw_easy;
+        }
+        nx_p = pf_p; nx_bin = pf_bin; have_nx = true;
+    }
+    if (A.work && lane == 0) {
+        unsigned long long *slot = A.work + DPMM_WORK_SLOTS + (size_t)wave_id * DPMM_WORK_PER_WAVE;      // (accumulates; cleared by the reader)
+        slot[0] += nw_easy; slot[3] += nw_tail; slot[4] += nw_br; slot[5] += nw_bb; slot[7] += (unsigned long long)(2 * nw_easy) << 32;
+    }
+    if (need2 && lane == 0) need2[wave_id] = nw_easy < 65535u ? nw_easy : 65535u;      // tiles settled here (no candidates): the direction screen's statistics count them
+}
+hipError_t launch_niw_lean(const NiwSweepArgs &a, uint32_t *list, uint32_t *need2, int grid, hipStream_t s) {
+    if (!a.tail || a.n <= 0 || !list) return hipErrorInvalidValue;
+    DPMM_LAUNCH(niw_lean_kernel, dim3(grid), dim3(256), 0, s, a, list, need2);
+    return hipGetLastError();
+}
+
+}  // namespace dpmm

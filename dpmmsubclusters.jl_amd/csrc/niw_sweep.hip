@@ -35,17 +35,11 @@
 // float4 at element 16t + 4g, so element (16t + 4g + jj) is component jj of that float4.
 #include "dpmm_device.h"
 #include "dpmm_kernels.h"
+#include "niw_device.h"
 #include <cstdlib>
 #include <cstring>
 
 namespace dpmm {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-template <int NB>
-__host__ __device__ constexpr int pair_base(int bi) {
-    return bi * NB - (bi * (bi - 1)) / 2;
-}
 
 template <int NB, int NG, int CH>
 struct NiwCfg {
@@ -86,147 +80,6 @@ struct NiwCfg {
     static constexpr int MAXPASS = (MAXPAIRS + 3) / 4;
 };
 
-// ---------------------------------------------------------------------------------------
-// Tail screen (shared by both sweep kernels).  Rows D-4..D-1 of y = R z need the last four features only (R upper
-// triangular), so q >= |T_k (x_t - m_t)|^2 with the 4x4 tail factor T_k.  The 15 constants of a cluster
-// {T00 T01 T02 T03 | T11 T12 T13 T22 | T23 T33 m0 m1 | m2 m3 cst} are wave-uniform: read through the constant address
-// space they arrive by scalar loads in SGPRs.  Lane = point: `xt` holds the four tail features of the lane's point,
-// `thr` = reference value - margin (+inf for lanes without a point).
-// Records are stored for PAIRS of clusters, element i of clusters 2p and 2p+1 side by side ([pair][16][2]): one packed-f32
-// instruction (v_pk_*) then serves both clusters.  Instruction count is what matters here: a wave that shares its SIMD with
-// an MFMA-streaming wave issues about one instruction per two MFMAs (scripts/microbench/issue_overlap.hip), so the phases of
-// the two resident waves do not overlap -- every VALU / SALU instruction saved is ~5 cycles of SIMD time.  For the same
-// reason the next record is NOT prefetched (it would cost 32 more SGPRs, i.e. copies or spills): while this wave waits for
-// its scalar load the other wave runs.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-struct TailPair { f32x2 v[16]; };
-__device__ __forceinline__ TailPair tail_load_pair(const float *tail, int pair) {
-    typedef const float __attribute__((address_space(4))) *cfp4;
-    const cfp4 P = (cfp4)(tail + (size_t)pair * 32);
-    TailPair T;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) T.v[q] = (f32x2){P[2 * q], P[2 * q + 1]};
-    return T;
-}
-// bit 0 / bit 1: cluster 2p / 2p+1 is below `thr` for every lane of the wave (lanes without a point carry thr = +inf)
-__device__ __forceinline__ unsigned tail_pair_far(const TailPair &T, const f32x4 &xt, float thr) {
-    const f32x2 x0 = (f32x2){xt.x, xt.x}, x1 = (f32x2){xt.y, xt.y}, x2 = (f32x2){xt.z, xt.z}, x3 = (f32x2){xt.w, xt.w};
-    const f32x2 z0 = x0 - T.v[10], z1 = x1 - T.v[11], z2 = x2 - T.v[12], z3 = x3 - T.v[13];
-    const f32x2 y3 = T.v[9] * z3;
-    const f32x2 y2 = __builtin_elementwise_fma(T.v[7], z2, T.v[8] * z3);
-    const f32x2 y1 = __builtin_elementwise_fma(T.v[4], z1, __builtin_elementwise_fma(T.v[5], z2, T.v[6] * z3));
-    const f32x2 y0 = __builtin_elementwise_fma(T.v[0], z0, __builtin_elementwise_fma(T.v[1], z1, __builtin_elementwise_fma(T.v[2], z2, T.v[3] * z3)));
-    f32x2 q4 = y3 * y3;
-    q4 = __builtin_elementwise_fma(y2, y2, q4); q4 = __builtin_elementwise_fma(y1, y1, q4); q4 = __builtin_elementwise_fma(y0, y0, q4);
-    const f32x2 ub = __builtin_elementwise_fma((f32x2){-0.5f, -0.5f}, q4, T.v[14]);
-    const unsigned fa = (__ballot(ub.x < thr) == ~0ull) ? 1u : 0u;
-    const unsigned fb = (__ballot(ub.y < thr) == ~0ull) ? 2u : 0u;
-    return fa | fb;
-}
-
-// Ball test in front of the per-point tail screen, lane = CLUSTER.  The wave's points sit in a ball around the tail mean c of its
-// reference cluster (radius r = max_i |x_i,tail - c|, one wave reduction); for every x in that ball
-//   |T_k (x - m_k)| >= |T_k (c - m_k)| - |T_k|_2 r,
-// so cst_k - 1/2 max(0, |T_k (c - m_k)| - |T_k|_F r)^2 bounds a_k for ALL points of the wave at once: lane j tests cluster j against the
-// wave's lowest threshold -- ~60 instructions for 64 clusters, where the per-point screen spends ~22 per PAIR of clusters.  On
-// label-homogeneous waves of well-separated data it clears nearly every cluster; whatever is left goes to the per-point screens.
-// Per-cluster records [K][16] = { m0 m1 m2 m3 | T00 T01 T02 T03 | T11 T12 T13 T22 | T23 T33 b cst } behind the pair records, b >= |T|_2 a
-// certified bound of the spectral norm (tail_opnorm_bound: within 19 %; the Frobenius norm, used first, can be twice the norm).
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ float dpp_f32(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, false));
-}
-// max / min over the 64 lanes (NaN operands are ignored by v_max / v_min), wave-uniform result
-__device__ __forceinline__ float wave_max_f32(float v) {
-    v = fmaxf(v, dpp_f32<0xB1, 0xF>(v));       // quad_perm [1,0,3,2]
-    v = fmaxf(v, dpp_f32<0x4E, 0xF>(v));       // quad_perm [2,3,0,1]
-    v = fmaxf(v, dpp_f32<0x141, 0xF>(v));      // row_half_mirror
-    v = fmaxf(v, dpp_f32<0x140, 0xF>(v));      // row_mirror: every lane holds the maximum of its row of 16
-    v = fmaxf(v, dpp_f32<0x142, 0xA>(v));      // row_bcast15 -> rows 1, 3
-    v = fmaxf(v, dpp_f32<0x143, 0xC>(v));      // row_bcast31 -> rows 2, 3: lane 63 holds the maximum
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
-__device__ __forceinline__ float wave_min_f32(float v) {
-    v = fminf(v, dpp_f32<0xB1, 0xF>(v));
-    v = fminf(v, dpp_f32<0x4E, 0xF>(v));
-    v = fminf(v, dpp_f32<0x141, 0xF>(v));
-    v = fminf(v, dpp_f32<0x140, 0xF>(v));
-    v = fminf(v, dpp_f32<0x142, 0xA>(v));
-    v = fminf(v, dpp_f32<0x143, 0xC>(v));
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
-__host__ __device__ __forceinline__ const float *ball_records(const float *tail, int K) { return tail + 32 * ((K + 1) >> 1); }
-struct BallWave { f32x4 c; float r, thr; bool ok; };
-// the wave's ball: centre = tail mean of reference cluster k0 (wave-uniform), radius over the valid lanes, lowest threshold.  Not usable
-// (ok = false) when a point's tail features or threshold are not finite: such a point is covered by no ball, and the per-point
-// screens keep every cluster for it.
-__device__ __forceinline__ BallWave ball_of_wave(const float *tail, int K, int k0, const f32x4 &xt, float my_thr, bool valid) {
-    typedef const float __attribute__((address_space(4))) *cfp4;
-    const cfp4 P = (cfp4)(ball_records(tail, K) + 16 * (size_t)k0);
-    BallWave B;
-    B.c = (f32x4){P[0], P[1], P[2], P[3]};
-    const f32x4 dx = xt - B.c;
-    float r2 = dx.x * dx.x;
-    r2 = __builtin_fmaf(dx.y, dx.y, r2); r2 = __builtin_fmaf(dx.z, dx.z, r2); r2 = __builtin_fmaf(dx.w, dx.w, r2);
-    B.ok = __ballot(valid && !(r2 < INFINITY && my_thr == my_thr)) == 0ull;
-    B.r = __builtin_amdgcn_sqrtf(wave_max_f32(valid ? r2 : 0.f)) * 1.00001f;      // (v_sqrt_f32, 1 ulp: covered by the slack factors)
-    B.thr = wave_min_f32(my_thr);
-    return B;
-}
-// lanes j: cluster base + j is below the wave's lowest threshold for every point of the ball
-__device__ __forceinline__ unsigned long long ball_far(const float *tail, int K, int base, int lane, const BallWave &B) {
-    const int j = base + lane;
-    const float *rec = ball_records(tail, K) + 16 * (size_t)(j < K ? j : 0);
-    const f32x4 m = *reinterpret_cast<const f32x4 *>(rec), t0 = *reinterpret_cast<const f32x4 *>(rec + 4);
-    const f32x4 t1 = *reinterpret_cast<const f32x4 *>(rec + 8), t2 = *reinterpret_cast<const f32x4 *>(rec + 12);
-    const f32x4 d = B.c - m;
-    const float y3 = t2.y * d.w;
-    const float y2 = __builtin_fmaf(t1.w, d.z, t2.x * d.w);
-    const float y1 = __builtin_fmaf(t1.x, d.y, __builtin_fmaf(t1.y, d.z, t1.z * d.w));
-    const float y0 = __builtin_fmaf(t0.x, d.x, __builtin_fmaf(t0.y, d.y, __builtin_fmaf(t0.z, d.z, t0.w * d.w)));
-    float qn = y3 * y3;
-    qn = __builtin_fmaf(y2, y2, qn); qn = __builtin_fmaf(y1, y1, qn); qn = __builtin_fmaf(y0, y0, qn);
-    float dn = d.x * d.x;
-    dn = __builtin_fmaf(d.y, d.y, dn); dn = __builtin_fmaf(d.z, d.z, dn); dn = __builtin_fmaf(d.w, d.w, dn);
-    // rounding slack: |T d| is computed to ~1e-6 |T|_F |d|; the margin of the screen (tens of nats) dwarfs it anyway
-    const float lb = fmaxf(__builtin_fmaf(-t2.z, __builtin_fmaf(1e-5f, __builtin_amdgcn_sqrtf(dn), B.r), __builtin_amdgcn_sqrtf(qn) * 0.99999f), 0.f);
-    const float ub = __builtin_fmaf(-0.5f * lb, lb, t2.w);
-    return __ballot(j < K && ub < B.thr);
-}
-
-// Reference BRACKET (D in 33 .. 64).  On a wave whose points all carried label k0 the cluster-level value a_k0(x) = cst - q(x) / 2,
-// q = |R (x - mu)|^2, usually decides nothing: every other cluster is excluded by the screens and the draw returns k0 whatever the value
-// is.  The screens only need a LOWER bound of it.  Two bf16 matrix passes give a certified one at ~1/7 of the Float32 evaluation's cycles:
-//   y^ = R~ z~ (R~, z~ = bf16 round-to-nearest-even of R and of the Float32 z = x - mu; bf16 products are exact in the Float32
-//   accumulator),  e^ = |R~| |z~|.
-// bf16 carries 8 significand bits: ONE rounding has unit round-off u = 2^-8, |R - R~| <= u |R~| and |z - z~| <= u |z~| (half an ulp of
-// the operand's binade, and the rounded value is never below that binade's base).  BOTH operands are rounded:
-//   |y_i - y^_i| <= sum_j |R - R~||z| + |R~||z - z~| <= sum_j u |R~| (1 + u) |z~| + u |R~||z~| = (2u + u^2) e^_i = 0.0078278 e^_i
-// (worst case R = z = 1 + 2^-8 -> R~ = z~ = 1: y - y^ = 0.0078278).  Float32 accumulation of the 64 exact products in y^ and e^ and the
-// rounding of the Float32 evaluation this bracket stands in for (another summation order of the same 64 terms, |R||z| <= (1 + u)^2
-// e^) add 3 * 64 * 2^-24 = 1.2e-5:
-//   |y_i (as the Float32 evaluation computes it)| <= |y^_i| + REFB_C e^_i,   REFB_C = 0.00785 > 0.0078278 + 0.0000115,
-//   q <= sum_i (|y^_i| + REFB_C e^_i)^2 (1 + 1e-4) =: q_hi   (the lane's four rows per block, then the ones-MFMA sum over the four row
-// groups; the factor covers the ~30 Float32 roundings of the two sums of squares).  Subnormal z that the conversion may flush are an
-// absolute error of 2^-126 |R~| per term -- nothing next to the 1e-20 added at the end for any factor the Float32 evaluation itself can
-// handle.  Checked per point on adversarial operands (every entry just below a bf16 midpoint, displaced trailing features, far
-// outliers) by tests/test_gpu_niw.py::test_reference_bracket_is_an_upper_bound through dpmm_debug_ref_bracket.
-// (Round 3 shipped REFB_C = 0.00395 = u (1 + 2u) + ..., i.e. ONE rounding of half the size: q_hi < q on exactly those operands.  It changed
-// no label -- the screens' 50-nat margin has ~32 nats of slack -- but it was not a bound.)
-// On the bench's clusters (condition number 35 000) q_hi - q is ~14 of q ~ 64: the thresholds move by a few nats of a 50-nat margin.
-// A non-finite x or parameter makes q_hi non-finite, every screen comparison false, and the wave takes the Float32 path.
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef short bf16x8_t __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-constexpr float REFB_C = 0.00785f;
-__host__ __device__ __forceinline__ const uint32_t *refb_records(const float *tail, int K) {
-    return reinterpret_cast<const uint32_t *>(ball_records(tail, K) + 16 * (size_t)K);
-}
-__device__ __forceinline__ uint32_t pack_bf16_pair(float a, float b) {
-    typedef float f32x2_t __attribute__((ext_vector_type(2)));
-    const f32x2_t v = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));      // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
-}
 template <int NG>
 __device__ __forceinline__ void ref_bracket(const uint32_t *__restrict__ Rb, const f32x4 (&x)[NG][4], const f32x4 (&mu)[4], int lane, float (&qhi)[NG],
                                             const float refb_c = REFB_C) {
@@ -295,39 +148,6 @@ __device__ __forceinline__ void ref_bracket(const uint32_t *__restrict__ Rb, con
 //           front of their Float32 16-row screen (every exclusion here is one the Float32 tests would have made: the order is free).
 // Overlapping clusters (component means at MixtureVar 4 / 1 instead of 100) are where they pay: there the 4-row bounds exclude nothing
 // and a tile runs ~30 sixteen-row screens (MixtureVar 4), or ~19 evaluations that leave after their first row block (MixtureVar 1).
-template <int NG>
-__device__ __forceinline__ bool bf16_bottom_excludes(const u32x4_t a, const f32x4 (&x3)[NG], const f32x4 m4, float cst, const float (&thr)[NG]) {
-    static_assert(NG % 2 == 0, "point groups are taken two at a time");
-    const u32x4_t absm = (u32x4_t){0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu};
-    const u32x4_t aa = a & absm;              // a: fragment 5 of the cluster's bf16 image -- block row 3 x features 32 .. 63 (zero for 32 .. 47)
-    bool skip = true;
-#pragma unroll
-    for (int n0 = 0; n0 < NG; n0 += 2) {
-        f32x4 y[2], e[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const f32x4 z = x3[n0 + h] - m4;
-            const u32x4_t zb = (u32x4_t){0u, 0u, pack_bf16_pair(z.x, z.y), pack_bf16_pair(z.z, z.w)};      // k-slots 0 .. 3: features 32 .. 47, zero rows of the fragment
-            y[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, zb), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            e[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aa), __builtin_bit_cast(bf16x8_t, zb & absm), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float ql = 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float t = fmaxf(__builtin_fmaf(-REFB_C, e[h][r], fabsf(y[h][r])), 0.f);
-                ql = __builtin_fmaf(t, t, ql);
-            }
-            // (a NaN anywhere makes the comparison false: not excluded.  thr = +inf for columns without a point)
-            unsigned long long mk = __ballot(__builtin_fmaf(-0.5f * 0.9999f, ql, cst) < thr[n0 + h]);
-            mk |= mk >> 32;
-            mk |= mk >> 16;
-            skip = skip && ((mk & 0xFFFFull) == 0xFFFFull);     // every point: one of its four row-group lanes proves the bound
-        }
-    }
-    return skip;
-}
 template <int NG>
 __device__ __forceinline__ bool bf16_top_excludes(const uint32_t *__restrict__ Rb, const f32x4 (&x)[NG][4], const f32x4 (&mu)[4], int lane, float cst,
                                                   const float (&thr)[NG]) {
@@ -1255,8 +1075,14 @@ __device__ __forceinline__ void load_rb0(const float *__restrict__ Rm, const flo
 // kernel spills > 100 SGPRs into VGPR lanes) and fewer branches per tile.  Same arithmetic, same results.
 // DIR: the instantiation with the direction screen (direction_far) in it -- a kernel of its own because its registers (the tile's z0 as bf16
 // for all four point groups) would cost the common kernel 40 spilled registers and 15 % of its time for a branch it never takes.
-template <int NB, int NG, int OCC, bool FAST = false, bool DIR = false>
+// LSTORE (D in 33 .. 64 while the bf16 sub-label evaluation of niw_lean.hip is active): the instantiation stops behind the label draw and
+// STORES the labels (bins = 2 z; the sub-label bit is a placeholder) -- niw_sub_kernel draws the sub-labels of the same tiles in a launch of
+// its own.  The tiles come from a list (A.tdf re-used as `const uint32_t *`: [0] = count, [1 ..] = wave-tile indices; Student-t mode does
+// not exist in these instantiations) or, with a null list, from the usual schedule.
+template <int NB, int NG, int OCC, bool FAST = false, bool DIR = false, bool LSTORE = false>
 __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs A) {
+    const float *const a_tdf = LSTORE ? nullptr : A.tdf;
+    const uint32_t *const tlist = LSTORE ? reinterpret_cast<const uint32_t *>(A.tdf) : nullptr;
 #ifdef DPMM_STAMPS
     unsigned long long T_x = 0, T_quad = 0, T_epi = 0, T_draw = 0, T_p2 = 0, T_tot = 0, N_scr = 0, N_tail = 0, T_prep = 0, T_far = 0, T_surv = 0, T_init = 0, T_i1 = 0, T_i2 = 0, T_lastd = 0, T_long = 0, T_longat = 0, T_firstd = 0; int ntile = 0;
 #endif
@@ -1343,7 +1169,10 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
     // the screens) the wave goes straight to the Float32 evaluation for the next eight tiles, then tries again
     int br_fail = 0, br_skip = 0;
     int tile0, tnext_v = -1;
-    if (!dyn_ok) tile0 = wave_id < nwtiles ? wave_id : -1;
+    int li = wave_id;                          // LSTORE with a list: this wave's position in it (static stride over the list)
+    const int lcount = (LSTORE && tlist) ? (int)tlist[0] : 0;
+    if (LSTORE && tlist) tile0 = li < lcount ? (int)tlist[1 + li] : -1;
+    else if (!dyn_ok) tile0 = wave_id < nwtiles ? wave_id : -1;
     else if (wave_id < dyn0) tile0 = wave_id;
     else { q_issue(); tile0 = q_take(); if (tile0 >= 0) q_issue(); }
     for (int tile = tile0; tile >= 0; tile = tnext_v) {
@@ -1353,7 +1182,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
         const int64_t mypos = wbase + lane;    // position in processing order
         const bool valid = owner && mypos < A.n;
         const bool prefetched = nx_tile == tile;
-        const bool screening = FAST || (NB >= 2 && A.screen_margin > 0.f && !A.tdf && !A.scratch_by_tile && K > 1);
+        const bool screening = FAST || (NB >= 2 && A.screen_margin > 0.f && !a_tdf && !A.scratch_by_tile && K > 1);
         int myp32, binv = -1;
         if (prefetched) {
             myp32 = nx_p; binv = nx_bin;
@@ -1392,7 +1221,8 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
             }
         }
         int tnext;
-        if (!dyn_ok) tnext = tile + nwaves < nwtiles ? tile + nwaves : nwtiles;
+        if (LSTORE && tlist) { li += nwaves; tnext = li < lcount ? (int)tlist[1 + li] : nwtiles; }
+        else if (!dyn_ok) tnext = tile + nwaves < nwtiles ? tile + nwaves : nwtiles;
         else if (tile + nwaves < dyn0) tnext = tile + nwaves;                        // static successor
         else {
             if (!q_inflight) q_issue();                                               // first tile from the queue: this one claim is waited for
@@ -1439,7 +1269,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
         };
         // (ONE cluster, no table asked for: the draw returns index 0 whatever its value -- utils.jl:19-31 over one element -- so the value is not
         // computed: every fit from init_clusters = 1 spends its first `burnout` sweeps here, two evaluations per tile instead of three)
-        const bool lone = !FAST && K == 1 && !A.tdf && !A.labels_only && !A.scratch_by_tile;
+        const bool lone = !FAST && K == 1 && !a_tdf && !A.labels_only && !A.scratch_by_tile;
         if (!screening) {
             if (!lone) load_rb0<NB>(A.Rp, A.mup, rb0, mu, lane, g);
             for (int k = 0; k < (lone ? 0 : K); ++k) {
@@ -1449,7 +1279,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
                 const float qs = quad_stream<NB, NG>(Rcur, Rnext, A.mup + (size_t)(3 * (k + 1)) * DP, rb0, mu, x, lane, g, true, tot_all, A.prio);
                 ++nw_full;
                 STAMP(q1);
-                const float a = A.tdf ? A.cst[3 * k] - A.tdf[6 * k + 1] * log1pf(qs / A.tdf[6 * k])
+                const float a = a_tdf ? A.cst[3 * k] - a_tdf[6 * k + 1] * log1pf(qs / a_tdf[6 * k])
                                       : __builtin_fmaf(-0.5f, qs, A.cst[3 * k]);
                 record(k, a);
                 STAMP(q2);
@@ -1519,7 +1349,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
             STAMP(q0b);
             // the last row-block of the reference evaluation prefetches row-block 0 of k0's LEFT sub-cluster matrix:
             // on label-homogeneous waves that is the first matrix of the sub-label phase (rb0_mat tracks what rb0/mu hold)
-            const float *Rl0 = (!FAST && A.labels_only) ? nullptr : A.Rp + (size_t)(3 * k0 + 1) * MATSZ;
+            const float *Rl0 = ((!FAST && A.labels_only) || LSTORE) ? nullptr : A.Rp + (size_t)(3 * k0 + 1) * MATSZ;      // (LSTORE: no sub-label phase here, nothing to prefetch for it)
             const float *ml0 = A.mup + (size_t)(3 * k0 + 1) * DP;
             // Reference bracket (see ref_bracket): every point of the wave was in k0 -> bestn = the LOWER end of a certified bracket of
             // a_k0; nothing is recorded.  The Float32 evaluation follows behind the screens only if some cluster survives them.
@@ -1940,6 +1770,11 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
         }
         if (!FAST && A.labels_only) continue;
         STAMP(s3);
+        if constexpr (LSTORE) {
+            if (valid) A.bins[myp] = 2 * z;       // the label; niw_sub_kernel draws the sub-label (its uniform is the point's own: recomputed there)
+            nx_p = pf_p; nx_bin = pf_bin; nx_tile = tnext < nwtiles ? tnext : -1;
+            continue;
+        }
 
         // sub-labels: walk the distinct labels of this wave (wave-uniform loop)
         float b0 = -INFINITY, b1 = -INFINITY;
@@ -2017,9 +1852,26 @@ static hipError_t launch_direct(const NiwSweepArgs &a, int grid, hipStream_t s) 
         hipFuncSetAttribute((const void *)niw_sweep_direct_kernel<NB, NG, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / OCC);
         attr_set = true;
     }
-    const bool fast = NB >= 2 && b.screen_margin > 0.f && !b.tdf && !b.scratch_by_tile && !b.labels_only && b.K > 1 && b.lam == nullptr &&
+    // bit 2 of bf16scr (NB = 4, set by run_sweep while the bf16 sub-label evaluation is active): the LSTORE instantiations -- labels only, stored;
+    // b.tdf then carries the tile list (or null: all tiles), never Student-t parameters
+    const bool lstore = NB == 4 && (a.bf16scr & 4) != 0;
+    b.bf16scr &= 3;
+    const bool fast = NB >= 2 && b.screen_margin > 0.f && (lstore || !b.tdf) && !b.scratch_by_tile && !b.labels_only && b.K > 1 && b.lam == nullptr &&
                       b.tail != nullptr && b.lds_rows >= b.K && !b.final_argmax;
     if constexpr (NB == 4) {
+        if (lstore) {
+            static bool attr_ls = false;
+            if (!attr_ls) {
+                hipFuncSetAttribute((const void *)niw_sweep_direct_kernel<NB, NG, OCC, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / OCC);
+                hipFuncSetAttribute((const void *)niw_sweep_direct_kernel<NB, NG, OCC, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / OCC);
+                hipFuncSetAttribute((const void *)niw_sweep_direct_kernel<NB, NG, OCC, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / OCC);
+                attr_ls = true;
+            }
+            if (fast && b.sp_frag && b.sp_cons && b.bf16scr && b.K <= SP_MAXK) DPMM_LAUNCH((niw_sweep_direct_kernel<NB, NG, OCC, true, true, true>), dim3(grid), dim3(256), lds_bytes, s, b);
+            else if (fast) DPMM_LAUNCH((niw_sweep_direct_kernel<NB, NG, OCC, true, false, true>), dim3(grid), dim3(256), lds_bytes, s, b);
+            else DPMM_LAUNCH((niw_sweep_direct_kernel<NB, NG, OCC, false, false, true>), dim3(grid), dim3(256), lds_bytes, s, b);
+            return hipGetLastError();
+        }
         if (fast && b.sp_frag && b.sp_cons && b.bf16scr && b.K <= SP_MAXK) {
             static bool attr_dir = false;
             if (!attr_dir) {

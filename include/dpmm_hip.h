@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DPMM_ABI_VERSION 3   /* 3 (round 5): dpmm_last_sweep_work fills 16 words (was 8 in version 2), DPMM_OPT_NOISE_AHEAD's -1 = automatic, options 18..25 */
+#define DPMM_ABI_VERSION 3   /* 3 (round 5): dpmm_last_sweep_work fills 16 words (was 8 in version 2), DPMM_OPT_NOISE_AHEAD's -1 = automatic, options 18..27 */
 
 typedef struct dpmm_ctx dpmm_ctx;
 
@@ -86,6 +86,15 @@ enum {
                                          rank -- fails with DPMM_ECOMM; later collectives refuse with DPMM_ECOMM until dpmm_comm_release, calls without a collective
                                          (dpmm_get_labels, dpmm_sync) keep working */
     /* 24: was DPMM_OPT_F32_STATS (rounds 4: centred Float32 second moments, +4 % on the headline); removed in round 5 -- the statistics are Float64 throughout, as the reference's (priors/niw.jl:42-51) */
+    DPMM_OPT_B3_SUBLABELS = 26,       /* 1 (default): NIW sweep at D in 33..64 with tail records (D % 4 == 0, K > 1): the two sub-cluster quadratic forms of every label through
+                                         three-plane bf16 images (v = h + m + l exactly; six of the nine plane products; z = x - mu_k converted once per label,
+                                         R_s (x - mu_s) = R_s z + d_s) on v_mfma_f32_16x16x32_bf16 -- Float32-equivalent accuracy, another association of the same products --
+                                         in kernels of their own (niw_lean.hip): tiles the cheap screens settle completely in one launch, the rest label phase + sub-label
+                                         phase.  0: the Float32 chain inside the sweep kernel.  dpmm_debug_subloglik follows the setting.  Takes effect with the next
+                                         parameter set. */
+    DPMM_OPT_LEAN_TILES = 27,         /* 1 (default; with DPMM_OPT_B3_SUBLABELS): tiles whose points all had one label and for which the reference bracket, the ball test and the
+                                         4-row tail screens exclude every other cluster are finished -- label and sub-labels -- by niw_lean_kernel; the rest goes through the sweep
+                                         kernel (labels) and niw_sub_kernel (sub-labels).  Same labels and sub-labels either way.  0: every tile takes the second route. */
     DPMM_OPT_MULT_DRAWS_AHEAD = 25,   /* 1 (default): Multinomial device master: dpmm_step_stats launches the NEXT Dirichlet draws and their hand-over images
                                        * behind the statistics (the epoch after the last dpmm_mult_master_draw, the same K and outlier flag), into a second set of
                                        * buffers, and returns when the rows are on the host -- the draws run while the caller decides splits and merges.
@@ -107,7 +116,8 @@ enum {
                                          empty sub-cluster on the shard); the bad-cluster verdict comes out of the reduced rows' N column, a shard's candidate
                                          that is not bad gets its sub-labels back.  0: occupancy all-reduce -> reset -> statistics -> row all-reduce.  Same chain. */
     DPMM_OPT_KERNEL_TIMING = 15,      /* bit mask: 1 = HIP events around the sweep kernel, 2 = around the statistics pass (dpmm_last_kernel_ms), 4 = around the
-                                         all-reduces (dpmm_last_comm_ms); 0 (default): none -- every event is a barrier packet between two kernels, ~5 us each */
+                                         all-reduces (dpmm_last_comm_ms), 8 (with 1) = between the up to three launches of a D in 33..64 sweep (dpmm_last_sweep_parts_ms);
+                                         0 (default): none -- every event is a barrier packet between two kernels, ~5 us each */
     DPMM_OPT_WAVE_PRIO = 10       /* 0 / 1: NIW sweep (D <= 64) lowers a wave's issue priority while it streams matrix instructions and
                                      raises it in its scalar / VALU phases (default 1) */
 };

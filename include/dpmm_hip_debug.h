@@ -46,14 +46,20 @@ int dpmm_debug_mult_draws_ahead(dpmm_ctx *ctx, long long *used);
  * dpmm_suffstats_* call, measured with HIP events on the ctx stream (0 if none yet, or when DPMM_OPT_KERNEL_TIMING is off -- the default).
  * Calling this waits for the measured kernels (the closing event of each pair), not for later work on the stream. */
 int dpmm_last_kernel_ms(dpmm_ctx *ctx, float *sweep_ms, float *suffstats_ms);
+/* D in 33..64 with the bf16 sub-label evaluation active (DPMM_OPT_B3_SUBLABELS): a sweep is up to three launches -- niw_lean_kernel (tiles the cheap
+ * screens settle), the sweep kernel in its labels-only form (the rest), niw_sub_kernel (their sub-labels).  With DPMM_OPT_KERNEL_TIMING bits 0 and 3
+ * set: out3 = milliseconds of the three parts of the last dpmm_sweep (0 for a part that did not run; all 0 for any other kind of sweep). */
+int dpmm_last_sweep_parts_ms(dpmm_ctx *ctx, float *out3);
 /* Work the dpmm_sweep calls (NIW) since the previous call really executed, counted on the device (a slot per wave, no atomics):
  *   TOTALS over out16[7] launches of: out16[0] wave tiles, [1] full quadratic-form evaluations (per wave), [2] Float32 16-row MFMA screens
  *   (per wave; an evaluation left after its first row block counts as four), [3] tail-screened cluster pairs (per wave), [8] reference
  *   brackets, [11] bf16 bottom screens, [13] bf16 top screens (per wave: bf16 matrix work, NOT part of the Float32 figure);
  *   [4] Float32 matrix instructions per full evaluation, [5] per 16-row screen, [6] flops per Float32 matrix instruction
  *   (v_mfma_f32_16x16x4_f32: 2048), [9] / [12] / [14] bf16 matrix instructions per bracket / bottom screen / top screen, [10] flops per
- *   bf16 matrix instruction (v_mfma_f32_16x16x32_bf16: 16384), [15] 0.  Executed Float32 matrix flops of those launches =
- *   (out16[1]*out16[4] + out16[2]*out16[5]) * out16[6] -- the figure SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 reports.  The counters are cleared;
+ *   bf16 matrix instruction (v_mfma_f32_16x16x32_bf16: 16384), [15] low 32 bits: direction screens, high 32 bits: bf16 three-plane
+ *   evaluations of sub-cluster matrices (DPMM_OPT_B3_SUBLABELS: 144 bf16 matrix instructions + 4 Float32 row sums each).  Executed Float32
+ *   matrix flops of those launches = (out16[1]*out16[4] + out16[2]*out16[5] + 4 * (out16[15] >> 32)) * out16[6] -- the figure
+ *   SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 reports (summed over the kernels of a sweep).  The counters are cleared;
  *   calling this synchronises the stream (a benchmark calls it once after its timed loop, not once per step). */
 int dpmm_last_sweep_work(dpmm_ctx *ctx, uint64_t *out16);
 /* HIP-event time of the last all-reduce of each kind on the ctx stream (0 if none; synchronises the stream); DPMM_OPT_KERNEL_TIMING bit 4. */

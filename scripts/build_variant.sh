@@ -6,7 +6,7 @@ NAME=$1; shift
 cd "$(dirname "$0")/../dpmmsubclusters.jl_amd/csrc"
 mkdir -p build_$NAME
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -Wno-unused-result -Wno-unused-value -Wno-pass-failed $*"
-for f in niw_sweep.hip mult_sweep.hip labels.hip suffstats.hip niw_master.hip mult_master.hip dpmm_api.cpp; do
+for f in niw_sweep.hip niw_lean.hip mult_sweep.hip labels.hip suffstats.hip niw_master.hip mult_master.hip dpmm_api.cpp; do
   /opt/rocm/bin/hipcc $FLAGS -c $f -o build_$NAME/${f%.*}.o &
 done
 wait
