@@ -19,10 +19,13 @@ and exits with the child's code; under the driver's launcher it finds WORLD_SIZE
 size is not `--gpus` is an error, never a silent 1-GPU bench.  Prints ONE JSON line on rank 0.
 
 Besides the contract fields the JSON line carries
-  roofline      the dominant kernel (NIW sweep) against the FP32-MFMA peak: `achieved` = ALGORITHMIC flops / live launch time
-                (exceeds the peak because exact cluster screening skips work), `frac` = EXECUTED flops / time / peak with the
-                executed work counted ON THE DEVICE in the timed launches (dpmm_last_sweep_work), `dense_*` = the same
-                kernel with screening switched off (every cluster evaluated in full) in the same process;
+  roofline      the NIW sweep (for 33 <= D <= 64 three launches: niw_lean_kernel, which finishes the tiles its screens settle and
+                dominates, niw_sweep_direct_kernel<LSTORE> and niw_sub_kernel on the tiles it hands on; `launches_ms` splits the time)
+                against the matrix pipe: `achieved` = ALGORITHMIC Float32 flops / live duration of the sweep's launches (exceeds the
+                Float32 peak because exact cluster screening skips work), `frac` = share of the pipe's time the EXECUTED matrix
+                instructions stand for (Float32 ones against the Float32 peak + bf16 ones against the bf16 peak), counted ON THE
+                DEVICE in the timed launches (dpmm_last_sweep_work), `dense_*` = the same sweep with screening switched off (every
+                cluster evaluated in full) in the same process;
   comm          what the collective saw: world, transport, bytes per all-reduce, all-reduces per step in the timed block (1.0), their HIP-event time;
   blocks        min / median / max it/s over repeated blocks of `--steps` steps (the headline `value` is the first block);
   growth        a run of the same data from ONE initial cluster (`init_clusters=1`): it/s, K history, final log-posterior, NMI;
@@ -50,6 +53,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense FP32 matrix peak (no TF32/xf32 on gfx950)
+PEAK_BF16_MFMA_TFLOPS = 2516.8  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 = 16 x the FP32 matrix rate (matrix-cores table)
 PEAK_HBM_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E ~8 TB/s (6.29 TB/s measured copy)
 DATA_SEED, SAMPLER_SEED, BURNOUT, ALPHA = 12345, 123456789, 20, 10.0
 WORKER_OPTS = []              # --worker-opt ID=VALUE ...: (option, value) pairs set on every worker of the run
@@ -138,30 +142,40 @@ def pmc_traffic(which, kernel_substr):
         meta = pm.get("_meta", {})
         if meta.get("kernel_source_tag") != kernel_source_tag():
             return None, f"profiles/latest_{which}_pmc_summary.json is stale (collected on kernel sources {meta.get('kernel_source_tag')})"
+        subs = (kernel_substr,) if isinstance(kernel_substr, str) else tuple(kernel_substr)
+        tot, hit = 0.0, 0
         for name, c in pm.items():
-            if kernel_substr in name:
-                return (2.0 * c["FETCH_SIZE"]["median"] + c["WRITE_SIZE"]["median"]) * 1024.0, \
-                    f"profiles/latest_{which}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, median per launch; {meta.get('collected', '')})"
+            if name != "_meta" and any(k in name for k in subs) and "FETCH_SIZE" in c:
+                tot += (2.0 * c["FETCH_SIZE"]["median"] + c["WRITE_SIZE"]["median"]) * 1024.0; hit += 1
+        if hit:
+            return tot, (f"profiles/latest_{which}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, median per launch, "
+                         f"summed over the {hit} kernel(s) of the sweep; {meta.get('collected', '')})")
     except (OSError, ValueError, KeyError):
         pass
     return None, None
 
 
 def pmc_matrix_pipe(which, kernel_substr, launch_ms):
-    """What the PMC summary of THIS build says about the kernel's matrix pipe: busy share (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMD-normalised
-    cycles over GRBM_GUI_ACTIVE / 8 XCDs) and the Float32 matrix rate SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 flops / the live launch time --
-    the figure `frac` (device-counted Float32 matrix instructions) has to agree with.  {} when the file is stale or missing."""
+    """What the PMC summary of THIS build says about the matrix pipe in the sweep's kernels (summed over them): busy share
+    (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMD-normalised cycles over GRBM_GUI_ACTIVE / 8 XCDs) and the pipe time the counted matrix
+    operations stand for: SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 flops against the Float32 peak + SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512
+    flops against the bf16 peak, over the live launch time -- the figure `frac` (device-counted matrix instructions) has to agree
+    with.  {} when the file is stale or missing."""
     f = os.path.join(ROOT, "profiles", f"latest_{which}_pmc_summary.json")
     try:
         pm = json.load(open(f))
         if pm.get("_meta", {}).get("kernel_source_tag") != kernel_source_tag():
             return {}
+        subs = (kernel_substr,) if isinstance(kernel_substr, str) else tuple(kernel_substr)
+        busy_c = act_c = f32 = bf16 = 0.0
         for name, c in pm.items():
-            if kernel_substr in name and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
-                busy = (c["SQ_VALU_MFMA_BUSY_CYCLES"]["median"] / 1024.0) / (c["GRBM_GUI_ACTIVE"]["median"] / 8.0)
-                mops = c["SQ_INSTS_VALU_MFMA_MOPS_F32"]["median"]
-                return {"mfma_busy": busy, "pmc_f32_mops_per_launch": mops,
-                        "pmc_frac": mops * 512.0 / (launch_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
+            if name != "_meta" and any(k in name for k in subs) and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+                busy_c += c["SQ_VALU_MFMA_BUSY_CYCLES"]["median"]; act_c += c["GRBM_GUI_ACTIVE"]["median"]
+                f32 += c["SQ_INSTS_VALU_MFMA_MOPS_F32"]["median"]; bf16 += c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", {}).get("median", 0.0)
+        if act_c > 0:
+            t = launch_ms * 1e-3 * 1e12
+            return {"mfma_busy": (busy_c / 1024.0) / (act_c / 8.0), "pmc_f32_mops_per_launch": f32, "pmc_bf16_mops_per_launch": bf16,
+                    "pmc_frac": f32 * 512.0 / t / PEAK_F32_MFMA_TFLOPS + bf16 * 512.0 / t / PEAK_BF16_MFMA_TFLOPS}
     except (OSError, ValueError, KeyError, ZeroDivisionError):
         pass
     return {}
@@ -328,13 +342,32 @@ def _cpu_model():
     return "unknown"
 
 
+SWEEP_KERNELS_64 = ("niw_lean_kernel", "niw_sweep_direct_kernel", "niw_sub_kernel")
+
+
+def sweep_kernel_names(D):
+    """The launches of one NIW sweep.  33 <= D <= 64: niw_lean_kernel (every tile; finishes the tiles whose label candidates the
+    screens settle), niw_sweep_direct_kernel<..., LSTORE> (labels of the tiles it handed on) and niw_sub_kernel (their sub-labels);
+    D <= 32: niw_sweep_direct_kernel alone; D > 64: niw_sweep_kernel (behind its bracket launch)."""
+    return "+".join(SWEEP_KERNELS_64) if 32 < D <= 64 else ("niw_sweep_direct_kernel" if D <= 32 else "niw_sweep_kernel")
+
+
+def pipe_frac(work, sweep_ms):
+    """Share of the matrix pipe's time the device-counted matrix instructions of the sweep stand for: Float32 instructions at the
+    Float32 rate + bf16 instructions at the bf16 rate (one pipe executes both), over the live duration of the sweep's launches."""
+    t = sweep_ms * 1e-3 * 1e12
+    return work["executed_flops"] / t / PEAK_F32_MFMA_TFLOPS + work["bf16_flops"] / t / PEAK_BF16_MFMA_TFLOPS
+
+
 def niw_roofline(n, D, k_mean, sweep_ms, work):
     flops_alg = 2.0 * n * D * D * (k_mean + 2)
     exe = work["executed_flops"]
-    return {"kernel": "niw_sweep_direct_kernel" if D <= 64 else "niw_sweep_kernel", "bound": "mfma",
+    return {"kernel": sweep_kernel_names(D), "bound": "mfma",
             "achieved": flops_alg / (sweep_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": exe / (sweep_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": sweep_ms,
-            "algorithmic_flops_per_launch": flops_alg, "executed_flops_per_launch": exe, "pruning_factor": flops_alg / exe if exe else None,
+            "frac": pipe_frac(work, sweep_ms), "f32_frac": exe / (sweep_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "traffic": None, "avg_launch_ms": sweep_ms,
+            "algorithmic_flops_per_launch": flops_alg, "executed_flops_per_launch": exe, "executed_bf16_flops_per_launch": work["bf16_flops"],
+            "pruning_factor": flops_alg / exe if exe else None, "b3_evals_per_wave_tile": work.get("b3_evals", 0.0) / max(1.0, work["wave_tiles"]),
             "full_evals_per_wave_tile": work["full_evals"] / max(1.0, work["wave_tiles"]),
             "screens16_per_wave_tile": work["screens16"] / max(1.0, work["wave_tiles"]),
             "tail_pairs_per_wave_tile": work["tail_pairs"] / max(1.0, work["wave_tiles"]),
@@ -541,9 +574,12 @@ def main():
         a, _ = wk.last_kernel_ms()
         sweep_ms.append(a); ks.append(s.K)
 
+    parts_ms = []
+
     def collect_all():
         _, b = wk.last_kernel_ms()
         stats_ms.append(b)
+        parts_ms.append(wk.last_sweep_parts_ms())
         if world > 1:
             comm_ms.append(wk.last_comm_ms())
 
@@ -558,7 +594,7 @@ def main():
     ci1 = wk.comm_info()
     work.append(wk.last_sweep_work())     # per-launch averages over exactly the timed launches
     t_after = dict(s.timers)
-    wk.set_timing(7)
+    wk.set_timing(15)
     timed_block(args.steps, collect_all)
     wk.set_timing(1)
     block_rates = []
@@ -574,21 +610,34 @@ def main():
     # HBM bytes per launch of the sweep kernel: PMC counters need rocprofv3, so the figure comes from the counter summary that
     # scripts/collect_profiles.sh wrote for THIS command (profiles/latest_bench_pmc_summary.json); it carries the hash of the kernel
     # sources it was collected on and is not quoted for any other build or configuration
-    traffic, traffic_source = (pmc_traffic("bench", "niw_sweep_direct_kernel") if (N == 10 ** 7 and D == 64 and world == 1) else (None, None))
-    roof = {"kernel": "niw_sweep_direct_kernel<4,4,2,true>" if D <= 64 else "niw_sweep_kernel", "bound": "mfma",
+    sweep_kernels = SWEEP_KERNELS_64 if 32 < D <= 64 else ("niw_sweep_direct_kernel" if D <= 32 else "niw_sweep_kernel",)
+    traffic, traffic_source = (pmc_traffic("bench", sweep_kernels) if (N == 10 ** 7 and D == 64 and world == 1) else (None, None))
+    exe_bf16 = float(np.mean([w["bf16_flops"] for w in work]))
+    pm = np.asarray(parts_ms, np.float64).mean(axis=0) if parts_ms else np.zeros(3)
+    roof = {"kernel": sweep_kernel_names(D), "bound": "mfma",
             "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": exe / (avg_sweep_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "frac": float(np.mean([pipe_frac(w, avg_sweep_ms) for w in work])),
+            "f32_frac": exe / (avg_sweep_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "bf16_frac": exe_bf16 / (avg_sweep_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, "peak_bf16": PEAK_BF16_MFMA_TFLOPS,
+            "executed_bf16_flops_per_launch": exe_bf16,
+            "launches_ms": {"niw_lean_kernel": float(pm[0]), "niw_sweep_direct_kernel<LSTORE> (labels of the tiles handed on)": float(pm[1]),
+                            "niw_sub_kernel (their sub-labels)": float(pm[2]),
+                            "note": "HIP events between the launches of one sweep, recorded in the second block (timing bit 8); "
+                                    "avg_launch_ms is the sweep's events of the headline block"},
             "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": 4.0 * n_local * D + 4.0 * n_local,
             "avg_launch_ms": avg_sweep_ms, "algorithmic_flops_per_launch": flops_alg, "executed_flops_per_launch": exe,
             "executed_tflops": exe / (avg_sweep_ms * 1e-3) / 1e12, "pruning_factor": flops_alg / exe if exe else None,
             "algorithmic_frac": achieved / PEAK_F32_MFMA_TFLOPS,
             "work_per_launch": {k: float(np.mean([w[k] for w in work])) for k in ("wave_tiles", "full_evals", "screens16", "tail_pairs", "brackets")},
             "bf16_mfma_per_tile": float(np.mean([w["bf16_mfma"] / max(1.0, w["wave_tiles"]) for w in work])),
-            "frac_definition": "Float32 matrix instructions counted on the device in the timed launches x 2048 flops / live launch time / peak "
-                               "(= SQ_INSTS_VALU_MFMA_MOPS_F32 x 512: `pmc_frac`); the reference brackets' bf16 instructions are counted apart",
+            "frac_definition": "share of the matrix pipe's time: matrix instructions counted on the device in the timed launches, Float32 "
+                               "ones x 2048 flops against the Float32 peak (`f32_frac`) + bf16 ones x 16384 flops against the bf16 peak "
+                               "(`bf16_frac`: reference brackets, bf16 screens, three-plane sub-cluster evaluations), over the live duration "
+                               "of the sweep's launches (= (SQ_INSTS_VALU_MFMA_MOPS_F32 / peak_f32 + ..._BF16 / peak_bf16) x 512: `pmc_frac`); "
+                               "`achieved` = the sweep's algorithmic Float32 flops (SURVEY 8d) over the same duration",
             "stats_kernels_ms": float(np.mean(stats_ms)), "kernel_source_tag": kernel_source_tag()}
     if N == 10 ** 7 and D == 64 and world == 1:
-        roof.update(pmc_matrix_pipe("bench", "niw_sweep_direct_kernel", avg_sweep_ms))
+        roof.update(pmc_matrix_pipe("bench", sweep_kernels, avg_sweep_ms))
 
     # same kernel, same process, screening off: every cluster is evaluated in full (labels are bit-identical by construction)
     if not args.no_dense:
@@ -596,11 +645,12 @@ def main():
         dm, dw = [], []
         for _ in range(3):
             s.group_step(False, False)
-            dm.append(wk.last_kernel_ms()[0]); dw.append(wk.last_sweep_work()["executed_flops"])
+            dm.append(wk.last_kernel_ms()[0]); dw.append(wk.last_sweep_work())
         wk.set_option(binding.OPT_SCREEN_MARGIN, 50.0)
-        d_ms, d_fl = float(np.mean(dm[1:])), float(np.mean(dw[1:]))
+        d_ms, d_fl = float(np.mean(dm[1:])), float(np.mean([w["executed_flops"] for w in dw[1:]]))
         roof.update({"dense_launch_ms": d_ms, "dense_executed_tflops": d_fl / (d_ms * 1e-3) / 1e12,
-                     "dense_frac": d_fl / (d_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                     "dense_frac": float(np.mean([pipe_frac(w, d_ms) for w in dw[1:]])),
+                     "dense_f32_frac": d_fl / (d_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                      "dense_algorithmic_tflops": flops_alg / (d_ms * 1e-3) / 1e12})
 
     info = wk.comm_info()

@@ -332,7 +332,15 @@ __device__ __forceinline__ void ref_bracket_planes(const u32x4_t (&a)[6], const 
 // that exist already.  Every other tile (mixed previous labels, a candidate left, no previous labels) is appended to `list` ([0] = count,
 // cleared before the launch) and left untouched: niw_sweep_direct_kernel<.., LSTORE> + niw_sub_kernel take it.  The outcome is that of the
 // one-kernel path: a tile is settled here only if every later screen there would find nothing to do either.
+#ifdef DPMM_STAMPS
+#define LSTAMP(var) unsigned long long var; do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define LSTAMP(var)
+#endif
 __global__ __launch_bounds__(256, 2) void niw_lean_kernel(NiwSweepArgs A, uint32_t *__restrict__ list, uint32_t *__restrict__ need2) {
+#ifdef DPMM_STAMPS
+    unsigned long long T_x = 0, T_conv = 0, T_br = 0, T_scr = 0, T_u = 0, T_p2 = 0, T_tot = 0; int ntl = 0;
+#endif
     const int lane = threadIdx.x & 63, ci = lane & 15, g = lane >> 4;
     const bool use_order = A.order != nullptr && *A.order_total == (int32_t)A.n;
     const int K = A.K;
@@ -352,6 +360,10 @@ __global__ __launch_bounds__(256, 2) void niw_lean_kernel(NiwSweepArgs A, uint32
             myp32 = valid ? (use_order ? A.order[pos] : (int)pos) : -1;
             binv = valid ? A.bins[myp32] : -1;
         }
+        LSTAMP(s0);
+#ifdef DPMM_STAMPS
+        unsigned long long s1 = s0, s2 = s0, s3 = s0, s4 = s0, s5 = s0;
+#endif
         int pf_p = -1, pf_bin = -1;
         {
             const int64_t posn = (tile + nwaves) * 64 + lane;
@@ -382,6 +394,10 @@ __global__ __launch_bounds__(256, 2) void niw_lean_kernel(NiwSweepArgs A, uint32
                     for (int f = 0; f < 6; ++f) abr[f] = F[64 * f];
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#ifdef DPMM_STAMPS
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                { LSTAMP(t1); s1 = t1; }
+#endif
                 // the last four features of "this lane's point" (the tail screens' operand), as niw_sweep_direct_kernel takes them
                 const int src = ci + 16 * A.tail_g;
 #pragma unroll
@@ -395,9 +411,15 @@ __global__ __launch_bounds__(256, 2) void niw_lean_kernel(NiwSweepArgs A, uint32
                 b3_convert(x, mk, Z);                          // x's last use (but for x3)
             }
             if (pf_p >= 0) pf_bin = A.bins[pf_p];              // the next tile's previous labels (its indices have arrived with x)
+#ifdef DPMM_STAMPS
+            { LSTAMP(t2); s2 = t2; }
+#endif
             float qhi[4];
             ref_bracket_planes(abr, Z, qhi);
             ++nw_br;
+#ifdef DPMM_STAMPS
+            { LSTAMP(t3); s3 = t3; }
+#endif
             const float c0 = A.cst[3 * k0];
             float my_best = -INFINITY;
             float thrb[4];                                         // per point group: threshold of the column's point (+inf for a column without a point)
@@ -437,6 +459,9 @@ __global__ __launch_bounds__(256, 2) void niw_lean_kernel(NiwSweepArgs A, uint32
                 hard = cand != 0ull;
             }
         }
+#ifdef DPMM_STAMPS
+        { LSTAMP(t4); s4 = t4; }
+#endif
         float u_sub = 0.f;
         if (!hard) {
             H = b3_head(A.tail, A.cst, K, k0, lane, g);           // the sub-label evaluation's first fragments: in flight under the uniforms' arithmetic
@@ -448,6 +473,9 @@ __global__ __launch_bounds__(256, 2) void niw_lean_kernel(NiwSweepArgs A, uint32
             }
             hard = __ballot(valid && u0 <= 0.f) != 0ull;       // (a uniform of exactly 0 draws index 0, not k0: once in 2^24 points -- the general path)
         }
+#ifdef DPMM_STAMPS
+        { LSTAMP(t5); s5 = t5; }
+#endif
         if (hard) {
             if (lane == 0) { const uint32_t at = atomicAdd(&list[0], 1u); list[1 + at] = (uint32_t)tile; }
             ++nw_hard;
@@ -459,7 +487,16 @@ __global__ __launch_bounds__(256, 2) void niw_lean_kernel(NiwSweepArgs A, uint32
             ++nw_easy;
         }
         nx_p = pf_p; nx_bin = pf_bin; have_nx = true;
+#ifdef DPMM_STAMPS
+        { LSTAMP(s6); T_x += s1 - s0; T_conv += s2 - s1; T_br += s3 - s2; T_scr += s4 - s3; T_u += s5 - s4; T_p2 += s6 - s5; T_tot += s6 - s0; ++ntl; }
+#endif
     }
+#ifdef DPMM_STAMPS
+    if (A.dbg && lane == 0) {
+        unsigned long long *d = A.dbg + (size_t)(8192 + wave_id) * 16;
+        d[0] = T_x; d[1] = T_conv; d[2] = T_br; d[3] = T_scr; d[4] = T_u; d[5] = T_p2; d[6] = 0; d[7] = T_tot; d[8] = ntl;
+    }
+#endif
     if (A.work && lane == 0) {
         unsigned long long *slot = A.work + DPMM_WORK_SLOTS + (size_t)wave_id * DPMM_WORK_PER_WAVE;      // (accumulates; cleared by the reader)
         slot[0] += nw_easy; slot[3] += nw_tail; slot[4] += nw_br; slot[5] += nw_bb; slot[7] += (unsigned long long)(2 * nw_easy) << 32;

@@ -17,7 +17,7 @@ esac
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/under_rocprof.json 2> $OUT/trace.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- $SHORT > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- $SHORT > /dev/null 2> $OUT/pmc_write.err
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F64 --output-format csv -d $OUT/pmc_mfma -o p -- $SHORT > /dev/null 2> $OUT/pmc_mfma.err
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F64 --output-format csv -d $OUT/pmc_mfma -o p -- $SHORT > /dev/null 2> $OUT/pmc_mfma.err
 python3 scripts/pmc_summary.py $OUT "$SHORT" > $OUT/pmc_summary.json
 cp $OUT/pmc_summary.json $OUT/latest_${WHAT}_pmc_summary.json      # -> profiles/latest_${WHAT}_pmc_summary.json (bench.py's roofline.traffic)
 find $OUT -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv

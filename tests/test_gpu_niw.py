@@ -674,6 +674,81 @@ def test_bf16_screens_do_not_change_labels(pkg, D, sep, K):
     assert w1["screens16"] <= w0["screens16"] and w0["bf16_bottom_screens"] == 0 and w0["bf16_top_screens"] == 0
 
 
+@pytest.mark.parametrize("D,sep,K,n", [(64, 40.0, 7, 30000), (64, 2.0, 12, 30011), (64, 0.8, 7, 20000), (52, 2.0, 7, 30000), (36, 3.0, 9, 9999),
+                                       (64, 1.5, 100, 30000), (64, 6.0, 1, 5000)])
+def test_lean_tiles_do_not_change_labels(pkg, D, sep, K, n):
+    """D in 33 .. 64: the sweep runs as niw_lean_kernel (finishes the tiles whose label candidates its screens settle, hands the others on
+    through a tile list) + niw_sweep_direct_kernel<LSTORE> (labels of the listed tiles) + niw_sub_kernel (their sub-labels); with
+    DPMM_OPT_LEAN_TILES = 0 the last two do every tile.  Which launch finishes a tile must not show: labels AND sub-labels bit-equal over a
+    chain of sweeps (every sub-cluster value is the bf16 three-plane one in both), on separated clusters (nearly every tile settled in the lean
+    launch), overlapping ones (most handed on; the regime switch turns the lean launch off), padded D, a ragged last tile and K = 1.  With the
+    lean launch on, the labels are the oracle's draw on the kernel's own table and the sub-labels its draw on the kernel's own sub-cluster
+    values (sample_labels_worker! / create_subclusters_labels!, local_clusters_actions.jl:83-134)."""
+    from dpmmsubclusters_jl_amd import binding
+    P = make_problem(D, n, K, seed=140 + D + K, sep=sep, sorted_points=True)
+    out = {}
+    for on in (1, 0):
+        wk = gpu_worker(pkg, P, seed=29)
+        wk.set_option(binding.OPT_LEAN_TILES, on)
+        wk.set_timing(15)
+        wk.set_labels(P["z"] + 1, 1 + (np.arange(n) & 1))
+        wk.suffstats_packed(None)                      # the bin-sorted visiting order
+        wk.set_params_niw(P["mu"], P["invS"], P["logdet"], P["lr"], P["w"])
+        wk.last_sweep_work()
+        labs, lean_ms = [], []
+        for ep in (1, 2, 3, 4):
+            wk.sweep(ep)
+            labs.append(wk.get_labels())
+            lean_ms.append(wk.last_sweep_parts_ms()[0])
+            if ep == 4 and on:
+                u0, u1 = orc.uniforms(29, 4, 0, 0, n)
+                assert np.array_equal(orc.sample_log_cat(wk.debug_loglik(), u0), labs[-1][0])
+                assert_sublabels_bit_exact(wk, labs[-1][0], labs[-1][1], u1)
+            wk.suffstats_packed(None)
+            wk.set_params_niw(P["mu"], P["invS"], P["logdet"], P["lr"], P["w"])
+        work = wk.last_sweep_work()
+        assert work["b3_evals"] > 0                    # the sub-cluster values came from the three-plane evaluation
+        if not on or K == 1:
+            assert max(lean_ms) == 0.0
+        else:
+            assert lean_ms[1] > 0.0                    # (the first sweep has no previous-label bracket: no lean launch)
+        out[on] = labs
+        wk.close()
+    for a, b in zip(out[1], out[0]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("D,sep", [(64, 3.0), (64, 30.0), (40, 3.0)])
+def test_three_plane_subcluster_values(pkg, D, sep):
+    """DPMM_OPT_B3_SUBLABELS: the sub-cluster log-likelihoods come from bf16 matrix instructions on an exact three-plane split of
+    z = x - mu_k and of the factor R_s (6 of the 9 plane products; the dropped ones are below 2^-24 of a product), with
+    d_s = R_s (mu_k - mu_s) summed in Float64 and rounded once.  Against the Float64 value of the same Float32 parameters the error must stay
+    in the Float32 evaluation's own range (the tolerance north_star gives the Float32 path: a few ulp of the quadratic form), near and far
+    from the cluster (far: |z| large, where a split that lost bits would show first)."""
+    from dpmmsubclusters_jl_amd import binding
+    n, K = 8192 + 13, 6
+    P = make_problem(D, n, K, seed=77 + D, sep=sep)
+    tabs = {}
+    for b3 in (1, 0):
+        wk = gpu_worker(pkg, P, seed=3)
+        wk.set_option(binding.OPT_B3_SUBLABELS, b3)
+        wk.set_labels(P["z"] + 1, 1 + (np.arange(n) & 1))
+        wk.suffstats_packed(None)
+        wk.set_params_niw(P["mu"], P["invS"], P["logdet"], P["lr"], P["w"])
+        wk.sweep(1)
+        tabs[b3] = wk.debug_subloglik().astype(np.float64)
+        wk.close()
+    want = np.empty((2 * K, n))
+    for k in range(K):
+        for s_ in range(2):
+            j = 3 * k + 1 + s_
+            want[2 * k + s_] = orc.niw_loglik_f64(P["X"], D, P["mu"][j], P["invS"][j], P["logdet"][j]) + np.log(np.float64(P["lr"][k, s_]))
+    scale = 1.0 + np.abs(want)
+    e3, e1 = np.abs(tabs[1] - want) / scale, np.abs(tabs[0] - want) / scale
+    print(f"D={D} sep={sep}: relative error of the sub-cluster values -- three-plane max {e3.max():.3g} mean {e3.mean():.3g}; Float32 max {e1.max():.3g} mean {e1.mean():.3g}")
+    assert e3.max() < 2e-5 and e3.mean() < 2e-6
+
+
 @pytest.mark.parametrize("D,sep,K", [(64, 2.0, 12), (64, 1.0, 20), (64, 0.8, 7), (52, 2.0, 7), (36, 3.0, 9), (64, 1.5, 60), (64, 40.0, 7), (64, 0.3, 5)])
 def test_direction_screen_does_not_change_labels(pkg, D, sep, K):
     """DPMM_OPT_DIRECTION_SCREEN (D in 33 .. 64, K <= 64): q_k(x) >= (u' R_k (x - mu_k))^2 along the ONE direction u = R_k d / |R_k d|, d = mu_k0 - mu_k,
