@@ -240,7 +240,9 @@ struct dpmm_ctx {
     int opt_b3 = 1;                    // DPMM_OPT_B3_SUBLABELS: D in 33..64: sub-cluster evaluations through three-plane bf16 images, in kernels of their own (niw_lean.hip)
     bool have_b3 = false;              // the images behind the bracket's in d_tail belong to the parameter set on the device
     int opt_lean = 1;                  // DPMM_OPT_LEAN_TILES: tiles the cheap screens settle completely in niw_lean_kernel (-1 automatic is 1 with a regime switch; 0 never)
-    uint32_t *d_hard = nullptr;        // [1 + ceil(n / 64)]: count | wave tiles the lean kernel left to the general path
+    uint32_t *d_hard = nullptr;        // two lists of [2 + ceil(n / 64)] words, taking turns (hard_flip): count | wave tiles the lean kernel left to the general path;
+                                       // a lean launch clears the OTHER list's count for its successor (no fill launch), niw_sub_kernel reports the count to h_hard (no copy launch)
+    int hard_flip = 0;
     uint32_t *h_hard = nullptr;        // pinned: the count of the LAST sweep's list (read by the next sweep's regime decision, never waited for)
     int lean_off = 0;                  // sweeps left without the lean kernel (a sweep that left more than 30 % of its tiles switches it off for 15)
     int opt_bf16scr = 1;               // D <= 64 sweep: bf16 screens in front of the Float32 16-row screen / of a survivor's first row block (DPMM_OPT_BF16_SCREENS)
@@ -642,8 +644,9 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
         CHK_CREATE(hipHostMalloc((void **)&c->h_need, sizeof(uint32_t) * 12 * (size_t)std::max(1, c->sweep_grid_max), hipHostMallocDefault));
         memset(c->h_need, 0, sizeof(uint32_t) * 12 * (size_t)std::max(1, c->sweep_grid_max));
         if (c->NB == 4) {
-            CHK_CREATE(hipMalloc(&c->d_hard, sizeof(uint32_t) * (size_t)(2 + (n_local + 63) / 64)));
-            CHK_CREATE(hipMemsetAsync(c->d_hard, 0, sizeof(uint32_t) * 2, c->stream));
+            const size_t hw = (size_t)(2 + (n_local + 63) / 64);
+            CHK_CREATE(hipMalloc(&c->d_hard, sizeof(uint32_t) * 2 * hw));
+            CHK_CREATE(hipMemsetAsync(c->d_hard, 0, sizeof(uint32_t) * 2 * hw, c->stream));
             CHK_CREATE(hipHostMalloc((void **)&c->h_hard, 64, hipHostMallocDefault));
             memset(c->h_hard, 0, 64);
         }
@@ -1214,12 +1217,13 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
             const bool parts = (c->opt_timing & 8) != 0 && (c->opt_timing & 1) != 0;
             if (parts && !c->ev_part[0]) for (auto &e : c->ev_part) HIPCHK(c, hipEventCreate(&e));
             if (use_lean) {
-                HIPCHK(c, hipMemsetAsync(c->d_hard, 0, sizeof(uint32_t), c->stream));
+                const size_t hw = (size_t)(2 + (c->n + 63) / 64);
+                uint32_t *mine = c->d_hard + (size_t)c->hard_flip * hw, *other = c->d_hard + (size_t)(c->hard_flip ^ 1) * hw;
+                c->hard_flip ^= 1;
                 uint32_t *need2 = a.need ? c->h_need + 8 * (size_t)c->sweep_grid_max : nullptr;
-                HIPCHK(c, launch_niw_lean(a, c->d_hard, need2, c->sweep_grid, c->stream));
+                HIPCHK(c, launch_niw_lean(a, mine, need2, other, c->sweep_grid, c->stream));
                 if (parts) HIPCHK(c, hipEventRecord(c->ev_part[0], c->stream));
-                HIPCHK(c, launch_copy_bytes(c->h_hard, c->d_hard, sizeof(uint32_t), c->stream));
-                list = c->d_hard;
+                list = mine;
             }
             a.bf16scr |= 4;
             a.tdf = reinterpret_cast<const float *>(list);                         // (the LSTORE instantiations' tile list: null = all tiles)
@@ -1228,7 +1232,7 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
             c->have_parts = parts ? (use_lean ? 2 : 1) : 0;
             a.bf16scr &= 3;
             a.tdf = nullptr;
-            HIPCHK(c, launch_niw_sub(a, list, c->sweep_grid, c->stream));
+            HIPCHK(c, launch_niw_sub(a, list, list ? c->h_hard : nullptr, c->sweep_grid, c->stream));
         } else
         HIPCHK(c, launch_niw_sweep(c->NB, a, c->sweep_grid, c->stream));
     } else {

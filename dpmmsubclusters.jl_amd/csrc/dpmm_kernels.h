@@ -91,10 +91,10 @@ inline size_t niw_tail_floats(size_t cap) { return 16 * (cap + 2) + 16 * cap + (
 // out [2K][n]: both sub-cluster values of every point under every cluster (needs X, ldx, n, K, mup, cst, tail)
 hipError_t launch_niw_b3_debug(const NiwSweepArgs &a, float *out, hipStream_t s);
 // the sub-label phase alone for the wave tiles of `list` (list[0] = count, list[1 ..] = tile indices; null: all tiles); labels are read from bins
-hipError_t launch_niw_sub(const NiwSweepArgs &a, const uint32_t *list, int grid, hipStream_t s);
+hipError_t launch_niw_sub(const NiwSweepArgs &a, const uint32_t *list, uint32_t *count_out, int grid, hipStream_t s);      // count_out (pinned, nullable): receives list[0]
 // whole tiles where bracket + ball + tail screens settle them (every point had label k0, nothing else can compete): labels AND sub-labels; every
 // other tile is appended to list ([0] = count, cleared by the caller; [1 ..] = wave-tile indices) and left untouched.  need2 [4 grid] (nullable, pinned): tiles settled per wave
-hipError_t launch_niw_lean(const NiwSweepArgs &a, uint32_t *list, uint32_t *need2, int grid, hipStream_t s);
+hipError_t launch_niw_lean(const NiwSweepArgs &a, uint32_t *list, uint32_t *need2, uint32_t *other_list, int grid, hipStream_t s);      // list[0] must be 0; other_list[0] is cleared for the next launch
 hipError_t launch_niw_direction(const float *Rp, const float *mup, const float *cst, int D, int K, uint32_t *frag, float *cons, hipStream_t s);
 
 struct MultSweepArgs {

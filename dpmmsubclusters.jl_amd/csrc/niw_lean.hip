@@ -239,7 +239,9 @@ hipError_t launch_niw_b3_debug(const NiwSweepArgs &a, float *out, hipStream_t s)
 // The sub-label phase of the tiles named in `list` (list[0] = their number, list[1 ..] = wave-tile indices; null: every tile): the new labels are
 // in bins (niw_sweep_direct_kernel<.., LSTORE> stored 2 z + old sub-label), the second uniform of the point's Philox draw decides between left
 // and right (create_subclusters_labels!, local_clusters_actions.jl:83-95).  One wave per tile of 64 positions of the visiting order.
-__global__ __launch_bounds__(256, 2) void niw_sub_kernel(NiwSweepArgs A, const uint32_t *__restrict__ list) {
+__global__ __launch_bounds__(256, 2) void niw_sub_kernel(NiwSweepArgs A, const uint32_t *__restrict__ list, uint32_t *__restrict__ count_out) {
+    // (the list's length for the host's regime decision, written to pinned memory by the last launch that reads it: no copy launch)
+    if (list && count_out && blockIdx.x == 0 && threadIdx.x == 0) *count_out = list[0];
     const int lane = threadIdx.x & 63, ci = lane & 15, g = lane >> 4;
     const bool use_order = A.order != nullptr && *A.order_total == (int32_t)A.n;
     const int64_t nwtiles = (A.n + 63) / 64;
@@ -278,9 +280,9 @@ __global__ __launch_bounds__(256, 2) void niw_sub_kernel(NiwSweepArgs A, const u
     }
     if (A.work && lane == 0) A.work[DPMM_WORK_SLOTS + (size_t)wave_id * DPMM_WORK_PER_WAVE + 7] += (unsigned long long)nw_b3 << 32;
 }
-hipError_t launch_niw_sub(const NiwSweepArgs &a, const uint32_t *list, int grid, hipStream_t s) {
+hipError_t launch_niw_sub(const NiwSweepArgs &a, const uint32_t *list, uint32_t *count_out, int grid, hipStream_t s) {
     if (!a.tail || a.n <= 0) return hipErrorInvalidValue;
-    DPMM_LAUNCH(niw_sub_kernel, dim3(grid), dim3(256), 0, s, a, list);
+    DPMM_LAUNCH(niw_sub_kernel, dim3(grid), dim3(256), 0, s, a, list, count_out);
     return hipGetLastError();
 }
 
@@ -337,7 +339,10 @@ __device__ __forceinline__ void ref_bracket_planes(const u32x4_t (&a)[6], const 
 #else
 #define LSTAMP(var)
 #endif
-__global__ __launch_bounds__(256, 2) void niw_lean_kernel(NiwSweepArgs A, uint32_t *__restrict__ list, uint32_t *__restrict__ need2) {
+__global__ __launch_bounds__(256, 2) void niw_lean_kernel(NiwSweepArgs A, uint32_t *__restrict__ list, uint32_t *__restrict__ need2, uint32_t *__restrict__ other_list) {
+    // two lists take turns: this launch appends to `list` (count cleared by the previous lean launch) and clears the other one's count for the
+    // next -- every reader of that one finished before this launch started (stream order).  No fill launch in front of a sweep.
+    if (other_list && blockIdx.x == 0 && threadIdx.x == 0) other_list[0] = 0u;
 #ifdef DPMM_STAMPS
     unsigned long long T_x = 0, T_conv = 0, T_br = 0, T_scr = 0, T_u = 0, T_p2 = 0, T_tot = 0; int ntl = 0;
 #endif
@@ -346,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void niw_lean_kernel(NiwSweepArgs A, uint32
     const int K = A.K;
     const int64_t nwtiles = (A.n + 63) / 64;
     const int wave_id = (int)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int)gridDim.x * 4;
-    unsigned nw_easy = 0, nw_br = 0, nw_tail = 0, nw_hard = 0, nw_bb = 0;
+    unsigned nw_easy = 0, nw_br = 0, nw_tail = 0, nw_bb = 0;
     // the point indices and previous labels of the NEXT tile are fetched while this one is processed (order -> bins is a dependent chain of
     // two HBM round trips in front of the X gather otherwise)
     int nx_p = -1, nx_bin = -1;
@@ -478,7 +483,6 @@ __global__ __launch_bounds__(256, 2) void niw_lean_kernel(NiwSweepArgs A, uint32
 #endif
         if (hard) {
             if (lane == 0) { const uint32_t at = atomicAdd(&list[0], 1u); list[1 + at] = (uint32_t)tile; }
-            ++nw_hard;
             if (pf_p >= 0 && pf_bin < 0) pf_bin = A.bins[pf_p];        // (a tile that left before the bracket)
         } else {
             float bl, br;
@@ -503,9 +507,9 @@ __global__ __launch_bounds__(256, 2) void niw_lean_kernel(NiwSweepArgs A, uint32
     }
     if (need2 && lane == 0) need2[wave_id] = nw_easy < 65535u ? nw_easy : 65535u;      // tiles settled here (no candidates): the direction screen's statistics count them
 }
-hipError_t launch_niw_lean(const NiwSweepArgs &a, uint32_t *list, uint32_t *need2, int grid, hipStream_t s) {
+hipError_t launch_niw_lean(const NiwSweepArgs &a, uint32_t *list, uint32_t *need2, uint32_t *other_list, int grid, hipStream_t s) {
     if (!a.tail || a.n <= 0 || !list) return hipErrorInvalidValue;
-    DPMM_LAUNCH(niw_lean_kernel, dim3(grid), dim3(256), 0, s, a, list, need2);
+    DPMM_LAUNCH(niw_lean_kernel, dim3(grid), dim3(256), 0, s, a, list, need2, other_list);
     return hipGetLastError();
 }
 
