@@ -707,7 +707,7 @@ def test_lean_tiles_do_not_change_labels(pkg, D, sep, K, n):
             wk.suffstats_packed(None)
             wk.set_params_niw(P["mu"], P["invS"], P["logdet"], P["lr"], P["w"])
         work = wk.last_sweep_work()
-        assert work["b3_evals"] > 0                    # the sub-cluster values came from the three-plane evaluation
+        assert work["b3_evals"] > 0 or K == 1          # the sub-cluster values came from the three-plane evaluation (K = 1 has no tail records: the Float32 chain)
         if not on or K == 1 or K > 64:                 # (beyond 64 clusters the scalar pre-screen runs in the sweep kernel: no lean launch)
             assert max(lean_ms) == 0.0
         else:
@@ -743,10 +743,12 @@ def test_three_plane_subcluster_values(pkg, D, sep):
         for s_ in range(2):
             j = 3 * k + 1 + s_
             want[2 * k + s_] = orc.niw_loglik_f64(P["X"], D, P["mu"][j], P["invS"][j], P["logdet"][j]) + np.log(np.float64(P["lr"][k, s_]))
+    want += 0.5 * D * D * np.log(2 * np.pi)            # (the GPU tables omit the reference's constant term, mv_gaussian.jl:24)
     scale = 1.0 + np.abs(want)
     e3, e1 = np.abs(tabs[1] - want) / scale, np.abs(tabs[0] - want) / scale
     print(f"D={D} sep={sep}: relative error of the sub-cluster values -- three-plane max {e3.max():.3g} mean {e3.mean():.3g}; Float32 max {e1.max():.3g} mean {e1.mean():.3g}")
-    assert e3.max() < 2e-5 and e3.mean() < 2e-6
+    # measured: three-plane max 3.3e-7 .. 3.6e-7, mean 5.8e-8; the Float32 chain max 3.7e-7 .. 4.6e-7, mean 6.4e-8 .. 6.8e-8
+    assert e3.max() < 2e-6 and e3.mean() < 2e-7 and e3.max() <= 2 * e1.max()
 
 
 @pytest.mark.parametrize("D,sep,K", [(64, 2.0, 12), (64, 1.0, 20), (64, 0.8, 7), (52, 2.0, 7), (36, 3.0, 9), (64, 1.5, 60), (64, 40.0, 7), (64, 0.3, 5)])
