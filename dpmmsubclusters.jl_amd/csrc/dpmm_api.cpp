@@ -244,7 +244,10 @@ struct dpmm_ctx {
                                        // a lean launch clears the OTHER list's count for its successor (no fill launch), niw_sub_kernel reports the count to h_hard (no copy launch)
     int hard_flip = 0;
     uint32_t *h_hard = nullptr;        // pinned: the count of the LAST sweep's list (read by the next sweep's regime decision, never waited for)
-    int lean_off = 0;                  // sweeps left without the lean kernel (a sweep that left more than 30 % of its tiles switches it off for 15)
+    int lean_off = 0;                  // sweeps left without the lean kernel (a sweep that left more than 30 % of its tiles switches it off for lean_backoff)
+    bool lean_ran = false;             // the last sweep ran the lean kernel: h_hard holds its list's length
+    int lean_backoff = 15;             // 15, doubled by every retry that fails again (up to 1023), back to 15 by one that succeeds: a retry on overlapping
+                                       // clusters costs three sweeps' time (MixtureVar 4: 5.3 ms against 1.8), one in 16 was 0.22 ms per step
     int opt_bf16scr = 1;               // D <= 64 sweep: bf16 screens in front of the Float32 16-row screen / of a survivor's first row block (DPMM_OPT_BF16_SCREENS)
     int opt_bracket = 1;               // D <= 64 sweep: certified bf16 bracket of the reference cluster's value instead of its Float32 evaluation where that decides nothing (DPMM_OPT_REF_BRACKET)
     int opt_timing = 0;                // bit 0 / 1 / 2: HIP events around the sweep kernel / the statistics pass / the all-reduces (dpmm_last_kernel_ms, dpmm_last_comm_ms)
@@ -1208,9 +1211,15 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
             // First the tiles the cheap screens settle completely (niw_lean_kernel: labels and sub-labels in one go); what it leaves goes through
             // the list.  A sweep that left more than 30 % of its tiles (overlapping clusters: the screens' later stages do the work) switches the
             // lean kernel off for 15 sweeps -- every path gives the same labels and sub-labels, so the decision is free to be local.
-            const bool lean_ok = c->opt_lean != 0 && c->opt_bracket && a.use_prev && a.screen_margin > 0.f && !final_argmax && a.lam == nullptr && c->K > 1 && c->d_hard;
+            // (not while the direction screen's regime is on: eight or more candidates per tile behind the 4-row tests -- nothing for the cheap screens to settle)
+            const bool lean_ok = c->opt_lean != 0 && c->opt_bracket && a.use_prev && a.screen_margin > 0.f && !final_argmax && a.lam == nullptr && c->K > 1 && c->d_hard &&
+                                 !(c->sp_regime && c->opt_direction != 0 && c->sp_ready);
             const int64_t nwt = (c->n + 63) / 64;
-            if (lean_ok && c->lean_off == 0 && (int64_t)c->h_hard[0] * 10 > nwt * 3) c->lean_off = 15;      // (the count of the last sweep that ran the lean kernel)
+            if (lean_ok && c->lean_off == 0 && c->lean_ran) {            // the verdict on the last sweep that ran the lean kernel
+                if ((int64_t)c->h_hard[0] * 10 > nwt * 3) { c->lean_off = c->lean_backoff; c->lean_backoff = std::min(2 * c->lean_backoff + 1, 1023); }
+                else c->lean_backoff = 15;
+                c->lean_ran = false;
+            }
             const bool use_lean = lean_ok && c->lean_off == 0;
             if (lean_ok && c->lean_off > 0) { c->lean_off -= 1; c->h_hard[0] = 0; }
             const uint32_t *list = nullptr;
@@ -1220,6 +1229,7 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
                 const size_t hw = (size_t)(2 + (c->n + 63) / 64);
                 uint32_t *mine = c->d_hard + (size_t)c->hard_flip * hw, *other = c->d_hard + (size_t)(c->hard_flip ^ 1) * hw;
                 c->hard_flip ^= 1;
+                c->lean_ran = true;
                 uint32_t *need2 = a.need ? c->h_need + 8 * (size_t)c->sweep_grid_max : nullptr;
                 HIPCHK(c, launch_niw_lean(a, mine, need2, other, c->sweep_grid, c->stream));
                 if (parts) HIPCHK(c, hipEventRecord(c->ev_part[0], c->stream));
@@ -2580,7 +2590,7 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
         case DPMM_OPT_REF_BRACKET: c->opt_bracket = value != 0; return DPMM_OK;
         case DPMM_OPT_COMM_TIMEOUT_MS: c->comm_timeout_ms = value > 0 ? (int)std::min(value, 2.0e9) : 0; return DPMM_OK;
         case DPMM_OPT_BF16_SCREENS: c->opt_bf16scr = value != 0; return DPMM_OK;
-        case DPMM_OPT_LEAN_TILES: c->opt_lean = value != 0; c->lean_off = 0; return DPMM_OK;
+        case DPMM_OPT_LEAN_TILES: c->opt_lean = value != 0; c->lean_off = 0; c->lean_backoff = 15; c->lean_ran = false; return DPMM_OK;
         case DPMM_OPT_B3_SUBLABELS: c->opt_b3 = value != 0; if (!c->opt_b3) c->have_b3 = false; return DPMM_OK;      // (switching it ON takes effect with the next parameter set: its images are packed behind the parameters)
         case DPMM_OPT_DIRECTION_SCREEN:
             c->opt_direction = value < 0 ? -1 : (value != 0);

@@ -157,15 +157,29 @@ __device__ __forceinline__ void b3_mean(const float *__restrict__ mup, int k, in
     for (int t = 0; t < 4; ++t) mk[t] = *reinterpret_cast<const f32x4 *>(mup + (size_t)(3 * k) * 64 + 16 * t + 4 * g);
 }
 // the lane's 16 bytes of every (point group, 16-feature slice) of the B operand, as the sweep kernels hold x: point (n, ci) = p[16 n + ci]
+// (Every load unconditional: a column without a point reads row 0, a slice beyond ldx the row's last four floats, and a select zeroes them --
+// only on a wave that has such a lane.  With the load inside `cond ? load : 0` the compiler emitted sixteen exec-mask branches per tile, each
+// behind a wait for its index shuffle, and 130 register clears.)
 __device__ __forceinline__ void gather_x64(const float *__restrict__ X, int64_t ldx, int myp32, int ci, int g, f32x4 (&x)[4][4]) {
+    const bool plain = ldx >= 64 && __ballot(myp32 < 0) == 0ull;      // (wave-uniform)
+    int pn[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) pn[n] = __shfl(myp32, 16 * n + ci);
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
-        const int pn = __shfl(myp32, 16 * n + ci);
+        const float *row = X + (int64_t)(pn[n] >= 0 ? pn[n] : 0) * ldx;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int e = 16 * t + 4 * g;
-            x[n][t] = (pn >= 0 && e < ldx) ? *reinterpret_cast<const f32x4 *>(X + (int64_t)pn * ldx + e) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            x[n][t] = *reinterpret_cast<const f32x4 *>(row + (e < ldx ? e : (int)ldx - 4));
         }
+    }
+    if (!plain) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (!(pn[n] >= 0 && 16 * t + 4 * g < ldx)) x[n][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 }
 
@@ -248,12 +262,26 @@ __global__ __launch_bounds__(256, 2) void niw_sub_kernel(NiwSweepArgs A, const u
     const int64_t count = list ? (int64_t)list[0] : nwtiles;
     const int wave_id = (int)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int)gridDim.x * 4;
     unsigned nw_b3 = 0;
+    // A tile's chain list -> order -> bins -> x is four dependent round trips; the first three are taken off it: the tile index is known two
+    // tiles ahead, the point indices one tile ahead (requested at a tile's top), their labels requested once the indices have arrived (behind
+    // this tile's x gather) -- as niw_lean_kernel does.  All-tiles mode without them: 0.82 ms at N = 1e7.
+    auto tile_of = [&](int64_t i) -> int64_t { return i < count ? (list ? (int64_t)list[1 + i] : i) : -1; };
+    int64_t t_next = tile_of(wave_id), t_next2 = tile_of((int64_t)wave_id + nwaves);
+    int nx_p = -1, nx_bin = -1;
+    if (t_next >= 0) {
+        const int64_t pos = t_next * 64 + lane;
+        if (pos < A.n) { nx_p = use_order ? A.order[pos] : (int)pos; nx_bin = A.bins[nx_p]; }
+    }
     for (int64_t idx = wave_id; idx < count; idx += nwaves) {
-        const int64_t tile = list ? (int64_t)list[1 + idx] : idx;
-        const int64_t pos = tile * 64 + lane;
-        const bool valid = pos < A.n;
-        const int myp32 = valid ? (use_order ? A.order[pos] : (int)pos) : -1;
-        const int zb = valid ? A.bins[myp32] : -1;
+        t_next = t_next2;
+        t_next2 = tile_of(idx + 2 * (int64_t)nwaves);
+        const int myp32 = nx_p;
+        const int zb = nx_bin;
+        int pf_p = -1, pf_bin = -1;
+        if (t_next >= 0) {
+            const int64_t posn = t_next * 64 + lane;
+            if (posn < A.n) pf_p = use_order ? A.order[posn] : (int)posn;
+        }
         int z = zb >> 1;
         if ((unsigned)z >= (unsigned)A.K) z = -1;                       // (a label outside [0, K): left alone)
         float u_sub = 0.f;
@@ -271,12 +299,15 @@ __global__ __launch_bounds__(256, 2) void niw_sub_kernel(NiwSweepArgs A, const u
             __builtin_amdgcn_sched_barrier(0);
             B3Z Z;
             b3_convert(x, mk, Z);
+            if (pf_p >= 0 && pf_bin < 0) pf_bin = A.bins[pf_p];              // the next tile's labels (its indices arrived with x)
             float bl, br;
             b3_eval(A.tail, A.K, k, Z, H, lane, g, bl, br);
             if (z == k) { b0 = bl; b1 = br; }
             nw_b3 += 2;
         }
         if (z >= 0) A.bins[myp32] = 2 * z + draw2(b0, b1, u_sub);
+        if (pf_p >= 0 && pf_bin < 0) pf_bin = A.bins[pf_p];                  // (a tile without a label in range)
+        nx_p = pf_p; nx_bin = pf_bin;
     }
     if (A.work && lane == 0) A.work[DPMM_WORK_SLOTS + (size_t)wave_id * DPMM_WORK_PER_WAVE + 7] += (unsigned long long)nw_b3 << 32;
 }

@@ -19,15 +19,16 @@ for what in bench shard mult d256; do
 done
 bash scripts/pmc_insts.sh ${TAG}_insts bench > /dev/null 2>&1; cp $GRAFT_REPO_ROOT/gpurun_out/${TAG}_insts/pmc_summary.json $OUT/bench_insts_pmc_summary.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-tl() {  # name, command...
-  local name=$1; shift
+tl() {  # name, first kernel of a step, command...
+  local name=$1; local key=$2; shift; shift
   rm -rf $OUT/tl_$name
   rocprofv3 --kernel-trace --output-format csv -d $OUT/tl_$name -o t -- "$@" > /dev/null 2> $OUT/tl_$name.err
-  python3 scripts/step_timeline.py $OUT/tl_$name > $OUT/step_timeline_$name.txt 2>&1
+  python3 scripts/step_timeline.py $OUT/tl_$name $key > $OUT/step_timeline_$name.txt 2>&1
   rm -rf $OUT/tl_$name $OUT/tl_$name.err
 }
-tl n1e7 python3 scripts/config_step.py niw 64 10000000 60 notiming
-tl shard python3 scripts/config_step.py niw 64 1250000 100 notiming
-tl c4 python3 scripts/config_step.py mult 1000 1000000 60 notiming
-tl c5_shard python3 scripts/config_step.py niw 256 625000 40 notiming
+tl n1e7 niw_lean_kernel python3 scripts/config_step.py niw 64 10000000 60 notiming
+tl shard niw_lean_kernel python3 scripts/config_step.py niw 64 1250000 100 notiming
+tl var4 niw_sweep_direct python3 scripts/config_step.py niw 64 10000000 60 notiming x 4
+tl c4 sweep python3 scripts/config_step.py mult 1000 1000000 60 notiming
+tl c5_shard niw_sweep_kernel python3 scripts/config_step.py niw 256 625000 40 notiming
 ls -la $OUT
