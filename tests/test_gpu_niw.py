@@ -718,6 +718,40 @@ def test_lean_tiles_do_not_change_labels(pkg, D, sep, K, n):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
+def test_lean_tile_lists_take_turns(pkg):
+    """Two tile lists alternate between the sweeps that run the lean launch (a lean launch clears the OTHER list's counter for its successor, the
+    sub-label launch reports the length to the host): a chain in which the lean launch is switched on and off between sweeps -- a list is reused
+    after sweeps that did not touch it -- gives the labels and sub-labels of the chain that never ran it, and the reported lengths are those of
+    the sweeps that did (none behind a sweep without the launch)."""
+    from dpmmsubclusters_jl_amd import binding
+    D, n, K = 64, 60000 + 21, 9
+    P = make_problem(D, n, K, seed=171, sep=12.0, sorted_points=True)
+    pattern = [1, 1, 0, 1, 0, 0, 1, 1, 1, 0, 1]
+    out = {}
+    for mode in ("mixed", "off"):
+        wk = gpu_worker(pkg, P, seed=31)
+        wk.set_timing(15)
+        wk.set_labels(P["z"] + 1, 1 + (np.arange(n) & 1))
+        wk.suffstats_packed(None)
+        wk.set_params_niw(P["mu"], P["invS"], P["logdet"], P["lr"], P["w"])
+        labs, ran = [], []
+        for ep, on in enumerate(pattern, start=1):
+            wk.set_option(binding.OPT_LEAN_TILES, on if mode == "mixed" else 0)
+            wk.sweep(ep)
+            labs.append(wk.get_labels())
+            ran.append(wk.last_sweep_parts_ms()[0] > 0.0)
+            wk.suffstats_packed(None)
+            wk.set_params_niw(P["mu"], P["invS"], P["logdet"], P["lr"], P["w"])
+        if mode == "mixed":
+            assert ran == [bool(v) for v in pattern], ran
+        else:
+            assert not any(ran)
+        out[mode] = labs
+        wk.close()
+    for a, b in zip(out["mixed"], out["off"]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
 @pytest.mark.parametrize("D,sep", [(64, 3.0), (64, 30.0), (40, 3.0)])
 def test_three_plane_subcluster_values(pkg, D, sep):
     """DPMM_OPT_B3_SUBLABELS: the sub-cluster log-likelihoods come from bf16 matrix instructions on an exact three-plane split of
