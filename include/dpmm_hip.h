@@ -94,7 +94,9 @@ enum {
                                          parameter set. */
     DPMM_OPT_LEAN_TILES = 27,         /* 1 (default; with DPMM_OPT_B3_SUBLABELS): tiles whose points all had one label and for which the reference bracket, the ball test and the
                                          4-row tail screens exclude every other cluster are finished -- label and sub-labels -- by niw_lean_kernel; the rest goes through the sweep
-                                         kernel (labels) and niw_sub_kernel (sub-labels).  Same labels and sub-labels either way.  0: every tile takes the second route. */
+                                         kernel (labels) and niw_sub_kernel (sub-labels).  Same labels and sub-labels either way.  0: every tile takes the second route.
+                                         A sweep that hands on more than 30 % of its tiles switches the lean launch off for 15 sweeps (31, 63, ... up to 1023 while the
+                                         retries keep failing); it also stays off while the direction screen's regime is on and beyond 64 clusters (scalar pre-screen). */
     DPMM_OPT_MULT_DRAWS_AHEAD = 25,   /* 1 (default): Multinomial device master: dpmm_step_stats launches the NEXT Dirichlet draws and their hand-over images
                                        * behind the statistics (the epoch after the last dpmm_mult_master_draw, the same K and outlier flag), into a second set of
                                        * buffers, and returns when the rows are on the host -- the draws run while the caller decides splits and merges.
