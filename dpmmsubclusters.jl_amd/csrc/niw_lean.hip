@@ -90,7 +90,13 @@ __device__ __forceinline__ B3Head b3_head(const float *__restrict__ tail, const 
     H.cl = cst[3 * k + 1]; H.cr = cst[3 * k + 2];
     return H;
 }
-__device__ __forceinline__ void b3_eval(const float *__restrict__ tail, int K, int k, const B3Z &Z, const B3Head &H, int lane, int g, float &bl, float &br) {
+#ifndef B3_LATE_AT
+#define B3_LATE_AT 5
+#endif
+struct B3NoHook { __device__ __forceinline__ void operator()() const {} };
+// `late`: called once behind the LAST fragment request of the evaluation (nothing of the evaluation queues behind what it issues)
+template <class Hook = B3NoHook>
+__device__ __forceinline__ void b3_eval(const float *__restrict__ tail, int K, int k, const B3Z &Z, const B3Head &H, int lane, int g, float &bl, float &br, Hook late = Hook()) {
     const uint32_t *img = b3_images(tail, K) + (size_t)(3 * k + 1) * B3_WORDS;
     const float *dvec = b3_offsets(tail, K) + (size_t)(3 * k + 1) * B3_DVEC;
     const u32x4_t *F = reinterpret_cast<const u32x4_t *>(img) + lane;          // fragment f of plane p of matrix m: F[64 (18 m + 6 p + f)]
@@ -129,6 +135,7 @@ __device__ __forceinline__ void b3_eval(const float *__restrict__ tail, int K, i
     for (int b8 = 0; b8 < 8; ++b8) {
         const int bi = b8 & 3;
         if (b8 + 2 < 8) load_block(b8 + 2);
+        if (b8 == B3_LATE_AT) late();
         __builtin_amdgcn_sched_barrier(0);          // (the requests stay in front of this row block's matrix instructions; none of a later row block joins them)
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
@@ -253,7 +260,7 @@ hipError_t launch_niw_b3_debug(const NiwSweepArgs &a, float *out, hipStream_t s)
 // The sub-label phase of the tiles named in `list` (list[0] = their number, list[1 ..] = wave-tile indices; null: every tile): the new labels are
 // in bins (niw_sweep_direct_kernel<.., LSTORE> stored 2 z + old sub-label), the second uniform of the point's Philox draw decides between left
 // and right (create_subclusters_labels!, local_clusters_actions.jl:83-95).  One wave per tile of 64 positions of the visiting order.
-__global__ __launch_bounds__(256, 2) void niw_sub_kernel(NiwSweepArgs A, const uint32_t *__restrict__ list, uint32_t *__restrict__ count_out) {
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void niw_sub_kernel(NiwSweepArgs A, const uint32_t *__restrict__ list, uint32_t *__restrict__ count_out) {
     // (the list's length for the host's regime decision, written to pinned memory by the last launch that reads it: no copy launch)
     if (list && count_out && blockIdx.x == 0 && threadIdx.x == 0) *count_out = list[0];
     const int lane = threadIdx.x & 63, ci = lane & 15, g = lane >> 4;
@@ -267,6 +274,7 @@ __global__ __launch_bounds__(256, 2) void niw_sub_kernel(NiwSweepArgs A, const u
     // this tile's x gather) -- as niw_lean_kernel does.  All-tiles mode without them: 0.82 ms at N = 1e7.
     auto tile_of = [&](int64_t i) -> int64_t { return i < count ? (list ? (int64_t)list[1 + i] : i) : -1; };
     int64_t t_next = tile_of(wave_id), t_next2 = tile_of((int64_t)wave_id + nwaves);
+    const int touch_second = A.ldx > 32 ? 32 : 0;
     int nx_p = -1, nx_bin = -1;
     if (t_next >= 0) {
         const int64_t pos = t_next * 64 + lane;
@@ -301,7 +309,14 @@ __global__ __launch_bounds__(256, 2) void niw_sub_kernel(NiwSweepArgs A, const u
             b3_convert(x, mk, Z);
             if (pf_p >= 0 && pf_bin < 0) pf_bin = A.bins[pf_p];              // the next tile's labels (its indices arrived with x)
             float bl, br;
-            b3_eval(A.tail, A.K, k, Z, H, lane, g, bl, br);
+            // (the next tile's x rows touched behind the last fragment request, as in niw_lean_kernel: v254 / v255 are outside the kernel's budget)
+            auto touch_x = [&]() {
+                if (t_next >= 0 && !todo) {
+                    const float *row = A.X + (int64_t)(pf_p >= 0 ? pf_p : 0) * A.ldx;
+                    asm volatile("global_load_dword v254, %0, off\n\tglobal_load_dword v255, %1, off" :: "v"(row), "v"(row + touch_second) : "v254", "v255");
+                }
+            };
+            b3_eval(A.tail, A.K, k, Z, H, lane, g, bl, br, touch_x);
             if (z == k) { b0 = bl; b1 = br; }
             nw_b3 += 2;
         }
@@ -309,6 +324,7 @@ __global__ __launch_bounds__(256, 2) void niw_sub_kernel(NiwSweepArgs A, const u
         if (pf_p >= 0 && pf_bin < 0) pf_bin = A.bins[pf_p];                  // (a tile without a label in range)
         nx_p = pf_p; nx_bin = pf_bin;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (A.work && lane == 0) A.work[DPMM_WORK_SLOTS + (size_t)wave_id * DPMM_WORK_PER_WAVE + 7] += (unsigned long long)nw_b3 << 32;
 }
 hipError_t launch_niw_sub(const NiwSweepArgs &a, const uint32_t *list, uint32_t *count_out, int grid, hipStream_t s) {
@@ -370,7 +386,7 @@ __device__ __forceinline__ void ref_bracket_planes(const u32x4_t (&a)[6], const 
 #else
 #define LSTAMP(var)
 #endif
-__global__ __launch_bounds__(256, 2) void niw_lean_kernel(NiwSweepArgs A, uint32_t *__restrict__ list, uint32_t *__restrict__ need2, uint32_t *__restrict__ other_list) {
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void niw_lean_kernel(NiwSweepArgs A, uint32_t *__restrict__ list, uint32_t *__restrict__ need2, uint32_t *__restrict__ other_list) {
     // two lists take turns: this launch appends to `list` (count cleared by the previous lean launch) and clears the other one's count for the
     // next -- every reader of that one finished before this launch started (stream order).  No fill launch in front of a sweep.
     if (other_list && blockIdx.x == 0 && threadIdx.x == 0) other_list[0] = 0u;
@@ -383,28 +399,38 @@ __global__ __launch_bounds__(256, 2) void niw_lean_kernel(NiwSweepArgs A, uint32
     const int64_t nwtiles = (A.n + 63) / 64;
     const int wave_id = (int)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int)gridDim.x * 4;
     unsigned nw_easy = 0, nw_br = 0, nw_tail = 0, nw_bb = 0;
-    // the point indices and previous labels of the NEXT tile are fetched while this one is processed (order -> bins is a dependent chain of
-    // two HBM round trips in front of the X gather otherwise)
-    int nx_p = -1, nx_bin = -1;
-    bool have_nx = false;
+    // Off a tile's critical chain order -> bins -> x (three dependent HBM round trips): the point indices are fetched TWO tiles ahead, the
+    // previous labels one tile ahead, and the x rows of the NEXT tile are touched -- one dword per 128-byte line, into two registers nothing
+    // reads -- behind the last fragment request of this tile's evaluations: the next tile's gather, 1.5-2 k cycles later, finds the lines on
+    // their way (sweep 1.10 -> 1.08 ms).  (Vector memory returns in order: touched one row block earlier the evaluations' last fragments queue
+    // behind HBM, 1.09-1.11 ms; touched a whole tile ahead the lines are gone from L2 again -- 8 MB in flight per XCD against 4 -- 1.13 ms.  The
+    // loads are inline asm into v254 / v255, which the kernel's register budget -- amdgpu_num_vgpr(254) -- keeps away from the allocator:
+    // a register the compiler may move or reuse could be overwritten by a touch that returns later.  Its vmcnt bookkeeping does not see the
+    // touches: every wait it emits is then for MORE loads than it thinks, never fewer.)
+    auto index_of = [&](int64_t t) -> int {
+        const int64_t p = t * 64 + lane;
+        return (t < nwtiles && p < A.n) ? (use_order ? A.order[p] : (int)p) : -1;
+    };
+    int nx_p = index_of(wave_id), nx2_p = index_of((int64_t)wave_id + nwaves);
+    int nx_bin = nx_p >= 0 ? A.bins[nx_p] : -1;
+    const int touch_second = A.ldx > 32 ? 32 : 0;           // (floats: the row's second 128-byte line, if it has one)
     for (int64_t tile = wave_id; tile < nwtiles; tile += nwaves) {
         const int64_t pos = tile * 64 + lane;
         const bool valid = pos < A.n;
-        int myp32, binv;
-        if (have_nx) { myp32 = nx_p; binv = nx_bin; }
-        else {
-            myp32 = valid ? (use_order ? A.order[pos] : (int)pos) : -1;
-            binv = valid ? A.bins[myp32] : -1;
-        }
+        const int myp32 = nx_p, binv = nx_bin;
         LSTAMP(s0);
 #ifdef DPMM_STAMPS
         unsigned long long s1 = s0, s2 = s0, s3 = s0, s4 = s0, s5 = s0;
 #endif
-        int pf_p = -1, pf_bin = -1;
-        {
-            const int64_t posn = (tile + nwaves) * 64 + lane;
-            if (tile + nwaves < nwtiles && posn < A.n) pf_p = use_order ? A.order[posn] : (int)posn;
-        }
+        const int pf_p = nx2_p;                                  // the next tile's indices (here since the previous tile)
+        int pf_bin = pf_p >= 0 ? A.bins[pf_p] : -1;              // its previous labels
+        const int pf2_p = index_of(tile + 2 * (int64_t)nwaves);  // the indices of the tile after next
+        auto touch_x = [&]() {
+            if (tile + nwaves < nwtiles) {
+                const float *row = A.X + (int64_t)(pf_p >= 0 ? pf_p : 0) * A.ldx;
+                asm volatile("global_load_dword v254, %0, off\n\tglobal_load_dword v255, %1, off" :: "v"(row), "v"(row + touch_second) : "v254", "v255");
+            }
+        };
         int prev = binv >= 0 ? (binv >> 1) : -1;
         if ((unsigned)prev >= (unsigned)K) prev = -1;
         const unsigned long long pm = __ballot(prev >= 0);
@@ -446,7 +472,6 @@ __global__ __launch_bounds__(256, 2) void niw_lean_kernel(NiwSweepArgs A, uint32
                 for (int n = 0; n < 4; ++n) x3[n] = x[n][3];
                 b3_convert(x, mk, Z);                          // x's last use (but for x3)
             }
-            if (pf_p >= 0) pf_bin = A.bins[pf_p];              // the next tile's previous labels (its indices have arrived with x)
 #ifdef DPMM_STAMPS
             { LSTAMP(t2); s2 = t2; }
 #endif
@@ -514,14 +539,14 @@ __global__ __launch_bounds__(256, 2) void niw_lean_kernel(NiwSweepArgs A, uint32
 #endif
         if (hard) {
             if (lane == 0) { const uint32_t at = atomicAdd(&list[0], 1u); list[1 + at] = (uint32_t)tile; }
-            if (pf_p >= 0 && pf_bin < 0) pf_bin = A.bins[pf_p];        // (a tile that left before the bracket)
+            touch_x();
         } else {
             float bl, br;
-            b3_eval(A.tail, K, k0, Z, H, lane, g, bl, br);
+            b3_eval(A.tail, K, k0, Z, H, lane, g, bl, br, touch_x);
             if (valid) A.bins[myp32] = 2 * k0 + draw2(bl, br, u_sub);
             ++nw_easy;
         }
-        nx_p = pf_p; nx_bin = pf_bin; have_nx = true;
+        nx_p = pf_p; nx_bin = pf_bin; nx2_p = pf2_p;
 #ifdef DPMM_STAMPS
         { LSTAMP(s6); T_x += s1 - s0; T_conv += s2 - s1; T_br += s3 - s2; T_scr += s4 - s3; T_u += s5 - s4; T_p2 += s6 - s5; T_tot += s6 - s0; ++ntl; }
 #endif
@@ -532,6 +557,7 @@ __global__ __launch_bounds__(256, 2) void niw_lean_kernel(NiwSweepArgs A, uint32
         d[0] = T_x; d[1] = T_conv; d[2] = T_br; d[3] = T_scr; d[4] = T_u; d[5] = T_p2; d[6] = 0; d[7] = T_tot; d[8] = ntl;
     }
 #endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (no touch in flight at the end)
     if (A.work && lane == 0) {
         unsigned long long *slot = A.work + DPMM_WORK_SLOTS + (size_t)wave_id * DPMM_WORK_PER_WAVE;      // (accumulates; cleared by the reader)
         slot[0] += nw_easy; slot[3] += nw_tail; slot[4] += nw_br; slot[5] += nw_bb; slot[7] += (unsigned long long)(2 * nw_easy) << 32;
