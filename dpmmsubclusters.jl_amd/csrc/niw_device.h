@@ -101,9 +101,13 @@ __device__ __forceinline__ BallWave ball_of_wave(const float *tail, int K, int k
     return B;
 }
 // lanes j: cluster base + j is below the wave's lowest threshold for every point of the ball
+// (rec: this lane's record -- in global memory or in a workgroup's LDS copy; in_range: the lane names a cluster)
+__device__ __forceinline__ unsigned long long ball_far_rec(const float *rec, bool in_range, const BallWave &B);
 __device__ __forceinline__ unsigned long long ball_far(const float *tail, int K, int base, int lane, const BallWave &B) {
     const int j = base + lane;
-    const float *rec = ball_records(tail, K) + 16 * (size_t)(j < K ? j : 0);
+    return ball_far_rec(ball_records(tail, K) + 16 * (size_t)(j < K ? j : 0), j < K, B);
+}
+__device__ __forceinline__ unsigned long long ball_far_rec(const float *rec, bool in_range, const BallWave &B) {
     const f32x4 m = *reinterpret_cast<const f32x4 *>(rec), t0 = *reinterpret_cast<const f32x4 *>(rec + 4);
     const f32x4 t1 = *reinterpret_cast<const f32x4 *>(rec + 8), t2 = *reinterpret_cast<const f32x4 *>(rec + 12);
     const f32x4 d = B.c - m;
@@ -118,7 +122,7 @@ __device__ __forceinline__ unsigned long long ball_far(const float *tail, int K,
     // rounding slack: |T d| is computed to ~1e-6 |T|_F |d|; the margin of the screen (tens of nats) dwarfs it anyway
     const float lb = fmaxf(__builtin_fmaf(-t2.z, __builtin_fmaf(1e-5f, __builtin_amdgcn_sqrtf(dn), B.r), __builtin_amdgcn_sqrtf(qn) * 0.99999f), 0.f);
     const float ub = __builtin_fmaf(-0.5f * lb, lb, t2.w);
-    return __ballot(j < K && ub < B.thr);
+    return __ballot(in_range && ub < B.thr);
 }
 
 // Reference BRACKET (D in 33 .. 64).  On a wave whose points all carried label k0 the cluster-level value a_k0(x) = cst - q(x) / 2,

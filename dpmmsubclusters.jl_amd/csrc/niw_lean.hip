@@ -399,6 +399,16 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void 
     const int64_t nwtiles = (A.n + 63) / 64;
     const int wave_id = (int)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int)gridDim.x * 4;
     unsigned nw_easy = 0, nw_br = 0, nw_tail = 0, nw_bb = 0;
+    // the ball test's records (16 floats per cluster, the same for every tile) once per workgroup in LDS: the test then waits for an LDS read
+    // instead of an L2 round trip per tile
+    constexpr int BALL_LDS_K = 128;
+    __shared__ __attribute__((aligned(16))) float ball_lds[BALL_LDS_K * 16];
+    const bool ball_in_lds = A.ball && K <= BALL_LDS_K;
+    if (ball_in_lds) {
+        const float *src = ball_records(A.tail, K);
+        for (int e = threadIdx.x; e < 16 * K; e += 256) ball_lds[e] = src[e];
+        __syncthreads();
+    }
     // Off a tile's critical chain order -> bins -> x (three dependent HBM round trips): the point indices are fetched TWO tiles ahead, the
     // previous labels one tile ahead, and the x rows of the NEXT tile are touched -- one dword per 128-byte line, into two registers nothing
     // reads -- behind the last fragment request of this tile's evaluations: the next tile's gather, 1.5-2 k cycles later, finds the lines on
@@ -496,7 +506,10 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void 
             for (int base = 0; base < K && !hard; base += 64) {
                 unsigned long long cand = (K - base >= 64) ? ~0ull : ((1ull << (K - base)) - 1ull);
                 if (k0 >= base && k0 < base + 64) cand &= ~(1ull << (k0 - base));
-                if (ball.ok) cand &= ~ball_far(A.tail, K, base, lane, ball);
+                if (ball.ok) {
+                    const int j = base + lane;
+                    cand &= ~(ball_in_lds ? ball_far_rec(ball_lds + 16 * (j < K ? j : 0), j < K, ball) : ball_far(A.tail, K, base, lane, ball));
+                }
                 for (unsigned long long pend = cand; pend;) {
                     const int sh = __builtin_ctzll(pend) & ~1;            // (base is a multiple of 64: pair 2p sits at an even bit)
                     const int pr = (base + sh) >> 1;
