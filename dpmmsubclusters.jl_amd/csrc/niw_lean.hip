@@ -452,6 +452,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void 
         }
         B3Z Z;
         B3Head H;
+        float u_sub = 0.f, u0 = 1.f;
         if (!hard) {
             f32x4 xt = (f32x4){0.f, 0.f, 0.f, 0.f};
             f32x4 x3[4];                                           // the last 16 features (the bf16 bottom screens' operand)
@@ -464,6 +465,12 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void 
                     const u32x4_t *F = reinterpret_cast<const u32x4_t *>(refb_records(A.tail, K) + (size_t)k0 * REFB_WORDS) + lane;
 #pragma unroll
                     for (int f = 0; f < 6; ++f) abr[f] = F[64 * f];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // the point's uniforms need nothing of x: their ~150 vector instructions run while the gather is on its way
+                if (valid) {
+                    const Philox4 r = philox4x32_10(A.seed, (uint64_t)(A.first_index + myp32), A.epoch, STREAM_SWEEP);
+                    u0 = u01(r.v[0]); u_sub = u01(r.v[1]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #ifdef DPMM_STAMPS
@@ -536,15 +543,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void 
 #ifdef DPMM_STAMPS
         { LSTAMP(t4); s4 = t4; }
 #endif
-        float u_sub = 0.f;
         if (!hard) {
-            H = b3_head(A.tail, A.cst, K, k0, lane, g);           // the sub-label evaluation's first fragments: in flight under the uniforms' arithmetic
-            __builtin_amdgcn_sched_barrier(0);
-            float u0 = 1.f;
-            if (valid) {
-                const Philox4 r = philox4x32_10(A.seed, (uint64_t)(A.first_index + myp32), A.epoch, STREAM_SWEEP);
-                u0 = u01(r.v[0]); u_sub = u01(r.v[1]);
-            }
+            H = b3_head(A.tail, A.cst, K, k0, lane, g);           // the sub-label evaluation's first fragments
             hard = __ballot(valid && u0 <= 0.f) != 0ull;       // (a uniform of exactly 0 draws index 0, not k0: once in 2^24 points -- the general path)
         }
 #ifdef DPMM_STAMPS
