@@ -671,7 +671,11 @@ def main():
         "config": {"workload": f"NIW D={D} N={N} synthetic GMM, {K} true components, K_t={k_mean:.1f} live clusters, "
                                f"alpha=10, default NIW prior, steady state after {BURNOUT + 1} burn-in + {args.settle} settling sweeps",
                    "points_per_gpu": n_local, "worker_options_overridden": {str(o): v for o, v in WORKER_OPTS} or None,
-                   "parallelism": f"points sharded over {world} GPU(s); all-reduces of a statistics pass inside libdpmmhip.so: see comm"},
+                   "parallelism": f"points sharded over {world} GPU(s); all-reduces of a statistics pass inside libdpmmhip.so: see comm",
+                   "master": "DEVIATION from north_star's wording, stated here: the headline runs the engine's default for D >= 64 -- posteriors, "
+                             "factorisations and parameter draws on the GPU beside the statistics they consume (DPMMH_OPT_DEVICE_MASTER), every decision "
+                             "(gates, split / merge Metropolis steps) on the host.  The configuration north_star words (draws on the host) is the "
+                             "`host_master` block of this line; its rate and ratio to the headline are in also_measured"},
         "roofline": roof,
         "comm": {"world": info["world"], "transport": info["transport"], "occupancy_allreduce_bytes": info["counts_bytes"],
                  "rows_allreduce_bytes": info["rows_bytes"], "allreduces_since_attach": info["allreduces"],
