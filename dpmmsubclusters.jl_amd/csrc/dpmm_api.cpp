@@ -243,6 +243,7 @@ struct dpmm_ctx {
     uint32_t *d_hard = nullptr;        // two lists of [2 + ceil(n / 64)] words, taking turns (hard_flip): count | wave tiles the lean kernel left to the general path;
                                        // a lean launch clears the OTHER list's count for its successor (no fill launch), niw_sub_kernel reports the count to h_hard (no copy launch)
     int hard_flip = 0;
+    int perm_nbins = 0;                // bins of the sort that wrote sb.perm / sb.bin_start (0: none yet): the lean kernel aligns its tiles to them
     uint32_t *h_hard = nullptr;        // pinned: the count of the LAST sweep's list (read by the next sweep's regime decision, never waited for)
     int lean_off = 0;                  // sweeps left without the lean kernel (a sweep that left more than 30 % of its tiles switches it off for lean_backoff)
     bool lean_ran = false;             // the last sweep ran the lean kernel: h_hard holds its list's length
@@ -546,6 +547,9 @@ static int ensure_capacity(dpmm_ctx *c, int K) {
     return DPMM_OK;
 }
 
+// words of ONE tile list of the lean sweep: count + (position, count) per tile; at most ceil(n / 64) + NIW_LEAN_MAX_BINS tiles (bin-aligned)
+static size_t hard_list_words(int64_t n) { return 4 + 2 * ((size_t)((n + 63) / 64) + NIW_LEAN_MAX_BINS + 2); }
+
 int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t first_index, int device, uint64_t seed) {
     if (!out) return fail(nullptr, DPMM_EINVAL, "ctx out pointer is null");
     *out = nullptr;
@@ -647,7 +651,7 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
         CHK_CREATE(hipHostMalloc((void **)&c->h_need, sizeof(uint32_t) * 12 * (size_t)std::max(1, c->sweep_grid_max), hipHostMallocDefault));
         memset(c->h_need, 0, sizeof(uint32_t) * 12 * (size_t)std::max(1, c->sweep_grid_max));
         if (c->NB == 4) {
-            const size_t hw = (size_t)(2 + (n_local + 63) / 64);
+            const size_t hw = hard_list_words(n_local);
             CHK_CREATE(hipMalloc(&c->d_hard, sizeof(uint32_t) * 2 * hw));
             CHK_CREATE(hipMemsetAsync(c->d_hard, 0, sizeof(uint32_t) * 2 * hw, c->stream));
             CHK_CREATE(hipHostMalloc((void **)&c->h_hard, 64, hipHostMallocDefault));
@@ -1226,12 +1230,14 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
             const bool parts = (c->opt_timing & 8) != 0 && (c->opt_timing & 1) != 0;
             if (parts && !c->ev_part[0]) for (auto &e : c->ev_part) HIPCHK(c, hipEventCreate(&e));
             if (use_lean) {
-                const size_t hw = (size_t)(2 + (c->n + 63) / 64);
+                const size_t hw = hard_list_words(c->n);
                 uint32_t *mine = c->d_hard + (size_t)c->hard_flip * hw, *other = c->d_hard + (size_t)(c->hard_flip ^ 1) * hw;
                 c->hard_flip ^= 1;
                 c->lean_ran = true;
                 uint32_t *need2 = a.need ? c->h_need + 8 * (size_t)c->sweep_grid_max : nullptr;
-                HIPCHK(c, launch_niw_lean(a, mine, need2, other, c->sweep_grid, c->stream));
+                // (tiles aligned to the bins of the sort that wrote the visiting order, when there is one and it fits the kernel's table)
+                const bool al = a.order != nullptr && c->perm_nbins > 0 && c->perm_nbins <= NIW_LEAN_MAX_BINS;
+                HIPCHK(c, launch_niw_lean(a, mine, need2, other, al ? c->sb.bin_start : nullptr, al ? c->perm_nbins : 0, c->sweep_grid, c->stream));
                 if (parts) HIPCHK(c, hipEventRecord(c->ev_part[0], c->stream));
                 list = mine;
             }
@@ -1499,6 +1505,7 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
         HIPCHK(c, launch_sort_finish(c->dbins, a, c->stream));
     }
     c->have_perm = c->n > 0;
+    c->perm_nbins = nbins;
     if (flags_sent) *flags_sent = false;
     if (one_coll) {
         uint8_t *flags = reinterpret_cast<uint8_t *>(c->d_out) + sizeof(double) * (size_t)nbins * (size_t)c->packed_stride;

@@ -94,7 +94,10 @@ hipError_t launch_niw_b3_debug(const NiwSweepArgs &a, float *out, hipStream_t s)
 hipError_t launch_niw_sub(const NiwSweepArgs &a, const uint32_t *list, uint32_t *count_out, int grid, hipStream_t s);      // count_out (pinned, nullable): receives list[0]
 // whole tiles where bracket + ball + tail screens settle them (every point had label k0, nothing else can compete): labels AND sub-labels; every
 // other tile is appended to list ([0] = count, cleared by the caller; [1 ..] = wave-tile indices) and left untouched.  need2 [4 grid] (nullable, pinned): tiles settled per wave
-hipError_t launch_niw_lean(const NiwSweepArgs &a, uint32_t *list, uint32_t *need2, uint32_t *other_list, int grid, hipStream_t s);      // list[0] must be 0; other_list[0] is cleared for the next launch
+constexpr int NIW_LEAN_MAX_BINS = 256;      // bins of the sort the lean kernel can align its tiles to (beyond: tiles of 64 consecutive positions)
+// bin_start [nbins + 1] (nullable): the offsets of the sort that wrote a.order -- tiles never cross a bin.  The list holds (position, count) pairs:
+// 1 + 2 * (ceil(n / 64) + nbins) words at most.
+hipError_t launch_niw_lean(const NiwSweepArgs &a, uint32_t *list, uint32_t *need2, uint32_t *other_list, const int32_t *bin_start, int nbins, int grid, hipStream_t s);      // list[0] must be 0; other_list[0] is cleared for the next launch
 hipError_t launch_niw_direction(const float *Rp, const float *mup, const float *cst, int D, int K, uint32_t *frag, float *cons, hipStream_t s);
 
 struct MultSweepArgs {

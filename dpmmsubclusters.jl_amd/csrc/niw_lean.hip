@@ -76,7 +76,7 @@ __device__ __forceinline__ void b3_convert(const f32x4 (&x)[4][4], const f32x4 (
 // requests them there: b3_head)
 struct B3Head { u32x4_t a[2][2][3]; f32x4 d[2]; float cl, cr; };
 __device__ __forceinline__ B3Head b3_head(const float *__restrict__ tail, const float *__restrict__ cst, int K, int k, int lane, int g) {
-    const u32x4_t *F = reinterpret_cast<const u32x4_t *>(b3_images(tail, K) + (size_t)(3 * k + 1) * B3_WORDS) + lane;
+    const u32x4_t *F = reinterpret_cast<const u32x4_t *>(b3_images(tail, K) + (size_t)(3 * k + 1) * B3_WORDS) + (unsigned)lane;
     const float *dvec = b3_offsets(tail, K) + (size_t)(3 * k + 1) * B3_DVEC;
     B3Head H;
 #pragma unroll
@@ -85,7 +85,7 @@ __device__ __forceinline__ B3Head b3_head(const float *__restrict__ tail, const 
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int p = 0; p < 3; ++p) H.a[bi][s2][p] = F[64 * (6 * p + 2 * bi + s2)];
-        H.d[bi] = *reinterpret_cast<const f32x4 *>(dvec + 16 * bi + 4 * g);
+        H.d[bi] = *reinterpret_cast<const f32x4 *>(dvec + 16 * bi + 4u * (unsigned)g);
     }
     H.cl = cst[3 * k + 1]; H.cr = cst[3 * k + 2];
     return H;
@@ -99,7 +99,7 @@ template <class Hook = B3NoHook>
 __device__ __forceinline__ void b3_eval(const float *__restrict__ tail, int K, int k, const B3Z &Z, const B3Head &H, int lane, int g, float &bl, float &br, Hook late = Hook()) {
     const uint32_t *img = b3_images(tail, K) + (size_t)(3 * k + 1) * B3_WORDS;
     const float *dvec = b3_offsets(tail, K) + (size_t)(3 * k + 1) * B3_DVEC;
-    const u32x4_t *F = reinterpret_cast<const u32x4_t *>(img) + lane;          // fragment f of plane p of matrix m: F[64 (18 m + 6 p + f)]
+    const u32x4_t *F = reinterpret_cast<const u32x4_t *>(img) + (unsigned)lane;          // fragment f of plane p of matrix m: F[64 (18 m + 6 p + f)]
     constexpr int F0[4] = {0, 2, 4, 5};                                        // first fragment of a row block (refb_map's order: (0,0) (0,1) (1,0) (1,1) (2,1) (3,1))
     u32x4_t Af[8][2][3];                                                       // [block 4 m + bi][slice of the block][plane]; SSA values: nothing is copied
     f32x4 dv[8];
@@ -109,7 +109,7 @@ __device__ __forceinline__ void b3_eval(const float *__restrict__ tail, int K, i
         for (int s2 = 0; s2 < (bi < 2 ? 2 : 1); ++s2)
 #pragma unroll
             for (int p = 0; p < 3; ++p) Af[b8][s2][p] = F[64 * (18 * m + 6 * p + F0[bi] + s2)];
-        dv[b8] = *reinterpret_cast<const f32x4 *>(dvec + B3_DVEC * m + 16 * bi + 4 * g);
+        dv[b8] = *reinterpret_cast<const f32x4 *>(dvec + B3_DVEC * m + 16 * bi + 4u * (unsigned)g);
     };
 #pragma unroll
     for (int bi = 0; bi < 2; ++bi) {
@@ -161,7 +161,7 @@ __device__ __forceinline__ void b3_eval(const float *__restrict__ tail, int K, i
 // the cluster-level mean of cluster k in the x registers' layout
 __device__ __forceinline__ void b3_mean(const float *__restrict__ mup, int k, int g, f32x4 (&mk)[4]) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) mk[t] = *reinterpret_cast<const f32x4 *>(mup + (size_t)(3 * k) * 64 + 16 * t + 4 * g);
+    for (int t = 0; t < 4; ++t) mk[t] = *reinterpret_cast<const f32x4 *>(mup + (size_t)(3 * k) * 64 + 16 * t + 4u * (unsigned)g);
 }
 // the lane's 16 bytes of every (point group, 16-feature slice) of the B operand, as the sweep kernels hold x: point (n, ci) = p[16 n + ci]
 // (Every load unconditional: a column without a point reads row 0, a slice beyond ldx the row's last four floats, and a select zeroes them --
@@ -272,13 +272,20 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void 
     // A tile's chain list -> order -> bins -> x is four dependent round trips; the first three are taken off it: the tile index is known two
     // tiles ahead, the point indices one tile ahead (requested at a tile's top), their labels requested once the indices have arrived (behind
     // this tile's x gather) -- as niw_lean_kernel does.  All-tiles mode without them: 0.82 ms at N = 1e7.
-    auto tile_of = [&](int64_t i) -> int64_t { return i < count ? (list ? (int64_t)list[1 + i] : i) : -1; };
+    // entry i of the list = (first position, number of positions <= 64): the lean kernel's tiles are aligned to the sort's bins; without a
+    // list tile i is positions 64 i ..  A span is packed as position << 7 | count (n < 2^31, count <= 64); -1: none.
+    auto tile_of = [&](int64_t i) -> int64_t {
+        if (i >= count) return -1;
+        if (list) return ((int64_t)list[1 + 2 * i] << 7) | (int64_t)list[2 + 2 * i];
+        const int64_t e = A.n - 64 * i;
+        return ((64 * i) << 7) | (e < 64 ? e : 64);
+    };
     int64_t t_next = tile_of(wave_id), t_next2 = tile_of((int64_t)wave_id + nwaves);
     const int touch_second = A.ldx > 32 ? 32 : 0;
     int nx_p = -1, nx_bin = -1;
     if (t_next >= 0) {
-        const int64_t pos = t_next * 64 + lane;
-        if (pos < A.n) { nx_p = use_order ? A.order[pos] : (int)pos; nx_bin = A.bins[nx_p]; }
+        const int64_t pos = (t_next >> 7) + lane;
+        if (lane < (int)(t_next & 127)) { nx_p = use_order ? A.order[pos] : (int)pos; nx_bin = A.bins[nx_p]; }
     }
     for (int64_t idx = wave_id; idx < count; idx += nwaves) {
         t_next = t_next2;
@@ -287,8 +294,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void 
         const int zb = nx_bin;
         int pf_p = -1, pf_bin = -1;
         if (t_next >= 0) {
-            const int64_t posn = t_next * 64 + lane;
-            if (posn < A.n) pf_p = use_order ? A.order[posn] : (int)posn;
+            const int64_t posn = (t_next >> 7) + lane;
+            if (lane < (int)(t_next & 127)) pf_p = use_order ? A.order[posn] : (int)posn;
         }
         int z = zb >> 1;
         if ((unsigned)z >= (unsigned)A.K) z = -1;                       // (a label outside [0, K): left alone)
@@ -386,7 +393,8 @@ __device__ __forceinline__ void ref_bracket_planes(const u32x4_t (&a)[6], const 
 #else
 #define LSTAMP(var)
 #endif
-__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void niw_lean_kernel(NiwSweepArgs A, uint32_t *__restrict__ list, uint32_t *__restrict__ need2, uint32_t *__restrict__ other_list) {
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void niw_lean_kernel(NiwSweepArgs A, uint32_t *__restrict__ list, uint32_t *__restrict__ need2, uint32_t *__restrict__ other_list,
+                                                                                                   const int32_t *__restrict__ bin_start, int nbins) {
     // two lists take turns: this launch appends to `list` (count cleared by the previous lean launch) and clears the other one's count for the
     // next -- every reader of that one finished before this launch started (stream order).  No fill launch in front of a sweep.
     if (other_list && blockIdx.x == 0 && threadIdx.x == 0) other_list[0] = 0u;
@@ -396,7 +404,6 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void 
     const int lane = threadIdx.x & 63, ci = lane & 15, g = lane >> 4;
     const bool use_order = A.order != nullptr && *A.order_total == (int32_t)A.n;
     const int K = A.K;
-    const int64_t nwtiles = (A.n + 63) / 64;
     const int wave_id = (int)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int)gridDim.x * 4;
     unsigned nw_easy = 0, nw_br = 0, nw_tail = 0, nw_bb = 0;
     // the ball test's records (16 floats per cluster, the same for every tile) once per workgroup in LDS: the test then waits for an LDS read
@@ -407,36 +414,72 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void 
     if (ball_in_lds) {
         const float *src = ball_records(A.tail, K);
         for (int e = threadIdx.x; e < 16 * K; e += 256) ball_lds[e] = src[e];
-        __syncthreads();
     }
-    // Off a tile's critical chain order -> bins -> x (three dependent HBM round trips): the point indices are fetched TWO tiles ahead, the
-    // previous labels one tile ahead, and the x rows of the NEXT tile are touched -- one dword per 128-byte line, into two registers nothing
+    // TILES ALIGNED TO THE SORT'S BINS.  The visiting order is sorted by bin (label, sub-label); a tile of 64 consecutive positions that
+    // crosses from one cluster into the next has mixed previous labels and goes to the general path -- 31 such tiles per sweep at K = 32,
+    // whatever N, and the two launches that take them are a tile's latency each (45 us of the 8-GPU shard's 355).  With bin_start (the sort's
+    // bin offsets, nbins + 1 entries) a tile never crosses a bin: bin b owns ceil(count_b / 64) tiles, its last one partly filled.
+    // Whole-bin relabels since the sort (split, merge) keep a tile's points in one cluster; a tile is still CHECKED against the labels.
+    constexpr int MAXB = NIW_LEAN_MAX_BINS;
+    __shared__ int tstart_s[MAXB + 2], bstart_s[MAXB + 2], wsum_s[4];
+    const bool aligned = bin_start != nullptr && use_order && nbins >= 1 && nbins <= MAXB && bin_start[nbins] == (int32_t)A.n;      // (workgroup-uniform)
+    const int nb = aligned ? nbins : 1;                     // (no usable table: ONE bin holding every position -- tiles of 64 consecutive positions)
+    {
+        const int tid = threadIdx.x;
+        int c = 0;
+        if (tid < nb) {
+            const int s0 = aligned ? bin_start[tid] : 0, s1 = aligned ? bin_start[tid + 1] : (int)A.n;
+            c = (s1 - s0 + 63) >> 6; bstart_s[tid] = s0;
+        }
+        if (tid == nb) bstart_s[nb] = (int)A.n;
+        int inc = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off); if (lane >= off) inc += v; }
+        if (lane == 63) wsum_s[tid >> 6] = inc;
+        __syncthreads();
+        const int w = tid >> 6;
+        inc += (w > 0 ? wsum_s[0] : 0) + (w > 1 ? wsum_s[1] : 0) + (w > 2 ? wsum_s[2] : 0);
+        tstart_s[tid + 1] = inc;
+        if (tid == 0) tstart_s[0] = 0;
+    }
+    __syncthreads();
+    const int ntiles_all = __builtin_amdgcn_readfirstlane(tstart_s[nb]);
+    int bptr = 0;
+    // the span of tile t (first position, number of positions); the tiles a wave asks for increase: one running bin pointer
+    auto span_of = [&](int t, int &p0, int &cn) {
+        p0 = 0; cn = 0;
+        if (t >= ntiles_all) return;
+        while (t >= __builtin_amdgcn_readfirstlane(tstart_s[bptr + 1])) ++bptr;
+        p0 = __builtin_amdgcn_readfirstlane(bstart_s[bptr]) + 64 * (t - __builtin_amdgcn_readfirstlane(tstart_s[bptr]));
+        const int e = __builtin_amdgcn_readfirstlane(bstart_s[bptr + 1]) - p0;
+        cn = e < 64 ? e : 64;
+    };
+    // Off a tile's critical chain order -> bins -> x (three dependent HBM round trips): the point indices and previous labels of the next tile
+    // are fetched while this one is processed, and the x rows of the NEXT tile are touched -- one dword per 128-byte line, into two registers nothing
     // reads -- behind the last fragment request of this tile's evaluations: the next tile's gather, 1.5-2 k cycles later, finds the lines on
     // their way (sweep 1.10 -> 1.08 ms).  (Vector memory returns in order: touched one row block earlier the evaluations' last fragments queue
     // behind HBM, 1.09-1.11 ms; touched a whole tile ahead the lines are gone from L2 again -- 8 MB in flight per XCD against 4 -- 1.13 ms.  The
     // loads are inline asm into v254 / v255, which the kernel's register budget -- amdgpu_num_vgpr(254) -- keeps away from the allocator:
     // a register the compiler may move or reuse could be overwritten by a touch that returns later.  Its vmcnt bookkeeping does not see the
     // touches: every wait it emits is then for MORE loads than it thinks, never fewer.)
-    auto index_of = [&](int64_t t) -> int {
-        const int64_t p = t * 64 + lane;
-        return (t < nwtiles && p < A.n) ? (use_order ? A.order[p] : (int)p) : -1;
-    };
-    int nx_p = index_of(wave_id), nx2_p = index_of((int64_t)wave_id + nwaves);
+    auto index_at = [&](int p0, int cn) -> int { return lane < cn ? (use_order ? A.order[p0 + lane] : p0 + lane) : -1; };
+    int c_p0, c_cn, n_p0, n_cn;                              // spans of this tile and of the next one
+    span_of(wave_id, c_p0, c_cn);
+    span_of(wave_id + nwaves, n_p0, n_cn);
+    int nx_p = index_at(c_p0, c_cn);
     int nx_bin = nx_p >= 0 ? A.bins[nx_p] : -1;
     const int touch_second = A.ldx > 32 ? 32 : 0;           // (floats: the row's second 128-byte line, if it has one)
-    for (int64_t tile = wave_id; tile < nwtiles; tile += nwaves) {
-        const int64_t pos = tile * 64 + lane;
-        const bool valid = pos < A.n;
+    for (int tile = wave_id; tile < ntiles_all; tile += nwaves) {
+        const bool valid = lane < c_cn;
         const int myp32 = nx_p, binv = nx_bin;
         LSTAMP(s0);
 #ifdef DPMM_STAMPS
         unsigned long long s1 = s0, s2 = s0, s3 = s0, s4 = s0, s5 = s0;
 #endif
-        const int pf_p = nx2_p;                                  // the next tile's indices (here since the previous tile)
-        int pf_bin = pf_p >= 0 ? A.bins[pf_p] : -1;              // its previous labels
-        const int pf2_p = index_of(tile + 2 * (int64_t)nwaves);  // the indices of the tile after next
+        const int pf_p = index_at(n_p0, n_cn);                   // the next tile's indices
+        int pf_bin = -1;                                         // its previous labels: requested when the indices have arrived (with x)
         auto touch_x = [&]() {
-            if (tile + nwaves < nwtiles) {
+            if (n_cn > 0) {
                 const float *row = A.X + (int64_t)(pf_p >= 0 ? pf_p : 0) * A.ldx;
                 asm volatile("global_load_dword v254, %0, off\n\tglobal_load_dword v255, %1, off" :: "v"(row), "v"(row + touch_second) : "v254", "v255");
             }
@@ -462,7 +505,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void 
                 gather_x64(A.X, A.ldx, myp32, ci, g, x);
                 b3_mean(A.mup, k0, g, mk);
                 {
-                    const u32x4_t *F = reinterpret_cast<const u32x4_t *>(refb_records(A.tail, K) + (size_t)k0 * REFB_WORDS) + lane;
+                    const u32x4_t *F = reinterpret_cast<const u32x4_t *>(refb_records(A.tail, K) + (size_t)k0 * REFB_WORDS) + (unsigned)lane;
 #pragma unroll
                     for (int f = 0; f < 6; ++f) abr[f] = F[64 * f];
                 }
@@ -489,6 +532,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void 
                 for (int n = 0; n < 4; ++n) x3[n] = x[n][3];
                 b3_convert(x, mk, Z);                          // x's last use (but for x3)
             }
+            if (pf_p >= 0) pf_bin = A.bins[pf_p];              // the next tile's previous labels (its indices have arrived with x)
 #ifdef DPMM_STAMPS
             { LSTAMP(t2); s2 = t2; }
 #endif
@@ -505,7 +549,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void 
             for (int n = 0; n < 4; ++n) {
                 const float bn = __builtin_fmaf(-0.5f, qhi[n], c0);
                 if (g == n) my_best = bn;
-                thrb[n] = (tile * 64 + 16 * n + ci < A.n) ? bn - A.screen_margin : INFINITY;
+                thrb[n] = (16 * n + ci < c_cn) ? bn - A.screen_margin : INFINITY;
             }
             const float my_thr = valid ? my_best - A.screen_margin : INFINITY;
             BallWave ball; ball.ok = false;
@@ -551,7 +595,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void 
         { LSTAMP(t5); s5 = t5; }
 #endif
         if (hard) {
-            if (lane == 0) { const uint32_t at = atomicAdd(&list[0], 1u); list[1 + at] = (uint32_t)tile; }
+            if (lane == 0) { const uint32_t at = atomicAdd(&list[0], 1u); list[1 + 2 * at] = (uint32_t)c_p0; list[2 + 2 * at] = (uint32_t)c_cn; }
+            if (pf_p >= 0 && pf_bin < 0) pf_bin = A.bins[pf_p];        // (a tile that left before the bracket)
             touch_x();
         } else {
             float bl, br;
@@ -559,7 +604,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void 
             if (valid) A.bins[myp32] = 2 * k0 + draw2(bl, br, u_sub);
             ++nw_easy;
         }
-        nx_p = pf_p; nx_bin = pf_bin; nx2_p = pf2_p;
+        nx_p = pf_p; nx_bin = pf_bin;
+        c_p0 = n_p0; c_cn = n_cn;
+        span_of(tile + 2 * nwaves, n_p0, n_cn);
 #ifdef DPMM_STAMPS
         { LSTAMP(s6); T_x += s1 - s0; T_conv += s2 - s1; T_br += s3 - s2; T_scr += s4 - s3; T_u += s5 - s4; T_p2 += s6 - s5; T_tot += s6 - s0; ++ntl; }
 #endif
@@ -577,9 +624,10 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void 
     }
     if (need2 && lane == 0) need2[wave_id] = nw_easy < 65535u ? nw_easy : 65535u;      // tiles settled here (no candidates): the direction screen's statistics count them
 }
-hipError_t launch_niw_lean(const NiwSweepArgs &a, uint32_t *list, uint32_t *need2, uint32_t *other_list, int grid, hipStream_t s) {
+hipError_t launch_niw_lean(const NiwSweepArgs &a, uint32_t *list, uint32_t *need2, uint32_t *other_list, const int32_t *bin_start, int nbins, int grid, hipStream_t s) {
     if (!a.tail || a.n <= 0 || !list) return hipErrorInvalidValue;
-    DPMM_LAUNCH(niw_lean_kernel, dim3(grid), dim3(256), 0, s, a, list, need2, other_list);
+    if (nbins > NIW_LEAN_MAX_BINS) { bin_start = nullptr; nbins = 0; }
+    DPMM_LAUNCH(niw_lean_kernel, dim3(grid), dim3(256), 0, s, a, list, need2, other_list, bin_start, nbins);
     return hipGetLastError();
 }
 

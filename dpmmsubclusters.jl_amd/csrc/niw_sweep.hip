@@ -1169,18 +1169,27 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
     // the screens) the wave goes straight to the Float32 evaluation for the next eight tiles, then tries again
     int br_fail = 0, br_skip = 0;
     int tile0, tnext_v = -1;
-    int li = wave_id;                          // LSTORE with a list: this wave's position in it (static stride over the list)
+    // LSTORE with a list: entry i = (first position in the visiting order, number of positions <= 64) at tlist[1 + 2 i], tlist[2 + 2 i] -- the
+    // lean kernel's tiles are aligned to the bins of the sort, not to multiples of 64.  `tile` is then the entry's index (static stride over the
+    // list), l_pos / l_end the current entry's span; every validity test below compares with n_end (= A.n without a list).
+    int li = wave_id;
     const int lcount = (LSTORE && tlist) ? (int)tlist[0] : 0;
-    if (LSTORE && tlist) tile0 = li < lcount ? (int)tlist[1 + li] : -1;
+    const int tile_sent = (LSTORE && tlist) ? 0x7fffffff : nwtiles;      // "no further tile"
+    int l_pos = 0, l_end = 0;                  // (wave-uniform, positions < 2^31)
+    if (LSTORE && tlist) {
+        tile0 = li < lcount ? li : -1;
+        if (tile0 >= 0) { l_pos = __builtin_amdgcn_readfirstlane((int)tlist[1 + 2 * li]); l_end = l_pos + __builtin_amdgcn_readfirstlane((int)tlist[2 + 2 * li]); }
+    }
     else if (!dyn_ok) tile0 = wave_id < nwtiles ? wave_id : -1;
     else if (wave_id < dyn0) tile0 = wave_id;
     else { q_issue(); tile0 = q_take(); if (tile0 >= 0) q_issue(); }
     for (int tile = tile0; tile >= 0; tile = tnext_v) {
-        const int64_t wbase = (int64_t)tile * WPTS;
+        const int64_t wbase = (LSTORE && tlist) ? (int64_t)l_pos : (int64_t)tile * WPTS;
+        const int64_t n_end = (LSTORE && tlist) ? (int64_t)l_end : A.n;
         ++nw_tiles;
         STAMP(s0);
         const int64_t mypos = wbase + lane;    // position in processing order
-        const bool valid = owner && mypos < A.n;
+        const bool valid = owner && mypos < n_end;
         const bool prefetched = nx_tile == tile;
         const bool screening = FAST || (NB >= 2 && A.screen_margin > 0.f && !a_tdf && !A.scratch_by_tile && K > 1);
         int myp32, binv = -1;
@@ -1221,7 +1230,11 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
             }
         }
         int tnext;
-        if (LSTORE && tlist) { li += nwaves; tnext = li < lcount ? (int)tlist[1 + li] : nwtiles; }
+        int nl_pos = 0, nl_end = 0;
+        if (LSTORE && tlist) {
+            li += nwaves; tnext = li < lcount ? li : tile_sent;
+            if (li < lcount) { nl_pos = __builtin_amdgcn_readfirstlane((int)tlist[1 + 2 * li]); nl_end = nl_pos + __builtin_amdgcn_readfirstlane((int)tlist[2 + 2 * li]); }
+        }
         else if (!dyn_ok) tnext = tile + nwaves < nwtiles ? tile + nwaves : nwtiles;
         else if (tile + nwaves < dyn0) tnext = tile + nwaves;                        // static successor
         else {
@@ -1230,11 +1243,11 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
             if (tnext >= 0) q_issue();                                                // the tile after next, read one tile from now
             else tnext = nwtiles;
         }
-        tnext_v = tnext < nwtiles ? tnext : -1;
+        tnext_v = tnext < tile_sent ? tnext : -1;
         int pf_p = -1, pf_bin = -1;
-        if (tnext < nwtiles) {
-            const int64_t posn = (int64_t)tnext * WPTS + lane;
-            if (owner && posn < A.n) pf_p = use_order ? A.order[posn] : (int)posn;
+        if (tnext < tile_sent) {
+            const int64_t posn = ((LSTORE && tlist) ? (int64_t)nl_pos : (int64_t)tnext * WPTS) + lane;
+            if (owner && posn < ((LSTORE && tlist) ? (int64_t)nl_end : A.n)) pf_p = use_order ? A.order[posn] : (int)posn;
         }
 #ifdef DPMM_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1301,7 +1314,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
             // (the global-table draw of a screened tile visits evaluated clusters only as well: no -inf rows to write)
             bool pvalid[NG];
 #pragma unroll
-            for (int n = 0; n < NG; ++n) pvalid[n] = wbase + 16 * n + ci < A.n;
+            for (int n = 0; n < NG; ++n) pvalid[n] = wbase + 16 * n + ci < n_end;
             STAMP(qa);
             float bestn[NG];
 #pragma unroll
@@ -1772,7 +1785,8 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
         STAMP(s3);
         if constexpr (LSTORE) {
             if (valid) A.bins[myp] = 2 * z;       // the label; niw_sub_kernel draws the sub-label (its uniform is the point's own: recomputed there)
-            nx_p = pf_p; nx_bin = pf_bin; nx_tile = tnext < nwtiles ? tnext : -1;
+            nx_p = pf_p; nx_bin = pf_bin; nx_tile = tnext < tile_sent ? tnext : -1;
+            if (LSTORE && tlist) { l_pos = nl_pos; l_end = nl_end; }
             continue;
         }
 

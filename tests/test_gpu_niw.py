@@ -464,7 +464,8 @@ def test_reference_bracket_does_not_change_labels(pkg, D, sep, K):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     f1, f0 = out[1][1]["full_evals"], out[0][1]["full_evals"]
     print(f"D={D} sep={sep} K={K}: full evaluations per wave tile {f1 / out[1][1]['wave_tiles']:.2f} with the bracket, {f0 / out[0][1]['wave_tiles']:.2f} without")
-    assert f1 <= f0
+    # (per tile: with the lean launch the tiles are aligned to the sort's bins -- a few more, partly filled ones -- and it only runs with the bracket)
+    assert f1 / out[1][1]['wave_tiles'] <= f0 / out[0][1]['wave_tiles'] + 1e-9
     if sep >= 40.0 and D >= 33:                       # (D <= 32 has no bracket: the option changes nothing there)
         assert f1 < 0.8 * f0
 
