@@ -1079,10 +1079,13 @@ __device__ __forceinline__ void load_rb0(const float *__restrict__ Rm, const flo
 // STORES the labels (bins = 2 z; the sub-label bit is a placeholder) -- niw_sub_kernel draws the sub-labels of the same tiles in a launch of
 // its own.  The tiles come from a list (A.tdf re-used as `const uint32_t *`: [0] = count, [1 ..] = wave-tile indices; Student-t mode does
 // not exist in these instantiations) or, with a null list, from the usual schedule.
-template <int NB, int NG, int OCC, bool FAST = false, bool DIR = false, bool LSTORE = false>
+// LIST (with LSTORE): A.tdf names a list of spans to process instead of every tile -- an instantiation of its own, so that the all-tiles
+// LSTORE kernels do not carry the list's state (15 instead of 4 spilled registers, all-tiles sweep 1.53 -> 1.64 ms when they did)
+template <int NB, int NG, int OCC, bool FAST = false, bool DIR = false, bool LSTORE = false, bool LIST = false>
 __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs A) {
     const float *const a_tdf = LSTORE ? nullptr : A.tdf;
-    const uint32_t *const tlist = LSTORE ? reinterpret_cast<const uint32_t *>(A.tdf) : nullptr;
+    static_assert(!LIST || LSTORE, "a list belongs to the label-storing instantiations");
+    const uint32_t *const tlist = LIST ? reinterpret_cast<const uint32_t *>(A.tdf) : nullptr;
 #ifdef DPMM_STAMPS
     unsigned long long T_x = 0, T_quad = 0, T_epi = 0, T_draw = 0, T_p2 = 0, T_tot = 0, N_scr = 0, N_tail = 0, T_prep = 0, T_far = 0, T_surv = 0, T_init = 0, T_i1 = 0, T_i2 = 0, T_lastd = 0, T_long = 0, T_longat = 0, T_firstd = 0; int ntile = 0;
 #endif
@@ -1173,10 +1176,10 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
     // lean kernel's tiles are aligned to the bins of the sort, not to multiples of 64.  `tile` is then the entry's index (static stride over the
     // list), l_pos / l_end the current entry's span; every validity test below compares with n_end (= A.n without a list).
     int li = wave_id;
-    const int lcount = (LSTORE && tlist) ? (int)tlist[0] : 0;
-    const int tile_sent = (LSTORE && tlist) ? 0x7fffffff : nwtiles;      // "no further tile"
+    const int lcount = LIST ? (int)tlist[0] : 0;
+    const int tile_sent = LIST ? 0x7fffffff : nwtiles;      // "no further tile"
     int l_pos = 0, l_end = 0;                  // (wave-uniform, positions < 2^31)
-    if (LSTORE && tlist) {
+    if (LIST) {
         tile0 = li < lcount ? li : -1;
         if (tile0 >= 0) { l_pos = __builtin_amdgcn_readfirstlane((int)tlist[1 + 2 * li]); l_end = l_pos + __builtin_amdgcn_readfirstlane((int)tlist[2 + 2 * li]); }
     }
@@ -1184,8 +1187,8 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
     else if (wave_id < dyn0) tile0 = wave_id;
     else { q_issue(); tile0 = q_take(); if (tile0 >= 0) q_issue(); }
     for (int tile = tile0; tile >= 0; tile = tnext_v) {
-        const int64_t wbase = (LSTORE && tlist) ? (int64_t)l_pos : (int64_t)tile * WPTS;
-        const int64_t n_end = (LSTORE && tlist) ? (int64_t)l_end : A.n;
+        const int64_t wbase = LIST ? (int64_t)l_pos : (int64_t)tile * WPTS;
+        const int64_t n_end = LIST ? (int64_t)l_end : A.n;
         ++nw_tiles;
         STAMP(s0);
         const int64_t mypos = wbase + lane;    // position in processing order
@@ -1231,7 +1234,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
         }
         int tnext;
         int nl_pos = 0, nl_end = 0;
-        if (LSTORE && tlist) {
+        if (LIST) {
             li += nwaves; tnext = li < lcount ? li : tile_sent;
             if (li < lcount) { nl_pos = __builtin_amdgcn_readfirstlane((int)tlist[1 + 2 * li]); nl_end = nl_pos + __builtin_amdgcn_readfirstlane((int)tlist[2 + 2 * li]); }
         }
@@ -1246,8 +1249,8 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
         tnext_v = tnext < tile_sent ? tnext : -1;
         int pf_p = -1, pf_bin = -1;
         if (tnext < tile_sent) {
-            const int64_t posn = ((LSTORE && tlist) ? (int64_t)nl_pos : (int64_t)tnext * WPTS) + lane;
-            if (owner && posn < ((LSTORE && tlist) ? (int64_t)nl_end : A.n)) pf_p = use_order ? A.order[posn] : (int)posn;
+            const int64_t posn = (LIST ? (int64_t)nl_pos : (int64_t)tnext * WPTS) + lane;
+            if (owner && posn < (LIST ? (int64_t)nl_end : A.n)) pf_p = use_order ? A.order[posn] : (int)posn;
         }
 #ifdef DPMM_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1786,7 +1789,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
         if constexpr (LSTORE) {
             if (valid) A.bins[myp] = 2 * z;       // the label; niw_sub_kernel draws the sub-label (its uniform is the point's own: recomputed there)
             nx_p = pf_p; nx_bin = pf_bin; nx_tile = tnext < tile_sent ? tnext : -1;
-            if (LSTORE && tlist) { l_pos = nl_pos; l_end = nl_end; }
+            if (LIST) { l_pos = nl_pos; l_end = nl_end; }
             continue;
         }
 
@@ -1879,7 +1882,14 @@ static hipError_t launch_direct(const NiwSweepArgs &a, int grid, hipStream_t s) 
                 hipFuncSetAttribute((const void *)niw_sweep_direct_kernel<NB, NG, OCC, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / OCC);
                 hipFuncSetAttribute((const void *)niw_sweep_direct_kernel<NB, NG, OCC, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / OCC);
                 hipFuncSetAttribute((const void *)niw_sweep_direct_kernel<NB, NG, OCC, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / OCC);
+                hipFuncSetAttribute((const void *)niw_sweep_direct_kernel<NB, NG, OCC, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / OCC);
+                hipFuncSetAttribute((const void *)niw_sweep_direct_kernel<NB, NG, OCC, true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / OCC);
                 attr_ls = true;
+            }
+            if (b.tdf != nullptr) {             // a list of spans (behind niw_lean_kernel: a few dozen tiles): no direction-screen instantiation for it
+                if (fast) DPMM_LAUNCH((niw_sweep_direct_kernel<NB, NG, OCC, true, false, true, true>), dim3(grid), dim3(256), lds_bytes, s, b);
+                else DPMM_LAUNCH((niw_sweep_direct_kernel<NB, NG, OCC, false, false, true, true>), dim3(grid), dim3(256), lds_bytes, s, b);
+                return hipGetLastError();
             }
             if (fast && b.sp_frag && b.sp_cons && b.bf16scr && b.K <= SP_MAXK) DPMM_LAUNCH((niw_sweep_direct_kernel<NB, NG, OCC, true, true, true>), dim3(grid), dim3(256), lds_bytes, s, b);
             else if (fast) DPMM_LAUNCH((niw_sweep_direct_kernel<NB, NG, OCC, true, false, true>), dim3(grid), dim3(256), lds_bytes, s, b);
