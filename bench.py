@@ -19,8 +19,8 @@ and exits with the child's code; under the driver's launcher it finds WORLD_SIZE
 size is not `--gpus` is an error, never a silent 1-GPU bench.  Prints ONE JSON line on rank 0.
 
 Besides the contract fields the JSON line carries
-  roofline      the NIW sweep (for 33 <= D <= 64 three launches: niw_lean_kernel, which finishes the tiles its screens settle and
-                dominates, niw_sweep_direct_kernel<LSTORE> and niw_sub_kernel on the tiles it hands on; `launches_ms` splits the time)
+  roofline      the NIW sweep (for 33 <= D <= 64 two launches: niw_lean_kernel, which finishes the tiles its screens settle and
+                dominates, and niw_sweep_direct_kernel<LSTORE,LIST> on the spans it hands on; `launches_ms` splits the time)
                 against the matrix pipe: `achieved` = ALGORITHMIC Float32 flops / live duration of the sweep's launches (exceeds the
                 Float32 peak because exact cluster screening skips work), `frac` = share of the pipe's time the EXECUTED matrix
                 instructions stand for (Float32 ones against the Float32 peak + bf16 ones against the bf16 peak), counted ON THE
@@ -347,7 +347,8 @@ SWEEP_KERNELS_64 = ("niw_lean_kernel", "niw_sweep_direct_kernel", "niw_sub_kerne
 
 def sweep_kernel_names(D):
     """The launches of one NIW sweep.  33 <= D <= 64: niw_lean_kernel (every tile; finishes the tiles whose label candidates the
-    screens settle), niw_sweep_direct_kernel<..., LSTORE> (labels of the tiles it handed on) and niw_sub_kernel (their sub-labels);
+    screens settle) and niw_sweep_direct_kernel<..., LSTORE, LIST> (labels and sub-labels of the spans it handed on); without the lean
+    launch (overlapping clusters, K > 64) niw_sweep_direct_kernel<..., LSTORE> (labels) and niw_sub_kernel (sub-labels) on every tile;
     D <= 32: niw_sweep_direct_kernel alone; D > 64: niw_sweep_kernel (behind its bracket launch)."""
     return "+".join(SWEEP_KERNELS_64) if 32 < D <= 64 else ("niw_sweep_direct_kernel" if D <= 32 else "niw_sweep_kernel")
 
@@ -620,8 +621,9 @@ def main():
             "f32_frac": exe / (avg_sweep_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
             "bf16_frac": exe_bf16 / (avg_sweep_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, "peak_bf16": PEAK_BF16_MFMA_TFLOPS,
             "executed_bf16_flops_per_launch": exe_bf16,
-            "launches_ms": {"niw_lean_kernel": float(pm[0]), "niw_sweep_direct_kernel<LSTORE> (labels of the tiles handed on)": float(pm[1]),
-                            "niw_sub_kernel (their sub-labels)": float(pm[2]),
+            "launches_ms": {"niw_lean_kernel": float(pm[0]),
+                            "niw_sweep_direct_kernel<LSTORE,LIST> (labels and sub-labels of the spans handed on)": float(pm[1]),
+                            "niw_sub_kernel (every tile's sub-labels: only in sweeps without the lean launch)": float(pm[2]),
                             "note": "HIP events between the launches of one sweep, recorded in the second block (timing bit 8); "
                                     "avg_launch_ms is the sweep's events of the headline block"},
             "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": 4.0 * n_local * D + 4.0 * n_local,

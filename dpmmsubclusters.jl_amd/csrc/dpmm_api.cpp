@@ -1243,12 +1243,15 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
             }
             a.bf16scr |= 4;
             a.tdf = reinterpret_cast<const float *>(list);                         // (the LSTORE instantiations' tile list: null = all tiles)
+            const float *mdist_kept = a.mdist;
+            if (list) a.mdist = reinterpret_cast<const float *>(c->h_hard);        // (LIST instantiations: where the list's length goes; they also finish the spans' sub-labels)
             HIPCHK(c, launch_niw_sweep(c->NB, a, c->sweep_grid, c->stream));
+            a.mdist = mdist_kept;
             if (parts) HIPCHK(c, hipEventRecord(c->ev_part[1], c->stream));
             c->have_parts = parts ? (use_lean ? 2 : 1) : 0;
             a.bf16scr &= 3;
             a.tdf = nullptr;
-            HIPCHK(c, launch_niw_sub(a, list, list ? c->h_hard : nullptr, c->sweep_grid, c->stream));
+            if (!list) HIPCHK(c, launch_niw_sub(a, nullptr, nullptr, c->sweep_grid, c->stream));      // (every tile; a list's spans were finished by the LIST launch)
         } else
         HIPCHK(c, launch_niw_sweep(c->NB, a, c->sweep_grid, c->stream));
     } else {

@@ -36,6 +36,7 @@
 #include "dpmm_device.h"
 #include "dpmm_kernels.h"
 #include "niw_device.h"
+#include "niw_b3.h"
 #include <cstdlib>
 #include <cstring>
 
@@ -1140,6 +1141,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
     int nx_p = -1, nx_bin = -1;
     int nx_tile = -1;
     unsigned nw_tiles = 0, nw_full = 0, nw_scr = 0, nw_tail = 0, nw_br = 0, nw_bb = 0, nw_bt = 0;   // executed-work counters of this wave (wave-uniform); nw_bb / nw_bt: bf16 bottom / top screens
+    unsigned nw_b3l = 0;                      // LIST: three-plane sub-cluster evaluations (the high half of work slot 7, as niw_lean.hip's kernels count them)
     unsigned nw_sp = 0, nw_cand = 0;          // direction screens run (DIR); candidates behind the 4-row tests (DIR: counted; else = nw_bb, every one gets a bottom screen)
     unsigned nw_dcand = 0, nw_dexcl = 0;      // DIR: candidates the direction screens were given, and how many of them they removed (the screen's yield)
     const int rounds_all = nwtiles / nwaves;
@@ -1178,6 +1180,9 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
     int li = wave_id;
     const int lcount = LIST ? (int)tlist[0] : 0;
     const int tile_sent = LIST ? 0x7fffffff : nwtiles;      // "no further tile"
+    // (the list's length for the host's regime decision: A.mdist -- the pre-screen's table, never read when a list is walked (lam == nullptr) --
+    // carries a pinned word for it; a field of its own would move every instantiation's scalars)
+    if constexpr (LIST) { if (A.mdist && blockIdx.x == 0 && tid == 0) *reinterpret_cast<uint32_t *>(const_cast<float *>(A.mdist)) = tlist[0]; }
     int l_pos = 0, l_end = 0;                  // (wave-uniform, positions < 2^31)
     if (LIST) {
         tile0 = li < lcount ? li : -1;
@@ -1786,6 +1791,34 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
         }
         if (!FAST && A.labels_only) continue;
         STAMP(s3);
+        if constexpr (LIST) {
+            // A span handed on by niw_lean_kernel is finished HERE: the sub-labels of the labels just drawn, by the three-plane evaluation on
+            // the x this wave still holds (b3_eval, niw_b3.h: the same device functions, operands and order as niw_sub_kernel -- the same
+            // bits) -- one launch for the handed-on spans instead of two.  (This instantiation runs a few spans per sweep: its registers do not
+            // matter.)
+            if constexpr (NB == 4 && NG == 4) {
+                float b0 = -INFINITY, b1 = -INFINITY;
+                unsigned long long todo = __ballot(valid);
+                while (todo) {
+                    const int leader = __ffsll((long long)todo) - 1;
+                    const int kk = __builtin_amdgcn_readfirstlane(__shfl(z, leader));
+                    todo &= ~__ballot(valid && z == kk);
+                    f32x4 mk[4];
+                    b3_mean(A.mup, kk, g, mk);
+                    const B3Head H = b3_head(A.tail, A.cst, K, kk, lane, g);
+                    B3Z Z;
+                    b3_convert(x, mk, Z);
+                    float bl, br;
+                    b3_eval(A.tail, K, kk, Z, H, lane, g, bl, br);
+                    if (z == kk) { b0 = bl; b1 = br; }
+                    nw_b3l += 2;
+                }
+                if (valid) A.bins[myp] = 2 * z + draw2(b0, b1, u_sub);
+            }
+            nx_p = pf_p; nx_bin = pf_bin; nx_tile = tnext < tile_sent ? tnext : -1;
+            l_pos = nl_pos; l_end = nl_end;
+            continue;
+        }
         if constexpr (LSTORE) {
             if (valid) A.bins[myp] = 2 * z;       // the label; niw_sub_kernel draws the sub-label (its uniform is the point's own: recomputed there)
             nx_p = pf_p; nx_bin = pf_bin; nx_tile = tnext < tile_sent ? tnext : -1;
@@ -1832,6 +1865,7 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
     if (A.work && lane == 0) {      // one slot per wave, no atomics (see the LDS-staged kernel)
         unsigned long long *slot = A.work + DPMM_WORK_SLOTS + (size_t)wave_id * DPMM_WORK_PER_WAVE;      // (accumulates over launches; cleared by the reader)
         slot[0] += nw_tiles; slot[1] += nw_full; slot[2] += nw_scr; slot[3] += nw_tail; slot[4] += nw_br; slot[5] += nw_bb; slot[6] += nw_bt; slot[7] += nw_sp;
+        if constexpr (LIST) slot[7] += (unsigned long long)nw_b3l << 32;
     }
     if (A.need && lane == 0) {                // (this launch only: plain store into the host's pinned block)
         const unsigned nc = DIR ? nw_cand : nw_bb;

@@ -93,8 +93,9 @@ enum {
                                          phase.  0: the Float32 chain inside the sweep kernel.  dpmm_debug_subloglik follows the setting.  Takes effect with the next
                                          parameter set. */
     DPMM_OPT_LEAN_TILES = 27,         /* 1 (default; with DPMM_OPT_B3_SUBLABELS): tiles whose points all had one label and for which the reference bracket, the ball test and the
-                                         4-row tail screens exclude every other cluster are finished -- label and sub-labels -- by niw_lean_kernel; the rest goes through the sweep
-                                         kernel (labels) and niw_sub_kernel (sub-labels).  Same labels and sub-labels either way.  0: every tile takes the second route.
+                                         4-row tail screens exclude every other cluster are finished -- label and sub-labels -- by niw_lean_kernel (its tiles aligned to the
+                                         bins of the last sort); what it hands on is finished by one launch of the sweep kernel.  Same labels and sub-labels either way.
+                                         0: every tile through the sweep kernel (labels) and niw_sub_kernel (sub-labels).
                                          A sweep that hands on more than 30 % of its tiles switches the lean launch off for 15 sweeps (31, 63, ... up to 1023 while the
                                          retries keep failing); it also stays off while the direction screen's regime is on and beyond 64 clusters (scalar pre-screen). */
     DPMM_OPT_MULT_DRAWS_AHEAD = 25,   /* 1 (default): Multinomial device master: dpmm_step_stats launches the NEXT Dirichlet draws and their hand-over images

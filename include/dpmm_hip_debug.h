@@ -46,9 +46,11 @@ int dpmm_debug_mult_draws_ahead(dpmm_ctx *ctx, long long *used);
  * dpmm_suffstats_* call, measured with HIP events on the ctx stream (0 if none yet, or when DPMM_OPT_KERNEL_TIMING is off -- the default).
  * Calling this waits for the measured kernels (the closing event of each pair), not for later work on the stream. */
 int dpmm_last_kernel_ms(dpmm_ctx *ctx, float *sweep_ms, float *suffstats_ms);
-/* D in 33..64 with the bf16 sub-label evaluation active (DPMM_OPT_B3_SUBLABELS): a sweep is up to three launches -- niw_lean_kernel (tiles the cheap
- * screens settle), the sweep kernel in its labels-only form (the rest), niw_sub_kernel (their sub-labels).  With DPMM_OPT_KERNEL_TIMING bits 0 and 3
- * set: out3 = milliseconds of the three parts of the last dpmm_sweep (0 for a part that did not run; all 0 for any other kind of sweep). */
+/* D in 33..64 with the bf16 sub-label evaluation active (DPMM_OPT_B3_SUBLABELS): a sweep is niw_lean_kernel (tiles the cheap screens settle) + the
+ * sweep kernel on the spans it hands on (labels and sub-labels in one launch), or -- without the lean launch -- the sweep kernel in its labels-only
+ * form + niw_sub_kernel on every tile.  With DPMM_OPT_KERNEL_TIMING bits 0 and 3 set: out3 = milliseconds of {lean launch, sweep-kernel launch,
+ * what follows it up to the end of the sweep (niw_sub_kernel, if it ran)} of the last dpmm_sweep (0 for a part that did not run; all 0 for any other
+ * kind of sweep). */
 int dpmm_last_sweep_parts_ms(dpmm_ctx *ctx, float *out3);
 /* Work the dpmm_sweep calls (NIW) since the previous call really executed, counted on the device (a slot per wave, no atomics):
  *   TOTALS over out16[7] launches of: out16[0] wave tiles, [1] full quadratic-form evaluations (per wave), [2] Float32 16-row MFMA screens
