@@ -678,9 +678,9 @@ def test_bf16_screens_do_not_change_labels(pkg, D, sep, K):
 @pytest.mark.parametrize("D,sep,K,n", [(64, 40.0, 7, 30000), (64, 40.0, 5, 200037), (60, 30.0, 9, 50001), (64, 2.0, 12, 30011), (64, 0.8, 7, 20000), (52, 2.0, 7, 30000),
                                        (36, 3.0, 9, 9999), (64, 1.5, 100, 30000), (64, 40.0, 300, 120000), (64, 6.0, 1, 5000)])
 def test_lean_tiles_do_not_change_labels(pkg, D, sep, K, n):
-    """D in 33 .. 64: the sweep runs as niw_lean_kernel (finishes the tiles whose label candidates its screens settle, hands the others on
-    through a tile list) + niw_sweep_direct_kernel<LSTORE> (labels of the listed tiles) + niw_sub_kernel (their sub-labels); with
-    DPMM_OPT_LEAN_TILES = 0 the last two do every tile.  Which launch finishes a tile must not show: labels AND sub-labels bit-equal over a
+    """D in 33 .. 64: the sweep runs as niw_lean_kernel (finishes the tiles whose label candidates its screens settle -- tiles aligned to the bins
+    of the sort --, hands the others on as a list of spans) + niw_sweep_direct_kernel<LSTORE, LIST> (labels and sub-labels of the listed spans);
+    with DPMM_OPT_LEAN_TILES = 0 niw_sweep_direct_kernel<LSTORE> (labels) + niw_sub_kernel (sub-labels) do every tile.  Which launch finishes a tile must not show: labels AND sub-labels bit-equal over a
     chain of sweeps (every sub-cluster value is the bf16 three-plane one in both), on separated clusters (nearly every tile settled in the lean
     launch), overlapping ones (most handed on; the regime switch turns the lean launch off), padded D, a ragged last tile and K = 1.  With the
     lean launch on, the labels are the oracle's draw on the kernel's own table and the sub-labels its draw on the kernel's own sub-cluster
