@@ -1087,6 +1087,15 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
     const float *const a_tdf = LSTORE ? nullptr : A.tdf;
     static_assert(!LIST || LSTORE, "a list belongs to the label-storing instantiations");
     const uint32_t *const tlist = LIST ? reinterpret_cast<const uint32_t *>(A.tdf) : nullptr;
+    if constexpr (LIST) {
+        // most sweeps hand on nothing (and a workgroup whose four waves are beyond the list has nothing to do either): leave before the staging below;
+        // the list's length still goes to the host (A.mdist: see further down)
+        const uint32_t lc = tlist[0];
+        if (lc == 0u || blockIdx.x * 4u >= lc) {
+            if (A.mdist && blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<uint32_t *>(const_cast<float *>(A.mdist)) = lc;
+            return;
+        }
+    }
 #ifdef DPMM_STAMPS
     unsigned long long T_x = 0, T_quad = 0, T_epi = 0, T_draw = 0, T_p2 = 0, T_tot = 0, N_scr = 0, N_tail = 0, T_prep = 0, T_far = 0, T_surv = 0, T_init = 0, T_i1 = 0, T_i2 = 0, T_lastd = 0, T_long = 0, T_longat = 0, T_firstd = 0; int ntile = 0;
 #endif
