@@ -1,3 +1,4 @@
+"""Dev helper: the headline, roofline and legs of a bench.py line at a glance.   python3 scripts/show_bench.py <file with the JSON line>"""
 import json,sys
 d=json.loads(open(sys.argv[1]).readline())
 print(d['value'], d['ms_per_step'], d['blocks'])
