@@ -719,6 +719,54 @@ def test_lean_tiles_do_not_change_labels(pkg, D, sep, K, n):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
+def test_lean_tiles_behind_whole_bin_relabels(pkg):
+    """niw_lean_kernel aligns its tiles to the bins of the LAST sort; between that sort and the sweep the master relabels whole bins: a split moves
+    (k, right) to a new cluster K + 1 (local_clusters_actions.jl:265-278), a merge folds cluster b into a (:293-304), remove-empty renumbers
+    (:446-455).  The sort's bin table is then stale -- more clusters than it has bins, bins whose points carry another label -- but every tile
+    still holds one label, and the sweep must be the sweep without the lean launch, bit for bit: labels and sub-labels of two sweeps after each
+    kind of relabel."""
+    from dpmmsubclusters_jl_amd import binding
+    D, n, K = 64, 40000 + 9, 6
+    P = make_problem(D, n, K + 2, seed=303, sep=25.0, sorted_points=True)     # parameters for up to K + 2 clusters
+    def params(wk, k):
+        wk.set_params_niw(P["mu"][:3 * k], P["invS"][:3 * k], P["logdet"][:3 * k], P["lr"][:k], (P["w"][:k] / P["w"][:k].sum()).astype(np.float32))
+    out = {}
+    for on in (1, 0):
+        wk = pkg.Worker(pkg.PRIOR_NIW, D, n, first_index=0, device=0, seed=41)
+        wk.upload_points(P["X"])
+        wk.set_option(binding.OPT_LEAN_TILES, on)
+        wk.set_timing(15)
+        params(wk, K)
+        z0 = np.minimum(P["z"], K - 1) + 1
+        wk.set_labels(z0, 1 + (np.arange(n) // 7 & 1))
+        labs, ran = [], []
+        def two_sweeps(k, ep):
+            for e in (ep, ep + 1):
+                wk.suffstats_packed(None) if e == ep + 1 else None
+                params(wk, k)
+                wk.sweep(e)
+                labs.append(wk.get_labels())
+                ran.append(wk.last_sweep_parts_ms()[0] > 0.0)
+        wk.suffstats_packed(None)                      # the sort: 2 K bins
+        wk.split([2, 5], [K + 1, K + 2], epoch=3)      # (2, right) -> cluster 7, (5, right) -> cluster 8: the table knows 12 bins, the labels 8 clusters
+        two_sweeps(K + 2, 10)
+        wk.suffstats_packed(None)
+        wk.merge([1], [7])                             # cluster 7 folded into 1
+        two_sweeps(K + 2, 20)
+        wk.suffstats_packed(None)
+        lab = wk.get_labels()[0]
+        cnt = np.bincount(lab, minlength=K + 3)[1:K + 3]
+        if (cnt == 0).any():
+            wk.remove_empty(cnt)
+            two_sweeps(int((cnt > 0).sum()), 30)
+        assert any(ran) == bool(on)
+        out[on] = labs
+        wk.close()
+    assert len(out[1]) == len(out[0]) >= 4
+    for a, b in zip(out[1], out[0]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
 def test_lean_tile_lists_take_turns(pkg):
     """Two tile lists alternate between the sweeps that run the lean launch (a lean launch clears the OTHER list's counter for its successor, the
     sub-label launch reports the length to the host): a chain in which the lean launch is switched on and off between sweeps -- a list is reused
