@@ -132,27 +132,39 @@ def kernel_source_tag():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(which, kernel_substr):
+def pmc_traffic(which, kernel_substr, allow_stale=False):
     """HBM bytes per launch of a kernel from profiles/latest_<which>_pmc_summary.json (written by scripts/collect_profiles.sh together
     with the hash of the kernel sources it profiled): 2 x FETCH_SIZE (the gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE, KiB.
-    None when the file is missing or was collected on other kernel sources."""
+    (None, why) when the file is missing or was collected on other kernel sources -- unless allow_stale: then the figure is returned
+    with a source text that says on which sources it was collected (the caller reports `traffic_is_current: false` beside it)."""
     f = os.path.join(ROOT, "profiles", f"latest_{which}_pmc_summary.json")
     try:
         pm = json.load(open(f))
         meta = pm.get("_meta", {})
-        if meta.get("kernel_source_tag") != kernel_source_tag():
-            return None, f"profiles/latest_{which}_pmc_summary.json is stale (collected on kernel sources {meta.get('kernel_source_tag')})"
+        stale = meta.get("kernel_source_tag") != kernel_source_tag()
+        why = f"profiles/latest_{which}_pmc_summary.json is stale (collected on kernel sources {meta.get('kernel_source_tag')})"
+        if stale and not allow_stale:
+            return None, why
         subs = (kernel_substr,) if isinstance(kernel_substr, str) else tuple(kernel_substr)
         tot, hit = 0.0, 0
         for name, c in pm.items():
             if name != "_meta" and any(k in name for k in subs) and "FETCH_SIZE" in c:
                 tot += (2.0 * c["FETCH_SIZE"]["median"] + c["WRITE_SIZE"]["median"]) * 1024.0; hit += 1
         if hit:
-            return tot, (f"profiles/latest_{which}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, median per launch, "
-                         f"summed over the {hit} kernel(s) of the sweep; {meta.get('collected', '')})")
+            return tot, ((why + "; ") if stale else "") + (
+                f"profiles/latest_{which}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, median per launch, "
+                f"summed over the {hit} kernel(s) of the sweep; {meta.get('collected', '')})")
     except (OSError, ValueError, KeyError):
         pass
     return None, None
+
+
+def pmc_is_current(which):
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", f"latest_{which}_pmc_summary.json")))
+        return pm.get("_meta", {}).get("kernel_source_tag") == kernel_source_tag()
+    except (OSError, ValueError):
+        return False
 
 
 def pmc_matrix_pipe(which, kernel_substr, launch_ms):
@@ -366,7 +378,8 @@ def niw_roofline(n, D, k_mean, sweep_ms, work):
     return {"kernel": sweep_kernel_names(D), "bound": "mfma",
             "achieved": flops_alg / (sweep_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": pipe_frac(work, sweep_ms), "f32_frac": exe / (sweep_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-            "traffic": None, "avg_launch_ms": sweep_ms,
+            "traffic": None, "avg_launch_ms": sweep_ms, "algorithmic_bytes_per_launch": (4.0 * D + 4.0) * n,
+            "hbm_frac": (4.0 * D + 4.0) * n / (sweep_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
             "algorithmic_flops_per_launch": flops_alg, "executed_flops_per_launch": exe, "executed_bf16_flops_per_launch": work["bf16_flops"],
             "pruning_factor": flops_alg / exe if exe else None, "b3_evals_per_wave_tile": work.get("b3_evals", 0.0) / max(1.0, work["wave_tiles"]),
             "full_evals_per_wave_tile": work["full_evals"] / max(1.0, work["wave_tiles"]),
@@ -420,6 +433,8 @@ def run_legs(args, pkg, host, torch, one_gpu_ms):
         r, work = steady_state(pkg, host, torch, pkg.PRIOR_NIW, niw64, X, y, K, 100, settle=60)
         r["workload"] = "what each of 8 GPUs holds of the headline: NIW D=64, n=1.25e6, K=32, one GPU, no collective"
         r["roofline"] = niw_roofline(n, D, r["K_t"], r["sweep_kernel_ms"], work)
+        tr, src = pmc_traffic("shard", SWEEP_KERNELS_64, allow_stale=True)
+        r["roofline"].update({"traffic": tr, "traffic_source": src, "traffic_is_current": pmc_is_current("shard") if tr else None})
         legs["c3_shard"] = r
         # 1 -> 8 projection.  A rank of the 8-GPU run does this step in the ONE-COLLECTIVE form of the per-step pass (speculative reset, 3K
         # rows through one all-reduce, finalize kernel: dpmm_api.cpp run_stats) plus that all-reduce over xGMI.  The form is measured here
@@ -461,12 +476,12 @@ def run_legs(args, pkg, host, torch, one_gpu_ms):
         bytes_u8 = float(n) * (ld8 + 12.0)
         t_sweep = r["sweep_kernel_ms"] * 1e-3
         t = (r["sweep_kernel_ms"] + r["stats_kernels_ms"]) * 1e-3
-        tr_sweep, src = pmc_traffic("mult", "mult_sweep")
-        tr_stats, _ = pmc_traffic("mult", "mult_stats")
+        tr_sweep, src = pmc_traffic("mult", "mult_sweep", allow_stale=True)
+        tr_stats, _ = pmc_traffic("mult", "mult_stats", allow_stale=True)
         r["roofline"] = {"kernel": "mult_sweep_u8_kernel", "bound": "hbm",
                          "achieved": bytes_u8 / t_sweep / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": bytes_u8 / t_sweep / 1e9 / PEAK_HBM_GBPS,
                          "algorithmic_bytes_per_launch": bytes_u8, "avg_launch_ms": r["sweep_kernel_ms"],
-                         "traffic": tr_sweep, "traffic_source": src,
+                         "traffic": tr_sweep, "traffic_source": src, "traffic_is_current": pmc_is_current("mult") if tr_sweep else None,
                          "traffic_frac": (tr_sweep / t_sweep / 1e9 / PEAK_HBM_GBPS) if tr_sweep else None,
                          "pass_traffic": (tr_sweep + tr_stats) if (tr_sweep and tr_stats) else None,
                          "pass_traffic_frac": ((tr_sweep + tr_stats) / t / 1e9 / PEAK_HBM_GBPS) if (tr_sweep and tr_stats) else None,
@@ -482,10 +497,66 @@ def run_legs(args, pkg, host, torch, one_gpu_ms):
         r, work = steady_state(pkg, host, torch, pkg.PRIOR_NIW, prior, X, y, K, 30)
         r["workload"] = "what each of 8 GPUs holds of C5: NIW D=256, n=6.25e5, K=32, one GPU, no collective"
         r["roofline"] = niw_roofline(n, Dh, r["K_t"], r["sweep_kernel_ms"], work)
+        tr, src = pmc_traffic("d256", ("niw_sweep_kernel", "niw_bracket_big_kernel"), allow_stale=True)
+        r["roofline"].update({"traffic": tr, "traffic_source": src, "traffic_is_current": pmc_is_current("d256") if tr else None})
         legs["c5_shard"] = r
         del X
         torch.cuda.empty_cache()
     return legs
+
+COMPACT_LIMIT = 4096          # bytes of the ONE stdout line (the driver keeps an 8 KB tail and parses the last line)
+
+
+def compact_line(out):
+    """The ONE JSON line of the contract (last line of stdout), < 4 KB whatever the run measured: the contract fields, `config`
+    (workload, master, also_measured: scalars only), `roofline` of the dominant kernel and `cpu_baseline`.  Everything else the run
+    measured (legs, growth history, host-master block, comm, blocks, the full roofline with its definitions) is `bench_details.json`
+    beside this file and a dump on stderr.  Round 5's line had grown to 20 KB and the driver could not parse it."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: out[k] for k in keep if k in out}
+    cfg = out.get("config", {})
+    line["config"] = {k: cfg[k] for k in ("workload", "points_per_gpu", "parallelism", "master", "worker_options_overridden", "also_measured") if cfg.get(k) is not None}
+    r = out.get("roofline", {})
+    rk = ("kernel", "bound", "achieved", "peak", "unit", "frac", "hbm_frac", "traffic", "traffic_frac", "traffic_is_current", "algorithmic_bytes_per_launch",
+          "avg_launch_ms", "lean_kernel_ms", "mfma_pipe_frac", "pmc_frac", "mfma_busy", "dense_f32_frac", "dense_launch_ms", "pruning_factor", "stats_kernels_ms")
+    line["roofline"] = {k: r[k] for k in rk if r.get(k) is not None or k == "traffic"}
+    c = out.get("cpu_baseline")
+    if c is not None:
+        line["cpu_baseline"] = {k: c[k] for k in ("value", "unit", "cores", "kind", "sample", "cpu_model", "julia_found") if k in c}
+    line["details"] = "bench_details.json (written beside bench.py; also dumped on stderr)"
+
+    def rnd(o):
+        if isinstance(o, float):
+            return float(f"{o:.5g}")
+        if isinstance(o, dict):
+            return {k: rnd(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [rnd(v) for v in o]
+        return o
+    line = rnd(line)
+    line["value"] = out["value"]; line["ms_per_step"] = out["ms_per_step"]     # the headline itself at full precision
+    txt = json.dumps(line, separators=(",", ":"))
+    if len(txt) > COMPACT_LIMIT:          # never let prose push the line over: drop the optional texts, longest first
+        for path in (("config", "master"), ("cpu_baseline", "sample"), ("config", "parallelism")):
+            d = line.get(path[0], {})
+            if path[1] in d and len(txt) > COMPACT_LIMIT:
+                d[path[1]] = str(d[path[1]])[:160]
+                txt = json.dumps(line, separators=(",", ":"))
+    assert len(txt) <= COMPACT_LIMIT and "\n" not in txt, len(txt)
+    return txt
+
+
+def emit(out):
+    """Write the full record to bench_details.json + stderr, then the compact contract line as the LAST line of stdout."""
+    full = json.dumps(out)
+    try:
+        with open(os.path.join(ROOT, "bench_details.json"), "w") as f:
+            f.write(full + "\n")
+    except OSError as e:
+        print(f"bench.py: bench_details.json not written ({e})", file=sys.stderr)
+    print("bench.py details: " + full, file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    print(compact_line(out), flush=True)
 
 
 def main():
@@ -612,33 +683,44 @@ def main():
     # scripts/collect_profiles.sh wrote for THIS command (profiles/latest_bench_pmc_summary.json); it carries the hash of the kernel
     # sources it was collected on and is not quoted for any other build or configuration
     sweep_kernels = SWEEP_KERNELS_64 if 32 < D <= 64 else ("niw_sweep_direct_kernel" if D <= 32 else "niw_sweep_kernel",)
-    traffic, traffic_source = (pmc_traffic("bench", sweep_kernels) if (N == 10 ** 7 and D == 64 and world == 1) else (None, None))
+    headline_shape = (N == 10 ** 7 and D == 64 and world == 1)
+    traffic, traffic_source = (pmc_traffic("bench", sweep_kernels, allow_stale=True) if headline_shape else (None, None))
     exe_bf16 = float(np.mean([w["bf16_flops"] for w in work]))
     pm = np.asarray(parts_ms, np.float64).mean(axis=0) if parts_ms else np.zeros(3)
-    roof = {"kernel": sweep_kernel_names(D), "bound": "mfma",
-            "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": float(np.mean([pipe_frac(w, avg_sweep_ms) for w in work])),
+    # Which roof: the sweep's Float32 flops of SURVEY 8d are not what the kernel executes any more (exact screening removes 31 of 32
+    # clusters per tile on this data: algorithmic flops / time is 16 x the Float32 matrix peak), so the ceiling that bounds the launch is
+    # HBM: every point's D features are read once per sweep whatever the screens decide.  `achieved` = SURVEY 8d's bytes per point
+    # (4 D + 4) x the points of the launch / live launch time; the matrix pipe's share is kept beside it (`mfma_pipe_frac`).
+    alg_bytes = 4.0 * n_local * D + 4.0 * n_local
+    hbm_gbps = alg_bytes / (avg_sweep_ms * 1e-3) / 1e9
+    roof = {"kernel": sweep_kernel_names(D), "bound": "hbm",
+            "achieved": hbm_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": hbm_gbps / PEAK_HBM_GBPS, "hbm_frac": hbm_gbps / PEAK_HBM_GBPS,
+            "traffic": traffic, "traffic_source": traffic_source, "traffic_is_current": (pmc_is_current("bench") if traffic is not None else None),
+            "traffic_frac": (traffic / (avg_sweep_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS) if traffic else None,
+            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_sweep_ms, "lean_kernel_ms": float(pm[0]) if parts_ms else None,
+            "mfma_pipe_frac": float(np.mean([pipe_frac(w, avg_sweep_ms) for w in work])),
             "f32_frac": exe / (avg_sweep_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-            "bf16_frac": exe_bf16 / (avg_sweep_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, "peak_bf16": PEAK_BF16_MFMA_TFLOPS,
+            "bf16_frac": exe_bf16 / (avg_sweep_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, "peak_f32_mfma": PEAK_F32_MFMA_TFLOPS, "peak_bf16": PEAK_BF16_MFMA_TFLOPS,
             "executed_bf16_flops_per_launch": exe_bf16,
             "launches_ms": {"niw_lean_kernel": float(pm[0]),
                             "niw_sweep_direct_kernel<LSTORE,LIST> (labels and sub-labels of the spans handed on)": float(pm[1]),
                             "niw_sub_kernel (every tile's sub-labels: only in sweeps without the lean launch)": float(pm[2]),
                             "note": "HIP events between the launches of one sweep, recorded in the second block (timing bit 8); "
                                     "avg_launch_ms is the sweep's events of the headline block"},
-            "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": 4.0 * n_local * D + 4.0 * n_local,
-            "avg_launch_ms": avg_sweep_ms, "algorithmic_flops_per_launch": flops_alg, "executed_flops_per_launch": exe,
+            "algorithmic_flops_per_launch": flops_alg, "executed_flops_per_launch": exe,
             "executed_tflops": exe / (avg_sweep_ms * 1e-3) / 1e12, "pruning_factor": flops_alg / exe if exe else None,
-            "algorithmic_frac": achieved / PEAK_F32_MFMA_TFLOPS,
+            "algorithmic_tflops": achieved, "algorithmic_mfma_frac": achieved / PEAK_F32_MFMA_TFLOPS,
             "work_per_launch": {k: float(np.mean([w[k] for w in work])) for k in ("wave_tiles", "full_evals", "screens16", "tail_pairs", "brackets")},
             "bf16_mfma_per_tile": float(np.mean([w["bf16_mfma"] / max(1.0, w["wave_tiles"]) for w in work])),
-            "frac_definition": "share of the matrix pipe's time: matrix instructions counted on the device in the timed launches, Float32 "
-                               "ones x 2048 flops against the Float32 peak (`f32_frac`) + bf16 ones x 16384 flops against the bf16 peak "
-                               "(`bf16_frac`: reference brackets, bf16 screens, three-plane sub-cluster evaluations), over the live duration "
-                               "of the sweep's launches (= (SQ_INSTS_VALU_MFMA_MOPS_F32 / peak_f32 + ..._BF16 / peak_bf16) x 512: `pmc_frac`); "
-                               "`achieved` = the sweep's algorithmic Float32 flops (SURVEY 8d) over the same duration",
+            "frac_definition": "`frac` = `hbm_frac` = algorithmic bytes of the sweep (SURVEY 8d: (4 D + 4) bytes per point) / live duration of the sweep's "
+                               "launches / 8 TB/s.  `mfma_pipe_frac` = share of the matrix pipe's time: matrix instructions counted on the device in the "
+                               "timed launches, Float32 ones x 2048 flops against the Float32 peak (`f32_frac`) + bf16 ones x 16384 flops against the "
+                               "bf16 peak (`bf16_frac`: reference brackets, bf16 screens, three-plane sub-cluster evaluations) "
+                               "(= (SQ_INSTS_VALU_MFMA_MOPS_F32 / peak_f32 + ..._BF16 / peak_bf16) x 512: `pmc_frac`); `algorithmic_tflops` = the "
+                               "sweep's algorithmic Float32 flops (SURVEY 8d) over the same duration: above the Float32 peak because exact screening "
+                               "skips clusters; `dense_*` = the same sweep with screening off",
             "stats_kernels_ms": float(np.mean(stats_ms)), "kernel_source_tag": kernel_source_tag()}
-    if N == 10 ** 7 and D == 64 and world == 1:
+    if headline_shape:
         roof.update(pmc_matrix_pipe("bench", sweep_kernels, avg_sweep_ms))
 
     # same kernel, same process, screening off: every cluster is evaluated in full (labels are bit-identical by construction)
@@ -670,14 +752,15 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"NIW D={D} N={N} synthetic GMM, {K} true components, K_t={k_mean:.1f} live clusters, "
-                               f"alpha=10, default NIW prior, steady state after {BURNOUT + 1} burn-in + {args.settle} settling sweeps",
+        "config": {"workload": f"NIW D={D} N={N} synthetic GMM of the reference's generator (data_generators.jl:19-42), {K} true components, "
+                               f"MixtureVar 100 (component means ~ N(0, 100 I): well-separated clusters -- overlapping ones are the overlap_* entries "
+                               f"of also_measured), K_t={k_mean:.1f} live clusters, alpha=10, default NIW prior, steady state after {BURNOUT + 1} burn-in "
+                               f"+ {args.settle} settling sweeps",
                    "points_per_gpu": n_local, "worker_options_overridden": {str(o): v for o, v in WORKER_OPTS} or None,
                    "parallelism": f"points sharded over {world} GPU(s); all-reduces of a statistics pass inside libdpmmhip.so: see comm",
-                   "master": "DEVIATION from north_star's wording, stated here: the headline runs the engine's default for D >= 64 -- posteriors, "
-                             "factorisations and parameter draws on the GPU beside the statistics they consume (DPMMH_OPT_DEVICE_MASTER), every decision "
-                             "(gates, split / merge Metropolis steps) on the host.  The configuration north_star words (draws on the host) is the "
-                             "`host_master` block of this line; its rate and ratio to the headline are in also_measured"},
+                   "master": "DEVIATION from north_star's wording: the headline runs the engine's default for D >= 64 -- posteriors, factorisations and "
+                             "parameter draws on the GPU beside the statistics (DPMMH_OPT_DEVICE_MASTER), every decision (gates, split / merge Metropolis "
+                             "steps) on the host.  north_star's configuration (draws on the host) = also_measured.host_master_*"},
         "roofline": roof,
         "comm": {"world": info["world"], "transport": info["transport"], "occupancy_allreduce_bytes": info["counts_bytes"],
                  "rows_allreduce_bytes": info["rows_bytes"], "allreduces_since_attach": info["allreduces"],
@@ -773,7 +856,7 @@ def main():
         if "c4" in lg:
             also["c4_traffic_frac"] = lg["c4"]["roofline"].get("traffic_frac")
         out["config"]["also_measured"] = also
-        print(json.dumps(out), flush=True)
+        emit(out)
     wk.close()
     if dist is not None:
         dist.barrier()
