@@ -994,6 +994,8 @@ int dpmm_commit_params(dpmm_ctx *c, int K) {
                 c->have_screen_prep = true;
             }
         }
+        c->predictive = false;          // (before the tables: direction_tables decides the three-plane images from it -- the first parameter set behind a
+                                        //  dpmm_set_predictive_* call used to get none and drew one sweep's sub-labels with the Float32 chain: ADVICE r5)
         if (int rc = direction_tables(c, K)) return rc;
     } else {
         HIPCHK(c, launch_copy_bytes(c->d_cst, hcst, sizeof(float) * 3 * K, c->stream));
@@ -1252,8 +1254,10 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
             a.bf16scr &= 3;
             a.tdf = nullptr;
             if (!list) HIPCHK(c, launch_niw_sub(a, nullptr, nullptr, c->sweep_grid, c->stream));      // (every tile; a list's spans were finished by the LIST launch)
-        } else
-        HIPCHK(c, launch_niw_sweep(c->NB, a, c->sweep_grid, c->stream));
+        } else {
+            HIPCHK(c, launch_niw_sweep(c->NB, a, c->sweep_grid, c->stream));
+            if (!table) c->have_parts = 0;          // (a one-launch sweep records no part events: dpmm_last_sweep_parts_ms must not mix its ev[0] / ev[1] with an older sweep's)
+        }
     } else {
         MultSweepArgs a{};
         a.X = c->dX; a.ldx = c->ldx; a.n = c->n; a.first_index = c->first; a.D = c->D; a.K = c->K;
@@ -2041,6 +2045,7 @@ int dpmm_niw_master_draw(dpmm_ctx *c, uint32_t epoch, int K, const int32_t *slot
     const bool normals = !ahead && noise_ready(c, epoch, K, c->draw_cur);       // (noise_join above made the main stream wait for them)
     HIPCHK(c, launch_niw_master_draw(ma, hs, K, epoch, c->d_Y[c->draw_cur], c->d_ld_sigma[c->draw_cur], hlr, hw, c->d_Rp, c->d_mup, c->d_cst,
                                      c->have_tail ? c->d_tail : nullptr, c->NB, c->d_work, ahead ? 2 : (normals ? 7 : 3), c->stream));
+    c->predictive = false;              // (before the tables, as in set_params)
     if (int rc = direction_tables(c, K)) return rc;
     // The normals of the NEXT draws (epoch + 1, a few clusters more than now for the splits in between) into the other buffer, on the
     // second stream: they depend on nothing the master decides, and run beside the sweep instead of in front of it.  Whoever draws
@@ -2648,13 +2653,18 @@ int dpmm_last_sweep_work(dpmm_ctx *c, uint64_t *out16) {
     std::vector<unsigned long long> h((size_t)DPMM_WORK_PER_WAVE * (size_t)c->work_waves);
     if (!h.empty()) HIPCHK(c, hipMemcpy(h.data(), c->d_work + DPMM_WORK_SLOTS, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
     for (int i = 0; i < 16; ++i) out16[i] = 0;
+    unsigned long long w7_lo = 0, w7_hi = 0;
     for (size_t w = 0; w < (size_t)c->work_waves; ++w) {
         for (int i = 0; i < 4; ++i) out16[i] += h[DPMM_WORK_PER_WAVE * w + i];
         out16[8] += h[DPMM_WORK_PER_WAVE * w + 4];
         out16[11] += h[DPMM_WORK_PER_WAVE * w + 5];
         out16[13] += h[DPMM_WORK_PER_WAVE * w + 6];
-        out16[15] += h[DPMM_WORK_PER_WAVE * w + 7];          // low half: direction screens (8 bf16 matrix instructions per 16 clusters + 4 Float32 row sums each); high half: bf16 three-plane sub-cluster evaluations (niw_lean.hip)
+        // slot 7 packs two counters per wave -- low half: direction screens (8 bf16 matrix instructions per 16 clusters + 4 Float32 row sums
+        // each); high half: bf16 three-plane sub-cluster evaluations (niw_lean.hip).  The halves are summed SEPARATELY over the waves (a raw
+        // 64-bit sum lets the low halves' carry run into the evaluation count after a few thousand launches between two reads: ADVICE r5)
+        w7_lo += h[DPMM_WORK_PER_WAVE * w + 7] & 0xFFFFFFFFull; w7_hi += h[DPMM_WORK_PER_WAVE * w + 7] >> 32;
     }
+    out16[15] = std::min<unsigned long long>(w7_lo, 0xFFFFFFFFull) | (std::min<unsigned long long>(w7_hi, 0xFFFFFFFFull) << 32);      // (each half saturates at 2^32 - 1)
     // totals of the launches since the previous call (out16[7] of them); the slots start again from zero
     const long long launches = c->work_launches;
     if (!h.empty()) HIPCHK(c, hipMemsetAsync(c->d_work + DPMM_WORK_SLOTS, 0, sizeof(unsigned long long) * h.size(), c->stream));
@@ -2787,7 +2797,7 @@ int dpmm_debug_subloglik(dpmm_ctx *c, float *out) {
     HIPCHK(c, hipSetDevice(c->device));
     if (c->n == 0) return DPMM_OK;
     const int K = c->K, K2 = 2 * K;
-    if (c->prior == DPMM_PRIOR_NIW && c->have_b3 && c->opt_b3 && c->have_tail) {
+    if (c->prior == DPMM_PRIOR_NIW && c->have_b3 && c->opt_b3 && c->have_tail && !c->predictive) {      // (the same condition as run_sweep's)
         // the sweeps' sub-label phase runs the three-plane bf16 evaluation (niw_lean.hip): the same device functions, for every point and cluster
         NiwSweepArgs a{};
         a.X = c->dX; a.ldx = c->ldx; a.n = c->n; a.K = K; a.mup = c->d_mup; a.cst = c->d_cst; a.tail = c->d_tail;

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void 
             const int s0 = aligned ? bin_start[tid] : 0, s1 = aligned ? bin_start[tid + 1] : (int)A.n;
             c = (s1 - s0 + 63) >> 6; bstart_s[tid] = s0;
         }
-        if (tid == nb) bstart_s[nb] = (int)A.n;
+        if (tid == 0) bstart_s[nb] = (int)A.n;                    // (by thread 0, not by thread nb: nb may equal the workgroup size -- ADVICE r5)
         int inc = c;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off); if (lane >= off) inc += v; }

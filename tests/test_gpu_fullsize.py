@@ -209,3 +209,112 @@ def test_c5_shard_size_niw_d256(pkg, host):
     l2, s2 = wk.get_labels()
     assert np.array_equal(l2, lab6) and np.array_equal(s2, sub6)
     wk.close()
+
+
+def test_c2_size_niw_d64(pkg, host):
+    """BASELINE config 2 at its size (it ran only as a bench leg): NIW D = 64, N = 1e6, 32 true components, one GPU -- below 4e6
+    points the sort works in tiles of 512 points (C3's N = 1e7 takes the 2048-point ones) and the statistics pass in 1024 workgroups.
+    Conservation against an independent Float64 pass, the oracle on three windows of the SECOND sweep (bin-sorted visiting order, lean launch
+    and screening active), bitwise reproducibility, two-shard invariance."""
+    N, D, K = 10 ** 6, 64, 32
+    X, y = host.gaussian_mixture_shard(N, D, K, 100.0, 2024, 0, N)
+    prior, par = _niw_params(host, X, y, K, D, 5)
+    lr = np.full((K, 2), 0.5, np.float32); w = np.full(K, 1.0 / K, np.float32)
+    sub0 = 1 + (np.arange(N) & 1)
+
+    def run(lo, hi, seed=77):
+        wk = pkg.Worker(pkg.PRIOR_NIW, D, hi - lo, first_index=lo, device=0, seed=seed)
+        wk.upload_points(X[lo:hi])
+        wk.set_timing(15)
+        wk.set_labels(y[lo:hi], sub0[lo:hi])
+        prior.upload(wk, par, lr, w)
+        wk.sweep(5)
+        lab, sub = wk.get_labels()
+        packed = wk.suffstats_packed(None)
+        prior.upload(wk, par, lr, w)
+        wk.last_sweep_work()
+        wk.sweep(6)
+        lean_ms = wk.last_sweep_parts_ms()[0]
+        work = wk.last_sweep_work()
+        lab6, sub6 = wk.get_labels()
+        return wk, lab, sub, packed, lab6, sub6, lean_ms, work
+
+    wk, lab, sub, packed, lab6, sub6, lean_ms, work = run(0, N)
+    assert lean_ms > 0.0 and work["b3_evals"] > 0                     # the second sweep ran as lean launch + list launch
+    assert lab.min() >= 1 and lab.max() <= K and set(np.unique(sub)) <= {1, 2} and (lab == y).mean() > 0.999
+    Nk, sums, S = wk.unpack(packed, K)
+    assert Nk[:, 0].sum() == N and np.array_equal(Nk[:, 0], Nk[:, 1] + Nk[:, 2])
+    assert np.array_equal(Nk[:, 0], np.bincount(lab, minlength=K + 1)[1:])
+    Xd = X.astype(np.float64)
+    np.testing.assert_allclose(sums[:, 0].sum(0), Xd.sum(0), rtol=1e-10, atol=1e-6)
+    np.testing.assert_allclose(np.trace(S[:, 0].sum(0)), float((Xd * Xd).sum()), rtol=1e-10)
+    for k in (int(np.argmax(Nk[:, 0])), int(np.argmin(Nk[:, 0]))):   # two full second-moment matrices (and their sub-cluster halves) against numpy
+        for h in (0, 1, 2):
+            m = (lab == k + 1) if h == 0 else ((lab == k + 1) & (sub == h))
+            np.testing.assert_allclose(S[k, h], Xd[m].T @ Xd[m], rtol=1e-11, atol=1e-6)
+            np.testing.assert_allclose(sums[k, h], Xd[m].sum(0), rtol=1e-11, atol=1e-7)
+    del Xd
+    _check_niw_windows(host, X, y, par, lr, w, lab6, sub6, seed=77, epoch=6, width=20000)
+    # bitwise reproducibility of the two-sweep chain
+    wk.set_labels(y, sub0); prior.upload(wk, par, lr, w); wk.sweep(5)
+    l5, s5 = wk.get_labels()
+    assert np.array_equal(l5, lab) and np.array_equal(s5, sub)
+    assert np.array_equal(wk.suffstats_packed(None), packed)
+    prior.upload(wk, par, lr, w); wk.sweep(6)
+    l6, s6 = wk.get_labels()
+    assert np.array_equal(l6, lab6) and np.array_equal(s6, sub6)
+    wk.close()
+    h = N // 3 + 77                                                   # two ragged shards: same labels, same total statistics
+    wa, la, sa, pa, la6, sa6, _, _ = run(0, h)
+    wb, lb, sb, pb, lb6, sb6, _, _ = run(h, N)
+    assert np.array_equal(np.concatenate([la, lb]), lab) and np.array_equal(np.concatenate([sa, sb]), sub)
+    assert np.array_equal(np.concatenate([la6, lb6]), lab6) and np.array_equal(np.concatenate([sa6, sb6]), sub6)
+    Na, suma, Sa = wa.unpack(pa, K); Nb, sumb, Sb = wb.unpack(pb, K)
+    assert np.array_equal(Na + Nb, Nk)
+    np.testing.assert_allclose(suma + sumb, sums, rtol=1e-12, atol=1e-7)
+    np.testing.assert_allclose(Sa + Sb, S, rtol=1e-12, atol=1e-6)
+    wa.close(); wb.close()
+
+
+def test_c5_full_n_niw_d256(pkg, host):
+    """BASELINE config 5 at its FULL N on one GPU (5e6 x 256 Float32 = 5.1 GB fits one MI355X): NIW D = 256, N = 5e6, K = 32.
+    The host holds the Float32 matrix only; the independent Float64 pass runs in blocks of 5e5 points.
+    Conservation against that pass, the oracle on three windows of the second sweep (bracket launch, workgroup-wide
+    screening, the 16-block statistics kernel with 2048-point sort tiles), bitwise reproducibility."""
+    N, D, K = 5 * 10 ** 6, 256, 32
+    X, y = host.gaussian_mixture_shard(N, D, K, 100.0, 4321, 0, N)
+    prior, par = _niw_params(host, X, y, K, D, 9)
+    lr = np.full((K, 2), 0.5, np.float32); w = np.full(K, 1.0 / K, np.float32)
+    sub0 = 1 + (np.arange(N) & 1)
+    wk = pkg.Worker(pkg.PRIOR_NIW, D, N, first_index=0, device=0, seed=43)
+    wk.upload_points(X)
+    wk.set_labels(y, sub0)
+    prior.upload(wk, par, lr, w)
+    wk.sweep(5)
+    lab, sub = wk.get_labels()
+    packed = wk.suffstats_packed(None)
+    assert (lab == y).mean() > 0.999 and set(np.unique(sub)) <= {1, 2}
+    Nk, sums, S = wk.unpack(packed, K)
+    assert Nk[:, 0].sum() == N and np.array_equal(Nk[:, 0], np.bincount(lab, minlength=K + 1)[1:])
+    assert np.array_equal(Nk[:, 0], Nk[:, 1] + Nk[:, 2])
+    col = np.zeros(D); sq = 0.0
+    k = int(np.argmin(Nk[:, 0])); Sk = np.zeros((D, D))
+    for a in range(0, N, 500000):
+        blk = X[a:a + 500000].astype(np.float64)
+        col += blk.sum(0); sq += float((blk * blk).sum())
+        m = lab[a:a + 500000] == k + 1
+        if m.any():
+            Sk += blk[m].T @ blk[m]
+    np.testing.assert_allclose(sums[:, 0].sum(0), col, rtol=1e-10, atol=1e-6)
+    np.testing.assert_allclose(np.trace(S[:, 0].sum(0)), sq, rtol=1e-10)
+    np.testing.assert_allclose(S[k, 0], Sk, rtol=1e-10, atol=1e-6)
+    prior.upload(wk, par, lr, w)
+    wk.sweep(6)
+    lab6, sub6 = wk.get_labels()
+    _check_niw_windows(host, X, y, par, lr, w, lab6, sub6, seed=43, epoch=6, width=1500)
+    wk.set_labels(lab, sub); wk.suffstats_packed(None)
+    prior.upload(wk, par, lr, w)
+    wk.sweep(6)
+    l2, s2 = wk.get_labels()
+    assert np.array_equal(l2, lab6) and np.array_equal(s2, sub6)
+    wk.close()

@@ -709,7 +709,8 @@ def test_lean_tiles_do_not_change_labels(pkg, D, sep, K, n):
             wk.set_params_niw(P["mu"], P["invS"], P["logdet"], P["lr"], P["w"])
         work = wk.last_sweep_work()
         assert work["b3_evals"] > 0 or K == 1          # the sub-cluster values came from the three-plane evaluation (K = 1 has no tail records: the Float32 chain)
-        if not on or K == 1 or K > 64:                 # (beyond 64 clusters the scalar pre-screen runs in the sweep kernel: no lean launch)
+        if not on or K == 1 or K > 64:                 # (set_params path beyond 64 clusters: the scalar pre-screen runs in the sweep kernel, no lean launch;
+                                                       #  the device-master path has no pre-screen and does run it: test_lean_tiles_beyond_64_clusters_*)
             assert max(lean_ms) == 0.0
         else:
             assert max(lean_ms) > 0.0                  # (overlapping clusters: one lean launch, then the regime switch keeps it off)
@@ -717,6 +718,115 @@ def test_lean_tiles_do_not_change_labels(pkg, D, sep, K, n):
         wk.close()
     for a, b in zip(out[1], out[0]):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("K,n,sep", [(70, 40000, 30.0), (100, 30011, 30.0), (127, 51000, 25.0), (128, 52000, 25.0), (128, 30000, 2.0), (129, 52001, 25.0), (200, 60000, 30.0),
+                                     (300, 120000, 40.0)])
+def test_lean_tiles_beyond_64_clusters_without_the_prescreen(pkg, K, n, sep):
+    """ADVICE r5 (high + medium).  The device-master path never builds the K > 64 pre-screen (lam == nullptr), so THERE the lean launch runs at
+    any K: the candidate loop's chunks beyond the first 64 clusters, ball records from global memory beyond 128 clusters, bin-aligned tiles up
+    to 256 bins (K = 128: nbins == the workgroup size -- the table's sentinel used to be written by a thread that does not exist; the last
+    bin's tiles then got garbage counts) and 64-position tiles beyond.  DPMM_OPT_PRESCREEN = 0 reaches exactly that kernel configuration
+    through set_params: lean launch on / off must give bit-equal labels and sub-labels, the lean launch must have run, and the labels are
+    the oracle's draw on the kernel's own table."""
+    from dpmmsubclusters_jl_amd import binding
+    P = make_problem(64, n, K, seed=700 + K, sep=sep, sorted_points=True)
+    out = {}
+    for on in (1, 0):
+        wk = pkg.Worker(pkg.PRIOR_NIW, 64, n, first_index=0, device=0, seed=31)
+        wk.upload_points(P["X"])
+        wk.set_option(binding.OPT_PRESCREEN, 0)
+        wk.set_option(binding.OPT_LEAN_TILES, on)
+        wk.set_timing(15)
+        wk.set_params_niw(P["mu"], P["invS"], P["logdet"], P["lr"], P["w"])
+        wk.set_labels(P["z"] + 1, 1 + (np.arange(n) & 1))
+        wk.suffstats_packed(None)
+        wk.set_params_niw(P["mu"], P["invS"], P["logdet"], P["lr"], P["w"])
+        labs, lean_ms = [], []
+        for ep in (1, 2, 3):
+            wk.sweep(ep)
+            labs.append(wk.get_labels())
+            lean_ms.append(wk.last_sweep_parts_ms()[0])
+            if ep == 3 and on:
+                u0, u1 = orc.uniforms(31, 3, 0, 0, n)
+                assert np.array_equal(orc.sample_log_cat(wk.debug_loglik(), u0), labs[-1][0])
+                assert_sublabels_bit_exact(wk, labs[-1][0], labs[-1][1], u1)
+            N_, _, _ = wk.suffstats()
+            assert int(N_.sum()) == n                  # conservation: every point swept, every label in range
+            wk.set_params_niw(P["mu"], P["invS"], P["logdet"], P["lr"], P["w"])
+        assert (max(lean_ms) > 0.0) == bool(on), lean_ms
+        out[on] = labs
+        wk.close()
+    for a, b in zip(out[1], out[0]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("K", [96, 128, 160])
+def test_lean_tiles_beyond_64_clusters_device_master_chain(pkg, K):
+    """The same through the engine's default path (dpmm_niw_master_draw: parameters drawn on the device, no pre-screen): 12 group_steps from
+    the generator's labels with K_true = 96 / 128 / 160, lean launch on and off -- K history, labels and sub-labels identical."""
+    import importlib
+    from dpmmsubclusters_jl_amd import binding
+    host = importlib.import_module("dpmmsubclusters_jl_amd.host")
+    N, D = 160000, 64
+    X, y = host.gaussian_mixture_shard(N, D, K, 100.0, 1000 + K, 0, N)
+    prior = host.niw_hyperparams(1.0, np.zeros(D), D + 3, np.eye(D))
+    out = {}
+    for on in (1, 0):
+        wk = pkg.Worker(pkg.PRIOR_NIW, D, N, device=0, seed=17)
+        wk.upload_points(X)
+        wk.set_option(binding.OPT_LEAN_TILES, on)
+        wk.set_timing(15)
+        s = host.DPMMSampler(wk, prior, 10.0, N, 17, burnout=4)
+        s.start_from_labels(y, 1 + np.random.default_rng(2).integers(0, 2, N), K)
+        ks, snaps, ran = [], [], 0.0
+        for it in range(12):
+            s.group_step(False, False)
+            ks.append(s.K)
+            ran = max(ran, wk.last_sweep_parts_ms()[0])
+            if it % 4 == 3:
+                snaps.append(wk.get_labels())
+        assert (ran > 0.0) == bool(on)
+        out[on] = (ks, snaps)
+        wk.close()
+    assert out[1][0] == out[0][0], (out[1][0], out[0][0])
+    for a, b in zip(out[1][1], out[0][1]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    lab = out[1][1][-1][0]
+    assert lab.min() >= 1 and lab.max() <= out[1][0][-1]
+
+
+def test_a_predictive_table_in_between_does_not_change_the_chain(pkg):
+    """the first parameter set behind a dpmm_set_predictive_* call used to be packed without the three-plane images (the flag was
+    cleared one statement too late) -- that one sweep drew its sub-labels with the Float32 chain, so a run that calls predict in between was not the
+    chain of a run that does not.  Also: the part events of a two-launch sweep are not reported behind a later one-launch sweep."""
+    from dpmmsubclusters_jl_amd import binding
+    D, n, K = 64, 30000, 6
+    P = make_problem(D, n, K, seed=811, sep=20.0, sorted_points=True)
+    R = np.stack([np.linalg.cholesky(np.linalg.inv(P["invS"][3 * k].reshape(D, D).astype(np.float64))).T for k in range(K)]).astype(np.float32)
+    out = {}
+    for with_predict in (0, 1):
+        wk = gpu_worker(pkg, P, seed=37)
+        wk.set_timing(15)
+        wk.set_labels(P["z"] + 1, 1 + (np.arange(n) & 1))
+        wk.suffstats_packed(None)
+        if with_predict:
+            tab = wk.predict_table_niw(P["mu"][::3], R.reshape(K, -1), P["logdet"][::3], np.full(K, 30.0), P["w"])
+            assert tab.shape == (K, n) and np.isfinite(tab).all()
+        wk.set_params_niw(P["mu"], P["invS"], P["logdet"], P["lr"], P["w"])
+        wk.last_sweep_work()
+        wk.sweep(1)
+        out[with_predict] = (wk.get_labels(), wk.last_sweep_work()["b3_evals"], wk.debug_subloglik())
+        assert wk.last_sweep_parts_ms()[0] > 0.0
+        # a one-launch sweep afterwards (three-plane evaluation off): no part times of the older sweep
+        wk.set_option(binding.OPT_B3_SUBLABELS, 0)
+        wk.set_params_niw(P["mu"], P["invS"], P["logdet"], P["lr"], P["w"])
+        wk.sweep(2)
+        assert tuple(wk.last_sweep_parts_ms()) == (0.0, 0.0, 0.0)
+        wk.close()
+    assert out[1][1] > 0 and out[1][1] == out[0][1]
+    assert np.array_equal(out[0][0][0], out[1][0][0]) and np.array_equal(out[0][0][1], out[1][0][1])
+    assert np.array_equal(out[0][2], out[1][2])
 
 
 def test_lean_tiles_behind_whole_bin_relabels(pkg):
