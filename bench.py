@@ -523,6 +523,11 @@ def compact_line(out):
     c = out.get("cpu_baseline")
     if c is not None:
         line["cpu_baseline"] = {k: c[k] for k in ("value", "unit", "cores", "kind", "sample", "cpu_model", "julia_found") if k in c}
+    cm = out.get("comm")
+    if cm and cm.get("world", 1) > 1:          # what the collective saw, for the driver's scaling record
+        line["comm"] = {"world": cm["world"], "transport": cm["transport"], "rows_allreduce_bytes": cm["rows_allreduce_bytes"],
+                        "allreduces_per_step": cm["allreduces_per_step_in_timed_block"], "rows_allreduce_ms": cm["rows_allreduce_ms"],
+                        "one_collective_per_step_pass": cm["one_collective_per_step_pass"]}
     line["details"] = "bench_details.json (written beside bench.py; also dumped on stderr)"
 
     def rnd(o):
@@ -556,6 +561,11 @@ def emit(out):
         print(f"bench.py: bench_details.json not written ({e})", file=sys.stderr)
     print("bench.py details: " + full, file=sys.stderr, flush=True)
     sys.stdout.flush()
+    try:       # C stdio of the libraries in this process (RCCL prints its version banner through a buffered printf that otherwise lands BEHIND the line at exit)
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
     print(compact_line(out), flush=True)
 
 

@@ -239,6 +239,8 @@ struct dpmm_ctx {
     int sp_cooldown = 0;               // parameter sets the screen stays off after it removed less than a quarter of what it was given
     int opt_b3 = 1;                    // DPMM_OPT_B3_SUBLABELS: D in 33..64: sub-cluster evaluations through three-plane bf16 images, in kernels of their own (niw_lean.hip)
     bool have_b3 = false;              // the images behind the bracket's in d_tail belong to the parameter set on the device
+    int opt_chain = 0x7fffffff;        // DPMM_OPT_CHAIN_FUSION (bit mask): 1 = the sort's starts inside the scatter launch; 2 = the three-plane images in the hand-over launch
+    int opt_master_poll = 1;           // DPMM_OPT_MASTER_POLL: dpmm_step_master_device waits on the posteriors' own records in pinned memory (no event between posteriors and draws)
     int opt_lean = 1;                  // DPMM_OPT_LEAN_TILES: tiles the cheap screens settle completely in niw_lean_kernel (-1 automatic is 1 with a regime switch; 0 never)
     uint32_t *d_hard = nullptr;        // two lists of [2 + ceil(n / 64)] words, taking turns (hard_flip): count | wave tiles the lean kernel left to the general path;
                                        // a lean launch clears the OTHER list's count for its successor (no fill launch), niw_sub_kernel reports the count to h_hard (no copy launch)
@@ -936,7 +938,7 @@ int dpmm_params_staging(dpmm_ctx *c, int slots, float **mu, float **mat, float *
     return DPMM_OK;
 }
 
-static int direction_tables(dpmm_ctx *c, int K);
+static int direction_tables(dpmm_ctx *c, int K, bool b3_done);
 
 int dpmm_commit_params(dpmm_ctx *c, int K) {
     if (!c) return DPMM_EINVAL;
@@ -996,7 +998,7 @@ int dpmm_commit_params(dpmm_ctx *c, int K) {
         }
         c->predictive = false;          // (before the tables: direction_tables decides the three-plane images from it -- the first parameter set behind a
                                         //  dpmm_set_predictive_* call used to get none and drew one sweep's sub-labels with the Float32 chain: ADVICE r5)
-        if (int rc = direction_tables(c, K)) return rc;
+        if (int rc = direction_tables(c, K, false)) return rc;
     } else {
         HIPCHK(c, launch_copy_bytes(c->d_cst, hcst, sizeof(float) * 3 * K, c->stream));
         HIPCHK(c, launch_gather_rows(c->d_raw, c->ldx, hmat, c->D, hslot, 3 * K, c->D, c->stream));
@@ -1017,12 +1019,14 @@ int dpmm_commit_params(dpmm_ctx *c, int K) {
 // write their counts into pinned memory; that sweep has been waited for by whoever brings new parameters), with hysteresis: on from 8 per
 // tile, off below 4.  While it is on, the sweeps run the screen in front of the 4-row pair tests; the first sweep, every 32nd and the one
 // after a change of K keep the usual order and count.
-static int direction_tables(dpmm_ctx *c, int K) {
+static bool want_b3_images(const dpmm_ctx *c) { return c->prior == DPMM_PRIOR_NIW && c->NB == 4 && c->opt_b3 && c->have_tail && !c->predictive; }
+static int direction_tables(dpmm_ctx *c, int K, bool b3_done) {
     c->sp_ready = false;
     c->have_refb_big = false;
     c->have_b3 = false;
-    if (c->prior == DPMM_PRIOR_NIW && c->NB == 4 && c->opt_b3 && c->have_tail && !c->predictive) {
-        HIPCHK(c, launch_niw_b3_pack(c->d_Rp, c->d_mup, K, c->d_tail, c->stream));      // the sub-cluster factors' bf16 planes + offsets (niw_lean.hip)
+    if (want_b3_images(c)) {
+        // the sub-cluster factors' bf16 planes + offsets (niw_lean.hip) -- b3_done: the hand-over launch wrote them (niw_master_pack_roles_kernel)
+        if (!b3_done) HIPCHK(c, launch_niw_b3_pack(c->d_Rp, c->d_mup, K, c->d_tail, c->stream));
         c->have_b3 = true;
     }
     if (c->prior == DPMM_PRIOR_NIW && (c->NB == 8 || c->NB == 16) && c->d_refb_big && c->opt_bracket && c->have_tail && K > 1) {
@@ -1489,7 +1493,7 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
         // cached (labels are tracked by the histogram); the other sub-cluster is cache - computed (derive_rows_kernel below)
         derive = c->opt_derive != 0;
         const int force_all = (c->cache_force || c->cache_K != c->K) ? 1 : 0;
-        HIPCHK(c, launch_step_scan_scatter(c->dbins, a, derive ? 1 : 0, force_all, c->stream));
+        HIPCHK(c, launch_step_scan_scatter(c->dbins, a, derive ? 1 : 0, force_all, c->opt_chain & 1, c->stream));
         if (derive) { c->sel_all_ones = 0; c->cache_force = false; c->cache_K = c->K; }
     } else {
         if (c->n > 0) {
@@ -1824,11 +1828,53 @@ int dpmm_step_stats_device(dpmm_ctx *c, uint32_t reset_epoch, const uint8_t **ba
 }
 
 static const uint64_t MASTER_MARK = 0x7ff8dead0000beefull;
-static bool master_marks_left(const double *sm, int K) {
+static bool master_records_marked(const double *sm, int64_t nrec) {
     const volatile uint64_t *w = reinterpret_cast<const volatile uint64_t *>(sm);
-    for (int64_t r = 0; r < 3 * (int64_t)K; ++r)
+    for (int64_t r = nrec - 1; r >= 0; --r)           // (from the back: the last workgroups of the launch finish last)
         for (int e = 0; e < 5; ++e) if (w[r * DPMM_MASTER_NSCALARS + e] == MASTER_MARK) return true;
     return false;
+}
+static bool master_marks_left(const double *sm, int K) { return master_records_marked(sm, 3 * (int64_t)K); }
+static void master_mark_records(double *sm, int64_t nrec) {
+    for (int64_t r = 0; r < nrec; ++r)
+        for (int e = 0; e < 5; ++e) std::memcpy(&sm[r * DPMM_MASTER_NSCALARS + e], &MASTER_MARK, 8);
+}
+// The wait of dpmm_step_master_device WITHOUT an event (DPMM_OPT_MASTER_POLL, round 6).  The posterior workgroups store their five scalars per
+// distribution straight into pinned host memory; every record starts out as MASTER_MARK (a NaN payload no kernel produces), so "no mark left"
+// IS "the posteriors' results are on the host" -- the witness of rounds 3-5 promoted to the wait itself.  What it buys: no event record sits
+// between the posteriors and the draws launched ahead behind them (a barrier packet with a completion signal: 6 us of stream time at
+// N = 1e7, 10 us at the 8-GPU shard size where the second stream's normals join there too), and the host sees the records when they land
+// instead of when the runtime has processed the signal.  Everything an EARLIER kernel of the stream wrote to pinned memory (the bad-cluster
+// flags) is complete by then: a kernel starts after its predecessor's end-of-kernel release.  The loop keeps the watchdog's contract (a wait
+// behind an enqueued collective is armed; an abort ends it) and asks the stream once a millisecond whether it failed or drained.
+static int wait_master_records(dpmm_ctx *c, const double *sm, int64_t nrec, const double *pr, int64_t npr) {
+    const bool armed = c->watchdog && c->coll_pending;
+    if (armed) wd_arm(c);
+    int rc = DPMM_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto next_query = t0 + std::chrono::milliseconds(1);
+    std::chrono::steady_clock::time_point drained{};
+    bool is_drained = false;
+    for (uint64_t spin = 0;; ++spin) {
+        if (!master_records_marked(sm, nrec) && !(npr > 0 && master_records_marked(pr, npr))) break;
+        __builtin_ia32_pause();
+        if ((spin & 63u) != 63u) continue;
+        if (c->comm_aborted.load(std::memory_order_relaxed)) break;                         // (reported by wd_disarm below)
+        const auto now = std::chrono::steady_clock::now();
+        if (now < next_query) continue;
+        next_query = now + std::chrono::milliseconds(1);
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q == hipSuccess) {       // the stream is empty and records are still marked: stores in flight (seen in rounds 3-5 behind an event wait) -- or never written
+            if (!is_drained) { is_drained = true; drained = now; ++c->dbg_early_wait; }
+            else if (now - drained > std::chrono::seconds(5)) { rc = fail(c, DPMM_EHIP, "posterior records missing 5 s after the stream drained"); break; }
+        } else if (q != hipErrorNotReady) { c->err = std::string("hipStreamQuery while waiting for the posteriors: ") + hipGetErrorString(q); rc = DPMM_EHIP; break; }
+    }
+    if (armed && wd_disarm(c)) {
+        c->err = "collective timed out: a peer rank is gone or stuck (communicator aborted after DPMM_OPT_COMM_TIMEOUT_MS)";
+        return DPMM_ECOMM;
+    }
+    if (c->comm_aborted.load(std::memory_order_relaxed) && rc == DPMM_OK && master_records_marked(sm, nrec)) return fail(c, DPMM_ECOMM, "communicator aborted");
+    return rc;
 }
 
 int dpmm_debug_set_prelaunch_hook(void (*fn)(void *), void *arg) {
@@ -1912,14 +1958,15 @@ int dpmm_step_master_device(dpmm_ctx *c, uint32_t reset_epoch, const int32_t *sl
     // Witness of the event wait below: every scalar record the posteriors write starts out as a marker no kernel produces (a NaN with a
     // payload; the kernels' own NaN is the plain quiet one).  A record still carrying it after the wait means the wait returned before
     // the kernels' stores reached host memory: counted (dpmm_debug_counters) and waited out.
-    for (int64_t r = 0; r < 3 * (int64_t)K; ++r)
-        for (int e = 0; e < 5; ++e) std::memcpy(&sm[r * DPMM_MASTER_NSCALARS + e], &MASTER_MARK, 8);
+    master_mark_records(sm, 3 * (int64_t)K);
+    const bool poll = c->opt_master_poll != 0;
     bool flags_sent = false;
     if (int rc = run_stats(c, nullptr, 0, true, reset_epoch, reinterpret_cast<uint8_t *>(c->h_out), &flags_sent)) return rc;
     if (!flags_sent) HIPCHK(c, launch_copy_bytes(c->h_out, reinterpret_cast<const uint8_t *>(c->d_out) + out_bytes, (size_t)K + 1, c->stream));
     if (napairs > 0 && fuse_pairs) {
         // posteriors + the pooled pair log-determinants the master may ask for (dpmm_niw_master_pairs_ahead) in ONE launch: the pairs need
         // the rows of this pass only.  (On the second stream behind the posteriors they reached the host 12 + 26 us later.)
+        if (poll) master_mark_records(c->h_apairs, napairs);      // (nobody reads the pair records between two passes: dpmm_niw_master_pairs copies them out)
         HIPCHK(c, launch_niw_master_posterior_pairs(c->ma, c->d_jobs, K, c->d_out, sm, c->d_apairs, napairs, c->h_apairs, c->stream));
         c->apairs_index.clear();
         for (int p = 0; p < napairs; ++p) c->apairs_index[((uint32_t)c->apairs_req[2 * p] << 16) | (uint32_t)c->apairs_req[2 * p + 1]] = p;
@@ -1927,7 +1974,9 @@ int dpmm_step_master_device(dpmm_ctx *c, uint32_t reset_epoch, const int32_t *sl
         c->apairs_inflight = false; c->apairs_valid = true;      // (the host waits for ev_master below: the records are there when it returns)
         c->apairs_req.clear();
     } else HIPCHK(c, launch_niw_master_posterior(c->ma, c->d_jobs, K, c->d_out, sm, c->stream));
-    HIPCHK(c, hipEventRecord(c->ev_master, c->stream));
+    const bool fused_pairs_launched = napairs > 0 && fuse_pairs;
+    const bool need_event = !poll || (napairs > 0 && !fuse_pairs);      // (the second stream's pair job waits for the posteriors through it)
+    if (need_event) HIPCHK(c, hipEventRecord(c->ev_master, c->stream));
     if (napairs > 0 && !fuse_pairs) {
         // The pooled pair log-determinants the master may ask for after its split decisions (dpmm_niw_master_pairs_ahead): they need the
         // stored rows of this pass only, so they run on the second stream while the host works; dpmm_niw_master_pairs answers from
@@ -1960,7 +2009,8 @@ int dpmm_step_master_device(dpmm_ctx *c, uint32_t reset_epoch, const int32_t *sl
         c->spec_slots.assign(slots, slots + K);
     }
     if (int rc = flush_undo(c)) return rc;      // (behind the posteriors, the event and the draws launched ahead)
-    HIPCHK(c, sync_event(c, c->ev_master));
+    if (poll) { if (int rc = wait_master_records(c, sm, 3 * (int64_t)K, c->h_apairs, fused_pairs_launched ? napairs : 0)) return rc; }
+    else HIPCHK(c, sync_event(c, c->ev_master));
     if (master_marks_left(sm, K)) {
         ++c->dbg_early_wait;
         const auto t0 = std::chrono::steady_clock::now();
@@ -2043,10 +2093,12 @@ int dpmm_niw_master_draw(dpmm_ctx *c, uint32_t epoch, int K, const int32_t *slot
     NiwMasterArgs ma = c->ma;
     ma.mu_draw = c->d_mu_draw[c->draw_cur];
     const bool normals = !ahead && noise_ready(c, epoch, K, c->draw_cur);       // (noise_join above made the main stream wait for them)
-    HIPCHK(c, launch_niw_master_draw(ma, hs, K, epoch, c->d_Y[c->draw_cur], c->d_ld_sigma[c->draw_cur], hlr, hw, c->d_Rp, c->d_mup, c->d_cst,
-                                     c->have_tail ? c->d_tail : nullptr, c->NB, c->d_work, ahead ? 2 : (normals ? 7 : 3), c->stream));
     c->predictive = false;              // (before the tables, as in set_params)
-    if (int rc = direction_tables(c, K)) return rc;
+    // DPMM_OPT_CHAIN_FUSION bit 2: the hand-over partitioned by role, with the three-plane images in the same launch (no niw_b3_pack launch)
+    const bool roles = (c->opt_chain & 2) != 0, b3_in_pack = roles && want_b3_images(c);
+    HIPCHK(c, launch_niw_master_draw(ma, hs, K, epoch, c->d_Y[c->draw_cur], c->d_ld_sigma[c->draw_cur], hlr, hw, c->d_Rp, c->d_mup, c->d_cst,
+                                     c->have_tail ? c->d_tail : nullptr, c->NB, c->d_work, (ahead ? 2 : (normals ? 7 : 3)) | (roles ? 8 : 0) | (b3_in_pack ? 16 : 0), c->stream));
+    if (int rc = direction_tables(c, K, b3_in_pack)) return rc;
     // The normals of the NEXT draws (epoch + 1, a few clusters more than now for the splits in between) into the other buffer, on the
     // second stream: they depend on nothing the master decides, and run beside the sweep instead of in front of it.  Whoever draws
     // with another epoch, or for more clusters, generates its own.
@@ -2605,6 +2657,8 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
         case DPMM_OPT_REF_BRACKET: c->opt_bracket = value != 0; return DPMM_OK;
         case DPMM_OPT_COMM_TIMEOUT_MS: c->comm_timeout_ms = value > 0 ? (int)std::min(value, 2.0e9) : 0; return DPMM_OK;
         case DPMM_OPT_BF16_SCREENS: c->opt_bf16scr = value != 0; return DPMM_OK;
+        case DPMM_OPT_MASTER_POLL: c->opt_master_poll = value != 0; return DPMM_OK;
+        case DPMM_OPT_CHAIN_FUSION: c->opt_chain = value < 0 ? 0x7fffffff : (int)value; return DPMM_OK;
         case DPMM_OPT_LEAN_TILES: c->opt_lean = value != 0; c->lean_off = 0; c->lean_backoff = 15; c->lean_ran = false; return DPMM_OK;
         case DPMM_OPT_B3_SUBLABELS: c->opt_b3 = value != 0; if (!c->opt_b3) c->have_b3 = false; return DPMM_OK;      // (switching it ON takes effect with the next parameter set: its images are packed behind the parameters)
         case DPMM_OPT_DIRECTION_SCREEN:

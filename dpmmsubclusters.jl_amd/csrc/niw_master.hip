@@ -702,6 +702,144 @@ __global__ void niw_master_pack_kernel(const double *__restrict__ Yall, const fl
     }
 }
 
+// The same hand-over with the work PARTITIONED OVER WORKGROUPS BY ROLE (round 6, DPMM_OPT_CHAIN_FUSION bit 2) + the three-plane images and
+// offsets of the sub-cluster factors (niw_b3_pack_kernel's job, niw_lean.hip) in the same launch.  niw_master_pack_kernel walks its outputs
+// one grid-stride loop after the other: a thread pays the latency of every loop in turn (9.5 us for a few hundred kilobytes), and the images
+// followed in a launch of their own (5 us, the launch floor).  Here a workgroup has ONE role -- fragment images | constants, means, tail and
+// ball records | bracket images | three-plane images | offsets -- and the roles run side by side: one latency chain instead of five and one
+// launch instead of two.  Values: every output is computed from the same Float64 factors by the same expressions (the three-plane images and
+// offsets from (float)Y as niw_b3_pack_kernel computes them from the Float32 fragment image that holds exactly those floats; the offsets'
+// Float64 sums in the same order: four 16-column partial sums per row, combined by two butterfly steps).
+struct PackRoles { int first[6]; };      // role r owns workgroups [first[r], first[r + 1])
+__global__ __launch_bounds__(256) void niw_master_pack_roles_kernel(const double *__restrict__ Yall, const float *__restrict__ mu_draw, const float *__restrict__ logdet_sigma,
+                                                                    const float *__restrict__ lr, const float *__restrict__ wts, float *__restrict__ Rp,
+                                                                    float *__restrict__ mup, float *__restrict__ cst, float *__restrict__ tail, int D, int DPm, int NB,
+                                                                    int nmat, unsigned long long *__restrict__ work, PackRoles R, int with_b3) {
+    const int NP = NB * (NB + 1) / 2;
+    const int DP = 16 * NB;
+    const int K = nmat / 3;
+    int role = 0;
+    while (role < 4 && (int)blockIdx.x >= R.first[role + 1]) ++role;
+    const int64_t t0 = ((int64_t)blockIdx.x - R.first[role]) * 256 + threadIdx.x, stride = (int64_t)(R.first[role + 1] - R.first[role]) * 256;
+    auto Rel = [&](int64_t j, int row, int col) -> float {          // R[row][col] of matrix j as the sweep's Float32 (0 outside the upper triangle / beyond D)
+        return (row < D && col < D && col >= row) ? (float)Yall[j * DPm * DPm + (int64_t)col * DPm + row] : 0.f;
+    };
+    if (role == 0) {                       // the Float32 fragment images: four consecutive columns of one row per thread, one 16-byte store
+        const int64_t total4 = (int64_t)nmat * NP * 64;
+        for (int64_t u = t0; u < total4; u += stride) {
+            const int lane = (int)(u & 63);
+            const int64_t pj = u >> 6;
+            const int pair = (int)(pj % NP);
+            const int64_t j = pj / NP;
+            int bi = 0, rem = pair;
+            while (rem >= NB - bi) { rem -= NB - bi; ++bi; }
+            const int t = bi + rem;
+            const int row = 16 * bi + (lane & 15), col = 16 * t + 4 * (lane >> 4);
+            float4 v;
+            v.x = Rel(j, row, col); v.y = Rel(j, row, col + 1); v.z = Rel(j, row, col + 2); v.w = Rel(j, row, col + 3);
+            reinterpret_cast<float4 *>(Rp)[u] = v;
+        }
+        return;
+    }
+    if (role == 1) {                       // constants | padded means | tail pair records | ball records: ONE index space, one item per thread and trip
+        if (work && t0 < 8) { work[t0] = 0ull; work[8 + 16 * t0] = 0ull; }     // counters / queue heads of the next sweep
+        const bool tl = tail && D >= 4;
+        const int f0 = D - 4, NPR = (K + 1) / 2;
+        const int64_t n0 = nmat, n1 = n0 + (int64_t)nmat * DP, n2 = n1 + (tl ? (int64_t)NPR * 32 : 0), n3 = n2 + (tl ? (int64_t)K * 16 : 0);
+        const int tr[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3}, tc[10] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3};
+        for (int64_t i = t0; i < n3; i += stride) {
+            if (i < n0) {
+                const int k = (int)(i / 3), w = (int)(i % 3);
+                const float lw = w == 0 ? logf(wts[k]) : logf(lr[2 * k + (w - 1)]);
+                cst[i] = -0.5f * logdet_sigma[i] + lw;
+            } else if (i < n1) {
+                const int64_t e = i - n0;
+                const int d = (int)(e % DP);
+                const int64_t j = e / DP;
+                mup[e] = d < D ? mu_draw[j * DPm + d] : 0.f;
+            } else if (i < n2) {
+                const int64_t e = i - n1;
+                const int c = (int)(e & 1), q = (int)((e >> 1) & 15), k = 2 * (int)(e >> 5) + c;
+                const int64_t j = k < K ? 3 * k : 0;
+                float v = 0.f;
+                if (k >= K) v = (q == 14) ? -INFINITY : 0.f;
+                else if (q < 10) v = (float)Yall[j * DPm * DPm + (int64_t)(f0 + tc[q]) * DPm + (f0 + tr[q])];
+                else if (q < 14) v = mu_draw[j * DPm + f0 + (q - 10)];
+                else if (q == 14) v = -0.5f * logdet_sigma[j] + logf(wts[k]);
+                tail[e] = v;
+            } else {
+                const int64_t e = i - n2;
+                float *ball = tail + 32 * NPR;
+                const int q = (int)(e & 15), k = (int)(e >> 4);
+                const int64_t j = 3 * (int64_t)k;
+                float v;
+                if (q < 4) v = mu_draw[j * DPm + f0 + q];
+                else if (q < 14) v = (float)Yall[j * DPm * DPm + (int64_t)(f0 + tc[q - 4]) * DPm + (f0 + tr[q - 4])];
+                else if (q == 14) {
+                    float t10[10];
+#pragma unroll
+                    for (int ii = 0; ii < 10; ++ii) t10[ii] = (float)Yall[j * DPm * DPm + (int64_t)(f0 + tc[ii]) * DPm + (f0 + tr[ii])];
+                    v = tail_opnorm_bound(t10);
+                } else v = -0.5f * logdet_sigma[j] + logf(wts[k]);
+                ball[e] = v;
+            }
+        }
+        return;
+    }
+    if (!(tail && D >= 4 && NB == 4)) return;
+    const int NPR = (K + 1) / 2;
+    float *ball = tail + 32 * NPR;
+    uint32_t *refb = reinterpret_cast<uint32_t *>(ball + 16 * (size_t)K);
+    if (role == 2) {                       // bf16 image of the cluster-level factors (reference bracket)
+        for (int64_t e = t0; e < (int64_t)K * REFB_WORDS; e += stride) {
+            const int64_t j = 3 * (e / REFB_WORDS);
+            int row, c0, c1;
+            refb_map((int)(e % REFB_WORDS), row, c0, c1);
+            refb[e] = bf16_rne_bits(Rel(j, row, c0)) | (bf16_rne_bits(Rel(j, row, c1)) << 16);
+        }
+        return;
+    }
+    if (!with_b3) return;
+    uint32_t *img = refb + (size_t)K * REFB_WORDS;                                         // = b3_images(tail, K)
+    float *dvec = reinterpret_cast<float *>(img + (size_t)3 * K * B3_WORDS);              // = b3_offsets(tail, K)
+    if (role == 3) {                       // the three planes of the 2K sub-cluster factors: one element pair -> three dwords
+        for (int64_t i = t0; i < (int64_t)2 * K * REFB_WORDS; i += stride) {
+            const int e = (int)(i % REFB_WORDS);
+            const int64_t m = i / REFB_WORDS, j = 3 * (m >> 1) + 1 + (m & 1);
+            int row, c0, c1;
+            refb_map(e, row, c0, c1);
+            const float v0 = Rel(j, row, c0), v1 = Rel(j, row, c1);
+            uint32_t *out = img + (size_t)j * B3_WORDS + e;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) out[(size_t)p * REFB_WORDS] = bf16x3_plane_bits(v0, p) | (bf16x3_plane_bits(v1, p) << 16);
+        }
+        return;
+    }
+    // role 4: the offsets d = R_s (mu_k - mu_s), Float64: four threads per row (16 columns each), the order of niw_b3_pack_kernel
+    const int64_t nd = (int64_t)2 * K * 256;
+    for (int64_t i0 = t0 - (threadIdx.x & 63); i0 < nd; i0 += stride) {          // (wave-uniform trip count: the butterfly needs its four lanes)
+        const int64_t i = i0 + (threadIdx.x & 63);
+        const bool on = i < nd;
+        const int part = (int)(i & 3), row = (int)((i >> 2) & 63);
+        const int64_t m = on ? (i >> 8) : 0, k = m >> 1, j = 3 * k + 1 + (m & 1);
+        double rv[16], dm[16];
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) {                                          // all sixteen loads of a thread in flight at once
+            const int c = 16 * part + cc;
+            rv[cc] = (double)Rel(j, row, c);
+            const float mk = c < D ? mu_draw[3 * k * DPm + c] : 0.f, ms = c < D ? mu_draw[j * DPm + c] : 0.f;
+            dm[cc] = (double)mk - (double)ms;
+        }
+        double acc = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc)
+            if (16 * part + cc >= row) acc += rv[cc] * dm[cc];
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        if (on && part == 0) dvec[(size_t)j * B3_DVEC + row] = (float)acc;
+    }
+}
+
 // Pooled statistics of cluster pairs for the merge proposals (shared_actions.jl:21-27): job p pools the four stored rows of slots
 // pairs[2p], pairs[2p+1]; P = nu' psi' of the pooled set -> scratch matrix p; small[NS p + {0,1,2,4}] = N, kappa', nu', log Gamma_D(nu' / 2).
 __global__ __launch_bounds__(256) void niw_form_pair_kernel(NiwMasterArgs A, const int32_t *__restrict__ pairs, double *__restrict__ scratch,
@@ -1107,7 +1245,23 @@ hipError_t launch_niw_master_draw(const NiwMasterArgs &a, const int32_t *slot_of
         attr = true;
     }
     if (what & 1) DPMM_LAUNCH(niw_draw_kernel, dim3(3 * K), dim3(256), niw_master_lds_bytes(a.DP), s, a, slot_of_cluster, epoch, Y, logdet_sigma, (what & 4) ? 1 : 0);
-    if (what & 2) DPMM_LAUNCH(niw_master_pack_kernel, dim3(512), dim3(256), 0, s, Y, a.mu_draw, logdet_sigma, lr, wts, Rp, mup, cst, tail, a.D, a.DP, NB,
+    if ((what & 2) && (what & 8)) {
+        // the hand-over partitioned by role (+ the three-plane images when what & 16): workgroups per role from the number of items
+        const int nmat = 3 * K, NP = NB * (NB + 1) / 2, DPs = 16 * NB;
+        const bool tl = tail != nullptr && a.D >= 4;
+        auto blocks = [](int64_t items, int cap) -> int { return (int)std::max<int64_t>(1, std::min<int64_t>((items + 255) / 256, cap)); };
+        PackRoles R;
+        R.first[0] = 0;
+        R.first[1] = R.first[0] + blocks((int64_t)nmat * NP * 64, 2048);
+        R.first[2] = R.first[1] + blocks((int64_t)nmat * (1 + DPs) + (tl ? (int64_t)((K + 1) / 2) * 32 + (int64_t)K * 16 : 0), 512);
+        const bool img = tl && NB == 4;
+        R.first[3] = R.first[2] + (img ? blocks((int64_t)K * REFB_WORDS, 1024) : 0);
+        const bool b3 = img && (what & 16);
+        R.first[4] = R.first[3] + (b3 ? blocks((int64_t)2 * K * REFB_WORDS, 2048) : 0);
+        R.first[5] = R.first[4] + (b3 ? blocks((int64_t)2 * K * 256, 256) : 0);
+        DPMM_LAUNCH(niw_master_pack_roles_kernel, dim3(R.first[5]), dim3(256), 0, s, Y, a.mu_draw, logdet_sigma, lr, wts, Rp, mup, cst, tail, a.D, a.DP, NB,
+                    nmat, work, R, b3 ? 1 : 0);
+    } else if (what & 2) DPMM_LAUNCH(niw_master_pack_kernel, dim3(512), dim3(256), 0, s, Y, a.mu_draw, logdet_sigma, lr, wts, Rp, mup, cst, tail, a.D, a.DP, NB,
                                      3 * K, work);
     return hipGetLastError();
 }

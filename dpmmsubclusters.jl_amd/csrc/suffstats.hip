@@ -338,15 +338,67 @@ __global__ __launch_bounds__(256) void starts_step_kernel(int32_t *bin_total, ui
     starts_body(bin_total, bin_sel, nbins, chunk, bin_start, item_start, perm_total, part, pb);
 }
 
-template <int TILE>
+// STEP (the per-step pass, round 6): the starts of starts_step_kernel are computed HERE -- every tile's wave forms the exclusive prefix of the
+// 2K bin totals itself (one wave-level scan per 64 bins: K = 32 is one), workgroup 0 also publishes what the later launches read (bin_start,
+// item_start, perm_total, the statistics' bin selection and modes) and clears the histogram's running totals for the next pass.  One launch
+// less in the chain sweep -> statistics (4.6 us at its latency floor, whatever n).  Same values: integer prefix sums.
+struct StepStarts {
+    const int32_t *bin_total; uint8_t *bin_sel; int chunk; int32_t *bin_start_out; int32_t *item_start; int32_t *perm_total; int32_t *fast_total;
+    uint8_t *mode; const uint8_t *dirty; int force_all;
+};
+template <int TILE, bool STEP>
 __global__ __launch_bounds__(64) void scatter_kernel(const int32_t *__restrict__ bins, int64_t n, int nbins, int nt,
                                                      const int32_t *__restrict__ tile_hist,
-                                                     const int32_t *__restrict__ bin_start, int32_t *__restrict__ perm) {
+                                                     const int32_t *__restrict__ bin_start, int32_t *__restrict__ perm, StepStarts st) {
     extern __shared__ int base[];
     const int lane = threadIdx.x;
     int nbits = 0;
     while ((1 << nbits) < nbins) ++nbits;
-    for (int b = lane; b < nbins; b += 64) base[b] = bin_start[b] + tile_hist[(int64_t)b * nt + blockIdx.x];
+    if constexpr (STEP) {
+        const bool pub = blockIdx.x == 0;
+        const bool all = pub && st.mode && (st.force_all || st.dirty[DPMM_MAX_CLUSTERS_K]);
+        int carry = 0, icarry = 0;
+        for (int b0 = 0; b0 < nbins; b0 += 64) {
+            const int b = b0 + lane;
+            const int t = b < nbins ? st.bin_total[b] : 0;
+            int inc = t;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off); if (lane >= off) inc += v; }
+            const int excl = carry + inc - t;
+            if (b < nbins) base[b] = excl + tile_hist[(int64_t)b * nt + blockIdx.x];
+            carry += __shfl(inc, 63);
+            if (pub) {
+                int sel = 0;
+                if (b < nbins) {
+                    if (st.mode) {
+                        const int k = b >> 1;
+                        const int nl = st.bin_total[2 * k], nr = st.bin_total[2 * k + 1];
+                        const int m = (all || st.dirty[k] || nl + nr == 0) ? 0 : (nl <= nr ? 2 : 1);
+                        sel = (b & 1) ? (m != 2) : (m != 1);
+                        if (!(b & 1)) st.mode[k] = (uint8_t)m;
+                        st.bin_sel[b] = (uint8_t)sel;
+                    } else sel = st.bin_sel[b];
+                }
+                const int items = sel ? (t + st.chunk - 1) / st.chunk : 0;
+                int iinc = items;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(iinc, off); if (lane >= off) iinc += v; }
+                if (b < nbins) {
+                    st.bin_start_out[b] = excl;
+                    st.item_start[b] = icarry + iinc - items;
+                    if (st.fast_total) st.fast_total[b * FAST_TOTAL_STRIDE] = 0;
+                }
+                icarry += __shfl(iinc, 63);
+            }
+        }
+        if (pub && lane == 0) {
+            st.bin_start_out[nbins] = carry;
+            st.item_start[nbins] = icarry;
+            if (st.perm_total) *st.perm_total = carry;
+        }
+    } else {
+        for (int b = lane; b < nbins; b += 64) base[b] = bin_start[b] + tile_hist[(int64_t)b * nt + blockIdx.x];
+    }
     __syncthreads();
     const int64_t tbase = (int64_t)blockIdx.x * TILE;
     // all loads of the tile in flight before the first is used (one wave per tile: a load per trip would serialise 32 latencies)
@@ -1174,13 +1226,22 @@ hipError_t launch_mult_stats(const StatsArgs &a, hipStream_t s) {
 
 // second half of the sort (needs the selection mask and the chunk size of the statistics pass)
 static void launch_scatter(const int32_t *bins, const StatsArgs &a, int nt, hipStream_t s) {
+    const StepStarts none{};
     DPMM_TILE_DISPATCH(a.sb.tile,
-        DPMM_LAUNCH(scatter_kernel<512>, dim3(nt), dim3(64), a.nbins * sizeof(int), s, bins, a.n, a.nbins, nt, a.sb.tile_hist, a.sb.bin_start, a.sb.perm),
-        DPMM_LAUNCH(scatter_kernel<2048>, dim3(nt), dim3(64), a.nbins * sizeof(int), s, bins, a.n, a.nbins, nt, a.sb.tile_hist, a.sb.bin_start, a.sb.perm));
+        DPMM_LAUNCH((scatter_kernel<512, false>), dim3(nt), dim3(64), a.nbins * sizeof(int), s, bins, a.n, a.nbins, nt, a.sb.tile_hist, a.sb.bin_start, a.sb.perm, none),
+        DPMM_LAUNCH((scatter_kernel<2048, false>), dim3(nt), dim3(64), a.nbins * sizeof(int), s, bins, a.n, a.nbins, nt, a.sb.tile_hist, a.sb.bin_start, a.sb.perm, none));
 }
-hipError_t launch_step_scan_scatter(const int32_t *bins, const StatsArgs &a, int derive, int force_all, hipStream_t s) {
+hipError_t launch_step_scan_scatter(const int32_t *bins, const StatsArgs &a, int derive, int force_all, int fused_starts, hipStream_t s) {
     const int nt = sort_nt(a.n, a.sb);
     DPMM_LAUNCH(scan_tiles_kernel, dim3(a.nbins), dim3(256), 0, s, a.sb.tile_cnt, a.sb.tile_hist, nt, a.sb.bin_total);
+    if (fused_starts && nt > 0) {          // the starts inside the scatter launch (StepStarts above)
+        const StepStarts st{a.sb.bin_total, a.sb.bin_sel, a.chunk, a.sb.bin_start, a.sb.item_start, a.sb.perm_total, a.sb.fast_total,
+                            derive ? a.sb.cmode : (uint8_t *)nullptr, a.sb.cdirty, force_all};
+        DPMM_TILE_DISPATCH(a.sb.tile,
+            DPMM_LAUNCH((scatter_kernel<512, true>), dim3(nt), dim3(64), a.nbins * sizeof(int), s, bins, a.n, a.nbins, nt, a.sb.tile_hist, a.sb.bin_start, a.sb.perm, st),
+            DPMM_LAUNCH((scatter_kernel<2048, true>), dim3(nt), dim3(64), a.nbins * sizeof(int), s, bins, a.n, a.nbins, nt, a.sb.tile_hist, a.sb.bin_start, a.sb.perm, st));
+        return hipGetLastError();
+    }
     DPMM_LAUNCH(starts_step_kernel, dim3(1), dim3(256), 0, s, a.sb.bin_total, a.sb.bin_sel, a.nbins, a.chunk, a.sb.bin_start, a.sb.item_start,
                 a.sb.perm_total, a.sb.fast_total, derive ? a.sb.cmode : (uint8_t *)nullptr, a.sb.cdirty, force_all);
     launch_scatter(bins, a, nt, s);

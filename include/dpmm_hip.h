@@ -98,6 +98,12 @@ enum {
                                          0: every tile through the sweep kernel (labels) and niw_sub_kernel (sub-labels).
                                          A sweep that hands on more than 30 % of its tiles switches the lean launch off for 15 sweeps (31, 63, ... up to 1023 while the
                                          retries keep failing); it also stays off while the direction screen's regime is on and beyond 64 clusters (scalar pre-screen). */
+    DPMM_OPT_MASTER_POLL = 28,        /* 1 (default, round 6): dpmm_step_master_device waits on the posteriors' own records in pinned host memory (every record starts as a
+                                         marker no kernel produces) instead of on an event: no barrier packet between the posteriors and the draws launched behind them.
+                                         0: the event wait of rounds 3-5.  Same values either way. */
+    DPMM_OPT_CHAIN_FUSION = 29,       /* bit mask (default: all; round 6): launches of the n-independent chain of a step folded into their neighbours --
+                                         1: the sort's bin / item starts inside the scatter launch (no starts_step launch); 2: the three-plane sub-cluster images
+                                         written by the launch that packs the parameters (no niw_b3_pack launch).  0: the launches of round 5.  Same values. */
     DPMM_OPT_MULT_DRAWS_AHEAD = 25,   /* 1 (default): Multinomial device master: dpmm_step_stats launches the NEXT Dirichlet draws and their hand-over images
                                        * behind the statistics (the epoch after the last dpmm_mult_master_draw, the same K and outlier flag), into a second set of
                                        * buffers, and returns when the rows are on the host -- the draws run while the caller decides splits and merges.

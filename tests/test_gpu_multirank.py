@@ -210,7 +210,10 @@ def test_bench_starts_its_own_ranks_and_reports_the_collective(tmp_path):
                        env=env, capture_output=True, text=True, timeout=800)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
-    d = json.loads(line)
+    short = json.loads(line)                               # the contract line: compact, with the collective's summary
+    assert len(line) < 4096 and short["n_gpus"] == 2 and short["comm"]["world"] == 2 and short["comm"]["allreduces_per_step"] == 1.0
+    d = json.loads([ln for ln in r.stderr.splitlines() if ln.startswith("bench.py details: ")][-1][len("bench.py details: "):])      # everything the run measured
+    assert d["value"] == short["value"]
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
     assert d["comm"]["world"] == 2 and d["comm"]["transport"] == ("host" if share else "rccl")
     assert d["comm"]["rows_allreduce_bytes"] == 3 * 32 * (1 + 64 + 64 * 65 // 2) * 8 and d["comm"]["rows_allreduce_ms"] > 0
@@ -231,7 +234,9 @@ def test_bench_with_eight_ranks_on_one_gpu(tmp_path):
                         "--settle", "5", "--blocks", "1", "--no-legs", "--no-cpu-baseline", "--no-dense", "--growth-iters", "40"],
                        env=env, capture_output=True, text=True, timeout=1400)
     assert r.returncode == 0, r.stderr[-2000:]
-    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    short = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert short["n_gpus"] == 8 and short["comm"]["world"] == 8
+    d = json.loads([ln for ln in r.stderr.splitlines() if ln.startswith("bench.py details: ")][-1][len("bench.py details: "):])
     assert d["n_gpus"] == 8 and d["value"] > 0 and d["comm"]["world"] == 8 and d["comm"]["transport"] == "host"
     assert d["config"]["points_per_gpu"] == 100000 and d["growth"]["K_final"] >= 2 and d["host_master"]["it_per_s"] > 0
 

@@ -829,6 +829,50 @@ def test_a_predictive_table_in_between_does_not_change_the_chain(pkg):
     assert np.array_equal(out[0][2], out[1][2])
 
 
+@pytest.mark.parametrize("D,N,K,var", [(64, 120000, 10, 100.0), (64, 90000, 6, 2.0), (48, 60000, 5, 50.0), (16, 50000, 4, 50.0), (128, 40000, 4, 100.0)])
+def test_folded_launches_and_the_polling_wait_are_the_same_chain(pkg, D, N, K, var):
+    """Round 6: the n-independent chain of a step lost launches -- the sort's starts inside the scatter launch, the three-plane images inside the
+    hand-over launch (workgroups partitioned by role), no event between the posteriors and the draws launched ahead (the host waits on the
+    posteriors' own records in pinned memory).  Each is value-neutral: 25 group_steps from ONE cluster (splits, merges, bad-cluster resets,
+    subset passes) with everything on, with DPMM_OPT_CHAIN_FUSION = 0 and with DPMM_OPT_MASTER_POLL = 0 -- K history, labels and sub-labels equal
+    at every checkpoint, and the sub-cluster values the next sweep would draw from (dpmm_debug_subloglik: written by the folded launch in one
+    run, by niw_b3_pack_kernel in the other) equal bit for bit."""
+    import importlib
+    from dpmmsubclusters_jl_amd import binding
+    host = importlib.import_module("dpmmsubclusters_jl_amd.host")
+    X, y = host.gaussian_mixture_shard(N, D, K, var, 500 + D, 0, N)
+    prior = host.niw_hyperparams(1.0, np.zeros(D), D + 3, np.eye(D))
+    out = {}
+    for name, opts in (("all", ()), ("unfused", ((binding.OPT_CHAIN_FUSION, 0),)), ("event", ((binding.OPT_MASTER_POLL, 0),)),
+                       ("round5", ((binding.OPT_CHAIN_FUSION, 0), (binding.OPT_MASTER_POLL, 0)))):
+        wk = pkg.Worker(pkg.PRIOR_NIW, D, N, device=0, seed=3)
+        wk.upload_points(X)
+        for o, v in opts:
+            wk.set_option(o, v)
+        s = host.DPMMSampler(wk, prior, 10.0, N, 3, burnout=5)
+        s.init_first_clusters(1)
+        ks, snaps = [], []
+        for it in range(25):
+            s.group_step(False, False)
+            ks.append(s.K)
+            if it % 8 == 7:
+                snaps.append(wk.get_labels())
+        tab = None
+        if D <= 64:
+            s.sample_clusters()                  # a parameter set for the CURRENT clusters (the last step may have changed K)
+            wk.K = s.K
+            tab = wk.debug_subloglik()
+        out[name] = (ks, snaps, tab)
+        wk.close()
+    print("K history:", out["all"][0])
+    for name in ("unfused", "event", "round5"):
+        assert out[name][0] == out["all"][0], name
+        for a, b in zip(out[name][1], out["all"][1]):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), name
+        if out["all"][2] is not None:
+            assert np.array_equal(out[name][2], out["all"][2], equal_nan=True), name
+
+
 def test_lean_tiles_behind_whole_bin_relabels(pkg):
     """niw_lean_kernel aligns its tiles to the bins of the LAST sort; between that sort and the sweep the master relabels whole bins: a split moves
     (k, right) to a new cluster K + 1 (local_clusters_actions.jl:265-278), a merge folds cluster b into a (:293-304), remove-empty renumbers
