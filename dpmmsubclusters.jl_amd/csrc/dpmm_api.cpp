@@ -188,6 +188,7 @@ struct dpmm_ctx {
     int32_t *d_apairs = nullptr;                            // [2 cap] slot pairs of the launch-ahead job
     size_t apairs_cap = 0;
     std::vector<int32_t> apairs_shadow;
+    int32_t *h_apairs_list[2] = {nullptr, nullptr}; size_t h_apairs_list_cap[2] = {0, 0}; int apairs_pin_flip = 0; const int32_t *apairs_pinned_cur = nullptr;      // the fused pair jobs' list in pinned memory (DPMM_OPT_CHAIN_FUSION bit 4)
     double *h_apairs = nullptr;                             // pinned [cap][DPMM_MASTER_NSCALARS]
     bool apairs_inflight = false, apairs_valid = false;     // main stream has not waited for ev_pairs yet / the records answer dpmm_niw_master_pairs
     std::unordered_map<uint32_t, int> apairs_index;         // (slot_i << 16 | slot_j) -> record
@@ -239,7 +240,7 @@ struct dpmm_ctx {
     int sp_cooldown = 0;               // parameter sets the screen stays off after it removed less than a quarter of what it was given
     int opt_b3 = 1;                    // DPMM_OPT_B3_SUBLABELS: D in 33..64: sub-cluster evaluations through three-plane bf16 images, in kernels of their own (niw_lean.hip)
     bool have_b3 = false;              // the images behind the bracket's in d_tail belong to the parameter set on the device
-    int opt_chain = 0x7fffffff;        // DPMM_OPT_CHAIN_FUSION (bit mask): 1 = the sort's starts inside the scatter launch; 2 = the three-plane images in the hand-over launch
+    int opt_chain = 0x7fffffff;        // DPMM_OPT_CHAIN_FUSION (bit mask): 1 = the sort's starts inside the scatter launch; 2 = the three-plane images in the hand-over launch; 4 = the fused pair jobs' list read from pinned memory; 8 = the bad-cluster reset counted ahead by the histogram and applied by the scatter (no reset launch); 16 = the draws' normals generated inside the posteriors' launch
     int opt_master_poll = 1;           // DPMM_OPT_MASTER_POLL: dpmm_step_master_device waits on the posteriors' own records in pinned memory (no event between posteriors and draws)
     int opt_lean = 1;                  // DPMM_OPT_LEAN_TILES: tiles the cheap screens settle completely in niw_lean_kernel (-1 automatic is 1 with a regime switch; 0 never)
     uint32_t *d_hard = nullptr;        // two lists of [2 + ceil(n / 64)] words, taking turns (hard_flip): count | wave tiles the lean kernel left to the general path;
@@ -625,6 +626,7 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
     const size_t nbmax = 2 * DPMM_MAX_CLUSTERS;
     CHK_CREATE(hipMalloc(&c->sb.tile_hist, sizeof(int32_t) * nbmax * (size_t)std::max(1, c->nt_sort)));
     CHK_CREATE(hipMalloc(&c->sb.tile_cnt, sizeof(int32_t) * nbmax * (size_t)std::max(1, c->nt_sort)));
+    CHK_CREATE(hipMalloc(&c->sb.tile_spec, sizeof(int32_t) * (size_t)STEP_SPEC_MAX_BINS * (size_t)std::max(1, c->nt_sort)));
     CHK_CREATE(hipMalloc(&c->sb.fast_total, sizeof(int32_t) * nbmax * FAST_TOTAL_STRIDE));
     CHK_CREATE(hipMemsetAsync(c->sb.fast_total, 0, sizeof(int32_t) * nbmax * FAST_TOTAL_STRIDE, c->stream));
     CHK_CREATE(hipMalloc(&c->sb.ticket, sizeof(unsigned)));
@@ -673,7 +675,7 @@ int dpmm_destroy(dpmm_ctx *c) {
     if (c->stream && !c->comm_aborted.load()) hipStreamSynchronize(c->stream);
     free_params(c);
     hipFree(c->dX); hipFree(c->dX8); hipFree(c->dbins); hipFree(c->d_gt); hipFree(c->d_cont);
-    hipFree(c->sb.tile_hist); hipFree(c->sb.tile_cnt); hipFree(c->sb.fast_total); hipFree(c->sb.ticket); hipFree(c->sb.prev_lab); hipFree(c->sb.cdirty); hipFree(c->sb.cmode); hipFree(c->sb.bin_total); hipFree(c->sb.bin_start); hipFree(c->sb.item_start);
+    hipFree(c->sb.tile_hist); hipFree(c->sb.tile_cnt); hipFree(c->sb.tile_spec); hipFree(c->sb.fast_total); hipFree(c->sb.ticket); hipFree(c->sb.prev_lab); hipFree(c->sb.cdirty); hipFree(c->sb.cmode); hipFree(c->sb.bin_total); hipFree(c->sb.bin_start); hipFree(c->sb.item_start);
     hipFree(c->sb.perm); hipFree(c->sb.bin_sel); hipFree(c->sb.perm_total); hipFree(c->d_small); hipFree(c->d_proj); hipFree(c->d_vals); hipFree(c->d_smart);
     hipFree(c->d_m0); hipFree(c->d_psi_lo); hipFree(c->d_pairs);
     for (int i = 0; i < 2; ++i) { hipFree(c->d_Y[i]); hipFree(c->d_ld_sigma[i]); hipFree(c->d_mu_draw[i]); }
@@ -687,6 +689,7 @@ int dpmm_destroy(dpmm_ctx *c) {
     if (c->ev_rows) hipEventDestroy(c->ev_rows);
     hipFree(c->d_apairs);
     if (c->h_apairs) hipHostFree(c->h_apairs);
+    for (auto &b : c->h_apairs_list) if (b) hipHostFree(b);
     hipFree(c->d_jobs); hipFree(c->d_dslots);
     for (int i = 0; i < 4; ++i) if (c->h_list[i]) hipHostFree(c->h_list[i]);
     if (c->h_master) hipHostFree(c->h_master);
@@ -1479,7 +1482,10 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
         // reset_bad_clusters! (local_clusters_actions.jl:501-516) on the device, four launches: histogram (+ running bin totals) ->
         // [occupancies summed over the ranks] -> flags + sub-labels of flagged clusters re-drawn + touched tiles re-counted -> scan + starts
         // -> scatter.  The flags live right behind the packed rows, so that rows + flags reach the master in one copy.
-        HIPCHK(c, launch_step_hist(c->dbins, c->n, nbins, c->sb, c->stream));
+        // DPMM_OPT_CHAIN_FUSION bit 8 (round 6): no reset launch -- the histogram counts the reset ahead for the clusters that are one-sided in a
+        // tile, the scan derives the flags and picks those counts for flagged clusters, the scatter applies the re-draw while it places
+        const bool fold_reset = (c->opt_chain & 8) != 0 && nbins <= STEP_SPEC_MAX_BINS && c->sb.tile_spec != nullptr;
+        HIPCHK(c, launch_step_hist(c->dbins, c->n, nbins, c->sb, c->stream, fold_reset ? 1 : 0, c->first, c->seed, reset_epoch));
         const long long *gc = nullptr;
         if (comm_attached(c) && !one_coll) {
             HIPCHK(c, launch_widen_counts(c->sb.fast_total, FAST_TOTAL_STRIDE, c->d_counts64, nbins, c->stream));
@@ -1488,12 +1494,13 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
         }
         uint8_t *flags = reinterpret_cast<uint8_t *>(c->d_out) + sizeof(double) * (size_t)nbins * (size_t)c->packed_stride;
         // (one collective: this shard's own occupancies decide which clusters are reset speculatively; the verdict follows the all-reduce)
-        HIPCHK(c, launch_step_reset(c->dbins, c->n, c->first, nbins, c->sb, gc, flags, c->K, c->seed, reset_epoch, one_coll ? c->d_cside : nullptr, c->stream));
+        if (!fold_reset) HIPCHK(c, launch_step_reset(c->dbins, c->n, c->first, nbins, c->sb, gc, flags, c->K, c->seed, reset_epoch, one_coll ? c->d_cside : nullptr, c->stream));
         // Statistics of the SMALLER sub-cluster only wherever no point entered or left the cluster since its cluster-level row was
         // cached (labels are tracked by the histogram); the other sub-cluster is cache - computed (derive_rows_kernel below)
         derive = c->opt_derive != 0;
         const int force_all = (c->cache_force || c->cache_K != c->K) ? 1 : 0;
-        HIPCHK(c, launch_step_scan_scatter(c->dbins, a, derive ? 1 : 0, force_all, c->opt_chain & 1, c->stream));
+        const StepReset rs{gc, flags, c->K, one_coll ? c->d_cside : nullptr, c->first, c->seed, reset_epoch};
+        HIPCHK(c, launch_step_scan_scatter(c->dbins, a, derive ? 1 : 0, force_all, c->opt_chain & 1, fold_reset ? &rs : nullptr, c->stream));
         if (derive) { c->sel_all_ones = 0; c->cache_force = false; c->cache_K = c->K; }
     } else {
         if (c->n > 0) {
@@ -1950,9 +1957,38 @@ int dpmm_step_master_device(dpmm_ctx *c, uint32_t reset_epoch, const int32_t *sl
                 kp[i] = inv[c->apairs_req[i]];
                 if (kp[i] < 0) { fuse_pairs = false; break; }
             }
-            if (fuse_pairs) { if (int rc = device_list(c, c->d_apairs, c->apairs_shadow, kp.data(), kp.size())) return rc; }
+            if (fuse_pairs) {
+                // The fused pair jobs read their two cluster indices straight from pinned host memory (round 6): the list changes whenever a merge
+                // gate opens or closes (a bad-cluster reset closes one: most steps of the bench chain), and the copy launch that brought it to the
+                // device sat on the main stream between the sweep and the statistics kernels (5 us).  Two buffers take turns: the launch that read
+                // the other one has been waited for (its records were) before a new list is written.
+                if (c->opt_chain & 4) {
+                    if (!(c->apairs_shadow.size() == kp.size() && memcmp(c->apairs_shadow.data(), kp.data(), sizeof(int32_t) * kp.size()) == 0) || !c->apairs_pinned_cur) {
+                        c->apairs_shadow.assign(kp.begin(), kp.end());
+                        c->apairs_pin_flip ^= 1;
+                        int32_t *&buf = c->h_apairs_list[c->apairs_pin_flip];
+                        size_t &cap = c->h_apairs_list_cap[c->apairs_pin_flip];
+                        if (kp.size() > cap) {
+                            if (buf) HIPCHK(c, hipHostFree(buf));
+                            buf = nullptr; cap = 0;
+                            size_t nc = 2048;
+                            while (nc < kp.size()) nc *= 2;
+                            HIPCHK(c, hipHostMalloc((void **)&buf, sizeof(int32_t) * nc, hipHostMallocDefault));
+                            cap = nc;
+                        }
+                        memcpy(buf, kp.data(), sizeof(int32_t) * kp.size());
+                        c->apairs_pinned_cur = buf;
+                    }
+                } else {
+                    if (c->apairs_pinned_cur) { c->apairs_shadow.clear(); c->apairs_pinned_cur = nullptr; }      // (the shadow described the pinned list, not d_apairs)
+                    if (int rc = device_list(c, c->d_apairs, c->apairs_shadow, kp.data(), kp.size())) return rc;
+                }
+            }
         } else fuse_pairs = false;
-        if (!fuse_pairs) if (int rc = device_list(c, c->d_apairs, c->apairs_shadow, c->apairs_req.data(), c->apairs_req.size(), c->stream2)) return rc;
+        if (!fuse_pairs) {
+            if (c->apairs_pinned_cur) { c->apairs_shadow.clear(); c->apairs_pinned_cur = nullptr; }
+            if (int rc = device_list(c, c->d_apairs, c->apairs_shadow, c->apairs_req.data(), c->apairs_req.size(), c->stream2)) return rc;
+        }
     } else fuse_pairs = false;
     double *sm = reinterpret_cast<double *>(c->h_master + jobs_bytes);
     // Witness of the event wait below: every scalar record the posteriors write starts out as a marker no kernel produces (a NaN with a
@@ -1963,17 +1999,30 @@ int dpmm_step_master_device(dpmm_ctx *c, uint32_t reset_epoch, const int32_t *sl
     bool flags_sent = false;
     if (int rc = run_stats(c, nullptr, 0, true, reset_epoch, reinterpret_cast<uint8_t *>(c->h_out), &flags_sent)) return rc;
     if (!flags_sent) HIPCHK(c, launch_copy_bytes(c->h_out, reinterpret_cast<const uint8_t *>(c->d_out) + out_bytes, (size_t)K + 1, c->stream));
-    if (napairs > 0 && fuse_pairs) {
+    // DPMM_OPT_CHAIN_FUSION bit 16 (D <= 128, draws launched ahead): the normals of those draws are generated by extra workgroups of the
+    // posteriors' launch (niw_post_both_kernel) -- no kernel beside the sweep on the second stream, no cross-stream wait in front of the draws
+    const bool noise_in_post = draw_epoch != 0 && (c->opt_chain & 16) != 0 && niw_master_can_fuse_pairs(c->ma);
+    bool normals_by_post = false;
+    if (noise_in_post) {
+        if (int rc = noise_join(c)) return rc;                 // (a kernel of the other scheme still writing that buffer: rare -- the option was just switched)
+        c->noise_valid = false;
+    }
+    if ((napairs > 0 && fuse_pairs) || noise_in_post) {
         // posteriors + the pooled pair log-determinants the master may ask for (dpmm_niw_master_pairs_ahead) in ONE launch: the pairs need
         // the rows of this pass only.  (On the second stream behind the posteriors they reached the host 12 + 26 us later.)
-        if (poll) master_mark_records(c->h_apairs, napairs);      // (nobody reads the pair records between two passes: dpmm_niw_master_pairs copies them out)
-        HIPCHK(c, launch_niw_master_posterior_pairs(c->ma, c->d_jobs, K, c->d_out, sm, c->d_apairs, napairs, c->h_apairs, c->stream));
+        const int nfp = fuse_pairs ? napairs : 0;
+        if (poll && nfp > 0) master_mark_records(c->h_apairs, nfp);      // (nobody reads the pair records between two passes: dpmm_niw_master_pairs copies them out)
+        HIPCHK(c, launch_niw_master_posterior_pairs(c->ma, c->d_jobs, K, c->d_out, sm, ((c->opt_chain & 4) && c->apairs_pinned_cur) ? c->apairs_pinned_cur : c->d_apairs, nfp, c->h_apairs, c->stream,
+                                                    noise_in_post ? 3 * K : 0, draw_epoch, noise_in_post ? c->d_Y[c->draw_cur ^ 1] : nullptr));
+        normals_by_post = noise_in_post;
+    } else HIPCHK(c, launch_niw_master_posterior(c->ma, c->d_jobs, K, c->d_out, sm, c->stream));
+    if (napairs > 0 && fuse_pairs) {
         c->apairs_index.clear();
         for (int p = 0; p < napairs; ++p) c->apairs_index[((uint32_t)c->apairs_req[2 * p] << 16) | (uint32_t)c->apairs_req[2 * p + 1]] = p;
         c->apairs_dirty.assign((size_t)c->master_slots, 0);
         c->apairs_inflight = false; c->apairs_valid = true;      // (the host waits for ev_master below: the records are there when it returns)
         c->apairs_req.clear();
-    } else HIPCHK(c, launch_niw_master_posterior(c->ma, c->d_jobs, K, c->d_out, sm, c->stream));
+    }
     const bool fused_pairs_launched = napairs > 0 && fuse_pairs;
     const bool need_event = !poll || (napairs > 0 && !fuse_pairs);      // (the second stream's pair job waits for the posteriors through it)
     if (need_event) HIPCHK(c, hipEventRecord(c->ev_master, c->stream));
@@ -1998,7 +2047,7 @@ int dpmm_step_master_device(dpmm_ctx *c, uint32_t reset_epoch, const int32_t *sl
         // ~15 us of signalling each way -- posteriors -> draws -> pack took 26 + 14 + 27 + 17 + 10 us at the 8-GPU shard size, the gaps
         // being the two cross-stream waits.  The normals were generated on the second stream during the sweep: that event is long done.)
         const int32_t *hs = c->d_dslots;
-        const bool have_normals = noise_ready(c, draw_epoch, K, c->draw_cur ^ 1);
+        const bool have_normals = normals_by_post || noise_ready(c, draw_epoch, K, c->draw_cur ^ 1);
         if (int rc = noise_join(c)) return rc;             // (also when its normals are not the ones wanted: the kernel writes the buffer the draws go to)
         NiwMasterArgs ma = c->ma;
         ma.mu_draw = c->d_mu_draw[c->draw_cur ^ 1];
@@ -2104,7 +2153,8 @@ int dpmm_niw_master_draw(dpmm_ctx *c, uint32_t epoch, int K, const int32_t *slot
     // with another epoch, or for more clusters, generates its own.
     // (launched by noise_flush right AFTER the sweep kernel of this step: the launch and its event record would otherwise sit on the
     // host's critical path between the master's decisions and the sweep launch)
-    c->noise_pending = c->opt_noise_ahead < 0 ? (c->D >= 128 || c->n < 4000000) : c->opt_noise_ahead != 0; c->noise_pend_epoch = epoch + 1; c->noise_pend_nmat = 3 * std::min(K + 4, c->master_K);
+    c->noise_pending = c->opt_noise_ahead < 0 ? (c->D >= 128 || c->n < 4000000) : c->opt_noise_ahead != 0; c->noise_pend_epoch = epoch + 1;
+    if ((c->opt_chain & 16) && niw_master_can_fuse_pairs(c->ma)) c->noise_pending = false;      // (the posteriors' launch generates them: dpmm_step_master_device) c->noise_pend_nmat = 3 * std::min(K + 4, c->master_K);
     c->work_zeroed = true;
     c->have_screen_prep = false;     // (the K > 64 far mask needs the raw factors: not built on this path; the tail screen is)
     c->K = K;
@@ -2675,11 +2725,12 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
                 HIPCHK(c, sync_stream(c, c->stream));
                 const int nt = (int)((c->n + t - 1) / t);
                 const size_t nbmax = 2 * DPMM_MAX_CLUSTERS;
-                int32_t *th = nullptr, *tc = nullptr;
+                int32_t *th = nullptr, *tc = nullptr, *tsp = nullptr;
                 HIPCHK(c, hipMalloc(&th, sizeof(int32_t) * nbmax * (size_t)std::max(1, nt)));
                 if (hipMalloc(&tc, sizeof(int32_t) * nbmax * (size_t)std::max(1, nt)) != hipSuccess) { hipFree(th); return fail(c, DPMM_EHIP, "DPMM_OPT_SORT_TILE: out of device memory for the 512-point tile tables"); }
-                hipFree(c->sb.tile_hist); hipFree(c->sb.tile_cnt);
-                c->sb.tile_hist = th; c->sb.tile_cnt = tc;
+                if (hipMalloc(&tsp, sizeof(int32_t) * (size_t)STEP_SPEC_MAX_BINS * (size_t)std::max(1, nt)) != hipSuccess) { hipFree(th); hipFree(tc); return fail(c, DPMM_EHIP, "DPMM_OPT_SORT_TILE: out of device memory for the 512-point tile tables"); }
+                hipFree(c->sb.tile_hist); hipFree(c->sb.tile_cnt); hipFree(c->sb.tile_spec);
+                c->sb.tile_hist = th; c->sb.tile_cnt = tc; c->sb.tile_spec = tsp;
                 c->nt_sort = nt; c->sort_tile_min = t;
             }
             c->sb.tile = t; return DPMM_OK;          // (the tile tables are rebuilt by every pass; perm stays a valid order)

@@ -177,6 +177,7 @@ struct SortBufs {
     int tile;             // points per sorting wave of this context's passes: SORT_TILE or SORT_TILE_SMALL
     int32_t *tile_hist;   // [nbins][ntiles_sort] exclusive prefix over the tiles of a bin (written by the scan from tile_cnt)
     int32_t *tile_cnt;    // [nbins][ntiles_sort] points of bin b in tile t (written by the histogram)
+    int32_t *tile_spec;   // [min(nbins, STEP_SPEC_MAX_BINS)][ntiles_sort] the same counts with the bad-cluster reset of the tile's one-sided clusters counted ahead (hist_kernel<.., SPEC>)
     int32_t *fast_total;  // [nbins][FAST_TOTAL_STRIDE] (element 0 of each line) running bin totals of the per-step histogram (integer atomics), cleared by scan_starts_kernel
     unsigned *ticket;     // [1] unused since the per-step scan and the starts are two launches (kept: the buffers are allocated as a set)
     uint16_t *prev_lab;   // [n] cluster label of every point at the previous per-step pass (0xFFFF: none yet); null: no tracking
@@ -191,7 +192,9 @@ struct SortBufs {
 };
 
 hipError_t launch_sort_by_bin(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s);
-hipError_t launch_step_hist(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s);
+constexpr int STEP_SPEC_MAX_BINS = 512;      // bins (2K) up to which the per-step histogram counts the bad-cluster reset ahead (a second set of LDS counters per tile)
+struct StepReset { const long long *global_counts; uint8_t *flags; int K; uint8_t *cside; int64_t first; uint64_t seed; uint32_t epoch; };
+hipError_t launch_step_hist(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s, int spec = 0, int64_t first = 0, uint64_t seed = 0, uint32_t epoch = 0);
 hipError_t launch_step_reset(int32_t *bins, int64_t n, int64_t first, int nbins, const SortBufs &b, const long long *global_counts, uint8_t *flags,
                              int K, uint64_t seed, uint32_t epoch, uint8_t *cside, hipStream_t s);     // cside != null: speculative reset of this shard's candidates
 // rows [2K][stride] of the speculatively reset labels -> red [3K][stride] (the travelling rows of the one-collective pass; Multinomial: its reduce does not write them itself)
@@ -200,7 +203,7 @@ hipError_t launch_niw_finalize_rows(const double *red, double *out, int64_t stri
 hipError_t launch_niw_undo_reset(int32_t *bins, int64_t n, int K, const uint8_t *flags, const uint8_t *cside, hipStream_t s);
 struct StatsArgs;
 hipError_t launch_sort_finish(const int32_t *bins, const StatsArgs &a, hipStream_t s);
-hipError_t launch_step_scan_scatter(const int32_t *bins, const StatsArgs &a, int derive, int force_all, int fused_starts, hipStream_t s);
+hipError_t launch_step_scan_scatter(int32_t *bins, const StatsArgs &a, int derive, int force_all, int fused_starts, const StepReset *rs, hipStream_t s);
 hipError_t launch_derive_rows(double *out, double *cache, const uint8_t *mode, uint8_t *dirty, int64_t stride, int K, const uint8_t *flags_src,
                               uint8_t *flags_dst, hipStream_t s);
 
@@ -269,7 +272,8 @@ hipError_t launch_niw_rows_gather(const double *rows_store, const int32_t *slots
 hipError_t launch_niw_master_posterior(const NiwMasterArgs &a, const int32_t *jobs, int njobs, const double *rows, double *small, hipStream_t s);
 bool niw_master_can_fuse_pairs(const NiwMasterArgs &a);
 hipError_t launch_niw_master_posterior_pairs(const NiwMasterArgs &a, const int32_t *jobs, int njobs, const double *rows, double *small,
-                                             const int32_t *cluster_pairs, int npairs, double *pair_small, hipStream_t s);
+                                             const int32_t *cluster_pairs, int npairs, double *pair_small, hipStream_t s,
+                                             int noise_nmat = 0, uint32_t noise_epoch = 0, double *noise_Y = nullptr);   // noise_Y: also the standard normals of the draws that follow (round 6)
 hipError_t launch_niw_draw_inputs(const NiwMasterArgs &a, const int32_t *slot_of_cluster, int K, uint32_t epoch, double *Aout, double *xiout, hipStream_t s);
 hipError_t launch_niw_master_noise(const NiwMasterArgs &a, int nmat, uint32_t epoch, double *Y, hipStream_t s);
 hipError_t launch_niw_master_draw(const NiwMasterArgs &a, const int32_t *slot_of_cluster, int K, uint32_t epoch, double *Y, float *logdet_sigma,

@@ -1161,11 +1161,26 @@ __global__ __launch_bounds__(256) void niw_post_lds_kernel(NiwMasterArgs A, cons
 }
 // the 3 njobs posteriors of a statistics pass and npairs pooled pairs of the same pass in ONE launch (the pairs behind the posteriors in the
 // grid): the pair jobs name clusters and read the rows of the pass, so they depend on nothing the posterior workgroups write
+// (round 6, DPMM_OPT_CHAIN_FUSION bit 16) ... and, behind the pairs in the grid, the standard normals of the draws that follow this launch on the
+// same stream (niw_noise_kernel's job, `nsplit` workgroups per matrix): the posteriors keep 96 of 256 compute units busy for 27 us, the normals
+// fit beside them.  On a second stream beside the sweep they competed with the sweep for two thirds of its duration, and the draws had to wait
+// for that stream's event in front of them -- a barrier packet between posteriors and draws, 6 us of the chain that does not shrink with n.
 __global__ __launch_bounds__(256) void niw_post_both_kernel(NiwMasterArgs A, const int32_t *__restrict__ jobs, const double *__restrict__ rows,
                                                             double *__restrict__ small, int nposts, const int32_t *__restrict__ pair_jobs,
-                                                            double *__restrict__ pair_small) {
+                                                            double *__restrict__ pair_small, int npairs, uint32_t noise_epoch, double *__restrict__ noise_Y, int nsplit) {
     if ((int)blockIdx.x < nposts) niw_post_lds_body<false>(A, jobs, rows, small, (int)blockIdx.x);
-    else niw_post_lds_body<true>(A, pair_jobs, rows, pair_small, (int)blockIdx.x - nposts);
+    else if ((int)blockIdx.x < nposts + npairs) niw_post_lds_body<true>(A, pair_jobs, rows, pair_small, (int)blockIdx.x - nposts);
+    else {
+        const int nb = (int)blockIdx.x - nposts - npairs, mat = nb / nsplit, part = nb - mat * nsplit;
+        const int DP = A.DP, HP = DP / 2;
+        double *Y = noise_Y + (int64_t)mat * DP * DP;
+        for (int p2 = part * 256 + threadIdx.x; p2 < DP * HP; p2 += nsplit * 256) {
+            const int r = p2 / HP, c = 2 * (p2 - r * HP);
+            double n0, n1;
+            bartlett_pair(A, (uint64_t)mat, noise_epoch, r, c, n0, n1);
+            Y[(int64_t)r * DP + c] = n0; Y[(int64_t)r * DP + c + 1] = n1;
+        }
+    }
 }
 size_t niw_post_lds_bytes(int DP) { return sizeof(double) * ((size_t)DP * (DP + 1) + 3 * (size_t)DP + 16); }
 constexpr int NIW_POST_LDS_MAXDP = 128;
@@ -1173,11 +1188,14 @@ constexpr int NIW_POST_LDS_MAXDP = 128;
 bool niw_master_can_fuse_pairs(const NiwMasterArgs &a) { return a.DP <= NIW_POST_LDS_MAXDP; }
 // posteriors of njobs clusters + npairs pooled pairs (CLUSTER indices of the same pass) in one launch; D <= 128 only
 hipError_t launch_niw_master_posterior_pairs(const NiwMasterArgs &a, const int32_t *jobs, int njobs, const double *rows, double *small,
-                                             const int32_t *cluster_pairs, int npairs, double *pair_small, hipStream_t s) {
+                                             const int32_t *cluster_pairs, int npairs, double *pair_small, hipStream_t s,
+                                             int noise_nmat, uint32_t noise_epoch, double *noise_Y) {
     static bool attr = false;
     if (!attr) { hipFuncSetAttribute((const void *)niw_post_both_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)niw_post_lds_bytes(NIW_POST_LDS_MAXDP)); attr = true; }
-    DPMM_LAUNCH(niw_post_both_kernel, dim3(3 * njobs + npairs), dim3(256), niw_post_lds_bytes(a.DP), s, a, jobs, rows, small, 3 * njobs,
-                       cluster_pairs, pair_small);
+    const int nsplit = a.DP >= 128 ? 8 : (a.DP >= 48 ? 4 : 1);      // (workgroups per matrix, as launch_niw_master_noise)
+    const int nnoise = (noise_Y && noise_nmat > 0) ? noise_nmat * nsplit : 0;
+    DPMM_LAUNCH(niw_post_both_kernel, dim3(3 * njobs + npairs + nnoise), dim3(256), niw_post_lds_bytes(a.DP), s, a, jobs, rows, small, 3 * njobs,
+                       cluster_pairs, pair_small, npairs, noise_epoch, noise_Y, nsplit);
     return hipGetLastError();
 }
 hipError_t launch_niw_master_pairs(const NiwMasterArgs &a, const int32_t *pairs, int n, double *scratch, double *small, hipStream_t s) {

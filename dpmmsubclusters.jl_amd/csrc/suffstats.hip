@@ -39,10 +39,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // W waves per workgroup, one sort tile each: the bin totals go to `fast_total` once per WORKGROUP.  With labels in no particular storage order
 // every tile holds every bin, and one wave per workgroup meant tiles x bins atomics on `nbins` addresses (N = 1e6, K = 32: 125 k atomics, 2 k
 // in a row per address at ~13 ns each = the kernel's 26 us; 33 us at N = 1e7).
-template <int TILE, int W>
+// SPEC (round 6, DPMM_OPT_CHAIN_FUSION bit 8: no reset_recount launch).  reset_bad_clusters! re-draws the sub-labels of every cluster with an
+// EMPTY sub-cluster -- known only when the whole shard is counted, which is why the reset was a launch of its own that read every label again
+// (7 us at the 8-GPU shard size, 17-21 us at N = 1e7).  But a cluster that will be flagged has one sub-bin empty in EVERY tile, and the re-draw
+// is a pure function of (seed, global point index, epoch): a tile can count the outcome ahead.  For every cluster that is one-sided IN THIS TILE
+// (exactly one of its two sub-bins is empty here; ~never for a healthy cluster: 2^-64 at 64 of its points per tile) the wave evaluates the
+// re-draw of those points and counts the result; `tile_spec` gets that count for such clusters and the plain count for all others.  The scan
+// then reads tile_spec for flagged clusters and tile_cnt for the rest, and the scatter applies the same re-draw to the labels it places
+// (scatter_kernel<.., STEP>, RESET): same labels, same permutation as histogram -> reset_recount -> scan.
+template <int TILE, int W, bool SPEC>
 __global__ __launch_bounds__(64 * W) void hist_kernel(const int32_t *__restrict__ bins, int64_t n, int nbins, int nt,
                                                       int32_t *__restrict__ tile_hist, int32_t *__restrict__ fast_total,
-                                                      uint16_t *__restrict__ prev_lab, uint8_t *__restrict__ dirty) {
+                                                      uint16_t *__restrict__ prev_lab, uint8_t *__restrict__ dirty,
+                                                      int32_t *__restrict__ tile_spec, int64_t first, uint64_t seed, uint32_t epoch) {
     extern __shared__ int cnt_all[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int *const cnt = cnt_all + wave * nbins;
@@ -50,6 +59,9 @@ __global__ __launch_bounds__(64 * W) void hist_kernel(const int32_t *__restrict_
     for (int b = lane; b < nbins; b += 64) cnt[b] = 0;
     __syncthreads();
     const int64_t base = (int64_t)tile * TILE;
+    int4 v[TILE / 256];                      // (a full tile's labels stay in registers for the SPEC phase)
+#pragma unroll
+    for (int it = 0; it < TILE / 256; ++it) v[it] = make_int4(-1, -1, -1, -1);
     if (tile < nt) {
     auto track = [&](int64_t i, int bv) {            // rare: a point whose label is not the one it had at the previous pass
         // (a label outside [0, K) -- perm_total != n acknowledges that they can occur -- still LEAVES the cluster the point was in: that
@@ -66,7 +78,6 @@ __global__ __launch_bounds__(64 * W) void hist_kernel(const int32_t *__restrict_
         // full tile: 16-byte loads, all of them in flight before the first is used; 256 points with one common bin (the usual case
         // after an ordered sweep: neighbours share a label) cost one LDS add instead of 256 same-address atomics
         const int4 *src = reinterpret_cast<const int4 *>(bins + base);
-        int4 v[TILE / 256];
 #pragma unroll
         for (int it = 0; it < TILE / 256; ++it) v[it] = src[it * 64 + lane];
         if (prev_lab) {
@@ -139,6 +150,49 @@ __global__ __launch_bounds__(64 * W) void hist_kernel(const int32_t *__restrict_
     __syncthreads();
     if (tile < nt)
         for (int b = lane; b < nbins; b += 64) tile_hist[(int64_t)b * nt + tile] = cnt[b];
+    if constexpr (SPEC) {
+        if (tile_spec && tile < nt) {                  // (wave-uniform; everything below is wave-local: this wave's counters, no workgroup barrier)
+            int *const spc = cnt_all + (W + wave) * nbins;
+            const bool full = base + TILE <= n;
+            auto onesided = [&](int bv) -> bool {
+                if ((unsigned)bv >= (unsigned)nbins) return false;
+                const int z2 = bv & ~1;
+                return (cnt[z2] == 0) != (cnt[z2 + 1] == 0);
+            };
+            bool mine = false;
+            if (full) {
+#pragma unroll
+                for (int it = 0; it < TILE / 256; ++it) mine = mine || onesided(v[it].x) || onesided(v[it].y) || onesided(v[it].z) || onesided(v[it].w);
+            } else {
+                for (int it = 0; it < TILE / 64; ++it) { const int64_t i = base + it * 64 + lane; if (i < n) mine = mine || onesided(bins[i]); }
+            }
+            const bool some = __any(mine);
+            if (some) {
+                for (int b = lane; b < nbins; b += 64) spc[b] = 0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                auto redraw = [&](int64_t i, int bv) {
+                    if (!onesided(bv)) return;
+                    const Philox4 r = philox4x32_10(seed, (uint64_t)(first + i), epoch, STREAM_RESET);      // reset_recount_kernel's draw
+                    atomicAdd(&spc[(bv & ~1) + (int)(r.v[0] & 1u)], 1);
+                };
+                if (full) {
+#pragma unroll
+                    for (int it = 0; it < TILE / 256; ++it) {
+                        const int64_t i0 = base + (int64_t)(it * 64 + lane) * 4;
+                        redraw(i0, v[it].x); redraw(i0 + 1, v[it].y); redraw(i0 + 2, v[it].z); redraw(i0 + 3, v[it].w);
+                    }
+                } else {
+                    for (int it = 0; it < TILE / 64; ++it) { const int64_t i = base + it * 64 + lane; if (i < n) redraw(i, bins[i]); }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+            }
+            for (int b = lane; b < nbins; b += 64) {
+                const int z2 = b & ~1;
+                const bool one = some && ((cnt[z2] == 0) != (cnt[z2 + 1] == 0));
+                tile_spec[(int64_t)b * nt + tile] = one ? spc[b] : cnt[b];
+            }
+        }
+    }
     if (fast_total)
         for (int b = threadIdx.x; b < nbins; b += 64 * W) {
             int v = 0;
@@ -262,6 +316,41 @@ __global__ __launch_bounds__(256) void scan_tiles_kernel(const int32_t *__restri
     __shared__ int part[256];
     scan_one_bin(tile_cnt, tile_hist, nt, bin_total, part);
 }
+// The scan of the per-step pass when the histogram counted the bad-cluster reset ahead (hist_kernel<.., SPEC>): the workgroup of bin b derives
+// its cluster's flag from the 2K sub-cluster occupancies exactly as reset_recount_kernel does (`totals`: this shard's; `global_counts`: summed
+// over the ranks; `cside` != null: the speculative form of the one-collective pass -- candidates, and which side their points were on) and
+// scans tile_spec for a flagged cluster, tile_cnt otherwise.  Workgroup 0 publishes flags[0..K), flags[K] = any, cside[].
+__global__ __launch_bounds__(256) void scan_tiles_step_kernel(const int32_t *__restrict__ tile_cnt, const int32_t *__restrict__ tile_spec, int32_t *__restrict__ tile_hist,
+                                                              int nt, int32_t *__restrict__ bin_total, const int32_t *__restrict__ totals,
+                                                              const long long *__restrict__ global_counts, uint8_t *__restrict__ flags, int K,
+                                                              uint8_t *__restrict__ cside) {
+    __shared__ int part[256];
+    __shared__ int any_s;
+    auto occupancy = [&](int k, long long &a, long long &b) {
+        a = global_counts ? global_counts[2 * k] : (long long)totals[(2 * k) * FAST_TOTAL_STRIDE];
+        b = global_counts ? global_counts[2 * k + 1] : (long long)totals[(2 * k + 1) * FAST_TOTAL_STRIDE];
+    };
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) any_s = 0;
+        __syncthreads();
+        bool anyl = false;
+        for (int k = threadIdx.x; k < K; k += 256) {
+            long long a, b;
+            occupancy(k, a, b);
+            const bool bad = cside ? ((a == 0) != (b == 0)) : (a == 0 || b == 0);
+            flags[k] = bad ? 1 : 0;
+            if (cside) cside[k] = bad ? (b == 0 ? 1 : 2) : 0;
+            anyl = anyl || bad;
+        }
+        if (anyl) any_s = 1;              // (benign race: every writer stores 1)
+        __syncthreads();
+        if (threadIdx.x == 0) flags[K] = any_s ? 1 : 0;
+    }
+    long long a, b;
+    occupancy((int)blockIdx.x >> 1, a, b);
+    const bool bad = cside ? ((a == 0) != (b == 0)) : (a == 0 || b == 0);
+    scan_one_bin(bad ? tile_spec : tile_cnt, tile_hist, nt, bin_total, part);
+}
 
 // bin_start[b] = sum_{b'<b} total ; item_start[b] = sum_{b'<b} ceil(sel*total / chunk)
 __device__ __forceinline__ void starts_body(const int32_t *bin_total, const uint8_t *bin_sel,
@@ -345,15 +434,26 @@ __global__ __launch_bounds__(256) void starts_step_kernel(int32_t *bin_total, ui
 struct StepStarts {
     const int32_t *bin_total; uint8_t *bin_sel; int chunk; int32_t *bin_start_out; int32_t *item_start; int32_t *perm_total; int32_t *fast_total;
     uint8_t *mode; const uint8_t *dirty; int force_all;
+    const uint8_t *reset_flags; int64_t first; uint64_t seed; uint32_t epoch;      // (reset_flags != null: apply the bad-cluster reset while placing)
 };
 template <int TILE, bool STEP>
-__global__ __launch_bounds__(64) void scatter_kernel(const int32_t *__restrict__ bins, int64_t n, int nbins, int nt,
+__global__ __launch_bounds__(64) void scatter_kernel(int32_t *bins, int64_t n, int nbins, int nt,
                                                      const int32_t *__restrict__ tile_hist,
                                                      const int32_t *__restrict__ bin_start, int32_t *__restrict__ perm, StepStarts st) {
     extern __shared__ int base[];
     const int lane = threadIdx.x;
     int nbits = 0;
     while ((1 << nbits) < nbins) ++nbits;
+    // STEP with st.reset_flags: the bad-cluster reset is APPLIED here (the histogram counted it ahead, the scan chose those counts): a point of a
+    // flagged cluster gets the sub-label of reset_recount_kernel's draw, is stored, and is placed by it
+    uint8_t *const rflag = reinterpret_cast<uint8_t *>(base + nbins);
+    bool do_reset = false;
+    if constexpr (STEP) {
+        if (st.reset_flags && st.reset_flags[nbins >> 1]) {           // flags[K]: any cluster flagged (workgroup-uniform)
+            do_reset = true;
+            for (int k = lane; k < (nbins >> 1); k += 64) rflag[k] = st.reset_flags[k];
+        }
+    }
     if constexpr (STEP) {
         const bool pub = blockIdx.x == 0;
         const bool all = pub && st.mode && (st.force_all || st.dirty[DPMM_MAX_CLUSTERS_K]);
@@ -413,6 +513,13 @@ __global__ __launch_bounds__(64) void scatter_kernel(const int32_t *__restrict__
         const int64_t i = tbase + it * 64 + lane;
         int b = i < n ? bv[it] : -1;
         if ((unsigned)b >= (unsigned)nbins) b = -1;
+        if constexpr (STEP) {
+            if (do_reset && b >= 0 && rflag[b >> 1]) {
+                const Philox4 r = philox4x32_10(st.seed, (uint64_t)(st.first + i), st.epoch, STREAM_RESET);
+                b = (b & ~1) + (int)(r.v[0] & 1u);
+                bins[i] = b;
+            }
+        }
         const bool valid = b >= 0;
         // lanes with the same bin, by one ballot per bit of the bin id (a fixed ceil(log2 nbins) steps; the leader-by-leader loop it
         // replaces took one step per DISTINCT bin in the wave: ~40 on unsorted labels, e.g. bag-of-words data); a wave with one
@@ -478,10 +585,15 @@ hipError_t launch_derive_rows(double *out, double *cache, const uint8_t *mode, u
 static inline int sort_nt(int64_t n, const SortBufs &b) { return (int)((n + b.tile - 1) / b.tile); }
 template <int TILE>
 static inline void launch_hist(const int32_t *bins, int64_t n, int nbins, int nt, int32_t *tile_cnt, int32_t *fast_total, uint16_t *prev_lab, uint8_t *dirty,
-                               hipStream_t s) {
+                               hipStream_t s, int32_t *tile_spec = nullptr, int64_t first = 0, uint64_t seed = 0, uint32_t epoch = 0) {
     // eight tiles per workgroup while eight count arrays fit comfortably in LDS (K <= 512), else one
-    if (nbins <= 1024) DPMM_LAUNCH((hist_kernel<TILE, 8>), dim3((nt + 7) / 8), dim3(512), 8 * nbins * sizeof(int), s, bins, n, nbins, nt, tile_cnt, fast_total, prev_lab, dirty);
-    else DPMM_LAUNCH((hist_kernel<TILE, 1>), dim3(nt), dim3(64), nbins * sizeof(int), s, bins, n, nbins, nt, tile_cnt, fast_total, prev_lab, dirty);
+    if (tile_spec && nbins <= STEP_SPEC_MAX_BINS)       // (a second set of eight counter arrays: 32 KiB at 512 bins)
+        DPMM_LAUNCH((hist_kernel<TILE, 8, true>), dim3((nt + 7) / 8), dim3(512), 16 * nbins * sizeof(int), s, bins, n, nbins, nt, tile_cnt, fast_total, prev_lab, dirty,
+                    tile_spec, first, seed, epoch);
+    else if (nbins <= 1024) DPMM_LAUNCH((hist_kernel<TILE, 8, false>), dim3((nt + 7) / 8), dim3(512), 8 * nbins * sizeof(int), s, bins, n, nbins, nt, tile_cnt, fast_total, prev_lab, dirty,
+                                        (int32_t *)nullptr, (int64_t)0, (uint64_t)0, 0u);
+    else DPMM_LAUNCH((hist_kernel<TILE, 1, false>), dim3(nt), dim3(64), nbins * sizeof(int), s, bins, n, nbins, nt, tile_cnt, fast_total, prev_lab, dirty,
+                     (int32_t *)nullptr, (int64_t)0, (uint64_t)0, 0u);
 }
 hipError_t launch_sort_by_bin(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s) {
     const int nt = sort_nt(n, b);
@@ -494,12 +606,14 @@ hipError_t launch_sort_by_bin(const int32_t *bins, int64_t n, int nbins, const S
 }
 // The sort of the per-step pass in four launches (n > 0): histogram (+ running totals) -> [caller: all-reduce of the totals] ->
 // launch_step_reset (flags, sub-label reset, re-count of the touched tiles) -> launch_step_scan_scatter (scan + starts, scatter).
-hipError_t launch_step_hist(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s) {
+// spec (DPMM_OPT_CHAIN_FUSION bit 8, nbins <= STEP_SPEC_MAX_BINS): the tiles also count the outcome of the bad-cluster reset ahead (hist_kernel<.., SPEC>)
+hipError_t launch_step_hist(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s, int spec, int64_t first, uint64_t seed, uint32_t epoch) {
     const int nt = sort_nt(n, b);
     uint8_t *dirty = b.prev_lab ? b.cdirty : (uint8_t *)nullptr;
+    int32_t *ts = (spec && b.tile_spec && nbins <= STEP_SPEC_MAX_BINS) ? b.tile_spec : (int32_t *)nullptr;
     DPMM_TILE_DISPATCH(b.tile,
-        launch_hist<512>(bins, n, nbins, nt, b.tile_cnt, b.fast_total, b.prev_lab, dirty, s),
-        launch_hist<2048>(bins, n, nbins, nt, b.tile_cnt, b.fast_total, b.prev_lab, dirty, s));
+        launch_hist<512>(bins, n, nbins, nt, b.tile_cnt, b.fast_total, b.prev_lab, dirty, s, ts, first, seed, epoch),
+        launch_hist<2048>(bins, n, nbins, nt, b.tile_cnt, b.fast_total, b.prev_lab, dirty, s, ts, first, seed, epoch));
     return hipGetLastError();
 }
 hipError_t launch_step_reset(int32_t *bins, int64_t n, int64_t first, int nbins, const SortBufs &b, const long long *global_counts, uint8_t *flags,
@@ -1227,19 +1341,26 @@ hipError_t launch_mult_stats(const StatsArgs &a, hipStream_t s) {
 // second half of the sort (needs the selection mask and the chunk size of the statistics pass)
 static void launch_scatter(const int32_t *bins, const StatsArgs &a, int nt, hipStream_t s) {
     const StepStarts none{};
+    int32_t *b = const_cast<int32_t *>(bins);          // (only the STEP instantiation with reset_flags writes labels)
     DPMM_TILE_DISPATCH(a.sb.tile,
-        DPMM_LAUNCH((scatter_kernel<512, false>), dim3(nt), dim3(64), a.nbins * sizeof(int), s, bins, a.n, a.nbins, nt, a.sb.tile_hist, a.sb.bin_start, a.sb.perm, none),
-        DPMM_LAUNCH((scatter_kernel<2048, false>), dim3(nt), dim3(64), a.nbins * sizeof(int), s, bins, a.n, a.nbins, nt, a.sb.tile_hist, a.sb.bin_start, a.sb.perm, none));
+        DPMM_LAUNCH((scatter_kernel<512, false>), dim3(nt), dim3(64), a.nbins * sizeof(int), s, b, a.n, a.nbins, nt, a.sb.tile_hist, a.sb.bin_start, a.sb.perm, none),
+        DPMM_LAUNCH((scatter_kernel<2048, false>), dim3(nt), dim3(64), a.nbins * sizeof(int), s, b, a.n, a.nbins, nt, a.sb.tile_hist, a.sb.bin_start, a.sb.perm, none));
 }
-hipError_t launch_step_scan_scatter(const int32_t *bins, const StatsArgs &a, int derive, int force_all, int fused_starts, hipStream_t s) {
+// rs (nullable): the bad-cluster reset folded into this chain -- the histogram counted it ahead (launch_step_hist with spec), the scan derives the
+// flags and picks the counts, the scatter applies it (needs fused_starts: the STEP instantiation)
+hipError_t launch_step_scan_scatter(int32_t *bins, const StatsArgs &a, int derive, int force_all, int fused_starts, const StepReset *rs, hipStream_t s) {
     const int nt = sort_nt(a.n, a.sb);
-    DPMM_LAUNCH(scan_tiles_kernel, dim3(a.nbins), dim3(256), 0, s, a.sb.tile_cnt, a.sb.tile_hist, nt, a.sb.bin_total);
-    if (fused_starts && nt > 0) {          // the starts inside the scatter launch (StepStarts above)
+    if (rs) DPMM_LAUNCH(scan_tiles_step_kernel, dim3(a.nbins), dim3(256), 0, s, a.sb.tile_cnt, a.sb.tile_spec, a.sb.tile_hist, nt, a.sb.bin_total, a.sb.fast_total,
+                        rs->global_counts, rs->flags, rs->K, rs->cside);
+    else DPMM_LAUNCH(scan_tiles_kernel, dim3(a.nbins), dim3(256), 0, s, a.sb.tile_cnt, a.sb.tile_hist, nt, a.sb.bin_total);
+    if ((fused_starts || rs) && nt > 0) {          // the starts inside the scatter launch (StepStarts above)
         const StepStarts st{a.sb.bin_total, a.sb.bin_sel, a.chunk, a.sb.bin_start, a.sb.item_start, a.sb.perm_total, a.sb.fast_total,
-                            derive ? a.sb.cmode : (uint8_t *)nullptr, a.sb.cdirty, force_all};
+                            derive ? a.sb.cmode : (uint8_t *)nullptr, a.sb.cdirty, force_all,
+                            rs ? rs->flags : (const uint8_t *)nullptr, rs ? rs->first : 0, rs ? rs->seed : 0, rs ? rs->epoch : 0u};
+        const size_t lds = a.nbins * sizeof(int) + (size_t)(((a.nbins >> 1) + 3) & ~3);
         DPMM_TILE_DISPATCH(a.sb.tile,
-            DPMM_LAUNCH((scatter_kernel<512, true>), dim3(nt), dim3(64), a.nbins * sizeof(int), s, bins, a.n, a.nbins, nt, a.sb.tile_hist, a.sb.bin_start, a.sb.perm, st),
-            DPMM_LAUNCH((scatter_kernel<2048, true>), dim3(nt), dim3(64), a.nbins * sizeof(int), s, bins, a.n, a.nbins, nt, a.sb.tile_hist, a.sb.bin_start, a.sb.perm, st));
+            DPMM_LAUNCH((scatter_kernel<512, true>), dim3(nt), dim3(64), lds, s, bins, a.n, a.nbins, nt, a.sb.tile_hist, a.sb.bin_start, a.sb.perm, st),
+            DPMM_LAUNCH((scatter_kernel<2048, true>), dim3(nt), dim3(64), lds, s, bins, a.n, a.nbins, nt, a.sb.tile_hist, a.sb.bin_start, a.sb.perm, st));
         return hipGetLastError();
     }
     DPMM_LAUNCH(starts_step_kernel, dim3(1), dim3(256), 0, s, a.sb.bin_total, a.sb.bin_sel, a.nbins, a.chunk, a.sb.bin_start, a.sb.item_start,

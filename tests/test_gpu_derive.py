@@ -152,3 +152,57 @@ def test_engine_chain_with_and_without_derivation(pkg, D, N, Kt):
     if np.array_equal(l1, l0) and np.array_equal(s1, s0):
         np.testing.assert_allclose(p1, p0, rtol=1e-11, atol=1e-8)
         assert abs(lp1 - lp0) <= 1e-9 * abs(lp0)
+
+
+@pytest.mark.parametrize("D,n,K,order", [(32, 70001, 5, "random"), (64, 300017, 9, "sorted"), (16, 2500000, 6, "random"), (8, 40000, 200, "random"),
+                                         (8, 50000, 256, "sorted"), (8, 50000, 300, "random"), (4, 700, 3, "random")])
+def test_reset_counted_ahead_is_the_reset_launch(pkg, D, n, K, order):
+    """Round 6 (DPMM_OPT_CHAIN_FUSION bit 8): the per-step pass without a reset launch -- the histogram counts the outcome of reset_bad_clusters!
+    (local_clusters_actions.jl:501-516) ahead for the clusters that are one-sided in a tile, the scan derives the flags and picks those counts
+    for the flagged clusters, the scatter applies the re-draw while it places -- against the pass with the launch (bit 8 off): the same flags,
+    the same labels and sub-labels for EVERY point, the same visiting order (the next sweep's tiles) and bitwise the same rows.  Cases: several
+    bad clusters at once (left-empty, right-empty), a cluster that is one-sided in some tiles only (not flagged: its speculative counts must
+    not be used), empty clusters, points in storage order and shuffled, tiles of 512 and 2048 points with a ragged last tile, 2K = 512 bins
+    (the limit of the folded form), 2K = 600 (beyond it: the launch stays) and a shard smaller than one tile."""
+    from dpmmsubclusters_jl_amd import binding
+    rng = np.random.default_rng(1000 + K + D)
+    X = rng.normal(size=(n, D)).astype(np.float32)
+    lab = rng.integers(1, K + 1, n)
+    if order == "sorted":
+        lab.sort()
+    sub = rng.integers(1, 3, n)
+    bad_l, bad_r, partial, empty = 1, min(3, K), 2, (K if K > 4 else None)
+    sub[lab == bad_l] = 2                         # left sub-cluster empty
+    sub[lab == bad_r] = 1                         # right sub-cluster empty
+    idx = np.flatnonzero(lab == partial)
+    sub[idx[: len(idx) // 2]] = 1                 # one-sided in the first half of its points (whole tiles of them when sorted), mixed in the rest
+    if empty is not None:
+        lab[lab == empty] = partial if partial != empty else 1
+    out = {}
+    for fold in (1, 0):
+        wk = pkg.Worker(pkg.PRIOR_NIW, D, n, first_index=12345, device=0, seed=77)
+        wk.upload_points(X)
+        wk.set_option(binding.OPT_CHAIN_FUSION, 0x7fffffff if fold else 0x7fffffff & ~8)
+        wk.set_num_clusters(K)
+        wk.set_labels(lab, sub)
+        passes = []
+        for ep in (5, 6):                         # the second pass: derived halves + whatever the first reset left one-sided by chance
+            packed, bad = wk.step_stats(reset_epoch=ep)
+            passes.append((packed.copy(), bad.copy(), wk.get_labels(), wk.debug_perm() if hasattr(wk, "debug_perm") else None))
+        out[fold] = passes
+        wk.close()
+    for (p1, b1, (l1, s1), o1), (p0, b0, (l0, s0), o0) in zip(out[1], out[0]):
+        assert np.array_equal(b1, b0)
+        assert np.array_equal(l1, l0) and np.array_equal(s1, s0)
+        assert np.array_equal(p1, p0, equal_nan=True)
+        if o1 is not None:
+            assert np.array_equal(o1, o0)
+    b = out[1][0][1]
+    assert b[bad_l - 1] == 1 and b[bad_r - 1] == 1 and b[partial - 1] == 0
+    l1, s1 = out[1][0][2]
+    assert np.array_equal(l1, lab)                                                    # the reset moves sub-labels only
+    for k in (bad_l, bad_r):
+        if (lab == k).sum() > 40:
+            assert set(np.unique(s1[lab == k])) == {1, 2}
+    keep = ~np.isin(lab, [bad_l, bad_r] + [k + 1 for k in np.flatnonzero(b)])
+    assert np.array_equal(s1[keep], sub[keep])                                        # nobody else's sub-label moved

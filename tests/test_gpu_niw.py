@@ -752,7 +752,7 @@ def test_lean_tiles_beyond_64_clusters_without_the_prescreen(pkg, K, n, sep):
                 assert np.array_equal(orc.sample_log_cat(wk.debug_loglik(), u0), labs[-1][0])
                 assert_sublabels_bit_exact(wk, labs[-1][0], labs[-1][1], u1)
             N_, _, _ = wk.suffstats()
-            assert int(N_.sum()) == n                  # conservation: every point swept, every label in range
+            assert int(N_[:, 0].sum()) == n and np.array_equal(N_[:, 0], N_[:, 1] + N_[:, 2])      # conservation: every point swept, every label in range
             wk.set_params_niw(P["mu"], P["invS"], P["logdet"], P["lr"], P["w"])
         assert (max(lean_ms) > 0.0) == bool(on), lean_ms
         out[on] = labs
@@ -832,8 +832,9 @@ def test_a_predictive_table_in_between_does_not_change_the_chain(pkg):
 @pytest.mark.parametrize("D,N,K,var", [(64, 120000, 10, 100.0), (64, 90000, 6, 2.0), (48, 60000, 5, 50.0), (16, 50000, 4, 50.0), (128, 40000, 4, 100.0)])
 def test_folded_launches_and_the_polling_wait_are_the_same_chain(pkg, D, N, K, var):
     """Round 6: the n-independent chain of a step lost launches -- the sort's starts inside the scatter launch, the three-plane images inside the
-    hand-over launch (workgroups partitioned by role), no event between the posteriors and the draws launched ahead (the host waits on the
-    posteriors' own records in pinned memory).  Each is value-neutral: 25 group_steps from ONE cluster (splits, merges, bad-cluster resets,
+    hand-over launch (workgroups partitioned by role), the bad-cluster reset counted ahead by the histogram and applied by the scatter, the
+    draws' normals generated inside the posteriors' launch, the pair list read from pinned memory, no event between the posteriors and the
+    draws launched ahead (the host waits on the posteriors' own records in pinned memory).  Each is value-neutral: 25 group_steps from ONE cluster (splits, merges, bad-cluster resets,
     subset passes) with everything on, with DPMM_OPT_CHAIN_FUSION = 0 and with DPMM_OPT_MASTER_POLL = 0 -- K history, labels and sub-labels equal
     at every checkpoint, and the sub-cluster values the next sweep would draw from (dpmm_debug_subloglik: written by the folded launch in one
     run, by niw_b3_pack_kernel in the other) equal bit for bit."""
@@ -862,9 +863,12 @@ def test_folded_launches_and_the_polling_wait_are_the_same_chain(pkg, D, N, K, v
             s.sample_clusters()                  # a parameter set for the CURRENT clusters (the last step may have changed K)
             wk.K = s.K
             tab = wk.debug_subloglik()
-        out[name] = (ks, snaps, tab)
+        out[name] = (ks, snaps, tab, [int(v) for v in s.model.get("counters")[4:6]])
         wk.close()
-    print("K history:", out["all"][0])
+    print("K history:", out["all"][0], "; bad-cluster resets (total, steps):", out["all"][3])
+    assert out["all"][3] == out["round5"][3]
+    if D == 64 and var == 100.0:
+        assert out["all"][3][0] > 0          # (the folded reset did run: hist_kernel<.., SPEC> + scan_tiles_step_kernel + the scatter's re-draw)
     for name in ("unfused", "event", "round5"):
         assert out[name][0] == out["all"][0], name
         for a, b in zip(out[name][1], out["all"][1]):
