@@ -627,6 +627,7 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
     CHK_CREATE(hipMalloc(&c->sb.tile_hist, sizeof(int32_t) * nbmax * (size_t)std::max(1, c->nt_sort)));
     CHK_CREATE(hipMalloc(&c->sb.tile_cnt, sizeof(int32_t) * nbmax * (size_t)std::max(1, c->nt_sort)));
     CHK_CREATE(hipMalloc(&c->sb.tile_spec, sizeof(int32_t) * (size_t)STEP_SPEC_MAX_BINS * (size_t)std::max(1, c->nt_sort)));
+    CHK_CREATE(hipMalloc(&c->sb.spec_bins, sizeof(int32_t) * nalloc));
     CHK_CREATE(hipMalloc(&c->sb.fast_total, sizeof(int32_t) * nbmax * FAST_TOTAL_STRIDE));
     CHK_CREATE(hipMemsetAsync(c->sb.fast_total, 0, sizeof(int32_t) * nbmax * FAST_TOTAL_STRIDE, c->stream));
     CHK_CREATE(hipMalloc(&c->sb.ticket, sizeof(unsigned)));
@@ -675,7 +676,7 @@ int dpmm_destroy(dpmm_ctx *c) {
     if (c->stream && !c->comm_aborted.load()) hipStreamSynchronize(c->stream);
     free_params(c);
     hipFree(c->dX); hipFree(c->dX8); hipFree(c->dbins); hipFree(c->d_gt); hipFree(c->d_cont);
-    hipFree(c->sb.tile_hist); hipFree(c->sb.tile_cnt); hipFree(c->sb.tile_spec); hipFree(c->sb.fast_total); hipFree(c->sb.ticket); hipFree(c->sb.prev_lab); hipFree(c->sb.cdirty); hipFree(c->sb.cmode); hipFree(c->sb.bin_total); hipFree(c->sb.bin_start); hipFree(c->sb.item_start);
+    hipFree(c->sb.tile_hist); hipFree(c->sb.tile_cnt); hipFree(c->sb.tile_spec); hipFree(c->sb.spec_bins); hipFree(c->sb.fast_total); hipFree(c->sb.ticket); hipFree(c->sb.prev_lab); hipFree(c->sb.cdirty); hipFree(c->sb.cmode); hipFree(c->sb.bin_total); hipFree(c->sb.bin_start); hipFree(c->sb.item_start);
     hipFree(c->sb.perm); hipFree(c->sb.bin_sel); hipFree(c->sb.perm_total); hipFree(c->d_small); hipFree(c->d_proj); hipFree(c->d_vals); hipFree(c->d_smart);
     hipFree(c->d_m0); hipFree(c->d_psi_lo); hipFree(c->d_pairs);
     for (int i = 0; i < 2; ++i) { hipFree(c->d_Y[i]); hipFree(c->d_ld_sigma[i]); hipFree(c->d_mu_draw[i]); }
@@ -1484,7 +1485,7 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
         // -> scatter.  The flags live right behind the packed rows, so that rows + flags reach the master in one copy.
         // DPMM_OPT_CHAIN_FUSION bit 8 (round 6): no reset launch -- the histogram counts the reset ahead for the clusters that are one-sided in a
         // tile, the scan derives the flags and picks those counts for flagged clusters, the scatter applies the re-draw while it places
-        const bool fold_reset = (c->opt_chain & 8) != 0 && nbins <= STEP_SPEC_MAX_BINS && c->sb.tile_spec != nullptr;
+        const bool fold_reset = (c->opt_chain & 8) != 0 && nbins <= STEP_SPEC_MAX_BINS && c->sb.tile_spec != nullptr && c->sb.spec_bins != nullptr;
         HIPCHK(c, launch_step_hist(c->dbins, c->n, nbins, c->sb, c->stream, fold_reset ? 1 : 0, c->first, c->seed, reset_epoch));
         const long long *gc = nullptr;
         if (comm_attached(c) && !one_coll) {

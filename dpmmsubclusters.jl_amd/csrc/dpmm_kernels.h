@@ -177,6 +177,7 @@ struct SortBufs {
     int tile;             // points per sorting wave of this context's passes: SORT_TILE or SORT_TILE_SMALL
     int32_t *tile_hist;   // [nbins][ntiles_sort] exclusive prefix over the tiles of a bin (written by the scan from tile_cnt)
     int32_t *tile_cnt;    // [nbins][ntiles_sort] points of bin b in tile t (written by the histogram)
+    int32_t *spec_bins;   // [n] the re-drawn bin of every point whose cluster was one-sided in the point's tile (written by hist_kernel<.., SPEC>, read by the scatter for flagged clusters)
     int32_t *tile_spec;   // [min(nbins, STEP_SPEC_MAX_BINS)][ntiles_sort] the same counts with the bad-cluster reset of the tile's one-sided clusters counted ahead (hist_kernel<.., SPEC>)
     int32_t *fast_total;  // [nbins][FAST_TOTAL_STRIDE] (element 0 of each line) running bin totals of the per-step histogram (integer atomics), cleared by scan_starts_kernel
     unsigned *ticket;     // [1] unused since the per-step scan and the starts are two launches (kept: the buffers are allocated as a set)

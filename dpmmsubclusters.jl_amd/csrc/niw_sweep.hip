@@ -1416,7 +1416,11 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
             bool bracketed = false;
             if constexpr (NB == 4) {
                 bool try_bracket = false;
-                if (A.bracket && k1 == k0 && A.use_prev && (FAST || (A.tail != nullptr && !A.labels_only))) {
+                // (LIST: a span is here BECAUSE niw_lean_kernel could not settle it against this very bracket -- q_hi far above q on an ill-conditioned
+                //  factor, or a far point -- so the screens of the retry would run against the same hopeless thresholds, let every candidate
+                //  through and leave K - 1 survivors to the early-exit evaluations: the 90-105 us launches of round 5.  The exact reference value
+                //  first (one evaluation), then the cheap screens do their work.  Labels are the same with or without a bracket.)
+                if (!LIST && A.bracket && k1 == k0 && A.use_prev && (FAST || (A.tail != nullptr && !A.labels_only))) {
                     if (br_skip > 0) --br_skip;
                     else {
                         const int prevl0 = binv >= 0 ? (binv >> 1) : -1;

@@ -44,14 +44,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // (7 us at the 8-GPU shard size, 17-21 us at N = 1e7).  But a cluster that will be flagged has one sub-bin empty in EVERY tile, and the re-draw
 // is a pure function of (seed, global point index, epoch): a tile can count the outcome ahead.  For every cluster that is one-sided IN THIS TILE
 // (exactly one of its two sub-bins is empty here; ~never for a healthy cluster: 2^-64 at 64 of its points per tile) the wave evaluates the
-// re-draw of those points and counts the result; `tile_spec` gets that count for such clusters and the plain count for all others.  The scan
-// then reads tile_spec for flagged clusters and tile_cnt for the rest, and the scatter applies the same re-draw to the labels it places
+// re-draw of those points, counts the result into `tile_spec` (written for such (tile, cluster) pairs only) and notes each point's new bin (`spec_bins`).  The scan
+// then reads tile_spec for flagged clusters and tile_cnt for the rest, and the scatter stores spec_bins for the points of flagged clusters and places them by it
 // (scatter_kernel<.., STEP>, RESET): same labels, same permutation as histogram -> reset_recount -> scan.
 template <int TILE, int W, bool SPEC>
 __global__ __launch_bounds__(64 * W) void hist_kernel(const int32_t *__restrict__ bins, int64_t n, int nbins, int nt,
                                                       int32_t *__restrict__ tile_hist, int32_t *__restrict__ fast_total,
                                                       uint16_t *__restrict__ prev_lab, uint8_t *__restrict__ dirty,
-                                                      int32_t *__restrict__ tile_spec, int64_t first, uint64_t seed, uint32_t epoch) {
+                                                      int32_t *__restrict__ tile_spec, int32_t *__restrict__ spec_bins, int64_t first, uint64_t seed, uint32_t epoch) {
     extern __shared__ int cnt_all[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int *const cnt = cnt_all + wave * nbins;
@@ -159,13 +159,9 @@ __global__ __launch_bounds__(64 * W) void hist_kernel(const int32_t *__restrict_
                 const int z2 = bv & ~1;
                 return (cnt[z2] == 0) != (cnt[z2 + 1] == 0);
             };
+            // does the tile hold a one-sided cluster at all?  One pass over the tile's counters (lane = bin); almost never: then nothing per point
             bool mine = false;
-            if (full) {
-#pragma unroll
-                for (int it = 0; it < TILE / 256; ++it) mine = mine || onesided(v[it].x) || onesided(v[it].y) || onesided(v[it].z) || onesided(v[it].w);
-            } else {
-                for (int it = 0; it < TILE / 64; ++it) { const int64_t i = base + it * 64 + lane; if (i < n) mine = mine || onesided(bins[i]); }
-            }
+            for (int b = lane; b < nbins; b += 64) mine = mine || ((cnt[b] == 0) != (cnt[b ^ 1] == 0));
             const bool some = __any(mine);
             if (some) {
                 for (int b = lane; b < nbins; b += 64) spc[b] = 0;
@@ -173,7 +169,9 @@ __global__ __launch_bounds__(64 * W) void hist_kernel(const int32_t *__restrict_
                 auto redraw = [&](int64_t i, int bv) {
                     if (!onesided(bv)) return;
                     const Philox4 r = philox4x32_10(seed, (uint64_t)(first + i), epoch, STREAM_RESET);      // reset_recount_kernel's draw
-                    atomicAdd(&spc[(bv & ~1) + (int)(r.v[0] & 1u)], 1);
+                    const int nb = (bv & ~1) + (int)(r.v[0] & 1u);
+                    spec_bins[i] = nb;                      // (what the scatter stores and places by if the cluster is flagged: no second draw there)
+                    atomicAdd(&spc[nb], 1);
                 };
                 if (full) {
 #pragma unroll
@@ -186,11 +184,9 @@ __global__ __launch_bounds__(64 * W) void hist_kernel(const int32_t *__restrict_
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
             }
-            for (int b = lane; b < nbins; b += 64) {
-                const int z2 = b & ~1;
-                const bool one = some && ((cnt[z2] == 0) != (cnt[z2 + 1] == 0));
-                tile_spec[(int64_t)b * nt + tile] = one ? spc[b] : cnt[b];
-            }
+            if (some)          // (only the one-sided clusters' entries are ever read: scan_tiles_step_kernel)
+                for (int b = lane; b < nbins; b += 64)
+                    if ((cnt[b] == 0) != (cnt[b ^ 1] == 0)) tile_spec[(int64_t)b * nt + tile] = spc[b];
         }
     }
     if (fast_total)
@@ -281,14 +277,13 @@ __global__ __launch_bounds__(64) void reset_recount_kernel(int32_t *__restrict__
 }
 
 // exclusive scan over the tiles of one bin (in place) + bin total
-__device__ __forceinline__ void scan_one_bin(const int32_t *__restrict__ tile_cnt, int32_t *__restrict__ tile_hist, int nt,
-                                             int32_t *__restrict__ bin_total, int *part) {
-    const int32_t *src = tile_cnt + (int64_t)blockIdx.x * nt;
+template <class Src>
+__device__ __forceinline__ void scan_one_bin_of(Src src, int32_t *__restrict__ tile_hist, int nt, int32_t *__restrict__ bin_total, int *part) {
     int32_t *row = tile_hist + (int64_t)blockIdx.x * nt;
     const int per = (nt + 255) / 256;
     const int lo = threadIdx.x * per, hi = min(lo + per, nt);
     int s = 0;
-    for (int i = lo; i < hi; ++i) s += src[i];
+    for (int i = lo; i < hi; ++i) s += src(i);
     // inclusive scan over the 256 partials: inside each wave with shuffles (no barrier), the four wave totals through LDS (ONE barrier;
     // the Hillis-Steele loop this replaces had sixteen)
     int inc = s;
@@ -305,11 +300,16 @@ __device__ __forceinline__ void scan_one_bin(const int32_t *__restrict__ tile_cn
     if (threadIdx.x == 255) part[255] = inc;       // (the total, where the callers read it)
     int run = inc - s;  // exclusive prefix of this thread's range
     for (int i = lo; i < hi; ++i) {
-        const int v = src[i];
+        const int v = src(i);
         row[i] = run;
         run += v;
     }
     if (threadIdx.x == 255) bin_total[blockIdx.x] = inc;
+}
+__device__ __forceinline__ void scan_one_bin(const int32_t *__restrict__ tile_cnt, int32_t *__restrict__ tile_hist, int nt,
+                                             int32_t *__restrict__ bin_total, int *part) {
+    const int32_t *src = tile_cnt + (int64_t)blockIdx.x * nt;
+    scan_one_bin_of([src](int i) -> int { return src[i]; }, tile_hist, nt, bin_total, part);
 }
 __global__ __launch_bounds__(256) void scan_tiles_kernel(const int32_t *__restrict__ tile_cnt, int32_t *__restrict__ tile_hist, int nt,
                                                          int32_t *__restrict__ bin_total) {
@@ -349,7 +349,11 @@ __global__ __launch_bounds__(256) void scan_tiles_step_kernel(const int32_t *__r
     long long a, b;
     occupancy((int)blockIdx.x >> 1, a, b);
     const bool bad = cside ? ((a == 0) != (b == 0)) : (a == 0 || b == 0);
-    scan_one_bin(bad ? tile_spec : tile_cnt, tile_hist, nt, bin_total, part);
+    if (!bad) { scan_one_bin(tile_cnt, tile_hist, nt, bin_total, part); return; }
+    // a flagged cluster: one of its sub-bins is empty in every tile, so every tile that holds points of it counted the re-draw ahead (tile_spec
+    // is written for exactly those (tile, cluster) pairs); a tile without points of it wrote nothing and contributes nothing
+    const int32_t *c0 = tile_cnt + (int64_t)blockIdx.x * nt, *c1 = tile_cnt + (int64_t)(blockIdx.x ^ 1) * nt, *sp = tile_spec + (int64_t)blockIdx.x * nt;
+    scan_one_bin_of([c0, c1, sp](int i) -> int { return (c0[i] | c1[i]) != 0 ? sp[i] : 0; }, tile_hist, nt, bin_total, part);
 }
 
 // bin_start[b] = sum_{b'<b} total ; item_start[b] = sum_{b'<b} ceil(sel*total / chunk)
@@ -434,7 +438,7 @@ __global__ __launch_bounds__(256) void starts_step_kernel(int32_t *bin_total, ui
 struct StepStarts {
     const int32_t *bin_total; uint8_t *bin_sel; int chunk; int32_t *bin_start_out; int32_t *item_start; int32_t *perm_total; int32_t *fast_total;
     uint8_t *mode; const uint8_t *dirty; int force_all;
-    const uint8_t *reset_flags; int64_t first; uint64_t seed; uint32_t epoch;      // (reset_flags != null: apply the bad-cluster reset while placing)
+    const uint8_t *reset_flags; const int32_t *spec_bins;      // (reset_flags != null: apply the bad-cluster reset while placing -- spec_bins[i]: the histogram's re-draw of point i)
 };
 template <int TILE, bool STEP>
 __global__ __launch_bounds__(64) void scatter_kernel(int32_t *bins, int64_t n, int nbins, int nt,
@@ -515,8 +519,7 @@ __global__ __launch_bounds__(64) void scatter_kernel(int32_t *bins, int64_t n, i
         if ((unsigned)b >= (unsigned)nbins) b = -1;
         if constexpr (STEP) {
             if (do_reset && b >= 0 && rflag[b >> 1]) {
-                const Philox4 r = philox4x32_10(st.seed, (uint64_t)(st.first + i), st.epoch, STREAM_RESET);
-                b = (b & ~1) + (int)(r.v[0] & 1u);
+                b = st.spec_bins[i];             // (the histogram's re-draw of this point: its cluster was one-sided in the point's tile -- every flagged cluster is, in every tile)
                 bins[i] = b;
             }
         }
@@ -585,15 +588,15 @@ hipError_t launch_derive_rows(double *out, double *cache, const uint8_t *mode, u
 static inline int sort_nt(int64_t n, const SortBufs &b) { return (int)((n + b.tile - 1) / b.tile); }
 template <int TILE>
 static inline void launch_hist(const int32_t *bins, int64_t n, int nbins, int nt, int32_t *tile_cnt, int32_t *fast_total, uint16_t *prev_lab, uint8_t *dirty,
-                               hipStream_t s, int32_t *tile_spec = nullptr, int64_t first = 0, uint64_t seed = 0, uint32_t epoch = 0) {
+                               hipStream_t s, int32_t *tile_spec = nullptr, int32_t *spec_bins = nullptr, int64_t first = 0, uint64_t seed = 0, uint32_t epoch = 0) {
     // eight tiles per workgroup while eight count arrays fit comfortably in LDS (K <= 512), else one
     if (tile_spec && nbins <= STEP_SPEC_MAX_BINS)       // (a second set of eight counter arrays: 32 KiB at 512 bins)
         DPMM_LAUNCH((hist_kernel<TILE, 8, true>), dim3((nt + 7) / 8), dim3(512), 16 * nbins * sizeof(int), s, bins, n, nbins, nt, tile_cnt, fast_total, prev_lab, dirty,
-                    tile_spec, first, seed, epoch);
+                    tile_spec, spec_bins, first, seed, epoch);
     else if (nbins <= 1024) DPMM_LAUNCH((hist_kernel<TILE, 8, false>), dim3((nt + 7) / 8), dim3(512), 8 * nbins * sizeof(int), s, bins, n, nbins, nt, tile_cnt, fast_total, prev_lab, dirty,
-                                        (int32_t *)nullptr, (int64_t)0, (uint64_t)0, 0u);
+                                        (int32_t *)nullptr, (int32_t *)nullptr, (int64_t)0, (uint64_t)0, 0u);
     else DPMM_LAUNCH((hist_kernel<TILE, 1, false>), dim3(nt), dim3(64), nbins * sizeof(int), s, bins, n, nbins, nt, tile_cnt, fast_total, prev_lab, dirty,
-                     (int32_t *)nullptr, (int64_t)0, (uint64_t)0, 0u);
+                     (int32_t *)nullptr, (int32_t *)nullptr, (int64_t)0, (uint64_t)0, 0u);
 }
 hipError_t launch_sort_by_bin(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s) {
     const int nt = sort_nt(n, b);
@@ -610,10 +613,10 @@ hipError_t launch_sort_by_bin(const int32_t *bins, int64_t n, int nbins, const S
 hipError_t launch_step_hist(const int32_t *bins, int64_t n, int nbins, const SortBufs &b, hipStream_t s, int spec, int64_t first, uint64_t seed, uint32_t epoch) {
     const int nt = sort_nt(n, b);
     uint8_t *dirty = b.prev_lab ? b.cdirty : (uint8_t *)nullptr;
-    int32_t *ts = (spec && b.tile_spec && nbins <= STEP_SPEC_MAX_BINS) ? b.tile_spec : (int32_t *)nullptr;
+    int32_t *ts = (spec && b.tile_spec && b.spec_bins && nbins <= STEP_SPEC_MAX_BINS) ? b.tile_spec : (int32_t *)nullptr;
     DPMM_TILE_DISPATCH(b.tile,
-        launch_hist<512>(bins, n, nbins, nt, b.tile_cnt, b.fast_total, b.prev_lab, dirty, s, ts, first, seed, epoch),
-        launch_hist<2048>(bins, n, nbins, nt, b.tile_cnt, b.fast_total, b.prev_lab, dirty, s, ts, first, seed, epoch));
+        launch_hist<512>(bins, n, nbins, nt, b.tile_cnt, b.fast_total, b.prev_lab, dirty, s, ts, b.spec_bins, first, seed, epoch),
+        launch_hist<2048>(bins, n, nbins, nt, b.tile_cnt, b.fast_total, b.prev_lab, dirty, s, ts, b.spec_bins, first, seed, epoch));
     return hipGetLastError();
 }
 hipError_t launch_step_reset(int32_t *bins, int64_t n, int64_t first, int nbins, const SortBufs &b, const long long *global_counts, uint8_t *flags,
@@ -1356,7 +1359,7 @@ hipError_t launch_step_scan_scatter(int32_t *bins, const StatsArgs &a, int deriv
     if ((fused_starts || rs) && nt > 0) {          // the starts inside the scatter launch (StepStarts above)
         const StepStarts st{a.sb.bin_total, a.sb.bin_sel, a.chunk, a.sb.bin_start, a.sb.item_start, a.sb.perm_total, a.sb.fast_total,
                             derive ? a.sb.cmode : (uint8_t *)nullptr, a.sb.cdirty, force_all,
-                            rs ? rs->flags : (const uint8_t *)nullptr, rs ? rs->first : 0, rs ? rs->seed : 0, rs ? rs->epoch : 0u};
+                            rs ? rs->flags : (const uint8_t *)nullptr, rs ? a.sb.spec_bins : (const int32_t *)nullptr};
         const size_t lds = a.nbins * sizeof(int) + (size_t)(((a.nbins >> 1) + 3) & ~3);
         DPMM_TILE_DISPATCH(a.sb.tile,
             DPMM_LAUNCH((scatter_kernel<512, true>), dim3(nt), dim3(64), lds, s, bins, a.n, a.nbins, nt, a.sb.tile_hist, a.sb.bin_start, a.sb.perm, st),
