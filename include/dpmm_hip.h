@@ -101,11 +101,12 @@ enum {
     DPMM_OPT_MASTER_POLL = 28,        /* 1 (default, round 6): dpmm_step_master_device waits on the posteriors' own records in pinned host memory (every record starts as a
                                          marker no kernel produces) instead of on an event: no barrier packet between the posteriors and the draws launched behind them.
                                          0: the event wait of rounds 3-5.  Same values either way. */
-    DPMM_OPT_CHAIN_FUSION = 29,       /* bit mask (default: all; round 6): launches of the n-independent chain of a step folded into their neighbours --
+    DPMM_OPT_CHAIN_FUSION = 29,       /* bit mask (default, also for a negative value: all but bit 32; round 6): launches of the n-independent chain of a step folded into their neighbours --
                                          1: the sort's bin / item starts inside the scatter launch (no starts_step launch); 2: the three-plane sub-cluster images
                                          written by the launch that packs the parameters (no niw_b3_pack launch); 4: the list of pooled-pair jobs that ride in the posteriors'
                                          launch is read from pinned host memory (no copy launch when the merge gates change); 8: the bad-cluster reset is counted ahead by the per-step
-                                         histogram for the clusters that are one-sided in a tile and applied by the scatter launch (no reset_recount launch; K <= 256); 16: the standard
+                                         histogram for the clusters that are one-sided in a tile and applied by the scatter launch (no reset_recount launch; K <= 256; from 4e6 points per
+                                         shard -- below, the launch it removes is at its 5 us floor and cheaper: bit 32 forces the folded form at any size); 16: the standard
                                          normals of the draws launched ahead are generated by extra workgroups of the posteriors' launch (D <= 128; no kernel on the second stream beside
                                          the sweep, no cross-stream wait in front of the draws).  0: the launches of round 5.  Same values. */
     DPMM_OPT_MULT_DRAWS_AHEAD = 25,   /* 1 (default): Multinomial device master: dpmm_step_stats launches the NEXT Dirichlet draws and their hand-over images

@@ -60,7 +60,8 @@ ORC_API void orc_philox(uint64_t seed, uint64_t idx, uint32_t epoch, uint32_t st
 /* streams */
 enum { ORC_STREAM_SWEEP = 0, ORC_STREAM_INIT = 1, ORC_STREAM_SPLIT = 2, ORC_STREAM_RESET = 3 };
 
-static inline float u01(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
+/* (0, 1): odd multiples of 2^-24 (never 0: a threshold t = u * sum of exactly 0 would stop the scan at index 0 whatever its probability) */
+static inline float u01(uint32_t r) { return (float)((r >> 8) | 1u) * (1.0f / 16777216.0f); }
 
 ORC_API void orc_uniforms(uint64_t seed, uint32_t epoch, uint32_t stream, int64_t first_idx, int64_t n,
                           float *u0, float *u1) {

@@ -182,7 +182,7 @@ def test_reset_counted_ahead_is_the_reset_launch(pkg, D, n, K, order):
     for fold in (1, 0):
         wk = pkg.Worker(pkg.PRIOR_NIW, D, n, first_index=12345, device=0, seed=77)
         wk.upload_points(X)
-        wk.set_option(binding.OPT_CHAIN_FUSION, 0x7fffffff if fold else 0x7fffffff & ~8)
+        wk.set_option(binding.OPT_CHAIN_FUSION, 0x7fffffff if fold else 0x7fffffff & ~(8 | 32))        # (bit 32: the folded form below 4e6 points too)
         wk.set_num_clusters(K)
         wk.set_labels(lab, sub)
         passes = []

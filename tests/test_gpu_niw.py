@@ -844,7 +844,7 @@ def test_folded_launches_and_the_polling_wait_are_the_same_chain(pkg, D, N, K, v
     X, y = host.gaussian_mixture_shard(N, D, K, var, 500 + D, 0, N)
     prior = host.niw_hyperparams(1.0, np.zeros(D), D + 3, np.eye(D))
     out = {}
-    for name, opts in (("all", ()), ("unfused", ((binding.OPT_CHAIN_FUSION, 0),)), ("event", ((binding.OPT_MASTER_POLL, 0),)),
+    for name, opts in (("all", ((binding.OPT_CHAIN_FUSION, 0x7fffffff),)), ("default", ()), ("unfused", ((binding.OPT_CHAIN_FUSION, 0),)), ("event", ((binding.OPT_MASTER_POLL, 0),)),
                        ("round5", ((binding.OPT_CHAIN_FUSION, 0), (binding.OPT_MASTER_POLL, 0)))):
         wk = pkg.Worker(pkg.PRIOR_NIW, D, N, device=0, seed=3)
         wk.upload_points(X)
@@ -869,7 +869,7 @@ def test_folded_launches_and_the_polling_wait_are_the_same_chain(pkg, D, N, K, v
     assert out["all"][3] == out["round5"][3]
     if D == 64 and var == 100.0:
         assert out["all"][3][0] > 0          # (the folded reset did run: hist_kernel<.., SPEC> + scan_tiles_step_kernel + the scatter's re-draw)
-    for name in ("unfused", "event", "round5"):
+    for name in ("default", "unfused", "event", "round5"):
         assert out[name][0] == out["all"][0], name
         for a, b in zip(out[name][1], out["all"][1]):
             assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), name
