@@ -1103,36 +1103,6 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
     const int tid = threadIdx.x, lane = tid & 63;
     const int ci = lane & 15, g = lane >> 4;
     const int K = A.K;
-    if constexpr (LIST && NB == 4) {
-        // A workgroup that has spans warms ITS XCD's L2 with the cluster-level images first (round 6).  The launch runs behind niw_lean_kernel,
-        // which has streamed the points through every L2: a span's candidates then wait for memory, not for L2, at each of their dependent
-        // operand fetches -- bottom screen, top screen, 16-row screen, evaluation: ~5 k cycles per candidate, one candidate after the other in
-        // one wave.  A span with a far outlier point keeps all K - 1 candidates to the end (no 4-row or ball bound excludes anything for it):
-        // 31 x 5 k cycles = the 90-105 us launches of round 5 (45 % of the sweeps at N = 1e7, scripts/stamps_list.py).  One pass of loads with
-        // everything in flight (K = 32: 520 KB, 16 lines per thread) costs one memory latency.  No effect on values.
-        if (K <= 128) {
-            unsigned sink = 0u;
-            // `count` records of `rec_bytes` bytes, `stride_bytes` apart: one flat index over all their 128-byte lines, eight loads per thread in flight
-            auto touch = [&](const void *base, int count, size_t rec_bytes, size_t stride_bytes) {
-                const char *p0 = reinterpret_cast<const char *>(base);
-                const int lpr = (int)((rec_bytes + 127) >> 7), nl = count * lpr;
-                for (int i0 = tid; i0 < nl; i0 += 256 * 8) {
-                    unsigned v[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int i = i0 + 256 * u;
-                        v[u] = i < nl ? *reinterpret_cast<const volatile unsigned *>(p0 + (size_t)(i / lpr) * stride_bytes + ((size_t)(i % lpr) << 7)) : 0u;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) sink += v[u];
-                }
-            };
-            touch(A.Rp, K, sizeof(float) * MATSZ, sizeof(float) * 3 * MATSZ);
-            touch(refb_records(A.tail, K), K, sizeof(uint32_t) * REFB_WORDS, sizeof(uint32_t) * REFB_WORDS);
-            touch(A.mup, K, sizeof(float) * DP, sizeof(float) * 3 * DP);
-            asm volatile("" :: "v"(sink));
-        }
-    }
     if (A.prio) __builtin_amdgcn_s_setprio(2);
     const bool use_order = A.order != nullptr && *A.order_total == (int32_t)A.n;
     const bool owner = lane < WPTS;
@@ -1416,10 +1386,10 @@ __global__ __launch_bounds__(256, OCC) void niw_sweep_direct_kernel(NiwSweepArgs
             bool bracketed = false;
             if constexpr (NB == 4) {
                 bool try_bracket = false;
-                // (LIST: a span is here BECAUSE niw_lean_kernel could not settle it against this very bracket -- q_hi far above q on an ill-conditioned
-                //  factor, or a far point -- so the screens of the retry would run against the same hopeless thresholds, let every candidate
-                //  through and leave K - 1 survivors to the early-exit evaluations: the 90-105 us launches of round 5.  The exact reference value
-                //  first (one evaluation), then the cheap screens do their work.  Labels are the same with or without a bracket.)
+                // (LIST: a span is here because niw_lean_kernel could not settle it against this very bracket -- the screens of a retry would run
+                //  against the same thresholds: the exact reference value first, one evaluation.  Labels are the same with or without a bracket.
+                //  What round 5 took for "a far outlier tile" in 45 % of the sweeps -- launches of 45 and 100 us -- were tiles with a uniform of
+                //  exactly 0: gone since the uniforms are in (0, 1), dpmm_device.h u01; scripts/parts_trace.py: 24 of 24 sweeps hand on nothing.)
                 if (!LIST && A.bracket && k1 == k0 && A.use_prev && (FAST || (A.tail != nullptr && !A.labels_only))) {
                     if (br_skip > 0) --br_skip;
                     else {

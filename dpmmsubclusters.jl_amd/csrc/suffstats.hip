@@ -283,6 +283,15 @@ __device__ __forceinline__ void scan_one_bin_of(Src src, int32_t *__restrict__ t
     const int per = (nt + 255) / 256;
     const int lo = threadIdx.x * per, hi = min(lo + per, nt);
     int s = 0;
+    // a thread's counts stay in registers between the two passes when they fit (up to 24 per thread: 6144 tiles = 12.6e6 points per shard at
+    // 2048-point tiles): the second pass then reads nothing -- the flagged clusters' source is three loads per element
+    constexpr int KEEP = 24;
+    int kept[KEEP];
+    const bool keep = per <= KEEP;
+    if (keep) {
+#pragma unroll
+        for (int u = 0; u < KEEP; ++u) { kept[u] = (u < per && lo + u < hi) ? src(lo + u) : 0; s += kept[u]; }
+    } else
     for (int i = lo; i < hi; ++i) s += src(i);
     // inclusive scan over the 256 partials: inside each wave with shuffles (no barrier), the four wave totals through LDS (ONE barrier;
     // the Hillis-Steele loop this replaces had sixteen)
@@ -299,6 +308,11 @@ __device__ __forceinline__ void scan_one_bin_of(Src src, int32_t *__restrict__ t
     inc += before;
     if (threadIdx.x == 255) part[255] = inc;       // (the total, where the callers read it)
     int run = inc - s;  // exclusive prefix of this thread's range
+    if (keep) {
+#pragma unroll
+        for (int u = 0; u < KEEP; ++u)
+            if (u < per && lo + u < hi) { row[lo + u] = run; run += kept[u]; }
+    } else
     for (int i = lo; i < hi; ++i) {
         const int v = src(i);
         row[i] = run;
@@ -439,6 +453,7 @@ struct StepStarts {
     const int32_t *bin_total; uint8_t *bin_sel; int chunk; int32_t *bin_start_out; int32_t *item_start; int32_t *perm_total; int32_t *fast_total;
     uint8_t *mode; const uint8_t *dirty; int force_all;
     const uint8_t *reset_flags; const int32_t *spec_bins;      // (reset_flags != null: apply the bad-cluster reset while placing -- spec_bins[i]: the histogram's re-draw of point i)
+    const int32_t *tile_cnt;                                    // (the histogram's counts: does this tile hold a point of a flagged cluster at all?)
 };
 template <int TILE, bool STEP>
 __global__ __launch_bounds__(64) void scatter_kernel(int32_t *bins, int64_t n, int nbins, int nt,
@@ -454,8 +469,14 @@ __global__ __launch_bounds__(64) void scatter_kernel(int32_t *bins, int64_t n, i
     bool do_reset = false;
     if constexpr (STEP) {
         if (st.reset_flags && st.reset_flags[nbins >> 1]) {           // flags[K]: any cluster flagged (workgroup-uniform)
-            do_reset = true;
-            for (int k = lane; k < (nbins >> 1); k += 64) rflag[k] = st.reset_flags[k];
+            // ... and only a tile that holds points of a flagged cluster looks at its points' flags (in storage order most tiles hold none)
+            bool need = false;
+            for (int b = lane; b < nbins; b += 64) {
+                const uint8_t f = st.reset_flags[b >> 1];
+                if (!(b & 1)) rflag[b >> 1] = f;
+                need = need || (f && st.tile_cnt[(int64_t)b * nt + blockIdx.x] > 0);
+            }
+            do_reset = __any(need);
         }
     }
     if constexpr (STEP) {
@@ -1359,7 +1380,7 @@ hipError_t launch_step_scan_scatter(int32_t *bins, const StatsArgs &a, int deriv
     if ((fused_starts || rs) && nt > 0) {          // the starts inside the scatter launch (StepStarts above)
         const StepStarts st{a.sb.bin_total, a.sb.bin_sel, a.chunk, a.sb.bin_start, a.sb.item_start, a.sb.perm_total, a.sb.fast_total,
                             derive ? a.sb.cmode : (uint8_t *)nullptr, a.sb.cdirty, force_all,
-                            rs ? rs->flags : (const uint8_t *)nullptr, rs ? a.sb.spec_bins : (const int32_t *)nullptr};
+                            rs ? rs->flags : (const uint8_t *)nullptr, rs ? a.sb.spec_bins : (const int32_t *)nullptr, a.sb.tile_cnt};
         const size_t lds = a.nbins * sizeof(int) + (size_t)(((a.nbins >> 1) + 3) & ~3);
         DPMM_TILE_DISPATCH(a.sb.tile,
             DPMM_LAUNCH((scatter_kernel<512, true>), dim3(nt), dim3(64), lds, s, bins, a.n, a.nbins, nt, a.sb.tile_hist, a.sb.bin_start, a.sb.perm, st),
