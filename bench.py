@@ -360,7 +360,7 @@ SWEEP_KERNELS_64 = ("niw_lean_kernel", "niw_sweep_direct_kernel", "niw_sub_kerne
 def sweep_kernel_names(D):
     """The launches of one NIW sweep.  33 <= D <= 64: niw_lean_kernel (every tile; finishes the tiles whose label candidates the
     screens settle) and niw_sweep_direct_kernel<..., LSTORE, LIST> (labels and sub-labels of the spans it handed on); without the lean
-    launch (overlapping clusters, K > 64) niw_sweep_direct_kernel<..., LSTORE> (labels) and niw_sub_kernel (sub-labels) on every tile;
+    launch (overlapping clusters; K > 64 on the set_params path, whose pre-screen runs in the sweep kernel) niw_sweep_direct_kernel<..., LSTORE> (labels) and niw_sub_kernel (sub-labels) on every tile;
     D <= 32: niw_sweep_direct_kernel alone; D > 64: niw_sweep_kernel (behind its bracket launch)."""
     return "+".join(SWEEP_KERNELS_64) if 32 < D <= 64 else ("niw_sweep_direct_kernel" if D <= 32 else "niw_sweep_kernel")
 

@@ -240,7 +240,7 @@ struct dpmm_ctx {
     int sp_cooldown = 0;               // parameter sets the screen stays off after it removed less than a quarter of what it was given
     int opt_b3 = 1;                    // DPMM_OPT_B3_SUBLABELS: D in 33..64: sub-cluster evaluations through three-plane bf16 images, in kernels of their own (niw_lean.hip)
     bool have_b3 = false;              // the images behind the bracket's in d_tail belong to the parameter set on the device
-    int opt_chain = 0x7fffffff & ~32;  // DPMM_OPT_CHAIN_FUSION (bit mask): 1 = the sort's starts inside the scatter launch; 2 = the three-plane images in the hand-over launch; 4 = the fused pair jobs' list read from pinned memory; 8 = the bad-cluster reset counted ahead by the histogram and applied by the scatter (no reset launch); 16 = the draws' normals generated inside the posteriors' launch
+    int opt_chain = 0x7fffffff & ~(8 | 32);  // (bits 8 / 32: built, value-neutral, measured -- no gain at either size: off by default) DPMM_OPT_CHAIN_FUSION (bit mask): 1 = the sort's starts inside the scatter launch; 2 = the three-plane images in the hand-over launch; 4 = the fused pair jobs' list read from pinned memory; 8 = the bad-cluster reset counted ahead by the histogram and applied by the scatter (no reset launch); 16 = the draws' normals generated inside the posteriors' launch
     int opt_master_poll = 1;           // DPMM_OPT_MASTER_POLL: dpmm_step_master_device waits on the posteriors' own records in pinned memory (no event between posteriors and draws)
     int opt_lean = 1;                  // DPMM_OPT_LEAN_TILES: tiles the cheap screens settle completely in niw_lean_kernel (-1 automatic is 1 with a regime switch; 0 never)
     uint32_t *d_hard = nullptr;        // two lists of [2 + ceil(n / 64)] words, taking turns (hard_flip): count | wave tiles the lean kernel left to the general path;
@@ -1485,8 +1485,9 @@ static int run_stats(dpmm_ctx *c, const int64_t *idx, int n_idx, bool with_reset
         // -> scatter.  The flags live right behind the packed rows, so that rows + flags reach the master in one copy.
         // DPMM_OPT_CHAIN_FUSION bit 8 (round 6): no reset launch -- the histogram counts the reset ahead for the clusters that are one-sided in a
         // tile, the scan derives the flags and picks those counts for flagged clusters, the scatter applies the re-draw while it places
-        // (where it pays: the launch it removes re-reads every label -- 17-21 us at N = 1e7 against +10 us in the three kernels that take its work
-        //  over; at the 8-GPU shard size that launch is at its 5 us floor and the fold costs 7: automatic from 4e6 points, bit 32 forces it)
+        // (measured, round 6: the launch it removes costs 18 us at N = 1e7 and 7 us at the 8-GPU shard size; the three kernels that take its work
+        //  over grow by 6.5 + 4.3 + 9.2 us and 2.4 + 2.0 + 3.4 us -- no gain at either size, so the bit is OFF by default; it is value-neutral and
+        //  tested (tests/test_gpu_derive.py).  Bit 8 alone applies from 4e6 points per shard, bit 32 at any size.)
         const bool fold_reset = (c->opt_chain & 8) != 0 && (c->n >= 4000000 || (c->opt_chain & 32) != 0) && nbins <= STEP_SPEC_MAX_BINS &&
                                 c->sb.tile_spec != nullptr && c->sb.spec_bins != nullptr;
         HIPCHK(c, launch_step_hist(c->dbins, c->n, nbins, c->sb, c->stream, fold_reset ? 1 : 0, c->first, c->seed, reset_epoch));
@@ -2712,7 +2713,7 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
         case DPMM_OPT_COMM_TIMEOUT_MS: c->comm_timeout_ms = value > 0 ? (int)std::min(value, 2.0e9) : 0; return DPMM_OK;
         case DPMM_OPT_BF16_SCREENS: c->opt_bf16scr = value != 0; return DPMM_OK;
         case DPMM_OPT_MASTER_POLL: c->opt_master_poll = value != 0; return DPMM_OK;
-        case DPMM_OPT_CHAIN_FUSION: c->opt_chain = value < 0 ? (0x7fffffff & ~32) : (int)value; return DPMM_OK;
+        case DPMM_OPT_CHAIN_FUSION: c->opt_chain = value < 0 ? (0x7fffffff & ~(8 | 32)) : (int)value; return DPMM_OK;
         case DPMM_OPT_LEAN_TILES: c->opt_lean = value != 0; c->lean_off = 0; c->lean_backoff = 15; c->lean_ran = false; return DPMM_OK;
         case DPMM_OPT_B3_SUBLABELS: c->opt_b3 = value != 0; if (!c->opt_b3) c->have_b3 = false; return DPMM_OK;      // (switching it ON takes effect with the next parameter set: its images are packed behind the parameters)
         case DPMM_OPT_DIRECTION_SCREEN:

@@ -97,16 +97,18 @@ enum {
                                          bins of the last sort); what it hands on is finished by one launch of the sweep kernel.  Same labels and sub-labels either way.
                                          0: every tile through the sweep kernel (labels) and niw_sub_kernel (sub-labels).
                                          A sweep that hands on more than 30 % of its tiles switches the lean launch off for 15 sweeps (31, 63, ... up to 1023 while the
-                                         retries keep failing); it also stays off while the direction screen's regime is on and beyond 64 clusters (scalar pre-screen). */
+                                         retries keep failing); it also stays off while the direction screen's regime is on, and -- on the dpmm_set_params_* path only -- beyond 64 clusters, where the
+                                         scalar pre-screen (DPMM_OPT_PRESCREEN) runs inside the sweep kernel.  Parameters drawn on the device (dpmm_niw_master_draw) come without a pre-screen: there
+                                         the lean launch runs at any K (tiles aligned to the sort's bins up to 256 bins, 64 consecutive positions beyond; tests/test_gpu_niw.py). */
     DPMM_OPT_MASTER_POLL = 28,        /* 1 (default, round 6): dpmm_step_master_device waits on the posteriors' own records in pinned host memory (every record starts as a
                                          marker no kernel produces) instead of on an event: no barrier packet between the posteriors and the draws launched behind them.
                                          0: the event wait of rounds 3-5.  Same values either way. */
-    DPMM_OPT_CHAIN_FUSION = 29,       /* bit mask (default, also for a negative value: all but bit 32; round 6): launches of the n-independent chain of a step folded into their neighbours --
+    DPMM_OPT_CHAIN_FUSION = 29,       /* bit mask (default, also for a negative value: 1 | 2 | 4 | 16; round 6): launches of the n-independent chain of a step folded into their neighbours --
                                          1: the sort's bin / item starts inside the scatter launch (no starts_step launch); 2: the three-plane sub-cluster images
                                          written by the launch that packs the parameters (no niw_b3_pack launch); 4: the list of pooled-pair jobs that ride in the posteriors'
-                                         launch is read from pinned host memory (no copy launch when the merge gates change); 8: the bad-cluster reset is counted ahead by the per-step
-                                         histogram for the clusters that are one-sided in a tile and applied by the scatter launch (no reset_recount launch; K <= 256; from 4e6 points per
-                                         shard -- below, the launch it removes is at its 5 us floor and cheaper: bit 32 forces the folded form at any size); 16: the standard
+                                         launch is read from pinned host memory (no copy launch when the merge gates change); 8: (off by default: measured, no gain) the bad-cluster reset is counted ahead by the per-step
+                                         histogram for the clusters that are one-sided in a tile and applied by the scatter launch (no reset_recount launch; K <= 256; from 4e6
+                                         points per shard, with bit 32 at any size); 16: the standard
                                          normals of the draws launched ahead are generated by extra workgroups of the posteriors' launch (D <= 128; no kernel on the second stream beside
                                          the sweep, no cross-stream wait in front of the draws).  0: the launches of round 5.  Same values. */
     DPMM_OPT_MULT_DRAWS_AHEAD = 25,   /* 1 (default): Multinomial device master: dpmm_step_stats launches the NEXT Dirichlet draws and their hand-over images
