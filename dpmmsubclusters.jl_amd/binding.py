@@ -103,7 +103,7 @@ HOST_ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_voi
 
 # dpmm_set_option keys (include/dpmm_hip.h)
 MASTER_NSCALARS = 8          # DPMM_MASTER_NSCALARS
-OPT_SCREEN_MARGIN, OPT_TAIL_SCREEN, OPT_PRESCREEN, OPT_ORDERED_SWEEP, OPT_MULT_FORCE_F32, OPT_STATS_ITEMS, OPT_STATS_GROUPS, OPT_TRACE_SLOW, OPT_LOGLIK_REF_CONST, OPT_WAVE_PRIO, OPT_MULT_NO_U8, OPT_SWEEP_GRID, OPT_SWEEP_QUEUE_ROUNDS, OPT_BALL_SCREEN, OPT_KERNEL_TIMING, OPT_STATS_DERIVE, OPT_NOISE_AHEAD, OPT_REF_BRACKET, OPT_SORT_TILE, OPT_ONE_COLLECTIVE, OPT_BF16_SCREENS, OPT_COMM_TIMEOUT_MS, OPT_DIRECTION_SCREEN, _OPT_RESERVED_24, OPT_MULT_DRAWS_AHEAD, OPT_B3_SUBLABELS, OPT_LEAN_TILES, OPT_MASTER_POLL, OPT_CHAIN_FUSION = range(1, 30)
+OPT_SCREEN_MARGIN, OPT_TAIL_SCREEN, OPT_PRESCREEN, OPT_ORDERED_SWEEP, OPT_MULT_FORCE_F32, OPT_STATS_ITEMS, OPT_STATS_GROUPS, OPT_TRACE_SLOW, OPT_LOGLIK_REF_CONST, OPT_WAVE_PRIO, OPT_MULT_NO_U8, OPT_SWEEP_GRID, OPT_SWEEP_QUEUE_ROUNDS, OPT_BALL_SCREEN, OPT_KERNEL_TIMING, OPT_STATS_DERIVE, OPT_NOISE_AHEAD, OPT_REF_BRACKET, OPT_SORT_TILE, OPT_ONE_COLLECTIVE, OPT_BF16_SCREENS, OPT_COMM_TIMEOUT_MS, OPT_DIRECTION_SCREEN, _OPT_RESERVED_24, OPT_MULT_DRAWS_AHEAD, OPT_B3_SUBLABELS, OPT_LEAN_TILES, OPT_MASTER_POLL, OPT_CHAIN_FUSION, OPT_LEAN_DIRECTION = range(1, 31)
 
 
 class DpmmError(RuntimeError):

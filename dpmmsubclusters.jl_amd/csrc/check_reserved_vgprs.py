@@ -1,39 +1,50 @@
 #!/usr/bin/env python3
-"""Build-time check of the lean kernels' reserved registers.
+"""Build-time check of the lean kernels' touches (rewritten in round 6).
 
-niw_lean_kernel / niw_sub_kernel touch the next tile's x rows with inline-asm `global_load_dword v254 / v255`: two registers nothing reads, loaded
-behind the compiler's back so that no wait is ever emitted for them.  That is only safe while the register allocator never places a value of
-its own in v254 / v255 -- a touch returning late would overwrite it.  `amdgpu_num_vgpr(254)` asks for that; this script PROVES it on the
-generated code: in the device assembly of niw_lean.hip no instruction other than the touches names v254 or v255 (alone or inside a register
-range), and no kernel that contains a touch spills vector registers around it unnoticed (reported, not fatal).
+niw_lean_kernel / niw_sub_kernel touch the next tile's x rows behind the compiler's back (inline asm; its vmcnt bookkeeping must not see them).
+Round 5 loaded them into v254 / v255 and relied on amdgpu_num_vgpr(254) to keep the allocator away; round 6's first change that added register
+pressure made the allocator use those registers, and this script -- then checking exactly that -- stopped the build.  The touches now have no
+register destination (global_load_lds_dword: M0 + 4 * lane in LDS), so what has to hold in the generated code is:
+
+  * every global_load_lds_dword of niw_lean.hip sits between `s_mov_b32 sN, m0` (save) and `s_mov_b32 m0, sN` (restore, the same sN), with
+    nothing in between but the M0 write, s_nop and the touches themselves: the compiler's own uses of M0 never see the sink's address;
+  * no load names a fixed high register as in the old scheme (v254 / v255 as a destination of global_load_dword).
 
     check_reserved_vgprs.py <device assembly .s>        exit status 1 (with the offending lines) if the property does not hold
 """
 import re
 import sys
 
-RESERVED = (254, 255)
-
 
 def offending(lines):
+    """(bad lines, number of touches).  Walks the assembly; an LDS-DMA touch outside a save ... restore window of M0 is bad."""
     bad, touches = [], 0
-    single = re.compile(r"\bv(\d+)\b")
-    rng = re.compile(r"\bv\[(\d+):(\d+)\]")
+    saved = None              # the SGPR holding M0 inside a window, else None
     for no, raw in enumerate(lines, 1):
         line = raw.split(";")[0].strip()
         if not line or line.startswith((".", "//")) or line.endswith(":"):
             continue
-        regs = {int(m.group(1)) for m in single.finditer(line)}
-        for m in rng.finditer(line):
-            regs.update(range(int(m.group(1)), int(m.group(2)) + 1))
-        hit = [r for r in RESERVED if r in regs]
-        if not hit:
+        m = re.match(r"s_mov_b32\s+(s\d+),\s*m0$", line)
+        if m:
+            saved = m.group(1)
             continue
-        m = re.match(r"global_load_dword\s+v(\d+),\s*v\[\d+:\d+\],\s*off\s*$", line)
-        if m and int(m.group(1)) in RESERVED:
+        m = re.match(r"s_mov_b32\s+m0,\s*(\S+)$", line)
+        if m and saved is not None:
+            if m.group(1) == saved:
+                saved = None              # restored: window closed
+            continue                      # (the sink's base)
+        if line.startswith("global_load_lds_dword"):
             touches += 1
+            if saved is None:
+                bad.append((no, raw.rstrip()))
             continue
-        bad.append((no, raw.rstrip()))
+        if saved is not None and not line.startswith("s_nop"):
+            bad.append((no, raw.rstrip()))          # something else inside the window: it could read or write M0
+            saved = None
+        if re.match(r"global_load_dword\s+v25[45],", line):
+            bad.append((no, raw.rstrip()))          # the old scheme
+    if saved is not None:
+        bad.append((len(lines), "M0 saved and never restored"))
     return bad, touches
 
 
@@ -41,14 +52,14 @@ def main():
     lines = open(sys.argv[1]).read().split("\n")
     bad, touches = offending(lines)
     if touches == 0:
-        print("check_reserved_vgprs: no touch load found -- the check does not apply any more (remove it together with the touches)", file=sys.stderr)
+        print("check_reserved_vgprs: no LDS-DMA touch found -- the check does not apply any more (remove it together with the touches)", file=sys.stderr)
         return 1
     if bad:
-        print(f"check_reserved_vgprs: v254 / v255 are used outside the {touches} touch loads -- a late touch could overwrite a live value:", file=sys.stderr)
+        print(f"check_reserved_vgprs: {len(bad)} line(s) break the touches' M0 save / restore window:", file=sys.stderr)
         for no, l in bad[:20]:
             print(f"  line {no}: {l}", file=sys.stderr)
         return 1
-    print(f"check_reserved_vgprs: ok ({touches} touch loads, v254 / v255 named nowhere else)")
+    print(f"check_reserved_vgprs: ok ({touches} LDS-DMA touches, each inside a save / restore of M0)")
     return 0
 
 

@@ -241,6 +241,7 @@ struct dpmm_ctx {
     int opt_b3 = 1;                    // DPMM_OPT_B3_SUBLABELS: D in 33..64: sub-cluster evaluations through three-plane bf16 images, in kernels of their own (niw_lean.hip)
     bool have_b3 = false;              // the images behind the bracket's in d_tail belong to the parameter set on the device
     int opt_chain = 0x7fffffff & ~(8 | 32);  // (bits 8 / 32: built, value-neutral, measured -- no gain at either size: off by default) DPMM_OPT_CHAIN_FUSION (bit mask): 1 = the sort's starts inside the scatter launch; 2 = the three-plane images in the hand-over launch; 4 = the fused pair jobs' list read from pinned memory; 8 = the bad-cluster reset counted ahead by the histogram and applied by the scatter (no reset launch); 16 = the draws' normals generated inside the posteriors' launch
+    int opt_lean_dir = 1;              // DPMM_OPT_LEAN_DIRECTION: the lean kernel runs the direction screen while its tables exist (0: no lean launch in that regime, as in rounds 4-5)
     int opt_master_poll = 1;           // DPMM_OPT_MASTER_POLL: dpmm_step_master_device waits on the posteriors' own records in pinned memory (no event between posteriors and draws)
     int opt_lean = 1;                  // DPMM_OPT_LEAN_TILES: tiles the cheap screens settle completely in niw_lean_kernel (-1 automatic is 1 with a regime switch; 0 never)
     uint32_t *d_hard = nullptr;        // two lists of [2 + ceil(n / 64)] words, taking turns (hard_flip): count | wave tiles the lean kernel left to the general path;
@@ -653,8 +654,10 @@ int dpmm_create(dpmm_ctx **out, int prior_kind, int D, int64_t n_local, int64_t 
         CHK_CREATE(hipMalloc(&c->d_sp_frag, sizeof(uint32_t) * (size_t)SP_MAXK * SP_FRAG_WORDS));
         CHK_CREATE(hipMalloc(&c->d_sp_cons, sizeof(float) * (size_t)SP_MAXK * SP_CONS_FLOATS));
         // ([8 grid]: two words per wave of the sweep kernel | [4 grid]: tiles the lean kernel settled, per wave)
-        CHK_CREATE(hipHostMalloc((void **)&c->h_need, sizeof(uint32_t) * 12 * (size_t)std::max(1, c->sweep_grid_max), hipHostMallocDefault));
-        memset(c->h_need, 0, sizeof(uint32_t) * 12 * (size_t)std::max(1, c->sweep_grid_max));
+        // [0, 8 g): two words per wave of the general kernel | [8 g, 12 g): one word per wave of the lean kernel (tiles settled without the direction
+        // screen) | [12 g, 20 g): two words per wave of the lean kernel WITH the direction screen (round 6)      (g = sweep_grid_max workgroups of 4 waves)
+        CHK_CREATE(hipHostMalloc((void **)&c->h_need, sizeof(uint32_t) * 20 * (size_t)std::max(1, c->sweep_grid_max), hipHostMallocDefault));
+        memset(c->h_need, 0, sizeof(uint32_t) * 20 * (size_t)std::max(1, c->sweep_grid_max));
         if (c->NB == 4) {
             const size_t hw = hard_list_words(n_local);
             CHK_CREATE(hipMalloc(&c->d_hard, sizeof(uint32_t) * 2 * hw));
@@ -1044,20 +1047,27 @@ static int direction_tables(dpmm_ctx *c, int K, bool b3_done) {
         const int nw = 4 * c->sweep_grid;
         unsigned long long many_ub = 0, tiles_ub = 0;        // sweeps that ran the screen in front of the tail pairs: counted there, an upper bound
         unsigned long long given = 0, removed = 0;            // the last sweep's direction screens, if it ran any
+        bool lean_dir = false;                                // ... in the lean kernel
         for (int w = 0; w < nw; ++w) {
             const uint32_t v = c->h_need[2 * w];
             if (v & 0x8000u) { many_ub += v >> 16; tiles_ub += v & 0x7FFFu; } else { many += v >> 16; tiles += v & 0x7FFFu; }
             if (c->sp_last) { const uint32_t y = c->h_need[2 * w + 1]; given += y & 0xFFFFu; removed += y >> 16; }
             tiles += c->h_need[8 * (size_t)c->sweep_grid_max + w];      // tiles niw_lean_kernel settled (no candidate behind the 4-row tests)
+            // ... and the tiles it settled WITH the direction screen: their candidates and the screen's yield, in the general kernel's format
+            const uint32_t v3 = c->h_need[12 * (size_t)c->sweep_grid_max + 2 * w], y3 = c->h_need[12 * (size_t)c->sweep_grid_max + 2 * w + 1];
+            if (v3 & 0x8000u) { many_ub += v3 >> 16; tiles_ub += v3 & 0x7FFFu; } else { many += v3 >> 16; tiles += v3 & 0x7FFFu; }
+            given += y3 & 0xFFFFu; removed += y3 >> 16;
+            if (y3) lean_dir = true;
         }
         memset(c->h_need, 0, sizeof(uint32_t) * 2 * (size_t)nw);
         memset(c->h_need + 8 * (size_t)c->sweep_grid_max, 0, sizeof(uint32_t) * (size_t)nw);      // (read once: a later launch on a smaller grid, or one that does not count, leaves zeros -- "no tiles")
+        memset(c->h_need + 12 * (size_t)c->sweep_grid_max, 0, sizeof(uint32_t) * 2 * (size_t)nw);
         // (break-even measured on the growth run: at 4.3 candidates per tile the screen costs 3 % of the step, at 28 it saves a third)
         if (tiles > 0) c->sp_regime = c->sp_regime ? (many >= tiles * 4) : (many >= tiles * 8);
         else if (tiles_ub > 0 && many_ub < tiles_ub * 4) c->sp_regime = false;        // even the upper bound is below the switch-off level
         // clusters that overlap along every direction (a chain that is still growing: one cluster over several components): the screen is
         // given candidates and removes few -- off for 64 parameter sets, then it may try again
-        if (c->sp_last && given > 0 && removed * 4 < given) { c->sp_regime = false; c->sp_cooldown = 64; }
+        if ((c->sp_last || lean_dir) && given > 0 && removed * 4 < given) { c->sp_regime = false; c->sp_cooldown = 64; }
         if (c->sp_cooldown > 0) { c->sp_cooldown -= 1; c->sp_regime = false; }
         want = c->sp_regime;
     }
@@ -1226,8 +1236,9 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
             // the list.  A sweep that left more than 30 % of its tiles (overlapping clusters: the screens' later stages do the work) switches the
             // lean kernel off for 15 sweeps -- every path gives the same labels and sub-labels, so the decision is free to be local.
             // (not while the direction screen's regime is on: eight or more candidates per tile behind the 4-row tests -- nothing for the cheap screens to settle)
+            // (round 6: the lean kernel runs the direction screen itself while the tables exist -- it used to stay off in that regime)
             const bool lean_ok = c->opt_lean != 0 && c->opt_bracket && a.use_prev && a.screen_margin > 0.f && !final_argmax && a.lam == nullptr && c->K > 1 && c->d_hard &&
-                                 !(c->sp_regime && c->opt_direction != 0 && c->sp_ready);
+                                 !(c->opt_lean_dir == 0 && c->sp_regime && c->opt_direction != 0 && c->sp_ready);
             const int64_t nwt = (c->n + 63) / 64;
             if (lean_ok && c->lean_off == 0 && c->lean_ran) {            // the verdict on the last sweep that ran the lean kernel
                 if ((int64_t)c->h_hard[0] * 10 > nwt * 3) { c->lean_off = c->lean_backoff; c->lean_backoff = std::min(2 * c->lean_backoff + 1, 1023); }
@@ -1247,7 +1258,10 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
                 uint32_t *need2 = a.need ? c->h_need + 8 * (size_t)c->sweep_grid_max : nullptr;
                 // (tiles aligned to the bins of the sort that wrote the visiting order, when there is one and it fits the kernel's table)
                 const bool al = a.order != nullptr && c->perm_nbins > 0 && c->perm_nbins <= NIW_LEAN_MAX_BINS;
-                HIPCHK(c, launch_niw_lean(a, mine, need2, other, al ? c->sb.bin_start : nullptr, al ? c->perm_nbins : 0, c->sweep_grid, c->stream));
+                uint32_t *need3 = a.need ? c->h_need + 12 * (size_t)c->sweep_grid_max : nullptr;
+                NiwSweepArgs al_args = a;
+                if (!c->opt_lean_dir) { al_args.sp_frag = nullptr; al_args.sp_cons = nullptr; }
+                HIPCHK(c, launch_niw_lean(al_args, mine, need2, other, al ? c->sb.bin_start : nullptr, al ? c->perm_nbins : 0, need3, c->sweep_grid, c->stream));
                 if (parts) HIPCHK(c, hipEventRecord(c->ev_part[0], c->stream));
                 list = mine;
             }
@@ -2713,6 +2727,7 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
         case DPMM_OPT_COMM_TIMEOUT_MS: c->comm_timeout_ms = value > 0 ? (int)std::min(value, 2.0e9) : 0; return DPMM_OK;
         case DPMM_OPT_BF16_SCREENS: c->opt_bf16scr = value != 0; return DPMM_OK;
         case DPMM_OPT_MASTER_POLL: c->opt_master_poll = value != 0; return DPMM_OK;
+        case DPMM_OPT_LEAN_DIRECTION: c->opt_lean_dir = value != 0; c->lean_off = 0; c->lean_backoff = 15; c->lean_ran = false; return DPMM_OK;
         case DPMM_OPT_CHAIN_FUSION: c->opt_chain = value < 0 ? (0x7fffffff & ~(8 | 32)) : (int)value; return DPMM_OK;
         case DPMM_OPT_LEAN_TILES: c->opt_lean = value != 0; c->lean_off = 0; c->lean_backoff = 15; c->lean_ran = false; return DPMM_OK;
         case DPMM_OPT_B3_SUBLABELS: c->opt_b3 = value != 0; if (!c->opt_b3) c->have_b3 = false; return DPMM_OK;      // (switching it ON takes effect with the next parameter set: its images are packed behind the parameters)

@@ -97,7 +97,7 @@ hipError_t launch_niw_sub(const NiwSweepArgs &a, const uint32_t *list, uint32_t 
 constexpr int NIW_LEAN_MAX_BINS = 256;      // bins of the sort the lean kernel can align its tiles to (beyond: tiles of 64 consecutive positions)
 // bin_start [nbins + 1] (nullable): the offsets of the sort that wrote a.order -- tiles never cross a bin.  The list holds (position, count) pairs:
 // 1 + 2 * (ceil(n / 64) + nbins) words at most.
-hipError_t launch_niw_lean(const NiwSweepArgs &a, uint32_t *list, uint32_t *need2, uint32_t *other_list, const int32_t *bin_start, int nbins, int grid, hipStream_t s);      // list[0] must be 0; other_list[0] is cleared for the next launch
+hipError_t launch_niw_lean(const NiwSweepArgs &a, uint32_t *list, uint32_t *need2, uint32_t *other_list, const int32_t *bin_start, int nbins, uint32_t *need3, int grid, hipStream_t s);      // list[0] must be 0; other_list[0] is cleared for the next launch
 hipError_t launch_niw_direction(const float *Rp, const float *mup, const float *cst, int D, int K, uint32_t *frag, float *cons, hipStream_t s);
 
 struct MultSweepArgs {

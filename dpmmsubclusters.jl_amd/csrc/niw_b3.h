@@ -21,12 +21,19 @@ __device__ __forceinline__ void b3_split_pair(float a, float b, uint32_t &ph, ui
     pl = pack_bf16_pair(sa, sb);
 }
 // z = x - mk for all four point groups (mk: a cluster-level mean in the x registers' layout), split into planes
-__device__ __forceinline__ void b3_convert(const f32x4 (&x)[4][4], const f32x4 (&mk)[4], B3Z &Z) {
+// NZ: also the lane's sum of squares of z per point group, in direction_far's order of additions (the direction screen's |z0|, niw_device.h)
+template <bool NZ = false>
+__device__ __forceinline__ void b3_convert(const f32x4 (&x)[4][4], const f32x4 (&mk)[4], B3Z &Z, float *part = nullptr, int part_stride = 1) {
 #pragma unroll
-    for (int n = 0; n < 4; ++n)
+    for (int n = 0; n < 4; ++n) {
+        float pn = 0.f;
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
             const f32x4 lo = x[n][2 * sl] - mk[2 * sl], hi = x[n][2 * sl + 1] - mk[2 * sl + 1];
+            if constexpr (NZ) {
+                pn = __builtin_fmaf(lo.x, lo.x, pn); pn = __builtin_fmaf(lo.y, lo.y, pn); pn = __builtin_fmaf(lo.z, lo.z, pn); pn = __builtin_fmaf(lo.w, lo.w, pn);
+                pn = __builtin_fmaf(hi.x, hi.x, pn); pn = __builtin_fmaf(hi.y, hi.y, pn); pn = __builtin_fmaf(hi.z, hi.z, pn); pn = __builtin_fmaf(hi.w, hi.w, pn);
+            }
             uint32_t H[4], M[4], L[4];
             b3_split_pair(lo.x, lo.y, H[0], M[0], L[0]);
             b3_split_pair(lo.z, lo.w, H[1], M[1], L[1]);
@@ -36,6 +43,8 @@ __device__ __forceinline__ void b3_convert(const f32x4 (&x)[4][4], const f32x4 (
             Z.p[n][sl][1] = (u32x4_t){M[0], M[1], M[2], M[3]};
             Z.p[n][sl][2] = (u32x4_t){L[0], L[1], L[2], L[3]};
         }
+        if constexpr (NZ) part[n * part_stride] = pn;          // (niw_lean_kernel: LDS, so that the four sums are not four registers across the bracket)
+    }
 }
 // Both sub-cluster values of the wave's points for cluster k (wave-uniform) from the planes of z = x - mu_k: bl / br = cst - |R_s z + d_s|^2 / 2
 // for "this lane's point" (point lane & 15 of point group lane >> 4).  ONE pipeline over the eight row blocks of the two matrices (left

@@ -195,4 +195,48 @@ __device__ __forceinline__ bool bf16_bottom_excludes(const u32x4_t a, const f32x
     return skip;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// The direction screen's matrix product and bounds (niw_sweep.hip: direction_far describes the bound) on operands that exist: zb = the bf16 pairs of
+// z0 = x - mu_k0 in the x registers' layout ([point group][32-feature slice]), nz = |z0| per point (direction_norm of the lane's partial sum of
+// squares).  niw_sweep_direct_kernel<.., DIR> forms both from x; niw_lean_kernel passes plane h of its three-plane split -- the same
+// subtraction, the same v_cvt_pk_bf16_f32 -- and the norm it accumulated during the conversion.  Returns the mask of excluded clusters (bit k).
+__device__ __forceinline__ float direction_norm(float part) {      // part: the lane's sum of squares over its 16 features of the point
+    const f32x4 tot = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, part, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);      // |z0|^2 of point (n, lane & 15)
+    return __builtin_sqrtf(tot[0]) * 1.00001f;
+}
+template <int NG>
+__device__ __forceinline__ unsigned long long direction_far_core(const uint32_t *__restrict__ frag, const float *__restrict__ cons, const u32x4_t (&zb)[NG][2],
+                                                                 const float (&nz)[NG], const float (&thr)[NG], int lane, int g, int K) {
+    unsigned long long far = 0ull;
+    const int nblk = (K + 15) >> 4;
+    for (int blk = 0; blk < nblk; ++blk) {
+        const u32x4_t a0 = reinterpret_cast<const u32x4_t *>(frag)[(2 * blk) * 64 + lane], a1 = reinterpret_cast<const u32x4_t *>(frag)[(2 * blk + 1) * 64 + lane];
+        const f32x4 cB = *reinterpret_cast<const f32x4 *>(cons + 16 * blk + 4 * g), cE = *reinterpret_cast<const f32x4 *>(cons + 64 + 16 * blk + 4 * g),
+                    cK = *reinterpret_cast<const f32x4 *>(cons + 128 + 16 * blk + 4 * g);
+        bool ok[4] = {true, true, true, true};
+        const f32x4 tau = cB * 0.02f;
+#pragma unroll
+        for (int n = 0; n < NG; ++n) {
+            f32x4 sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a0), __builtin_bit_cast(bf16x8_t, zb[n][0]), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a1), __builtin_bit_cast(bf16x8_t, zb[n][1]), sv, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {       // cluster 16 blk + 4 g + r against point (n, lane & 15); thr = +inf for a column without a point, NaN excludes nothing
+                float t = __builtin_fmaf(-cE[r], nz[n], fabsf(sv[r] + cB[r]));
+                t = t >= tau[r] ? t : 0.f;                                   // (NaN: 0)
+                const float ub = __builtin_fmaf(-0.4995f * t, t, cK[r]);
+                ok[r] = ok[r] && (ub < thr[n]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned long long m = __ballot(ok[r]);
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg)
+                if (((m >> (16 * gg)) & 0xFFFFull) == 0xFFFFull) far |= 1ull << (16 * blk + 4 * gg + r);
+        }
+    }
+    return K >= 64 ? far : far & ((1ull << K) - 1ull);
+}
+
 }  // namespace dpmm

@@ -106,11 +106,27 @@ hipError_t launch_niw_b3_debug(const NiwSweepArgs &a, float *out, hipStream_t s)
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------------------ the touch
+// Both kernels below pull the NEXT tile's x rows towards L2 behind the last fragment request of a tile's evaluations: one dword per 128-byte
+// line, data nobody reads.  Rounds 5 loaded them into v254 / v255 by inline asm and asked the allocator to stay away (amdgpu_num_vgpr(254)) --
+// which it does only while the kernel fits: the first change that added pressure (round 6, the direction screen in niw_lean_kernel) made it
+// place live values there, and the build-time check of ADVICE r5 (check_reserved_vgprs.py) stopped the build.  The touches now have NO
+// register destination: global_load_lds_dword writes a lane's dword to LDS at M0 + 4 lane (a 512-byte sink every wave of the workgroup shares;
+// nothing reads it), M0 saved and restored inside the statement.  The compiler's vmcnt bookkeeping does not see them: every wait it emits is
+// then for MORE loads than it thinks, never fewer; no touch is in flight when a wave ends (s_waitcnt vmcnt(0) at the end of both kernels).
+// check_reserved_vgprs.py (run by the Makefile) checks the generated code: every LDS-DMA touch sits between a save and a restore of M0.
+#define DPMM_TOUCH_ROWS(row0, row1, sink_base)                                                                                         \
+    do {                                                                                                                               \
+        unsigned m0_save__;                                                                                                            \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\tglobal_load_lds_dword %2, off offset:256\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(m0_save__) : "v"(row0), "v"(row1), "s"(sink_base));                                                         \
+    } while (0)
+
 // ------------------------------------------------------------------------------------------------------------------ sub-labels alone
 // The sub-label phase of the tiles named in `list` (list[0] = their number, list[1 ..] = wave-tile indices; null: every tile): the new labels are
 // in bins (niw_sweep_direct_kernel<.., LSTORE> stored 2 z + old sub-label), the second uniform of the point's Philox draw decides between left
 // and right (create_subclusters_labels!, local_clusters_actions.jl:83-95).  One wave per tile of 64 positions of the visiting order.
-__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void niw_sub_kernel(NiwSweepArgs A, const uint32_t *__restrict__ list, uint32_t *__restrict__ count_out) {
+__global__ __launch_bounds__(256, 2) void niw_sub_kernel(NiwSweepArgs A, const uint32_t *__restrict__ list, uint32_t *__restrict__ count_out) {
     // (the list's length for the host's regime decision, written to pinned memory by the last launch that reads it: no copy launch)
     if (list && count_out && blockIdx.x == 0 && threadIdx.x == 0) *count_out = list[0];
     const int lane = threadIdx.x & 63, ci = lane & 15, g = lane >> 4;
@@ -132,6 +148,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void 
     };
     int64_t t_next = tile_of(wave_id), t_next2 = tile_of((int64_t)wave_id + nwaves);
     const int touch_second = A.ldx > 32 ? 32 : 0;
+    __shared__ float touch_sink[128];
+    const unsigned sink_base = (unsigned)(uintptr_t)touch_sink;
     int nx_p = -1, nx_bin = -1;
     if (t_next >= 0) {
         const int64_t pos = (t_next >> 7) + lane;
@@ -166,11 +184,11 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void 
             b3_convert(x, mk, Z);
             if (pf_p >= 0 && pf_bin < 0) pf_bin = A.bins[pf_p];              // the next tile's labels (its indices arrived with x)
             float bl, br;
-            // (the next tile's x rows touched behind the last fragment request, as in niw_lean_kernel: v254 / v255 are outside the kernel's budget)
+            // (the next tile's x rows touched behind the last fragment request, as in niw_lean_kernel)
             auto touch_x = [&]() {
                 if (t_next >= 0 && !todo) {
                     const float *row = A.X + (int64_t)(pf_p >= 0 ? pf_p : 0) * A.ldx;
-                    asm volatile("global_load_dword v254, %0, off\n\tglobal_load_dword v255, %1, off" :: "v"(row), "v"(row + touch_second) : "v254", "v255");
+                    DPMM_TOUCH_ROWS(row, row + touch_second, sink_base);
                 }
             };
             b3_eval(A.tail, A.K, k, Z, H, lane, g, bl, br, touch_x);
@@ -243,8 +261,8 @@ __device__ __forceinline__ void ref_bracket_planes(const u32x4_t (&a)[6], const 
 #else
 #define LSTAMP(var)
 #endif
-__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void niw_lean_kernel(NiwSweepArgs A, uint32_t *__restrict__ list, uint32_t *__restrict__ need2, uint32_t *__restrict__ other_list,
-                                                                                                   const int32_t *__restrict__ bin_start, int nbins) {
+__global__ __launch_bounds__(256, 2) void niw_lean_kernel(NiwSweepArgs A, uint32_t *__restrict__ list, uint32_t *__restrict__ need2, uint32_t *__restrict__ other_list,
+                                                                                                   const int32_t *__restrict__ bin_start, int nbins, uint32_t *__restrict__ need3) {
     // two lists take turns: this launch appends to `list` (count cleared by the previous lean launch) and clears the other one's count for the
     // next -- every reader of that one finished before this launch started (stream order).  No fill launch in front of a sweep.
     if (other_list && blockIdx.x == 0 && threadIdx.x == 0) other_list[0] = 0u;
@@ -256,6 +274,17 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void 
     const int K = A.K;
     const int wave_id = (int)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int)gridDim.x * 4;
     unsigned nw_easy = 0, nw_br = 0, nw_tail = 0, nw_bb = 0;
+    // THE DIRECTION SCREEN IN THIS KERNEL (round 6).  While the library keeps the screen's tables (overlapping clusters: tiles keep eight or more
+    // candidates behind the 4-row tests; A.sp_frag / A.sp_cons, K <= 64) rounds 4-5 ran no lean launch at all: nothing settles without the screen,
+    // and the two launches that took every tile instead cost 1.9 ms at N = 1e7 against 1.0.  The screen's operand is plane h of z0 = x - mu_k0 --
+    // it exists here -- and |z0| is accumulated by the conversion: a tile that keeps six or more candidates behind the ball test puts all of them
+    // through direction_far_core (niw_device.h: the general kernel's own matrix product and bounds); what is left takes the 4-row pairs and the
+    // bf16 bottom screens as before.  Every exclusion is a certified bound, so a tile settled here is one whose draw returns k0.
+    // The statistics the library's regime switch reads (candidates per tile, the screen's yield) go to need3 in the general kernel's format,
+    // for the tiles SETTLED here (a tile handed on is counted by the launch that finishes it).
+    const bool use_dir = A.sp_frag != nullptr && A.sp_cons != nullptr && A.bf16scr && K >= 3 && K <= SP_MAXK;
+    const bool dir_first = use_dir && (A.bf16scr & 2) != 0;
+    unsigned nw_sp = 0, nw_cand = 0, nw_dcand = 0, nw_dexcl = 0, nw_ctiles = 0;
     // the ball test's records (16 floats per cluster, the same for every tile) once per workgroup in LDS: the test then waits for an LDS read
     // instead of an L2 round trip per tile
     constexpr int BALL_LDS_K = 128;
@@ -305,13 +334,10 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void 
         cn = e < 64 ? e : 64;
     };
     // Off a tile's critical chain order -> bins -> x (three dependent HBM round trips): the point indices and previous labels of the next tile
-    // are fetched while this one is processed, and the x rows of the NEXT tile are touched -- one dword per 128-byte line, into two registers nothing
-    // reads -- behind the last fragment request of this tile's evaluations: the next tile's gather, 1.5-2 k cycles later, finds the lines on
+    // are fetched while this one is processed, and the x rows of the NEXT tile are touched -- one dword per 128-byte line, by LDS-DMA into a sink
+    // nothing reads (DPMM_TOUCH_ROWS above) -- behind the last fragment request of this tile's evaluations: the next tile's gather, 1.5-2 k cycles later, finds the lines on
     // their way (sweep 1.10 -> 1.08 ms).  (Vector memory returns in order: touched one row block earlier the evaluations' last fragments queue
-    // behind HBM, 1.09-1.11 ms; touched a whole tile ahead the lines are gone from L2 again -- 8 MB in flight per XCD against 4 -- 1.13 ms.  The
-    // loads are inline asm into v254 / v255, which the kernel's register budget -- amdgpu_num_vgpr(254) -- keeps away from the allocator:
-    // a register the compiler may move or reuse could be overwritten by a touch that returns later.  Its vmcnt bookkeeping does not see the
-    // touches: every wait it emits is then for MORE loads than it thinks, never fewer.)
+    // behind HBM, 1.09-1.11 ms; touched a whole tile ahead the lines are gone from L2 again -- 8 MB in flight per XCD against 4 -- 1.13 ms.)
     auto index_at = [&](int p0, int cn) -> int { return lane < cn ? (use_order ? A.order[p0 + lane] : p0 + lane) : -1; };
     int c_p0, c_cn, n_p0, n_cn;                              // spans of this tile and of the next one
     span_of(wave_id, c_p0, c_cn);
@@ -319,6 +345,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void 
     int nx_p = index_at(c_p0, c_cn);
     int nx_bin = nx_p >= 0 ? A.bins[nx_p] : -1;
     const int touch_second = A.ldx > 32 ? 32 : 0;           // (floats: the row's second 128-byte line, if it has one)
+    __shared__ float touch_sink[128];
+    const unsigned sink_base = (unsigned)(uintptr_t)touch_sink;
     for (int tile = wave_id; tile < ntiles_all; tile += nwaves) {
         const bool valid = lane < c_cn;
         const int myp32 = nx_p, binv = nx_bin;
@@ -331,7 +359,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void 
         auto touch_x = [&]() {
             if (n_cn > 0) {
                 const float *row = A.X + (int64_t)(pf_p >= 0 ? pf_p : 0) * A.ldx;
-                asm volatile("global_load_dword v254, %0, off\n\tglobal_load_dword v255, %1, off" :: "v"(row), "v"(row + touch_second) : "v254", "v255");
+                DPMM_TOUCH_ROWS(row, row + touch_second, sink_base);
             }
         };
         int prev = binv >= 0 ? (binv >> 1) : -1;
@@ -349,6 +377,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void 
         if (!hard) {
             f32x4 xt = (f32x4){0.f, 0.f, 0.f, 0.f};
             f32x4 x3[4];                                           // the last 16 features (the bf16 bottom screens' operand)
+            float nz[4] = {0.f, 0.f, 0.f, 0.f};                   // |z0| per point group's point (direction screen)
             u32x4_t abr[6];                                        // k0's bracket fragments: requested with x, used behind the conversion
             {
                 f32x4 x[4][4], mk[4];
@@ -380,7 +409,12 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void 
                 }
 #pragma unroll
                 for (int n = 0; n < 4; ++n) x3[n] = x[n][3];
-                b3_convert(x, mk, Z);                          // x's last use (but for x3)
+                if (use_dir) {
+                    float part[4];
+                    b3_convert<true>(x, mk, Z, part);           // x's last use (but for x3)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) nz[n] = direction_norm(part[n]);
+                } else b3_convert(x, mk, Z);                   // x's last use (but for x3)
             }
             if (pf_p >= 0) pf_bin = A.bins[pf_p];              // the next tile's previous labels (its indices have arrived with x)
 #ifdef DPMM_STAMPS
@@ -411,6 +445,18 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void 
                     const int j = base + lane;
                     cand &= ~(ball_in_lds ? ball_far_rec(ball_lds + 16 * (j < K ? j : 0), j < K, ball) : ball_far(A.tail, K, base, lane, ball));
                 }
+                unsigned tile_cand = 0, tile_dc = 0, tile_dx = 0, tile_sp = 0;       // (this tile's share of the statistics: counted only if it is settled here)
+                auto direction = [&]() {
+                    const int nc = __builtin_popcountll(cand);
+                    if (nc >= 6) {                                    // (below: the candidates' own screens are cheaper)
+                        u32x4_t zb[4][2];
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) { zb[n][0] = Z.p[n][0][0]; zb[n][1] = Z.p[n][1][0]; }
+                        cand &= ~direction_far_core<4>(A.sp_frag + (size_t)k0 * SP_FRAG_WORDS, A.sp_cons + (size_t)k0 * SP_CONS_FLOATS, zb, nz, thrb, lane, g, K);
+                        tile_sp = 1; tile_dc = (unsigned)nc; tile_dx = (unsigned)(nc - __builtin_popcountll(cand));
+                    }
+                };
+                if (dir_first) { tile_cand = (unsigned)__builtin_popcountll(cand); direction(); }
                 for (unsigned long long pend = cand; pend;) {
                     const int sh = __builtin_ctzll(pend) & ~1;            // (base is a multiple of 64: pair 2p sits at an even bit)
                     const int pr = (base + sh) >> 1;
@@ -418,6 +464,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void 
                     ++nw_tail;
                     cand &= ~((unsigned long long)tail_pair_far(tail_load_pair(A.tail, pr), xt, my_thr) << sh);
                 }
+                if (use_dir && !dir_first) { tile_cand = (unsigned)__builtin_popcountll(cand); direction(); }       // (a measuring sweep: what the 4-row tests leave)
                 // what the 4-row tests leave (0.8 clusters per tile on the bench data): the bf16 bottom screen, as niw_sweep_direct_kernel runs it
                 // next (fragment 5 of the candidate's bracket image, its last 16 means, its constant); a candidate that passes it is left to that kernel
                 if (A.bf16scr) {
@@ -432,6 +479,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void 
                     }
                 }
                 hard = cand != 0ull;
+                if (use_dir && !hard) { nw_cand += tile_cand; nw_sp += tile_sp; nw_dcand += tile_dc; nw_dexcl += tile_dx; ++nw_ctiles; }
             }
         }
 #ifdef DPMM_STAMPS
@@ -470,14 +518,24 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (no touch in flight at the end)
     if (A.work && lane == 0) {
         unsigned long long *slot = A.work + DPMM_WORK_SLOTS + (size_t)wave_id * DPMM_WORK_PER_WAVE;      // (accumulates; cleared by the reader)
-        slot[0] += nw_easy; slot[3] += nw_tail; slot[4] += nw_br; slot[5] += nw_bb; slot[7] += (unsigned long long)(2 * nw_easy) << 32;
+        slot[0] += nw_easy; slot[3] += nw_tail; slot[4] += nw_br; slot[5] += nw_bb; slot[7] += ((unsigned long long)(2 * nw_easy) << 32) + nw_sp;
     }
-    if (need2 && lane == 0) need2[wave_id] = nw_easy < 65535u ? nw_easy : 65535u;      // tiles settled here (no candidates): the direction screen's statistics count them
+    // tiles settled here: without the screen they had no candidate behind the 4-row tests (need2: a plain count); with it, the candidates they had
+    // and the screen's yield in the general kernel's two-word format (need3; bit 15: counted in front of the 4-row tests, an upper bound)
+    if (need2 && lane == 0) need2[wave_id] = use_dir ? 0u : (nw_easy < 65535u ? nw_easy : 65535u);
+    if (need3 && lane == 0) {
+        uint32_t word = 0u, yield = 0u;
+        if (use_dir) {
+            word = ((nw_cand < 65535u ? nw_cand : 65535u) << 16) | (nw_ctiles < 32767u ? nw_ctiles : 32767u) | (dir_first ? 0x8000u : 0u);
+            yield = ((nw_dexcl < 65535u ? nw_dexcl : 65535u) << 16) | (nw_dcand < 65535u ? nw_dcand : 65535u);
+        }
+        need3[2 * wave_id] = word; need3[2 * wave_id + 1] = yield;
+    }
 }
-hipError_t launch_niw_lean(const NiwSweepArgs &a, uint32_t *list, uint32_t *need2, uint32_t *other_list, const int32_t *bin_start, int nbins, int grid, hipStream_t s) {
+hipError_t launch_niw_lean(const NiwSweepArgs &a, uint32_t *list, uint32_t *need2, uint32_t *other_list, const int32_t *bin_start, int nbins, uint32_t *need3, int grid, hipStream_t s) {
     if (!a.tail || a.n <= 0 || !list) return hipErrorInvalidValue;
     if (nbins > NIW_LEAN_MAX_BINS) { bin_start = nullptr; nbins = 0; }
-    DPMM_LAUNCH(niw_lean_kernel, dim3(grid), dim3(256), 0, s, a, list, need2, other_list, bin_start, nbins);
+    DPMM_LAUNCH(niw_lean_kernel, dim3(grid), dim3(256), 0, s, a, list, need2, other_list, bin_start, nbins, need3);
     return hipGetLastError();
 }
 

@@ -222,38 +222,9 @@ __device__ __forceinline__ unsigned long long direction_far(const uint32_t *__re
             part = __builtin_fmaf(hi.x, hi.x, part); part = __builtin_fmaf(hi.y, hi.y, part); part = __builtin_fmaf(hi.z, hi.z, part); part = __builtin_fmaf(hi.w, hi.w, part);
             zb[n][sl] = (u32x4_t){pack_bf16_pair(lo.x, lo.y), pack_bf16_pair(lo.z, lo.w), pack_bf16_pair(hi.x, hi.y), pack_bf16_pair(hi.z, hi.w)};
         }
-        const f32x4 tot = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, part, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);      // |z0|^2 of point (n, lane & 15)
-        nz[n] = __builtin_sqrtf(tot[0]) * 1.00001f;
+        nz[n] = direction_norm(part);
     }
-    unsigned long long far = 0ull;
-    const int nblk = (K + 15) >> 4;
-    for (int blk = 0; blk < nblk; ++blk) {
-        const u32x4_t a0 = reinterpret_cast<const u32x4_t *>(frag)[(2 * blk) * 64 + lane], a1 = reinterpret_cast<const u32x4_t *>(frag)[(2 * blk + 1) * 64 + lane];
-        const f32x4 cB = *reinterpret_cast<const f32x4 *>(cons + 16 * blk + 4 * g), cE = *reinterpret_cast<const f32x4 *>(cons + 64 + 16 * blk + 4 * g),
-                    cK = *reinterpret_cast<const f32x4 *>(cons + 128 + 16 * blk + 4 * g);
-        bool ok[4] = {true, true, true, true};
-        const f32x4 tau = cB * 0.02f;
-#pragma unroll
-        for (int n = 0; n < NG; ++n) {
-            f32x4 sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a0), __builtin_bit_cast(bf16x8_t, zb[n][0]), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a1), __builtin_bit_cast(bf16x8_t, zb[n][1]), sv, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {       // cluster 16 blk + 4 g + r against point (n, lane & 15); thr = +inf for a column without a point, NaN excludes nothing
-                float t = __builtin_fmaf(-cE[r], nz[n], fabsf(sv[r] + cB[r]));
-                t = t >= tau[r] ? t : 0.f;                                   // (NaN: 0)
-                const float ub = __builtin_fmaf(-0.4995f * t, t, cK[r]);
-                ok[r] = ok[r] && (ub < thr[n]);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const unsigned long long m = __ballot(ok[r]);
-#pragma unroll
-            for (int gg = 0; gg < 4; ++gg)
-                if (((m >> (16 * gg)) & 0xFFFFull) == 0xFFFFull) far |= 1ull << (16 * blk + 4 * gg + r);
-        }
-    }
-    return K >= 64 ? far : far & ((1ull << K) - 1ull);
+    return direction_far_core<NG>(frag, cons, zb, nz, thr, lane, g, K);      // (niw_device.h: shared with niw_lean_kernel, whose plane h of z0 IS zb)
 }
 
 // Reference bracket of the LDS-staged kernels (D = 128, 256: NB = 8, 16): the same certified bound as ref_bracket -- q <= sum_r (|y^_r| + c e^_r)^2
@@ -1931,10 +1902,13 @@ static hipError_t launch_direct(const NiwSweepArgs &a, int grid, hipStream_t s) 
                 hipFuncSetAttribute((const void *)niw_sweep_direct_kernel<NB, NG, OCC, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / OCC);
                 hipFuncSetAttribute((const void *)niw_sweep_direct_kernel<NB, NG, OCC, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / OCC);
                 hipFuncSetAttribute((const void *)niw_sweep_direct_kernel<NB, NG, OCC, true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / OCC);
+                hipFuncSetAttribute((const void *)niw_sweep_direct_kernel<NB, NG, OCC, true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / OCC);
                 attr_ls = true;
             }
-            if (b.tdf != nullptr) {             // a list of spans (behind niw_lean_kernel: a few dozen tiles): no direction-screen instantiation for it
-                if (fast) DPMM_LAUNCH((niw_sweep_direct_kernel<NB, NG, OCC, true, false, true, true>), dim3(grid), dim3(256), lds_bytes, s, b);
+            if (b.tdf != nullptr) {             // a list of spans (behind niw_lean_kernel): with the direction screen while its tables exist (round 6: the lean kernel
+                                                //  runs in that regime too, and the spans it hands on there keep dozens of candidates behind the 4-row tests)
+                if (fast && b.sp_frag && b.sp_cons && b.bf16scr && b.K <= SP_MAXK) DPMM_LAUNCH((niw_sweep_direct_kernel<NB, NG, OCC, true, true, true, true>), dim3(grid), dim3(256), lds_bytes, s, b);
+                else if (fast) DPMM_LAUNCH((niw_sweep_direct_kernel<NB, NG, OCC, true, false, true, true>), dim3(grid), dim3(256), lds_bytes, s, b);
                 else DPMM_LAUNCH((niw_sweep_direct_kernel<NB, NG, OCC, false, false, true, true>), dim3(grid), dim3(256), lds_bytes, s, b);
                 return hipGetLastError();
             }

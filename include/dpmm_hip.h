@@ -111,6 +111,9 @@ enum {
                                          points per shard, with bit 32 at any size); 16: the standard
                                          normals of the draws launched ahead are generated by extra workgroups of the posteriors' launch (D <= 128; no kernel on the second stream beside
                                          the sweep, no cross-stream wait in front of the draws).  0: the launches of round 5.  Same values. */
+    DPMM_OPT_LEAN_DIRECTION = 30,     /* 1 (default, round 6): while the direction screen's tables exist (DPMM_OPT_DIRECTION_SCREEN: overlapping clusters) niw_lean_kernel runs the
+                                         screen itself -- on plane h of z0 = x - mu_k0, which it holds -- and settles the tiles it clears; the launch behind it gets a
+                                         direction-screen instantiation for the spans handed on.  0: no lean launch in that regime (rounds 4-5).  Same labels and sub-labels. */
     DPMM_OPT_MULT_DRAWS_AHEAD = 25,   /* 1 (default): Multinomial device master: dpmm_step_stats launches the NEXT Dirichlet draws and their hand-over images
                                        * behind the statistics (the epoch after the last dpmm_mult_master_draw, the same K and outlier flag), into a second set of
                                        * buffers, and returns when the rows are on the host -- the draws run while the caller decides splits and merges.

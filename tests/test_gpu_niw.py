@@ -1036,6 +1036,53 @@ def test_direction_screen_does_not_change_labels(pkg, D, sep, K):
     assert w1["bf16_bottom_screens"] <= w0["bf16_bottom_screens"] and w1["screens16"] <= w0["screens16"] and w1["full_evals"] <= w0["full_evals"]
 
 
+@pytest.mark.parametrize("D,sep,K,n", [(64, 2.0, 12, 60000), (64, 1.0, 20, 60000), (52, 2.0, 7, 30000), (64, 1.5, 60, 90000), (64, 0.3, 5, 20000), (64, 3.0, 3, 20000)])
+def test_lean_kernel_with_the_direction_screen(pkg, D, sep, K, n):
+    """Round 6 (DPMM_OPT_LEAN_DIRECTION): while the direction screen's tables exist, niw_lean_kernel runs the screen itself -- its operand is plane h
+    of z0 = x - mu_k0, which the kernel holds, |z0| is accumulated by the conversion -- and settles the tiles the screen clears; rounds 4-5 ran
+    no lean launch in that regime (labels + sub-labels in two launches over every tile).  The launch behind it walks the handed-on spans with a
+    direction-screen instantiation of its own.  Which launch finishes a tile must not show: labels AND sub-labels of a chain of sweeps equal the
+    chain with DPMM_OPT_LEAN_DIRECTION = 0 and the chain without any lean launch, bit for bit; the labels are the oracle's draw on the kernel's own
+    unscreened table; and the lean launch did run direction screens (overlapping clusters) or none (clusters it cannot separate / too few)."""
+    from dpmmsubclusters_jl_amd import binding
+    P = make_problem(D, n, K, seed=640 + D + K, sep=sep, sorted_points=True)
+    out = {}
+    for name, opts in (("lean_dir", ((binding.OPT_DIRECTION_SCREEN, 1),)), ("no_lean_dir", ((binding.OPT_DIRECTION_SCREEN, 1), (binding.OPT_LEAN_DIRECTION, 0))),
+                       ("no_lean", ((binding.OPT_DIRECTION_SCREEN, 1), (binding.OPT_LEAN_TILES, 0))), ("no_dir", ((binding.OPT_DIRECTION_SCREEN, 0),))):
+        wk = gpu_worker(pkg, P, seed=53)
+        for o, v in opts:
+            wk.set_option(o, v)
+        wk.set_timing(15)
+        wk.set_labels(P["z"] + 1, 1 + (np.arange(n) & 1))
+        wk.suffstats_packed(None)
+        wk.set_params_niw(P["mu"], P["invS"], P["logdet"], P["lr"], P["w"])
+        wk.last_sweep_work()
+        labs, lean_ms = [], []
+        for ep in (1, 2, 3):
+            wk.sweep(ep)
+            labs.append(wk.get_labels())
+            lean_ms.append(wk.last_sweep_parts_ms()[0])
+            if ep == 3 and name == "lean_dir":
+                u0, u1 = orc.uniforms(53, 3, 0, 0, n)
+                assert np.array_equal(orc.sample_log_cat(wk.debug_loglik(), u0), labs[-1][0])
+                assert_sublabels_bit_exact(wk, labs[-1][0], labs[-1][1], u1)
+            wk.suffstats_packed(None)
+            wk.set_params_niw(P["mu"], P["invS"], P["logdet"], P["lr"], P["w"])
+        out[name] = (labs, lean_ms, wk.last_sweep_work())
+        wk.close()
+    for name in ("no_lean_dir", "no_lean", "no_dir"):
+        for a, b in zip(out["lean_dir"][0], out[name][0]):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), name
+    w = out["lean_dir"][2]
+    print(f"D={D} sep={sep} K={K}: lean launch ms {[round(v, 3) for v in out['lean_dir'][1]]} (without the screen in it: {[round(v, 3) for v in out['no_lean_dir'][1]]}); "
+          f"direction screens per wave tile {w['direction_screens'] / max(1.0, w['wave_tiles']):.2f}")
+    assert max(out["no_lean"][1]) == 0.0
+    if K >= 3:
+        assert out["lean_dir"][1][0] > 0.0                      # the lean launch runs in the screen's regime now
+    if sep in (2.0, 1.0, 1.5) and K >= 7:
+        assert w["direction_screens"] > 0
+
+
 def test_direction_screen_switches_itself_on_and_off(pkg):
     """Automatic mode: the tables are built for the sweep AFTER one whose tiles kept eight or more candidates on average behind the 4-row
     tests (overlapping clusters), and no longer once they keep fewer than 4 (separated clusters)."""
