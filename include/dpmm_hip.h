@@ -97,7 +97,7 @@ enum {
                                          bins of the last sort); what it hands on is finished by one launch of the sweep kernel.  Same labels and sub-labels either way.
                                          0: every tile through the sweep kernel (labels) and niw_sub_kernel (sub-labels).
                                          A sweep that hands on more than 30 % of its tiles switches the lean launch off for 15 sweeps (31, 63, ... up to 1023 while the
-                                         retries keep failing); it also stays off while the direction screen's regime is on, and -- on the dpmm_set_params_* path only -- beyond 64 clusters, where the
+                                         retries keep failing); with DPMM_OPT_LEAN_DIRECTION = 0 it also stays off while the direction screen's regime is on (rounds 4-5), and -- on the dpmm_set_params_* path only -- beyond 64 clusters, where the
                                          scalar pre-screen (DPMM_OPT_PRESCREEN) runs inside the sweep kernel.  Parameters drawn on the device (dpmm_niw_master_draw) come without a pre-screen: there
                                          the lean launch runs at any K (tiles aligned to the sort's bins up to 256 bins, 64 consecutive positions beyond; tests/test_gpu_niw.py). */
     DPMM_OPT_MASTER_POLL = 28,        /* 1 (default, round 6): dpmm_step_master_device waits on the posteriors' own records in pinned host memory (every record starts as a
