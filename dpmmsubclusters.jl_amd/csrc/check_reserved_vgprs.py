@@ -1,15 +1,16 @@
 #!/usr/bin/env python3
 """Build-time check of the lean kernels' touches (per kernel since round 6).
 
-niw_lean_kernel / niw_sub_kernel touch the next tile's x rows behind the compiler's back (inline asm; its vmcnt bookkeeping must not see them), in
-one of two flavours (niw_lean.hip, DPMM_TOUCH_ROWS_*):
+niw_lean_kernel / niw_sub_kernel touch the next tile's x rows behind the compiler's back (inline asm; its vmcnt bookkeeping must not see them):
+`global_load_dword v254 / v255`, two registers nothing reads.  Safe only while the register allocator never places a value of its own there -- a
+touch returning late would overwrite it.  amdgpu_num_vgpr(254) asks for that and is honoured only while the kernel fits: round 6's first
+change that added pressure made the allocator use them, and this script stopped the build (the kernel that needs the whole register file,
+niw_lean_kernel_dir, has no touch since).  Property checked, per kernel of the assembly: in a kernel WITH register touches no other instruction
+names v254 or v255 (alone or inside a register range).
 
-  REGS  `global_load_dword v254 / v255`: two registers nothing reads.  Safe only while the register allocator never places a value of its own
-        there -- a touch returning late would overwrite it.  amdgpu_num_vgpr(254) asks for that and is honoured only while the kernel fits
-        (round 6's first change that added pressure made the allocator use them: this script stopped the build).  Property checked, per kernel:
-        no instruction other than the touches names v254 or v255 (alone or inside a register range).
-  LDS   `global_load_lds_dword` (no register destination; M0 + 4 * lane in LDS).  Property: every such load sits between `s_mov_b32 sN, m0`
-        (save) and `s_mov_b32 m0, sN` (restore, the same sN) with nothing in between but the M0 write, s_nop and the touches themselves.
+An experimental second flavour is recognised as well (docs/experiments/r06_lds_dma_touch.patch: `global_load_lds_dword`, no register destination):
+every such load must sit between `s_mov_b32 sN, m0` (save) and `s_mov_b32 m0, sN` (restore, the same sN) with nothing in between but the M0
+write, s_nop and the touches themselves.
 
     check_reserved_vgprs.py <device assembly .s>        exit status 1 (with the offending lines) if a property does not hold
 """

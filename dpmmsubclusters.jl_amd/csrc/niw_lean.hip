@@ -107,27 +107,18 @@ hipError_t launch_niw_b3_debug(const NiwSweepArgs &a, float *out, hipStream_t s)
 }
 
 // ------------------------------------------------------------------------------------------------------------------ the touch
-// Both kernels below pull the NEXT tile's x rows towards L2 behind the last fragment request of a tile's evaluations: one dword per 128-byte
-// line, data nobody reads.  Rounds 5 loaded them into v254 / v255 by inline asm and asked the allocator to stay away (amdgpu_num_vgpr(254)) --
-// which it does only while the kernel fits: the first change that added pressure (round 6, the direction screen in niw_lean_kernel) made it
-// place live values there, and the build-time check of ADVICE r5 (check_reserved_vgprs.py) stopped the build.  A second flavour has NO
-// register destination: global_load_lds_dword writes a lane's dword to LDS at M0 + 4 lane (a 512-byte sink every wave of the workgroup shares;
-// nothing reads it), M0 saved and restored inside the statement.  The compiler's vmcnt bookkeeping does not see them: every wait it emits is
-// then for MORE loads than it thinks, never fewer; no touch is in flight when a wave ends (s_waitcnt vmcnt(0) at the end of both kernels).
-// check_reserved_vgprs.py (run by the Makefile) checks the generated code kernel by kernel: a kernel with register touches names v254 / v255
-// nowhere else; every LDS-DMA touch sits between a save and a restore of M0.
-// Two flavours (round 6, measured on one box with scripts/build_variant.sh + variant_time.py: lean launch 0.999 ms with the register flavour, 1.037 ms with
-// the LDS one at N = 1e7; equal at the shard size):
-//   REGS   round 5's loads into v254 / v255 -- for the kernels that FIT below them (niw_sub_kernel, niw_lean_kernel<false>: 251-254 registers):
-//          the allocator stays away only while it can, which is why the build checks the generated code of exactly these kernels;
-//   LDS    no register destination -- for niw_lean_kernel<true>, whose direction screen needs the whole register file.
+// niw_sub_kernel and niw_lean_kernel pull the NEXT tile's x rows towards L2 behind the last fragment request of a tile's evaluations: one dword per
+// 128-byte line, loaded by inline asm into v254 / v255 -- two registers nothing reads; the compiler's vmcnt bookkeeping does not see the loads (every
+// wait it emits is then for MORE loads than it thinks, never fewer; no touch is in flight when a wave ends: s_waitcnt vmcnt(0) at the end of both
+// kernels).  That is safe only while the register allocator never places a value of its own in v254 / v255, which amdgpu_num_vgpr(254) obtains
+// only while the kernel FITS below them: the first change that added register pressure (round 6, the direction screen's code in the lean kernel)
+// made it put ds_bpermute results there -- and the build-time check ADVICE r5 had asked for (check_reserved_vgprs.py, run by the Makefile on
+// the generated assembly, kernel by kernel) stopped the build.  So: the kernels that fit (niw_sub_kernel 254, niw_lean_kernel 251 registers)
+// keep the touch, checked on every build; niw_lean_kernel_dir, which needs the whole register file, has NONE.  (A touch without a register
+// destination was built for it -- global_load_lds_dword into an LDS sink, M0 saved and restored inside the statement -- and measured: the
+// lean launch 0.999 -> 1.037 ms on the bench data, and niw_lean_kernel_dir 1.192 ms WITHOUT any touch against 1.216 with the LDS one, which also
+// fetched 3.7 GB against 2.8: lines brought in by LDS-DMA loads do not stay in L2 for the gather that follows.  docs/experiments/r06_*.patch)
 #define DPMM_TOUCH_ROWS_REGS(row0, row1) asm volatile("global_load_dword v254, %0, off\n\tglobal_load_dword v255, %1, off" :: "v"(row0), "v"(row1) : "v254", "v255")
-#define DPMM_TOUCH_ROWS_LDS(row0, row1, sink_base)                                                                                     \
-    do {                                                                                                                               \
-        unsigned m0_save__;                                                                                                            \
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\tglobal_load_lds_dword %2, off offset:256\n\ts_mov_b32 m0, %0" \
-                     : "=&s"(m0_save__) : "v"(row0), "v"(row1), "s"(sink_base));                                                         \
-    } while (0)
 
 // ------------------------------------------------------------------------------------------------------------------ sub-labels alone
 // The sub-label phase of the tiles named in `list` (list[0] = their number, list[1 ..] = wave-tile indices; null: every tile): the new labels are
@@ -342,8 +333,8 @@ __device__ __forceinline__ void niw_lean_body(NiwSweepArgs A, uint32_t *__restri
         cn = e < 64 ? e : 64;
     };
     // Off a tile's critical chain order -> bins -> x (three dependent HBM round trips): the point indices and previous labels of the next tile
-    // are fetched while this one is processed, and the x rows of the NEXT tile are touched -- one dword per 128-byte line, by LDS-DMA into a sink
-    // nothing reads (DPMM_TOUCH_ROWS above) -- behind the last fragment request of this tile's evaluations: the next tile's gather, 1.5-2 k cycles later, finds the lines on
+    // are fetched while this one is processed, and the x rows of the NEXT tile are touched -- one dword per 128-byte line, into two registers nothing
+    // reads (DPMM_TOUCH_ROWS_REGS above; not in niw_lean_kernel_dir) -- behind the last fragment request of this tile's evaluations: the next tile's gather, 1.5-2 k cycles later, finds the lines on
     // their way (sweep 1.10 -> 1.08 ms).  (Vector memory returns in order: touched one row block earlier the evaluations' last fragments queue
     // behind HBM, 1.09-1.11 ms; touched a whole tile ahead the lines are gone from L2 again -- 8 MB in flight per XCD against 4 -- 1.13 ms.)
     auto index_at = [&](int p0, int cn) -> int { return lane < cn ? (use_order ? A.order[p0 + lane] : p0 + lane) : -1; };
@@ -353,8 +344,6 @@ __device__ __forceinline__ void niw_lean_body(NiwSweepArgs A, uint32_t *__restri
     int nx_p = index_at(c_p0, c_cn);
     int nx_bin = nx_p >= 0 ? A.bins[nx_p] : -1;
     const int touch_second = A.ldx > 32 ? 32 : 0;           // (floats: the row's second 128-byte line, if it has one)
-    __shared__ float touch_sink[128];
-    const unsigned sink_base = (unsigned)(uintptr_t)touch_sink;
     for (int tile = wave_id; tile < ntiles_all; tile += nwaves) {
         const bool valid = lane < c_cn;
         const int myp32 = nx_p, binv = nx_bin;
@@ -367,7 +356,7 @@ __device__ __forceinline__ void niw_lean_body(NiwSweepArgs A, uint32_t *__restri
         auto touch_x = [&]() {
             if (n_cn > 0) {
                 const float *row = A.X + (int64_t)(pf_p >= 0 ? pf_p : 0) * A.ldx;
-                if constexpr (DIR) DPMM_TOUCH_ROWS_LDS(row, row + touch_second, sink_base); else DPMM_TOUCH_ROWS_REGS(row, row + touch_second);
+                if constexpr (!DIR) DPMM_TOUCH_ROWS_REGS(row, row + touch_second);      // (niw_lean_kernel_dir: no touch, see above)
             }
         };
         int prev = binv >= 0 ? (binv >> 1) : -1;
@@ -543,7 +532,7 @@ __device__ __forceinline__ void niw_lean_body(NiwSweepArgs A, uint32_t *__restri
     }
 }
 // niw_lean_kernel: the kernel of the bench data (no direction screen; 251 registers, touches into v254 / v255); niw_lean_kernel_dir: with the screen
-// (the whole register file, LDS touches) -- launched while the library keeps the screen's tables
+// (the whole register file, no touch) -- launched while the library keeps the screen's tables
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void niw_lean_kernel(NiwSweepArgs A, uint32_t *__restrict__ list, uint32_t *__restrict__ need2,
                                                                                                    uint32_t *__restrict__ other_list, const int32_t *__restrict__ bin_start, int nbins,
                                                                                                    uint32_t *__restrict__ need3) {

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun): rocprofv3 evidence.  Outputs under gpurun_out/$1/ (copy the summaries into profiles/).
 #   pass 1: kernel trace + stats; further passes: PMC counters, each in its own run (never combined with other trace domains).
-#   $2 = what to profile: "bench" (headline NIW D=64 N=1e7, default), "mult" (C4), "d256" (C5 shard), "shard" (C3 shard)
+#   $2 = what to profile: "bench" (headline NIW D=64 N=1e7, default), "mult" (C4), "d256" (C5 shard), "shard" (C3 shard), "var4" (headline shape, MixtureVar 4)
 set -u
 TAG=${1:-prof}
 WHAT=${2:-bench}
@@ -13,6 +13,7 @@ case $WHAT in
   shard) CMD="python3 scripts/config_step.py niw 64 1250000 100"; SHORT="python3 scripts/config_step.py niw 64 1250000 5";;
   mult)  CMD="python3 scripts/config_step.py mult 1000 1000000 20"; SHORT="python3 scripts/config_step.py mult 1000 1000000 5";;
   d256)  CMD="python3 scripts/config_step.py niw 256 625000 20"; SHORT="python3 scripts/config_step.py niw 256 625000 5";;
+  var4)  CMD="python3 scripts/config_step.py niw 64 10000000 40 timing x 4"; SHORT="python3 scripts/config_step.py niw 64 10000000 5 timing x 4";;      # overlapping clusters (MixtureVar 4): niw_lean_kernel_dir
 esac
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/under_rocprof.json 2> $OUT/trace.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- $SHORT > /dev/null 2> $OUT/pmc_fetch.err

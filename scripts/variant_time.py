@@ -1,5 +1,5 @@
 """Dev helper: sweep / statistics kernel times of an experimental library build (scripts/build_variant.sh) on the bench shape.
-   python3 scripts/variant_time.py <lib name or path> [N]"""
+   python3 scripts/variant_time.py <lib name or path> [N] [MixtureVar = 100]"""
 import importlib, os, sys
 import numpy as np
 sys.path.insert(0, ".")
@@ -13,13 +13,14 @@ if name != "default":
 host = importlib.import_module("dpmmsubclusters_jl_amd.host")
 N = int(float(sys.argv[2])) if len(sys.argv) > 2 else 10 ** 7
 D, K = 64, 32
-X, y = host.gaussian_mixture_shard(N, D, K, 100.0, 12345, 0, N)
+mixvar = float(sys.argv[3]) if len(sys.argv) > 3 else 100.0
+X, y = host.gaussian_mixture_shard(N, D, K, mixvar, 12345, 0, N)
 prior = host.niw_hyperparams(1.0, np.zeros(D), D + 3, np.eye(D))
 wk = pkg.Worker(pkg.PRIOR_NIW, D, N, device=0, seed=123456789)
 wk.upload_points(X)
 s = host.DPMMSampler(wk, prior, 10.0, N, 123456789, burnout=20)
 s.start_from_labels(y, 1 + np.random.default_rng(0).integers(0, 2, N), K)
-for _ in range(30):
+for _ in range(30 if mixvar >= 50 else 70):          # (overlapping clusters: the regime switches settle within ~50 sweeps)
     s.group_step(False, False)
 sw, st = [], []
 for _ in range(20):
