@@ -1235,7 +1235,6 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
             // First the tiles the cheap screens settle completely (niw_lean_kernel: labels and sub-labels in one go); what it leaves goes through
             // the list.  A sweep that left more than 30 % of its tiles (overlapping clusters: the screens' later stages do the work) switches the
             // lean kernel off for 15 sweeps -- every path gives the same labels and sub-labels, so the decision is free to be local.
-            // (not while the direction screen's regime is on: eight or more candidates per tile behind the 4-row tests -- nothing for the cheap screens to settle)
             // (round 6: the lean kernel runs the direction screen itself while the tables exist -- it used to stay off in that regime)
             const bool lean_ok = c->opt_lean != 0 && c->opt_bracket && a.use_prev && a.screen_margin > 0.f && !final_argmax && a.lam == nullptr && c->K > 1 && c->d_hard &&
                                  !(c->opt_lean_dir == 0 && c->sp_regime && c->opt_direction != 0 && c->sp_ready);

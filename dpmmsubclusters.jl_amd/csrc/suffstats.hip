@@ -233,6 +233,14 @@ __global__ __launch_bounds__(64) void reset_recount_kernel(int32_t *__restrict__
     if (blockIdx.x == 0 && lane == 0) flags[K] = any ? 1 : 0;
     if (!any) return;
     __syncthreads();
+    // does this tile hold a point of a flagged cluster at all?  The histogram's counts say so without reading the tile's labels (round 6: with the
+    // points of a component contiguous in storage -- the reference generator's layout -- 94 % of the tiles leave here: 18 -> 5 us at N = 1e7)
+    {
+        bool need = false;
+        for (int k = lane; k < K; k += 64)
+            if (f[k]) need = need || (tile_cnt[(int64_t)(2 * k) * nt + blockIdx.x] | tile_cnt[(int64_t)(2 * k + 1) * nt + blockIdx.x]) != 0;
+        if (!__any(need)) return;
+    }
     const int64_t base = (int64_t)blockIdx.x * TILE;
     constexpr int PER = TILE / 64;
     int v[PER];
