@@ -210,15 +210,18 @@ __global__ __launch_bounds__(64 * W) void hist_kernel(const int32_t *__restrict_
 // and to undo the reset of a candidate that turns out not to be bad (all of its points go back to that side).  flags[] then holds the
 // candidates, not the verdict: niw_finalize_rows_kernel writes the verdict behind the all-reduce.
 template <int TILE>
-__global__ __launch_bounds__(64) void reset_recount_kernel(int32_t *__restrict__ bins, int64_t n, int64_t first, int nbins, int nt,
-                                                           const int32_t *__restrict__ totals, const long long *__restrict__ global_counts,
-                                                           int32_t *__restrict__ tile_cnt, uint8_t *__restrict__ flags, int K, uint64_t seed, uint32_t epoch,
-                                                           uint8_t *__restrict__ cside) {
+__global__ __launch_bounds__(TILE / 8) void reset_recount_kernel(int32_t *__restrict__ bins, int64_t n, int64_t first, int nbins, int nt,
+                                                                 const int32_t *__restrict__ totals, const long long *__restrict__ global_counts,
+                                                                 int32_t *__restrict__ tile_cnt, uint8_t *__restrict__ flags, int K, uint64_t seed, uint32_t epoch,
+                                                                 uint8_t *__restrict__ cside) {
+    // TILE / 8 threads per tile, eight points each (round 6: one wave per 2048-point tile drew 32 Philox blocks per lane one after the other -- the
+    // launch lasted as long as ONE tile of a flagged cluster, 17-21 us at N = 1e7; four waves share it now)
+    constexpr int NT = TILE / 8, PER = 8;
     extern __shared__ int cnt[];                 // [nbins] counters | [K] flag bytes
     uint8_t *f = reinterpret_cast<uint8_t *>(cnt + nbins);
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
     bool anyl = false;
-    for (int k = lane; k < K; k += 64) {
+    for (int k = tid; k < K; k += NT) {
         const long long a = global_counts ? global_counts[2 * k] : (long long)totals[(2 * k) * FAST_TOTAL_STRIDE];
         const long long b = global_counts ? global_counts[2 * k + 1] : (long long)totals[(2 * k + 1) * FAST_TOTAL_STRIDE];
         const bool bad = cside ? ((a == 0) != (b == 0)) : (a == 0 || b == 0);
@@ -229,34 +232,32 @@ __global__ __launch_bounds__(64) void reset_recount_kernel(int32_t *__restrict__
             if (cside) cside[k] = bad ? (b == 0 ? 1 : 2) : 0;
         }
     }
-    const bool any = __any(anyl);
-    if (blockIdx.x == 0 && lane == 0) flags[K] = any ? 1 : 0;
+    const bool any = __syncthreads_or(anyl ? 1 : 0) != 0;        // (also publishes f[] to the workgroup)
+    if (blockIdx.x == 0 && tid == 0) flags[K] = any ? 1 : 0;
     if (!any) return;
-    __syncthreads();
     // does this tile hold a point of a flagged cluster at all?  The histogram's counts say so without reading the tile's labels (round 6: with the
-    // points of a component contiguous in storage -- the reference generator's layout -- 94 % of the tiles leave here: 18 -> 5 us at N = 1e7)
+    // points of a component contiguous in storage -- the reference generator's layout -- 94 % of the tiles leave here)
     {
         bool need = false;
-        for (int k = lane; k < K; k += 64)
+        for (int k = tid; k < K; k += NT)
             if (f[k]) need = need || (tile_cnt[(int64_t)(2 * k) * nt + blockIdx.x] | tile_cnt[(int64_t)(2 * k + 1) * nt + blockIdx.x]) != 0;
-        if (!__any(need)) return;
+        if (!__syncthreads_or(need ? 1 : 0)) return;
     }
     const int64_t base = (int64_t)blockIdx.x * TILE;
-    constexpr int PER = TILE / 64;
     int v[PER];
     bool hit = false;
-    const bool full = base + TILE <= n;       // full tile: 16-byte loads (lane owns four consecutive points per trip), else one point per trip
+    const bool full = base + TILE <= n;       // full tile: 16-byte loads (a thread owns four consecutive points per trip), else one point per trip
     if (full) {
         const int4 *src = reinterpret_cast<const int4 *>(bins + base);
 #pragma unroll
         for (int it = 0; it < PER / 4; ++it) {
-            const int4 q = src[it * 64 + lane];
+            const int4 q = src[it * NT + tid];
             v[4 * it] = q.x; v[4 * it + 1] = q.y; v[4 * it + 2] = q.z; v[4 * it + 3] = q.w;
         }
     } else {
 #pragma unroll
         for (int it = 0; it < PER; ++it) {
-            const int64_t i = base + it * 64 + lane;
+            const int64_t i = base + it * NT + tid;
             v[it] = i < n ? bins[i] : -1;
         }
     }
@@ -265,12 +266,12 @@ __global__ __launch_bounds__(64) void reset_recount_kernel(int32_t *__restrict__
         const int z = v[it] >> 1;
         hit = hit || (v[it] >= 0 && z < K && f[z]);
     }
-    if (!__any(hit)) return;
-    for (int b = lane; b < nbins; b += 64) cnt[b] = 0;
+    if (!__syncthreads_or(hit ? 1 : 0)) return;
+    for (int b = tid; b < nbins; b += NT) cnt[b] = 0;
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < PER; ++it) {
-        const int64_t i = full ? base + (int64_t)((it >> 2) * 64 + lane) * 4 + (it & 3) : base + it * 64 + lane;
+        const int64_t i = full ? base + (int64_t)((it >> 2) * NT + tid) * 4 + (it & 3) : base + it * NT + tid;
         int bv = v[it];
         const int z = bv >> 1;
         if (bv >= 0 && z < K && f[z]) {
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(64) void reset_recount_kernel(int32_t *__restrict__
         if ((unsigned)bv < (unsigned)nbins) atomicAdd(&cnt[bv], 1);
     }
     __syncthreads();
-    for (int b = lane; b < nbins; b += 64) tile_cnt[(int64_t)b * nt + blockIdx.x] = cnt[b];
+    for (int b = tid; b < nbins; b += NT) tile_cnt[(int64_t)b * nt + blockIdx.x] = cnt[b];
 }
 
 // exclusive scan over the tiles of one bin (in place) + bin total
@@ -654,7 +655,7 @@ hipError_t launch_step_reset(int32_t *bins, int64_t n, int64_t first, int nbins,
     const size_t lds = nbins * sizeof(int) + ((K + 3) & ~3);
     DPMM_TILE_DISPATCH(b.tile,
         DPMM_LAUNCH(reset_recount_kernel<512>, dim3(nt), dim3(64), lds, s, bins, n, first, nbins, nt, b.fast_total, global_counts, b.tile_cnt, flags, K, seed, epoch, cside),
-        DPMM_LAUNCH(reset_recount_kernel<2048>, dim3(nt), dim3(64), lds, s, bins, n, first, nbins, nt, b.fast_total, global_counts, b.tile_cnt, flags, K, seed, epoch, cside));
+        DPMM_LAUNCH(reset_recount_kernel<2048>, dim3(nt), dim3(256), lds, s, bins, n, first, nbins, nt, b.fast_total, global_counts, b.tile_cnt, flags, K, seed, epoch, cside));
     return hipGetLastError();
 }
 
