@@ -68,13 +68,7 @@ __device__ __forceinline__ B3Head b3_head(const float *__restrict__ tail, const 
     H.cl = cst[3 * k + 1]; H.cr = cst[3 * k + 2];
     return H;
 }
-#ifndef B3_LATE_AT
-#define B3_LATE_AT 5        // the row block (0 .. 7) whose turn calls the `late` hook: 5 is the one that issues the evaluation's last fragment request.
-#endif                      // (measured, N = 1e7 sweep: 5 -> 1.08 ms, 4 -> 1.09-1.11, 3 -> 1.14-1.16: a hook that issues vector-memory loads earlier puts them in front of fragments)
-struct B3NoHook { __device__ __forceinline__ void operator()() const {} };
-// `late`: called once behind the LAST fragment request of the evaluation (nothing of the evaluation queues behind what it issues)
-template <class Hook = B3NoHook>
-__device__ __forceinline__ void b3_eval(const float *__restrict__ tail, int K, int k, const B3Z &Z, const B3Head &H, int lane, int g, float &bl, float &br, Hook late = Hook()) {
+__device__ __forceinline__ void b3_eval(const float *__restrict__ tail, int K, int k, const B3Z &Z, const B3Head &H, int lane, int g, float &bl, float &br) {
     const uint32_t *img = b3_images(tail, K) + (size_t)(3 * k + 1) * B3_WORDS;
     const float *dvec = b3_offsets(tail, K) + (size_t)(3 * k + 1) * B3_DVEC;
     const u32x4_t *F = reinterpret_cast<const u32x4_t *>(img) + (unsigned)lane;          // fragment f of plane p of matrix m: F[64 (18 m + 6 p + f)]
@@ -113,7 +107,6 @@ __device__ __forceinline__ void b3_eval(const float *__restrict__ tail, int K, i
     for (int b8 = 0; b8 < 8; ++b8) {
         const int bi = b8 & 3;
         if (b8 + 2 < 8) load_block(b8 + 2);
-        if (b8 == B3_LATE_AT) late();
         __builtin_amdgcn_sched_barrier(0);          // (the requests stay in front of this row block's matrix instructions; none of a later row block joins them)
 #pragma unroll
         for (int n = 0; n < 4; ++n) {

@@ -106,31 +106,26 @@ hipError_t launch_niw_b3_debug(const NiwSweepArgs &a, float *out, hipStream_t s)
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------------------------------------------ the touch
-// niw_sub_kernel and niw_lean_kernel pull the NEXT tile's x rows towards L2 behind the last fragment request of a tile's evaluations: one dword per
-// 128-byte line, loaded by inline asm into v254 / v255 -- two registers nothing reads; the compiler's vmcnt bookkeeping does not see the loads (every
-// wait it emits is then for MORE loads than it thinks, never fewer; no touch is in flight when a wave ends: s_waitcnt vmcnt(0) at the end of both
-// kernels).  That is safe only while the register allocator never places a value of its own in v254 / v255, which amdgpu_num_vgpr(254) obtains
-// only while the kernel FITS below them: the first change that added register pressure (round 6, the direction screen's code in the lean kernel)
-// made it put ds_bpermute results there -- and the build-time check ADVICE r5 had asked for (check_reserved_vgprs.py, run by the Makefile on
-// the generated assembly, kernel by kernel) stopped the build.  So: the kernels that fit (niw_sub_kernel 254, niw_lean_kernel 251 registers)
-// keep the touch, checked on every build; niw_lean_kernel_dir, which needs the whole register file, has NONE.  (A touch without a register
-// destination was built for it -- global_load_lds_dword into an LDS sink, M0 saved and restored inside the statement -- and measured: the
-// lean launch 0.999 -> 1.037 ms on the bench data, and niw_lean_kernel_dir 1.192 ms WITHOUT any touch against 1.216 with the LDS one, which also
-// fetched 3.7 GB against 2.8: lines brought in by LDS-DMA loads do not stay in L2 for the gather that follows.  docs/experiments/r06_*.patch)
-#define DPMM_TOUCH_ROWS_REGS(row0, row1) asm volatile("global_load_dword v254, %0, off\n\tglobal_load_dword v255, %1, off" :: "v"(row0), "v"(row1) : "v254", "v255")
+// (Rounds 5-6 pulled the NEXT tile's x rows towards L2 from here -- one dword per 128-byte line behind the evaluations' last fragment request, loaded by
+// inline asm into two registers kept away from the allocator -- for 2 % of the launch when it was built.  Measured again at the end of round 6, after
+// the records moved to LDS and the uniforms under the gather: with and without it the launch takes the same time (N = 1e7: 1.011 / 1.024 ms without,
+// 1.020 / 1.019 with; 8-GPU shard 0.146 / 0.147; overlapping clusters 1.199 / 1.204 and 1.483 / 1.466), and the lines it pulled were fetched twice where the
+// gather missed them (2.83 GB of traffic against 2.60 algorithmic).  Removed, with the reserved registers and the build-time check they needed.)
 
 // ------------------------------------------------------------------------------------------------------------------ sub-labels alone
 // The sub-label phase of the tiles named in `list` (list[0] = their number, list[1 ..] = wave-tile indices; null: every tile): the new labels are
 // in bins (niw_sweep_direct_kernel<.., LSTORE> stored 2 z + old sub-label), the second uniform of the point's Philox draw decides between left
 // and right (create_subclusters_labels!, local_clusters_actions.jl:83-95).  One wave per tile of 64 positions of the visiting order.
-__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void niw_sub_kernel(NiwSweepArgs A, const uint32_t *__restrict__ list, uint32_t *__restrict__ count_out) {
+// (LISTED: with a list.  Two instantiations: in ONE kernel the words of a span -- loaded with a list, computed without -- shared registers, and the
+//  no-list path waited for every outstanding load before it wrote them)
+template <bool LISTED>
+__global__ __launch_bounds__(256, 2) void niw_sub_kernel(NiwSweepArgs A, const uint32_t *__restrict__ list, uint32_t *__restrict__ count_out) {
     // (the list's length for the host's regime decision, written to pinned memory by the last launch that reads it: no copy launch)
-    if (list && count_out && blockIdx.x == 0 && threadIdx.x == 0) *count_out = list[0];
+    if (LISTED && count_out && blockIdx.x == 0 && threadIdx.x == 0) *count_out = list[0];
     const int lane = threadIdx.x & 63, ci = lane & 15, g = lane >> 4;
     const bool use_order = A.order != nullptr && *A.order_total == (int32_t)A.n;
     const int64_t nwtiles = (A.n + 63) / 64;
-    const int64_t count = list ? (int64_t)list[0] : nwtiles;
+    const int64_t count = LISTED ? (int64_t)list[0] : nwtiles;
     const int wave_id = (int)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int)gridDim.x * 4;
     unsigned nw_b3 = 0;
     // A tile's chain list -> order -> bins -> x is four dependent round trips; the first three are taken off it: the tile index is known two
@@ -138,31 +133,37 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void 
     // this tile's x gather) -- as niw_lean_kernel does.  All-tiles mode without them: 0.82 ms at N = 1e7.
     // entry i of the list = (first position, number of positions <= 64): the lean kernel's tiles are aligned to the sort's bins; without a
     // list tile i is positions 64 i ..  A span is packed as position << 7 | count (n < 2^31, count <= 64); -1: none.
-    auto tile_of = [&](int64_t i) -> int64_t {
-        if (i >= count) return -1;
-        if (list) return ((int64_t)list[1 + 2 * i] << 7) | (int64_t)list[2 + 2 * i];
-        const int64_t e = A.n - 64 * i;
-        return ((64 * i) << 7) | (e < 64 ? e : 64);
+    // (What a tile's top needs of loaded values -- the span two tiles ahead, the labels of this tile's points -- is FORMED one tile earlier, at the end
+    //  of the tile that requested it: formed at the top, behind the index load issued there, every tile began with s_waitcnt vmcnt(0).)
+    auto span_words = [&](int64_t i, uint32_t &w0, uint32_t &w1) {           // the two words of span i as loaded (combined by pack_span when they have landed)
+        w0 = 0u; w1 = 0xffffffffu;                                          // (w1 = ~0: none)
+        if (i >= count) return;
+        if constexpr (LISTED) { w0 = list[1 + 2 * i]; w1 = list[2 + 2 * i]; }
+        else { const int64_t e = A.n - 64 * i; w0 = (uint32_t)(64 * i); w1 = (uint32_t)(e < 64 ? e : 64); }
     };
-    int64_t t_next = tile_of(wave_id), t_next2 = tile_of((int64_t)wave_id + nwaves);
-    const int touch_second = A.ldx > 32 ? 32 : 0;
-    int nx_p = -1, nx_bin = -1;
+    auto pack_span = [](uint32_t w0, uint32_t w1) -> int64_t { return w1 == 0xffffffffu ? (int64_t)-1 : (((int64_t)w0 << 7) | (int64_t)w1); };
+    auto label_of = [&](int bin) -> int { const int zz = bin >> 1; return (unsigned)zz < (unsigned)A.K ? zz : -1; };      // (a label outside [0, K): left alone)
+    uint32_t sa, sb, sa2, sb2;
+    span_words(wave_id, sa, sb);
+    span_words((int64_t)wave_id + nwaves, sa2, sb2);
+    int64_t t_next = pack_span(sa, sb);
+    int nx_p = -1, nx_z = -1;
     if (t_next >= 0) {
         const int64_t pos = (t_next >> 7) + lane;
-        if (lane < (int)(t_next & 127)) { nx_p = use_order ? A.order[pos] : (int)pos; nx_bin = A.bins[nx_p]; }
+        if (lane < (int)(t_next & 127)) { nx_p = use_order ? A.order[pos] : (int)pos; nx_z = label_of(A.bins[nx_p]); }
     }
     for (int64_t idx = wave_id; idx < count; idx += nwaves) {
-        t_next = t_next2;
-        t_next2 = tile_of(idx + 2 * (int64_t)nwaves);
+        t_next = pack_span(sa2, sb2);
         const int myp32 = nx_p;
-        const int zb = nx_bin;
+        const int z = nx_z;
         int pf_p = -1, pf_bin = -1;
-        if (t_next >= 0) {
+        const bool has_next = t_next >= 0 && lane < (int)(t_next & 127);      // (the lane has a point in the next tile: known without its index)
+        bool bin_asked = false;                                                // (wave-uniform)
+        if (has_next) {
             const int64_t posn = (t_next >> 7) + lane;
-            if (lane < (int)(t_next & 127)) pf_p = use_order ? A.order[posn] : (int)posn;
+            pf_p = use_order ? A.order[posn] : (int)posn;
         }
-        int z = zb >> 1;
-        if ((unsigned)z >= (unsigned)A.K) z = -1;                       // (a label outside [0, K): left alone)
+        span_words(idx + 2 * (int64_t)nwaves, sa2, sb2);                      // (requested behind the last use of the words it replaces)
         float u_sub = 0.f;
         if (z >= 0) u_sub = u01(philox4x32_10(A.seed, (uint64_t)(A.first_index + myp32), A.epoch, STREAM_SWEEP).v[1]);
         float b0 = -INFINITY, b1 = -INFINITY;
@@ -178,29 +179,28 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void 
             __builtin_amdgcn_sched_barrier(0);
             B3Z Z;
             b3_convert(x, mk, Z);
-            if (pf_p >= 0 && pf_bin < 0) pf_bin = A.bins[pf_p];              // the next tile's labels (its indices arrived with x)
+            if (!bin_asked) {                                                 // the next tile's labels (its indices arrived with x)
+                int q = pf_p;
+                asm volatile("" : "+v"(q));                                   // (the address is formed HERE: hoisted out of the loop it waited for the index in front of the gather)
+                if (has_next) pf_bin = A.bins[q];
+                bin_asked = true;
+            }
             float bl, br;
-            // (the next tile's x rows touched behind the last fragment request, as in niw_lean_kernel)
-            auto touch_x = [&]() {
-                if (t_next >= 0 && !todo) {
-                    const float *row = A.X + (int64_t)(pf_p >= 0 ? pf_p : 0) * A.ldx;
-                    DPMM_TOUCH_ROWS_REGS(row, row + touch_second);
-                }
-            };
-            b3_eval(A.tail, A.K, k, Z, H, lane, g, bl, br, touch_x);
+            b3_eval(A.tail, A.K, k, Z, H, lane, g, bl, br);
             if (z == k) { b0 = bl; b1 = br; }
             nw_b3 += 2;
         }
         if (z >= 0) A.bins[myp32] = 2 * z + draw2(b0, b1, u_sub);
-        if (pf_p >= 0 && pf_bin < 0) pf_bin = A.bins[pf_p];                  // (a tile without a label in range)
-        nx_p = pf_p; nx_bin = pf_bin;
+        if (!bin_asked && has_next) pf_bin = A.bins[pf_p];                   // (a tile without a label in range)
+        nx_p = pf_p; nx_z = has_next ? label_of(pf_bin) : -1;
+        asm volatile("" : "+v"(nx_z));                                          // (here, not sunk to the next tile's top)
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (A.work && lane == 0) A.work[DPMM_WORK_SLOTS + (size_t)wave_id * DPMM_WORK_PER_WAVE + 7] += (unsigned long long)nw_b3 << 32;
 }
 hipError_t launch_niw_sub(const NiwSweepArgs &a, const uint32_t *list, uint32_t *count_out, int grid, hipStream_t s) {
     if (!a.tail || a.n <= 0) return hipErrorInvalidValue;
-    DPMM_LAUNCH(niw_sub_kernel, dim3(grid), dim3(256), 0, s, a, list, count_out);
+    if (list) DPMM_LAUNCH(niw_sub_kernel<true>, dim3(grid), dim3(256), 0, s, a, list, count_out);
+    else DPMM_LAUNCH(niw_sub_kernel<false>, dim3(grid), dim3(256), 0, s, a, list, count_out);
     return hipGetLastError();
 }
 
@@ -332,35 +332,29 @@ __device__ __forceinline__ void niw_lean_body(NiwSweepArgs A, uint32_t *__restri
         const int e = __builtin_amdgcn_readfirstlane(bstart_s[bptr + 1]) - p0;
         cn = e < 64 ? e : 64;
     };
-    // Off a tile's critical chain order -> bins -> x (three dependent HBM round trips): the point indices and previous labels of the next tile
-    // are fetched while this one is processed, and the x rows of the NEXT tile are touched -- one dword per 128-byte line, into two registers nothing
-    // reads (DPMM_TOUCH_ROWS_REGS above; not in niw_lean_kernel_dir) -- behind the last fragment request of this tile's evaluations: the next tile's gather, 1.5-2 k cycles later, finds the lines on
-    // their way (sweep 1.10 -> 1.08 ms).  (Vector memory returns in order: touched one row block earlier the evaluations' last fragments queue
-    // behind HBM, 1.09-1.11 ms; touched a whole tile ahead the lines are gone from L2 again -- 8 MB in flight per XCD against 4 -- 1.13 ms.)
+    // Off a tile's critical chain order -> bins -> x (three dependent round trips): the point indices and previous labels of the next tile are
+    // fetched while this one is processed.
     auto index_at = [&](int p0, int cn) -> int { return lane < cn ? (use_order ? A.order[p0 + lane] : p0 + lane) : -1; };
     int c_p0, c_cn, n_p0, n_cn;                              // spans of this tile and of the next one
     span_of(wave_id, c_p0, c_cn);
     span_of(wave_id + nwaves, n_p0, n_cn);
     int nx_p = index_at(c_p0, c_cn);
-    int nx_bin = nx_p >= 0 ? A.bins[nx_p] : -1;
-    const int touch_second = A.ldx > 32 ? 32 : 0;           // (floats: the row's second 128-byte line, if it has one)
+    // carried from tile to tile: the previous LABEL of the lane's point (-1: none), formed at the END of the tile that fetched the bin word, where that
+    // load has long landed.  (Formed at the next tile's top it sat behind the index load issued there and the compiler answered with s_waitcnt
+    // vmcnt(0) -- that load, the last store's acknowledgement -- in front of every gather.  Measured: no change of the launch time; kept for the shorter chain.)
+    auto label_of = [&](int bin) -> int { const int pv = bin >= 0 ? (bin >> 1) : -1; return (unsigned)pv < (unsigned)K ? pv : -1; };
+    int nx_prev = label_of(nx_p >= 0 ? A.bins[nx_p] : -1);
     for (int tile = wave_id; tile < ntiles_all; tile += nwaves) {
         const bool valid = lane < c_cn;
-        const int myp32 = nx_p, binv = nx_bin;
+        const int myp32 = nx_p;
         LSTAMP(s0);
 #ifdef DPMM_STAMPS
         unsigned long long s1 = s0, s2 = s0, s3 = s0, s4 = s0, s5 = s0;
 #endif
         const int pf_p = index_at(n_p0, n_cn);                   // the next tile's indices
         int pf_bin = -1;                                         // its previous labels: requested when the indices have arrived (with x)
-        auto touch_x = [&]() {
-            if (n_cn > 0) {
-                const float *row = A.X + (int64_t)(pf_p >= 0 ? pf_p : 0) * A.ldx;
-                if constexpr (!DIR) DPMM_TOUCH_ROWS_REGS(row, row + touch_second);      // (niw_lean_kernel_dir: no touch, see above)
-            }
-        };
-        int prev = binv >= 0 ? (binv >> 1) : -1;
-        if ((unsigned)prev >= (unsigned)K) prev = -1;
+        bool bin_asked = false;                                  // (wave-uniform)
+        const int prev = nx_prev;
         const unsigned long long pm = __ballot(prev >= 0);
         bool hard = pm == 0ull;
         int k0 = 0;
@@ -415,7 +409,8 @@ __device__ __forceinline__ void niw_lean_body(NiwSweepArgs A, uint32_t *__restri
                     } else b3_convert(x, mk, Z);
                 } else b3_convert(x, mk, Z);                   // x's last use (but for x3)
             }
-            if (pf_p >= 0) pf_bin = A.bins[pf_p];              // the next tile's previous labels (its indices have arrived with x)
+            if (lane < n_cn) pf_bin = A.bins[pf_p];            // the next tile's previous labels (its indices have arrived with x)
+            bin_asked = true;
 #ifdef DPMM_STAMPS
             { LSTAMP(t2); s2 = t2; }
 #endif
@@ -493,15 +488,15 @@ __device__ __forceinline__ void niw_lean_body(NiwSweepArgs A, uint32_t *__restri
 #endif
         if (hard) {
             if (lane == 0) { const uint32_t at = atomicAdd(&list[0], 1u); list[1 + 2 * at] = (uint32_t)c_p0; list[2 + 2 * at] = (uint32_t)c_cn; }
-            if (pf_p >= 0 && pf_bin < 0) pf_bin = A.bins[pf_p];        // (a tile that left before the bracket)
-            touch_x();
+            if (!bin_asked && lane < n_cn) pf_bin = A.bins[pf_p];      // (a tile that left before the bracket)
         } else {
             float bl, br;
-            b3_eval(A.tail, K, k0, Z, H, lane, g, bl, br, touch_x);
+            b3_eval(A.tail, K, k0, Z, H, lane, g, bl, br);
             if (valid) A.bins[myp32] = 2 * k0 + draw2(bl, br, u_sub);
             ++nw_easy;
         }
-        nx_p = pf_p; nx_bin = pf_bin;
+        nx_p = pf_p; nx_prev = label_of(pf_bin);
+        asm volatile("" : "+v"(nx_prev));                      // (here, not sunk to the next tile's top)
         c_p0 = n_p0; c_cn = n_cn;
         span_of(tile + 2 * nwaves, n_p0, n_cn);
 #ifdef DPMM_STAMPS
@@ -514,7 +509,6 @@ __device__ __forceinline__ void niw_lean_body(NiwSweepArgs A, uint32_t *__restri
         d[0] = T_x; d[1] = T_conv; d[2] = T_br; d[3] = T_scr; d[4] = T_u; d[5] = T_p2; d[6] = 0; d[7] = T_tot; d[8] = ntl;
     }
 #endif
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (no touch in flight at the end)
     if (A.work && lane == 0) {
         unsigned long long *slot = A.work + DPMM_WORK_SLOTS + (size_t)wave_id * DPMM_WORK_PER_WAVE;      // (accumulates; cleared by the reader)
         slot[0] += nw_easy; slot[3] += nw_tail; slot[4] += nw_br; slot[5] += nw_bb; slot[7] += ((unsigned long long)(2 * nw_easy) << 32) + nw_sp;
@@ -531,11 +525,10 @@ __device__ __forceinline__ void niw_lean_body(NiwSweepArgs A, uint32_t *__restri
         need3[2 * wave_id] = word; need3[2 * wave_id + 1] = yield;
     }
 }
-// niw_lean_kernel: the kernel of the bench data (no direction screen; 251 registers, touches into v254 / v255); niw_lean_kernel_dir: with the screen
-// (the whole register file, no touch) -- launched while the library keeps the screen's tables
-__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(254))) void niw_lean_kernel(NiwSweepArgs A, uint32_t *__restrict__ list, uint32_t *__restrict__ need2,
-                                                                                                   uint32_t *__restrict__ other_list, const int32_t *__restrict__ bin_start, int nbins,
-                                                                                                   uint32_t *__restrict__ need3) {
+// niw_lean_kernel: the kernel of the bench data (no direction screen); niw_lean_kernel_dir: with the screen (a handful of spilled registers: loop-invariant
+// addresses) -- launched while the library keeps the screen's tables
+__global__ __launch_bounds__(256, 2) void niw_lean_kernel(NiwSweepArgs A, uint32_t *__restrict__ list, uint32_t *__restrict__ need2, uint32_t *__restrict__ other_list,
+                                                         const int32_t *__restrict__ bin_start, int nbins, uint32_t *__restrict__ need3) {
     niw_lean_body<false>(A, list, need2, other_list, bin_start, nbins, need3);
 }
 __global__ __launch_bounds__(256, 2) void niw_lean_kernel_dir(NiwSweepArgs A, uint32_t *__restrict__ list, uint32_t *__restrict__ need2, uint32_t *__restrict__ other_list,

@@ -96,40 +96,3 @@ def test_product_never_imports_the_oracle():
                 assert "liboracle" not in txt and "orc_" not in txt, f
 
 
-def test_reserved_register_check_of_the_lean_kernels():
-    """niw_lean.hip touches the next tile's rows behind the compiler's back, in two flavours.  REGS (inline-asm loads into v254 /
-    v255, kept free by amdgpu_num_vgpr(254)) is safe only while the allocator stays away: round 6's first change that added register pressure made
-    it use them and this check -- run by the Makefile on the generated assembly -- stopped the build; the kernel with the direction screen therefore
-    uses LDS (LDS-DMA loads without a register destination inside a save / restore of M0).  The check, per kernel: a kernel with register touches
-    names v254 / v255 nowhere else; an LDS touch sits inside a well-formed M0 window."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("crv", os.path.join(ROOT, "dpmmsubclusters.jl_amd", "csrc", "check_reserved_vgprs.py"))
-    crv = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(crv)
-    regs = ["\tglobal_load_dword v254, v[214:215], off", "\tglobal_load_dword v255, v[216:217], off", "\tv_add_f32 v253, v1, v2 ; v255 in a comment",
-            "\tv_mfma_f32_16x16x32_bf16 v[0:3], v[250:253], v[10:13], v[0:3]"]
-    bad, reg_t, lds_t = crv.offending(regs)
-    assert bad == [] and reg_t == 2 and lds_t == 0
-    assert crv.offending(regs + ["\tv_mov_b32 v254, v3"])[0]
-    assert crv.offending(regs + ["\tv_mfma_f32_16x16x32_bf16 v[0:3], v[252:255], v[10:13], v[0:3]"])[0]
-    assert crv.offending(regs + ["\tglobal_load_dwordx2 v[254:255], v[2:3], off"])[0]
-    assert crv.offending(regs + ["\tscratch_store_dword off, v255, s32"])[0]
-    assert crv.offending(["\tv_mov_b32 v254, v3", "\tds_bpermute_b32 v255, v240, v105"])[0] == []      # a kernel WITHOUT register touches may use every register
-    lds = ["\ts_mov_b32 s36, m0", "\ts_mov_b32 m0, s73", "\ts_nop 0", "\tglobal_load_lds_dword v[214:215], off", "\tglobal_load_lds_dword v[216:217], off offset:256",
-           "\ts_mov_b32 m0, s36", "\tv_mov_b32 v255, v2"]
-    bad, reg_t, lds_t = crv.offending(lds)
-    assert bad == [] and reg_t == 0 and lds_t == 2
-    assert crv.offending(["\tglobal_load_lds_dword v[2:3], off"])[0]                                   # no window
-    assert crv.offending(lds[:3] + ["\tv_readlane_b32 s4, v3, 2"] + lds[3:])[0]                        # a foreign instruction inside the window
-    assert crv.offending(lds[:5])[0]                                                                    # never restored
-    assert crv.offending(lds[:5] + ["\ts_mov_b32 m0, s37"])[0]                                         # restored from another register
-    built = os.path.join(ROOT, "dpmmsubclusters.jl_amd", "csrc", "build", "niw_lean.s")
-    if os.path.exists(built):       # the assembly of THIS build, when the library was built here: every kernel of it
-        ks = crv.kernels(open(built).read().split("\n"))
-        assert len(ks) >= 3
-        seen = 0
-        for name, start, body in ks:
-            bad, reg_t, lds_t = crv.offending(body, start + 1)
-            assert bad == [], (name, bad[:3])
-            seen += reg_t + lds_t
-        assert seen >= 6
