@@ -248,7 +248,7 @@ __device__ __forceinline__ void ref_bracket_planes(const u32x4_t (&a)[6], const 
 // A whole tile (64 positions of the visiting order) in one go WHERE THE SCREENS SETTLE IT: every point of the wave had label k0; the certified
 // bracket of a_k0 (lower end), the ball test and the 4-row tail screens -- the first stages of niw_sweep_direct_kernel's cascade, same
 // records, same thresholds -- exclude every other cluster for every point.  Then that kernel's draw returns k0 whatever a_k0 is (its
-// `ref_skipped` branch; index 0 for a uniform of exactly 0 -- such a tile is left to it), and what remains is the sub-label phase on planes
+// `ref_skipped` branch; uniforms are in (0, 1): u01, dpmm_device.h), and what remains is the sub-label phase on planes
 // that exist already.  Every other tile (mixed previous labels, a candidate left, no previous labels) is appended to `list` ([0] = count,
 // cleared before the launch) and left untouched: niw_sweep_direct_kernel<.., LSTORE> + niw_sub_kernel take it.  The outcome is that of the
 // one-kernel path: a tile is settled here only if every later screen there would find nothing to do either.
@@ -364,7 +364,7 @@ __device__ __forceinline__ void niw_lean_body(NiwSweepArgs A, uint32_t *__restri
         }
         B3Z Z;
         B3Head H;
-        float u_sub = 0.f, u0 = 1.f;
+        float u_sub = 0.f;
         if (!hard) {
             f32x4 xt = (f32x4){0.f, 0.f, 0.f, 0.f};
             f32x4 x3[4];                                           // the last 16 features (the bf16 bottom screens' operand)
@@ -383,7 +383,7 @@ __device__ __forceinline__ void niw_lean_body(NiwSweepArgs A, uint32_t *__restri
                 // the point's uniforms need nothing of x: their ~150 vector instructions run while the gather is on its way
                 if (valid) {
                     const Philox4 r = philox4x32_10(A.seed, (uint64_t)(A.first_index + myp32), A.epoch, STREAM_SWEEP);
-                    u0 = u01(r.v[0]); u_sub = u01(r.v[1]);
+                    u_sub = u01(r.v[1]);               // (the label's uniform r.v[0] is in (0, 1) -- u01, dpmm_device.h -- and the draw of a settled tile returns k0 whatever it is)
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #ifdef DPMM_STAMPS
@@ -481,7 +481,6 @@ __device__ __forceinline__ void niw_lean_body(NiwSweepArgs A, uint32_t *__restri
 #endif
         if (!hard) {
             H = b3_head(A.tail, A.cst, K, k0, lane, g);           // the sub-label evaluation's first fragments
-            hard = __ballot(valid && u0 <= 0.f) != 0ull;       // (a uniform of exactly 0 draws index 0, not k0: once in 2^24 points -- the general path)
         }
 #ifdef DPMM_STAMPS
         { LSTAMP(t5); s5 = t5; }
