@@ -38,6 +38,7 @@ Besides the contract fields the JSON line carries
   cpu_baseline  the reference algorithm's worker path on the host cores, P worker processes (see oracle/cpu_baseline.py).
 """
 import argparse
+import gc
 import hashlib
 import importlib
 import json
@@ -640,14 +641,22 @@ def main():
         return [float(v) for v in t]
 
     def timed_block(nsteps, collect=None):
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(nsteps):
-            s.group_step(False, False)
-            if collect is not None:
-                collect()
-        fence()
-        return max_over_ranks([time.perf_counter() - t0])[0]
+        # (no cyclic garbage collection inside a timed block: the interpreter holds the legs' dictionaries and 640 MB of numpy data by now, and a
+        #  generation-2 pass in the middle of 30 steps of 1.5 ms is a visible fraction of the block)
+        gc.collect()
+        gc.disable()
+        try:
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(nsteps):
+                s.group_step(False, False)
+                if collect is not None:
+                    collect()
+            fence()
+            dt = time.perf_counter() - t0
+        finally:
+            gc.enable()
+        return max_over_ranks([dt])[0]
 
     n_local = hi - lo
     sweep_ms, stats_ms, ks, work, comm_ms = [], [], [], [], []
