@@ -86,6 +86,7 @@ ABI = [
     ("dpmm_step_stats", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]),
     ("dpmm_debug_subloglik", ctypes.c_int, [ctypes.c_void_p, _c_f32p]),
     ("dpmm_debug_ref_bracket", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, _c_f32p, _c_f32p]),
+    ("dpmm_debug_pair_ball", ctypes.c_int, [ctypes.c_void_p, _c_f32p, _c_f32p]),
     ("dpmm_debug_bracket_big", ctypes.c_int, [ctypes.c_void_p, _c_f32p, ctypes.POINTER(ctypes.c_uint32)]),
     ("dpmm_debug_mult_draws_ahead", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong)]),
     ("dpmm_last_sweep_work", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]),
@@ -103,7 +104,7 @@ HOST_ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_voi
 
 # dpmm_set_option keys (include/dpmm_hip.h)
 MASTER_NSCALARS = 8          # DPMM_MASTER_NSCALARS
-OPT_SCREEN_MARGIN, OPT_TAIL_SCREEN, OPT_PRESCREEN, OPT_ORDERED_SWEEP, OPT_MULT_FORCE_F32, OPT_STATS_ITEMS, OPT_STATS_GROUPS, OPT_TRACE_SLOW, OPT_LOGLIK_REF_CONST, OPT_WAVE_PRIO, OPT_MULT_NO_U8, OPT_SWEEP_GRID, OPT_SWEEP_QUEUE_ROUNDS, OPT_BALL_SCREEN, OPT_KERNEL_TIMING, OPT_STATS_DERIVE, OPT_NOISE_AHEAD, OPT_REF_BRACKET, OPT_SORT_TILE, OPT_ONE_COLLECTIVE, OPT_BF16_SCREENS, OPT_COMM_TIMEOUT_MS, OPT_DIRECTION_SCREEN, _OPT_RESERVED_24, OPT_MULT_DRAWS_AHEAD, OPT_B3_SUBLABELS, OPT_LEAN_TILES, OPT_MASTER_POLL, OPT_CHAIN_FUSION, OPT_LEAN_DIRECTION = range(1, 31)
+OPT_SCREEN_MARGIN, OPT_TAIL_SCREEN, OPT_PRESCREEN, OPT_ORDERED_SWEEP, OPT_MULT_FORCE_F32, OPT_STATS_ITEMS, OPT_STATS_GROUPS, OPT_TRACE_SLOW, OPT_LOGLIK_REF_CONST, OPT_WAVE_PRIO, OPT_MULT_NO_U8, OPT_SWEEP_GRID, OPT_SWEEP_QUEUE_ROUNDS, OPT_BALL_SCREEN, OPT_KERNEL_TIMING, OPT_STATS_DERIVE, OPT_NOISE_AHEAD, OPT_REF_BRACKET, OPT_SORT_TILE, OPT_ONE_COLLECTIVE, OPT_BF16_SCREENS, OPT_COMM_TIMEOUT_MS, OPT_DIRECTION_SCREEN, _OPT_RESERVED_24, OPT_MULT_DRAWS_AHEAD, OPT_B3_SUBLABELS, OPT_LEAN_TILES, OPT_MASTER_POLL, OPT_CHAIN_FUSION, OPT_LEAN_DIRECTION, OPT_PAIR_BALL = range(1, 32)
 
 
 class DpmmError(RuntimeError):
@@ -615,6 +616,12 @@ class Worker:
         qhi = np.empty(self.n, np.float32); q = np.empty(self.n, np.float32)
         self._chk(self._lib.dpmm_debug_ref_bracket(self._h, int(cluster), ctypes.c_float(c_override), _p(qhi, _c_f32p), _p(q, _c_f32p)))
         return qhi, q
+
+    def debug_pair_ball(self):
+        """(pd (K, K), sn (K,)): the pair-ball table of the parameters on the device; include/dpmm_hip_debug.h."""
+        pd = np.empty((self.K, self.K), np.float32); sn = np.empty(self.K, np.float32)
+        self._chk(self._lib.dpmm_debug_pair_ball(self._h, _p(pd, _c_f32p), _p(sn, _c_f32p)))
+        return pd, sn
 
     def debug_bracket_big(self):
         """(aref (n,), tile_flags (ceil(n / 128),)): what the D > 64 sweep reads from the bracket launch in front of it; include/dpmm_hip_debug.h."""

@@ -241,6 +241,8 @@ struct dpmm_ctx {
     int opt_b3 = 1;                    // DPMM_OPT_B3_SUBLABELS: D in 33..64: sub-cluster evaluations through three-plane bf16 images, in kernels of their own (niw_lean.hip)
     bool have_b3 = false;              // the images behind the bracket's in d_tail belong to the parameter set on the device
     int opt_chain = 0x7fffffff & ~(8 | 32);  // (bits 8 / 32: built, value-neutral, measured -- no gain at either size: off by default) DPMM_OPT_CHAIN_FUSION (bit mask): 1 = the sort's starts inside the scatter launch; 2 = the three-plane images in the hand-over launch; 4 = the fused pair jobs' list read from pinned memory; 8 = the bad-cluster reset counted ahead by the histogram and applied by the scatter (no reset launch); 16 = the draws' normals generated inside the posteriors' launch
+    int opt_pair_ball = 1;             // DPMM_OPT_PAIR_BALL: the lean kernel's full-dimension ball test on the K x K table of pair distances (niw_pair_ball_kernel, K <= 256)
+    bool have_pb = false;              // ... and that table belongs to the parameter set on the device
     int opt_lean_dir = 1;              // DPMM_OPT_LEAN_DIRECTION: the lean kernel runs the direction screen while its tables exist (0: no lean launch in that regime, as in rounds 4-5)
     int opt_master_poll = 1;           // DPMM_OPT_MASTER_POLL: dpmm_step_master_device waits on the posteriors' own records in pinned memory (no event between posteriors and draws)
     int opt_lean = 1;                  // DPMM_OPT_LEAN_TILES: tiles the cheap screens settle completely in niw_lean_kernel (-1 automatic is 1 with a regime switch; 0 never)
@@ -945,7 +947,7 @@ int dpmm_params_staging(dpmm_ctx *c, int slots, float **mu, float **mat, float *
     return DPMM_OK;
 }
 
-static int direction_tables(dpmm_ctx *c, int K, bool b3_done);
+static int direction_tables(dpmm_ctx *c, int K, bool b3_done, bool pb_done = false);
 
 int dpmm_commit_params(dpmm_ctx *c, int K) {
     if (!c) return DPMM_EINVAL;
@@ -1026,16 +1028,21 @@ int dpmm_commit_params(dpmm_ctx *c, int K) {
 // write their counts into pinned memory; that sweep has been waited for by whoever brings new parameters), with hysteresis: on from 8 per
 // tile, off below 4.  While it is on, the sweeps run the screen in front of the 4-row pair tests; the first sweep, every 32nd and the one
 // after a change of K keep the usual order and count.
+static bool want_pair_ball(const dpmm_ctx *c, int K) { return c->opt_pair_ball && c->opt_ball && K >= 2 && K <= PB_MAXK; }      // (with the images: want_b3_images)
 static bool want_b3_images(const dpmm_ctx *c) { return c->prior == DPMM_PRIOR_NIW && c->NB == 4 && c->opt_b3 && c->have_tail && !c->predictive; }
-static int direction_tables(dpmm_ctx *c, int K, bool b3_done) {
+static int direction_tables(dpmm_ctx *c, int K, bool b3_done, bool pb_done) {
     c->sp_ready = false;
     c->have_refb_big = false;
     c->have_b3 = false;
     if (want_b3_images(c)) {
         // the sub-cluster factors' bf16 planes + offsets (niw_lean.hip) -- b3_done: the hand-over launch wrote them (niw_master_pack_roles_kernel)
-        if (!b3_done) HIPCHK(c, launch_niw_b3_pack(c->d_Rp, c->d_mup, K, c->d_tail, c->stream));
+        // ... and the lean kernel's pair-ball table (same life as the images; one more row of workgroups of the same launch -- or a role of the hand-over launch)
+        const bool pb = want_pair_ball(c, K);
+        const int what = (b3_done ? 0 : 1) | ((pb && !pb_done) ? 2 : 0);
+        if (what) HIPCHK(c, launch_niw_b3_pack(c->d_Rp, c->d_mup, K, c->d_tail, what, c->stream));
         c->have_b3 = true;
-    }
+        c->have_pb = pb;
+    } else c->have_pb = false;
     if (c->prior == DPMM_PRIOR_NIW && (c->NB == 8 || c->NB == 16) && c->d_refb_big && c->opt_bracket && c->have_tail && K > 1) {
         HIPCHK(c, launch_niw_refb_big(c->d_Rp, c->NB, K, c->d_refb_big, c->stream));      // D = 128, 256: the reference bracket's images
         c->have_refb_big = true;
@@ -1260,6 +1267,7 @@ static int run_sweep(dpmm_ctx *c, uint32_t epoch, int final_argmax, float *table
                 uint32_t *need3 = a.need ? c->h_need + 12 * (size_t)c->sweep_grid_max : nullptr;
                 NiwSweepArgs al_args = a;
                 if (!c->opt_lean_dir) { al_args.sp_frag = nullptr; al_args.sp_cons = nullptr; }
+                if (c->have_pb && c->opt_pair_ball && al_args.ball) al_args.ball |= 2;      // (a bit of `ball`: a field of its own re-lays every kernel's scalars)
                 HIPCHK(c, launch_niw_lean(al_args, mine, need2, other, al ? c->sb.bin_start : nullptr, al ? c->perm_nbins : 0, need3, c->sweep_grid, c->stream));
                 if (parts) HIPCHK(c, hipEventRecord(c->ev_part[0], c->stream));
                 list = mine;
@@ -2162,10 +2170,10 @@ int dpmm_niw_master_draw(dpmm_ctx *c, uint32_t epoch, int K, const int32_t *slot
     const bool normals = !ahead && noise_ready(c, epoch, K, c->draw_cur);       // (noise_join above made the main stream wait for them)
     c->predictive = false;              // (before the tables, as in set_params)
     // DPMM_OPT_CHAIN_FUSION bit 2: the hand-over partitioned by role, with the three-plane images in the same launch (no niw_b3_pack launch)
-    const bool roles = (c->opt_chain & 2) != 0, b3_in_pack = roles && want_b3_images(c);
+    const bool roles = (c->opt_chain & 2) != 0, b3_in_pack = roles && want_b3_images(c), pb_in_pack = b3_in_pack && want_pair_ball(c, K);
     HIPCHK(c, launch_niw_master_draw(ma, hs, K, epoch, c->d_Y[c->draw_cur], c->d_ld_sigma[c->draw_cur], hlr, hw, c->d_Rp, c->d_mup, c->d_cst,
-                                     c->have_tail ? c->d_tail : nullptr, c->NB, c->d_work, (ahead ? 2 : (normals ? 7 : 3)) | (roles ? 8 : 0) | (b3_in_pack ? 16 : 0), c->stream));
-    if (int rc = direction_tables(c, K, b3_in_pack)) return rc;
+                                     c->have_tail ? c->d_tail : nullptr, c->NB, c->d_work, (ahead ? 2 : (normals ? 7 : 3)) | (roles ? 8 : 0) | (b3_in_pack ? 16 : 0) | (pb_in_pack ? 32 : 0), c->stream));
+    if (int rc = direction_tables(c, K, b3_in_pack, pb_in_pack)) return rc;
     // The normals of the NEXT draws (epoch + 1, a few clusters more than now for the splits in between) into the other buffer, on the
     // second stream: they depend on nothing the master decides, and run beside the sweep instead of in front of it.  Whoever draws
     // with another epoch, or for more clusters, generates its own.
@@ -2726,6 +2734,7 @@ int dpmm_set_option(dpmm_ctx *c, int option, double value) {
         case DPMM_OPT_COMM_TIMEOUT_MS: c->comm_timeout_ms = value > 0 ? (int)std::min(value, 2.0e9) : 0; return DPMM_OK;
         case DPMM_OPT_BF16_SCREENS: c->opt_bf16scr = value != 0; return DPMM_OK;
         case DPMM_OPT_MASTER_POLL: c->opt_master_poll = value != 0; return DPMM_OK;
+        case DPMM_OPT_PAIR_BALL: c->opt_pair_ball = value != 0; if (!c->opt_pair_ball) c->have_pb = false; return DPMM_OK;      // (ON takes effect with the next parameter set)
         case DPMM_OPT_LEAN_DIRECTION: c->opt_lean_dir = value != 0; c->lean_off = 0; c->lean_backoff = 15; c->lean_ran = false; return DPMM_OK;
         case DPMM_OPT_CHAIN_FUSION: c->opt_chain = value < 0 ? (0x7fffffff & ~(8 | 32)) : (int)value; return DPMM_OK;
         case DPMM_OPT_LEAN_TILES: c->opt_lean = value != 0; c->lean_off = 0; c->lean_backoff = 15; c->lean_ran = false; return DPMM_OK;
@@ -3013,6 +3022,19 @@ int dpmm_debug_ref_bracket(dpmm_ctx *c, int64_t cluster, float c_override, float
     if (e == hipSuccess) e = sync_stream(c, c->stream);
     hipFree(d);
     if (e != hipSuccess) { c->err = std::string("dpmm_debug_ref_bracket: ") + hipGetErrorString(e); return DPMM_EHIP; }
+    return DPMM_OK;
+}
+
+int dpmm_debug_pair_ball(dpmm_ctx *c, float *pd, float *sn) {
+    if (!c || !pd || !sn) return DPMM_EINVAL;
+    if (c->prior != DPMM_PRIOR_NIW || c->NB != 4) return fail(c, DPMM_ESTATE, "the pair-ball table exists for the NIW prior with D in 33..64 only");
+    if (!c->have_params || !c->have_pb) return fail(c, DPMM_ESTATE, "no pair-ball table for the parameters on the device (DPMM_OPT_PAIR_BALL, 2 <= K <= 256, tail records)");
+    HIPCHK(c, hipSetDevice(c->device));
+    const float *t = c->d_tail + niw_pair_ball_offset((size_t)c->K);
+    const size_t K = (size_t)c->K;
+    HIPCHK(c, hipMemcpyAsync(pd, t, sizeof(float) * K * K, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(sn, t + K * K, sizeof(float) * K, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, sync_stream(c, c->stream));
     return DPMM_OK;
 }
 

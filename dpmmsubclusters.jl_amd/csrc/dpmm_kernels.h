@@ -86,8 +86,15 @@ hipError_t launch_niw_refb_big(const float *Rp, int NB, int K, uint32_t *out, hi
 hipError_t launch_niw_bracket_big(int NB, const NiwSweepArgs &a, const uint32_t *refb, uint32_t *tile_flag, float *aref, hipStream_t s);
 // ---- niw_lean.hip: the bf16 three-plane evaluation of the sub-cluster quadratic forms (NB = 4)
 // images [3K][B3_WORDS] and offset vectors [3K][B3_DVEC] of the 2K sub-cluster factors from the Float32 fragment image, written behind the bracket's images in `tail`
-hipError_t launch_niw_b3_pack(const float *Rp, const float *mup, int K, float *tail, hipStream_t s);
-inline size_t niw_tail_floats(size_t cap) { return 16 * (cap + 2) + 16 * cap + (size_t)REFB_WORDS * cap + 3 * cap * (size_t)B3_WORDS + 3 * cap * (size_t)B3_DVEC; }      // pair records | ball records | bracket images | b3 images | b3 offsets
+hipError_t launch_niw_b3_pack(const float *Rp, const float *mup, int K, float *tail, int what, hipStream_t s);      // what bit 0: images + offsets; bit 1: the pair-ball table (2 <= K <= PB_MAXK) behind them
+// the pair-ball table behind the offsets (round 6; K <= PB_MAXK): pd [K][K] -- pd[k K + j] = a certified LOWER bound of |R_j (mu_k - mu_j)|, the distance of
+// cluster k's mean from cluster j's in j's own metric -- and sn [K], certified UPPER bounds of the spectral norms |R_j|_2 (niw_pair_ball_kernel, niw_lean.hip)
+constexpr int PB_MAXK = 256;
+inline size_t niw_pair_ball_floats(size_t K) { return K <= (size_t)PB_MAXK ? K * K + K : 0; }
+inline size_t niw_pair_ball_offset(size_t K) { return 32 * ((K + 1) >> 1) + 16 * K + (size_t)REFB_WORDS * K + 3 * K * (size_t)B3_WORDS + 3 * K * (size_t)B3_DVEC; }      // floats from `tail` (= b3_offsets(tail, K) + 3 K B3_DVEC, niw_b3.h)
+inline size_t niw_tail_floats(size_t cap) {      // pair records | ball records | bracket images | b3 images | b3 offsets | pair-ball table
+    return 16 * (cap + 2) + 16 * cap + (size_t)REFB_WORDS * cap + 3 * cap * (size_t)B3_WORDS + 3 * cap * (size_t)B3_DVEC + niw_pair_ball_floats(cap < (size_t)PB_MAXK ? cap : (size_t)PB_MAXK);
+}
 // out [2K][n]: both sub-cluster values of every point under every cluster (needs X, ldx, n, K, mup, cst, tail)
 hipError_t launch_niw_b3_debug(const NiwSweepArgs &a, float *out, hipStream_t s);
 // the sub-label phase alone for the wave tiles of `list` (list[0] = count, list[1 ..] = tile indices; null: all tiles); labels are read from bins

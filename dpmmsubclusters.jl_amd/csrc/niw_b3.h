@@ -11,6 +11,87 @@ namespace dpmm {
 __host__ __device__ __forceinline__ const uint32_t *b3_images(const float *tail, int K) { return refb_records(tail, K) + (size_t)K * REFB_WORDS; }
 __host__ __device__ __forceinline__ const float *b3_offsets(const float *tail, int K) { return reinterpret_cast<const float *>(b3_images(tail, K) + (size_t)3 * K * B3_WORDS); }
 
+__host__ __device__ __forceinline__ const float *pair_ball_table(const float *tail, int K) { return b3_offsets(tail, K) + (size_t)3 * K * B3_DVEC; }      // pd [K][K] | sn [K] (= tail + niw_pair_ball_offset(K), dpmm_kernels.h)
+
+// One workgroup (256 threads) tabulates column j of the pair-ball table and s_j (niw_lean.hip: the test and its derivation).  elemR(row, col): R_j's
+// Float32 element for col >= row; mean(k, c): the Float32 cluster-level mean the sweep subtracts.
+//   s_j^2 <= max row sum of |R_j' R_j| (>= its largest eigenvalue): thread (tr, tc) forms the 4 x 4 block of P = R' R at rows 4 tr, columns 4 tc from
+//   two 16-byte LDS reads per row of R (64 x 16 multiply-adds per thread), the 16 threads of a row block add their partial row sums;
+//   D_k,j: wave w takes k = w, w + 4, ..: lane = row of R_j, the 64 differences mu_k - mu_j broadcast by v_readlane.
+// Slack: a Float32 dot product of 64 terms errs by <= 64 * 2^-24 of the sum of its terms' magnitudes -- 1e-3 on s_j^2 covers the row sums (the
+// errors of a row add up to <= 5e-4 of the largest eigenvalue), 1e-4 s_j |v| comes off D, which is itself rounded DOWN by 1e-4.
+// (COLMAJOR: consecutive threads of the staging loop take consecutive ROWS of a column -- for a source stored column by column)
+template <bool COLMAJOR, class ElemR, class Mean>
+__device__ __forceinline__ void pair_ball_block(ElemR elemR, Mean mean, int K, int j, float *__restrict__ pd) {
+    float *sn = pd + (size_t)K * K;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    constexpr int LD = 68;                                  // (rows 16-byte aligned)
+    __shared__ __attribute__((aligned(16))) float Rs[64 * LD];
+    __shared__ float rowsum[64];
+    __shared__ float s_sh;
+    for (int e = tid; e < 4096; e += 256) {
+        const int row = COLMAJOR ? (e & 63) : (e >> 6), col = COLMAJOR ? (e >> 6) : (e & 63);
+        Rs[row * LD + col] = col >= row ? elemR(row, col) : 0.f;
+    }
+    __syncthreads();
+    {
+        const int tr = tid >> 4, tc = tid & 15;
+        float p[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) p[a][b] = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < 64; ++i) {                      // (zeros below the diagonal: no case distinction)
+            const f32x4 ra = *reinterpret_cast<const f32x4 *>(Rs + i * LD + 4 * tr), rb = *reinterpret_cast<const f32x4 *>(Rs + i * LD + 4 * tc);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) p[a][b] = __builtin_fmaf(ra[a], rb[b], p[a][b]);
+        }
+        float rs[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            rs[a] = fabsf(p[a][0]) + fabsf(p[a][1]) + fabsf(p[a][2]) + fabsf(p[a][3]);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) rs[a] += __shfl_xor(rs[a], o);      // over the 16 column blocks (consecutive lanes)
+        }
+        if (tc == 0) { rowsum[4 * tr] = rs[0]; rowsum[4 * tr + 1] = rs[1]; rowsum[4 * tr + 2] = rs[2]; rowsum[4 * tr + 3] = rs[3]; }
+    }
+    __syncthreads();
+    if (w == 0) {
+        const float mx = wave_max_f32(rowsum[lane]);
+        if (lane == 0) { const float sj = __builtin_sqrtf(mx) * 1.001f; s_sh = sj; sn[j] = (mx == mx && mx < INFINITY) ? sj : INFINITY; }
+    }
+    __syncthreads();
+    const float sj = s_sh;
+    const float mj = mean(j, lane);
+    for (int k0 = w; k0 < K; k0 += 16) {                     // four clusters per trip and wave (wave-uniform): one LDS read of R per column serves all four
+        float v[4], y[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int k = k0 + 4 * q; v[q] = (k < K ? mean(k, lane) : mj) - mj; y[q] = 0.f; }      // the subtraction the sweep's z = x - mu rests on
+#pragma unroll 8
+        for (int c = 0; c < 64; ++c) {
+            const float rc = Rs[lane * LD + c];             // (zeros left of the diagonal)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                y[q] = __builtin_fmaf(rc, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[q]), c)), y[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float y2 = y[q] * y[q], v2 = v[q] * v[q];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { y2 += __shfl_xor(y2, o); v2 += __shfl_xor(v2, o); }
+            const int k = k0 + 4 * q;
+            if (lane == 0 && k < K) {
+                float d = __builtin_sqrtf(y2) * 0.9999f - 1e-4f * sj * __builtin_sqrtf(v2);
+                if (!(d > 0.f) || k == j) d = 0.f;            // (NaN, or nothing to gain: the test then never fires)
+                pd[(size_t)k * K + j] = d;
+            }
+        }
+    }
+}
+
 struct B3Z { u32x4_t p[4][2][3]; };      // [point group][32-feature slice][plane]: the B operands of the wave's 64 points (96 registers)
 
 __device__ __forceinline__ void b3_split_pair(float a, float b, uint32_t &ph, uint32_t &pm, uint32_t &pl) {

@@ -43,7 +43,7 @@ namespace dpmm {
 // ------------------------------------------------------------------------------------------------------------------ images
 // Three-plane bf16 images and offset vectors of the 2K sub-cluster factors from the Float32 fragment image both pack kernels write
 // (NB = 4: Rp [3K][10][64][4], mup [3K][64]); one workgroup per sub-cluster matrix.
-__global__ __launch_bounds__(256) void niw_b3_pack_kernel(const float *__restrict__ Rp, const float *__restrict__ mup, float *__restrict__ tail, int K) {
+__global__ __launch_bounds__(256) void niw_b3_pack_kernel(const float *__restrict__ Rp, const float *__restrict__ mup, float *__restrict__ tail, int K, int y0) {
     constexpr int NP = 10;
     uint32_t *img = const_cast<uint32_t *>(b3_images(tail, K));
     float *dvec = const_cast<float *>(b3_offsets(tail, K));
@@ -56,8 +56,19 @@ __global__ __launch_bounds__(256) void niw_b3_pack_kernel(const float *__restric
         const int ln = (row & 15) + 16 * ((col & 15) >> 2);
         return Rj[(size_t)pair * 256 + ln * 4 + (col & 3)];
     };
-    if (blockIdx.y < 3) {               // one plane of the matrix: 1536 dwords, six per thread
-        const int plane = blockIdx.y;
+    const int yy = (int)blockIdx.y + y0;      // 0 .. 2: planes, 3: offsets, 4: the pair-ball table
+    if (yy == 4) {                      // the table's column of cluster k (one workgroup per CLUSTER: the even ones of this row)
+        if (blockIdx.x & 1) return;
+        const float *Rk = Rp + (size_t)(3 * k) * NP * 256;
+        auto elemR = [&](int row, int col) -> float {
+            const int bi = row >> 4, t = col >> 4;
+            return Rk[(size_t)(pair_base<4>(bi) + (t - bi)) * 256 + ((row & 15) + 16 * ((col & 15) >> 2)) * 4 + (col & 3)];
+        };
+        pair_ball_block<false>(elemR, [&](int kk, int c) -> float { return mup[(size_t)(3 * kk) * 64 + c]; }, K, k, const_cast<float *>(pair_ball_table(tail, K)));
+        return;
+    }
+    if (yy < 3) {                       // one plane of the matrix: 1536 dwords, six per thread
+        const int plane = yy;
         uint32_t *out = img + (size_t)j * B3_WORDS + (size_t)plane * REFB_WORDS;
         for (int e = threadIdx.x; e < REFB_WORDS; e += 256) {
             int row, c0, c1;
@@ -75,12 +86,25 @@ __global__ __launch_bounds__(256) void niw_b3_pack_kernel(const float *__restric
         if (part == 0) dvec[(size_t)j * B3_DVEC + row] = (float)acc;
     }
 }
-hipError_t launch_niw_b3_pack(const float *Rp, const float *mup, int K, float *tail, hipStream_t s) {
-    if (K < 1) return hipSuccess;
-    DPMM_LAUNCH(niw_b3_pack_kernel, dim3(2 * K, 4), dim3(256), 0, s, Rp, mup, tail, K);
+hipError_t launch_niw_b3_pack(const float *Rp, const float *mup, int K, float *tail, int what, hipStream_t s) {      // what bit 0: images + offsets, bit 1: the pair-ball table
+    const bool pb = (what & 2) && K >= 2 && K <= PB_MAXK;
+    if (K < 1 || !((what & 1) || pb)) return hipSuccess;
+    const int y0 = (what & 1) ? 0 : 4, ny = (pb ? 5 : 4) - y0;
+    DPMM_LAUNCH(niw_b3_pack_kernel, dim3(2 * K, ny), dim3(256), 0, s, Rp, mup, tail, K, y0);
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------------------ the pair-ball table
+// A ball test in ALL D features on quantities that do not depend on the tile (round 6).  For every x, with c = mu_k0 the mean of the tile's
+// reference cluster:   |R_j (x - mu_j)| >= |R_j (c - mu_j)| - |R_j (x - c)| >= D_k0,j - |R_j|_2 |x - c|,
+// so  a_j(x) <= cst_j - 1/2 max(0, D_k0,j - s_j r)^2  for every point of a tile whose points lie within r of c: ONE comparison per cluster and
+// tile (lane = cluster) once D_k0,j = |R_j (mu_k0 - mu_j)| and s_j >= |R_j|_2 are tabulated per parameter set.  The 4-feature ball test that
+// follows it (ball_far_rec) sees a distance of ~ sqrt(4) standard deviations of the means where this one sees sqrt(D): on the bench data it leaves
+// 3.1 tail-pair tests and 0.8 bottom screens per tile (23 and 5.9 at K = 256), this one none.
+// One workgroup per cluster j (pair_ball_block, niw_b3.h: a row of workgroups of niw_b3_pack_kernel, or a role of the device master's hand-over):  s_j^2 <= max row sum of |R_j' R_j| (an upper bound of its largest eigenvalue; within ~1.4 of it for the factors of
+// Wishart-like precisions), in Float32 with the slack of its own rounding;  D_k,j for every k from the Float32 means the sweep subtracts
+// (wave w takes k = w, w + 4, ..: lane = row of R_j, the 64 differences broadcast by v_readlane).  Slack: the matrix-vector product in Float32
+// errs by <= 64 * 2^-24 * |R_j|_F |v| <= 4e-5 s_j |v|, taken off D; D itself is rounded DOWN by 1e-4.
 // Diagnostic (dpmm_debug_subloglik while the bf16 evaluation is active): for every point of the shard and every cluster k the two values a
 // sweep would compute if the point's label were k -- out[(2k + s) n + i] -- through the same device functions, one wave per 64 points
 __global__ __launch_bounds__(256) void niw_b3_debug_kernel(NiwSweepArgs A, float *__restrict__ out) {
@@ -286,9 +310,16 @@ __device__ __forceinline__ void niw_lean_body(NiwSweepArgs A, uint32_t *__restri
     unsigned nw_sp = 0, nw_cand = 0, nw_dcand = 0, nw_dexcl = 0, nw_ctiles = 0;
     // the ball test's records (16 floats per cluster, the same for every tile) once per workgroup in LDS: the test then waits for an LDS read
     // instead of an L2 round trip per tile
-    constexpr int BALL_LDS_K = 128;
+    constexpr int BALL_LDS_K = 256;
     __shared__ __attribute__((aligned(16))) float ball_lds[BALL_LDS_K * 16];
     const bool ball_in_lds = A.ball && K <= BALL_LDS_K;
+    // the pair-ball test (A.ball bit 1: the table of niw_pair_ball_kernel belongs to these parameters; not in the direction-screen instantiation: on
+    // overlapping clusters it clears nothing): the norm bounds s_j once per workgroup in LDS, the row of distances of a tile's k0 requested per tile
+    __shared__ float pb_s[PB_MAXK];
+    const bool use_pb = !DIR && (A.ball & 2) != 0 && ball_in_lds && K <= PB_MAXK;
+    const float *pb_d = pair_ball_table(A.tail, K);
+    if (use_pb)
+        for (int e = threadIdx.x; e < K; e += 256) pb_s[e] = pb_d[(size_t)K * K + e];
     if (ball_in_lds) {
         const float *src = ball_records(A.tail, K);
         for (int e = threadIdx.x; e < 16 * K; e += 256) ball_lds[e] = src[e];
@@ -411,6 +442,10 @@ __device__ __forceinline__ void niw_lean_body(NiwSweepArgs A, uint32_t *__restri
             }
             if (lane < n_cn) pf_bin = A.bins[pf_p];            // the next tile's previous labels (its indices have arrived with x)
             bin_asked = true;
+            // pair-ball distance D_k0,j of "this lane's cluster" j = lane (requested here: the bracket covers the trip; clusters 64 .. are
+            // requested in their turn -- four registers across the bracket were three spilled ones)
+            float pbv0 = 0.f;
+            if (use_pb) pbv0 = pb_d[(size_t)k0 * K + (lane < K ? lane : 0)];
 #ifdef DPMM_STAMPS
             { LSTAMP(t2); s2 = t2; }
 #endif
@@ -432,10 +467,36 @@ __device__ __forceinline__ void niw_lean_body(NiwSweepArgs A, uint32_t *__restri
             const float my_thr = valid ? my_best - A.screen_margin : INFINITY;
             BallWave ball; ball.ok = false;
             if (A.ball) ball = ball_of_wave(A.tail, K, k0, xt, my_thr, valid);
+            // the pair-ball radius: r >= max |x - mu_k0| over the tile's points.  |z_h|^2 of 16 points at a time is the diagonal of the Gram matrix of
+            // plane h with itself (the lane's registers ARE both operands: row = column = lane & 15, the same eight features per lane group);
+            // |z| <= |z_h| / (1 - 2^-9) component by component, the products are exact, their Float32 sum of 64 non-negative terms errs by < 4e-6:
+            // the factor 1.005 covers both.  Point p of a group sits in lane group p / 4, register p % 4.
+            float pb_r = INFINITY;
+            if (use_pb && ball.ok) {
+                float m2 = 0.f;
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    f32x4 gq = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    gq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, Z.p[n][0][0]), __builtin_bit_cast(bf16x8_t, Z.p[n][0][0]), gq, 0, 0, 0);
+                    gq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, Z.p[n][1][0]), __builtin_bit_cast(bf16x8_t, Z.p[n][1][0]), gq, 0, 0, 0);
+                    const float dsel = (ci & 2) ? ((ci & 1) ? gq[3] : gq[2]) : ((ci & 1) ? gq[1] : gq[0]);
+                    const bool mine = g == (ci >> 2) && 16 * n + ci < c_cn;
+                    m2 = fmaxf(m2, mine ? dsel : 0.f);
+                }
+                const float mx = wave_max_f32(m2);
+                pb_r = (mx == mx) ? __builtin_amdgcn_sqrtf(mx) * 1.005f : INFINITY;
+            }
             for (int base = 0; base < K && !hard; base += 64) {
                 unsigned long long cand = (K - base >= 64) ? ~0ull : ((1ull << (K - base)) - 1ull);
                 if (k0 >= base && k0 < base + 64) cand &= ~(1ull << (k0 - base));
-                if (ball.ok) {
+                if (pb_r < INFINITY) {                             // (wave-uniform)
+                    const int j = base + lane, jj = j < K ? j : 0;
+                    const float dv = base == 0 ? pbv0 : pb_d[(size_t)k0 * K + jj];
+                    const float lb = fmaxf(__builtin_fmaf(-pb_s[jj], pb_r, dv), 0.f);
+                    const float ub = __builtin_fmaf(-0.5f * lb, lb, ball_lds[16 * jj + 15]);
+                    cand &= ~__ballot(j < K && ub < ball.thr);
+                }
+                if (ball.ok && cand) {
                     const int j = base + lane;
                     cand &= ~(ball_in_lds ? ball_far_rec(ball_lds + 16 * (j < K ? j : 0), j < K, ball) : ball_far(A.tail, K, base, lane, ball));
                 }

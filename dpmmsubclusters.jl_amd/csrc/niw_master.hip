@@ -30,6 +30,7 @@
 #include <algorithm>
 #include "dpmm_device.h"
 #include "dpmm_kernels.h"
+#include "niw_b3.h"        // pair_ball_block: the lean kernel's pair-ball table, a role of the hand-over kernel
 
 namespace dpmm {
 
@@ -710,7 +711,7 @@ __global__ void niw_master_pack_kernel(const double *__restrict__ Yall, const fl
 // launch instead of two.  Values: every output is computed from the same Float64 factors by the same expressions (the three-plane images and
 // offsets from (float)Y as niw_b3_pack_kernel computes them from the Float32 fragment image that holds exactly those floats; the offsets'
 // Float64 sums in the same order: four 16-column partial sums per row, combined by two butterfly steps).
-struct PackRoles { int first[6]; };      // role r owns workgroups [first[r], first[r + 1])
+struct PackRoles { int first[7]; };      // role r owns workgroups [first[r], first[r + 1])
 __global__ __launch_bounds__(256) void niw_master_pack_roles_kernel(const double *__restrict__ Yall, const float *__restrict__ mu_draw, const float *__restrict__ logdet_sigma,
                                                                     const float *__restrict__ lr, const float *__restrict__ wts, float *__restrict__ Rp,
                                                                     float *__restrict__ mup, float *__restrict__ cst, float *__restrict__ tail, int D, int DPm, int NB,
@@ -719,7 +720,7 @@ __global__ __launch_bounds__(256) void niw_master_pack_roles_kernel(const double
     const int DP = 16 * NB;
     const int K = nmat / 3;
     int role = 0;
-    while (role < 4 && (int)blockIdx.x >= R.first[role + 1]) ++role;
+    while (role < 5 && (int)blockIdx.x >= R.first[role + 1]) ++role;
     const int64_t t0 = ((int64_t)blockIdx.x - R.first[role]) * 256 + threadIdx.x, stride = (int64_t)(R.first[role + 1] - R.first[role]) * 256;
     auto Rel = [&](int64_t j, int row, int col) -> float {          // R[row][col] of matrix j as the sweep's Float32 (0 outside the upper triangle / beyond D)
         return (row < D && col < D && col >= row) ? (float)Yall[j * DPm * DPm + (int64_t)col * DPm + row] : 0.f;
@@ -797,6 +798,13 @@ __global__ __launch_bounds__(256) void niw_master_pack_roles_kernel(const double
             refb_map((int)(e % REFB_WORDS), row, c0, c1);
             refb[e] = bf16_rne_bits(Rel(j, row, c0)) | (bf16_rne_bits(Rel(j, row, c1)) << 16);
         }
+        return;
+    }
+    if (role == 5) {                       // the lean kernel's pair-ball table (niw_b3.h pair_ball_block): one workgroup per cluster, from the floats roles 0 / 1 write
+        const int j = (int)blockIdx.x - R.first[5];
+        pair_ball_block<true>([&](int row, int col) -> float { return Rel(3 * (int64_t)j, row, col); },
+                              [&](int kk, int c) -> float { return c < D ? mu_draw[(int64_t)(3 * kk) * DPm + c] : 0.f; }, K, j,
+                              const_cast<float *>(pair_ball_table(tail, K)));
         return;
     }
     if (!with_b3) return;
@@ -1277,7 +1285,9 @@ hipError_t launch_niw_master_draw(const NiwMasterArgs &a, const int32_t *slot_of
         const bool b3 = img && (what & 16);
         R.first[4] = R.first[3] + (b3 ? blocks((int64_t)2 * K * REFB_WORDS, 2048) : 0);
         R.first[5] = R.first[4] + (b3 ? blocks((int64_t)2 * K * 256, 256) : 0);
-        DPMM_LAUNCH(niw_master_pack_roles_kernel, dim3(R.first[5]), dim3(256), 0, s, Y, a.mu_draw, logdet_sigma, lr, wts, Rp, mup, cst, tail, a.D, a.DP, NB,
+        const bool pb = b3 && (what & 32) && K >= 2 && K <= PB_MAXK;
+        R.first[6] = R.first[5] + (pb ? K : 0);
+        DPMM_LAUNCH(niw_master_pack_roles_kernel, dim3(R.first[6]), dim3(256), 0, s, Y, a.mu_draw, logdet_sigma, lr, wts, Rp, mup, cst, tail, a.D, a.DP, NB,
                     nmat, work, R, b3 ? 1 : 0);
     } else if (what & 2) DPMM_LAUNCH(niw_master_pack_kernel, dim3(512), dim3(256), 0, s, Y, a.mu_draw, logdet_sigma, lr, wts, Rp, mup, cst, tail, a.D, a.DP, NB,
                                      3 * K, work);

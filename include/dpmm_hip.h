@@ -114,6 +114,11 @@ enum {
     DPMM_OPT_LEAN_DIRECTION = 30,     /* 1 (default, round 6): while the direction screen's tables exist (DPMM_OPT_DIRECTION_SCREEN: overlapping clusters) niw_lean_kernel runs the
                                          screen itself -- on plane h of z0 = x - mu_k0, which it holds -- and settles the tiles it clears; the launch behind it gets a
                                          direction-screen instantiation for the spans handed on.  0: no lean launch in that regime (rounds 4-5).  Same labels and sub-labels. */
+    DPMM_OPT_PAIR_BALL = 31,          /* 1 (default, round 6): D in 33..64 NIW sweep, 2 <= K <= 256: behind every parameter set one small launch tabulates, for all pairs
+                                         (k, j), a certified lower bound of |R_j (mu_k - mu_j)| -- the distance of cluster k's mean from cluster j's in j's own
+                                         metric -- and per cluster an upper bound of |R_j|_2; niw_lean_kernel then excludes cluster j for a whole tile of points
+                                         within r of mu_k0 when cst_j - (D_k0,j - |R_j|_2 r)^2 / 2 is below the tile's lowest threshold: the ball test in all D
+                                         features, one comparison per cluster and tile, in front of the 4-feature one.  0: without it.  Same labels and sub-labels. */
     DPMM_OPT_MULT_DRAWS_AHEAD = 25,   /* 1 (default): Multinomial device master: dpmm_step_stats launches the NEXT Dirichlet draws and their hand-over images
                                        * behind the statistics (the epoch after the last dpmm_mult_master_draw, the same K and outlier flag), into a second set of
                                        * buffers, and returns when the rows are on the host -- the draws run while the caller decides splits and merges.

@@ -34,6 +34,9 @@ int dpmm_debug_niw_draw_inputs(dpmm_ctx *ctx, uint32_t epoch, int K, const int32
  * q_hi[i] >= q[i] for every point; c_override > 0 replaces the library's rounding constant (tests show a too-small one failing).
  * NIW with D in 33..64, D % 4 == 0 and K > 2 only (DPMM_ESTATE otherwise). */
 int dpmm_debug_ref_bracket(dpmm_ctx *ctx, int64_t cluster, float c_override, float *q_hi, float *q);
+/* The pair-ball table of the parameters on the device (DPMM_OPT_PAIR_BALL; NIW, D in 33..64, 2 <= K <= 256): pd [K][K], pd[k K + j] = the
+ * tabulated lower bound of |R_j (mu_k - mu_j)|; sn [K] = the tabulated upper bounds of |R_j|_2.  Tests check both against Float64 values. */
+int dpmm_debug_pair_ball(dpmm_ctx *ctx, float *pd, float *sn);
 /* D = 65 .. 256 (the LDS-staged sweep kernels): the reference bracket runs as a launch of its own in front of the sweep (niw_bracket_big_kernel).
    This runs it on the current labels and parameters and returns what the sweep would read: tile_flags[ceil(n / 128)] = 1 + k0 (0-based k0)
    for a 128-point tile of the visiting order whose points all carry label k0 + 1, else 0; aref[n] = per POSITION of the visiting order

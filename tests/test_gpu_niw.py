@@ -720,6 +720,59 @@ def test_lean_tiles_do_not_change_labels(pkg, D, sep, K, n):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
+@pytest.mark.parametrize("D,sep,K,n,prescreen", [(64, 40.0, 7, 30000, 1), (64, 40.0, 32, 60000, 1), (60, 30.0, 9, 50001, 1), (64, 2.0, 12, 30011, 1), (52, 6.0, 6, 20000, 1),
+                                                 (64, 30.0, 100, 40000, 0), (64, 25.0, 200, 60000, 0), (64, 25.0, 256, 70000, 0), (64, 4.0, 2, 9000, 1)])
+def test_pair_ball_table_and_labels(pkg, D, sep, K, n, prescreen):
+    """Round 6: the lean kernel's ball test in all D features on a K x K table tabulated per parameter set (DPMM_OPT_PAIR_BALL; niw_pair_ball_kernel):
+    pd[k, j] must be a LOWER bound of |R_j (mu_k - mu_j)| = sqrt((mu_k - mu_j)' Sigma_j^-1 (mu_k - mu_j)) and sn[j] an UPPER bound of
+    |R_j|_2 = sqrt(lambda_max(Sigma_j^-1)) -- both checked against Float64 values of the Float32 parameters, both tight enough to be of use --
+    and a chain of sweeps with the test on must give the labels AND sub-labels of the chain without it, on separated clusters (where it clears
+    every candidate: no tail-pair test left), overlapping ones, padded D, K = 2 and beyond 64 clusters (the path without the pre-screen)."""
+    from dpmmsubclusters_jl_amd import binding
+    P = make_problem(D, n, K, seed=900 + D + K, sep=sep, sorted_points=True)
+    out, work = {}, {}
+    for on in (1, 0):
+        wk = pkg.Worker(pkg.PRIOR_NIW, D, n, first_index=0, device=0, seed=37)
+        wk.upload_points(P["X"])
+        wk.set_option(binding.OPT_PRESCREEN, prescreen)
+        wk.set_option(binding.OPT_PAIR_BALL, on)
+        wk.set_timing(15)
+        wk.set_params_niw(P["mu"], P["invS"], P["logdet"], P["lr"], P["w"])
+        wk.set_labels(P["z"] + 1, 1 + (np.arange(n) & 1))
+        wk.suffstats_packed(None)                      # the bin-sorted visiting order
+        wk.set_params_niw(P["mu"], P["invS"], P["logdet"], P["lr"], P["w"])
+        if on:
+            pd, sn = wk.debug_pair_ball()
+            mu = P["mu"][0::3].astype(np.float64)
+            iS = P["invS"].reshape(3 * K, D, D)[0::3].astype(np.float64)
+            dm = mu[:, None, :] - mu[None, :, :]                                  # [k, j] = mu_k - mu_j
+            true_d = np.sqrt(np.maximum(np.einsum("kja,jab,kjb->kj", dm, iS, dm), 0.0))
+            true_s = np.sqrt(np.linalg.eigvalsh(iS)[:, -1])
+            assert np.all(pd <= true_d * (1 + 1e-5) + 1e-6) and np.all(np.diag(pd) == 0)
+            off = ~np.eye(K, dtype=bool)
+            assert np.all(pd[off] >= 0.995 * true_d[off] - 1e-3)                 # (a bound nobody could use would pass the first check as well)
+            assert np.all(sn >= true_s * (1 - 1e-5)) and np.all(sn <= 2.0 * true_s)
+        else:
+            with pytest.raises(binding.DpmmError):
+                wk.debug_pair_ball()
+        wk.last_sweep_work()
+        labs = []
+        for ep in (1, 2, 3):
+            wk.sweep(ep)
+            labs.append(wk.get_labels())
+            wk.suffstats_packed(None)
+            wk.set_params_niw(P["mu"], P["invS"], P["logdet"], P["lr"], P["w"])
+        out[on] = labs
+        work[on] = wk.last_sweep_work()
+        wk.close()
+    for a, b in zip(out[1], out[0]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    t1, t0 = work[1]["tail_pairs"], work[0]["tail_pairs"]
+    print(f"D={D} sep={sep} K={K}: tail-pair tests per sweep {t0 / 3:.0f} without the pair-ball test, {t1 / 3:.0f} with it")
+    assert t1 <= t0                            # (these problems' covariances are close to isotropic: the 4-feature ball test leaves little to clear; the bench
+                                               #  data's inverse-Wishart clusters are where it leaves 3.1 pairs per tile and this one 0.1: scripts/parts_trace.py)
+
+
 @pytest.mark.parametrize("K,n,sep", [(70, 40000, 30.0), (100, 30011, 30.0), (127, 51000, 25.0), (128, 52000, 25.0), (128, 30000, 2.0), (129, 52001, 25.0), (200, 60000, 30.0),
                                      (300, 120000, 40.0)])
 def test_lean_tiles_beyond_64_clusters_without_the_prescreen(pkg, K, n, sep):
