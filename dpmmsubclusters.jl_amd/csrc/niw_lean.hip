@@ -465,14 +465,19 @@ __device__ __forceinline__ void niw_lean_body(NiwSweepArgs A, uint32_t *__restri
                 thrb[n] = (16 * n + ci < c_cn) ? bn - A.screen_margin : INFINITY;
             }
             const float my_thr = valid ? my_best - A.screen_margin : INFINITY;
+            // the 4-feature ball of the wave is formed only for a tile the pair-ball test leaves a candidate of (its centre is a scalar load away)
             BallWave ball; ball.ok = false;
-            if (A.ball) ball = ball_of_wave(A.tail, K, k0, xt, my_thr, valid);
+            bool ball_made = false;
+            float thr_min = INFINITY;
+            const bool thr_ok = use_pb && __ballot(valid && !(my_thr == my_thr)) == 0ull;       // (the pair-ball test's threshold: the wave's lowest)
+            if (use_pb) thr_min = wave_min_f32(my_thr);
+            else if (A.ball) { ball = ball_of_wave(A.tail, K, k0, xt, my_thr, valid); ball_made = true; }
             // the pair-ball radius: r >= max |x - mu_k0| over the tile's points.  |z_h|^2 of 16 points at a time is the diagonal of the Gram matrix of
             // plane h with itself (the lane's registers ARE both operands: row = column = lane & 15, the same eight features per lane group);
             // |z| <= |z_h| / (1 - 2^-9) component by component, the products are exact, their Float32 sum of 64 non-negative terms errs by < 4e-6:
             // the factor 1.005 covers both.  Point p of a group sits in lane group p / 4, register p % 4.
             float pb_r = INFINITY;
-            if (use_pb && ball.ok) {
+            if (thr_ok) {
                 float m2 = 0.f;
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
@@ -494,8 +499,9 @@ __device__ __forceinline__ void niw_lean_body(NiwSweepArgs A, uint32_t *__restri
                     const float dv = base == 0 ? pbv0 : pb_d[(size_t)k0 * K + jj];
                     const float lb = fmaxf(__builtin_fmaf(-pb_s[jj], pb_r, dv), 0.f);
                     const float ub = __builtin_fmaf(-0.5f * lb, lb, ball_lds[16 * jj + 15]);
-                    cand &= ~__ballot(j < K && ub < ball.thr);
+                    cand &= ~__ballot(j < K && ub < thr_min);
                 }
+                if (cand && A.ball && !ball_made) { ball = ball_of_wave(A.tail, K, k0, xt, my_thr, valid); ball_made = true; }
                 if (ball.ok && cand) {
                     const int j = base + lane;
                     cand &= ~(ball_in_lds ? ball_far_rec(ball_lds + 16 * (j < K ? j : 0), j < K, ball) : ball_far(A.tail, K, base, lane, ball));
