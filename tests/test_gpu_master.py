@@ -272,6 +272,48 @@ def test_engine_with_device_master_recovers_components(pkg, D, N, Kt):
     wk.close()
 
 
+def test_pair_ball_table_of_the_device_master(pkg):
+    """The lean kernel's pair-ball table (DPMM_OPT_PAIR_BALL) as the device master's hand-over launch tabulates it -- a role of that launch, from
+    the Float64 factors it hands over -- against Float64 values of the parameters the engine reports for the same draw: pd[k, j] a lower bound of
+    |R_j (mu_k - mu_j)|, sn[j] an upper bound of |R_j|_2, both tight; on the reference generator's data (inverse-Wishart covariances: the case the
+    test exists for)."""
+    import importlib
+    host = importlib.import_module("dpmmsubclusters_jl_amd.host")
+    engine = importlib.import_module("dpmmsubclusters_jl_amd.host.engine")
+    D, N, Kt = 64, 60000, 6
+    X, y = host.gaussian_mixture_shard(N, D, Kt, 100.0, 12345, 0, N)      # (the bench's generator seed; with 4321 one component has a 10-sigma direction and its tiles' balls reach a neighbour: 0.9 tail-pair tests per tile stay)
+    prior = host.niw_hyperparams(1.0, np.zeros(D), D + 3, np.eye(D))
+    wk = pkg.Worker(pkg.PRIOR_NIW, D, N, device=0, seed=11)
+    wk.upload_points(X)
+    s = host.DPMMSampler(wk, prior, 10.0, N, 11, burnout=5)
+    s._configure()
+    s.model.set_option(engine.OPT_DEVICE_MASTER, 1)
+    s.start_from_labels(y, 1 + (np.arange(N) & 1), Kt)
+    for _ in range(12):
+        s.group_step(True, False)
+    K = s.K
+    assert K == Kt
+    pd, sn = wk.debug_pair_ball()
+    p = s.params
+    mu = np.asarray(p["mu"], np.float64).reshape(K, 3, D)[:, 0]
+    R = np.asarray(p["R"], np.float64).reshape(K, 3, D, D)[:, 0]
+    dm = mu[:, None, :] - mu[None, :, :]                                   # [k, j] = mu_k - mu_j
+    true_d = np.linalg.norm(np.einsum("jab,kjb->kja", R, dm), axis=2)
+    true_s = np.linalg.norm(R, 2, axis=(1, 2))
+    off = ~np.eye(K, dtype=bool)
+    assert np.all(pd <= true_d * (1 + 1e-6) + 1e-6) and np.all(np.diag(pd) == 0)
+    assert np.all(pd[off] >= 0.995 * true_d[off] - 1e-3)
+    assert np.all(sn >= true_s * (1 - 1e-6)) and np.all(sn <= 2.0 * true_s)
+    # and it clears the sweep's candidates on this data: next to no tail-pair test is left
+    wk.set_timing(15)
+    wk.last_sweep_work()
+    for _ in range(3):
+        s.group_step(True, False)
+    w = wk.last_sweep_work()
+    assert w["tail_pairs"] <= 0.2 * w["wave_tiles"], w
+    wk.close()
+
+
 def test_device_master_matches_host_path_statistics(pkg):
     """Same data, same seeds, host path vs device path: the chains differ (different random streams for the draws) but both must
     end in the same partition on well-separated data, with identical statistics rows for identical labels."""
