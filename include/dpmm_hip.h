@@ -114,7 +114,7 @@ enum {
     DPMM_OPT_LEAN_DIRECTION = 30,     /* 1 (default, round 6): while the direction screen's tables exist (DPMM_OPT_DIRECTION_SCREEN: overlapping clusters) niw_lean_kernel runs the
                                          screen itself -- on plane h of z0 = x - mu_k0, which it holds -- and settles the tiles it clears; the launch behind it gets a
                                          direction-screen instantiation for the spans handed on.  0: no lean launch in that regime (rounds 4-5).  Same labels and sub-labels. */
-    DPMM_OPT_PAIR_BALL = 31,          /* 1 (default, round 6): D in 33..64 NIW sweep, 2 <= K <= 256: behind every parameter set one small launch tabulates, for all pairs
+    DPMM_OPT_PAIR_BALL = 31,          /* 1 (default, round 6): D in 33..64 NIW sweep, 2 <= K <= 256: with every parameter set the library tabulates (workgroups of a launch that runs anyway), for all pairs
                                          (k, j), a certified lower bound of |R_j (mu_k - mu_j)| -- the distance of cluster k's mean from cluster j's in j's own
                                          metric -- and per cluster an upper bound of |R_j|_2; niw_lean_kernel then excludes cluster j for a whole tile of points
                                          within r of mu_k0 when cst_j - (D_k0,j - |R_j|_2 r)^2 / 2 is below the tile's lowest threshold: the ball test in all D
