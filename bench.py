@@ -641,9 +641,10 @@ def main():
         return [float(v) for v in t]
 
     def timed_block(nsteps, collect=None):
-        # (no cyclic garbage collection inside a timed block: the interpreter holds the legs' dictionaries and 640 MB of numpy data by now, and a
-        #  generation-2 pass in the middle of 30 steps of 1.5 ms is a visible fraction of the block)
-        gc.collect()
+        # No cyclic garbage collection INSIDE a timed block -- and no collection in front of it either: gc.collect() here kept the host busy for a
+        # few hundred milliseconds, the GPU idled, its clocks fell back, and the 45 ms block that followed ran its kernels 6 % slower (measured on
+        # one box, alternating: 640 / 647 it/s with the collect, 682 / 685 without; sweep launch 1.02 against 0.95 ms).  The warm-up steps run
+        # right up to the block for the same reason.
         gc.disable()
         try:
             fence()

@@ -29,16 +29,16 @@ for _ in range(warm):
 torch.cuda.synchronize(); wk.sync()
 wk.set_timing(1)
 wk.last_sweep_work()
-ts = []
+ts, km = [], []
 t0 = time.perf_counter()
 for _ in range(steps):
     a = time.perf_counter()
     s.group_step(False, False)
-    wk.last_kernel_ms()
+    km.append(wk.last_kernel_ms()[0])
     ts.append(1e3 * (time.perf_counter() - a))
 torch.cuda.synchronize(); wk.sync()
 el = time.perf_counter() - t0
-print(f"headline block: {steps / el:.1f} it/s ({1e3 * el / steps:.4f} ms per step); per step ms: " + " ".join(f"{t:.2f}" for t in ts))
+print(f"headline block: {steps / el:.1f} it/s ({1e3 * el / steps:.4f} ms per step); sweep kernel median {np.median(km):.4f} ms; per step ms: " + " ".join(f"{t:.2f}" for t in ts))
 ts2 = []
 for _ in range(steps):
     a = time.perf_counter(); s.group_step(False, False); ts2.append(1e3 * (time.perf_counter() - a))
