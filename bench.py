@@ -623,8 +623,7 @@ def main():
     # (clock / power state of a GPU that was idle during the upload) -- the metric is the steady-state rate of a long run
     for _ in range(args.settle):
         s.group_step(False, False)
-    for _ in range(args.warmup):
-        s.group_step(False, False)
+    # (the W warm-up steps run further down: directly in front of the timed block, behind everything else the block needs set up)
 
     def fence():
         torch.cuda.synchronize()
@@ -679,9 +678,18 @@ def main():
     # measured live in the timed region); the statistics / all-reduce events (four to eight more per step) are recorded in the first
     # of the extra blocks.  fit / dp_parallel record none (DPMM_OPT_KERNEL_TIMING is off by default).
     wk.set_timing(1)
+    # The W untimed warm-up steps, as the timed ones will run (same timing mode, same per-step event read), with NOTHING between them and the
+    # block but its fence: a host pause there -- a garbage collection, the set-up calls below on a bad day -- lets the GPU idle, its clocks fall
+    # back, and a 45 ms block runs 5-20 % slower (one default run of this round: 544 it/s with blocks 652-674 behind it; another: 646 with 663-692).
+    # (so the host timers, the device's work counters and the collective counts below cover the W warm-up steps + the K timed ones: per-step / per-launch
+    #  averages of steps that are all alike)
+    gc.disable()
     t_before = dict(s.timers)
-    wk.last_sweep_work()              # clear the device's work counters: they add up over the timed launches and are read once afterwards
+    wk.last_sweep_work()              # clear the device's work counters: they add up over the launches that follow and are read once afterwards
     ci0 = wk.comm_info()
+    for _ in range(args.warmup):
+        s.group_step(False, False)
+        wk.last_kernel_ms()
     elapsed = timed_block(args.steps, collect)
     ci1 = wk.comm_info()
     work.append(wk.last_sweep_work())     # per-launch averages over exactly the timed launches
@@ -785,13 +793,13 @@ def main():
         "comm": {"world": info["world"], "transport": info["transport"], "occupancy_allreduce_bytes": info["counts_bytes"],
                  "rows_allreduce_bytes": info["rows_bytes"], "allreduces_since_attach": info["allreduces"],
                  "one_collective_per_step_pass": info["one_collective"],
-                 "allreduces_per_step_in_timed_block": (ci1["allreduces"] - ci0["allreduces"]) / args.steps,
+                 "allreduces_per_step_in_timed_block": (ci1["allreduces"] - ci0["allreduces"]) / (args.steps + args.warmup),
                  "occupancy_allreduce_ms": float(np.mean([c[0] for c in comm_ms])) if comm_ms else None,
                  "rows_allreduce_ms": float(np.mean([c[1] for c in comm_ms])) if comm_ms else None,
                  "note": "HIP events on the ctx stream around each all-reduce of the timed steps (rank 0); they include waiting for the slowest rank"},
         "blocks": {"it_per_s": block_rates, "min": float(np.min(block_rates)) if block_rates else None,
                    "median": float(np.median(block_rates)) if block_rates else None, "max": float(np.max(block_rates)) if block_rates else None},
-        "host_ms_per_step": {k: 1e3 * (t_after[k] - t_before[k]) / args.steps for k in t_after},
+        "host_ms_per_step": {k: 1e3 * (t_after[k] - t_before[k]) / (args.steps + args.warmup) for k in t_after},
     }
 
     final_params = (s.params, np.log(s.weights), np.log(s.lr_weights))   # before the growth run re-uses the context's staging
